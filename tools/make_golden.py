@@ -1,0 +1,270 @@
+#!/opt/conda/bin/python3.9
+"""
+Golden-vector generator: runs the REAL reference (CSTR-Edinburgh/snickery,
+mounted read-only at /root/reference) in this container and records inputs and
+outputs of its search path as small .npz fixtures under tests/golden/.
+
+  /opt/conda/bin/python3.9 tools/make_golden.py        # needs h5py (conda python)
+
+What it does (SURVEY.md section 10 recipe):
+  1. copies the reference's Python-2 modules to a TEMP dir and converts that
+     copy with lib2to3 (nothing converted is ever written into this repo);
+  2. applies the three py3 patches (integer division, bytes unit names);
+  3. puts empty stub modules for magphase / libaudio / pywrapfst / pylab /
+     smoothing.* / StashableKDTree first on sys.path (imported at module level
+     by the reference but not needed by the search path);
+  4. writes a tiny synthetic magphase-60 voice (raw float32 stream files);
+  5. runs the converted train_simple.main_work  -> real HDF5 unit DB;
+  6. runs the converted synth_simple.Synthesiser(cfg).synth_utt(...) with
+     greedy_joint_search wrapped to record (unit_features, path) and to stop
+     before waveform generation;
+  7. injects the same arrays into the converted synth_halfphone.Synthesiser to
+     record preselect_units_acoustic() and the join cost_cache built by
+     make_on_the_fly_join_lattice_BLOCK_DIRECT() (the OpenFST compile step is
+     replaced by a capture of its input dict -- OpenFST is not available).
+
+Only data (inputs + expected outputs) is stored.  The fixtures are what
+tests/test_oracle_golden.py pins the oracle against.
+"""
+import os
+import sys
+import shutil
+import subprocess
+import tempfile
+import types
+import numpy as np
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, '..', 'tests', 'golden')
+
+MODULES = ['synth_simple', 'synth_halfphone', 'fst_functions_wrapped', 'speech_manip',
+           'data_manipulation', 'segmentaxis', 'const', 'matrix_operations',
+           'file_naming', 'util', 'train_simple', 'train_halfphone', 'label_manip',
+           'resample', 'resample_labels', 'mulaw2', 'varying_filter', 'data_fudging']
+
+DIMS = {'mag': 60, 'real': 45, 'imag': 45, 'lf0': 1}
+
+
+def convert_reference(tmp):
+    src = os.path.join(tmp, 'conv')
+    os.makedirs(src)
+    for m in MODULES:
+        shutil.copy(os.path.join(REF, 'script', m + '.py'), os.path.join(src, m + '.py'))
+    files = [os.path.join(src, m + '.py') for m in MODULES]
+    subprocess.check_call([sys.executable, '-m', 'lib2to3', '-w', '-n'] + files,
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+    def patch(fname, old, new, count=1):
+        p = os.path.join(src, fname)
+        s = open(p).read()
+        assert s.count(old) >= count, (fname, old, s.count(old))
+        s = s.replace(old, new)
+        open(p, 'w').write(s)
+
+    patch('synth_simple.py', 'm/multiepoch', 'm//multiepoch')
+    patch('synth_halfphone.py', 'm/multiepoch', 'm//multiepoch')
+    patch('synth_halfphone.py', ':n/2]', ':n//2]')
+    patch('synth_halfphone.py', 'n/2:]', 'n//2:]')
+    patch('train_simple.py', 'unit_names = np.array(unit_names)',
+          "unit_names = np.array(unit_names).astype('S50')")
+    patch('train_simple.py', 'filenames = [base] * m',
+          "filenames = np.array([base] * m).astype('S50')")
+
+    stubs = os.path.join(tmp, 'stubs')
+    os.makedirs(os.path.join(stubs, 'smoothing'))
+    for name in ['magphase', 'libaudio', 'pywrapfst', 'pylab', 'StashableKDTree']:
+        open(os.path.join(stubs, name + '.py'), 'w').write('')
+    for name in ['__init__', 'fft_feats', 'libwavgen', 'libaudio']:
+        open(os.path.join(stubs, 'smoothing', name + '.py'), 'w').write('')
+    sys.path.insert(0, src)
+    sys.path.insert(0, stubs)
+    return src
+
+
+def write_voice(root, rng):
+    """Synthetic magphase-60 stream files with speech-like continuity and ~30% UV."""
+    names = ['arctic_a%04d' % i for i in range(1, 9)] + ['arctic_b0001', 'arctic_b0002']
+    for stream in DIMS:
+        os.makedirs(os.path.join(root, 'low', stream))
+    for name in names:
+        n = int(rng.randint(110, 190))
+        base = np.cumsum(rng.randn(n, 8), axis=0) * 0.3
+        for stream, dim in DIMS.items():
+            proj = rng.randn(8, dim) if stream != 'lf0' else rng.randn(8, 1) * 0.05
+            data = base.dot(proj) + 0.1 * rng.randn(n, dim)
+            if stream == 'lf0':
+                data = 5.0 + data
+                uv = np.zeros(n, dtype=bool)
+                pos = 0
+                while pos < n:
+                    seg = int(rng.randint(5, 30))
+                    if rng.rand() < 0.3:
+                        uv[pos:pos + seg] = True
+                    pos += seg
+                data[uv, 0] = 0.0
+            data.astype(np.float32).tofile(os.path.join(root, 'low', stream, name + '.' + stream))
+    return names
+
+
+def write_config(path, workdir, data, multiepoch):
+    ref_cfg = open(os.path.join(REF, 'config', 'slt_simplified_mini.cfg')).read()
+    # the reference's own README demo config, re-pointed at the synthetic voice
+    cfg = ref_cfg.replace("workdir = \n", "workdir = %r\n" % workdir)
+    assert 'workdir = %r' % workdir in cfg
+    cfg += "\n\n## ---- overrides appended by tools/make_golden.py ----\n"
+    cfg += "data = %r\n" % data
+    cfg += "join_datadirs = [data + '/low/']\n"
+    cfg += "target_datadirs = join_datadirs\n"
+    cfg += "test_data_dirs = join_datadirs\n"
+    cfg += "test_patterns = ['arctic_b']\n"
+    cfg += "n_train_utts = 100\n"
+    cfg += "search_epsilon = 0.0\n"
+    cfg += "multiepoch = %d\n" % multiepoch
+    open(path, 'w').write(cfg)
+
+
+class StopAfterSearch(Exception):
+    pass
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix='snk_golden_')
+    try:
+        convert_reference(tmp)
+        rng = np.random.RandomState(20240)
+        data = os.path.join(tmp, 'voice')
+        names = write_voice(data, rng)
+        workdir = os.path.join(tmp, 'work')
+        os.makedirs(workdir)
+
+        import h5py
+        import train_simple
+        import synth_simple
+
+        fixtures = {}
+        for me in (6, 1):
+            cfgfile = os.path.join(tmp, 'mini_me%d.cfg' % me)
+            write_config(cfgfile, workdir, data, me)
+            config = {}
+            exec(compile(open(cfgfile).read(), cfgfile, 'exec'), config)
+            del config['__builtins__']
+            if me == 6:
+                train_simple.main_work(config, overwrite_existing_data=True)
+            synth = synth_simple.Synthesiser(cfgfile)
+
+            captured = []
+            orig = synth.greedy_joint_search
+
+            def wrapped(unit_features, start_state=-1, holdout=[]):
+                path = orig(unit_features, start_state=start_state, holdout=holdout)
+                captured.append((np.array(unit_features), np.array(path)))
+                raise StopAfterSearch()
+
+            synth.greedy_joint_search = wrapped
+            for base in synth.get_sentence_set('test'):
+                try:
+                    synth.synth_utt(base, synth_type='test')
+                except StopAfterSearch:
+                    pass
+            assert len(captured) == 2, len(captured)
+            tree_data = np.array(synth.joint_tree.data)
+            fixtures['greedy_me%d_tree_shape' % me] = np.array(tree_data.shape)
+            fixtures['greedy_me%d_tree_dtype_is_f64' % me] = np.array(tree_data.dtype == np.float64)
+            for i, (uf, path) in enumerate(captured):
+                fixtures['greedy_me%d_utt%d_unit_features' % (me, i)] = uf
+                fixtures['greedy_me%d_utt%d_path' % (me, i)] = path.astype(np.int64)
+            # natural-path known answer (resynth_training_chunk, synth_simple.py:909-916)
+            if me == 1:
+                start = 37
+                feats = synth.train_unit_features[start:start + 25, :]
+                synth.greedy_joint_search = orig
+                natural = orig(feats, start_state=start)
+                fixtures['greedy_me1_natural_start'] = np.array(start)
+                fixtures['greedy_me1_natural_path'] = np.array(natural, dtype=np.int64)
+            if me == 6:
+                # DB arrays exactly as the reference loaded them from its own HDF5
+                fixtures['F_unw'] = synth.train_unit_features_unweighted
+                fixtures['JC_unw'] = synth.join_contexts_unweighted
+                fixtures['mean_target'] = synth.mean_vec_target
+                fixtures['std_target'] = synth.std_vec_target
+                fixtures['mean_join'] = synth.mean_vec_join
+                fixtures['std_join'] = synth.std_vec_join
+                fixtures['target_weight_vector'] = np.array(synth.target_weight_vector)
+                fixtures['unit_end_data_rows'] = np.array(synth.unit_end_data[[0, 5, -1], :])
+                fixtures['unit_start_data_rows'] = np.array(synth.unit_start_data[[0, 5, -1], :])
+                fixtures['train_unit_features_w_rows'] = np.array(
+                    synth_simple.weight(synth.train_unit_features_unweighted[[0, 7, -1]],
+                                        synth.target_weight_vector))
+                fixtures['target_stream_weights'] = np.array(config['target_stream_weights'])
+                fixtures['join_stream_weights'] = np.array(config['join_stream_weights'])
+                fixtures['join_cost_weight'] = np.array(config['join_cost_weight'])
+                # raw target streams of the first test utterance (host-prep fixture)
+                base = synth.get_sentence_set('test')[0]
+                for stream in ('mag', 'lf0'):
+                    fixtures['test0_raw_' + stream] = np.fromfile(
+                        os.path.join(data, 'low', stream, base + '.' + stream),
+                        dtype=np.float32).reshape(-1, DIMS[stream])
+                dbfile = synth_simple.get_data_dump_name(config)
+                fixtures['db_basename'] = np.array(os.path.basename(dbfile))
+                with h5py.File(dbfile, 'r') as f:
+                    fixtures['hdf5_keys'] = np.array(sorted(f.keys()))
+                    fixtures['hdf5_std_target_shape'] = np.array(f['std_target'].shape)
+                    fixtures['hdf5_mean_target_shape'] = np.array(f['mean_target'].shape)
+
+        # ---- preselect + join lattice from converted synth_halfphone ----
+        import synth_halfphone
+        import scipy.spatial
+        sh = synth_halfphone.Synthesiser.__new__(synth_halfphone.Synthesiser)
+        K = 12
+        sh.config = {'n_candidates': K, 'target_representation': 'epoch',
+                     'join_cost_type': 'pitch_sync'}
+        sh.verbose = False
+        F_unw = fixtures['F_unw']
+        JC_unw = fixtures['JC_unw']
+        wt = fixtures['target_weight_vector']
+        jw = np.array(config['join_stream_weights']) * config['join_cost_weight']
+        wj = np.concatenate([[w] * DIMS[s] for w, s in zip(jw, config['stream_list_join'])])
+        sh.train_unit_features = synth_halfphone.weight(F_unw, wt)
+        jcw = synth_halfphone.weight(JC_unw, wj)
+        sh.unit_end_data = jcw[1:, :]
+        sh.unit_start_data = jcw[:-1, :]
+        sh.tree = scipy.spatial.cKDTree(sh.train_unit_features, leafsize=100,
+                                        compact_nodes=False, balanced_tree=False)  # synth_halfphone.py:379
+        uf = fixtures['greedy_me6_utt0_unit_features'][:40]
+        cand, dist = sh.preselect_units_acoustic(uf)
+        cand = np.array(cand)
+        # exercise the reference's exclusions: unit 0, unit N-1 and padding -1
+        cand_edit = cand.copy()
+        cand_edit[3, 2] = 0
+        cand_edit[4, 1] = F_unw.shape[0] - 1
+        cand_edit[5, 0] = -1
+        cand_edit[6, 4] = cand_edit[5, 3] + 1      # a natural join (cost exactly 0)
+        captured_cache = []
+        synth_halfphone.cost_cache_to_compiled_fst = \
+            lambda cost_cache, join_cost_weight=1.0: captured_cache.append(dict(cost_cache))
+        sh.make_on_the_fly_join_lattice_BLOCK_DIRECT(cand_edit)
+        cache = captured_cache[0]
+        keys = np.array(sorted(cache.keys()), dtype=np.int64)
+        vals = np.array([cache[tuple(k)] for k in keys], dtype=np.float64)
+        fixtures['knn_K'] = np.array(K)
+        fixtures['knn_queries'] = uf
+        fixtures['knn_candidates'] = cand.astype(np.int64)
+        fixtures['knn_distances'] = np.array(dist, dtype=np.float64)
+        fixtures['join_candidates'] = cand_edit.astype(np.int64)
+        fixtures['join_cache_keys'] = keys
+        fixtures['join_cache_values'] = vals
+        fixtures['join_weight_vector'] = wj
+
+        np.savez_compressed(os.path.join(OUT, 'reference_mini.npz'), **fixtures)
+        sz = os.path.getsize(os.path.join(OUT, 'reference_mini.npz'))
+        print('wrote tests/golden/reference_mini.npz (%d bytes), N=%d' % (sz, F_unw.shape[0]))
+        for k in sorted(fixtures):
+            print('  ', k, np.shape(fixtures[k]))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == '__main__':
+    main()
