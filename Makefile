@@ -1,0 +1,24 @@
+# Builds libsnkhip.so (gfx950 only) and the C oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := snickery_amd/csrc
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wno-unused-value -Iinclude
+LIB   := snickery_amd/libsnkhip.so
+OBJS  := $(CSRC)/knn_kernels.o $(CSRC)/viterbi_kernels.o $(CSRC)/greedy_kernels.o $(CSRC)/snk_api.o
+
+all: $(LIB) oracle
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/snk_internal.h include/snk.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(OBJS) $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

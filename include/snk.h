@@ -1,0 +1,159 @@
+/*
+ * snk.h -- C ABI of libsnkhip.so: the MI355X (gfx950) unit-selection search
+ * engine that replaces the CPU hot path of CSTR-Edinburgh/snickery
+ * (script/synth_simple.py, script/synth_halfphone.py).
+ *
+ * The reference has no FFI for this path: the search sits behind plain Python
+ * methods of `Synthesiser`.  Each entry point below names the reference
+ * method / third-party call it replaces (file:line in the reference checkout).
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; the message is
+ *     available from snk_last_error() (thread-local).
+ *   - all pointers are caller-owned HOST memory unless the name ends in _dev.
+ *   - matrices are dense row-major.
+ *   - one handle = one device + one HIP stream; a handle is not thread-safe,
+ *     different handles are independent (the reference's only concurrency is
+ *     process-level, synth_halfphone.py:897-903).
+ *   - there is NO CPU fallback: every compute entry point fails if no gfx950
+ *     device is usable.
+ */
+#ifndef SNK_H
+#define SNK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct snk_engine *snk_handle;
+
+/* library */
+int         snk_abi_version(void);
+const char *snk_last_error(void);
+int         snk_device_count(int *count_out);
+
+/* lifetime */
+int snk_create(int device_id, snk_handle *handle_out);
+int snk_destroy(snk_handle h);
+
+/* Replaces the HDF5 arrays the Synthesiser keeps after loading
+ * (synth_simple.py:87-97, synth_halfphone.py:184-225):
+ *   F_unw  (N, Dt)    float32  train_unit_features (unweighted)
+ *   JC_unw (Njc, Dj)  float32  join_contexts (unweighted), Njc = N+1
+ * Device copies are made; the host arrays may be freed afterwards. */
+int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt,
+                  const float *JC_unw, int64_t Njc, int Dj);
+
+/* Replaces set_target_weights / set_join_weights (synth_simple.py:234-274,
+ * synth_halfphone.py:682-737) + weight() (speech_manip.py:209-213):
+ * per-COLUMN weight vectors, F = F_unw * wt (float64), JC = JC_unw * wj,
+ * unit_end_data = JC[1:], unit_start_data = JC[:-1].  O(N*D) on device, no index
+ * rebuild (the reference rebuilds its KD-trees here). */
+int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, int n_wj);
+
+/* Replaces `self.tree.query(unit_features, k=n_candidates)` in
+ * preselect_units_acoustic (synth_halfphone.py:1359-1366; tree built at :379):
+ *   Q (T, D) float64 weighted target vectors, D == Dt
+ *   cand_out (T, K) int64 unit ids ascending by distance (ties: lower id first)
+ *   dist_out (T, K) float64 Euclidean distances (not squared)
+ * K > N pads with id -1 / distance 1e15 (const.VERY_BIG_WEIGHT_VALUE). */
+int snk_knn(snk_handle h, const double *Q, int64_t T, int D, int K,
+            int64_t *cand_out, double *dist_out);
+
+/* Replaces preselect_units_monophone_then_acoustic (synth_halfphone.py:1369-1396,
+ * per-phone trees :385-402): K-NN restricted to DB units whose class id equals the
+ * query's; short classes padded with -1 / 1e15.
+ *   unit_class (N) int32 set once with snk_set_unit_classes; query_class (T) int32 */
+int snk_set_unit_classes(snk_handle h, const int32_t *unit_class, int64_t N);
+int snk_knn_by_class(snk_handle h, const double *Q, int64_t T, int D, int K,
+                     const int32_t *query_class, int64_t *cand_out, double *dist_out);
+
+/* Replaces make_on_the_fly_join_lattice_BLOCK_DIRECT's cost computation
+ * (synth_halfphone.py:3206-3322; get_natural_distance_vectorised :2942-2951):
+ *   J_out (T-1, K, K) float64, J[t,a,b] = ||unit_end[cand[t,a]] - unit_start[cand[t+1,b]]||_2,
+ *   +inf where either unit is unusable (id == -1, id < 1 or id >= N-1, :3238-3268). */
+int snk_join_costs(snk_handle h, const int64_t *cand, int64_t T, int K, double *J_out);
+
+/* Replaces viterbi_search (synth_halfphone.py:1399-1436): target sausage lattice
+ * (fst_functions_wrapped.py:28-58) o join lattice (:172-217), openfst.compose (:368)
+ * and openfst.shortestpath (:389), as one dynamic programme over the T x K trellis.
+ *   cand (T,K) int64, tdist (T,K) float64 -> path_out (T) int64 unit ids,
+ *   *path_len_out = T, or 0 when no complete path exists (incl. T < 2),
+ *   *cost_out = accumulated path cost (float64). */
+int snk_viterbi(snk_handle h, const int64_t *cand, const double *tdist, int64_t T, int K,
+                int64_t *path_out, int64_t *path_len_out, double *cost_out);
+
+/* snk_knn + snk_viterbi without the host round trip between them (what synth_utt does
+ * at synth_halfphone.py:1601-1625).  cand_out / dist_out may be NULL. */
+int snk_knn_viterbi(snk_handle h, const double *Q, int64_t T, int D, int K,
+                    int64_t *cand_out, double *dist_out,
+                    int64_t *path_out, int64_t *path_len_out, double *cost_out);
+
+/* Batched form of snk_knn_viterbi for throughput callers (balance_stream_weights.py:82-92
+ * loops synth_utt over a tune set): n_utts utterances, rows concatenated in Q,
+ * row_offsets (n_utts+1).  path_out has row_offsets[n_utts] entries; path_len_out and
+ * cost_out have n_utts entries.  Stages of consecutive utterances overlap on device. */
+int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offsets,
+                          int n_utts, int D, int K,
+                          int64_t *path_out, int64_t *path_len_out, double *cost_out);
+
+/* Replaces get_tree_for_greedy_search's data layout (synth_simple.py:190-225,
+ * synth_halfphone.py:539-596).  Nothing is materialised: the windowed DB
+ * (N-me+1, me*Dt) is addressed in place.
+ *   join_split_mode 0: synth_simple (prev = unit_start_data, current = unit_end_data)
+ *   join_split_mode 1: synth_halfphone epoch DB (first/second half of the columns) */
+int snk_set_greedy_layout(snk_handle h, int multiepoch, int last_frame_as_target,
+                          int join_split_mode);
+
+/* Replaces greedy_joint_search (synth_simple.py:458-503 == synth_halfphone.py:1900-1945),
+ * i.e. the per-step joint_tree.query(k=1) at :488-490.
+ *   Q (T, Dt) float64 weighted targets (NOT yet reshaped by multiepoch)
+ *   path_out  (T / multiepoch) int64 indices into the windowed DB
+ *   dist_out  (T / multiepoch) float64 Euclidean distance of each pick (may be NULL)
+ *   eps: search_epsilon; the engine always returns the exact nearest neighbour, which
+ *        satisfies the reference's (1+eps) guarantee for every eps >= 0. */
+int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_state,
+               double eps, int64_t *path_out, double *dist_out, int64_t *nsteps_out);
+
+/* Replaces get_target_scores_per_stream / get_join_scores_per_stream
+ * (synth_halfphone.py:1964-1981): squared errors along a path, per column.
+ *   mode 0: Viterbi  (E[p[:-1]] - S[p[1:]])^2 ; mode 1: greedy (prev[p[1:]] - cur[p[:-1]])^2
+ *   tsq_out (L, Dt), jsq_out (L-1, Dj') float64 */
+int snk_path_scores(snk_handle h, const double *Q, const int64_t *path, int64_t L, int mode,
+                    double *tsq_out, double *jsq_out);
+
+/* Per-stage device times of the most recent call, measured with HIP events on the
+ * engine's stream (names via snk_timer_name): the reference's start_clock/stop_clock
+ * stage log (synth_halfphone.py:1953-1961). Returns number of timers written. */
+int         snk_get_timers(snk_handle h, double *ms_out, int capacity);
+const char *snk_timer_name(int index);
+int         snk_timer_count(void);
+int         snk_reset_timers(snk_handle h);
+
+/* Multi-GPU (database row-sharded over ranks).  The shard holds rows
+ * [row_offset, row_offset+N) of the global DB: candidate ids reported by the *_dev calls
+ * are global ids.  Device-pointer entry points so that the exchange step
+ * (RCCL all-gather of the per-rank top-K) can run on device buffers owned by the caller. */
+int snk_set_shard(snk_handle h, int64_t global_row_offset, int64_t global_N);
+int snk_knn_local_dev(snk_handle h, const double *Q, int64_t T, int D, int K,
+                      double *d2_dev_out /* (T,K) squared distances */,
+                      int64_t *id_dev_out /* (T,K) global ids, -1 padded */);
+/* merge G gathered lists (G,T,K) -> (T,K), ordered by (distance, id); host outputs */
+int snk_merge_topk_dev(snk_handle h, const double *d2_dev, const int64_t *id_dev,
+                       int G, int64_t T, int K, int64_t *cand_out, double *dist_out);
+/* upload the FULL join matrix only (ranks that run the Viterbi of an utterance) */
+int snk_upload_join_only(snk_handle h, const float *JC_unw, int64_t Njc, int Dj);
+
+/* Engine tuning / introspection (not part of the reference surface) */
+int snk_set_option(snk_handle h, const char *name, double value);
+int snk_get_info(snk_handle h, const char *name, double *value_out);
+/* gfx950 self-test of the f64 MFMA fragment mapping the K-NN kernel relies on */
+int snk_selftest_mfma(snk_handle h, double *max_abs_err_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNK_H */

@@ -1,0 +1,9 @@
+"""snickery_amd -- MI355X-native unit-selection search for Snickery voices.
+
+The compute path is libsnkhip.so (hand-written HIP for gfx950 behind the C ABI in
+include/snk.h).  There is no CPU fallback: constructing an engine without the library or
+without a gfx950 device raises.
+"""
+from .engine import HipSearchEngine, SnkError, library_path, load_library  # noqa: F401
+
+__all__ = ['HipSearchEngine', 'SnkError', 'library_path', 'load_library']

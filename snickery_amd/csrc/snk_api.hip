@@ -1,0 +1,845 @@
+// C ABI of libsnkhip.so (include/snk.h): host-side engine around the gfx950 kernels.
+// Device memory, streams and events are plain HIP; there is no CPU compute fallback.
+#include "snk_internal.h"
+#include "../../include/snk.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+using namespace snk;
+
+static thread_local std::string g_err;
+
+static int fail(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define CHK(expr)                    \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_) return rc_;         \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+enum TimerId {
+    TM_H2D = 0, TM_PREP, TM_KNN_MINIMA, TM_KNN_THRESHOLD, TM_KNN_FILTER, TM_KNN_FINALIZE,
+    TM_JOIN, TM_VITERBI_DP, TM_D2H, TM_GREEDY_TARGET, TM_GREEDY_STEPS, TM_WEIGHTS, TM_COUNT
+};
+static const char *kTimerNames[TM_COUNT] = {
+    "h2d_queries", "prepare_queries", "knn_minima", "knn_threshold", "knn_filter", "knn_finalize",
+    "join_costs", "viterbi_dp", "d2h_results", "greedy_target_gemm", "greedy_steps", "set_weights"};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        size_t want = need + need / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+        bytes = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct EvPair { hipEvent_t a, b; int id; };
+
+struct UttSlot {      // per in-flight utterance workspace (batch pipeline uses two)
+    DevBuf cand, tdist, J, bp, path, plen, cost;
+    hipEvent_t knn_done = nullptr, vit_done = nullptr;
+};
+
+struct snk_engine {
+    int device = 0;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    // database
+    int64_t N = 0, Njc = 0, Nalloc = 0;
+    int Dt = 0, Dj = 0, Dpad = 0, Djpad = 0;
+    DevBuf F_unw, JC_unw, Fw, fnorm, JCw, wt, wj, unit_class;
+    bool have_db = false, have_join = false, have_weights = false, have_classes = false;
+    int64_t shard_offset = 0, global_N = -1;
+    // k-nn workspace
+    DevBuf Qraw, Qp, qnorm, thr, gmin, cnt, lkey, lidx, status, qclass, d2tmp;
+    UttSlot slot[2];
+    // greedy
+    GreedyLayout glay{};
+    bool have_glay = false;
+    DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist;
+    // options
+    int cap = 4096;
+    double sample_frac = 1.0 / 16.0;
+    int nt_override = 0;
+    int timers_on = 1;
+    int last_retries = 0;
+    int tie_overflow = 0;
+    // timers
+    std::vector<EvPair> pending;
+    std::vector<hipEvent_t> ev_pool;
+    double tm_ms[TM_COUNT] = {0};
+    int64_t tm_n[TM_COUNT] = {0};
+};
+
+static hipEvent_t ev_get(snk_engine *h)
+{
+    if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct StageTimer {     // records an event pair around a stage on a stream
+    snk_engine *h; hipStream_t s; EvPair ep; bool on;
+    StageTimer(snk_engine *h_, hipStream_t s_, int id) : h(h_), s(s_), on(h_->timers_on != 0)
+    {
+        if (!on) return;
+        ep.id = id; ep.a = ev_get(h); ep.b = ev_get(h);
+        (void)hipEventRecord(ep.a, s);
+    }
+    ~StageTimer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(ep.b, s);
+        h->pending.push_back(ep);
+    }
+};
+
+static void collect_timers(snk_engine *h)   // call after the streams were synchronised
+{
+    for (auto &ep : h->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { h->tm_ms[ep.id] += ms; h->tm_n[ep.id] += 1; }
+        h->ev_pool.push_back(ep.a);
+        h->ev_pool.push_back(ep.b);
+    }
+    h->pending.clear();
+}
+
+static int roundup(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); }
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int snk_abi_version(void) { return 1; }
+const char *snk_last_error(void) { return g_err.c_str(); }
+
+int snk_device_count(int *count_out)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count_out = 0; return fail("hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count_out = n;
+    return 0;
+}
+
+int snk_create(int device_id, snk_handle *out)
+{
+    if (!out) return fail("snk_create: null handle_out");
+    *out = nullptr;
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (n <= 0) return fail("snk_create: no HIP device available (this engine has no CPU fallback)");
+    if (device_id < 0 || device_id >= n) return fail("snk_create: device %d out of range (0..%d)", device_id, n - 1);
+    HIPCHK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("snk_create: device %d is %s; this library is built for gfx950 (MI355X) only",
+                    device_id, prop.gcnArchName);
+    snk_engine *h = new snk_engine();
+    h->device = device_id;
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipEventCreateWithFlags(&h->slot[i].knn_done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->slot[i].vit_done, hipEventDisableTiming));
+    }
+    *out = h;
+    return 0;
+}
+
+int snk_destroy(snk_handle h)
+{
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream2);
+    collect_timers(h);
+    DevBuf *bufs[] = {&h->F_unw, &h->JC_unw, &h->Fw, &h->fnorm, &h->JCw, &h->wt, &h->wj, &h->unit_class,
+                      &h->Qraw, &h->Qp, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
+                      &h->status, &h->qclass, &h->d2tmp, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
+                      &h->gpath, &h->gdist};
+    for (auto *b : bufs) b->release();
+    for (int i = 0; i < 2; ++i) {
+        UttSlot &s = h->slot[i];
+        DevBuf *sb[] = {&s.cand, &s.tdist, &s.J, &s.bp, &s.path, &s.plen, &s.cost};
+        for (auto *b : sb) b->release();
+        if (s.knn_done) (void)hipEventDestroy(s.knn_done);
+        if (s.vit_done) (void)hipEventDestroy(s.vit_done);
+    }
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(h->stream);
+    (void)hipStreamDestroy(h->stream2);
+    delete h;
+    return 0;
+}
+
+static int upload_join(snk_engine *h, const float *JC_unw, int64_t Njc, int Dj)
+{
+    if (!JC_unw || Njc < 2 || Dj < 1) return fail("upload: bad join matrix (Njc=%lld Dj=%d)", (long long)Njc, Dj);
+    h->Njc = Njc; h->Dj = Dj; h->Djpad = roundup(Dj, 32);
+    CHK(h->JC_unw.ensure((size_t)Njc * Dj * sizeof(float)));
+    CHK(h->JCw.ensure((size_t)Njc * h->Djpad * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->JC_unw.p, JC_unw, (size_t)Njc * Dj * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_join = true;
+    h->have_weights = false;
+    return 0;
+}
+
+int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt, const float *JC_unw,
+                  int64_t Njc, int Dj)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (!F_unw || N < 1 || Dt < 1) return fail("snk_upload_db: bad target matrix (N=%lld Dt=%d)", (long long)N, Dt);
+    if (Dt > 256) return fail("snk_upload_db: Dt=%d > 256 columns is not supported", Dt);
+    if (N >= (1LL << 31) - 4096) return fail("snk_upload_db: N=%lld exceeds the 31-bit unit id range", (long long)N);
+    if (JC_unw && Njc != N + 1) return fail("snk_upload_db: join_contexts must have N+1 rows (got %lld, N=%lld)", (long long)Njc, (long long)N);
+    h->N = N; h->Dt = Dt; h->Dpad = roundup(Dt, SNK_DPAD);
+    h->Nalloc = roundup(N, 16) + 16 * SNK_NT_MAX;
+    CHK(h->F_unw.ensure((size_t)N * Dt * sizeof(float)));
+    CHK(h->Fw.ensure((size_t)h->Nalloc * h->Dpad * sizeof(double)));
+    CHK(h->fnorm.ensure((size_t)h->Nalloc * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->F_unw.p, F_unw, (size_t)N * Dt * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_db = true;
+    h->have_weights = false;
+    h->have_classes = false;
+    h->have_glay = false;
+    if (h->global_N < 0) { h->shard_offset = 0; }
+    if (JC_unw) CHK(upload_join(h, JC_unw, Njc, Dj));
+    return 0;
+}
+
+int snk_upload_join_only(snk_handle h, const float *JC_unw, int64_t Njc, int Dj)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    return upload_join(h, JC_unw, Njc, Dj);
+}
+
+int snk_set_shard(snk_handle h, int64_t global_row_offset, int64_t global_N)
+{
+    if (!h) return fail("null handle");
+    if (global_row_offset < 0 || global_N < 1) return fail("snk_set_shard: bad arguments");
+    h->shard_offset = global_row_offset;
+    h->global_N = global_N;
+    return 0;
+}
+
+int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, int n_wj)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->have_db && !h->have_join) return fail("snk_set_weights: no database uploaded");
+    if (h->have_db) {
+        if (!wt || n_wt != h->Dt)
+            return fail("snk_set_weights: target weight vector has %d entries, database has %d columns", n_wt, h->Dt);
+        CHK(h->wt.ensure((size_t)n_wt * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(h->wt.p, wt, (size_t)n_wt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    if (h->have_join) {
+        if (!wj || n_wj != h->Dj)
+            return fail("snk_set_weights: join weight vector has %d entries, join_contexts has %d columns", n_wj, h->Dj);
+        CHK(h->wj.ensure((size_t)n_wj * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(h->wj.p, wj, (size_t)n_wj * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    {
+        StageTimer t(h, h->stream, TM_WEIGHTS);
+        if (h->have_db)
+            launch_weight_target(h->F_unw.as<float>(), h->N, h->Dt, h->wt.as<double>(), h->Fw.as<double>(),
+                                 h->fnorm.as<double>(), h->Nalloc, h->Dpad, nullptr, h->stream);
+        if (h->have_join)
+            launch_weight_join(h->JC_unw.as<float>(), h->Njc, h->Dj, h->wj.as<double>(), h->JCw.as<double>(),
+                               h->Djpad, h->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    collect_timers(h);
+    h->have_weights = true;
+    return 0;
+}
+
+int snk_set_unit_classes(snk_handle h, const int32_t *unit_class, int64_t N)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->have_db || N != h->N) return fail("snk_set_unit_classes: N=%lld does not match the database (%lld)", (long long)N, (long long)h->N);
+    CHK(h->unit_class.ensure((size_t)h->Nalloc * sizeof(int32_t)));
+    HIPCHK(hipMemsetAsync(h->unit_class.p, 0xff, (size_t)h->Nalloc * sizeof(int32_t), h->stream));
+    HIPCHK(hipMemcpyAsync(h->unit_class.p, unit_class, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_classes = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// K-NN pipeline on device.  Q must already be on the device (Qraw).  Results go to the
+// given device buffers.  Synchronises the stream once per attempt to read the status word.
+// ---------------------------------------------------------------------------
+static KnnPlan make_plan(snk_engine *h, int K)
+{
+    KnnPlan p{};
+    p.dch = h->Dpad / 64;
+    int nt = (p.dch == 1) ? 8 : (p.dch == 2) ? 4 : (p.dch == 3) ? 2 : 1;
+    if (h->nt_override > 0 && p.dch <= 2) {
+        if (h->nt_override == 2 || h->nt_override == 4 || (h->nt_override == 8 && p.dch == 1)) nt = h->nt_override;
+    }
+    p.nt = nt;
+    const int64_t slab_rows = 16 * nt;
+    p.n_slabs = (h->N + slab_rows - 1) / slab_rows;
+    // stage-A sample: a strided subset of slabs, large enough to hold >= 4K groups of
+    // slab-lane minima (16 groups per slab) whenever the database allows it
+    int64_t want = (int64_t)ceil((double)p.n_slabs * h->sample_frac);
+    const int64_t min_slabs = (4 * (int64_t)K + 15) / 16;
+    if (want < min_slabs) want = min_slabs;
+    if (want > p.n_slabs) want = p.n_slabs;
+    if (want < 1) want = 1;
+    p.a_stride = p.n_slabs / want;
+    if (p.a_stride < 1) p.a_stride = 1;
+    p.a_count = (p.n_slabs + p.a_stride - 1) / p.a_stride;
+    p.a_start = 0;
+    return p;
+}
+
+static int knn_device(snk_engine *h, int64_t T, int K, const int32_t *qclass_dev,
+                      int64_t *cand_dev, double *dist_dev, double *d2_dev)
+{
+    if (K < 1 || K > 208) return fail("K-NN: n_candidates=%d outside the supported range 1..208", K);
+    const int64_t Tpad = roundup(T, 16);
+    const KnnPlan p = make_plan(h, K);
+    const bool cls = qclass_dev != nullptr;
+    const int32_t *uc = cls ? h->unit_class.as<int32_t>() : nullptr;
+    int cap = h->cap;
+    if (cap < 2 * K) cap = 2 * K;
+    const int64_t G = p.a_count * 16;
+    CHK(h->Qp.ensure((size_t)Tpad * h->Dpad * sizeof(double)));
+    CHK(h->qnorm.ensure((size_t)Tpad * sizeof(double)));
+    CHK(h->thr.ensure((size_t)Tpad * sizeof(double)));
+    CHK(h->gmin.ensure((size_t)Tpad * G * sizeof(double)));
+    CHK(h->cnt.ensure((size_t)Tpad * sizeof(int)));
+    CHK(h->lkey.ensure((size_t)Tpad * cap * sizeof(double)));
+    CHK(h->lidx.ensure((size_t)Tpad * cap * sizeof(int)));
+    CHK(h->status.ensure(sizeof(int)));
+    hipStream_t s = h->stream;
+    {
+        StageTimer t(h, s, TM_PREP);
+        launch_prepare_queries(h->Qraw.as<double>(), T, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(),
+                               Tpad, h->Dpad, s);
+    }
+    // small databases: fewer than K sampled groups cannot bound the K-th neighbour
+    const bool use_sample = (G >= K);
+    if (use_sample) {
+        {
+            StageTimer t(h, s, TM_KNN_MINIMA);
+            launch_knn_minima(p, h->Fw.as<double>(), h->fnorm.as<double>(), h->Qp.as<double>(), Tpad,
+                              h->gmin.as<double>(), G, uc, qclass_dev, s);
+        }
+        {
+            StageTimer t(h, s, TM_KNN_THRESHOLD);
+            launch_knn_threshold(h->gmin.as<double>(), G, T, Tpad, K, h->thr.as<double>(), s);
+        }
+    } else {
+        // tiny databases take every unit; the lists are bounded by the retry loop below
+        launch_fill_threshold(h->thr.as<double>(), T, Tpad, DBL_MAX, s);
+    }
+    h->last_retries = 0;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        HIPCHK(hipMemsetAsync(h->cnt.p, 0, (size_t)Tpad * sizeof(int), s));
+        HIPCHK(hipMemsetAsync(h->status.p, 0, sizeof(int), s));
+        {
+            StageTimer t(h, s, TM_KNN_FILTER);
+            launch_knn_filter(p, h->Fw.as<double>(), h->fnorm.as<double>(), h->Qp.as<double>(),
+                              h->thr.as<double>(), Tpad, h->cnt.as<int>(), h->lkey.as<double>(),
+                              h->lidx.as<int>(), cap, uc, qclass_dev, s);
+        }
+        {
+            StageTimer t(h, s, TM_KNN_FINALIZE);
+            launch_knn_finalize(h->Fw.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
+                                h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
+                                h->shard_offset, cand_dev, dist_dev, d2_dev, h->status.as<int>(), s);
+        }
+        int status = 0;
+        HIPCHK(hipMemcpyAsync(&status, h->status.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipGetLastError());
+        if (status == 0) return 0;
+        if (status & 2) h->tie_overflow = 1;   // > 256-K near ties at the cut: (key, id) order kept
+        if (!(status & 1)) return 0;
+        // some list overflowed: tighten those rows' thresholds from what was stored, retry
+        h->last_retries = attempt + 1;
+        launch_knn_retighten(h->cnt.as<int>(), h->lkey.as<double>(), cap, T, K, h->thr.as<double>(), s);
+    }
+    return fail("K-NN: candidate lists still overflow after 6 threshold refinements (cap=%d)", cap);
+}
+
+static int check_ready(snk_engine *h, bool need_target, bool need_join)
+{
+    if (!h) return fail("null handle");
+    if (need_target && !h->have_db) return fail("no unit database uploaded (snk_upload_db)");
+    if (need_join && !h->have_join) return fail("no join_contexts uploaded");
+    if (!h->have_weights) return fail("weights not set (snk_set_weights)");
+    return 0;
+}
+
+static int upload_queries(snk_engine *h, const double *Q, int64_t T, int D)
+{
+    if (!Q) return fail("null query matrix");
+    if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
+    if (T < 1) return fail("query matrix has no rows");
+    CHK(h->Qraw.ensure((size_t)T * D * sizeof(double)));
+    StageTimer t(h, h->stream, TM_H2D);
+    HIPCHK(hipMemcpyAsync(h->Qraw.p, Q, (size_t)T * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+static int slot_ensure(snk_engine *h, UttSlot &s, int64_t T, int K)
+{
+    CHK(s.cand.ensure((size_t)T * K * sizeof(int64_t)));
+    CHK(s.tdist.ensure((size_t)T * K * sizeof(double)));
+    CHK(s.J.ensure((size_t)(T > 1 ? T - 1 : 1) * K * K * sizeof(double)));
+    CHK(s.bp.ensure((size_t)T * K));
+    CHK(s.path.ensure((size_t)T * sizeof(int64_t)));
+    CHK(s.plen.ensure(sizeof(int64_t)));
+    CHK(s.cost.ensure(sizeof(double)));
+    return 0;
+}
+
+int snk_knn(snk_handle h, const double *Q, int64_t T, int D, int K, int64_t *cand_out, double *dist_out)
+{
+    CHK(check_ready(h, true, false));
+    HIPCHK(hipSetDevice(h->device));
+    if (!cand_out || !dist_out) return fail("snk_knn: null output");
+    CHK(upload_queries(h, Q, T, D));
+    UttSlot &s = h->slot[0];
+    CHK(s.cand.ensure((size_t)T * K * sizeof(int64_t)));
+    CHK(s.tdist.ensure((size_t)T * K * sizeof(double)));
+    CHK(knn_device(h, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
+    {
+        StageTimer t(h, h->stream, TM_D2H);
+        HIPCHK(hipMemcpyAsync(cand_out, s.cand.p, (size_t)T * K * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(dist_out, s.tdist.p, (size_t)T * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    collect_timers(h);
+    return 0;
+}
+
+int snk_knn_by_class(snk_handle h, const double *Q, int64_t T, int D, int K, const int32_t *query_class,
+                     int64_t *cand_out, double *dist_out)
+{
+    CHK(check_ready(h, true, false));
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->have_classes) return fail("snk_knn_by_class: unit classes not set (snk_set_unit_classes)");
+    if (!query_class || !cand_out || !dist_out) return fail("snk_knn_by_class: null argument");
+    CHK(upload_queries(h, Q, T, D));
+    const int64_t Tpad = roundup(T, 16);
+    CHK(h->qclass.ensure((size_t)Tpad * sizeof(int32_t)));
+    HIPCHK(hipMemsetAsync(h->qclass.p, 0xfe, (size_t)Tpad * sizeof(int32_t), h->stream));
+    HIPCHK(hipMemcpyAsync(h->qclass.p, query_class, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    UttSlot &s = h->slot[0];
+    CHK(s.cand.ensure((size_t)T * K * sizeof(int64_t)));
+    CHK(s.tdist.ensure((size_t)T * K * sizeof(double)));
+    CHK(knn_device(h, T, K, h->qclass.as<int32_t>(), s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
+    HIPCHK(hipMemcpyAsync(cand_out, s.cand.p, (size_t)T * K * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(dist_out, s.tdist.p, (size_t)T * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    collect_timers(h);
+    return 0;
+}
+
+static int64_t join_units(snk_engine *h)
+{
+    // data_frames of unit_end_data = rows of join_contexts - 1 (synth_halfphone.py:3227)
+    return h->Njc - 1;
+}
+
+static int viterbi_device(snk_engine *h, UttSlot &s, int64_t T, int K, hipStream_t st)
+{
+    if (K > 208) return fail("viterbi: n_candidates=%d > 208 not supported", K);
+    {
+        StageTimer t(h, st, TM_JOIN);
+        launch_join_costs(h->JCw.as<double>(), h->Djpad, h->Dj, join_units(h), s.cand.as<int64_t>(), T, K,
+                          s.J.as<double>(), st);
+    }
+    {
+        StageTimer t(h, st, TM_VITERBI_DP);
+        launch_viterbi_dp(s.cand.as<int64_t>(), s.tdist.as<double>(), s.J.as<double>(), T, K, join_units(h),
+                          s.bp.as<unsigned char>(), s.path.as<int64_t>(), s.plen.as<int64_t>(),
+                          s.cost.as<double>(), st);
+    }
+    return 0;
+}
+
+int snk_join_costs(snk_handle h, const int64_t *cand, int64_t T, int K, double *J_out)
+{
+    CHK(check_ready(h, false, true));
+    HIPCHK(hipSetDevice(h->device));
+    if (!cand || !J_out) return fail("snk_join_costs: null argument");
+    if (T < 2) return fail("snk_join_costs: need at least 2 columns");
+    if (K < 1 || K > 208) return fail("snk_join_costs: K=%d outside 1..208", K);
+    UttSlot &s = h->slot[0];
+    CHK(slot_ensure(h, s, T, K));
+    HIPCHK(hipMemcpyAsync(s.cand.p, cand, (size_t)T * K * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    {
+        StageTimer t(h, h->stream, TM_JOIN);
+        launch_join_costs(h->JCw.as<double>(), h->Djpad, h->Dj, join_units(h), s.cand.as<int64_t>(), T, K,
+                          s.J.as<double>(), h->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(J_out, s.J.p, (size_t)(T - 1) * K * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    collect_timers(h);
+    return 0;
+}
+
+int snk_viterbi(snk_handle h, const int64_t *cand, const double *tdist, int64_t T, int K,
+                int64_t *path_out, int64_t *path_len_out, double *cost_out)
+{
+    CHK(check_ready(h, false, true));
+    HIPCHK(hipSetDevice(h->device));
+    if (!cand || !tdist || !path_out || !path_len_out) return fail("snk_viterbi: null argument");
+    if (T < 1 || K < 1) return fail("snk_viterbi: empty trellis");
+    UttSlot &s = h->slot[0];
+    CHK(slot_ensure(h, s, T, K));
+    HIPCHK(hipMemcpyAsync(s.cand.p, cand, (size_t)T * K * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(s.tdist.p, tdist, (size_t)T * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CHK(viterbi_device(h, s, T, K, h->stream));
+    HIPCHK(hipGetLastError());
+    double cost = 0;
+    HIPCHK(hipMemcpyAsync(path_len_out, s.plen.p, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&cost, s.cost.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(path_out, s.path.p, (size_t)T * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (cost_out) *cost_out = cost;
+    collect_timers(h);
+    return 0;
+}
+
+int snk_knn_viterbi(snk_handle h, const double *Q, int64_t T, int D, int K, int64_t *cand_out,
+                    double *dist_out, int64_t *path_out, int64_t *path_len_out, double *cost_out)
+{
+    CHK(check_ready(h, true, true));
+    HIPCHK(hipSetDevice(h->device));
+    if (!path_out || !path_len_out) return fail("snk_knn_viterbi: null output");
+    if (h->Njc != h->N + 1) return fail("snk_knn_viterbi: join_contexts rows (%lld) != N+1", (long long)h->Njc);
+    CHK(upload_queries(h, Q, T, D));
+    UttSlot &s = h->slot[0];
+    CHK(slot_ensure(h, s, T, K));
+    CHK(knn_device(h, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
+    CHK(viterbi_device(h, s, T, K, h->stream));
+    HIPCHK(hipGetLastError());
+    double cost = 0;
+    {
+        StageTimer t(h, h->stream, TM_D2H);
+        if (cand_out) HIPCHK(hipMemcpyAsync(cand_out, s.cand.p, (size_t)T * K * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        if (dist_out) HIPCHK(hipMemcpyAsync(dist_out, s.tdist.p, (size_t)T * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(path_len_out, s.plen.p, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(&cost, s.cost.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(path_out, s.path.p, (size_t)T * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (cost_out) *cost_out = cost;
+    collect_timers(h);
+    return 0;
+}
+
+int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D,
+                          int K, int64_t *path_out, int64_t *path_len_out, double *cost_out)
+{
+    CHK(check_ready(h, true, true));
+    HIPCHK(hipSetDevice(h->device));
+    if (!Q || !row_offsets || n_utts < 1 || !path_out || !path_len_out || !cost_out)
+        return fail("snk_knn_viterbi_batch: null/empty argument");
+    if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
+    if (h->Njc != h->N + 1) return fail("snk_knn_viterbi_batch: join_contexts rows != N+1");
+    // K-NN of utterance u+1 (stream) overlaps join costs + DP of utterance u (stream2).
+    for (int u = 0; u < n_utts; ++u) {
+        const int64_t r0 = row_offsets[u], T = row_offsets[u + 1] - r0;
+        if (T < 1) return fail("snk_knn_viterbi_batch: utterance %d has no rows", u);
+        UttSlot &s = h->slot[u & 1];
+        CHK(slot_ensure(h, s, T, K));
+        if (u >= 2) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));   // slot reuse
+        CHK(h->Qraw.ensure((size_t)T * D * sizeof(double)));
+        {
+            StageTimer t(h, h->stream, TM_H2D);
+            HIPCHK(hipMemcpyAsync(h->Qraw.p, Q + r0 * D, (size_t)T * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        }
+        CHK(knn_device(h, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
+        HIPCHK(hipEventRecord(s.knn_done, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->stream2, s.knn_done, 0));
+        CHK(viterbi_device(h, s, T, K, h->stream2));
+        HIPCHK(hipMemcpyAsync(path_len_out + u, s.plen.p, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream2));
+        HIPCHK(hipMemcpyAsync(cost_out + u, s.cost.p, sizeof(double), hipMemcpyDeviceToHost, h->stream2));
+        HIPCHK(hipMemcpyAsync(path_out + r0, s.path.p, (size_t)T * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream2));
+        HIPCHK(hipEventRecord(s.vit_done, h->stream2));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream2));
+    HIPCHK(hipGetLastError());
+    collect_timers(h);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// greedy search
+// ---------------------------------------------------------------------------
+int snk_set_greedy_layout(snk_handle h, int multiepoch, int last_frame_as_target, int join_split_mode)
+{
+    if (!h) return fail("null handle");
+    if (!h->have_db || !h->have_join) return fail("snk_set_greedy_layout: upload the database first");
+    if (multiepoch < 1 || multiepoch > 16) return fail("snk_set_greedy_layout: multiepoch=%d outside 1..16", multiepoch);
+    if (join_split_mode != 0 && join_split_mode != 1) return fail("snk_set_greedy_layout: join_split_mode must be 0 or 1");
+    if (join_split_mode == 1 && (h->Dj % 2)) return fail("snk_set_greedy_layout: join_split_mode 1 needs an even number of join columns");
+    const int64_t Nrep = h->Njc - 1;            // rows of unit_start_data / unit_end_data
+    if (Nrep != h->N) return fail("snk_set_greedy_layout: join_contexts rows (%lld) != N+1", (long long)h->Njc);
+    if (h->N < multiepoch) return fail("snk_set_greedy_layout: database shorter than one multiepoch window");
+    GreedyLayout g{};
+    g.me = multiepoch;
+    g.last_frame_as_target = last_frame_as_target ? 1 : 0;
+    g.join_split_mode = join_split_mode;
+    g.Nwin = h->N - multiepoch + 1;
+    if (join_split_mode == 0) {
+        // prev = unit_start_data = JC[:-1] (row i); current = unit_end_data = JC[1:], shifted by
+        // the multiepoch overlap (synth_simple.py:194-195,213-214): window i -> JC row i + me
+        g.jdim = h->Dj; g.prev_col0 = 0; g.cur_col0 = 0; g.prev_row0 = 0; g.cur_row0 = multiepoch;
+    } else {
+        // synth_halfphone.py:552-553: halves of the unit_start_data columns
+        g.jdim = h->Dj / 2; g.prev_col0 = 0; g.cur_col0 = h->Dj / 2; g.prev_row0 = 0; g.cur_row0 = multiepoch - 1;
+    }
+    if (greedy_shmem_bytes(g, h->Dt, h->Dj) > 150 * 1024)
+        return fail("snk_set_greedy_layout: feature dimensions too large for the greedy scan tile");
+    h->glay = g;
+    h->have_glay = true;
+    return 0;
+}
+
+int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_state, double eps,
+               int64_t *path_out, double *dist_out, int64_t *nsteps_out)
+{
+    CHK(check_ready(h, true, true));
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->have_glay) return fail("snk_greedy: greedy layout not set (snk_set_greedy_layout)");
+    if (!path_out || !nsteps_out) return fail("snk_greedy: null output");
+    if (!(eps >= 0.0)) return fail("snk_greedy: search_epsilon must be >= 0");
+    const GreedyLayout &g = h->glay;
+    if (start_state >= g.Nwin) return fail("snk_greedy: start_state %lld out of range", (long long)start_state);
+    CHK(upload_queries(h, Q, T, D));
+    const int64_t nsteps = T / g.me;          // py2 integer division: tail frames dropped
+    *nsteps_out = nsteps;
+    if (nsteps == 0) { HIPCHK(hipStreamSynchronize(h->stream)); collect_timers(h); return 0; }
+    const int nblk = greedy_blocks(g);
+    CHK(h->gprev.ensure((size_t)g.jdim * sizeof(double)));
+    CHK(h->gblkmin.ensure((size_t)nblk * sizeof(double)));
+    CHK(h->gblkarg.ensure((size_t)nblk * sizeof(int64_t)));
+    CHK(h->gpath.ensure((size_t)nsteps * sizeof(int64_t)));
+    CHK(h->gdist.ensure((size_t)nsteps * sizeof(double)));
+    {
+        StageTimer t(h, h->stream, TM_GREEDY_STEPS);
+        launch_greedy(g, h->F_unw.as<float>(), h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Dj,
+                      h->wj.as<double>(), h->Qraw.as<double>(), nsteps, start_state, h->gprev.as<double>(),
+                      h->gblkmin.as<double>(), h->gblkarg.as<int64_t>(), nblk, h->gpath.as<int64_t>(),
+                      h->gdist.as<double>(), h->stream);
+    }
+    HIPCHK(hipGetLastError());
+    {
+        StageTimer t(h, h->stream, TM_D2H);
+        HIPCHK(hipMemcpyAsync(path_out, h->gpath.p, (size_t)nsteps * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        if (dist_out) HIPCHK(hipMemcpyAsync(dist_out, h->gdist.p, (size_t)nsteps * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    collect_timers(h);
+    return 0;
+}
+
+int snk_path_scores(snk_handle h, const double *Q, const int64_t *path, int64_t L, int mode,
+                    double *tsq_out, double *jsq_out)
+{
+    CHK(check_ready(h, true, true));
+    HIPCHK(hipSetDevice(h->device));
+    if (!Q || !path || !tsq_out || L < 1) return fail("snk_path_scores: null/empty argument");
+    if (mode != 0 && mode != 1) return fail("snk_path_scores: mode must be 0 (viterbi) or 1 (greedy)");
+    if (mode == 1 && !h->have_glay) return fail("snk_path_scores: greedy layout not set");
+    GreedyLayout g = h->glay;
+    int me = 1, nep = 1, jcols = h->Dj;
+    if (mode == 1) { me = g.me; nep = (g.last_frame_as_target && me > 1) ? 2 : me; jcols = g.jdim; }
+    const int64_t limit = (mode == 1) ? g.Nwin : h->N;
+    for (int64_t l = 0; l < L; ++l)
+        if (path[l] < 0 || path[l] >= limit) return fail("snk_path_scores: path[%lld]=%lld out of range", (long long)l, (long long)path[l]);
+    const size_t qrows = (size_t)L * me;
+    CHK(h->Qraw.ensure(qrows * h->Dt * sizeof(double)));
+    CHK(h->gpath.ensure((size_t)L * sizeof(int64_t)));
+    const size_t tbytes = (size_t)L * nep * h->Dt * sizeof(double);
+    const size_t jbytes = (size_t)(L > 1 ? L - 1 : 1) * jcols * sizeof(double);
+    CHK(h->d2tmp.ensure(tbytes + jbytes));
+    HIPCHK(hipMemcpyAsync(h->Qraw.p, Q, qrows * h->Dt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->gpath.p, path, (size_t)L * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    double *tsq = h->d2tmp.as<double>();
+    double *jsq = reinterpret_cast<double *>(reinterpret_cast<char *>(h->d2tmp.p) + tbytes);
+    launch_path_scores(g, mode, h->F_unw.as<float>(), h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Dj,
+                       h->wj.as<double>(), h->Qraw.as<double>(), h->gpath.as<int64_t>(), L, tsq, jsq, jcols, h->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(tsq_out, tsq, tbytes, hipMemcpyDeviceToHost, h->stream));
+    if (jsq_out && L > 1) HIPCHK(hipMemcpyAsync(jsq_out, jsq, (size_t)(L - 1) * jcols * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU device-pointer entry points
+// ---------------------------------------------------------------------------
+int snk_knn_local_dev(snk_handle h, const double *Q, int64_t T, int D, int K, double *d2_dev_out,
+                      int64_t *id_dev_out)
+{
+    CHK(check_ready(h, true, false));
+    HIPCHK(hipSetDevice(h->device));
+    if (!d2_dev_out || !id_dev_out) return fail("snk_knn_local_dev: null output");
+    CHK(upload_queries(h, Q, T, D));
+    CHK(knn_device(h, T, K, nullptr, id_dev_out, nullptr, d2_dev_out));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    collect_timers(h);
+    return 0;
+}
+
+int snk_merge_topk_dev(snk_handle h, const double *d2_dev, const int64_t *id_dev, int G, int64_t T, int K,
+                       int64_t *cand_out, double *dist_out)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (!d2_dev || !id_dev || !cand_out || !dist_out) return fail("snk_merge_topk_dev: null argument");
+    if (G < 1 || (int64_t)G * K > 8192) return fail("snk_merge_topk_dev: G*K=%d exceeds 8192", G * K);
+    UttSlot &s = h->slot[0];
+    CHK(s.cand.ensure((size_t)T * K * sizeof(int64_t)));
+    CHK(s.tdist.ensure((size_t)T * K * sizeof(double)));
+    launch_merge_topk(d2_dev, id_dev, G, T, K, s.cand.as<int64_t>(), s.tdist.as<double>(), h->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(cand_out, s.cand.p, (size_t)T * K * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(dist_out, s.tdist.p, (size_t)T * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// timers / options / self test
+// ---------------------------------------------------------------------------
+int snk_timer_count(void) { return TM_COUNT; }
+const char *snk_timer_name(int i) { return (i >= 0 && i < TM_COUNT) ? kTimerNames[i] : ""; }
+
+int snk_get_timers(snk_handle h, double *ms_out, int capacity)
+{
+    if (!h || !ms_out) return -1;
+    // layout: [total_ms x TM_COUNT][launch count x TM_COUNT]
+    int n = 0;
+    for (int i = 0; i < TM_COUNT && n < capacity; ++i) ms_out[n++] = h->tm_ms[i];
+    for (int i = 0; i < TM_COUNT && n < capacity; ++i) ms_out[n++] = (double)h->tm_n[i];
+    return n;
+}
+
+int snk_reset_timers(snk_handle h)
+{
+    if (!h) return fail("null handle");
+    for (int i = 0; i < TM_COUNT; ++i) { h->tm_ms[i] = 0; h->tm_n[i] = 0; }
+    return 0;
+}
+
+int snk_set_option(snk_handle h, const char *name, double value)
+{
+    if (!h || !name) return fail("snk_set_option: null argument");
+    if (!strcmp(name, "list_capacity")) {
+        if (value < 64 || value > 8192) return fail("list_capacity must be in 64..8192");
+        h->cap = (int)value;
+    } else if (!strcmp(name, "sample_fraction")) {
+        if (!(value > 0.0 && value <= 1.0)) return fail("sample_fraction must be in (0,1]");
+        h->sample_frac = value;
+    } else if (!strcmp(name, "db_tiles_per_wave")) {
+        h->nt_override = (int)value;
+    } else if (!strcmp(name, "timers")) {
+        h->timers_on = value != 0.0;
+    } else {
+        return fail("snk_set_option: unknown option '%s'", name);
+    }
+    return 0;
+}
+
+int snk_get_info(snk_handle h, const char *name, double *out)
+{
+    if (!h || !name || !out) return fail("snk_get_info: null argument");
+    if (!strcmp(name, "n_units")) *out = (double)h->N;
+    else if (!strcmp(name, "target_dim")) *out = h->Dt;
+    else if (!strcmp(name, "join_dim")) *out = h->Dj;
+    else if (!strcmp(name, "last_knn_retries")) *out = h->last_retries;
+    else if (!strcmp(name, "list_capacity")) *out = h->cap;
+    else if (!strcmp(name, "tie_overflow")) *out = h->tie_overflow;
+    else if (!strcmp(name, "device")) *out = h->device;
+    else if (!strcmp(name, "db_tiles_per_wave")) { KnnPlan p = make_plan(h, 100); *out = p.nt; }
+    else if (!strcmp(name, "sample_slabs")) { KnnPlan p = make_plan(h, 100); *out = (double)p.a_count; }
+    else if (!strcmp(name, "n_slabs")) { KnnPlan p = make_plan(h, 100); *out = (double)p.n_slabs; }
+    else return fail("snk_get_info: unknown item '%s'", name);
+    return 0;
+}
+
+int snk_selftest_mfma(snk_handle h, double *max_abs_err_out)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    double A[64], B[64], C[256], R[256];
+    for (int i = 0; i < 16; ++i)
+        for (int k = 0; k < 4; ++k) A[i * 4 + k] = (double)(3 * i + 7 * k + 1);      // asymmetric
+    for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 16; ++j) B[k * 16 + j] = (double)(5 * k - 2 * j + (k * j) % 3);
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            double acc = 0;
+            for (int k = 0; k < 4; ++k) acc += A[i * 4 + k] * B[k * 16 + j];
+            R[i * 16 + j] = acc;
+        }
+    DevBuf dA, dB, dC;
+    CHK(dA.ensure(sizeof(A))); CHK(dB.ensure(sizeof(B))); CHK(dC.ensure(sizeof(C)));
+    HIPCHK(hipMemcpy(dA.p, A, sizeof(A), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dB.p, B, sizeof(B), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dC.p, 0, sizeof(C)));
+    launch_mfma_selftest(dA.as<double>(), dB.as<double>(), dC.as<double>(), h->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(C, dC.p, sizeof(C), hipMemcpyDeviceToHost));
+    double err = 0;
+    for (int i = 0; i < 256; ++i) err = fmax(err, fabs(C[i] - R[i]));
+    dA.release(); dB.release(); dC.release();
+    if (max_abs_err_out) *max_abs_err_out = err;
+    return 0;
+}
+
+}  // extern "C"

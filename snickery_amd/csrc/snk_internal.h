@@ -1,0 +1,83 @@
+// Internal declarations shared by the HIP translation units of libsnkhip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SNK_DPAD 64          // K-NN feature chunk: columns padded to multiples of 64 doubles
+#define SNK_NT_MAX 8         // max DB tiles (16 rows each) a wave keeps in registers
+#define SNK_VERY_BIG 1000000000000000.0   // const.py:3
+
+namespace snk {
+
+// ---- database preparation -------------------------------------------------
+void launch_weight_target(const float *F_unw, int64_t N, int Dt, const double *wt,
+                          double *Fw, double *fnorm, int64_t Nalloc, int Dpad,
+                          const int32_t *unit_class, hipStream_t s);
+void launch_weight_join(const float *JC_unw, int64_t Njc, int Dj, const double *wj,
+                        double *JCw, int Djpad, hipStream_t s);
+
+// ---- K-NN -----------------------------------------------------------------
+struct KnnPlan {
+    int nt;              // DB tiles per wave (slab = 16*nt rows)
+    int dch;             // Dpad / 64
+    int64_t n_slabs;     // slabs covering the DB
+    int64_t a_start, a_stride, a_count;   // stage-A sample: slabs a_start + i*a_stride
+};
+
+void launch_prepare_queries(const double *Q, int64_t T, int D, double *Qp, double *qnorm,
+                            int64_t Tpad, int Dpad, hipStream_t s);
+// stage A: per-(row, lane-group) minima over the sampled slabs
+void launch_knn_minima(const KnnPlan &p, const double *Fw, const double *fnorm,
+                       const double *Qp, int64_t Tpad, double *gmin, int64_t G,
+                       const int32_t *unit_class, const int32_t *query_class, hipStream_t s);
+// K-th smallest of the minima -> per-row key-space threshold
+void launch_knn_threshold(const double *gmin, int64_t G, int64_t T, int64_t Tpad, int K,
+                          double *thr, hipStream_t s);
+void launch_fill_threshold(double *thr, int64_t T, int64_t Tpad, double value, hipStream_t s);
+// stage B: filtered sweep of the whole DB, candidates appended to per-row lists
+void launch_knn_filter(const KnnPlan &p, const double *Fw, const double *fnorm,
+                       const double *Qp, const double *thr, int64_t Tpad,
+                       int *cnt, double *lkey, int *lidx, int cap,
+                       const int32_t *unit_class, const int32_t *query_class, hipStream_t s);
+// stage C: per-row select + exact re-rank in canonical order + sort
+void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, const double *qnorm,
+                         int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
+                         int cap, int64_t id_offset,
+                         int64_t *cand, double *dist, double *d2_out, int *status, hipStream_t s);
+// tighten thresholds from (overflowed) lists: K-th smallest key present
+void launch_knn_retighten(const int *cnt, const double *lkey, int cap, int64_t T, int K,
+                          double *thr, hipStream_t s);
+void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, int K,
+                       int64_t *cand, double *dist, hipStream_t s);
+
+// ---- join costs + Viterbi -------------------------------------------------
+void launch_join_costs(const double *JCw, int Djpad, int Dj, int64_t n_units,
+                       const int64_t *cand, int64_t T, int K, double *J, hipStream_t s);
+void launch_viterbi_dp(const int64_t *cand, const double *tdist, const double *J,
+                       int64_t T, int K, int64_t n_units, unsigned char *bp_global,
+                       int64_t *path, int64_t *path_len, double *cost, hipStream_t s);
+
+// ---- greedy ---------------------------------------------------------------
+struct GreedyLayout {
+    int me, last_frame_as_target, join_split_mode;
+    int64_t Nwin;         // N - me + 1
+    int jdim;             // columns of prev/current join rep
+    int prev_col0, cur_col0;      // first column inside a JCw row
+    int64_t prev_row0, cur_row0;  // JCw row of window 0 for prev / current
+};
+void launch_greedy(const GreedyLayout &g, const float *F_unw, int Dt, const double *wt,
+                   const float *JC_unw, int Dj, const double *wj, const double *Q,
+                   int64_t nsteps, int64_t start_state, double *prev_vec, double *blk_min,
+                   int64_t *blk_arg, int nblk, int64_t *path, double *dist, hipStream_t s);
+size_t greedy_shmem_bytes(const GreedyLayout &g, int Dt, int Dj);
+int greedy_blocks(const GreedyLayout &g);
+
+void launch_path_scores(const GreedyLayout &g, int mode, const float *F_unw, int Dt, const double *wt,
+                        const float *JC_unw, int Dj, const double *wj, const double *Q,
+                        const int64_t *path, int64_t L, double *tsq, double *jsq, int jcols,
+                        hipStream_t s);
+
+// ---- self test --------------------------------------------------------------
+void launch_mfma_selftest(const double *A, const double *B, double *C, hipStream_t s);
+
+}  // namespace snk

@@ -1,0 +1,303 @@
+"""ctypes binding of libsnkhip.so (include/snk.h).
+
+``HipSearchEngine`` mirrors the search-related methods of the reference's ``Synthesiser``
+(script/synth_simple.py, script/synth_halfphone.py) one level below the config/HDF5 front end
+in ``snickery_amd.synthesiser``: same argument meaning, numpy in / numpy out.
+"""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class SnkError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, 'libsnkhip.so')
+
+
+_c_i64p = ctypes.POINTER(ctypes.c_int64)
+_c_i32p = ctypes.POINTER(ctypes.c_int32)
+_c_f64p = ctypes.POINTER(ctypes.c_double)
+_c_f32p = ctypes.POINTER(ctypes.c_float)
+
+# every symbol include/snk.h declares: (restype, argtypes)
+_SIGNATURES = {
+    'snk_abi_version': (ctypes.c_int, []),
+    'snk_last_error': (ctypes.c_char_p, []),
+    'snk_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    'snk_create': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    'snk_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'snk_upload_db': (ctypes.c_int, [ctypes.c_void_p, _c_f32p, ctypes.c_int64, ctypes.c_int,
+                                     _c_f32p, ctypes.c_int64, ctypes.c_int]),
+    'snk_set_weights': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int, _c_f64p, ctypes.c_int]),
+    'snk_knn': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                               _c_i64p, _c_f64p]),
+    'snk_set_unit_classes': (ctypes.c_int, [ctypes.c_void_p, _c_i32p, ctypes.c_int64]),
+    'snk_knn_by_class': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int,
+                                        ctypes.c_int, _c_i32p, _c_i64p, _c_f64p]),
+    'snk_join_costs': (ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int64, ctypes.c_int, _c_f64p]),
+    'snk_viterbi': (ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_f64p, ctypes.c_int64, ctypes.c_int,
+                                   _c_i64p, _c_i64p, _c_f64p]),
+    'snk_knn_viterbi': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int,
+                                       ctypes.c_int, _c_i64p, _c_f64p, _c_i64p, _c_i64p, _c_f64p]),
+    'snk_knn_viterbi_batch': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, _c_i64p, _c_i64p, _c_f64p]),
+    'snk_set_greedy_layout': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'snk_greedy': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
+                                  ctypes.c_double, _c_i64p, _c_f64p, _c_i64p]),
+    'snk_path_scores': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int64, ctypes.c_int,
+                                       _c_f64p, _c_f64p]),
+    'snk_get_timers': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int]),
+    'snk_timer_name': (ctypes.c_char_p, [ctypes.c_int]),
+    'snk_timer_count': (ctypes.c_int, []),
+    'snk_reset_timers': (ctypes.c_int, [ctypes.c_void_p]),
+    'snk_set_shard': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]),
+    'snk_knn_local_dev': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    'snk_merge_topk_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                          ctypes.c_int64, ctypes.c_int, _c_i64p, _c_f64p]),
+    'snk_upload_join_only': (ctypes.c_int, [ctypes.c_void_p, _c_f32p, ctypes.c_int64, ctypes.c_int]),
+    'snk_set_option': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]),
+    'snk_get_info': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, _c_f64p]),
+    'snk_selftest_mfma': (ctypes.c_int, [ctypes.c_void_p, _c_f64p]),
+}
+
+
+def load_library():
+    """Load libsnkhip.so and bind every symbol of include/snk.h.  Raises SnkError when the
+    library has not been built (``python -c 'import __graft_entry__ as g; g.build()'`` or
+    ``make``): the product never falls back to a CPU path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.isfile(path):
+        raise SnkError('%s not found: build it with `make` (hipcc --offload-arch=gfx950); '
+                       'there is no CPU fallback' % path)
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _LIB = lib
+    return lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a, typ):
+    return a.ctypes.data_as(typ)
+
+
+class HipSearchEngine(object):
+    """One engine = one MI355X + one HIP stream (see include/snk.h)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        self._check(self._lib.snk_create(int(device), ctypes.byref(self._h)))
+        self.device = int(device)
+        self.n_units = 0
+        self.Dt = 0
+        self.Dj = 0
+
+    # -- plumbing -----------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise SnkError(self._lib.snk_last_error().decode('utf-8', 'replace'))
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.snk_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- database -----------------------------------------------------------
+    def upload_db(self, train_unit_features_unweighted, join_contexts_unweighted):
+        F = np.ascontiguousarray(train_unit_features_unweighted, dtype=np.float32)
+        JC = np.ascontiguousarray(join_contexts_unweighted, dtype=np.float32)
+        assert F.ndim == 2 and JC.ndim == 2
+        self._check(self._lib.snk_upload_db(self._h, _ptr(F, _c_f32p), F.shape[0], F.shape[1],
+                                            _ptr(JC, _c_f32p), JC.shape[0], JC.shape[1]))
+        self.n_units, self.Dt = F.shape
+        self.Dj = JC.shape[1]
+
+    def upload_join_only(self, join_contexts_unweighted):
+        JC = np.ascontiguousarray(join_contexts_unweighted, dtype=np.float32)
+        self._check(self._lib.snk_upload_join_only(self._h, _ptr(JC, _c_f32p), JC.shape[0], JC.shape[1]))
+        self.Dj = JC.shape[1]
+
+    def set_weights(self, target_weight_vector, join_weight_vector):
+        """Per-COLUMN weight vectors (what set_target_weights / set_join_weights build from
+        the per-stream weights, synth_simple.py:234-274)."""
+        wt = _f64(target_weight_vector)
+        wj = _f64(join_weight_vector)
+        self._check(self._lib.snk_set_weights(self._h, _ptr(wt, _c_f64p), wt.size, _ptr(wj, _c_f64p), wj.size))
+
+    def set_unit_classes(self, unit_class):
+        uc = np.ascontiguousarray(unit_class, dtype=np.int32)
+        self._check(self._lib.snk_set_unit_classes(self._h, _ptr(uc, _c_i32p), uc.size))
+
+    def set_shard(self, global_row_offset, global_n):
+        self._check(self._lib.snk_set_shard(self._h, int(global_row_offset), int(global_n)))
+
+    # -- search ---------------------------------------------------------------
+    def knn(self, unit_features, n_candidates):
+        """preselect_units_acoustic (synth_halfphone.py:1359-1366): (candidates, distances)."""
+        Q = _f64(unit_features)
+        T, D = Q.shape
+        K = int(n_candidates)
+        cand = np.empty((T, K), dtype=np.int64)
+        dist = np.empty((T, K), dtype=np.float64)
+        self._check(self._lib.snk_knn(self._h, _ptr(Q, _c_f64p), T, D, K, _ptr(cand, _c_i64p), _ptr(dist, _c_f64p)))
+        return cand, dist
+
+    def knn_by_class(self, unit_features, n_candidates, query_class):
+        """preselect_units_monophone_then_acoustic (synth_halfphone.py:1369-1396)."""
+        Q = _f64(unit_features)
+        T, D = Q.shape
+        K = int(n_candidates)
+        qc = np.ascontiguousarray(query_class, dtype=np.int32)
+        assert qc.size == T
+        cand = np.empty((T, K), dtype=np.int64)
+        dist = np.empty((T, K), dtype=np.float64)
+        self._check(self._lib.snk_knn_by_class(self._h, _ptr(Q, _c_f64p), T, D, K, _ptr(qc, _c_i32p),
+                                               _ptr(cand, _c_i64p), _ptr(dist, _c_f64p)))
+        return cand, dist
+
+    def join_costs(self, candidates):
+        cand = np.ascontiguousarray(candidates, dtype=np.int64)
+        T, K = cand.shape
+        J = np.empty((T - 1, K, K), dtype=np.float64)
+        self._check(self._lib.snk_join_costs(self._h, _ptr(cand, _c_i64p), T, K, _ptr(J, _c_f64p)))
+        return J
+
+    def viterbi(self, candidates, distances):
+        """viterbi_search (synth_halfphone.py:1399-1436): (path list[int], cost)."""
+        cand = np.ascontiguousarray(candidates, dtype=np.int64)
+        tdist = _f64(distances)
+        T, K = cand.shape
+        assert tdist.shape == (T, K)
+        path = np.empty((T,), dtype=np.int64)
+        plen = ctypes.c_int64(0)
+        cost = ctypes.c_double(0.0)
+        self._check(self._lib.snk_viterbi(self._h, _ptr(cand, _c_i64p), _ptr(tdist, _c_f64p), T, K,
+                                          _ptr(path, _c_i64p), ctypes.byref(plen), ctypes.byref(cost)))
+        return [int(v) for v in path[:plen.value]], float(cost.value)
+
+    def knn_viterbi(self, unit_features, n_candidates, return_candidates=False):
+        Q = _f64(unit_features)
+        T, D = Q.shape
+        K = int(n_candidates)
+        path = np.empty((T,), dtype=np.int64)
+        plen = ctypes.c_int64(0)
+        cost = ctypes.c_double(0.0)
+        cand = dist = None
+        cp = dp = None
+        if return_candidates:
+            cand = np.empty((T, K), dtype=np.int64)
+            dist = np.empty((T, K), dtype=np.float64)
+            cp, dp = _ptr(cand, _c_i64p), _ptr(dist, _c_f64p)
+        self._check(self._lib.snk_knn_viterbi(self._h, _ptr(Q, _c_f64p), T, D, K, cp, dp,
+                                              _ptr(path, _c_i64p), ctypes.byref(plen), ctypes.byref(cost)))
+        out = ([int(v) for v in path[:plen.value]], float(cost.value))
+        if return_candidates:
+            return out + (cand, dist)
+        return out
+
+    def knn_viterbi_batch(self, utterances, n_candidates):
+        """Several utterances in one call (stages of consecutive utterances overlap).
+        Returns (list of paths (np.int64 arrays), costs array)."""
+        mats = [_f64(u) for u in utterances]
+        D = mats[0].shape[1]
+        offs = np.zeros(len(mats) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([m.shape[0] for m in mats])
+        Q = np.ascontiguousarray(np.vstack(mats))
+        paths = np.empty((int(offs[-1]),), dtype=np.int64)
+        plen = np.zeros(len(mats), dtype=np.int64)
+        cost = np.zeros(len(mats), dtype=np.float64)
+        self._check(self._lib.snk_knn_viterbi_batch(self._h, _ptr(Q, _c_f64p), _ptr(offs, _c_i64p), len(mats), D,
+                                                    int(n_candidates), _ptr(paths, _c_i64p),
+                                                    _ptr(plen, _c_i64p), _ptr(cost, _c_f64p)))
+        out = [paths[offs[u]:offs[u] + plen[u]].copy() for u in range(len(mats))]
+        return out, cost
+
+    def set_greedy_layout(self, multiepoch=1, last_frame_as_target=False, join_split_mode=0):
+        """get_tree_for_greedy_search (synth_simple.py:190-229) without building anything."""
+        self._check(self._lib.snk_set_greedy_layout(self._h, int(multiepoch), int(bool(last_frame_as_target)),
+                                                    int(join_split_mode)))
+
+    def greedy(self, unit_features, start_state=-1, search_epsilon=0.0, return_distances=False):
+        """greedy_joint_search (synth_simple.py:458-503): list of window indices."""
+        Q = _f64(unit_features)
+        T, D = Q.shape
+        path = np.empty((max(T, 1),), dtype=np.int64)
+        dist = np.empty((max(T, 1),), dtype=np.float64)
+        n = ctypes.c_int64(0)
+        self._check(self._lib.snk_greedy(self._h, _ptr(Q, _c_f64p), T, D, int(start_state), float(search_epsilon),
+                                         _ptr(path, _c_i64p), _ptr(dist, _c_f64p), ctypes.byref(n)))
+        p = [int(v) for v in path[:n.value]]
+        if return_distances:
+            return p, dist[:n.value].copy()
+        return p
+
+    def path_scores(self, unit_features, path, mode, n_target_cols, n_join_cols):
+        Q = _f64(unit_features)
+        p = np.ascontiguousarray(path, dtype=np.int64)
+        L = p.size
+        tsq = np.empty((L, n_target_cols), dtype=np.float64)
+        jsq = np.empty((max(L - 1, 0), n_join_cols), dtype=np.float64)
+        self._check(self._lib.snk_path_scores(self._h, _ptr(Q, _c_f64p), _ptr(p, _c_i64p), L, int(mode),
+                                              _ptr(tsq, _c_f64p), _ptr(jsq, _c_f64p)))
+        return tsq, jsq
+
+    # -- multi-GPU (device pointers) ------------------------------------------
+    def knn_local_dev(self, unit_features, n_candidates, d2_dev_ptr, id_dev_ptr):
+        Q = _f64(unit_features)
+        T, D = Q.shape
+        self._check(self._lib.snk_knn_local_dev(self._h, _ptr(Q, _c_f64p), T, D, int(n_candidates),
+                                                ctypes.c_void_p(d2_dev_ptr), ctypes.c_void_p(id_dev_ptr)))
+
+    def merge_topk_dev(self, d2_dev_ptr, id_dev_ptr, n_lists, T, n_candidates):
+        K = int(n_candidates)
+        cand = np.empty((T, K), dtype=np.int64)
+        dist = np.empty((T, K), dtype=np.float64)
+        self._check(self._lib.snk_merge_topk_dev(self._h, ctypes.c_void_p(d2_dev_ptr), ctypes.c_void_p(id_dev_ptr),
+                                                 int(n_lists), int(T), K, _ptr(cand, _c_i64p), _ptr(dist, _c_f64p)))
+        return cand, dist
+
+    # -- introspection ----------------------------------------------------------
+    def timers(self):
+        """{stage: (total_ms, launches)} measured with HIP events on the engine's stream."""
+        n = self._lib.snk_timer_count()
+        buf = np.zeros(2 * n, dtype=np.float64)
+        self._lib.snk_get_timers(self._h, _ptr(buf, _c_f64p), 2 * n)
+        return dict((self._lib.snk_timer_name(i).decode(), (float(buf[i]), int(buf[n + i]))) for i in range(n))
+
+    def reset_timers(self):
+        self._check(self._lib.snk_reset_timers(self._h))
+
+    def set_option(self, name, value):
+        self._check(self._lib.snk_set_option(self._h, name.encode(), float(value)))
+
+    def info(self, name):
+        v = ctypes.c_double(0.0)
+        self._check(self._lib.snk_get_info(self._h, name.encode(), ctypes.byref(v)))
+        return float(v.value)
+
+    def selftest_mfma(self):
+        v = ctypes.c_double(0.0)
+        self._check(self._lib.snk_selftest_mfma(self._h, ctypes.byref(v)))
+        return float(v.value)

@@ -1,0 +1,268 @@
+"""GPU parity tests (run on the MI355X box): the HIP path, called through the C ABI
+(ctypes -> libsnkhip.so), against the CPU oracle on the same inputs and against the committed
+reference-generated golden vectors.  Bar: bit-exact indices AND bit-exact float64 distances /
+costs versus the oracle (same canonical summation order); rtol 1e-12 versus the reference's own
+numpy/scipy values (different summation order)."""
+import numpy as np
+import pytest
+
+import snk_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+DIMS = {'mag': 60, 'real': 45, 'imag': 45, 'lf0': 1}
+
+
+@pytest.fixture(scope='module')
+def engine():
+    import snickery_amd
+    e = snickery_amd.HipSearchEngine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope='module')
+def mini_engine(engine, mini_voice):
+    engine.upload_db(mini_voice['F_unw'], mini_voice['JC_unw'])
+    engine.set_weights(mini_voice['wt'], mini_voice['wj'])
+    return engine
+
+
+def synth_setup(N, Dt, Dj, seed=0):
+    F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed)
+    rng = np.random.RandomState(seed + 100)
+    wt = 0.2 + rng.rand(Dt)
+    wj = 0.05 + 0.2 * rng.rand(Dj)
+    F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
+    return F_unw, JC_unw, wt, wj, F, E, S
+
+
+def test_library_loaded_is_in_tree():
+    import snickery_amd
+    assert snickery_amd.library_path().endswith('snickery_amd/libsnkhip.so')
+    assert snickery_amd.load_library().snk_abi_version() == 1
+
+
+def test_mfma_f64_fragment_mapping(engine):
+    assert engine.selftest_mfma() == 0.0
+
+
+def test_knn_golden(mini_engine, golden, mini_voice):
+    K = int(golden['knn_K'])
+    cand, dist = mini_engine.knn(golden['knn_queries'], K)
+    assert cand.dtype == np.int64 and dist.dtype == np.float64
+    assert np.array_equal(cand, golden['knn_candidates'])                   # reference's own output
+    np.testing.assert_allclose(dist, golden['knn_distances'], rtol=1e-12)   # reference summation order
+    oc, od = o.knn_bruteforce(mini_voice['F'], golden['knn_queries'], K)
+    assert np.array_equal(cand, oc)
+    assert np.array_equal(dist, od)                                          # bit-exact vs oracle
+
+
+@pytest.mark.parametrize('N,T,K,Dt', [(20000, 100, 50, 61), (5000, 37, 100, 61), (3000, 16, 7, 20),
+                                      (9000, 50, 30, 184), (1500, 33, 200, 100), (700, 20, 16, 130)])
+def test_knn_synthetic(engine, N, T, K, Dt):
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(N, Dt, 24, seed=N % 97)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    U = o.synthetic_targets(F_unw, T, seed=3) * wt
+    cand, dist = engine.knn(U, K)
+    oc, od = o.knn_bruteforce(F, U, K)
+    assert np.array_equal(cand, oc)
+    assert np.array_equal(dist, od)
+
+
+def test_knn_ties_and_padding(engine):
+    """Exact duplicates (digital silence in real voices): order among equal distances is
+    (distance, lower id); K > N pads with -1 / 1e15."""
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(400, 61, 24, seed=5)
+    F_unw[100:140] = F_unw[50]                 # 41 identical rows
+    F_unw[300] = F_unw[50]
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    F = o.weight(F_unw, wt)
+    U = (F_unw[[50, 10, 399]] + 0.001) * wt
+    cand, dist = engine.knn(U, 60)
+    oc, od = o.knn_bruteforce(F, U, 60)
+    assert np.array_equal(cand, oc) and np.array_equal(dist, od)
+    assert list(cand[0, :42]) == [50] + list(range(100, 140)) + [300]
+    small_F, small_JC = F_unw[:20], JC_unw[:21]
+    engine.upload_db(small_F, small_JC)
+    engine.set_weights(wt, wj)
+    cand, dist = engine.knn(U, 32)
+    oc, od = o.knn_bruteforce(o.weight(small_F, wt), U, 32)
+    assert np.array_equal(cand, oc) and np.array_equal(dist, od)
+    assert np.all(cand[:, 20:] == -1) and np.all(dist[:, 20:] == o.VERY_BIG_WEIGHT_VALUE)
+
+
+def test_knn_list_overflow_retry(engine):
+    """A tiny candidate-list capacity forces the overflow -> re-tighten -> retry path."""
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(30000, 61, 24, seed=11)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    U = o.synthetic_targets(F_unw, 48, seed=8) * wt
+    engine.set_option('list_capacity', 64)
+    engine.set_option('sample_fraction', 1.0 / 64)
+    try:
+        cand, dist = engine.knn(U, 20)
+        retries = engine.info('last_knn_retries')
+    finally:
+        engine.set_option('list_capacity', 4096)
+        engine.set_option('sample_fraction', 1.0 / 16)
+    oc, od = o.knn_bruteforce(F, U, 20)
+    assert np.array_equal(cand, oc) and np.array_equal(dist, od)
+    assert retries >= 1
+
+
+def test_knn_by_class(engine):
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(6000, 61, 24, seed=2)
+    rng = np.random.RandomState(4)
+    cls = rng.randint(0, 12, size=6000).astype(np.int32)
+    cls[:5] = 77                                # a class with 5 members only
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    engine.set_unit_classes(cls)
+    U = o.synthetic_targets(F_unw, 40, seed=9) * wt
+    qc = rng.randint(0, 12, size=40).astype(np.int32)
+    qc[7] = 77
+    cand, dist = engine.knn_by_class(U, 10, qc)
+    oc, od = o.knn_by_class(F, U, 10, cls, qc)
+    assert np.array_equal(cand, oc) and np.array_equal(dist, od)
+    assert list(cand[7, 5:]) == [-1] * 5
+
+
+def test_join_costs_golden(mini_engine, golden, mini_voice):
+    cand = golden['join_candidates']
+    J = mini_engine.join_costs(cand)
+    Jo = o.join_cost_dense(mini_voice['E'], mini_voice['S'], cand)
+    assert np.array_equal(J, Jo)                                  # bit-exact incl. +inf pattern
+    cache = dict(zip(map(tuple, golden['join_cache_keys'].tolist()), golden['join_cache_values']))
+    ok = o.valid_mask(cand, mini_voice['F'].shape[0])
+    n_nat = 0
+    for t in range(cand.shape[0] - 1):
+        for a in range(cand.shape[1]):
+            for b in range(cand.shape[1]):
+                if ok[t, a] and ok[t + 1, b]:
+                    ref = cache[(int(cand[t, a]), int(cand[t + 1, b]))]
+                    assert abs(J[t, a, b] - ref) <= 1e-12 * ref
+                    if cand[t + 1, b] == cand[t, a] + 1:
+                        assert J[t, a, b] == 0.0          # natural join: exactly zero
+                        n_nat += 1
+    assert n_nat > 0
+
+
+@pytest.mark.parametrize('N,T,K,Dj', [(4000, 60, 50, 151), (2500, 30, 100, 302), (2000, 25, 13, 40),
+                                      (3000, 20, 200, 151)])
+def test_viterbi_synthetic(engine, N, T, K, Dj):
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(N, 61, Dj, seed=K)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    U = o.synthetic_targets(F_unw, T, seed=5) * wt
+    cand, dist = o.knn_bruteforce(F, U, K)
+    cand[2, 1] = -1
+    cand[3, 0] = 0
+    cand[4, 2] = N - 1
+    J = engine.join_costs(cand)
+    assert np.array_equal(J, o.join_cost_dense(E, S, cand))
+    path, cost = engine.viterbi(cand, dist)
+    opath, ocost = o.viterbi(cand, dist, E, S)
+    assert path == opath
+    assert cost == ocost
+    p2, c2, cand2, dist2 = engine.knn_viterbi(U, K, return_candidates=True)
+    oc, od = o.knn_bruteforce(F, U, K)
+    assert np.array_equal(cand2, oc) and np.array_equal(dist2, od)
+    op2, oc2 = o.viterbi(oc, od, E, S)
+    assert p2 == op2 and c2 == oc2
+
+
+def test_viterbi_golden_and_edges(mini_engine, golden, mini_voice):
+    cand, dist = golden['join_candidates'], golden['knn_distances']
+    path, cost = mini_engine.viterbi(cand, dist)
+    opath, ocost = o.viterbi(cand, dist, mini_voice['E'], mini_voice['S'])
+    assert path == opath and cost == ocost
+    assert mini_engine.viterbi(cand[:1], dist[:1]) == ([], float('inf'))      # T < 2
+    dead = cand.copy()
+    dead[5, :] = -1                                                            # no usable unit
+    assert mini_engine.viterbi(dead, dist) == ([], float('inf'))
+    assert o.viterbi(dead, dist, mini_voice['E'], mini_voice['S']) == ([], np.inf)
+
+
+def test_viterbi_batch_equals_single(engine):
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(8000, 61, 151, seed=21)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    utts = [o.synthetic_targets(F_unw, T, seed=s) * wt for s, T in [(1, 40), (2, 75), (3, 16), (4, 51), (5, 33)]]
+    paths, costs = engine.knn_viterbi_batch(utts, 40)
+    for u, U in enumerate(utts):
+        p, c = engine.knn_viterbi(U, 40)
+        assert list(paths[u]) == p and costs[u] == c
+        oc, od = o.knn_bruteforce(F, U, 40)
+        op, ocst = o.viterbi(oc, od, E, S)
+        assert p == op and c == ocst
+
+
+def test_greedy_golden(mini_engine, golden, mini_voice):
+    for me in (6, 1):
+        mini_engine.set_greedy_layout(me, False, 0)
+        for utt in (0, 1):
+            U = golden['greedy_me%d_utt%d_unit_features' % (me, utt)]
+            path, d = mini_engine.greedy(U, return_distances=True)
+            assert np.array_equal(np.array(path), golden['greedy_me%d_utt%d_path' % (me, utt)])
+            pr, cr, Fwin = o.greedy_layout(mini_voice['F'], mini_voice['E'], mini_voice['S'], me)
+            op, od = o.greedy_search(pr, cr, Fwin, o.greedy_queries(U, me))
+            assert path == op and np.array_equal(d, od)
+    # natural path known answer (synth_simple.py:909-928)
+    mini_engine.set_greedy_layout(1, False, 0)
+    start = int(golden['greedy_me1_natural_start'])
+    ref = golden['greedy_me1_natural_path']
+    path, d = mini_engine.greedy(mini_voice['F'][start:start + len(ref)], start_state=start, return_distances=True)
+    assert np.array_equal(np.array(path), ref) and np.all(d == 0.0)
+
+
+@pytest.mark.parametrize('me,lfat,mode,Dj', [(6, False, 0, 151), (3, True, 0, 40), (4, False, 1, 80), (1, False, 1, 302)])
+def test_greedy_synthetic(engine, me, lfat, mode, Dj):
+    N = 5000
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(N, 61, Dj, seed=me)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    engine.set_greedy_layout(me, lfat, mode)
+    U = o.synthetic_targets(F_unw, 63, seed=6) * wt
+    pr, cr, Fwin = o.greedy_layout(F, E, S, me, lfat, mode)
+    Q = o.greedy_queries(U, me, lfat)
+    for start in (-1, 17):
+        path, d = engine.greedy(U, start_state=start, return_distances=True)
+        op, od = o.greedy_search(pr, cr, Fwin, Q, start_state=start)
+        assert path == op
+        assert np.array_equal(d, od)
+
+
+def test_path_scores(engine):
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(3000, 61, 151, seed=31)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    U = o.synthetic_targets(F_unw, 30, seed=2) * wt
+    path, cost = engine.knn_viterbi(U, 20)
+    tsq, jsq = engine.path_scores(U, path, 0, 61, 151)
+    assert np.array_equal(tsq, o.target_scores(F, U, path))
+    assert np.array_equal(jsq, o.join_scores_viterbi(E, S, path))
+    engine.set_greedy_layout(3, False, 0)
+    gp = engine.greedy(U)
+    pr, cr, Fwin = o.greedy_layout(F, E, S, 3)
+    Q = o.greedy_queries(U, 3)
+    tsq, jsq = engine.path_scores(U, gp, 1, 61 * 3, 151)
+    assert np.array_equal(tsq, o.target_scores(Fwin, Q, gp))
+    assert np.array_equal(jsq, o.join_scores_greedy(pr, cr, gp))
+
+
+def test_error_behaviour(engine):
+    import snickery_amd
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(500, 61, 24, seed=1)
+    engine.upload_db(F_unw, JC_unw)
+    with pytest.raises(snickery_amd.SnkError):
+        engine.knn(np.zeros((4, 61)), 5)              # weights not set
+    with pytest.raises(snickery_amd.SnkError):
+        engine.set_weights(wt[:10], wj)               # wrong length
+    engine.set_weights(wt, wj)
+    with pytest.raises(snickery_amd.SnkError):
+        engine.knn(np.zeros((4, 60)), 5)              # wrong dimension
+    with pytest.raises(snickery_amd.SnkError):
+        engine.greedy(np.zeros((4, 61)))              # layout not set
