@@ -33,6 +33,7 @@ struct GreedyArgs {
     int me, nep; int ep[GR_MAX_EP];       // epochs of the window that enter the target term
     int prev_col0, cur_col0, jdim;
     int64_t prev_row0, cur_row0, Nwin;
+    int R;                                // windows per workgroup (<= GR_R, fits LDS)
     const double *Q;                      // (T, Dt) weighted targets, row-major
     const double *prev_vec;               // (jdim)
 };
@@ -43,13 +44,13 @@ greedy_scan_kernel(GreedyArgs a, int64_t step, double *__restrict__ blk_min,
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int64_t i0 = (int64_t)blockIdx.x * GR_R;
-    const int rows = (int)((a.Nwin - i0 < GR_R) ? (a.Nwin - i0) : GR_R);
+    const int64_t i0 = (int64_t)blockIdx.x * a.R;
+    const int rows = (int)((a.Nwin - i0 < a.R) ? (a.Nwin - i0) : a.R);
     const int frows = rows + a.me - 1;
 
     float *jt = reinterpret_cast<float *>(smem);                    // [GR_R][Dj]
-    float *ft = jt + ((GR_R * a.Dj + 3) & ~3);                      // [GR_R+me-1][Dt]
-    double *wjs = reinterpret_cast<double *>(ft + (((GR_R + a.me - 1) * a.Dt + 3) & ~3));
+    float *ft = jt + ((a.R * a.Dj + 3) & ~3);                       // [R+me-1][Dt]
+    double *wjs = reinterpret_cast<double *>(ft + (((a.R + a.me - 1) * a.Dt + 3) & ~3));
     double *wts = wjs + a.Dj;
     double *prevs = wts + a.Dt;
     double *qs = prevs + a.jdim;                                     // [nep][Dt]
@@ -154,6 +155,25 @@ __global__ void greedy_init_prev_kernel(GreedyArgs a, int64_t start_state, doubl
     prev_vec[c] = __dmul_rn((double)src[c], a.wj[a.prev_col0 + c]);
 }
 
+static int greedy_rows(const GreedyLayout &g, int Dt, int Dj)
+{
+    const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
+    const size_t fixed = (size_t)(Dj + Dt + g.jdim + nep * Dt) * sizeof(double) + (size_t)(g.me + 2) * Dt * 4 + 64;
+    const size_t budget = 144 * 1024;
+    if (fixed >= budget) return 0;
+    size_t r = (budget - fixed) / ((size_t)(Dj + Dt) * sizeof(float));
+    if (r > GR_R) r = GR_R;
+    if (r >= 64) r = (r / 32) * 32;
+    return (int)r;
+}
+
+static size_t greedy_shmem_for(const GreedyLayout &g, int Dt, int Dj, int R)
+{
+    const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
+    return (size_t)(((R * Dj + 3) & ~3) + (((R + g.me - 1) * Dt + 3) & ~3)) * sizeof(float)
+           + (size_t)(Dj + Dt + g.jdim + nep * Dt) * sizeof(double);
+}
+
 void launch_greedy(const GreedyLayout &g, const float *F_unw, int Dt, const double *wt,
                    const float *JC_unw, int Dj, const double *wj, const double *Q,
                    int64_t nsteps, int64_t start_state, double *prev_vec, double *blk_min,
@@ -168,8 +188,8 @@ void launch_greedy(const GreedyLayout &g, const float *F_unw, int Dt, const doub
     a.prev_col0 = g.prev_col0; a.cur_col0 = g.cur_col0; a.jdim = g.jdim;
     a.prev_row0 = g.prev_row0; a.cur_row0 = g.cur_row0; a.Nwin = g.Nwin;
     a.Q = Q; a.prev_vec = prev_vec;
-    const size_t shmem = (size_t)(((GR_R * Dj + 3) & ~3) + (((GR_R + g.me - 1) * Dt + 3) & ~3)) * sizeof(float)
-                         + (size_t)(Dj + Dt + g.jdim + a.nep * Dt) * sizeof(double);
+    a.R = greedy_rows(g, Dt, Dj);
+    const size_t shmem = greedy_shmem_for(g, Dt, Dj, a.R);
     static size_t attr = 0;
     if (shmem > attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&greedy_scan_kernel),
@@ -187,12 +207,16 @@ void launch_greedy(const GreedyLayout &g, const float *F_unw, int Dt, const doub
 
 size_t greedy_shmem_bytes(const GreedyLayout &g, int Dt, int Dj)
 {
-    const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
-    return (size_t)(((GR_R * Dj + 3) & ~3) + (((GR_R + g.me - 1) * Dt + 3) & ~3)) * sizeof(float)
-           + (size_t)(Dj + Dt + g.jdim + nep * Dt) * sizeof(double);
+    const int R = greedy_rows(g, Dt, Dj);
+    if (R < 8) return (size_t)1 << 30;      // does not fit
+    return greedy_shmem_for(g, Dt, Dj, R);
 }
 
-int greedy_blocks(const GreedyLayout &g) { return (int)((g.Nwin + GR_R - 1) / GR_R); }
+int greedy_blocks(const GreedyLayout &g, int Dt, int Dj)
+{
+    const int R = greedy_rows(g, Dt, Dj);
+    return (int)((g.Nwin + R - 1) / R);
+}
 
 // ---------------------------------------------------------------------------
 // per-column squared errors along a path (get_target_scores_per_stream /

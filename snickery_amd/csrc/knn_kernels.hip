@@ -8,7 +8,10 @@
 //   prepare_queries : pad Q to [Tpad][Dpad], row norms
 //   sweep<MODE 0>   : stage A, strided sample of DB slabs -> per (row, lane-group) minima
 //   threshold       : K-th smallest group minimum  = valid upper bound of the K-th NN key
-//   sweep<MODE 1>   : stage B, whole DB; keys <= threshold are appended to per-row lists
+//   sweep<MODE 1>   : stage B, whole DB; (row, unit, key) entries with key <= threshold are
+//                     appended to wave-private chunks of a global entry pool (no atomics and
+//                     no waits in the MFMA loop: plain stores at a wave-uniform cursor)
+//   bucket          : entry pool -> per-row candidate lists
 //   finalize        : per row: sort list, take top K (+ near ties), recompute those
 //                     distances exactly in the canonical (oracle) order, final sort
 //
@@ -28,7 +31,8 @@ namespace snk {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-#define QCAP 512   // LDS append-queue entries per wave per region
+#define POOL_CHUNK 2048         // entries per wave-private chunk of the entry pool
+struct __attribute__((aligned(16))) PoolEntry { double key; int idx; int row; };
 
 // ---------------------------------------------------------------------------
 // f64 MFMA C/D fragment mapping (gfx950): lane l holds D[row = (l>>4) + 4*r][col = l&15]
@@ -37,28 +41,64 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int frag_row(int lane, int r) { return (lane >> 4) + 4 * r; }
 
-template <int NT, int DCH, int MODE, bool CLS>
-__global__ void __launch_bounds__(256, 1)
+template <int NT, int DCH, int MODE, bool CLS, int WPS>
+__global__ void __launch_bounds__(256, WPS)
 knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
           const double *__restrict__ Qp, const double *__restrict__ thr,
-          int nQT, int64_t slab_start, int64_t slab_stride, int64_t n_slabs,
+          int nQT, int64_t row_stride, int64_t row_limit, int64_t n_slabs,
+          int64_t wave_stride, int64_t tile_stride, unsigned int *__restrict__ slab_counter,
           double *__restrict__ gmin, int64_t G,
-          int *__restrict__ cnt, double *__restrict__ lkey, int *__restrict__ lidx, int cap,
+          PoolEntry *__restrict__ pool, unsigned int *__restrict__ pool_ctl,
+          int *__restrict__ chunk_fill, int max_chunks,
           const int32_t *__restrict__ unit_class, const int32_t *__restrict__ query_class)
 {
     constexpr int KS = DCH * 16;          // MFMA k-steps per output tile
     constexpr int DP = DCH * 64;          // padded feature columns
-    __shared__ double q_key[4][2][QCAP];
-    __shared__ int q_idx[4][2][QCAP];
-    __shared__ int q_row[4][2][QCAP];
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int64_t w = (int64_t)blockIdx.x * 4 + wv;
-    if (w >= n_slabs) return;              // whole wave exits; no barriers are used
-    const int64_t slab = slab_start + w * slab_stride;
-    const int64_t base = slab * (16 * NT);
     const int r16 = lane & 15, g = lane >> 4;
+
+    // Persistent waves: the grid covers (CUs - reserved) compute units once; every wave pulls
+    // slab indices from a device-wide counter until the database is exhausted (dynamic tail
+    // balancing; the reserved CUs stay free for the Viterbi recursion of the previous utterance).
+    auto grab_slab = [&]() -> int64_t {
+        unsigned int v = 0;
+        if (lane == 0) v = atomicAdd(slab_counter, 1u);
+        return (int64_t)__builtin_amdgcn_readfirstlane(v);
+    };
+
+    // entry-pool cursor (MODE 1): this wave appends to a private chunk of the global pool at a
+    // wave-uniform position; a new chunk costs one returning atomic per POOL_CHUNK entries.
+    // pool_ctl[0] = chunks handed out, pool_ctl[1] = overflow flag.
+    int chunk_id = -1;
+    int cused = POOL_CHUNK;      // forces a chunk grab before the first append
+    auto new_chunk = [&]() {
+        if (chunk_id >= 0 && lane == 0) chunk_fill[chunk_id] = cused;
+        unsigned int c = 0;
+        if (lane == 0) c = atomicAdd(&pool_ctl[0], 1u);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if ((int)c >= max_chunks) {          // pool exhausted: drop, the host retries
+            if (lane == 0) pool_ctl[1] = 1u;
+            chunk_id = -1;
+        } else {
+            chunk_id = (int)c;
+        }
+        cused = 0;
+    };
+
+    int64_t w = grab_slab();
+    while (w < n_slabs) {
+    const int64_t w_next = grab_slab();
+    // Row mapping: tile nt, lane-row r16 of slab w holds database row
+    //     (w*wave_stride + nt*tile_stride + r16) * row_stride
+    // stage B (filter): wave_stride = 16*NT, tile_stride = 16, row_stride = 1 -> a contiguous slab.
+    // stage A (minima): row_stride = sampling stride (uniform at single-unit granularity, which
+    //   matters for speech databases where the neighbours of a target are runs of consecutive
+    //   units), wave_stride = 16 and tile_stride = 16*slabs, so that the NT rows that share one
+    //   minimum (same slab, same lane) lie far apart and a run of consecutive units lands in
+    //   distinct groups.
+    const int64_t base = w * wave_stride;
 
     // ---- B fragments: this wave's DB rows, resident for the whole kernel ----
     double b[NT][KS];
@@ -66,7 +106,8 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
     int ucls[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int64_t row = base + nt * 16 + r16;
+        int64_t row = (base + nt * tile_stride + r16) * row_stride;
+        if (row >= row_limit) row = row_limit;          // a padding row (norm = +inf)
         const double *src = Fw + row * DP + 16 * g;
 #pragma unroll
         for (int ch = 0; ch < DCH; ++ch)
@@ -106,42 +147,8 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
     };
     load_tile(qt, a_nxt, th_nxt, qc_nxt);
 
-    // append queue state (MODE 1).  Entries found while tile i is computed are given their
-    // list slots (one returning atomic each) at the top of tile i+1 and stored at the top of
-    // tile i+2: the atomics' round trip hides behind a whole tile of MFMA work, and the only
-    // vmcnt wait of the loop (the query double-buffer rotate) finds everything a tile old.
-    int region = 0;
-    int qcount = 0;          // wave-uniform: entries in the region being filled
-    int pend_n = 0;          // entries of the other region whose slot atomics are in flight
-    int pend_slot = 0;
-
-    auto flush_blocking = [&](int reg, int from, int to) {
-        for (int e = from + lane; e < to; e += 64) {
-            const int row = q_row[wv][reg][e];
-            const int slot = atomicAdd(&cnt[row], 1);
-            if (slot < cap) {
-                lkey[(int64_t)row * cap + slot] = q_key[wv][reg][e];
-                lidx[(int64_t)row * cap + slot] = q_idx[wv][reg][e];
-            }
-        }
-    };
-    auto complete_pending = [&]() {
-        if (pend_n) {
-            if (lane < pend_n) {
-                const int preg = region ^ 1;
-                const int row = q_row[wv][preg][lane];
-                if (pend_slot < cap) {
-                    lkey[(int64_t)row * cap + pend_slot] = q_key[wv][preg][lane];
-                    lidx[(int64_t)row * cap + pend_slot] = q_idx[wv][preg][lane];
-                }
-            }
-            pend_n = 0;
-        }
-    };
-
-    // all prologue loads (B fragments, first query tile) land before the loop, so that inside
-    // the loop the compiler's waitcnt scoreboard never has to cover a prologue load with a
-    // conservative vmcnt(0) that would also wait for the freshly issued slot atomics
+    // all prologue loads (B fragments, first query tile) land before the tile loop, so that
+    // inside it the only vmcnt wait is the query double-buffer rotate
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -162,18 +169,6 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
         for (int s = 0; s < KS; ++s) a_cur[s] = a_nxt[s];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { th_cur[r] = th_nxt[r]; qc_cur[r] = qc_nxt[r]; }
-
-        if (MODE == 1) {
-            complete_pending();
-            if (qcount) {
-                const int first = qcount < 64 ? qcount : 64;
-                if (lane < first) pend_slot = atomicAdd(&cnt[q_row[wv][region][lane]], 1);
-                if (qcount > 64) flush_blocking(region, 64, qcount);
-                pend_n = first;
-                region ^= 1;
-                qcount = 0;
-            }
-        }
 
         // prefetch the next tile (unconditional: the last one wraps and is simply unused)
         const int qt_next = (qt + 1 == nQT) ? 0 : qt + 1;
@@ -196,6 +191,8 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
                 if (nt + 1 < NT)
                     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[s], b[nt + 1][s], acc1, 0, 0, 0);
             }
+            // room for the worst case of this pair of tiles (2 x 4 x 64 entries)
+            if (MODE == 1 && cused + 512 > POOL_CHUNK) new_chunk();
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (nt + j >= NT) break;
@@ -212,22 +209,18 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
                         const bool pass = ok && (key <= th_cur[r]);
                         const unsigned long long m = __ballot(pass);
                         if (m) {
-                            if (pass) {
-                                const int slot = qcount + __builtin_amdgcn_mbcnt_hi(
+                            const int n = __popcll(m);
+                            if (pass && chunk_id >= 0) {
+                                const int rank = __builtin_amdgcn_mbcnt_hi(
                                     (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                q_key[wv][region][slot] = key;
-                                q_idx[wv][region][slot] = (int)(base + (nt + j) * 16 + r16);
-                                q_row[wv][region][slot] = qt * 16 + frag_row(lane, r);
+                                PoolEntry e;
+                                e.key = key;
+                                e.idx = (int)(base + (nt + j) * tile_stride + r16);
+                                e.row = qt * 16 + frag_row(lane, r);
+                                pool[(int64_t)chunk_id * POOL_CHUNK + cused + rank] = e;
                             }
-                            qcount += __popcll(m);
+                            cused += n;
                         }
-                    }
-                }
-                if (MODE == 1) {
-                    // rare: a dense neighbourhood -- keep room for one more tile (<=256 entries)
-                    if (qcount > QCAP - 256) {
-                        flush_blocking(region, 0, qcount);
-                        qcount = 0;
                     }
                 }
             }
@@ -242,49 +235,59 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
         }
         qt = qt_next;
     }
+    w = w_next;
+    }   // slab loop
 
     if (MODE == 1) {
-        complete_pending();
-        if (qcount) flush_blocking(region, 0, qcount);
+        if (chunk_id >= 0 && lane == 0) chunk_fill[chunk_id] = cused;
     }
 }
 
-template <int NT, int DCH>
+template <int NT, int DCH, int WPS>
 static void launch_sweep_t(int mode, bool cls, int blocks, hipStream_t s,
                            const double *Fw, const double *fnorm, const double *Qp,
-                           const double *thr, int nQT, int64_t s0, int64_t sstride, int64_t ns,
-                           double *gmin, int64_t G, int *cnt, double *lkey, int *lidx, int cap,
+                           const double *thr, int nQT, int64_t rstride, int64_t rlimit, int64_t ns,
+                           int64_t wstride, int64_t tstride, unsigned int *ctr,
+                           double *gmin, int64_t G, PoolEntry *pool, unsigned int *pool_ctl,
+                           int *chunk_fill, int max_chunks,
                            const int32_t *uc, const int32_t *qc)
 {
-#define SNK_LAUNCH(MODE, CLS)                                                               \
-    hipLaunchKernelGGL((knn_sweep<NT, DCH, MODE, CLS>), dim3(blocks), dim3(256), 0, s, Fw,  \
-                       fnorm, Qp, thr, nQT, s0, sstride, ns, gmin, G, cnt, lkey, lidx, cap, \
-                       uc, qc)
+#define SNK_LAUNCH(MODE, CLS)                                                                    \
+    hipLaunchKernelGGL((knn_sweep<NT, DCH, MODE, CLS, WPS>), dim3(blocks), dim3(256), 0, s, Fw,  \
+                       fnorm, Qp, thr, nQT, rstride, rlimit, ns, wstride, tstride, ctr, gmin, G, \
+                       pool, pool_ctl, chunk_fill, max_chunks, uc, qc)
     if (mode == 0) { if (cls) SNK_LAUNCH(0, true); else SNK_LAUNCH(0, false); }
     else           { if (cls) SNK_LAUNCH(1, true); else SNK_LAUNCH(1, false); }
 #undef SNK_LAUNCH
 }
 
-static void launch_sweep(const KnnPlan &p, int mode, int64_t s0, int64_t sstride, int64_t ns,
+static void launch_sweep(const KnnPlan &p, int mode, int64_t rstride, int64_t rlimit, int64_t ns,
+                         int64_t wstride, int64_t tstride,
                          const double *Fw, const double *fnorm, const double *Qp,
-                         const double *thr, int64_t Tpad, double *gmin, int64_t G, int *cnt,
-                         double *lkey, int *lidx, int cap, const int32_t *uc, const int32_t *qc,
-                         hipStream_t s)
+                         const double *thr, int64_t Tpad, double *gmin, int64_t G, void *pool,
+                         unsigned int *pool_ctl, int *chunk_fill, int max_chunks,
+                         const int32_t *uc, const int32_t *qc, hipStream_t s)
 {
     if (ns <= 0) return;
-    const int blocks = (int)((ns + 3) / 4);
+    const int wps = (p.nt == 4 && p.dch == 1) ? 2 : 1;       // NT=4 fits two waves per SIMD
+    int64_t blocks = (ns + 3) / 4;
+    const int64_t max_blocks = (int64_t)p.grid_cus * wps;
+    if (blocks > max_blocks) blocks = max_blocks;
     const int nQT = (int)(Tpad / 16);
     const bool cls = (uc != nullptr);
-#define SNK_CASE(NT_, DCH_)                                                                   \
-    if (p.nt == NT_ && p.dch == DCH_) {                                                       \
-        launch_sweep_t<NT_, DCH_>(mode, cls, blocks, s, Fw, fnorm, Qp, thr, nQT, s0, sstride, \
-                                  ns, gmin, G, cnt, lkey, lidx, cap, uc, qc);                 \
-        return;                                                                               \
+    (void)hipMemsetAsync(p.slab_counter, 0, sizeof(unsigned int), s);
+#define SNK_CASE(NT_, DCH_, WPS_)                                                              \
+    if (p.nt == NT_ && p.dch == DCH_) {                                                        \
+        launch_sweep_t<NT_, DCH_, WPS_>(mode, cls, (int)blocks, s, Fw, fnorm, Qp, thr, nQT, rstride, \
+                                        rlimit, ns, wstride, tstride, p.slab_counter, gmin, G,   \
+                                        reinterpret_cast<PoolEntry *>(pool), pool_ctl, chunk_fill, \
+                                        max_chunks, uc, qc);                                   \
+        return;                                                                                \
     }
-    SNK_CASE(8, 1) SNK_CASE(4, 1) SNK_CASE(2, 1)
-    SNK_CASE(4, 2) SNK_CASE(2, 2)
-    SNK_CASE(2, 3)
-    SNK_CASE(1, 4)
+    SNK_CASE(8, 1, 1) SNK_CASE(4, 1, 2) SNK_CASE(2, 1, 1)
+    SNK_CASE(4, 2, 1) SNK_CASE(2, 2, 1)
+    SNK_CASE(2, 3, 1)
+    SNK_CASE(1, 4, 1)
 #undef SNK_CASE
 }
 
@@ -292,16 +295,82 @@ void launch_knn_minima(const KnnPlan &p, const double *Fw, const double *fnorm, 
                        int64_t Tpad, double *gmin, int64_t G, const int32_t *uc,
                        const int32_t *qc, hipStream_t s)
 {
-    launch_sweep(p, 0, p.a_start, p.a_stride, p.a_count, Fw, fnorm, Qp, nullptr, Tpad, gmin, G,
+    launch_sweep(p, 0, p.a_stride, p.row_limit, p.a_count, 16, 16 * p.a_count, Fw, fnorm, Qp, nullptr, Tpad, gmin, G,
                  nullptr, nullptr, nullptr, 0, uc, qc, s);
 }
 
 void launch_knn_filter(const KnnPlan &p, const double *Fw, const double *fnorm, const double *Qp,
-                       const double *thr, int64_t Tpad, int *cnt, double *lkey, int *lidx, int cap,
-                       const int32_t *uc, const int32_t *qc, hipStream_t s)
+                       const double *thr, int64_t Tpad, void *pool, unsigned int *pool_ctl,
+                       int *chunk_fill, int max_chunks, const int32_t *uc, const int32_t *qc,
+                       hipStream_t s)
 {
-    launch_sweep(p, 1, 0, 1, p.n_slabs, Fw, fnorm, Qp, thr, Tpad, nullptr, 0, cnt, lkey, lidx, cap,
-                 uc, qc, s);
+    launch_sweep(p, 1, 1, p.row_limit, p.n_slabs, 16 * p.nt, 16, Fw, fnorm, Qp, thr, Tpad, nullptr, 0,
+                 pool, pool_ctl, chunk_fill, max_chunks, uc, qc, s);
+}
+
+size_t knn_pool_bytes(int max_chunks) { return (size_t)max_chunks * POOL_CHUNK * sizeof(PoolEntry); }
+
+// ---------------------------------------------------------------------------
+// bucket: entry pool -> per-row lists.  One workgroup per chunk (grid-stride); the returning
+// atomics on the per-row counters are latency-hidden by thousands of threads in flight.
+// status bit 0: a row list overflowed `cap` (or the pool overflowed).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__restrict__ pool_ctl,
+                  const int *__restrict__ chunk_fill, int max_chunks, int Tpad, int *__restrict__ cnt,
+                  double *__restrict__ lkey, int *__restrict__ lidx, int cap, int *__restrict__ status)
+{
+    // per chunk: LDS histogram by row -> one global atomic per (chunk, row) reserves a run of
+    // list slots -> entries of one row land contiguously
+    extern __shared__ int bsm[];
+    int *hist = bsm;             // [Tpad] count, then base
+    int used = (int)pool_ctl[0];
+    if (used > max_chunks) used = max_chunks;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && pool_ctl[1]) atomicOr(status, 1);
+    constexpr int EPT = POOL_CHUNK / 256;
+    for (int c = blockIdx.x; c < used; c += gridDim.x) {
+        const int n = chunk_fill[c];
+        if (n == 0) continue;
+        for (int i = threadIdx.x; i < Tpad; i += 256) hist[i] = 0;
+        __syncthreads();
+        PoolEntry en[EPT];
+        int rank[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = threadIdx.x + k * 256;
+            if (e < n) {
+                en[k] = pool[(int64_t)c * POOL_CHUNK + e];
+                rank[k] = atomicAdd(&hist[en[k].row], 1);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < Tpad; i += 256) {
+            const int h = hist[i];
+            if (h > 0) hist[i] = atomicAdd(&cnt[i], h);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = threadIdx.x + k * 256;
+            if (e < n) {
+                const int slot = hist[en[k].row] + rank[k];
+                if (slot < cap) {
+                    lkey[(int64_t)en[k].row * cap + slot] = en[k].key;
+                    lidx[(int64_t)en[k].row * cap + slot] = en[k].idx;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int *chunk_fill,
+                       int max_chunks, int64_t Tpad, int *cnt, double *lkey, int *lidx, int cap,
+                       int *status, hipStream_t s)
+{
+    hipLaunchKernelGGL(knn_bucket_kernel, dim3(1024), dim3(256), (size_t)Tpad * sizeof(int), s,
+                       reinterpret_cast<const PoolEntry *>(pool), pool_ctl, chunk_fill, max_chunks,
+                       (int)Tpad, cnt, lkey, lidx, cap, status);
 }
 
 // ---------------------------------------------------------------------------
@@ -361,43 +430,123 @@ __device__ void bitonic_sort_pairs(double *key, int *idx, int P)
 }
 
 // ---------------------------------------------------------------------------
-// threshold: K-th smallest of the group minima of one row
+// threshold: EXACT K-th smallest of the G group minima of one row, by an 8-bit MSB-first
+// radix select on the order-preserving integer image of the float64 keys (8 passes over the
+// row's minima, which sit in L2; 256-bin histogram in LDS per pass).
+// Each group is one (slab, lane) pair = NT database rows, so at most NT*K database rows have a
+// key <= the returned threshold when every row was visited (the overflow fallback relies on it).
 // ---------------------------------------------------------------------------
-#define THR_BINS 2048
+__device__ __forceinline__ unsigned long long f64_sortable(double v)
+{
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double f64_unsortable(unsigned long long u)
+{
+    u = (u >> 63) ? (u & 0x7fffffffffffffffull) : ~u;
+    return __longlong_as_double((long long)u);
+}
+
+#define THR_FOLD 512
+#define THR_COLL 4096
 __global__ void __launch_bounds__(256)
 knn_threshold_kernel(const double *__restrict__ gmin, int64_t G, int64_t T, int K,
-                     double *__restrict__ thr)
+                     double *__restrict__ thr, int keep_min)
 {
-    __shared__ double key[THR_BINS];
-    __shared__ int idx[THR_BINS];
+    __shared__ double key[THR_COLL];
+    __shared__ int idx[THR_COLL];
+    __shared__ int hist[256];
+    __shared__ unsigned long long prefix_s;
+    __shared__ int remaining_s, n_coll;
+    __shared__ double bound_s;
     const int64_t row = blockIdx.x;
     if (row >= T) {                      // padding rows never pass
         if (threadIdx.x == 0) thr[row] = -DBL_MAX;
         return;
     }
-    for (int i = threadIdx.x; i < THR_BINS; i += blockDim.x) { key[i] = DBL_MAX; idx[i] = i; }
-    __syncthreads();
-    // fold G minima into THR_BINS groups (a min over a union of groups is still one element
-    // per group, so the K-th smallest bin value bounds the K-th smallest key from above)
     const double *src = gmin + row * G;
-    for (int64_t i0 = 0; i0 < G; i0 += THR_BINS) {
-        for (int i = threadIdx.x; i < THR_BINS && i0 + i < G; i += blockDim.x)
-            key[i] = fmin(key[i], src[i0 + i]);
+    if (G < K) {                         // fewer than K groups: accept everything
+        if (threadIdx.x == 0) thr[row] = DBL_MAX;
+        return;
     }
-    __syncthreads();
-    bitonic_sort_pairs(key, idx, THR_BINS);
+    double result;
+    bool done = false;
+    if (K <= THR_FOLD) {
+        // fast exact path: fold to THR_FOLD bins by min; bins[K-1] bounds the answer and at most
+        // K bins (K*ceil(G/THR_FOLD) values) lie at or below it; collect those and sort them
+        for (int i = threadIdx.x; i < THR_FOLD; i += blockDim.x) { key[i] = DBL_MAX; idx[i] = i; }
+        if (threadIdx.x == 0) n_coll = 0;
+        __syncthreads();
+        for (int64_t i0 = 0; i0 < G; i0 += THR_FOLD)
+            for (int i = threadIdx.x; i < THR_FOLD && i0 + i < G; i += blockDim.x)
+                key[i] = fmin(key[i], src[i0 + i]);
+        __syncthreads();
+        bitonic_sort_pairs(key, idx, THR_FOLD);
+        if (threadIdx.x == 0) bound_s = key[K - 1];
+        __syncthreads();
+        const double bound = bound_s;
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < G; i += blockDim.x) {
+            const double v = src[i];
+            if (v <= bound) {
+                const int slot = atomicAdd(&n_coll, 1);
+                if (slot < THR_COLL) { key[slot] = v; idx[slot] = slot; }
+            }
+        }
+        __syncthreads();
+        const int n = n_coll;
+        if (n <= THR_COLL) {
+            int P = 2;
+            while (P < n) P <<= 1;
+            for (int i = n + threadIdx.x; i < P; i += blockDim.x) { key[i] = DBL_MAX; idx[i] = i; }
+            __syncthreads();
+            bitonic_sort_pairs(key, idx, P);
+            result = key[K - 1];
+            done = true;
+        }
+        __syncthreads();
+    }
+    if (!done) {
+        // general exact path: 8-bit MSB-first radix select on the order-preserving integer image
+        if (threadIdx.x == 0) { prefix_s = 0ull; remaining_s = K; }
+        __syncthreads();
+        for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 56 - 8 * pass;
+            hist[threadIdx.x] = 0;
+            __syncthreads();
+            const unsigned long long prefix = prefix_s;
+            const unsigned long long mask = pass ? (~0ull << (shift + 8)) : 0ull;
+            for (int64_t i = threadIdx.x; i < G; i += blockDim.x) {
+                const unsigned long long u = f64_sortable(src[i]);
+                if ((u & mask) == prefix) atomicAdd(&hist[(int)((u >> shift) & 0xff)], 1);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int rem = remaining_s, bin = 0;
+                for (; bin < 256; ++bin) {
+                    if (hist[bin] >= rem) break;
+                    rem -= hist[bin];
+                }
+                prefix_s = prefix | ((unsigned long long)bin << shift);
+                remaining_s = rem;
+            }
+            __syncthreads();
+        }
+        result = f64_unsortable(prefix_s);
+    }
     if (threadIdx.x == 0) {
-        double v = key[K - 1];           // K <= THR_BINS enforced by the host
+        double v = result;
         if (v < DBL_MAX) v = v + fabs(v) * 1e-13 + 1e-300;
-        thr[row] = v;                    // DBL_MAX: fewer than K groups -> accept everything
+        if (keep_min) v = fmin(v, thr[row]);
+        thr[row] = v;
     }
 }
 
 void launch_knn_threshold(const double *gmin, int64_t G, int64_t T, int64_t Tpad, int K,
-                          double *thr, hipStream_t s)
+                          double *thr, int keep_min, hipStream_t s)
 {
     hipLaunchKernelGGL(knn_threshold_kernel, dim3((unsigned)Tpad), dim3(256), 0, s, gmin, G, T, K,
-                       thr);
+                       thr, keep_min);
 }
 
 __global__ void fill_threshold_kernel(double *thr, int64_t T, int64_t Tpad, double value)
@@ -500,42 +649,14 @@ void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, co
     int P = 2;
     while (P < cap) P <<= 1;
     const size_t shmem = (size_t)P * (sizeof(double) + sizeof(int));
+    static size_t attr = 0;
+    if (shmem > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_finalize_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        attr = shmem;
+    }
     hipLaunchKernelGGL(knn_finalize_kernel, dim3((unsigned)T), dim3(256), shmem, s, Fw, Dpad, D, Qp,
                        qnorm, T, K, cnt, lkey, lidx, cap, id_offset, cand, dist, d2_out, status);
-}
-
-// ---------------------------------------------------------------------------
-// retighten: after a list overflow, the K-th smallest key among the cap entries that were
-// stored is a valid (and much tighter) threshold for the retry
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-knn_retighten_kernel(const int *__restrict__ cnt, const double *__restrict__ lkey, int cap,
-                     int64_t T, int K, double *__restrict__ thr)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int64_t row = blockIdx.x;
-    if (cnt[row] <= cap) return;          // this row was fine: keep its threshold
-    int P = 2;
-    while (P < cap) P <<= 1;
-    double *key = reinterpret_cast<double *>(smem);
-    int *idx = reinterpret_cast<int *>(smem + (size_t)P * sizeof(double));
-    for (int i = threadIdx.x; i < P; i += blockDim.x) {
-        key[i] = (i < cap) ? lkey[row * cap + i] : DBL_MAX;
-        idx[i] = i;
-    }
-    __syncthreads();
-    bitonic_sort_pairs(key, idx, P);
-    if (threadIdx.x == 0) thr[row] = key[K - 1];
-}
-
-void launch_knn_retighten(const int *cnt, const double *lkey, int cap, int64_t T, int K,
-                          double *thr, hipStream_t s)
-{
-    int P = 2;
-    while (P < cap) P <<= 1;
-    const size_t shmem = (size_t)P * (sizeof(double) + sizeof(int));
-    hipLaunchKernelGGL(knn_retighten_kernel, dim3((unsigned)T), dim3(256), shmem, s, cnt, lkey, cap,
-                       T, K, thr);
 }
 
 // ---------------------------------------------------------------------------
@@ -577,6 +698,12 @@ void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, in
     int P = 2;
     while (P < G * K) P <<= 1;
     const size_t shmem = (size_t)P * (sizeof(double) + sizeof(int));
+    static size_t attr = 0;
+    if (shmem > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_topk_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        attr = shmem;
+    }
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)T), dim3(256), shmem, s, d2, id, G, T, K,
                        cand, dist);
 }

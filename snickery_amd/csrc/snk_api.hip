@@ -41,11 +41,11 @@ static int fail(const char *fmt, ...)
 
 // ---------------------------------------------------------------------------
 enum TimerId {
-    TM_H2D = 0, TM_PREP, TM_KNN_MINIMA, TM_KNN_THRESHOLD, TM_KNN_FILTER, TM_KNN_FINALIZE,
+    TM_H2D = 0, TM_PREP, TM_KNN_MINIMA, TM_KNN_THRESHOLD, TM_KNN_FILTER, TM_KNN_BUCKET, TM_KNN_FINALIZE,
     TM_JOIN, TM_VITERBI_DP, TM_D2H, TM_GREEDY_TARGET, TM_GREEDY_STEPS, TM_WEIGHTS, TM_COUNT
 };
 static const char *kTimerNames[TM_COUNT] = {
-    "h2d_queries", "prepare_queries", "knn_minima", "knn_threshold", "knn_filter", "knn_finalize",
+    "h2d_queries", "prepare_queries", "knn_minima", "knn_threshold", "knn_filter", "knn_bucket", "knn_finalize",
     "join_costs", "viterbi_dp", "d2h_results", "greedy_target_gemm", "greedy_steps", "set_weights"};
 
 struct DevBuf {
@@ -82,8 +82,10 @@ struct snk_engine {
     bool have_db = false, have_join = false, have_weights = false, have_classes = false;
     int64_t shard_offset = 0, global_N = -1;
     // k-nn workspace
-    DevBuf Qraw, Qp, qnorm, thr, gmin, cnt, lkey, lidx, status, qclass, d2tmp;
-    UttSlot slot[2];
+    DevBuf Qraw, Qp, qnorm, thr, gmin, cnt, lkey, lidx, status, qclass, d2tmp, slabctr, pool, poolctl, chunkfill;
+    UttSlot slot[4];
+    hipStream_t dp_stream[2] = {nullptr, nullptr};
+    DevBuf res_path, res_plen, res_cost, Qall;
     // greedy
     GreedyLayout glay{};
     bool have_glay = false;
@@ -93,8 +95,12 @@ struct snk_engine {
     double sample_frac = 1.0 / 16.0;
     int nt_override = 0;
     int timers_on = 1;
+    int n_cus = 256;
+    int reserved_cus = 2;
+    int pool_chunks = 4096;    // entry pool: 4096 chunks x 2048 entries x 16 B = 128 MiB      // left free by the persistent K-NN sweep for Viterbi DP blocks
     int last_retries = 0;
     int tie_overflow = 0;
+    int64_t last_T = 0;
     // timers
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> ev_pool;
@@ -170,12 +176,16 @@ int snk_create(int device_id, snk_handle *out)
                     device_id, prop.gcnArchName);
     snk_engine *h = new snk_engine();
     h->device = device_id;
+    h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (h->slabctr.ensure(64)) { delete h; return 1; }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
         HIPCHK(hipEventCreateWithFlags(&h->slot[i].knn_done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->slot[i].vit_done, hipEventDisableTiming));
     }
+    h->dp_stream[0] = h->stream2;
+    HIPCHK(hipStreamCreateWithFlags(&h->dp_stream[1], hipStreamNonBlocking));
     *out = h;
     return 0;
 }
@@ -189,10 +199,13 @@ int snk_destroy(snk_handle h)
     collect_timers(h);
     DevBuf *bufs[] = {&h->F_unw, &h->JC_unw, &h->Fw, &h->fnorm, &h->JCw, &h->wt, &h->wj, &h->unit_class,
                       &h->Qraw, &h->Qp, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
-                      &h->status, &h->qclass, &h->d2tmp, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
+                      &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
                       &h->gpath, &h->gdist};
     for (auto *b : bufs) b->release();
-    for (int i = 0; i < 2; ++i) {
+    (void)hipStreamSynchronize(h->dp_stream[1]);
+    (void)hipStreamDestroy(h->dp_stream[1]);
+    h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
+    for (int i = 0; i < 4; ++i) {
         UttSlot &s = h->slot[i];
         DevBuf *sb[] = {&s.cand, &s.tdist, &s.J, &s.bp, &s.path, &s.plen, &s.cost};
         for (auto *b : sb) b->release();
@@ -321,31 +334,35 @@ static KnnPlan make_plan(snk_engine *h, int K)
     p.nt = nt;
     const int64_t slab_rows = 16 * nt;
     p.n_slabs = (h->N + slab_rows - 1) / slab_rows;
-    // stage-A sample: a strided subset of slabs, large enough to hold >= 4K groups of
-    // slab-lane minima (16 groups per slab) whenever the database allows it
-    int64_t want = (int64_t)ceil((double)p.n_slabs * h->sample_frac);
-    const int64_t min_slabs = (4 * (int64_t)K + 15) / 16;
-    if (want < min_slabs) want = min_slabs;
-    if (want > p.n_slabs) want = p.n_slabs;
-    if (want < 1) want = 1;
-    p.a_stride = p.n_slabs / want;
-    if (p.a_stride < 1) p.a_stride = 1;
-    p.a_count = (p.n_slabs + p.a_stride - 1) / p.a_stride;
-    p.a_start = 0;
+    p.row_limit = h->N;
+    p.grid_cus = h->n_cus - h->reserved_cus;
+    if (p.grid_cus < 1) p.grid_cus = 1;
+    p.slab_counter = h->slabctr.as<unsigned int>();
+    // stage-A sample: every a_stride-th database row (uniform at single-unit granularity),
+    // at least 4K groups of sampled-slab-lane minima (16 groups per slab of 16*nt sampled rows)
+    int64_t stride = (int64_t)floor(1.0 / h->sample_frac + 0.5);
+    if (stride < 1) stride = 1;
+    const int64_t min_rows = ((4 * (int64_t)K + 15) / 16) * slab_rows;
+    while (stride > 1 && (h->N + stride - 1) / stride < min_rows) --stride;
+    p.a_stride = stride;
+    const int64_t sample_rows = (h->N + stride - 1) / stride;
+    p.a_count = (sample_rows + slab_rows - 1) / slab_rows;
     return p;
 }
 
-static int knn_device(snk_engine *h, int64_t T, int K, const int32_t *qclass_dev,
+static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_t *qclass_dev,
                       int64_t *cand_dev, double *dist_dev, double *d2_dev)
 {
     if (K < 1 || K > 208) return fail("K-NN: n_candidates=%d outside the supported range 1..208", K);
     const int64_t Tpad = roundup(T, 16);
-    const KnnPlan p = make_plan(h, K);
+    const KnnPlan p0 = make_plan(h, K);
     const bool cls = qclass_dev != nullptr;
     const int32_t *uc = cls ? h->unit_class.as<int32_t>() : nullptr;
     int cap = h->cap;
     if (cap < 2 * K) cap = 2 * K;
-    const int64_t G = p.a_count * 16;
+    if (K > 4096) return fail("K-NN: K too large");
+    KnnPlan p = p0;
+    int64_t G = p.a_count * 16;
     CHK(h->Qp.ensure((size_t)Tpad * h->Dpad * sizeof(double)));
     CHK(h->qnorm.ensure((size_t)Tpad * sizeof(double)));
     CHK(h->thr.ensure((size_t)Tpad * sizeof(double)));
@@ -354,37 +371,56 @@ static int knn_device(snk_engine *h, int64_t T, int K, const int32_t *qclass_dev
     CHK(h->lkey.ensure((size_t)Tpad * cap * sizeof(double)));
     CHK(h->lidx.ensure((size_t)Tpad * cap * sizeof(int)));
     CHK(h->status.ensure(sizeof(int)));
+    const int max_chunks = h->pool_chunks;
+    CHK(h->pool.ensure(knn_pool_bytes(max_chunks)));
+    CHK(h->poolctl.ensure(2 * sizeof(unsigned int)));
+    CHK(h->chunkfill.ensure((size_t)max_chunks * sizeof(int)));
     hipStream_t s = h->stream;
     {
         StageTimer t(h, s, TM_PREP);
-        launch_prepare_queries(h->Qraw.as<double>(), T, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(),
+        launch_prepare_queries(Qdev, T, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(),
                                Tpad, h->Dpad, s);
     }
-    // small databases: fewer than K sampled groups cannot bound the K-th neighbour
-    const bool use_sample = (G >= K);
-    if (use_sample) {
-        {
-            StageTimer t(h, s, TM_KNN_MINIMA);
-            launch_knn_minima(p, h->Fw.as<double>(), h->fnorm.as<double>(), h->Qp.as<double>(), Tpad,
-                              h->gmin.as<double>(), G, uc, qclass_dev, s);
-        }
-        {
-            StageTimer t(h, s, TM_KNN_THRESHOLD);
-            launch_knn_threshold(h->gmin.as<double>(), G, T, Tpad, K, h->thr.as<double>(), s);
-        }
-    } else {
-        // tiny databases take every unit; the lists are bounded by the retry loop below
-        launch_fill_threshold(h->thr.as<double>(), T, Tpad, DBL_MAX, s);
-    }
     h->last_retries = 0;
-    for (int attempt = 0; attempt < 6; ++attempt) {
+    h->last_T = T;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // attempt 0: thresholds from a strided sample of slabs (stage A).
+        // attempt 1 (a candidate list overflowed): stage A over EVERY slab -- at most
+        //   nt*K database rows then lie under each threshold, which the lists always hold.
+        if (attempt == 1) {
+            p.a_stride = 1; p.a_count = p.n_slabs;
+            G = p.a_count * 16;
+            CHK(h->gmin.ensure((size_t)Tpad * G * sizeof(double)));
+            h->last_retries = 1;
+        }
+        if (G >= K) {       // tiny databases: fewer than K groups cannot bound the K-th neighbour
+            {
+                StageTimer t(h, s, TM_KNN_MINIMA);
+                launch_knn_minima(p, h->Fw.as<double>(), h->fnorm.as<double>(), h->Qp.as<double>(), Tpad,
+                                  h->gmin.as<double>(), G, uc, qclass_dev, s);
+            }
+            {
+                StageTimer t(h, s, TM_KNN_THRESHOLD);
+                launch_knn_threshold(h->gmin.as<double>(), G, T, Tpad, K, h->thr.as<double>(), attempt, s);
+            }
+        } else {
+            launch_fill_threshold(h->thr.as<double>(), T, Tpad, DBL_MAX, s);
+        }
         HIPCHK(hipMemsetAsync(h->cnt.p, 0, (size_t)Tpad * sizeof(int), s));
         HIPCHK(hipMemsetAsync(h->status.p, 0, sizeof(int), s));
+        HIPCHK(hipMemsetAsync(h->poolctl.p, 0, 2 * sizeof(unsigned int), s));
+        HIPCHK(hipMemsetAsync(h->chunkfill.p, 0, (size_t)max_chunks * sizeof(int), s));
         {
             StageTimer t(h, s, TM_KNN_FILTER);
             launch_knn_filter(p, h->Fw.as<double>(), h->fnorm.as<double>(), h->Qp.as<double>(),
-                              h->thr.as<double>(), Tpad, h->cnt.as<int>(), h->lkey.as<double>(),
-                              h->lidx.as<int>(), cap, uc, qclass_dev, s);
+                              h->thr.as<double>(), Tpad, h->pool.p, h->poolctl.as<unsigned int>(),
+                              h->chunkfill.as<int>(), max_chunks, uc, qclass_dev, s);
+        }
+        {
+            StageTimer t(h, s, TM_KNN_BUCKET);
+            launch_knn_bucket(h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
+                              Tpad, h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
+                              h->status.as<int>(), s);
         }
         {
             StageTimer t(h, s, TM_KNN_FINALIZE);
@@ -396,14 +432,12 @@ static int knn_device(snk_engine *h, int64_t T, int K, const int32_t *qclass_dev
         HIPCHK(hipMemcpyAsync(&status, h->status.p, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         HIPCHK(hipGetLastError());
-        if (status == 0) return 0;
         if (status & 2) h->tie_overflow = 1;   // > 256-K near ties at the cut: (key, id) order kept
         if (!(status & 1)) return 0;
-        // some list overflowed: tighten those rows' thresholds from what was stored, retry
-        h->last_retries = attempt + 1;
-        launch_knn_retighten(h->cnt.as<int>(), h->lkey.as<double>(), cap, T, K, h->thr.as<double>(), s);
     }
-    return fail("K-NN: candidate lists still overflow after 6 threshold refinements (cap=%d)", cap);
+    return fail("K-NN: a candidate list overflowed its capacity (%d) even with exact thresholds: more "
+                "than %d database units are tied with the K-th neighbour of a query (mass duplicates) "
+                "or list_capacity < %d", cap, cap, p.nt * K);
 }
 
 static int check_ready(snk_engine *h, bool need_target, bool need_join)
@@ -447,7 +481,7 @@ int snk_knn(snk_handle h, const double *Q, int64_t T, int D, int K, int64_t *can
     UttSlot &s = h->slot[0];
     CHK(s.cand.ensure((size_t)T * K * sizeof(int64_t)));
     CHK(s.tdist.ensure((size_t)T * K * sizeof(double)));
-    CHK(knn_device(h, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
+    CHK(knn_device(h, h->Qraw.as<double>(), T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
     {
         StageTimer t(h, h->stream, TM_D2H);
         HIPCHK(hipMemcpyAsync(cand_out, s.cand.p, (size_t)T * K * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
@@ -473,7 +507,7 @@ int snk_knn_by_class(snk_handle h, const double *Q, int64_t T, int D, int K, con
     UttSlot &s = h->slot[0];
     CHK(s.cand.ensure((size_t)T * K * sizeof(int64_t)));
     CHK(s.tdist.ensure((size_t)T * K * sizeof(double)));
-    CHK(knn_device(h, T, K, h->qclass.as<int32_t>(), s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
+    CHK(knn_device(h, h->Qraw.as<double>(), T, K, h->qclass.as<int32_t>(), s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
     HIPCHK(hipMemcpyAsync(cand_out, s.cand.p, (size_t)T * K * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(dist_out, s.tdist.p, (size_t)T * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -559,7 +593,7 @@ int snk_knn_viterbi(snk_handle h, const double *Q, int64_t T, int D, int K, int6
     CHK(upload_queries(h, Q, T, D));
     UttSlot &s = h->slot[0];
     CHK(slot_ensure(h, s, T, K));
-    CHK(knn_device(h, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
+    CHK(knn_device(h, h->Qraw.as<double>(), T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
     CHK(viterbi_device(h, s, T, K, h->stream));
     HIPCHK(hipGetLastError());
     double cost = 0;
@@ -586,30 +620,54 @@ int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offs
         return fail("snk_knn_viterbi_batch: null/empty argument");
     if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
     if (h->Njc != h->N + 1) return fail("snk_knn_viterbi_batch: join_contexts rows != N+1");
-    // K-NN of utterance u+1 (stream) overlaps join costs + DP of utterance u (stream2).
+    if (K > 208) return fail("viterbi: n_candidates=%d > 208 not supported", K);
+    const int64_t total = row_offsets[n_utts];
+    for (int u = 0; u < n_utts; ++u)
+        if (row_offsets[u + 1] - row_offsets[u] < 1) return fail("snk_knn_viterbi_batch: utterance %d has no rows", u);
+    // Pipeline: the main stream runs K-NN(u) and the join costs of u; the T-step recursion of u
+    // runs on one of two side streams and lands on the compute units the persistent K-NN sweep
+    // leaves free, overlapping K-NN(u+1), K-NN(u+2).  All results stay on the device until the
+    // end of the batch (one D2H), so no host copy serialises the streams.
+    CHK(h->Qall.ensure((size_t)total * D * sizeof(double)));
+    CHK(h->res_path.ensure((size_t)total * sizeof(int64_t)));
+    CHK(h->res_plen.ensure((size_t)n_utts * sizeof(int64_t)));
+    CHK(h->res_cost.ensure((size_t)n_utts * sizeof(double)));
+    {
+        StageTimer t(h, h->stream, TM_H2D);
+        HIPCHK(hipMemcpyAsync(h->Qall.p, Q, (size_t)total * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
     for (int u = 0; u < n_utts; ++u) {
         const int64_t r0 = row_offsets[u], T = row_offsets[u + 1] - r0;
-        if (T < 1) return fail("snk_knn_viterbi_batch: utterance %d has no rows", u);
-        UttSlot &s = h->slot[u & 1];
+        UttSlot &s = h->slot[u & 3];
+        hipStream_t dps = h->dp_stream[u & 1];
         CHK(slot_ensure(h, s, T, K));
-        if (u >= 2) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));   // slot reuse
-        CHK(h->Qraw.ensure((size_t)T * D * sizeof(double)));
+        if (u >= 4) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));   // slot reuse
+        CHK(knn_device(h, h->Qall.as<double>() + r0 * D, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
         {
-            StageTimer t(h, h->stream, TM_H2D);
-            HIPCHK(hipMemcpyAsync(h->Qraw.p, Q + r0 * D, (size_t)T * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            StageTimer t(h, h->stream, TM_JOIN);
+            launch_join_costs(h->JCw.as<double>(), h->Djpad, h->Dj, join_units(h), s.cand.as<int64_t>(), T, K,
+                              s.J.as<double>(), h->stream);
         }
-        CHK(knn_device(h, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
         HIPCHK(hipEventRecord(s.knn_done, h->stream));
-        HIPCHK(hipStreamWaitEvent(h->stream2, s.knn_done, 0));
-        CHK(viterbi_device(h, s, T, K, h->stream2));
-        HIPCHK(hipMemcpyAsync(path_len_out + u, s.plen.p, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream2));
-        HIPCHK(hipMemcpyAsync(cost_out + u, s.cost.p, sizeof(double), hipMemcpyDeviceToHost, h->stream2));
-        HIPCHK(hipMemcpyAsync(path_out + r0, s.path.p, (size_t)T * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream2));
-        HIPCHK(hipEventRecord(s.vit_done, h->stream2));
+        HIPCHK(hipStreamWaitEvent(dps, s.knn_done, 0));
+        {
+            StageTimer t(h, dps, TM_VITERBI_DP);
+            launch_viterbi_dp(s.cand.as<int64_t>(), s.tdist.as<double>(), s.J.as<double>(), T, K, join_units(h),
+                              s.bp.as<unsigned char>(), h->res_path.as<int64_t>() + r0,
+                              h->res_plen.as<int64_t>() + u, h->res_cost.as<double>() + u, dps);
+        }
+        HIPCHK(hipEventRecord(s.vit_done, dps));
+    }
+    HIPCHK(hipStreamSynchronize(h->dp_stream[0]));
+    HIPCHK(hipStreamSynchronize(h->dp_stream[1]));
+    HIPCHK(hipGetLastError());
+    {
+        StageTimer t(h, h->stream, TM_D2H);
+        HIPCHK(hipMemcpyAsync(path_out, h->res_path.p, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(path_len_out, h->res_plen.p, (size_t)n_utts * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(cost_out, h->res_cost.p, (size_t)n_utts * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream2));
-    HIPCHK(hipGetLastError());
     collect_timers(h);
     return 0;
 }
@@ -661,7 +719,7 @@ int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_st
     const int64_t nsteps = T / g.me;          // py2 integer division: tail frames dropped
     *nsteps_out = nsteps;
     if (nsteps == 0) { HIPCHK(hipStreamSynchronize(h->stream)); collect_timers(h); return 0; }
-    const int nblk = greedy_blocks(g);
+    const int nblk = greedy_blocks(g, h->Dt, h->Dj);
     CHK(h->gprev.ensure((size_t)g.jdim * sizeof(double)));
     CHK(h->gblkmin.ensure((size_t)nblk * sizeof(double)));
     CHK(h->gblkarg.ensure((size_t)nblk * sizeof(int64_t)));
@@ -728,7 +786,7 @@ int snk_knn_local_dev(snk_handle h, const double *Q, int64_t T, int D, int K, do
     HIPCHK(hipSetDevice(h->device));
     if (!d2_dev_out || !id_dev_out) return fail("snk_knn_local_dev: null output");
     CHK(upload_queries(h, Q, T, D));
-    CHK(knn_device(h, T, K, nullptr, id_dev_out, nullptr, d2_dev_out));
+    CHK(knn_device(h, h->Qraw.as<double>(), T, K, nullptr, id_dev_out, nullptr, d2_dev_out));
     HIPCHK(hipStreamSynchronize(h->stream));
     collect_timers(h);
     return 0;
@@ -786,6 +844,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
         h->sample_frac = value;
     } else if (!strcmp(name, "db_tiles_per_wave")) {
         h->nt_override = (int)value;
+    } else if (!strcmp(name, "reserved_cus")) {
+        if (value < 0 || value > 64) return fail("reserved_cus must be in 0..64");
+        h->reserved_cus = (int)value;
     } else if (!strcmp(name, "timers")) {
         h->timers_on = value != 0.0;
     } else {
@@ -803,6 +864,16 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "last_knn_retries")) *out = h->last_retries;
     else if (!strcmp(name, "list_capacity")) *out = h->cap;
     else if (!strcmp(name, "tie_overflow")) *out = h->tie_overflow;
+    else if (!strcmp(name, "last_list_mean") || !strcmp(name, "last_list_max")) {
+        // candidate-list lengths of the most recent K-NN call (debug / tuning aid)
+        const int64_t n = h->last_T;
+        if (n <= 0) { *out = 0; return 0; }
+        std::vector<int> c((size_t)n);
+        HIPCHK(hipMemcpy(c.data(), h->cnt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        double sum = 0, mx = 0;
+        for (int64_t i = 0; i < n; ++i) { sum += c[i]; if (c[i] > mx) mx = c[i]; }
+        *out = !strcmp(name, "last_list_max") ? mx : sum / (double)n;
+    }
     else if (!strcmp(name, "device")) *out = h->device;
     else if (!strcmp(name, "db_tiles_per_wave")) { KnnPlan p = make_plan(h, 100); *out = p.nt; }
     else if (!strcmp(name, "sample_slabs")) { KnnPlan p = make_plan(h, 100); *out = (double)p.a_count; }

@@ -21,7 +21,10 @@ struct KnnPlan {
     int nt;              // DB tiles per wave (slab = 16*nt rows)
     int dch;             // Dpad / 64
     int64_t n_slabs;     // slabs covering the DB
-    int64_t a_start, a_stride, a_count;   // stage-A sample: slabs a_start + i*a_stride
+    int64_t a_stride, a_count;   // stage-A sample: every a_stride-th DB row, a_count virtual slabs
+    int64_t row_limit;           // first padding row (rows >= N have norm +inf)
+    int grid_cus;                // compute units the persistent sweep may occupy
+    unsigned int *slab_counter;  // device word: dynamic slab dispenser
 };
 
 void launch_prepare_queries(const double *Q, int64_t T, int D, double *Qp, double *qnorm,
@@ -32,21 +35,23 @@ void launch_knn_minima(const KnnPlan &p, const double *Fw, const double *fnorm,
                        const int32_t *unit_class, const int32_t *query_class, hipStream_t s);
 // K-th smallest of the minima -> per-row key-space threshold
 void launch_knn_threshold(const double *gmin, int64_t G, int64_t T, int64_t Tpad, int K,
-                          double *thr, hipStream_t s);
+                          double *thr, int keep_min, hipStream_t s);
 void launch_fill_threshold(double *thr, int64_t T, int64_t Tpad, double value, hipStream_t s);
-// stage B: filtered sweep of the whole DB, candidates appended to per-row lists
+// stage B: filtered sweep of the whole DB; passing (row, unit, key) entries go to wave-private
+// chunks of a global entry pool; bucket scatters the pool into per-row lists
 void launch_knn_filter(const KnnPlan &p, const double *Fw, const double *fnorm,
                        const double *Qp, const double *thr, int64_t Tpad,
-                       int *cnt, double *lkey, int *lidx, int cap,
+                       void *pool, unsigned int *pool_ctl, int *chunk_fill, int max_chunks,
                        const int32_t *unit_class, const int32_t *query_class, hipStream_t s);
+size_t knn_pool_bytes(int max_chunks);
+void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int *chunk_fill,
+                       int max_chunks, int64_t Tpad, int *cnt, double *lkey, int *lidx, int cap,
+                       int *status, hipStream_t s);
 // stage C: per-row select + exact re-rank in canonical order + sort
 void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, const double *qnorm,
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
                          int cap, int64_t id_offset,
                          int64_t *cand, double *dist, double *d2_out, int *status, hipStream_t s);
-// tighten thresholds from (overflowed) lists: K-th smallest key present
-void launch_knn_retighten(const int *cnt, const double *lkey, int cap, int64_t T, int K,
-                          double *thr, hipStream_t s);
 void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, int K,
                        int64_t *cand, double *dist, hipStream_t s);
 
@@ -70,7 +75,7 @@ void launch_greedy(const GreedyLayout &g, const float *F_unw, int Dt, const doub
                    int64_t nsteps, int64_t start_state, double *prev_vec, double *blk_min,
                    int64_t *blk_arg, int nblk, int64_t *path, double *dist, hipStream_t s);
 size_t greedy_shmem_bytes(const GreedyLayout &g, int Dt, int Dj);
-int greedy_blocks(const GreedyLayout &g);
+int greedy_blocks(const GreedyLayout &g, int Dt, int Dj);
 
 void launch_path_scores(const GreedyLayout &g, int mode, const float *F_unw, int Dt, const double *wt,
                         const float *JC_unw, int Dj, const double *wj, const double *Q,

@@ -21,7 +21,7 @@ def engine():
     e.close()
 
 
-@pytest.fixture(scope='module')
+@pytest.fixture()
 def mini_engine(engine, mini_voice):
     engine.upload_db(mini_voice['F_unw'], mini_voice['JC_unw'])
     engine.set_weights(mini_voice['wt'], mini_voice['wj'])
@@ -100,7 +100,7 @@ def test_knn_list_overflow_retry(engine):
     engine.upload_db(F_unw, JC_unw)
     engine.set_weights(wt, wj)
     U = o.synthetic_targets(F_unw, 48, seed=8) * wt
-    engine.set_option('list_capacity', 64)
+    engine.set_option('list_capacity', 192)
     engine.set_option('sample_fraction', 1.0 / 64)
     try:
         cand, dist = engine.knn(U, 20)

@@ -15,7 +15,7 @@ print('gen %.1fs' % (time.time() - t0), flush=True)
 wt = np.full(Dt, 0.7); wj = np.full(Dj, 0.1)
 eng = snickery_amd.HipSearchEngine(0)
 eng.upload_db(F_unw, JC_unw); eng.set_weights(wt, wj)
-utts = [o.synthetic_targets(F_unw, T, seed=s) * wt for s in range(1, 9)]
+utts = [o.synthetic_targets(F_unw, T, seed=s) * wt for s in range(1, 17)]
 for nt in (8, 4):
     eng.set_option('db_tiles_per_wave', nt)
     eng.knn_viterbi(utts[0], K)
@@ -24,10 +24,11 @@ for nt in (8, 4):
     for U in utts[:4]:
         p, c = eng.knn_viterbi(U, K)
     dt = (time.time() - t0) / 4
-    print('NT=%d single: %.3f ms/utt  %.0f frames/s  retries=%d' % (nt, dt * 1e3, T / dt, eng.info('last_knn_retries')))
+    print('NT=%d single: %.3f ms/utt  %.0f frames/s  retries=%d listmean=%.0f listmax=%.0f' % (nt, dt * 1e3, T / dt, eng.info('last_knn_retries'), eng.info('last_list_mean'), eng.info('last_list_max')))
     for k, (ms, n) in eng.timers().items():
         if n: print('   %-18s %8.3f ms avg over %d' % (k, ms / n, n))
-eng.set_option('db_tiles_per_wave', 8)
+eng.set_option('db_tiles_per_wave', 4)
+eng.knn_viterbi_batch(utts[:2], K)
 eng.reset_timers()
 t0 = time.time()
 paths, costs = eng.knn_viterbi_batch(utts, K)
