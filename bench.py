@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: synthesised frames/sec (+ xRT) of the full-database K-NN preselection
++ join costs + Viterbi search on synthetic magphase-60 targets (BASELINE.json `metric`,
+workload B* of SURVEY.md 8d: |DB| = 1 048 576 units, Dt = 61, Dj = 302, T = 600, K = 100).
+
+  python bench.py --gpus 1 --steps 5 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one batch of --utts utterances (T frames each) through the whole hot path with
+the unit database already resident in HBM.  N > 1: the database is row-sharded over the ranks
+(strong scaling: database and batch are fixed), local top-K lists are all-gathered over RCCL,
+utterance u's Viterbi runs on rank u mod N.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense FP64 matrix: 256 CU x 4 SIMD x 2048 FLOP / 64 clk x 2.4 GHz
+FRAMESHIFT_MS = 5.0             # config/slt_simplified_mini.cfg:40
+
+
+def synthetic_db(N, Dt, Dj, seed=0):
+    """SURVEY 8d generator (same as oracle.snk_oracle.synthetic_db; duplicated here so that the
+    product benchmark does not import the oracle)."""
+    rng = np.random.RandomState(seed)
+    F = np.cumsum(rng.randn(N, Dt), axis=0)
+    F = (F / F.std()).astype(np.float32)
+    JC = np.cumsum(rng.randn(N + 1, Dj), axis=0)
+    JC = (JC / JC.std()).astype(np.float32)
+    return F, JC
+
+
+def synthetic_targets(F_unw, T, seed, noise=0.3):
+    rng = np.random.RandomState(seed)
+    N, Dt = F_unw.shape
+    s = rng.randint(0, max(N - T, 1))
+    return F_unw[s:s + T].astype(np.float64) + noise * rng.randn(min(T, N - s), Dt)
+
+
+def cpu_baseline(F_unw, JC_unw, wt, wj, K, sample_frames, seed):
+    """The reference's CPU formulation (oracle = test infrastructure, timed here as the
+    reported baseline only): scipy cKDTree preselection (synth_halfphone.py:379,1364), the
+    Python pair loop + numpy gather join costs (:3251-3301), DP Viterbi.  One thread, like
+    the reference's search."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import scipy.spatial
+    import snk_oracle as o
+    F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
+    t0 = time.time()
+    tree = scipy.spatial.cKDTree(F, leafsize=100, compact_nodes=False, balanced_tree=False)
+    t_build = time.time() - t0
+    U = synthetic_targets(F_unw, sample_frames, seed) * wt
+    t0 = time.time()
+    d, i = tree.query(U, k=K)
+    t_knn = time.time() - t0
+    cand = np.asarray(i, dtype=np.int64)
+    t0 = time.time()
+    cache = o.join_cost_cache(E, S, cand)
+    t_join = time.time() - t0
+    t0 = time.time()
+    path, cost = o.viterbi(cand, np.asarray(d), E, S)
+    t_dp = time.time() - t0
+    total = t_knn + t_join + t_dp
+    return {
+        'value': sample_frames / total, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+        'sample': '%d frames of the same workload (K=%d, full %d-unit DB): cKDTree.query %.2fs + '
+                  'pair-loop join costs %.2fs (%d arcs) + DP %.2fs; tree build %.1fs not counted'
+                  % (sample_frames, K, F.shape[0], t_knn, t_join, len(cache), t_dp, t_build),
+    }, (cand, np.asarray(d), path, cost, U)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--units', type=int, default=1048576)
+    ap.add_argument('--frames', type=int, default=600)
+    ap.add_argument('--candidates', type=int, default=100)
+    ap.add_argument('--utts', type=int, default=8, help='utterances per step (batch)')
+    ap.add_argument('--target-dim', type=int, default=61)
+    ap.add_argument('--join-dim', type=int, default=302)
+    ap.add_argument('--cpu-sample-frames', type=int, default=48)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    N, Dt, Dj, T, K, U = args.units, args.target_dim, args.join_dim, args.frames, args.candidates, args.utts
+
+    import torch
+    import snickery_amd
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    F_unw, JC_unw = synthetic_db(N, Dt, Dj, seed=0)
+    wt = np.full(Dt, 0.8 * 0.5)                 # target_stream_weights * (1 - join_cost_weight)
+    wj = np.full(Dj, 0.2 * 0.25)                # join_stream_weights * join_cost_weight
+    utts = [synthetic_targets(F_unw, T, seed=1 + u) * wt for u in range(U)]
+    frames_per_step = sum(u.shape[0] for u in utts)
+
+    eng = snickery_amd.HipSearchEngine(local_rank)       # raises without libsnkhip.so / gfx950
+    if world == 1:
+        eng.upload_db(F_unw, JC_unw)
+        eng.set_weights(wt, wj)
+        n_local = N
+
+        def step():
+            return eng.knn_viterbi_batch(utts, K)
+    else:
+        from snickery_amd.dist import HipShardEngine, ShardedSearch, shard_bounds
+        lo, hi = shard_bounds(N, world, rank)
+        eng.upload_target_only(F_unw[lo:hi])
+        eng.upload_join_only(JC_unw)
+        eng.set_shard(lo, N)
+        eng.set_weights(wt, wj)
+        n_local = hi - lo
+        search = ShardedSearch(HipShardEngine(eng, torch.device('cuda', local_rank)))
+
+        def step():
+            return search.knn_viterbi_batch(utts, K)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        paths, costs = step()
+    eng.reset_timers()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        paths, costs = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    timers = eng.timers()
+    if rank == 0:
+        total_frames = frames_per_step * args.steps
+        value = total_frames / elapsed
+        ms, launches = timers['knn_filter']
+        avg_ms = ms / max(launches, 1)
+        flops = 2.0 * T * n_local * Dt          # algorithmic: SURVEY 8d, per utterance, this rank's shard
+        achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        out = {
+            'metric': 'synthesised frames/sec, full-DB K=%d K-NN preselection + Viterbi' % K,
+            'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'xRT': (total_frames * FRAMESHIFT_MS / 1e3) / elapsed,
+            'config': {'workload': 'B* synthetic magphase-60 (SURVEY 8d): |DB|=%d units, Dt=%d, Dj=%d, '
+                                   'T=%d frames x %d utterances per step, K=%d, search_epsilon=0'
+                                   % (N, Dt, Dj, T, U, K),
+                       'units': N, 'target_dim': Dt, 'join_dim': Dj, 'frames': T, 'utts_per_step': U,
+                       'n_candidates': K, 'sharding': 'db-rows/%d + all-gather top-K' % world if world > 1 else 'none'},
+            'roofline': {'bound': 'mfma', 'kernel': 'knn_sweep<filter> (v_mfma_f64_16x16x4_f64)',
+                         'achieved': achieved, 'peak': F64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / F64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'avg_launch_ms': avg_ms, 'launches': launches,
+                         'flops_per_launch': flops},
+            'stages_ms_per_utt': dict((k, v[0] / max(v[1], 1)) for k, v in timers.items() if v[1]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, ref = cpu_baseline(F_unw, JC_unw, wt, wj, K, args.cpu_sample_frames, seed=1)
+            out['cpu_baseline'] = base
+            # the same sample through the HIP path must select the same units
+            gp, gc, gcand, gdist = eng.knn_viterbi(ref[4], K, return_candidates=True)
+            out['cpu_baseline']['gpu_matches_cpu_path'] = bool(gp == ref[2])
+            out['cpu_baseline']['gpu_matches_cpu_candidates'] = bool(np.array_equal(gcand, ref[0]))
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()

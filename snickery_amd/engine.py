@@ -134,6 +134,12 @@ class HipSearchEngine(object):
         self.n_units, self.Dt = F.shape
         self.Dj = JC.shape[1]
 
+    def upload_target_only(self, train_unit_features_unweighted):
+        """Shard of the target features without a join matrix (multi-GPU K-NN ranks)."""
+        F = np.ascontiguousarray(train_unit_features_unweighted, dtype=np.float32)
+        self._check(self._lib.snk_upload_db(self._h, _ptr(F, _c_f32p), F.shape[0], F.shape[1], None, 0, 0))
+        self.n_units, self.Dt = F.shape
+
     def upload_join_only(self, join_contexts_unweighted):
         JC = np.ascontiguousarray(join_contexts_unweighted, dtype=np.float32)
         self._check(self._lib.snk_upload_join_only(self._h, _ptr(JC, _c_f32p), JC.shape[0], JC.shape[1]))
