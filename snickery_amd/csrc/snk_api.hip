@@ -65,6 +65,23 @@ struct DevBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+struct HostBuf {        // pinned host staging (pageable D2H of > ~64 KB pins the user buffer: ms)
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return 0;
+        if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+        size_t want = need + need / 4 + 4096;
+        if (want < ((size_t)8 << 20)) want = (size_t)8 << 20;     // pinned allocations cost milliseconds
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return fail("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+        bytes = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+};
+
 struct EvPair { hipEvent_t a, b; int id; };
 
 struct UttSlot {      // per in-flight utterance workspace (batch pipeline uses two)
@@ -85,7 +102,8 @@ struct snk_engine {
     DevBuf Qraw, Qp, qnorm, thr, gmin, cnt, lkey, lidx, status, qclass, d2tmp, slabctr, pool, poolctl, chunkfill;
     UttSlot slot[4];
     hipStream_t dp_stream[2] = {nullptr, nullptr};
-    DevBuf res_path, res_plen, res_cost, Qall;
+    DevBuf res_path, res_plen, res_cost, Qall, res_status;
+    HostBuf hstage;
     // greedy
     GreedyLayout glay{};
     bool have_glay = false;
@@ -100,6 +118,7 @@ struct snk_engine {
     int pool_chunks = 4096;    // entry pool: 4096 chunks x 2048 entries x 16 B = 128 MiB      // left free by the persistent K-NN sweep for Viterbi DP blocks
     int last_retries = 0;
     int tie_overflow = 0;
+    int batch_redos = 0;
     int64_t last_T = 0;
     // timers
     std::vector<EvPair> pending;
@@ -141,6 +160,28 @@ static void collect_timers(snk_engine *h)   // call after the streams were synch
         h->ev_pool.push_back(ep.b);
     }
     h->pending.clear();
+}
+
+// device -> pinned staging -> user memory; `parts` are (dst, src, bytes) triples
+struct D2HPart { void *dst; const void *src; size_t bytes; };
+static int staged_d2h(snk_engine *h, hipStream_t st, const D2HPart *parts, int n)
+{
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (parts[i].bytes + 63) & ~(size_t)63;
+    CHK(h->hstage.ensure(total));
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (parts[i].bytes)
+            HIPCHK(hipMemcpyAsync((char *)h->hstage.p + off, parts[i].src, parts[i].bytes, hipMemcpyDeviceToHost, st));
+        off += (parts[i].bytes + 63) & ~(size_t)63;
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (parts[i].bytes) memcpy(parts[i].dst, (char *)h->hstage.p + off, parts[i].bytes);
+        off += (parts[i].bytes + 63) & ~(size_t)63;
+    }
+    return 0;
 }
 
 static int roundup(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); }
@@ -205,6 +246,7 @@ int snk_destroy(snk_handle h)
     (void)hipStreamSynchronize(h->dp_stream[1]);
     (void)hipStreamDestroy(h->dp_stream[1]);
     h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
+    h->res_status.release(); h->hstage.release();
     for (int i = 0; i < 4; ++i) {
         UttSlot &s = h->slot[i];
         DevBuf *sb[] = {&s.cand, &s.tdist, &s.J, &s.bp, &s.path, &s.plen, &s.cost};
@@ -327,7 +369,7 @@ static KnnPlan make_plan(snk_engine *h, int K)
 {
     KnnPlan p{};
     p.dch = h->Dpad / 64;
-    int nt = (p.dch == 1) ? 8 : (p.dch == 2) ? 4 : (p.dch == 3) ? 2 : 1;
+    int nt = (p.dch == 1) ? 4 : (p.dch == 2) ? 4 : (p.dch == 3) ? 2 : 1;
     if (h->nt_override > 0 && p.dch <= 2) {
         if (h->nt_override == 2 || h->nt_override == 4 || (h->nt_override == 8 && p.dch == 1)) nt = h->nt_override;
     }
@@ -350,8 +392,11 @@ static KnnPlan make_plan(snk_engine *h, int K)
     return p;
 }
 
+// deferred_status != nullptr: enqueue the first attempt only, leave its status word in that device
+// int and do NOT synchronise (batch pipeline: the caller checks all words at the end of the batch
+// and redoes the rare overflowed utterance synchronously).
 static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_t *qclass_dev,
-                      int64_t *cand_dev, double *dist_dev, double *d2_dev)
+                      int64_t *cand_dev, double *dist_dev, double *d2_dev, int *deferred_status = nullptr)
 {
     if (K < 1 || K > 208) return fail("K-NN: n_candidates=%d outside the supported range 1..208", K);
     const int64_t Tpad = roundup(T, 16);
@@ -383,10 +428,13 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
     }
     h->last_retries = 0;
     h->last_T = T;
+    int *status_dev = deferred_status ? deferred_status : h->status.as<int>();
     for (int attempt = 0; attempt < 2; ++attempt) {
         // attempt 0: thresholds from a strided sample of slabs (stage A).
         // attempt 1 (a candidate list overflowed): stage A over EVERY slab -- at most
         //   nt*K database rows then lie under each threshold, which the lists always hold.
+        launch_knn_reset(h->cnt.as<int>(), Tpad, status_dev, h->poolctl.as<unsigned int>(),
+                         h->slabctr.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, s);
         if (attempt == 1) {
             p.a_stride = 1; p.a_count = p.n_slabs;
             G = p.a_count * 16;
@@ -406,10 +454,6 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         } else {
             launch_fill_threshold(h->thr.as<double>(), T, Tpad, DBL_MAX, s);
         }
-        HIPCHK(hipMemsetAsync(h->cnt.p, 0, (size_t)Tpad * sizeof(int), s));
-        HIPCHK(hipMemsetAsync(h->status.p, 0, sizeof(int), s));
-        HIPCHK(hipMemsetAsync(h->poolctl.p, 0, 2 * sizeof(unsigned int), s));
-        HIPCHK(hipMemsetAsync(h->chunkfill.p, 0, (size_t)max_chunks * sizeof(int), s));
         {
             StageTimer t(h, s, TM_KNN_FILTER);
             launch_knn_filter(p, h->Fw.as<double>(), h->fnorm.as<double>(), h->Qp.as<double>(),
@@ -420,14 +464,15 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             StageTimer t(h, s, TM_KNN_BUCKET);
             launch_knn_bucket(h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
                               Tpad, h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
-                              h->status.as<int>(), s);
+                              status_dev, s);
         }
         {
             StageTimer t(h, s, TM_KNN_FINALIZE);
             launch_knn_finalize(h->Fw.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
-                                h->shard_offset, cand_dev, dist_dev, d2_dev, h->status.as<int>(), s);
+                                h->shard_offset, cand_dev, dist_dev, d2_dev, status_dev, s);
         }
+        if (deferred_status) return 0;
         int status = 0;
         HIPCHK(hipMemcpyAsync(&status, h->status.p, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -484,8 +529,9 @@ int snk_knn(snk_handle h, const double *Q, int64_t T, int D, int K, int64_t *can
     CHK(knn_device(h, h->Qraw.as<double>(), T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
     {
         StageTimer t(h, h->stream, TM_D2H);
-        HIPCHK(hipMemcpyAsync(cand_out, s.cand.p, (size_t)T * K * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(dist_out, s.tdist.p, (size_t)T * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        D2HPart parts[2] = {{cand_out, s.cand.p, (size_t)T * K * sizeof(int64_t)},
+                            {dist_out, s.tdist.p, (size_t)T * K * sizeof(double)}};
+        CHK(staged_d2h(h, h->stream, parts, 2));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     collect_timers(h);
@@ -599,13 +645,13 @@ int snk_knn_viterbi(snk_handle h, const double *Q, int64_t T, int D, int K, int6
     double cost = 0;
     {
         StageTimer t(h, h->stream, TM_D2H);
-        if (cand_out) HIPCHK(hipMemcpyAsync(cand_out, s.cand.p, (size_t)T * K * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-        if (dist_out) HIPCHK(hipMemcpyAsync(dist_out, s.tdist.p, (size_t)T * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(path_len_out, s.plen.p, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(&cost, s.cost.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(path_out, s.path.p, (size_t)T * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        D2HPart parts[5] = {{cand_out, s.cand.p, cand_out ? (size_t)T * K * sizeof(int64_t) : 0},
+                            {dist_out, s.tdist.p, dist_out ? (size_t)T * K * sizeof(double) : 0},
+                            {path_len_out, s.plen.p, sizeof(int64_t)},
+                            {&cost, s.cost.p, sizeof(double)},
+                            {path_out, s.path.p, (size_t)T * sizeof(int64_t)}};
+        CHK(staged_d2h(h, h->stream, parts, 5));
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
     if (cost_out) *cost_out = cost;
     collect_timers(h);
     return 0;
@@ -632,6 +678,7 @@ int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offs
     CHK(h->res_path.ensure((size_t)total * sizeof(int64_t)));
     CHK(h->res_plen.ensure((size_t)n_utts * sizeof(int64_t)));
     CHK(h->res_cost.ensure((size_t)n_utts * sizeof(double)));
+    CHK(h->res_status.ensure((size_t)n_utts * sizeof(int)));
     {
         StageTimer t(h, h->stream, TM_H2D);
         HIPCHK(hipMemcpyAsync(h->Qall.p, Q, (size_t)total * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -642,7 +689,8 @@ int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offs
         hipStream_t dps = h->dp_stream[u & 1];
         CHK(slot_ensure(h, s, T, K));
         if (u >= 4) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));   // slot reuse
-        CHK(knn_device(h, h->Qall.as<double>() + r0 * D, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
+        CHK(knn_device(h, h->Qall.as<double>() + r0 * D, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(),
+                       nullptr, h->res_status.as<int>() + u));
         {
             StageTimer t(h, h->stream, TM_JOIN);
             launch_join_costs(h->JCw.as<double>(), h->Djpad, h->Dj, join_units(h), s.cand.as<int64_t>(), T, K,
@@ -661,13 +709,34 @@ int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offs
     HIPCHK(hipStreamSynchronize(h->dp_stream[0]));
     HIPCHK(hipStreamSynchronize(h->dp_stream[1]));
     HIPCHK(hipGetLastError());
+    // deferred K-NN status words: redo the (rare) utterance whose sampled thresholds overflowed a list
+    {
+        std::vector<int> st((size_t)n_utts);
+        HIPCHK(hipMemcpyAsync(st.data(), h->res_status.p, (size_t)n_utts * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int u = 0; u < n_utts; ++u) {
+            if (st[u] & 2) h->tie_overflow = 1;
+            if (!(st[u] & 1)) continue;
+            const int64_t r0 = row_offsets[u], T = row_offsets[u + 1] - r0;
+            UttSlot &s = h->slot[0];
+            CHK(slot_ensure(h, s, T, K));
+            CHK(knn_device(h, h->Qall.as<double>() + r0 * D, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
+            launch_join_costs(h->JCw.as<double>(), h->Djpad, h->Dj, join_units(h), s.cand.as<int64_t>(), T, K,
+                              s.J.as<double>(), h->stream);
+            launch_viterbi_dp(s.cand.as<int64_t>(), s.tdist.as<double>(), s.J.as<double>(), T, K, join_units(h),
+                              s.bp.as<unsigned char>(), h->res_path.as<int64_t>() + r0,
+                              h->res_plen.as<int64_t>() + u, h->res_cost.as<double>() + u, h->stream);
+            HIPCHK(hipStreamSynchronize(h->stream));
+            h->batch_redos += 1;
+        }
+    }
     {
         StageTimer t(h, h->stream, TM_D2H);
-        HIPCHK(hipMemcpyAsync(path_out, h->res_path.p, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(path_len_out, h->res_plen.p, (size_t)n_utts * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(cost_out, h->res_cost.p, (size_t)n_utts * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        D2HPart parts[3] = {{path_out, h->res_path.p, (size_t)total * sizeof(int64_t)},
+                            {path_len_out, h->res_plen.p, (size_t)n_utts * sizeof(int64_t)},
+                            {cost_out, h->res_cost.p, (size_t)n_utts * sizeof(double)}};
+        CHK(staged_d2h(h, h->stream, parts, 3));
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
     collect_timers(h);
     return 0;
 }
@@ -864,6 +933,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "last_knn_retries")) *out = h->last_retries;
     else if (!strcmp(name, "list_capacity")) *out = h->cap;
     else if (!strcmp(name, "tie_overflow")) *out = h->tie_overflow;
+    else if (!strcmp(name, "batch_redos")) *out = h->batch_redos;
     else if (!strcmp(name, "last_list_mean") || !strcmp(name, "last_list_max")) {
         // candidate-list lengths of the most recent K-NN call (debug / tuning aid)
         const int64_t n = h->last_T;

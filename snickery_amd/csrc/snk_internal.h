@@ -44,6 +44,8 @@ void launch_knn_filter(const KnnPlan &p, const double *Fw, const double *fnorm,
                        void *pool, unsigned int *pool_ctl, int *chunk_fill, int max_chunks,
                        const int32_t *unit_class, const int32_t *query_class, hipStream_t s);
 size_t knn_pool_bytes(int max_chunks);
+void launch_knn_reset(int *cnt, int64_t Tpad, int *status, unsigned int *pool_ctl,
+                      unsigned int *slab_counter, int *chunk_fill, int max_chunks, hipStream_t s);
 void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int *chunk_fill,
                        int max_chunks, int64_t Tpad, int *cnt, double *lkey, int *lidx, int cap,
                        int *status, hipStream_t s);

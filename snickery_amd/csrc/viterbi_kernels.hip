@@ -26,23 +26,26 @@ __device__ __forceinline__ bool unit_usable(int64_t id, int64_t n_units)
 }
 
 template <int RT, int DC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 join_cost_kernel(const double *__restrict__ JCw, int Djpad, int64_t n_units,
                  const int64_t *__restrict__ cand, int64_t T, int K, double *__restrict__ J)
 {
-    constexpr int NR = 16 * RT;
+    // one wavefront per (column pair t, 8RT x 8RT block of the K x K matrix): fine-grained work
+    // items (2396 at T=600, K=100) balance over the chip; thread (ta, tb) of the 8 x 8 lane grid
+    // keeps an RT x RT block of pair accumulators
+    constexpr int NR = 8 * RT;
     constexpr int DCP = DC + 1;
-    extern __shared__ __align__(16) unsigned char smem[];
-    double *Es = reinterpret_cast<double *>(smem);           // [NR][DCP]
-    double *Ss = Es + NR * DCP;                              // [NR][DCP]
+    __shared__ double Es[NR * DCP];
+    __shared__ double Ss[NR * DCP];
     __shared__ int64_t rowE[NR], rowS[NR];
     __shared__ unsigned char okE[NR], okS[NR];
 
     const int64_t t = blockIdx.x;
+    const int a0 = blockIdx.y * NR, b0 = blockIdx.z * NR;
     const int tid = threadIdx.x;
-    for (int i = tid; i < NR; i += 256) {
-        int64_t a = (i < K) ? cand[t * K + i] : -1;
-        int64_t b = (i < K) ? cand[(t + 1) * K + i] : -1;
+    for (int i = tid; i < NR; i += 64) {
+        const int64_t a = (a0 + i < K) ? cand[t * K + a0 + i] : -1;
+        const int64_t b = (b0 + i < K) ? cand[(t + 1) * K + b0 + i] : -1;
         const bool va = unit_usable(a, n_units), vb = unit_usable(b, n_units);
         okE[i] = va; okS[i] = vb;
         rowE[i] = va ? a + 1 : 0;      // unit_end_data[a]   = JCw[a+1]
@@ -50,7 +53,7 @@ join_cost_kernel(const double *__restrict__ JCw, int Djpad, int64_t n_units,
     }
     __syncthreads();
 
-    const int ta = tid >> 4, tb = tid & 15;
+    const int ta = tid >> 3, tb = tid & 7;
     double acc[RT][RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -58,13 +61,16 @@ join_cost_kernel(const double *__restrict__ JCw, int Djpad, int64_t n_units,
         for (int j = 0; j < RT; ++j) acc[i][j] = 0.0;
 
     for (int c0 = 0; c0 < Djpad; c0 += DC) {
-        for (int e = tid; e < NR * DC; e += 256) {
-            const int r = e / DC, c = e % DC;
-            Es[r * DCP + c] = JCw[rowE[r] * Djpad + c0 + c];
-            Ss[r * DCP + c] = JCw[rowS[r] * Djpad + c0 + c];
+        // gather the candidate rows' column chunk: DC doubles = 256 contiguous bytes per row
+        for (int e = tid; e < NR * (DC / 2); e += 64) {
+            const int r = e / (DC / 2), c = (e % (DC / 2)) * 2;
+            const double2 ve = *reinterpret_cast<const double2 *>(JCw + rowE[r] * Djpad + c0 + c);
+            const double2 vs = *reinterpret_cast<const double2 *>(JCw + rowS[r] * Djpad + c0 + c);
+            Es[r * DCP + c] = ve.x; Es[r * DCP + c + 1] = ve.y;
+            Ss[r * DCP + c] = vs.x; Ss[r * DCP + c + 1] = vs.y;
         }
         __syncthreads();
-#pragma unroll 4
+#pragma unroll 2
         for (int c = 0; c < DC; ++c) {
             double ev[RT], sv[RT];
 #pragma unroll
@@ -85,9 +91,10 @@ join_cost_kernel(const double *__restrict__ JCw, int Djpad, int64_t n_units,
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < RT; ++j) {
-            const int a = ta * RT + i, b = tb * RT + j;
+            const int al = ta * RT + i, bl = tb * RT + j;
+            const int a = a0 + al, b = b0 + bl;
             if (a < K && b < K) {
-                const bool ok = okE[a] && okS[b];
+                const bool ok = okE[al] && okS[bl];
                 J[(t * K + a) * K + b] = ok ? __dsqrt_rn(acc[i][j]) : __builtin_inf();
             }
         }
@@ -97,14 +104,8 @@ template <int RT, int DC>
 static void launch_join_t(const double *JCw, int Djpad, int64_t n_units, const int64_t *cand,
                           int64_t T, int K, double *J, hipStream_t s)
 {
-    const size_t shmem = (size_t)2 * 16 * RT * (DC + 1) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&join_cost_kernel<RT, DC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((join_cost_kernel<RT, DC>), dim3((unsigned)(T - 1)), dim3(256), shmem, s,
+    const int nb = (K + 8 * RT - 1) / (8 * RT);
+    hipLaunchKernelGGL((join_cost_kernel<RT, DC>), dim3((unsigned)(T - 1), nb, nb), dim3(64), 0, s,
                        JCw, Djpad, n_units, cand, T, K, J);
 }
 
@@ -112,14 +113,10 @@ void launch_join_costs(const double *JCw, int Djpad, int /*Dj*/, int64_t n_units
                        const int64_t *cand, int64_t T, int K, double *J, hipStream_t s)
 {
     if (T < 2) return;
-    const int need = (K + 15) / 16;
-    if (need <= 1) launch_join_t<1, 32>(JCw, Djpad, n_units, cand, T, K, J, s);
-    else if (need <= 2) launch_join_t<2, 32>(JCw, Djpad, n_units, cand, T, K, J, s);
-    else if (need <= 4) launch_join_t<4, 32>(JCw, Djpad, n_units, cand, T, K, J, s);
-    else if (need <= 5) launch_join_t<5, 32>(JCw, Djpad, n_units, cand, T, K, J, s);
-    else if (need <= 7) launch_join_t<7, 32>(JCw, Djpad, n_units, cand, T, K, J, s);
-    else if (need <= 10) launch_join_t<10, 32>(JCw, Djpad, n_units, cand, T, K, J, s);
-    else launch_join_t<13, 32>(JCw, Djpad, n_units, cand, T, K, J, s);   // K <= 208
+    if (K <= 16) launch_join_t<2, 16>(JCw, Djpad, n_units, cand, T, K, J, s);
+    else if (K <= 32) launch_join_t<4, 16>(JCw, Djpad, n_units, cand, T, K, J, s);
+    else if (K <= 40 || (K > 56 && K <= 80)) launch_join_t<5, 16>(JCw, Djpad, n_units, cand, T, K, J, s);
+    else launch_join_t<7, 16>(JCw, Djpad, n_units, cand, T, K, J, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,166 @@
+"""Host-side target preparation and file conventions of the reference, restated for Python 3.
+
+These are the steps either side of the search path (a1, a2, a5) that a drop-in
+must reproduce bit for bit so that the engine receives the same query vectors and finds the
+same database file.  Plain numpy, no GPU involved.
+"""
+import os
+import numpy as np
+
+SPECIAL_UV_VALUE = -1000.0        # const.py:13
+UV_SCALING_FACTOR = 20.0          # const.py:15
+VUV_STREAM_NAMES = ['f0', 'lf0']  # const.py:9
+TARGET_REP_WIDTHS = {'onepoint': 1, 'twopoint': 2, 'threepoint': 3, 'epoch': 1, 'sample': 1}  # const.py:17
+
+
+def load_config(config_file):
+    """A config is a Python source file exec'd into a dict (synth_simple.py:56-58)."""
+    config = {}
+    with open(config_file) as f:
+        exec(compile(f.read(), config_file, 'exec'), config)
+    del config['__builtins__']
+    return config
+
+
+def make_train_condition_name(config):
+    """file_naming.py:20-31."""
+    if not config['target_representation'] == 'sample':
+        jstreams = '-'.join(config['stream_list_join'])
+        tstreams = '-'.join(config['stream_list_target'])
+        return '%s_utts_jstreams-%s_tstreams-%s_rep-%s' % (
+            config['n_train_utts'], jstreams, tstreams, config.get('target_representation', 'twopoint'))
+    streams = '-'.join(config['stream_list_target'])
+    return '%s_utts_streams-%s_rep-%s' % (config['n_train_utts'], streams,
+                                          config.get('target_representation', 'twopoint'))
+
+
+def get_data_dump_name(config):
+    """file_naming.py:5-18 (without creating directories)."""
+    return os.path.join(config['workdir'], 'data_dumps', make_train_condition_name(config) + '.hdf5')
+
+
+def make_synthesis_condition_name(config):
+    """file_naming.py:33-67."""
+    smooth = 'smooth_' if config.get('synth_smooth', False) else ''
+    greedy = 'greedy-yes_' if config.get('greedy_search', False) else 'greedy-no_'
+    target_weights = '-'.join([str(val) for val in config['target_stream_weights']])
+    if config['target_representation'] == 'sample':
+        return 'sample_target-%s' % (target_weights)
+    join_weights = '-'.join([str(val) for val in config['join_stream_weights']])
+    name = '%s%starget-%s_join-%s_scale-%s_presel-%s_jmetric-%s_cand-%s_taper-%s' % (
+        greedy, smooth, target_weights, join_weights, config['join_cost_weight'],
+        config['preselection_method'], config.get('join_cost_type', 'natural2'),
+        config.get('n_candidates', 30), config.get('taper_length', 50))
+    name += 'multiepoch-%s' % (config.get('multiepoch', 1))
+    return name
+
+
+def get_speech(infile, dim):
+    """speech_manip.py:102-111: raw little-endian float32 matrix."""
+    data = np.fromfile(infile, dtype=np.float32)
+    assert data.size % float(dim) == 0.0, 'specified dimension %s not compatible with data' % (dim)
+    return data.reshape((-1, dim))
+
+
+def locate_stream_directories(directories, streams):
+    """data_manipulation.py:72-92."""
+    stream_directories = {}
+    for stream in streams:
+        for directory in directories:
+            candidate_dir = os.path.join(directory, stream)
+            if os.path.isdir(candidate_dir):
+                if stream in stream_directories:
+                    raise ValueError('Found at least 2 directories for stream %s: %s and %s' % (
+                        stream, stream_directories[stream], candidate_dir))
+                stream_directories[stream] = candidate_dir
+    for stream in streams:
+        if stream not in stream_directories:
+            raise ValueError('No subdirectory found under %s for stream %s' % (','.join(directories), stream))
+    return stream_directories
+
+
+def compose_speech(feat_dir_dict, base, stream_list, datadims, ignore_streams=('triphone',)):
+    """data_manipulation.py:12-70: hstack the streams, unvoiced (<= 0) lf0/f0 -> -1000, trim to
+    the shortest stream.  A missing file is signalled by a (1,1) zero matrix, as in the reference."""
+    stream_list = [s for s in stream_list if s not in ignore_streams]
+    stream_data_list = []
+    for stream in stream_list:
+        fname = os.path.join(feat_dir_dict[stream], base + '.' + stream)
+        if not os.path.isfile(fname):
+            return np.zeros((1, 1))
+        data = get_speech(fname, datadims[stream])
+        if stream == 'aef':
+            data = np.vstack([np.zeros((1, datadims[stream])), data, np.zeros((1, datadims[stream]))])
+        if stream in VUV_STREAM_NAMES:
+            data[data <= 0.0] = SPECIAL_UV_VALUE
+        stream_data_list.append(data)
+    nframe = min(d.shape[0] for d in stream_data_list)
+    return np.hstack([d[:nframe, :] for d in stream_data_list])
+
+
+def standardise(speech, mean_vec, std_vec):
+    """data_manipulation.py:162-186: (x - mean) / std; unvoiced cells become std * -20."""
+    uv_positions = (speech == SPECIAL_UV_VALUE)
+    mean_vec = np.asarray(mean_vec).reshape((1, -1))
+    std_vec = np.asarray(std_vec).reshape((1, -1))
+    speech = (speech - mean_vec) / std_vec
+    uv_values = std_vec * -1.0 * UV_SCALING_FACTOR
+    for column in range(speech.shape[1]):
+        speech[:, column][uv_positions[:, column]] = uv_values[0, column]
+    return speech
+
+
+def weight(speech, weight_vec):
+    """speech_manip.py:209-213."""
+    return speech * np.array(weight_vec).reshape((1, -1))
+
+
+def stream_weight_vector(weights, stream_list, datadims):
+    vec = []
+    for i, stream in enumerate(stream_list):
+        vec.extend([weights[i]] * datadims[stream])
+    return vec
+
+
+def get_selection_vector(stream_list, stream_dims, truncation_values):
+    """synth_simple.py:968-980."""
+    assert len(truncation_values) == len(stream_list), (truncation_values, stream_list)
+    selection_vector = []
+    start = 0
+    for stream, trunc in zip(stream_list, truncation_values):
+        stream_dim = stream_dims[stream]
+        if trunc == -1:
+            trunc = stream_dim
+        assert trunc <= stream_dim, 'stream %s has only %s dims, cannot truncate to %s' % (stream, stream_dim, trunc)
+        selection_vector.extend(range(start, start + trunc))
+        start += stream_dim
+    return selection_vector
+
+
+def load_database(datafile):
+    """The train_simple.py / train_halfphone.py unit database as a dict of arrays.
+
+    Tries h5py on the .hdf5 itself; without h5py (the default interpreter of this image has
+    none) falls back to ``<datafile>.npz`` written by tools/hdf5_to_npz.py."""
+    wanted = ['train_unit_features', 'train_unit_names', 'filenames', 'mean_target', 'std_target',
+              'mean_join', 'std_join', 'join_contexts', 'unit_index_within_sentence_dset', 'cutpoints',
+              'duration_monophones', 'duration_stats']
+    try:
+        import h5py
+    except ImportError:
+        h5py = None
+    if h5py is not None and os.path.isfile(datafile):
+        out = {}
+        with h5py.File(datafile, 'r') as f:
+            for k in wanted:
+                if k in f:
+                    out[k] = f[k][...]
+        return out
+    npz = datafile + '.npz'
+    if os.path.isfile(npz):
+        z = np.load(npz, allow_pickle=False)
+        return dict((k, z[k]) for k in z.files)
+    if os.path.isfile(datafile):
+        raise RuntimeError('%s exists but this interpreter has no h5py; convert it once with\n'
+                           '  /opt/conda/bin/python3.9 tools/hdf5_to_npz.py %s' % (datafile, datafile))
+    raise RuntimeError('data: \n   %s   \ndoes not exist -- try other?' % (datafile))

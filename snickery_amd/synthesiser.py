@@ -1,0 +1,412 @@
+"""Drop-in ``Synthesiser`` for the SEARCH path of Snickery's script/synth_simple.py and
+script/synth_halfphone.py: same config files, same unit database, same method names,
+arguments and return values -- the search itself runs on the MI355X through libsnkhip.so.
+
+Scope: config load, database load, stream weighting/truncation, multiepoch
+greedy search, acoustic / class-restricted preselection, join lattice + Viterbi, per-stream
+scores, sentence selection, ``.trace``-style path output.  Waveform generation (magphase
+concatenation, after the search) is outside the path and is NOT performed: ``synth_utt``
+returns the selected unit path.
+
+flavour='simple'    mirrors synth_simple.Synthesiser  (greedy only, synth_simple.py:48-185)
+flavour='halfphone' mirrors synth_halfphone.Synthesiser with target_representation == 'epoch'
+                    (greedy or preselect + Viterbi, synth_halfphone.py:151-415).
+"""
+import glob
+import os
+import timeit
+
+import numpy as np
+
+from . import hostprep as hp
+from .engine import HipSearchEngine
+
+APPLY_JCW_ON_TOP = True          # synth_simple.py:43, synth_halfphone.py (same flag)
+LABEL_DELIMITER = '/'            # const.py:6
+VERY_BIG_WEIGHT_VALUE = 1000000000000000.0
+
+
+class Synthesiser(object):
+
+    def __init__(self, config_file, holdout_percent=0.0, flavour=None, device=0, verbose=True):
+        self.mode_of_operation = 'normal'
+        self.verbose = verbose
+        self.config = hp.load_config(config_file)
+        self.config_file = config_file
+        if flavour is None:
+            flavour = 'simple' if self.config.get('greedy_search', False) else 'halfphone'
+        assert flavour in ('simple', 'halfphone')
+        self.flavour = flavour
+
+        self.stream_list_target = self.config['stream_list_target']
+        self.stream_list_join = self.config['stream_list_join']
+        self.datadims_target = self.config['datadims_target']
+        self.datadims_join = self.config['datadims_join']
+        self.target_representation = 'epoch' if flavour == 'simple' else self.config['target_representation']
+
+        db = hp.load_database(hp.get_data_dump_name(self.config))
+        self.train_unit_features_unweighted = np.asarray(db['train_unit_features'])
+        self.train_unit_names = db['train_unit_names']
+        self.train_filenames = db['filenames']
+        self.mean_vec_target = db['mean_target']
+        self.std_vec_target = db['std_target']
+        self.mean_vec_join = db['mean_join']
+        self.std_vec_join = db['std_join']
+        self.join_contexts_unweighted = np.asarray(db['join_contexts'])
+        self.unit_index_within_sentence = db.get('unit_index_within_sentence_dset')
+        self.train_cutpoints = db.get('cutpoints')      # absent from train_simple DBs
+        self.number_of_units = self.train_unit_features_unweighted.shape[0]
+
+        self.holdout_percent = holdout_percent
+        self.holdout_samples = 0
+        if holdout_percent > 0.0:
+            hs = int(self.number_of_units * (holdout_percent / 100.0))
+            self.train_unit_features_unweighted_dev = self.train_unit_features_unweighted[-hs:, :]
+            self.train_unit_features_unweighted = self.train_unit_features_unweighted[:-hs, :]
+            self.train_unit_names_dev = self.train_unit_names[-hs:]
+            self.train_unit_names = self.train_unit_names[:-hs]
+            # the join rows of the held-out units are dropped with them (synth_simple.py:253-255)
+            self.join_contexts_unweighted = self.join_contexts_unweighted[:-hs, :]
+            self.number_of_units -= hs
+            self.holdout_samples = hs
+
+        # join layout: synth_halfphone doubles the join weight vector for an epoch database from
+        # train_halfphone.py whose rows are [j_t, j_{t+1}] (synth_halfphone.py:693-695)
+        dj = sum(self.datadims_join[s] for s in self.stream_list_join)
+        self._double_join = (self.join_contexts_unweighted.shape[1] == 2 * dj)
+        if not self._double_join and self.join_contexts_unweighted.shape[1] != dj:
+            raise ValueError('join_contexts has %d columns, streams give %d' % (
+                self.join_contexts_unweighted.shape[1], dj))
+
+        self.engine = HipSearchEngine(device)      # raises: no CPU fallback
+        self.engine.upload_db(self.train_unit_features_unweighted, self.join_contexts_unweighted)
+
+        self._target_stream_w = None
+        self._join_stream_w = None
+        self._target_trunc = None
+        self._join_trunc = None
+        if APPLY_JCW_ON_TOP:
+            self.set_target_weights(np.array(self.config['target_stream_weights']) * (1.0 - self.config['join_cost_weight']), _apply=False)
+            self.set_join_weights(np.array(self.config['join_stream_weights']) * self.config['join_cost_weight'], _apply=False)
+        else:
+            self.set_target_weights(self.config['target_stream_weights'], _apply=False)
+            self.set_join_weights(self.config['join_stream_weights'], _apply=False)
+        if flavour == 'simple':
+            if 'truncate_target_streams' in self.config:
+                self.truncate_target_streams(self.config['truncate_target_streams'], _apply=False)
+            if 'truncate_join_streams' in self.config:
+                self.truncate_join_streams(self.config['truncate_join_streams'], _apply=False)
+        self._apply_weights()
+
+        self.first_silent_unit = 0
+        if self.target_representation == 'epoch':
+            self.config['preselection_method'] = 'acoustic'
+        if flavour == 'simple':
+            assert self.config['greedy_search'] is True
+        if self.config.get('greedy_search', False):
+            if self.config.get('multiple_search_trees', 1) > 1:
+                raise SystemExit('multiple_search_trees not implemented yet -- try adjusting search_epsilon instead to speed up search')
+            self.get_tree_for_greedy_search()
+        elif self.config.get('preselection_method') == 'monophone_then_acoustic':
+            self._setup_monophone_classes()
+
+        self.test_data_target_dirs = hp.locate_stream_directories(self.config['test_data_dirs'], self.stream_list_target)
+        if self.config.get('tune_data_dirs', ''):
+            self.tune_data_target_dirs = hp.locate_stream_directories(self.config['tune_data_dirs'], self.stream_list_target)
+
+    # ------------------------------------------------------------------ weights
+    def set_join_weights(self, weights, _apply=True):
+        """synth_simple.py:234-255 / synth_halfphone.py:682-707."""
+        assert len(weights) == len(self.stream_list_join)
+        vec = hp.stream_weight_vector(list(weights), self.stream_list_join, self.datadims_join)
+        if self._double_join:
+            vec = vec + vec
+        self.join_weight_vector = np.array(vec, dtype=np.float64)
+        if _apply:
+            self._apply_weights()
+
+    def set_target_weights(self, weights, _apply=True):
+        """synth_simple.py:257-274 / synth_halfphone.py:713-737."""
+        assert len(weights) == len(self.stream_list_target), (weights, self.stream_list_target)
+        vec = hp.stream_weight_vector(list(weights), self.stream_list_target, self.datadims_target)
+        vec = vec * hp.TARGET_REP_WIDTHS[self.target_representation]
+        if self.config.get('add_duration_as_target', False):
+            vec.append(self.config.get('duration_target_weight', 0.0))
+        self.target_weight_vector = np.array(vec, dtype=np.float64)
+        if _apply:
+            self._apply_weights()
+
+    def truncate_join_streams(self, truncation_values, _apply=True):
+        """synth_simple.py:982-985.  Dropping columns == zero weight + zero query column: both
+        add exactly +0.0 to every squared distance, in the same column order."""
+        self._join_trunc = hp.get_selection_vector(self.stream_list_join, self.datadims_join, truncation_values)
+        if _apply:
+            self._apply_weights()
+
+    def truncate_target_streams(self, truncation_values, _apply=True):
+        """synth_simple.py:987-992."""
+        self._target_trunc = hp.get_selection_vector(self.stream_list_target, self.datadims_target, truncation_values)
+        self.target_truncation_vector = self._target_trunc
+        if _apply:
+            self._apply_weights()
+
+    def _apply_weights(self):
+        wt = self.target_weight_vector.copy()
+        if self._target_trunc is not None:
+            keep = np.zeros(wt.size, dtype=bool)
+            keep[self._target_trunc] = True
+            wt[~keep] = 0.0
+        wj = self.join_weight_vector.copy()
+        if self._join_trunc is not None:
+            keep = np.zeros(wj.size, dtype=bool)
+            n1 = len(hp.stream_weight_vector([1] * len(self.stream_list_join), self.stream_list_join, self.datadims_join))
+            for off in ([0, n1] if self._double_join else [0]):
+                keep[np.array(self._join_trunc) + off] = True
+            wj[~keep] = 0.0
+        self._device_wt, self._device_wj = wt, wj
+        self.engine.set_weights(wt, wj)      # O(N*D) on device, no index rebuild
+
+    def _mask_query(self, unit_features):
+        if self._target_trunc is None:
+            return unit_features
+        q = np.zeros_like(unit_features)
+        q[:, self._target_trunc] = unit_features[:, self._target_trunc]
+        return q
+
+    # ------------------------------------------------------------------ search
+    def get_tree_for_greedy_search(self):
+        """synth_simple.py:190-229 / synth_halfphone.py:539-609: nothing is built -- the engine
+        addresses the windowed database in place."""
+        self.engine.set_greedy_layout(self.config.get('multiepoch', 1),
+                                      self.config.get('last_frame_as_target', False),
+                                      1 if (self.flavour == 'halfphone' and self._double_join) else 0)
+
+    def greedy_joint_search(self, unit_features, start_state=-1, holdout=[]):
+        """synth_simple.py:458-503."""
+        assert self.config['target_representation'] == 'epoch'
+        t = self.start_clock('Greedy search')
+        unit_features = np.asarray(unit_features, dtype=np.float64)
+        if self._target_trunc is not None and unit_features.shape[1] == len(self._target_trunc):
+            full = np.zeros((unit_features.shape[0], self.target_weight_vector.size))
+            full[:, self._target_trunc] = unit_features
+            unit_features = full
+        path = self.engine.greedy(unit_features, start_state=start_state,
+                                  search_epsilon=self.config.get('search_epsilon', 0.0))
+        self.stop_clock(t)
+        return path
+
+    def preselect_units_acoustic(self, unit_features):
+        """synth_halfphone.py:1359-1366."""
+        t = self.start_clock('Acoustic select units ')
+        candidates, distances = self.engine.knn(np.asarray(unit_features, dtype=np.float64), self.config['n_candidates'])
+        self.stop_clock(t)
+        return (candidates, distances)
+
+    def _setup_monophone_classes(self):
+        """Per-phone trees of synth_halfphone.py:385-402 become one class id per unit."""
+        names = [n.decode() if isinstance(n, bytes) else str(n) for n in self.train_unit_names]
+        monophones = [n.split(LABEL_DELIMITER)[2] for n in names]
+        self.monophone_ids = dict((m, i) for i, m in enumerate(sorted(set(monophones))))
+        self.engine.set_unit_classes(np.array([self.monophone_ids[m] for m in monophones], dtype=np.int32))
+
+    def preselect_units_monophone_then_acoustic(self, unit_features, unit_names):
+        """synth_halfphone.py:1369-1396."""
+        t = self.start_clock('Preselect units ')
+        if not hasattr(self, 'monophone_ids'):
+            self._setup_monophone_classes()
+        monophones = [q.split(LABEL_DELIMITER)[2] for q in unit_names]
+        assert len(monophones) == unit_features.shape[0], (len(monophones), unit_features.shape[0])
+        for phone in monophones:
+            assert phone in self.monophone_ids, 'unseen monophone %s' % (phone)
+        qc = np.array([self.monophone_ids[m] for m in monophones], dtype=np.int32)
+        out = self.engine.knn_by_class(np.asarray(unit_features, dtype=np.float64), self.config['n_candidates'], qc)
+        self.stop_clock(t)
+        return out
+
+    def viterbi_search(self, candidates, distances):
+        """synth_halfphone.py:1399-1436."""
+        t = self.start_clock('Compose and find shortest path')
+        best_path, cost = self.engine.viterbi(candidates, distances)
+        self.stop_clock(t)
+        self.last_path_cost = cost
+        self.report('got shortest path:')
+        self.report(best_path)
+        return best_path
+
+    # ------------------------------------------------------------------ drivers
+    def get_sentence_set(self, set_name):
+        """synth_simple.py:287-339."""
+        assert set_name in ['test', 'tune']
+        first_stream = self.stream_list_target[0]
+        if set_name == 'test':
+            data_dirs = self.test_data_target_dirs[first_stream]
+            name_patterns = self.config.get('test_patterns', [])
+            limit = self.config['n_test_utts']
+        else:
+            data_dirs = self.tune_data_target_dirs[first_stream]
+            name_patterns = self.config.get('tune_patterns', [])
+            limit = self.config['n_tune_utts']
+        flist = sorted(glob.glob(data_dirs + '/*.' + first_stream))
+        flist = [os.path.split(f)[-1].rsplit('.', 1)[0] for f in flist]
+        if name_patterns:
+            selected = []
+            for fname in flist:
+                for pattern in name_patterns:
+                    if pattern in fname and fname not in selected:
+                        selected.append(fname)
+            flist = selected
+        train_names = set(n.decode() if isinstance(n, bytes) else str(n) for n in np.unique(self.train_filenames))
+        flist = [n for n in flist if n not in train_names]
+        if limit > 0:
+            flist = flist[:limit]
+        return flist
+
+    def synth_from_config(self, synth_type='test', outdir=''):
+        """synth_simple.py:279-284: returns {utterance: path}."""
+        return dict((f, self.synth_utt(f, synth_type=synth_type, outdir=outdir)) for f in self.get_sentence_set(synth_type))
+
+    def prepare_targets(self, base, synth_type='test'):
+        """Target preparation of synth_utt (synth_simple.py:370-396, synth_halfphone.py:1507-1552)."""
+        data_dirs = self.test_data_target_dirs if synth_type == 'test' else self.tune_data_target_dirs
+        unnorm_speech = hp.compose_speech(data_dirs, base, self.stream_list_target, self.config['datadims_target'])
+        if self.config.get('standardise_target_data', True):
+            speech = hp.standardise(unnorm_speech, self.mean_vec_target, self.std_vec_target)
+        else:
+            speech = unnorm_speech
+        if self.flavour == 'simple':
+            unit_features = speech[1:-1, :] if self.config.get('REPLICATE_IS2018_EXP', False) else speech
+        else:
+            if self.config['target_representation'] != 'epoch':
+                raise NotImplementedError('label-driven halfphone target preparation (read_label / '
+                                          'get_halfphone_stats) is outside this build: pass prepared '
+                                          'unit_features to the preselect_* methods')
+            unit_features = speech[1:-1, :]
+        if self.flavour == 'simple' or self.config.get('weight_target_data', True):
+            unit_features = hp.weight(unit_features, self.target_weight_vector)
+        return self._mask_query(unit_features)
+
+    def synth_utt(self, base, synth_type='tune', outstem='', outdir=''):
+        """Search part of synth_utt (synth_simple.py:342-456 / synth_halfphone.py:1478-1696).
+        Returns the unit path, or (tscores, jscores) in 'stream_weight_balancing' mode."""
+        t = self.start_clock('Get speech ')
+        unit_features = self.prepare_targets(base, synth_type)
+        self.stop_clock(t)
+        if self.config.get('greedy_search', False):
+            assert self.config.get('target_representation') == 'epoch'
+            best_path = self.greedy_joint_search(unit_features)
+        else:
+            method = self.config['preselection_method']
+            if method == 'acoustic':
+                candidates, distances = self.preselect_units_acoustic(unit_features)
+            else:
+                raise SystemExit('preselection_method %s needs unit labels: call the preselect_* method directly' % method)
+            if self.mode_of_operation == 'find_join_candidates':
+                return candidates
+            best_path = self.viterbi_search(candidates, distances)
+        if self.mode_of_operation == 'stream_weight_balancing':
+            return (self.get_target_scores_per_stream(unit_features, best_path),
+                    self.get_join_scores_per_stream(best_path))
+        if self.config.get('get_selection_info', False) and (outdir or outstem):
+            stem = outstem or os.path.join(outdir, base)
+            with open(stem + '.trace.txt', 'w') as f:
+                for line in self.get_path_information_epoch(unit_features, best_path):
+                    f.write(line + '\n')
+        return best_path
+
+    # ------------------------------------------------------------------ scores / info
+    def _aggregate(self, sq_errs, stream_list, datadims, reps=1):
+        """aggregate_squared_errors_by_stream (synth_halfphone.py:2977-3008)."""
+        out, start = [], 0
+        width = sum(datadims[s] for s in stream_list)
+        for stream in stream_list:
+            w = datadims[stream]
+            acc = 0.0
+            for r in range(reps):
+                acc = acc + sq_errs[:, r * width + start: r * width + start + w].sum(axis=1)
+            out.append(acc)
+            start += w
+        return np.vstack(out).T
+
+    def get_target_scores_per_stream(self, target_features, best_path):
+        me = self.config.get('multiepoch', 1) if self.config.get('greedy_search', False) else 1
+        nep = 2 if (me > 1 and self.config.get('last_frame_as_target', False)) else me
+        mode = 1 if self.config.get('greedy_search', False) else 0
+        tsq, _ = self.engine.path_scores(np.asarray(target_features, dtype=np.float64)[:len(best_path) * me],
+                                         best_path, mode, nep * self.target_weight_vector.size,
+                                         self._join_score_cols(mode))
+        return self._aggregate(tsq, self.stream_list_target, self.datadims_target, reps=nep)
+
+    def _join_score_cols(self, mode):
+        n = self.join_weight_vector.size
+        return n // 2 if (mode == 1 and self.flavour == 'halfphone' and self._double_join) else n
+
+    def get_join_scores_per_stream(self, best_path):
+        me = self.config.get('multiepoch', 1) if self.config.get('greedy_search', False) else 1
+        mode = 1 if self.config.get('greedy_search', False) else 0
+        nep = 2 if (me > 1 and self.config.get('last_frame_as_target', False)) else me
+        dummy = np.zeros((len(best_path) * me, self.target_weight_vector.size))
+        _, jsq = self.engine.path_scores(dummy, best_path, mode, nep * self.target_weight_vector.size,
+                                         self._join_score_cols(mode))
+        reps = 2 if (self._double_join and mode == 0) else 1
+        return self._aggregate(jsq, self.stream_list_join, self.datadims_join, reps=reps)
+
+    def get_path_information_epoch(self, target_features, best_path):
+        """'<filename> <index_within_sentence>' per selected unit (the .trace.txt artefact)."""
+        lines = []
+        for p in best_path:
+            fn = self.train_filenames[p]
+            fn = fn.decode() if isinstance(fn, bytes) else str(fn)
+            ix = int(self.unit_index_within_sentence[p]) if self.unit_index_within_sentence is not None else int(p)
+            lines.append('%s %s' % (fn, ix))
+        return lines
+
+    # ------------------------------------------------------------------ reconfiguration
+    def reconfigure_settings(self, changed_config_values):
+        """synth_simple.py:776-830: returns a description of what changed ('' if nothing).
+        Re-weighting is a device-side O(N*D) pass; no tree is rebuilt."""
+        assert self.config['target_representation'] == 'epoch'
+        assert self.config['greedy_search']
+        for key in ['join_stream_weights', 'target_stream_weights', 'join_cost_weight', 'search_epsilon',
+                    'multiepoch', 'magphase_use_target_f0', 'magphase_overlap',
+                    'truncate_target_streams', 'truncate_join_streams']:
+            assert key in changed_config_values, key
+        rebuild = False
+        description = ''
+        for item in ['join_cost_weight', 'join_stream_weights', 'target_stream_weights', 'multiepoch',
+                     'truncate_target_streams', 'truncate_join_streams']:
+            if self.config.get(item) != changed_config_values[item]:
+                description += '%s: %s -> %s\n' % (item, self.config.get(item), changed_config_values[item])
+                self.config[item] = changed_config_values[item]
+                rebuild = True
+        for item, default in [('search_epsilon', 1.0), ('magphase_use_target_f0', True), ('magphase_overlap', 0)]:
+            if self.config.get(item, default) != changed_config_values[item]:
+                description += '%s: %s -> %s\n' % (item, self.config.get(item, default), changed_config_values[item])
+                self.config[item] = changed_config_values[item]
+        if rebuild:
+            self.set_join_weights(np.array(self.config['join_stream_weights']) * self.config['join_cost_weight'], _apply=False)
+            self.set_target_weights(np.array(self.config['target_stream_weights']) * (1.0 - self.config['join_cost_weight']), _apply=False)
+            self.truncate_target_streams(self.config['truncate_target_streams'], _apply=False)
+            self.truncate_join_streams(self.config['truncate_join_streams'], _apply=False)
+            self._apply_weights()
+            self.get_tree_for_greedy_search()
+        return description
+
+    def reconfigure_from_config_file(self):
+        """synth_simple.py:834-852."""
+        return self.reconfigure_settings(hp.load_config(self.config_file))
+
+    # ------------------------------------------------------------------ clock / report
+    def report(self, msg):
+        if self.verbose:
+            print(msg)
+
+    def start_clock(self, comment):
+        return (timeit.default_timer(), comment)
+
+    def stop_clock(self, start):
+        start_time, comment = start
+        if self.verbose:
+            print('%s--> took %.2f seconds' % ((comment + '... ').ljust(45), timeit.default_timer() - start_time))
+
+    def close(self):
+        self.engine.close()

@@ -1,0 +1,81 @@
+"""GPU tests of the drop-in Synthesiser front end: driven through config file + unit database +
+stream files exactly like the reference's synth_simple.py / synth_halfphone.py."""
+import numpy as np
+import pytest
+
+import snk_oracle as o
+from voice_fixture import build_voice
+
+pytestmark = pytest.mark.gpu
+
+
+def test_synth_simple_flavour_reproduces_reference_paths(tmp_path, golden, mini_voice):
+    from snickery_amd.synthesiser import Synthesiser
+    for me in (6, 1):
+        cfgfile, config = build_voice(tmp_path, golden, greedy=True, multiepoch=me)
+        synth = Synthesiser(cfgfile, verbose=False)
+        assert synth.flavour == 'simple'
+        assert synth.get_sentence_set('test') == ['arctic_b0001']
+        paths = synth.synth_from_config()
+        assert np.array_equal(np.array(paths['arctic_b0001']), golden['greedy_me%d_utt0_path' % me])
+        p1 = synth.greedy_joint_search(golden['greedy_me%d_utt1_unit_features' % me])
+        assert np.array_equal(np.array(p1), golden['greedy_me%d_utt1_path' % me])
+        synth.close()
+
+
+def test_reconfigure_settings_and_scores(tmp_path, golden, mini_voice):
+    from snickery_amd.synthesiser import Synthesiser
+    cfgfile, config = build_voice(tmp_path, golden, greedy=True, multiepoch=3)
+    synth = Synthesiser(cfgfile, verbose=False)
+    new = dict(config)
+    new.update(join_stream_weights=[0.4, 0.3, 0.2, 0.1], target_stream_weights=[0.3, 0.7], join_cost_weight=0.35,
+               search_epsilon=0.0, multiepoch=4, magphase_use_target_f0=True, magphase_overlap=0,
+               truncate_target_streams=[40, -1], truncate_join_streams=[30, -1, 20, 1])
+    desc = synth.reconfigure_settings(new)
+    assert 'join_cost_weight: 0.2 -> 0.35' in desc and 'multiepoch: 3 -> 4' in desc
+    assert synth.reconfigure_settings(new) == ''
+    # oracle with the reference's own semantics: weight, then DROP the truncated columns
+    dims = {'lf0': 1, 'mag': 60, 'real': 45, 'imag': 45}
+    tw, jw = o.apply_jcw(new['target_stream_weights'], new['join_stream_weights'], new['join_cost_weight'])
+    wt = o.stream_weight_vector(list(tw), ['mag', 'lf0'], dims)
+    wj = o.stream_weight_vector(list(jw), ['mag', 'real', 'imag', 'lf0'], dims)
+    F, E, S = o.weighted_db(golden['F_unw'], golden['JC_unw'], wt, wj)
+    tsel = list(range(40)) + [60]
+    jsel = list(range(30)) + list(range(60, 105)) + list(range(105, 125)) + [150]
+    F, E, S = F[:, tsel], E[:, jsel], S[:, jsel]
+    pr, cr, Fwin = o.greedy_layout(F, E, S, 4)
+    synth.mode_of_operation = 'stream_weight_balancing'
+    tscores, jscores = synth.synth_utt('arctic_b0001', synth_type='test')
+    synth.mode_of_operation = 'normal'
+    path = synth.synth_utt('arctic_b0001', synth_type='test')
+    U = synth.prepare_targets('arctic_b0001')[:, tsel]
+    op, _ = o.greedy_search(pr, cr, Fwin, o.greedy_queries(U, 4))
+    assert path == op
+    # per-stream scores (what balance_stream_weights.py consumes)
+    ot = o.target_scores(Fwin, o.greedy_queries(U, 4), op)
+    oj = o.join_scores_greedy(pr, cr, op)
+    assert tscores.shape == (len(op), 2) and jscores.shape == (len(op) - 1, 4)
+    np.testing.assert_allclose(tscores.sum(), ot.sum(), rtol=1e-12)
+    np.testing.assert_allclose(jscores.sum(), oj.sum(), rtol=1e-12)
+    synth.close()
+
+
+def test_halfphone_flavour_viterbi(tmp_path, golden, mini_voice):
+    """greedy_search=False: preselect + Viterbi on a train_simple database (the combination
+    BASELINE config 2 describes; parity against the oracle)."""
+    from snickery_amd.synthesiser import Synthesiser
+    cfgfile, config = build_voice(tmp_path, golden, greedy=False, multiepoch=1, n_candidates=12)
+    synth = Synthesiser(cfgfile, verbose=False)
+    assert synth.flavour == 'halfphone'
+    U = synth.prepare_targets('arctic_b0001')
+    assert np.array_equal(U, golden['greedy_me6_utt0_unit_features'][1:-1])     # speech[1:-1] (:1525)
+    cand, dist = synth.preselect_units_acoustic(golden['knn_queries'])
+    assert np.array_equal(cand, golden['knn_candidates'])
+    path = synth.viterbi_search(golden['join_candidates'], golden['knn_distances'])
+    opath, ocost = o.viterbi(golden['join_candidates'], golden['knn_distances'], mini_voice['E'], mini_voice['S'])
+    assert path == opath and synth.last_path_cost == ocost
+    full = synth.synth_utt('arctic_b0001', synth_type='test')
+    oc, od = o.knn_bruteforce(mini_voice['F'], U, 12)
+    op, _ = o.viterbi(oc, od, mini_voice['E'], mini_voice['S'])
+    assert full == op
+    synth.close()

@@ -200,6 +200,29 @@ def test_viterbi_batch_equals_single(engine):
         assert p == op and c == ocst
 
 
+def test_viterbi_batch_redo_on_overflow(engine):
+    """Batch pipeline with deferred K-NN status: an utterance whose sampled thresholds overflow a
+    candidate list is redone with exact thresholds at the end of the batch."""
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(30000, 61, 40, seed=13)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    utts = [o.synthetic_targets(F_unw, T, seed=s) * wt for s, T in [(1, 33), (2, 48), (3, 20)]]
+    engine.set_option('list_capacity', 192)
+    engine.set_option('sample_fraction', 1.0 / 64)
+    try:
+        before = engine.info('batch_redos')
+        paths, costs = engine.knn_viterbi_batch(utts, 20)
+        redos = engine.info('batch_redos') - before
+    finally:
+        engine.set_option('list_capacity', 4096)
+        engine.set_option('sample_fraction', 1.0 / 16)
+    assert redos >= 1
+    for u, U in enumerate(utts):
+        oc, od = o.knn_bruteforce(F, U, 20)
+        op, ocst = o.viterbi(oc, od, E, S)
+        assert list(paths[u]) == op and costs[u] == ocst
+
+
 def test_greedy_golden(mini_engine, golden, mini_voice):
     for me in (6, 1):
         mini_engine.set_greedy_layout(me, False, 0)
