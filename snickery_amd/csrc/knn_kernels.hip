@@ -44,7 +44,7 @@ __device__ __forceinline__ int frag_row(int lane, int r) { return (lane >> 4) + 
 template <int NT, int DCH, int MODE, bool CLS, int WPS>
 __global__ void __launch_bounds__(256, WPS)
 knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
-          const double *__restrict__ Qp, const double *__restrict__ thr,
+          const double *__restrict__ Qf, const double *__restrict__ thr,
           int nQT, int64_t row_stride, int64_t row_limit, int64_t n_slabs,
           int64_t wave_stride, int64_t tile_stride, unsigned int *__restrict__ slab_counter,
           int qsplit,
@@ -55,6 +55,12 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
 {
     constexpr int KS = DCH * 16;          // MFMA k-steps per output tile
     constexpr int DP = DCH * 64;          // padded feature columns
+    // per-wave LDS staging of passing entries: the MFMA loop itself issues no vector-memory
+    // stores (stores share vmcnt with the query prefetch, and the rotate's wait would stall on
+    // a store issued late in the tile); the stage is flushed to the pool at the next tile top,
+    // a whole tile before anything waits on vmcnt again
+    constexpr int STAGE_CAP = 64 * (((WPS >= 2) ? 1 : ((NT >= 2) ? 2 : 1)) * 4) + 256;  // one step's worst case + slack
+    __shared__ PoolEntry stage[(MODE == 1) ? 4 : 1][(MODE == 1) ? STAGE_CAP : 1];
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -74,6 +80,7 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
     // pool_ctl[0] = chunks handed out, pool_ctl[1] = overflow flag.
     int chunk_id = -1;
     int cused = POOL_CHUNK;      // forces a chunk grab before the first append
+    int lcount = 0;              // entries waiting in this wave's LDS stage
     auto new_chunk = [&]() {
         if (chunk_id >= 0 && lane == 0) chunk_fill[chunk_id] = cused;
         unsigned int c = 0;
@@ -86,6 +93,16 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
             chunk_id = (int)c;
         }
         cused = 0;
+    };
+
+    auto flush_stage = [&]() {
+        if (cused + lcount > POOL_CHUNK) new_chunk();
+        if (chunk_id >= 0) {
+            for (int e = lane; e < lcount; e += 64)
+                pool[(int64_t)chunk_id * POOL_CHUNK + cused + e] = stage[wv][e];
+        }
+        cused += lcount;
+        lcount = 0;
     };
 
     // work item = (slab, part): the query tiles of a slab may be split over `qsplit` items so that
@@ -137,13 +154,15 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
     double a_cur[KS], a_nxt[KS];
     double th_cur[4], th_nxt[4];
     int qc_cur[4], qc_nxt[4];
+    // query tiles are read from the FRAGMENT-ORDER copy Qf[tile][chunk][pair][lane][2]: every
+    // load instruction of the wave covers 1 KB of contiguous memory
     auto load_tile = [&](int t, double (&a)[KS], double (&th)[4], int (&qc)[4]) {
-        const double *src = Qp + ((int64_t)t * 16 + r16) * DP + 16 * g;
+        const double *src = Qf + (int64_t)t * (16 * DP) + lane * 2;
 #pragma unroll
         for (int ch = 0; ch < DCH; ++ch)
 #pragma unroll
             for (int s = 0; s < 16; s += 2) {
-                double2 v = *reinterpret_cast<const double2 *>(src + ch * 64 + s);
+                double2 v = *reinterpret_cast<const double2 *>(src + (ch * 8 + s / 2) * 128);
                 a[ch * 16 + s] = v.x;
                 a[ch * 16 + s + 1] = v.y;
             }
@@ -175,7 +194,7 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
     // Software pipeline over (tile, step): while the MFMA chain of one step issues, the VALU
     // epilogue of the PREVIOUS step (keys, threshold compares) runs in the MFMA shadows; only
     // the rare "some key passed" case branches, after the chain.
-    constexpr int CH = (WPS >= 2) ? 1 : 2;      // database tiles per step (independent chains)
+    constexpr int CH = (WPS >= 2) ? 1 : ((NT >= 2) ? 2 : 1);   // database tiles per step (independent MFMA chains)
     constexpr int NSTEP = NT / CH;
     constexpr int NEL = CH * 4;                  // results per lane per step
     constexpr int GAP = KS / NEL;                // MFMA k-steps between two epilogue elements
@@ -191,41 +210,26 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
 #pragma unroll
     for (int r = 0; r < 4; ++r) mn[r] = DBL_MAX;
 
-    // slow path of an epilogue: append the passing results of one finished step
-    auto append_step = [&](const double (&key)[NEL], const double (&th)[4], const int (&qc)[4],
-                           int nt0, int qtile) {
-        if (cused + 64 * NEL > POOL_CHUNK) new_chunk();
+    // one query tile: A holds this tile's fragments (prefetched a tile ago), A_load receives the
+    // next tile's.  The two register sets ping-pong (the tile loop is unrolled by two), so no
+    // fragment is ever copied.
+    auto tile_body = [&](double (&A)[KS], double (&A_load)[KS], int it) {
+        // the one vmcnt wait per tile: everything outstanding here is a whole tile old
 #pragma unroll
-        for (int e = 0; e < NEL; ++e) {
-            const int j = e / 4, r = e % 4;
-            bool pass = key[e] <= th[r];
-            if (CLS) pass = pass && (ucls[nt0 + j] == qc[r]);
-            const unsigned long long m = __ballot(pass);
-            if (m) {
-                if (pass && chunk_id >= 0) {
-                    const int rank = __builtin_amdgcn_mbcnt_hi(
-                        (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    PoolEntry en;
-                    en.key = key[e];
-                    en.idx = (int)(base + (nt0 + j) * tile_stride + r16);
-                    en.row = qtile * 16 + frag_row(lane, r);
-                    pool[(int64_t)chunk_id * POOL_CHUNK + cused + rank] = en;
-                }
-                cused += __popcll(m);
-            }
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(A[s]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (MODE == 1) asm volatile("" : "+v"(th_nxt[r]));
+            if (CLS) asm volatile("" : "+v"(qc_nxt[r]));
+            th_cur[r] = th_nxt[r]; qc_cur[r] = qc_nxt[r];
         }
-    };
 
-    for (int it = 0; it < n_tiles; ++it) {
-        // rotate the query double buffer: the one vmcnt wait per tile
-#pragma unroll
-        for (int s = 0; s < KS; ++s) a_cur[s] = a_nxt[s];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { th_cur[r] = th_nxt[r]; qc_cur[r] = qc_nxt[r]; }
+        // entries staged during the previous tile go out now, a whole tile before the next wait
+        if (MODE == 1 && lcount) flush_stage();
 
         // prefetch the next tile (unconditional: the last one wraps and is simply unused)
         const int qt_next = (qt + 1 == qt_hi) ? qt_lo : qt + 1;
-        load_tile(qt_next, a_nxt, th_nxt, qc_nxt);
+        load_tile(qt_next, A_load, th_nxt, qc_nxt);
 
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
@@ -235,28 +239,41 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
             const double (&pth)[4] = (st > 0) ? th_cur : th_prev;
             const int (&pqc)[4] = (st > 0) ? qc_cur : qc_prev;
             const int pqt = (st > 0) ? qt : qt_prev;
-            double key[NEL];
-            bool anyv = false;
             d4 acc[CH];
 #pragma unroll
             for (int j = 0; j < CH; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+            // room in the LDS stage for this step's worst case (rarely taken)
+            if (MODE == 1 && lcount > STAGE_CAP - 64 * NEL) flush_stage();
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
 #pragma unroll
                 for (int j = 0; j < CH; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[s], b[st * CH + j][s], acc[j], 0, 0, 0);
-                if (s % GAP == 0 && s / GAP < NEL) {
+                    acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[s], b[st * CH + j][s], acc[j], 0, 0, 0);
+                if (s % GAP == (GAP > 1 ? 1 : 0) && s / GAP < NEL) {
+                    // one result of the PENDING step per MFMA gap: key, threshold test and (for the
+                    // few that pass) a predicated 16-byte LDS store -- all in the MFMA shadow
                     const int e = s / GAP, j = e / 4, r = e % 4;
-                    key[e] = __builtin_fma(-2.0, pacc[j][r], fn[pnt + j]);
+                    const double key = __builtin_fma(-2.0, pacc[j][r], fn[pnt + j]);
                     bool ok = true;
                     if (CLS) ok = (ucls[pnt + j] == pqc[r]);
-                    if (MODE == 0) { if (ok) mn[r] = fmin(mn[r], key[e]); }
-                    else anyv = anyv || (ok && key[e] <= pth[r]);
+                    if (MODE == 0) { if (ok) mn[r] = fmin(mn[r], key); }
+                    else {
+                        const bool pass = ok && (key <= pth[r]);
+                        const unsigned long long m = __ballot(pass);
+                        if (pass) {
+                            const int rank = __builtin_amdgcn_mbcnt_hi(
+                                (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                            PoolEntry en;
+                            en.key = key;
+                            en.idx = (int)(base + (pnt + j) * tile_stride + r16);
+                            en.row = pqt * 16 + frag_row(lane, r);
+                            stage[wv][lcount + rank] = en;
+                        }
+                        lcount += __popcll(m);
+                    }
                 }
             }
-            if (MODE == 1) {
-                if (__ballot(anyv)) append_step(key, pth, pqc, pnt, pqt);
-            } else if (st == 0) {
+            if (MODE == 0 && st == 0) {
                 // minima of the previous tile are complete now
                 if (it > 0) {
 #pragma unroll
@@ -273,24 +290,38 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
         for (int r = 0; r < 4; ++r) { th_prev[r] = th_cur[r]; qc_prev[r] = qc_cur[r]; }
         qt_prev = qt;
         qt = qt_next;
+    };
+    for (int it = 0; it < n_tiles; it += 2) {
+        tile_body(a_nxt, a_cur, it);
+        if (it + 1 < n_tiles) tile_body(a_cur, a_nxt, it + 1);
     }
     // drain the last pending step of this slab (not overlapped: once per slab)
     {
         const int pnt = (NSTEP - 1) * CH;
-        double key[NEL];
-        bool anyv = false;
+        if (MODE == 1 && lcount > STAGE_CAP - 64 * NEL) flush_stage();
 #pragma unroll
         for (int e = 0; e < NEL; ++e) {
             const int j = e / 4, r = e % 4;
-            key[e] = __builtin_fma(-2.0, pacc[j][r], fn[pnt + j]);
+            const double key = __builtin_fma(-2.0, pacc[j][r], fn[pnt + j]);
             bool ok = true;
             if (CLS) ok = (ucls[pnt + j] == qc_prev[r]);
-            if (MODE == 0) { if (ok) mn[r] = fmin(mn[r], key[e]); }
-            else anyv = anyv || (ok && key[e] <= th_prev[r]);
+            if (MODE == 0) { if (ok) mn[r] = fmin(mn[r], key); }
+            else {
+                const bool pass = ok && (key <= th_prev[r]);
+                const unsigned long long m = __ballot(pass);
+                if (pass) {
+                    const int rank = __builtin_amdgcn_mbcnt_hi(
+                        (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    PoolEntry en;
+                    en.key = key;
+                    en.idx = (int)(base + (pnt + j) * tile_stride + r16);
+                    en.row = qt_prev * 16 + frag_row(lane, r);
+                    stage[wv][lcount + rank] = en;
+                }
+                lcount += __popcll(m);
+            }
         }
-        if (MODE == 1) {
-            if (__ballot(anyv)) append_step(key, th_prev, qc_prev, pnt, qt_prev);
-        } else {
+        if (MODE == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 gmin[((int64_t)qt_prev * 16 + frag_row(lane, r)) * G + w * 16 + r16] = mn[r];
@@ -300,6 +331,7 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
     }   // work-item loop
 
     if (MODE == 1) {
+        if (lcount) flush_stage();
         if (chunk_id >= 0 && lane == 0) chunk_fill[chunk_id] = cused;
     }
 }
@@ -315,7 +347,7 @@ static void launch_sweep_t(int mode, bool cls, int blocks, hipStream_t s,
 {
 #define SNK_LAUNCH(MODE, CLS)                                                                    \
     hipLaunchKernelGGL((knn_sweep<NT, DCH, MODE, CLS, WPS>), dim3(blocks), dim3(256), 0, s, Fw,  \
-                       fnorm, Qp, thr, nQT, rstride, rlimit, ns, wstride, tstride, ctr, qsplit,  \
+                       fnorm, Qp, thr, nQT, rstride, rlimit, ns, wstride, tstride, ctr, qsplit,              \
                        gmin, G,                                                                   \
                        pool, pool_ctl, chunk_fill, max_chunks, uc, qc)
     if (mode == 0) { if (cls) SNK_LAUNCH(0, true); else SNK_LAUNCH(0, false); }
@@ -460,15 +492,24 @@ void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int
 // query preparation
 // ---------------------------------------------------------------------------
 __global__ void prepare_queries_kernel(const double *__restrict__ Q, int64_t T, int D,
-                                       double *__restrict__ Qp, double *__restrict__ qnorm,
-                                       int64_t Tpad, int Dpad)
+                                       double *__restrict__ Qp, double *__restrict__ Qf,
+                                       double *__restrict__ qnorm, int64_t Tpad, int Dpad)
 {
     const int64_t row = blockIdx.x;
     const int c = threadIdx.x;
     __shared__ double sq[256];
     double v = 0.0;
     if (row < T && c < D) v = Q[row * D + c];
-    if (c < Dpad) Qp[row * Dpad + c] = v;
+    if (c < Dpad) {
+        Qp[row * Dpad + c] = v;                       // row-major copy (exact re-rank)
+        // fragment-order copy for the sweep: element c of row (tile, r16) belongs to chunk ch,
+        // lane group g, k-step s: lane = g*16 + r16, pair = s/2, slot = s%2
+        const int64_t tile = row >> 4;
+        const int r16 = (int)(row & 15);
+        const int ch = c >> 6, g = (c >> 4) & 3, sidx = c & 15;
+        const int lane = g * 16 + r16;
+        Qf[tile * (16 * Dpad) + ((int64_t)(ch * 8 + (sidx >> 1)) * 64 + lane) * 2 + (sidx & 1)] = v;
+    }
     sq[c] = v * v;
     __syncthreads();
     if (c == 0) {
@@ -478,10 +519,10 @@ __global__ void prepare_queries_kernel(const double *__restrict__ Q, int64_t T, 
     }
 }
 
-void launch_prepare_queries(const double *Q, int64_t T, int D, double *Qp, double *qnorm,
+void launch_prepare_queries(const double *Q, int64_t T, int D, double *Qp, double *Qf, double *qnorm,
                             int64_t Tpad, int Dpad, hipStream_t s)
 {
-    hipLaunchKernelGGL(prepare_queries_kernel, dim3((unsigned)Tpad), dim3(256), 0, s, Q, T, D, Qp,
+    hipLaunchKernelGGL(prepare_queries_kernel, dim3((unsigned)Tpad), dim3(256), 0, s, Q, T, D, Qp, Qf,
                        qnorm, Tpad, Dpad);
 }
 

@@ -99,7 +99,7 @@ struct snk_engine {
     bool have_db = false, have_join = false, have_weights = false, have_classes = false;
     int64_t shard_offset = 0, global_N = -1;
     // k-nn workspace
-    DevBuf Qraw, Qp, qnorm, thr, gmin, cnt, lkey, lidx, status, qclass, d2tmp, slabctr, pool, poolctl, chunkfill;
+    DevBuf Qraw, Qp, Qf, qnorm, thr, gmin, cnt, lkey, lidx, status, qclass, d2tmp, slabctr, pool, poolctl, chunkfill;
     UttSlot slot[4];
     hipStream_t dp_stream[2] = {nullptr, nullptr};
     DevBuf res_path, res_plen, res_cost, Qall, res_status;
@@ -239,7 +239,7 @@ int snk_destroy(snk_handle h)
     (void)hipStreamSynchronize(h->stream2);
     collect_timers(h);
     DevBuf *bufs[] = {&h->F_unw, &h->JC_unw, &h->Fw, &h->fnorm, &h->JCw, &h->wt, &h->wj, &h->unit_class,
-                      &h->Qraw, &h->Qp, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
+                      &h->Qraw, &h->Qp, &h->Qf, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
                       &h->gpath, &h->gdist};
     for (auto *b : bufs) b->release();
@@ -409,6 +409,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
     KnnPlan p = p0;
     int64_t G = p.a_count * 16;
     CHK(h->Qp.ensure((size_t)Tpad * h->Dpad * sizeof(double)));
+    CHK(h->Qf.ensure((size_t)Tpad * h->Dpad * sizeof(double)));
     CHK(h->qnorm.ensure((size_t)Tpad * sizeof(double)));
     CHK(h->thr.ensure((size_t)Tpad * sizeof(double)));
     CHK(h->gmin.ensure((size_t)Tpad * G * sizeof(double)));
@@ -423,7 +424,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
     hipStream_t s = h->stream;
     {
         StageTimer t(h, s, TM_PREP);
-        launch_prepare_queries(Qdev, T, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(),
+        launch_prepare_queries(Qdev, T, h->Dt, h->Qp.as<double>(), h->Qf.as<double>(), h->qnorm.as<double>(),
                                Tpad, h->Dpad, s);
     }
     h->last_retries = 0;
@@ -444,7 +445,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         if (G >= K) {       // tiny databases: fewer than K groups cannot bound the K-th neighbour
             {
                 StageTimer t(h, s, TM_KNN_MINIMA);
-                launch_knn_minima(p, h->Fw.as<double>(), h->fnorm.as<double>(), h->Qp.as<double>(), Tpad,
+                launch_knn_minima(p, h->Fw.as<double>(), h->fnorm.as<double>(), h->Qf.as<double>(), Tpad,
                                   h->gmin.as<double>(), G, uc, qclass_dev, s);
             }
             {
@@ -456,7 +457,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         }
         {
             StageTimer t(h, s, TM_KNN_FILTER);
-            launch_knn_filter(p, h->Fw.as<double>(), h->fnorm.as<double>(), h->Qp.as<double>(),
+            launch_knn_filter(p, h->Fw.as<double>(), h->fnorm.as<double>(), h->Qf.as<double>(),
                               h->thr.as<double>(), Tpad, h->pool.p, h->poolctl.as<unsigned int>(),
                               h->chunkfill.as<int>(), max_chunks, uc, qclass_dev, s);
         }
@@ -526,7 +527,10 @@ int snk_knn(snk_handle h, const double *Q, int64_t T, int D, int K, int64_t *can
     UttSlot &s = h->slot[0];
     CHK(s.cand.ensure((size_t)T * K * sizeof(int64_t)));
     CHK(s.tdist.ensure((size_t)T * K * sizeof(double)));
-    CHK(knn_device(h, h->Qraw.as<double>(), T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
+    {
+        const int rc = knn_device(h, h->Qraw.as<double>(), T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr);
+        if (rc) { (void)hipStreamSynchronize(h->stream); collect_timers(h); return rc; }
+    }
     {
         StageTimer t(h, h->stream, TM_D2H);
         D2HPart parts[2] = {{cand_out, s.cand.p, (size_t)T * K * sizeof(int64_t)},

@@ -27,8 +27,9 @@ struct KnnPlan {
     unsigned int *slab_counter;  // device word: dynamic slab dispenser
 };
 
-void launch_prepare_queries(const double *Q, int64_t T, int D, double *Qp, double *qnorm,
+void launch_prepare_queries(const double *Q, int64_t T, int D, double *Qp, double *Qf, double *qnorm,
                             int64_t Tpad, int Dpad, hipStream_t s);
+// Qf = fragment-order copy of the padded queries (see prepare_queries_kernel)
 // stage A: per-(row, lane-group) minima over the sampled slabs
 void launch_knn_minima(const KnnPlan &p, const double *Fw, const double *fnorm,
                        const double *Qp, int64_t Tpad, double *gmin, int64_t G,
