@@ -159,6 +159,13 @@ def main():
         ms, launches = timers['knn_filter']
         avg_ms = ms / max(launches, 1)
         flops = 2.0 * T * n_local * Dt          # algorithmic: SURVEY 8d, per utterance, this rank's shard
+        # HBM bytes per launch from the committed PMC passes (separate --pmc runs, FETCH_SIZE
+        # doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for the profiled shape
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        if world == 1 and N == 1048576 and Dt == 61 and os.path.isfile(tfile):
+            with open(tfile) as f:
+                traffic = json.load(f)['hbm_bytes_per_launch']
         achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             'metric': 'synthesised frames/sec, full-DB K=%d K-NN preselection + Viterbi' % K,
@@ -173,7 +180,7 @@ def main():
                        'n_candidates': K, 'sharding': 'db-rows/%d + all-gather top-K' % world if world > 1 else 'none'},
             'roofline': {'bound': 'mfma', 'kernel': 'knn_sweep<filter> (v_mfma_f64_16x16x4_f64)',
                          'achieved': achieved, 'peak': F64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / F64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'frac': achieved / F64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
                          'avg_launch_ms': avg_ms, 'launches': launches,
                          'flops_per_launch': flops},
             'stages_ms_per_utt': dict((k, v[0] / max(v[1], 1)) for k, v in timers.items() if v[1]),
