@@ -71,6 +71,13 @@ int snk_set_unit_classes(snk_handle h, const int32_t *unit_class, int64_t N);
 int snk_knn_by_class(snk_handle h, const double *Q, int64_t T, int D, int K,
                      const int32_t *query_class, int64_t *cand_out, double *dist_out);
 
+/* Distance part of preselect_units_quinphone (synth_halfphone.py:1343-1349): the candidate ids come
+ * from the label index on the host (quinphone -> triphone -> diphone -> monophone back-off,
+ * :1315-1334); dist_out[t,k] = ||F[cand[t,k]] - Q[t]||_2.  As in the reference's numpy fancy
+ * indexing a negative id counts from the end of the database (padding -1 -> last unit). */
+int snk_candidate_distances(snk_handle h, const double *Q, int64_t T, int D, const int64_t *cand, int K,
+                            double *dist_out);
+
 /* Replaces make_on_the_fly_join_lattice_BLOCK_DIRECT's cost computation
  * (synth_halfphone.py:3206-3322; get_natural_distance_vectorised :2942-2951):
  *   J_out (T-1, K, K) float64, J[t,a,b] = ||unit_end[cand[t,a]] - unit_start[cand[t+1,b]]||_2,

@@ -255,6 +255,64 @@ def knn_by_class(F, U, K, unit_class, query_class):
 
 
 # --------------------------------------------------------------------------
+# a9: quinphone preselection (synth_halfphone.py:1305-1354, label_manip.py:16-32)
+# --------------------------------------------------------------------------
+def break_quinphone(quinphone, delimiter='/'):
+    """label_manip.py:16-32: (mono, diphone, triphone, quinphone); diphone direction by _L/_R."""
+    q = quinphone.split(delimiter)
+    assert len(q) == 5
+    mono = q[2]
+    tri = delimiter.join(q[1:4])
+    if mono.endswith('_L'):
+        di = delimiter.join(q[1:3])
+    elif mono.endswith('_R'):
+        di = delimiter.join(q[2:4])
+    else:
+        raise SystemExit('efvaedvsdv')
+    return (mono, di, tri, quinphone)
+
+
+def build_unit_index(train_unit_names):
+    """synth_halfphone.py:281-292."""
+    unit_index = {}
+    for i, quinphone in enumerate(train_unit_names):
+        for form in break_quinphone(quinphone):
+            unit_index.setdefault(form, []).append(i)
+    return unit_index
+
+
+def candidate_distances(F, U, cand):
+    """dists of synth_halfphone.py:1343-1349: row -1 indexes the LAST unit (numpy semantics)."""
+    cand = np.asarray(cand, dtype=np.int64)
+    out = np.empty(cand.shape, dtype=np.float64)
+    for t in range(cand.shape[0]):
+        out[t] = np.sqrt(sqdist_rows(F[cand[t]], U[t]))
+    return out
+
+
+def preselect_units_quinphone(unit_index, F, U, unit_names, K):
+    """quinphone, then triphone, diphone, monophone matches in database order, no
+    de-duplication, stop at K; nothing found -> [1]; pad with -1."""
+    candidates = []
+    for quinphone in unit_names:
+        cur = []
+        mono, di, tri, quin = break_quinphone(quinphone)
+        for form in [quin, tri, di, mono]:
+            for unit in unit_index.get(form, []):
+                cur.append(unit)
+                if len(cur) == K:
+                    break
+            if len(cur) == K:
+                break
+        if len(cur) == 0:
+            cur = [1]
+        cur += [-1] * (K - len(cur))
+        candidates.append(cur)
+    candidates = np.array(candidates, dtype=np.int64)
+    return candidates, candidate_distances(F, U, candidates)
+
+
+# --------------------------------------------------------------------------
 # a10: join cost (synth_halfphone.py:2942-2951 inside :3206-3322)
 # --------------------------------------------------------------------------
 def valid_mask(cand, n_units):

@@ -841,6 +841,38 @@ void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, co
 }
 
 // ---------------------------------------------------------------------------
+// distances of GIVEN candidates (quinphone preselection, synth_halfphone.py:1343-1349):
+// dist[t,k] = ||F[cand[t,k]] - q_t||, canonical order; a negative id indexes from the end of the
+// database exactly like the reference's numpy fancy indexing (padding -1 -> last unit)
+// ---------------------------------------------------------------------------
+__global__ void candidate_dist_kernel(const double *__restrict__ Fw, int Dpad, int D, int64_t N,
+                                      const double *__restrict__ Qp, const int64_t *__restrict__ cand,
+                                      int64_t T, int K, double *__restrict__ dist)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * K) return;
+    const int64_t t = i / K;
+    int64_t id = cand[i];
+    if (id < 0) id += N;
+    if (id < 0 || id >= N) { dist[i] = __builtin_nan(""); return; }
+    const double *f = Fw + id * Dpad, *q = Qp + t * Dpad;
+    double acc = 0.0;
+    for (int c = 0; c < D; ++c) {
+        const double d = __dsub_rn(f[c], q[c]);
+        acc = __dadd_rn(acc, __dmul_rn(d, d));
+    }
+    dist[i] = __dsqrt_rn(acc);
+}
+
+void launch_candidate_dist(const double *Fw, int Dpad, int D, int64_t N, const double *Qp,
+                           const int64_t *cand, int64_t T, int K, double *dist, hipStream_t s)
+{
+    const int64_t n = T * K;
+    hipLaunchKernelGGL(candidate_dist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Fw, Dpad,
+                       D, N, Qp, cand, T, K, dist);
+}
+
+// ---------------------------------------------------------------------------
 // merge of G gathered per-shard top-K lists (multi-GPU exchange step)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)

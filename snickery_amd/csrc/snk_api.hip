@@ -565,6 +565,32 @@ int snk_knn_by_class(snk_handle h, const double *Q, int64_t T, int D, int K, con
     return 0;
 }
 
+int snk_candidate_distances(snk_handle h, const double *Q, int64_t T, int D, const int64_t *cand, int K,
+                            double *dist_out)
+{
+    CHK(check_ready(h, true, false));
+    HIPCHK(hipSetDevice(h->device));
+    if (!cand || !dist_out || K < 1) return fail("snk_candidate_distances: null/empty argument");
+    CHK(upload_queries(h, Q, T, D));
+    const int64_t Tpad = roundup(T, 16);
+    CHK(h->Qp.ensure((size_t)Tpad * h->Dpad * sizeof(double)));
+    CHK(h->Qf.ensure((size_t)Tpad * h->Dpad * sizeof(double)));
+    CHK(h->qnorm.ensure((size_t)Tpad * sizeof(double)));
+    UttSlot &s = h->slot[0];
+    CHK(s.cand.ensure((size_t)T * K * sizeof(int64_t)));
+    CHK(s.tdist.ensure((size_t)T * K * sizeof(double)));
+    launch_prepare_queries(h->Qraw.as<double>(), T, h->Dt, h->Qp.as<double>(), h->Qf.as<double>(), h->qnorm.as<double>(),
+                           Tpad, h->Dpad, h->stream);
+    HIPCHK(hipMemcpyAsync(s.cand.p, cand, (size_t)T * K * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    launch_candidate_dist(h->Fw.as<double>(), h->Dpad, h->Dt, h->N, h->Qp.as<double>(), s.cand.as<int64_t>(), T, K,
+                          s.tdist.as<double>(), h->stream);
+    HIPCHK(hipGetLastError());
+    D2HPart parts[1] = {{dist_out, s.tdist.p, (size_t)T * K * sizeof(double)}};
+    CHK(staged_d2h(h, h->stream, parts, 1));
+    collect_timers(h);
+    return 0;
+}
+
 static int64_t join_units(snk_engine *h)
 {
     // data_frames of unit_end_data = rows of join_contexts - 1 (synth_halfphone.py:3227)

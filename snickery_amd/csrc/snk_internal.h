@@ -55,6 +55,8 @@ void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, co
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
                          int cap, int64_t id_offset,
                          int64_t *cand, double *dist, double *d2_out, int *status, hipStream_t s);
+void launch_candidate_dist(const double *Fw, int Dpad, int D, int64_t N, const double *Qp,
+                           const int64_t *cand, int64_t T, int K, double *dist, hipStream_t s);
 void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, int K,
                        int64_t *cand, double *dist, hipStream_t s);
 

@@ -40,6 +40,8 @@ _SIGNATURES = {
     'snk_set_unit_classes': (ctypes.c_int, [ctypes.c_void_p, _c_i32p, ctypes.c_int64]),
     'snk_knn_by_class': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int,
                                         ctypes.c_int, _c_i32p, _c_i64p, _c_f64p]),
+    'snk_candidate_distances': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int, _c_i64p,
+                                               ctypes.c_int, _c_f64p]),
     'snk_join_costs': (ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int64, ctypes.c_int, _c_f64p]),
     'snk_viterbi': (ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_f64p, ctypes.c_int64, ctypes.c_int,
                                    _c_i64p, _c_i64p, _c_f64p]),
@@ -182,6 +184,17 @@ class HipSearchEngine(object):
         self._check(self._lib.snk_knn_by_class(self._h, _ptr(Q, _c_f64p), T, D, K, _ptr(qc, _c_i32p),
                                                _ptr(cand, _c_i64p), _ptr(dist, _c_f64p)))
         return cand, dist
+
+    def candidate_distances(self, unit_features, candidates):
+        """Distance part of preselect_units_quinphone (synth_halfphone.py:1343-1349)."""
+        Q = _f64(unit_features)
+        cand = np.ascontiguousarray(candidates, dtype=np.int64)
+        T, D = Q.shape
+        assert cand.shape[0] == T
+        dist = np.empty(cand.shape, dtype=np.float64)
+        self._check(self._lib.snk_candidate_distances(self._h, _ptr(Q, _c_f64p), T, D, _ptr(cand, _c_i64p),
+                                                      cand.shape[1], _ptr(dist, _c_f64p)))
+        return dist
 
     def join_costs(self, candidates):
         cand = np.ascontiguousarray(candidates, dtype=np.int64)

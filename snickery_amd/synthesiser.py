@@ -223,6 +223,58 @@ class Synthesiser(object):
         self.stop_clock(t)
         return out
 
+    @staticmethod
+    def break_quinphone(quinphone):
+        """label_manip.py:16-32."""
+        q = quinphone.split(LABEL_DELIMITER)
+        assert len(q) == 5
+        mono = q[2]
+        tri = LABEL_DELIMITER.join(q[1:4])
+        if mono.endswith('_L'):
+            di = LABEL_DELIMITER.join(q[1:3])
+        elif mono.endswith('_R'):
+            di = LABEL_DELIMITER.join(q[2:4])
+        else:
+            raise SystemExit('efvaedvsdv')
+        return (mono, di, tri, quinphone)
+
+    def _setup_unit_index(self):
+        """synth_halfphone.py:281-292: label -> unit ids, for every back-off level."""
+        self.unit_index = {}
+        for i, name in enumerate(self.train_unit_names):
+            name = name.decode() if isinstance(name, bytes) else str(name)
+            for form in self.break_quinphone(name):
+                self.unit_index.setdefault(form, []).append(i)
+
+    def preselect_units_quinphone(self, unit_features, unit_names):
+        """synth_halfphone.py:1305-1354: label back-off lookup on the host, distances on the GPU."""
+        t = self.start_clock('Preselect units ')
+        if not hasattr(self, 'unit_index'):
+            self._setup_unit_index()
+        K = self.config['n_candidates']
+        candidates = []
+        for quinphone in unit_names:
+            cur = []
+            mono, di, tri, quin = self.break_quinphone(quinphone)
+            for form in [quin, tri, di, mono]:
+                for unit in self.unit_index.get(form, []):
+                    cur.append(unit)
+                    if len(cur) == K:
+                        break
+                if len(cur) == K:
+                    break
+            if len(cur) == 0:
+                self.report('Warning: no cands in training data to match %s! Use v naive backoff to silence...' % (quinphone))
+                cur = [1]
+            cur += [-1] * (K - len(cur))
+            candidates.append(cur)
+        candidates = np.array(candidates, dtype=np.int64)
+        self.stop_clock(t)
+        t = self.start_clock('Compute target distances...')
+        distances = self.engine.candidate_distances(np.asarray(unit_features, dtype=np.float64), candidates)
+        self.stop_clock(t)
+        return (candidates, distances)
+
     def viterbi_search(self, candidates, distances):
         """synth_halfphone.py:1399-1436."""
         t = self.start_clock('Compose and find shortest path')

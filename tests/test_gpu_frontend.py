@@ -79,3 +79,18 @@ def test_halfphone_flavour_viterbi(tmp_path, golden, mini_voice):
     op, _ = o.viterbi(oc, od, mini_voice['E'], mini_voice['S'])
     assert full == op
     synth.close()
+
+
+def test_quinphone_preselection(tmp_path, golden, mini_voice):
+    """preselect_units_quinphone: label back-off on the host, candidate distances on the GPU;
+    candidates identical to the reference's own output, distances bit-exact vs the oracle."""
+    from snickery_amd.synthesiser import Synthesiser
+    cfgfile, config = build_voice(tmp_path, golden, greedy=False, multiepoch=1, n_candidates=9)
+    synth = Synthesiser(cfgfile, verbose=False)
+    synth.train_unit_names = golden['quin_unit_names']
+    qnames = [n.decode() for n in golden['quin_query_names']]
+    cand, dist = synth.preselect_units_quinphone(golden['quin_queries'], qnames)
+    assert np.array_equal(cand, golden['quin_candidates'])
+    np.testing.assert_allclose(dist, golden['quin_distances'], rtol=1e-12)
+    assert np.array_equal(dist, o.candidate_distances(mini_voice['F'], golden['quin_queries'], cand))
+    synth.close()

@@ -152,3 +152,13 @@ def test_knn_by_class_padding(mini_voice):
     assert np.all(cls[cand[0]] == cls[10]) and cand[0, 0] == 10
     assert list(cand[1, 3:]) == [-1, -1] and np.all(dist[1, 3:] == o.VERY_BIG_WEIGHT_VALUE)
     assert set(cand[1, :3]) == {0, 1, 2}
+
+
+def test_quinphone_preselection_matches_reference(golden, mini_voice):
+    names = [n.decode() for n in golden['quin_unit_names']]
+    qnames = [n.decode() for n in golden['quin_query_names']]
+    index = o.build_unit_index(names)
+    cand, dist = o.preselect_units_quinphone(index, mini_voice['F'], golden['quin_queries'], qnames, 9)
+    assert np.array_equal(cand, golden['quin_candidates'])
+    np.testing.assert_allclose(dist, golden['quin_distances'], rtol=1e-12)
+    assert list(golden['quin_candidates'][2]) == [1] + [-1] * 8          # unseen label -> naive back-off

@@ -257,6 +257,34 @@ def main():
         fixtures['join_cache_values'] = vals
         fixtures['join_weight_vector'] = wj
 
+        # ---- quinphone preselection (synth_halfphone.py:1305-1354) with synthetic labels ----
+        from label_manip import break_quinphone
+        prng = np.random.RandomState(77)
+        phones = ['a', 'b', 'k', 's', 'sil']
+        N = F_unw.shape[0]
+        names = []
+        for i in range(N):
+            ctx = [phones[prng.randint(len(phones))] for _ in range(5)]
+            ctx[2] = ctx[2] + ('_L' if i % 2 == 0 else '_R')
+            names.append('/'.join(ctx))
+        sh.train_unit_names = np.array(names)
+        sh.unit_index = {}
+        for (i, quinphone) in enumerate(sh.train_unit_names):          # synth_halfphone.py:281-292
+            mono, diphone, triphone, quinphone = break_quinphone(quinphone)
+            for form in [mono, diphone, triphone, quinphone]:
+                if form not in sh.unit_index:
+                    sh.unit_index[form] = []
+                sh.unit_index[form].append(i)
+        qnames = [names[5], names[40], 'zz/zz/zz_L/zz/zz', 'a/b/k_R/s/a', names[300]]
+        qfeats = fixtures['greedy_me6_utt0_unit_features'][:len(qnames)]
+        sh.config['n_candidates'] = 9
+        qc, qd = sh.preselect_units_quinphone(qfeats, qnames)
+        fixtures['quin_unit_names'] = np.array(names).astype('S40')
+        fixtures['quin_query_names'] = np.array(qnames).astype('S40')
+        fixtures['quin_queries'] = qfeats
+        fixtures['quin_candidates'] = np.array(qc, dtype=np.int64)
+        fixtures['quin_distances'] = np.array(qd, dtype=np.float64)
+
         np.savez_compressed(os.path.join(OUT, 'reference_mini.npz'), **fixtures)
         sz = os.path.getsize(os.path.join(OUT, 'reference_mini.npz'))
         print('wrote tests/golden/reference_mini.npz (%d bytes), N=%d' % (sz, F_unw.shape[0]))
