@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense FP64 matrix: 256 CU x 4 SIMD x 2048 FLOP / 64 clk x 2.4 GHz
+F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X dense FP32 matrix (MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 clk)
 FRAMESHIFT_MS = 5.0             # config/slt_simplified_mini.cfg:40
 
 
@@ -161,8 +162,14 @@ def main():
         flops = 2.0 * T * n_local * Dt          # algorithmic: SURVEY 8d, per utterance, this rank's shard
         # HBM bytes per launch from the committed PMC passes (separate --pmc runs, FETCH_SIZE
         # doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for the profiled shape
+        # which sweep did the filtering: the f32 prefilter (default; results are made exact by the
+        # float64 re-rank) or, when it had to fall back / was switched off, the f64 sweep
+        f32_mode = eng.info('precision') == 1 and eng.info('f16_ready') == 1 and eng.info('f16_fallbacks') == 0
+        peak = F32_MFMA_PEAK_TFLOPS if f32_mode else F64_MFMA_PEAK_TFLOPS
+        kname = ('knn_sweep16<filter> (v_mfma_f32_32x32x2_f32 prefilter; exact f64 re-rank in knn_finalize)'
+                 if f32_mode else 'knn_sweep<filter> (v_mfma_f64_16x16x4_f64)')
         traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        tfile = os.path.join(ROOT, 'profiles', 'r01_traffic_f32.json' if f32_mode else 'r01_traffic.json')
         if world == 1 and N == 1048576 and Dt == 61 and os.path.isfile(tfile):
             with open(tfile) as f:
                 traffic = json.load(f)['hbm_bytes_per_launch']
@@ -171,16 +178,16 @@ def main():
             'metric': 'synthesised frames/sec, full-DB K=%d K-NN preselection + Viterbi' % K,
             'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f64' if not f32_mode else 'f64 (f32 matrix prefilter + exact f64 re-rank)', 'data': 'synthetic',
             'xRT': (total_frames * FRAMESHIFT_MS / 1e3) / elapsed,
             'config': {'workload': 'B* synthetic magphase-60 (SURVEY 8d): |DB|=%d units, Dt=%d, Dj=%d, '
                                    'T=%d frames x %d utterances per step, K=%d, search_epsilon=0'
                                    % (N, Dt, Dj, T, U, K),
                        'units': N, 'target_dim': Dt, 'join_dim': Dj, 'frames': T, 'utts_per_step': U,
                        'n_candidates': K, 'sharding': 'db-rows/%d + all-gather top-K' % world if world > 1 else 'none'},
-            'roofline': {'bound': 'mfma', 'kernel': 'knn_sweep<filter> (v_mfma_f64_16x16x4_f64)',
-                         'achieved': achieved, 'peak': F64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / F64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+            'roofline': {'bound': 'mfma', 'kernel': kname,
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': traffic,
                          'avg_launch_ms': avg_ms, 'launches': launches,
                          'flops_per_launch': flops},
             'stages_ms_per_utt': dict((k, v[0] / max(v[1], 1)) for k, v in timers.items() if v[1]),

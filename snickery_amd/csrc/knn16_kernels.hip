@@ -1,0 +1,393 @@
+// Single-precision PREFILTER for the K-NN preselection (gfx950): the same DB-stationary sweep as
+// knn_kernels.hip, but on the f32 matrix pipe (v_mfma_f32_32x32x2_f32, exact f32 FMA chains at
+// twice the f64 MFMA rate) over float32 copies of the weighted database and of -2q.
+//
+// Exactness is kept by construction, not by precision:
+//   * key~ = fnorm - 2 q.f comes straight out of the accumulator (||f||^2 rides along in a spare
+//     padding column against 1.0 in the query operand).
+//   * |key~ - key| <= eps_t = c * (2 ||q_t|| Fmax + Fmax^2): input rounding 2^-24 per operand plus a
+//     65-term f32 FMA chain give 4.1e-6 analytically; c = 8e-6.  (A half-precision split
+//     (f16 hi+lo, 16x MFMA rate) was built first and rejected: with f32 accumulators its provable
+//     bound is ~1e-4 relative, too coarse for databases whose neighbour distances differ by 1e-5.)
+//   * thresholds are raised by eps, the filter passes key~ <= thr + eps, and knn_finalize re-ranks
+//     every survivor within 2 eps of the K-th key with EXACT float64 canonical distances.  The
+//     approximate keys never reach the caller.
+//   * anything that does not fit (no spare column, list overflow, > SEL_MAX near ties) falls back
+//     to the f64 sweep.
+//
+// Operand roles: A = database tile (32 units), B = query tile (32 frames); a lane of the 32x32
+// result holds ONE query column and 16 database rows, so the threshold is one scalar per lane.
+// The k index is permuted: lane half h covers columns 32h..32h+31 (step kk -> column 32h+kk), so
+// every lane reads 128 contiguous bytes per tile.
+#include "snk_internal.h"
+#include <float.h>
+
+namespace snk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f16acc __attribute__((ext_vector_type(16)));
+
+struct __attribute__((aligned(16))) PoolEntry16 { double key; int idx; int row; };   // == PoolEntry
+
+// C/D layout of the 32x32 f32 MFMA results: lane l holds column (l & 31) and, in register r, row
+//   (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+__device__ __forceinline__ int crow32(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---------------------------------------------------------------------------
+// operand construction.  Fragment order: [tile][j4 = 0..7][lane][4 floats] with
+//   value = X[row(lane & 31)][column 32*(lane >> 5) + 4*j4 + i]
+// so each of the 8 load instructions of a tile covers 1 KB of contiguous memory.
+// ---------------------------------------------------------------------------
+__global__ void build_db16_kernel(const double *__restrict__ Fw, const double *__restrict__ fnorm, int64_t N,
+                                  int Dt, int Dpad, int64_t n_tiles, int64_t sample_stride, int64_t G,
+                                  int nt_a, f32x4 *__restrict__ A32)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (item >= n_tiles * 8) return;
+    const int64_t tile = item / 8;
+    const int j4 = (int)(item % 8);
+    const int r = lane & 31, h = lane >> 5;
+    int64_t row;
+    if (sample_stride <= 0) {
+        row = tile * 32 + r;
+    } else {
+        // scattered sample: wave w owns tiles [w*nt_a, (w+1)*nt_a); the 16*nt_a rows a lane half
+        // reduces together are spaced G sampled rows apart, consecutive sampled rows fall into
+        // different groups
+        const int64_t w = tile / nt_a;
+        const int nt = (int)(tile % nt_a);
+        const int hh = (r >> 2) & 1, reg = (r & 3) + 4 * (r >> 3);
+        const int64_t m = (int64_t)nt * 16 + reg;
+        row = (m * G + (2 * w + hh)) * sample_stride;
+    }
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = 32 * h + 4 * j4 + i;
+        float x = 0.0f;
+        if (row < N) {
+            if (c < Dt) x = (float)Fw[row * Dpad + c];
+            else if (c == Dt) x = (float)fnorm[row];
+        } else if (c == Dt) x = 3.0e38f;           // padding unit: key never passes
+        v[i] = x;
+    }
+    A32[item * 64 + lane] = v;
+}
+
+__global__ void fmax_kernel(const double *__restrict__ fnorm, int64_t N, double *__restrict__ out)
+{
+    __shared__ double red[256];
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmax(m, fnorm[i]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(red[0]));
+}
+
+void launch_build_db16(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,
+                       int64_t sample_stride, int64_t G, int nt_a, void *A32, hipStream_t s)
+{
+    const int64_t items = n_tiles * 8;
+    hipLaunchKernelGGL(build_db16_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, Fw, fnorm, N, Dt,
+                       Dpad, n_tiles, sample_stride, G, nt_a, reinterpret_cast<f32x4 *>(A32));
+}
+
+void launch_fmax(const double *fnorm, int64_t N, double *out, hipStream_t s)
+{
+    (void)hipMemsetAsync(out, 0, sizeof(double), s);
+    hipLaunchKernelGGL(fmax_kernel, dim3(512), dim3(256), 0, s, fnorm, N, out);
+}
+
+// Query fragments (same fragment order): -2q in float32, 1.0 in the fnorm column; also eps_t.
+__global__ void prepare_queries16_kernel(const double *__restrict__ Qp, const double *__restrict__ qnorm,
+                                         int64_t T, int Dt, int Dpad, const double *__restrict__ fmax2,
+                                         double eps_c, f32x4 *__restrict__ B32, double *__restrict__ eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_tiles = (T + 31) / 32;
+    if (item >= n_tiles * 8) return;
+    const int64_t tile = item / 8;
+    const int j4 = (int)(item % 8);
+    const int64_t row = tile * 32 + (lane & 31);
+    const int h = lane >> 5;
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = 32 * h + 4 * j4 + i;
+        float x = 0.0f;
+        if (row < T) {
+            if (c < Dt) x = (float)(-2.0 * Qp[row * Dpad + c]);
+            else if (c == Dt) x = 1.0f;
+        }
+        v[i] = x;
+    }
+    B32[item * 64 + lane] = v;
+    if (j4 == 0 && h == 0) {
+        const double fm = sqrt(*fmax2);
+        const double qn = (row < T) ? sqrt(qnorm[row]) : 0.0;
+        eps[row] = eps_c * (2.0 * qn * fm + fm * fm) + 1e-30;
+    }
+}
+
+void launch_prepare_queries16(const double *Qp, const double *qnorm, int64_t T, int Dt, int Dpad,
+                              const double *fmax2, double eps_c, void *B32, double *eps, hipStream_t s)
+{
+    const int64_t items = ((T + 31) / 32) * 8;
+    hipLaunchKernelGGL(prepare_queries16_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, Qp, qnorm,
+                       T, Dt, Dpad, fmax2, eps_c, reinterpret_cast<f32x4 *>(B32), eps);
+}
+
+// ---------------------------------------------------------------------------
+// the sweep
+//   MODE 0: minima per (wave slab, lane half) group over the scattered sample -> gmin32[row][G]
+//   MODE 1: filter over the whole database -> entry pool (same pool / bucket / finalize as f64)
+// ---------------------------------------------------------------------------
+template <int NT, int MODE>
+__global__ void __launch_bounds__(256, 1)
+knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
+            const float *__restrict__ thr32, int nQT, int64_t n_slabs,
+            unsigned int *__restrict__ slab_counter, int qsplit, float *__restrict__ gmin32, int64_t G,
+            PoolEntry16 *__restrict__ pool, unsigned int *__restrict__ pool_ctl, int *__restrict__ chunk_fill,
+            int max_chunks, int pool_chunk)
+{
+    constexpr int STAGE_CAP = 64 * 16 + 128;
+    __shared__ PoolEntry16 stage[(MODE == 1) ? 4 : 1][(MODE == 1) ? STAGE_CAP : 1];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int qcol = lane & 31;
+
+    auto grab = [&]() -> int64_t {
+        unsigned int v = 0;
+        if (lane == 0) v = atomicAdd(slab_counter, 1u);
+        return (int64_t)__builtin_amdgcn_readfirstlane(v);
+    };
+    int chunk_id = -1, cused = pool_chunk, lcount = 0;
+    auto new_chunk = [&]() {
+        if (chunk_id >= 0 && lane == 0) chunk_fill[chunk_id] = cused;
+        unsigned int c = 0;
+        if (lane == 0) c = atomicAdd(&pool_ctl[0], 1u);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if ((int)c >= max_chunks) { if (lane == 0) pool_ctl[1] = 1u; chunk_id = -1; }
+        else chunk_id = (int)c;
+        cused = 0;
+    };
+    auto flush_stage = [&]() {
+        if (cused + lcount > pool_chunk) new_chunk();
+        if (chunk_id >= 0)
+            for (int e = lane; e < lcount; e += 64)
+                pool[(int64_t)chunk_id * pool_chunk + cused + e] = stage[wv][e];
+        cused += lcount;
+        lcount = 0;
+    };
+
+    const int64_t n_items = n_slabs * qsplit;
+    int64_t item = grab();
+    while (item < n_items) {
+        const int64_t item_next = grab();
+        const int64_t w = item / qsplit;
+        const int part = (int)(item % qsplit);
+        const int qt_lo = (int)(((int64_t)nQT * part) / qsplit);
+        const int qt_hi = (int)(((int64_t)nQT * (part + 1)) / qsplit);
+
+        // database fragments of this slab: resident in registers
+        f32x4 af[NT][8];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j4 = 0; j4 < 8; ++j4) af[nt][j4] = A32[((w * NT + nt) * 8 + j4) * 64 + lane];
+        float gm = FLT_MAX;
+
+        f32x4 bq[2][8];
+        float th[2];
+        auto load_q = [&](int t, f32x4 (&x)[8], float &t32) {
+#pragma unroll
+            for (int j4 = 0; j4 < 8; ++j4) x[j4] = B32[((int64_t)t * 8 + j4) * 64 + lane];
+            if (MODE == 1) t32 = thr32[t * 32 + qcol];
+        };
+        int qt = qt_lo + (int)((w * 3) % (qt_hi - qt_lo));
+        load_q(qt, bq[0], th[0]);
+
+        auto tile_body = [&](f32x4 (&x)[8], float &tcur, f32x4 (&nx)[8], float &tnext) {
+            // the tile's own operands must have landed (one tile old); staged entries go out first
+#pragma unroll
+            for (int j4 = 0; j4 < 8; ++j4) {
+                float x0 = x[j4][0], x1 = x[j4][1], x2 = x[j4][2], x3 = x[j4][3];
+                asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+                x[j4][0] = x0; x[j4][1] = x1; x[j4][2] = x2; x[j4][3] = x3;
+            }
+            if (MODE == 1) { asm volatile("" : "+v"(tcur)); if (lcount) flush_stage(); }
+            const int qt_next = (qt + 1 == qt_hi) ? qt_lo : qt + 1;
+            load_q(qt_next, nx, tnext);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f16acc acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int j4 = 0; j4 < 8; ++j4)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[nt][j4][i], x[j4][i], acc, 0, 0, 0);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gm = fminf(gm, acc[r]);
+                } else {
+                    if (lcount > STAGE_CAP - 64 * 16) flush_stage();
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool pass = acc[r] <= tcur;
+                        const unsigned long long m = __ballot(pass);
+                        if (m) {
+                            if (pass) {
+                                const int rank = __builtin_amdgcn_mbcnt_hi(
+                                    (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                PoolEntry16 en;
+                                en.key = (double)acc[r];
+                                en.idx = (int)((w * NT + nt) * 32 + crow32(lane, r));
+                                en.row = qt * 32 + qcol;
+                                stage[wv][lcount + rank] = en;
+                            }
+                            lcount += __popcll(m);
+                        }
+                    }
+                }
+            }
+            if (MODE == 0) {
+                // group = (slab w, lane half): min over the 16*NT rows this lane reduced
+                gmin32[((int64_t)qt * 32 + qcol) * G + 2 * w + (lane >> 5)] = gm;
+                gm = FLT_MAX;
+            }
+            qt = qt_next;
+        };
+        const int n_t = qt_hi - qt_lo;
+        for (int it = 0; it < n_t; it += 2) {
+            tile_body(bq[0], th[0], bq[1], th[1]);
+            if (it + 1 < n_t) tile_body(bq[1], th[1], bq[0], th[0]);
+        }
+        item = item_next;
+    }
+    if (MODE == 1) {
+        if (lcount) flush_stage();
+        if (chunk_id >= 0 && lane == 0) chunk_fill[chunk_id] = cused;
+    }
+}
+
+template <int NT>
+static void launch16_t(int mode, int blocks, hipStream_t s, const void *A32, const void *B32,
+                       const float *thr32, int nQT, int64_t n_slabs, unsigned int *ctr,
+                       int qsplit, float *gmin32, int64_t G, void *pool, unsigned int *pool_ctl,
+                       int *chunk_fill, int max_chunks, int pool_chunk)
+{
+    if (mode == 0)
+        hipLaunchKernelGGL((knn_sweep16<NT, 0>), dim3(blocks), dim3(256), 0, s, (const f32x4 *)A32,
+                           (const f32x4 *)B32, thr32, nQT, n_slabs, ctr, qsplit, gmin32, G, (PoolEntry16 *)pool,
+                           pool_ctl, chunk_fill, max_chunks, pool_chunk);
+    else
+        hipLaunchKernelGGL((knn_sweep16<NT, 1>), dim3(blocks), dim3(256), 0, s, (const f32x4 *)A32,
+                           (const f32x4 *)B32, thr32, nQT, n_slabs, ctr, qsplit, gmin32, G, (PoolEntry16 *)pool,
+                           pool_ctl, chunk_fill, max_chunks, pool_chunk);
+}
+
+// nt: tiles (32 units) per wave.  Returns false when the shape is not instantiated.
+bool launch_knn_sweep16(int mode, int nt, int grid_cus, const void *A32, const void *B32,
+                        const float *thr32, int64_t T32, int64_t n_slabs, unsigned int *ctr,
+                        float *gmin32, int64_t G, void *pool, unsigned int *pool_ctl, int *chunk_fill,
+                        int max_chunks, int pool_chunk, hipStream_t s)
+{
+    const int nQT = (int)(T32 / 32);
+    const int64_t max_blocks = (int64_t)grid_cus * ((nt <= 4) ? 2 : 1);
+    int qsplit = 1;
+    while (n_slabs * qsplit < 2 * 4 * max_blocks && qsplit * 2 <= nQT && qsplit < 8) qsplit *= 2;
+    int64_t blocks = (n_slabs * qsplit + 3) / 4;
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (nt == 4) {
+        launch16_t<4>(mode, (int)blocks, s, A32, B32, thr32, nQT, n_slabs, ctr, qsplit, gmin32, G, pool,
+                      pool_ctl, chunk_fill, max_chunks, pool_chunk);
+        return true;
+    }
+    if (nt == 8) {
+        launch16_t<8>(mode, (int)blocks, s, A32, B32, thr32, nQT, n_slabs, ctr, qsplit, gmin32, G, pool,
+                      pool_ctl, chunk_fill, max_chunks, pool_chunk);
+        return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------
+// threshold from the f32 group minima: K-th smallest of G values + eps_t, as f32 rounded UP
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+knn_threshold16_kernel(const float *__restrict__ gmin32, int64_t G, int64_t T, int64_t T32, int K,
+                       const double *__restrict__ eps, double *__restrict__ thr, float *__restrict__ thr32)
+{
+    extern __shared__ float tkey[];
+    const int64_t row = blockIdx.x;
+    if (row >= T) { if (threadIdx.x == 0) { thr32[row] = -FLT_MAX; thr[row] = -DBL_MAX; } return; }
+    int P = 2;
+    while (P < G) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) tkey[i] = (i < G) ? gmin32[row * G + i] : FLT_MAX;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool up = ((i & k) == 0);
+                    const float a = tkey[i], b = tkey[ixj];
+                    if (up ? (b < a) : (a < b)) { tkey[i] = b; tkey[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x == 0) {
+        double v = DBL_MAX;
+        float v32 = FLT_MAX;
+        if (G >= K && tkey[K - 1] < FLT_MAX) {
+            // group minima are approximate: + eps makes the K-th smallest a true upper bound of the
+            // K-th nearest key; + eps again so that the filter's approximate test keeps everything
+            v = (double)tkey[K - 1] + 2.0 * eps[row];
+            v32 = (float)v;
+            if ((double)v32 < v) v32 = nextafterf(v32, FLT_MAX);
+        }
+        thr[row] = v;
+        thr32[row] = v32;
+    }
+}
+
+void launch_knn_threshold16(const float *gmin32, int64_t G, int64_t T, int64_t T32, int K, const double *eps,
+                            double *thr, float *thr32, hipStream_t s)
+{
+    int P = 2;
+    while (P < G) P <<= 1;
+    hipLaunchKernelGGL(knn_threshold16_kernel, dim3((unsigned)T32), dim3(256), (size_t)P * sizeof(float), s,
+                       gmin32, G, T, T32, K, eps, thr, thr32);
+}
+
+// ---------------------------------------------------------------------------
+// self test of the f32 32x32x2 MFMA operand / result maps: C(32x32) = A(32x2) * B(2x32)
+// ---------------------------------------------------------------------------
+__global__ void mfma16_selftest_kernel(const float *A, const float *B, float *C)
+{
+    const int lane = threadIdx.x;
+    const float a = A[(lane & 31) * 2 + (lane >> 5)];      // A[row = l&31][k = l>>5]
+    const float b = B[(lane >> 5) * 32 + (lane & 31)];     // B[k = l>>5][col = l&31]
+    f16acc acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) C[crow32(lane, r) * 32 + (lane & 31)] = acc[r];
+}
+
+void launch_mfma16_selftest(const float *A, const float *B, float *C, hipStream_t s)
+{
+    hipLaunchKernelGGL(mfma16_selftest_kernel, dim3(1), dim3(64), 0, s, A, B, C);
+}
+
+}  // namespace snk

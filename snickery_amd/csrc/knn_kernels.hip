@@ -423,6 +423,8 @@ void launch_knn_reset(int *cnt, int64_t Tpad, int *status, unsigned int *pool_ct
                        pool_ctl, slab_counter, chunk_fill, max_chunks);
 }
 
+int knn_pool_chunk_entries() { return POOL_CHUNK; }
+
 size_t knn_pool_bytes(int max_chunks) { return (size_t)max_chunks * POOL_CHUNK * sizeof(PoolEntry); }
 
 // ---------------------------------------------------------------------------
@@ -432,7 +434,7 @@ size_t knn_pool_bytes(int max_chunks) { return (size_t)max_chunks * POOL_CHUNK *
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__restrict__ pool_ctl,
-                  const int *__restrict__ chunk_fill, int max_chunks, int Tpad, int *__restrict__ cnt,
+                  const int *__restrict__ chunk_fill, int max_chunks, int Tpad, int n_valid, int *__restrict__ cnt,
                   double *__restrict__ lkey, int *__restrict__ lidx, int cap, int *__restrict__ status)
 {
     // per chunk: LDS histogram by row -> one global atomic per (chunk, row) reserves a run of
@@ -453,9 +455,10 @@ knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__rest
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
             const int e = threadIdx.x + k * 256;
+            rank[k] = -1;
             if (e < n) {
                 en[k] = pool[(int64_t)c * POOL_CHUNK + e];
-                rank[k] = atomicAdd(&hist[en[k].row], 1);
+                if (en[k].idx < n_valid) rank[k] = atomicAdd(&hist[en[k].row], 1);   // padding units never count
             }
         }
         __syncthreads();
@@ -467,7 +470,7 @@ knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__rest
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
             const int e = threadIdx.x + k * 256;
-            if (e < n) {
+            if (e < n && rank[k] >= 0) {
                 const int slot = hist[en[k].row] + rank[k];
                 if (slot < cap) {
                     lkey[(int64_t)en[k].row * cap + slot] = en[k].key;
@@ -480,12 +483,12 @@ knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__rest
 }
 
 void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int *chunk_fill,
-                       int max_chunks, int64_t Tpad, int *cnt, double *lkey, int *lidx, int cap,
-                       int *status, hipStream_t s)
+                       int max_chunks, int64_t Tpad, int64_t n_valid, int *cnt, double *lkey, int *lidx,
+                       int cap, int *status, hipStream_t s)
 {
     hipLaunchKernelGGL(knn_bucket_kernel, dim3(1024), dim3(256), (size_t)Tpad * sizeof(int), s,
                        reinterpret_cast<const PoolEntry *>(pool), pool_ctl, chunk_fill, max_chunks,
-                       (int)Tpad, cnt, lkey, lidx, cap, status);
+                       (int)Tpad, (int)n_valid, cnt, lkey, lidx, cap, status);
 }
 
 // ---------------------------------------------------------------------------
@@ -688,13 +691,14 @@ void launch_fill_threshold(double *thr, int64_t T, int64_t Tpad, double value, h
 // ---------------------------------------------------------------------------
 // finalize: sort the row's candidate list, exact re-rank, output
 // ---------------------------------------------------------------------------
-#define SEL_MAX 256      // candidates re-ranked exactly per row (K + near ties)
+#define SEL_MAX 512      // candidates re-ranked exactly per row (K + near ties / key error margin)
 
 __global__ void __launch_bounds__(256)
 knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double *__restrict__ Qp,
                     const double *__restrict__ qnorm, int64_t T, int K,
                     const int *__restrict__ cnt, const double *__restrict__ lkey,
                     const int *__restrict__ lidx, int cap, int64_t id_offset,
+                    const double *__restrict__ eps,
                     int64_t *__restrict__ cand, double *__restrict__ dist,
                     double *__restrict__ d2_out, int *__restrict__ status)
 {
@@ -738,6 +742,8 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
         __syncthreads();
     }
     kmin = red_min[0]; kmax = red_max[0];
+    // keys from the f16 prefilter are only good to +-eps: widen every selection margin by 2 eps
+    const double margin = eps ? 2.0 * eps[row] : 0.0;
     const double scale = (kmax > kmin) ? 256.0 / (kmax - kmin) : 0.0;
     bool fast = (n > SEL_MAX) && (scale > 0.0) && (kk == K);
     if (fast) {
@@ -751,6 +757,11 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
             int cum = 0, b = 0;
             for (; b < 256; ++b) { cum += hist[b]; if (cum >= K) break; }
             int cut = b + 1;                       // one bin past the K-th key's bin (near ties)
+            if (margin > 0.0) {                    // ... and everything within the key error margin
+                const double upper = kmin + (double)(b + 1) / scale + margin;
+                const int cm = (int)((upper - kmin) * scale) + 1;
+                if (cm > cut) cut = cm;
+            }
             if (cut > 255) cut = 255;
             int tot = 0;
             for (int i = 0; i <= cut; ++i) tot += hist[i];
@@ -780,24 +791,24 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
                 // GEMM-form keys carry ~1e-13 relative error: re-rank every candidate within a
                 // safety margin of the K-th key so that the exact order decides
                 const double kth = key[kk - 1];
-                const double delta = 1e-10 * (fabs(kth) + qnorm[row] + 1.0);
+                const double delta = 1e-10 * (fabs(kth) + qnorm[row] + 1.0) + margin;
                 while (ns < n && ns < SEL_MAX && key[ns] <= kth + delta) ++ns;
                 if (ns == SEL_MAX && ns < n && key[ns] <= kth + delta) atomicOr(status, 2);
             }
             n_sel_s = ns;
         }
         __syncthreads();
-        if (threadIdx.x < n_sel_s) ex_idx[threadIdx.x] = idx[threadIdx.x];
+        for (int e = threadIdx.x; e < n_sel_s; e += blockDim.x) ex_idx[e] = idx[e];
         __syncthreads();
     }
     const int n_sel = n_sel_s;
     // exact squared distance in the canonical order: acc = acc + (q_c - f_c)*(q_c - f_c),
     // c ascending, separately rounded sub / mul / add (bit-identical to the oracle)
-    if (threadIdx.x < SEL_MAX) {
+    for (int e = threadIdx.x; e < SEL_MAX; e += blockDim.x) {
         double acc = DBL_MAX;
         int id = 0x7fffffff;
-        if (threadIdx.x < n_sel) {
-            id = ex_idx[threadIdx.x];
+        if (e < n_sel) {
+            id = ex_idx[e];
             const double *f = Fw + (int64_t)id * Dpad;
             const double *q = Qp + row * Dpad;
             acc = 0.0;
@@ -806,9 +817,8 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
                 acc = __dadd_rn(acc, __dmul_rn(d, d));
             }
         }
-        __syncthreads();
-        ex_key[threadIdx.x] = acc;
-        ex_idx[threadIdx.x] = id;
+        ex_key[e] = acc;
+        ex_idx[e] = id;
     }
     __syncthreads();
     bitonic_sort_pairs(ex_key, ex_idx, SEL_MAX);
@@ -824,8 +834,8 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
 
 void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, const double *qnorm,
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
-                         int cap, int64_t id_offset, int64_t *cand, double *dist, double *d2_out,
-                         int *status, hipStream_t s)
+                         int cap, int64_t id_offset, const double *eps, int64_t *cand, double *dist,
+                         double *d2_out, int *status, hipStream_t s)
 {
     int P = 2;
     while (P < cap) P <<= 1;
@@ -837,7 +847,7 @@ void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, co
         attr = shmem;
     }
     hipLaunchKernelGGL(knn_finalize_kernel, dim3((unsigned)T), dim3(256), shmem, s, Fw, Dpad, D, Qp,
-                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, cand, dist, d2_out, status);
+                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, cand, dist, d2_out, status);
 }
 
 // ---------------------------------------------------------------------------

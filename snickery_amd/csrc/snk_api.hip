@@ -103,6 +103,15 @@ struct snk_engine {
     UttSlot slot[4];
     hipStream_t dp_stream[2] = {nullptr, nullptr};
     DevBuf res_path, res_plen, res_cost, Qall, res_status;
+    // f16-split prefilter state
+    DevBuf a16h, a16l, s16h, s16l, b16h, b16l, eps16, thr32, gmin32, fmax2;
+    bool f16_ready = false;
+    int precision = 1;            // 1: f32 prefilter + exact f64 re-rank (default), 0: f64 sweep only
+    int nt16 = 4;
+    int64_t n_slabs16 = 0, n_slabs16_a = 0, stride16 = 16;
+    double eps_c = 8e-6;          // 2x the analytical f32 bound (knn16_kernels.hip)
+    int f16_fallbacks = 0;
+    int last_f16_status = 0;
     HostBuf hstage;
     // greedy
     GreedyLayout glay{};
@@ -247,6 +256,8 @@ int snk_destroy(snk_handle h)
     (void)hipStreamDestroy(h->dp_stream[1]);
     h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
     h->res_status.release(); h->hstage.release();
+    { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2};
+      for (auto *b : fb) b->release(); }
     for (int i = 0; i < 4; ++i) {
         UttSlot &s = h->slot[i];
         DevBuf *sb[] = {&s.cand, &s.tdist, &s.J, &s.bp, &s.path, &s.plen, &s.cost};
@@ -342,6 +353,35 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
                                h->Djpad, h->stream);
     }
     HIPCHK(hipGetLastError());
+    // f16-split operands of the prefilter (knn16_kernels.hip): needs three spare padding columns
+    // for the ||f||^2 pieces and values inside the half-precision range
+    h->f16_ready = false;
+    if (h->have_db && h->Dpad == 64 && h->Dpad - h->Dt >= 1) {
+        const int nt = h->nt16;
+        CHK(h->fmax2.ensure(sizeof(double)));
+        launch_fmax(h->fnorm.as<double>(), h->N, h->fmax2.as<double>(), h->stream);
+        double fmax2 = 0.0;
+        HIPCHK(hipMemcpyAsync(&fmax2, h->fmax2.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const int64_t slab_rows = 32 * nt;
+        h->n_slabs16 = (h->N + slab_rows - 1) / slab_rows;
+        int64_t stride = (int64_t)floor(1.0 / h->sample_frac + 0.5);
+        if (stride < 1) stride = 1;
+        h->stride16 = stride;
+        h->n_slabs16_a = (h->N / stride) / slab_rows;
+        if (fmax2 < 1.0e30 && h->n_slabs16_a >= 1) {
+            const int64_t tiles_b = h->n_slabs16 * nt, tiles_a = h->n_slabs16_a * nt;
+            const size_t per_tile = (size_t)8 * 64 * 16;
+            CHK(h->a16h.ensure(tiles_b * per_tile));
+            CHK(h->s16h.ensure(tiles_a * per_tile));
+            launch_build_db16(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_b, 0, 0, nt,
+                              h->a16h.p, h->stream);
+            launch_build_db16(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_a, stride,
+                              2 * h->n_slabs16_a, nt, h->s16h.p, h->stream);
+            HIPCHK(hipGetLastError());
+            h->f16_ready = true;
+        }
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     collect_timers(h);
     h->have_weights = true;
@@ -399,7 +439,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
                       int64_t *cand_dev, double *dist_dev, double *d2_dev, int *deferred_status = nullptr)
 {
     if (K < 1 || K > 208) return fail("K-NN: n_candidates=%d outside the supported range 1..208", K);
-    const int64_t Tpad = roundup(T, 16);
+    const int64_t Tpad = roundup(T, 32);
     const KnnPlan p0 = make_plan(h, K);
     const bool cls = qclass_dev != nullptr;
     const int32_t *uc = cls ? h->unit_class.as<int32_t>() : nullptr;
@@ -430,6 +470,60 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
     h->last_retries = 0;
     h->last_T = T;
     int *status_dev = deferred_status ? deferred_status : h->status.as<int>();
+
+    // ---- fast path: f16-split prefilter (exact results through the float64 re-rank) ----
+    if (h->precision == 1 && h->f16_ready && !cls && 2 * h->n_slabs16_a >= K) {
+        const int64_t G16 = 2 * h->n_slabs16_a;
+        CHK(h->b16h.ensure((size_t)(Tpad / 32) * 8 * 64 * 16));
+        CHK(h->eps16.ensure((size_t)Tpad * sizeof(double)));
+        CHK(h->thr32.ensure((size_t)Tpad * sizeof(float)));
+        CHK(h->gmin32.ensure((size_t)Tpad * G16 * sizeof(float)));
+        launch_knn_reset(h->cnt.as<int>(), Tpad, status_dev, h->poolctl.as<unsigned int>(),
+                         h->slabctr.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, s);
+        {
+            StageTimer t(h, s, TM_PREP);
+            launch_prepare_queries16(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad,
+                                     h->fmax2.as<double>(), h->eps_c, h->b16h.p, h->eps16.as<double>(), s);
+        }
+        {
+            StageTimer t(h, s, TM_KNN_MINIMA);
+            launch_knn_sweep16(0, h->nt16, p0.grid_cus, h->s16h.p, h->b16h.p,
+                               nullptr, Tpad, h->n_slabs16_a, h->slabctr.as<unsigned int>(), h->gmin32.as<float>(),
+                               G16, nullptr, nullptr, nullptr, 0, knn_pool_chunk_entries(), s);
+        }
+        {
+            StageTimer t(h, s, TM_KNN_THRESHOLD);
+            launch_knn_threshold16(h->gmin32.as<float>(), G16, T, Tpad, K, h->eps16.as<double>(), h->thr.as<double>(),
+                                   h->thr32.as<float>(), s);
+        }
+        {
+            StageTimer t(h, s, TM_KNN_FILTER);
+            launch_knn_sweep16(1, h->nt16, p0.grid_cus, h->a16h.p, h->b16h.p,
+                               h->thr32.as<float>(), Tpad, h->n_slabs16, h->slabctr.as<unsigned int>() + 1, nullptr, 0,
+                               h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
+                               knn_pool_chunk_entries(), s);
+        }
+        {
+            StageTimer t(h, s, TM_KNN_BUCKET);
+            launch_knn_bucket(h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
+                              Tpad, h->N, h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap, status_dev, s);
+        }
+        {
+            StageTimer t(h, s, TM_KNN_FINALIZE);
+            launch_knn_finalize(h->Fw.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
+                                h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
+                                h->shard_offset, h->eps16.as<double>(), cand_dev, dist_dev, d2_dev, status_dev, s);
+        }
+        if (deferred_status) return 0;       // the batch caller redoes failures with precision 0
+        int status = 0;
+        HIPCHK(hipMemcpyAsync(&status, h->status.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipGetLastError());
+        h->last_f16_status = status;
+        if (status == 0) return 0;
+        h->f16_fallbacks += 1;               // overflow or too many near ties: exact f64 sweep below
+    }
+
     for (int attempt = 0; attempt < 2; ++attempt) {
         // attempt 0: thresholds from a strided sample of slabs (stage A).
         // attempt 1 (a candidate list overflowed): stage A over EVERY slab -- at most
@@ -464,14 +558,14 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         {
             StageTimer t(h, s, TM_KNN_BUCKET);
             launch_knn_bucket(h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
-                              Tpad, h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
+                              Tpad, h->N, h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
                               status_dev, s);
         }
         {
             StageTimer t(h, s, TM_KNN_FINALIZE);
             launch_knn_finalize(h->Fw.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
-                                h->shard_offset, cand_dev, dist_dev, d2_dev, status_dev, s);
+                                h->shard_offset, nullptr, cand_dev, dist_dev, d2_dev, status_dev, s);
         }
         if (deferred_status) return 0;
         int status = 0;
@@ -745,12 +839,18 @@ int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offs
         HIPCHK(hipMemcpyAsync(st.data(), h->res_status.p, (size_t)n_utts * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         for (int u = 0; u < n_utts; ++u) {
+            if (st[u] == 0) continue;
             if (st[u] & 2) h->tie_overflow = 1;
-            if (!(st[u] & 1)) continue;
             const int64_t r0 = row_offsets[u], T = row_offsets[u + 1] - r0;
             UttSlot &s = h->slot[0];
             CHK(slot_ensure(h, s, T, K));
-            CHK(knn_device(h, h->Qall.as<double>() + r0 * D, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
+            {
+                const int saved = h->precision;
+                h->precision = 0;
+                const int rc = knn_device(h, h->Qall.as<double>() + r0 * D, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr);
+                h->precision = saved;
+                if (rc) return rc;
+            }
             launch_join_costs(h->JCw.as<double>(), h->Djpad, h->Dj, join_units(h), s.cand.as<int64_t>(), T, K,
                               s.J.as<double>(), h->stream);
             launch_viterbi_dp(s.cand.as<int64_t>(), s.tdist.as<double>(), s.J.as<double>(), T, K, join_units(h),
@@ -943,6 +1043,13 @@ int snk_set_option(snk_handle h, const char *name, double value)
         h->sample_frac = value;
     } else if (!strcmp(name, "db_tiles_per_wave")) {
         h->nt_override = (int)value;
+    } else if (!strcmp(name, "f32_tiles_per_wave")) {
+        if (value != 4.0 && value != 8.0) return fail("f32_tiles_per_wave must be 4 or 8");
+        h->nt16 = (int)value;
+        h->have_weights = false;          // operands are laid out per slab: set_weights must be called again
+    } else if (!strcmp(name, "precision")) {
+        if (value != 0.0 && value != 1.0) return fail("precision must be 0 (f64 sweep) or 1 (f32 prefilter + exact f64 re-rank)");
+        h->precision = (int)value;
     } else if (!strcmp(name, "reserved_cus")) {
         if (value < 0 || value > 64) return fail("reserved_cus must be in 0..64");
         h->reserved_cus = (int)value;
@@ -964,6 +1071,11 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "list_capacity")) *out = h->cap;
     else if (!strcmp(name, "tie_overflow")) *out = h->tie_overflow;
     else if (!strcmp(name, "batch_redos")) *out = h->batch_redos;
+    else if (!strcmp(name, "f16_ready")) *out = h->f16_ready ? 1 : 0;
+    else if (!strcmp(name, "f16_fallbacks")) *out = h->f16_fallbacks;
+    else if (!strcmp(name, "last_f16_status")) *out = h->last_f16_status;
+    else if (!strcmp(name, "pool_chunks_used")) { unsigned int v[2] = {0, 0}; HIPCHK(hipMemcpy(v, h->poolctl.p, sizeof(v), hipMemcpyDeviceToHost)); *out = v[0] + 1e6 * v[1]; }
+    else if (!strcmp(name, "precision")) *out = h->precision;
     else if (!strcmp(name, "last_list_mean") || !strcmp(name, "last_list_max")) {
         // candidate-list lengths of the most recent K-NN call (debug / tuning aid)
         const int64_t n = h->last_T;
@@ -979,6 +1091,29 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "sample_slabs")) { KnnPlan p = make_plan(h, 100); *out = (double)p.a_count; }
     else if (!strcmp(name, "n_slabs")) { KnnPlan p = make_plan(h, 100); *out = (double)p.n_slabs; }
     else return fail("snk_get_info: unknown item '%s'", name);
+    return 0;
+}
+
+static int selftest_mfma16(snk_engine *h, double *err_out)
+{
+    float A[64], B[64], C[1024], R[1024];
+    for (int i = 0; i < 32; ++i) for (int k = 0; k < 2; ++k) A[i * 2 + k] = (float)((3 * i + 7 * k + 1) % 11 - 5);
+    for (int k = 0; k < 2; ++k) for (int j = 0; j < 32; ++j) B[k * 32 + j] = (float)((5 * k - 2 * j + (k * j) % 3) % 7);
+    for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) {
+        float acc = 0; for (int k = 0; k < 2; ++k) acc += A[i * 2 + k] * B[k * 32 + j]; R[i * 32 + j] = acc; }
+    DevBuf dA, dB, dC;
+    CHK(dA.ensure(sizeof(A))); CHK(dB.ensure(sizeof(B))); CHK(dC.ensure(sizeof(C)));
+    HIPCHK(hipMemcpy(dA.p, A, sizeof(A), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dB.p, B, sizeof(B), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dC.p, 0, sizeof(C)));
+    launch_mfma16_selftest(dA.as<float>(), dB.as<float>(), dC.as<float>(), h->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(C, dC.p, sizeof(C), hipMemcpyDeviceToHost));
+    double err = 0;
+    for (int i = 0; i < 1024; ++i) err = fmax(err, fabs((double)C[i] - (double)R[i]));
+    dA.release(); dB.release(); dC.release();
+    *err_out = err;
     return 0;
 }
 
@@ -1009,7 +1144,9 @@ int snk_selftest_mfma(snk_handle h, double *max_abs_err_out)
     double err = 0;
     for (int i = 0; i < 256; ++i) err = fmax(err, fabs(C[i] - R[i]));
     dA.release(); dB.release(); dC.release();
-    if (max_abs_err_out) *max_abs_err_out = err;
+    double err16 = 0;
+    CHK(selftest_mfma16(h, &err16));          // f16 32x32x16 operand / result maps of the prefilter
+    if (max_abs_err_out) *max_abs_err_out = fmax(err, err16);
     return 0;
 }
 

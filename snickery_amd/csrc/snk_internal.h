@@ -48,17 +48,32 @@ size_t knn_pool_bytes(int max_chunks);
 void launch_knn_reset(int *cnt, int64_t Tpad, int *status, unsigned int *pool_ctl,
                       unsigned int *slab_counter, int *chunk_fill, int max_chunks, hipStream_t s);
 void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int *chunk_fill,
-                       int max_chunks, int64_t Tpad, int *cnt, double *lkey, int *lidx, int cap,
-                       int *status, hipStream_t s);
+                       int max_chunks, int64_t Tpad, int64_t n_valid, int *cnt, double *lkey, int *lidx,
+                       int cap, int *status, hipStream_t s);
 // stage C: per-row select + exact re-rank in canonical order + sort
 void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, const double *qnorm,
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
-                         int cap, int64_t id_offset,
+                         int cap, int64_t id_offset, const double *eps,
                          int64_t *cand, double *dist, double *d2_out, int *status, hipStream_t s);
 void launch_candidate_dist(const double *Fw, int Dpad, int D, int64_t N, const double *Qp,
                            const int64_t *cand, int64_t T, int K, double *dist, hipStream_t s);
 void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, int K,
                        int64_t *cand, double *dist, hipStream_t s);
+
+// ---- float32 prefilter (knn16_kernels.hip) ---------------------------------------------
+void launch_build_db16(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,
+                       int64_t sample_stride, int64_t G, int nt_a, void *A32, hipStream_t s);
+void launch_fmax(const double *fnorm, int64_t N, double *out, hipStream_t s);
+void launch_prepare_queries16(const double *Qp, const double *qnorm, int64_t T, int Dt, int Dpad,
+                              const double *fmax2, double eps_c, void *B32, double *eps, hipStream_t s);
+bool launch_knn_sweep16(int mode, int nt, int grid_cus, const void *A32, const void *B32,
+                        const float *thr32, int64_t T32, int64_t n_slabs, unsigned int *ctr,
+                        float *gmin32, int64_t G, void *pool, unsigned int *pool_ctl, int *chunk_fill,
+                        int max_chunks, int pool_chunk, hipStream_t s);
+void launch_knn_threshold16(const float *gmin32, int64_t G, int64_t T, int64_t T32, int K, const double *eps,
+                            double *thr, float *thr32, hipStream_t s);
+void launch_mfma16_selftest(const float *A, const float *B, float *C, hipStream_t s);
+int knn_pool_chunk_entries();
 
 // ---- join costs + Viterbi -------------------------------------------------
 void launch_join_costs(const double *JCw, int Djpad, int Dj, int64_t n_units,
