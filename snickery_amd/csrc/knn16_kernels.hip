@@ -151,14 +151,14 @@ void launch_prepare_queries16(const double *Qp, const double *qnorm, int64_t T, 
 //   MODE 1: filter over the whole database -> entry pool (same pool / bucket / finalize as f64)
 // ---------------------------------------------------------------------------
 template <int NT, int MODE>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1)
 knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
             const float *__restrict__ thr32, int nQT, int64_t n_slabs,
             unsigned int *__restrict__ slab_counter, int qsplit, float *__restrict__ gmin32, int64_t G,
             PoolEntry16 *__restrict__ pool, unsigned int *__restrict__ pool_ctl, int *__restrict__ chunk_fill,
             int max_chunks, int pool_chunk)
 {
-    constexpr int STAGE_CAP = 64 * 16 + 128;
+    constexpr int STAGE_CAP = 64 * 16 + 256;
     __shared__ PoolEntry16 stage[(MODE == 1) ? 4 : 1][(MODE == 1) ? STAGE_CAP : 1];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -198,80 +198,114 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
         const int qt_hi = (int)(((int64_t)nQT * (part + 1)) / qsplit);
 
         // database fragments of this slab: resident in registers
-        f32x4 af[NT][8];
+        float af[NT][32];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int j4 = 0; j4 < 8; ++j4) af[nt][j4] = A32[((w * NT + nt) * 8 + j4) * 64 + lane];
-        float gm = FLT_MAX;
+            for (int j4 = 0; j4 < 8; ++j4) {
+                const f32x4 v = A32[((w * NT + nt) * 8 + j4) * 64 + lane];
+                af[nt][4 * j4] = v[0]; af[nt][4 * j4 + 1] = v[1]; af[nt][4 * j4 + 2] = v[2]; af[nt][4 * j4 + 3] = v[3];
+            }
 
-        f32x4 bq[2][8];
-        float th[2];
-        auto load_q = [&](int t, f32x4 (&x)[8], float &t32) {
-#pragma unroll
-            for (int j4 = 0; j4 < 8; ++j4) x[j4] = B32[((int64_t)t * 8 + j4) * 64 + lane];
-            if (MODE == 1) t32 = thr32[t * 32 + qcol];
-        };
-        int qt = qt_lo + (int)((w * 3) % (qt_hi - qt_lo));
-        load_q(qt, bq[0], th[0]);
-
-        auto tile_body = [&](f32x4 (&x)[8], float &tcur, f32x4 (&nx)[8], float &tnext) {
-            // the tile's own operands must have landed (one tile old); staged entries go out first
+        float b0[32], b1[32];
+        float th_cur = 0.f, th_nxt = 0.f, th_prev = -FLT_MAX;
+        auto load_q = [&](int t, float (&x)[32]) {
 #pragma unroll
             for (int j4 = 0; j4 < 8; ++j4) {
-                float x0 = x[j4][0], x1 = x[j4][1], x2 = x[j4][2], x3 = x[j4][3];
-                asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-                x[j4][0] = x0; x[j4][1] = x1; x[j4][2] = x2; x[j4][3] = x3;
+                const f32x4 v = B32[((int64_t)t * 8 + j4) * 64 + lane];
+                x[4 * j4] = v[0]; x[4 * j4 + 1] = v[1]; x[4 * j4 + 2] = v[2]; x[4 * j4 + 3] = v[3];
             }
-            if (MODE == 1) { asm volatile("" : "+v"(tcur)); if (lcount) flush_stage(); }
+            if (MODE == 1) th_nxt = thr32[t * 32 + qcol];
+        };
+        int qt = qt_lo + (int)((w * 3) % (qt_hi - qt_lo));
+        int qt_prev = qt;
+        load_q(qt, b0);
+
+        // software pipeline: while the 32-MFMA chain of one 32x32 tile issues, the 16 results of the
+        // PREVIOUS tile are tested (and the few that pass staged in LDS) in the MFMA shadows
+        f16acc pacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pacc[r] = 0.0f;
+        float gm = FLT_MAX;
+
+        auto tile_body = [&](float (&x)[32], float (&nx)[32], int it) {
+            // the tile's own operands must have landed (they were requested a tile ago)
+#pragma unroll
+            for (int k = 0; k < 32; ++k) asm volatile("" : "+v"(x[k]));
+            if (MODE == 1) asm volatile("" : "+v"(th_nxt));
+            th_cur = th_nxt;
+            if (MODE == 1 && lcount) flush_stage();      // staged entries leave a whole tile early
             const int qt_next = (qt + 1 == qt_hi) ? qt_lo : qt + 1;
-            load_q(qt_next, nx, tnext);
+            load_q(qt_next, nx);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
+                const int pnt = (nt > 0) ? nt - 1 : NT - 1;
+                const float pth = (nt > 0) ? th_cur : th_prev;
+                const int pqt = (nt > 0) ? qt : qt_prev;
+                if (MODE == 1 && lcount > STAGE_CAP - 64 * 16) flush_stage();
                 f16acc acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-                for (int j4 = 0; j4 < 8; ++j4)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[nt][j4][i], x[j4][i], acc, 0, 0, 0);
-                if (MODE == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) gm = fminf(gm, acc[r]);
-                } else {
-                    if (lcount > STAGE_CAP - 64 * 16) flush_stage();
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const bool pass = acc[r] <= tcur;
-                        const unsigned long long m = __ballot(pass);
-                        if (m) {
+                for (int k = 0; k < 32; ++k) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[nt][k], x[k], acc, 0, 0, 0);
+                    if ((k & 1) == 1) {
+                        const int r = k >> 1;
+                        const float key = pacc[r];
+                        if (MODE == 0) gm = fminf(gm, key);
+                        else {
+                            const bool pass = key <= pth;
+                            const unsigned long long m = __ballot(pass);
                             if (pass) {
                                 const int rank = __builtin_amdgcn_mbcnt_hi(
                                     (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                                 PoolEntry16 en;
-                                en.key = (double)acc[r];
-                                en.idx = (int)((w * NT + nt) * 32 + crow32(lane, r));
-                                en.row = qt * 32 + qcol;
+                                en.key = (double)key;
+                                en.idx = (int)((w * NT + pnt) * 32 + crow32(lane, r));
+                                en.row = pqt * 32 + qcol;
                                 stage[wv][lcount + rank] = en;
                             }
                             lcount += __popcll(m);
                         }
                     }
                 }
+                if (MODE == 0 && nt == 0) {
+                    // the previous query tile's group minimum is complete now
+                    if (it > 0) gmin32[((int64_t)qt_prev * 32 + qcol) * G + 2 * w + (lane >> 5)] = gm;
+                    gm = FLT_MAX;
+                }
+                pacc = acc;
             }
-            if (MODE == 0) {
-                // group = (slab w, lane half): min over the 16*NT rows this lane reduced
-                gmin32[((int64_t)qt * 32 + qcol) * G + 2 * w + (lane >> 5)] = gm;
-                gm = FLT_MAX;
-            }
+            th_prev = th_cur;
+            qt_prev = qt;
             qt = qt_next;
         };
         const int n_t = qt_hi - qt_lo;
         for (int it = 0; it < n_t; it += 2) {
-            tile_body(bq[0], th[0], bq[1], th[1]);
-            if (it + 1 < n_t) tile_body(bq[1], th[1], bq[0], th[0]);
+            tile_body(b0, b1, it);
+            if (it + 1 < n_t) tile_body(b1, b0, it + 1);
         }
+        // drain the last pending tile of this work item
+        if (MODE == 1 && lcount > STAGE_CAP - 64 * 16) flush_stage();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float key = pacc[r];
+            if (MODE == 0) gm = fminf(gm, key);
+            else {
+                const bool pass = key <= th_prev;
+                const unsigned long long m = __ballot(pass);
+                if (pass) {
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    PoolEntry16 en;
+                    en.key = (double)key;
+                    en.idx = (int)((w * NT + NT - 1) * 32 + crow32(lane, r));
+                    en.row = qt_prev * 32 + qcol;
+                    stage[wv][lcount + rank] = en;
+                }
+                lcount += __popcll(m);
+            }
+        }
+        if (MODE == 0) gmin32[((int64_t)qt_prev * 32 + qcol) * G + 2 * w + (lane >> 5)] = gm;
         item = item_next;
     }
     if (MODE == 1) {
@@ -303,13 +337,18 @@ bool launch_knn_sweep16(int mode, int nt, int grid_cus, const void *A32, const v
                         int max_chunks, int pool_chunk, hipStream_t s)
 {
     const int nQT = (int)(T32 / 32);
-    const int64_t max_blocks = (int64_t)grid_cus * ((nt <= 4) ? 2 : 1);
+    const int64_t max_blocks = (int64_t)grid_cus * ((nt <= 2) ? 2 : 1);
     int qsplit = 1;
     while (n_slabs * qsplit < 2 * 4 * max_blocks && qsplit * 2 <= nQT && qsplit < 8) qsplit *= 2;
     int64_t blocks = (n_slabs * qsplit + 3) / 4;
     if (blocks > max_blocks) blocks = max_blocks;
     if (nt == 4) {
         launch16_t<4>(mode, (int)blocks, s, A32, B32, thr32, nQT, n_slabs, ctr, qsplit, gmin32, G, pool,
+                      pool_ctl, chunk_fill, max_chunks, pool_chunk);
+        return true;
+    }
+    if (nt == 2) {
+        launch16_t<2>(mode, (int)blocks, s, A32, B32, thr32, nQT, n_slabs, ctr, qsplit, gmin32, G, pool,
                       pool_ctl, chunk_fill, max_chunks, pool_chunk);
         return true;
     }

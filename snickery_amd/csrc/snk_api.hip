@@ -100,8 +100,8 @@ struct snk_engine {
     int64_t shard_offset = 0, global_N = -1;
     // k-nn workspace
     DevBuf Qraw, Qp, Qf, qnorm, thr, gmin, cnt, lkey, lidx, status, qclass, d2tmp, slabctr, pool, poolctl, chunkfill;
-    UttSlot slot[4];
-    hipStream_t dp_stream[2] = {nullptr, nullptr};
+    UttSlot slot[8];
+    hipStream_t dp_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf res_path, res_plen, res_cost, Qall, res_status;
     // f16-split prefilter state
     DevBuf a16h, a16l, s16h, s16l, b16h, b16l, eps16, thr32, gmin32, fmax2;
@@ -230,12 +230,12 @@ int snk_create(int device_id, snk_handle *out)
     if (h->slabctr.ensure(64)) { delete h; return 1; }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
         HIPCHK(hipEventCreateWithFlags(&h->slot[i].knn_done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->slot[i].vit_done, hipEventDisableTiming));
     }
     h->dp_stream[0] = h->stream2;
-    HIPCHK(hipStreamCreateWithFlags(&h->dp_stream[1], hipStreamNonBlocking));
+    for (int i = 1; i < 4; ++i) HIPCHK(hipStreamCreateWithFlags(&h->dp_stream[i], hipStreamNonBlocking));
     *out = h;
     return 0;
 }
@@ -252,13 +252,12 @@ int snk_destroy(snk_handle h)
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
                       &h->gpath, &h->gdist};
     for (auto *b : bufs) b->release();
-    (void)hipStreamSynchronize(h->dp_stream[1]);
-    (void)hipStreamDestroy(h->dp_stream[1]);
+    for (int i = 1; i < 4; ++i) { (void)hipStreamSynchronize(h->dp_stream[i]); (void)hipStreamDestroy(h->dp_stream[i]); }
     h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
     h->res_status.release(); h->hstage.release();
     { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2};
       for (auto *b : fb) b->release(); }
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
         UttSlot &s = h->slot[i];
         DevBuf *sb[] = {&s.cand, &s.tdist, &s.J, &s.bp, &s.path, &s.plen, &s.cost};
         for (auto *b : sb) b->release();
@@ -809,10 +808,10 @@ int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offs
     }
     for (int u = 0; u < n_utts; ++u) {
         const int64_t r0 = row_offsets[u], T = row_offsets[u + 1] - r0;
-        UttSlot &s = h->slot[u & 3];
-        hipStream_t dps = h->dp_stream[u & 1];
+        UttSlot &s = h->slot[u & 7];
+        hipStream_t dps = h->dp_stream[u & 3];
         CHK(slot_ensure(h, s, T, K));
-        if (u >= 4) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));   // slot reuse
+        if (u >= 8) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));   // slot reuse
         CHK(knn_device(h, h->Qall.as<double>() + r0 * D, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(),
                        nullptr, h->res_status.as<int>() + u));
         {
@@ -830,8 +829,7 @@ int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offs
         }
         HIPCHK(hipEventRecord(s.vit_done, dps));
     }
-    HIPCHK(hipStreamSynchronize(h->dp_stream[0]));
-    HIPCHK(hipStreamSynchronize(h->dp_stream[1]));
+    for (int i = 0; i < 4; ++i) HIPCHK(hipStreamSynchronize(h->dp_stream[i]));
     HIPCHK(hipGetLastError());
     // deferred K-NN status words: redo the (rare) utterance whose sampled thresholds overflowed a list
     {
@@ -1044,7 +1042,7 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "db_tiles_per_wave")) {
         h->nt_override = (int)value;
     } else if (!strcmp(name, "f32_tiles_per_wave")) {
-        if (value != 4.0 && value != 8.0) return fail("f32_tiles_per_wave must be 4 or 8");
+        if (value != 2.0 && value != 4.0 && value != 8.0) return fail("f32_tiles_per_wave must be 2, 4 or 8");
         h->nt16 = (int)value;
         h->have_weights = false;          // operands are laid out per slab: set_weights must be called again
     } else if (!strcmp(name, "precision")) {

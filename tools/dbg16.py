@@ -13,7 +13,7 @@ print('selftest', eng.selftest_mfma())
 eng.upload_db(F_unw, JC_unw); eng.set_weights(wt, wj)
 print('f16_ready', eng.info('f16_ready'))
 U = synthetic_targets(F_unw, T, seed=1) * wt
-for nt16 in (4, 8):
+for nt16 in (2, 4):
     eng.set_option('f32_tiles_per_wave', nt16); eng.set_weights(wt, wj); cap = nt16
     c, d = eng.knn(U, K)
     eng.reset_timers()
