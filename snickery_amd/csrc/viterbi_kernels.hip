@@ -60,16 +60,34 @@ join_cost_kernel(const double *__restrict__ JCw, int Djpad, int64_t n_units,
 #pragma unroll
         for (int j = 0; j < RT; ++j) acc[i][j] = 0.0;
 
+    // register-staged gather: the next column chunk's global loads are in flight while the
+    // current chunk is being accumulated (DC doubles = 128 contiguous bytes per row and chunk)
+    constexpr int PER = (NR * (DC / 2) + 63) / 64;       // double2 loads per lane and matrix
+    double2 pe[PER], ps[PER];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = tid + k * 64;
+            if (e < NR * (DC / 2)) {
+                const int r = e / (DC / 2), c = (e % (DC / 2)) * 2;
+                pe[k] = *reinterpret_cast<const double2 *>(JCw + rowE[r] * Djpad + c0 + c);
+                ps[k] = *reinterpret_cast<const double2 *>(JCw + rowS[r] * Djpad + c0 + c);
+            }
+        }
+    };
+    fetch(0);
     for (int c0 = 0; c0 < Djpad; c0 += DC) {
-        // gather the candidate rows' column chunk: DC doubles = 256 contiguous bytes per row
-        for (int e = tid; e < NR * (DC / 2); e += 64) {
-            const int r = e / (DC / 2), c = (e % (DC / 2)) * 2;
-            const double2 ve = *reinterpret_cast<const double2 *>(JCw + rowE[r] * Djpad + c0 + c);
-            const double2 vs = *reinterpret_cast<const double2 *>(JCw + rowS[r] * Djpad + c0 + c);
-            Es[r * DCP + c] = ve.x; Es[r * DCP + c + 1] = ve.y;
-            Ss[r * DCP + c] = vs.x; Ss[r * DCP + c + 1] = vs.y;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = tid + k * 64;
+            if (e < NR * (DC / 2)) {
+                const int r = e / (DC / 2), c = (e % (DC / 2)) * 2;
+                Es[r * DCP + c] = pe[k].x; Es[r * DCP + c + 1] = pe[k].y;
+                Ss[r * DCP + c] = ps[k].x; Ss[r * DCP + c + 1] = ps[k].y;
+            }
         }
         __syncthreads();
+        if (c0 + DC < Djpad) fetch(c0 + DC);
 #pragma unroll 2
         for (int c = 0; c < DC; ++c) {
             double ev[RT], sv[RT];

@@ -2,6 +2,14 @@ import os
 import sys
 import pytest
 
+# torch bundles its own libamdhip64 with the same SONAME as /opt/rocm's: whichever is loaded first
+# serves the whole process.  Tests that hand torch CUDA tensors to libsnkhip.so (the multi-GPU
+# exchange buffers) need torch's runtime to come first, exactly as in bench.py.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'oracle')):
     if p not in sys.path:

@@ -94,3 +94,46 @@ def test_quinphone_preselection(tmp_path, golden, mini_voice):
     np.testing.assert_allclose(dist, golden['quin_distances'], rtol=1e-12)
     assert np.array_equal(dist, o.candidate_distances(mini_voice['F'], golden['quin_queries'], cand))
     synth.close()
+
+
+def test_shard_engine_device_pointer_api(golden, mini_voice):
+    """The multi-GPU exchange path on one GPU: shard-local top-K written straight into torch CUDA
+    tensors (what RCCL all-gathers), then merged on device.  Two half-database 'shards' on the same
+    GPU stand in for two ranks; the merged result must equal the unsharded search."""
+    import torch
+    import snickery_amd
+    from snickery_amd.dist import HipShardEngine, ShardedSearch, shard_bounds
+    F_unw, JC_unw = mini_voice['F_unw'], mini_voice['JC_unw']
+    N = F_unw.shape[0]
+    U = golden['knn_queries']
+    K = 12
+    dev = torch.device('cuda', 0)
+    d2_all = torch.empty(2, U.shape[0], K, dtype=torch.float64, device=dev)
+    id_all = torch.empty(2, U.shape[0], K, dtype=torch.int64, device=dev)
+    engines = []
+    for r in range(2):
+        lo, hi = shard_bounds(N, 2, r)
+        e = snickery_amd.HipSearchEngine(0)
+        e.upload_target_only(F_unw[lo:hi])
+        e.upload_join_only(JC_unw)
+        e.set_shard(lo, N)
+        e.set_weights(mini_voice['wt'], mini_voice['wj'])
+        e.knn_local_dev(U, K, d2_all[r].data_ptr(), id_all[r].data_ptr())
+        engines.append(e)
+    torch.cuda.synchronize()
+    cand, dist = engines[0].merge_topk_dev(d2_all.data_ptr(), id_all.data_ptr(), 2, U.shape[0], K)
+    assert np.array_equal(cand, golden['knn_candidates'])
+    oc, od = o.knn_bruteforce(mini_voice['F'], U, K)
+    assert np.array_equal(cand, oc) and np.array_equal(dist, od)
+    # Viterbi on a "rank" that holds only a target shard but the full join matrix
+    path, cost = engines[1].viterbi(golden['join_candidates'], golden['knn_distances'])
+    assert (path, cost) == o.viterbi(golden['join_candidates'], golden['knn_distances'], mini_voice['E'], mini_voice['S'])
+    # world_size 1 through the ShardedSearch front end
+    search = ShardedSearch(HipShardEngine(engines[0], dev), rank=0, world_size=1)
+    engines[0].upload_db(F_unw, JC_unw)
+    engines[0].set_shard(0, N)
+    engines[0].set_weights(mini_voice['wt'], mini_voice['wj'])
+    c1, d1 = search.knn(U, K)
+    assert np.array_equal(c1, oc) and np.array_equal(d1, od)
+    for e in engines:
+        e.close()
