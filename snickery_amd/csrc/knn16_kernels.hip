@@ -154,11 +154,12 @@ template <int NT, int MODE>
 __global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1)
 knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
             const float *__restrict__ thr32, int nQT, int64_t n_slabs,
-            unsigned int *__restrict__ slab_counter, int qsplit, float *__restrict__ gmin32, int64_t G,
+            unsigned int *__restrict__ slab_counter, int qsplit, int64_t n_main_slabs, int qsplit_tail,
+            float *__restrict__ gmin32, int64_t G,
             PoolEntry16 *__restrict__ pool, unsigned int *__restrict__ pool_ctl, int *__restrict__ chunk_fill,
             int max_chunks, int pool_chunk)
 {
-    constexpr int STAGE_CAP = 64 * 16 + 256;
+    constexpr int STAGE_CAP = 64 * 16 * 2 + 256;
     __shared__ PoolEntry16 stage[(MODE == 1) ? 4 : 1][(MODE == 1) ? STAGE_CAP : 1];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -188,14 +189,20 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
         lcount = 0;
     };
 
-    const int64_t n_items = n_slabs * qsplit;
+    // work items: whole rounds of (slab, part) items first; the slabs of the last, partial round
+    // are cut into more parts so that the tail of the persistent sweep stays short
+    const int64_t n_main_items = n_main_slabs * qsplit;
+    const int64_t n_items = n_main_items + (n_slabs - n_main_slabs) * qsplit_tail;
     int64_t item = grab();
     while (item < n_items) {
         const int64_t item_next = grab();
-        const int64_t w = item / qsplit;
-        const int part = (int)(item % qsplit);
-        const int qt_lo = (int)(((int64_t)nQT * part) / qsplit);
-        const int qt_hi = (int)(((int64_t)nQT * (part + 1)) / qsplit);
+        const bool tail = item >= n_main_items;
+        const int qs = tail ? qsplit_tail : qsplit;
+        const int64_t rel = tail ? item - n_main_items : item;
+        const int64_t w = (tail ? n_main_slabs : 0) + rel / qs;
+        const int part = (int)(rel % qs);
+        const int qt_lo = (int)(((int64_t)nQT * part) / qs);
+        const int qt_hi = (int)(((int64_t)nQT * (part + 1)) / qs);
 
         // database fragments of this slab: resident in registers
         float af[NT][32];
@@ -223,9 +230,13 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
 
         // software pipeline: while the 32-MFMA chain of one 32x32 tile issues, the 16 results of the
         // PREVIOUS tile are tested (and the few that pass staged in LDS) in the MFMA shadows
-        f16acc pacc;
+        constexpr int CH = (NT >= 2) ? 2 : 1;          // database tiles per step: independent MFMA chains
+        constexpr int NSTEP = NT / CH;
+        f16acc pacc[CH];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pacc[r] = 0.0f;
+        for (int j = 0; j < CH; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pacc[j][r] = 0.0f;
         float gm = FLT_MAX;
 
         auto tile_body = [&](float (&x)[32], float (&nx)[32], int it) {
@@ -238,43 +249,54 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
             const int qt_next = (qt + 1 == qt_hi) ? qt_lo : qt + 1;
             load_q(qt_next, nx);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int pnt = (nt > 0) ? nt - 1 : NT - 1;
-                const float pth = (nt > 0) ? th_cur : th_prev;
-                const int pqt = (nt > 0) ? qt : qt_prev;
-                if (MODE == 1 && lcount > STAGE_CAP - 64 * 16) flush_stage();
-                f16acc acc;
+            for (int st = 0; st < NSTEP; ++st) {
+                const int pnt = ((st > 0) ? st - 1 : NSTEP - 1) * CH;
+                const float pth = (st > 0) ? th_cur : th_prev;
+                const int pqt = (st > 0) ? qt : qt_prev;
+                if (MODE == 1 && lcount > STAGE_CAP - 64 * 16 * CH) flush_stage();
+                f16acc acc[CH];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                for (int j = 0; j < CH; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 32; ++k) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[nt][k], x[k], acc, 0, 0, 0);
-                    if ((k & 1) == 1) {
-                        const int r = k >> 1;
-                        const float key = pacc[r];
-                        if (MODE == 0) gm = fminf(gm, key);
-                        else {
-                            const bool pass = key <= pth;
-                            const unsigned long long m = __ballot(pass);
-                            if (pass) {
-                                const int rank = __builtin_amdgcn_mbcnt_hi(
-                                    (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                PoolEntry16 en;
-                                en.key = (double)key;
-                                en.idx = (int)((w * NT + pnt) * 32 + crow32(lane, r));
-                                en.row = pqt * 32 + qcol;
-                                stage[wv][lcount + rank] = en;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[st * CH + j][k], x[k], acc[j], 0, 0, 0);
+                    // one pending result per MFMA: 16*CH results over 32*CH MFMAs
+                    if (CH == 2 || (k & 1) == 1) {
+                        const int e = (CH == 2) ? k : (k >> 1);      // 0 .. 16*CH-1
+                        if (e < 16 * CH) {
+                            const int j = e / 16, r = e % 16;
+                            const float key = pacc[j][r];
+                            if (MODE == 0) gm = fminf(gm, key);
+                            else {
+                                const bool pass = key <= pth;
+                                const unsigned long long m = __ballot(pass);
+                                if (pass) {
+                                    const int rank = __builtin_amdgcn_mbcnt_hi(
+                                        (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                    PoolEntry16 en;
+                                    en.key = (double)key;
+                                    en.idx = (int)((w * NT + pnt + j) * 32 + crow32(lane, r));
+                                    en.row = pqt * 32 + qcol;
+                                    stage[wv][lcount + rank] = en;
+                                }
+                                lcount += __popcll(m);
                             }
-                            lcount += __popcll(m);
                         }
                     }
                 }
-                if (MODE == 0 && nt == 0) {
+                if (MODE == 0 && st == 0) {
                     // the previous query tile's group minimum is complete now
                     if (it > 0) gmin32[((int64_t)qt_prev * 32 + qcol) * G + 2 * w + (lane >> 5)] = gm;
                     gm = FLT_MAX;
                 }
-                pacc = acc;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    pacc[j] = acc[j];
+                }
             }
             th_prev = th_cur;
             qt_prev = qt;
@@ -285,26 +307,28 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
             tile_body(b0, b1, it);
             if (it + 1 < n_t) tile_body(b1, b0, it + 1);
         }
-        // drain the last pending tile of this work item
-        if (MODE == 1 && lcount > STAGE_CAP - 64 * 16) flush_stage();
+        // drain the last pending step of this work item
+        if (MODE == 1 && lcount > STAGE_CAP - 64 * 16 * CH) flush_stage();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float key = pacc[r];
-            if (MODE == 0) gm = fminf(gm, key);
-            else {
-                const bool pass = key <= th_prev;
-                const unsigned long long m = __ballot(pass);
-                if (pass) {
-                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    PoolEntry16 en;
-                    en.key = (double)key;
-                    en.idx = (int)((w * NT + NT - 1) * 32 + crow32(lane, r));
-                    en.row = qt_prev * 32 + qcol;
-                    stage[wv][lcount + rank] = en;
+        for (int j = 0; j < CH; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float key = pacc[j][r];
+                if (MODE == 0) gm = fminf(gm, key);
+                else {
+                    const bool pass = key <= th_prev;
+                    const unsigned long long m = __ballot(pass);
+                    if (pass) {
+                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        PoolEntry16 en;
+                        en.key = (double)key;
+                        en.idx = (int)((w * NT + (NSTEP - 1) * CH + j) * 32 + crow32(lane, r));
+                        en.row = qt_prev * 32 + qcol;
+                        stage[wv][lcount + rank] = en;
+                    }
+                    lcount += __popcll(m);
                 }
-                lcount += __popcll(m);
             }
-        }
         if (MODE == 0) gmin32[((int64_t)qt_prev * 32 + qcol) * G + 2 * w + (lane >> 5)] = gm;
         item = item_next;
     }
@@ -317,17 +341,16 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
 template <int NT>
 static void launch16_t(int mode, int blocks, hipStream_t s, const void *A32, const void *B32,
                        const float *thr32, int nQT, int64_t n_slabs, unsigned int *ctr,
-                       int qsplit, float *gmin32, int64_t G, void *pool, unsigned int *pool_ctl,
-                       int *chunk_fill, int max_chunks, int pool_chunk)
+                       int qsplit, int64_t n_main, int qtail, float *gmin32, int64_t G, void *pool,
+                       unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk)
 {
-    if (mode == 0)
-        hipLaunchKernelGGL((knn_sweep16<NT, 0>), dim3(blocks), dim3(256), 0, s, (const f32x4 *)A32,
-                           (const f32x4 *)B32, thr32, nQT, n_slabs, ctr, qsplit, gmin32, G, (PoolEntry16 *)pool,
-                           pool_ctl, chunk_fill, max_chunks, pool_chunk);
-    else
-        hipLaunchKernelGGL((knn_sweep16<NT, 1>), dim3(blocks), dim3(256), 0, s, (const f32x4 *)A32,
-                           (const f32x4 *)B32, thr32, nQT, n_slabs, ctr, qsplit, gmin32, G, (PoolEntry16 *)pool,
-                           pool_ctl, chunk_fill, max_chunks, pool_chunk);
+#define SNK_L16(MODE_)                                                                                    \
+    hipLaunchKernelGGL((knn_sweep16<NT, MODE_>), dim3(blocks), dim3(256), 0, s, (const f32x4 *)A32,          \
+                       (const f32x4 *)B32, thr32, nQT, n_slabs, ctr, qsplit, n_main, qtail, gmin32, G, (PoolEntry16 *)pool, \
+                       pool_ctl, chunk_fill, max_chunks, pool_chunk)
+    if (mode == 0) SNK_L16(0);
+    else SNK_L16(1);
+#undef SNK_L16
 }
 
 // nt: tiles (32 units) per wave.  Returns false when the shape is not instantiated.
@@ -342,21 +365,17 @@ bool launch_knn_sweep16(int mode, int nt, int grid_cus, const void *A32, const v
     while (n_slabs * qsplit < 2 * 4 * max_blocks && qsplit * 2 <= nQT && qsplit < 8) qsplit *= 2;
     int64_t blocks = (n_slabs * qsplit + 3) / 4;
     if (blocks > max_blocks) blocks = max_blocks;
-    if (nt == 4) {
-        launch16_t<4>(mode, (int)blocks, s, A32, B32, thr32, nQT, n_slabs, ctr, qsplit, gmin32, G, pool,
-                      pool_ctl, chunk_fill, max_chunks, pool_chunk);
-        return true;
+    int64_t n_main = n_slabs;
+    int qtail = qsplit;
+    sweep_tail_split(n_slabs, qsplit, blocks * 4, nQT, &n_main, &qtail);
+#define SNK_NT16(NT_)                                                                                      \
+    if (nt == NT_) {                                                                                       \
+        launch16_t<NT_>(mode, (int)blocks, s, A32, B32, thr32, nQT, n_slabs, ctr, qsplit, n_main, qtail,   \
+                        gmin32, G, pool, pool_ctl, chunk_fill, max_chunks, pool_chunk);                    \
+        return true;                                                                                       \
     }
-    if (nt == 2) {
-        launch16_t<2>(mode, (int)blocks, s, A32, B32, thr32, nQT, n_slabs, ctr, qsplit, gmin32, G, pool,
-                      pool_ctl, chunk_fill, max_chunks, pool_chunk);
-        return true;
-    }
-    if (nt == 8) {
-        launch16_t<8>(mode, (int)blocks, s, A32, B32, thr32, nQT, n_slabs, ctr, qsplit, gmin32, G, pool,
-                      pool_ctl, chunk_fill, max_chunks, pool_chunk);
-        return true;
-    }
+    SNK_NT16(4) SNK_NT16(2) SNK_NT16(8)
+#undef SNK_NT16
     return false;
 }
 

@@ -47,7 +47,7 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
           const double *__restrict__ Qf, const double *__restrict__ thr,
           int nQT, int64_t row_stride, int64_t row_limit, int64_t n_slabs,
           int64_t wave_stride, int64_t tile_stride, unsigned int *__restrict__ slab_counter,
-          int qsplit,
+          int qsplit, int64_t n_main_slabs, int qsplit_tail,
           double *__restrict__ gmin, int64_t G,
           PoolEntry *__restrict__ pool, unsigned int *__restrict__ pool_ctl,
           int *__restrict__ chunk_fill, int max_chunks,
@@ -107,14 +107,20 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
 
     // work item = (slab, part): the query tiles of a slab may be split over `qsplit` items so that
     // a small sweep (stage A) still spreads over every compute unit
-    const int64_t n_items = n_slabs * qsplit;
+    // whole rounds of items first; the slabs of the last, partial round are cut into more parts
+    // so that the tail of the persistent sweep stays short
+    const int64_t n_main_items = n_main_slabs * qsplit;
+    const int64_t n_items = n_main_items + (n_slabs - n_main_slabs) * qsplit_tail;
     int64_t item = grab_slab();
     while (item < n_items) {
     const int64_t item_next = grab_slab();
-    const int64_t w = item / qsplit;
-    const int part = (int)(item % qsplit);
-    const int qt_lo = (int)(((int64_t)nQT * part) / qsplit);
-    const int qt_hi = (int)(((int64_t)nQT * (part + 1)) / qsplit);
+    const bool tail = item >= n_main_items;
+    const int qs = tail ? qsplit_tail : qsplit;
+    const int64_t rel = tail ? item - n_main_items : item;
+    const int64_t w = (tail ? n_main_slabs : 0) + rel / qs;
+    const int part = (int)(rel % qs);
+    const int qt_lo = (int)(((int64_t)nQT * part) / qs);
+    const int qt_hi = (int)(((int64_t)nQT * (part + 1)) / qs);
     const int n_tiles = qt_hi - qt_lo;
     // Row mapping: tile nt, lane-row r16 of slab w holds database row
     //     (w*wave_stride + nt*tile_stride + r16) * row_stride
@@ -336,18 +342,38 @@ knn_sweep(const double *__restrict__ Fw, const double *__restrict__ fnorm,
     }
 }
 
+// Persistent sweeps hand out (slab, part) items round by round.  When the item count is not a
+// multiple of the resident waves the last round is partial: its slabs are cut into `*qtail` parts
+// (>= qsplit, <= 8) so that about one full round of short items finishes the sweep.
+void sweep_tail_split(int64_t n_slabs, int qsplit, int64_t waves, int nQT, int64_t *n_main, int *qtail)
+{
+    *n_main = n_slabs;
+    *qtail = qsplit;
+    if (waves <= 0) return;
+    const int64_t items = n_slabs * qsplit;
+    const int64_t full_rounds = items / waves;
+    const int64_t main_slabs = (full_rounds * waves) / qsplit;
+    const int64_t rest = n_slabs - main_slabs;
+    if (rest <= 0 || full_rounds == 0) return;
+    int q = qsplit;
+    while (rest * q < waves && q * 2 <= nQT && q < 8) q *= 2;
+    if (q == qsplit) return;
+    *n_main = main_slabs;
+    *qtail = q;
+}
+
 template <int NT, int DCH, int WPS>
 static void launch_sweep_t(int mode, bool cls, int blocks, hipStream_t s,
                            const double *Fw, const double *fnorm, const double *Qp,
                            const double *thr, int nQT, int64_t rstride, int64_t rlimit, int64_t ns,
                            int64_t wstride, int64_t tstride, unsigned int *ctr, int qsplit,
-                           double *gmin, int64_t G, PoolEntry *pool, unsigned int *pool_ctl,
+                           int64_t n_main, int qtail, double *gmin, int64_t G, PoolEntry *pool, unsigned int *pool_ctl,
                            int *chunk_fill, int max_chunks,
                            const int32_t *uc, const int32_t *qc)
 {
 #define SNK_LAUNCH(MODE, CLS)                                                                    \
     hipLaunchKernelGGL((knn_sweep<NT, DCH, MODE, CLS, WPS>), dim3(blocks), dim3(256), 0, s, Fw,  \
-                       fnorm, Qp, thr, nQT, rstride, rlimit, ns, wstride, tstride, ctr, qsplit,              \
+                       fnorm, Qp, thr, nQT, rstride, rlimit, ns, wstride, tstride, ctr, qsplit, n_main, qtail, \
                        gmin, G,                                                                   \
                        pool, pool_ctl, chunk_fill, max_chunks, uc, qc)
     if (mode == 0) { if (cls) SNK_LAUNCH(0, true); else SNK_LAUNCH(0, false); }
@@ -373,10 +399,13 @@ static void launch_sweep(const KnnPlan &p, int mode, int64_t rstride, int64_t rl
     if (blocks > max_blocks) blocks = max_blocks;
     const bool cls = (uc != nullptr);
     unsigned int *ctr = p.slab_counter + mode;               // zeroed by knn_reset
+    int64_t n_main = ns;
+    int qtail = qsplit;
+    sweep_tail_split(ns, qsplit, blocks * 4, nQT, &n_main, &qtail);
 #define SNK_CASE(NT_, DCH_, WPS_)                                                              \
     if (p.nt == NT_ && p.dch == DCH_) {                                                        \
         launch_sweep_t<NT_, DCH_, WPS_>(mode, cls, (int)blocks, s, Fw, fnorm, Qp, thr, nQT, rstride, \
-                                        rlimit, ns, wstride, tstride, ctr, qsplit, gmin, G,      \
+                                        rlimit, ns, wstride, tstride, ctr, qsplit, n_main, qtail, gmin, G, \
                                         reinterpret_cast<PoolEntry *>(pool), pool_ctl, chunk_fill, \
                                         max_chunks, uc, qc);                                   \
         return;                                                                                \

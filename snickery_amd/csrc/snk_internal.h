@@ -74,6 +74,7 @@ void launch_knn_threshold16(const float *gmin32, int64_t G, int64_t T, int64_t T
                             double *thr, float *thr32, hipStream_t s);
 void launch_mfma16_selftest(const float *A, const float *B, float *C, hipStream_t s);
 int knn_pool_chunk_entries();
+void sweep_tail_split(int64_t n_slabs, int qsplit, int64_t waves, int nQT, int64_t *n_main, int *qtail);
 
 // ---- join costs + Viterbi -------------------------------------------------
 void launch_join_costs(const double *JCw, int Djpad, int Dj, int64_t n_units,
