@@ -15,16 +15,14 @@
 // stream over (Dj + Dt) * 4 bytes per unit.  Squared distances are accumulated in the canonical
 // oracle order (column by column, separately rounded sub/mul/add), so the argmin is bit-exact.
 //
-// Per step: greedy_scan_kernel (one workgroup per R consecutive windows; the R rows form ONE
-// contiguous span of the row-major matrix, copied to LDS with 16-byte loads; thread t then
-// walks row t, odd row pitch => conflict-free) and greedy_pick_kernel (cross-block argmin,
-// appends to the path, fetches the winner's `current_join_rep` row as the next `prev`).
+// Per step ONE launch of greedy_step_kernel (see the comment on the kernel).
 #include "snk_internal.h"
 #include <float.h>
 
 namespace snk {
 
-#define GR_R 128          // windows per workgroup
+#define GR_R 256          // windows per workgroup (one thread per window)
+#define GR_CC 32          // columns per staged chunk
 #define GR_MAX_EP 16      // max multiepoch
 
 struct GreedyArgs {
@@ -33,74 +31,90 @@ struct GreedyArgs {
     int me, nep; int ep[GR_MAX_EP];       // epochs of the window that enter the target term
     int prev_col0, cur_col0, jdim;
     int64_t prev_row0, cur_row0, Nwin;
-    int R;                                // windows per workgroup (<= GR_R, fits LDS)
+    int64_t n_jc_rows, n_f_rows;          // matrix heights (clamp for the ragged last workgroup)
     const double *Q;                      // (T, Dt) weighted targets, row-major
-    const double *prev_vec;               // (jdim)
+    double *prev_vec;                     // (jdim): read by every block, rewritten by the last one
 };
 
+// One step of the greedy search = ONE launch:
+//   every workgroup scans GR_R consecutive windows (thread t owns window i0+t): the join columns
+//   and then, epoch by epoch, the target columns stream through LDS in 32-column chunks
+//   (coalesced loads: a wave instruction reads 32 consecutive floats of two rows), register-staged
+//   one chunk ahead; thread t accumulates its window's squared distance in the canonical column
+//   order.  The workgroup's (min, argmin) goes to global memory; the workgroup that arrives LAST
+//   (agent-scope release/acquire around an arrival counter) reduces all partial results, appends
+//   the winner to the path and fetches its `current_join_rep` row as the next step's `prev`.
 __global__ void __launch_bounds__(GR_R)
-greedy_scan_kernel(GreedyArgs a, int64_t step, double *__restrict__ blk_min,
-                   int64_t *__restrict__ blk_arg)
+greedy_step_kernel(GreedyArgs a, int64_t step, double *__restrict__ blk_min, int64_t *__restrict__ blk_arg,
+                   unsigned int *__restrict__ arrive, int64_t *__restrict__ path, double *__restrict__ dist)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int64_t i0 = (int64_t)blockIdx.x * a.R;
-    const int rows = (int)((a.Nwin - i0 < a.R) ? (a.Nwin - i0) : a.R);
-    const int frows = rows + a.me - 1;
-
-    float *jt = reinterpret_cast<float *>(smem);                    // [GR_R][Dj]
-    float *ft = jt + ((a.R * a.Dj + 3) & ~3);                       // [R+me-1][Dt]
-    double *wjs = reinterpret_cast<double *>(ft + (((a.R + a.me - 1) * a.Dt + 3) & ~3));
-    double *wts = wjs + a.Dj;
-    double *prevs = wts + a.Dt;
-    double *qs = prevs + a.jdim;                                     // [nep][Dt]
+    __shared__ float buf[2][GR_R][GR_CC + 1];
+    __shared__ double ref[GR_CC], wgt[GR_CC];
     __shared__ double red_v[GR_R];
     __shared__ int64_t red_i[GR_R];
+    __shared__ int is_last;
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * GR_R;
 
-    // contiguous spans -> LDS
-    {
-        const float *src = a.JC_unw + (a.prev_row0 + i0) * a.Dj;
-        const int n = rows * a.Dj;
-        for (int e = tid; e < n; e += GR_R) jt[e] = src[e];
-        const float *fsrc = a.F_unw + i0 * a.Dt;
-        const int nf = frows * a.Dt;
-        for (int e = tid; e < nf; e += GR_R) ft[e] = fsrc[e];
-        for (int e = tid; e < a.Dj; e += GR_R) wjs[e] = a.wj[e];
-        for (int e = tid; e < a.Dt; e += GR_R) wts[e] = a.wt[e];
-        for (int e = tid; e < a.jdim; e += GR_R) prevs[e] = a.prev_vec[e];
-        for (int e = tid; e < a.nep * a.Dt; e += GR_R) {
-            const int k = e / a.Dt, c = e % a.Dt;
-            qs[e] = a.Q[(step * a.me + a.ep[k]) * a.Dt + c];
+    // chunk schedule: part 0 = join columns, parts 1..nep = target columns of epoch ep[k]
+    const int jch = (a.jdim + GR_CC - 1) / GR_CC, tch = (a.Dt + GR_CC - 1) / GR_CC;
+    const int n_chunks = jch + a.nep * tch;
+    auto chunk_info = [&](int c, const float *&base, int &pitch, int64_t &row0, int64_t &nrows, int &col0,
+                          int &ncols, const double *&w, const double *&rf) {
+        if (c < jch) {
+            base = a.JC_unw; pitch = a.Dj; row0 = a.prev_row0 + i0; nrows = a.n_jc_rows;
+            col0 = a.prev_col0 + c * GR_CC; ncols = min(GR_CC, a.jdim - c * GR_CC);
+            w = a.wj + col0; rf = a.prev_vec + c * GR_CC;
+        } else {
+            const int k = (c - jch) / tch, cc = (c - jch) % tch;
+            base = a.F_unw; pitch = a.Dt; row0 = i0 + a.ep[k]; nrows = a.n_f_rows;
+            col0 = cc * GR_CC; ncols = min(GR_CC, a.Dt - cc * GR_CC);
+            w = a.wt + col0; rf = a.Q + (step * a.me + a.ep[k]) * a.Dt + col0;
         }
+    };
+    float stage[GR_CC];      // this thread's share of the next chunk
+    auto fetch = [&](int c) {
+        const float *base; int pitch, col0, ncols; int64_t row0, nrows; const double *w, *rf;
+        chunk_info(c, base, pitch, row0, nrows, col0, ncols, w, rf);
+#pragma unroll
+        for (int j = 0; j < GR_CC; ++j) {
+            const int e = tid + j * GR_R;             // lanes -> consecutive columns of a row
+            const int r = e / GR_CC, cc = e % GR_CC;
+            int64_t row = row0 + r;
+            if (row >= nrows) row = nrows - 1;
+            stage[j] = (cc < ncols) ? base[row * pitch + col0 + cc] : 0.0f;
+        }
+    };
+    double acc_j = 0.0, acc_t = 0.0;
+    fetch(0);
+    for (int c = 0; c < n_chunks; ++c) {
+        const float *base; int pitch, col0, ncols; int64_t row0, nrows; const double *w, *rf;
+        chunk_info(c, base, pitch, row0, nrows, col0, ncols, w, rf);
+        float (*B)[GR_CC + 1] = buf[c & 1];
+#pragma unroll
+        for (int j = 0; j < GR_CC; ++j) {
+            const int e = tid + j * GR_R;
+            B[e / GR_CC][e % GR_CC] = stage[j];
+        }
+        if (tid < GR_CC) {
+            ref[tid] = (tid < ncols) ? rf[tid] : 0.0;
+            wgt[tid] = (tid < ncols) ? w[tid] : 0.0;
+        }
+        __syncthreads();
+        if (c + 1 < n_chunks) fetch(c + 1);           // in flight while this chunk is accumulated
+        double acc = (c < jch) ? acc_j : acc_t;
+        for (int cc = 0; cc < ncols; ++cc) {
+            const double v = __dmul_rn((double)B[tid][cc], wgt[cc]);
+            const double d = __dsub_rn(v, ref[cc]);
+            acc = __dadd_rn(acc, __dmul_rn(d, d));
+        }
+        if (c < jch) acc_j = acc; else acc_t = acc;
+        __syncthreads();
     }
-    __syncthreads();
-
     double best = DBL_MAX;
     int64_t arg = INT64_MAX;
-    if (tid < rows) {
-        double accj = 0.0;
-        const float *jr = jt + tid * a.Dj + a.prev_col0;
-        const double *wjr = wjs + a.prev_col0;
-        for (int c = 0; c < a.jdim; ++c) {
-            const double v = __dmul_rn((double)jr[c], wjr[c]);
-            const double d = __dsub_rn(v, prevs[c]);
-            accj = __dadd_rn(accj, __dmul_rn(d, d));
-        }
-        double acct = 0.0;
-        for (int k = 0; k < a.nep; ++k) {
-            const float *fr = ft + (tid + a.ep[k]) * a.Dt;
-            const double *q = qs + k * a.Dt;
-            for (int c = 0; c < a.Dt; ++c) {
-                const double v = __dmul_rn((double)fr[c], wts[c]);
-                const double d = __dsub_rn(v, q[c]);
-                acct = __dadd_rn(acct, __dmul_rn(d, d));
-            }
-        }
-        best = __dadd_rn(accj, acct);
-        arg = i0 + tid;
-    }
-    red_v[tid] = best;
-    red_i[tid] = arg;
+    if (i0 + tid < a.Nwin) { best = __dadd_rn(acc_j, acc_t); arg = i0 + tid; }
+    red_v[tid] = best; red_i[tid] = arg;
     __syncthreads();
     for (int off = GR_R / 2; off > 0; off >>= 1) {
         if (tid < off) {
@@ -110,27 +124,31 @@ greedy_scan_kernel(GreedyArgs a, int64_t step, double *__restrict__ blk_min,
         }
         __syncthreads();
     }
-    if (tid == 0) { blk_min[blockIdx.x] = red_v[0]; blk_arg[blockIdx.x] = red_i[0]; }
-}
-
-__global__ void __launch_bounds__(256)
-greedy_pick_kernel(GreedyArgs a, int64_t step, const double *__restrict__ blk_min,
-                   const int64_t *__restrict__ blk_arg, int nblk, double *__restrict__ prev_vec,
-                   int64_t *__restrict__ path, double *__restrict__ dist)
-{
-    __shared__ double red_v[256];
-    __shared__ int64_t red_i[256];
-    const int tid = threadIdx.x;
-    double best = DBL_MAX;
-    int64_t arg = INT64_MAX;
-    for (int b = tid; b < nblk; b += 256) {
-        const double v = blk_min[b];
-        const int64_t i = blk_arg[b];
+    if (tid == 0) {
+        blk_min[blockIdx.x] = red_v[0];
+        blk_arg[blockIdx.x] = red_i[0];
+        // publish, then arrive (MI355X guide G16: agent-scope release before the counter)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (t == gridDim.x - 1);
+        if (is_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    // ---- last workgroup: global argmin (lowest index on exact ties), path, next prev ----
+    best = DBL_MAX; arg = INT64_MAX;
+    for (int b = tid; b < (int)gridDim.x; b += GR_R) {
+        const double v = __hip_atomic_load(&blk_min[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t i = __hip_atomic_load(&blk_arg[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v < best || (v == best && i < arg)) { best = v; arg = i; }
     }
     red_v[tid] = best; red_i[tid] = arg;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = GR_R / 2; off > 0; off >>= 1) {
         if (tid < off) {
             const double v2 = red_v[tid + off];
             const int64_t i2 = red_i[tid + off];
@@ -139,84 +157,62 @@ greedy_pick_kernel(GreedyArgs a, int64_t step, const double *__restrict__ blk_mi
         __syncthreads();
     }
     const int64_t ix = red_i[0];
-    if (tid == 0) { path[step] = ix; if (dist) dist[step] = __dsqrt_rn(red_v[0]); }
+    if (tid == 0) {
+        path[step] = ix;
+        if (dist) dist[step] = __dsqrt_rn(red_v[0]);
+        *arrive = 0;                                   // re-armed for the next step (next launch)
+    }
     // prev_join_vector = current_join_rep[ix]   (synth_simple.py:501)
     const float *src = a.JC_unw + (a.cur_row0 + ix) * a.Dj + a.cur_col0;
-    for (int c = tid; c < a.jdim; c += 256)
-        prev_vec[c] = __dmul_rn((double)src[c], a.wj[a.cur_col0 + c]);
+    for (int c = tid; c < a.jdim; c += GR_R)
+        a.prev_vec[c] = __dmul_rn((double)src[c], a.wj[a.cur_col0 + c]);
 }
 
-__global__ void greedy_init_prev_kernel(GreedyArgs a, int64_t start_state, double *prev_vec)
+__global__ void greedy_init_prev_kernel(GreedyArgs a, int64_t start_state, unsigned int *arrive)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) *arrive = 0;
     if (c >= a.jdim) return;
-    if (start_state < 0) { prev_vec[c] = 0.0; return; }     // np.zeros((n,)) synth_simple.py:467-468
+    if (start_state < 0) { a.prev_vec[c] = 0.0; return; }     // np.zeros((n,)) synth_simple.py:467-468
     const float *src = a.JC_unw + (a.prev_row0 + start_state) * a.Dj + a.prev_col0;
-    prev_vec[c] = __dmul_rn((double)src[c], a.wj[a.prev_col0 + c]);
+    a.prev_vec[c] = __dmul_rn((double)src[c], a.wj[a.prev_col0 + c]);
 }
 
-static int greedy_rows(const GreedyLayout &g, int Dt, int Dj)
+static void fill_args(GreedyArgs &a, const GreedyLayout &g, const float *F_unw, int Dt, const double *wt,
+                      const float *JC_unw, int Dj, const double *wj, const double *Q, double *prev_vec,
+                      bool greedy_mode)
 {
-    const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
-    const size_t fixed = (size_t)(Dj + Dt + g.jdim + nep * Dt) * sizeof(double) + (size_t)(g.me + 2) * Dt * 4 + 64;
-    const size_t budget = 144 * 1024;
-    if (fixed >= budget) return 0;
-    size_t r = (budget - fixed) / ((size_t)(Dj + Dt) * sizeof(float));
-    if (r > GR_R) r = GR_R;
-    if (r >= 64) r = (r / 32) * 32;
-    return (int)r;
-}
-
-static size_t greedy_shmem_for(const GreedyLayout &g, int Dt, int Dj, int R)
-{
-    const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
-    return (size_t)(((R * Dj + 3) & ~3) + (((R + g.me - 1) * Dt + 3) & ~3)) * sizeof(float)
-           + (size_t)(Dj + Dt + g.jdim + nep * Dt) * sizeof(double);
+    a.JC_unw = JC_unw; a.Dj = Dj; a.wj = wj;
+    a.F_unw = F_unw; a.Dt = Dt; a.wt = wt;
+    if (!greedy_mode) { a.me = 1; a.nep = 1; a.ep[0] = 0; }
+    else {
+        a.me = g.me;
+        if (g.last_frame_as_target && g.me > 1) { a.nep = 2; a.ep[0] = 0; a.ep[1] = g.me - 1; }
+        else { a.nep = g.me; for (int e = 0; e < g.me; ++e) a.ep[e] = e; }
+    }
+    a.prev_col0 = g.prev_col0; a.cur_col0 = g.cur_col0; a.jdim = g.jdim;
+    a.prev_row0 = g.prev_row0; a.cur_row0 = g.cur_row0; a.Nwin = g.Nwin;
+    a.n_jc_rows = g.Nwin + g.me;          // join_contexts has N+1 = Nwin + me rows
+    a.n_f_rows = g.Nwin + g.me - 1;       // N
+    a.Q = Q; a.prev_vec = prev_vec;
 }
 
 void launch_greedy(const GreedyLayout &g, const float *F_unw, int Dt, const double *wt,
                    const float *JC_unw, int Dj, const double *wj, const double *Q,
                    int64_t nsteps, int64_t start_state, double *prev_vec, double *blk_min,
-                   int64_t *blk_arg, int nblk, int64_t *path, double *dist, hipStream_t s)
+                   int64_t *blk_arg, int nblk, unsigned int *arrive, int64_t *path, double *dist, hipStream_t s)
 {
     GreedyArgs a{};
-    a.JC_unw = JC_unw; a.Dj = Dj; a.wj = wj;
-    a.F_unw = F_unw; a.Dt = Dt; a.wt = wt;
-    a.me = g.me;
-    if (g.last_frame_as_target && g.me > 1) { a.nep = 2; a.ep[0] = 0; a.ep[1] = g.me - 1; }
-    else { a.nep = g.me; for (int e = 0; e < g.me; ++e) a.ep[e] = e; }
-    a.prev_col0 = g.prev_col0; a.cur_col0 = g.cur_col0; a.jdim = g.jdim;
-    a.prev_row0 = g.prev_row0; a.cur_row0 = g.cur_row0; a.Nwin = g.Nwin;
-    a.Q = Q; a.prev_vec = prev_vec;
-    a.R = greedy_rows(g, Dt, Dj);
-    const size_t shmem = greedy_shmem_for(g, Dt, Dj, a.R);
-    static size_t attr = 0;
-    if (shmem > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&greedy_scan_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        attr = shmem;
-    }
-    hipLaunchKernelGGL(greedy_init_prev_kernel, dim3((g.jdim + 255) / 256), dim3(256), 0, s, a,
-                       start_state, prev_vec);
-    for (int64_t st = 0; st < nsteps; ++st) {
-        hipLaunchKernelGGL(greedy_scan_kernel, dim3(nblk), dim3(GR_R), shmem, s, a, st, blk_min, blk_arg);
-        hipLaunchKernelGGL(greedy_pick_kernel, dim3(1), dim3(256), 0, s, a, st, blk_min, blk_arg, nblk,
-                           prev_vec, path, dist);
-    }
+    fill_args(a, g, F_unw, Dt, wt, JC_unw, Dj, wj, Q, prev_vec, true);
+    hipLaunchKernelGGL(greedy_init_prev_kernel, dim3((g.jdim + 255) / 256), dim3(256), 0, s, a, start_state, arrive);
+    for (int64_t st = 0; st < nsteps; ++st)
+        hipLaunchKernelGGL(greedy_step_kernel, dim3(nblk), dim3(GR_R), 0, s, a, st, blk_min, blk_arg, arrive,
+                           path, dist);
 }
 
-size_t greedy_shmem_bytes(const GreedyLayout &g, int Dt, int Dj)
-{
-    const int R = greedy_rows(g, Dt, Dj);
-    if (R < 8) return (size_t)1 << 30;      // does not fit
-    return greedy_shmem_for(g, Dt, Dj, R);
-}
+size_t greedy_shmem_bytes(const GreedyLayout &, int, int) { return 0; }    // static LDS only (fits any shape)
 
-int greedy_blocks(const GreedyLayout &g, int Dt, int Dj)
-{
-    const int R = greedy_rows(g, Dt, Dj);
-    return (int)((g.Nwin + R - 1) / R);
-}
+int greedy_blocks(const GreedyLayout &g, int, int) { return (int)((g.Nwin + GR_R - 1) / GR_R); }
 
 // ---------------------------------------------------------------------------
 // per-column squared errors along a path (get_target_scores_per_stream /
@@ -262,17 +258,7 @@ void launch_path_scores(const GreedyLayout &g, int mode, const float *F_unw, int
                         hipStream_t s)
 {
     GreedyArgs a{};
-    a.JC_unw = JC_unw; a.Dj = Dj; a.wj = wj;
-    a.F_unw = F_unw; a.Dt = Dt; a.wt = wt;
-    if (mode == 0) { a.me = 1; a.nep = 1; a.ep[0] = 0; }
-    else {
-        a.me = g.me;
-        if (g.last_frame_as_target && g.me > 1) { a.nep = 2; a.ep[0] = 0; a.ep[1] = g.me - 1; }
-        else { a.nep = g.me; for (int e = 0; e < g.me; ++e) a.ep[e] = e; }
-    }
-    a.prev_col0 = g.prev_col0; a.cur_col0 = g.cur_col0; a.jdim = g.jdim;
-    a.prev_row0 = g.prev_row0; a.cur_row0 = g.cur_row0; a.Nwin = g.Nwin;
-    a.Q = Q;
+    fill_args(a, g, F_unw, Dt, wt, JC_unw, Dj, wj, Q, nullptr, mode == 1);
     hipLaunchKernelGGL(path_scores_kernel, dim3((unsigned)L), dim3(256), 0, s, a, mode, path, L, jcols,
                        (int64_t)0, tsq, jsq);
 }

@@ -926,7 +926,7 @@ int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_st
         StageTimer t(h, h->stream, TM_GREEDY_STEPS);
         launch_greedy(g, h->F_unw.as<float>(), h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Dj,
                       h->wj.as<double>(), h->Qraw.as<double>(), nsteps, start_state, h->gprev.as<double>(),
-                      h->gblkmin.as<double>(), h->gblkarg.as<int64_t>(), nblk, h->gpath.as<int64_t>(),
+                      h->gblkmin.as<double>(), h->gblkarg.as<int64_t>(), nblk, h->slabctr.as<unsigned int>() + 8, h->gpath.as<int64_t>(),
                       h->gdist.as<double>(), h->stream);
     }
     HIPCHK(hipGetLastError());

@@ -94,7 +94,7 @@ struct GreedyLayout {
 void launch_greedy(const GreedyLayout &g, const float *F_unw, int Dt, const double *wt,
                    const float *JC_unw, int Dj, const double *wj, const double *Q,
                    int64_t nsteps, int64_t start_state, double *prev_vec, double *blk_min,
-                   int64_t *blk_arg, int nblk, int64_t *path, double *dist, hipStream_t s);
+                   int64_t *blk_arg, int nblk, unsigned int *arrive, int64_t *path, double *dist, hipStream_t s);
 size_t greedy_shmem_bytes(const GreedyLayout &g, int Dt, int Dj);
 int greedy_blocks(const GreedyLayout &g, int Dt, int Dj);
 
