@@ -150,8 +150,8 @@ class HipSearchEngine(object):
     def set_weights(self, target_weight_vector, join_weight_vector):
         """Per-COLUMN weight vectors (what set_target_weights / set_join_weights build from
         the per-stream weights, synth_simple.py:234-274)."""
-        wt = _f64(target_weight_vector)
-        wj = _f64(join_weight_vector)
+        wt = _f64(target_weight_vector if target_weight_vector is not None else [])
+        wj = _f64(join_weight_vector if join_weight_vector is not None else [])
         self._check(self._lib.snk_set_weights(self._h, _ptr(wt, _c_f64p), wt.size, _ptr(wj, _c_f64p), wj.size))
 
     def set_unit_classes(self, unit_class):

@@ -5,6 +5,7 @@ must reproduce bit for bit so that the engine receives the same query vectors an
 same database file.  Plain numpy, no GPU involved.
 """
 import os
+import re
 import numpy as np
 
 SPECIAL_UV_VALUE = -1000.0        # const.py:13
@@ -164,3 +165,109 @@ def load_database(datafile):
         raise RuntimeError('%s exists but this interpreter has no h5py; convert it once with\n'
                            '  /opt/conda/bin/python3.9 tools/hdf5_to_npz.py %s' % (datafile, datafile))
     raise RuntimeError('data: \n   %s   \ndoes not exist -- try other?' % (datafile))
+
+
+# --------------------------------------------------------------------------
+# Label-driven halfphone targets (synth_halfphone.py:1527-1549): the host side
+# that turns a state-aligned HTK label + frame-level speech into one target row
+# per halfphone.  Pinned by tests/golden/reference_mini.npz (halfphone_* keys).
+# --------------------------------------------------------------------------
+LABEL_DELIMITER = '/'              # const.py:19
+HTK_UNITS_PER_FRAME = 50000        # train_halfphone.py:924 (5 ms frames in 100 ns units)
+STATES_PER_PHONE = 5
+
+
+def extract_quinphone(label, quinphone_regex):
+    """label_manip.py:7-14: the five phones (ll, l, c, r, rr) of a full-context label."""
+    found = re.match(quinphone_regex, label)
+    assert found, 'quinphone_regex does not match label %s' % (label,)
+    phones = found.groups()
+    assert len(phones) == 5
+    return phones
+
+
+def read_label(labfile, quinphone_regex):
+    """train_halfphone.py:905-929.  One entry per label line:
+    ((start_frame, end_frame), [ll, l, c, r, rr, state]); times floor-divided to frames (the
+    reference relies on Python-2 integer division)."""
+    entries = []
+    with open(labfile, 'r') as f:
+        for line in f:
+            fields = re.split(r'\s+', line.strip(' \n'))
+            if len(fields) < 3:
+                raise ValueError('label line with fewer than 3 fields in %s: %r' % (labfile, line))
+            start, end, lab = fields[:3]
+            state = lab.strip(']').split('[')[-1]
+            entries.append(((int(start) // HTK_UNITS_PER_FRAME, int(end) // HTK_UNITS_PER_FRAME),
+                            list(extract_quinphone(lab, quinphone_regex)) + [state]))
+    return entries
+
+
+def reinsert_terminal_silence(speech, labels, silence_symbols=('#',)):
+    """train_halfphone.py:643-670: zero frames for the leading / trailing silence the label has
+    but the (trimmed) speech lacks."""
+    lead = 0
+    for (_, end), lab in labels:
+        if lab[2] not in silence_symbols:
+            break
+        lead = end
+    trail_from = -1
+    for (start, _), lab in reversed(labels):
+        if lab[2] not in silence_symbols:
+            break
+        trail_from = start
+    trail = labels[-1][0][1] - trail_from
+    width = speech.shape[1]
+    return np.vstack([np.zeros((lead, width)), speech, np.zeros((trail, width))])
+
+
+def suppress_weird_festival_pauses(labels, replace_list=('B_150',), replacement='pau'):
+    """synth_halfphone.py:116-126."""
+    return [(times, [replacement if phone in replace_list else phone for phone in lab])
+            for (times, lab) in labels]
+
+
+def get_halfphone_stats(speech, labels, representation_type='twopoint'):
+    """train_halfphone.py:956-1071.  HTK states 2,3 form the left halfphone and 4,5,6 the right
+    one; a unit is described by the frame at its start (first frame of state 2 / 4), middle (last
+    frame of state 2 / 5) and end (last frame of state 3 / 6), end frames clamped to the speech.
+    Returns (names (2P,) str array, features (2P, reps*dim), timings [(start, end)] * 2P)."""
+    if representation_type not in ('onepoint', 'twopoint', 'threepoint'):
+        raise ValueError('Unknown halfphone representation type: %s ' % (representation_type,))
+    n_frames = speech.shape[0]
+    assert len(labels) % STATES_PER_PHONE == 0, 'There must be 5 states for each phone in label'
+    n_units = 2 * (len(labels) // STATES_PER_PHONE)
+    side_of_state = {'2': '_L', '4': '_R'}
+    names, starts, middles, ends = [], [], [], []
+    for (start, end), lab in labels:
+        end = min(end, n_frames - 1)
+        assert len(lab) == 6
+        state = lab[5]
+        if state in side_of_state:
+            phones = list(lab[:5])
+            phones[2] += side_of_state[state]
+            assert LABEL_DELIMITER not in ''.join(phones), \
+                'delimiter %s occurs in one or more name element (%s)' % (LABEL_DELIMITER, phones)
+            names.append(LABEL_DELIMITER.join(phones))
+            starts.append(start)
+        if state in ('2', '5'):
+            middles.append(end)
+        elif state in ('3', '6'):
+            ends.append(end)
+        elif state != '4':
+            raise ValueError('bad state number %r' % (state,))
+    assert len(names) == n_units == len(starts) == len(ends) == len(middles)
+    points = {'onepoint': [middles], 'twopoint': [starts, ends],
+              'threepoint': [starts, middles, ends]}[representation_type]
+    features = np.hstack([speech[p, :] for p in points])
+    return np.array(names), features, list(zip(starts, ends))
+
+
+def get_norm_durations(unit_names, timings, duration_stats, oov_stats=(5.0, 5.0)):
+    """train_halfphone.py:1122-1132: (frames - mean) / std per halfphone, statistics looked up by
+    the unit's monophone (with _L/_R); (N, 1) float64."""
+    out = np.empty((len(unit_names), 1), dtype=np.float64)
+    for i, (name, (start, end)) in enumerate(zip(unit_names, timings)):
+        mean, std = duration_stats.get(name.split(LABEL_DELIMITER)[2], oov_stats)
+        out[i, 0] = (float(end - start) - mean) / std
+    return out

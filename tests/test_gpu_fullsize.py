@@ -79,3 +79,87 @@ def test_headline_size_properties(engine):
     # batch entry point returns the same thing
     paths, costs = engine.knn_viterbi_batch([U, U[:100]], K)
     assert list(paths[0]) == path and costs[0] == cost
+
+
+def test_config_b2_shape_k50(engine):
+    """BASELINE configs[1] shape (slt_arctic full, magphase-60 targets, K=50, search_epsilon=0
+    Viterbi): whole K-NN + Viterbi against the C oracle."""
+    N, Dt, Dj, T, K = 300000, 61, 302, 240, 50
+    F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=12)
+    wt = np.full(Dt, 0.5)
+    wj = np.full(Dj, 0.04)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    F, JCw = o.weight(F_unw, wt), o.weight(JC_unw, wj)
+    U = o.synthetic_targets(F_unw, T, seed=13) * wt
+    path, cost, cand, dist = engine.knn_viterbi(U, K, return_candidates=True)
+    oc_cand, oc_dist = oc.knn(F, U, K)
+    assert np.array_equal(cand, oc_cand) and np.array_equal(dist, oc_dist)
+    opath, ocost = oc.viterbi(oc_cand, oc_dist, JCw)
+    assert path == opath and cost == ocost
+
+
+def test_config_b5_shape_halfphone_classes(engine):
+    """BASELINE configs[4] shape (synth_halfphone: wide linguistic+acoustic target vector,
+    monophone-restricted K-NN, K=100): class-restricted lists against the oracle on sampled rows,
+    then the Viterbi over the padded lists against the C oracle's DP."""
+    N, Dt, Dj, T, K = 400000, 184, 151, 120, 100
+    F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=21)
+    rng = np.random.RandomState(22)
+    wt = 0.1 + 0.5 * rng.rand(Dt)
+    wj = np.full(Dj, 0.05)
+    cls = rng.randint(0, 45, size=N).astype(np.int32)
+    cls[1000:1060] = 99                          # a rare phone: 60 units < K
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    engine.set_unit_classes(cls)
+    F, JCw = o.weight(F_unw, wt), o.weight(JC_unw, wj)
+    U = o.synthetic_targets(F_unw, T, seed=23) * wt
+    qc = rng.randint(0, 45, size=T).astype(np.int32)
+    qc[50] = 99
+    cand, dist = engine.knn_by_class(U, K, qc)
+    rows = list(range(0, T, 7)) + [50]
+    ocand, odist = o.knn_by_class(F, U[rows], K, cls, qc[rows])
+    assert np.array_equal(cand[rows], ocand) and np.array_equal(dist[rows], odist)
+    assert np.all(cls[cand[cand >= 0].reshape(-1)] == np.repeat(qc, K)[(cand >= 0).reshape(-1)])
+    assert list(cand[50, 60:]) == [-1] * 40
+    path, cost = engine.viterbi(cand, dist)
+    opath, ocost = oc.viterbi(cand, dist, JCw)
+    assert path == opath and cost == ocost
+
+
+def test_config_b4_shape_two_shards_k200(engine):
+    """BASELINE configs[3] shape (row-sharded DB, K=200, all-gather of shard-local top-K, one
+    Viterbi): two half-database shards on this GPU stand in for two ranks."""
+    import torch
+    import snickery_amd
+    from snickery_amd.dist import shard_bounds
+    N, Dt, Dj, T, K = 500000, 61, 302, 96, 200
+    F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=31)
+    wt = np.full(Dt, 0.4)
+    wj = np.full(Dj, 0.05)
+    F, JCw = o.weight(F_unw, wt), o.weight(JC_unw, wj)
+    U = o.synthetic_targets(F_unw, T, seed=32) * wt
+    dev = torch.device('cuda', 0)
+    d2_all = torch.empty(2, T, K, dtype=torch.float64, device=dev)
+    id_all = torch.empty(2, T, K, dtype=torch.int64, device=dev)
+    shards = []
+    for r in range(2):
+        lo, hi = shard_bounds(N, 2, r)
+        e = snickery_amd.HipSearchEngine(0)
+        e.upload_target_only(F_unw[lo:hi])
+        e.set_shard(lo, N)
+        e.set_weights(wt, None)
+        e.knn_local_dev(U, K, d2_all[r].data_ptr(), id_all[r].data_ptr())
+        shards.append(e)
+    torch.cuda.synchronize()
+    cand, dist = shards[0].merge_topk_dev(d2_all.data_ptr(), id_all.data_ptr(), 2, T, K)
+    oc_cand, oc_dist = oc.knn(F, U, K)
+    assert np.array_equal(cand, oc_cand) and np.array_equal(dist, oc_dist)
+    for e in shards:
+        e.close()
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    path, cost = engine.viterbi(cand, dist)
+    opath, ocost = oc.viterbi(oc_cand, oc_dist, JCw)
+    assert path == opath and cost == ocost

@@ -71,6 +71,10 @@ def convert_reference(tmp):
     patch('train_simple.py', 'filenames = [base] * m',
           "filenames = np.array([base] * m).astype('S50')")
 
+    patch('train_halfphone.py', 'int(start) / 50000', 'int(start) // 50000')
+    patch('train_halfphone.py', '(int(end) / 50000)', '(int(end) // 50000)')
+    patch('train_halfphone.py', 'nphones = len(labels) / 5', 'nphones = len(labels) // 5')
+
     stubs = os.path.join(tmp, 'stubs')
     os.makedirs(os.path.join(stubs, 'smoothing'))
     for name in ['magphase', 'libaudio', 'pywrapfst', 'pylab', 'StashableKDTree']:
@@ -284,6 +288,48 @@ def main():
         fixtures['quin_queries'] = qfeats
         fixtures['quin_candidates'] = np.array(qc, dtype=np.int64)
         fixtures['quin_distances'] = np.array(qd, dtype=np.float64)
+
+        # ---- label-driven halfphone targets (synth_halfphone.py:1527-1549) on a synthetic
+        # state-aligned label: read_label / get_halfphone_stats / get_norm_durations ----
+        import re
+        import train_halfphone
+        regex_text = r'([^~]+)~([^-]+)-([^\+]+)\+([^\=]+)\=([^:]+)'
+        regex = re.compile(regex_text)
+        lrng = np.random.RandomState(99)
+        seq = ['xx', 'xx', '#', 'h', 'e', 'B_150', 'l', 'ou', '#', 'xx', 'xx']
+        lines, now = [], 0
+        for i in range(2, len(seq) - 2):
+            for state in range(2, 7):
+                dur = int(lrng.randint(1, 9)) * 50000 + (20000 if state == 4 else 0)   # odd times exercise flooring
+                lab = '%s~%s-%s+%s=%s:/A:1_2/B:3[%d]' % (seq[i - 2], seq[i - 1], seq[i], seq[i + 1], seq[i + 2], state)
+                lines.append('%d %d %s' % (now, now + dur, lab))
+                now += dur
+        label_text = '\n'.join(lines) + '\n'
+        labfile = os.path.join(tmp, 'utt.lab')
+        open(labfile, 'w').write(label_text)
+        labs = train_halfphone.read_label(labfile, regex)
+        label_frames = labs[-1][0][1]
+        hp_speech = lrng.randn(label_frames - 3, 7)          # 3 frames short: end clamping
+        fixtures['halfphone_regex'] = np.array(regex_text.encode())
+        fixtures['halfphone_label_text'] = np.array(label_text.encode())
+        fixtures['halfphone_label_times'] = np.array([t for (t, q) in labs], dtype=np.int64)
+        fixtures['halfphone_label_fields'] = np.array([q for (t, q) in labs]).astype('S8')
+        fixtures['halfphone_speech'] = hp_speech
+        for rep in ['onepoint', 'twopoint', 'threepoint']:
+            hnames, hfeats, htimes = train_halfphone.get_halfphone_stats(hp_speech, labs, representation_type=rep)
+            fixtures['halfphone_features_' + rep] = np.array(hfeats)
+        htimes = list(htimes)
+        fixtures['halfphone_names'] = np.array(hnames).astype('S40')
+        fixtures['halfphone_timings'] = np.array(htimes, dtype=np.int64)
+        dstats = {'h_L': (4.0, 1.5), 'h_R': (6.5, 2.0), 'e_L': (3.0, 0.5), '#_L': (10.0, 4.0), 'ou_R': (7.25, 3.0)}
+        fixtures['halfphone_duration_monophones'] = np.array(sorted(dstats)).astype('S8')
+        fixtures['halfphone_duration_stats'] = np.array([dstats[k] for k in sorted(dstats)], dtype=np.float64)
+        fixtures['halfphone_norm_durations'] = train_halfphone.get_norm_durations(hnames, htimes, dstats)
+        supp = synth_halfphone.suppress_weird_festival_pauses(labs)
+        fixtures['halfphone_suppressed_fields'] = np.array([q for (t, q) in supp]).astype('S8')
+        trimmed = hp_speech[labs[4][0][1]:labs[-5][0][0]]    # as if the terminal silences had been trimmed
+        fixtures['halfphone_reinserted_silence'] = train_halfphone.reinsert_terminal_silence(trimmed, labs)
+        fixtures['halfphone_trimmed_range'] = np.array([labs[4][0][1], labs[-5][0][0]], dtype=np.int64)
 
         np.savez_compressed(os.path.join(OUT, 'reference_mini.npz'), **fixtures)
         sz = os.path.getsize(os.path.join(OUT, 'reference_mini.npz'))
