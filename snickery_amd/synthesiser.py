@@ -13,6 +13,7 @@ flavour='halfphone' mirrors synth_halfphone.Synthesiser with target_representati
                     (greedy or preselect + Viterbi, synth_halfphone.py:151-415).
 """
 import glob
+import re
 import os
 import timeit
 
@@ -56,6 +57,13 @@ class Synthesiser(object):
         self.unit_index_within_sentence = db.get('unit_index_within_sentence_dset')
         self.train_cutpoints = db.get('cutpoints')      # absent from train_simple DBs
         self.number_of_units = self.train_unit_features_unweighted.shape[0]
+        if self.config.get('add_duration_as_target', False):
+            # synth_halfphone.py:206-211
+            monophones = [m.decode() if isinstance(m, bytes) else str(m) for m in db['duration_monophones']]
+            stats = np.asarray(db['duration_stats'])
+            self.duration_stats = dict(zip(monophones, zip(stats[:, 0].tolist(), stats[:, 1].tolist())))
+        if self.target_representation != 'epoch':
+            self.quinphone_regex = re.compile(self.config['quinphone_regex'])     # synth_halfphone.py:281-282
 
         self.holdout_percent = holdout_percent
         self.holdout_samples = 0
@@ -317,9 +325,14 @@ class Synthesiser(object):
         """synth_simple.py:279-284: returns {utterance: path}."""
         return dict((f, self.synth_utt(f, synth_type=synth_type, outdir=outdir)) for f in self.get_sentence_set(synth_type))
 
-    def prepare_targets(self, base, synth_type='test'):
-        """Target preparation of synth_utt (synth_simple.py:370-396, synth_halfphone.py:1507-1552)."""
+    def prepare_targets(self, base, synth_type='test', return_names=False):
+        """Target preparation of synth_utt (synth_simple.py:370-396, synth_halfphone.py:1478-1552):
+        frame-level targets for the epoch representation, one row per halfphone (taken at the
+        state-alignment points of the utterance's label) otherwise."""
+        if synth_type not in ('test', 'tune'):
+            raise SystemExit('Unknown synth_type  9489384')
         data_dirs = self.test_data_target_dirs if synth_type == 'test' else self.tune_data_target_dirs
+        unit_names = None
         unnorm_speech = hp.compose_speech(data_dirs, base, self.stream_list_target, self.config['datadims_target'])
         if self.config.get('standardise_target_data', True):
             speech = hp.standardise(unnorm_speech, self.mean_vec_target, self.std_vec_target)
@@ -328,20 +341,33 @@ class Synthesiser(object):
         if self.flavour == 'simple':
             unit_features = speech[1:-1, :] if self.config.get('REPLICATE_IS2018_EXP', False) else speech
         else:
-            if self.config['target_representation'] != 'epoch':
-                raise NotImplementedError('label-driven halfphone target preparation (read_label / '
-                                          'get_halfphone_stats) is outside this build: pass prepared '
-                                          'unit_features to the preselect_* methods')
-            unit_features = speech[1:-1, :]
-        if self.flavour == 'simple' or self.config.get('weight_target_data', True):
+            if self.target_representation == 'epoch':
+                unit_features = speech[1:-1, :]
+            else:
+                lab_dir = self.config.get('%s_lab_dir' % synth_type, '')
+                labfile = os.path.join(lab_dir, base + '.' + self.config['lab_extension'])
+                self.report('reading %s' % (labfile))
+                labs = hp.read_label(labfile, self.quinphone_regex)
+                if self.config.get('untrim_silence_target_speech', False):
+                    speech = hp.reinsert_terminal_silence(speech, labs)
+                if self.config.get('suppress_weird_festival_pauses', False):
+                    labs = hp.suppress_weird_festival_pauses(labs)
+                unit_names, unit_features, unit_timings = hp.get_halfphone_stats(
+                    speech, labs, representation_type=self.target_representation)
+                if self.config.get('add_duration_as_target', False):
+                    norm_durations = hp.get_norm_durations(unit_names, unit_timings, self.duration_stats)
+                    norm_durations *= self.config.get('target_duration_stretch_factor', 1.0)
+                    unit_features = np.hstack([unit_features, norm_durations])
+        if self.flavour == 'simple' or self.config['weight_target_data']:
             unit_features = hp.weight(unit_features, self.target_weight_vector)
-        return self._mask_query(unit_features)
+        unit_features = self._mask_query(unit_features)
+        return (unit_features, unit_names) if return_names else unit_features
 
     def synth_utt(self, base, synth_type='tune', outstem='', outdir=''):
         """Search part of synth_utt (synth_simple.py:342-456 / synth_halfphone.py:1478-1696).
         Returns the unit path, or (tscores, jscores) in 'stream_weight_balancing' mode."""
         t = self.start_clock('Get speech ')
-        unit_features = self.prepare_targets(base, synth_type)
+        unit_features, unit_names = self.prepare_targets(base, synth_type, return_names=True)
         self.stop_clock(t)
         if self.config.get('greedy_search', False):
             assert self.config.get('target_representation') == 'epoch'
@@ -350,8 +376,12 @@ class Synthesiser(object):
             method = self.config['preselection_method']
             if method == 'acoustic':
                 candidates, distances = self.preselect_units_acoustic(unit_features)
+            elif method == 'quinphone':
+                candidates, distances = self.preselect_units_quinphone(unit_features, unit_names)
+            elif method == 'monophone_then_acoustic':
+                candidates, distances = self.preselect_units_monophone_then_acoustic(unit_features, unit_names)
             else:
-                raise SystemExit('preselection_method %s needs unit labels: call the preselect_* method directly' % method)
+                raise SystemExit('preselection_method unknown')
             if self.mode_of_operation == 'find_join_candidates':
                 return candidates
             best_path = self.viterbi_search(candidates, distances)

@@ -1,5 +1,7 @@
 """GPU tests of the drop-in Synthesiser front end: driven through config file + unit database +
 stream files exactly like the reference's synth_simple.py / synth_halfphone.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -137,3 +139,47 @@ def test_shard_engine_device_pointer_api(golden, mini_voice):
     assert np.array_equal(c1, oc) and np.array_equal(d1, od)
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize('method', ['monophone_then_acoustic', 'quinphone'])
+def test_halfphone_label_driven_synth_utt(tmp_path, golden, method):
+    """synth_halfphone.py:1478-1625 end to end for a label-driven voice: twopoint halfphone targets
+    + normalised duration from the state-aligned label (host, pinned to the reference in
+    test_hostprep.py), label-aware preselection and Viterbi on the GPU; against the oracle."""
+    import re
+    from snickery_amd import hostprep as hp
+    from snickery_amd.synthesiser import Synthesiser
+    from voice_fixture import build_halfphone_voice
+    K = 10
+    cfgfile, config, db = build_halfphone_voice(tmp_path, golden, method, n_candidates=K)
+    synth = Synthesiser(cfgfile, verbose=False)
+    assert synth.target_weight_vector.size == 2 * 61 + 1 and synth.target_weight_vector[-1] == 0.3
+    U, names = synth.prepare_targets('arctic_b0001', 'test', return_names=True)
+    # the same preparation spelled out with the host functions
+    dirs = hp.locate_stream_directories(config['test_data_dirs'], config['stream_list_target'])
+    speech = hp.standardise(hp.compose_speech(dirs, 'arctic_b0001', config['stream_list_target'],
+                                              config['datadims_target']), golden['mean_target'], golden['std_target'])
+    labs = hp.suppress_weird_festival_pauses(hp.read_label(os.path.join(config['test_lab_dir'], 'arctic_b0001.lab'),
+                                                          re.compile(config['quinphone_regex'])))
+    enames, feats, timings = hp.get_halfphone_stats(speech, labs, 'twopoint')
+    nd = hp.get_norm_durations(enames, timings, synth.duration_stats) * 1.1
+    expect = hp.weight(np.hstack([feats, nd]), synth.target_weight_vector)
+    assert list(names) == list(enames) and np.array_equal(U, expect) and U.shape == (22, 123)
+    F = o.weight(db['train_unit_features'], synth.target_weight_vector)
+    JCw = o.weight(db['join_contexts'], synth.join_weight_vector)
+    unit_names = [n.decode() for n in db['train_unit_names']]
+    if method == 'monophone_then_acoustic':
+        monos = [n.split('/')[2] for n in unit_names]
+        ids = dict((m, i) for i, m in enumerate(sorted(set(monos))))
+        ocand, odist = o.knn_by_class(F, U, K, np.array([ids[m] for m in monos]),
+                                      np.array([ids[n.split('/')[2]] for n in names]))
+        cand, dist = synth.preselect_units_monophone_then_acoustic(U, names)
+    else:
+        ocand, odist = o.preselect_units_quinphone(o.build_unit_index(unit_names), F, U, list(names), K)
+        cand, dist = synth.preselect_units_quinphone(U, names)
+        assert any('pau' in n for n in names)            # unseen phone -> the reference's naive back-off
+    assert np.array_equal(cand, ocand) and np.array_equal(dist, odist)
+    opath, ocost = o.viterbi(ocand, odist, JCw[1:], JCw[:-1])
+    assert synth.synth_utt('arctic_b0001', synth_type='test') == opath
+    assert synth.last_path_cost == ocost
+    synth.close()

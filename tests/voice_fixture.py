@@ -38,7 +38,7 @@ join_cost_type = 'pitch_sync'
 '''
 
 
-def build_voice(tmpdir, golden, greedy=True, multiepoch=6, n_candidates=12):
+def build_voice(tmpdir, golden, greedy=True, multiepoch=6, n_candidates=12, extra_config='', db_override=None):
     from snickery_amd import hostprep as hp
     workdir = os.path.join(str(tmpdir), 'work')
     data = os.path.join(str(tmpdir), 'voice')
@@ -52,13 +52,71 @@ def build_voice(tmpdir, golden, greedy=True, multiepoch=6, n_candidates=12):
     with open(cfgfile, 'w') as f:
         f.write(CFG % dict(workdir=workdir, data=data, greedy=str(bool(greedy)), multiepoch=multiepoch,
                            n_candidates=n_candidates))
+        f.write(extra_config)
     config = hp.load_config(cfgfile)
     N = golden['F_unw'].shape[0]
-    np.savez(hp.get_data_dump_name(config) + '.npz',
-             train_unit_features=golden['F_unw'], join_contexts=golden['JC_unw'],
-             mean_target=golden['mean_target'], std_target=golden['std_target'],
-             mean_join=golden['mean_join'], std_join=golden['std_join'],
-             train_unit_names=np.array(['_'] * N).astype('S50'),
-             filenames=np.array(['arctic_a%04d' % (1 + i // 150) for i in range(N)]).astype('S50'),
-             unit_index_within_sentence_dset=(np.arange(N) % 150).astype(np.int32))
+    db = dict(train_unit_features=golden['F_unw'], join_contexts=golden['JC_unw'],
+              mean_target=golden['mean_target'], std_target=golden['std_target'],
+              mean_join=golden['mean_join'], std_join=golden['std_join'],
+              train_unit_names=np.array(['_'] * N).astype('S50'),
+              filenames=np.array(['arctic_a%04d' % (1 + i // 150) for i in range(N)]).astype('S50'),
+              unit_index_within_sentence_dset=(np.arange(N) % 150).astype(np.int32))
+    db.update(db_override or {})
+    np.savez(hp.get_data_dump_name(config) + '.npz', **db)
     return cfgfile, config
+
+
+PHONES = ['a', 'b', 'k', 's', '#']
+
+
+def build_halfphone_voice(tmpdir, golden, preselection_method, n_candidates=10, seed=5):
+    """A label-driven halfphone voice (twopoint targets + normalised duration, quinphone unit
+    names) assembled from the golden frame database, plus a state-aligned label for the test
+    utterance.  Returns (cfgfile, config, db arrays)."""
+    rng = np.random.RandomState(seed)
+    F, JC = golden['F_unw'], golden['JC_unw']
+    n_units = (F.shape[0] - 1) // 2
+    feats = np.hstack([F[0:2 * n_units:2], F[1:2 * n_units:2], rng.randn(n_units, 1).astype(np.float32)])
+    names = []
+    for i in range(n_units):
+        ctx = [PHONES[rng.randint(len(PHONES))] for _ in range(5)]
+        ctx[2] += '_L' if i % 2 == 0 else '_R'
+        names.append('/'.join(ctx))
+    monos = sorted(set(n.split('/')[2] for n in names))[:-1]          # one phone left to oov_stats
+    override = dict(train_unit_features=feats.astype(np.float32), join_contexts=JC[:n_units + 1],
+                    train_unit_names=np.array(names).astype('S50'),
+                    filenames=np.array(['arctic_a0001'] * n_units).astype('S50'),
+                    unit_index_within_sentence_dset=np.arange(n_units).astype(np.int32),
+                    duration_monophones=np.array(monos).astype('S10'),
+                    duration_stats=np.column_stack([4.0 + rng.rand(len(monos)) * 4, 1.0 + rng.rand(len(monos))]))
+    labdir = os.path.join(str(tmpdir), 'lab')
+    os.makedirs(labdir, exist_ok=True)
+    extra = '''
+target_representation = 'twopoint'
+add_duration_as_target = True
+duration_target_weight = 0.3
+target_duration_stretch_factor = 1.1
+quinphone_regex = r'([^~]+)~([^-]+)-([^\\+]+)\\+([^\\=]+)\\=([^:]+)'
+lab_extension = 'lab'
+test_lab_dir = %r
+preselection_method = %r
+suppress_weird_festival_pauses = True
+''' % (labdir, preselection_method)
+    cfgfile, config = build_voice(tmpdir, golden, greedy=False, multiepoch=1, n_candidates=n_candidates,
+                                  extra_config=extra, db_override=override)
+    n_frames = golden['test0_raw_mag'].shape[0]
+    seq = ['xx', 'xx', '#'] + [PHONES[rng.randint(4)] for _ in range(9)] + ['#', 'xx', 'xx']
+    if preselection_method == 'quinphone':
+        seq[6] = 'B_150'                              # becomes 'pau', a phone the database lacks
+    lines, now = [], 0
+    n_states = 5 * (len(seq) - 4)
+    durs = rng.multinomial(n_frames + 2 - n_states, np.ones(n_states) / n_states) + 1   # label 2 frames longer
+    for i in range(2, len(seq) - 2):
+        for state in range(2, 7):
+            dur = int(durs[(i - 2) * 5 + state - 2]) * 50000
+            lines.append('%d %d %s~%s-%s+%s=%s:/x[%d]' % (now, now + dur, seq[i - 2], seq[i - 1], seq[i],
+                                                       seq[i + 1], seq[i + 2], state))
+            now += dur
+    with open(os.path.join(labdir, 'arctic_b0001.lab'), 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    return cfgfile, config, override
