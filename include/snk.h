@@ -151,6 +151,18 @@ int snk_knn_local_dev(snk_handle h, const double *Q, int64_t T, int D, int K,
 /* merge G gathered lists (G,T,K) -> (T,K), ordered by (distance, id); host outputs */
 int snk_merge_topk_dev(snk_handle h, const double *d2_dev, const int64_t *id_dev,
                        int G, int64_t T, int K, int64_t *cand_out, double *dist_out);
+/* Batch form of the two calls above for throughput callers (the sharded counterpart of
+ * snk_knn_viterbi_batch): rows of n_utts utterances concatenated in Q (host), row_offsets (n_utts+1).
+ *   step 1, every rank:   snk_knn_local_batch_dev -> (R, K) lists in caller device buffers, R = all rows
+ *   exchange (caller):    RCCL all-to-all, rank r receives the rows of the utterances it owns from
+ *                         every shard -> (G, R_own, K)
+ *   step 2, owner rank:   snk_merge_viterbi_batch_dev -> merged candidates, join costs, Viterbi;
+ *                         paths / lengths / costs of the owned utterances on the host. */
+int snk_knn_local_batch_dev(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts,
+                            int D, int K, double *d2_dev_out, int64_t *id_dev_out);
+int snk_merge_viterbi_batch_dev(snk_handle h, const double *d2_dev, const int64_t *id_dev, int G,
+                                const int64_t *row_offsets, int n_utts, int K,
+                                int64_t *path_out, int64_t *path_len_out, double *cost_out);
 /* upload the FULL join matrix only (ranks that run the Viterbi of an utterance) */
 int snk_upload_join_only(snk_handle h, const float *JC_unw, int64_t Njc, int Dj);
 

@@ -42,11 +42,12 @@ static int fail(const char *fmt, ...)
 // ---------------------------------------------------------------------------
 enum TimerId {
     TM_H2D = 0, TM_PREP, TM_KNN_MINIMA, TM_KNN_THRESHOLD, TM_KNN_FILTER, TM_KNN_BUCKET, TM_KNN_FINALIZE,
-    TM_JOIN, TM_VITERBI_DP, TM_D2H, TM_GREEDY_TARGET, TM_GREEDY_STEPS, TM_WEIGHTS, TM_COUNT
+    TM_JOIN, TM_VITERBI_DP, TM_D2H, TM_GREEDY_TARGET, TM_GREEDY_STEPS, TM_WEIGHTS, TM_MERGE, TM_COUNT
 };
 static const char *kTimerNames[TM_COUNT] = {
     "h2d_queries", "prepare_queries", "knn_minima", "knn_threshold", "knn_filter", "knn_bucket", "knn_finalize",
-    "join_costs", "viterbi_dp", "d2h_results", "greedy_target_gemm", "greedy_steps", "set_weights"};
+    "join_costs", "viterbi_dp", "d2h_results", "greedy_target_gemm", "greedy_steps", "set_weights",
+    "merge_topk"};
 
 struct DevBuf {
     void *p = nullptr;
@@ -101,8 +102,8 @@ struct snk_engine {
     // k-nn workspace
     DevBuf Qraw, Qp, Qf, qnorm, thr, gmin, cnt, lkey, lidx, status, qclass, d2tmp, slabctr, pool, poolctl, chunkfill;
     UttSlot slot[8];
-    hipStream_t dp_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-    DevBuf res_path, res_plen, res_cost, Qall, res_status;
+    hipStream_t dp_stream[2] = {nullptr, nullptr};
+    DevBuf res_path, res_plen, res_cost, Qall, res_status, mcand, mdist;
     // f16-split prefilter state
     DevBuf a16h, a16l, s16h, s16l, b16h, b16l, eps16, thr32, gmin32, fmax2;
     bool f16_ready = false;
@@ -124,6 +125,7 @@ struct snk_engine {
     int timers_on = 1;
     int n_cus = 256;
     int reserved_cus = 2;
+    int batch_rows = 2400;     // rows per K-NN call of the batch entry points (utterances are grouped)
     int pool_chunks = 4096;    // entry pool: 4096 chunks x 2048 entries x 16 B = 128 MiB      // left free by the persistent K-NN sweep for Viterbi DP blocks
     int last_retries = 0;
     int tie_overflow = 0;
@@ -146,7 +148,7 @@ static hipEvent_t ev_get(snk_engine *h)
 
 struct StageTimer {     // records an event pair around a stage on a stream
     snk_engine *h; hipStream_t s; EvPair ep; bool on;
-    StageTimer(snk_engine *h_, hipStream_t s_, int id) : h(h_), s(s_), on(h_->timers_on != 0)
+    StageTimer(snk_engine *h_, hipStream_t s_, int id) : h(h_), s(s_), on(h_->timers_on != 0 && id >= 0)
     {
         if (!on) return;
         ep.id = id; ep.a = ev_get(h); ep.b = ev_get(h);
@@ -229,13 +231,16 @@ int snk_create(int device_id, snk_handle *out)
     h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (h->slabctr.ensure(64)) { delete h; return 1; }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    // Two side streams take the T-step recursions of alternate utterance groups.  (ROCm multiplexes
+    // the streams of a process onto 4 hardware queues: with more side streams one of them shares a
+    // queue with the main stream and a recursion stalls the K-NN sweep queued behind it.)
     HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     for (int i = 0; i < 8; ++i) {
         HIPCHK(hipEventCreateWithFlags(&h->slot[i].knn_done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->slot[i].vit_done, hipEventDisableTiming));
     }
     h->dp_stream[0] = h->stream2;
-    for (int i = 1; i < 4; ++i) HIPCHK(hipStreamCreateWithFlags(&h->dp_stream[i], hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->dp_stream[1], hipStreamNonBlocking));
     *out = h;
     return 0;
 }
@@ -252,7 +257,7 @@ int snk_destroy(snk_handle h)
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
                       &h->gpath, &h->gdist};
     for (auto *b : bufs) b->release();
-    for (int i = 1; i < 4; ++i) { (void)hipStreamSynchronize(h->dp_stream[i]); (void)hipStreamDestroy(h->dp_stream[i]); }
+    (void)hipStreamSynchronize(h->dp_stream[1]); (void)hipStreamDestroy(h->dp_stream[1]);
     h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
     h->res_status.release(); h->hstage.release();
     { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2};
@@ -366,6 +371,9 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
         h->n_slabs16 = (h->N + slab_rows - 1) / slab_rows;
         int64_t stride = (int64_t)floor(1.0 / h->sample_frac + 0.5);
         if (stride < 1) stride = 1;
+        // small databases (one rank's shard of a row-sharded one): keep >= 512 sample groups so the
+        // K-th smallest group minimum stays close to the K-th nearest sampled unit
+        while (stride > 1 && (h->N / stride) / slab_rows < 256) --stride;
         h->stride16 = stride;
         h->n_slabs16_a = (h->N / stride) / slab_rows;
         if (fmax2 < 1.0e30 && h->n_slabs16_a >= 1) {
@@ -456,7 +464,13 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
     CHK(h->lkey.ensure((size_t)Tpad * cap * sizeof(double)));
     CHK(h->lidx.ensure((size_t)Tpad * cap * sizeof(int)));
     CHK(h->status.ensure(sizeof(int)));
-    const int max_chunks = h->pool_chunks;
+    // entry pool: room for ~3K survivors per row plus one partly filled chunk per resident wave
+    int max_chunks = h->pool_chunks;
+    {
+        const int64_t per_row = cap < 3072 ? cap : 3072;
+        const int64_t need = (Tpad * per_row) / knn_pool_chunk_entries() + 2048;
+        if (need > max_chunks) max_chunks = (int)need;
+    }
     CHK(h->pool.ensure(knn_pool_bytes(max_chunks)));
     CHK(h->poolctl.ensure(2 * sizeof(unsigned int)));
     CHK(h->chunkfill.ensure((size_t)max_chunks * sizeof(int)));
@@ -780,6 +794,58 @@ int snk_knn_viterbi(snk_handle h, const double *Q, int64_t T, int D, int K, int6
     return 0;
 }
 
+// Groups consecutive utterances into K-NN calls of about h->batch_rows rows: the search is per row,
+// so one sweep over the database serves every utterance of the group and the per-call stages
+// (sample minima, thresholds, bucket, re-rank) amortise.  first[g] .. first[g+1] are the utterances
+// of group g.
+static std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offsets, int n_utts)
+{
+    std::vector<int> first(1, 0);
+    int64_t rows = 0;
+    for (int u = 0; u < n_utts; ++u) {
+        const int64_t T = row_offsets[u + 1] - row_offsets[u];
+        if (u > first.back() && (h->batch_rows <= 0 || rows + T > h->batch_rows)) { first.push_back(u); rows = 0; }
+        rows += T;
+    }
+    first.push_back(n_utts);
+    return first;
+}
+
+// Join costs and recursions of the utterances [u0, u1) whose candidate rows are resident in
+// cand_all / tdist_all (batch row numbering).  The join costs of the whole group are ONE launch on
+// the main stream (its rows form one long sequence; the slab between two utterances is never read),
+// the recursions ONE launch (a workgroup per utterance) on the side stream of the group's parity,
+// where they land on the compute units the persistent K-NN sweep of the next group leaves free.
+static int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u0, int u1, int K,
+                         const int64_t *cand_all, const double *tdist_all, bool side_stream)
+{
+    const int64_t r0 = row_offsets[u0], rows = row_offsets[u1] - r0;
+    UttSlot &s = h->slot[g & 1];
+    hipStream_t dps = side_stream ? h->dp_stream[g & 1] : h->stream;
+    if (side_stream && g >= 2) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));   // slot reuse
+    CHK(s.J.ensure((size_t)(rows > 1 ? rows - 1 : 1) * K * K * sizeof(double)));
+    CHK(s.bp.ensure((size_t)rows * K));
+    {
+        StageTimer t(h, h->stream, TM_JOIN);
+        launch_join_costs(h->JCw.as<double>(), h->Djpad, h->Dj, join_units(h), cand_all + r0 * K, rows, K,
+                          s.J.as<double>(), h->stream);
+    }
+    if (side_stream) {
+        HIPCHK(hipEventRecord(s.knn_done, h->stream));
+        HIPCHK(hipStreamWaitEvent(dps, s.knn_done, 0));
+    }
+    std::vector<int64_t> off((size_t)(u1 - u0) + 1);
+    for (int u = u0; u <= u1; ++u) off[(size_t)(u - u0)] = row_offsets[u] - r0;
+    {
+        StageTimer t(h, dps, TM_VITERBI_DP);
+        launch_viterbi_dp_batch(cand_all + r0 * K, tdist_all + r0 * K, s.J.as<double>(), off.data(), u1 - u0, u0, K,
+                                join_units(h), s.bp.as<unsigned char>(), h->res_path.as<int64_t>() + r0,
+                                h->res_plen.as<int64_t>(), h->res_cost.as<double>(), dps);
+    }
+    if (side_stream) HIPCHK(hipEventRecord(s.vit_done, dps));
+    return 0;
+}
+
 int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D,
                           int K, int64_t *path_out, int64_t *path_len_out, double *cost_out)
 {
@@ -793,67 +859,48 @@ int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offs
     const int64_t total = row_offsets[n_utts];
     for (int u = 0; u < n_utts; ++u)
         if (row_offsets[u + 1] - row_offsets[u] < 1) return fail("snk_knn_viterbi_batch: utterance %d has no rows", u);
-    // Pipeline: the main stream runs K-NN(u) and the join costs of u; the T-step recursion of u
-    // runs on one of two side streams and lands on the compute units the persistent K-NN sweep
-    // leaves free, overlapping K-NN(u+1), K-NN(u+2).  All results stay on the device until the
-    // end of the batch (one D2H), so no host copy serialises the streams.
+    // Pipeline: the main stream runs the K-NN of a group of utterances and their join costs; the
+    // T-step recursions run on a side stream, overlapping the K-NN of the next group.  All results
+    // stay on the device until the end of the batch (one D2H), so no host copy serialises the streams.
+    const std::vector<int> first = group_utterances(h, row_offsets, n_utts);
+    const int n_groups = (int)first.size() - 1;
     CHK(h->Qall.ensure((size_t)total * D * sizeof(double)));
+    CHK(h->mcand.ensure((size_t)total * K * sizeof(int64_t)));
+    CHK(h->mdist.ensure((size_t)total * K * sizeof(double)));
     CHK(h->res_path.ensure((size_t)total * sizeof(int64_t)));
     CHK(h->res_plen.ensure((size_t)n_utts * sizeof(int64_t)));
     CHK(h->res_cost.ensure((size_t)n_utts * sizeof(double)));
-    CHK(h->res_status.ensure((size_t)n_utts * sizeof(int)));
+    CHK(h->res_status.ensure((size_t)n_groups * sizeof(int)));
     {
         StageTimer t(h, h->stream, TM_H2D);
         HIPCHK(hipMemcpyAsync(h->Qall.p, Q, (size_t)total * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
-    for (int u = 0; u < n_utts; ++u) {
-        const int64_t r0 = row_offsets[u], T = row_offsets[u + 1] - r0;
-        UttSlot &s = h->slot[u & 7];
-        hipStream_t dps = h->dp_stream[u & 3];
-        CHK(slot_ensure(h, s, T, K));
-        if (u >= 8) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));   // slot reuse
-        CHK(knn_device(h, h->Qall.as<double>() + r0 * D, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(),
-                       nullptr, h->res_status.as<int>() + u));
-        {
-            StageTimer t(h, h->stream, TM_JOIN);
-            launch_join_costs(h->JCw.as<double>(), h->Djpad, h->Dj, join_units(h), s.cand.as<int64_t>(), T, K,
-                              s.J.as<double>(), h->stream);
-        }
-        HIPCHK(hipEventRecord(s.knn_done, h->stream));
-        HIPCHK(hipStreamWaitEvent(dps, s.knn_done, 0));
-        {
-            StageTimer t(h, dps, TM_VITERBI_DP);
-            launch_viterbi_dp(s.cand.as<int64_t>(), s.tdist.as<double>(), s.J.as<double>(), T, K, join_units(h),
-                              s.bp.as<unsigned char>(), h->res_path.as<int64_t>() + r0,
-                              h->res_plen.as<int64_t>() + u, h->res_cost.as<double>() + u, dps);
-        }
-        HIPCHK(hipEventRecord(s.vit_done, dps));
+    for (int g = 0; g < n_groups; ++g) {
+        const int64_t r0 = row_offsets[first[g]], rows = row_offsets[first[g + 1]] - r0;
+        CHK(knn_device(h, h->Qall.as<double>() + r0 * D, rows, K, nullptr, h->mcand.as<int64_t>() + r0 * K,
+                       h->mdist.as<double>() + r0 * K, nullptr, h->res_status.as<int>() + g));
+        CHK(viterbi_group(h, g, row_offsets, first[g], first[g + 1], K, h->mcand.as<int64_t>(), h->mdist.as<double>(), true));
     }
-    for (int i = 0; i < 4; ++i) HIPCHK(hipStreamSynchronize(h->dp_stream[i]));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamSynchronize(h->dp_stream[i]));
     HIPCHK(hipGetLastError());
-    // deferred K-NN status words: redo the (rare) utterance whose sampled thresholds overflowed a list
+    // deferred K-NN status words: redo the (rare) group whose sampled thresholds overflowed a list
     {
-        std::vector<int> st((size_t)n_utts);
-        HIPCHK(hipMemcpyAsync(st.data(), h->res_status.p, (size_t)n_utts * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        std::vector<int> st((size_t)n_groups);
+        HIPCHK(hipMemcpyAsync(st.data(), h->res_status.p, (size_t)n_groups * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        for (int u = 0; u < n_utts; ++u) {
-            if (st[u] == 0) continue;
-            if (st[u] & 2) h->tie_overflow = 1;
-            const int64_t r0 = row_offsets[u], T = row_offsets[u + 1] - r0;
-            UttSlot &s = h->slot[0];
-            CHK(slot_ensure(h, s, T, K));
+        for (int g = 0; g < n_groups; ++g) {
+            if (st[g] == 0) continue;
+            if (st[g] & 2) h->tie_overflow = 1;
+            const int64_t r0 = row_offsets[first[g]], rows = row_offsets[first[g + 1]] - r0;
             {
                 const int saved = h->precision;
                 h->precision = 0;
-                const int rc = knn_device(h, h->Qall.as<double>() + r0 * D, T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr);
+                const int rc = knn_device(h, h->Qall.as<double>() + r0 * D, rows, K, nullptr,
+                                          h->mcand.as<int64_t>() + r0 * K, h->mdist.as<double>() + r0 * K, nullptr);
                 h->precision = saved;
                 if (rc) return rc;
             }
-            launch_join_costs(h->JCw.as<double>(), h->Djpad, h->Dj, join_units(h), s.cand.as<int64_t>(), T, K,
-                              s.J.as<double>(), h->stream);
-            launch_viterbi_dp(s.cand.as<int64_t>(), s.tdist.as<double>(), s.J.as<double>(), T, K, join_units(h),
-                              s.bp.as<unsigned char>(), h->res_path.as<int64_t>() + r0,
-                              h->res_plen.as<int64_t>() + u, h->res_cost.as<double>() + u, h->stream);
+            CHK(viterbi_group(h, g, row_offsets, first[g], first[g + 1], K, h->mcand.as<int64_t>(), h->mdist.as<double>(), false));
             HIPCHK(hipStreamSynchronize(h->stream));
             h->batch_redos += 1;
         }
@@ -1007,6 +1054,97 @@ int snk_merge_topk_dev(snk_handle h, const double *d2_dev, const int64_t *id_dev
     return 0;
 }
 
+// Batch form of snk_knn_local_dev: the rows of all utterances against this rank's shard, first
+// attempts enqueued back to back (status words checked once at the end, the rare overflowed
+// utterance redone with the exact f64 sweep).  Results are complete when the call returns.
+int snk_knn_local_batch_dev(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
+                            double *d2_dev_out, int64_t *id_dev_out)
+{
+    CHK(check_ready(h, true, false));
+    HIPCHK(hipSetDevice(h->device));
+    if (!Q || !row_offsets || n_utts < 1 || !d2_dev_out || !id_dev_out)
+        return fail("snk_knn_local_batch_dev: null/empty argument");
+    if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
+    const int64_t total = row_offsets[n_utts];
+    for (int u = 0; u < n_utts; ++u)
+        if (row_offsets[u + 1] - row_offsets[u] < 1) return fail("snk_knn_local_batch_dev: utterance %d has no rows", u);
+    // the search is per row: fixed-size row groups, whatever the utterance boundaries
+    const int64_t step = h->batch_rows > 0 ? h->batch_rows : total;
+    const int n_groups = (int)((total + step - 1) / step);
+    CHK(h->Qall.ensure((size_t)total * D * sizeof(double)));
+    CHK(h->res_status.ensure((size_t)n_groups * sizeof(int)));
+    {
+        StageTimer t(h, h->stream, TM_H2D);
+        HIPCHK(hipMemcpyAsync(h->Qall.p, Q, (size_t)total * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    for (int g = 0; g < n_groups; ++g) {
+        const int64_t r0 = g * step, rows = (r0 + step <= total) ? step : total - r0;
+        CHK(knn_device(h, h->Qall.as<double>() + r0 * D, rows, K, nullptr, id_dev_out + r0 * K, nullptr,
+                       d2_dev_out + r0 * K, h->res_status.as<int>() + g));
+    }
+    std::vector<int> st((size_t)n_groups);
+    HIPCHK(hipMemcpyAsync(st.data(), h->res_status.p, (size_t)n_groups * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    for (int g = 0; g < n_groups; ++g) {
+        if (st[g] == 0) continue;
+        if (st[g] & 2) h->tie_overflow = 1;
+        const int64_t r0 = g * step, rows = (r0 + step <= total) ? step : total - r0;
+        const int saved = h->precision;
+        h->precision = 0;
+        const int rc = knn_device(h, h->Qall.as<double>() + r0 * D, rows, K, nullptr, id_dev_out + r0 * K, nullptr,
+                                  d2_dev_out + r0 * K);
+        h->precision = saved;
+        if (rc) return rc;
+        h->batch_redos += 1;
+    }
+    collect_timers(h);
+    return 0;
+}
+
+// Second half of the sharded search on the rank that owns the utterances: merge the G shard-local
+// lists of every row (the exchange step delivered them as (G, R, K)), then join costs on the main
+// stream and the T-step recursions on the side streams, as in snk_knn_viterbi_batch.
+int snk_merge_viterbi_batch_dev(snk_handle h, const double *d2_dev, const int64_t *id_dev, int G,
+                                const int64_t *row_offsets, int n_utts, int K,
+                                int64_t *path_out, int64_t *path_len_out, double *cost_out)
+{
+    CHK(check_ready(h, false, true));
+    HIPCHK(hipSetDevice(h->device));
+    if (!d2_dev || !id_dev || !row_offsets || n_utts < 1 || !path_out || !path_len_out || !cost_out)
+        return fail("snk_merge_viterbi_batch_dev: null/empty argument");
+    if (K < 1 || K > 208) return fail("viterbi: n_candidates=%d outside 1..208", K);
+    if (G < 1 || (int64_t)G * K > 8192) return fail("snk_merge_viterbi_batch_dev: G*K=%d exceeds 8192", G * K);
+    const int64_t total = row_offsets[n_utts];
+    for (int u = 0; u < n_utts; ++u)
+        if (row_offsets[u + 1] - row_offsets[u] < 1) return fail("snk_merge_viterbi_batch_dev: utterance %d has no rows", u);
+    CHK(h->mcand.ensure((size_t)total * K * sizeof(int64_t)));
+    CHK(h->mdist.ensure((size_t)total * K * sizeof(double)));
+    CHK(h->res_path.ensure((size_t)total * sizeof(int64_t)));
+    CHK(h->res_plen.ensure((size_t)n_utts * sizeof(int64_t)));
+    CHK(h->res_cost.ensure((size_t)n_utts * sizeof(double)));
+    {
+        StageTimer t(h, h->stream, TM_MERGE);
+        launch_merge_topk(d2_dev, id_dev, G, total, K, h->mcand.as<int64_t>(), h->mdist.as<double>(), h->stream);
+    }
+    {
+        const std::vector<int> first = group_utterances(h, row_offsets, n_utts);
+        for (int g = 0; g + 1 < (int)first.size(); ++g)
+            CHK(viterbi_group(h, g, row_offsets, first[g], first[g + 1], K, h->mcand.as<int64_t>(), h->mdist.as<double>(), true));
+    }
+    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamSynchronize(h->dp_stream[i]));
+    HIPCHK(hipGetLastError());
+    {
+        StageTimer t(h, h->stream, TM_D2H);
+        D2HPart parts[3] = {{path_out, h->res_path.p, (size_t)total * sizeof(int64_t)},
+                            {path_len_out, h->res_plen.p, (size_t)n_utts * sizeof(int64_t)},
+                            {cost_out, h->res_cost.p, (size_t)n_utts * sizeof(double)}};
+        CHK(staged_d2h(h, h->stream, parts, 3));
+    }
+    collect_timers(h);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // timers / options / self test
 // ---------------------------------------------------------------------------
@@ -1051,6 +1189,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "reserved_cus")) {
         if (value < 0 || value > 64) return fail("reserved_cus must be in 0..64");
         h->reserved_cus = (int)value;
+    } else if (!strcmp(name, "batch_rows")) {
+        if (value < 0 || value > 8192) return fail("batch_rows must be in 0..8192 (0: one K-NN call per utterance)");
+        h->batch_rows = (int)value;
     } else if (!strcmp(name, "timers")) {
         h->timers_on = value != 0.0;
     } else {
@@ -1074,6 +1215,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "last_f16_status")) *out = h->last_f16_status;
     else if (!strcmp(name, "pool_chunks_used")) { unsigned int v[2] = {0, 0}; HIPCHK(hipMemcpy(v, h->poolctl.p, sizeof(v), hipMemcpyDeviceToHost)); *out = v[0] + 1e6 * v[1]; }
     else if (!strcmp(name, "precision")) *out = h->precision;
+    else if (!strcmp(name, "batch_rows")) *out = h->batch_rows;
     else if (!strcmp(name, "last_list_mean") || !strcmp(name, "last_list_max")) {
         // candidate-list lengths of the most recent K-NN call (debug / tuning aid)
         const int64_t n = h->last_T;

@@ -79,6 +79,14 @@ void sweep_tail_split(int64_t n_slabs, int qsplit, int64_t waves, int nQT, int64
 // ---- join costs + Viterbi -------------------------------------------------
 void launch_join_costs(const double *JCw, int Djpad, int Dj, int64_t n_units,
                        const int64_t *cand, int64_t T, int K, double *J, hipStream_t s);
+struct DpBatch {                      // kernel-argument descriptor of one batched recursion launch
+    static constexpr int MAX = 24;
+    int64_t off[MAX + 1];
+    int first;
+};
+void launch_viterbi_dp_batch(const int64_t *cand, const double *tdist, const double *J, const int64_t *off,
+                             int n_utts, int first_utt, int K, int64_t n_units, unsigned char *bp_global,
+                             int64_t *path, int64_t *path_len, double *cost, hipStream_t s);
 void launch_viterbi_dp(const int64_t *cand, const double *tdist, const double *J,
                        int64_t T, int K, int64_t n_units, unsigned char *bp_global,
                        int64_t *path, int64_t *path_len, double *cost, hipStream_t s);

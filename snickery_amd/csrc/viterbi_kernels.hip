@@ -12,8 +12,8 @@
 //   naturally adjacent units must join at exactly 0.0 (E[a] == S[a+1] bit for bit), which a
 //   ||e||^2+||s||^2-2e.s form cannot guarantee.  Candidate rows are gathered from HBM in
 //   32-column chunks into LDS and each thread keeps an RT x RT block of pair accumulators.
-// viterbi_dp_kernel: one 1024-thread workgroup walks the trellis; the K x K slab of the next
-//   step is prefetched into registers while the current step reduces, back-pointers stay in LDS.
+// viterbi_dp_kernel: one 1024-thread workgroup walks the trellis; the K x K slabs of the next
+//   2-4 steps are in flight into registers while the current step reduces, back-pointers stay in LDS.
 #include "snk_internal.h"
 #include <float.h>
 
@@ -25,64 +25,72 @@ __device__ __forceinline__ bool unit_usable(int64_t id, int64_t n_units)
     return id >= 1 && id < n_units - 1;
 }
 
-template <int RT, int DC>
-__global__ void __launch_bounds__(64)
-join_cost_kernel(const double *__restrict__ JCw, int Djpad, int64_t n_units,
-                 const int64_t *__restrict__ cand, int64_t T, int K, double *__restrict__ J)
+// One wavefront computes an (8 RTA) x (8 RTB) block of the K x K matrix of one column pair:
+// thread (ta, tb) of the 8 x 8 lane grid keeps an RTA x RTB block of pair accumulators.
+template <int RTA, int RTB, int DC>
+__device__ __forceinline__ void join_tile(const double *__restrict__ JCw, int Djpad, int64_t n_units,
+                                          const int64_t *__restrict__ cand, int64_t t, int K, int a0, int b0,
+                                          double *__restrict__ J, double *Es, double *Ss, int64_t *rowE,
+                                          int64_t *rowS, unsigned char *okE, unsigned char *okS)
 {
-    // one wavefront per (column pair t, 8RT x 8RT block of the K x K matrix): fine-grained work
-    // items (2396 at T=600, K=100) balance over the chip; thread (ta, tb) of the 8 x 8 lane grid
-    // keeps an RT x RT block of pair accumulators
-    constexpr int NR = 8 * RT;
+    constexpr int NRA = 8 * RTA, NRB = 8 * RTB;
     constexpr int DCP = DC + 1;
-    __shared__ double Es[NR * DCP];
-    __shared__ double Ss[NR * DCP];
-    __shared__ int64_t rowE[NR], rowS[NR];
-    __shared__ unsigned char okE[NR], okS[NR];
-
-    const int64_t t = blockIdx.x;
-    const int a0 = blockIdx.y * NR, b0 = blockIdx.z * NR;
     const int tid = threadIdx.x;
-    for (int i = tid; i < NR; i += 64) {
+    for (int i = tid; i < NRA; i += 64) {
         const int64_t a = (a0 + i < K) ? cand[t * K + a0 + i] : -1;
-        const int64_t b = (b0 + i < K) ? cand[(t + 1) * K + b0 + i] : -1;
-        const bool va = unit_usable(a, n_units), vb = unit_usable(b, n_units);
-        okE[i] = va; okS[i] = vb;
+        const bool va = unit_usable(a, n_units);
+        okE[i] = va;
         rowE[i] = va ? a + 1 : 0;      // unit_end_data[a]   = JCw[a+1]
+    }
+    for (int i = tid; i < NRB; i += 64) {
+        const int64_t b = (b0 + i < K) ? cand[(t + 1) * K + b0 + i] : -1;
+        const bool vb = unit_usable(b, n_units);
+        okS[i] = vb;
         rowS[i] = vb ? b : 0;          // unit_start_data[b] = JCw[b]
     }
     __syncthreads();
 
     const int ta = tid >> 3, tb = tid & 7;
-    double acc[RT][RT];
+    double acc[RTA][RTB];
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
+    for (int i = 0; i < RTA; ++i)
 #pragma unroll
-        for (int j = 0; j < RT; ++j) acc[i][j] = 0.0;
+        for (int j = 0; j < RTB; ++j) acc[i][j] = 0.0;
 
     // register-staged gather: the next column chunk's global loads are in flight while the
     // current chunk is being accumulated (DC doubles = 128 contiguous bytes per row and chunk)
-    constexpr int PER = (NR * (DC / 2) + 63) / 64;       // double2 loads per lane and matrix
-    double2 pe[PER], ps[PER];
+    constexpr int PERA = (NRA * (DC / 2) + 63) / 64;     // double2 loads per lane
+    constexpr int PERB = (NRB * (DC / 2) + 63) / 64;
+    double2 pe[PERA], ps[PERB];
     auto fetch = [&](int c0) {
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
+        for (int k = 0; k < PERA; ++k) {
             const int e = tid + k * 64;
-            if (e < NR * (DC / 2)) {
-                const int r = e / (DC / 2), c = (e % (DC / 2)) * 2;
-                pe[k] = *reinterpret_cast<const double2 *>(JCw + rowE[r] * Djpad + c0 + c);
-                ps[k] = *reinterpret_cast<const double2 *>(JCw + rowS[r] * Djpad + c0 + c);
-            }
+            if (e < NRA * (DC / 2))
+                pe[k] = *reinterpret_cast<const double2 *>(JCw + rowE[e / (DC / 2)] * Djpad + c0 + (e % (DC / 2)) * 2);
+        }
+#pragma unroll
+        for (int k = 0; k < PERB; ++k) {
+            const int e = tid + k * 64;
+            if (e < NRB * (DC / 2))
+                ps[k] = *reinterpret_cast<const double2 *>(JCw + rowS[e / (DC / 2)] * Djpad + c0 + (e % (DC / 2)) * 2);
         }
     };
     fetch(0);
     for (int c0 = 0; c0 < Djpad; c0 += DC) {
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
+        for (int k = 0; k < PERA; ++k) {
             const int e = tid + k * 64;
-            if (e < NR * (DC / 2)) {
+            if (e < NRA * (DC / 2)) {
                 const int r = e / (DC / 2), c = (e % (DC / 2)) * 2;
                 Es[r * DCP + c] = pe[k].x; Es[r * DCP + c + 1] = pe[k].y;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PERB; ++k) {
+            const int e = tid + k * 64;
+            if (e < NRB * (DC / 2)) {
+                const int r = e / (DC / 2), c = (e % (DC / 2)) * 2;
                 Ss[r * DCP + c] = ps[k].x; Ss[r * DCP + c + 1] = ps[k].y;
             }
         }
@@ -90,15 +98,15 @@ join_cost_kernel(const double *__restrict__ JCw, int Djpad, int64_t n_units,
         if (c0 + DC < Djpad) fetch(c0 + DC);
 #pragma unroll 2
         for (int c = 0; c < DC; ++c) {
-            double ev[RT], sv[RT];
+            double ev[RTA], sv[RTB];
 #pragma unroll
-            for (int i = 0; i < RT; ++i) ev[i] = Es[(ta * RT + i) * DCP + c];
+            for (int i = 0; i < RTA; ++i) ev[i] = Es[(ta * RTA + i) * DCP + c];
 #pragma unroll
-            for (int j = 0; j < RT; ++j) sv[j] = Ss[(tb * RT + j) * DCP + c];
+            for (int j = 0; j < RTB; ++j) sv[j] = Ss[(tb * RTB + j) * DCP + c];
 #pragma unroll
-            for (int i = 0; i < RT; ++i)
+            for (int i = 0; i < RTA; ++i)
 #pragma unroll
-                for (int j = 0; j < RT; ++j) {
+                for (int j = 0; j < RTB; ++j) {
                     const double d = __dsub_rn(ev[i], sv[j]);
                     acc[i][j] = __dadd_rn(acc[i][j], __dmul_rn(d, d));
                 }
@@ -106,10 +114,10 @@ join_cost_kernel(const double *__restrict__ JCw, int Djpad, int64_t n_units,
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
+    for (int i = 0; i < RTA; ++i)
 #pragma unroll
-        for (int j = 0; j < RT; ++j) {
-            const int al = ta * RT + i, bl = tb * RT + j;
+        for (int j = 0; j < RTB; ++j) {
+            const int al = ta * RTA + i, bl = tb * RTB + j;
             const int a = a0 + al, b = b0 + bl;
             if (a < K && b < K) {
                 const bool ok = okE[al] && okS[bl];
@@ -118,23 +126,62 @@ join_cost_kernel(const double *__restrict__ JCw, int Djpad, int64_t n_units,
         }
 }
 
-template <int RT, int DC>
-static void launch_join_t(const double *JCw, int Djpad, int64_t n_units, const int64_t *cand,
-                          int64_t T, int K, double *J, hipStream_t s)
+// The K candidates of a column are cut into n_tiles row blocks: n_tiles-1 of 8*RTM rows and a
+// last one of 8*RTL >= the remainder (K=100: 56 + 48 rows instead of 2 x 56: 8% padding, not 25%).
+// Work items are fine-grained ((T-1) * n_tiles^2 single-wave workgroups) and balance over the chip.
+template <int RTM, int RTL, int DC>
+__global__ void __launch_bounds__(64)
+join_cost_kernel(const double *__restrict__ JCw, int Djpad, int64_t n_units,
+                 const int64_t *__restrict__ cand, int64_t T, int K, int n_tiles, double *__restrict__ J)
 {
-    const int nb = (K + 8 * RT - 1) / (8 * RT);
-    hipLaunchKernelGGL((join_cost_kernel<RT, DC>), dim3((unsigned)(T - 1), nb, nb), dim3(64), 0, s,
-                       JCw, Djpad, n_units, cand, T, K, J);
+    constexpr int RTX = (RTM > RTL) ? RTM : RTL;
+    constexpr int NR = 8 * RTX;
+    __shared__ double Es[NR * (DC + 1)];
+    __shared__ double Ss[NR * (DC + 1)];
+    __shared__ int64_t rowE[NR], rowS[NR];
+    __shared__ unsigned char okE[NR], okS[NR];
+    const int64_t t = blockIdx.x;
+    const bool lastA = (int)blockIdx.y == n_tiles - 1, lastB = (int)blockIdx.z == n_tiles - 1;
+    const int a0 = blockIdx.y * 8 * RTM, b0 = blockIdx.z * 8 * RTM;
+#define SNK_TILE(A_, B_) join_tile<A_, B_, DC>(JCw, Djpad, n_units, cand, t, K, a0, b0, J, Es, Ss, rowE, rowS, okE, okS)
+    if (RTM == RTL) SNK_TILE(RTL, RTL);
+    else if (lastA && lastB) SNK_TILE(RTL, RTL);
+    else if (lastA) SNK_TILE(RTL, RTM);
+    else if (lastB) SNK_TILE(RTM, RTL);
+    else SNK_TILE(RTM, RTM);
+#undef SNK_TILE
 }
 
+template <int RTM, int RTL, int DC>
+static void launch_join_t(const double *JCw, int Djpad, int64_t n_units, const int64_t *cand,
+                          int64_t T, int K, int n_tiles, double *J, hipStream_t s)
+{
+    hipLaunchKernelGGL((join_cost_kernel<RTM, RTL, DC>), dim3((unsigned)(T - 1), n_tiles, n_tiles), dim3(64), 0, s,
+                       JCw, Djpad, n_units, cand, T, K, n_tiles, J);
+}
+
+// cand holds T rows; J gets T-1 slabs (slab r: rows r and r+1).  A batch passes the concatenated
+// rows of several utterances: the slab between two utterances is computed and never read.
 void launch_join_costs(const double *JCw, int Djpad, int /*Dj*/, int64_t n_units,
                        const int64_t *cand, int64_t T, int K, double *J, hipStream_t s)
 {
     if (T < 2) return;
-    if (K <= 16) launch_join_t<2, 16>(JCw, Djpad, n_units, cand, T, K, J, s);
-    else if (K <= 32) launch_join_t<4, 16>(JCw, Djpad, n_units, cand, T, K, J, s);
-    else if (K <= 40 || (K > 56 && K <= 80)) launch_join_t<5, 16>(JCw, Djpad, n_units, cand, T, K, J, s);
-    else launch_join_t<7, 16>(JCw, Djpad, n_units, cand, T, K, J, s);
+    const int n_tiles = (K + 55) / 56;
+    const int last = K - 56 * (n_tiles - 1);
+    const int rtl = (last + 7) / 8;
+    if (n_tiles == 1) {
+        if (rtl <= 2) launch_join_t<2, 2, 16>(JCw, Djpad, n_units, cand, T, K, 1, J, s);
+        else if (rtl <= 4) launch_join_t<4, 4, 16>(JCw, Djpad, n_units, cand, T, K, 1, J, s);
+        else if (rtl == 5) launch_join_t<5, 5, 16>(JCw, Djpad, n_units, cand, T, K, 1, J, s);
+        else if (rtl == 6) launch_join_t<6, 6, 16>(JCw, Djpad, n_units, cand, T, K, 1, J, s);
+        else launch_join_t<7, 7, 16>(JCw, Djpad, n_units, cand, T, K, 1, J, s);
+    } else {
+        if (rtl <= 2) launch_join_t<7, 2, 16>(JCw, Djpad, n_units, cand, T, K, n_tiles, J, s);
+        else if (rtl <= 4) launch_join_t<7, 4, 16>(JCw, Djpad, n_units, cand, T, K, n_tiles, J, s);
+        else if (rtl == 5) launch_join_t<7, 5, 16>(JCw, Djpad, n_units, cand, T, K, n_tiles, J, s);
+        else if (rtl == 6) launch_join_t<7, 6, 16>(JCw, Djpad, n_units, cand, T, K, n_tiles, J, s);
+        else launch_join_t<7, 7, 16>(JCw, Djpad, n_units, cand, T, K, n_tiles, J, s);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -142,24 +189,44 @@ void launch_join_costs(const double *JCw, int Djpad, int /*Dj*/, int64_t n_units
 //           delta_t[k] = tdist[t,k] + min_k' ( delta_{t-1}[k'] + J[t-1,k',k] )
 // ties: lowest k', then lowest final k  (oracle/snk_oracle.py: viterbi)
 // ---------------------------------------------------------------------------
-#define VIT_KPP 16
-// PF = true : K <= 128, each thread owns <= 16 predecessors and prefetches the next slab
-// PF = false: larger K, predecessors are read from L2 inside the step
-template <bool PF>
-__global__ void __launch_bounds__(1024)
-viterbi_dp_kernel(const int64_t *__restrict__ cand, const double *__restrict__ tdist,
-                  const double *__restrict__ J, int64_t T, int K, int64_t n_units, int KP,
-                  int parts, int kpp, int bp_in_lds, unsigned char *__restrict__ bp_global,
-                  int64_t *__restrict__ path, int64_t *__restrict__ path_len,
-                  double *__restrict__ cost)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// PD > 0: each thread owns KPM predecessors of its column (part p: kp in [p*KPM, (p+1)*KPM)) and
+//         keeps the K x K slabs of the next PD steps in flight in registers: a single workgroup
+//         pulls 8*K*K bytes per step through one CU, and without several slabs in flight every
+//         step pays a full HBM round trip.  Slabs are read with buffer loads (one VGPR offset per
+//         thread, the slab/row part in an SGPR).  Predecessors kp >= K need no predicate: their
+//         delta stays +inf and an out-of-range buffer load returns 0.
+// PD = 0: larger K, predecessors are read from L2 inside the step
+template <int KPM, int PD, int NTH, bool BPL>
+__global__ void __launch_bounds__(NTH)
+viterbi_dp_kernel(const int64_t *__restrict__ cand_all, const double *__restrict__ tdist_all,
+                  const double *__restrict__ J_all, const DpBatch batch, int K, int64_t n_units, int KP,
+                  int parts, int kpp, unsigned char *__restrict__ bp_all,
+                  int64_t *__restrict__ path_all, int64_t *__restrict__ path_len_all,
+                  double *__restrict__ cost_all)
 {
+    // one workgroup per utterance of the launch: rows [off[u], off[u+1]) of the group's matrices;
+    // J row r holds the costs between rows r and r+1 (the row joining two utterances is unused)
+    const int64_t r0 = batch.off[blockIdx.x];
+    const int64_t T = batch.off[blockIdx.x + 1] - r0;
+    const int64_t *__restrict__ cand = cand_all + r0 * K;
+    const double *__restrict__ tdist = tdist_all + r0 * K;
+    const double *__restrict__ J = J_all + r0 * K * K;
+    unsigned char *__restrict__ bp_global = bp_all + r0 * K;
+    int64_t *__restrict__ path = path_all + r0;
+    int64_t *__restrict__ path_len = path_len_all + batch.first + blockIdx.x;
+    double *__restrict__ cost = cost_all + batch.first + blockIdx.x;
     extern __shared__ __align__(16) unsigned char smem[];
     double *delta = reinterpret_cast<double *>(smem);              // [KP]
     double *pval = delta + KP;                                     // [parts][KP]
     int *parg = reinterpret_cast<int *>(pval + (size_t)parts * KP);// [parts][KP]
-    unsigned char *bp = bp_in_lds
-        ? reinterpret_cast<unsigned char *>(parg + (size_t)parts * KP) : bp_global;  // [T][K]
+    // back-pointers [T][K]: in LDS when they fit, else in global memory.  Two typed pointers, not
+    // one generic one: a flat store would make every later wait a full vmcnt(0)/lgkmcnt(0).
+    unsigned char *bp_lds = reinterpret_cast<unsigned char *>(parg + (size_t)parts * KP);
     __shared__ int final_slot;
+    constexpr bool PF = PD > 0;
+    constexpr int NB = PF ? PD : 1;
 
     const int tid = threadIdx.x;
     const int k = tid % KP, part = tid / KP;
@@ -171,75 +238,95 @@ viterbi_dp_kernel(const int64_t *__restrict__ cand, const double *__restrict__ t
         if (tid == 0) { *path_len = 0; *cost = inf; }
         return;
     }
-    if (part == 0) {
-        double v = inf;
-        if (k < K && unit_usable(cand[k], n_units)) v = tdist[k];
-        delta[k] = v;
-    }
-    double jreg[VIT_KPP];
-    if (PF && active) {
+    // target cost of column t with unusable candidates folded in as +inf (inf + x == inf)
+    auto target_cost = [&](int64_t t) -> double {
+        return unit_usable(cand[t * K + k], n_units) ? tdist[t * K + k] : inf;
+    };
+    if (part == 0) delta[k] = (k < K) ? target_cost(0) : inf;
+
+    const __amdgpu_buffer_rsrc_t jres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(J), 0, (int)((T - 1) * K * K * 8), 0x00020000);
+    // idle threads (k >= K) run the same convergent code with an out-of-range offset: their
+    // loads return 0 without touching memory and their results are never stored
+    const int voff = active ? (kp0 * K + k) * 8 : 0x7ffffff8;
+    double jb[NB][KPM];
+    auto load_slab = [&](int64_t slab, double (&dst)[KPM]) {       // slab t-1 feeds step t
+        const int sbase = (int)(slab * K * K * 8);
 #pragma unroll
-        for (int i = 0; i < VIT_KPP; ++i) {
-            const int kp = kp0 + i;
-            jreg[i] = (i < kpp && kp < K) ? J[(int64_t)kp * K + k] : inf;
+        for (int i = 0; i < KPM; ++i)
+            dst[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(jres, voff, sbase + i * K * 8, 0));
+    };
+    // target cost and candidate id of the column NB steps ahead: plain independent loads staged
+    // like the slabs and combined at the point of use (a dependent load here would force vmcnt(0) and drain
+    // the slab pipeline every step)
+    double td_raw[NB];
+    int64_t id_raw[NB];
+    const bool lead = active && part == 0;
+    auto load_target = [&](int64_t t, double &td, int64_t &id) {
+        const int64_t tn = (t < T ? t : T - 1) * K + (lead ? k : 0);
+        td = tdist[tn];
+        id = cand[tn];
+    };
+    if (PF) {
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            load_slab(s < T - 2 ? s : T - 2, jb[s]);
+            load_target(1 + s, td_raw[s], id_raw[s]);
         }
     }
     __syncthreads();
 
-    for (int64_t t = 1; t < T; ++t) {
+    // One loop, NB steps per trip, no prologue/epilogue copies of the register stages: after its
+    // slab is consumed a stage is refilled with the slab NB steps ahead (index clamped to the last
+    // slab: a clamped re-load is never consumed), and the up to NB-1 surplus steps of the last trip
+    // run with their stores switched off.
+    auto step = [&](int64_t t, double (&jr)[KPM], double &tdr, int64_t &idr) {
+        const bool valid = t < T;                       // uniform
         double best = inf;
-        int arg = kp0;
-        double td = 0.0;
-        bool ok_k = false;
-        double jnext[VIT_KPP];
+        int arg = 0;
+        double td = inf;
+        if (PF) {
+            td = unit_usable(idr, n_units) ? tdr : inf;
+            load_target(t + NB, tdr, idr);
+#pragma unroll
+            for (int i = 0; i < KPM; ++i) {
+                const double tot = __dadd_rn(delta[kp0 + i], jr[i]);
+                if (tot < best) { best = tot; arg = i; }
+            }
+            arg += kp0;
+            load_slab(t - 1 + NB < T - 2 ? t - 1 + NB : T - 2, jr);
+        } else if (active) {
+            if (part == 0) td = target_cost(t);
+            arg = kp0;
+            const double *Jt = J + (t - 1) * K * K;
+            for (int i = 0; i < kpp; ++i) {
+                const int kp = kp0 + i;
+                if (kp < K) {
+                    const double tot = __dadd_rn(delta[kp], Jt[(int64_t)kp * K + k]);
+                    if (tot < best) { best = tot; arg = kp; }
+                }
+            }
+        }
         if (active) {
-            if (PF && t + 1 < T) {     // next slab column: independent of delta
-#pragma unroll
-                for (int i = 0; i < VIT_KPP; ++i) {
-                    const int kp = kp0 + i;
-                    jnext[i] = (i < kpp && kp < K) ? J[(t * K + kp) * K + k] : inf;
-                }
-            }
-            if (part == 0) {
-                td = tdist[t * K + k];
-                ok_k = unit_usable(cand[t * K + k], n_units);
-            }
-            if (PF) {
-#pragma unroll
-                for (int i = 0; i < VIT_KPP; ++i) {
-                    const int kp = kp0 + i;
-                    if (i < kpp && kp < K) {
-                        const double tot = __dadd_rn(delta[kp], jreg[i]);
-                        if (tot < best) { best = tot; arg = kp; }
-                    }
-                }
-            } else {
-                const double *Jt = J + (t - 1) * K * K;
-                for (int i = 0; i < kpp; ++i) {
-                    const int kp = kp0 + i;
-                    if (kp < K) {
-                        const double tot = __dadd_rn(delta[kp], Jt[(int64_t)kp * K + k]);
-                        if (tot < best) { best = tot; arg = kp; }
-                    }
-                }
-            }
             pval[part * KP + k] = best;
             parg[part * KP + k] = arg;
         }
         __syncthreads();
-        if (active && part == 0) {
+        if (lead && valid) {
             for (int p = 1; p < parts; ++p) {
                 const double v = pval[p * KP + k];
                 if (v < best) { best = v; arg = parg[p * KP + k]; }
             }
-            delta[k] = ok_k ? __dadd_rn(td, best) : inf;
-            bp[t * K + k] = (unsigned char)arg;
-        }
-        if (PF && active && t + 1 < T) {
-#pragma unroll
-            for (int i = 0; i < VIT_KPP; ++i) jreg[i] = jnext[i];
+            delta[k] = __dadd_rn(td, best);
+            if constexpr (BPL) bp_lds[t * K + k] = (unsigned char)arg;
+            else bp_global[t * K + k] = (unsigned char)arg;
         }
         __syncthreads();
+    };
+
+    for (int64_t t = 1; t < T; t += NB) {
+#pragma unroll
+        for (int s = 0; s < NB; ++s) step(t + s, jb[s], td_raw[s], id_raw[s]);
     }
 
     if (tid == 0) {
@@ -250,14 +337,71 @@ viterbi_dp_kernel(const int64_t *__restrict__ cand, const double *__restrict__ t
         if (best == inf) { *path_len = 0; *cost = inf; final_slot = -1; }
         else { *path_len = T; *cost = best; final_slot = slot; }
     }
-    if (!bp_in_lds) __threadfence();
+    if (!BPL) __threadfence();
     __syncthreads();
     if (tid == 0 && final_slot >= 0) {
         int slot = final_slot;
         for (int64_t t = T - 1; t >= 0; --t) {
             path[t] = cand[t * K + slot];
-            if (t > 0) slot = bp[t * K + slot];
+            if (t > 0) {
+                if constexpr (BPL) slot = bp_lds[t * K + slot];
+                else slot = bp_global[t * K + slot];
+            }
         }
+    }
+}
+
+// Launches one workgroup per utterance; `off` (n+1 row offsets into the group's matrices) travels
+// in the kernel arguments.  path_len / cost are indexed by first_utt + i.
+void launch_viterbi_dp_batch(const int64_t *cand, const double *tdist, const double *J, const int64_t *off,
+                             int n_utts, int first_utt, int K, int64_t n_units, unsigned char *bp_global,
+                             int64_t *path, int64_t *path_len, double *cost, hipStream_t s)
+{
+    int KP = 64;
+    while (KP < K) KP <<= 1;                // K <= 256
+    for (int u0 = 0; u0 < n_utts; u0 += DpBatch::MAX) {
+        const int n = (n_utts - u0 < DpBatch::MAX) ? n_utts - u0 : DpBatch::MAX;
+        DpBatch batch;
+        int64_t Tmax = 0;
+        for (int i = 0; i <= n; ++i) batch.off[i] = off[u0 + i];
+        for (int i = 0; i < n; ++i) Tmax = (off[u0 + i + 1] - off[u0 + i] > Tmax) ? off[u0 + i + 1] - off[u0 + i] : Tmax;
+        batch.first = first_utt + u0;
+        const int64_t T = Tmax;
+        // K <= 64: 1024 threads, 16 column parts; K <= 128: 512 threads (256 registers per thread hold
+        // 3 slabs in flight); larger K: 1024 threads, predecessors read inside the step
+        const bool fits = (double)(T - 1) * K * K * 8.0 < 2147483648.0;      // 32-bit buffer offsets
+        const int nth = (KP == 128 && fits) ? 512 : 1024;
+        const int parts = nth / KP;
+        int kpp = (K + parts - 1) / parts;
+        int variant = 0;
+        if (fits && KP == 64) { variant = 1; kpp = 4; }
+        else if (fits && KP == 128 && kpp <= 25) { variant = 2; kpp = 25; }
+        else if (fits && KP == 128) { variant = 3; kpp = 32; }
+        const size_t base = (size_t)KP * 8 + (size_t)parts * KP * 12;
+        const size_t bp_bytes = (size_t)T * K;
+        const int bp_in_lds = (base + bp_bytes + 64 <= 150 * 1024) ? 1 : 0;
+        const size_t shmem = base + (bp_in_lds ? bp_bytes : 0);
+#define SNK_DP1(KPM_, PD_, NTH_, BPL_)                                                             \
+    {                                                                                              \
+        static bool attr_set = false;                                                              \
+        if (!attr_set) {                                                                           \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&viterbi_dp_kernel<KPM_, PD_, NTH_, BPL_>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));    \
+            attr_set = true;                                                                       \
+        }                                                                                          \
+        hipLaunchKernelGGL((viterbi_dp_kernel<KPM_, PD_, NTH_, BPL_>), dim3(n), dim3(NTH_), shmem, s, cand, \
+                           tdist, J, batch, K, n_units, KP, parts, kpp, bp_global, path, path_len, cost); \
+    }
+#define SNK_DP(KPM_, PD_, NTH_)                                                                    \
+    {                                                                                              \
+        if (bp_in_lds) SNK_DP1(KPM_, PD_, NTH_, true) else SNK_DP1(KPM_, PD_, NTH_, false)         \
+    }
+        if (variant == 1) SNK_DP(4, 4, 1024)
+        else if (variant == 2) SNK_DP(25, 3, 512)
+        else if (variant == 3) SNK_DP(32, 3, 512)
+        else SNK_DP(1, 0, 1024)
+#undef SNK_DP1
+#undef SNK_DP
     }
 }
 
@@ -265,29 +409,8 @@ void launch_viterbi_dp(const int64_t *cand, const double *tdist, const double *J
                        int64_t n_units, unsigned char *bp_global, int64_t *path, int64_t *path_len,
                        double *cost, hipStream_t s)
 {
-    int KP = 64;
-    while (KP < K) KP <<= 1;                // K <= 256
-    const int parts = 1024 / KP;
-    const int kpp = (K + parts - 1) / parts;
-    const bool pf = (kpp <= VIT_KPP);
-    const size_t base = (size_t)KP * 8 + (size_t)parts * KP * 12;
-    const size_t bp_bytes = (size_t)T * K;
-    const int bp_in_lds = (base + bp_bytes + 64 <= 150 * 1024) ? 1 : 0;
-    const size_t shmem = base + (bp_in_lds ? bp_bytes : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&viterbi_dp_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&viterbi_dp_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));
-        attr_set = true;
-    }
-    if (pf)
-        hipLaunchKernelGGL(viterbi_dp_kernel<true>, dim3(1), dim3(1024), shmem, s, cand, tdist, J,
-                           T, K, n_units, KP, parts, kpp, bp_in_lds, bp_global, path, path_len, cost);
-    else
-        hipLaunchKernelGGL(viterbi_dp_kernel<false>, dim3(1), dim3(1024), shmem, s, cand, tdist, J,
-                           T, K, n_units, KP, parts, kpp, bp_in_lds, bp_global, path, path_len, cost);
+    const int64_t off[2] = {0, T};
+    launch_viterbi_dp_batch(cand, tdist, J, off, 1, 0, K, n_units, bp_global, path, path_len, cost, s);
 }
 
 }  // namespace snk

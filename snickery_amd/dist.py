@@ -2,10 +2,11 @@
 (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).
 
 Exchange step (the only collective on the data path): every rank computes the
-top-K of ALL query rows against ITS shard, the per-rank lists (T, K) of (squared distance,
-global unit id) are all-gathered, and each rank merges the G*K candidates of every row to the
-global top-K ordered by (distance, id).  The Viterbi of an utterance then runs on ONE GPU
-(utterance u on rank u mod G) against a replicated join matrix.
+top-K of ALL query rows against ITS shard; the per-rank lists (T, K) of (squared distance,
+global unit id) are exchanged and merged to the global top-K ordered by (distance, id).  A single
+utterance all-gathers its lists (every rank gets the candidates); a batch assigns utterances to
+ranks in contiguous blocks and uses an all-to-all, so that every list travels only to the ONE GPU
+that runs that utterance's Viterbi against a replicated join matrix.
 
 The class is engine-agnostic: the product passes a ``snickery_amd.HipSearchEngine`` and CUDA
 tensors; the CPU tests (gloo, world_size 2) pass a stand-in engine built on the oracle.
@@ -43,6 +44,13 @@ class HipShardEngine(object):
     def viterbi(self, cand, dist_):
         return self.engine.viterbi(cand, dist_)
 
+    def knn_local_batch(self, utterances, K, d2_out, id_out):
+        self.engine.knn_local_batch_dev(utterances, K, d2_out.data_ptr(), id_out.data_ptr())
+
+    def merge_viterbi_batch(self, d2_all, id_all, G, lengths, K):
+        torch.cuda.synchronize(self.device)          # the exchange ran on torch's stream
+        return self.engine.merge_viterbi_batch_dev(d2_all.data_ptr(), id_all.data_ptr(), G, lengths, K)
+
 
 class ShardedSearch(object):
     def __init__(self, shard_engine, rank=None, world_size=None, group=None):
@@ -69,31 +77,52 @@ class ShardedSearch(object):
 
     def knn_viterbi_batch(self, utterances, K):
         """Paths of all utterances (list of int64 arrays) and costs, gathered on every rank.
-        K-NN is sharded over the database; utterance u's Viterbi runs on rank u mod G."""
+
+        Step 1 (every rank): shard-local top-K of ALL rows of the batch.  Exchange: utterances are
+        owned by ranks in contiguous blocks, so the (R, K) list matrices are already ordered by
+        destination and ONE all-to-all per matrix hands every owner the lists of its utterances
+        from every shard as (G, R_own, K) -- (G-1)/G * R*K*16 B sent per rank instead of the
+        G-fold all-gather volume.  Step 2 (owner): merge, join costs, Viterbi."""
         G = self.world
-        mine = {}
-        for u, U in enumerate(utterances):
-            cand, d = self.knn(U, K)
-            if u % G == self.rank:
-                path, cost = self.e.viterbi(cand, d)
-                mine[u] = (np.asarray(path, dtype=np.int64), float(cost))
-        if G == 1:
-            return [mine[u][0] for u in range(len(utterances))], np.array([mine[u][1] for u in range(len(utterances))])
-        # results exchange (small, host side): pad paths to a common length
+        n = len(utterances)
         lens = [int(np.shape(U)[0]) for U in utterances]
+        owned = [shard_bounds(n, G, r) for r in range(G)]          # utterance blocks per rank
+        rows_to = [sum(lens[a:b]) for a, b in owned]
+        R = sum(lens)
+        d2 = self.e.alloc(R, K, dtype=torch.float64)
+        ids = self.e.alloc(R, K, dtype=torch.int64)
+        self.e.knn_local_batch(utterances, K, d2, ids)
+        lo, hi = owned[self.rank]
+        r_own = rows_to[self.rank]
+        if G == 1:
+            d2_all, id_all = d2, ids
+        else:
+            d2_all = self.e.alloc(G * r_own, K, dtype=torch.float64)
+            id_all = self.e.alloc(G * r_own, K, dtype=torch.int64)
+            dist.all_to_all_single(d2_all, d2, [r_own] * G, rows_to, group=self.group)
+            dist.all_to_all_single(id_all, ids, [r_own] * G, rows_to, group=self.group)
+        if hi > lo:
+            own_paths, own_costs = self.e.merge_viterbi_batch(d2_all, id_all, G, lens[lo:hi], K)
+        else:
+            own_paths, own_costs = [], []
+        if G == 1:
+            return [np.asarray(p, dtype=np.int64) for p in own_paths], np.asarray(own_costs, dtype=np.float64)
+        # results exchange (small): one fixed-size record per owned-utterance slot
+        slots = max(b - a for a, b in owned)
         Lmax = max(lens)
-        buf = torch.full((len(utterances), Lmax + 2), -1.0, dtype=torch.float64)
-        for u, (p, c) in mine.items():
-            buf[u, 0] = float(len(p))
-            buf[u, 1] = c
-            buf[u, 2:2 + len(p)] = torch.from_numpy(p.astype(np.float64))
+        buf = torch.full((slots, Lmax + 2), -1.0, dtype=torch.float64)
+        for j, (p, c) in enumerate(zip(own_paths, own_costs)):
+            buf[j, 0] = float(len(p))
+            buf[j, 1] = float(c)
+            buf[j, 2:2 + len(p)] = torch.from_numpy(np.asarray(p, dtype=np.float64))
         buf = buf.to(self.e.device) if str(self.e.device) != 'cpu' else buf
         allb = [torch.empty_like(buf) for _ in range(G)]
         dist.all_gather(allb, buf, group=self.group)
+        allb = [b.cpu().numpy() for b in allb]
         paths, costs = [], []
-        for u in range(len(utterances)):
-            row = allb[u % G][u].cpu().numpy()
-            n = int(row[0])
-            paths.append(row[2:2 + n].astype(np.int64))
-            costs.append(row[1])
+        for r, (a, b) in enumerate(owned):
+            for j in range(b - a):
+                row = allb[r][j]
+                paths.append(row[2:2 + int(row[0])].astype(np.int64))
+                costs.append(row[1])
         return paths, np.array(costs)

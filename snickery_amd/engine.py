@@ -63,6 +63,10 @@ _SIGNATURES = {
                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'snk_merge_topk_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                           ctypes.c_int64, ctypes.c_int, _c_i64p, _c_f64p]),
+    'snk_knn_local_batch_dev': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    'snk_merge_viterbi_batch_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                   _c_i64p, ctypes.c_int, ctypes.c_int, _c_i64p, _c_i64p, _c_f64p]),
     'snk_upload_join_only': (ctypes.c_int, [ctypes.c_void_p, _c_f32p, ctypes.c_int64, ctypes.c_int]),
     'snk_set_option': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]),
     'snk_get_info': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, _c_f64p]),
@@ -296,6 +300,31 @@ class HipSearchEngine(object):
         self._check(self._lib.snk_merge_topk_dev(self._h, ctypes.c_void_p(d2_dev_ptr), ctypes.c_void_p(id_dev_ptr),
                                                  int(n_lists), int(T), K, _ptr(cand, _c_i64p), _ptr(dist, _c_f64p)))
         return cand, dist
+
+    def knn_local_batch_dev(self, utterances, n_candidates, d2_dev_ptr, id_dev_ptr):
+        """Shard-local top-K of the rows of all utterances, written to caller device buffers
+        (R, K) in utterance order; complete when the call returns."""
+        mats = [_f64(u) for u in utterances]
+        offs = np.zeros(len(mats) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([m.shape[0] for m in mats])
+        Q = np.ascontiguousarray(np.vstack(mats))
+        self._check(self._lib.snk_knn_local_batch_dev(self._h, _ptr(Q, _c_f64p), _ptr(offs, _c_i64p), len(mats),
+                                                      Q.shape[1], int(n_candidates),
+                                                      ctypes.c_void_p(d2_dev_ptr), ctypes.c_void_p(id_dev_ptr)))
+
+    def merge_viterbi_batch_dev(self, d2_dev_ptr, id_dev_ptr, n_lists, lengths, n_candidates):
+        """Owner-rank half of the sharded search: (G, R, K) gathered lists of the utterances with
+        the given row counts -> (list of paths, costs)."""
+        offs = np.zeros(len(lengths) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum(lengths)
+        paths = np.empty((int(offs[-1]),), dtype=np.int64)
+        plen = np.zeros(len(lengths), dtype=np.int64)
+        cost = np.zeros(len(lengths), dtype=np.float64)
+        self._check(self._lib.snk_merge_viterbi_batch_dev(self._h, ctypes.c_void_p(d2_dev_ptr),
+                                                          ctypes.c_void_p(id_dev_ptr), int(n_lists),
+                                                          _ptr(offs, _c_i64p), len(lengths), int(n_candidates),
+                                                          _ptr(paths, _c_i64p), _ptr(plen, _c_i64p), _ptr(cost, _c_f64p)))
+        return [paths[offs[u]:offs[u] + plen[u]].copy() for u in range(len(lengths))], cost
 
     # -- introspection ----------------------------------------------------------
     def timers(self):

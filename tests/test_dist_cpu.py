@@ -1,6 +1,6 @@
 """world_size-2 gloo test of the sharded search path (snickery_amd/dist.py) on CPU.
 The GPU engine is replaced by a stand-in built on the oracle; what is under test is the
-sharding arithmetic, the all-gather exchange, the merge rule and the utterance->rank
+sharding arithmetic, the all-gather / all-to-all exchanges, the merge rule and the utterance->rank
 assignment of the Viterbi."""
 import os
 import sys
@@ -52,6 +52,23 @@ class OracleShardEngine(object):
         import snk_oracle as o
         return o.viterbi(cand, d, self.E, self.S)
 
+    def knn_local_batch(self, utterances, K, d2_out, id_out):
+        r0 = 0
+        for U in utterances:
+            self.knn_local(U, K, d2_out[r0:r0 + U.shape[0]], id_out[r0:r0 + U.shape[0]])
+            r0 += U.shape[0]
+
+    def merge_viterbi_batch(self, d2_all, id_all, G, lengths, K):
+        R = sum(lengths)
+        cand, dd = self.merge(d2_all, id_all, G, R, K)
+        paths, costs, r0 = [], [], 0
+        for T in lengths:
+            p, c = self.viterbi(cand[r0:r0 + T], dd[r0:r0 + T])
+            paths.append(p)
+            costs.append(c)
+            r0 += T
+        return paths, costs
+
 
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
@@ -78,6 +95,11 @@ def _worker(rank, world, port, out):
         c, dd = o.knn_bruteforce(F, U, K)
         p, cost = o.viterbi(c, dd, E, S)
         ok = ok and list(paths[u]) == p and costs[u] == cost
+    # fewer utterances than ranks: the last rank owns nothing and still takes part in the exchange
+    paths1, costs1 = search.knn_viterbi_batch(utts[1:2], K)
+    c, dd = o.knn_bruteforce(F, utts[1], K)
+    p, cost = o.viterbi(c, dd, E, S)
+    ok = ok and len(paths1) == 1 and list(paths1[0]) == p and costs1[0] == cost
     out[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()

@@ -163,3 +163,47 @@ def test_config_b4_shape_two_shards_k200(engine):
     path, cost = engine.viterbi(cand, dist)
     opath, ocost = oc.viterbi(oc_cand, oc_dist, JCw)
     assert path == opath and cost == ocost
+
+
+def test_sharded_batch_pipeline_on_one_gpu(engine):
+    """The two device halves of ShardedSearch.knn_viterbi_batch with the exchange done by hand:
+    4 shard engines on this GPU produce their local lists for a ragged batch, the (G, R_own, K)
+    blocks an all-to-all would deliver are sliced out, and the owner-side merge + Viterbi must
+    reproduce the unsharded batch search exactly."""
+    import torch
+    import snickery_amd
+    from snickery_amd.dist import shard_bounds
+    N, Dt, Dj, K, G = 262144, 61, 151, 100, 4
+    F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=41)
+    wt = np.full(Dt, 0.4)
+    wj = np.full(Dj, 0.07)
+    utts = [o.synthetic_targets(F_unw, T, seed=50 + i) * wt for i, T in enumerate([300, 64, 411, 2, 150])]
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    ref_paths, ref_costs = engine.knn_viterbi_batch(utts, K)
+    lens = [u.shape[0] for u in utts]
+    R = sum(lens)
+    dev = torch.device('cuda', 0)
+    d2 = torch.empty(G, R, K, dtype=torch.float64, device=dev)
+    ids = torch.empty(G, R, K, dtype=torch.int64, device=dev)
+    fallbacks = 0
+    for r in range(G):
+        lo, hi = shard_bounds(N, G, r)
+        e = snickery_amd.HipSearchEngine(0)
+        e.upload_target_only(F_unw[lo:hi])
+        e.set_shard(lo, N)
+        e.set_weights(wt, None)
+        e.knn_local_batch_dev(utts, K, d2[r].data_ptr(), ids[r].data_ptr())
+        fallbacks += e.info('f16_fallbacks') + e.info('batch_redos')
+        e.close()
+    torch.cuda.synchronize()
+    assert fallbacks == 0                      # shard-sized databases keep the f32 prefilter path
+    # "rank" 1 of 2 owners: utterances 3..4; "rank" 0: utterances 0..2
+    for a, b in [(0, 3), (3, 5)]:
+        r0, r1 = sum(lens[:a]), sum(lens[:b])
+        d2_own = d2[:, r0:r1].contiguous()
+        id_own = ids[:, r0:r1].contiguous()
+        paths, costs = engine.merge_viterbi_batch_dev(d2_own.data_ptr(), id_own.data_ptr(), G, lens[a:b], K)
+        for j, u in enumerate(range(a, b)):
+            assert np.array_equal(paths[j], ref_paths[u]) and costs[j] == ref_costs[u]
+    assert len(ref_paths[3]) == 2

@@ -102,12 +102,14 @@ def test_knn_list_overflow_retry(engine):
     U = o.synthetic_targets(F_unw, 48, seed=8) * wt
     engine.set_option('list_capacity', 192)
     engine.set_option('sample_fraction', 1.0 / 64)
+    engine.set_option('precision', 0)          # the f64 sweep's own sampled thresholds
     try:
         cand, dist = engine.knn(U, 20)
         retries = engine.info('last_knn_retries')
     finally:
         engine.set_option('list_capacity', 4096)
         engine.set_option('sample_fraction', 1.0 / 16)
+        engine.set_option('precision', 1)
     oc, od = o.knn_bruteforce(F, U, 20)
     assert np.array_equal(cand, oc) and np.array_equal(dist, od)
     assert retries >= 1
@@ -209,6 +211,7 @@ def test_viterbi_batch_redo_on_overflow(engine):
     utts = [o.synthetic_targets(F_unw, T, seed=s) * wt for s, T in [(1, 33), (2, 48), (3, 20)]]
     engine.set_option('list_capacity', 192)
     engine.set_option('sample_fraction', 1.0 / 64)
+    engine.set_option('precision', 0)          # the f64 sweep's own sampled thresholds
     try:
         before = engine.info('batch_redos')
         paths, costs = engine.knn_viterbi_batch(utts, 20)
