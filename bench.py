@@ -9,8 +9,10 @@ workload B* of SURVEY.md 8d: |DB| = 1 048 576 units, Dt = 61, Dj = 302, T = 600,
 
 One "step" = one batch of --utts utterances (T frames each) through the whole hot path with
 the unit database already resident in HBM.  N > 1: the database is row-sharded over the ranks
-(strong scaling: database and batch are fixed), local top-K lists are all-gathered over RCCL,
-utterance u's Viterbi runs on rank u mod N.  Rank 0 prints ONE JSON line.
+(strong scaling: database and batch are fixed), every rank sweeps its shard for all rows of the
+batch, the local top-K lists travel by ONE all-to-all over RCCL to the rank that owns the utterance
+(contiguous blocks of utterances per rank), which merges them and runs join costs + Viterbi.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -159,7 +161,11 @@ def main():
         value = total_frames / elapsed
         ms, launches = timers['knn_filter']
         avg_ms = ms / max(launches, 1)
-        flops = 2.0 * T * n_local * Dt          # algorithmic: SURVEY 8d, per utterance, this rank's shard
+        # algorithmic flops: 2 * rows * N_local * Dt for the rows this rank swept; the
+        # batch entry points group utterances, so one filter launch covers rows_per_launch rows
+        rows_swept = frames_per_step * args.steps
+        rows_per_launch = rows_swept / max(launches, 1)
+        flops = 2.0 * rows_per_launch * n_local * Dt
         # HBM bytes per launch from the committed PMC passes (separate --pmc runs, FETCH_SIZE
         # doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for the profiled shape
         # which sweep did the filtering: the f32 prefilter (default; results are made exact by the
@@ -172,7 +178,9 @@ def main():
         tfile = os.path.join(ROOT, 'profiles', 'r01_traffic_f32.json' if f32_mode else 'r01_traffic.json')
         if world == 1 and N == 1048576 and Dt == 61 and os.path.isfile(tfile):
             with open(tfile) as f:
-                traffic = json.load(f)['hbm_bytes_per_launch']
+                tj = json.load(f)
+            if int(tj.get('rows_per_launch', 600)) == int(round(rows_per_launch)):
+                traffic = tj['hbm_bytes_per_launch']
         achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             'metric': 'synthesised frames/sec, full-DB K=%d K-NN preselection + Viterbi' % K,
@@ -184,13 +192,16 @@ def main():
                                    'T=%d frames x %d utterances per step, K=%d, search_epsilon=0'
                                    % (N, Dt, Dj, T, U, K),
                        'units': N, 'target_dim': Dt, 'join_dim': Dj, 'frames': T, 'utts_per_step': U,
-                       'n_candidates': K, 'sharding': 'db-rows/%d + all-gather top-K' % world if world > 1 else 'none'},
+                       'n_candidates': K, 'sharding': 'db-rows/%d + all-to-all of local top-K' % world if world > 1 else 'none'},
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic,
                          'avg_launch_ms': avg_ms, 'launches': launches,
-                         'flops_per_launch': flops},
-            'stages_ms_per_utt': dict((k, v[0] / max(v[1], 1)) for k, v in timers.items() if v[1]),
+                         'rows_per_launch': rows_per_launch, 'flops_per_launch': flops,
+                         'note': 'peak is the 2.4 GHz datasheet rate; under MFMA load this part holds '
+                                 '1.9-2.0 GHz (MI355X_MICROARCH.md, DVFS give-back)'},
+            'stages_ms_per_step': dict((k, v[0] / args.steps) for k, v in timers.items() if v[1]),
+            'stage_launches_per_step': dict((k, v[1] / args.steps) for k, v in timers.items() if v[1]),
         }
         if world == 1 and not args.no_cpu_baseline:
             base, ref = cpu_baseline(F_unw, JC_unw, wt, wj, K, args.cpu_sample_frames, seed=1)

@@ -264,26 +264,34 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
 #pragma unroll
                     for (int j = 0; j < CH; ++j)
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[st * CH + j][k], x[k], acc[j], 0, 0, 0);
-                    // one pending result per MFMA: 16*CH results over 32*CH MFMAs
-                    if (CH == 2 || (k & 1) == 1) {
-                        const int e = (CH == 2) ? k : (k >> 1);      // 0 .. 16*CH-1
-                        if (e < 16 * CH) {
-                            const int j = e / 16, r = e % 16;
-                            const float key = pacc[j][r];
-                            if (MODE == 0) gm = fminf(gm, key);
-                            else {
-                                const bool pass = key <= pth;
-                                const unsigned long long m = __ballot(pass);
-                                if (pass) {
-                                    const int rank = __builtin_amdgcn_mbcnt_hi(
-                                        (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                    PoolEntry16 en;
-                                    en.key = (double)key;
-                                    en.idx = (int)((w * NT + pnt + j) * 32 + crow32(lane, r));
-                                    en.row = pqt * 32 + qcol;
-                                    stage[wv][lcount + rank] = en;
+                    // the 16*CH pending results are tested four at a time in the MFMA shadows: one
+                    // min3/min + compare per group; the per-result ballots run only when some lane
+                    // of the group passes (a few entries per 32x32 tile do)
+                    if ((k & 3) == 3) {
+                        const int e0 = (CH == 2) ? (k - 3) : ((k - 7) >> 1);      // first result of the group
+                        if (e0 + 3 < 16 * CH && (CH == 2 || (k & 7) == 7)) {
+                            const int j = e0 / 16, r0 = e0 % 16;
+                            const float m4 = fminf(__builtin_fminf(__builtin_fminf(pacc[j][r0], pacc[j][r0 + 1]), pacc[j][r0 + 2]),
+                                                   pacc[j][r0 + 3]);
+                            if (MODE == 0) gm = fminf(gm, m4);
+                            else if (__any(m4 <= pth)) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int r = r0 + q;
+                                    const float key = pacc[j][r];
+                                    const bool pass = key <= pth;
+                                    const unsigned long long m = __ballot(pass);
+                                    if (pass) {
+                                        const int rank = __builtin_amdgcn_mbcnt_hi(
+                                            (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                        PoolEntry16 en;
+                                        en.key = (double)key;
+                                        en.idx = (int)((w * NT + pnt + j) * 32 + crow32(lane, r));
+                                        en.row = pqt * 32 + qcol;
+                                        stage[wv][lcount + rank] = en;
+                                    }
+                                    lcount += __popcll(m);
                                 }
-                                lcount += __popcll(m);
                             }
                         }
                     }

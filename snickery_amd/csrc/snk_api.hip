@@ -125,7 +125,7 @@ struct snk_engine {
     int timers_on = 1;
     int n_cus = 256;
     int reserved_cus = 2;
-    int batch_rows = 2400;     // rows per K-NN call of the batch entry points (utterances are grouped)
+    int batch_rows = 8192;     // rows per K-NN call of the batch entry points (utterances are grouped)
     int pool_chunks = 4096;    // entry pool: 4096 chunks x 2048 entries x 16 B = 128 MiB      // left free by the persistent K-NN sweep for Viterbi DP blocks
     int last_retries = 0;
     int tie_overflow = 0;

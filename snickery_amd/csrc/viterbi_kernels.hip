@@ -12,8 +12,9 @@
 //   naturally adjacent units must join at exactly 0.0 (E[a] == S[a+1] bit for bit), which a
 //   ||e||^2+||s||^2-2e.s form cannot guarantee.  Candidate rows are gathered from HBM in
 //   32-column chunks into LDS and each thread keeps an RT x RT block of pair accumulators.
-// viterbi_dp_kernel: one 1024-thread workgroup walks the trellis; the K x K slabs of the next
-//   2-4 steps are in flight into registers while the current step reduces, back-pointers stay in LDS.
+// viterbi_dp_kernel: one workgroup per utterance walks the trellis; the K x K slabs of the next
+//   steps are in flight into registers, the minimum over predecessors finishes inside the
+//   wavefront, back-pointers stay in LDS.
 #include "snk_internal.h"
 #include <float.h>
 
@@ -35,18 +36,19 @@ __device__ __forceinline__ void join_tile(const double *__restrict__ JCw, int Dj
 {
     constexpr int NRA = 8 * RTA, NRB = 8 * RTB;
     constexpr int DCP = DC + 1;
+    static_assert(DC == 16, "one wave-wide double2 load covers 8 rows x 16 columns");
     const int tid = threadIdx.x;
     for (int i = tid; i < NRA; i += 64) {
         const int64_t a = (a0 + i < K) ? cand[t * K + a0 + i] : -1;
         const bool va = unit_usable(a, n_units);
         okE[i] = va;
-        rowE[i] = va ? a + 1 : 0;      // unit_end_data[a]   = JCw[a+1]
+        rowE[i] = (va ? a + 1 : 0) * Djpad;    // unit_end_data[a]   = JCw[a+1]  (element offset)
     }
     for (int i = tid; i < NRB; i += 64) {
         const int64_t b = (b0 + i < K) ? cand[(t + 1) * K + b0 + i] : -1;
         const bool vb = unit_usable(b, n_units);
         okS[i] = vb;
-        rowS[i] = vb ? b : 0;          // unit_start_data[b] = JCw[b]
+        rowS[i] = (vb ? b : 0) * Djpad;        // unit_start_data[b] = JCw[b]
     }
     __syncthreads();
 
@@ -58,41 +60,28 @@ __device__ __forceinline__ void join_tile(const double *__restrict__ JCw, int Dj
         for (int j = 0; j < RTB; ++j) acc[i][j] = 0.0;
 
     // register-staged gather: the next column chunk's global loads are in flight while the
-    // current chunk is being accumulated (DC doubles = 128 contiguous bytes per row and chunk)
-    constexpr int PERA = (NRA * (DC / 2) + 63) / 64;     // double2 loads per lane
-    constexpr int PERB = (NRB * (DC / 2) + 63) / 64;
-    double2 pe[PERA], ps[PERB];
+    // current chunk is being accumulated (DC doubles = 128 contiguous bytes per row and chunk).
+    // Load k of a lane covers row 8k + lane/8, columns 2*(lane%8)..+1 of the chunk: RTA (RTB)
+    // unconditional, independent loads per lane and matrix.
+    const int lr = tid >> 3, lc = (tid & 7) * 2;
+    double2 pe[RTA], ps[RTB];
     auto fetch = [&](int c0) {
 #pragma unroll
-        for (int k = 0; k < PERA; ++k) {
-            const int e = tid + k * 64;
-            if (e < NRA * (DC / 2))
-                pe[k] = *reinterpret_cast<const double2 *>(JCw + rowE[e / (DC / 2)] * Djpad + c0 + (e % (DC / 2)) * 2);
-        }
+        for (int k = 0; k < RTA; ++k)
+            pe[k] = *reinterpret_cast<const double2 *>(JCw + rowE[8 * k + lr] + c0 + lc);
 #pragma unroll
-        for (int k = 0; k < PERB; ++k) {
-            const int e = tid + k * 64;
-            if (e < NRB * (DC / 2))
-                ps[k] = *reinterpret_cast<const double2 *>(JCw + rowS[e / (DC / 2)] * Djpad + c0 + (e % (DC / 2)) * 2);
-        }
+        for (int k = 0; k < RTB; ++k)
+            ps[k] = *reinterpret_cast<const double2 *>(JCw + rowS[8 * k + lr] + c0 + lc);
     };
     fetch(0);
     for (int c0 = 0; c0 < Djpad; c0 += DC) {
 #pragma unroll
-        for (int k = 0; k < PERA; ++k) {
-            const int e = tid + k * 64;
-            if (e < NRA * (DC / 2)) {
-                const int r = e / (DC / 2), c = (e % (DC / 2)) * 2;
-                Es[r * DCP + c] = pe[k].x; Es[r * DCP + c + 1] = pe[k].y;
-            }
+        for (int k = 0; k < RTA; ++k) {
+            Es[(8 * k + lr) * DCP + lc] = pe[k].x; Es[(8 * k + lr) * DCP + lc + 1] = pe[k].y;
         }
 #pragma unroll
-        for (int k = 0; k < PERB; ++k) {
-            const int e = tid + k * 64;
-            if (e < NRB * (DC / 2)) {
-                const int r = e / (DC / 2), c = (e % (DC / 2)) * 2;
-                Ss[r * DCP + c] = ps[k].x; Ss[r * DCP + c + 1] = ps[k].y;
-            }
+        for (int k = 0; k < RTB; ++k) {
+            Ss[(8 * k + lr) * DCP + lc] = ps[k].x; Ss[(8 * k + lr) * DCP + lc + 1] = ps[k].y;
         }
         __syncthreads();
         if (c0 + DC < Djpad) fetch(c0 + DC);
@@ -188,26 +177,27 @@ void launch_join_costs(const double *JCw, int Djpad, int /*Dj*/, int64_t n_units
 // Viterbi:  delta_0[k] = tdist[0,k]
 //           delta_t[k] = tdist[t,k] + min_k' ( delta_{t-1}[k'] + J[t-1,k',k] )
 // ties: lowest k', then lowest final k  (oracle/snk_oracle.py: viterbi)
+//
+// One workgroup per utterance, ceil(K/16) wavefronts.  A wavefront owns 16 columns k; its four
+// 16-lane rows split the predecessors: row p takes k' in [p*KPM, (p+1)*KPM).  So the minimum over
+// k' finishes with two cross-row exchanges inside the wavefront, and a step costs ONE barrier
+// (delta is double-buffered in LDS).  Every thread keeps its KPM slab entries of the next NB steps
+// in flight in registers: a single workgroup pulls 8*K*K bytes per step through one CU, and without
+// several slabs in flight every step would pay a full memory round trip.  Slabs are read with
+// buffer loads (one VGPR offset per thread, the slab/row part in an SGPR).  Predecessors k' >= K
+// need no predicate: their delta stays +inf and an out-of-range buffer load returns 0.
 // ---------------------------------------------------------------------------
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// PD > 0: each thread owns KPM predecessors of its column (part p: kp in [p*KPM, (p+1)*KPM)) and
-//         keeps the K x K slabs of the next PD steps in flight in registers: a single workgroup
-//         pulls 8*K*K bytes per step through one CU, and without several slabs in flight every
-//         step pays a full HBM round trip.  Slabs are read with buffer loads (one VGPR offset per
-//         thread, the slab/row part in an SGPR).  Predecessors kp >= K need no predicate: their
-//         delta stays +inf and an out-of-range buffer load returns 0.
-// PD = 0: larger K, predecessors are read from L2 inside the step
-template <int KPM, int PD, int NTH, bool BPL>
+template <int KPM, int NB, int NTH, bool BPL>
 __global__ void __launch_bounds__(NTH)
 viterbi_dp_kernel(const int64_t *__restrict__ cand_all, const double *__restrict__ tdist_all,
                   const double *__restrict__ J_all, const DpBatch batch, int K, int64_t n_units, int KP,
-                  int parts, int kpp, unsigned char *__restrict__ bp_all,
-                  int64_t *__restrict__ path_all, int64_t *__restrict__ path_len_all,
-                  double *__restrict__ cost_all)
+                  unsigned char *__restrict__ bp_all, int64_t *__restrict__ path_all,
+                  int64_t *__restrict__ path_len_all, double *__restrict__ cost_all)
 {
-    // one workgroup per utterance of the launch: rows [off[u], off[u+1]) of the group's matrices;
-    // J row r holds the costs between rows r and r+1 (the row joining two utterances is unused)
+    // rows [off[u], off[u+1]) of the group's matrices; J row r holds the costs between rows r and
+    // r+1 (the row joining two utterances is unused)
     const int64_t r0 = batch.off[blockIdx.x];
     const int64_t T = batch.off[blockIdx.x + 1] - r0;
     const int64_t *__restrict__ cand = cand_all + r0 * K;
@@ -217,62 +207,57 @@ viterbi_dp_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
     int64_t *__restrict__ path = path_all + r0;
     int64_t *__restrict__ path_len = path_len_all + batch.first + blockIdx.x;
     double *__restrict__ cost = cost_all + batch.first + blockIdx.x;
+
     extern __shared__ __align__(16) unsigned char smem[];
-    double *delta = reinterpret_cast<double *>(smem);              // [KP]
-    double *pval = delta + KP;                                     // [parts][KP]
-    int *parg = reinterpret_cast<int *>(pval + (size_t)parts * KP);// [parts][KP]
-    // back-pointers [T][K]: in LDS when they fit, else in global memory.  Two typed pointers, not
-    // one generic one: a flat store would make every later wait a full vmcnt(0)/lgkmcnt(0).
-    unsigned char *bp_lds = reinterpret_cast<unsigned char *>(parg + (size_t)parts * KP);
+    double *delta = reinterpret_cast<double *>(smem);              // [2][KP], KP >= 4*KPM
+    // back-pointers [T][K]: in LDS when they fit, else in global memory (two typed pointers: a
+    // flat store would turn every later wait into a full vmcnt(0)/lgkmcnt(0))
+    unsigned char *bp_lds = reinterpret_cast<unsigned char *>(delta + 2 * KP);
     __shared__ int final_slot;
-    constexpr bool PF = PD > 0;
-    constexpr int NB = PF ? PD : 1;
 
     const int tid = threadIdx.x;
-    const int k = tid % KP, part = tid / KP;
-    const bool active = (k < K) && (part < parts);
-    const int kp0 = part * kpp;
+    const int lane = tid & 63;
+    const int k = (tid >> 6) * 16 + (lane & 15);
+    const int part = lane >> 4;
+    const int kp0 = part * KPM;
+    const bool col = k < K;
+    const bool lead = col && part == 0;
     const double inf = __builtin_inf();
 
     if (T < 2) {                      // the reference's J has no states for T < 2
         if (tid == 0) { *path_len = 0; *cost = inf; }
         return;
     }
-    // target cost of column t with unusable candidates folded in as +inf (inf + x == inf)
-    auto target_cost = [&](int64_t t) -> double {
-        return unit_usable(cand[t * K + k], n_units) ? tdist[t * K + k] : inf;
-    };
-    if (part == 0) delta[k] = (k < K) ? target_cost(0) : inf;
+    for (int i = tid; i < 2 * KP; i += (int)blockDim.x) delta[i] = inf;
+    __syncthreads();
+    if (lead) delta[k] = unit_usable(cand[k], n_units) ? tdist[k] : inf;
 
-    const __amdgpu_buffer_rsrc_t jres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double *>(J), 0, (int)((T - 1) * K * K * 8), 0x00020000);
-    // idle threads (k >= K) run the same convergent code with an out-of-range offset: their
-    // loads return 0 without touching memory and their results are never stored
-    const int voff = active ? (kp0 * K + k) * 8 : 0x7ffffff8;
+    // idle columns (k >= K) run the same convergent code with an out-of-range offset: their loads
+    // return 0 without touching memory and their results are never stored
+    const int voff = col ? (kp0 * K + k) * 8 : 0x7ffffff8;
     double jb[NB][KPM];
     auto load_slab = [&](int64_t slab, double (&dst)[KPM]) {       // slab t-1 feeds step t
-        const int sbase = (int)(slab * K * K * 8);
+        // one descriptor per slab (scalar arithmetic): offsets stay 32-bit for any T
+        const __amdgpu_buffer_rsrc_t jres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double *>(J + slab * K * K), 0, K * K * 8, 0x00020000);
 #pragma unroll
         for (int i = 0; i < KPM; ++i)
-            dst[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(jres, voff, sbase + i * K * 8, 0));
+            dst[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(jres, voff, i * K * 8, 0));
     };
     // target cost and candidate id of the column NB steps ahead: plain independent loads staged
-    // like the slabs and combined at the point of use (a dependent load here would force vmcnt(0) and drain
-    // the slab pipeline every step)
+    // like the slabs and combined at the point of use (a dependent load would force vmcnt(0) and
+    // drain the slab pipeline every step)
     double td_raw[NB];
     int64_t id_raw[NB];
-    const bool lead = active && part == 0;
     auto load_target = [&](int64_t t, double &td, int64_t &id) {
-        const int64_t tn = (t < T ? t : T - 1) * K + (lead ? k : 0);
+        const int64_t tn = (t < T ? t : T - 1) * K + (col ? k : 0);
         td = tdist[tn];
         id = cand[tn];
     };
-    if (PF) {
 #pragma unroll
-        for (int s = 0; s < NB; ++s) {
-            load_slab(s < T - 2 ? s : T - 2, jb[s]);
-            load_target(1 + s, td_raw[s], id_raw[s]);
-        }
+    for (int s = 0; s < NB; ++s) {
+        load_slab(s < T - 2 ? s : T - 2, jb[s]);
+        load_target(1 + s, td_raw[s], id_raw[s]);
     }
     __syncthreads();
 
@@ -282,42 +267,28 @@ viterbi_dp_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
     // run with their stores switched off.
     auto step = [&](int64_t t, double (&jr)[KPM], double &tdr, int64_t &idr) {
         const bool valid = t < T;                       // uniform
+        const double *dprev = delta + ((t - 1) & 1) * KP;
+        double *dcur = delta + (t & 1) * KP;
+        const double td = unit_usable(idr, n_units) ? tdr : inf;
+        load_target(t + NB, tdr, idr);
         double best = inf;
         int arg = 0;
-        double td = inf;
-        if (PF) {
-            td = unit_usable(idr, n_units) ? tdr : inf;
-            load_target(t + NB, tdr, idr);
 #pragma unroll
-            for (int i = 0; i < KPM; ++i) {
-                const double tot = __dadd_rn(delta[kp0 + i], jr[i]);
-                if (tot < best) { best = tot; arg = i; }
-            }
-            arg += kp0;
-            load_slab(t - 1 + NB < T - 2 ? t - 1 + NB : T - 2, jr);
-        } else if (active) {
-            if (part == 0) td = target_cost(t);
-            arg = kp0;
-            const double *Jt = J + (t - 1) * K * K;
-            for (int i = 0; i < kpp; ++i) {
-                const int kp = kp0 + i;
-                if (kp < K) {
-                    const double tot = __dadd_rn(delta[kp], Jt[(int64_t)kp * K + k]);
-                    if (tot < best) { best = tot; arg = kp; }
-                }
-            }
+        for (int i = 0; i < KPM; ++i) {
+            const double tot = __dadd_rn(dprev[kp0 + i], jr[i]);
+            if (tot < best) { best = tot; arg = i; }
         }
-        if (active) {
-            pval[part * KP + k] = best;
-            parg[part * KP + k] = arg;
+        arg += kp0;
+        load_slab(t - 1 + NB < T - 2 ? t - 1 + NB : T - 2, jr);
+        // minimum over the four predecessor ranges (lane rows); equal values keep the lower k'
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) {
+            const double ob = __shfl_xor(best, m, 64);
+            const int oa = __shfl_xor(arg, m, 64);
+            if (ob < best || (ob == best && oa < arg)) { best = ob; arg = oa; }
         }
-        __syncthreads();
         if (lead && valid) {
-            for (int p = 1; p < parts; ++p) {
-                const double v = pval[p * KP + k];
-                if (v < best) { best = v; arg = parg[p * KP + k]; }
-            }
-            delta[k] = __dadd_rn(td, best);
+            dcur[k] = __dadd_rn(td, best);
             if constexpr (BPL) bp_lds[t * K + k] = (unsigned char)arg;
             else bp_global[t * K + k] = (unsigned char)arg;
         }
@@ -329,11 +300,12 @@ viterbi_dp_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
         for (int s = 0; s < NB; ++s) step(t + s, jb[s], td_raw[s], id_raw[s]);
     }
 
+    const double *dlast = delta + ((T - 1) & 1) * KP;
     if (tid == 0) {
         double best = inf;
         int slot = 0;
         for (int kk = 0; kk < K; ++kk)
-            if (delta[kk] < best) { best = delta[kk]; slot = kk; }
+            if (dlast[kk] < best) { best = dlast[kk]; slot = kk; }
         if (best == inf) { *path_len = 0; *cost = inf; final_slot = -1; }
         else { *path_len = T; *cost = best; final_slot = slot; }
     }
@@ -357,49 +329,46 @@ void launch_viterbi_dp_batch(const int64_t *cand, const double *tdist, const dou
                              int n_utts, int first_utt, int K, int64_t n_units, unsigned char *bp_global,
                              int64_t *path, int64_t *path_len, double *cost, hipStream_t s)
 {
-    int KP = 64;
-    while (KP < K) KP <<= 1;                // K <= 256
     for (int u0 = 0; u0 < n_utts; u0 += DpBatch::MAX) {
         const int n = (n_utts - u0 < DpBatch::MAX) ? n_utts - u0 : DpBatch::MAX;
         DpBatch batch;
-        int64_t Tmax = 0;
+        int64_t T = 0;
         for (int i = 0; i <= n; ++i) batch.off[i] = off[u0 + i];
-        for (int i = 0; i < n; ++i) Tmax = (off[u0 + i + 1] - off[u0 + i] > Tmax) ? off[u0 + i + 1] - off[u0 + i] : Tmax;
+        for (int i = 0; i < n; ++i) T = (off[u0 + i + 1] - off[u0 + i] > T) ? off[u0 + i + 1] - off[u0 + i] : T;
         batch.first = first_utt + u0;
-        const int64_t T = Tmax;
-        // K <= 64: 1024 threads, 16 column parts; K <= 128: 512 threads (256 registers per thread hold
-        // 3 slabs in flight); larger K: 1024 threads, predecessors read inside the step
-        const bool fits = (double)(T - 1) * K * K * 8.0 < 2147483648.0;      // 32-bit buffer offsets
-        const int nth = (KP == 128 && fits) ? 512 : 1024;
-        const int parts = nth / KP;
-        int kpp = (K + parts - 1) / parts;
-        int variant = 0;
-        if (fits && KP == 64) { variant = 1; kpp = 4; }
-        else if (fits && KP == 128 && kpp <= 25) { variant = 2; kpp = 25; }
-        else if (fits && KP == 128) { variant = 3; kpp = 32; }
-        const size_t base = (size_t)KP * 8 + (size_t)parts * KP * 12;
+        // K <= 64: 4 x 16 predecessors, 4 slabs in flight; K <= 100: 4 x 25, 3 slabs; K <= 128:
+        // 4 x 32, 3 slabs; K <= 208: 4 x 52 -- 13 wavefronts leave 128 registers per thread, which
+        // hold a single slab
+        int variant, kpm;
+        if (K <= 64) { variant = 0; kpm = 16; }
+        else if (K <= 100) { variant = 1; kpm = 25; }
+        else if (K <= 128) { variant = 2; kpm = 32; }
+        else { variant = 3; kpm = 52; }
+        const int KP = 4 * kpm;
+        const int nth = 64 * ((K + 15) / 16);
+        const size_t base = (size_t)2 * KP * 8;
         const size_t bp_bytes = (size_t)T * K;
         const int bp_in_lds = (base + bp_bytes + 64 <= 150 * 1024) ? 1 : 0;
         const size_t shmem = base + (bp_in_lds ? bp_bytes : 0);
-#define SNK_DP1(KPM_, PD_, NTH_, BPL_)                                                             \
+#define SNK_DP1(KPM_, NB_, NTH_, BPL_)                                                             \
     {                                                                                              \
         static bool attr_set = false;                                                              \
         if (!attr_set) {                                                                           \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&viterbi_dp_kernel<KPM_, PD_, NTH_, BPL_>), \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&viterbi_dp_kernel<KPM_, NB_, NTH_, BPL_>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));    \
             attr_set = true;                                                                       \
         }                                                                                          \
-        hipLaunchKernelGGL((viterbi_dp_kernel<KPM_, PD_, NTH_, BPL_>), dim3(n), dim3(NTH_), shmem, s, cand, \
-                           tdist, J, batch, K, n_units, KP, parts, kpp, bp_global, path, path_len, cost); \
+        hipLaunchKernelGGL((viterbi_dp_kernel<KPM_, NB_, NTH_, BPL_>), dim3(n), dim3(nth), shmem, s, cand, \
+                           tdist, J, batch, K, n_units, KP, bp_global, path, path_len, cost);      \
     }
-#define SNK_DP(KPM_, PD_, NTH_)                                                                    \
+#define SNK_DP(KPM_, NB_, NTH_)                                                                    \
     {                                                                                              \
-        if (bp_in_lds) SNK_DP1(KPM_, PD_, NTH_, true) else SNK_DP1(KPM_, PD_, NTH_, false)         \
+        if (bp_in_lds) SNK_DP1(KPM_, NB_, NTH_, true) else SNK_DP1(KPM_, NB_, NTH_, false)         \
     }
-        if (variant == 1) SNK_DP(4, 4, 1024)
-        else if (variant == 2) SNK_DP(25, 3, 512)
-        else if (variant == 3) SNK_DP(32, 3, 512)
-        else SNK_DP(1, 0, 1024)
+        if (variant == 0) SNK_DP(16, 4, 256)
+        else if (variant == 1) SNK_DP(25, 3, 448)
+        else if (variant == 2) SNK_DP(32, 3, 512)
+        else SNK_DP(52, 1, 832)
 #undef SNK_DP1
 #undef SNK_DP
     }
