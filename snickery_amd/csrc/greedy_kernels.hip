@@ -10,6 +10,7 @@
 // The windowed database is never materialised (the reference hstacks an (N-me+1) x 517 float64
 // copy, 4.1 GB at N = 1 M): window i reads rows i..i+me-1 of the UNWEIGHTED float32 feature
 // matrix and row i of the unweighted join matrix exactly as the HDF5 file stores them, and
+// (rows padded to a multiple of 4 floats on the device, so every access is 16 bytes wide) and
 // applies the float64 stream weights on the fly (fl64(f32 * w) is bit-identical to the
 // reference's speech_manip.weight()).  Every step is therefore a pure HBM-bandwidth-bound
 // stream over (Dj + Dt) * 4 bytes per unit.  Squared distances are accumulated in the canonical
@@ -22,98 +23,120 @@
 namespace snk {
 
 #define GR_R 256          // windows per workgroup (one thread per window)
-#define GR_CC 32          // columns per staged chunk
+#define GR_CC 32          // columns per staged chunk (8 float4 per row)
+#define GR_LP 36          // LDS row pitch in floats: 16-byte aligned rows, conflict-free 128-bit access
 #define GR_MAX_EP 16      // max multiepoch
+#define GR_S1 256          // arrival counters of the first / second level (see greedy_finish_step)
+#define GR_S2 16
 
 struct GreedyArgs {
-    const float *JC_unw; int Dj; const double *wj;
-    const float *F_unw; int Dt; const double *wt;
+    const float *JC_unw; int Jp, Dj; const double *wj;   // Jp / Fp: row pitch in floats (multiple of 4,
+    const float *F_unw; int Fp, Dt; const double *wt;    // zero-filled padding columns)
     int me, nep; int ep[GR_MAX_EP];       // epochs of the window that enter the target term
     int prev_col0, cur_col0, jdim;
     int64_t prev_row0, cur_row0, Nwin;
     int64_t n_jc_rows, n_f_rows;          // matrix heights (clamp for the ragged last workgroup)
     const double *Q;                      // (T, Dt) weighted targets, row-major
-    double *prev_vec;                     // (jdim): read by every block, rewritten by the last one
 };
 
-// One step of the greedy search = ONE launch:
-//   every workgroup scans GR_R consecutive windows (thread t owns window i0+t): the join columns
-//   and then, epoch by epoch, the target columns stream through LDS in 32-column chunks
-//   (coalesced loads: a wave instruction reads 32 consecutive floats of two rows), register-staged
-//   one chunk ahead; thread t accumulates its window's squared distance in the canonical column
-//   order.  The workgroup's (min, argmin) goes to global memory; the workgroup that arrives LAST
-//   (agent-scope release/acquire around an arrival counter) reduces all partial results, appends
-//   the winner to the path and fetches its `current_join_rep` row as the next step's `prev`.
-__global__ void __launch_bounds__(GR_R)
-greedy_step_kernel(GreedyArgs a, int64_t step, double *__restrict__ blk_min, int64_t *__restrict__ blk_arg,
-                   unsigned int *__restrict__ arrive, int64_t *__restrict__ path, double *__restrict__ dist)
-{
-    __shared__ float buf[2][GR_R][GR_CC + 1];
-    __shared__ double ref[GR_CC], wgt[GR_CC];
-    __shared__ double red_v[GR_R];
-    __shared__ int64_t red_i[GR_R];
-    __shared__ int is_last;
-    const int tid = threadIdx.x;
-    const int64_t i0 = (int64_t)blockIdx.x * GR_R;
+__device__ __forceinline__ int greedy_join_chunks(const GreedyArgs &a) { return (a.jdim + GR_CC - 1) / GR_CC; }
+__device__ __forceinline__ int greedy_target_chunks(const GreedyArgs &a) { return (a.Dt + GR_CC - 1) / GR_CC; }
 
-    // chunk schedule: part 0 = join columns, parts 1..nep = target columns of epoch ep[k]
-    const int jch = (a.jdim + GR_CC - 1) / GR_CC, tch = (a.Dt + GR_CC - 1) / GR_CC;
-    const int n_chunks = jch + a.nep * tch;
-    auto chunk_info = [&](int c, const float *&base, int &pitch, int64_t &row0, int64_t &nrows, int &col0,
-                          int &ncols, const double *&w, const double *&rf) {
+// The (weight, reference) pair of every column of the scan in chunk order -- join columns against
+// `prev`, then the target columns of each epoch against the query rows of this step -- padded with
+// (0, 0) to whole chunks.  Built by one workgroup for the NEXT step; the scan stages it in LDS and reads it with
+// 16-byte LDS broadcasts.
+// prev_row < 0: prev = 0 (np.zeros, synth_simple.py:467-468).
+__device__ void greedy_write_table(const GreedyArgs &a, int64_t step, int64_t prev_row, bool prev_is_current,
+                                   double *__restrict__ tab, int tid, int nthreads)
+{
+    const int jch = greedy_join_chunks(a), tch = greedy_target_chunks(a);
+    const int n = (jch + a.nep * tch) * GR_CC;
+    for (int e = tid; e < n; e += nthreads) {
+        const int c = e / GR_CC, cc = e % GR_CC;
+        double w = 0.0, ref = 0.0;
         if (c < jch) {
-            base = a.JC_unw; pitch = a.Dj; row0 = a.prev_row0 + i0; nrows = a.n_jc_rows;
-            col0 = a.prev_col0 + c * GR_CC; ncols = min(GR_CC, a.jdim - c * GR_CC);
-            w = a.wj + col0; rf = a.prev_vec + c * GR_CC;
+            const int col = c * GR_CC + cc;
+            if (col < a.jdim) {
+                w = a.wj[a.prev_col0 + col];
+                if (prev_row >= 0) {
+                    // prev_join_vector = current_join_rep[ix] (synth_simple.py:501) or prev_join_rep[start]
+                    const int col0 = prev_is_current ? a.cur_col0 : a.prev_col0;
+                    const int64_t row0 = prev_is_current ? a.cur_row0 : a.prev_row0;
+                    ref = __dmul_rn((double)a.JC_unw[(row0 + prev_row) * a.Jp + col0 + col], a.wj[col0 + col]);
+                }
+            }
         } else {
-            const int k = (c - jch) / tch, cc = (c - jch) % tch;
-            base = a.F_unw; pitch = a.Dt; row0 = i0 + a.ep[k]; nrows = a.n_f_rows;
-            col0 = cc * GR_CC; ncols = min(GR_CC, a.Dt - cc * GR_CC);
-            w = a.wt + col0; rf = a.Q + (step * a.me + a.ep[k]) * a.Dt + col0;
+            const int k = (c - jch) / tch, col = ((c - jch) % tch) * GR_CC + cc;
+            if (col < a.Dt) {
+                w = a.wt[col];
+                ref = a.Q[(step * a.me + a.ep[k]) * a.Dt + col];
+            }
         }
-    };
-    float stage[GR_CC];      // this thread's share of the next chunk
-    auto fetch = [&](int c) {
-        const float *base; int pitch, col0, ncols; int64_t row0, nrows; const double *w, *rf;
-        chunk_info(c, base, pitch, row0, nrows, col0, ncols, w, rf);
-#pragma unroll
-        for (int j = 0; j < GR_CC; ++j) {
-            const int e = tid + j * GR_R;             // lanes -> consecutive columns of a row
-            const int r = e / GR_CC, cc = e % GR_CC;
-            int64_t row = row0 + r;
-            if (row >= nrows) row = nrows - 1;
-            stage[j] = (cc < ncols) ? base[row * pitch + col0 + cc] : 0.0f;
-        }
-    };
-    double acc_j = 0.0, acc_t = 0.0;
-    fetch(0);
-    for (int c = 0; c < n_chunks; ++c) {
-        const float *base; int pitch, col0, ncols; int64_t row0, nrows; const double *w, *rf;
-        chunk_info(c, base, pitch, row0, nrows, col0, ncols, w, rf);
-        float (*B)[GR_CC + 1] = buf[c & 1];
-#pragma unroll
-        for (int j = 0; j < GR_CC; ++j) {
-            const int e = tid + j * GR_R;
-            B[e / GR_CC][e % GR_CC] = stage[j];
-        }
-        if (tid < GR_CC) {
-            ref[tid] = (tid < ncols) ? rf[tid] : 0.0;
-            wgt[tid] = (tid < ncols) ? w[tid] : 0.0;
-        }
-        __syncthreads();
-        if (c + 1 < n_chunks) fetch(c + 1);           // in flight while this chunk is accumulated
-        double acc = (c < jch) ? acc_j : acc_t;
-        for (int cc = 0; cc < ncols; ++cc) {
-            const double v = __dmul_rn((double)B[tid][cc], wgt[cc]);
-            const double d = __dsub_rn(v, ref[cc]);
-            acc = __dadd_rn(acc, __dmul_rn(d, d));
-        }
-        if (c < jch) acc_j = acc; else acc_t = acc;
-        __syncthreads();
+        tab[2 * e] = w;
+        tab[2 * e + 1] = ref;
     }
-    double best = DBL_MAX;
-    int64_t arg = INT64_MAX;
-    if (i0 + tid < a.Nwin) { best = __dadd_rn(acc_j, acc_t); arg = i0 + tid; }
+}
+
+// acc += sum over the 32 columns of a chunk of (fl64(x) * w - ref)^2, in the canonical column order
+// with separately rounded operations.  `row` is the window's row of the chunk in LDS, `tc` the
+// chunk's (w, ref) pairs in LDS (read as 16-byte broadcasts).  Eight columns are in flight at a
+// time: their conversions, products and squares are independent, only the eight final additions
+// form a chain -- written out that way so that neither LDS latency nor the latency of dependent
+// float64 operations is exposed when a SIMD holds a single wavefront.
+__device__ __forceinline__ double greedy_accumulate_chunk(const float *row, const double *__restrict__ tc, double acc)
+{
+    // `tc`: the chunk's 32 (w, ref) pairs in GLOBAL memory at a wave-uniform address: scalar loads
+    // into SGPRs (no LDS bandwidth, no vector registers), requested one group of eight columns ahead
+    struct Group { float4 x0, x1; double w[8], r[8]; };
+    auto load = [&](int g, Group &G) {
+        G.x0 = *reinterpret_cast<const float4 *>(row + 8 * g);
+        G.x1 = *reinterpret_cast<const float4 *>(row + 8 * g + 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { G.w[i] = tc[2 * (8 * g + i)]; G.r[i] = tc[2 * (8 * g + i) + 1]; }
+    };
+    auto consume = [&](const Group &G) {
+        const float xs[8] = {G.x0.x, G.x0.y, G.x0.z, G.x0.w, G.x1.x, G.x1.y, G.x1.z, G.x1.w};
+        double sq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double d = __dsub_rn(__dmul_rn((double)xs[i], G.w[i]), G.r[i]);
+            sq[i] = __dmul_rn(d, d);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = __dadd_rn(acc, sq[i]);     // padded columns: w = ref = 0 adds +0.0
+    };
+    // the loads of group g+1 are issued (and pinned there) before group g is consumed
+    Group A, B;
+    load(0, A);
+    __builtin_amdgcn_sched_barrier(0);
+    load(1, B);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(A);
+    __builtin_amdgcn_sched_barrier(0);
+    load(2, A);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(B);
+    __builtin_amdgcn_sched_barrier(0);
+    load(3, B);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(A);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(B);
+    return acc;
+}
+
+// Tail of a step, shared by both scan kernels: workgroup (min, argmin) -> global memory; the
+// workgroup that arrives LAST (sc1 stores drained before an arrival counter, sc1 loads after) reduces all
+// partial results, appends the winner to the path and writes the next step's table (its
+// `current_join_rep` row is the next `prev`).
+__device__ void greedy_finish_step(const GreedyArgs &a, int64_t step, int64_t nsteps, double best, int64_t arg,
+                                   double *__restrict__ tab_next, double *__restrict__ blk_min,
+                                   int64_t *__restrict__ blk_arg, unsigned int *__restrict__ arrive,
+                                   int64_t *__restrict__ path, double *__restrict__ dist,
+                                   double *red_v, int64_t *red_i, int *is_last_p)
+{
+    const int tid = threadIdx.x;
     red_v[tid] = best; red_i[tid] = arg;
     __syncthreads();
     for (int off = GR_R / 2; off > 0; off >>= 1) {
@@ -125,21 +148,30 @@ greedy_step_kernel(GreedyArgs a, int64_t step, double *__restrict__ blk_min, int
         __syncthreads();
     }
     if (tid == 0) {
-        blk_min[blockIdx.x] = red_v[0];
-        blk_arg[blockIdx.x] = red_i[0];
-        // publish, then arrive (MI355X guide G16: agent-scope release before the counter)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // publish, then arrive.  The 16 handed-off bytes are written with sc1 (agent-scope) stores,
+        // drained before the counter add, and read back with sc1 loads by the last workgroup: no
+        // release/acquire fence.  (A release fence per workgroup writes back the XCD's L2 and
+        // serialises at ~1.2 us per workgroup and XCD: 1 ms per step at 5 860 workgroups, measured.)
+        __hip_atomic_store(&blk_min[blockIdx.x], red_v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&blk_arg[blockIdx.x], red_i[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int t = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (t == gridDim.x - 1);
-        if (is_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Arrival tree: 256 -> 16 -> 1 monotonic counters, each on its own 128-byte line (one counter
+        // for all workgroups serialises at ~0.1 us per add: 0.6 ms per step at 5 860 workgroups,
+        // measured).  A workgroup climbs a level only when its add completes the counter's quota.
+        const unsigned int nb = gridDim.x, b = blockIdx.x, round = (unsigned int)step + 1u;
+        const unsigned int S1 = nb < GR_S1 ? nb : GR_S1, s1 = b % S1, q1 = (nb - s1 + S1 - 1) / S1;
+        bool last = false;
+        if (__hip_atomic_fetch_add(arrive + 32 * s1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == round * q1 - 1) {
+            const unsigned int S2 = S1 < GR_S2 ? S1 : GR_S2, s2 = s1 % S2, q2 = (S1 - s2 + S2 - 1) / S2;
+            if (__hip_atomic_fetch_add(arrive + 32 * (GR_S1 + s2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == round * q2 - 1)
+                last = __hip_atomic_fetch_add(arrive + 32 * (GR_S1 + GR_S2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       == round * S2 - 1;
         }
+        *is_last_p = last;
     }
     __syncthreads();
-    if (!is_last) return;
-    // ---- last workgroup: global argmin (lowest index on exact ties), path, next prev ----
+    if (!*is_last_p) return;
+    // ---- last workgroup: global argmin (lowest index on exact ties), path, next step's table ----
     best = DBL_MAX; arg = INT64_MAX;
     for (int b = tid; b < (int)gridDim.x; b += GR_R) {
         const double v = __hip_atomic_load(&blk_min[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -160,30 +192,85 @@ greedy_step_kernel(GreedyArgs a, int64_t step, double *__restrict__ blk_min, int
     if (tid == 0) {
         path[step] = ix;
         if (dist) dist[step] = __dsqrt_rn(red_v[0]);
-        *arrive = 0;                                   // re-armed for the next step (next launch)
     }
-    // prev_join_vector = current_join_rep[ix]   (synth_simple.py:501)
-    const float *src = a.JC_unw + (a.cur_row0 + ix) * a.Dj + a.cur_col0;
-    for (int c = tid; c < a.jdim; c += GR_R)
-        a.prev_vec[c] = __dmul_rn((double)src[c], a.wj[a.cur_col0 + c]);
+    if (step + 1 < nsteps) greedy_write_table(a, step + 1, ix, true, tab_next, tid, GR_R);
 }
 
-__global__ void greedy_init_prev_kernel(GreedyArgs a, int64_t start_state, unsigned int *arrive)
+// One step of the greedy search = ONE launch:
+//   every workgroup scans GR_R consecutive windows (thread t owns window i0+t): the join columns
+//   and then, epoch by epoch, the target columns stream through LDS in 32-column chunks with
+//   16-byte global loads, LDS writes and LDS reads (rows are padded to a multiple of 4 floats on
+//   the device), register-staged one chunk ahead; thread t accumulates its window's squared
+//   distance in the canonical column order, weights and references coming from the step's table.
+//   The workgroup's (min, argmin) goes to global memory; the workgroup that arrives LAST
+//   (sc1 stores / an arrival counter / sc1 loads) reduces all partial results, appends
+//   the winner to the path and writes the next step's table (its `current_join_rep` row is the
+//   next `prev`).
+__global__ void __launch_bounds__(GR_R)
+greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__restrict__ tab,
+                   double *__restrict__ tab_next, double *__restrict__ blk_min, int64_t *__restrict__ blk_arg,
+                   unsigned int *__restrict__ arrive, int64_t *__restrict__ path, double *__restrict__ dist)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0) *arrive = 0;
-    if (c >= a.jdim) return;
-    if (start_state < 0) { a.prev_vec[c] = 0.0; return; }     // np.zeros((n,)) synth_simple.py:467-468
-    const float *src = a.JC_unw + (a.prev_row0 + start_state) * a.Dj + a.prev_col0;
-    a.prev_vec[c] = __dmul_rn((double)src[c], a.wj[a.prev_col0 + c]);
+    __shared__ __align__(16) float buf[2][GR_R][GR_LP];
+    __shared__ double red_v[GR_R];
+    __shared__ int64_t red_i[GR_R];
+    __shared__ int is_last;
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * GR_R;
+
+    // chunk schedule: part 0 = join columns, parts 1..nep = target columns of epoch ep[k]
+    const int jch = greedy_join_chunks(a), tch = greedy_target_chunks(a);
+    const int n_chunks = jch + a.nep * tch;
+
+    const int lr = tid >> 3, lq = tid & 7;          // this lane's row (mod 32) and float4 of a chunk
+    float4 stage[8];                               // this thread's share of the next chunk
+    auto fetch = [&](int c) {
+        const float *base; int pitch, col0; int64_t row0, nrows;
+        if (c < jch) {
+            base = a.JC_unw; pitch = a.Jp; row0 = a.prev_row0 + i0; nrows = a.n_jc_rows;
+            col0 = a.prev_col0 + c * GR_CC;
+        } else {
+            const int k = (c - jch) / tch;
+            base = a.F_unw; pitch = a.Fp; row0 = i0 + a.ep[k]; nrows = a.n_f_rows;
+            col0 = ((c - jch) % tch) * GR_CC;
+        }
+        const bool in_row = col0 + 4 * lq < pitch;   // float4s beyond the padded row are not read
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int64_t row = row0 + 32 * j + lr;         // 8 lanes cover 128 bytes of one row
+            if (row >= nrows) row = nrows - 1;
+            stage[j] = in_row ? *reinterpret_cast<const float4 *>(base + row * pitch + col0 + 4 * lq)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    double acc_j = 0.0, acc_t = 0.0;
+    fetch(0);
+    for (int c = 0; c < n_chunks; ++c) {
+        float (*B)[GR_LP] = buf[c & 1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<float4 *>(&B[32 * j + lr][4 * lq]) = stage[j];
+        __syncthreads();
+        if (c + 1 < n_chunks) fetch(c + 1);           // in flight while this chunk is accumulated
+        const double acc = greedy_accumulate_chunk(&B[tid][0], tab + 2 * (size_t)c * GR_CC, (c < jch) ? acc_j : acc_t);
+        if (c < jch) acc_j = acc; else acc_t = acc;
+    }
+    double best = DBL_MAX;
+    int64_t arg = INT64_MAX;
+    if (i0 + tid < a.Nwin) { best = __dadd_rn(acc_j, acc_t); arg = i0 + tid; }
+    greedy_finish_step(a, step, nsteps, best, arg, tab_next, blk_min, blk_arg, arrive, path, dist, red_v, red_i, &is_last);
 }
 
-static void fill_args(GreedyArgs &a, const GreedyLayout &g, const float *F_unw, int Dt, const double *wt,
-                      const float *JC_unw, int Dj, const double *wj, const double *Q, double *prev_vec,
-                      bool greedy_mode)
+__global__ void greedy_init_kernel(GreedyArgs a, int64_t start_state, double *__restrict__ tab, unsigned int *arrive)
 {
-    a.JC_unw = JC_unw; a.Dj = Dj; a.wj = wj;
-    a.F_unw = F_unw; a.Dt = Dt; a.wt = wt;
+    for (int i = threadIdx.x; i < 32 * (GR_S1 + GR_S2 + 1); i += blockDim.x) arrive[i] = 0;
+    greedy_write_table(a, 0, start_state, false, tab, threadIdx.x, blockDim.x);
+}
+
+static void fill_args(GreedyArgs &a, const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt,
+                      const float *JC_unw, int Jp, int Dj, const double *wj, const double *Q, bool greedy_mode)
+{
+    a.JC_unw = JC_unw; a.Jp = Jp; a.Dj = Dj; a.wj = wj;
+    a.F_unw = F_unw; a.Fp = Fp; a.Dt = Dt; a.wt = wt;
     if (!greedy_mode) { a.me = 1; a.nep = 1; a.ep[0] = 0; }
     else {
         a.me = g.me;
@@ -194,20 +281,31 @@ static void fill_args(GreedyArgs &a, const GreedyLayout &g, const float *F_unw, 
     a.prev_row0 = g.prev_row0; a.cur_row0 = g.cur_row0; a.Nwin = g.Nwin;
     a.n_jc_rows = g.Nwin + g.me;          // join_contexts has N+1 = Nwin + me rows
     a.n_f_rows = g.Nwin + g.me - 1;       // N
-    a.Q = Q; a.prev_vec = prev_vec;
+    a.Q = Q;
 }
 
-void launch_greedy(const GreedyLayout &g, const float *F_unw, int Dt, const double *wt,
-                   const float *JC_unw, int Dj, const double *wj, const double *Q,
-                   int64_t nsteps, int64_t start_state, double *prev_vec, double *blk_min,
+size_t greedy_counter_bytes() { return (size_t)32 * (GR_S1 + GR_S2 + 1) * sizeof(unsigned int); }
+
+// doubles of one (weight, reference) table; the caller provides two (steps alternate)
+size_t greedy_table_doubles(const GreedyLayout &g, int Dt)
+{
+    const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
+    const int jch = (g.jdim + GR_CC - 1) / GR_CC;
+    return (size_t)(jch + nep * ((Dt + GR_CC - 1) / GR_CC)) * GR_CC * 2;
+}
+
+void launch_greedy(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt,
+                   const float *JC_unw, int Jp, int Dj, const double *wj, const double *Q,
+                   int64_t nsteps, int64_t start_state, double *tables, double *blk_min,
                    int64_t *blk_arg, int nblk, unsigned int *arrive, int64_t *path, double *dist, hipStream_t s)
 {
     GreedyArgs a{};
-    fill_args(a, g, F_unw, Dt, wt, JC_unw, Dj, wj, Q, prev_vec, true);
-    hipLaunchKernelGGL(greedy_init_prev_kernel, dim3((g.jdim + 255) / 256), dim3(256), 0, s, a, start_state, arrive);
+    fill_args(a, g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, Q, true);
+    double *tab[2] = {tables, tables + greedy_table_doubles(g, Dt)};
+    hipLaunchKernelGGL(greedy_init_kernel, dim3(1), dim3(256), 0, s, a, start_state, tab[0], arrive);
     for (int64_t st = 0; st < nsteps; ++st)
-        hipLaunchKernelGGL(greedy_step_kernel, dim3(nblk), dim3(GR_R), 0, s, a, st, blk_min, blk_arg, arrive,
-                           path, dist);
+        hipLaunchKernelGGL(greedy_step_kernel, dim3(nblk), dim3(GR_R), 0, s, a, st, nsteps, tab[st & 1],
+                           tab[(st + 1) & 1], blk_min, blk_arg, arrive, path, dist);
 }
 
 size_t greedy_shmem_bytes(const GreedyLayout &, int, int) { return 0; }    // static LDS only (fits any shape)
@@ -228,7 +326,7 @@ __global__ void path_scores_kernel(GreedyArgs a, int mode, const int64_t *__rest
     const int tcols = a.nep * a.Dt;
     for (int e = tid; e < tcols; e += blockDim.x) {
         const int k = e / a.Dt, c = e % a.Dt;
-        const double f = __dmul_rn((double)a.F_unw[(p + a.ep[k]) * a.Dt + c], a.wt[c]);
+        const double f = __dmul_rn((double)a.F_unw[(p + a.ep[k]) * a.Fp + c], a.wt[c]);
         const double q = a.Q[(l * a.me + a.ep[k]) * a.Dt + c];
         const double d = __dsub_rn(f, q);
         tsq[l * tcols + e] = __dmul_rn(d, d);
@@ -238,13 +336,13 @@ __global__ void path_scores_kernel(GreedyArgs a, int mode, const int64_t *__rest
         for (int c = tid; c < jcols; c += blockDim.x) {
             double x, y;
             if (mode == 0) {   // (unit_end_data[p[:-1]] - unit_start_data[p[1:]])**2
-                x = __dmul_rn((double)a.JC_unw[(p + 1) * a.Dj + c], a.wj[c]);
-                y = __dmul_rn((double)a.JC_unw[pn * a.Dj + c], a.wj[c]);
+                x = __dmul_rn((double)a.JC_unw[(p + 1) * a.Jp + c], a.wj[c]);
+                y = __dmul_rn((double)a.JC_unw[pn * a.Jp + c], a.wj[c]);
                 const double d = __dsub_rn(x, y);
                 jsq[l * jcols + c] = __dmul_rn(d, d);
             } else {           // (prev_join_rep[p[1:]] - current_join_rep[p[:-1]])**2
-                x = __dmul_rn((double)a.JC_unw[(a.prev_row0 + pn) * a.Dj + a.prev_col0 + c], a.wj[a.prev_col0 + c]);
-                y = __dmul_rn((double)a.JC_unw[(a.cur_row0 + p) * a.Dj + a.cur_col0 + c], a.wj[a.cur_col0 + c]);
+                x = __dmul_rn((double)a.JC_unw[(a.prev_row0 + pn) * a.Jp + a.prev_col0 + c], a.wj[a.prev_col0 + c]);
+                y = __dmul_rn((double)a.JC_unw[(a.cur_row0 + p) * a.Jp + a.cur_col0 + c], a.wj[a.cur_col0 + c]);
                 const double d = __dsub_rn(x, y);
                 jsq[l * jcols + c] = __dmul_rn(d, d);
             }
@@ -252,13 +350,13 @@ __global__ void path_scores_kernel(GreedyArgs a, int mode, const int64_t *__rest
     }
 }
 
-void launch_path_scores(const GreedyLayout &g, int mode, const float *F_unw, int Dt, const double *wt,
-                        const float *JC_unw, int Dj, const double *wj, const double *Q,
+void launch_path_scores(const GreedyLayout &g, int mode, const float *F_unw, int Fp, int Dt, const double *wt,
+                        const float *JC_unw, int Jp, int Dj, const double *wj, const double *Q,
                         const int64_t *path, int64_t L, double *tsq, double *jsq, int jcols,
                         hipStream_t s)
 {
     GreedyArgs a{};
-    fill_args(a, g, F_unw, Dt, wt, JC_unw, Dj, wj, Q, nullptr, mode == 1);
+    fill_args(a, g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, Q, mode == 1);
     hipLaunchKernelGGL(path_scores_kernel, dim3((unsigned)L), dim3(256), 0, s, a, mode, path, L, jcols,
                        (int64_t)0, tsq, jsq);
 }

@@ -964,7 +964,7 @@ void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, in
 // database weighting: F = F_unw * wt (float64), row norms; JC = JC_unw * wj
 // (speech_manip.py:209-213 applied by set_target_weights / set_join_weights)
 // ---------------------------------------------------------------------------
-__global__ void weight_target_kernel(const float *__restrict__ F_unw, int64_t N, int Dt,
+__global__ void weight_target_kernel(const float *__restrict__ F_unw, int Fp, int64_t N, int Dt,
                                      const double *__restrict__ wt, double *__restrict__ Fw,
                                      double *__restrict__ fnorm, int64_t Nalloc, int Dpad)
 {
@@ -975,7 +975,7 @@ __global__ void weight_target_kernel(const float *__restrict__ F_unw, int64_t N,
     double acc = 0.0;
     for (int c = lane; c < Dpad; c += 64) {
         double v = 0.0;
-        if (row < N && c < Dt) v = __dmul_rn((double)F_unw[row * Dt + c], wt[c]);
+        if (row < N && c < Dt) v = __dmul_rn((double)F_unw[row * Fp + c], wt[c]);
         Fw[row * Dpad + c] = v;
         acc += v * v;
     }
@@ -983,15 +983,15 @@ __global__ void weight_target_kernel(const float *__restrict__ F_unw, int64_t N,
     if (lane == 0) fnorm[row] = (row < N) ? acc : __builtin_inf();
 }
 
-void launch_weight_target(const float *F_unw, int64_t N, int Dt, const double *wt, double *Fw,
+void launch_weight_target(const float *F_unw, int Fp, int64_t N, int Dt, const double *wt, double *Fw,
                           double *fnorm, int64_t Nalloc, int Dpad, const int32_t *, hipStream_t s)
 {
     const int wpb = 4;
     hipLaunchKernelGGL(weight_target_kernel, dim3((unsigned)((Nalloc + wpb - 1) / wpb)),
-                       dim3(64 * wpb), 0, s, F_unw, N, Dt, wt, Fw, fnorm, Nalloc, Dpad);
+                       dim3(64 * wpb), 0, s, F_unw, Fp, N, Dt, wt, Fw, fnorm, Nalloc, Dpad);
 }
 
-__global__ void weight_join_kernel(const float *__restrict__ JC_unw, int64_t Njc, int Dj,
+__global__ void weight_join_kernel(const float *__restrict__ JC_unw, int Jp, int64_t Njc, int Dj,
                                    const double *__restrict__ wj, double *__restrict__ JCw,
                                    int Djpad)
 {
@@ -1000,15 +1000,15 @@ __global__ void weight_join_kernel(const float *__restrict__ JC_unw, int64_t Njc
     if (i >= total) return;
     const int64_t row = i / Djpad;
     const int c = (int)(i % Djpad);
-    JCw[i] = (c < Dj) ? __dmul_rn((double)JC_unw[row * Dj + c], wj[c]) : 0.0;
+    JCw[i] = (c < Dj) ? __dmul_rn((double)JC_unw[row * Jp + c], wj[c]) : 0.0;
 }
 
-void launch_weight_join(const float *JC_unw, int64_t Njc, int Dj, const double *wj, double *JCw,
+void launch_weight_join(const float *JC_unw, int Jp, int64_t Njc, int Dj, const double *wj, double *JCw,
                         int Djpad, hipStream_t s)
 {
     const int64_t total = Njc * Djpad;
     hipLaunchKernelGGL(weight_join_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       JC_unw, Njc, Dj, wj, JCw, Djpad);
+                       JC_unw, Jp, Njc, Dj, wj, JCw, Djpad);
 }
 
 // ---------------------------------------------------------------------------

@@ -96,6 +96,7 @@ struct snk_engine {
     // database
     int64_t N = 0, Njc = 0, Nalloc = 0;
     int Dt = 0, Dj = 0, Dpad = 0, Djpad = 0;
+    int Fp = 0, Jp = 0;           // row pitch (floats, multiple of 4) of the unweighted device copies
     DevBuf F_unw, JC_unw, Fw, fnorm, JCw, wt, wj, unit_class;
     bool have_db = false, have_join = false, have_weights = false, have_classes = false;
     int64_t shard_offset = 0, global_N = -1;
@@ -117,7 +118,7 @@ struct snk_engine {
     // greedy
     GreedyLayout glay{};
     bool have_glay = false;
-    DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist;
+    DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist, gsync;
     // options
     int cap = 4096;
     double sample_frac = 1.0 / 16.0;
@@ -255,7 +256,7 @@ int snk_destroy(snk_handle h)
     DevBuf *bufs[] = {&h->F_unw, &h->JC_unw, &h->Fw, &h->fnorm, &h->JCw, &h->wt, &h->wj, &h->unit_class,
                       &h->Qraw, &h->Qp, &h->Qf, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
-                      &h->gpath, &h->gdist};
+                      &h->gpath, &h->gdist, &h->gsync};
     for (auto *b : bufs) b->release();
     (void)hipStreamSynchronize(h->dp_stream[1]); (void)hipStreamDestroy(h->dp_stream[1]);
     h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
@@ -280,9 +281,12 @@ static int upload_join(snk_engine *h, const float *JC_unw, int64_t Njc, int Dj)
 {
     if (!JC_unw || Njc < 2 || Dj < 1) return fail("upload: bad join matrix (Njc=%lld Dj=%d)", (long long)Njc, Dj);
     h->Njc = Njc; h->Dj = Dj; h->Djpad = roundup(Dj, 32);
-    CHK(h->JC_unw.ensure((size_t)Njc * Dj * sizeof(float)));
+    h->Jp = roundup(Dj, 4);     // 16-byte aligned rows, zero-filled padding (greedy scan: 128-bit loads)
+    CHK(h->JC_unw.ensure((size_t)Njc * h->Jp * sizeof(float)));
+    if (h->Jp != Dj) HIPCHK(hipMemsetAsync(h->JC_unw.p, 0, (size_t)Njc * h->Jp * sizeof(float), h->stream));
     CHK(h->JCw.ensure((size_t)Njc * h->Djpad * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(h->JC_unw.p, JC_unw, (size_t)Njc * Dj * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpy2DAsync(h->JC_unw.p, (size_t)h->Jp * sizeof(float), JC_unw, (size_t)Dj * sizeof(float),
+                            (size_t)Dj * sizeof(float), (size_t)Njc, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_join = true;
     h->have_weights = false;
@@ -300,10 +304,13 @@ int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt, const flo
     if (JC_unw && Njc != N + 1) return fail("snk_upload_db: join_contexts must have N+1 rows (got %lld, N=%lld)", (long long)Njc, (long long)N);
     h->N = N; h->Dt = Dt; h->Dpad = roundup(Dt, SNK_DPAD);
     h->Nalloc = roundup(N, 16) + 16 * SNK_NT_MAX;
-    CHK(h->F_unw.ensure((size_t)N * Dt * sizeof(float)));
+    h->Fp = roundup(Dt, 4);
+    CHK(h->F_unw.ensure((size_t)N * h->Fp * sizeof(float)));
+    if (h->Fp != Dt) HIPCHK(hipMemsetAsync(h->F_unw.p, 0, (size_t)N * h->Fp * sizeof(float), h->stream));
     CHK(h->Fw.ensure((size_t)h->Nalloc * h->Dpad * sizeof(double)));
     CHK(h->fnorm.ensure((size_t)h->Nalloc * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(h->F_unw.p, F_unw, (size_t)N * Dt * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpy2DAsync(h->F_unw.p, (size_t)h->Fp * sizeof(float), F_unw, (size_t)Dt * sizeof(float),
+                            (size_t)Dt * sizeof(float), (size_t)N, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_db = true;
     h->have_weights = false;
@@ -350,10 +357,10 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
     {
         StageTimer t(h, h->stream, TM_WEIGHTS);
         if (h->have_db)
-            launch_weight_target(h->F_unw.as<float>(), h->N, h->Dt, h->wt.as<double>(), h->Fw.as<double>(),
+            launch_weight_target(h->F_unw.as<float>(), h->Fp, h->N, h->Dt, h->wt.as<double>(), h->Fw.as<double>(),
                                  h->fnorm.as<double>(), h->Nalloc, h->Dpad, nullptr, h->stream);
         if (h->have_join)
-            launch_weight_join(h->JC_unw.as<float>(), h->Njc, h->Dj, h->wj.as<double>(), h->JCw.as<double>(),
+            launch_weight_join(h->JC_unw.as<float>(), h->Jp, h->Njc, h->Dj, h->wj.as<double>(), h->JCw.as<double>(),
                                h->Djpad, h->stream);
     }
     HIPCHK(hipGetLastError());
@@ -964,16 +971,17 @@ int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_st
     *nsteps_out = nsteps;
     if (nsteps == 0) { HIPCHK(hipStreamSynchronize(h->stream)); collect_timers(h); return 0; }
     const int nblk = greedy_blocks(g, h->Dt, h->Dj);
-    CHK(h->gprev.ensure((size_t)g.jdim * sizeof(double)));
+    CHK(h->gprev.ensure(2 * greedy_table_doubles(g, h->Dt) * sizeof(double)));     // (weight, reference) tables
+    CHK(h->gsync.ensure(greedy_counter_bytes()));
     CHK(h->gblkmin.ensure((size_t)nblk * sizeof(double)));
     CHK(h->gblkarg.ensure((size_t)nblk * sizeof(int64_t)));
     CHK(h->gpath.ensure((size_t)nsteps * sizeof(int64_t)));
     CHK(h->gdist.ensure((size_t)nsteps * sizeof(double)));
     {
         StageTimer t(h, h->stream, TM_GREEDY_STEPS);
-        launch_greedy(g, h->F_unw.as<float>(), h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Dj,
+        launch_greedy(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
                       h->wj.as<double>(), h->Qraw.as<double>(), nsteps, start_state, h->gprev.as<double>(),
-                      h->gblkmin.as<double>(), h->gblkarg.as<int64_t>(), nblk, h->slabctr.as<unsigned int>() + 8, h->gpath.as<int64_t>(),
+                      h->gblkmin.as<double>(), h->gblkarg.as<int64_t>(), nblk, h->gsync.as<unsigned int>(), h->gpath.as<int64_t>(),
                       h->gdist.as<double>(), h->stream);
     }
     HIPCHK(hipGetLastError());
@@ -1011,7 +1019,7 @@ int snk_path_scores(snk_handle h, const double *Q, const int64_t *path, int64_t 
     HIPCHK(hipMemcpyAsync(h->gpath.p, path, (size_t)L * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
     double *tsq = h->d2tmp.as<double>();
     double *jsq = reinterpret_cast<double *>(reinterpret_cast<char *>(h->d2tmp.p) + tbytes);
-    launch_path_scores(g, mode, h->F_unw.as<float>(), h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Dj,
+    launch_path_scores(g, mode, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
                        h->wj.as<double>(), h->Qraw.as<double>(), h->gpath.as<int64_t>(), L, tsq, jsq, jcols, h->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(tsq_out, tsq, tbytes, hipMemcpyDeviceToHost, h->stream));

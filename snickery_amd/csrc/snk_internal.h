@@ -10,10 +10,10 @@
 namespace snk {
 
 // ---- database preparation -------------------------------------------------
-void launch_weight_target(const float *F_unw, int64_t N, int Dt, const double *wt,
+void launch_weight_target(const float *F_unw, int Fp, int64_t N, int Dt, const double *wt,
                           double *Fw, double *fnorm, int64_t Nalloc, int Dpad,
                           const int32_t *unit_class, hipStream_t s);
-void launch_weight_join(const float *JC_unw, int64_t Njc, int Dj, const double *wj,
+void launch_weight_join(const float *JC_unw, int Jp, int64_t Njc, int Dj, const double *wj,
                         double *JCw, int Djpad, hipStream_t s);
 
 // ---- K-NN -----------------------------------------------------------------
@@ -99,15 +99,18 @@ struct GreedyLayout {
     int prev_col0, cur_col0;      // first column inside a JCw row
     int64_t prev_row0, cur_row0;  // JCw row of window 0 for prev / current
 };
-void launch_greedy(const GreedyLayout &g, const float *F_unw, int Dt, const double *wt,
-                   const float *JC_unw, int Dj, const double *wj, const double *Q,
-                   int64_t nsteps, int64_t start_state, double *prev_vec, double *blk_min,
+// Fp / Jp: row pitch (floats, multiple of 4) of the unweighted device matrices
+void launch_greedy(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt,
+                   const float *JC_unw, int Jp, int Dj, const double *wj, const double *Q,
+                   int64_t nsteps, int64_t start_state, double *tables, double *blk_min,
                    int64_t *blk_arg, int nblk, unsigned int *arrive, int64_t *path, double *dist, hipStream_t s);
+size_t greedy_table_doubles(const GreedyLayout &g, int Dt);
+size_t greedy_counter_bytes();
 size_t greedy_shmem_bytes(const GreedyLayout &g, int Dt, int Dj);
 int greedy_blocks(const GreedyLayout &g, int Dt, int Dj);
 
-void launch_path_scores(const GreedyLayout &g, int mode, const float *F_unw, int Dt, const double *wt,
-                        const float *JC_unw, int Dj, const double *wj, const double *Q,
+void launch_path_scores(const GreedyLayout &g, int mode, const float *F_unw, int Fp, int Dt, const double *wt,
+                        const float *JC_unw, int Jp, int Dj, const double *wj, const double *Q,
                         const int64_t *path, int64_t L, double *tsq, double *jsq, int jcols,
                         hipStream_t s);
 
