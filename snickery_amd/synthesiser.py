@@ -363,6 +363,31 @@ class Synthesiser(object):
         unit_features = self._mask_query(unit_features)
         return (unit_features, unit_names) if return_names else unit_features
 
+    def synth_utts_bulk(self, fnames, synth_type='test'):
+        """synth_utt over a list of utterances (the reference's commented-out synth_utts_bulk,
+        synth_halfphone.py:1060-1180, and the list comprehension of balance_stream_weights.py:92).
+        With acoustic preselection + Viterbi the whole list goes through ONE call of the batch entry
+        point (grouped K-NN, one join launch and one recursion launch per group); other
+        configurations loop.  Returns what synth_utt returns, per utterance."""
+        fnames = list(fnames)
+        batched = (not self.config.get('greedy_search', False)
+                   and self.config.get('preselection_method') == 'acoustic'
+                   and self.mode_of_operation in ('normal', 'stream_weight_balancing')
+                   and not self.config.get('get_selection_info', False))
+        if not batched or not fnames:
+            return [self.synth_utt(f, synth_type=synth_type) for f in fnames]
+        t = self.start_clock('Get speech (bulk)')
+        feats = [self.prepare_targets(f, synth_type) for f in fnames]
+        self.stop_clock(t)
+        t = self.start_clock('Batched preselection + Viterbi')
+        paths, costs = self.engine.knn_viterbi_batch(feats, self.config['n_candidates'])
+        self.stop_clock(t)
+        paths = [[int(u) for u in p] for p in paths]
+        if self.mode_of_operation == 'stream_weight_balancing':
+            return [(self.get_target_scores_per_stream(U, p), self.get_join_scores_per_stream(p))
+                    for U, p in zip(feats, paths)]
+        return paths
+
     def synth_utt(self, base, synth_type='tune', outstem='', outdir=''):
         """Search part of synth_utt (synth_simple.py:342-456 / synth_halfphone.py:1478-1696).
         Returns the unit path, or (tscores, jscores) in 'stream_weight_balancing' mode."""

@@ -183,3 +183,40 @@ def test_halfphone_label_driven_synth_utt(tmp_path, golden, method):
     assert synth.synth_utt('arctic_b0001', synth_type='test') == opath
     assert synth.last_path_cost == ocost
     synth.close()
+
+
+def test_bulk_synthesis_and_stream_weight_balancing(tmp_path, golden, mini_voice):
+    """balance_stream_weights.py's consumer pattern on the GPU path: the whole tune set through the
+    batch entry point equals utterance-by-utterance synth_utt, and the balancing loop's first
+    measurement is exactly the per-stream contributions of those paths."""
+    from snickery_amd.synthesiser import Synthesiser
+    from snickery_amd.balance_stream_weights import balance_stream_weights, mean_nonzero_contributions
+    extra = '''
+join_cost_weight = 1.0
+tune_data_dirs = test_data_dirs
+tune_patterns = ['arctic_b']
+n_tune_utts = 5
+'''
+    cfgfile, config = build_voice(tmp_path, golden, greedy=False, multiepoch=1, n_candidates=12, extra_config=extra)
+    for stream in ('mag', 'lf0'):                       # a second, shorter tune utterance
+        golden['test0_raw_' + stream][10:97].astype(np.float32).tofile(
+            os.path.join(config['data'], 'low', stream, 'arctic_b0002.' + stream))
+    synth = Synthesiser(cfgfile, verbose=False)
+    names = synth.get_sentence_set('tune')
+    assert names == ['arctic_b0001', 'arctic_b0002']
+    paths = synth.synth_utts_bulk(names, synth_type='tune')
+    assert paths == [synth.synth_utt(n, synth_type='tune') for n in names]
+    synth.mode_of_operation = 'stream_weight_balancing'
+    bulk = synth.synth_utts_bulk(names, synth_type='tune')
+    single = [synth.synth_utt(n, synth_type='tune') for n in names]
+    for (bt, bj), (st, sj) in zip(bulk, single):
+        assert np.array_equal(bt, st) and np.array_equal(bj, sj)
+        assert bt.shape[1] == 2 and bj.shape[1] == 4
+    res = balance_stream_weights(synth, max_epochs=3, report=lambda *_: None)
+    synth.set_join_weights(np.ones(4))
+    synth.set_target_weights(np.ones(2))
+    ones = [synth.synth_utt(n, synth_type='tune') for n in names]
+    first = mean_nonzero_contributions(np.vstack([j for t, j in ones]), np.vstack([t for t, j in ones]))
+    assert np.array_equal(res['contribs'][0], first)
+    assert len(res['losses']) == 3 and res['best_weights'].shape == (6,) and np.all(res['best_weights'] >= 0)
+    synth.close()

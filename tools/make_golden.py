@@ -41,7 +41,8 @@ OUT = os.path.join(HERE, '..', 'tests', 'golden')
 MODULES = ['synth_simple', 'synth_halfphone', 'fst_functions_wrapped', 'speech_manip',
            'data_manipulation', 'segmentaxis', 'const', 'matrix_operations',
            'file_naming', 'util', 'train_simple', 'train_halfphone', 'label_manip',
-           'resample', 'resample_labels', 'mulaw2', 'varying_filter', 'data_fudging']
+           'resample', 'resample_labels', 'mulaw2', 'varying_filter', 'data_fudging',
+           'balance_stream_weights']
 
 DIMS = {'mag': 60, 'real': 45, 'imag': 45, 'lf0': 1}
 
@@ -330,6 +331,34 @@ def main():
         trimmed = hp_speech[labs[4][0][1]:labs[-5][0][0]]    # as if the terminal silences had been trimmed
         fixtures['halfphone_reinserted_silence'] = train_halfphone.reinsert_terminal_silence(trimmed, labs)
         fixtures['halfphone_trimmed_range'] = np.array([labs[4][0][1], labs[-5][0][0]], dtype=np.int64)
+
+        # ---- the reference's balance_stream_weights.py (host logic only) driven by a deterministic
+        # stand-in Synthesiser (tests/bsw_stub.py): recorded weight trajectory and result ----
+        import io
+        import runpy
+        import contextlib
+        sys.path.insert(0, os.path.join(HERE, '..', 'tests'))
+        import bsw_stub
+        real_synth_class = synth_halfphone.Synthesiser
+        synth_halfphone.Synthesiser = bsw_stub.StubSynthesiser
+        old_argv = sys.argv
+        sys.argv = ['balance_stream_weights.py', '-c', 'unused.cfg']
+        out = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(out):
+                runpy.run_path(os.path.join(tmp, 'conv', 'balance_stream_weights.py'), run_name='__main__')
+        finally:
+            sys.argv = old_argv
+            synth_halfphone.Synthesiser = real_synth_class
+        lines = out.getvalue().splitlines()
+        traj = [[float(x) for x in l.split(':', 1)[1].split()] for l in lines if l.startswith('     weights:')]
+        loss = [float(l.split('loss')[1].split('=')[0]) for l in lines if l.startswith('=== iteration')]
+        jw = [l for l in lines if l.startswith('join_stream_weights = ')][0]
+        tw = [l for l in lines if l.startswith('target_stream_weights = ')][0]
+        fixtures['bsw_weight_trajectory'] = np.array(traj)            # printed with %f
+        fixtures['bsw_losses'] = np.array(loss)
+        fixtures['bsw_join_stream_weights'] = np.array(eval(jw.split('=', 1)[1]))
+        fixtures['bsw_target_stream_weights'] = np.array(eval(tw.split('=', 1)[1]))
 
         np.savez_compressed(os.path.join(OUT, 'reference_mini.npz'), **fixtures)
         sz = os.path.getsize(os.path.join(OUT, 'reference_mini.npz'))
