@@ -197,6 +197,7 @@ static int staged_d2h(snk_engine *h, hipStream_t st, const D2HPart *parts, int n
 }
 
 static int roundup(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); }
+#define SNK_KNN_MAX_ROWS 8192       // rows of one K-NN call (batch_rows is capped to it)
 
 // ---------------------------------------------------------------------------
 extern "C" {
@@ -453,6 +454,18 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
                       int64_t *cand_dev, double *dist_dev, double *d2_dev, int *deferred_status = nullptr)
 {
     if (K < 1 || K > 208) return fail("K-NN: n_candidates=%d outside the supported range 1..208", K);
+    if (T > SNK_KNN_MAX_ROWS) {
+        // very long query matrices: the per-row workspaces (and the bucket kernel's LDS histogram)
+        // are sized for SNK_KNN_MAX_ROWS rows; the search is per row, so it is cut into calls
+        for (int64_t r0 = 0; r0 < T; r0 += SNK_KNN_MAX_ROWS) {
+            const int64_t rows = (T - r0 < SNK_KNN_MAX_ROWS) ? T - r0 : SNK_KNN_MAX_ROWS;
+            CHK(knn_device(h, Qdev + r0 * h->Dt, rows, K, qclass_dev ? qclass_dev + r0 : nullptr,
+                           cand_dev ? cand_dev + r0 * K : nullptr, dist_dev ? dist_dev + r0 * K : nullptr,
+                           d2_dev ? d2_dev + r0 * K : nullptr));
+        }
+        if (deferred_status) HIPCHK(hipMemsetAsync(deferred_status, 0, sizeof(int), h->stream));
+        return 0;
+    }
     const int64_t Tpad = roundup(T, 32);
     const KnnPlan p0 = make_plan(h, K);
     const bool cls = qclass_dev != nullptr;

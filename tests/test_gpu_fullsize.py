@@ -207,3 +207,24 @@ def test_sharded_batch_pipeline_on_one_gpu(engine):
         for j, u in enumerate(range(a, b)):
             assert np.array_equal(paths[j], ref_paths[u]) and costs[j] == ref_costs[u]
     assert len(ref_paths[3]) == 2
+
+
+def test_very_long_utterance(engine):
+    """An utterance longer than the rows of one K-NN call (8192): the search is cut by rows inside
+    the library, join costs / recursion run over the whole utterance (back-pointers in global memory)."""
+    N, Dt, Dj, T, K = 20000, 61, 40, 9000, 16
+    F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=61)
+    wt = np.full(Dt, 0.5)
+    wj = np.full(Dj, 0.1)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    F, JCw = o.weight(F_unw, wt), o.weight(JC_unw, wj)
+    rng = np.random.RandomState(62)
+    U = (F_unw[rng.randint(0, N, T)] + 0.3 * rng.randn(T, Dt)) * wt
+    path, cost, cand, dist = engine.knn_viterbi(U, K, return_candidates=True)
+    oc_cand, oc_dist = oc.knn(F, U, K)
+    assert np.array_equal(cand, oc_cand) and np.array_equal(dist, oc_dist)
+    opath, ocost = oc.viterbi(oc_cand, oc_dist, JCw)
+    assert path == opath and cost == ocost
+    paths, costs = engine.knn_viterbi_batch([U[:100], U, U[:7]], K)
+    assert list(paths[1]) == path and costs[1] == cost
