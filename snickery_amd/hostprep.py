@@ -271,3 +271,56 @@ def get_norm_durations(unit_names, timings, duration_stats, oov_stats=(5.0, 5.0)
         mean, std = duration_stats.get(name.split(LABEL_DELIMITER)[2], oov_stats)
         out[i, 0] = (float(end - start) - mean) / std
     return out
+
+
+# --------------------------------------------------------------------------
+# Per-stream standardisation statistics of the database writer
+# (data_manipulation.py:96-234; used by train_simple.py:86-87)
+# --------------------------------------------------------------------------
+def _readable_streams(flist, dim, exclude_uv):
+    """The stream files that exist and hold only finite values; for VUV streams only the voiced
+    frames (first column > 0)."""
+    for fname in flist:
+        if not os.path.isfile(fname):
+            continue
+        speech = get_speech(fname, dim)
+        if np.sum(np.isnan(speech)) + np.sum(np.isinf(speech)) > 0:
+            continue                                   # the reference prints 'EXCLUDE' and moves on
+        if exclude_uv:
+            speech = speech[speech[:, 0] > 0.0, :]
+        yield speech
+
+
+def get_mean(flist, dim, exclude_uv=False):
+    """data_manipulation.py:96-123: per-coefficient mean over all frames -> (mean_vec, frame_count)."""
+    frame_sum = np.zeros(dim)
+    frame_count = 0
+    for speech in _readable_streams(flist, dim, exclude_uv):
+        frame_sum += speech.sum(axis=0)
+        frame_count += speech.shape[0]
+    return frame_sum / float(frame_count), frame_count
+
+
+def get_std(flist, dim, mean_vec, exclude_uv=False):
+    """data_manipulation.py:125-160: ONE value per stream -- the largest per-coefficient standard
+    deviation -- replicated to a (1, dim) row (the reference's shape)."""
+    diff_sum = np.zeros(dim)
+    frame_count = 0
+    mean_row = np.asarray(mean_vec).reshape((1, -1))
+    for speech in _readable_streams(flist, dim, exclude_uv):
+        diff_sum += ((speech - mean_row) ** 2).sum(axis=0)
+        frame_count += speech.shape[0]
+    std_val = (diff_sum.max() / float(frame_count)) ** 0.5
+    return np.ones((1, dim)) * std_val
+
+
+def get_mean_std(feat_dir_dict, stream_list, datadims, flist):
+    """data_manipulation.py:205-234: hstack of the per-stream vectors: mean (D,), std (1, D)."""
+    means, stds = [], []
+    for stream in stream_list:
+        stream_files = [os.path.join(feat_dir_dict[stream], base + '.' + stream) for base in flist]
+        uv = stream in VUV_STREAM_NAMES
+        mean, _ = get_mean(stream_files, datadims[stream], exclude_uv=uv)
+        means.append(mean)
+        stds.append(get_std(stream_files, datadims[stream], mean, exclude_uv=uv))
+    return np.hstack(means), np.hstack(stds)

@@ -125,3 +125,40 @@ def test_balance_stream_weights_matches_reference_loop(golden):
     # columns without any positive entry contribute 0.0 (no division by zero)
     m = mean_nonzero_contributions(np.array([[0.0, 2.0], [0.0, 4.0]]), np.array([[1.0], [0.0]]))
     assert list(m) == [0.0, 3.0, 1.0]
+
+
+def test_database_writer_reproduces_reference_database(tmp_path, golden):
+    """snickery_amd.train_simple on the regenerated synthetic voice (same seeded generator that
+    tools/make_golden.py fed to the REFERENCE's train_simple.main_work): every array of the unit
+    database is bit-identical to what the reference wrote, names / dtypes / shapes included."""
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from make_golden import write_voice
+    from voice_fixture import CFG
+    from snickery_amd import hostprep as hp, train_simple
+    data = os.path.join(str(tmp_path), 'voice')
+    write_voice(data, np.random.RandomState(20240))
+    cfgfile = os.path.join(str(tmp_path), 'voice.cfg')
+    with open(cfgfile, 'w') as f:
+        f.write(CFG % dict(workdir=os.path.join(str(tmp_path), 'work'), data=data, greedy='True', multiepoch=6,
+                           n_candidates=12))
+    config = hp.load_config(cfgfile)
+    dbfile = train_simple.main_work(config, overwrite_existing_data=False, report=lambda *_: None)
+    assert os.path.basename(dbfile) == str(golden['db_basename'])
+    db = hp.load_database(dbfile)
+    assert sorted(db.keys()) == sorted(k.decode() if isinstance(k, bytes) else str(k) for k in golden['hdf5_keys'])
+    for key, gkey in [('train_unit_features', 'F_unw'), ('join_contexts', 'JC_unw'), ('mean_target', 'mean_target'),
+                      ('std_target', 'std_target'), ('mean_join', 'mean_join'), ('std_join', 'std_join')]:
+        assert db[key].dtype == np.float32 and db[key].shape == golden[gkey].shape
+        assert np.array_equal(db[key], golden[gkey]), key
+    n = db['train_unit_features'].shape[0]
+    assert db['join_contexts'].shape[0] == n + 1 and db['std_target'].shape == (1, 61)
+    assert db['train_unit_names'].dtype == np.dtype('S50') and set(db['train_unit_names']) == {b'_'}
+    assert db['unit_index_within_sentence_dset'].dtype == np.int32 and db['unit_index_within_sentence_dset'][0] == 0
+    assert not any(b'arctic_b' in fn for fn in db['filenames'])          # test material is held out
+    # existing data is protected unless overwriting is asked for (train_simple.py:33-37)
+    import pytest
+    with pytest.raises(SystemExit):
+        train_simple.main_work(config, overwrite_existing_data=False, report=lambda *_: None)
+    train_simple.main_work(config, overwrite_existing_data=True, report=lambda *_: None)
