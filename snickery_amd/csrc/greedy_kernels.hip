@@ -24,10 +24,14 @@ namespace snk {
 
 #define GR_R 256          // windows per workgroup (one thread per window)
 #define GR_CC 32          // columns per staged chunk (8 float4 per row)
+#define GR_NSTG 3         // chunks in flight in registers per thread
+#define GR_NFL 18         // 16-byte loads per thread that fetch a resident target block
 #define GR_LP 36          // LDS row pitch in floats: 16-byte aligned rows, conflict-free 128-bit access
 #define GR_MAX_EP 16      // max multiepoch
 #define GR_S1 256          // arrival counters of the first / second level (see greedy_finish_step)
 #define GR_S2 16
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct GreedyArgs {
     const float *JC_unw; int Jp, Dj; const double *wj;   // Jp / Fp: row pitch in floats (multiple of 4,
@@ -220,11 +224,27 @@ greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__r
 
     // chunk schedule: part 0 = join columns, parts 1..nep = target columns of epoch ep[k]
     const int jch = greedy_join_chunks(a), tch = greedy_target_chunks(a);
-    const int n_chunks = jch + a.nep * tch;
+    double acc_j = 0.0, acc_t = 0.0;
 
+    // Target term from a resident block: when the GR_R + me - 1 target rows of this workgroup fit the
+    // LDS of the chunk buffers (magphase-60: 261 rows x 68 floats), they are read from HBM ONCE and
+    // every epoch of every window is accumulated from LDS; the chunked loop below then streams the
+    // join columns only.  Otherwise the target columns go through the chunk loop too, epoch by epoch
+    // (each target row is then re-read once per epoch, through L2).
+    const int frows = GR_R + a.me - 1, fpitch = a.Fp + 4;
+    // (whole 32-column chunks only: the accumulation reads 32 floats per chunk from a row)
+    const bool resident = (a.Fp % GR_CC) == 0 && (size_t)frows * fpitch * sizeof(float) <= sizeof(buf);
+    // Chunk loop: join columns (and the target columns when they are not resident).  GR_NSTG chunks
+    // are in flight in registers.  The loads are inline asm: the compiler sinks ordinary loads of a
+    // software pipeline to their use (measured: no load was in flight behind the arithmetic), and it
+    // does not count asm loads in its own vmcnt waits, so every wait here is explicit.  Stage s is
+    // consumed in chunk order, so before chunk c at most GR_NSTG-1 younger chunks (8 loads each) may
+    // still be outstanding.
+    const int n_chunks = resident ? jch : jch + a.nep * tch;
     const int lr = tid >> 3, lq = tid & 7;          // this lane's row (mod 32) and float4 of a chunk
-    float4 stage[8];                               // this thread's share of the next chunk
-    auto fetch = [&](int c) {
+    f32x4 stage[GR_NSTG][8];
+    auto fetch = [&](int c, f32x4 (&st)[8]) {
+        if (c >= n_chunks) c = n_chunks - 1;          // surplus request: re-read, never consumed
         const float *base; int pitch, col0; int64_t row0, nrows;
         if (c < jch) {
             base = a.JC_unw; pitch = a.Jp; row0 = a.prev_row0 + i0; nrows = a.n_jc_rows;
@@ -234,26 +254,70 @@ greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__r
             base = a.F_unw; pitch = a.Fp; row0 = i0 + a.ep[k]; nrows = a.n_f_rows;
             col0 = ((c - jch) % tch) * GR_CC;
         }
-        const bool in_row = col0 + 4 * lq < pitch;   // float4s beyond the padded row are not read
+        col0 += 4 * lq;
+        if (col0 > pitch - 4) col0 = pitch - 4;       // float4s beyond the padded row: finite data, weight 0
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             int64_t row = row0 + 32 * j + lr;         // 8 lanes cover 128 bytes of one row
             if (row >= nrows) row = nrows - 1;
-            stage[j] = in_row ? *reinterpret_cast<const float4 *>(base + row * pitch + col0 + 4 * lq)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *src = base + row * pitch + col0;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st[j]) : "v"(src) : "memory");
         }
     };
-    double acc_j = 0.0, acc_t = 0.0;
-    fetch(0);
-    for (int c = 0; c < n_chunks; ++c) {
+    if (!resident) {
+#pragma unroll
+        for (int s = 0; s < GR_NSTG; ++s) fetch(s, stage[s]);
+    }
+    if (resident) {
+        float *Fs = &buf[0][0][0];
+        const int fq = a.Fp >> 2, nq = frows * fq;       // float4s of the block
+        // all of a thread's loads are in flight together (GR_NFL x 16 bytes; the block holds at most
+        // sizeof(buf) / 16 = 4608 float4 = 18 per thread)
+        f32x4 v[GR_NFL];
+#pragma unroll
+        for (int u = 0; u < GR_NFL; ++u) {
+            const int e = u * GR_R + tid;
+            int64_t row = i0 + (e < nq ? e / fq : 0);
+            if (row >= a.n_f_rows) row = a.n_f_rows - 1;
+            v[u] = *reinterpret_cast<const f32x4 *>(a.F_unw + row * a.Fp + 4 * (e < nq ? e % fq : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < GR_NFL; ++u) {
+            const int e = u * GR_R + tid;
+            if (e < nq) *reinterpret_cast<f32x4 *>(Fs + (size_t)(e / fq) * fpitch + 4 * (e % fq)) = v[u];
+        }
+        __syncthreads();
+        // the first join chunks are requested now and land behind the target arithmetic
+#pragma unroll
+        for (int s = 0; s < GR_NSTG; ++s) fetch(s, stage[s]);
+        for (int k = 0; k < a.nep; ++k) {
+            const float *frow = Fs + (size_t)(tid + a.ep[k]) * fpitch;
+            for (int c2 = 0; c2 < tch; ++c2)
+                acc_t = greedy_accumulate_chunk(frow + c2 * GR_CC, tab + 2 * (size_t)(jch + k * tch + c2) * GR_CC, acc_t);
+        }
+        __syncthreads();                                 // the chunk buffers alias the block
+    }
+    auto consume = [&](int c, f32x4 (&st)[8]) {
         float (*B)[GR_LP] = buf[c & 1];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<float4 *>(&B[32 * j + lr][4 * lq]) = stage[j];
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4 *>(&B[32 * j + lr][4 * lq]) = st[j];
         __syncthreads();
-        if (c + 1 < n_chunks) fetch(c + 1);           // in flight while this chunk is accumulated
+        fetch(c + GR_NSTG, st);                       // refill this stage
         const double acc = greedy_accumulate_chunk(&B[tid][0], tab + 2 * (size_t)c * GR_CC, (c < jch) ? acc_j : acc_t);
         if (c < jch) acc_j = acc; else acc_t = acc;
+    };
+    for (int c0 = 0; c0 < n_chunks; c0 += GR_NSTG) {
+#pragma unroll
+        for (int s = 0; s < GR_NSTG; ++s) {
+            // chunk c0+s: everything but the (GR_NSTG-1) younger chunks has landed
+            asm volatile("s_waitcnt vmcnt(%8)"
+                         : "+v"(stage[s][0]), "+v"(stage[s][1]), "+v"(stage[s][2]), "+v"(stage[s][3]),
+                           "+v"(stage[s][4]), "+v"(stage[s][5]), "+v"(stage[s][6]), "+v"(stage[s][7])
+                         : "n"(8 * (GR_NSTG - 1)) : "memory");
+            if (c0 + s < n_chunks) consume(c0 + s, stage[s]);      // uniform
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus requests of the last trip
     double best = DBL_MAX;
     int64_t arg = INT64_MAX;
     if (i0 + tid < a.Nwin) { best = __dadd_rn(acc_j, acc_t); arg = i0 + tid; }

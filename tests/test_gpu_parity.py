@@ -244,10 +244,13 @@ def test_greedy_golden(mini_engine, golden, mini_voice):
     assert np.array_equal(np.array(path), ref) and np.all(d == 0.0)
 
 
-@pytest.mark.parametrize('me,lfat,mode,Dj', [(6, False, 0, 151), (3, True, 0, 40), (4, False, 1, 80), (1, False, 1, 302)])
-def test_greedy_synthetic(engine, me, lfat, mode, Dj):
+@pytest.mark.parametrize('me,lfat,mode,Dj,Dt', [(6, False, 0, 151, 61), (3, True, 0, 40, 61), (4, False, 1, 80, 61),
+                                               (1, False, 1, 302, 61), (16, False, 0, 151, 61),
+                                               (5, False, 0, 151, 90),      # target rows too wide to stay in LDS
+                                               (2, True, 0, 33, 7)])
+def test_greedy_synthetic(engine, me, lfat, mode, Dj, Dt):
     N = 5000
-    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(N, 61, Dj, seed=me)
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(N, Dt, Dj, seed=me)
     engine.upload_db(F_unw, JC_unw)
     engine.set_weights(wt, wj)
     engine.set_greedy_layout(me, lfat, mode)
