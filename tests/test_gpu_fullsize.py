@@ -193,12 +193,15 @@ def test_sharded_batch_pipeline_on_one_gpu(engine):
         e.upload_target_only(F_unw[lo:hi])
         e.set_shard(lo, N)
         e.set_weights(wt, None)
+        if r % 2:
+            e.set_option('batch_rows', 200)       # row groups that cut through utterances
         e.knn_local_batch_dev(utts, K, d2[r].data_ptr(), ids[r].data_ptr())
         fallbacks += e.info('f16_fallbacks') + e.info('batch_redos')
         e.close()
     torch.cuda.synchronize()
     assert fallbacks == 0                      # shard-sized databases keep the f32 prefilter path
     # "rank" 1 of 2 owners: utterances 3..4; "rank" 0: utterances 0..2
+    engine.set_option('batch_rows', 256)           # several recursion groups on the owner as well
     for a, b in [(0, 3), (3, 5)]:
         r0, r1 = sum(lens[:a]), sum(lens[:b])
         d2_own = d2[:, r0:r1].contiguous()
@@ -206,6 +209,7 @@ def test_sharded_batch_pipeline_on_one_gpu(engine):
         paths, costs = engine.merge_viterbi_batch_dev(d2_own.data_ptr(), id_own.data_ptr(), G, lens[a:b], K)
         for j, u in enumerate(range(a, b)):
             assert np.array_equal(paths[j], ref_paths[u]) and costs[j] == ref_costs[u]
+    engine.set_option('batch_rows', 8192)
     assert len(ref_paths[3]) == 2
 
 

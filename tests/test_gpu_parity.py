@@ -202,6 +202,29 @@ def test_viterbi_batch_equals_single(engine):
         assert p == op and c == ocst
 
 
+def test_viterbi_batch_groups(engine):
+    """Many small K-NN groups (batch_rows far below the batch): group boundaries between and inside
+    long utterances, alternating side streams and workspace reuse from the third group on; then one
+    group for everything.  Same paths and costs either way, equal to the single-utterance calls."""
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(12000, 61, 151, seed=23)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    lens = [40, 130, 7, 64, 2, 90, 33, 1, 51, 77, 120]
+    utts = [o.synthetic_targets(F_unw, T, seed=30 + i) * wt for i, T in enumerate(lens)]
+    single = [engine.knn_viterbi(U, 30) for U in utts]
+    assert engine.info('batch_rows') == 8192
+    try:
+        for rows in (100, 1, 0, 8192):
+            engine.set_option('batch_rows', rows)
+            paths, costs = engine.knn_viterbi_batch(utts, 30)
+            for u in range(len(utts)):
+                assert list(paths[u]) == single[u][0] and (costs[u] == single[u][1] or len(single[u][0]) == 0)
+    finally:
+        engine.set_option('batch_rows', 8192)
+    assert len(paths[7]) == 0 and len(paths[4]) == 2          # T = 1: no path (SURVEY 9.2)
+    assert engine.info('batch_redos') == 0 and engine.info('f16_fallbacks') == 0
+
+
 def test_viterbi_batch_redo_on_overflow(engine):
     """Batch pipeline with deferred K-NN status: an utterance whose sampled thresholds overflow a
     candidate list is redone with exact thresholds at the end of the batch."""
@@ -219,6 +242,7 @@ def test_viterbi_batch_redo_on_overflow(engine):
     finally:
         engine.set_option('list_capacity', 4096)
         engine.set_option('sample_fraction', 1.0 / 16)
+        engine.set_option('precision', 1)
     assert redos >= 1
     for u, U in enumerate(utts):
         oc, od = o.knn_bruteforce(F, U, 20)
