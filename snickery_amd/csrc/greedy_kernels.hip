@@ -9,11 +9,11 @@
 //
 // The windowed database is never materialised (the reference hstacks an (N-me+1) x 517 float64
 // copy, 4.1 GB at N = 1 M): window i reads rows i..i+me-1 of the UNWEIGHTED float32 feature
-// matrix and row i of the unweighted join matrix exactly as the HDF5 file stores them, and
-// (rows padded to a multiple of 4 floats on the device, so every access is 16 bytes wide) and
-// applies the float64 stream weights on the fly (fl64(f32 * w) is bit-identical to the
-// reference's speech_manip.weight()).  Every step is therefore a pure HBM-bandwidth-bound
-// stream over (Dj + Dt) * 4 bytes per unit.  Squared distances are accumulated in the canonical
+// matrix and row i of the unweighted join matrix as the HDF5 file stores them (rows padded to a
+// multiple of 4 floats on the device, so every access is 16 bytes wide) and applies the float64
+// stream weights on the fly (fl64(f32 * w) is bit-identical to the
+// reference's speech_manip.weight()).  Every step is therefore a stream over (Dj + Dt) * 4
+// bytes per unit (HBM-bound by design).  Squared distances are accumulated in the canonical
 // oracle order (column by column, separately rounded sub/mul/add), so the argmin is bit-exact.
 //
 // Per step ONE launch of greedy_step_kernel (see the comment on the kernel).
@@ -201,15 +201,16 @@ __device__ void greedy_finish_step(const GreedyArgs &a, int64_t step, int64_t ns
 }
 
 // One step of the greedy search = ONE launch:
-//   every workgroup scans GR_R consecutive windows (thread t owns window i0+t): the join columns
-//   and then, epoch by epoch, the target columns stream through LDS in 32-column chunks with
-//   16-byte global loads, LDS writes and LDS reads (rows are padded to a multiple of 4 floats on
-//   the device), register-staged one chunk ahead; thread t accumulates its window's squared
-//   distance in the canonical column order, weights and references coming from the step's table.
-//   The workgroup's (min, argmin) goes to global memory; the workgroup that arrives LAST
-//   (sc1 stores / an arrival counter / sc1 loads) reduces all partial results, appends
-//   the winner to the path and writes the next step's table (its `current_join_rep` row is the
-//   next `prev`).
+//   every workgroup scans GR_R consecutive windows (thread t owns window i0+t) with 16-byte global
+//   loads, LDS writes and LDS reads (rows are padded to a multiple of 4 floats on the device).
+//   Target term: the workgroup's GR_R + me - 1 target rows are read once into LDS and every epoch
+//   of every window is accumulated from there (wider targets: streamed chunk by chunk instead).
+//   Join term: 32-column chunks stream through LDS, GR_NSTG chunks in flight in registers.
+//   Thread t accumulates its window's squared distance in the canonical column order, weights
+//   and references coming from the step's table.  The workgroup's (min, argmin) goes to global
+//   memory; the workgroup that arrives LAST (sc1 stores / arrival tree / sc1 loads) reduces all
+//   partial results, appends the winner to the path and writes the next step's table (its
+//   `current_join_rep` row is the next `prev`).
 __global__ void __launch_bounds__(GR_R)
 greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__restrict__ tab,
                    double *__restrict__ tab_next, double *__restrict__ blk_min, int64_t *__restrict__ blk_arg,
