@@ -283,6 +283,28 @@ class Synthesiser(object):
         self.stop_clock(t)
         return (candidates, distances)
 
+    def join_knn(self, k, first=0, last=None):
+        """Nearest `unit_end_data` rows of `unit_start_data[first:last]`: the K-NN of
+        initialise_join_table_with_knn (active_learning_join.py:184-212: sklearn KDTree over
+        unit_end_data, queried with unit_start_data) on the GPU engine.  The join matrix takes the
+        place of the target database in a second engine; rows are queried in slices.
+        Returns (indices (n, k) int64, distances (n, k) float64)."""
+        if getattr(self, '_join_engine', None) is None:
+            self._join_engine = HipSearchEngine(self.engine.device)
+            self._join_engine.upload_target_only(self.join_contexts_unweighted[1:, :])
+            self._join_engine_weights = None
+        if self._join_engine_weights is None or not np.array_equal(self._join_engine_weights, self._device_wj):
+            self._join_engine.set_weights(self._device_wj, None)
+            self._join_engine_weights = self._device_wj.copy()
+        S = self.join_contexts_unweighted[:-1, :][first:last]
+        out_i, out_d = [], []
+        for r0 in range(0, S.shape[0], 8192):
+            q = hp.weight(S[r0:r0 + 8192].astype(np.float64), self._device_wj)
+            i, d = self._join_engine.knn(q, k)
+            out_i.append(i)
+            out_d.append(d)
+        return np.vstack(out_i), np.vstack(out_d)
+
     def viterbi_search(self, candidates, distances):
         """synth_halfphone.py:1399-1436."""
         t = self.start_clock('Compose and find shortest path')
@@ -517,3 +539,6 @@ class Synthesiser(object):
 
     def close(self):
         self.engine.close()
+        if getattr(self, '_join_engine', None) is not None:
+            self._join_engine.close()
+            self._join_engine = None

@@ -220,3 +220,18 @@ n_tune_utts = 5
     assert np.array_equal(res['contribs'][0], first)
     assert len(res['losses']) == 3 and res['best_weights'].shape == (6,) and np.all(res['best_weights'] >= 0)
     synth.close()
+
+
+def test_join_knn(tmp_path, golden, mini_voice):
+    """initialise_join_table_with_knn's search (active_learning_join.py:198-204): unit_start_data rows
+    against unit_end_data, on the engine; bit-exact against the oracle's brute force."""
+    from snickery_amd.synthesiser import Synthesiser
+    cfgfile, config = build_voice(tmp_path, golden, greedy=False, multiepoch=1, n_candidates=12)
+    synth = Synthesiser(cfgfile, verbose=False)
+    E, S = mini_voice['E'], mini_voice['S']
+    idx, dist = synth.join_knn(6, first=100, last=260)
+    oi, od = o.knn_bruteforce(E, S[100:260], 6)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    # the natural successor joins at exactly 0 (E[i] == S[i+1]): unit i+1's start row finds unit i first
+    assert np.all(idx[:, 0] == np.arange(100, 260) - 1) and np.all(dist[:, 0] == 0.0)
+    synth.close()
