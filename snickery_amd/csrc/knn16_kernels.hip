@@ -5,20 +5,21 @@
 // Exactness is kept by construction, not by precision:
 //   * key~ = fnorm - 2 q.f comes straight out of the accumulator (||f||^2 rides along in a spare
 //     padding column against 1.0 in the query operand).
-//   * |key~ - key| <= eps_t = c * (2 ||q_t|| Fmax + Fmax^2): input rounding 2^-24 per operand plus a
-//     65-term f32 FMA chain give 4.1e-6 analytically; c = 8e-6.  (A half-precision split
-//     (f16 hi+lo, 16x MFMA rate) was built first and rejected: with f32 accumulators its provable
+//   * |key~ - key| <= e(q,f) = c * (2 ||q|| ||f|| + ||f||^2): input rounding 2^-24 per operand plus
+//     a (Dpad+1)-term f32 FMA chain; c = 2 (Dpad+3) 2^-24 (8e-6 at 64 columns).  (A half-precision
+//     split (f16 hi+lo, 16x MFMA rate) was built first and rejected: with f32 accumulators its provable
 //     bound is ~1e-4 relative, too coarse for databases whose neighbour distances differ by 1e-5.)
-//   * thresholds are raised by eps, the filter passes key~ <= thr + eps, and knn_finalize re-ranks
-//     every survivor within 2 eps of the K-th key with EXACT float64 canonical distances.  The
-//     approximate keys never reach the caller.
+//   * thresholds are raised by eps_t = e(q_t, Fmax), the filter passes key~ <= thr + eps_t, and
+//     knn_finalize re-ranks every survivor within 2 max_i e(q_t, f_i) (over the row's survivors) of
+//     the K-th key with EXACT float64 canonical distances.  The approximate keys never reach the caller.
 //   * anything that does not fit (no spare column, list overflow, > SEL_MAX near ties) falls back
 //     to the f64 sweep.
+//   * rows of DCH = 1..4 chunks of 64 columns (Dt <= 255): fragments [tile][chunk][j4][lane].
 //
 // Operand roles: A = database tile (32 units), B = query tile (32 frames); a lane of the 32x32
 // result holds ONE query column and 16 database rows, so the threshold is one scalar per lane.
-// The k index is permuted: lane half h covers columns 32h..32h+31 (step kk -> column 32h+kk), so
-// every lane reads 128 contiguous bytes per tile.
+// The k index is permuted: within a chunk lane half h covers columns 32h..32h+31 (step kk -> column
+// 32h+kk), so every lane reads 128 contiguous bytes per tile and chunk.
 #include "snk_internal.h"
 #include <float.h>
 
@@ -34,9 +35,9 @@ struct __attribute__((aligned(16))) PoolEntry16 { double key; int idx; int row; 
 __device__ __forceinline__ int crow32(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // ---------------------------------------------------------------------------
-// operand construction.  Fragment order: [tile][j4 = 0..7][lane][4 floats] with
-//   value = X[row(lane & 31)][column 32*(lane >> 5) + 4*j4 + i]
-// so each of the 8 load instructions of a tile covers 1 KB of contiguous memory.
+// operand construction.  Fragment order: [tile][chunk = 0..DCH-1][j4 = 0..7][lane][4 floats] with
+//   value = X[row(lane & 31)][column 64*chunk + 32*(lane >> 5) + 4*j4 + i]       (DCH = Dpad / 64)
+// so each of the 8*DCH load instructions of a tile covers 1 KB of contiguous memory.
 // ---------------------------------------------------------------------------
 __global__ void build_db16_kernel(const double *__restrict__ Fw, const double *__restrict__ fnorm, int64_t N,
                                   int Dt, int Dpad, int64_t n_tiles, int64_t sample_stride, int64_t G,
@@ -44,9 +45,10 @@ __global__ void build_db16_kernel(const double *__restrict__ Fw, const double *_
 {
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (item >= n_tiles * 8) return;
-    const int64_t tile = item / 8;
-    const int j4 = (int)(item % 8);
+    const int per_tile = 8 * (Dpad / 64);
+    if (item >= n_tiles * per_tile) return;
+    const int64_t tile = item / per_tile;
+    const int j4 = (int)(item % per_tile);            // chunk * 8 + j4
     const int r = lane & 31, h = lane >> 5;
     int64_t row;
     if (sample_stride <= 0) {
@@ -64,7 +66,7 @@ __global__ void build_db16_kernel(const double *__restrict__ Fw, const double *_
     f32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int c = 32 * h + 4 * j4 + i;
+        const int c = 64 * (j4 >> 3) + 32 * h + 4 * (j4 & 7) + i;
         float x = 0.0f;
         if (row < N) {
             if (c < Dt) x = (float)Fw[row * Dpad + c];
@@ -94,7 +96,7 @@ __global__ void fmax_kernel(const double *__restrict__ fnorm, int64_t N, double 
 void launch_build_db16(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,
                        int64_t sample_stride, int64_t G, int nt_a, void *A32, hipStream_t s)
 {
-    const int64_t items = n_tiles * 8;
+    const int64_t items = n_tiles * 8 * (Dpad / 64);
     hipLaunchKernelGGL(build_db16_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, Fw, fnorm, N, Dt,
                        Dpad, n_tiles, sample_stride, G, nt_a, reinterpret_cast<f32x4 *>(A32));
 }
@@ -113,15 +115,16 @@ __global__ void prepare_queries16_kernel(const double *__restrict__ Qp, const do
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_tiles = (T + 31) / 32;
-    if (item >= n_tiles * 8) return;
-    const int64_t tile = item / 8;
-    const int j4 = (int)(item % 8);
+    const int per_tile = 8 * (Dpad / 64);
+    if (item >= n_tiles * per_tile) return;
+    const int64_t tile = item / per_tile;
+    const int j4 = (int)(item % per_tile);            // chunk * 8 + j4
     const int64_t row = tile * 32 + (lane & 31);
     const int h = lane >> 5;
     f32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int c = 32 * h + 4 * j4 + i;
+        const int c = 64 * (j4 >> 3) + 32 * h + 4 * (j4 & 7) + i;
         float x = 0.0f;
         if (row < T) {
             if (c < Dt) x = (float)(-2.0 * Qp[row * Dpad + c]);
@@ -140,7 +143,7 @@ __global__ void prepare_queries16_kernel(const double *__restrict__ Qp, const do
 void launch_prepare_queries16(const double *Qp, const double *qnorm, int64_t T, int Dt, int Dpad,
                               const double *fmax2, double eps_c, void *B32, double *eps, hipStream_t s)
 {
-    const int64_t items = ((T + 31) / 32) * 8;
+    const int64_t items = ((T + 31) / 32) * 8 * (Dpad / 64);
     hipLaunchKernelGGL(prepare_queries16_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, Qp, qnorm,
                        T, Dt, Dpad, fmax2, eps_c, reinterpret_cast<f32x4 *>(B32), eps);
 }
@@ -150,8 +153,8 @@ void launch_prepare_queries16(const double *Qp, const double *qnorm, int64_t T, 
 //   MODE 0: minima per (wave slab, lane half) group over the scattered sample -> gmin32[row][G]
 //   MODE 1: filter over the whole database -> entry pool (same pool / bucket / finalize as f64)
 // ---------------------------------------------------------------------------
-template <int NT, int MODE>
-__global__ void __launch_bounds__(256, (NT <= 2) ? 2 : 1)
+template <int NT, int MODE, int DCH>
+__global__ void __launch_bounds__(256, (NT <= 2 && DCH == 1) ? 2 : 1)
 knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
             const float *__restrict__ thr32, int nQT, int64_t n_slabs,
             unsigned int *__restrict__ slab_counter, int qsplit, int64_t n_main_slabs, int qsplit_tail,
@@ -205,21 +208,22 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
         const int qt_hi = (int)(((int64_t)nQT * (part + 1)) / qs);
 
         // database fragments of this slab: resident in registers
-        float af[NT][32];
+        constexpr int KS = 32 * DCH;                  // MFMA k-steps (and floats per lane) per 32-row tile
+        float af[NT][KS];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int j4 = 0; j4 < 8; ++j4) {
-                const f32x4 v = A32[((w * NT + nt) * 8 + j4) * 64 + lane];
+            for (int j4 = 0; j4 < 8 * DCH; ++j4) {
+                const f32x4 v = A32[((w * NT + nt) * (8 * DCH) + j4) * 64 + lane];
                 af[nt][4 * j4] = v[0]; af[nt][4 * j4 + 1] = v[1]; af[nt][4 * j4 + 2] = v[2]; af[nt][4 * j4 + 3] = v[3];
             }
 
-        float b0[32], b1[32];
+        float b0[KS], b1[KS];
         float th_cur = 0.f, th_nxt = 0.f, th_prev = -FLT_MAX;
-        auto load_q = [&](int t, float (&x)[32]) {
+        auto load_q = [&](int t, float (&x)[KS]) {
 #pragma unroll
-            for (int j4 = 0; j4 < 8; ++j4) {
-                const f32x4 v = B32[((int64_t)t * 8 + j4) * 64 + lane];
+            for (int j4 = 0; j4 < 8 * DCH; ++j4) {
+                const f32x4 v = B32[((int64_t)t * (8 * DCH) + j4) * 64 + lane];
                 x[4 * j4] = v[0]; x[4 * j4 + 1] = v[1]; x[4 * j4 + 2] = v[2]; x[4 * j4 + 3] = v[3];
             }
             if (MODE == 1) th_nxt = thr32[t * 32 + qcol];
@@ -239,10 +243,10 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
             for (int r = 0; r < 16; ++r) pacc[j][r] = 0.0f;
         float gm = FLT_MAX;
 
-        auto tile_body = [&](float (&x)[32], float (&nx)[32], int it) {
+        auto tile_body = [&](float (&x)[KS], float (&nx)[KS], int it) {
             // the tile's own operands must have landed (they were requested a tile ago)
 #pragma unroll
-            for (int k = 0; k < 32; ++k) asm volatile("" : "+v"(x[k]));
+            for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(x[k]));
             if (MODE == 1) asm volatile("" : "+v"(th_nxt));
             th_cur = th_nxt;
             if (MODE == 1 && lcount) flush_stage();      // staged entries leave a whole tile early
@@ -260,10 +264,12 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 32; ++k) {
+                for (int kk = 0; kk < KS; ++kk) {
 #pragma unroll
                     for (int j = 0; j < CH; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[st * CH + j][k], x[k], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[st * CH + j][kk], x[kk], acc[j], 0, 0, 0);
+                    const int k = kk;                   // the pending results are tested during the first 32 k-steps
+                    if (kk >= 32) continue;
                     // the 16*CH pending results are tested four at a time in the MFMA shadows: one
                     // min3/min + compare per group; the per-result ballots run only when some lane
                     // of the group passes (a few entries per 32x32 tile do)
@@ -346,14 +352,14 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
     }
 }
 
-template <int NT>
+template <int NT, int DCH>
 static void launch16_t(int mode, int blocks, hipStream_t s, const void *A32, const void *B32,
                        const float *thr32, int nQT, int64_t n_slabs, unsigned int *ctr,
                        int qsplit, int64_t n_main, int qtail, float *gmin32, int64_t G, void *pool,
                        unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk)
 {
 #define SNK_L16(MODE_)                                                                                    \
-    hipLaunchKernelGGL((knn_sweep16<NT, MODE_>), dim3(blocks), dim3(256), 0, s, (const f32x4 *)A32,          \
+    hipLaunchKernelGGL((knn_sweep16<NT, MODE_, DCH>), dim3(blocks), dim3(256), 0, s, (const f32x4 *)A32,          \
                        (const f32x4 *)B32, thr32, nQT, n_slabs, ctr, qsplit, n_main, qtail, gmin32, G, (PoolEntry16 *)pool, \
                        pool_ctl, chunk_fill, max_chunks, pool_chunk)
     if (mode == 0) SNK_L16(0);
@@ -361,14 +367,15 @@ static void launch16_t(int mode, int blocks, hipStream_t s, const void *A32, con
 #undef SNK_L16
 }
 
-// nt: tiles (32 units) per wave.  Returns false when the shape is not instantiated.
-bool launch_knn_sweep16(int mode, int nt, int grid_cus, const void *A32, const void *B32,
+// nt: tiles (32 units) per wave, dch: 64-column chunks per row.  Returns false when the shape is not
+// instantiated.
+bool launch_knn_sweep16(int mode, int nt, int dch, int grid_cus, const void *A32, const void *B32,
                         const float *thr32, int64_t T32, int64_t n_slabs, unsigned int *ctr,
                         float *gmin32, int64_t G, void *pool, unsigned int *pool_ctl, int *chunk_fill,
                         int max_chunks, int pool_chunk, hipStream_t s)
 {
     const int nQT = (int)(T32 / 32);
-    const int64_t max_blocks = (int64_t)grid_cus * ((nt <= 2) ? 2 : 1);
+    const int64_t max_blocks = (int64_t)grid_cus * ((nt <= 2 && dch == 1) ? 2 : 1);
     int qsplit = 1;
     while (n_slabs * qsplit < 2 * 4 * max_blocks && qsplit * 2 <= nQT && qsplit < 8) qsplit *= 2;
     int64_t blocks = (n_slabs * qsplit + 3) / 4;
@@ -376,13 +383,13 @@ bool launch_knn_sweep16(int mode, int nt, int grid_cus, const void *A32, const v
     int64_t n_main = n_slabs;
     int qtail = qsplit;
     sweep_tail_split(n_slabs, qsplit, blocks * 4, nQT, &n_main, &qtail);
-#define SNK_NT16(NT_)                                                                                      \
-    if (nt == NT_) {                                                                                       \
-        launch16_t<NT_>(mode, (int)blocks, s, A32, B32, thr32, nQT, n_slabs, ctr, qsplit, n_main, qtail,   \
-                        gmin32, G, pool, pool_ctl, chunk_fill, max_chunks, pool_chunk);                    \
+#define SNK_NT16(NT_, DCH_)                                                                                \
+    if (nt == NT_ && dch == DCH_) {                                                                        \
+        launch16_t<NT_, DCH_>(mode, (int)blocks, s, A32, B32, thr32, nQT, n_slabs, ctr, qsplit, n_main, qtail, \
+                              gmin32, G, pool, pool_ctl, chunk_fill, max_chunks, pool_chunk);              \
         return true;                                                                                       \
     }
-    SNK_NT16(4) SNK_NT16(2) SNK_NT16(8)
+    SNK_NT16(4, 1) SNK_NT16(2, 1) SNK_NT16(8, 1) SNK_NT16(2, 2) SNK_NT16(1, 3) SNK_NT16(1, 4)
 #undef SNK_NT16
     return false;
 }

@@ -720,14 +720,14 @@ void launch_fill_threshold(double *thr, int64_t T, int64_t Tpad, double value, h
 // ---------------------------------------------------------------------------
 // finalize: sort the row's candidate list, exact re-rank, output
 // ---------------------------------------------------------------------------
-#define SEL_MAX 512      // candidates re-ranked exactly per row (K + near ties / key error margin)
+#define SEL_MAX 1024     // candidates re-ranked exactly per row (K + near ties / key error margin)
 
 __global__ void __launch_bounds__(256)
 knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double *__restrict__ Qp,
                     const double *__restrict__ qnorm, int64_t T, int K,
                     const int *__restrict__ cnt, const double *__restrict__ lkey,
                     const int *__restrict__ lidx, int cap, int64_t id_offset,
-                    const double *__restrict__ eps,
+                    const double *__restrict__ eps, const double *__restrict__ fnorm, double eps_c,
                     int64_t *__restrict__ cand, double *__restrict__ dist,
                     double *__restrict__ d2_out, int *__restrict__ status)
 {
@@ -753,13 +753,17 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
     // largest key of the list; every entry in the bins up to (and one past) the bin holding the
     // K-th smallest key is re-ranked exactly.  Falls back to the full sort when that set does
     // not fit SEL_MAX (massive ties).
-    double kmin = DBL_MAX, kmax = -DBL_MAX;
+    double kmin = DBL_MAX, kmax = -DBL_MAX, fmax2 = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const double v = lkey[row * cap + i];
-        key[i] = v; idx[i] = lidx[row * cap + i];
+        const int id = lidx[row * cap + i];
+        key[i] = v; idx[i] = id;
         kmin = fmin(kmin, v); kmax = fmax(kmax, v);
+        if (eps) fmax2 = fmax(fmax2, fnorm[id]);       // largest ||f||^2 among THIS row's survivors
     }
     red_min[threadIdx.x] = kmin; red_max[threadIdx.x] = kmax;
+    __shared__ double red_fm[256];
+    red_fm[threadIdx.x] = fmax2;
     hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) n_sel_s = 0;
     __syncthreads();
@@ -767,12 +771,20 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
         if (threadIdx.x < off) {
             red_min[threadIdx.x] = fmin(red_min[threadIdx.x], red_min[threadIdx.x + off]);
             red_max[threadIdx.x] = fmax(red_max[threadIdx.x], red_max[threadIdx.x + off]);
+            red_fm[threadIdx.x] = fmax(red_fm[threadIdx.x], red_fm[threadIdx.x + off]);
         }
         __syncthreads();
     }
     kmin = red_min[0]; kmax = red_max[0];
-    // keys from the f16 prefilter are only good to +-eps: widen every selection margin by 2 eps
-    const double margin = eps ? 2.0 * eps[row] : 0.0;
+    // keys from the f32 prefilter are only good to +-e_i = c (2 |q| |f_i| + |f_i|^2): every selection
+    // margin is widened by 2 max_i e_i over the survivors of THIS row (their norms, not the largest
+    // norm of the whole database that the filter threshold has to assume)
+    double margin = 0.0;
+    if (eps) {
+        const double fm = sqrt(red_fm[0]), qn = sqrt(qnorm[row]);
+        margin = 2.0 * (eps_c * (2.0 * qn * fm + fm * fm) + 1e-30);
+        if (margin > 2.0 * eps[row]) margin = 2.0 * eps[row];
+    }
     const double scale = (kmax > kmin) ? 256.0 / (kmax - kmin) : 0.0;
     bool fast = (n > SEL_MAX) && (scale > 0.0) && (kk == K);
     if (fast) {
@@ -833,7 +845,9 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
     const int n_sel = n_sel_s;
     // exact squared distance in the canonical order: acc = acc + (q_c - f_c)*(q_c - f_c),
     // c ascending, separately rounded sub / mul / add (bit-identical to the oracle)
-    for (int e = threadIdx.x; e < SEL_MAX; e += blockDim.x) {
+    int SP = 256;                         // sort size: the selection, padded to a power of two
+    while (SP < n_sel || SP < K) SP <<= 1;
+    for (int e = threadIdx.x; e < SP; e += blockDim.x) {
         double acc = DBL_MAX;
         int id = 0x7fffffff;
         if (e < n_sel) {
@@ -850,7 +864,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
         ex_idx[e] = id;
     }
     __syncthreads();
-    bitonic_sort_pairs(ex_key, ex_idx, SEL_MAX);
+    bitonic_sort_pairs(ex_key, ex_idx, SP);
     for (int j = threadIdx.x; j < K; j += blockDim.x) {
         int64_t c = -1;
         double d2 = SNK_VERY_BIG * SNK_VERY_BIG, d = SNK_VERY_BIG;
@@ -863,8 +877,8 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
 
 void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, const double *qnorm,
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
-                         int cap, int64_t id_offset, const double *eps, int64_t *cand, double *dist,
-                         double *d2_out, int *status, hipStream_t s)
+                         int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c,
+                         int64_t *cand, double *dist, double *d2_out, int *status, hipStream_t s)
 {
     int P = 2;
     while (P < cap) P <<= 1;
@@ -876,7 +890,7 @@ void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, co
         attr = shmem;
     }
     hipLaunchKernelGGL(knn_finalize_kernel, dim3((unsigned)T), dim3(256), shmem, s, Fw, Dpad, D, Qp,
-                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, cand, dist, d2_out, status);
+                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cand, dist, d2_out, status);
 }
 
 // ---------------------------------------------------------------------------

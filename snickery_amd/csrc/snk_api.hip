@@ -109,7 +109,7 @@ struct snk_engine {
     DevBuf a16h, a16l, s16h, s16l, b16h, b16l, eps16, thr32, gmin32, fmax2;
     bool f16_ready = false;
     int precision = 1;            // 1: f32 prefilter + exact f64 re-rank (default), 0: f64 sweep only
-    int nt16 = 4;
+    int nt16 = 4, nt16_eff = 4;
     int64_t n_slabs16 = 0, n_slabs16_a = 0, stride16 = 16;
     double eps_c = 8e-6;          // 2x the analytical f32 bound (knn16_kernels.hip)
     int f16_fallbacks = 0;
@@ -368,8 +368,15 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
     // f16-split operands of the prefilter (knn16_kernels.hip): needs three spare padding columns
     // for the ||f||^2 pieces and values inside the half-precision range
     h->f16_ready = false;
-    if (h->have_db && h->Dpad == 64 && h->Dpad - h->Dt >= 1) {
-        const int nt = h->nt16;
+    if (h->have_db && h->Dpad <= 256 && h->Dpad - h->Dt >= 1) {
+        // tiles per wavefront: the database fragments of a slab stay in registers (32 * Dpad / 64
+        // floats per tile and lane), so wider rows leave room for fewer tiles
+        const int dch16 = h->Dpad / 64;
+        const int nt = (dch16 == 1) ? h->nt16 : (dch16 == 2) ? 2 : 1;
+        h->nt16_eff = nt;
+        // |key~ - key| <= c (2 |q| Fmax + Fmax^2): operand rounding 2^-24 each and an f32 FMA chain of
+        // Dpad + 1 terms; c = 2 x that (8e-6 at Dpad = 64)
+        h->eps_c = 2.0 * (double)(h->Dpad + 3) * 5.9604644775390625e-08;
         CHK(h->fmax2.ensure(sizeof(double)));
         launch_fmax(h->fnorm.as<double>(), h->N, h->fmax2.as<double>(), h->stream);
         double fmax2 = 0.0;
@@ -386,7 +393,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
         h->n_slabs16_a = (h->N / stride) / slab_rows;
         if (fmax2 < 1.0e30 && h->n_slabs16_a >= 1) {
             const int64_t tiles_b = h->n_slabs16 * nt, tiles_a = h->n_slabs16_a * nt;
-            const size_t per_tile = (size_t)8 * 64 * 16;
+            const size_t per_tile = (size_t)8 * 64 * 16 * dch16;
             CHK(h->a16h.ensure(tiles_b * per_tile));
             CHK(h->s16h.ensure(tiles_a * per_tile));
             launch_build_db16(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_b, 0, 0, nt,
@@ -507,7 +514,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
     // ---- fast path: f16-split prefilter (exact results through the float64 re-rank) ----
     if (h->precision == 1 && h->f16_ready && !cls && 2 * h->n_slabs16_a >= K) {
         const int64_t G16 = 2 * h->n_slabs16_a;
-        CHK(h->b16h.ensure((size_t)(Tpad / 32) * 8 * 64 * 16));
+        CHK(h->b16h.ensure((size_t)(Tpad / 32) * 8 * 64 * 16 * (h->Dpad / 64)));
         CHK(h->eps16.ensure((size_t)Tpad * sizeof(double)));
         CHK(h->thr32.ensure((size_t)Tpad * sizeof(float)));
         CHK(h->gmin32.ensure((size_t)Tpad * G16 * sizeof(float)));
@@ -520,7 +527,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         }
         {
             StageTimer t(h, s, TM_KNN_MINIMA);
-            launch_knn_sweep16(0, h->nt16, p0.grid_cus, h->s16h.p, h->b16h.p,
+            launch_knn_sweep16(0, h->nt16_eff, h->Dpad / 64, p0.grid_cus, h->s16h.p, h->b16h.p,
                                nullptr, Tpad, h->n_slabs16_a, h->slabctr.as<unsigned int>(), h->gmin32.as<float>(),
                                G16, nullptr, nullptr, nullptr, 0, knn_pool_chunk_entries(), s);
         }
@@ -531,7 +538,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         }
         {
             StageTimer t(h, s, TM_KNN_FILTER);
-            launch_knn_sweep16(1, h->nt16, p0.grid_cus, h->a16h.p, h->b16h.p,
+            launch_knn_sweep16(1, h->nt16_eff, h->Dpad / 64, p0.grid_cus, h->a16h.p, h->b16h.p,
                                h->thr32.as<float>(), Tpad, h->n_slabs16, h->slabctr.as<unsigned int>() + 1, nullptr, 0,
                                h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
                                knn_pool_chunk_entries(), s);
@@ -545,7 +552,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             StageTimer t(h, s, TM_KNN_FINALIZE);
             launch_knn_finalize(h->Fw.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
-                                h->shard_offset, h->eps16.as<double>(), cand_dev, dist_dev, d2_dev, status_dev, s);
+                                h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), h->eps_c, cand_dev, dist_dev, d2_dev, status_dev, s);
         }
         if (deferred_status) return 0;       // the batch caller redoes failures with precision 0
         int status = 0;
@@ -598,7 +605,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             StageTimer t(h, s, TM_KNN_FINALIZE);
             launch_knn_finalize(h->Fw.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
-                                h->shard_offset, nullptr, cand_dev, dist_dev, d2_dev, status_dev, s);
+                                h->shard_offset, nullptr, nullptr, 0.0, cand_dev, dist_dev, d2_dev, status_dev, s);
         }
         if (deferred_status) return 0;
         int status = 0;

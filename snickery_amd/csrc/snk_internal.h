@@ -53,7 +53,7 @@ void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int
 // stage C: per-row select + exact re-rank in canonical order + sort
 void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, const double *qnorm,
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
-                         int cap, int64_t id_offset, const double *eps,
+                         int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c,
                          int64_t *cand, double *dist, double *d2_out, int *status, hipStream_t s);
 void launch_candidate_dist(const double *Fw, int Dpad, int D, int64_t N, const double *Qp,
                            const int64_t *cand, int64_t T, int K, double *dist, hipStream_t s);
@@ -66,7 +66,7 @@ void launch_build_db16(const double *Fw, const double *fnorm, int64_t N, int Dt,
 void launch_fmax(const double *fnorm, int64_t N, double *out, hipStream_t s);
 void launch_prepare_queries16(const double *Qp, const double *qnorm, int64_t T, int Dt, int Dpad,
                               const double *fmax2, double eps_c, void *B32, double *eps, hipStream_t s);
-bool launch_knn_sweep16(int mode, int nt, int grid_cus, const void *A32, const void *B32,
+bool launch_knn_sweep16(int mode, int nt, int dch, int grid_cus, const void *A32, const void *B32,
                         const float *thr32, int64_t T32, int64_t n_slabs, unsigned int *ctr,
                         float *gmin32, int64_t G, void *pool, unsigned int *pool_ctl, int *chunk_fill,
                         int max_chunks, int pool_chunk, hipStream_t s);

@@ -59,16 +59,24 @@ def test_knn_golden(mini_engine, golden, mini_voice):
 
 
 @pytest.mark.parametrize('N,T,K,Dt', [(20000, 100, 50, 61), (5000, 37, 100, 61), (3000, 16, 7, 20),
-                                      (9000, 50, 30, 184), (1500, 33, 200, 100), (700, 20, 16, 130)])
+                                      (9000, 50, 30, 184), (1500, 33, 200, 100), (700, 20, 16, 130),
+                                      (40000, 70, 40, 100), (40000, 45, 60, 184), (30000, 40, 25, 250),
+                                      (20000, 33, 20, 128)])
 def test_knn_synthetic(engine, N, T, K, Dt):
+    """Dt <= 63: one 64-column chunk; 100 / 184 / 250: the two-, three- and four-chunk f32 prefilter;
+    128: no spare column for the norm -> f64 sweep.  Small N: too few sample groups -> f64 sweep."""
     F_unw, JC_unw, wt, wj, F, E, S = synth_setup(N, Dt, 24, seed=N % 97)
     engine.upload_db(F_unw, JC_unw)
     engine.set_weights(wt, wj)
     U = o.synthetic_targets(F_unw, T, seed=3) * wt
+    before = engine.info('f16_fallbacks')
     cand, dist = engine.knn(U, K)
     oc, od = o.knn_bruteforce(F, U, K)
     assert np.array_equal(cand, oc)
     assert np.array_equal(dist, od)
+    if N >= 20000:
+        assert engine.info('f16_ready') == (0 if Dt % 64 == 0 else 1)
+        assert engine.info('f16_fallbacks') == before          # the prefilter's margin held
 
 
 def test_knn_ties_and_padding(engine):
