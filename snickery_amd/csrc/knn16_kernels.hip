@@ -39,6 +39,37 @@ __device__ __forceinline__ int crow32(int lane, int r) { return (r & 3) + 8 * (r
 //   value = X[row(lane & 31)][column 64*chunk + 32*(lane >> 5) + 4*j4 + i]       (DCH = Dpad / 64)
 // so each of the 8*DCH load instructions of a tile covers 1 KB of contiguous memory.
 // ---------------------------------------------------------------------------
+// database row held by row r of tile `tile`: identity for the full operand; for the sample operand
+// wave w owns tiles [w*nt_a, (w+1)*nt_a), the 16*nt_a rows a lane half reduces together are spaced
+// G sampled rows apart, and consecutive sampled rows fall into different groups
+__device__ __forceinline__ int64_t tile_row16(int64_t tile, int r, int64_t sample_stride, int64_t G, int nt_a)
+{
+    if (sample_stride <= 0) return tile * 32 + r;
+    const int64_t w = tile / nt_a;
+    const int nt = (int)(tile % nt_a);
+    const int hh = (r >> 2) & 1, reg = (r & 3) + 4 * (r >> 3);
+    const int64_t m = (int64_t)nt * 16 + reg;
+    return (m * G + (2 * w + hh)) * sample_stride;
+}
+
+// class id of every tile row in tile order (-1 beyond the database): what the class-restricted sweep
+// compares with the query's class
+__global__ void build_class16_kernel(const int32_t *__restrict__ unit_class, int64_t N, int64_t n_tiles,
+                                     int64_t sample_stride, int64_t G, int nt_a, int32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tiles * 32) return;
+    const int64_t row = tile_row16(i >> 5, (int)(i & 31), sample_stride, G, nt_a);
+    out[i] = (row < N) ? unit_class[row] : -1;
+}
+
+void launch_build_class16(const int32_t *unit_class, int64_t N, int64_t n_tiles, int64_t sample_stride, int64_t G,
+                          int nt_a, int32_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(build_class16_kernel, dim3((unsigned)((n_tiles * 32 + 255) / 256)), dim3(256), 0, s,
+                       unit_class, N, n_tiles, sample_stride, G, nt_a, out);
+}
+
 __global__ void build_db16_kernel(const double *__restrict__ Fw, const double *__restrict__ fnorm, int64_t N,
                                   int Dt, int Dpad, int64_t n_tiles, int64_t sample_stride, int64_t G,
                                   int nt_a, f32x4 *__restrict__ A32)
@@ -50,19 +81,7 @@ __global__ void build_db16_kernel(const double *__restrict__ Fw, const double *_
     const int64_t tile = item / per_tile;
     const int j4 = (int)(item % per_tile);            // chunk * 8 + j4
     const int r = lane & 31, h = lane >> 5;
-    int64_t row;
-    if (sample_stride <= 0) {
-        row = tile * 32 + r;
-    } else {
-        // scattered sample: wave w owns tiles [w*nt_a, (w+1)*nt_a); the 16*nt_a rows a lane half
-        // reduces together are spaced G sampled rows apart, consecutive sampled rows fall into
-        // different groups
-        const int64_t w = tile / nt_a;
-        const int nt = (int)(tile % nt_a);
-        const int hh = (r >> 2) & 1, reg = (r & 3) + 4 * (r >> 3);
-        const int64_t m = (int64_t)nt * 16 + reg;
-        row = (m * G + (2 * w + hh)) * sample_stride;
-    }
+    const int64_t row = tile_row16(tile, r, sample_stride, G, nt_a);
     f32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -153,9 +172,10 @@ void launch_prepare_queries16(const double *Qp, const double *qnorm, int64_t T, 
 //   MODE 0: minima per (wave slab, lane half) group over the scattered sample -> gmin32[row][G]
 //   MODE 1: filter over the whole database -> entry pool (same pool / bucket / finalize as f64)
 // ---------------------------------------------------------------------------
-template <int NT, int MODE, int DCH>
-__global__ void __launch_bounds__(256, (NT <= 2 && DCH == 1) ? 2 : 1)
+template <int NT, int MODE, int DCH, bool CLS>
+__global__ void __launch_bounds__(256, (NT <= 2 && DCH == 1 && !CLS) ? 2 : 1)
 knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
+            const int32_t *__restrict__ tile_class, const int32_t *__restrict__ query_class,
             const float *__restrict__ thr32, int nQT, int64_t n_slabs,
             unsigned int *__restrict__ slab_counter, int qsplit, int64_t n_main_slabs, int qsplit_tail,
             float *__restrict__ gmin32, int64_t G,
@@ -218,6 +238,17 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
                 af[nt][4 * j4] = v[0]; af[nt][4 * j4 + 1] = v[1]; af[nt][4 * j4 + 2] = v[2]; af[nt][4 * j4 + 3] = v[3];
             }
 
+        // class-restricted search: the class of each of this lane's 16 rows per tile; a result counts
+        // only when it equals the class of the lane's query column
+        int ucls[CLS ? NT : 1][CLS ? 16 : 1];
+        if (CLS) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ucls[nt][r] = tile_class[(w * NT + nt) * 32 + crow32(lane, r)];
+        }
+        int qc_cur = -2, qc_nxt = -2, qc_prev = -2;
+
         float b0[KS], b1[KS];
         float th_cur = 0.f, th_nxt = 0.f, th_prev = -FLT_MAX;
         auto load_q = [&](int t, float (&x)[KS]) {
@@ -227,6 +258,7 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
                 x[4 * j4] = v[0]; x[4 * j4 + 1] = v[1]; x[4 * j4 + 2] = v[2]; x[4 * j4 + 3] = v[3];
             }
             if (MODE == 1) th_nxt = thr32[t * 32 + qcol];
+            if (CLS) qc_nxt = query_class[t * 32 + qcol];
         };
         int qt = qt_lo + (int)((w * 3) % (qt_hi - qt_lo));
         int qt_prev = qt;
@@ -248,7 +280,9 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
 #pragma unroll
             for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(x[k]));
             if (MODE == 1) asm volatile("" : "+v"(th_nxt));
+            if (CLS) asm volatile("" : "+v"(qc_nxt));
             th_cur = th_nxt;
+            qc_cur = qc_nxt;
             if (MODE == 1 && lcount) flush_stage();      // staged entries leave a whole tile early
             const int qt_next = (qt + 1 == qt_hi) ? qt_lo : qt + 1;
             load_q(qt_next, nx);
@@ -257,6 +291,7 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
                 const int pnt = ((st > 0) ? st - 1 : NSTEP - 1) * CH;
                 const float pth = (st > 0) ? th_cur : th_prev;
                 const int pqt = (st > 0) ? qt : qt_prev;
+                const int pqc = (st > 0) ? qc_cur : qc_prev;
                 if (MODE == 1 && lcount > STAGE_CAP - 64 * 16 * CH) flush_stage();
                 f16acc acc[CH];
 #pragma unroll
@@ -277,14 +312,19 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
                         const int e0 = (CH == 2) ? (k - 3) : ((k - 7) >> 1);      // first result of the group
                         if (e0 + 3 < 16 * CH && (CH == 2 || (k & 7) == 7)) {
                             const int j = e0 / 16, r0 = e0 % 16;
-                            const float m4 = fminf(__builtin_fminf(__builtin_fminf(pacc[j][r0], pacc[j][r0 + 1]), pacc[j][r0 + 2]),
-                                                   pacc[j][r0 + 3]);
+                            float v4[4] = {pacc[j][r0], pacc[j][r0 + 1], pacc[j][r0 + 2], pacc[j][r0 + 3]};
+                            if (CLS) {                  // results of other classes never count (inf > any threshold)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    v4[q] = (ucls[pnt + j][r0 + q] != pqc) ? __builtin_inff() : v4[q];
+                            }
+                            const float m4 = fminf(__builtin_fminf(__builtin_fminf(v4[0], v4[1]), v4[2]), v4[3]);
                             if (MODE == 0) gm = fminf(gm, m4);
                             else if (__any(m4 <= pth)) {
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
                                     const int r = r0 + q;
-                                    const float key = pacc[j][r];
+                                    const float key = v4[q];
                                     const bool pass = key <= pth;
                                     const unsigned long long m = __ballot(pass);
                                     if (pass) {
@@ -313,6 +353,7 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
                 }
             }
             th_prev = th_cur;
+            qc_prev = qc_cur;
             qt_prev = qt;
             qt = qt_next;
         };
@@ -327,7 +368,7 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
         for (int j = 0; j < CH; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float key = pacc[j][r];
+                const float key = (CLS && ucls[(NSTEP - 1) * CH + j][r] != qc_prev) ? __builtin_inff() : pacc[j][r];
                 if (MODE == 0) gm = fminf(gm, key);
                 else {
                     const bool pass = key <= th_prev;
@@ -352,30 +393,33 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
     }
 }
 
-template <int NT, int DCH>
+template <int NT, int DCH, bool CLS>
 static void launch16_t(int mode, int blocks, hipStream_t s, const void *A32, const void *B32,
+                       const int32_t *tile_class, const int32_t *query_class,
                        const float *thr32, int nQT, int64_t n_slabs, unsigned int *ctr,
                        int qsplit, int64_t n_main, int qtail, float *gmin32, int64_t G, void *pool,
                        unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk)
 {
 #define SNK_L16(MODE_)                                                                                    \
-    hipLaunchKernelGGL((knn_sweep16<NT, MODE_, DCH>), dim3(blocks), dim3(256), 0, s, (const f32x4 *)A32,          \
-                       (const f32x4 *)B32, thr32, nQT, n_slabs, ctr, qsplit, n_main, qtail, gmin32, G, (PoolEntry16 *)pool, \
-                       pool_ctl, chunk_fill, max_chunks, pool_chunk)
+    hipLaunchKernelGGL((knn_sweep16<NT, MODE_, DCH, CLS>), dim3(blocks), dim3(256), 0, s, (const f32x4 *)A32, \
+                       (const f32x4 *)B32, tile_class, query_class, thr32, nQT, n_slabs, ctr, qsplit, n_main, qtail, \
+                       gmin32, G, (PoolEntry16 *)pool, pool_ctl, chunk_fill, max_chunks, pool_chunk)
     if (mode == 0) SNK_L16(0);
     else SNK_L16(1);
 #undef SNK_L16
 }
 
-// nt: tiles (32 units) per wave, dch: 64-column chunks per row.  Returns false when the shape is not
-// instantiated.
+// nt: tiles (32 units) per wave, dch: 64-column chunks per row; tile_class / query_class non-null:
+// class-restricted search.  Returns false when the shape is not instantiated.
 bool launch_knn_sweep16(int mode, int nt, int dch, int grid_cus, const void *A32, const void *B32,
+                        const int32_t *tile_class, const int32_t *query_class,
                         const float *thr32, int64_t T32, int64_t n_slabs, unsigned int *ctr,
                         float *gmin32, int64_t G, void *pool, unsigned int *pool_ctl, int *chunk_fill,
                         int max_chunks, int pool_chunk, hipStream_t s)
 {
+    const bool cls = tile_class != nullptr;
     const int nQT = (int)(T32 / 32);
-    const int64_t max_blocks = (int64_t)grid_cus * ((nt <= 2 && dch == 1) ? 2 : 1);
+    const int64_t max_blocks = (int64_t)grid_cus * ((nt <= 2 && dch == 1 && !cls) ? 2 : 1);
     int qsplit = 1;
     while (n_slabs * qsplit < 2 * 4 * max_blocks && qsplit * 2 <= nQT && qsplit < 8) qsplit *= 2;
     int64_t blocks = (n_slabs * qsplit + 3) / 4;
@@ -383,13 +427,15 @@ bool launch_knn_sweep16(int mode, int nt, int dch, int grid_cus, const void *A32
     int64_t n_main = n_slabs;
     int qtail = qsplit;
     sweep_tail_split(n_slabs, qsplit, blocks * 4, nQT, &n_main, &qtail);
-#define SNK_NT16(NT_, DCH_)                                                                                \
-    if (nt == NT_ && dch == DCH_) {                                                                        \
-        launch16_t<NT_, DCH_>(mode, (int)blocks, s, A32, B32, thr32, nQT, n_slabs, ctr, qsplit, n_main, qtail, \
-                              gmin32, G, pool, pool_ctl, chunk_fill, max_chunks, pool_chunk);              \
+#define SNK_NT16(NT_, DCH_, CLS_)                                                                          \
+    if (nt == NT_ && dch == DCH_ && cls == CLS_) {                                                         \
+        launch16_t<NT_, DCH_, CLS_>(mode, (int)blocks, s, A32, B32, tile_class, query_class, thr32, nQT, n_slabs, ctr, \
+                                    qsplit, n_main, qtail, gmin32, G, pool, pool_ctl, chunk_fill, max_chunks, pool_chunk); \
         return true;                                                                                       \
     }
-    SNK_NT16(4, 1) SNK_NT16(2, 1) SNK_NT16(8, 1) SNK_NT16(2, 2) SNK_NT16(1, 3) SNK_NT16(1, 4)
+    SNK_NT16(4, 1, false) SNK_NT16(2, 1, false) SNK_NT16(8, 1, false) SNK_NT16(2, 2, false) SNK_NT16(1, 3, false)
+    SNK_NT16(1, 4, false)
+    SNK_NT16(2, 1, true) SNK_NT16(2, 2, true) SNK_NT16(1, 3, true) SNK_NT16(1, 4, true)
 #undef SNK_NT16
     return false;
 }

@@ -107,7 +107,8 @@ struct snk_engine {
     DevBuf res_path, res_plen, res_cost, Qall, res_status, mcand, mdist;
     // f16-split prefilter state
     DevBuf a16h, a16l, s16h, s16l, b16h, b16l, eps16, thr32, gmin32, fmax2;
-    bool f16_ready = false;
+    bool f16_ready = false, cls16_ready = false;
+    DevBuf cls16_full, cls16_samp;      // class id per tile row of the two f32 operands
     int precision = 1;            // 1: f32 prefilter + exact f64 re-rank (default), 0: f64 sweep only
     int nt16 = 4, nt16_eff = 4;
     int64_t n_slabs16 = 0, n_slabs16_a = 0, stride16 = 16;
@@ -257,7 +258,7 @@ int snk_destroy(snk_handle h)
     DevBuf *bufs[] = {&h->F_unw, &h->JC_unw, &h->Fw, &h->fnorm, &h->JCw, &h->wt, &h->wj, &h->unit_class,
                       &h->Qraw, &h->Qp, &h->Qf, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
-                      &h->gpath, &h->gdist, &h->gsync};
+                      &h->gpath, &h->gdist, &h->gsync, &h->cls16_full, &h->cls16_samp};
     for (auto *b : bufs) b->release();
     (void)hipStreamSynchronize(h->dp_stream[1]); (void)hipStreamDestroy(h->dp_stream[1]);
     h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
@@ -368,6 +369,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
     // f16-split operands of the prefilter (knn16_kernels.hip): needs three spare padding columns
     // for the ||f||^2 pieces and values inside the half-precision range
     h->f16_ready = false;
+    h->cls16_ready = false;
     if (h->have_db && h->Dpad <= 256 && h->Dpad - h->Dt >= 1) {
         // tiles per wavefront: the database fragments of a slab stay in registers (32 * Dpad / 64
         // floats per tile and lane), so wider rows leave room for fewer tiles
@@ -420,6 +422,7 @@ int snk_set_unit_classes(snk_handle h, const int32_t *unit_class, int64_t N)
     HIPCHK(hipMemcpyAsync(h->unit_class.p, unit_class, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_classes = true;
+    h->cls16_ready = false;
     return 0;
 }
 
@@ -512,8 +515,29 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
     int *status_dev = deferred_status ? deferred_status : h->status.as<int>();
 
     // ---- fast path: f16-split prefilter (exact results through the float64 re-rank) ----
-    if (h->precision == 1 && h->f16_ready && !cls && 2 * h->n_slabs16_a >= K) {
-        const int64_t G16 = 2 * h->n_slabs16_a;
+    // class-restricted searches run the 2-tile (one chunk) / 2- / 1-tile variants of the f32 sweep
+    const int dch16 = h->Dpad / 64;
+    const int nt_run = (cls && dch16 == 1) ? 2 : h->nt16_eff;
+    const int slab_factor = h->nt16_eff / (nt_run > 0 ? nt_run : 1);
+    if (h->precision == 1 && h->f16_ready && (!cls || (h->nt16_eff % nt_run) == 0) &&
+        2 * h->n_slabs16_a * slab_factor >= K) {
+        const int64_t n_slabs_a = h->n_slabs16_a * slab_factor, n_slabs_b = h->n_slabs16 * slab_factor;
+        const int64_t G16 = 2 * n_slabs_a;
+        const int32_t *cls_full = nullptr, *cls_samp = nullptr;
+        if (cls) {
+            if (!h->cls16_ready) {
+                const int64_t tiles_b = h->n_slabs16 * h->nt16_eff, tiles_a = h->n_slabs16_a * h->nt16_eff;
+                CHK(h->cls16_full.ensure((size_t)tiles_b * 32 * sizeof(int32_t)));
+                CHK(h->cls16_samp.ensure((size_t)tiles_a * 32 * sizeof(int32_t)));
+                launch_build_class16(h->unit_class.as<int32_t>(), h->N, tiles_b, 0, 0, h->nt16_eff,
+                                     h->cls16_full.as<int32_t>(), s);
+                launch_build_class16(h->unit_class.as<int32_t>(), h->N, tiles_a, h->stride16, 2 * h->n_slabs16_a,
+                                     h->nt16_eff, h->cls16_samp.as<int32_t>(), s);
+                h->cls16_ready = true;
+            }
+            cls_full = h->cls16_full.as<int32_t>();
+            cls_samp = h->cls16_samp.as<int32_t>();
+        }
         CHK(h->b16h.ensure((size_t)(Tpad / 32) * 8 * 64 * 16 * (h->Dpad / 64)));
         CHK(h->eps16.ensure((size_t)Tpad * sizeof(double)));
         CHK(h->thr32.ensure((size_t)Tpad * sizeof(float)));
@@ -527,8 +551,8 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         }
         {
             StageTimer t(h, s, TM_KNN_MINIMA);
-            launch_knn_sweep16(0, h->nt16_eff, h->Dpad / 64, p0.grid_cus, h->s16h.p, h->b16h.p,
-                               nullptr, Tpad, h->n_slabs16_a, h->slabctr.as<unsigned int>(), h->gmin32.as<float>(),
+            launch_knn_sweep16(0, nt_run, dch16, p0.grid_cus, h->s16h.p, h->b16h.p, cls_samp, qclass_dev,
+                               nullptr, Tpad, n_slabs_a, h->slabctr.as<unsigned int>(), h->gmin32.as<float>(),
                                G16, nullptr, nullptr, nullptr, 0, knn_pool_chunk_entries(), s);
         }
         {
@@ -538,8 +562,8 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         }
         {
             StageTimer t(h, s, TM_KNN_FILTER);
-            launch_knn_sweep16(1, h->nt16_eff, h->Dpad / 64, p0.grid_cus, h->a16h.p, h->b16h.p,
-                               h->thr32.as<float>(), Tpad, h->n_slabs16, h->slabctr.as<unsigned int>() + 1, nullptr, 0,
+            launch_knn_sweep16(1, nt_run, dch16, p0.grid_cus, h->a16h.p, h->b16h.p, cls_full, qclass_dev,
+                               h->thr32.as<float>(), Tpad, n_slabs_b, h->slabctr.as<unsigned int>() + 1, nullptr, 0,
                                h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
                                knn_pool_chunk_entries(), s);
         }
@@ -684,7 +708,7 @@ int snk_knn_by_class(snk_handle h, const double *Q, int64_t T, int D, int K, con
     if (!h->have_classes) return fail("snk_knn_by_class: unit classes not set (snk_set_unit_classes)");
     if (!query_class || !cand_out || !dist_out) return fail("snk_knn_by_class: null argument");
     CHK(upload_queries(h, Q, T, D));
-    const int64_t Tpad = roundup(T, 16);
+    const int64_t Tpad = roundup(T, 32);
     CHK(h->qclass.ensure((size_t)Tpad * sizeof(int32_t)));
     HIPCHK(hipMemsetAsync(h->qclass.p, 0xfe, (size_t)Tpad * sizeof(int32_t), h->stream));
     HIPCHK(hipMemcpyAsync(h->qclass.p, query_class, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
