@@ -440,6 +440,7 @@ bool launch_knn_sweep16(int mode, int nt, int dch, int grid_cus, const void *A32
     return false;
 }
 
+#define THR16_GROUPS 1024
 // ---------------------------------------------------------------------------
 // threshold from the f32 group minima: K-th smallest of G values + eps_t, as f32 rounded UP
 // ---------------------------------------------------------------------------
@@ -450,9 +451,15 @@ knn_threshold16_kernel(const float *__restrict__ gmin32, int64_t G, int64_t T, i
     extern __shared__ float tkey[];
     const int64_t row = blockIdx.x;
     if (row >= T) { if (threadIdx.x == 0) { thr32[row] = -FLT_MAX; thr[row] = -DBL_MAX; } return; }
+    // more than 1024 groups are folded (minimum over every P-th group): the K-th smallest minimum of
+    // ANY partition of the sample into groups bounds the K-th nearest key from above
     int P = 2;
-    while (P < G) P <<= 1;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) tkey[i] = (i < G) ? gmin32[row * G + i] : FLT_MAX;
+    while (P < G && P < THR16_GROUPS) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        float m = FLT_MAX;
+        for (int64_t g = i; g < G; g += P) m = fminf(m, gmin32[row * G + g]);
+        tkey[i] = m;
+    }
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -469,7 +476,7 @@ knn_threshold16_kernel(const float *__restrict__ gmin32, int64_t G, int64_t T, i
     if (threadIdx.x == 0) {
         double v = DBL_MAX;
         float v32 = FLT_MAX;
-        if (G >= K && tkey[K - 1] < FLT_MAX) {
+        if (G >= K && P >= K && tkey[K - 1] < FLT_MAX) {
             // group minima are approximate: + eps makes the K-th smallest a true upper bound of the
             // K-th nearest key; + eps again so that the filter's approximate test keeps everything
             v = (double)tkey[K - 1] + 2.0 * eps[row];
@@ -485,7 +492,7 @@ void launch_knn_threshold16(const float *gmin32, int64_t G, int64_t T, int64_t T
                             double *thr, float *thr32, hipStream_t s)
 {
     int P = 2;
-    while (P < G) P <<= 1;
+    while (P < G && P < THR16_GROUPS) P <<= 1;
     hipLaunchKernelGGL(knn_threshold16_kernel, dim3((unsigned)T32), dim3(256), (size_t)P * sizeof(float), s,
                        gmin32, G, T, T32, K, eps, thr, thr32);
 }
