@@ -12,7 +12,7 @@ out = os.path.join(ROOT, 'profiles')
 def one(pattern):
     hits = glob.glob(os.path.join(src, pattern))
     assert hits, pattern
-    return hits[0]
+    return max(hits, key=os.path.getmtime)          # the newest run
 
 
 def counters(sub):
@@ -34,7 +34,7 @@ json.dump(bench, open(os.path.join(out, tag + '_bench.json'), 'w'), indent=1)
 shutil.copy(one('stats/*/*_kernel_stats.csv'), os.path.join(out, tag + '_kernel_stats.csv'))
 stats = list(csv.DictReader(open(os.path.join(out, tag + '_kernel_stats.csv'))))
 
-FILT = 'knn_sweep16<4, 1>'
+FILT = 'knn_sweep16<4, 1, 1, false>'
 fetch = pick(counters('fetch'), FILT)['FETCH_SIZE']
 write = pick(counters('write'), FILT)['WRITE_SIZE']
 mf = pick(counters('mfma'), FILT)
@@ -43,7 +43,7 @@ write_b = sum(write) / len(write) * 1024
 rows_per_launch = bench['roofline']['rows_per_launch']
 N, Dt = bench['config']['units'], bench['config']['target_dim']
 traffic = {
-    'kernel': 'knn_sweep16<4,1> (f32 filter)', 'rows_per_launch': rows_per_launch,
+    'kernel': 'knn_sweep16<4,1,1,false> (f32 filter)', 'rows_per_launch': rows_per_launch,
     'fetch_size_kb_reported': sum(fetch) / len(fetch), 'fetch_bytes_corrected_x2': fetch_b, 'write_bytes': write_b,
     'hbm_bytes_per_launch': fetch_b + write_b,
     'algorithmic_bytes_per_launch': N * 64 * 4 + rows_per_launch * Dt * 8 + rows_per_launch * 100 * 16,
