@@ -729,13 +729,14 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
                     const int *__restrict__ lidx, int cap, int64_t id_offset,
                     const double *__restrict__ eps, const double *__restrict__ fnorm, double eps_c,
                     int64_t *__restrict__ cand, double *__restrict__ dist,
-                    double *__restrict__ d2_out, int *__restrict__ status)
+                    double *__restrict__ d2_out, int *__restrict__ status, int *__restrict__ rowflag)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int64_t row = blockIdx.x;
     const int n_all = cnt[row];
+    if (rowflag && threadIdx.x == 0) rowflag[row] = 0;
     if (n_all > cap) {                    // list overflowed: host re-tightens and retries
-        if (threadIdx.x == 0) atomicOr(status, 1);
+        if (threadIdx.x == 0) { atomicOr(status, 1); if (rowflag) rowflag[row] = 1; }
         return;
     }
     const int n = n_all;
@@ -834,7 +835,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
                 const double kth = key[kk - 1];
                 const double delta = 1e-10 * (fabs(kth) + qnorm[row] + 1.0) + margin;
                 while (ns < n && ns < SEL_MAX && key[ns] <= kth + delta) ++ns;
-                if (ns == SEL_MAX && ns < n && key[ns] <= kth + delta) atomicOr(status, 2);
+                if (ns == SEL_MAX && ns < n && key[ns] <= kth + delta) { atomicOr(status, 2); if (rowflag) rowflag[row] = 2; }
             }
             n_sel_s = ns;
         }
@@ -878,7 +879,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
 void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, const double *qnorm,
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
                          int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c,
-                         int64_t *cand, double *dist, double *d2_out, int *status, hipStream_t s)
+                         int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s)
 {
     int P = 2;
     while (P < cap) P <<= 1;
@@ -890,7 +891,125 @@ void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, co
         attr = shmem;
     }
     hipLaunchKernelGGL(knn_finalize_kernel, dim3((unsigned)T), dim3(256), shmem, s, Fw, Dpad, D, Qp,
-                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cand, dist, d2_out, status);
+                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cand, dist, d2_out, status, rowflag);
+}
+
+// ---------------------------------------------------------------------------
+// Last resort for rows the list pipeline cannot serve (more database units tied with -- or within
+// rounding of -- the K-th neighbour than a candidate list holds: digital silence, mass duplicates):
+// one workgroup per row computes the canonical distance to EVERY unit, radix-selects the K-th
+// smallest value and takes the K smallest (distance, id) pairs, ties by lowest id.  Slow (a full
+// float64 scan per row by one workgroup) and exact by construction.
+//   scratch: n_rows x scratch_pitch doubles
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+knn_exact_rows_kernel(const double *__restrict__ Fw, int Dpad, int D, int64_t N, const double *__restrict__ Qp,
+                      const int *__restrict__ rows, int K, double *__restrict__ scratch, int64_t scratch_pitch,
+                      const int32_t *__restrict__ unit_class, const int32_t *__restrict__ query_class,
+                      int64_t id_offset, int64_t *__restrict__ cand, double *__restrict__ dist,
+                      double *__restrict__ d2_out)
+{
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long prefix_s;
+    __shared__ unsigned int want_s, n_less_s, taken_s, short_s, scan_s[1024];
+    __shared__ double skey[256];
+    __shared__ int sidx[256];
+    const int tid = threadIdx.x;
+    const int64_t row = rows[blockIdx.x];
+    double *val = scratch + (int64_t)blockIdx.x * scratch_pitch;
+    const double *q = Qp + row * Dpad;
+    const int qc = query_class ? query_class[row] : 0;
+    // 1. canonical squared distances (column by column, separately rounded sub / mul / add)
+    for (int64_t i = tid; i < N; i += 1024) {
+        double acc = __builtin_inf();
+        if (!unit_class || unit_class[i] == qc) {
+            const double *f = Fw + i * Dpad;
+            acc = 0.0;
+            for (int c = 0; c < D; ++c) {
+                const double d = __dsub_rn(q[c], f[c]);
+                acc = __dadd_rn(acc, __dmul_rn(d, d));
+            }
+        }
+        val[i] = acc;
+    }
+    __syncthreads();
+    // 2. radix select (8 x 8 bits; non-negative doubles order like their bit patterns): value of the
+    //    K-th smallest entry and the number of entries strictly below it
+    if (tid == 0) { prefix_s = 0ull; want_s = (unsigned int)K; n_less_s = 0u; short_s = 0u; }
+    __syncthreads();
+    for (int pass = 7; pass >= 0; --pass) {
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = prefix_s;
+        const int shift = 8 * pass;
+        for (int64_t i = tid; i < N; i += 1024) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(val[i]);
+            if (pass == 7 || (b >> (shift + 8)) == (prefix >> (shift + 8)))
+                atomicAdd(&hist[(b >> shift) & 255ull], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned int want = want_s, cum = 0u;
+            int b = 0;
+            for (; b < 256; ++b) { if (cum + hist[b] >= want) break; cum += hist[b]; }
+            if (b == 256) { b = 255; short_s = 1u; }        // fewer than K entries in total (N < K)
+            prefix_s = prefix | ((unsigned long long)b << shift);
+            want_s = want - cum;
+            n_less_s += cum;
+        }
+        __syncthreads();
+    }
+    const double vk = short_s ? __builtin_inf() : __longlong_as_double((long long)prefix_s);
+    const unsigned int n_less = n_less_s < (unsigned int)K ? n_less_s : (unsigned int)K;   // entries strictly below vk
+    const unsigned int n_tie = (unsigned int)K - n_less;     // how many entries equal to vk are taken (lowest ids)
+    // 3. collect: everything below vk, then the ties in id order
+    if (tid < 256) { skey[tid] = DBL_MAX; sidx[tid] = 0x7fffffff; }
+    if (tid == 0) taken_s = 0u;
+    __syncthreads();
+    for (int64_t i = tid; i < N; i += 1024)
+        if (val[i] < vk) {
+            const unsigned int slot = atomicAdd(&taken_s, 1u);
+            if (slot < 256u) { skey[slot] = val[i]; sidx[slot] = (int)i; }
+        }
+    __syncthreads();
+    unsigned int tie_base = 0u;
+    for (int64_t i0 = 0; i0 < N && tie_base < n_tie; i0 += 1024) {
+        const int64_t i = i0 + tid;
+        const unsigned int flag = (i < N && val[i] == vk && vk < __builtin_inf()) ? 1u : 0u;
+        scan_s[tid] = flag;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan
+            const unsigned int v = (tid >= off) ? scan_s[tid - off] : 0u;
+            __syncthreads();
+            scan_s[tid] += v;
+            __syncthreads();
+        }
+        const unsigned int pos = tie_base + scan_s[tid] - flag;
+        if (flag && pos < n_tie) { skey[n_less + pos] = vk; sidx[n_less + pos] = (int)i; }
+        const unsigned int total = scan_s[1023];
+        __syncthreads();
+        tie_base += total;
+    }
+    __syncthreads();
+    // 4. order by (distance, id) and write
+    bitonic_sort_pairs(skey, sidx, 256);
+    for (int j = tid; j < K; j += 1024) {
+        int64_t c = -1;
+        double d2 = SNK_VERY_BIG * SNK_VERY_BIG, d = SNK_VERY_BIG;
+        if (skey[j] < __builtin_inf() && sidx[j] != 0x7fffffff) { c = (int64_t)sidx[j] + id_offset; d2 = skey[j]; d = __dsqrt_rn(d2); }
+        if (cand) cand[row * K + j] = c;
+        if (dist) dist[row * K + j] = d;
+        if (d2_out) d2_out[row * K + j] = d2;
+    }
+}
+
+void launch_knn_exact_rows(const double *Fw, int Dpad, int D, int64_t N, const double *Qp, const int *rows,
+                           int n_rows, int K, double *scratch, int64_t scratch_pitch, const int32_t *unit_class,
+                           const int32_t *query_class, int64_t id_offset, int64_t *cand, double *dist,
+                           double *d2_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(knn_exact_rows_kernel, dim3((unsigned)n_rows), dim3(1024), 0, s, Fw, Dpad, D, N, Qp, rows, K,
+                       scratch, scratch_pitch, unit_class, query_class, id_offset, cand, dist, d2_out);
 }
 
 // ---------------------------------------------------------------------------

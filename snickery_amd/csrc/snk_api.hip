@@ -104,7 +104,8 @@ struct snk_engine {
     DevBuf Qraw, Qp, Qf, qnorm, thr, gmin, cnt, lkey, lidx, status, qclass, d2tmp, slabctr, pool, poolctl, chunkfill;
     UttSlot slot[8];
     hipStream_t dp_stream[2] = {nullptr, nullptr};
-    DevBuf res_path, res_plen, res_cost, Qall, res_status, mcand, mdist;
+    DevBuf res_path, res_plen, res_cost, Qall, res_status, mcand, mdist, rowflag, exact_rows, exact_scratch;
+    int exact_row_fallbacks = 0;
     // f16-split prefilter state
     DevBuf a16h, a16l, s16h, s16l, b16h, b16l, eps16, thr32, gmin32, fmax2;
     bool f16_ready = false, cls16_ready = false;
@@ -262,6 +263,7 @@ int snk_destroy(snk_handle h)
     for (auto *b : bufs) b->release();
     (void)hipStreamSynchronize(h->dp_stream[1]); (void)hipStreamDestroy(h->dp_stream[1]);
     h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
+    h->rowflag.release(); h->exact_rows.release(); h->exact_scratch.release();
     h->res_status.release(); h->hstage.release();
     { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2};
       for (auto *b : fb) b->release(); }
@@ -494,6 +496,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
     CHK(h->lkey.ensure((size_t)Tpad * cap * sizeof(double)));
     CHK(h->lidx.ensure((size_t)Tpad * cap * sizeof(int)));
     CHK(h->status.ensure(sizeof(int)));
+    CHK(h->rowflag.ensure((size_t)Tpad * sizeof(int)));
     // entry pool: room for ~3K survivors per row plus one partly filled chunk per resident wave
     int max_chunks = h->pool_chunks;
     {
@@ -576,7 +579,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             StageTimer t(h, s, TM_KNN_FINALIZE);
             launch_knn_finalize(h->Fw.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
-                                h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), h->eps_c, cand_dev, dist_dev, d2_dev, status_dev, s);
+                                h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), h->eps_c, cand_dev, dist_dev, d2_dev, status_dev, nullptr, s);
         }
         if (deferred_status) return 0;       // the batch caller redoes failures with precision 0
         int status = 0;
@@ -629,19 +632,39 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             StageTimer t(h, s, TM_KNN_FINALIZE);
             launch_knn_finalize(h->Fw.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
-                                h->shard_offset, nullptr, nullptr, 0.0, cand_dev, dist_dev, d2_dev, status_dev, s);
+                                h->shard_offset, nullptr, nullptr, 0.0, cand_dev, dist_dev, d2_dev, status_dev, h->rowflag.as<int>(), s);
         }
         if (deferred_status) return 0;
         int status = 0;
         HIPCHK(hipMemcpyAsync(&status, h->status.p, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         HIPCHK(hipGetLastError());
-        if (status & 2) h->tie_overflow = 1;   // > 256-K near ties at the cut: (key, id) order kept
-        if (!(status & 1)) return 0;
+        if (status == 0) return 0;
+        if ((status & 1) && attempt == 0) continue;          // a list overflowed: exact thresholds next
+        // Rows the list pipeline cannot serve: more units tied with (or within rounding of) the K-th
+        // neighbour than a list or the exact re-rank holds -- mass duplicates.  They get the
+        // one-workgroup-per-row exact selection (slow, exact, ties by lowest id).
+        std::vector<int> flags((size_t)T);
+        HIPCHK(hipMemcpyAsync(flags.data(), h->rowflag.p, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<int> rows;
+        for (int64_t t = 0; t < T; ++t) if (flags[(size_t)t]) rows.push_back((int)t);
+        if (status & 2) h->tie_overflow = 1;
+        for (size_t r0 = 0; r0 < rows.size(); r0 += 64) {    // 64 rows (x Nalloc doubles of scratch) at a time
+            const int n = (int)((rows.size() - r0 < 64) ? rows.size() - r0 : 64);
+            CHK(h->exact_rows.ensure((size_t)64 * sizeof(int)));
+            CHK(h->exact_scratch.ensure((size_t)64 * h->Nalloc * sizeof(double)));
+            HIPCHK(hipMemcpyAsync(h->exact_rows.p, rows.data() + r0, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+            launch_knn_exact_rows(h->Fw.as<double>(), h->Dpad, h->Dt, h->N, h->Qp.as<double>(), h->exact_rows.as<int>(), n, K,
+                                  h->exact_scratch.as<double>(), h->Nalloc, uc, qclass_dev, h->shard_offset,
+                                  cand_dev, dist_dev, d2_dev, s);
+            HIPCHK(hipStreamSynchronize(s));
+        }
+        HIPCHK(hipGetLastError());
+        h->exact_row_fallbacks += (int)rows.size();
+        return 0;
     }
-    return fail("K-NN: a candidate list overflowed its capacity (%d) even with exact thresholds: more "
-                "than %d database units are tied with the K-th neighbour of a query (mass duplicates) "
-                "or list_capacity < %d", cap, cap, p.nt * K);
+    return fail("K-NN: internal error (attempt loop fell through)");
 }
 
 static int check_ready(snk_engine *h, bool need_target, bool need_join)
@@ -1261,6 +1284,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "last_knn_retries")) *out = h->last_retries;
     else if (!strcmp(name, "list_capacity")) *out = h->cap;
     else if (!strcmp(name, "tie_overflow")) *out = h->tie_overflow;
+    else if (!strcmp(name, "exact_row_fallbacks")) *out = h->exact_row_fallbacks;
     else if (!strcmp(name, "batch_redos")) *out = h->batch_redos;
     else if (!strcmp(name, "f16_ready")) *out = h->f16_ready ? 1 : 0;
     else if (!strcmp(name, "f16_fallbacks")) *out = h->f16_fallbacks;

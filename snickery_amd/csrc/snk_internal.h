@@ -51,10 +51,14 @@ void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int
                        int max_chunks, int64_t Tpad, int64_t n_valid, int *cnt, double *lkey, int *lidx,
                        int cap, int *status, hipStream_t s);
 // stage C: per-row select + exact re-rank in canonical order + sort
+void launch_knn_exact_rows(const double *Fw, int Dpad, int D, int64_t N, const double *Qp, const int *rows,
+                           int n_rows, int K, double *scratch, int64_t scratch_pitch, const int32_t *unit_class,
+                           const int32_t *query_class, int64_t id_offset, int64_t *cand, double *dist,
+                           double *d2_out, hipStream_t s);
 void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, const double *qnorm,
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
                          int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c,
-                         int64_t *cand, double *dist, double *d2_out, int *status, hipStream_t s);
+                         int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s);
 void launch_candidate_dist(const double *Fw, int Dpad, int D, int64_t N, const double *Qp,
                            const int64_t *cand, int64_t T, int K, double *dist, hipStream_t s);
 void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, int K,

@@ -327,3 +327,34 @@ def test_error_behaviour(engine):
         engine.knn(np.zeros((4, 60)), 5)              # wrong dimension
     with pytest.raises(snickery_amd.SnkError):
         engine.greedy(np.zeros((4, 61)))              # layout not set
+
+
+def test_knn_mass_duplicates(engine):
+    """More database units exactly tied with the K-th neighbour than a candidate list holds (digital
+    silence in a real voice): the rows fall through to the exact one-workgroup-per-row selection and
+    come back in the reference order -- distance, then lowest unit id."""
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(30000, 61, 24, seed=17)
+    F_unw = F_unw.copy()
+    F_unw[2000:9000] = F_unw[1234]                 # 7000 identical "silence" frames (> list capacity 4096)
+    F_unw[9000:9050] = F_unw[1234] + 1e-4          # and a few near them
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    F = o.weight(F_unw, wt)
+    U = np.vstack([(F_unw[1234] + 0.01) * wt, o.synthetic_targets(F_unw, 5, seed=2) * wt, F_unw[1234] * wt])
+    before = engine.info('exact_row_fallbacks')
+    cand, dist = engine.knn(U, 60)
+    oc, od = o.knn_bruteforce(F, U, 60)
+    assert np.array_equal(cand, oc) and np.array_equal(dist, od)
+    assert engine.info('exact_row_fallbacks') - before >= 2
+    assert list(cand[6, :3]) == [1234, 2000, 2001] and dist[6, 0] == 0.0
+    # the same through the class-restricted search and the batch entry point
+    cls = (np.arange(30000) % 3).astype(np.int32)
+    engine.set_unit_classes(cls)
+    qc = np.array([0, 1, 2, 0, 1, 2, 1], dtype=np.int32)
+    cand, dist = engine.knn_by_class(U, 60, qc)
+    oc, od = o.knn_by_class(F, U, 60, cls, qc)
+    assert np.array_equal(cand, oc) and np.array_equal(dist, od)
+    paths, costs = engine.knn_viterbi_batch([U, U[:3]], 60)
+    oc, od = o.knn_bruteforce(F, U, 60)
+    op, ocst = o.viterbi(oc, od, E, S)
+    assert list(paths[0]) == op and costs[0] == ocst
