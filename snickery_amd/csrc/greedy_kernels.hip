@@ -82,13 +82,12 @@ __device__ void greedy_write_table(const GreedyArgs &a, int64_t step, int64_t pr
     }
 }
 
-// acc += sum over the 32 columns of a chunk of (fl64(x) * w - ref)^2, in the canonical column order
-// with separately rounded operations.  `row` is the window's row of the chunk in LDS, `tc` the
-// chunk's (w, ref) pairs in LDS (read as 16-byte broadcasts).  Eight columns are in flight at a
-// time: their conversions, products and squares are independent, only the eight final additions
-// form a chain -- written out that way so that neither LDS latency nor the latency of dependent
-// float64 operations is exposed when a SIMD holds a single wavefront.
-__device__ __forceinline__ double greedy_accumulate_chunk(const float *row, const double *__restrict__ tc, double acc)
+// acc += sum over `ngroups` x 8 consecutive columns of (fl64(x) * w - ref)^2, in the canonical column
+// order with separately rounded operations.  `row` points at the window's columns in LDS, `tc` at
+// their (w, ref) pairs in the step's table.  Eight columns are in flight at a time: their
+// conversions, products and squares are independent, only the eight final additions form a chain.
+__device__ __forceinline__ double greedy_accumulate_chunk(const float *row, const double *__restrict__ tc, double acc,
+                                                          int ngroups = GR_CC / 8)
 {
     // `tc`: the chunk's 32 (w, ref) pairs in GLOBAL memory at a wave-uniform address: scalar loads
     // into SGPRs (no LDS bandwidth, no vector registers), requested one group of eight columns ahead
@@ -110,23 +109,21 @@ __device__ __forceinline__ double greedy_accumulate_chunk(const float *row, cons
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc = __dadd_rn(acc, sq[i]);     // padded columns: w = ref = 0 adds +0.0
     };
-    // the loads of group g+1 are issued (and pinned there) before group g is consumed
+    // the loads of group g+1 are issued (and pinned there) before group g is consumed; `ngroups`
+    // (even) groups of eight columns, contiguous in the row and in the table
     Group A, B;
     load(0, A);
     __builtin_amdgcn_sched_barrier(0);
-    load(1, B);
-    __builtin_amdgcn_sched_barrier(0);
-    consume(A);
-    __builtin_amdgcn_sched_barrier(0);
-    load(2, A);
-    __builtin_amdgcn_sched_barrier(0);
-    consume(B);
-    __builtin_amdgcn_sched_barrier(0);
-    load(3, B);
-    __builtin_amdgcn_sched_barrier(0);
-    consume(A);
-    __builtin_amdgcn_sched_barrier(0);
-    consume(B);
+    for (int g = 0; g < ngroups; g += 2) {
+        load(g + 1, B);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(A);
+        __builtin_amdgcn_sched_barrier(0);
+        load(g + 2 < ngroups ? g + 2 : g, A);           // the last trip re-reads its own group: never consumed
+        __builtin_amdgcn_sched_barrier(0);
+        consume(B);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     return acc;
 }
 
@@ -293,8 +290,7 @@ greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__r
         for (int s = 0; s < GR_NSTG; ++s) fetch(s, stage[s]);
         for (int k = 0; k < a.nep; ++k) {
             const float *frow = Fs + (size_t)(tid + a.ep[k]) * fpitch;
-            for (int c2 = 0; c2 < tch; ++c2)
-                acc_t = greedy_accumulate_chunk(frow + c2 * GR_CC, tab + 2 * (size_t)(jch + k * tch + c2) * GR_CC, acc_t);
+            acc_t = greedy_accumulate_chunk(frow, tab + 2 * (size_t)(jch + k * tch) * GR_CC, acc_t, tch * (GR_CC / 8));
         }
         __syncthreads();                                 // the chunk buffers alias the block
     }
