@@ -166,6 +166,22 @@ int snk_merge_viterbi_batch_dev(snk_handle h, const double *d2_dev, const int64_
 /* upload the FULL join matrix only (ranks that run the Viterbi of an utterance) */
 int snk_upload_join_only(snk_handle h, const float *JC_unw, int64_t Njc, int Dj);
 
+/* Waveform side (the step after the search).  Replaces retrieve_magphase_frag
+ * (synth_simple.py:538-652) and the overlap-add loop of concatenateMagPhaseEpoch_sep_files
+ * (:677-747) up to the call of the external vocoder.
+ *   snk_upload_frames: the analysis frames of ALL database utterances, concatenated:
+ *     spec (rows, 3*H) float32 = [mag | real | imag] per frame, fzv (rows, 2) float64 =
+ *     [interpolated f0, voicing flag] (speech_manip.lin_interp_f0 on the host).
+ *   snk_concat_fragments: n selected units; first_row[k] = frame row of unit k's first frame,
+ *     [utt_lo[k], utt_hi[k]) = frame rows of its utterance; multiepoch frames per unit, `overlap`
+ *     (even, <= multiepoch) cross-fade frames with the Hann weights in_taper (overlap entries,
+ *     matrix_operations.py:19).  Outputs (n*multiepoch rows): spec_out (rows, 3*H) float64,
+ *     fz_out (rows) float64 with unvoiced frames zeroed. */
+int snk_upload_frames(snk_handle h, const float *spec, const double *fzv, int64_t rows, int H);
+int snk_concat_fragments(snk_handle h, const int64_t *first_row, const int64_t *utt_lo, const int64_t *utt_hi,
+                         int64_t n, int multiepoch, int overlap, const double *in_taper,
+                         double *spec_out, double *fz_out);
+
 /* Engine tuning / introspection (not part of the reference surface) */
 int snk_set_option(snk_handle h, const char *name, double value);
 int snk_get_info(snk_handle h, const char *name, double *value_out);

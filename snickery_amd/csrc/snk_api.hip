@@ -105,6 +105,8 @@ struct snk_engine {
     UttSlot slot[8];
     hipStream_t dp_stream[2] = {nullptr, nullptr};
     DevBuf res_path, res_plen, res_cost, Qall, res_status, mcand, mdist, rowflag, exact_rows, exact_scratch;
+    DevBuf frames_spec, frames_fzv, cc_in, cc_out;      // waveform-side gather
+    int64_t frames_rows = 0; int frames_W = 0;
     int exact_row_fallbacks = 0;
     // f16-split prefilter state
     DevBuf a16h, a16l, s16h, s16l, b16h, b16l, eps16, thr32, gmin32, fmax2;
@@ -264,6 +266,7 @@ int snk_destroy(snk_handle h)
     (void)hipStreamSynchronize(h->dp_stream[1]); (void)hipStreamDestroy(h->dp_stream[1]);
     h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
     h->rowflag.release(); h->exact_rows.release(); h->exact_scratch.release();
+    h->frames_spec.release(); h->frames_fzv.release(); h->cc_in.release(); h->cc_out.release();
     h->res_status.release(); h->hstage.release();
     { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2};
       for (auto *b : fb) b->release(); }
@@ -1217,6 +1220,67 @@ int snk_merge_viterbi_batch_dev(snk_handle h, const double *d2_dev, const int64_
         CHK(staged_d2h(h, h->stream, parts, 3));
     }
     collect_timers(h);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// waveform-side gather
+// ---------------------------------------------------------------------------
+int snk_upload_frames(snk_handle h, const float *spec, const double *fzv, int64_t rows, int H)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (!spec || !fzv || rows < 1 || H < 1) return fail("snk_upload_frames: null/empty argument");
+    const size_t W = (size_t)3 * H;
+    CHK(h->frames_spec.ensure((size_t)rows * W * sizeof(float)));
+    CHK(h->frames_fzv.ensure((size_t)rows * 2 * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->frames_spec.p, spec, (size_t)rows * W * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->frames_fzv.p, fzv, (size_t)rows * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->frames_rows = rows;
+    h->frames_W = (int)W;
+    return 0;
+}
+
+int snk_concat_fragments(snk_handle h, const int64_t *first_row, const int64_t *utt_lo, const int64_t *utt_hi,
+                         int64_t n, int multiepoch, int overlap, const double *in_taper,
+                         double *spec_out, double *fz_out)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->frames_rows < 1) return fail("snk_concat_fragments: no analysis frames uploaded (snk_upload_frames)");
+    if (!first_row || !utt_lo || !utt_hi || !spec_out || !fz_out || n < 1) return fail("snk_concat_fragments: null/empty argument");
+    if (multiepoch < 1) return fail("snk_concat_fragments: multiepoch < 1");
+    if (overlap < 0 || (overlap % 2) != 0) return fail("snk_concat_fragments: frame overlap should be even number");
+    if (overlap > 0 && !in_taper) return fail("snk_concat_fragments: null taper");
+    if (overlap > 0 && 2 * overlap > multiepoch + overlap)
+        return fail("snk_concat_fragments: taper_length (%d) too long for (padded) unit length (%d)", overlap, multiepoch + overlap);
+    for (int64_t k = 0; k < n; ++k) {
+        if (utt_lo[k] < 0 || utt_hi[k] > h->frames_rows || utt_lo[k] >= utt_hi[k] || first_row[k] < utt_lo[k] ||
+            first_row[k] >= utt_hi[k])
+            return fail("snk_concat_fragments: unit %lld lies outside its utterance / the uploaded frames", (long long)k);
+        // the reference slices silently short (and asserts) when a window runs past its utterance without overlap
+        if (overlap == 0 && first_row[k] + multiepoch > utt_hi[k])
+            return fail("snk_concat_fragments: unit %lld runs past the end of its utterance (needs overlap > 0)", (long long)k);
+    }
+    const int64_t rows_out = n * multiepoch;
+    const size_t W = (size_t)h->frames_W;
+    const size_t in_bytes = (size_t)n * 3 * sizeof(int64_t) + (size_t)(overlap > 0 ? overlap : 1) * sizeof(double);
+    CHK(h->cc_in.ensure(in_bytes));
+    CHK(h->cc_out.ensure((size_t)rows_out * (W + 1) * sizeof(double)));
+    int64_t *d_first = h->cc_in.as<int64_t>(), *d_lo = d_first + n, *d_hi = d_lo + n;
+    double *d_taper = reinterpret_cast<double *>(d_hi + n);
+    HIPCHK(hipMemcpyAsync(d_first, first_row, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_lo, utt_lo, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_hi, utt_hi, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    if (overlap > 0) HIPCHK(hipMemcpyAsync(d_taper, in_taper, (size_t)overlap * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    double *d_spec = h->cc_out.as<double>(), *d_fz = d_spec + (size_t)rows_out * W;
+    launch_concat_fragments(h->frames_spec.as<float>(), (int)W, h->frames_fzv.as<double>(), d_first, d_lo, d_hi, n,
+                            multiepoch, overlap, d_taper, d_spec, d_fz, h->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(spec_out, d_spec, (size_t)rows_out * W * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(fz_out, d_fz, (size_t)rows_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
 

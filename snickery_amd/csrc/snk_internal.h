@@ -121,6 +121,11 @@ void launch_path_scores(const GreedyLayout &g, int mode, const float *F_unw, int
                         const int64_t *path, int64_t L, double *tsq, double *jsq, int jcols,
                         hipStream_t s);
 
+// ---- waveform-side gather ----------------------------------------------------
+void launch_concat_fragments(const float *spec, int W, const double *fzv, const int64_t *first_row,
+                             const int64_t *utt_lo, const int64_t *utt_hi, int64_t n, int me, int ov,
+                             const double *in_taper, double *out_spec, double *out_fz, hipStream_t s);
+
 // ---- self test --------------------------------------------------------------
 void launch_mfma_selftest(const double *A, const double *B, double *C, hipStream_t s);
 

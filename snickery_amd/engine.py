@@ -68,6 +68,9 @@ _SIGNATURES = {
     'snk_merge_viterbi_batch_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                    _c_i64p, ctypes.c_int, ctypes.c_int, _c_i64p, _c_i64p, _c_f64p]),
     'snk_upload_join_only': (ctypes.c_int, [ctypes.c_void_p, _c_f32p, ctypes.c_int64, ctypes.c_int]),
+    'snk_upload_frames': (ctypes.c_int, [ctypes.c_void_p, _c_f32p, _c_f64p, ctypes.c_int64, ctypes.c_int]),
+    'snk_concat_fragments': (ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_i64p, _c_i64p, ctypes.c_int64, ctypes.c_int,
+                                            ctypes.c_int, _c_f64p, _c_f64p, _c_f64p]),
     'snk_set_option': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]),
     'snk_get_info': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, _c_f64p]),
     'snk_selftest_mfma': (ctypes.c_int, [ctypes.c_void_p, _c_f64p]),
@@ -325,6 +328,30 @@ class HipSearchEngine(object):
                                                           _ptr(offs, _c_i64p), len(lengths), int(n_candidates),
                                                           _ptr(paths, _c_i64p), _ptr(plen, _c_i64p), _ptr(cost, _c_f64p)))
         return [paths[offs[u]:offs[u] + plen[u]].copy() for u in range(len(lengths))], cost
+
+    # -- waveform side ----------------------------------------------------------
+    def upload_frames(self, spec, fzv):
+        """spec (rows, 3*H) float32 = [mag | real | imag], fzv (rows, 2) float64 = [f0_interp, vuv]."""
+        spec = np.ascontiguousarray(spec, dtype=np.float32)
+        fzv = _f64(fzv)
+        assert spec.ndim == 2 and spec.shape[1] % 3 == 0 and fzv.shape == (spec.shape[0], 2)
+        self._check(self._lib.snk_upload_frames(self._h, _ptr(spec, _c_f32p), _ptr(fzv, _c_f64p), spec.shape[0],
+                                                spec.shape[1] // 3))
+        self._frames_H = spec.shape[1] // 3
+
+    def concat_fragments(self, first_row, utt_lo, utt_hi, multiepoch, overlap, in_taper):
+        first_row = np.ascontiguousarray(first_row, dtype=np.int64)
+        utt_lo = np.ascontiguousarray(utt_lo, dtype=np.int64)
+        utt_hi = np.ascontiguousarray(utt_hi, dtype=np.int64)
+        taper = _f64(in_taper if overlap > 0 else [0.0])
+        n = first_row.size
+        spec = np.empty((n * multiepoch, 3 * self._frames_H), dtype=np.float64)
+        fz = np.empty((n * multiepoch,), dtype=np.float64)
+        self._check(self._lib.snk_concat_fragments(self._h, _ptr(first_row, _c_i64p), _ptr(utt_lo, _c_i64p),
+                                                   _ptr(utt_hi, _c_i64p), n, int(multiepoch), int(overlap),
+                                                   _ptr(taper, _c_f64p), _ptr(spec, _c_f64p), _ptr(fz, _c_f64p)))
+        H = self._frames_H
+        return spec[:, :H], spec[:, H:2 * H], spec[:, 2 * H:], fz.reshape((-1, 1))
 
     # -- introspection ----------------------------------------------------------
     def timers(self):

@@ -324,3 +324,50 @@ def get_mean_std(feat_dir_dict, stream_list, datadims, flist):
         means.append(mean)
         stds.append(get_std(stream_files, datadims[stream], mean, exclude_uv=uv))
     return np.hstack(means), np.hstack(stds)
+
+
+# --------------------------------------------------------------------------
+# Waveform side: analysis frames of the selected units (synth_simple.py:507-747)
+# --------------------------------------------------------------------------
+FFTHALFLEN = 513                   # const.py: bins of the full-resolution magphase spectra
+
+
+def lin_interp_f0(fz):
+    """speech_manip.py:222-244: f0 linearly interpolated (and extrapolated) through the unvoiced
+    stretches, and the voicing flag; both (n, 1).  Same scipy call as the reference."""
+    import scipy.interpolate
+    y = np.asarray(fz).flatten()
+    voiced_ix = np.where(y > 0.0)[0]
+    voicing_flag = np.zeros(y.shape)
+    voicing_flag[voiced_ix] = 1.0
+    if voiced_ix.shape[0] == 0:
+        v_interpolated = np.asarray(fz)
+    else:
+        interpolator = scipy.interpolate.interp1d(voiced_ix, y[voiced_ix], kind='linear', axis=0,
+                                                  bounds_error=False, fill_value='extrapolate')
+        v_interpolated = interpolator(np.arange(y.shape[0]))
+    return (v_interpolated.reshape((-1, 1)), voicing_flag.reshape((-1, 1)))
+
+
+def in_taper(taper_length):
+    """matrix_operations.py:19: the rising half of the Hann cross-fade (the falling half is its mirror)."""
+    return np.hanning(((taper_length + 1) * 2) + 1)[1:taper_length + 1]
+
+
+def load_full_spectra(full_magphase_dir, names, fft_half_len=FFTHALFLEN):
+    """The mag / real / imag / f0 analysis files of the given utterances (synth_simple.py:558-563),
+    concatenated: spec (rows, 3*H) float32, fzv (rows, 2) float64 = [interpolated f0, voicing], and
+    {name: (first_row, end_row)}."""
+    specs, fzvs, spans, row = [], [], {}, 0
+    for name in names:
+        parts = [get_speech(os.path.join(full_magphase_dir, s, name + '.' + s), fft_half_len) for s in ('mag', 'real', 'imag')]
+        f0 = get_speech(os.path.join(full_magphase_dir, 'f0', name + '.f0'), 1)
+        n = parts[0].shape[0]
+        if not all(p.shape[0] == n for p in parts) or f0.shape[0] != n:
+            raise ValueError('analysis streams of %s differ in length' % name)
+        f0_interp, vuv = lin_interp_f0(f0)
+        specs.append(np.hstack(parts))
+        fzvs.append(np.hstack([f0_interp.astype(np.float64), vuv]))
+        spans[name] = (row, row + n)
+        row += n
+    return np.vstack(specs), np.vstack(fzvs), spans

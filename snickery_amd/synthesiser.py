@@ -283,6 +283,42 @@ class Synthesiser(object):
         self.stop_clock(t)
         return (candidates, distances)
 
+    def load_full_magphase(self, fft_half_len=hp.FFTHALFLEN):
+        """preload_all_magphase_utts (synth_simple.py:525-535): the full-resolution analysis frames of
+        every database utterance, resident on the device (1 M frames: 6.2 GB of 288)."""
+        names = []
+        for fn in self.train_filenames:
+            fn = fn.decode() if isinstance(fn, bytes) else str(fn)
+            if not names or names[-1] != fn:
+                if fn in names:
+                    raise ValueError('utterance %s is not contiguous in the database' % fn)
+                names.append(fn)
+        spec, fzv, self._frame_spans = hp.load_full_spectra(self.config['full_magphase_dir'], names, fft_half_len)
+        self.engine.upload_frames(spec, fzv)
+
+    def concatenate_magphase(self, path, overlap=None, fzero=None):
+        """retrieve_magphase_frag + the overlap-add of concatenateMagPhaseEpoch_sep_files
+        (synth_simple.py:538-747) up to the vocoder call: returns (mag, real, imag, fz), what the
+        reference hands to magphase.synthesis_from_lossless."""
+        if overlap is None:
+            overlap = self.config.get('magphase_overlap', 0)
+        assert overlap % 2 == 0, 'frame overlap should be even number'
+        if not hasattr(self, '_frame_spans'):
+            self.load_full_magphase()
+        multiepoch = self.config.get('multiepoch', 1)
+        first, lo, hi = [], [], []
+        for index in path:
+            fn = self.train_filenames[index]
+            fn = fn.decode() if isinstance(fn, bytes) else str(fn)
+            a, b = self._frame_spans[fn]
+            first.append(a + int(self.unit_index_within_sentence[index]))
+            lo.append(a)
+            hi.append(b)
+        mag, real, imag, fz = self.engine.concat_fragments(first, lo, hi, multiepoch, overlap, hp.in_taper(overlap))
+        if fzero is not None and np.size(fzero) > 0:
+            fz = fzero
+        return mag, real, imag, fz
+
     def join_knn(self, k, first=0, last=None):
         """Nearest `unit_end_data` rows of `unit_start_data[first:last]`: the K-NN of
         initialise_join_table_with_knn (active_learning_join.py:184-212: sklearn KDTree over

@@ -120,3 +120,24 @@ suppress_weird_festival_pauses = True
     with open(os.path.join(labdir, 'arctic_b0001.lab'), 'w') as f:
         f.write('\n'.join(lines) + '\n')
     return cfgfile, config, override
+
+
+def write_full_spectra(root, frames_per_utt, H, seed=77):
+    """Synthetic 'high/' analysis data (full_magphase_dir): per utterance mag / real / imag (frames, H)
+    and f0 (frames, 1) with unvoiced stretches (f0 = 0), float32 files in the reference's layout.
+    Shared by tools/make_golden.py (input of the reference's concatenation) and the tests."""
+    rng = np.random.RandomState(seed)
+    for stream in ('mag', 'real', 'imag', 'f0'):
+        os.makedirs(os.path.join(root, stream), exist_ok=True)
+    for name, n in frames_per_utt:
+        for stream in ('mag', 'real', 'imag'):
+            (rng.rand(n, H) * 2.0 + (0.5 if stream == 'mag' else -1.0)).astype(np.float32).tofile(
+                os.path.join(root, stream, name + '.' + stream))
+        f0 = 120.0 + 30.0 * np.sin(np.arange(n) / 9.0) + rng.rand(n)
+        pos = 0
+        while pos < n:
+            seg = int(rng.randint(4, 25))
+            if rng.rand() < 0.35:
+                f0[pos:pos + seg] = 0.0
+            pos += seg
+        f0.astype(np.float32).reshape(-1, 1).tofile(os.path.join(root, 'f0', name + '.f0'))

@@ -67,6 +67,8 @@ def convert_reference(tmp):
     patch('synth_halfphone.py', 'm/multiepoch', 'm//multiepoch')
     patch('synth_halfphone.py', ':n/2]', ':n//2]')
     patch('synth_halfphone.py', 'n/2:]', 'n//2:]')
+    patch('synth_simple.py', 'extra_frames=overlap/2', 'extra_frames=overlap//2')
+    patch('synth_simple.py', 'taper = overlap / 2', 'taper = overlap // 2')
     patch('train_simple.py', 'unit_names = np.array(unit_names)',
           "unit_names = np.array(unit_names).astype('S50')")
     patch('train_simple.py', 'filenames = [base] * m',
@@ -331,6 +333,50 @@ def main():
         trimmed = hp_speech[labs[4][0][1]:labs[-5][0][0]]    # as if the terminal silences had been trimmed
         fixtures['halfphone_reinserted_silence'] = train_halfphone.reinsert_terminal_silence(trimmed, labs)
         fixtures['halfphone_trimmed_range'] = np.array([labs[4][0][1], labs[-5][0][0]], dtype=np.int64)
+
+        # ---- waveform-side concatenation (synth_simple.py:538-747): retrieve_magphase_frag +
+        # concatenateMagPhaseEpoch_sep_files up to the vocoder call, on synthetic analysis data with a
+        # 17-bin spectrum (module constant patched at run time) ----
+        sys.path.insert(0, os.path.join(HERE, '..', 'tests'))
+        import voice_fixture
+        H = 17
+        synth_simple.FFTHALFLEN = H
+        cfgfile6 = os.path.join(tmp, 'mini_me6.cfg')
+        synth6 = synth_simple.Synthesiser(cfgfile6)
+        # py3: the HDF5 byte strings must be str for the reference's path joins
+        synth6.train_filenames = np.array([f.decode() if isinstance(f, bytes) else str(f) for f in synth6.train_filenames])
+        utt_frames = []
+        for base in sorted(set(fn.decode() if isinstance(fn, bytes) else str(fn) for fn in synth6.train_filenames)):
+            n = int(np.sum(np.array([f.decode() if isinstance(f, bytes) else str(f) for f in synth6.train_filenames]) == base))
+            utt_frames.append((base, n))
+        voice_fixture.write_full_spectra(os.path.join(data, 'high'), utt_frames, H, seed=77)
+        synth6.config['full_magphase_dir'] = os.path.join(data, 'high')
+        captured_syn = []
+        synth_simple.magphase.synthesis_from_lossless = lambda mag, real, imag, fz, sr: captured_syn.append(
+            (np.array(mag), np.array(real), np.array(imag), np.array(fz))) or np.zeros(4)
+        synth_simple.la.write_audio_file = lambda *a, **k: None
+        n_units = len(synth6.train_filenames)
+        uix = np.array(synth6.unit_index_within_sentence)
+        starts = np.nonzero(uix == 0)[0]
+        # a path with an utterance start (zero padding in front), windows that run past an utterance end
+        # (zero padding behind), ordinary windows and an immediate repeat
+        cpath = [int(starts[1]), int(starts[1]) + 6, int(starts[2]) - 3, int(starts[2]) - 6, 40, 46, 46, 300, int(starts[3]) - 1,
+                 int(fixtures['greedy_me6_utt0_path'][5])]
+        # (without overlap the reference asserts on windows that run past an utterance end)
+        safe_path = [int(starts[1]), int(starts[1]) + 6, 40, 46, 46, 300, int(fixtures['greedy_me6_utt0_path'][5])]
+        fixtures['concat_path_no_overlap'] = np.array(safe_path, dtype=np.int64)
+        for ov in (2, 0, 4):
+            synth6.concatenateMagPhaseEpoch_sep_files(cpath if ov else safe_path, os.path.join(tmp, 'x.wav'), overlap=ov)
+            m_, r_, i_, f_ = captured_syn[-1]
+            fixtures['concat_ov%d_mag' % ov] = m_
+            fixtures['concat_ov%d_real' % ov] = r_
+            fixtures['concat_ov%d_imag' % ov] = i_
+            fixtures['concat_ov%d_fz' % ov] = f_
+        fixtures['concat_path'] = np.array(cpath, dtype=np.int64)
+        fixtures['concat_utt_frames'] = np.array([n for (b, n) in utt_frames], dtype=np.int64)
+        fixtures['concat_utt_names'] = np.array([b for (b, n) in utt_frames]).astype('S50')
+        fixtures['concat_filenames'] = np.array(synth6.train_filenames).astype('S50')
+        fixtures['concat_unit_index'] = uix.astype(np.int32)
 
         # ---- the reference's balance_stream_weights.py (host logic only) driven by a deterministic
         # stand-in Synthesiser (tests/bsw_stub.py): recorded weight trajectory and result ----
