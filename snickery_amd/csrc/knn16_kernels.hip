@@ -182,7 +182,9 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
             PoolEntry16 *__restrict__ pool, unsigned int *__restrict__ pool_ctl, int *__restrict__ chunk_fill,
             int max_chunks, int pool_chunk)
 {
-    constexpr int STAGE_CAP = 64 * 16 * 2 + 256;
+    // per-wave staging area of survivors (a few per 32x32 tile); flushed to the wave's pool chunk one
+    // tile later, or on the spot when a burst would not fit (up to 256 entries per group of four results)
+    constexpr int STAGE_CAP = 768;
     __shared__ PoolEntry16 stage[(MODE == 1) ? 4 : 1][(MODE == 1) ? STAGE_CAP : 1];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -292,7 +294,6 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
                 const float pth = (st > 0) ? th_cur : th_prev;
                 const int pqt = (st > 0) ? qt : qt_prev;
                 const int pqc = (st > 0) ? qc_cur : qc_prev;
-                if (MODE == 1 && lcount > STAGE_CAP - 64 * 16 * CH) flush_stage();
                 f16acc acc[CH];
 #pragma unroll
                 for (int j = 0; j < CH; ++j)
@@ -321,6 +322,7 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
                             const float m4 = fminf(__builtin_fminf(__builtin_fminf(v4[0], v4[1]), v4[2]), v4[3]);
                             if (MODE == 0) gm = fminf(gm, m4);
                             else if (__any(m4 <= pth)) {
+                                if (lcount > STAGE_CAP - 256) flush_stage();
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
                                     const int r = r0 + q;
@@ -363,7 +365,6 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
             if (it + 1 < n_t) tile_body(b1, b0, it + 1);
         }
         // drain the last pending step of this work item
-        if (MODE == 1 && lcount > STAGE_CAP - 64 * 16 * CH) flush_stage();
 #pragma unroll
         for (int j = 0; j < CH; ++j)
 #pragma unroll
@@ -371,6 +372,7 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
                 const float key = (CLS && ucls[(NSTEP - 1) * CH + j][r] != qc_prev) ? __builtin_inff() : pacc[j][r];
                 if (MODE == 0) gm = fminf(gm, key);
                 else {
+                    if (lcount > STAGE_CAP - 64) flush_stage();
                     const bool pass = key <= th_prev;
                     const unsigned long long m = __ballot(pass);
                     if (pass) {
