@@ -88,7 +88,7 @@ def main():
     ap.add_argument('--units', type=int, default=1048576)
     ap.add_argument('--frames', type=int, default=600)
     ap.add_argument('--candidates', type=int, default=100)
-    ap.add_argument('--utts', type=int, default=16, help='utterances per step (batch)')
+    ap.add_argument('--utts', type=int, default=32, help='utterances per step (batch)')
     ap.add_argument('--target-dim', type=int, default=61)
     ap.add_argument('--join-dim', type=int, default=302)
     ap.add_argument('--cpu-sample-frames', type=int, default=48)

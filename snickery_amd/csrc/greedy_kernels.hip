@@ -9,9 +9,9 @@
 //
 // The windowed database is never materialised (the reference hstacks an (N-me+1) x 517 float64
 // copy, 4.1 GB at N = 1 M): window i reads rows i..i+me-1 of the UNWEIGHTED float32 feature
-// matrix and row i of the unweighted join matrix as the HDF5 file stores them (rows padded to a
-// multiple of 4 floats on the device, so every access is 16 bytes wide) and applies the float64
-// stream weights on the fly (fl64(f32 * w) is bit-identical to the
+// matrix and row i of the unweighted join matrix -- from a lane-major copy of the two matrices
+// that the device keeps for this scan (greedy_tile_kernel; built once per database and layout) --
+// and applies the float64 stream weights on the fly (fl64(f32 * w) is bit-identical to the
 // reference's speech_manip.weight()).  Every step is therefore a stream over (Dj + Dt) * 4
 // bytes per unit (HBM-bound by design).  Squared distances are accumulated in the canonical
 // oracle order (column by column, separately rounded sub/mul/add), so the argmin is bit-exact.
@@ -22,11 +22,8 @@
 
 namespace snk {
 
-#define GR_R 256          // windows per workgroup (one thread per window)
-#define GR_CC 32          // columns per staged chunk (8 float4 per row)
-#define GR_NSTG 3         // chunks in flight in registers per thread
-#define GR_NFL 18         // 16-byte loads per thread that fetch a resident target block
-#define GR_LP 36          // LDS row pitch in floats: 16-byte aligned rows, conflict-free 128-bit access
+#define GR_CC 32          // columns per chunk (8 float4 per window)
+#define GR_NSTG 3         // ring stages (chunks) in registers per thread: GR_NSTG - 1 requests ahead of the arithmetic
 #define GR_MAX_EP 16      // max multiepoch
 #define GR_S1 256          // arrival counters of the first / second level (see greedy_finish_step)
 #define GR_S2 16
@@ -36,31 +33,53 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct GreedyArgs {
     const float *JC_unw; int Jp, Dj; const double *wj;   // Jp / Fp: row pitch in floats (multiple of 4,
     const float *F_unw; int Fp, Dt; const double *wt;    // zero-filled padding columns)
+    const f32x4 *JT, *FT;                 // lane-major tiles of the scan columns (greedy_tile_kernel)
     int me, nep; int ep[GR_MAX_EP];       // epochs of the window that enter the target term
     int prev_col0, cur_col0, jdim;
     int64_t prev_row0, cur_row0, Nwin;
     int64_t n_jc_rows, n_f_rows;          // matrix heights (clamp for the ragged last workgroup)
     const double *Q;                      // (T, Dt) weighted targets, row-major
+    int lds_mode;                         // 1: target rows in LDS, interleaved chunk order (greedy_step_kernel)
 };
 
 __device__ __forceinline__ int greedy_join_chunks(const GreedyArgs &a) { return (a.jdim + GR_CC - 1) / GR_CC; }
 __device__ __forceinline__ int greedy_target_chunks(const GreedyArgs &a) { return (a.Dt + GR_CC - 1) / GR_CC; }
 
+// Chunk order of a window's scan.  Plain order (lds_mode 0): the join chunks, then the
+// target chunks epoch by epoch.  Interleaved order (lds_mode 1): join chunk j is followed
+// by the target chunks [j*nT/jch, (j+1)*nT/jch) -- the join chunks come from HBM, the target chunks
+// from LDS, and spreading the first among the second gives every HBM request several chunks of
+// arithmetic to land behind.  The two partial sums are separate accumulators, so only the order
+// within each kind matters for the result.
+// Slot c -> join chunk (returns true, *idx = j) or target chunk (returns false, *idx = k*tch + cc).
+__device__ __forceinline__ bool greedy_chunk_slot(const GreedyArgs &a, int jch, int nT, int c, int *idx)
+{
+    if (!a.lds_mode) {
+        if (c < jch) { *idx = c; return true; }
+        *idx = c - jch; return false;
+    }
+    int j = 0;
+    while (j + 1 < jch && (j + 1) + ((j + 1) * nT) / jch <= c) ++j;      // last join chunk at or before slot c
+    if (c == j + (j * nT) / jch) { *idx = j; return true; }
+    *idx = c - j - 1;
+    return false;
+}
+
 // The (weight, reference) pair of every column of the scan in chunk order -- join columns against
-// `prev`, then the target columns of each epoch against the query rows of this step -- padded with
-// (0, 0) to whole chunks.  Built by one workgroup for the NEXT step; the scan stages it in LDS and reads it with
-// 16-byte LDS broadcasts.
+// `prev`, target columns of each epoch against the query rows of this step -- padded with (0, 0) to
+// whole chunks.  Built by one workgroup for the NEXT step; the scan reads it with scalar loads.
 // prev_row < 0: prev = 0 (np.zeros, synth_simple.py:467-468).
 __device__ void greedy_write_table(const GreedyArgs &a, int64_t step, int64_t prev_row, bool prev_is_current,
                                    double *__restrict__ tab, int tid, int nthreads)
 {
     const int jch = greedy_join_chunks(a), tch = greedy_target_chunks(a);
-    const int n = (jch + a.nep * tch) * GR_CC;
+    const int nT = a.nep * tch, n = (jch + nT) * GR_CC;
     for (int e = tid; e < n; e += nthreads) {
         const int c = e / GR_CC, cc = e % GR_CC;
         double w = 0.0, ref = 0.0;
-        if (c < jch) {
-            const int col = c * GR_CC + cc;
+        int idx;
+        if (greedy_chunk_slot(a, jch, nT, c, &idx)) {
+            const int col = idx * GR_CC + cc;
             if (col < a.jdim) {
                 w = a.wj[a.prev_col0 + col];
                 if (prev_row >= 0) {
@@ -71,7 +90,7 @@ __device__ void greedy_write_table(const GreedyArgs &a, int64_t step, int64_t pr
                 }
             }
         } else {
-            const int k = (c - jch) / tch, col = ((c - jch) % tch) * GR_CC + cc;
+            const int k = idx / tch, col = (idx % tch) * GR_CC + cc;
             if (col < a.Dt) {
                 w = a.wt[col];
                 ref = a.Q[(step * a.me + a.ep[k]) * a.Dt + col];
@@ -82,52 +101,36 @@ __device__ void greedy_write_table(const GreedyArgs &a, int64_t step, int64_t pr
     }
 }
 
-// acc += sum over `ngroups` x 8 consecutive columns of (fl64(x) * w - ref)^2, in the canonical column
-// order with separately rounded operations.  `row` points at the window's columns in LDS, `tc` at
-// their (w, ref) pairs in the step's table.  Eight columns are in flight at a time: their
-// conversions, products and squares are independent, only the eight final additions form a chain.
-__device__ __forceinline__ double greedy_accumulate_chunk(const float *row, const double *__restrict__ tc, double acc,
-                                                          int ngroups = GR_CC / 8)
+// Lane-major tiles of the scan columns.  The scan gives every window (= database row) to one lane
+// and walks its columns in order, so the row-major matrices would need a transposition through LDS
+// in front of the arithmetic (two phases per workgroup, a barrier per chunk, 78 KB of LDS and only
+// two workgroups per compute unit: measured 4.5 TB/s with the arithmetic removed).  Instead the
+// device keeps a second copy in the order the scan reads:
+//     tile[row / 64][q][row % 64] = float4 of columns col0 + 4q .. col0 + 4q + 3 of `row`
+// (Q float4 groups per row, zero-filled beyond `ncols`), so that ONE 16-byte load per lane fetches
+// four columns of 64 consecutive windows as 1 KB of consecutive addresses, straight into the
+// registers the arithmetic reads.  No LDS, no barrier in the scan.
+__global__ void greedy_tile_kernel(const float *__restrict__ src, int pitch, int64_t nrows, int col0, int ncols,
+                                   int Q, int64_t n_elems, f32x4 *__restrict__ dst)
 {
-    // `tc`: the chunk's 32 (w, ref) pairs in GLOBAL memory at a wave-uniform address: scalar loads
-    // into SGPRs (no LDS bandwidth, no vector registers), requested one group of eight columns ahead
-    struct Group { float4 x0, x1; double w[8], r[8]; };
-    auto load = [&](int g, Group &G) {
-        G.x0 = *reinterpret_cast<const float4 *>(row + 8 * g);
-        G.x1 = *reinterpret_cast<const float4 *>(row + 8 * g + 4);
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_elems) return;
+    const int lane = (int)(idx & 63);
+    const int64_t g = idx >> 6;
+    const int q = (int)(g % Q);
+    const int64_t r = (g / Q) * 64 + lane;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < nrows) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { G.w[i] = tc[2 * (8 * g + i)]; G.r[i] = tc[2 * (8 * g + i) + 1]; }
-    };
-    auto consume = [&](const Group &G) {
-        const float xs[8] = {G.x0.x, G.x0.y, G.x0.z, G.x0.w, G.x1.x, G.x1.y, G.x1.z, G.x1.w};
-        double sq[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const double d = __dsub_rn(__dmul_rn((double)xs[i], G.w[i]), G.r[i]);
-            sq[i] = __dmul_rn(d, d);
+        for (int e = 0; e < 4; ++e) {
+            const int col = 4 * q + e;
+            if (col < ncols) v[e] = src[r * pitch + col0 + col];
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc = __dadd_rn(acc, sq[i]);     // padded columns: w = ref = 0 adds +0.0
-    };
-    // the loads of group g+1 are issued (and pinned there) before group g is consumed; `ngroups`
-    // (even) groups of eight columns, contiguous in the row and in the table
-    Group A, B;
-    load(0, A);
-    __builtin_amdgcn_sched_barrier(0);
-    for (int g = 0; g < ngroups; g += 2) {
-        load(g + 1, B);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(A);
-        __builtin_amdgcn_sched_barrier(0);
-        load(g + 2 < ngroups ? g + 2 : g, A);           // the last trip re-reads its own group: never consumed
-        __builtin_amdgcn_sched_barrier(0);
-        consume(B);
-        __builtin_amdgcn_sched_barrier(0);
     }
-    return acc;
+    dst[idx] = v;
 }
 
-// Tail of a step, shared by both scan kernels: workgroup (min, argmin) -> global memory; the
+// Tail of a step: workgroup (min, argmin) -> global memory; the
 // workgroup that arrives LAST (sc1 stores drained before an arrival counter, sc1 loads after) reduces all
 // partial results, appends the winner to the path and writes the next step's table (its
 // `current_join_rep` row is the next `prev`).
@@ -138,10 +141,12 @@ __device__ void greedy_finish_step(const GreedyArgs &a, int64_t step, int64_t ns
                                    double *red_v, int64_t *red_i, int *is_last_p)
 {
     const int tid = threadIdx.x;
+    int top = 1;                                          // half of the next power of two >= blockDim.x
+    while (2 * top < (int)blockDim.x) top <<= 1;
     red_v[tid] = best; red_i[tid] = arg;
     __syncthreads();
-    for (int off = GR_R / 2; off > 0; off >>= 1) {
-        if (tid < off) {
+    for (int off = top; off > 0; off >>= 1) {
+        if (tid < off && tid + off < (int)blockDim.x) {
             const double v2 = red_v[tid + off];
             const int64_t i2 = red_i[tid + off];
             if (v2 < red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid])) { red_v[tid] = v2; red_i[tid] = i2; }
@@ -174,15 +179,15 @@ __device__ void greedy_finish_step(const GreedyArgs &a, int64_t step, int64_t ns
     if (!*is_last_p) return;
     // ---- last workgroup: global argmin (lowest index on exact ties), path, next step's table ----
     best = DBL_MAX; arg = INT64_MAX;
-    for (int b = tid; b < (int)gridDim.x; b += GR_R) {
+    for (int b = tid; b < (int)gridDim.x; b += (int)blockDim.x) {
         const double v = __hip_atomic_load(&blk_min[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int64_t i = __hip_atomic_load(&blk_arg[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v < best || (v == best && i < arg)) { best = v; arg = i; }
     }
     red_v[tid] = best; red_i[tid] = arg;
     __syncthreads();
-    for (int off = GR_R / 2; off > 0; off >>= 1) {
-        if (tid < off) {
+    for (int off = top; off > 0; off >>= 1) {
+        if (tid < off && tid + off < (int)blockDim.x) {
             const double v2 = red_v[tid + off];
             const int64_t i2 = red_i[tid + off];
             if (v2 < red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid])) { red_v[tid] = v2; red_i[tid] = i2; }
@@ -194,130 +199,208 @@ __device__ void greedy_finish_step(const GreedyArgs &a, int64_t step, int64_t ns
         path[step] = ix;
         if (dist) dist[step] = __dsqrt_rn(red_v[0]);
     }
-    if (step + 1 < nsteps) greedy_write_table(a, step + 1, ix, true, tab_next, tid, GR_R);
+    if (step + 1 < nsteps) greedy_write_table(a, step + 1, ix, true, tab_next, tid, (int)blockDim.x);
 }
 
-// One step of the greedy search = ONE launch:
-//   every workgroup scans GR_R consecutive windows (thread t owns window i0+t) with 16-byte global
-//   loads, LDS writes and LDS reads (rows are padded to a multiple of 4 floats on the device).
-//   Target term: the workgroup's GR_R + me - 1 target rows are read once into LDS and every epoch
-//   of every window is accumulated from there (wider targets: streamed chunk by chunk instead).
-//   Join term: 32-column chunks stream through LDS, GR_NSTG chunks in flight in registers.
-//   Thread t accumulates its window's squared distance in the canonical column order, weights
-//   and references coming from the step's table.  The workgroup's (min, argmin) goes to global
-//   memory; the workgroup that arrives LAST (sc1 stores / arrival tree / sc1 loads) reduces all
-//   partial results, appends the winner to the path and writes the next step's table (its
-//   `current_join_rep` row is the next `prev`).
-__global__ void __launch_bounds__(GR_R)
+// One step of the greedy search = ONE launch of a persistent grid: one workgroup of up to 8 wavefronts
+// per compute unit; every wavefront owns 64-window tiles (tile t -> wavefront t mod #wavefronts) and
+// never waits for another.  Every lane owns one window of the tile and accumulates its squared
+// distance in the canonical column order, weights and references coming from the step's table.
+//
+//   Join columns: 16-byte loads from the lane-major tiles (greedy_tile_kernel) straight into the
+//   registers the arithmetic reads -- 1 KB of consecutive addresses per wavefront and request, no
+//   transposition through LDS.
+//   Target columns, lds_mode 1 (the default): the 64 + me - 1 target rows a tile's windows cover are
+//   loaded ONCE (lane = row; the me - 1 extra rows by the first lanes only) and written to the
+//   wavefront's private LDS block [row][column]; every epoch of every window reads its row from there
+//   (16-byte LDS reads, conflict-free at a pitch of 4 mod 64 floats).
+//   Target columns, lds_mode 0 (rows too wide for LDS): every epoch re-reads its rows from the
+//   tiles; those re-reads hit L2, whose path into a compute unit carries ~70 GB/s -- measured
+//   328 us per step at magphase-60 widths with the arithmetic removed, against 160 us of HBM time.
+//   One request ring per wavefront carries the chunks (32 columns) of successive tiles, GR_NSTG - 1
+//   chunks ahead of the arithmetic; it never drains inside a step.
+//   The step's (weight, reference) table is copied to LDS once per workgroup (the only barrier of
+//   the scan) and read from there with 16-byte broadcast reads, four columns ahead of the
+//   arithmetic.  (Scalar loads of the table cost ~150 ns each here and can only be waited for with
+//   lgkmcnt(0), so a request cannot stay in flight across a wait: the scan ran at the scalar-load
+//   latency.  LDS reads return in order: counted waits.)
+//
+//   The workgroup's (min, argmin) goes to global memory; the workgroup that arrives LAST (sc1
+//   stores / arrival tree / sc1 loads) reduces all partial results, appends the winner to the path
+//   and writes the next step's table (its `current_join_rep` row is the next `prev`).
+//
+// Software pipelining: every load is an ordinary load, so the compiler places the counted waits
+// itself and copies or spills a register only after its load has landed (loads written as inline
+// asm look complete to the register allocator the moment they issue: a copy between such a load
+// and its wait reads garbage -- seen here as results that changed from run to run).  What keeps a
+// request ahead of its use is the empty `asm volatile("" ::: "memory")` behind it: a load cannot
+// be sunk across a statement that may write memory.  The "+v" operands of the other empty
+// statements tie the arithmetic to the program order (without them the scheduler moves the
+// arithmetic of one batch in front of the requests for the next).
+#define GR_W 64            // windows per wavefront tile
+#define GR_MAXW 8          // wavefronts per workgroup
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <bool IN_LDS>
+__global__ void __launch_bounds__(GR_W * GR_MAXW)
 greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__restrict__ tab,
                    double *__restrict__ tab_next, double *__restrict__ blk_min, int64_t *__restrict__ blk_arg,
                    unsigned int *__restrict__ arrive, int64_t *__restrict__ path, double *__restrict__ dist)
 {
-    __shared__ __align__(16) float buf[2][GR_R][GR_LP];
-    __shared__ double red_v[GR_R];
-    __shared__ int64_t red_i[GR_R];
+    extern __shared__ __align__(16) char lds[];          // table | one target block per wavefront (lds_mode 1)
     __shared__ int is_last;
-    const int tid = threadIdx.x;
-    const int64_t i0 = (int64_t)blockIdx.x * GR_R;
-
-    // chunk schedule: part 0 = join columns, parts 1..nep = target columns of epoch ep[k]
+    const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: scalar address arithmetic
+    constexpr bool in_lds = IN_LDS;                      // == (a.lds_mode != 0)
     const int jch = greedy_join_chunks(a), tch = greedy_target_chunks(a);
-    double acc_j = 0.0, acc_t = 0.0;
+    const int nT = a.nep * tch, n_chunks = jch + nT, JQ = jch * 8, FQ = tch * 8;
+    const int pitch = tch * GR_CC + 4;
+    const int nB = a.me > 1 ? tch : 0;                   // chunks of the me - 1 extra rows
+    const int ring_per_tile = in_lds ? tch + nB + jch : n_chunks;
+    const int table_bytes = n_chunks * GR_CC * 16;
+    float *const Fs = reinterpret_cast<float *>(lds + table_bytes) + (size_t)wave * (GR_W + a.me - 1) * pitch;
+    const int ntiles = (int)((a.Nwin + GR_W - 1) / GR_W);
+    const int wave_id = blockIdx.x * nwaves + wave, wave_stride = gridDim.x * nwaves;
+    const int my_tiles = wave_id < ntiles ? (ntiles - 1 - wave_id) / wave_stride + 1 : 0;
+    const int total = my_tiles * ring_per_tile;          // ring chunks this wavefront consumes
 
-    // Target term from a resident block: when the GR_R + me - 1 target rows of this workgroup fit the
-    // LDS of the chunk buffers (magphase-60: 261 rows x 68 floats), they are read from HBM ONCE and
-    // every epoch of every window is accumulated from LDS; the chunked loop below then streams the
-    // join columns only.  Otherwise the target columns go through the chunk loop too, epoch by epoch
-    // (each target row is then re-read once per epoch, through L2).
-    const int frows = GR_R + a.me - 1, fpitch = a.Fp + 4;
-    // (whole 32-column chunks only: the accumulation reads 32 floats per chunk from a row)
-    const bool resident = (a.Fp % GR_CC) == 0 && (size_t)frows * fpitch * sizeof(float) <= sizeof(buf);
-    // Chunk loop: join columns (and the target columns when they are not resident).  GR_NSTG chunks
-    // are in flight in registers.  The loads are inline asm: the compiler sinks ordinary loads of a
-    // software pipeline to their use (measured: no load was in flight behind the arithmetic), and it
-    // does not count asm loads in its own vmcnt waits, so every wait here is explicit.  Stage s is
-    // consumed in chunk order, so before chunk c at most GR_NSTG-1 younger chunks (8 loads each) may
-    // still be outstanding.
-    const int n_chunks = resident ? jch : jch + a.nep * tch;
-    const int lr = tid >> 3, lq = tid & 7;          // this lane's row (mod 32) and float4 of a chunk
+    // request side: (tile, position in the tile's ring sequence).  A wavefront's 64 rows of one float4
+    // column group are 1 KB of consecutive addresses: scalar base + a per-lane byte offset (the tile
+    // arrays are padded with zero-filled tiles, so no row index needs a clamp).
+    //   lds_mode 1: own target rows, extra rows, join chunks;  lds_mode 0: the table's chunk order
+    int f_tile = wave_id, f_pos = 0;
+    const unsigned off_own = (unsigned)lane * 16u;
+    const unsigned off_extra = (unsigned)(lane < a.me - 1 ? lane : (a.me > 1 ? a.me - 2 : 0)) * 16u;
+    const unsigned jl = (unsigned)lane + (unsigned)a.prev_row0;
+    const unsigned off_join = (jl >> 6) * ((unsigned)JQ << 10) + (jl & 63u) * 16u;
+    const char *const FTb = reinterpret_cast<const char *>(a.FT), *const JTb = reinterpret_cast<const char *>(a.JT);
     f32x4 stage[GR_NSTG][8];
-    auto fetch = [&](int c, f32x4 (&st)[8]) {
-        if (c >= n_chunks) c = n_chunks - 1;          // surplus request: re-read, never consumed
-        const float *base; int pitch, col0; int64_t row0, nrows;
-        if (c < jch) {
-            base = a.JC_unw; pitch = a.Jp; row0 = a.prev_row0 + i0; nrows = a.n_jc_rows;
-            col0 = a.prev_col0 + c * GR_CC;
+    auto fetch = [&](f32x4 (&st)[8], int pin0) {
+        const int t = f_tile < ntiles ? f_tile : ntiles - 1;      // surplus request: re-read, never consumed
+        const char *base;
+        unsigned voff = off_own;
+        if (in_lds) {
+            if (f_pos < tch) base = FTb + (((size_t)t * FQ + f_pos * 8) << 10);
+            else if (f_pos < tch + nB) {
+                // the me - 1 extra rows = first rows of the next tile; the other lanes repeat the last
+                // of them (same cache line; every lane takes part, no exec mask around the loads)
+                base = FTb + (((size_t)(t + 1) * FQ + (f_pos - tch) * 8) << 10);
+                voff = off_extra;
+            } else { base = JTb + (((size_t)t * JQ + (f_pos - tch - nB) * 8) << 10); voff = off_join; }
+        } else if (f_pos < jch) {
+            base = JTb + (((size_t)t * JQ + f_pos * 8) << 10); voff = off_join;
         } else {
-            const int k = (c - jch) / tch;
-            base = a.F_unw; pitch = a.Fp; row0 = i0 + a.ep[k]; nrows = a.n_f_rows;
-            col0 = ((c - jch) % tch) * GR_CC;
+            const int k = (f_pos - jch) / tch, cc = (f_pos - jch) - k * tch;
+            const unsigned fl = (unsigned)lane + (unsigned)a.ep[k];       // row of epoch k: may reach into the next tile
+            base = FTb + (((size_t)t * FQ + cc * 8) << 10);
+            voff = (fl >> 6) * ((unsigned)FQ << 10) + (fl & 63u) * 16u;
         }
-        col0 += 4 * lq;
-        if (col0 > pitch - 4) col0 = pitch - 4;       // float4s beyond the padded row: finite data, weight 0
+        voff += (unsigned)pin0;
+        // nt: bytes this launch reads once (-5 % per step); the target re-reads of lds_mode 0 are not
+        if (in_lds || f_pos < jch) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            int64_t row = row0 + 32 * j + lr;         // 8 lanes cover 128 bytes of one row
-            if (row >= nrows) row = nrows - 1;
-            const float *src = base + row * pitch + col0;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st[j]) : "v"(src) : "memory");
+            for (int j = 0; j < 8; ++j)
+                st[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + voff + 1024 * j));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st[j] = *reinterpret_cast<const f32x4 *>(base + voff + 1024 * j);
         }
+        asm volatile("" ::: "memory");                  // the requests stay here (see above)
+        if (++f_pos == ring_per_tile) { f_pos = 0; f_tile += wave_stride; }
     };
-    if (!resident) {
+    // the first requests go out before the table copy, and land behind it
 #pragma unroll
-        for (int s = 0; s < GR_NSTG; ++s) fetch(s, stage[s]);
+    for (int s = 0; s < GR_NSTG - 1; ++s) fetch(stage[s], 0);
+
+    // the step's table -> LDS
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(tab);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
+        for (int e = tid; e < table_bytes / 16; e += blockDim.x) dst[e] = src[e];
     }
-    if (resident) {
-        float *Fs = &buf[0][0][0];
-        const int fq = a.Fp >> 2, nq = frows * fq;       // float4s of the block
-        // all of a thread's loads are in flight together (GR_NFL x 16 bytes; the block holds at most
-        // sizeof(buf) / 16 = 4608 float4 = 18 per thread)
-        f32x4 v[GR_NFL];
-#pragma unroll
-        for (int u = 0; u < GR_NFL; ++u) {
-            const int e = u * GR_R + tid;
-            int64_t row = i0 + (e < nq ? e / fq : 0);
-            if (row >= a.n_f_rows) row = a.n_f_rows - 1;
-            v[u] = *reinterpret_cast<const f32x4 *>(a.F_unw + row * a.Fp + 4 * (e < nq ? e % fq : 0));
-        }
-#pragma unroll
-        for (int u = 0; u < GR_NFL; ++u) {
-            const int e = u * GR_R + tid;
-            if (e < nq) *reinterpret_cast<f32x4 *>(Fs + (size_t)(e / fq) * fpitch + 4 * (e % fq)) = v[u];
-        }
-        __syncthreads();
-        // the first join chunks are requested now and land behind the target arithmetic
-#pragma unroll
-        for (int s = 0; s < GR_NSTG; ++s) fetch(s, stage[s]);
-        for (int k = 0; k < a.nep; ++k) {
-            const float *frow = Fs + (size_t)(tid + a.ep[k]) * fpitch;
-            acc_t = greedy_accumulate_chunk(frow, tab + 2 * (size_t)(jch + k * tch) * GR_CC, acc_t, tch * (GR_CC / 8));
-        }
-        __syncthreads();                                 // the chunk buffers alias the block
-    }
-    auto consume = [&](int c, f32x4 (&st)[8]) {
-        float (*B)[GR_LP] = buf[c & 1];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4 *>(&B[32 * j + lr][4 * lq]) = st[j];
-        __syncthreads();
-        fetch(c + GR_NSTG, st);                       // refill this stage
-        const double acc = greedy_accumulate_chunk(&B[tid][0], tab + 2 * (size_t)c * GR_CC, (c < jch) ? acc_j : acc_t);
-        if (c < jch) acc_j = acc; else acc_t = acc;
-    };
-    for (int c0 = 0; c0 < n_chunks; c0 += GR_NSTG) {
-#pragma unroll
-        for (int s = 0; s < GR_NSTG; ++s) {
-            // chunk c0+s: everything but the (GR_NSTG-1) younger chunks has landed
-            asm volatile("s_waitcnt vmcnt(%8)"
-                         : "+v"(stage[s][0]), "+v"(stage[s][1]), "+v"(stage[s][2]), "+v"(stage[s][3]),
-                           "+v"(stage[s][4]), "+v"(stage[s][5]), "+v"(stage[s][6]), "+v"(stage[s][7])
-                         : "n"(8 * (GR_NSTG - 1)) : "memory");
-            if (c0 + s < n_chunks) consume(c0 + s, stage[s]);      // uniform
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus requests of the last trip
+    __syncthreads();
+
+    // consume side: the table is read strictly in chunk order (greedy_chunk_slot), wrapping at the end
+    // of a window.  tq[b & 1][i] = (w, ref) of column i of batch b (four columns = 64 bytes, the same
+    // address in every lane: a broadcast read).
     double best = DBL_MAX;
     int64_t arg = INT64_MAX;
-    if (i0 + tid < a.Nwin) { best = __dadd_rn(acc_j, acc_t); arg = i0 + tid; }
+    double acc_j = 0.0, acc_t = 0.0;
+    int c_tile = wave_id, c_pos = 0, t_done = 0, slot = 0;
+    // tq[c & 7] = (w, ref) of column c of the stream: a sliding window of eight columns, the read for
+    // column c + 7 issued before column c is computed (its slot held column c - 1)
+    f64x2 tq[8];
+    int pin = 0;                                          // always 0; orders the refill behind the arithmetic
+    const f64x2 *const table = reinterpret_cast<const f64x2 *>(lds);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) tq[c] = table[c];
+    asm volatile("" ::: "memory");
+    // one chunk of arithmetic: x[g] = columns 4g .. 4g+3 of the chunk, table columns slot*32 .. slot*32+31
+    auto chunk = [&](f32x4 (&x)[8], double acc) -> double {
+        const f64x2 *const cur = table + slot * GR_CC;
+        if (++slot == n_chunks) slot = 0;
+        const f64x2 *const nxt = table + slot * GR_CC;
+#pragma unroll
+        for (int c = 0; c < GR_CC; ++c) {
+            tq[(c + 7) & 7] = c + 7 < GR_CC ? cur[c + 7] : nxt[c + 7 - GR_CC];
+            asm volatile("" ::: "memory");              // the request stays here
+            float xv = x[c >> 2][c & 3];
+            asm volatile("" : "+v"(xv));                // column c: behind the request for column c + 7
+            const f64x2 t = tq[c & 7];
+            const double d = __dsub_rn(__dmul_rn((double)xv, t.x), t.y);
+            acc = __dadd_rn(acc, __dmul_rn(d, d));        // padded columns: w = ref = 0 adds +0.0
+        }
+        return acc;
+    };
+    auto end_of_window = [&]() {
+        const int64_t i = (int64_t)c_tile * GR_W + lane;
+        const double d = __dadd_rn(acc_j, acc_t);
+        if (i < a.Nwin && d < best) { best = d; arg = i; }           // windows visited in increasing order
+        acc_j = 0.0; acc_t = 0.0; c_pos = 0; t_done = 0; c_tile += wave_stride;
+    };
+    auto handle = [&](f32x4 (&st)[8]) {
+        if (!in_lds) {
+            // chunk order of the table = ring order: join chunks, then the target chunks of each epoch
+            if (c_pos < jch) acc_j = chunk(st, acc_j); else acc_t = chunk(st, acc_t);
+            asm volatile("" : "+v"(acc_j), "+v"(acc_t), "+v"(pin));
+        } else if (c_pos < tch + nB) {
+            const bool extra = c_pos >= tch;
+            const int col = (extra ? c_pos - tch : c_pos) * GR_CC;
+            if (!extra || lane < a.me - 1) {
+                float *dst = Fs + (size_t)(extra ? lane + GR_W : lane) * pitch + col;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4 *>(dst + 4 * j) = st[j];
+            }
+        } else {
+            // join chunk j, then its share of the target chunks (interleaved order, greedy_chunk_slot)
+            const int j = c_pos - tch - nB;
+            acc_j = chunk(st, acc_j);
+            asm volatile("" : "+v"(acc_j), "+v"(pin));
+            const int t_goal = ((j + 1) * nT) / jch;
+            for (; t_done < t_goal; ++t_done) {
+                const int k = t_done / tch, cc = t_done - k * tch;
+                const float *row = Fs + (size_t)(lane + a.ep[k]) * pitch + cc * GR_CC;
+                f32x4 x[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = *reinterpret_cast<const f32x4 *>(row + 4 * q);
+                acc_t = chunk(x, acc_t);
+            }
+        }
+        if (++c_pos == ring_per_tile) end_of_window();
+    };
+    // Stage s holds ring chunk g with g % GR_NSTG == s.  Before chunk g is consumed, chunk g + GR_NSTG - 1
+    // is requested into the stage that chunk g - 1 has just left.
+    for (int g0 = 0; g0 < total; g0 += GR_NSTG) {
+#pragma unroll
+        for (int s = 0; s < GR_NSTG; ++s) {
+            fetch(stage[(s + GR_NSTG - 1) % GR_NSTG], pin);
+            asm volatile("" : "+v"(stage[s][0]), "+v"(pin));          // consume behind the request
+            if (g0 + s < total) handle(stage[s]);       // uniform
+        }
+    }
+    __syncthreads();                                      // the reduction arrays alias the table and the target blocks
+    double *red_v = reinterpret_cast<double *>(lds);
+    int64_t *red_i = reinterpret_cast<int64_t *>(lds + sizeof(double) * GR_W * GR_MAXW);
     greedy_finish_step(a, step, nsteps, best, arg, tab_next, blk_min, blk_arg, arrive, path, dist, red_v, red_i, &is_last);
 }
 
@@ -327,8 +410,10 @@ __global__ void greedy_init_kernel(GreedyArgs a, int64_t start_state, double *__
     greedy_write_table(a, 0, start_state, false, tab, threadIdx.x, blockDim.x);
 }
 
+static size_t greedy_join_tile_elems(const GreedyLayout &g);
 static void fill_args(GreedyArgs &a, const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt,
-                      const float *JC_unw, int Jp, int Dj, const double *wj, const double *Q, bool greedy_mode)
+                      const float *JC_unw, int Jp, int Dj, const double *wj, const double *Q, bool greedy_mode,
+                      const float *tiles = nullptr)
 {
     a.JC_unw = JC_unw; a.Jp = Jp; a.Dj = Dj; a.wj = wj;
     a.F_unw = F_unw; a.Fp = Fp; a.Dt = Dt; a.wt = wt;
@@ -343,6 +428,8 @@ static void fill_args(GreedyArgs &a, const GreedyLayout &g, const float *F_unw, 
     a.n_jc_rows = g.Nwin + g.me;          // join_contexts has N+1 = Nwin + me rows
     a.n_f_rows = g.Nwin + g.me - 1;       // N
     a.Q = Q;
+    a.JT = reinterpret_cast<const f32x4 *>(tiles);
+    a.FT = tiles ? a.JT + greedy_join_tile_elems(g) : nullptr;
 }
 
 size_t greedy_counter_bytes() { return (size_t)32 * (GR_S1 + GR_S2 + 1) * sizeof(unsigned int); }
@@ -355,23 +442,104 @@ size_t greedy_table_doubles(const GreedyLayout &g, int Dt)
     return (size_t)(jch + nep * ((Dt + GR_CC - 1) / GR_CC)) * GR_CC * 2;
 }
 
-void launch_greedy(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt,
-                   const float *JC_unw, int Jp, int Dj, const double *wj, const double *Q,
-                   int64_t nsteps, int64_t start_state, double *tables, double *blk_min,
-                   int64_t *blk_arg, int nblk, unsigned int *arrive, int64_t *path, double *dist, hipStream_t s)
+// float4 elements of the two tile arrays (join columns first, target columns behind them)
+static size_t greedy_join_tile_elems(const GreedyLayout &g)
 {
-    GreedyArgs a{};
-    fill_args(a, g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, Q, true);
-    double *tab[2] = {tables, tables + greedy_table_doubles(g, Dt)};
-    hipLaunchKernelGGL(greedy_init_kernel, dim3(1), dim3(256), 0, s, a, start_state, tab[0], arrive);
-    for (int64_t st = 0; st < nsteps; ++st)
-        hipLaunchKernelGGL(greedy_step_kernel, dim3(nblk), dim3(GR_R), 0, s, a, st, nsteps, tab[st & 1],
-                           tab[(st + 1) & 1], blk_min, blk_arg, arrive, path, dist);
+    // join_contexts has Nwin + me rows; zero-filled tiles behind them so that every 64-row tile a
+    // wavefront may ask for (window tiles rounded up, shifted by prev_row0) exists
+    const int64_t tiles = (g.Nwin + 63) / 64 + (g.prev_row0 + 63) / 64 + 1;
+    return (size_t)tiles * ((g.jdim + GR_CC - 1) / GR_CC * 8) * 64;
+}
+static size_t greedy_target_tile_elems(const GreedyLayout &g, int Dt)
+{
+    const int64_t tiles = (g.Nwin + 63) / 64 + 1;         // + the tile of the last windows' extra rows
+    return (size_t)tiles * ((Dt + GR_CC - 1) / GR_CC * 8) * 64;
+}
+size_t greedy_tile_bytes(const GreedyLayout &g, int Dt)
+{
+    return (greedy_join_tile_elems(g) + greedy_target_tile_elems(g, Dt)) * sizeof(f32x4);
 }
 
-size_t greedy_shmem_bytes(const GreedyLayout &, int, int) { return 0; }    // static LDS only (fits any shape)
+// Build the lane-major tiles from the row-major unweighted matrices (once per database + layout).
+void launch_greedy_tiles(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const float *JC_unw, int Jp,
+                         float *tiles, hipStream_t s)
+{
+    f32x4 *JT = reinterpret_cast<f32x4 *>(tiles);
+    f32x4 *FT = JT + greedy_join_tile_elems(g);
+    const int64_t nj = (int64_t)greedy_join_tile_elems(g), nf = (int64_t)greedy_target_tile_elems(g, Dt);
+    hipLaunchKernelGGL(greedy_tile_kernel, dim3((unsigned)((nj + 255) / 256)), dim3(256), 0, s, JC_unw, Jp,
+                       g.Nwin + g.me, g.prev_col0, g.jdim, (g.jdim + GR_CC - 1) / GR_CC * 8, nj, JT);
+    hipLaunchKernelGGL(greedy_tile_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, F_unw, Fp,
+                       g.Nwin + g.me - 1, 0, Dt, (Dt + GR_CC - 1) / GR_CC * 8, nf, FT);
+}
 
-int greedy_blocks(const GreedyLayout &g, int, int) { return (int)((g.Nwin + GR_R - 1) / GR_R); }
+// Wavefronts per workgroup and LDS bytes of greedy_step_kernel.  One workgroup per compute unit.
+// lds_mode 1 while at least 4 wavefronts' target blocks fit the 160 KB beside the table (8 at
+// magphase-60 widths); never more wavefronts than it takes to give every compute unit work.
+#define GR_LDS_BUDGET (160 * 1024)
+static size_t greedy_lds_table_bytes(const GreedyLayout &g, int Dt)
+{
+    return greedy_table_doubles(g, Dt) * sizeof(double);
+}
+static size_t greedy_lds_wave_bytes(const GreedyLayout &g, int Dt)
+{
+    return (size_t)(GR_W + g.me - 1) * ((Dt + GR_CC - 1) / GR_CC * GR_CC + 4) * sizeof(float);
+}
+static int greedy_lds_max_waves(const GreedyLayout &g, int Dt)
+{
+    const size_t fixed = greedy_lds_table_bytes(g, Dt) + 64;
+    if (fixed >= GR_LDS_BUDGET) return 0;
+    const size_t w = (GR_LDS_BUDGET - fixed) / greedy_lds_wave_bytes(g, Dt);
+    return (int)(w > GR_MAXW ? GR_MAXW : w);
+}
+bool greedy_lds_mode(const GreedyLayout &g, int Dt) { return greedy_lds_max_waves(g, Dt) >= 4; }
+// false: the table alone does not fit the LDS (tens of thousands of scan columns)
+bool greedy_supported(const GreedyLayout &g, int Dt)
+{
+    return greedy_lds_table_bytes(g, Dt) + (size_t)GR_W * GR_MAXW * 16 + 64 <= GR_LDS_BUDGET;
+}
+static int greedy_waves(const GreedyLayout &g, int Dt, int n_cus)
+{
+    const int64_t ntiles = (g.Nwin + GR_W - 1) / GR_W;
+    int64_t w = (ntiles + n_cus - 1) / n_cus;
+    const int wmax = greedy_lds_mode(g, Dt) ? greedy_lds_max_waves(g, Dt) : GR_MAXW;
+    if (w > wmax) w = wmax;
+    return (int)(w < 1 ? 1 : w);
+}
+static size_t greedy_lds_bytes(const GreedyLayout &g, int Dt, int waves)
+{
+    size_t b = greedy_lds_table_bytes(g, Dt) + (greedy_lds_mode(g, Dt) ? (size_t)waves * greedy_lds_wave_bytes(g, Dt) : 0);
+    const size_t red = (size_t)GR_W * GR_MAXW * 16;      // reduction arrays of the step's tail (aliased)
+    return b < red ? red : b;
+}
+
+void launch_greedy(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt,
+                   const float *JC_unw, int Jp, int Dj, const double *wj, const float *tiles, const double *Q,
+                   int64_t nsteps, int64_t start_state, double *tables, double *blk_min,
+                   int64_t *blk_arg, int nblk, int n_cus, unsigned int *arrive, int64_t *path, double *dist, hipStream_t s)
+{
+    GreedyArgs a{};
+    fill_args(a, g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, Q, true, tiles);
+    a.lds_mode = greedy_lds_mode(g, Dt) ? 1 : 0;
+    double *tab[2] = {tables, tables + greedy_table_doubles(g, Dt)};
+    hipLaunchKernelGGL(greedy_init_kernel, dim3(1), dim3(256), 0, s, a, start_state, tab[0], arrive);
+    const int waves = greedy_waves(g, Dt, n_cus);
+    const size_t lds = greedy_lds_bytes(g, Dt, waves);
+    auto kernel = a.lds_mode ? greedy_step_kernel<true> : greedy_step_kernel<false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int64_t st = 0; st < nsteps; ++st)
+        hipLaunchKernelGGL(kernel, dim3(nblk), dim3(GR_W * waves), lds, s, a, st, nsteps,
+                           tab[st & 1], tab[(st + 1) & 1], blk_min, blk_arg, arrive, path, dist);
+}
+
+// Persistent grid: one workgroup per compute unit (fewer when there are fewer tiles).
+int greedy_blocks(const GreedyLayout &g, int Dt, int n_cus)
+{
+    const int64_t ntiles = (g.Nwin + GR_W - 1) / GR_W;
+    const int waves = greedy_waves(g, Dt, n_cus);
+    const int64_t need = (ntiles + waves - 1) / waves;
+    return (int)(need < n_cus ? need : n_cus);
+}
 
 // ---------------------------------------------------------------------------
 // per-column squared errors along a path (get_target_scores_per_stream /

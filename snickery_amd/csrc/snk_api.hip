@@ -121,8 +121,8 @@ struct snk_engine {
     HostBuf hstage;
     // greedy
     GreedyLayout glay{};
-    bool have_glay = false;
-    DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist, gsync;
+    bool have_glay = false, gtiles_ready = false;
+    DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist, gsync, gtiles;
     // options
     int cap = 4096;
     double sample_frac = 1.0 / 16.0;
@@ -261,7 +261,7 @@ int snk_destroy(snk_handle h)
     DevBuf *bufs[] = {&h->F_unw, &h->JC_unw, &h->Fw, &h->fnorm, &h->JCw, &h->wt, &h->wj, &h->unit_class,
                       &h->Qraw, &h->Qp, &h->Qf, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
-                      &h->gpath, &h->gdist, &h->gsync, &h->cls16_full, &h->cls16_samp};
+                      &h->gpath, &h->gdist, &h->gsync, &h->gtiles, &h->cls16_full, &h->cls16_samp};
     for (auto *b : bufs) b->release();
     (void)hipStreamSynchronize(h->dp_stream[1]); (void)hipStreamDestroy(h->dp_stream[1]);
     h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
@@ -323,6 +323,7 @@ int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt, const flo
     h->have_weights = false;
     h->have_classes = false;
     h->have_glay = false;
+    h->gtiles_ready = false;
     if (h->global_N < 0) { h->shard_offset = 0; }
     if (JC_unw) CHK(upload_join(h, JC_unw, Njc, Dj));
     return 0;
@@ -1019,10 +1020,11 @@ int snk_set_greedy_layout(snk_handle h, int multiepoch, int last_frame_as_target
         // synth_halfphone.py:552-553: halves of the unit_start_data columns
         g.jdim = h->Dj / 2; g.prev_col0 = 0; g.cur_col0 = h->Dj / 2; g.prev_row0 = 0; g.cur_row0 = multiepoch - 1;
     }
-    if (greedy_shmem_bytes(g, h->Dt, h->Dj) > 150 * 1024)
-        return fail("snk_set_greedy_layout: feature dimensions too large for the greedy scan tile");
+    if (!greedy_supported(g, h->Dt))
+        return fail("snk_set_greedy_layout: too many scan columns for the greedy step's table (join %d + %d epochs x %d)", g.jdim, multiepoch, h->Dt);
     h->glay = g;
     h->have_glay = true;
+    h->gtiles_ready = false;
     return 0;
 }
 
@@ -1040,8 +1042,15 @@ int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_st
     const int64_t nsteps = T / g.me;          // py2 integer division: tail frames dropped
     *nsteps_out = nsteps;
     if (nsteps == 0) { HIPCHK(hipStreamSynchronize(h->stream)); collect_timers(h); return 0; }
-    const int nblk = greedy_blocks(g, h->Dt, h->Dj);
-    CHK(h->gprev.ensure(2 * greedy_table_doubles(g, h->Dt) * sizeof(double)));     // (weight, reference) tables
+    if (!h->gtiles_ready) {
+        // the scan reads a lane-major copy of its columns (greedy_kernels.hip); built on first use
+        CHK(h->gtiles.ensure(greedy_tile_bytes(g, h->Dt)));
+        launch_greedy_tiles(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->JC_unw.as<float>(), h->Jp, h->gtiles.as<float>(), h->stream);
+        HIPCHK(hipGetLastError());
+        h->gtiles_ready = true;
+    }
+    const int nblk = greedy_blocks(g, h->Dt, h->n_cus);
+    CHK(h->gprev.ensure(2 * greedy_table_doubles(g, h->Dt) * sizeof(double) + 512));   // + slack: the scan warms whole 512-byte spans     // (weight, reference) tables
     CHK(h->gsync.ensure(greedy_counter_bytes()));
     CHK(h->gblkmin.ensure((size_t)nblk * sizeof(double)));
     CHK(h->gblkarg.ensure((size_t)nblk * sizeof(int64_t)));
@@ -1050,8 +1059,8 @@ int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_st
     {
         StageTimer t(h, h->stream, TM_GREEDY_STEPS);
         launch_greedy(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
-                      h->wj.as<double>(), h->Qraw.as<double>(), nsteps, start_state, h->gprev.as<double>(),
-                      h->gblkmin.as<double>(), h->gblkarg.as<int64_t>(), nblk, h->gsync.as<unsigned int>(), h->gpath.as<int64_t>(),
+                      h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nsteps, start_state, h->gprev.as<double>(),
+                      h->gblkmin.as<double>(), h->gblkarg.as<int64_t>(), nblk, h->n_cus, h->gsync.as<unsigned int>(), h->gpath.as<int64_t>(),
                       h->gdist.as<double>(), h->stream);
     }
     HIPCHK(hipGetLastError());

@@ -108,13 +108,17 @@ struct GreedyLayout {
 };
 // Fp / Jp: row pitch (floats, multiple of 4) of the unweighted device matrices
 void launch_greedy(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt,
-                   const float *JC_unw, int Jp, int Dj, const double *wj, const double *Q,
+                   const float *JC_unw, int Jp, int Dj, const double *wj, const float *tiles, const double *Q,
                    int64_t nsteps, int64_t start_state, double *tables, double *blk_min,
-                   int64_t *blk_arg, int nblk, unsigned int *arrive, int64_t *path, double *dist, hipStream_t s);
+                   int64_t *blk_arg, int nblk, int n_cus, unsigned int *arrive, int64_t *path, double *dist, hipStream_t s);
 size_t greedy_table_doubles(const GreedyLayout &g, int Dt);
 size_t greedy_counter_bytes();
-size_t greedy_shmem_bytes(const GreedyLayout &g, int Dt, int Dj);
-int greedy_blocks(const GreedyLayout &g, int Dt, int Dj);
+// lane-major copy of the scan columns (built once per database + layout, read by the scan)
+size_t greedy_tile_bytes(const GreedyLayout &g, int Dt);
+void launch_greedy_tiles(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const float *JC_unw, int Jp,
+                         float *tiles, hipStream_t s);
+int greedy_blocks(const GreedyLayout &g, int Dt, int n_cus);
+bool greedy_supported(const GreedyLayout &g, int Dt);
 
 void launch_path_scores(const GreedyLayout &g, int mode, const float *F_unw, int Fp, int Dt, const double *wt,
                         const float *JC_unw, int Jp, int Dj, const double *wj, const double *Q,

@@ -278,7 +278,9 @@ def test_greedy_golden(mini_engine, golden, mini_voice):
 
 @pytest.mark.parametrize('me,lfat,mode,Dj,Dt', [(6, False, 0, 151, 61), (3, True, 0, 40, 61), (4, False, 1, 80, 61),
                                                (1, False, 1, 302, 61), (16, False, 0, 151, 61),
-                                               (5, False, 0, 151, 90),      # target rows too wide to stay in LDS
+                                               (5, False, 0, 151, 90),
+                                               (5, False, 0, 151, 200),     # target rows too wide for LDS: re-read through L2
+                                               (3, False, 1, 64, 250),
                                                (2, True, 0, 33, 7)])
 def test_greedy_synthetic(engine, me, lfat, mode, Dj, Dt):
     N = 5000

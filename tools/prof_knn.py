@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import snickery_amd
 from bench import synthetic_db, synthetic_targets
-N, Dt, Dj, T, K, U = 1048576, 61, 302, 600, 100, 16
+N, Dt, Dj, T, K, U = 1048576, 61, 302, 600, 100, 32
 F_unw, JC_unw = synthetic_db(N, Dt, Dj, seed=0)
 wt = np.full(Dt, 0.4); wj = np.full(Dj, 0.05)
 eng = snickery_amd.HipSearchEngine(0)
