@@ -7,12 +7,13 @@ workload B* of SURVEY.md 8d: |DB| = 1 048 576 units, Dt = 61, Dj = 302, T = 600,
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one batch of --utts utterances (T frames each) through the whole hot path with
-the unit database already resident in HBM.  N > 1: the database is row-sharded over the ranks
-(strong scaling: database and batch are fixed), every rank sweeps its shard for all rows of the
-batch, the local top-K lists travel by ONE all-to-all over RCCL to the rank that owns the utterance
+One "step" = one batch of --utts utterances PER GPU (T frames each) through the whole hot path with
+the unit database already resident in HBM.  N > 1: the database is row-sharded over the ranks and the
+batch grows with N (weak scaling: every rank sweeps 1/N of the database for N x --utts utterances,
+i.e. the single-GPU number of distance evaluations, and owns --utts utterances in the Viterbi
+stage); the local top-K lists travel by ONE all-to-all over RCCL to the rank that owns the utterance
 (contiguous blocks of utterances per rank), which merges them and runs join costs + Viterbi.
-Rank 0 prints ONE JSON line.
+--fixed-batch keeps the batch at --utts for every N (strong scaling).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -93,20 +94,32 @@ def main():
     ap.add_argument('--join-dim', type=int, default=302)
     ap.add_argument('--cpu-sample-frames', type=int, default=48)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--fixed-batch', action='store_true', help='N > 1: keep the batch at --utts (strong scaling)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     N, Dt, Dj, T, K, U = args.units, args.target_dim, args.join_dim, args.frames, args.candidates, args.utts
+    if not args.fixed_batch:
+        U *= world                  # weak scaling: --utts utterances per GPU and step
 
     import torch
     import snickery_amd
+    # SNK_BENCH_SHARE_GPU=1: functional test of the multi-rank path on a ONE-GPU box -- all ranks use
+    # cuda:0 and the collectives run on gloo through host memory (RCCL refuses two ranks on one
+    # device).  Never a measurement.
+    share_gpu = os.environ.get('SNK_BENCH_SHARE_GPU') == '1'
+    if share_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if share_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     F_unw, JC_unw = synthetic_db(N, Dt, Dj, seed=0)
     wt = np.full(Dt, 0.8 * 0.5)                 # target_stream_weights * (1 - join_cost_weight)
@@ -151,7 +164,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if share_gpu else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -185,13 +198,13 @@ def main():
         out = {
             'metric': 'synthesised frames/sec, full-DB K=%d K-NN preselection + Viterbi' % K,
             'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if args.fixed_batch else 'weak',
             'vs_baseline': None, 'dtype': 'f64' if not f32_mode else 'f64 (f32 matrix prefilter + exact f64 re-rank)', 'data': 'synthetic',
             'xRT': (total_frames * FRAMESHIFT_MS / 1e3) / elapsed,
             'config': {'workload': 'B* synthetic magphase-60 (SURVEY 8d): |DB|=%d units, Dt=%d, Dj=%d, '
                                    'T=%d frames x %d utterances per step, K=%d, search_epsilon=0'
                                    % (N, Dt, Dj, T, U, K),
-                       'units': N, 'target_dim': Dt, 'join_dim': Dj, 'frames': T, 'utts_per_step': U,
+                       'units': N, 'target_dim': Dt, 'join_dim': Dj, 'frames': T, 'utts_per_step': U, 'utts_per_gpu': U // world,
                        'n_candidates': K, 'sharding': 'db-rows/%d + all-to-all of local top-K' % world if world > 1 else 'none'},
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
@@ -203,6 +216,8 @@ def main():
             'stages_ms_per_step': dict((k, v[0] / args.steps) for k, v in timers.items() if v[1]),
             'stage_launches_per_step': dict((k, v[1] / args.steps) for k, v in timers.items() if v[1]),
         }
+        if share_gpu:
+            out['note'] = 'FUNCTIONAL TEST: all ranks share cuda:0, collectives on gloo through host memory; not a measurement'
         if world == 1 and not args.no_cpu_baseline:
             base, ref = cpu_baseline(F_unw, JC_unw, wt, wj, K, args.cpu_sample_frames, seed=1)
             out['cpu_baseline'] = base

@@ -16,6 +16,32 @@ import torch
 import torch.distributed as dist
 
 
+def _staged(group):
+    """True when the collectives must go through host memory: backend gloo with device buffers.
+    Only the functional tests do that (several ranks sharing the one GPU of a test box, where RCCL
+    refuses two ranks on one device); production runs nccl (= RCCL) on the device buffers."""
+    return dist.get_backend(group) == 'gloo'
+
+
+def _all_to_all(out, inp, out_splits, in_splits, group):
+    if _staged(group) and out.is_cuda:
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+
+
+def _all_gather(outs, inp, group):
+    if _staged(group) and inp.is_cuda:
+        tmp = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        dist.all_gather(tmp, inp.cpu(), group=group)
+        for o, t in zip(outs, tmp):
+            o.copy_(t)
+    else:
+        dist.all_gather(outs, inp, group=group)
+
+
 def shard_bounds(n_units, world_size, rank):
     """Contiguous row shard [lo, hi) of rank; sizes differ by at most one unit."""
     base, rem = divmod(int(n_units), int(world_size))
@@ -71,8 +97,8 @@ class ShardedSearch(object):
         d2_all = self.e.alloc(G, T, K, dtype=torch.float64)
         id_all = self.e.alloc(G, T, K, dtype=torch.int64)
         # one fused gather each for distances and ids: (T*K*8 B per rank, latency bound)
-        dist.all_gather(list(d2_all.unbind(0)), d2, group=self.group)
-        dist.all_gather(list(id_all.unbind(0)), ids, group=self.group)
+        _all_gather(list(d2_all.unbind(0)), d2, self.group)
+        _all_gather(list(id_all.unbind(0)), ids, self.group)
         return self.e.merge(d2_all, id_all, G, T, K)
 
     def knn_viterbi_batch(self, utterances, K):
@@ -99,8 +125,8 @@ class ShardedSearch(object):
         else:
             d2_all = self.e.alloc(G * r_own, K, dtype=torch.float64)
             id_all = self.e.alloc(G * r_own, K, dtype=torch.int64)
-            dist.all_to_all_single(d2_all, d2, [r_own] * G, rows_to, group=self.group)
-            dist.all_to_all_single(id_all, ids, [r_own] * G, rows_to, group=self.group)
+            _all_to_all(d2_all, d2, [r_own] * G, rows_to, self.group)
+            _all_to_all(id_all, ids, [r_own] * G, rows_to, self.group)
         if hi > lo:
             own_paths, own_costs = self.e.merge_viterbi_batch(d2_all, id_all, G, lens[lo:hi], K)
         else:
@@ -117,7 +143,7 @@ class ShardedSearch(object):
             buf[j, 2:2 + len(p)] = torch.from_numpy(np.asarray(p, dtype=np.float64))
         buf = buf.to(self.e.device) if str(self.e.device) != 'cpu' else buf
         allb = [torch.empty_like(buf) for _ in range(G)]
-        dist.all_gather(allb, buf, group=self.group)
+        _all_gather(allb, buf, self.group)
         allb = [b.cpu().numpy() for b in allb]
         paths, costs = [], []
         for r, (a, b) in enumerate(owned):

@@ -1,0 +1,80 @@
+"""The sharded search path (snickery_amd/dist.py) with the real HIP engine: two ranks share the one
+GPU of the test box (gloo collectives through host memory; RCCL refuses two ranks on one device).
+Everything but the RCCL transport itself is the production path: shard upload, shard-local top-K
+into device buffers, exchange, merge, join costs, Viterbi on the owner, result gather."""
+import json
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import snk_oracle as o
+    import snickery_amd
+    from snickery_amd.dist import HipShardEngine, ShardedSearch, shard_bounds
+    N, Dt, Dj, K = 30001, 61, 40, 25
+    F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=5)
+    wt = np.full(Dt, 0.4)
+    wj = np.full(Dj, 0.05)
+    F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
+    lo, hi = shard_bounds(N, world, rank)
+    torch.cuda.set_device(0)
+    eng = snickery_amd.HipSearchEngine(0)
+    eng.upload_target_only(F_unw[lo:hi])
+    eng.upload_join_only(JC_unw)
+    eng.set_shard(lo, N)
+    eng.set_weights(wt, wj)
+    search = ShardedSearch(HipShardEngine(eng, torch.device('cuda', 0)))
+    utts = [o.synthetic_targets(F_unw, T, seed=s) * wt for s, T in [(1, 40), (2, 25), (3, 33)]]
+    ok = True
+    cand, d = search.knn(utts[0], K)
+    oc, od = o.knn_bruteforce(F, utts[0], K)
+    ok = ok and np.array_equal(cand, oc) and np.array_equal(d, od)
+    for batch in (utts, utts[1:2]):                      # second batch: rank 1 owns nothing
+        paths, costs = search.knn_viterbi_batch(batch, K)
+        for u, U in enumerate(batch):
+            c, dd = o.knn_bruteforce(F, U, K)
+            p, cost = o.viterbi(c, dd, E, S)
+            ok = ok and list(paths[u]) == p and costs[u] == cost
+    out[rank] = bool(ok)
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_search_two_ranks_one_gpu():
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0] is True and out[1] is True
+
+
+def test_bench_two_ranks_one_gpu():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run), ranks sharing the GPU."""
+    env = dict(os.environ, SNK_BENCH_SHARE_GPU='1')
+    port = 31500 + (os.getpid() % 2000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+           '--gpus', '2', '--steps', '2', '--warmup', '1', '--units', '40000', '--frames', '60', '--utts', '5',
+           '--candidates', '20', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    js = json.loads(lines[0])
+    assert js['n_gpus'] == 2 and js['value'] > 0 and js['scaling'] == 'weak' and js['config']['utts_per_step'] == 10
+    assert 'roofline' in js and 'FUNCTIONAL TEST' in js['note']

@@ -1,4 +1,4 @@
-"""Small driver for PMC passes: two B* batch steps (16 utterances) through the batch entry point."""
+"""Small driver for PMC passes: two B* batch steps (32 utterances) through the batch entry point."""
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

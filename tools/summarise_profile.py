@@ -55,7 +55,7 @@ json.dump(traffic, open(os.path.join(out, 'r01_traffic_f32.json'), 'w'), indent=
 
 lines = ['# Round 1, profile %s -- grouped batch pipeline (K-NN per group of utterances, one join launch and one '
          'batched recursion launch per group)' % tag.split('_')[-1].upper(), '',
-         'Commands (MI355X, 1 GPU, B* workload, 16 utterances per step; tools/prof_round.sh):', '',
+         'Commands (MI355X, 1 GPU, B* workload, 32 utterances per step; tools/prof_round.sh):', '',
          '* `python bench.py --steps 5 --warmup 1` -> %s_bench.json: **%.0f frames/s** (xRT %.0f), roofline.frac %.3f of '
          'the 157.3 TFLOP/s f32 matrix peak, cpu_baseline %.1f frames/s' % (
              tag, bench['value'], bench['xRT'], bench['roofline']['frac'], bench['cpu_baseline']['value']),
