@@ -274,6 +274,79 @@ def get_norm_durations(unit_names, timings, duration_stats, oov_stats=(5.0, 5.0)
 
 
 # --------------------------------------------------------------------------
+# Pieces of the halfphone / pitch-synchronous database writer (train_halfphone.py)
+# --------------------------------------------------------------------------
+LABEL_LENGTH_DIFF_TOLERANCE = 5          # const.py:10
+TARGET_REP_WIDTHS = {'onepoint': 1, 'twopoint': 2, 'threepoint': 3, 'epoch': 1, 'sample': 1}    # const.py:17
+
+
+def read_pm(fname):
+    """train_halfphone.py:852-875: pitch-mark times (seconds) of an EST track file -- first field
+    of every line after 'EST_Header_End'.  Times that are not non-decreasing: a (1, 1) array of
+    ones, the reference's signal for an unusable file."""
+    with open(fname, 'r') as f:
+        lines = f.readlines()
+    start = None
+    for i, line in enumerate(lines):
+        if line.startswith('EST_Header_End'):
+            start = i + 1
+            break
+    if start is None:
+        raise ValueError('%s: no EST_Header_End line' % (fname,))
+    times = np.array([float(re.split(r'\s+', line)[0]) for line in lines[start:]])
+    if np.any(np.diff(times) < 0.0):
+        return np.ones((1, 1))
+    return times
+
+
+def get_cutpoints(timings, pms, sample_rate):
+    """train_halfphone.py:933-955: for every unit (start, end) in 5 ms frames, the pitch marks
+    nearest to its two ends (first of equally near ones).  Returns (cutpoints in samples (n, 2) int,
+    pitch-mark indices (n, 2) int)."""
+    indices = np.empty((len(timings), 2), dtype=int)
+    for i, (start, end) in enumerate(timings):
+        indices[i, 0] = np.argmin(np.abs(pms - start * 0.005))
+        indices[i, 1] = np.argmin(np.abs(pms - end * 0.005))
+    cutpoints = pms[indices].reshape((-1, 2)) * sample_rate
+    return np.array(cutpoints, dtype=int), indices
+
+
+def get_contexts_for_pitch_synchronous_joincost(speech, pm_indices):
+    """train_halfphone.py:1135-1162: row p = the pitch-synchronous join frame at the START of unit p
+    (= end of unit p-1), plus one last row for the end of the last unit: (n + 1, dim)."""
+    starts = np.append(pm_indices[:, 0], pm_indices[-1, 1])
+    return speech[starts, :]
+
+
+def pad_speech_to_length(speech, labels):
+    """train_halfphone.py:1333-1356: zero-pad or trim the speech to the label's frame count; more
+    than LABEL_LENGTH_DIFF_TOLERANCE frames apart: a (1, 1) zero matrix (utterance is skipped)."""
+    m, dim = speech.shape
+    nframe = labels[-1][0][1]
+    if abs(nframe - m) > LABEL_LENGTH_DIFF_TOLERANCE:
+        return np.array([[0.0]])
+    if nframe > m:
+        return np.vstack([speech, np.zeros((nframe - m, dim))])
+    return speech[:nframe, :]
+
+
+def get_halfphone_lengths(label):
+    """train_halfphone.py:1098-1119: (monophone + '_L' / '_R', frames) per halfphone; HTK states
+    2-3 form the left halfphone, 4-6 the right one."""
+    vals, curr_dur = [], 0
+    for (start, end), quinphone in label:
+        curr_dur += end - start
+        state = quinphone[-1]
+        if state == '3':
+            vals.append((quinphone[2] + '_L', curr_dur))
+            curr_dur = 0
+        if state == '6':
+            vals.append((quinphone[2] + '_R', curr_dur))
+            curr_dur = 0
+    return vals
+
+
+# --------------------------------------------------------------------------
 # Per-stream standardisation statistics of the database writer
 # (data_manipulation.py:96-234; used by train_simple.py:86-87)
 # --------------------------------------------------------------------------

@@ -263,3 +263,55 @@ def test_concatenate_magphase_matches_reference(tmp_path, golden, overlap):
         with pytest.raises(Exception):
             synth.concatenate_magphase([int(p) for p in golden['concat_path']], overlap=0)
     synth.close()
+
+
+def test_writer_to_search_round_trip_epoch_database(tmp_path):
+    """Producer -> consumer: a pitch-synchronous epoch database written by snickery_amd.train_halfphone
+    (2 x Dj join rows, byte-identical to the reference's file, tests/test_hostprep.py) is loaded by the
+    drop-in Synthesiser and searched (K-NN + join costs + Viterbi) on the GPU; the path equals the
+    oracle's on the arrays of that database, with the doubled join weight vector of
+    synth_halfphone.py:693-695."""
+    import sys
+    from snickery_amd import hostprep as hp, train_halfphone
+    from snickery_amd.synthesiser import Synthesiser
+    import voice_fixture
+    data = os.path.join(str(tmp_path), 'corpus')
+    voice_fixture.write_halfphone_corpus(data)
+    cfgfile = voice_fixture.halfphone_corpus_config(os.path.join(str(tmp_path), 'hp.cfg'),
+                                                    os.path.join(str(tmp_path), 'work'), data, 'epoch', False)
+    with open(cfgfile, 'a') as f:
+        f.write('''
+test_data_dirs = join_datadirs
+n_test_utts = 1
+weight_target_data = True
+weight_join_data = True
+target_stream_weights = [0.1, 1.0]
+join_stream_weights = [0.25, 0.25, 0.25, 0.25]
+join_cost_weight = 0.2
+greedy_search = False
+search_epsilon = 0.0
+multiepoch = 1
+n_candidates = 8
+preselection_method = 'acoustic'
+join_cost_type = 'natural2'
+get_selection_info = False
+hold_waves_in_memory = False
+preload_all_magphase_utts = False
+''')
+    config = hp.load_config(cfgfile)
+    train_halfphone.main_work(config, report=lambda *_: None)
+    synth = Synthesiser(cfgfile, verbose=False)
+    assert synth.flavour == 'halfphone' and synth._double_join
+    db = hp.load_database(train_halfphone.get_data_dump_name(config))
+    dims = config['datadims']
+    tw, jw = o.apply_jcw(config['target_stream_weights'], config['join_stream_weights'], config['join_cost_weight'])
+    wt = o.stream_weight_vector(list(tw), config['stream_list_target'], dims)
+    wj1 = o.stream_weight_vector(list(jw), config['stream_list_join'], dims)
+    wj = np.concatenate([wj1, wj1])
+    F, E, S = o.weighted_db(db['train_unit_features'], db['join_contexts'], wt, wj)
+    U = synth.prepare_targets('arctic_b0001')
+    path = synth.synth_utt('arctic_b0001', synth_type='test')
+    oc, od = o.knn_bruteforce(F, U, 8)
+    op, ocost = o.viterbi(oc, od, E, S)
+    assert path == op and synth.last_path_cost == ocost
+    synth.close()

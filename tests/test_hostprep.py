@@ -1,6 +1,8 @@
 """CPU tests of the host-side mirror of the reference interface (no GPU, no oracle needed):
 target preparation and file naming against values captured from the reference itself."""
 import os
+import sys
+import pytest
 import numpy as np
 
 from voice_fixture import build_voice
@@ -162,3 +164,37 @@ def test_database_writer_reproduces_reference_database(tmp_path, golden):
     with pytest.raises(SystemExit):
         train_simple.main_work(config, overwrite_existing_data=False, report=lambda *_: None)
     train_simple.main_work(config, overwrite_existing_data=True, report=lambda *_: None)
+
+
+@pytest.mark.parametrize('tag,rep,duration', [('epoch', 'epoch', False), ('twopoint', 'twopoint', True),
+                                              ('threepoint', 'threepoint', False)])
+def test_halfphone_database_writer_reproduces_reference_database(tmp_path, tag, rep, duration):
+    """snickery_amd.train_halfphone on the regenerated pitch-synchronous corpus (the same seeded
+    generator that tools/make_golden.py fed to the REFERENCE's train_halfphone.main_work): every
+    dataset of the database has the reference's name, shape, dtype and bytes (sha256) -- epoch voice
+    (pairs of join frames, pitch-mark triples), halfphone voices with and without the duration
+    target, including the reference's placement of the final join row."""
+    import hashlib
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import voice_fixture
+    from snickery_amd import hostprep as hp, train_halfphone
+    ref = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_trainhp.npz'), allow_pickle=True)
+    data = os.path.join(str(tmp_path), 'corpus')
+    voice_fixture.write_halfphone_corpus(data)
+    cfgfile = voice_fixture.halfphone_corpus_config(os.path.join(str(tmp_path), 'hp.cfg'), os.path.join(str(tmp_path), 'work'),
+                                                    data, rep, duration)
+    config = hp.load_config(cfgfile)
+    dbfile = train_halfphone.main_work(config, report=lambda *_: None)
+    assert os.path.basename(dbfile) == str(ref[tag + '_db_basename'])
+    db = hp.load_database(dbfile)
+    assert sorted(db.keys()) == sorted(k.decode() for k in ref[tag + '_keys'])
+    for key, arr in db.items():
+        arr = np.asarray(arr)
+        assert list(arr.shape) == list(ref['%s_%s_shape' % (tag, key)]), key
+        assert arr.dtype.str == str(ref['%s_%s_dtype' % (tag, key)]), key
+        if arr.ndim == 2:
+            assert np.array_equal(arr[[0, arr.shape[0] // 2, -1], :8], ref['%s_%s_rows' % (tag, key)]), key
+        assert hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest() == str(ref['%s_%s_sha256' % (tag, key)]), key
+    with pytest.raises(SystemExit):                       # existing data is protected (train_halfphone.py:78-82)
+        train_halfphone.main_work(config, report=lambda *_: None)

@@ -141,3 +141,82 @@ def write_full_spectra(root, frames_per_utt, H, seed=77):
                 f0[pos:pos + seg] = 0.0
             pos += seg
         f0.astype(np.float32).reshape(-1, 1).tofile(os.path.join(root, 'f0', name + '.f0'))
+
+
+# --------------------------------------------------------------------------------------------------
+# A small pitch-synchronous corpus for the database writers of train_halfphone.py: stream files,
+# pitch marks (.pm, EST track text) and state-aligned labels.  Shared by tools/make_golden.py (input
+# of the REFERENCE's train_halfphone.main_work) and tests/test_hostprep.py (input of ours).
+# --------------------------------------------------------------------------------------------------
+HP_CORPUS_CFG = '''
+workdir = %(workdir)r
+data = %(data)r
+join_datadirs = [data + '/low/']
+target_datadirs = join_datadirs
+test_patterns = ['arctic_b']
+n_train_utts = 0
+datadims = {'lf0':1, 'mag': 60, 'real': 45, 'imag': 45}
+stream_list_join = ['mag', 'real', 'imag', 'lf0']
+datadims_join = datadims
+stream_list_target = ['mag', 'lf0']
+datadims_target = datadims
+frameshift_ms = 5
+sample_rate = 16000
+target_representation = %(rep)r
+add_duration_as_target = %(duration)s
+pm_datadir = data + '/pm/'
+label_datadir = data + '/lab/'
+lab_extension = 'lab'
+quinphone_regex = r'([^~]+)~([^-]+)-([^\\+]+)\\+([^\\=]+)\\=([^:]+)'
+'''
+
+
+def write_halfphone_corpus(root, seed=4242):
+    """Four short utterances (one of them test material, one without pitch marks).  The number of
+    pitch marks equals the number of frames (the streams double as pitch-synchronous join
+    features); labels are 0..2 frames longer or shorter than the speech."""
+    rng = np.random.RandomState(seed)
+    dims = {'mag': 60, 'real': 45, 'imag': 45, 'lf0': 1}
+    names = ['arctic_a0001', 'arctic_a0002', 'arctic_a0003', 'arctic_a0004', 'arctic_b0001']
+    for stream in dims:
+        os.makedirs(os.path.join(root, 'low', stream), exist_ok=True)
+    for sub in ('pm', 'lab'):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    for u, name in enumerate(names):
+        n = int(rng.randint(45, 70))
+        base = np.cumsum(rng.randn(n, 8), axis=0) * 0.3
+        for stream, dim in dims.items():
+            proj = rng.randn(8, dim) if stream != 'lf0' else rng.randn(8, 1) * 0.05
+            data = base.dot(proj) + 0.1 * rng.randn(n, dim)
+            if stream == 'lf0':
+                data = 5.0 + data
+                uv = rng.rand(n) < 0.25
+                data[uv, 0] = 0.0
+            data.astype(np.float32).tofile(os.path.join(root, 'low', stream, name + '.' + stream))
+        if name != 'arctic_a0003':                        # that one has no pitch marks: skipped by the writers
+            times = np.cumsum(0.0045 + 0.001 * rng.rand(n))
+            with open(os.path.join(root, 'pm', name + '.pm'), 'w') as f:
+                f.write('EST_File Track\nDataType ascii\nNumFrames %d\nEST_Header_End\n' % n)
+                for t in times:
+                    f.write('%.6f 1\n' % t)
+        n_phones = 4 + u % 2
+        seq = ['xx', 'xx', '#'] + [PHONES[rng.randint(4)] for _ in range(n_phones - 2)] + ['#', 'xx', 'xx']
+        n_states = 5 * n_phones
+        total = n + (u % 3) - 1                            # label length: n-1, n, n+1 frames
+        durs = rng.multinomial(total - n_states, np.ones(n_states) / n_states) + 1
+        lines, now = [], 0
+        for i in range(2, len(seq) - 2):
+            for state in range(2, 7):
+                dur = int(durs[(i - 2) * 5 + state - 2]) * 50000
+                lines.append('%d %d %s~%s-%s+%s=%s:/x[%d]' % (now, now + dur, seq[i - 2], seq[i - 1], seq[i],
+                                                           seq[i + 1], seq[i + 2], state))
+                now += dur
+        with open(os.path.join(root, 'lab', name + '.lab'), 'w') as f:
+            f.write('\n'.join(lines) + '\n')
+    return names
+
+
+def halfphone_corpus_config(cfgfile, workdir, data, rep, duration):
+    with open(cfgfile, 'w') as f:
+        f.write(HP_CORPUS_CFG % dict(workdir=workdir, data=data, rep=rep, duration=str(bool(duration))))
+    return cfgfile

@@ -77,6 +77,14 @@ def convert_reference(tmp):
     patch('train_halfphone.py', 'int(start) / 50000', 'int(start) // 50000')
     patch('train_halfphone.py', '(int(end) / 50000)', '(int(end) // 50000)')
     patch('train_halfphone.py', 'nphones = len(labels) / 5', 'nphones = len(labels) // 5')
+    # main_work under py3 + h5py: integer unit count, byte strings for the S50 datasets
+    patch('train_halfphone.py', 'n_halfphones = (n_states / 5) * 2', 'n_halfphones = (n_states // 5) * 2')
+    patch('train_halfphone.py', 'phones_dset[start:start+m] = unit_names',
+          "phones_dset[start:start+m] = np.array(unit_names).astype('S50')")
+    patch('train_halfphone.py', 'filenames_dset[start:start+m] = filenames',
+          "filenames_dset[start:start+m] = np.array(filenames).astype('S50')")
+    patch('train_halfphone.py', 'f["duration_monophones"][:] = duration_monophones',
+          'f["duration_monophones"][:] = duration_monophones.astype(\'S50\')')
 
     stubs = os.path.join(tmp, 'stubs')
     os.makedirs(os.path.join(stubs, 'smoothing'))
@@ -405,6 +413,36 @@ def main():
         fixtures['bsw_losses'] = np.array(loss)
         fixtures['bsw_join_stream_weights'] = np.array(eval(jw.split('=', 1)[1]))
         fixtures['bsw_target_stream_weights'] = np.array(eval(tw.split('=', 1)[1]))
+
+        # ---- database writer of train_halfphone.py (main_work, :63-628) on a small pitch-synchronous
+        # corpus (tests/voice_fixture.write_halfphone_corpus): the reference's own HDF5 files, recorded
+        # as (shape, dtype, sha256) per dataset plus a few rows, in a separate fixture file ----
+        import hashlib
+        hp_data = os.path.join(tmp, 'hp_corpus')
+        voice_fixture.write_halfphone_corpus(hp_data)
+        trainhp = {}
+        for tag, rep, duration in (('epoch', 'epoch', False), ('twopoint', 'twopoint', True), ('threepoint', 'threepoint', False)):
+            hp_work = os.path.join(tmp, 'hp_work_' + tag)
+            os.makedirs(hp_work)
+            hp_cfg = voice_fixture.halfphone_corpus_config(os.path.join(tmp, 'hp_%s.cfg' % tag), hp_work, hp_data, rep, duration)
+            config = {}
+            exec(compile(open(hp_cfg).read(), hp_cfg, 'exec'), config)
+            del config['__builtins__']
+            with contextlib.redirect_stdout(io.StringIO()):
+                train_halfphone.main_work(config, overwrite_existing_data=True)
+            dbfile = train_halfphone.get_data_dump_name(config)
+            trainhp[tag + '_db_basename'] = np.array(os.path.basename(dbfile))
+            with h5py.File(dbfile, 'r') as f:
+                trainhp[tag + '_keys'] = np.array(sorted(f.keys())).astype('S40')
+                for key in f.keys():
+                    arr = f[key][...]
+                    trainhp['%s_%s_shape' % (tag, key)] = np.array(arr.shape, dtype=np.int64)
+                    trainhp['%s_%s_dtype' % (tag, key)] = np.array(arr.dtype.str)
+                    trainhp['%s_%s_sha256' % (tag, key)] = np.array(hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest())
+                    if arr.ndim == 2:
+                        trainhp['%s_%s_rows' % (tag, key)] = arr[[0, arr.shape[0] // 2, -1], :8]
+        np.savez_compressed(os.path.join(OUT, 'reference_trainhp.npz'), **trainhp)
+        print('wrote tests/golden/reference_trainhp.npz (%d bytes)' % os.path.getsize(os.path.join(OUT, 'reference_trainhp.npz')))
 
         np.savez_compressed(os.path.join(OUT, 'reference_mini.npz'), **fixtures)
         sz = os.path.getsize(os.path.join(OUT, 'reference_mini.npz'))
