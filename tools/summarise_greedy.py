@@ -24,7 +24,7 @@ write = ctr.get('WRITE_SIZE', 0.0) * 1024
 wave = ctr['SQ_WAVE_CYCLES']
 lines = ['# Round 1 -- greedy_step_kernel<lds> at N = 1.5 M units, Dt = 61, Dj = 151, multiepoch 6 (B3 shape)', '',
          'Command: `bash tools/prof_greedy.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes, over tools/prof_greedy.py: one 600-frame utterance = 100 steps).', '',
-         '* kernel-trace: %d launches, average **%.1f us** per step (under the tracer; tools/greedy_time.py with HIP events and no tracer: 260 us = 4.9 TB/s = 61 %)' % (len(dur), avg),
+         '* kernel-trace: %d launches, average **%.1f us** per step (under the tracer; tools/greedy_time.py with HIP events and no tracer: 260 us = 4.9 TB/s = 61 %%)' % (len(dur), avg),
          '* algorithmic bytes per step (Dj + Dt) x 4 x N = %.0f MB -> %.2f TB/s = **%.0f %% of the 8 TB/s HBM peak**' % (alg / 1e6, alg / (avg * 1e-6) / 1e12, 100 * alg / (avg * 1e-6) / 8e12),
          '* HBM traffic per step: FETCH_SIZE %.0f KB reported -> x2 (gfx950 correction) = %.0f MB; WRITE_SIZE %.1f MB; => %.2fx the algorithmic bytes' % (ctr['FETCH_SIZE'], fetch / 1e6, write / 1e6, (fetch + write) / alg),
          '* vector ALU: SQ_INSTS_VALU %.3g wavefront instructions per step (%.1f per column and window); SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = %.2f of the wavefront cycles; two wavefronts per SIMD -> VALU busy ~%.0f %%' % (
