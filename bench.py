@@ -13,7 +13,9 @@ batch grows with N (weak scaling: every rank sweeps 1/N of the database for N x 
 i.e. the single-GPU number of distance evaluations, and owns --utts utterances in the Viterbi
 stage); the local top-K lists travel by ONE all-to-all over RCCL to the rank that owns the utterance
 (contiguous blocks of utterances per rank), which merges them and runs join costs + Viterbi.
---fixed-batch keeps the batch at --utts for every N (strong scaling).  Rank 0 prints ONE JSON line.
+--fixed-batch keeps the batch at --utts for every N (strong scaling).  --db-shards S (a divisor of N)
+shards the database over S GPUs only and runs N/S such groups side by side, each on its share of
+the batch (S = 1: independent replicas, no collective).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -95,6 +97,10 @@ def main():
     ap.add_argument('--cpu-sample-frames', type=int, default=48)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--fixed-batch', action='store_true', help='N > 1: keep the batch at --utts (strong scaling)')
+    ap.add_argument('--db-shards', type=int, default=0,
+                    help='N > 1: shard the database over this many GPUs (a divisor of N; default N) and replicate '
+                         'those shard groups N / db-shards times, each group taking its share of the utterances; '
+                         '1 = independent replicas, no collective on the data path')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -137,16 +143,37 @@ def main():
             return eng.knn_viterbi_batch(utts, K)
     else:
         from snickery_amd.dist import HipShardEngine, ShardedSearch, shard_bounds
-        lo, hi = shard_bounds(N, world, rank)
-        eng.upload_target_only(F_unw[lo:hi])
-        eng.upload_join_only(JC_unw)
-        eng.set_shard(lo, N)
-        eng.set_weights(wt, wj)
+        # ranks [q*S, (q+1)*S) form shard group q: the database is row-sharded over the S ranks of a
+        # group, the groups are replicas of each other and split the batch (S = world: one group)
+        S = args.db_shards if args.db_shards > 0 else world
+        if world % S:
+            raise SystemExit('--db-shards %d does not divide the number of GPUs %d' % (S, world))
+        n_groups, my_group, sub_rank = world // S, rank // S, rank % S
+        group = None
+        if n_groups > 1 and S > 1:
+            groups = [dist.new_group(ranks=list(range(q * S, (q + 1) * S))) for q in range(n_groups)]
+            group = groups[my_group]
+        u_lo, u_hi = shard_bounds(U, n_groups, my_group)
+        my_utts = utts[u_lo:u_hi]
+        my_frames = sum(u.shape[0] for u in my_utts)
+        lo, hi = shard_bounds(N, S, sub_rank)
         n_local = hi - lo
-        search = ShardedSearch(HipShardEngine(eng, torch.device('cuda', local_rank)))
+        if S == 1:
+            eng.upload_db(F_unw, JC_unw)
+            eng.set_weights(wt, wj)
 
-        def step():
-            return search.knn_viterbi_batch(utts, K)
+            def step():
+                return eng.knn_viterbi_batch(my_utts, K)
+        else:
+            eng.upload_target_only(F_unw[lo:hi])
+            eng.upload_join_only(JC_unw)
+            eng.set_shard(lo, N)
+            eng.set_weights(wt, wj)
+            search = ShardedSearch(HipShardEngine(eng, torch.device('cuda', local_rank)), rank=sub_rank, world_size=S,
+                                   group=group)
+
+            def step():
+                return search.knn_viterbi_batch(my_utts, K)
 
     def sync():
         torch.cuda.synchronize()
@@ -176,7 +203,7 @@ def main():
         avg_ms = ms / max(launches, 1)
         # algorithmic flops: 2 * rows * N_local * Dt for the rows this rank swept; the
         # batch entry points group utterances, so one filter launch covers rows_per_launch rows
-        rows_swept = frames_per_step * args.steps
+        rows_swept = (frames_per_step if world == 1 else my_frames) * args.steps
         rows_per_launch = rows_swept / max(launches, 1)
         flops = 2.0 * rows_per_launch * n_local * Dt
         # HBM bytes per launch from the committed PMC passes (separate --pmc runs, FETCH_SIZE
@@ -205,7 +232,10 @@ def main():
                                    'T=%d frames x %d utterances per step, K=%d, search_epsilon=0'
                                    % (N, Dt, Dj, T, U, K),
                        'units': N, 'target_dim': Dt, 'join_dim': Dj, 'frames': T, 'utts_per_step': U, 'utts_per_gpu': U // world,
-                       'n_candidates': K, 'sharding': 'db-rows/%d + all-to-all of local top-K' % world if world > 1 else 'none'},
+                       'n_candidates': K,
+                       'sharding': 'none' if world == 1 else (
+                           '%d independent replicas' % world if S == 1 else
+                           'db-rows/%d + all-to-all of local top-K' % S + (' x %d replica groups' % n_groups if n_groups > 1 else ''))},
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic,

@@ -63,18 +63,23 @@ def test_sharded_search_two_ranks_one_gpu():
     assert out[0] is True and out[1] is True
 
 
-def test_bench_two_ranks_one_gpu():
-    """bench.py as the driver launches it for N > 1 (torch.distributed.run), ranks sharing the GPU."""
+@pytest.mark.parametrize('nproc,shards,sharding', [(2, 0, 'db-rows/2 + all-to-all of local top-K'),
+                                                   (4, 2, 'db-rows/2 + all-to-all of local top-K x 2 replica groups'),
+                                                   (2, 1, '2 independent replicas')])
+def test_bench_multi_rank_one_gpu(nproc, shards, sharding):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run), ranks sharing the GPU:
+    database sharded over all ranks (default), shard groups x replica groups, independent replicas."""
     env = dict(os.environ, SNK_BENCH_SHARE_GPU='1')
-    port = 31500 + (os.getpid() % 2000)
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+    port = 31500 + (os.getpid() % 2000) + nproc * 3 + shards
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
-           '--gpus', '2', '--steps', '2', '--warmup', '1', '--units', '40000', '--frames', '60', '--utts', '5',
-           '--candidates', '20', '--no-cpu-baseline']
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+           '--gpus', str(nproc), '--steps', '2', '--warmup', '1', '--units', '40000', '--frames', '60', '--utts', '5',
+           '--candidates', '20', '--no-cpu-baseline', '--db-shards', str(shards)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
     js = json.loads(lines[0])
-    assert js['n_gpus'] == 2 and js['value'] > 0 and js['scaling'] == 'weak' and js['config']['utts_per_step'] == 10
+    assert js['n_gpus'] == nproc and js['value'] > 0 and js['scaling'] == 'weak'
+    assert js['config']['utts_per_step'] == 5 * nproc and js['config']['sharding'] == sharding
     assert 'roofline' in js and 'FUNCTIONAL TEST' in js['note']
