@@ -132,6 +132,9 @@ def main():
     wj = np.full(Dj, 0.2 * 0.25)                # join_stream_weights * join_cost_weight
     utts = [synthetic_targets(F_unw, T, seed=1 + u) * wt for u in range(U)]
     frames_per_step = sum(u.shape[0] for u in utts)
+    # the batch as the C ABI takes it (one contiguous matrix + row offsets), built once: a tuning loop
+    # searches the same tune set every iteration.  Every step still uploads it to the device.
+    batch = snickery_amd.QueryBatch(utts)
 
     eng = snickery_amd.HipSearchEngine(local_rank)       # raises without libsnkhip.so / gfx950
     if world == 1:
@@ -140,7 +143,7 @@ def main():
         n_local = N
 
         def step():
-            return eng.knn_viterbi_batch(utts, K)
+            return eng.knn_viterbi_batch(batch, K)
     else:
         from snickery_amd.dist import HipShardEngine, ShardedSearch, shard_bounds
         # ranks [q*S, (q+1)*S) form shard group q: the database is row-sharded over the S ranks of a
@@ -154,8 +157,8 @@ def main():
             groups = [dist.new_group(ranks=list(range(q * S, (q + 1) * S))) for q in range(n_groups)]
             group = groups[my_group]
         u_lo, u_hi = shard_bounds(U, n_groups, my_group)
-        my_utts = utts[u_lo:u_hi]
-        my_frames = sum(u.shape[0] for u in my_utts)
+        my_utts = batch.subset(u_lo, u_hi)
+        my_frames = int(sum(my_utts.lengths))
         lo, hi = shard_bounds(N, S, sub_rank)
         n_local = hi - lo
         if S == 1:

@@ -160,6 +160,21 @@ int snk_merge_topk_dev(snk_handle h, const double *d2_dev, const int64_t *id_dev
  *                         paths / lengths / costs of the owned utterances on the host. */
 int snk_knn_local_batch_dev(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts,
                             int D, int K, double *d2_dev_out, int64_t *id_dev_out);
+/* Step 1 with shared bounds (fewer survivors per shard, the more the more shards there are):
+ *   snk_knn_local_batch_bounds_dev  -> per row, an upper bound of the K-th nearest key of THIS shard
+ *                                      (stage A only; DBL_MAX where no bound is available), device buffer;
+ *   caller:                            all-reduce MIN of the (R,) bounds over the shards -- the smallest
+ *                                      still bounds the K-th nearest key of the whole database;
+ *   snk_knn_local_batch_bounded_dev -> as snk_knn_local_batch_dev, filtering against those bounds; a
+ *                                      shard's list may hold fewer than K entries (id -1 padding, as for
+ *                                      shards smaller than K).  Q == NULL: the query rows of the bounds
+ *                                      call are still resident.
+ * Replaces nothing in the reference (SURVEY 8e sketches the plain all-gather); results are identical. */
+int snk_knn_local_batch_bounds_dev(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts,
+                                   int D, int K, double *bound_dev_out /* (R,) */);
+int snk_knn_local_batch_bounded_dev(snk_handle h, const double *Q /* nullable */, const int64_t *row_offsets,
+                                    int n_utts, int D, int K, const double *bound_dev_in /* (R,) */,
+                                    double *d2_dev_out, int64_t *id_dev_out);
 int snk_merge_viterbi_batch_dev(snk_handle h, const double *d2_dev, const int64_t *id_dev, int G,
                                 const int64_t *row_offsets, int n_utts, int K,
                                 int64_t *path_out, int64_t *path_len_out, double *cost_out);

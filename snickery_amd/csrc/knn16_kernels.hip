@@ -444,59 +444,73 @@ bool launch_knn_sweep16(int mode, int nt, int dch, int grid_cus, const void *A32
 
 #define THR16_GROUPS 1024
 // ---------------------------------------------------------------------------
-// threshold from the f32 group minima: K-th smallest of G values + eps_t, as f32 rounded UP
+// threshold from the f32 group minima: K-th smallest of G values + eps_t, as f32 rounded UP.
+// bound = (K-th smallest group minimum) + eps is a true upper bound of the K-th nearest key of THIS
+// database; thr = bound + eps so that the filter's approximate test keeps everything below it.
+// Row-sharded databases: the smallest bound over all shards still bounds the K-th nearest key of
+// the WHOLE database, so the ranks exchange their bounds (bound_out -> all-reduce MIN -> bound_in)
+// and every shard filters against that instead of its own, looser one: G times fewer survivors.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 knn_threshold16_kernel(const float *__restrict__ gmin32, int64_t G, int64_t T, int64_t T32, int K,
-                       const double *__restrict__ eps, double *__restrict__ thr, float *__restrict__ thr32)
+                       const double *__restrict__ eps, double *__restrict__ thr, float *__restrict__ thr32,
+                       const double *__restrict__ bound_in, double *__restrict__ bound_out)
 {
     extern __shared__ float tkey[];
     const int64_t row = blockIdx.x;
     if (row >= T) { if (threadIdx.x == 0) { thr32[row] = -FLT_MAX; thr[row] = -DBL_MAX; } return; }
-    // more than 1024 groups are folded (minimum over every P-th group): the K-th smallest minimum of
-    // ANY partition of the sample into groups bounds the K-th nearest key from above
-    int P = 2;
-    while (P < G && P < THR16_GROUPS) P <<= 1;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) {
-        float m = FLT_MAX;
-        for (int64_t g = i; g < G; g += P) m = fminf(m, gmin32[row * G + g]);
-        tkey[i] = m;
-    }
-    __syncthreads();
-    for (int k = 2; k <= P; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < P; i += blockDim.x) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const bool up = ((i & k) == 0);
-                    const float a = tkey[i], b = tkey[ixj];
-                    if (up ? (b < a) : (a < b)) { tkey[i] = b; tkey[ixj] = a; }
-                }
-            }
-            __syncthreads();
+    double bound = DBL_MAX;
+    if (bound_in) {
+        bound = bound_in[row];
+    } else {
+        // more than 1024 groups are folded (minimum over every P-th group): the K-th smallest minimum of
+        // ANY partition of the sample into groups bounds the K-th nearest key from above
+        int P = 2;
+        while (P < G && P < THR16_GROUPS) P <<= 1;
+        for (int i = threadIdx.x; i < P; i += blockDim.x) {
+            float m = FLT_MAX;
+            for (int64_t g = i; g < G; g += P) m = fminf(m, gmin32[row * G + g]);
+            tkey[i] = m;
         }
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = threadIdx.x; i < P; i += blockDim.x) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const bool up = ((i & k) == 0);
+                        const float a = tkey[i], b = tkey[ixj];
+                        if (up ? (b < a) : (a < b)) { tkey[i] = b; tkey[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        // group minima are approximate: + eps makes the K-th smallest a true upper bound
+        if (G >= K && P >= K && tkey[K - 1] < FLT_MAX) bound = (double)tkey[K - 1] + eps[row];
+    }
     if (threadIdx.x == 0) {
         double v = DBL_MAX;
         float v32 = FLT_MAX;
-        if (G >= K && P >= K && tkey[K - 1] < FLT_MAX) {
-            // group minima are approximate: + eps makes the K-th smallest a true upper bound of the
-            // K-th nearest key; + eps again so that the filter's approximate test keeps everything
-            v = (double)tkey[K - 1] + 2.0 * eps[row];
-            v32 = (float)v;
-            if ((double)v32 < v) v32 = nextafterf(v32, FLT_MAX);
+        if (bound < 0.5 * DBL_MAX) {
+            v = bound + eps[row];
+            if (v < (double)FLT_MAX) {
+                v32 = (float)v;
+                if ((double)v32 < v) v32 = nextafterf(v32, FLT_MAX);
+            }
         }
         thr[row] = v;
         thr32[row] = v32;
+        if (bound_out) bound_out[row] = bound;
     }
 }
 
 void launch_knn_threshold16(const float *gmin32, int64_t G, int64_t T, int64_t T32, int K, const double *eps,
-                            double *thr, float *thr32, hipStream_t s)
+                            double *thr, float *thr32, const double *bound_in, double *bound_out, hipStream_t s)
 {
     int P = 2;
     while (P < G && P < THR16_GROUPS) P <<= 1;
     hipLaunchKernelGGL(knn_threshold16_kernel, dim3((unsigned)T32), dim3(256), (size_t)P * sizeof(float), s,
-                       gmin32, G, T, T32, K, eps, thr, thr32);
+                       gmin32, G, T, T32, K, eps, thr, thr32, bound_in, bound_out);
 }
 
 // ---------------------------------------------------------------------------

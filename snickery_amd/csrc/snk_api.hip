@@ -122,10 +122,12 @@ struct snk_engine {
     // greedy
     GreedyLayout glay{};
     bool have_glay = false, gtiles_ready = false;
+    int64_t qall_rows = -1;               // rows of the batch resident in Qall
     DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist, gsync, gtiles;
     // options
     int cap = 4096;
     double sample_frac = 1.0 / 16.0;
+    int min_sample_slabs = 256;           // small databases / shards: the sample stride shrinks to keep this many sampled slabs
     int nt_override = 0;
     int timers_on = 1;
     int n_cus = 256;
@@ -396,7 +398,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
         if (stride < 1) stride = 1;
         // small databases (one rank's shard of a row-sharded one): keep >= 512 sample groups so the
         // K-th smallest group minimum stays close to the K-th nearest sampled unit
-        while (stride > 1 && (h->N / stride) / slab_rows < 256) --stride;
+        while (stride > 1 && (h->N / stride) / slab_rows < h->min_sample_slabs) --stride;
         h->stride16 = stride;
         h->n_slabs16_a = (h->N / stride) / slab_rows;
         if (fmax2 < 1.0e30 && h->n_slabs16_a >= 1) {
@@ -466,8 +468,15 @@ static KnnPlan make_plan(snk_engine *h, int K)
 // deferred_status != nullptr: enqueue the first attempt only, leave its status word in that device
 // int and do NOT synchronise (batch pipeline: the caller checks all words at the end of the batch
 // and redoes the rare overflowed utterance synchronously).
+//
+// Row-sharded databases (snk_knn_local_batch_bounds_dev / _bounded_dev): `bound_out` != nullptr runs stage
+// A only and leaves, per row, an upper bound of the K-th nearest key of THIS shard (DBL_MAX where the
+// f32 path cannot give one); `bound_in` != nullptr skips stage A and filters against bound_in + eps --
+// the caller passes the minimum of the bounds of all shards, which still bounds the K-th nearest key
+// of the whole database.  Lists may then hold fewer than K entries (padded with id -1).
 static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_t *qclass_dev,
-                      int64_t *cand_dev, double *dist_dev, double *d2_dev, int *deferred_status = nullptr)
+                      int64_t *cand_dev, double *dist_dev, double *d2_dev, int *deferred_status = nullptr,
+                      const double *bound_in = nullptr, double *bound_out = nullptr)
 {
     if (K < 1 || K > 208) return fail("K-NN: n_candidates=%d outside the supported range 1..208", K);
     if (T > SNK_KNN_MAX_ROWS) {
@@ -477,7 +486,8 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             const int64_t rows = (T - r0 < SNK_KNN_MAX_ROWS) ? T - r0 : SNK_KNN_MAX_ROWS;
             CHK(knn_device(h, Qdev + r0 * h->Dt, rows, K, qclass_dev ? qclass_dev + r0 : nullptr,
                            cand_dev ? cand_dev + r0 * K : nullptr, dist_dev ? dist_dev + r0 * K : nullptr,
-                           d2_dev ? d2_dev + r0 * K : nullptr));
+                           d2_dev ? d2_dev + r0 * K : nullptr, nullptr, bound_in ? bound_in + r0 : nullptr,
+                           bound_out ? bound_out + r0 : nullptr));
         }
         if (deferred_status) HIPCHK(hipMemsetAsync(deferred_status, 0, sizeof(int), h->stream));
         return 0;
@@ -556,7 +566,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             launch_prepare_queries16(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad,
                                      h->fmax2.as<double>(), h->eps_c, h->b16h.p, h->eps16.as<double>(), s);
         }
-        {
+        if (!bound_in) {
             StageTimer t(h, s, TM_KNN_MINIMA);
             launch_knn_sweep16(0, nt_run, dch16, p0.grid_cus, h->s16h.p, h->b16h.p, cls_samp, qclass_dev,
                                nullptr, Tpad, n_slabs_a, h->slabctr.as<unsigned int>(), h->gmin32.as<float>(),
@@ -565,8 +575,9 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         {
             StageTimer t(h, s, TM_KNN_THRESHOLD);
             launch_knn_threshold16(h->gmin32.as<float>(), G16, T, Tpad, K, h->eps16.as<double>(), h->thr.as<double>(),
-                                   h->thr32.as<float>(), s);
+                                   h->thr32.as<float>(), bound_in, bound_out, s);
         }
+        if (bound_out) return 0;             // stage A only
         {
             StageTimer t(h, s, TM_KNN_FILTER);
             launch_knn_sweep16(1, nt_run, dch16, p0.grid_cus, h->a16h.p, h->b16h.p, cls_full, qclass_dev,
@@ -595,6 +606,10 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         h->f16_fallbacks += 1;               // overflow or too many near ties: exact f64 sweep below
     }
 
+    if (bound_out) {                          // no f32 path for this shape: no bound, nothing is pruned
+        launch_fill_threshold(bound_out, T, T, DBL_MAX, s);
+        return 0;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         // attempt 0: thresholds from a strided sample of slabs (stage A).
         // attempt 1 (a candidate list overflowed): stage A over EVERY slab -- at most
@@ -1144,30 +1159,45 @@ int snk_merge_topk_dev(snk_handle h, const double *d2_dev, const int64_t *id_dev
 // Batch form of snk_knn_local_dev: the rows of all utterances against this rank's shard, first
 // attempts enqueued back to back (status words checked once at the end, the rare overflowed
 // utterance redone with the exact f64 sweep).  Results are complete when the call returns.
-int snk_knn_local_batch_dev(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
-                            double *d2_dev_out, int64_t *id_dev_out)
+// Shared body of the three shard-local batch calls.  bound_out: stage A only (per-row bounds);
+// bound_in: filter against the caller's bounds; Q == nullptr: the rows of the previous call are
+// still resident (the bounds call and the bounded call of one step see the same batch).
+static int knn_local_batch(snk_engine *h, const char *who, const double *Q, const int64_t *row_offsets, int n_utts,
+                           int D, int K, const double *bound_in, double *bound_out, double *d2_dev_out,
+                           int64_t *id_dev_out)
 {
     CHK(check_ready(h, true, false));
     HIPCHK(hipSetDevice(h->device));
-    if (!Q || !row_offsets || n_utts < 1 || !d2_dev_out || !id_dev_out)
-        return fail("snk_knn_local_batch_dev: null/empty argument");
+    if (!row_offsets || n_utts < 1 || (!bound_out && (!d2_dev_out || !id_dev_out)))
+        return fail("%s: null/empty argument", who);
     if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
     const int64_t total = row_offsets[n_utts];
     for (int u = 0; u < n_utts; ++u)
-        if (row_offsets[u + 1] - row_offsets[u] < 1) return fail("snk_knn_local_batch_dev: utterance %d has no rows", u);
+        if (row_offsets[u + 1] - row_offsets[u] < 1) return fail("%s: utterance %d has no rows", who, u);
     // the search is per row: fixed-size row groups, whatever the utterance boundaries
     const int64_t step = h->batch_rows > 0 ? h->batch_rows : total;
     const int n_groups = (int)((total + step - 1) / step);
-    CHK(h->Qall.ensure((size_t)total * D * sizeof(double)));
-    CHK(h->res_status.ensure((size_t)n_groups * sizeof(int)));
-    {
+    if (Q) {
+        CHK(h->Qall.ensure((size_t)total * D * sizeof(double)));
         StageTimer t(h, h->stream, TM_H2D);
         HIPCHK(hipMemcpyAsync(h->Qall.p, Q, (size_t)total * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        h->qall_rows = total;
+    } else if (h->qall_rows != total) {
+        return fail("%s: no query matrix given and the resident one has %lld rows, not %lld", who,
+                    (long long)h->qall_rows, (long long)total);
     }
+    CHK(h->res_status.ensure((size_t)n_groups * sizeof(int)));
     for (int g = 0; g < n_groups; ++g) {
         const int64_t r0 = g * step, rows = (r0 + step <= total) ? step : total - r0;
-        CHK(knn_device(h, h->Qall.as<double>() + r0 * D, rows, K, nullptr, id_dev_out + r0 * K, nullptr,
-                       d2_dev_out + r0 * K, h->res_status.as<int>() + g));
+        CHK(knn_device(h, h->Qall.as<double>() + r0 * D, rows, K, nullptr, id_dev_out ? id_dev_out + r0 * K : nullptr,
+                       nullptr, d2_dev_out ? d2_dev_out + r0 * K : nullptr, h->res_status.as<int>() + g,
+                       bound_in ? bound_in + r0 : nullptr, bound_out ? bound_out + r0 : nullptr));
+    }
+    if (bound_out) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipGetLastError());
+        collect_timers(h);
+        return 0;
     }
     std::vector<int> st((size_t)n_groups);
     HIPCHK(hipMemcpyAsync(st.data(), h->res_status.p, (size_t)n_groups * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1187,6 +1217,29 @@ int snk_knn_local_batch_dev(snk_handle h, const double *Q, const int64_t *row_of
     }
     collect_timers(h);
     return 0;
+}
+
+int snk_knn_local_batch_dev(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
+                            double *d2_dev_out, int64_t *id_dev_out)
+{
+    if (!Q) return fail("snk_knn_local_batch_dev: null query matrix");
+    return knn_local_batch(h, "snk_knn_local_batch_dev", Q, row_offsets, n_utts, D, K, nullptr, nullptr, d2_dev_out, id_dev_out);
+}
+
+int snk_knn_local_batch_bounds_dev(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
+                                   double *bound_dev_out)
+{
+    if (!Q || !bound_dev_out) return fail("snk_knn_local_batch_bounds_dev: null argument");
+    return knn_local_batch(h, "snk_knn_local_batch_bounds_dev", Q, row_offsets, n_utts, D, K, nullptr, bound_dev_out,
+                           nullptr, nullptr);
+}
+
+int snk_knn_local_batch_bounded_dev(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
+                                    const double *bound_dev_in, double *d2_dev_out, int64_t *id_dev_out)
+{
+    if (!bound_dev_in) return fail("snk_knn_local_batch_bounded_dev: null bounds");
+    return knn_local_batch(h, "snk_knn_local_batch_bounded_dev", Q, row_offsets, n_utts, D, K, bound_dev_in, nullptr,
+                           d2_dev_out, id_dev_out);
 }
 
 // Second half of the sharded search on the rank that owns the utterances: merge the G shard-local
@@ -1325,6 +1378,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "sample_fraction")) {
         if (!(value > 0.0 && value <= 1.0)) return fail("sample_fraction must be in (0,1]");
         h->sample_frac = value;
+    } else if (!strcmp(name, "min_sample_slabs")) {
+        if (!(value >= 1.0 && value <= 65536.0)) return fail("min_sample_slabs must be in 1..65536");
+        h->min_sample_slabs = (int)value;
     } else if (!strcmp(name, "db_tiles_per_wave")) {
         h->nt_override = (int)value;
     } else if (!strcmp(name, "f32_tiles_per_wave")) {

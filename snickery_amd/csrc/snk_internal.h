@@ -78,7 +78,7 @@ bool launch_knn_sweep16(int mode, int nt, int dch, int grid_cus, const void *A32
                         float *gmin32, int64_t G, void *pool, unsigned int *pool_ctl, int *chunk_fill,
                         int max_chunks, int pool_chunk, hipStream_t s);
 void launch_knn_threshold16(const float *gmin32, int64_t G, int64_t T, int64_t T32, int K, const double *eps,
-                            double *thr, float *thr32, hipStream_t s);
+                            double *thr, float *thr32, const double *bound_in, double *bound_out, hipStream_t s);
 void launch_mfma16_selftest(const float *A, const float *B, float *C, hipStream_t s);
 int knn_pool_chunk_entries();
 void sweep_tail_split(int64_t n_slabs, int qsplit, int64_t waves, int nQT, int64_t *n_main, int *qtail);

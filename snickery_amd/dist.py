@@ -42,6 +42,22 @@ def _all_gather(outs, inp, group):
         dist.all_gather(outs, inp, group=group)
 
 
+def _all_reduce_min(t, group):
+    if _staged(group) and t.is_cuda:
+        c = t.cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.MIN, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+
+
+def _lengths(utterances):
+    """Row counts of a list of per-utterance matrices or of a snickery_amd.QueryBatch."""
+    if hasattr(utterances, 'lengths'):
+        return list(utterances.lengths)
+    return [int(np.shape(U)[0]) for U in utterances]
+
+
 def shard_bounds(n_units, world_size, rank):
     """Contiguous row shard [lo, hi) of rank; sizes differ by at most one unit."""
     base, rem = divmod(int(n_units), int(world_size))
@@ -73,15 +89,25 @@ class HipShardEngine(object):
     def knn_local_batch(self, utterances, K, d2_out, id_out):
         self.engine.knn_local_batch_dev(utterances, K, d2_out.data_ptr(), id_out.data_ptr())
 
+    def knn_local_batch_bounds(self, utterances, K, bound_out):
+        self._lengths = _lengths(utterances)
+        _, self._columns = self.engine.knn_local_batch_bounds_dev(utterances, K, bound_out.data_ptr())
+
+    def knn_local_batch_bounded(self, utterances, K, bound_in, d2_out, id_out):
+        torch.cuda.synchronize(self.device)          # the all-reduce of the bounds ran on torch's stream
+        self.engine.knn_local_batch_bounded_dev(self._lengths, self._columns, K, bound_in.data_ptr(),
+                                                d2_out.data_ptr(), id_out.data_ptr())
+
     def merge_viterbi_batch(self, d2_all, id_all, G, lengths, K):
         torch.cuda.synchronize(self.device)          # the exchange ran on torch's stream
         return self.engine.merge_viterbi_batch_dev(d2_all.data_ptr(), id_all.data_ptr(), G, lengths, K)
 
 
 class ShardedSearch(object):
-    def __init__(self, shard_engine, rank=None, world_size=None, group=None):
+    def __init__(self, shard_engine, rank=None, world_size=None, group=None, shared_bounds=True):
         self.e = shard_engine
         self.group = group
+        self.shared_bounds = shared_bounds
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world_size is None else world_size
 
@@ -111,13 +137,22 @@ class ShardedSearch(object):
         G-fold all-gather volume.  Step 2 (owner): merge, join costs, Viterbi."""
         G = self.world
         n = len(utterances)
-        lens = [int(np.shape(U)[0]) for U in utterances]
+        lens = _lengths(utterances)
         owned = [shard_bounds(n, G, r) for r in range(G)]          # utterance blocks per rank
         rows_to = [sum(lens[a:b]) for a, b in owned]
         R = sum(lens)
         d2 = self.e.alloc(R, K, dtype=torch.float64)
         ids = self.e.alloc(R, K, dtype=torch.int64)
-        self.e.knn_local_batch(utterances, K, d2, ids)
+        if G > 1 and self.shared_bounds:
+            # every shard bounds the K-th nearest key of ITS units from a sample; the smallest of
+            # those bounds still bounds the K-th nearest key of the whole database, and filtering every
+            # shard against it leaves about 1/G of the survivors (R x 8 bytes, one all-reduce)
+            bound = self.e.alloc(R, dtype=torch.float64)
+            self.e.knn_local_batch_bounds(utterances, K, bound)
+            _all_reduce_min(bound, self.group)
+            self.e.knn_local_batch_bounded(utterances, K, bound, d2, ids)
+        else:
+            self.e.knn_local_batch(utterances, K, d2, ids)
         lo, hi = owned[self.rank]
         r_own = rows_to[self.rank]
         if G == 1:

@@ -65,6 +65,10 @@ _SIGNATURES = {
                                           ctypes.c_int64, ctypes.c_int, _c_i64p, _c_f64p]),
     'snk_knn_local_batch_dev': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    'snk_knn_local_batch_bounds_dev': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int, ctypes.c_int,
+                                                      ctypes.c_int, ctypes.c_void_p]),
+    'snk_knn_local_batch_bounded_dev': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int, ctypes.c_int,
+                                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'snk_merge_viterbi_batch_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                    _c_i64p, ctypes.c_int, ctypes.c_int, _c_i64p, _c_i64p, _c_f64p]),
     'snk_upload_join_only': (ctypes.c_int, [ctypes.c_void_p, _c_f32p, ctypes.c_int64, ctypes.c_int]),
@@ -103,6 +107,36 @@ def _f64(a):
 
 def _ptr(a, typ):
     return a.ctypes.data_as(typ)
+
+
+class QueryBatch(object):
+    """The query rows of several utterances as the C ABI takes them: one contiguous float64 matrix
+    (rows of all utterances in order) + row offsets.  Callers that search the same tune set again and
+    again (balance_stream_weights.py) build it once; every batch entry point accepts it in place of
+    the list of per-utterance matrices and then skips the concatenation (75 MB of host copying for
+    256 utterances of 600 frames)."""
+
+    def __init__(self, utterances):
+        mats = [_f64(u) for u in utterances]
+        self.lengths = [int(m.shape[0]) for m in mats]
+        self.offsets = np.zeros(len(mats) + 1, dtype=np.int64)
+        self.offsets[1:] = np.cumsum(self.lengths)
+        self.Q = np.ascontiguousarray(np.vstack(mats))
+
+    def __len__(self):
+        return len(self.lengths)
+
+    def subset(self, lo, hi):
+        """Utterances lo..hi-1 as a batch of their own (a view of the same rows)."""
+        b = QueryBatch.__new__(QueryBatch)
+        b.lengths = self.lengths[lo:hi]
+        b.offsets = self.offsets[lo:hi + 1] - self.offsets[lo]
+        b.Q = self.Q[self.offsets[lo]:self.offsets[hi]]
+        return b
+
+
+def _as_batch(utterances):
+    return utterances if isinstance(utterances, QueryBatch) else QueryBatch(utterances)
 
 
 class HipSearchEngine(object):
@@ -246,18 +280,15 @@ class HipSearchEngine(object):
     def knn_viterbi_batch(self, utterances, n_candidates):
         """Several utterances in one call (stages of consecutive utterances overlap).
         Returns (list of paths (np.int64 arrays), costs array)."""
-        mats = [_f64(u) for u in utterances]
-        D = mats[0].shape[1]
-        offs = np.zeros(len(mats) + 1, dtype=np.int64)
-        offs[1:] = np.cumsum([m.shape[0] for m in mats])
-        Q = np.ascontiguousarray(np.vstack(mats))
+        b = _as_batch(utterances)
+        offs, n = b.offsets, len(b)
         paths = np.empty((int(offs[-1]),), dtype=np.int64)
-        plen = np.zeros(len(mats), dtype=np.int64)
-        cost = np.zeros(len(mats), dtype=np.float64)
-        self._check(self._lib.snk_knn_viterbi_batch(self._h, _ptr(Q, _c_f64p), _ptr(offs, _c_i64p), len(mats), D,
+        plen = np.zeros(n, dtype=np.int64)
+        cost = np.zeros(n, dtype=np.float64)
+        self._check(self._lib.snk_knn_viterbi_batch(self._h, _ptr(b.Q, _c_f64p), _ptr(offs, _c_i64p), n, b.Q.shape[1],
                                                     int(n_candidates), _ptr(paths, _c_i64p),
                                                     _ptr(plen, _c_i64p), _ptr(cost, _c_f64p)))
-        out = [paths[offs[u]:offs[u] + plen[u]].copy() for u in range(len(mats))]
+        out = [paths[offs[u]:offs[u] + plen[u]].copy() for u in range(n)]
         return out, cost
 
     def set_greedy_layout(self, multiepoch=1, last_frame_as_target=False, join_split_mode=0):
@@ -307,13 +338,30 @@ class HipSearchEngine(object):
     def knn_local_batch_dev(self, utterances, n_candidates, d2_dev_ptr, id_dev_ptr):
         """Shard-local top-K of the rows of all utterances, written to caller device buffers
         (R, K) in utterance order; complete when the call returns."""
-        mats = [_f64(u) for u in utterances]
-        offs = np.zeros(len(mats) + 1, dtype=np.int64)
-        offs[1:] = np.cumsum([m.shape[0] for m in mats])
-        Q = np.ascontiguousarray(np.vstack(mats))
-        self._check(self._lib.snk_knn_local_batch_dev(self._h, _ptr(Q, _c_f64p), _ptr(offs, _c_i64p), len(mats),
-                                                      Q.shape[1], int(n_candidates),
+        b = _as_batch(utterances)
+        self._check(self._lib.snk_knn_local_batch_dev(self._h, _ptr(b.Q, _c_f64p), _ptr(b.offsets, _c_i64p), len(b),
+                                                      b.Q.shape[1], int(n_candidates),
                                                       ctypes.c_void_p(d2_dev_ptr), ctypes.c_void_p(id_dev_ptr)))
+
+    def knn_local_batch_bounds_dev(self, utterances, n_candidates, bound_dev_ptr):
+        """Stage A of the shard-local search only: per row of the batch, an upper bound of the K-th
+        nearest key of this shard, written to the caller's device buffer (R,) float64.  The caller
+        all-reduces (MIN) the bounds of all shards and hands them to knn_local_batch_bounded_dev."""
+        b = _as_batch(utterances)
+        self._check(self._lib.snk_knn_local_batch_bounds_dev(self._h, _ptr(b.Q, _c_f64p), _ptr(b.offsets, _c_i64p), len(b),
+                                                             b.Q.shape[1], int(n_candidates), ctypes.c_void_p(bound_dev_ptr)))
+        return b.offsets, b.Q.shape[1]
+
+    def knn_local_batch_bounded_dev(self, lengths, n_columns, n_candidates, bound_dev_ptr, d2_dev_ptr, id_dev_ptr):
+        """Shard-local top-K of the batch of the preceding knn_local_batch_bounds_dev call (its query
+        rows are still on the device), filtered against the caller's bounds; a list may hold fewer
+        than K entries (id -1 padding)."""
+        offs = np.zeros(len(lengths) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum(lengths)
+        self._check(self._lib.snk_knn_local_batch_bounded_dev(self._h, None, _ptr(offs, _c_i64p), len(lengths),
+                                                              int(n_columns), int(n_candidates),
+                                                              ctypes.c_void_p(bound_dev_ptr),
+                                                              ctypes.c_void_p(d2_dev_ptr), ctypes.c_void_p(id_dev_ptr)))
 
     def merge_viterbi_batch_dev(self, d2_dev_ptr, id_dev_ptr, n_lists, lengths, n_candidates):
         """Owner-rank half of the sharded search: (G, R, K) gathered lists of the utterances with

@@ -58,6 +58,24 @@ class OracleShardEngine(object):
             self.knn_local(U, K, d2_out[r0:r0 + U.shape[0]], id_out[r0:r0 + U.shape[0]])
             r0 += U.shape[0]
 
+    def knn_local_batch_bounds(self, utterances, K, bound_out):
+        # an upper bound of the K-th nearest squared distance of this shard: the exact one, loosened
+        import snk_oracle as o
+        r0 = 0
+        for U in utterances:
+            cand, d = o.knn_bruteforce(self.F, U, K)
+            for t in range(U.shape[0]):
+                ok = cand[t] >= 0
+                full = int(ok.sum()) == K
+                bound_out[r0 + t] = float(o.sqdist_rows(self.F[cand[t, ok]], U[t]).max()) * 1.5 if full else float('inf')
+            r0 += U.shape[0]
+
+    def knn_local_batch_bounded(self, utterances, K, bound_in, d2_out, id_out):
+        self.knn_local_batch(utterances, K, d2_out, id_out)
+        keep = d2_out <= bound_in.reshape(-1, 1)          # what a shard filtering against the bound returns
+        d2_out[~keep] = 1e30
+        id_out[~keep] = -1
+
     def merge_viterbi_batch(self, d2_all, id_all, G, lengths, K):
         R = sum(lengths)
         cand, dd = self.merge(d2_all, id_all, G, R, K)
