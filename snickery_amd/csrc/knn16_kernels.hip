@@ -85,7 +85,8 @@ __global__ void build_db16_kernel(const double *__restrict__ Fw, const double *_
     f32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int c = 64 * (j4 >> 3) + 32 * h + 4 * (j4 & 7) + i;
+        const int c = 64 * (j4 >> 3) + 2 * (4 * (j4 & 7) + i) + h;       // k-step kk = 4 (j4 & 7) + i multiplies columns 2kk, 2kk+1:
+                                                                       // padding columns gather in the last k-steps
         float x = 0.0f;
         if (row < N) {
             if (c < Dt) x = (float)Fw[row * Dpad + c];
@@ -143,7 +144,8 @@ __global__ void prepare_queries16_kernel(const double *__restrict__ Qp, const do
     f32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int c = 64 * (j4 >> 3) + 32 * h + 4 * (j4 & 7) + i;
+        const int c = 64 * (j4 >> 3) + 2 * (4 * (j4 & 7) + i) + h;       // k-step kk = 4 (j4 & 7) + i multiplies columns 2kk, 2kk+1:
+                                                                       // padding columns gather in the last k-steps
         float x = 0.0f;
         if (row < T) {
             if (c < Dt) x = (float)(-2.0 * Qp[row * Dpad + c]);
@@ -172,7 +174,10 @@ void launch_prepare_queries16(const double *Qp, const double *qnorm, int64_t T, 
 //   MODE 0: minima per (wave slab, lane half) group over the scattered sample -> gmin32[row][G]
 //   MODE 1: filter over the whole database -> entry pool (same pool / bucket / finalize as f64)
 // ---------------------------------------------------------------------------
-template <int NT, int MODE, int DCH, bool CLS>
+// KU: MFMA k-steps actually issued per tile (<= 32 * DCH).  The operands are zero beyond column Dt (the
+// norm column), so k-steps that would only multiply padding are skipped: 31 instead of 32 at Dt = 60, 61
+// (3 % of the matrix work; adding 0 x 0 to an accumulator does not change it, the keys are the same bits).
+template <int NT, int MODE, int DCH, bool CLS, int KU = 32 * DCH>
 __global__ void __launch_bounds__(256, (NT <= 2 && DCH == 1 && !CLS) ? 2 : 1)
 knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
             const int32_t *__restrict__ tile_class, const int32_t *__restrict__ query_class,
@@ -183,8 +188,15 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
             int max_chunks, int pool_chunk)
 {
     // per-wave staging area of survivors (a few per 32x32 tile); flushed to the wave's pool chunk one
-    // tile later, or on the spot when a burst would not fit (up to 256 entries per group of four results)
-    constexpr int STAGE_CAP = 768;
+    // tile later.  A burst that would not fit is flushed on the spot (SPOT: 768 entries = 49 KB of LDS per
+    // workgroup, checked per group of four results) or provided for up front (room for every result of
+    // a step, checked once per step).  The on-the-spot check sits inside the MFMA shadow code; the
+    // three- and four-chunk variants have no registers left for it (1.1 KB of scratch, 4x slower).
+#ifndef SNK_SWEEP16_SPOT
+#define SNK_SWEEP16_SPOT(NT_, DCH_, CLS_) ((DCH_) <= 2)
+#endif
+    constexpr bool SPOT = SNK_SWEEP16_SPOT(NT, DCH, CLS);
+    constexpr int STAGE_CAP = SPOT ? 768 : 64 * 16 * ((NT >= 2) ? 2 : 1) + 256;
     __shared__ PoolEntry16 stage[(MODE == 1) ? 4 : 1][(MODE == 1) ? STAGE_CAP : 1];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -294,18 +306,22 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
                 const float pth = (st > 0) ? th_cur : th_prev;
                 const int pqt = (st > 0) ? qt : qt_prev;
                 const int pqc = (st > 0) ? qc_cur : qc_prev;
+                if (MODE == 1 && !SPOT && lcount > STAGE_CAP - 64 * 16 * CH) flush_stage();
                 f16acc acc[CH];
 #pragma unroll
                 for (int j = 0; j < CH; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) {
+                for (int kk = 0; kk < KU; ++kk) {
 #pragma unroll
                     for (int j = 0; j < CH; ++j)
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[st * CH + j][kk], x[kk], acc[j], 0, 0, 0);
-                    const int k = kk;                   // the pending results are tested during the first 32 k-steps
-                    if (kk >= 32) continue;
+                    // the pending results are tested during the first 32 k-steps (one chunk); with skipped
+                    // trailing k-steps the schedule moves up by their number (at most 3)
+                    static_assert(KS - KU >= 0 && KS - KU <= 3, "at most three skipped k-steps");
+                    const int k = kk + (KS - KU);
+                    if (k >= 32) continue;
                     // the 16*CH pending results are tested four at a time in the MFMA shadows: one
                     // min3/min + compare per group; the per-result ballots run only when some lane
                     // of the group passes (a few entries per 32x32 tile do)
@@ -322,7 +338,7 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
                             const float m4 = fminf(__builtin_fminf(__builtin_fminf(v4[0], v4[1]), v4[2]), v4[3]);
                             if (MODE == 0) gm = fminf(gm, m4);
                             else if (__any(m4 <= pth)) {
-                                if (lcount > STAGE_CAP - 256) flush_stage();
+                                if (SPOT && lcount > STAGE_CAP - 256) flush_stage();
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
                                     const int r = r0 + q;
@@ -365,6 +381,7 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
             if (it + 1 < n_t) tile_body(b1, b0, it + 1);
         }
         // drain the last pending step of this work item
+        if (MODE == 1 && !SPOT && lcount > STAGE_CAP - 64 * 16 * CH) flush_stage();
 #pragma unroll
         for (int j = 0; j < CH; ++j)
 #pragma unroll
@@ -372,7 +389,7 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
                 const float key = (CLS && ucls[(NSTEP - 1) * CH + j][r] != qc_prev) ? __builtin_inff() : pacc[j][r];
                 if (MODE == 0) gm = fminf(gm, key);
                 else {
-                    if (lcount > STAGE_CAP - 64) flush_stage();
+                    if (SPOT && lcount > STAGE_CAP - 64) flush_stage();
                     const bool pass = key <= th_prev;
                     const unsigned long long m = __ballot(pass);
                     if (pass) {
@@ -395,7 +412,7 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
     }
 }
 
-template <int NT, int DCH, bool CLS>
+template <int NT, int DCH, bool CLS, int KU = 32 * DCH>
 static void launch16_t(int mode, int blocks, hipStream_t s, const void *A32, const void *B32,
                        const int32_t *tile_class, const int32_t *query_class,
                        const float *thr32, int nQT, int64_t n_slabs, unsigned int *ctr,
@@ -403,7 +420,7 @@ static void launch16_t(int mode, int blocks, hipStream_t s, const void *A32, con
                        unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk)
 {
 #define SNK_L16(MODE_)                                                                                    \
-    hipLaunchKernelGGL((knn_sweep16<NT, MODE_, DCH, CLS>), dim3(blocks), dim3(256), 0, s, (const f32x4 *)A32, \
+    hipLaunchKernelGGL((knn_sweep16<NT, MODE_, DCH, CLS, KU>), dim3(blocks), dim3(256), 0, s, (const f32x4 *)A32, \
                        (const f32x4 *)B32, tile_class, query_class, thr32, nQT, n_slabs, ctr, qsplit, n_main, qtail, \
                        gmin32, G, (PoolEntry16 *)pool, pool_ctl, chunk_fill, max_chunks, pool_chunk)
     if (mode == 0) SNK_L16(0);
@@ -411,9 +428,10 @@ static void launch16_t(int mode, int blocks, hipStream_t s, const void *A32, con
 #undef SNK_L16
 }
 
-// nt: tiles (32 units) per wave, dch: 64-column chunks per row; tile_class / query_class non-null:
+// nt: tiles (32 units) per wave, dch: 64-column chunks per row; k_steps: ceil((Dt + 1) / 2) k-steps carry
+// data (only 31 at dch = 1 has a variant of its own); tile_class / query_class non-null:
 // class-restricted search.  Returns false when the shape is not instantiated.
-bool launch_knn_sweep16(int mode, int nt, int dch, int grid_cus, const void *A32, const void *B32,
+bool launch_knn_sweep16(int mode, int nt, int dch, int k_steps, int grid_cus, const void *A32, const void *B32,
                         const int32_t *tile_class, const int32_t *query_class,
                         const float *thr32, int64_t T32, int64_t n_slabs, unsigned int *ctr,
                         float *gmin32, int64_t G, void *pool, unsigned int *pool_ctl, int *chunk_fill,
@@ -435,6 +453,17 @@ bool launch_knn_sweep16(int mode, int nt, int dch, int grid_cus, const void *A32
                                     qsplit, n_main, qtail, gmin32, G, pool, pool_ctl, chunk_fill, max_chunks, pool_chunk); \
         return true;                                                                                       \
     }
+    // shapes whose last k-steps are all padding (the reference's own widths): Dt = 60, 61 (magphase-60
+    // epoch targets, 31 of 32 k-steps) and Dt = 184, 185 (three-point halfphone targets, 93 of 96)
+#define SNK_KU16(NT_, DCH_, CLS_, KU_)                                                                     \
+    if (nt == NT_ && dch == DCH_ && cls == CLS_ && k_steps == KU_) {                                       \
+        launch16_t<NT_, DCH_, CLS_, KU_>(mode, (int)blocks, s, A32, B32, tile_class, query_class, thr32, nQT, n_slabs, \
+                                         ctr, qsplit, n_main, qtail, gmin32, G, pool, pool_ctl, chunk_fill, max_chunks, \
+                                         pool_chunk);                                                      \
+        return true;                                                                                       \
+    }
+    SNK_KU16(4, 1, false, 31) SNK_KU16(1, 3, false, 93) SNK_KU16(1, 3, true, 93)
+#undef SNK_KU16
     SNK_NT16(4, 1, false) SNK_NT16(2, 1, false) SNK_NT16(8, 1, false) SNK_NT16(2, 2, false) SNK_NT16(1, 3, false)
     SNK_NT16(1, 4, false)
     SNK_NT16(2, 1, true) SNK_NT16(2, 2, true) SNK_NT16(1, 3, true) SNK_NT16(1, 4, true)

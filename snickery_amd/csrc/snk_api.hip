@@ -568,7 +568,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         }
         if (!bound_in) {
             StageTimer t(h, s, TM_KNN_MINIMA);
-            launch_knn_sweep16(0, nt_run, dch16, p0.grid_cus, h->s16h.p, h->b16h.p, cls_samp, qclass_dev,
+            launch_knn_sweep16(0, nt_run, dch16, (h->Dt + 2) / 2, p0.grid_cus, h->s16h.p, h->b16h.p, cls_samp, qclass_dev,
                                nullptr, Tpad, n_slabs_a, h->slabctr.as<unsigned int>(), h->gmin32.as<float>(),
                                G16, nullptr, nullptr, nullptr, 0, knn_pool_chunk_entries(), s);
         }
@@ -580,7 +580,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         if (bound_out) return 0;             // stage A only
         {
             StageTimer t(h, s, TM_KNN_FILTER);
-            launch_knn_sweep16(1, nt_run, dch16, p0.grid_cus, h->a16h.p, h->b16h.p, cls_full, qclass_dev,
+            launch_knn_sweep16(1, nt_run, dch16, (h->Dt + 2) / 2, p0.grid_cus, h->a16h.p, h->b16h.p, cls_full, qclass_dev,
                                h->thr32.as<float>(), Tpad, n_slabs_b, h->slabctr.as<unsigned int>() + 1, nullptr, 0,
                                h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
                                knn_pool_chunk_entries(), s);

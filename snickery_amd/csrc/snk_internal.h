@@ -72,7 +72,7 @@ void launch_prepare_queries16(const double *Qp, const double *qnorm, int64_t T, 
                               const double *fmax2, double eps_c, void *B32, double *eps, hipStream_t s);
 void launch_build_class16(const int32_t *unit_class, int64_t N, int64_t n_tiles, int64_t sample_stride, int64_t G,
                           int nt_a, int32_t *out, hipStream_t s);
-bool launch_knn_sweep16(int mode, int nt, int dch, int grid_cus, const void *A32, const void *B32,
+bool launch_knn_sweep16(int mode, int nt, int dch, int k_steps, int grid_cus, const void *A32, const void *B32,
                         const int32_t *tile_class, const int32_t *query_class,
                         const float *thr32, int64_t T32, int64_t n_slabs, unsigned int *ctr,
                         float *gmin32, int64_t G, void *pool, unsigned int *pool_ctl, int *chunk_fill,

@@ -232,3 +232,32 @@ def test_very_long_utterance(engine):
     assert path == opath and cost == ocost
     paths, costs = engine.knn_viterbi_batch([U[:100], U, U[:7]], K)
     assert list(paths[1]) == path and costs[1] == cost
+
+
+@pytest.mark.parametrize('Dt,chunks', [(61, 1), (100, 2), (184, 3), (250, 4)])
+def test_f32_prefilter_is_not_slower_than_the_f64_sweep(engine, Dt, chunks):
+    """Performance guard for every chunk count of the f32 filter sweep (one kernel variant each): it
+    has four times the matrix rate of the float64 sweep, so it must not lose to it.  (A change that
+    made the three-chunk variant spill registers once cost 4x at the halfphone width and went
+    unnoticed because only the headline shape was timed.)"""
+    N, T, K = 300000, 2048, 100
+    F_unw, JC_unw = o.synthetic_db(N, Dt, 4, seed=3)
+    wt = np.full(Dt, 0.4)
+    U = o.synthetic_targets(F_unw, T, seed=4) * wt
+    times = {}
+    for precision in (1, 0):
+        engine.set_option('precision', precision)
+        engine.upload_db(F_unw, JC_unw)
+        engine.set_weights(wt, np.full(4, 0.1))
+        engine.knn(U, K)
+        engine.reset_timers()
+        for _ in range(2):
+            cand, dist = engine.knn(U, K)
+        times[precision] = engine.timers()['knn_filter'][0]
+        if precision == 1:
+            assert engine.info('f16_fallbacks') == 0
+            ref = (cand, dist)
+        else:
+            assert np.array_equal(cand, ref[0]) and np.array_equal(dist, ref[1])
+    engine.set_option('precision', 1)
+    assert times[1] < times[0], (Dt, times)
