@@ -34,7 +34,7 @@ json.dump(bench, open(os.path.join(out, tag + '_bench.json'), 'w'), indent=1)
 shutil.copy(one('stats/*/*_kernel_stats.csv'), os.path.join(out, tag + '_kernel_stats.csv'))
 stats = list(csv.DictReader(open(os.path.join(out, tag + '_kernel_stats.csv'))))
 
-FILT = 'knn_sweep16<4, 1, 1, false>'
+FILT = 'knn_sweep16<4, 1, 1, false'
 fetch = pick(counters('fetch'), FILT)['FETCH_SIZE']
 write = pick(counters('write'), FILT)['WRITE_SIZE']
 mf = pick(counters('mfma'), FILT)
