@@ -96,6 +96,9 @@ def main():
     ap.add_argument('--join-dim', type=int, default=302)
     ap.add_argument('--cpu-sample-frames', type=int, default=48)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--in-flight', type=int, default=1, choices=(1, 2),
+                    help='N = 1: steps in flight; 2 submits step i+1 before collecting step i (+2-4 %% frames/s; the '
+                         'recursions of a finished step then run beside every filter launch, whose own time grows 3 %%)')
     ap.add_argument('--fixed-batch', action='store_true', help='N > 1: keep the batch at --utts (strong scaling)')
     ap.add_argument('--db-shards', type=int, default=0,
                     help='N > 1: shard the database over this many GPUs (a divisor of N; default N) and replicate '
@@ -189,8 +192,22 @@ def main():
     eng.reset_timers()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        paths, costs = step()
+    if world == 1 and args.in_flight == 2:
+        # two steps in flight: step i+1 is submitted before step i is collected, so the tail of a step
+        # (its last recursions, the copy of the results, the host-side hand-over) runs beside the K-NN
+        # of the next one -- what a tuning loop over a tune set does.  All K steps complete inside
+        # the timed region.
+        batch.pin()
+        pending = None
+        for _ in range(args.steps):
+            ticket = eng.knn_viterbi_batch_submit(batch, K)
+            if pending is not None:
+                paths, costs = eng.knn_viterbi_batch_collect(pending)
+            pending = ticket
+        paths, costs = eng.knn_viterbi_batch_collect(pending)
+    else:
+        for _ in range(args.steps):
+            paths, costs = step()
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -235,7 +252,7 @@ def main():
                                    'T=%d frames x %d utterances per step, K=%d, search_epsilon=0'
                                    % (N, Dt, Dj, T, U, K),
                        'units': N, 'target_dim': Dt, 'join_dim': Dj, 'frames': T, 'utts_per_step': U, 'utts_per_gpu': U // world,
-                       'n_candidates': K,
+                       'n_candidates': K, 'steps_in_flight': args.in_flight if world == 1 else 1,
                        'sharding': 'none' if world == 1 else (
                            '%d independent replicas' % world if S == 1 else
                            'db-rows/%d + all-to-all of local top-K' % S + (' x %d replica groups' % n_groups if n_groups > 1 else ''))},

@@ -88,11 +88,26 @@ struct EvPair { hipEvent_t a, b; int id; };
 struct UttSlot {      // per in-flight utterance workspace (batch pipeline uses two)
     DevBuf cand, tdist, J, bp, path, plen, cost;
     hipEvent_t knn_done = nullptr, vit_done = nullptr;
+    bool vit_recorded = false;          // a recursion was queued on this workspace (its event is valid)
+};
+
+struct BatchSlot {    // one submitted batch (snk_knn_viterbi_batch_submit / _collect): two may be in flight
+    DevBuf Qall, cand, dist, path, plen, cost, status;
+    HostBuf stage;
+    hipEvent_t done = nullptr;            // results of this batch are in `stage`
+    bool busy = false;
+    int n_utts = 0, n_groups = 0, K = 0, D = 0;
+    int64_t total = 0;
+    std::vector<int> first;
+    std::vector<int64_t> offs;
 };
 
 struct snk_engine {
     int device = 0;
-    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr, copy_stream = nullptr;
+    BatchSlot bslot[2];
+    int bnext = 0;
+    hipEvent_t knn_all_done = nullptr;
     // database
     int64_t N = 0, Njc = 0, Nalloc = 0;
     int Dt = 0, Dj = 0, Dpad = 0, Djpad = 0;
@@ -171,13 +186,17 @@ struct StageTimer {     // records an event pair around a stage on a stream
 
 static void collect_timers(snk_engine *h)   // call after the streams were synchronised
 {
+    std::vector<EvPair> later;                // stages of a batch that is still in flight (submit / collect)
     for (auto &ep : h->pending) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { h->tm_ms[ep.id] += ms; h->tm_n[ep.id] += 1; }
+        const hipError_t e = hipEventElapsedTime(&ms, ep.a, ep.b);
+        if (e == hipErrorNotReady) { later.push_back(ep); continue; }
+        if (e == hipSuccess) { h->tm_ms[ep.id] += ms; h->tm_n[ep.id] += 1; }
         h->ev_pool.push_back(ep.a);
         h->ev_pool.push_back(ep.b);
     }
-    h->pending.clear();
+    (void)hipGetLastError();
+    h->pending.swap(later);
 }
 
 // device -> pinned staging -> user memory; `parts` are (dst, src, bytes) triples
@@ -248,6 +267,9 @@ int snk_create(int device_id, snk_handle *out)
         HIPCHK(hipEventCreateWithFlags(&h->slot[i].vit_done, hipEventDisableTiming));
     }
     h->dp_stream[0] = h->stream2;
+    HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->knn_all_done, hipEventDisableTiming));
+    for (auto &b : h->bslot) HIPCHK(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&h->dp_stream[1], hipStreamNonBlocking));
     *out = h;
     return 0;
@@ -280,6 +302,9 @@ int snk_destroy(snk_handle h)
         if (s.vit_done) (void)hipEventDestroy(s.vit_done);
     }
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    if (h->knn_all_done) (void)hipEventDestroy(h->knn_all_done);
+    for (auto &b : h->bslot) { b.Qall.release(); b.cand.release(); b.dist.release(); b.path.release(); b.plen.release(); b.cost.release(); b.status.release(); b.stage.release(); if (b.done) (void)hipEventDestroy(b.done); }
     (void)hipStreamDestroy(h->stream);
     (void)hipStreamDestroy(h->stream2);
     delete h;
@@ -910,12 +935,16 @@ static std::vector<int> group_utterances(const snk_engine *h, const int64_t *row
 // the recursions ONE launch (a workgroup per utterance) on the side stream of the group's parity,
 // where they land on the compute units the persistent K-NN sweep of the next group leaves free.
 static int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u0, int u1, int K,
-                         const int64_t *cand_all, const double *tdist_all, bool side_stream)
+                         const int64_t *cand_all, const double *tdist_all, bool side_stream,
+                         int64_t *res_path = nullptr, int64_t *res_plen = nullptr, double *res_cost = nullptr)
 {
+    if (!res_path) { res_path = h->res_path.as<int64_t>(); res_plen = h->res_plen.as<int64_t>(); res_cost = h->res_cost.as<double>(); }
     const int64_t r0 = row_offsets[u0], rows = row_offsets[u1] - r0;
     UttSlot &s = h->slot[g & 1];
     hipStream_t dps = side_stream ? h->dp_stream[g & 1] : h->stream;
-    if (side_stream && g >= 2) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));   // slot reuse
+    // workspace reuse: the join costs of this group overwrite what the last recursion queued on this
+    // workspace reads (an earlier group of this batch, or the tail of the batch submitted before)
+    if (s.vit_recorded) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));
     CHK(s.J.ensure((size_t)(rows > 1 ? rows - 1 : 1) * K * K * sizeof(double)));
     CHK(s.bp.ensure((size_t)rows * K));
     {
@@ -932,81 +961,152 @@ static int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u
     {
         StageTimer t(h, dps, TM_VITERBI_DP);
         launch_viterbi_dp_batch(cand_all + r0 * K, tdist_all + r0 * K, s.J.as<double>(), off.data(), u1 - u0, u0, K,
-                                join_units(h), s.bp.as<unsigned char>(), h->res_path.as<int64_t>() + r0,
-                                h->res_plen.as<int64_t>(), h->res_cost.as<double>(), dps);
+                                join_units(h), s.bp.as<unsigned char>(), res_path + r0, res_plen, res_cost, dps);
     }
-    if (side_stream) HIPCHK(hipEventRecord(s.vit_done, dps));
+    if (side_stream) { HIPCHK(hipEventRecord(s.vit_done, dps)); s.vit_recorded = true; }
+    else s.vit_recorded = false;             // ran on the main stream: ordered with everything that follows
     return 0;
 }
 
-int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D,
-                          int K, int64_t *path_out, int64_t *path_len_out, double *cost_out)
+// Page-lock a caller buffer that is uploaded again and again (the query rows of a tune set): a copy
+// from pageable memory makes the host wait for the stream, a copy from registered memory is queued.
+int snk_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return fail("snk_host_register: null/empty buffer");
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return 0;
+}
+
+int snk_host_unregister(void *ptr)
+{
+    if (!ptr) return fail("snk_host_unregister: null buffer");
+    HIPCHK(hipHostUnregister(ptr));
+    return 0;
+}
+
+// Batch pipeline.  The main stream runs the K-NN of a group of utterances and their join costs; the
+// T-step recursions run on a side stream, overlapping the K-NN of the next group.  All results stay
+// on the device until the end of the batch; a copy stream moves them to pinned host memory behind
+// the last recursions.  submit() only queues work (two batches may be in flight, each with its own
+// query / candidate / result buffers), collect() waits for one batch: a caller that submits batch
+// i+1 before collecting batch i hides the tail of batch i (its last group's recursions, the copy
+// and the host-side hand-over) behind the K-NN of batch i+1.
+int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D,
+                                 int K, int *ticket_out)
 {
     CHK(check_ready(h, true, true));
     HIPCHK(hipSetDevice(h->device));
-    if (!Q || !row_offsets || n_utts < 1 || !path_out || !path_len_out || !cost_out)
-        return fail("snk_knn_viterbi_batch: null/empty argument");
+    if (!Q || !row_offsets || n_utts < 1 || !ticket_out)
+        return fail("snk_knn_viterbi_batch_submit: null/empty argument");
     if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
     if (h->Njc != h->N + 1) return fail("snk_knn_viterbi_batch: join_contexts rows != N+1");
     if (K > 208) return fail("viterbi: n_candidates=%d > 208 not supported", K);
     const int64_t total = row_offsets[n_utts];
     for (int u = 0; u < n_utts; ++u)
         if (row_offsets[u + 1] - row_offsets[u] < 1) return fail("snk_knn_viterbi_batch: utterance %d has no rows", u);
-    // Pipeline: the main stream runs the K-NN of a group of utterances and their join costs; the
-    // T-step recursions run on a side stream, overlapping the K-NN of the next group.  All results
-    // stay on the device until the end of the batch (one D2H), so no host copy serialises the streams.
-    const std::vector<int> first = group_utterances(h, row_offsets, n_utts);
-    const int n_groups = (int)first.size() - 1;
-    CHK(h->Qall.ensure((size_t)total * D * sizeof(double)));
-    CHK(h->mcand.ensure((size_t)total * K * sizeof(int64_t)));
-    CHK(h->mdist.ensure((size_t)total * K * sizeof(double)));
-    CHK(h->res_path.ensure((size_t)total * sizeof(int64_t)));
-    CHK(h->res_plen.ensure((size_t)n_utts * sizeof(int64_t)));
-    CHK(h->res_cost.ensure((size_t)n_utts * sizeof(double)));
-    CHK(h->res_status.ensure((size_t)n_groups * sizeof(int)));
+    const int slot = h->bslot[h->bnext].busy ? (h->bnext ^ 1) : h->bnext;
+    BatchSlot &b = h->bslot[slot];
+    if (b.busy) return fail("snk_knn_viterbi_batch_submit: two batches are in flight already (collect one first)");
+    b.first = group_utterances(h, row_offsets, n_utts);
+    b.n_groups = (int)b.first.size() - 1;
+    b.n_utts = n_utts; b.K = K; b.D = D; b.total = total;
+    b.offs.assign(row_offsets, row_offsets + n_utts + 1);
+    CHK(b.Qall.ensure((size_t)total * D * sizeof(double)));
+    CHK(b.cand.ensure((size_t)total * K * sizeof(int64_t)));
+    CHK(b.dist.ensure((size_t)total * K * sizeof(double)));
+    CHK(b.path.ensure((size_t)total * sizeof(int64_t)));
+    CHK(b.plen.ensure((size_t)n_utts * sizeof(int64_t)));
+    CHK(b.cost.ensure((size_t)n_utts * sizeof(double)));
+    CHK(b.status.ensure((size_t)b.n_groups * sizeof(int)));
+    const size_t sz_path = ((size_t)total * sizeof(int64_t) + 63) & ~(size_t)63;
+    const size_t sz_u = ((size_t)n_utts * 8 + 63) & ~(size_t)63, sz_st = ((size_t)b.n_groups * sizeof(int) + 63) & ~(size_t)63;
+    CHK(b.stage.ensure(sz_path + 2 * sz_u + sz_st));
     {
         StageTimer t(h, h->stream, TM_H2D);
-        HIPCHK(hipMemcpyAsync(h->Qall.p, Q, (size_t)total * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(b.Qall.p, Q, (size_t)total * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
-    for (int g = 0; g < n_groups; ++g) {
-        const int64_t r0 = row_offsets[first[g]], rows = row_offsets[first[g + 1]] - r0;
-        CHK(knn_device(h, h->Qall.as<double>() + r0 * D, rows, K, nullptr, h->mcand.as<int64_t>() + r0 * K,
-                       h->mdist.as<double>() + r0 * K, nullptr, h->res_status.as<int>() + g));
-        CHK(viterbi_group(h, g, row_offsets, first[g], first[g + 1], K, h->mcand.as<int64_t>(), h->mdist.as<double>(), true));
+    for (int g = 0; g < b.n_groups; ++g) {
+        const int64_t r0 = row_offsets[b.first[g]], rows = row_offsets[b.first[g + 1]] - r0;
+        CHK(knn_device(h, b.Qall.as<double>() + r0 * D, rows, K, nullptr, b.cand.as<int64_t>() + r0 * K,
+                       b.dist.as<double>() + r0 * K, nullptr, b.status.as<int>() + g));
+        CHK(viterbi_group(h, g, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
+                          b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>()));
     }
-    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamSynchronize(h->dp_stream[i]));
+    // results -> pinned memory, behind the K-NN status words (main stream) and the last recursions
+    HIPCHK(hipEventRecord(h->knn_all_done, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->knn_all_done, 0));
+    for (int i = 0; i < 2; ++i)
+        if (h->slot[i].vit_recorded) HIPCHK(hipStreamWaitEvent(h->copy_stream, h->slot[i].vit_done, 0));
+    {
+        StageTimer t(h, h->copy_stream, TM_D2H);
+        char *st = (char *)b.stage.p;
+        HIPCHK(hipMemcpyAsync(st, b.path.p, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path, b.plen.p, (size_t)n_utts * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path + sz_u, b.cost.p, (size_t)n_utts * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u, b.status.p, (size_t)b.n_groups * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
+    }
+    HIPCHK(hipEventRecord(b.done, h->copy_stream));
     HIPCHK(hipGetLastError());
+    b.busy = true;
+    h->bnext = slot ^ 1;
+    *ticket_out = slot;
+    return 0;
+}
+
+int snk_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, int64_t *path_len_out, double *cost_out)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (ticket < 0 || ticket > 1 || !h->bslot[ticket].busy) return fail("snk_knn_viterbi_batch_collect: no batch behind ticket %d", ticket);
+    if (!path_out || !path_len_out || !cost_out) return fail("snk_knn_viterbi_batch_collect: null output");
+    BatchSlot &b = h->bslot[ticket];
+    const size_t sz_path = ((size_t)b.total * sizeof(int64_t) + 63) & ~(size_t)63;
+    const size_t sz_u = ((size_t)b.n_utts * 8 + 63) & ~(size_t)63;
+    HIPCHK(hipEventSynchronize(b.done));          // this batch only: the one submitted after it may still run
+    HIPCHK(hipGetLastError());
+    b.busy = false;
+    char *st = (char *)b.stage.p;
     // deferred K-NN status words: redo the (rare) group whose sampled thresholds overflowed a list
-    {
-        std::vector<int> st((size_t)n_groups);
-        HIPCHK(hipMemcpyAsync(st.data(), h->res_status.p, (size_t)n_groups * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    const int *status = reinterpret_cast<const int *>(st + sz_path + 2 * sz_u);
+    bool redone = false;
+    for (int g = 0; g < b.n_groups; ++g) {
+        if (status[g] == 0) continue;
+        if (status[g] & 2) h->tie_overflow = 1;
+        const int64_t r0 = b.offs[b.first[g]], rows = b.offs[b.first[g + 1]] - r0;
+        const int saved = h->precision;
+        h->precision = 0;
+        const int rc = knn_device(h, b.Qall.as<double>() + r0 * b.D, rows, b.K, nullptr,
+                                  b.cand.as<int64_t>() + r0 * b.K, b.dist.as<double>() + r0 * b.K, nullptr);
+        h->precision = saved;
+        if (rc) return rc;
+        CHK(viterbi_group(h, g, b.offs.data(), b.first[g], b.first[g + 1], b.K, b.cand.as<int64_t>(), b.dist.as<double>(), false,
+                          b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>()));
         HIPCHK(hipStreamSynchronize(h->stream));
-        for (int g = 0; g < n_groups; ++g) {
-            if (st[g] == 0) continue;
-            if (st[g] & 2) h->tie_overflow = 1;
-            const int64_t r0 = row_offsets[first[g]], rows = row_offsets[first[g + 1]] - r0;
-            {
-                const int saved = h->precision;
-                h->precision = 0;
-                const int rc = knn_device(h, h->Qall.as<double>() + r0 * D, rows, K, nullptr,
-                                          h->mcand.as<int64_t>() + r0 * K, h->mdist.as<double>() + r0 * K, nullptr);
-                h->precision = saved;
-                if (rc) return rc;
-            }
-            CHK(viterbi_group(h, g, row_offsets, first[g], first[g + 1], K, h->mcand.as<int64_t>(), h->mdist.as<double>(), false));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            h->batch_redos += 1;
-        }
+        h->batch_redos += 1;
+        redone = true;
     }
-    {
-        StageTimer t(h, h->stream, TM_D2H);
-        D2HPart parts[3] = {{path_out, h->res_path.p, (size_t)total * sizeof(int64_t)},
-                            {path_len_out, h->res_plen.p, (size_t)n_utts * sizeof(int64_t)},
-                            {cost_out, h->res_cost.p, (size_t)n_utts * sizeof(double)}};
-        CHK(staged_d2h(h, h->stream, parts, 3));
+    if (redone) {
+        HIPCHK(hipMemcpyAsync(st, b.path.p, (size_t)b.total * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path, b.plen.p, (size_t)b.n_utts * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path + sz_u, b.cost.p, (size_t)b.n_utts * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
     }
+    memcpy(path_out, st, (size_t)b.total * sizeof(int64_t));
+    memcpy(path_len_out, st + sz_path, (size_t)b.n_utts * sizeof(int64_t));
+    memcpy(cost_out, st + sz_path + sz_u, (size_t)b.n_utts * sizeof(double));
     collect_timers(h);
     return 0;
+}
+
+int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D,
+                          int K, int64_t *path_out, int64_t *path_len_out, double *cost_out)
+{
+    if (!path_out || !path_len_out || !cost_out) return fail("snk_knn_viterbi_batch: null/empty argument");
+    if (h && (h->bslot[0].busy || h->bslot[1].busy))
+        return fail("snk_knn_viterbi_batch: a submitted batch is still in flight (collect it first)");
+    int ticket = -1;
+    CHK(snk_knn_viterbi_batch_submit(h, Q, row_offsets, n_utts, D, K, &ticket));
+    return snk_knn_viterbi_batch_collect(h, ticket, path_out, path_len_out, cost_out);
 }
 
 // ---------------------------------------------------------------------------

@@ -49,6 +49,11 @@ _SIGNATURES = {
                                        ctypes.c_int, _c_i64p, _c_f64p, _c_i64p, _c_i64p, _c_f64p]),
     'snk_knn_viterbi_batch': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, _c_i64p, _c_i64p, _c_f64p]),
+    'snk_host_register': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
+    'snk_host_unregister': (ctypes.c_int, [ctypes.c_void_p]),
+    'snk_knn_viterbi_batch_submit': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    'snk_knn_viterbi_batch_collect': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_i64p, _c_i64p, _c_f64p]),
     'snk_set_greedy_layout': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'snk_greedy': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
                                   ctypes.c_double, _c_i64p, _c_f64p, _c_i64p]),
@@ -125,6 +130,23 @@ class QueryBatch(object):
 
     def __len__(self):
         return len(self.lengths)
+
+    def pin(self):
+        """Page-lock the rows (hipHostRegister): uploads of this batch are then queued on the stream
+        instead of making the host wait for it.  Undone when the batch is garbage collected."""
+        if not getattr(self, '_pinned', False):
+            lib = load_library()
+            if lib.snk_host_register(ctypes.c_void_p(self.Q.ctypes.data), self.Q.nbytes) != 0:
+                raise SnkError(lib.snk_last_error().decode('utf-8', 'replace'))
+            self._pinned = True
+        return self
+
+    def __del__(self):
+        if getattr(self, '_pinned', False):
+            try:
+                load_library().snk_host_unregister(ctypes.c_void_p(self.Q.ctypes.data))
+            except Exception:
+                pass
 
     def subset(self, lo, hi):
         """Utterances lo..hi-1 as a batch of their own (a view of the same rows)."""
@@ -290,6 +312,27 @@ class HipSearchEngine(object):
                                                     _ptr(plen, _c_i64p), _ptr(cost, _c_f64p)))
         out = [paths[offs[u]:offs[u] + plen[u]].copy() for u in range(n)]
         return out, cost
+
+    def knn_viterbi_batch_submit(self, utterances, n_candidates):
+        """Queue a batch and return at once; at most two batches may be in flight.  Returns a ticket
+        for knn_viterbi_batch_collect.  Submitting the next batch before collecting this one hides
+        this one's tail (last recursions, copy to the host) behind the next one's K-NN."""
+        b = _as_batch(utterances)
+        ticket = ctypes.c_int(-1)
+        self._check(self._lib.snk_knn_viterbi_batch_submit(self._h, _ptr(b.Q, _c_f64p), _ptr(b.offsets, _c_i64p), len(b),
+                                                           b.Q.shape[1], int(n_candidates), ctypes.byref(ticket)))
+        return (ticket.value, b)              # the batch (host rows) stays referenced until collected
+
+    def knn_viterbi_batch_collect(self, ticket):
+        """Wait for a submitted batch: (list of paths (np.int64 arrays), costs array)."""
+        tid, b = ticket
+        offs, n = b.offsets, len(b)
+        paths = np.empty((int(offs[-1]),), dtype=np.int64)
+        plen = np.zeros(n, dtype=np.int64)
+        cost = np.zeros(n, dtype=np.float64)
+        self._check(self._lib.snk_knn_viterbi_batch_collect(self._h, int(tid), _ptr(paths, _c_i64p), _ptr(plen, _c_i64p),
+                                                            _ptr(cost, _c_f64p)))
+        return [paths[offs[u]:offs[u] + plen[u]].copy() for u in range(n)], cost
 
     def set_greedy_layout(self, multiepoch=1, last_frame_as_target=False, join_split_mode=0):
         """get_tree_for_greedy_search (synth_simple.py:190-229) without building anything."""

@@ -258,6 +258,56 @@ def test_viterbi_batch_redo_on_overflow(engine):
         assert list(paths[u]) == op and costs[u] == ocst
 
 
+def test_viterbi_batch_submit_collect(engine):
+    """Two batches in flight (submit i+1 before collect i): results equal the one-call form and the
+    oracle, in submission order or not; a third submit and a one-call batch are refused while two /
+    any are pending; an overflowed group is redone at collect time."""
+    import snickery_amd
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(30000, 61, 40, seed=17)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    engine.set_option('batch_rows', 64)                  # several groups per batch
+    try:
+        batches = [[o.synthetic_targets(F_unw, T, seed=10 * b + i) * wt for i, T in enumerate(lens)]
+                   for b, lens in enumerate([(33, 48, 20, 7), (50, 2, 61), (40, 40, 40, 40, 9)])]
+        ref = [engine.knn_viterbi_batch(b, 20) for b in batches]
+        for u, U in enumerate(batches[0]):
+            oc, od = o.knn_bruteforce(F, U, 20)
+            op, ocst = o.viterbi(oc, od, E, S)
+            assert list(ref[0][0][u]) == op and ref[0][1][u] == ocst
+        t0 = engine.knn_viterbi_batch_submit(snickery_amd.QueryBatch(batches[0]).pin(), 20)
+        t1 = engine.knn_viterbi_batch_submit(batches[1], 20)
+        with pytest.raises(snickery_amd.SnkError):
+            engine.knn_viterbi_batch_submit(batches[2], 20)
+        with pytest.raises(snickery_amd.SnkError):
+            engine.knn_viterbi_batch(batches[2], 20)
+        got1 = engine.knn_viterbi_batch_collect(t1)          # out of order
+        t2 = engine.knn_viterbi_batch_submit(batches[2], 20)
+        got0 = engine.knn_viterbi_batch_collect(t0)
+        got2 = engine.knn_viterbi_batch_collect(t2)
+        with pytest.raises(snickery_amd.SnkError):
+            engine.knn_viterbi_batch_collect(t2)
+        for got, want in zip((got0, got1, got2), ref):
+            assert all(np.array_equal(a, b) for a, b in zip(got[0], want[0])) and np.array_equal(got[1], want[1])
+        # overflow -> redo while another batch is in flight
+        engine.set_option('list_capacity', 192)
+        engine.set_option('sample_fraction', 1.0 / 64)
+        engine.set_option('precision', 0)
+        before = engine.info('batch_redos')
+        ta = engine.knn_viterbi_batch_submit(batches[0], 20)
+        tb = engine.knn_viterbi_batch_submit(batches[2], 20)
+        ga = engine.knn_viterbi_batch_collect(ta)
+        gb = engine.knn_viterbi_batch_collect(tb)
+        assert engine.info('batch_redos') - before >= 1
+        for got, want in zip((ga, gb), (ref[0], ref[2])):
+            assert all(np.array_equal(a, b) for a, b in zip(got[0], want[0])) and np.array_equal(got[1], want[1])
+    finally:
+        engine.set_option('list_capacity', 4096)
+        engine.set_option('sample_fraction', 1.0 / 16)
+        engine.set_option('precision', 1)
+        engine.set_option('batch_rows', 8192)
+
+
 def test_greedy_golden(mini_engine, golden, mini_voice):
     for me in (6, 1):
         mini_engine.set_greedy_layout(me, False, 0)
