@@ -2,7 +2,7 @@
 K-NN, join costs + Viterbi (single and batch) and the greedy search, each compared bit for bit with
 the oracle.  Prints one line per case and a summary; exit code 1 on any mismatch.
 
-    python tools/fuzz_parity.py [n_cases] [seed]
+    python tests/fuzz_parity.py [n_cases] [seed]
 """
 import os
 import sys

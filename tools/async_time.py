@@ -1,6 +1,7 @@
+"""One-call batches against two batches in flight (submit i+1 before collect i) on the B* workload."""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, 'oracle')
+sys.path.insert(0, os.getcwd())
 import snickery_amd
 from bench import synthetic_db, synthetic_targets
 N, Dt, Dj, T, K, U = 1048576, 61, 302, 600, 100, 32

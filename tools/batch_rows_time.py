@@ -2,16 +2,17 @@
 import sys, os, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+sys.path.insert(0, ROOT)
 import torch
-import snickery_amd, snk_oracle as o
+import snickery_amd
+from bench import synthetic_db, synthetic_targets
 
 N, Dt, Dj, T, K, U = 1048576, 61, 302, 600, 100, int(sys.argv[1]) if len(sys.argv) > 1 else 16
-F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=0)
+F_unw, JC_unw = synthetic_db(N, Dt, Dj, seed=0)
 wt = np.full(Dt, 0.4); wj = np.full(Dj, 0.05)
 eng = snickery_amd.HipSearchEngine(0)
 eng.upload_db(F_unw, JC_unw); eng.set_weights(wt, wj)
-utts = [o.synthetic_targets(F_unw, T, seed=s) * wt for s in range(1, U + 1)]
+utts = [synthetic_targets(F_unw, T, seed=s) * wt for s in range(1, U + 1)]
 ref = None
 for rows, nst in ((0, 2), (600, 2), (1200, 2), (2400, 2), (3600, 2), (4800, 2), (8192, 2)):
     eng.set_option('batch_rows', rows)

@@ -2,17 +2,18 @@
 import sys, os, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+sys.path.insert(0, ROOT)
 import torch
-import snickery_amd, snk_oracle as o
+import snickery_amd
+from bench import synthetic_db, synthetic_targets
 
 N, Dt, Dj = 262144, 61, 302
-F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=0)
+F_unw, JC_unw = synthetic_db(N, Dt, Dj, seed=0)
 wt = np.full(Dt, 0.4); wj = np.full(Dj, 0.05)
 eng = snickery_amd.HipSearchEngine(0)
 eng.upload_db(F_unw, JC_unw); eng.set_weights(wt, wj)
 for T, K in ((600, 100), (600, 50), (600, 128), (600, 200), (1500, 100)):
-    U = o.synthetic_targets(F_unw, T, seed=3) * wt
+    U = synthetic_targets(F_unw, T, seed=3) * wt
     cand, dist = eng.knn(U, K)
     eng.viterbi(cand, dist)
     eng.reset_timers()

@@ -3,18 +3,19 @@ per-utterance calls vs one call over the concatenated rows of the whole batch.""
 import sys, os, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+sys.path.insert(0, ROOT)
 import torch
-import snickery_amd, snk_oracle as o
+import snickery_amd
+from bench import synthetic_db, synthetic_targets
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N, Dt, Dj, T, K, U = 1048576, 61, 302, 600, 100, 16
-F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=0)
+F_unw, JC_unw = synthetic_db(N, Dt, Dj, seed=0)
 wt = np.full(Dt, 0.4)
 eng = snickery_amd.HipSearchEngine(0)
 lo, hi = 0, N // G
 eng.upload_target_only(F_unw[lo:hi]); eng.set_shard(lo, N); eng.set_weights(wt, None)
-utts = [o.synthetic_targets(F_unw, T, seed=s) * wt for s in range(1, U + 1)]
+utts = [synthetic_targets(F_unw, T, seed=s) * wt for s in range(1, U + 1)]
 allq = np.vstack(utts)
 dev = torch.device('cuda', 0)
 d2 = torch.empty(U * T, K, dtype=torch.float64, device=dev)
