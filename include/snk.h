@@ -106,14 +106,14 @@ int snk_knn_viterbi(snk_handle h, const double *Q, int64_t T, int D, int K,
 int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offsets,
                           int n_utts, int D, int K,
                           int64_t *path_out, int64_t *path_len_out, double *cost_out);
+/* optional: page-lock a host buffer that is uploaded repeatedly (queued instead of blocking copies) */
+int snk_host_register(void *ptr, size_t bytes);
+int snk_host_unregister(void *ptr);
 /* The same in two halves: submit() queues the whole batch and returns, collect() waits for it.  Two
  * batches may be in flight; submitting batch i+1 before collecting batch i hides the tail of batch i
  * (last recursions, copy to the host) behind the K-NN of batch i+1 -- the shape of a tuning loop
  * over a large tune set (balance_stream_weights.py:82-92 searches the same utterances every iteration).
  * Q must stay valid until submit() returns; tickets are 0 / 1. */
-/* optional: page-lock a host buffer that is uploaded repeatedly (queued instead of blocking copies) */
-int snk_host_register(void *ptr, size_t bytes);
-int snk_host_unregister(void *ptr);
 int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts,
                                  int D, int K, int *ticket_out);
 int snk_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, int64_t *path_len_out,
