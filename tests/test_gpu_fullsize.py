@@ -260,4 +260,4 @@ def test_f32_prefilter_is_not_slower_than_the_f64_sweep(engine, Dt, chunks):
         else:
             assert np.array_equal(cand, ref[0]) and np.array_equal(dist, ref[1])
     engine.set_option('precision', 1)
-    assert times[1] < times[0], (Dt, times)
+    assert 1.25 * times[1] < times[0], (Dt, times)        # measured ratios: 1.6 (one chunk) to 2.15 (four)
