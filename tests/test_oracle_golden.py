@@ -162,3 +162,19 @@ def test_quinphone_preselection_matches_reference(golden, mini_voice):
     assert np.array_equal(cand, golden['quin_candidates'])
     np.testing.assert_allclose(dist, golden['quin_distances'], rtol=1e-12)
     assert list(golden['quin_candidates'][2]) == [1] + [-1] * 8          # unseen label -> naive back-off
+
+
+def test_knn_by_class_matches_reference_monophone_preselection(golden, mini_voice):
+    """oracle.knn_by_class against the REFERENCE's preselect_units_monophone_then_acoustic output
+    (tests/golden/reference_preselect.npz, generated by tools/make_golden.py)."""
+    import os
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_preselect.npz'))
+    K = int(ref['mono_n_candidates'])
+    names = [n.decode() for n in golden['quin_unit_names']]
+    qnames = [n.decode() for n in ref['mono_query_names']]
+    monos = sorted(set(n.split('/')[2] for n in names))
+    ucls = np.array([monos.index(n.split('/')[2]) for n in names], dtype=np.int32)
+    qcls = np.array([monos.index(n.split('/')[2]) for n in qnames], dtype=np.int32)
+    cand, dist = o.knn_by_class(mini_voice['F'], ref['mono_queries'], K, ucls, qcls)
+    assert np.array_equal(cand, ref['mono_candidates'])
+    np.testing.assert_allclose(dist, ref['mono_distances'], rtol=1e-12)

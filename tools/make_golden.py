@@ -300,6 +300,25 @@ def main():
         fixtures['quin_candidates'] = np.array(qc, dtype=np.int64)
         fixtures['quin_distances'] = np.array(qd, dtype=np.float64)
 
+        # ---- monophone-then-acoustic preselection (synth_halfphone.py:1369-1396): the per-phone trees and
+        # index converters exactly as Synthesiser.__init__ builds them (:385-402), same labels ----
+        import const
+        sh.number_of_units = N
+        sh.phonetrees = {}
+        sh.phonetrees_index_converters = {}
+        monophones = np.array([q.split(const.label_delimiter)[2] for q in sh.train_unit_names])
+        for phone in dict(zip(monophones, monophones)):
+            train = sh.train_unit_features[monophones == phone, :]
+            sh.phonetrees[phone] = scipy.spatial.cKDTree(train, leafsize=10, compact_nodes=False, balanced_tree=False)
+            sh.phonetrees_index_converters[phone] = np.arange(sh.number_of_units)[monophones == phone]
+        mnames = [names[i] for i in (5, 40, 300, 7, 512, 1000, 3)]
+        mfeats = fixtures['greedy_me6_utt0_unit_features'][10:10 + len(mnames)]
+        mc, md = sh.preselect_units_monophone_then_acoustic(mfeats, mnames)
+        presel = {'mono_query_names': np.array(mnames).astype('S40'), 'mono_queries': mfeats,
+                  'mono_candidates': np.array(mc, dtype=np.int64), 'mono_distances': np.array(md, dtype=np.float64),
+                  'mono_n_candidates': np.array(sh.config['n_candidates'])}
+        np.savez_compressed(os.path.join(OUT, 'reference_preselect.npz'), **presel)
+
         # ---- label-driven halfphone targets (synth_halfphone.py:1527-1549) on a synthetic
         # state-aligned label: read_label / get_halfphone_stats / get_norm_durations ----
         import re
