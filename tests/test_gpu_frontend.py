@@ -339,3 +339,23 @@ def test_monophone_then_acoustic_matches_reference_output(tmp_path, golden, mini
     oc, od = o.knn_by_class(mini_voice['F'], ref['mono_queries'], K, ucls, qcls)
     assert np.array_equal(cand, oc) and np.array_equal(dist, od)
     synth.close()
+
+
+def test_per_stream_scores_match_reference_output(tmp_path, golden):
+    """get_target_scores_per_stream / get_join_scores_per_stream (Viterbi and greedy forms) against
+    the REFERENCE's own values for the same database, weights, queries and path
+    (synth_halfphone.py:1964-1981, 2977-3008; tests/golden/reference_preselect.npz)."""
+    from snickery_amd.synthesiser import Synthesiser
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_preselect.npz'))
+    path = [int(v) for v in ref['scores_path']]
+    feats = golden['knn_queries']
+    cfgfile, config = build_voice(tmp_path, golden, greedy=False, multiepoch=1, n_candidates=12)
+    synth = Synthesiser(cfgfile, verbose=False)
+    np.testing.assert_allclose(synth.get_target_scores_per_stream(feats, path), ref['scores_target'], rtol=1e-12)
+    np.testing.assert_allclose(synth.get_join_scores_per_stream(path), ref['scores_join_viterbi'], rtol=1e-12)
+    synth.close()
+    cfgfile, config = build_voice(tmp_path, golden, greedy=True, multiepoch=1)
+    synth = Synthesiser(cfgfile, verbose=False)
+    np.testing.assert_allclose(synth.get_target_scores_per_stream(feats, path), ref['scores_target'], rtol=1e-12)
+    np.testing.assert_allclose(synth.get_join_scores_per_stream(path), ref['scores_join_greedy'], rtol=1e-12)
+    synth.close()

@@ -317,6 +317,23 @@ def main():
         presel = {'mono_query_names': np.array(mnames).astype('S40'), 'mono_queries': mfeats,
                   'mono_candidates': np.array(mc, dtype=np.int64), 'mono_distances': np.array(md, dtype=np.float64),
                   'mono_n_candidates': np.array(sh.config['n_candidates'])}
+        # ---- per-stream scores along a path (synth_halfphone.py:1964-1981, 2977-3008), Viterbi and
+        # greedy forms, on the reference's own weighted arrays ----
+        sh.stream_list_target = config['stream_list_target']
+        sh.datadims_target = config['datadims_target']
+        sh.stream_list_join = config['stream_list_join']
+        sh.datadims_join = config['datadims_join']
+        spath = [int(v) for v in fixtures['knn_candidates'][:, 0]]
+        sfeats = fixtures['knn_queries']
+        presel['scores_path'] = np.array(spath, dtype=np.int64)
+        presel['scores_target'] = np.array(sh.get_target_scores_per_stream(sfeats, spath))
+        sh.config['greedy_search'] = False
+        presel['scores_join_viterbi'] = np.array(sh.get_join_scores_per_stream(spath))
+        sh.config['greedy_search'] = True
+        sh.prev_join_rep = sh.unit_start_data
+        sh.current_join_rep = sh.unit_end_data
+        presel['scores_join_greedy'] = np.array(sh.get_join_scores_per_stream(spath))
+        sh.config['greedy_search'] = False
         np.savez_compressed(os.path.join(OUT, 'reference_preselect.npz'), **presel)
 
         # ---- label-driven halfphone targets (synth_halfphone.py:1527-1549) on a synthetic
