@@ -178,3 +178,45 @@ def test_knn_by_class_matches_reference_monophone_preselection(golden, mini_voic
     cand, dist = o.knn_by_class(mini_voice['F'], ref['mono_queries'], K, ucls, qcls)
     assert np.array_equal(cand, ref['mono_candidates'])
     np.testing.assert_allclose(dist, ref['mono_distances'], rtol=1e-12)
+
+
+def _parse_fst_text(text):
+    """AT&T text as the reference prints it into openfst.Compiler(): arcs 'src dst ilabel olabel [w]',
+    last line = the final state."""
+    arcs, final = [], None
+    for line in text.splitlines():
+        f = line.split()
+        if len(f) == 1:
+            final = int(f[0])
+        else:
+            arcs.append((int(f[0]), int(f[1]), int(f[2]), int(f[3]), float(f[4]) if len(f) > 4 else 0.0))
+    return arcs, final
+
+
+def test_viterbi_on_the_lattices_the_reference_itself_emits(golden, mini_voice):
+    """The arc text of the target sausage and of the join lattice, recorded from the reference's OWN
+    make_target_sausage_lattice / cost_cache_to_compiled_fst (a recording stand-in for
+    openfst.Compiler, tools/make_golden.py) for the 40-frame, K = 12 fixture with its padding,
+    first/last-unit and natural-join edits:
+      * the oracle's restatement of the two builders emits the same arcs;
+      * the tropical shortest path of T o J over that text (independent product search) is the path
+        and cost of the oracle's DP.
+    What stays unpinned is OpenFST's own compose / shortestpath arithmetic (float32 weights)."""
+    import os
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_preselect.npz'))
+    T_arcs, T_final = _parse_fst_text(bytes(ref['fst_target_text']).decode())
+    J_arcs, J_final = _parse_fst_text(bytes(ref['fst_join_text']).decode())
+    E, S = mini_voice['E'], mini_voice['S']
+    cand, dist = golden['join_candidates'], golden['knn_distances']
+    cache = dict(zip(map(tuple, golden['join_cache_keys'].tolist()), golden['join_cache_values']))
+    (oT, oTf), (oJ, oJf) = o.fst_arc_lists(cand, dist, cache)
+    assert oTf == T_final and oJf == J_final
+    assert oT == T_arcs                                   # same arcs in the same order ('%s' of a float round-trips)
+    assert sorted(oJ) == sorted(J_arcs)                   # the cache's iteration order is not part of the semantics
+    p_fst, c_fst = o.fst_shortest_path_bruteforce((T_arcs, T_final), (J_arcs, J_final))
+    p_dp, c_dp = o.viterbi(cand, dist, E, S)
+    assert p_fst == p_dp and len(p_dp) == cand.shape[0]
+    assert abs(c_fst - c_dp) <= 1e-12 * c_dp
+    # float32 weights as OpenFST stores them: the best path of this fixture does not change
+    p32, c32 = o.viterbi(cand, dist, E, S, mode='fst32')
+    assert p32 == p_dp and abs(c32 - c_dp) <= 1e-5 * c_dp

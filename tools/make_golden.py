@@ -88,8 +88,21 @@ def convert_reference(tmp):
 
     stubs = os.path.join(tmp, 'stubs')
     os.makedirs(os.path.join(stubs, 'smoothing'))
-    for name in ['magphase', 'libaudio', 'pywrapfst', 'pylab', 'StashableKDTree']:
+    for name in ['magphase', 'libaudio', 'pylab', 'StashableKDTree']:
         open(os.path.join(stubs, name + '.py'), 'w').write('')
+    # pywrapfst (OpenFST) is not available.  The stand-in records the arc text that the reference's
+    # lattice builders print into openfst.Compiler(); compile() returns an inert object.
+    open(os.path.join(stubs, 'pywrapfst.py'), 'w').write('''
+CAPTURED = []
+class _Inert(object):
+    def arcsort(self, **kw): return self
+class Compiler(object):
+    def __init__(self): self.text = []
+    def write(self, s): self.text.append(s)
+    def compile(self):
+        CAPTURED.append(''.join(self.text))
+        return _Inert()
+''')
     for name in ['__init__', 'fft_feats', 'libwavgen', 'libaudio']:
         open(os.path.join(stubs, 'smoothing', name + '.py'), 'w').write('')
     sys.path.insert(0, src)
@@ -317,6 +330,18 @@ def main():
         presel = {'mono_query_names': np.array(mnames).astype('S40'), 'mono_queries': mfeats,
                   'mono_candidates': np.array(mc, dtype=np.int64), 'mono_distances': np.array(md, dtype=np.float64),
                   'mono_n_candidates': np.array(sh.config['n_candidates'])}
+        # ---- the arc text of the two lattices as the reference's own builders print it into
+        # openfst.Compiler() (fst_functions_wrapped.py:28-58, 172-217), for the candidates / distances /
+        # cost cache recorded above ----
+        import fst_functions_wrapped
+        import pywrapfst
+        del pywrapfst.CAPTURED[:]
+        fst_functions_wrapped.make_target_sausage_lattice(fixtures['knn_distances'], fixtures['join_candidates'])
+        fst_functions_wrapped.cost_cache_to_compiled_fst(cache)
+        assert len(pywrapfst.CAPTURED) == 2
+        presel['fst_target_text'] = np.array(pywrapfst.CAPTURED[0].encode())
+        presel['fst_join_text'] = np.array(pywrapfst.CAPTURED[1].encode())
+
         # ---- per-stream scores along a path (synth_halfphone.py:1964-1981, 2977-3008), Viterbi and
         # greedy forms, on the reference's own weighted arrays ----
         sh.stream_list_target = config['stream_list_target']
