@@ -12,17 +12,21 @@ reference checkout, i.e. ``script/...``).
 
 Parity status
 -------------
-* weighting / greedy layout / greedy search / acoustic K-NN / join costs:
-  PINNED against outputs of the (lib2to3-converted) reference itself, captured
-  by ``tools/make_golden.py`` into ``tests/golden/*.npz``.
+* weighting / greedy layout / greedy search / acoustic, monophone-restricted and
+  quinphone K-NN / join costs / per-stream path scores: PINNED against outputs
+  of the (lib2to3-converted) reference itself, captured by
+  ``tools/make_golden.py`` into ``tests/golden/*.npz``.
 * Viterbi (``viterbi_search``): the reference delegates the arithmetic to
   OpenFST 1.5.4 (``pywrapfst``: compose + shortestpath, float32 tropical
   weights, ``fst_functions_wrapped.py:368,389``) which is not vendored and not
-  installable here.  The DP below restates the published shortest-path
-  semantics and is pinned by (i) an independent restatement of T o J built
-  from the exact arc lists the reference emits (``fst_shortest_path_bruteforce``)
-  and (ii) exhaustive path enumeration on tiny trellises.  Index parity versus
-  the OpenFST binary itself is "parity unpinned".
+  installable here.  The two lattice BUILDERS are pinned: their arc text is
+  recorded from the reference's own functions (a recording stand-in for
+  ``openfst.Compiler``) and ``fst_arc_lists`` below emits the same arcs.  The DP
+  restates the published shortest-path semantics and equals (i) an independent
+  product search of T o J over that recorded text
+  (``fst_shortest_path_bruteforce``) and (ii) exhaustive path enumeration on
+  tiny trellises.  Index parity versus the OpenFST binary's own compose /
+  shortestpath arithmetic is "parity unpinned".
 
 Canonical floating-point order
 ------------------------------
