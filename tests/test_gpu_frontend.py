@@ -359,3 +359,27 @@ def test_per_stream_scores_match_reference_output(tmp_path, golden):
     np.testing.assert_allclose(synth.get_target_scores_per_stream(feats, path), ref['scores_target'], rtol=1e-12)
     np.testing.assert_allclose(synth.get_join_scores_per_stream(path), ref['scores_join_greedy'], rtol=1e-12)
     synth.close()
+
+
+def test_reconfigure_settings_matches_reference_end_to_end(tmp_path, golden):
+    """The weight-tuning entry point against the REFERENCE's own run (tests/golden/reference_reconf.npz:
+    a fresh synth_simple.Synthesiser reconfigured with new stream weights, join cost weight,
+    multiepoch 6 -> 4 and truncated streams, then synth_utt): same description text, same prepared
+    target features, same greedy path."""
+    import json
+    from snickery_amd.synthesiser import Synthesiser
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_reconf.npz'))
+    extra = "truncate_target_streams = [-1, -1]\ntruncate_join_streams = [-1, -1, -1, -1]\nmagphase_overlap = 2\nmagphase_use_target_f0 = True\n"
+    cfgfile, config = build_voice(tmp_path, golden, greedy=True, multiepoch=6, extra_config=extra)
+    synth = Synthesiser(cfgfile, verbose=False)
+    new = dict(config)
+    new.update(json.loads(bytes(ref['reconf_settings_json']).decode()))
+    assert synth.reconfigure_settings(new) == bytes(ref['reconf_description']).decode()
+    U = synth.prepare_targets('arctic_b0001')
+    # the reference DROPS the truncated columns; here they stay in place with weight 0 (adds exactly +0.0)
+    tsel = list(range(40)) + [60]
+    np.testing.assert_allclose(U[:, tsel], ref['reconf_unit_features'], rtol=1e-12, atol=1e-300)
+    assert not np.any(U[:, 40:60])
+    path = synth.synth_utt('arctic_b0001', synth_type='test')
+    assert np.array_equal(np.array(path), ref['reconf_path'])
+    synth.close()

@@ -241,6 +241,40 @@ def main():
                     fixtures['hdf5_std_target_shape'] = np.array(f['std_target'].shape)
                     fixtures['hdf5_mean_target_shape'] = np.array(f['mean_target'].shape)
 
+        # ---- reconfigure_settings (synth_simple.py:776-830): the weight-tuning entry point.  A fresh
+        # Synthesiser on the multiepoch-6 voice is reconfigured (stream weights, join cost weight,
+        # multiepoch 4, truncated streams) and searched again: description text, the target features it
+        # prepares under the new settings and the greedy path ----
+        reconf = {}
+        cfgfile = os.path.join(tmp, 'mini_reconf.cfg')
+        write_config(cfgfile, workdir, data, 6)
+        with open(cfgfile, 'a') as f:
+            f.write("truncate_target_streams = [-1, -1]\ntruncate_join_streams = [-1, -1, -1, -1]\n")
+        synth_r = synth_simple.Synthesiser(cfgfile)
+        new_settings = dict(join_stream_weights=[0.4, 0.3, 0.2, 0.1], target_stream_weights=[0.3, 0.7],
+                            join_cost_weight=0.35, search_epsilon=0.0, multiepoch=4, magphase_use_target_f0=True,
+                            magphase_overlap=2, truncate_target_streams=[40, -1], truncate_join_streams=[30, -1, 20, 1])
+        desc = synth_r.reconfigure_settings(new_settings)
+        captured_r = []
+        orig_r = synth_r.greedy_joint_search
+
+        def wrapped_r(unit_features, start_state=-1, holdout=[]):
+            path = orig_r(unit_features, start_state=start_state, holdout=holdout)
+            captured_r.append((np.array(unit_features), np.array(path)))
+            raise StopAfterSearch()
+
+        synth_r.greedy_joint_search = wrapped_r
+        try:
+            synth_r.synth_utt(synth_r.get_sentence_set('test')[0], synth_type='test')
+        except StopAfterSearch:
+            pass
+        reconf['reconf_description'] = np.array(desc.encode())
+        reconf['reconf_settings_json'] = np.array(__import__('json').dumps(new_settings).encode())
+        reconf['reconf_unit_features'] = captured_r[0][0]
+        reconf['reconf_path'] = captured_r[0][1].astype(np.int64)
+        reconf['reconf_tree_shape'] = np.array(np.array(synth_r.joint_tree.data).shape)
+        np.savez_compressed(os.path.join(OUT, 'reference_reconf.npz'), **reconf)
+
         # ---- preselect + join lattice from converted synth_halfphone ----
         import synth_halfphone
         import scipy.spatial
