@@ -516,13 +516,16 @@ class Synthesiser(object):
         return self._aggregate(jsq, self.stream_list_join, self.datadims_join, reps=reps)
 
     def get_path_information_epoch(self, target_features, best_path):
-        """'<filename> <index_within_sentence>' per selected unit (the .trace.txt artefact)."""
+        """synth_simple.py:859-883 == synth_halfphone.py:2142-2153: one '<filename> <start> <end>' line per
+        selected unit (what goes into the .trace.txt artefact); start = index of the unit within its
+        sentence, end = start + multiepoch."""
+        multiepoch = self.config.get('multiepoch', 1)
         lines = []
         for p in best_path:
             fn = self.train_filenames[p]
             fn = fn.decode() if isinstance(fn, bytes) else str(fn)
-            ix = int(self.unit_index_within_sentence[p]) if self.unit_index_within_sentence is not None else int(p)
-            lines.append('%s %s' % (fn, ix))
+            start = int(self.unit_index_within_sentence[p]) if self.unit_index_within_sentence is not None else int(p)
+            lines.append('%s %s %s' % (fn, start, start + multiepoch))
         return lines
 
     # ------------------------------------------------------------------ reconfiguration

@@ -370,7 +370,9 @@ def test_reconfigure_settings_matches_reference_end_to_end(tmp_path, golden):
     from snickery_amd.synthesiser import Synthesiser
     ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_reconf.npz'))
     extra = "truncate_target_streams = [-1, -1]\ntruncate_join_streams = [-1, -1, -1, -1]\nmagphase_overlap = 2\nmagphase_use_target_f0 = True\n"
-    cfgfile, config = build_voice(tmp_path, golden, greedy=True, multiepoch=6, extra_config=extra)
+    cfgfile, config = build_voice(tmp_path, golden, greedy=True, multiepoch=6, extra_config=extra,
+                                  db_override=dict(filenames=ref['reconf_filenames'],
+                                                   unit_index_within_sentence_dset=ref['reconf_unit_index']))
     synth = Synthesiser(cfgfile, verbose=False)
     new = dict(config)
     new.update(json.loads(bytes(ref['reconf_settings_json']).decode()))
@@ -382,4 +384,8 @@ def test_reconfigure_settings_matches_reference_end_to_end(tmp_path, golden):
     assert not np.any(U[:, 40:60])
     path = synth.synth_utt('arctic_b0001', synth_type='test')
     assert np.array_equal(np.array(path), ref['reconf_path'])
+    # the .trace.txt lines (get_path_information_epoch); the reference ran under Python 3 here, where its
+    # HDF5 file names are bytes and print as b'...': Python 2 prints the bare name
+    want = [l.replace("b'", '').replace("'", '') for l in bytes(ref['reconf_trace_lines']).decode().splitlines()]
+    assert synth.get_path_information_epoch(U, path) == want
     synth.close()

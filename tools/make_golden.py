@@ -273,6 +273,9 @@ def main():
         reconf['reconf_unit_features'] = captured_r[0][0]
         reconf['reconf_path'] = captured_r[0][1].astype(np.int64)
         reconf['reconf_tree_shape'] = np.array(np.array(synth_r.joint_tree.data).shape)
+        reconf['reconf_trace_lines'] = np.array('\n'.join(synth_r.get_path_information_epoch(captured_r[0][0], captured_r[0][1])).encode())
+        reconf['reconf_filenames'] = np.array(synth_r.train_filenames).astype('S50')
+        reconf['reconf_unit_index'] = np.array(synth_r.unit_index_within_sentence).astype(np.int32)
         np.savez_compressed(os.path.join(OUT, 'reference_reconf.npz'), **reconf)
 
         # ---- preselect + join lattice from converted synth_halfphone ----
