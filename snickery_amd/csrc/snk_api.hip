@@ -523,6 +523,9 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
     const int32_t *uc = cls ? h->unit_class.as<int32_t>() : nullptr;
     int cap = h->cap;
     if (cap < 2 * K) cap = 2 * K;
+    // the sampled thresholds let ~17 K candidates per row through (mean; 3200 at K = 200): large K needs
+    // longer lists and a bigger pool share than the defaults sized for K <= 128
+    if (cap < 32 * K) cap = 32 * K < 8192 ? 32 * K : 8192;
     if (K > 4096) return fail("K-NN: K too large");
     KnnPlan p = p0;
     int64_t G = p.a_count * 16;
@@ -539,7 +542,8 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
     // entry pool: room for ~3K survivors per row plus one partly filled chunk per resident wave
     int max_chunks = h->pool_chunks;
     {
-        const int64_t per_row = cap < 3072 ? cap : 3072;
+        const int64_t want_row = 20 * (int64_t)K > 3072 ? 20 * (int64_t)K : 3072;
+        const int64_t per_row = cap < want_row ? cap : want_row;
         const int64_t need = (Tpad * per_row) / knn_pool_chunk_entries() + 2048;
         if (need > max_chunks) max_chunks = (int)need;
     }

@@ -261,3 +261,32 @@ def test_f32_prefilter_is_not_slower_than_the_f64_sweep(engine, Dt, chunks):
             assert np.array_equal(cand, ref[0]) and np.array_equal(dist, ref[1])
     engine.set_option('precision', 1)
     assert 1.25 * times[1] < times[0], (Dt, times)        # measured ratios: 1.6 (one chunk) to 2.15 (four)
+
+
+@pytest.mark.parametrize('N,Dt,Dj,T,K,U', [(700000, 61, 302, 300, 50, 4),        # B2
+                                           (1048576, 61, 302, 300, 100, 4),      # B*
+                                           (1500000, 61, 302, 300, 200, 4),      # B4 (K = 200)
+                                           (1300000, 184, 151, 120, 100, 8)])    # B5 (three-point halfphone width)
+def test_baseline_shapes_stay_on_the_fast_path(engine, N, Dt, Dj, T, K, U):
+    """Every BASELINE shape must run the f32 prefilter without falling back to the f64 sweep and
+    without redoing a group (silent, correct, 2x slower: K = 200 once overflowed the candidate
+    lists sized for K <= 128 on every call), and agree with the f64 path."""
+    from bench import synthetic_db, synthetic_targets
+    F_unw, JC_unw = synthetic_db(N, Dt, Dj, seed=0)
+    wt, wj = np.full(Dt, 0.4), np.full(Dj, 0.05)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    utts = [synthetic_targets(F_unw, T, seed=1 + u) * wt for u in range(U)]
+    before = (engine.info('f16_fallbacks'), engine.info('batch_redos'), engine.info('exact_row_fallbacks'))
+    paths, costs = engine.knn_viterbi_batch(utts, K)
+    cand, dist = engine.knn(utts[0], K)
+    assert (engine.info('f16_fallbacks'), engine.info('batch_redos'), engine.info('exact_row_fallbacks')) == before
+    engine.set_option('precision', 0)
+    try:
+        engine.set_weights(wt, wj)
+        paths0, costs0 = engine.knn_viterbi_batch(utts, K)
+        cand0, dist0 = engine.knn(utts[0], K)
+    finally:
+        engine.set_option('precision', 1)
+    assert all(np.array_equal(a, b) for a, b in zip(paths, paths0)) and np.array_equal(costs, costs0)
+    assert np.array_equal(cand, cand0) and np.array_equal(dist, dist0)
