@@ -787,7 +787,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
         if (margin > 2.0 * eps[row]) margin = 2.0 * eps[row];
     }
     const double scale = (kmax > kmin) ? 256.0 / (kmax - kmin) : 0.0;
-    bool fast = (n > SEL_MAX) && (scale > 0.0) && (kk == K);
+    bool fast = (n > 4 * K && n > 256) && (scale > 0.0) && (kk == K);
     if (fast) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             int b = (int)((key[i] - kmin) * scale);
