@@ -221,6 +221,7 @@ static int staged_d2h(snk_engine *h, hipStream_t st, const D2HPart *parts, int n
     return 0;
 }
 
+static int no_batch_in_flight(snk_engine *h, const char *who);
 static int roundup(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); }
 #define SNK_KNN_MAX_ROWS 8192       // rows of one K-NN call (batch_rows is capped to it)
 
@@ -330,6 +331,7 @@ static int upload_join(snk_engine *h, const float *JC_unw, int64_t Njc, int Dj)
 int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt, const float *JC_unw,
                   int64_t Njc, int Dj)
 {
+    CHK(no_batch_in_flight(h, "snk_upload_db"));
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
     if (!F_unw || N < 1 || Dt < 1) return fail("snk_upload_db: bad target matrix (N=%lld Dt=%d)", (long long)N, Dt);
@@ -374,6 +376,7 @@ int snk_set_shard(snk_handle h, int64_t global_row_offset, int64_t global_N)
 
 int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, int n_wj)
 {
+    CHK(no_batch_in_flight(h, "snk_set_weights"));
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
     if (!h->have_db && !h->have_join) return fail("snk_set_weights: no database uploaded");
@@ -447,6 +450,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
 
 int snk_set_unit_classes(snk_handle h, const int32_t *unit_class, int64_t N)
 {
+    CHK(no_batch_in_flight(h, "snk_set_unit_classes"));
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
     if (!h->have_db || N != h->N) return fail("snk_set_unit_classes: N=%lld does not match the database (%lld)", (long long)N, (long long)h->N);
@@ -721,6 +725,14 @@ static int check_ready(snk_engine *h, bool need_target, bool need_join)
     if (need_target && !h->have_db) return fail("no unit database uploaded (snk_upload_db)");
     if (need_join && !h->have_join) return fail("no join_contexts uploaded");
     if (!h->have_weights) return fail("weights not set (snk_set_weights)");
+    return 0;
+}
+
+// state changes (database, weights, classes) while a submitted batch is still in flight would be seen by it
+static int no_batch_in_flight(snk_engine *h, const char *who)
+{
+    if (h && (h->bslot[0].busy || h->bslot[1].busy))
+        return fail("%s: a submitted batch is still in flight (snk_knn_viterbi_batch_collect it first)", who);
     return 0;
 }
 

@@ -281,6 +281,8 @@ def test_viterbi_batch_submit_collect(engine):
             engine.knn_viterbi_batch_submit(batches[2], 20)
         with pytest.raises(snickery_amd.SnkError):
             engine.knn_viterbi_batch(batches[2], 20)
+        with pytest.raises(snickery_amd.SnkError):           # no re-weighting under a batch in flight
+            engine.set_weights(wt, wj)
         got1 = engine.knn_viterbi_batch_collect(t1)          # out of order
         t2 = engine.knn_viterbi_batch_submit(batches[2], 20)
         got0 = engine.knn_viterbi_batch_collect(t0)
