@@ -54,6 +54,14 @@ int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt,
  * rebuild (the reference rebuilds its KD-trees here). */
 int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, int n_wj);
 
+/* Replaces truncate_target_streams / truncate_join_streams (synth_simple.py:982-992,
+ * get_selection_vector :968-980; synth_halfphone.py:756-790): tcols / jcols list the columns that
+ * take part (ascending; n < 0: all).  The reference drops the other columns from its weighted copies
+ * and from the query rows; here they stay in place with weight 0 and zeroed query entries, which
+ * adds exactly +0.0 per column -- identical candidates, distances and paths.  Takes effect with the
+ * next snk_set_weights; query matrices keep their full width. */
+int snk_set_column_selection(snk_handle h, const int *tcols, int nt, const int *jcols, int nj);
+
 /* Replaces `self.tree.query(unit_features, k=n_candidates)` in
  * preselect_units_acoustic (synth_halfphone.py:1359-1366; tree built at :379):
  *   Q (T, D) float64 weighted target vectors, D == Dt

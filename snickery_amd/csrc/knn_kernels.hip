@@ -551,6 +551,20 @@ __global__ void prepare_queries_kernel(const double *__restrict__ Q, int64_t T, 
     }
 }
 
+// snk_set_column_selection: target columns that are selected out are zeroed in the uploaded query rows
+// (their database weights are zero, so the column then adds exactly +0.0 to every squared distance)
+__global__ void mask_columns_kernel(double *__restrict__ Q, int64_t n, int D, const double *__restrict__ mask)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && mask[i % D] == 0.0) Q[i] = 0.0;
+}
+
+void launch_mask_columns(double *Q, int64_t T, int D, const double *mask, hipStream_t s)
+{
+    const int64_t n = T * D;
+    if (n > 0) hipLaunchKernelGGL(mask_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Q, n, D, mask);
+}
+
 void launch_prepare_queries(const double *Q, int64_t T, int D, double *Qp, double *Qf, double *qnorm,
                             int64_t Tpad, int Dpad, hipStream_t s)
 {

@@ -138,6 +138,8 @@ struct snk_engine {
     GreedyLayout glay{};
     bool have_glay = false, gtiles_ready = false;
     int64_t qall_rows = -1;               // rows of the batch resident in Qall
+    std::vector<double> tsel, jsel;       // snk_set_column_selection: 1 = column takes part (empty: all do)
+    DevBuf tmask;                         // tsel on the device (query rows are masked after upload)
     DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist, gsync, gtiles;
     // options
     int cap = 4096;
@@ -374,6 +376,38 @@ int snk_set_shard(snk_handle h, int64_t global_row_offset, int64_t global_N)
     return 0;
 }
 
+// Stream truncation (truncate_target_streams / truncate_join_streams, synth_simple.py:982-992; the reference
+// drops the columns from its weighted copies and from the query rows).  Here the columns stay in place:
+// the next snk_set_weights gives them weight 0 and uploaded query rows get them zeroed, so each adds
+// exactly +0.0 to every squared distance -- same candidates, distances and paths as dropping them.
+// cols: ascending indices of the columns that take part; n < 0: all columns.
+int snk_set_column_selection(snk_handle h, const int *tcols, int nt, const int *jcols, int nj)
+{
+    CHK(no_batch_in_flight(h, "snk_set_column_selection"));
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    auto build = [&](const int *cols, int n, int width, std::vector<double> &sel, const char *what) -> int {
+        sel.clear();
+        if (n < 0) return 0;
+        if (width <= 0) return fail("snk_set_column_selection: no %s matrix uploaded", what);
+        if (n > 0 && !cols) return fail("snk_set_column_selection: null %s column list", what);
+        sel.assign((size_t)width, 0.0);
+        for (int i = 0; i < n; ++i) {
+            if (cols[i] < 0 || cols[i] >= width) return fail("snk_set_column_selection: %s column %d outside 0..%d", what, cols[i], width - 1);
+            sel[(size_t)cols[i]] = 1.0;
+        }
+        return 0;
+    };
+    CHK(build(tcols, nt, h->have_db ? h->Dt : 0, h->tsel, "target"));
+    CHK(build(jcols, nj, h->have_join ? h->Dj : 0, h->jsel, "join"));
+    if (!h->tsel.empty()) {
+        CHK(h->tmask.ensure(h->tsel.size() * sizeof(double)));
+        HIPCHK(hipMemcpy(h->tmask.p, h->tsel.data(), h->tsel.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    h->have_weights = false;                 // takes effect with the next snk_set_weights
+    return 0;
+}
+
 int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, int n_wj)
 {
     CHK(no_batch_in_flight(h, "snk_set_weights"));
@@ -384,13 +418,23 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
         if (!wt || n_wt != h->Dt)
             return fail("snk_set_weights: target weight vector has %d entries, database has %d columns", n_wt, h->Dt);
         CHK(h->wt.ensure((size_t)n_wt * sizeof(double)));
-        HIPCHK(hipMemcpyAsync(h->wt.p, wt, (size_t)n_wt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        std::vector<double> eff(wt, wt + n_wt);
+        if (!h->tsel.empty()) {
+            if ((int)h->tsel.size() != n_wt) return fail("snk_set_weights: the target column selection was made for %d columns", (int)h->tsel.size());
+            for (int c = 0; c < n_wt; ++c) eff[(size_t)c] *= h->tsel[(size_t)c];
+        }
+        HIPCHK(hipMemcpy(h->wt.p, eff.data(), (size_t)n_wt * sizeof(double), hipMemcpyHostToDevice));
     }
     if (h->have_join) {
         if (!wj || n_wj != h->Dj)
             return fail("snk_set_weights: join weight vector has %d entries, join_contexts has %d columns", n_wj, h->Dj);
         CHK(h->wj.ensure((size_t)n_wj * sizeof(double)));
-        HIPCHK(hipMemcpyAsync(h->wj.p, wj, (size_t)n_wj * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        std::vector<double> eff(wj, wj + n_wj);
+        if (!h->jsel.empty()) {
+            if ((int)h->jsel.size() != n_wj) return fail("snk_set_weights: the join column selection was made for %d columns", (int)h->jsel.size());
+            for (int c = 0; c < n_wj; ++c) eff[(size_t)c] *= h->jsel[(size_t)c];
+        }
+        HIPCHK(hipMemcpy(h->wj.p, eff.data(), (size_t)n_wj * sizeof(double), hipMemcpyHostToDevice));
     }
     {
         StageTimer t(h, h->stream, TM_WEIGHTS);
@@ -744,6 +788,7 @@ static int upload_queries(snk_engine *h, const double *Q, int64_t T, int D)
     CHK(h->Qraw.ensure((size_t)T * D * sizeof(double)));
     StageTimer t(h, h->stream, TM_H2D);
     HIPCHK(hipMemcpyAsync(h->Qraw.p, Q, (size_t)T * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (!h->tsel.empty()) launch_mask_columns(h->Qraw.as<double>(), T, D, h->tmask.as<double>(), h->stream);
     return 0;
 }
 
@@ -1040,6 +1085,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     {
         StageTimer t(h, h->stream, TM_H2D);
         HIPCHK(hipMemcpyAsync(b.Qall.p, Q, (size_t)total * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (!h->tsel.empty()) launch_mask_columns(b.Qall.as<double>(), total, D, h->tmask.as<double>(), h->stream);
     }
     for (int g = 0; g < b.n_groups; ++g) {
         const int64_t r0 = row_offsets[b.first[g]], rows = row_offsets[b.first[g + 1]] - r0;
@@ -1226,6 +1272,7 @@ int snk_path_scores(snk_handle h, const double *Q, const int64_t *path, int64_t 
     const size_t jbytes = (size_t)(L > 1 ? L - 1 : 1) * jcols * sizeof(double);
     CHK(h->d2tmp.ensure(tbytes + jbytes));
     HIPCHK(hipMemcpyAsync(h->Qraw.p, Q, qrows * h->Dt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (!h->tsel.empty()) launch_mask_columns(h->Qraw.as<double>(), (int64_t)qrows, h->Dt, h->tmask.as<double>(), h->stream);
     HIPCHK(hipMemcpyAsync(h->gpath.p, path, (size_t)L * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
     double *tsq = h->d2tmp.as<double>();
     double *jsq = reinterpret_cast<double *>(reinterpret_cast<char *>(h->d2tmp.p) + tbytes);
@@ -1297,6 +1344,7 @@ static int knn_local_batch(snk_engine *h, const char *who, const double *Q, cons
         CHK(h->Qall.ensure((size_t)total * D * sizeof(double)));
         StageTimer t(h, h->stream, TM_H2D);
         HIPCHK(hipMemcpyAsync(h->Qall.p, Q, (size_t)total * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (!h->tsel.empty()) launch_mask_columns(h->Qall.as<double>(), total, D, h->tmask.as<double>(), h->stream);
         h->qall_rows = total;
     } else if (h->qall_rows != total) {
         return fail("%s: no query matrix given and the resident one has %lld rows, not %lld", who,

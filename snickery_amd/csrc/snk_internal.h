@@ -27,6 +27,7 @@ struct KnnPlan {
     unsigned int *slab_counter;  // device word: dynamic slab dispenser
 };
 
+void launch_mask_columns(double *Q, int64_t T, int D, const double *mask, hipStream_t s);
 void launch_prepare_queries(const double *Q, int64_t T, int D, double *Qp, double *Qf, double *qnorm,
                             int64_t Tpad, int Dpad, hipStream_t s);
 // Qf = fragment-order copy of the padded queries (see prepare_queries_kernel)

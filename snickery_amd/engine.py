@@ -49,6 +49,8 @@ _SIGNATURES = {
                                        ctypes.c_int, _c_i64p, _c_f64p, _c_i64p, _c_i64p, _c_f64p]),
     'snk_knn_viterbi_batch': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, _c_i64p, _c_i64p, _c_f64p]),
+    'snk_set_column_selection': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                                ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     'snk_host_register': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
     'snk_host_unregister': (ctypes.c_int, [ctypes.c_void_p]),
     'snk_knn_viterbi_batch_submit': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int, ctypes.c_int,
@@ -312,6 +314,20 @@ class HipSearchEngine(object):
                                                     _ptr(plen, _c_i64p), _ptr(cost, _c_f64p)))
         out = [paths[offs[u]:offs[u] + plen[u]].copy() for u in range(n)]
         return out, cost
+
+    def set_column_selection(self, target_columns=None, join_columns=None):
+        """Stream truncation (truncate_target_streams / truncate_join_streams): indices of the columns
+        that take part, None = all.  Takes effect with the next set_weights; queries keep full width."""
+        def arr(cols):
+            if cols is None:
+                return None, -1
+            a = np.ascontiguousarray(cols, dtype=np.int32)
+            return a, int(a.size)
+        t, nt = arr(target_columns)
+        j, nj = arr(join_columns)
+        ip = ctypes.POINTER(ctypes.c_int)
+        self._check(self._lib.snk_set_column_selection(self._h, t.ctypes.data_as(ip) if t is not None else None, nt,
+                                                       j.ctypes.data_as(ip) if j is not None else None, nj))
 
     def knn_viterbi_batch_submit(self, utterances, n_candidates):
         """Queue a batch and return at once; at most two batches may be in flight.  Returns a ticket

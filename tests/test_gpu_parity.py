@@ -412,3 +412,42 @@ def test_knn_mass_duplicates(engine):
     oc, od = o.knn_bruteforce(F, U, 60)
     op, ocst = o.viterbi(oc, od, E, S)
     assert list(paths[0]) == op and costs[0] == ocst
+
+
+def test_column_selection_equals_dropped_columns(engine):
+    """snk_set_column_selection (stream truncation): full-width queries and matrices with selected-out
+    columns against the oracle on arrays with those columns DROPPED, as the reference does
+    (synth_simple.py:982-992) -- K-NN, Viterbi (single and batch), greedy, per-column path scores."""
+    N, Dt, Dj, K, T, me = 6000, 61, 40, 15, 36, 3
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(N, Dt, Dj, seed=41)
+    tsel = list(range(40)) + [60]                         # mag truncated to 40, lf0 kept
+    jsel = list(range(10)) + list(range(20, 33))
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_column_selection(tsel, jsel)
+    with pytest.raises(Exception):
+        engine.knn(o.synthetic_targets(F_unw, 4, seed=1) * wt, K)        # weights must be set again
+    engine.set_weights(wt, wj)
+    try:
+        U = o.synthetic_targets(F_unw, T, seed=5) * wt                   # full width, NOT masked by the caller
+        Fd, Ed, Sd, Ud = F[:, tsel], E[:, jsel], S[:, jsel], U[:, tsel]
+        cand, dist = engine.knn(U, K)
+        oc, od = o.knn_bruteforce(Fd, Ud, K)
+        assert np.array_equal(cand, oc) and np.array_equal(dist, od)
+        path, cost = engine.viterbi(cand, dist)
+        op, ocost = o.viterbi(oc, od, Ed, Sd)
+        assert path == op and cost == ocost
+        paths, costs = engine.knn_viterbi_batch([U[:20], U[20:]], K)
+        for u, (a, b) in enumerate([(0, 20), (20, T)]):
+            c2, d2 = o.knn_bruteforce(Fd, Ud[a:b], K)
+            p2, cost2 = o.viterbi(c2, d2, Ed, Sd)
+            assert list(paths[u]) == p2 and costs[u] == cost2
+        engine.set_greedy_layout(me, False, 0)
+        gp, gd = engine.greedy(U, return_distances=True)
+        pr, cr, Fwin = o.greedy_layout(Fd, Ed, Sd, me)
+        og, ogd = o.greedy_search(pr, cr, Fwin, o.greedy_queries(Ud, me))
+        assert gp == og and np.array_equal(gd, ogd)
+        tsq, jsq = engine.path_scores(U, path, 0, Dt, Dj)
+        assert not np.any(tsq[:, 40:60]) and not np.any(jsq[:, 10:20]) and not np.any(jsq[:, 33:])
+        np.testing.assert_allclose(tsq[:, tsel].sum(), o.target_scores(Fd, Ud, op).sum(), rtol=1e-12)
+    finally:
+        engine.set_column_selection(None, None)
