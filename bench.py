@@ -94,7 +94,8 @@ def main():
     ap.add_argument('--utts', type=int, default=32, help='utterances per step (batch)')
     ap.add_argument('--target-dim', type=int, default=61)
     ap.add_argument('--join-dim', type=int, default=302)
-    ap.add_argument('--cpu-sample-frames', type=int, default=48)
+    ap.add_argument('--cpu-sample-frames', type=int, default=600,
+                    help='frames of the CPU baseline sample (600 = one utterance of the workload, ~15 s on one core)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--in-flight', type=int, default=1, choices=(1, 2),
                     help='N = 1: steps in flight; 2 submits step i+1 before collecting step i (+2-4 %% frames/s; the '
