@@ -34,17 +34,26 @@ def one_case(rng, idx):
     if rng.rand() < 0.3:
         wt[rng.rand(Dt) < 0.3] = 0.0                       # truncated streams
     F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
-    desc = 'N=%d Dt=%d Dj=%d K=%d T=%d me=%d lfat=%d mode=%d prec=%d' % (N, Dt, Dj, K, T, me, lfat, mode, precision)
+    # stream truncation: the engine keeps full-width arrays and queries, the oracle gets dropped columns
+    tsel = jsel = None
+    if rng.rand() < 0.25 and mode == 0:
+        tsel = np.sort(rng.choice(Dt, size=int(rng.randint(1, Dt + 1)), replace=False))
+        jsel = np.sort(rng.choice(Dj, size=int(rng.randint(1, Dj + 1)), replace=False))
+        F, E, S = F[:, tsel], E[:, jsel], S[:, jsel]
+    drop = (lambda U: U[:, tsel]) if tsel is not None else (lambda U: U)
+    desc = 'N=%d Dt=%d Dj=%d K=%d T=%d me=%d lfat=%d mode=%d prec=%d sel=%d' % (N, Dt, Dj, K, T, me, lfat, mode, precision, tsel is not None)
     eng = snickery_amd.HipSearchEngine(0)
     bad = []
     try:
         eng.set_option('precision', precision)
         eng.upload_db(F_unw, JC_unw)
+        if tsel is not None:
+            eng.set_column_selection(tsel, jsel)
         eng.set_weights(wt, wj)
         U = o.synthetic_targets(F_unw, T, seed=int(rng.randint(1 << 30)), noise=float(rng.choice([0.0, 0.3, 2.0]))) * wt
         Keff = min(K, 208)
         cand, d = eng.knn(U, Keff)
-        oc, od = o.knn_bruteforce(F, U, Keff)
+        oc, od = o.knn_bruteforce(F, drop(U), Keff)
         if not (np.array_equal(cand, oc) and np.array_equal(d, od)):
             bad.append('knn')
         ncls = int(rng.choice([1, 3, 45]))
@@ -52,7 +61,7 @@ def one_case(rng, idx):
         qcls = rng.choice(np.unique(ucls), size=T).astype(np.int32)    # (a class without units is an error in the reference)
         eng.set_unit_classes(ucls)
         cc, cd = eng.knn_by_class(U, Keff, qcls)
-        occ, ocd = o.knn_by_class(F, U, Keff, ucls, qcls)
+        occ, ocd = o.knn_by_class(F, drop(U), Keff, ucls, qcls)
         if not (np.array_equal(cc, occ) and np.array_equal(cd, ocd)):
             bad.append('knn_by_class')
         if T >= 1:
@@ -64,7 +73,7 @@ def one_case(rng, idx):
             utts = [o.synthetic_targets(F_unw, t, seed=int(rng.randint(1 << 30))) * wt for t in lens]
             paths, costs = eng.knn_viterbi_batch(utts, Keff)
             for u, Uu in enumerate(utts):
-                c2, d2 = o.knn_bruteforce(F, Uu, Keff)
+                c2, d2 = o.knn_bruteforce(F, drop(Uu), Keff)
                 p2, cost2 = o.viterbi(c2, d2, E, S)
                 if not (list(paths[u]) == list(p2) and (len(p2) == 0 or costs[u] == cost2)):
                     bad.append('batch[%d]' % u)
@@ -75,7 +84,7 @@ def one_case(rng, idx):
             start = int(rng.choice([-1, 0, (N - me) // 2]))
             gp, gd = eng.greedy(Ug, start_state=start, return_distances=True)
             pr, cr, Fwin = o.greedy_layout(F, E, S, me, lfat, mode)
-            og, ogd = o.greedy_search(pr, cr, Fwin, o.greedy_queries(Ug, me, lfat), start_state=start)
+            og, ogd = o.greedy_search(pr, cr, Fwin, o.greedy_queries(drop(Ug), me, lfat), start_state=start)
             if not (list(gp) == list(og) and np.array_equal(gd, ogd)):
                 bad.append('greedy')
     except Exception as e:                                   # an engine error is a failure too
