@@ -737,7 +737,8 @@ void launch_fill_threshold(double *thr, int64_t T, int64_t Tpad, double value, h
 #define SEL_MAX 1024     // candidates re-ranked exactly per row (K + near ties / key error margin)
 
 __global__ void __launch_bounds__(256)
-knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double *__restrict__ Qp,
+knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_unw, int Fp,
+                    const double *__restrict__ wt, int Dpad, int D, const double *__restrict__ Qp,
                     const double *__restrict__ qnorm, int64_t T, int K,
                     const int *__restrict__ cnt, const double *__restrict__ lkey,
                     const int *__restrict__ lidx, int cap, int64_t id_offset,
@@ -867,12 +868,30 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
         int id = 0x7fffffff;
         if (e < n_sel) {
             id = ex_idx[e];
-            const double *f = Fw + (int64_t)id * Dpad;
             const double *q = Qp + row * Dpad;
             acc = 0.0;
-            for (int c = 0; c < D; ++c) {
-                const double d = __dsub_rn(q[c], f[c]);
-                acc = __dadd_rn(acc, __dmul_rn(d, d));
+            if (F_unw) {
+                // the weighted row is fl64(f32 * w): recomputed from the float32 row (half the gathered
+                // bytes of the float64 copy, 16-byte loads); the same bits
+                const float4 *f4 = reinterpret_cast<const float4 *>(F_unw + (int64_t)id * Fp);
+                for (int c4 = 0; 4 * c4 < D; ++c4) {
+                    const float4 v = f4[c4];
+                    const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = 4 * c4 + i;
+                        if (c < D) {
+                            const double d = __dsub_rn(q[c], __dmul_rn((double)xs[i], wt[c]));
+                            acc = __dadd_rn(acc, __dmul_rn(d, d));
+                        }
+                    }
+                }
+            } else {
+                const double *f = Fw + (int64_t)id * Dpad;
+                for (int c = 0; c < D; ++c) {
+                    const double d = __dsub_rn(q[c], f[c]);
+                    acc = __dadd_rn(acc, __dmul_rn(d, d));
+                }
             }
         }
         ex_key[e] = acc;
@@ -890,7 +909,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, int Dpad, int D, const double
     }
 }
 
-void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, const double *qnorm,
+void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const double *wt, int Dpad, int D, const double *Qp, const double *qnorm,
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
                          int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c,
                          int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s)
@@ -904,7 +923,7 @@ void launch_knn_finalize(const double *Fw, int Dpad, int D, const double *Qp, co
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         attr = shmem;
     }
-    hipLaunchKernelGGL(knn_finalize_kernel, dim3((unsigned)T), dim3(256), shmem, s, Fw, Dpad, D, Qp,
+    hipLaunchKernelGGL(knn_finalize_kernel, dim3((unsigned)T), dim3(256), shmem, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
                        qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cand, dist, d2_out, status, rowflag);
 }
 

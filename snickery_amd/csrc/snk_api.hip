@@ -669,7 +669,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         }
         {
             StageTimer t(h, s, TM_KNN_FINALIZE);
-            launch_knn_finalize(h->Fw.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
+            launch_knn_finalize(h->Fw.as<double>(), h->F_unw.as<float>(), h->Fp, h->wt.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
                                 h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), h->eps_c, cand_dev, dist_dev, d2_dev, status_dev, nullptr, s);
         }
@@ -726,7 +726,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         }
         {
             StageTimer t(h, s, TM_KNN_FINALIZE);
-            launch_knn_finalize(h->Fw.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
+            launch_knn_finalize(h->Fw.as<double>(), h->F_unw.as<float>(), h->Fp, h->wt.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
                                 h->shard_offset, nullptr, nullptr, 0.0, cand_dev, dist_dev, d2_dev, status_dev, h->rowflag.as<int>(), s);
         }
