@@ -38,9 +38,13 @@ struct GreedyArgs {
     int prev_col0, cur_col0, jdim;
     int64_t prev_row0, cur_row0, Nwin;
     int64_t n_jc_rows, n_f_rows;          // matrix heights (clamp for the ragged last workgroup)
-    const double *Q;                      // (T, Dt) weighted targets, row-major
+    const double *Q;                      // (rows, Dt) weighted targets of all utterances, row-major
     int lds_mode;                         // 1: target rows in LDS, interleaved chunk order (greedy_step_kernel)
+    // utterances of this scan (snk_greedy_batch: up to GR_MAXU share one pass over the database)
+    int nu;
+    int64_t q_off[3], nsteps_u[3], out_off[3];      // first query row, steps, first slot in path / dist
 };
+#define GR_MAXU 2          // utterances per scan: one weight and the references share 32 table bytes per column
 
 __device__ __forceinline__ int greedy_join_chunks(const GreedyArgs &a) { return (a.jdim + GR_CC - 1) / GR_CC; }
 __device__ __forceinline__ int greedy_target_chunks(const GreedyArgs &a) { return (a.Dt + GR_CC - 1) / GR_CC; }
@@ -65,39 +69,51 @@ __device__ __forceinline__ bool greedy_chunk_slot(const GreedyArgs &a, int jch, 
     return false;
 }
 
-// The (weight, reference) pair of every column of the scan in chunk order -- join columns against
-// `prev`, target columns of each epoch against the query rows of this step -- padded with (0, 0) to
-// whole chunks.  Built by one workgroup for the NEXT step; the scan reads it with scalar loads.
-// prev_row < 0: prev = 0 (np.zeros, synth_simple.py:467-468).
-__device__ void greedy_write_table(const GreedyArgs &a, int64_t step, int64_t prev_row, bool prev_is_current,
+// The table of a step: per column of the scan, in chunk order, the weight and the reference of every
+// utterance of the scan -- join columns against that utterance's `prev`, target columns against its
+// query rows of this step -- padded with zeros to whole chunks.  UB = 1: (w, ref) pairs, 16 bytes per
+// column; UB = 3: (w, ref0, ref1, ref2), 32 bytes.  Built by one workgroup for the NEXT step.
+// prev_row < 0: prev = 0 (np.zeros, synth_simple.py:467-468).  An utterance that has no such step
+// (shorter than the others) gets zero references; its result is ignored.
+template <int UB>
+__device__ void greedy_write_table(const GreedyArgs &a, int64_t step, const int64_t (&prev_row)[UB], bool prev_is_current,
                                    double *__restrict__ tab, int tid, int nthreads)
 {
+    constexpr int TS = (UB == 1) ? 2 : 4;
     const int jch = greedy_join_chunks(a), tch = greedy_target_chunks(a);
     const int nT = a.nep * tch, n = (jch + nT) * GR_CC;
     for (int e = tid; e < n; e += nthreads) {
         const int c = e / GR_CC, cc = e % GR_CC;
-        double w = 0.0, ref = 0.0;
+        double w = 0.0, ref[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) ref[u] = 0.0;
         int idx;
         if (greedy_chunk_slot(a, jch, nT, c, &idx)) {
             const int col = idx * GR_CC + cc;
             if (col < a.jdim) {
                 w = a.wj[a.prev_col0 + col];
-                if (prev_row >= 0) {
-                    // prev_join_vector = current_join_rep[ix] (synth_simple.py:501) or prev_join_rep[start]
-                    const int col0 = prev_is_current ? a.cur_col0 : a.prev_col0;
-                    const int64_t row0 = prev_is_current ? a.cur_row0 : a.prev_row0;
-                    ref = __dmul_rn((double)a.JC_unw[(row0 + prev_row) * a.Jp + col0 + col], a.wj[col0 + col]);
-                }
+                // prev_join_vector = current_join_rep[ix] (synth_simple.py:501) or prev_join_rep[start]
+                const int col0 = prev_is_current ? a.cur_col0 : a.prev_col0;
+                const int64_t row0 = prev_is_current ? a.cur_row0 : a.prev_row0;
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (u < a.nu && step < a.nsteps_u[u] && prev_row[u] >= 0)
+                        ref[u] = __dmul_rn((double)a.JC_unw[(row0 + prev_row[u]) * a.Jp + col0 + col], a.wj[col0 + col]);
             }
         } else {
             const int k = idx / tch, col = (idx % tch) * GR_CC + cc;
             if (col < a.Dt) {
                 w = a.wt[col];
-                ref = a.Q[(step * a.me + a.ep[k]) * a.Dt + col];
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (u < a.nu && step < a.nsteps_u[u])
+                        ref[u] = a.Q[(a.q_off[u] + step * a.me + a.ep[k]) * a.Dt + col];
             }
         }
-        tab[2 * e] = w;
-        tab[2 * e + 1] = ref;
+        tab[TS * e] = w;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) tab[TS * e + 1 + u] = ref[u];
+        if (UB == 2) tab[TS * e + 3] = 0.0;
     }
 }
 
@@ -130,41 +146,53 @@ __global__ void greedy_tile_kernel(const float *__restrict__ src, int pitch, int
     dst[idx] = v;
 }
 
-// Tail of a step: workgroup (min, argmin) -> global memory; the
-// workgroup that arrives LAST (sc1 stores drained before an arrival counter, sc1 loads after) reduces all
-// partial results, appends the winner to the path and writes the next step's table (its
-// `current_join_rep` row is the next `prev`).
-__device__ void greedy_finish_step(const GreedyArgs &a, int64_t step, int64_t nsteps, double best, int64_t arg,
+// Tail of a step: per utterance, workgroup (min, argmin) -> global memory; the workgroup that arrives
+// LAST (sc1 stores drained before an arrival counter, sc1 loads after) reduces all partial results,
+// appends the winners to the paths and writes the next step's table (a winner's `current_join_rep` row
+// is that utterance's next `prev`).
+template <int UB>
+__device__ void greedy_finish_step(const GreedyArgs &a, int64_t step, int64_t nsteps, const double (&best_in)[UB],
+                                   const int64_t (&arg_in)[UB],
                                    double *__restrict__ tab_next, double *__restrict__ blk_min,
                                    int64_t *__restrict__ blk_arg, unsigned int *__restrict__ arrive,
                                    int64_t *__restrict__ path, double *__restrict__ dist,
                                    double *red_v, int64_t *red_i, int *is_last_p)
 {
     const int tid = threadIdx.x;
+    const unsigned int nb = gridDim.x;
     int top = 1;                                          // half of the next power of two >= blockDim.x
     while (2 * top < (int)blockDim.x) top <<= 1;
-    red_v[tid] = best; red_i[tid] = arg;
-    __syncthreads();
-    for (int off = top; off > 0; off >>= 1) {
-        if (tid < off && tid + off < (int)blockDim.x) {
-            const double v2 = red_v[tid + off];
-            const int64_t i2 = red_i[tid + off];
-            if (v2 < red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid])) { red_v[tid] = v2; red_i[tid] = i2; }
+    auto block_reduce = [&](double best, int64_t arg) {
+        red_v[tid] = best; red_i[tid] = arg;
+        __syncthreads();
+        for (int off = top; off > 0; off >>= 1) {
+            if (tid < off && tid + off < (int)blockDim.x) {
+                const double v2 = red_v[tid + off];
+                const int64_t i2 = red_i[tid + off];
+                if (v2 < red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid])) { red_v[tid] = v2; red_i[tid] = i2; }
+            }
+            __syncthreads();
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        block_reduce(best_in[u], arg_in[u]);
+        // publish.  The handed-off bytes are written with sc1 (agent-scope) stores, drained before the
+        // counter add, and read back with sc1 loads by the last workgroup: no release/acquire fence.
+        // (A release fence per workgroup writes back the XCD's L2 and serialises at ~1.2 us per
+        // workgroup and XCD: 1 ms per step at 5 860 workgroups, measured.)
+        if (tid == 0) {
+            __hip_atomic_store(&blk_min[u * nb + blockIdx.x], red_v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&blk_arg[u * nb + blockIdx.x], red_i[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
     if (tid == 0) {
-        // publish, then arrive.  The 16 handed-off bytes are written with sc1 (agent-scope) stores,
-        // drained before the counter add, and read back with sc1 loads by the last workgroup: no
-        // release/acquire fence.  (A release fence per workgroup writes back the XCD's L2 and
-        // serialises at ~1.2 us per workgroup and XCD: 1 ms per step at 5 860 workgroups, measured.)
-        __hip_atomic_store(&blk_min[blockIdx.x], red_v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&blk_arg[blockIdx.x], red_i[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // Arrival tree: 256 -> 16 -> 1 monotonic counters, each on its own 128-byte line (one counter
         // for all workgroups serialises at ~0.1 us per add: 0.6 ms per step at 5 860 workgroups,
         // measured).  A workgroup climbs a level only when its add completes the counter's quota.
-        const unsigned int nb = gridDim.x, b = blockIdx.x, round = (unsigned int)step + 1u;
+        const unsigned int b = blockIdx.x, round = (unsigned int)step + 1u;
         const unsigned int S1 = nb < GR_S1 ? nb : GR_S1, s1 = b % S1, q1 = (nb - s1 + S1 - 1) / S1;
         bool last = false;
         if (__hip_atomic_fetch_add(arrive + 32 * s1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == round * q1 - 1) {
@@ -177,29 +205,26 @@ __device__ void greedy_finish_step(const GreedyArgs &a, int64_t step, int64_t ns
     }
     __syncthreads();
     if (!*is_last_p) return;
-    // ---- last workgroup: global argmin (lowest index on exact ties), path, next step's table ----
-    best = DBL_MAX; arg = INT64_MAX;
-    for (int b = tid; b < (int)gridDim.x; b += (int)blockDim.x) {
-        const double v = __hip_atomic_load(&blk_min[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int64_t i = __hip_atomic_load(&blk_arg[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v < best || (v == best && i < arg)) { best = v; arg = i; }
-    }
-    red_v[tid] = best; red_i[tid] = arg;
-    __syncthreads();
-    for (int off = top; off > 0; off >>= 1) {
-        if (tid < off && tid + off < (int)blockDim.x) {
-            const double v2 = red_v[tid + off];
-            const int64_t i2 = red_i[tid + off];
-            if (v2 < red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid])) { red_v[tid] = v2; red_i[tid] = i2; }
+    // ---- last workgroup: global argmin per utterance (lowest index on exact ties), paths, next table ----
+    int64_t winner[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        double best = DBL_MAX;
+        int64_t arg = INT64_MAX;
+        for (int b = tid; b < (int)nb; b += (int)blockDim.x) {
+            const double v = __hip_atomic_load(&blk_min[u * nb + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int64_t i = __hip_atomic_load(&blk_arg[u * nb + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v < best || (v == best && i < arg)) { best = v; arg = i; }
+        }
+        block_reduce(best, arg);
+        winner[u] = red_i[0];
+        if (tid == 0 && u < a.nu && step < a.nsteps_u[u]) {
+            path[a.out_off[u] + step] = red_i[0];
+            if (dist) dist[a.out_off[u] + step] = __dsqrt_rn(red_v[0]);
         }
         __syncthreads();
     }
-    const int64_t ix = red_i[0];
-    if (tid == 0) {
-        path[step] = ix;
-        if (dist) dist[step] = __dsqrt_rn(red_v[0]);
-    }
-    if (step + 1 < nsteps) greedy_write_table(a, step + 1, ix, true, tab_next, tid, (int)blockDim.x);
+    if (step + 1 < nsteps) greedy_write_table<UB>(a, step + 1, winner, true, tab_next, tid, (int)blockDim.x);
 }
 
 // One step of the greedy search = ONE launch of a persistent grid: one workgroup of up to 8 wavefronts
@@ -241,7 +266,10 @@ __device__ void greedy_finish_step(const GreedyArgs &a, int64_t step, int64_t ns
 #define GR_MAXW 8          // wavefronts per workgroup
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-template <bool IN_LDS>
+// UB: utterances per scan (1, or up to GR_MAXU).  Every column's weighted database value fl64(x * w) is
+// computed once and compared with the reference of each utterance: 2 + 3 UB float64 operations per
+// column and window instead of 5 UB, and ONE pass over the database per step for all of them.
+template <bool IN_LDS, int UB>
 __global__ void __launch_bounds__(GR_W * GR_MAXW)
 greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__restrict__ tab,
                    double *__restrict__ tab_next, double *__restrict__ blk_min, int64_t *__restrict__ blk_arg,
@@ -257,7 +285,11 @@ greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__r
     const int pitch = tch * GR_CC + 4;
     const int nB = a.me > 1 ? tch : 0;                   // chunks of the me - 1 extra rows
     const int ring_per_tile = in_lds ? tch + nB + jch : n_chunks;
-    const int table_bytes = n_chunks * GR_CC * 16;
+    constexpr int TS = (UB == 1) ? 2 : 4;                // table doubles per column
+    // ring stages: with several utterances a chunk carries 2-3 times the arithmetic, one chunk ahead is as
+    // much time as two were, and the registers go to the accumulators instead
+    constexpr int NSTG = (UB == 1) ? GR_NSTG : 2;
+    const int table_bytes = n_chunks * GR_CC * TS * 8;
     float *const Fs = reinterpret_cast<float *>(lds + table_bytes) + (size_t)wave * (GR_W + a.me - 1) * pitch;
     const int ntiles = (int)((a.Nwin + GR_W - 1) / GR_W);
     const int wave_id = blockIdx.x * nwaves + wave, wave_stride = gridDim.x * nwaves;
@@ -274,7 +306,7 @@ greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__r
     const unsigned jl = (unsigned)lane + (unsigned)a.prev_row0;
     const unsigned off_join = (jl >> 6) * ((unsigned)JQ << 10) + (jl & 63u) * 16u;
     const char *const FTb = reinterpret_cast<const char *>(a.FT), *const JTb = reinterpret_cast<const char *>(a.JT);
-    f32x4 stage[GR_NSTG][8];
+    f32x4 stage[NSTG][8];
     auto fetch = [&](f32x4 (&st)[8], int pin0) {
         const int t = f_tile < ntiles ? f_tile : ntiles - 1;      // surplus request: re-read, never consumed
         const char *base;
@@ -310,7 +342,7 @@ greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__r
     };
     // the first requests go out before the table copy, and land behind it
 #pragma unroll
-    for (int s = 0; s < GR_NSTG - 1; ++s) fetch(stage[s], 0);
+    for (int s = 0; s < NSTG - 1; ++s) fetch(stage[s], 0);
 
     // the step's table -> LDS
     {
@@ -323,46 +355,66 @@ greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__r
     // consume side: the table is read strictly in chunk order (greedy_chunk_slot), wrapping at the end
     // of a window.  tq[b & 1][i] = (w, ref) of column i of batch b (four columns = 64 bytes, the same
     // address in every lane: a broadcast read).
-    double best = DBL_MAX;
-    int64_t arg = INT64_MAX;
-    double acc_j = 0.0, acc_t = 0.0;
+    double best[UB], acc_j[UB], acc_t[UB];
+    int64_t arg[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) { best[u] = DBL_MAX; arg[u] = INT64_MAX; acc_j[u] = 0.0; acc_t[u] = 0.0; }
     int c_tile = wave_id, c_pos = 0, t_done = 0, slot = 0;
-    // tq[c & 7] = (w, ref) of column c of the stream: a sliding window of eight columns, the read for
-    // column c + 7 issued before column c is computed (its slot held column c - 1)
-    f64x2 tq[8];
+    // tq[c % RING]: the table entry of column c of the stream -- (w, ref) for one utterance, (w, ref0) and
+    // (ref1, ref2) for up to three: a sliding window of RING columns, the read for column c + RING - 1
+    // issued before column c is computed (its slot held column c - 1)
+    constexpr int RING = (UB == 1) ? 8 : 4;
+    constexpr int TQ = TS / 2;                            // 16-byte pieces per column
+    f64x2 tq[RING][TQ];
     int pin = 0;                                          // always 0; orders the refill behind the arithmetic
     const f64x2 *const table = reinterpret_cast<const f64x2 *>(lds);
 #pragma unroll
-    for (int c = 0; c < 7; ++c) tq[c] = table[c];
+    for (int c = 0; c < RING - 1; ++c)
+#pragma unroll
+        for (int h = 0; h < TQ; ++h) tq[c][h] = table[c * TQ + h];
     asm volatile("" ::: "memory");
     // one chunk of arithmetic: x[g] = columns 4g .. 4g+3 of the chunk, table columns slot*32 .. slot*32+31
-    auto chunk = [&](f32x4 (&x)[8], double acc) -> double {
-        const f64x2 *const cur = table + slot * GR_CC;
+    auto chunk = [&](f32x4 (&x)[8], double (&acc)[UB]) {
+        const f64x2 *const cur = table + slot * GR_CC * TQ;
         if (++slot == n_chunks) slot = 0;
-        const f64x2 *const nxt = table + slot * GR_CC;
+        const f64x2 *const nxt = table + slot * GR_CC * TQ;
 #pragma unroll
         for (int c = 0; c < GR_CC; ++c) {
-            tq[(c + 7) & 7] = c + 7 < GR_CC ? cur[c + 7] : nxt[c + 7 - GR_CC];
+#pragma unroll
+            for (int h = 0; h < TQ; ++h)
+                tq[(c + RING - 1) % RING][h] = c + RING - 1 < GR_CC ? cur[(c + RING - 1) * TQ + h]
+                                                                   : nxt[(c + RING - 1 - GR_CC) * TQ + h];
             asm volatile("" ::: "memory");              // the request stays here
             float xv = x[c >> 2][c & 3];
-            asm volatile("" : "+v"(xv));                // column c: behind the request for column c + 7
-            const f64x2 t = tq[c & 7];
-            const double d = __dsub_rn(__dmul_rn((double)xv, t.x), t.y);
-            acc = __dadd_rn(acc, __dmul_rn(d, d));        // padded columns: w = ref = 0 adds +0.0
+            // column c: behind the request for column c + RING - 1; with two utterances also behind column
+            // c - 1 (left alone the scheduler interleaves a whole chunk, runs out of registers and spills:
+            // 2-3x slower; serialising only every second column was 6 % slower than every column)
+            if (UB == 1) asm volatile("" : "+v"(xv));
+            else asm volatile("" : "+v"(xv), "+v"(acc[0]), "+v"(acc[UB - 1]));
+            const double xw = __dmul_rn((double)xv, tq[c % RING][0].x);
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const double ref = (u == 0) ? tq[c % RING][0].y : (u == 1 ? tq[c % RING][TQ - 1].x : tq[c % RING][TQ - 1].y);
+                const double d = __dsub_rn(xw, ref);
+                acc[u] = __dadd_rn(acc[u], __dmul_rn(d, d));      // padded columns: w = ref = 0 adds +0.0
+            }
         }
-        return acc;
     };
     auto end_of_window = [&]() {
         const int64_t i = (int64_t)c_tile * GR_W + lane;
-        const double d = __dadd_rn(acc_j, acc_t);
-        if (i < a.Nwin && d < best) { best = d; arg = i; }           // windows visited in increasing order
-        acc_j = 0.0; acc_t = 0.0; c_pos = 0; t_done = 0; c_tile += wave_stride;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const double d = __dadd_rn(acc_j[u], acc_t[u]);
+            if (i < a.Nwin && d < best[u]) { best[u] = d; arg[u] = i; }       // windows visited in increasing order
+            acc_j[u] = 0.0; acc_t[u] = 0.0;
+        }
+        c_pos = 0; t_done = 0; c_tile += wave_stride;
     };
     auto handle = [&](f32x4 (&st)[8]) {
         if (!in_lds) {
             // chunk order of the table = ring order: join chunks, then the target chunks of each epoch
-            if (c_pos < jch) acc_j = chunk(st, acc_j); else acc_t = chunk(st, acc_t);
-            asm volatile("" : "+v"(acc_j), "+v"(acc_t), "+v"(pin));
+            if (c_pos < jch) chunk(st, acc_j); else chunk(st, acc_t);
+            asm volatile("" : "+v"(acc_j[0]), "+v"(acc_t[0]), "+v"(pin));
         } else if (c_pos < tch + nB) {
             const bool extra = c_pos >= tch;
             const int col = (extra ? c_pos - tch : c_pos) * GR_CC;
@@ -374,8 +426,8 @@ greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__r
         } else {
             // join chunk j, then its share of the target chunks (interleaved order, greedy_chunk_slot)
             const int j = c_pos - tch - nB;
-            acc_j = chunk(st, acc_j);
-            asm volatile("" : "+v"(acc_j), "+v"(pin));
+            chunk(st, acc_j);
+            asm volatile("" : "+v"(acc_j[0]), "+v"(pin));
             const int t_goal = ((j + 1) * nT) / jch;
             for (; t_done < t_goal; ++t_done) {
                 const int k = t_done / tch, cc = t_done - k * tch;
@@ -383,17 +435,17 @@ greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__r
                 f32x4 x[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) x[q] = *reinterpret_cast<const f32x4 *>(row + 4 * q);
-                acc_t = chunk(x, acc_t);
+                chunk(x, acc_t);
             }
         }
         if (++c_pos == ring_per_tile) end_of_window();
     };
     // Stage s holds ring chunk g with g % GR_NSTG == s.  Before chunk g is consumed, chunk g + GR_NSTG - 1
     // is requested into the stage that chunk g - 1 has just left.
-    for (int g0 = 0; g0 < total; g0 += GR_NSTG) {
+    for (int g0 = 0; g0 < total; g0 += NSTG) {
 #pragma unroll
-        for (int s = 0; s < GR_NSTG; ++s) {
-            fetch(stage[(s + GR_NSTG - 1) % GR_NSTG], pin);
+        for (int s = 0; s < NSTG; ++s) {
+            fetch(stage[(s + NSTG - 1) % NSTG], pin);
             asm volatile("" : "+v"(stage[s][0]), "+v"(pin));          // consume behind the request
             if (g0 + s < total) handle(stage[s]);       // uniform
         }
@@ -401,13 +453,18 @@ greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__r
     __syncthreads();                                      // the reduction arrays alias the table and the target blocks
     double *red_v = reinterpret_cast<double *>(lds);
     int64_t *red_i = reinterpret_cast<int64_t *>(lds + sizeof(double) * GR_W * GR_MAXW);
-    greedy_finish_step(a, step, nsteps, best, arg, tab_next, blk_min, blk_arg, arrive, path, dist, red_v, red_i, &is_last);
+    greedy_finish_step<UB>(a, step, nsteps, best, arg, tab_next, blk_min, blk_arg, arrive, path, dist, red_v, red_i, &is_last);
 }
 
-__global__ void greedy_init_kernel(GreedyArgs a, int64_t start_state, double *__restrict__ tab, unsigned int *arrive)
+template <int UB>
+__global__ void greedy_init_kernel(GreedyArgs a, int64_t s0, int64_t s1, int64_t s2, double *__restrict__ tab, unsigned int *arrive)
 {
     for (int i = threadIdx.x; i < 32 * (GR_S1 + GR_S2 + 1); i += blockDim.x) arrive[i] = 0;
-    greedy_write_table(a, 0, start_state, false, tab, threadIdx.x, blockDim.x);
+    const int64_t all[3] = {s0, s1, s2};
+    int64_t start[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) start[u] = all[u];
+    greedy_write_table<UB>(a, 0, start, false, tab, threadIdx.x, blockDim.x);
 }
 
 static size_t greedy_join_tile_elems(const GreedyLayout &g);
@@ -435,11 +492,12 @@ static void fill_args(GreedyArgs &a, const GreedyLayout &g, const float *F_unw, 
 size_t greedy_counter_bytes() { return (size_t)32 * (GR_S1 + GR_S2 + 1) * sizeof(unsigned int); }
 
 // doubles of one (weight, reference) table; the caller provides two (steps alternate)
-size_t greedy_table_doubles(const GreedyLayout &g, int Dt)
+// ub: utterances per scan (1: two doubles per column; 2, 3: four)
+size_t greedy_table_doubles(const GreedyLayout &g, int Dt, int ub)
 {
     const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
     const int jch = (g.jdim + GR_CC - 1) / GR_CC;
-    return (size_t)(jch + nep * ((Dt + GR_CC - 1) / GR_CC)) * GR_CC * 2;
+    return (size_t)(jch + nep * ((Dt + GR_CC - 1) / GR_CC)) * GR_CC * (ub <= 1 ? 2 : 4);
 }
 
 // float4 elements of the two tile arrays (join columns first, target columns behind them)
@@ -477,40 +535,86 @@ void launch_greedy_tiles(const GreedyLayout &g, const float *F_unw, int Fp, int 
 // lds_mode 1 while at least 4 wavefronts' target blocks fit the 160 KB beside the table (8 at
 // magphase-60 widths); never more wavefronts than it takes to give every compute unit work.
 #define GR_LDS_BUDGET (160 * 1024)
-static size_t greedy_lds_table_bytes(const GreedyLayout &g, int Dt)
+static size_t greedy_lds_table_bytes(const GreedyLayout &g, int Dt, int ub)
 {
-    return greedy_table_doubles(g, Dt) * sizeof(double);
+    return greedy_table_doubles(g, Dt, ub) * sizeof(double);
 }
 static size_t greedy_lds_wave_bytes(const GreedyLayout &g, int Dt)
 {
     return (size_t)(GR_W + g.me - 1) * ((Dt + GR_CC - 1) / GR_CC * GR_CC + 4) * sizeof(float);
 }
-static int greedy_lds_max_waves(const GreedyLayout &g, int Dt)
+static int greedy_lds_max_waves(const GreedyLayout &g, int Dt, int ub)
 {
-    const size_t fixed = greedy_lds_table_bytes(g, Dt) + 64;
+    const size_t fixed = greedy_lds_table_bytes(g, Dt, ub) + 64;
     if (fixed >= GR_LDS_BUDGET) return 0;
     const size_t w = (GR_LDS_BUDGET - fixed) / greedy_lds_wave_bytes(g, Dt);
     return (int)(w > GR_MAXW ? GR_MAXW : w);
 }
-bool greedy_lds_mode(const GreedyLayout &g, int Dt) { return greedy_lds_max_waves(g, Dt) >= 4; }
+// the layout decision does not depend on the number of utterances per scan (judged for one)
+bool greedy_lds_mode(const GreedyLayout &g, int Dt) { return greedy_lds_max_waves(g, Dt, 1) >= 4; }
 // false: the table alone does not fit the LDS (tens of thousands of scan columns)
 bool greedy_supported(const GreedyLayout &g, int Dt)
 {
-    return greedy_lds_table_bytes(g, Dt) + (size_t)GR_W * GR_MAXW * 16 + 64 <= GR_LDS_BUDGET;
+    return greedy_lds_table_bytes(g, Dt, 1) + (size_t)GR_W * GR_MAXW * 16 + 64 <= GR_LDS_BUDGET;
 }
-static int greedy_waves(const GreedyLayout &g, int Dt, int n_cus)
+// utterances per scan the LDS allows: three when the wider table still leaves four wavefronts their blocks
+int greedy_max_utts(const GreedyLayout &g, int Dt)
+{
+    if (greedy_lds_table_bytes(g, Dt, GR_MAXU) + (size_t)GR_W * GR_MAXW * 16 + 64 > GR_LDS_BUDGET) return 1;
+    if (greedy_lds_mode(g, Dt) && greedy_lds_max_waves(g, Dt, GR_MAXU) < 4) return 1;
+    return GR_MAXU;
+}
+static int greedy_waves(const GreedyLayout &g, int Dt, int n_cus, int ub)
 {
     const int64_t ntiles = (g.Nwin + GR_W - 1) / GR_W;
     int64_t w = (ntiles + n_cus - 1) / n_cus;
-    const int wmax = greedy_lds_mode(g, Dt) ? greedy_lds_max_waves(g, Dt) : GR_MAXW;
+    const int wmax = greedy_lds_mode(g, Dt) ? greedy_lds_max_waves(g, Dt, ub) : GR_MAXW;
     if (w > wmax) w = wmax;
     return (int)(w < 1 ? 1 : w);
 }
-static size_t greedy_lds_bytes(const GreedyLayout &g, int Dt, int waves)
+static size_t greedy_lds_bytes(const GreedyLayout &g, int Dt, int waves, int ub)
 {
-    size_t b = greedy_lds_table_bytes(g, Dt) + (greedy_lds_mode(g, Dt) ? (size_t)waves * greedy_lds_wave_bytes(g, Dt) : 0);
+    size_t b = greedy_lds_table_bytes(g, Dt, ub) + (greedy_lds_mode(g, Dt) ? (size_t)waves * greedy_lds_wave_bytes(g, Dt) : 0);
     const size_t red = (size_t)GR_W * GR_MAXW * 16;      // reduction arrays of the step's tail (aliased)
     return b < red ? red : b;
+}
+
+// nu utterances (1 .. GR_MAXU) share every scan: q_off[u] = first row of utterance u in Q, nsteps_u[u] its
+// steps, out_off[u] its first slot in path / dist, start[u] its start state.  blk_min / blk_arg hold
+// max(nu, 1) x nblk entries; tables holds two tables of greedy_table_doubles(g, Dt, nu) doubles.
+void launch_greedy_batch(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt,
+                         const float *JC_unw, int Jp, int Dj, const double *wj, const float *tiles, const double *Q,
+                         int nu, const int64_t *q_off, const int64_t *nsteps_u, const int64_t *out_off,
+                         const int64_t *start, double *tables, double *blk_min,
+                         int64_t *blk_arg, int nblk, int n_cus, unsigned int *arrive, int64_t *path, double *dist, hipStream_t s)
+{
+    GreedyArgs a{};
+    fill_args(a, g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, Q, true, tiles);
+    a.lds_mode = greedy_lds_mode(g, Dt) ? 1 : 0;
+    a.nu = nu;
+    int64_t nsteps = 0, st3[3] = {-1, -1, -1};
+    for (int u = 0; u < 3; ++u) {
+        a.q_off[u] = u < nu ? q_off[u] : 0;
+        a.nsteps_u[u] = u < nu ? nsteps_u[u] : 0;
+        a.out_off[u] = u < nu ? out_off[u] : 0;
+        if (u < nu) { st3[u] = start[u]; if (nsteps_u[u] > nsteps) nsteps = nsteps_u[u]; }
+    }
+    const int ub = nu <= 1 ? 1 : GR_MAXU;
+    double *tab[2] = {tables, tables + greedy_table_doubles(g, Dt, ub)};
+    const int waves = greedy_waves(g, Dt, n_cus, ub);
+    const size_t lds = greedy_lds_bytes(g, Dt, waves, ub);
+    void (*kernel)(GreedyArgs, int64_t, int64_t, const double *, double *, double *, int64_t *, unsigned int *, int64_t *, double *);
+    if (ub == 1) {
+        hipLaunchKernelGGL(greedy_init_kernel<1>, dim3(1), dim3(256), 0, s, a, st3[0], st3[1], st3[2], tab[0], arrive);
+        kernel = a.lds_mode ? greedy_step_kernel<true, 1> : greedy_step_kernel<false, 1>;
+    } else {
+        hipLaunchKernelGGL(greedy_init_kernel<GR_MAXU>, dim3(1), dim3(256), 0, s, a, st3[0], st3[1], st3[2], tab[0], arrive);
+        kernel = a.lds_mode ? greedy_step_kernel<true, GR_MAXU> : greedy_step_kernel<false, GR_MAXU>;
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int64_t st = 0; st < nsteps; ++st)
+        hipLaunchKernelGGL(kernel, dim3(nblk), dim3(GR_W * waves), lds, s, a, st, nsteps,
+                           tab[st & 1], tab[(st + 1) & 1], blk_min, blk_arg, arrive, path, dist);
 }
 
 void launch_greedy(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt,
@@ -518,25 +622,16 @@ void launch_greedy(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, co
                    int64_t nsteps, int64_t start_state, double *tables, double *blk_min,
                    int64_t *blk_arg, int nblk, int n_cus, unsigned int *arrive, int64_t *path, double *dist, hipStream_t s)
 {
-    GreedyArgs a{};
-    fill_args(a, g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, Q, true, tiles);
-    a.lds_mode = greedy_lds_mode(g, Dt) ? 1 : 0;
-    double *tab[2] = {tables, tables + greedy_table_doubles(g, Dt)};
-    hipLaunchKernelGGL(greedy_init_kernel, dim3(1), dim3(256), 0, s, a, start_state, tab[0], arrive);
-    const int waves = greedy_waves(g, Dt, n_cus);
-    const size_t lds = greedy_lds_bytes(g, Dt, waves);
-    auto kernel = a.lds_mode ? greedy_step_kernel<true> : greedy_step_kernel<false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int64_t st = 0; st < nsteps; ++st)
-        hipLaunchKernelGGL(kernel, dim3(nblk), dim3(GR_W * waves), lds, s, a, st, nsteps,
-                           tab[st & 1], tab[(st + 1) & 1], blk_min, blk_arg, arrive, path, dist);
+    const int64_t zero = 0;
+    launch_greedy_batch(g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, tiles, Q, 1, &zero, &nsteps, &zero, &start_state,
+                        tables, blk_min, blk_arg, nblk, n_cus, arrive, path, dist, s);
 }
 
 // Persistent grid: one workgroup per compute unit (fewer when there are fewer tiles).
-int greedy_blocks(const GreedyLayout &g, int Dt, int n_cus)
+int greedy_blocks(const GreedyLayout &g, int Dt, int n_cus, int ub)
 {
     const int64_t ntiles = (g.Nwin + GR_W - 1) / GR_W;
-    const int waves = greedy_waves(g, Dt, n_cus);
+    const int waves = greedy_waves(g, Dt, n_cus, ub <= 1 ? 1 : GR_MAXU);
     const int64_t need = (ntiles + waves - 1) / waves;
     return (int)(need < n_cus ? need : n_cus);
 }

@@ -10,6 +10,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 using namespace snk;
 
@@ -1245,6 +1246,81 @@ int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_st
         StageTimer t(h, h->stream, TM_D2H);
         HIPCHK(hipMemcpyAsync(path_out, h->gpath.p, (size_t)nsteps * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
         if (dist_out) HIPCHK(hipMemcpyAsync(dist_out, h->gdist.p, (size_t)nsteps * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    collect_timers(h);
+    return 0;
+}
+
+// Several utterances through the greedy search together: up to three share every scan of the database
+// (one weighted value per column and window, one comparison per utterance), so the database is read
+// once per step for all of them.  Results equal snk_greedy utterance by utterance.
+int snk_greedy_batch(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D,
+                     const int64_t *start_states, double eps, int64_t *path_out, double *dist_out,
+                     int64_t *nsteps_out)
+{
+    CHK(check_ready(h, true, true));
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->have_glay) return fail("snk_greedy_batch: greedy layout not set (snk_set_greedy_layout)");
+    if (!Q || !row_offsets || n_utts < 1 || !path_out || !nsteps_out) return fail("snk_greedy_batch: null/empty argument");
+    if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
+    if (!(eps >= 0.0)) return fail("snk_greedy_batch: search_epsilon must be >= 0");
+    const GreedyLayout &g = h->glay;
+    const int64_t total = row_offsets[n_utts];
+    std::vector<int64_t> nsteps((size_t)n_utts), out_off((size_t)n_utts + 1, 0);
+    for (int u = 0; u < n_utts; ++u) {
+        const int64_t T = row_offsets[u + 1] - row_offsets[u];
+        if (T < 1) return fail("snk_greedy_batch: utterance %d has no rows", u);
+        if (start_states && start_states[u] >= g.Nwin) return fail("snk_greedy_batch: start_state %lld out of range", (long long)start_states[u]);
+        nsteps[(size_t)u] = T / g.me;             // py2 integer division: tail frames dropped
+        nsteps_out[u] = nsteps[(size_t)u];
+        out_off[(size_t)u + 1] = out_off[(size_t)u] + nsteps[(size_t)u];
+    }
+    const int64_t total_steps = out_off[(size_t)n_utts];
+    CHK(upload_queries(h, Q, total, D));
+    if (total_steps == 0) { HIPCHK(hipStreamSynchronize(h->stream)); collect_timers(h); return 0; }
+    if (!h->gtiles_ready) {
+        CHK(h->gtiles.ensure(greedy_tile_bytes(g, h->Dt)));
+        launch_greedy_tiles(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->JC_unw.as<float>(), h->Jp, h->gtiles.as<float>(), h->stream);
+        HIPCHK(hipGetLastError());
+        h->gtiles_ready = true;
+    }
+    const int ub = greedy_max_utts(g, h->Dt);
+    const int nblk = greedy_blocks(g, h->Dt, h->n_cus, ub);
+    CHK(h->gprev.ensure(2 * greedy_table_doubles(g, h->Dt, ub) * sizeof(double) + 512));
+    CHK(h->gsync.ensure(greedy_counter_bytes()));
+    CHK(h->gblkmin.ensure((size_t)ub * nblk * sizeof(double)));
+    CHK(h->gblkarg.ensure((size_t)ub * nblk * sizeof(int64_t)));
+    CHK(h->gpath.ensure((size_t)total_steps * sizeof(int64_t)));
+    CHK(h->gdist.ensure((size_t)total_steps * sizeof(double)));
+    // utterances of similar length share a scan (the scan runs for the longest of its group)
+    std::vector<int> order((size_t)n_utts);
+    for (int u = 0; u < n_utts; ++u) order[(size_t)u] = u;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return nsteps[(size_t)x] > nsteps[(size_t)y]; });
+    {
+        StageTimer t(h, h->stream, TM_GREEDY_STEPS);
+        for (int i = 0; i < n_utts; i += ub) {
+            int nu = 0;
+            int64_t q_off[3], ns[3], oo[3], st[3];
+            for (; nu < ub && i + nu < n_utts; ++nu) {
+                const int u = order[(size_t)(i + nu)];
+                if (nsteps[(size_t)u] == 0) break;             // sorted: the rest have no steps either
+                q_off[nu] = row_offsets[u]; ns[nu] = nsteps[(size_t)u]; oo[nu] = out_off[(size_t)u];
+                st[nu] = start_states ? start_states[u] : -1;
+            }
+            if (nu == 0) break;
+            launch_greedy_batch(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
+                                h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nu, q_off, ns, oo, st,
+                                h->gprev.as<double>(), h->gblkmin.as<double>(), h->gblkarg.as<int64_t>(),
+                                greedy_blocks(g, h->Dt, h->n_cus, nu), h->n_cus, h->gsync.as<unsigned int>(),
+                                h->gpath.as<int64_t>(), h->gdist.as<double>(), h->stream);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    {
+        StageTimer t(h, h->stream, TM_D2H);
+        HIPCHK(hipMemcpyAsync(path_out, h->gpath.p, (size_t)total_steps * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        if (dist_out) HIPCHK(hipMemcpyAsync(dist_out, h->gdist.p, (size_t)total_steps * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     collect_timers(h);

@@ -112,13 +112,19 @@ void launch_greedy(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, co
                    const float *JC_unw, int Jp, int Dj, const double *wj, const float *tiles, const double *Q,
                    int64_t nsteps, int64_t start_state, double *tables, double *blk_min,
                    int64_t *blk_arg, int nblk, int n_cus, unsigned int *arrive, int64_t *path, double *dist, hipStream_t s);
-size_t greedy_table_doubles(const GreedyLayout &g, int Dt);
+size_t greedy_table_doubles(const GreedyLayout &g, int Dt, int ub = 1);
+int greedy_max_utts(const GreedyLayout &g, int Dt);
+void launch_greedy_batch(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt,
+                         const float *JC_unw, int Jp, int Dj, const double *wj, const float *tiles, const double *Q,
+                         int nu, const int64_t *q_off, const int64_t *nsteps_u, const int64_t *out_off,
+                         const int64_t *start, double *tables, double *blk_min,
+                         int64_t *blk_arg, int nblk, int n_cus, unsigned int *arrive, int64_t *path, double *dist, hipStream_t s);
 size_t greedy_counter_bytes();
 // lane-major copy of the scan columns (built once per database + layout, read by the scan)
 size_t greedy_tile_bytes(const GreedyLayout &g, int Dt);
 void launch_greedy_tiles(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const float *JC_unw, int Jp,
                          float *tiles, hipStream_t s);
-int greedy_blocks(const GreedyLayout &g, int Dt, int n_cus);
+int greedy_blocks(const GreedyLayout &g, int Dt, int n_cus, int ub = 1);
 bool greedy_supported(const GreedyLayout &g, int Dt);
 
 void launch_path_scores(const GreedyLayout &g, int mode, const float *F_unw, int Fp, int Dt, const double *wt,

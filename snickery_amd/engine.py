@@ -49,6 +49,8 @@ _SIGNATURES = {
                                        ctypes.c_int, _c_i64p, _c_f64p, _c_i64p, _c_i64p, _c_f64p]),
     'snk_knn_viterbi_batch': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, _c_i64p, _c_i64p, _c_f64p]),
+    'snk_greedy_batch': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int, ctypes.c_int, _c_i64p,
+                                        ctypes.c_double, _c_i64p, _c_f64p, _c_i64p]),
     'snk_set_column_selection': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                                 ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     'snk_host_register': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
@@ -368,6 +370,27 @@ class HipSearchEngine(object):
         if return_distances:
             return p, dist[:n.value].copy()
         return p
+
+    def greedy_batch(self, utterances, start_states=None, search_epsilon=0.0, return_distances=False):
+        """greedy_joint_search for several utterances in one call; up to three share every scan of the
+        database.  Returns a list of paths (and a list of distance arrays)."""
+        b = _as_batch(utterances)
+        n = len(b)
+        me_steps = np.zeros(n, dtype=np.int64)
+        total_rows = int(b.offsets[-1])
+        path = np.empty((max(total_rows, 1),), dtype=np.int64)
+        dist = np.empty((max(total_rows, 1),), dtype=np.float64)
+        st = None if start_states is None else np.ascontiguousarray(start_states, dtype=np.int64)
+        self._check(self._lib.snk_greedy_batch(self._h, _ptr(b.Q, _c_f64p), _ptr(b.offsets, _c_i64p), n, b.Q.shape[1],
+                                               _ptr(st, _c_i64p) if st is not None else None, float(search_epsilon),
+                                               _ptr(path, _c_i64p), _ptr(dist, _c_f64p), _ptr(me_steps, _c_i64p)))
+        outs, douts, pos = [], [], 0
+        for u in range(n):
+            k = int(me_steps[u])
+            outs.append([int(v) for v in path[pos:pos + k]])
+            douts.append(dist[pos:pos + k].copy())
+            pos += k
+        return (outs, douts) if return_distances else outs
 
     def path_scores(self, unit_features, path, mode, n_target_cols, n_join_cols):
         Q = _f64(unit_features)

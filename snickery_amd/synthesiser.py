@@ -428,10 +428,24 @@ class Synthesiser(object):
         point (grouped K-NN, one join launch and one recursion launch per group); other
         configurations loop.  Returns what synth_utt returns, per utterance."""
         fnames = list(fnames)
-        batched = (not self.config.get('greedy_search', False)
-                   and self.config.get('preselection_method') == 'acoustic'
-                   and self.mode_of_operation in ('normal', 'stream_weight_balancing')
-                   and not self.config.get('get_selection_info', False))
+        plain = (self.mode_of_operation in ('normal', 'stream_weight_balancing')
+                 and not self.config.get('get_selection_info', False))
+        if plain and fnames and self.config.get('greedy_search', False):
+            # greedy voices (what balance_stream_weights.py tunes): two utterances share every scan of
+            # the database (snk_greedy_batch)
+            assert self.config.get('target_representation') == 'epoch'
+            t = self.start_clock('Get speech (bulk)')
+            feats = [self.prepare_targets(f, synth_type) for f in fnames]
+            self.stop_clock(t)
+            t = self.start_clock('Batched greedy search')
+            paths = self.engine.greedy_batch(feats, search_epsilon=self.config.get('search_epsilon', 0.0))
+            self.stop_clock(t)
+            if self.mode_of_operation == 'stream_weight_balancing':
+                return [(self.get_target_scores_per_stream(U, p), self.get_join_scores_per_stream(p))
+                        for U, p in zip(feats, paths)]
+            return paths
+        batched = (plain and not self.config.get('greedy_search', False)
+                   and self.config.get('preselection_method') == 'acoustic')
         if not batched or not fnames:
             return [self.synth_utt(f, synth_type=synth_type) for f in fnames]
         t = self.start_clock('Get speech (bulk)')

@@ -389,3 +389,20 @@ def test_reconfigure_settings_matches_reference_end_to_end(tmp_path, golden):
     want = [l.replace("b'", '').replace("'", '') for l in bytes(ref['reconf_trace_lines']).decode().splitlines()]
     assert synth.get_path_information_epoch(U, path) == want
     synth.close()
+
+
+def test_bulk_greedy_equals_one_by_one(tmp_path, golden):
+    """synth_utts_bulk on a greedy voice (snk_greedy_batch: two utterances per scan of the database)
+    returns what synth_utt returns utterance by utterance -- the reference's own path for the test
+    sentence -- in normal and in stream-weight-balancing mode."""
+    from snickery_amd.synthesiser import Synthesiser
+    cfgfile, config = build_voice(tmp_path, golden, greedy=True, multiepoch=6)
+    synth = Synthesiser(cfgfile, verbose=False)
+    names = ['arctic_b0001'] * 3
+    bulk = synth.synth_utts_bulk(names, synth_type='test')
+    assert all(np.array_equal(np.array(p), golden['greedy_me6_utt0_path']) for p in bulk)
+    synth.mode_of_operation = 'stream_weight_balancing'
+    one = synth.synth_utt('arctic_b0001', synth_type='test')
+    for t, j in synth.synth_utts_bulk(names, synth_type='test'):
+        assert np.array_equal(t, one[0]) and np.array_equal(j, one[1])
+    synth.close()

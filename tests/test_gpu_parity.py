@@ -451,3 +451,29 @@ def test_column_selection_equals_dropped_columns(engine):
         np.testing.assert_allclose(tsq[:, tsel].sum(), o.target_scores(Fd, Ud, op).sum(), rtol=1e-12)
     finally:
         engine.set_column_selection(None, None)
+
+
+@pytest.mark.parametrize('me,lfat,mode,Dj,Dt', [(6, False, 0, 151, 61), (3, True, 0, 40, 61), (4, False, 1, 80, 61),
+                                               (5, False, 0, 151, 200)])
+def test_greedy_batch_equals_single_and_oracle(engine, me, lfat, mode, Dj, Dt):
+    """snk_greedy_batch (two utterances share every scan): ragged lengths, an odd number of
+    utterances, one too short for a single step, start states -- each path and distance equal to
+    snk_greedy's and the oracle's."""
+    N = 5000
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(N, Dt, Dj, seed=20 + me)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    engine.set_greedy_layout(me, lfat, mode)
+    lens = [63, 40, me - 1 if me > 1 else 1, 57, 22]
+    utts = [o.synthetic_targets(F_unw, T, seed=30 + i) * wt for i, T in enumerate(lens)]
+    starts = [-1, 17, -1, 0, 400]
+    paths, dists = engine.greedy_batch(utts, start_states=starts, return_distances=True)
+    pr, cr, Fwin = o.greedy_layout(F, E, S, me, lfat, mode)
+    for u, U in enumerate(utts):
+        sp, sd = engine.greedy(U, start_state=starts[u], return_distances=True)
+        assert paths[u] == sp and np.array_equal(dists[u], sd)
+        if len(U) >= me:
+            op, od = o.greedy_search(pr, cr, Fwin, o.greedy_queries(U, me, lfat), start_state=starts[u])
+            assert paths[u] == op and np.array_equal(dists[u], od)
+        else:
+            assert paths[u] == []
