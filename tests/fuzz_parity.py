@@ -87,6 +87,14 @@ def one_case(rng, idx):
             og, ogd = o.greedy_search(pr, cr, Fwin, o.greedy_queries(drop(Ug), me, lfat), start_state=start)
             if not (list(gp) == list(og) and np.array_equal(gd, ogd)):
                 bad.append('greedy')
+            # two utterances per scan
+            Ug2 = o.synthetic_targets(F_unw, max(me, Tg - 5), seed=int(rng.randint(1 << 30))) * wt
+            bp, bd = eng.greedy_batch([Ug, Ug2, Ug[:Tg // 2 + 1]], start_states=[start, -1, start], return_distances=True)
+            og2, ogd2 = o.greedy_search(pr, cr, Fwin, o.greedy_queries(drop(Ug2), me, lfat), start_state=-1)
+            s3, d3 = eng.greedy(Ug[:Tg // 2 + 1], start_state=start, return_distances=True)
+            if not (bp[0] == list(og) and np.array_equal(bd[0], ogd) and bp[1] == list(og2) and np.array_equal(bd[1], ogd2)
+                    and bp[2] == s3 and np.array_equal(bd[2], d3)):
+                bad.append('greedy_batch')
     except Exception as e:                                   # an engine error is a failure too
         bad.append('EXC %s: %s' % (type(e).__name__, str(e)[:200]))
     finally:
