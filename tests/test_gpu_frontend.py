@@ -185,9 +185,11 @@ def test_halfphone_label_driven_synth_utt(tmp_path, golden, method):
     synth.close()
 
 
-def test_bulk_synthesis_and_stream_weight_balancing(tmp_path, golden, mini_voice):
+@pytest.mark.parametrize('greedy,me', [(False, 1), (True, 3)])
+def test_bulk_synthesis_and_stream_weight_balancing(tmp_path, golden, mini_voice, greedy, me):
     """balance_stream_weights.py's consumer pattern on the GPU path: the whole tune set through the
-    batch entry point equals utterance-by-utterance synth_utt, and the balancing loop's first
+    batch entry point (K-NN + Viterbi batch, or two greedy searches per scan on a greedy voice -- what
+    the reference's loop tunes) equals utterance-by-utterance synth_utt, and the balancing loop's first
     measurement is exactly the per-stream contributions of those paths."""
     from snickery_amd.synthesiser import Synthesiser
     from snickery_amd.balance_stream_weights import balance_stream_weights, mean_nonzero_contributions
@@ -197,7 +199,7 @@ tune_data_dirs = test_data_dirs
 tune_patterns = ['arctic_b']
 n_tune_utts = 5
 '''
-    cfgfile, config = build_voice(tmp_path, golden, greedy=False, multiepoch=1, n_candidates=12, extra_config=extra)
+    cfgfile, config = build_voice(tmp_path, golden, greedy=greedy, multiepoch=me, n_candidates=12, extra_config=extra)
     for stream in ('mag', 'lf0'):                       # a second, shorter tune utterance
         golden['test0_raw_' + stream][10:97].astype(np.float32).tofile(
             os.path.join(config['data'], 'low', stream, 'arctic_b0002.' + stream))
