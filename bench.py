@@ -217,6 +217,24 @@ def main():
         elapsed = float(t.item())
 
     timers = eng.timers()
+    # a second, separately timed pass with two steps in flight (not `value`: see --in-flight)
+    two_in_flight = None
+    if world == 1 and args.in_flight == 1:
+        batch.pin()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pending = None
+        for _ in range(args.steps):
+            ticket = eng.knn_viterbi_batch_submit(batch, K)
+            if pending is not None:
+                eng.knn_viterbi_batch_collect(pending)
+            pending = ticket
+        p2, c2 = eng.knn_viterbi_batch_collect(pending)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t1
+        two_in_flight = {'value': frames_per_step * args.steps / e2, 'unit': 'frames/s', 'ms_per_step': e2 / args.steps * 1e3,
+                         'same_results': bool(all(np.array_equal(a, b) for a, b in zip(p2, paths)) and np.array_equal(c2, costs)),
+                         'note': 'step i+1 submitted before step i is collected (snk_knn_viterbi_batch_submit / _collect)'}
     if rank == 0:
         total_frames = frames_per_step * args.steps
         value = total_frames / elapsed
@@ -267,6 +285,8 @@ def main():
             'stages_ms_per_step': dict((k, v[0] / args.steps) for k, v in timers.items() if v[1]),
             'stage_launches_per_step': dict((k, v[1] / args.steps) for k, v in timers.items() if v[1]),
         }
+        if two_in_flight is not None:
+            out['two_in_flight'] = two_in_flight
         if share_gpu:
             out['note'] = 'FUNCTIONAL TEST: all ranks share cuda:0, collectives on gloo through host memory; not a measurement'
         if world == 1 and not args.no_cpu_baseline:
