@@ -134,3 +134,57 @@ int snko_greedy(const double *prev_rep, const double *cur_rep, int jd, const dou
     free(prev); free(d2);
     return 0;
 }
+
+/* The same search straight from the UNWEIGHTED float32 matrices (what the HDF5 holds), weights applied
+ * on the fly: fl64(f32 * w) is the value speech_manip.weight() produces (synth_simple.py:245,269), so
+ * this equals snko_greedy on the weighted float64 copies without needing 8 bytes per database cell --
+ * the form the parity tests use at N = 1.5 M.  Layout as get_tree_for_greedy_search
+ * (synth_simple.py:190-225, synth_halfphone.py:539-596):
+ *   split 0: prev_join_rep[i] = JCw[i], current_join_rep[i] = JCw[i + me]   (unit_start / unit_end, :194-195,213-214)
+ *   split 1: prev = first half of the columns of JCw[i], current = second half of JCw[i + me - 1]  (:552-553)
+ * Q (steps * nep, Dt) weighted query rows in window order; lowest index wins exact ties.
+ * dists may be NULL; d2_first (Nwin) may be NULL, else it receives the squared distances of step
+ * `d2_step` (for tests of the (1+eps) contract of approximate searches). */
+int snko_greedy_f32(const float *F_unw, int64_t N, int Dt, const double *wt, const float *JC_unw, int Dj,
+                    const double *wj, int me, const int *ep, int nep, int split, const double *Q, int64_t steps,
+                    int64_t start_state, int64_t *path, double *dists, int64_t d2_step, double *d2_out)
+{
+    const int64_t Nwin = N - me + 1;
+    const int jd = split ? Dj / 2 : Dj;
+    const int pcol0 = 0, ccol0 = split ? Dj / 2 : 0;
+    const int64_t crow0 = split ? me - 1 : me;
+    double *prev = (double *)calloc((size_t)jd, sizeof(double));
+    double *d2 = (double *)malloc((size_t)Nwin * sizeof(double));
+    if (start_state >= 0)
+        for (int c = 0; c < jd; ++c) prev[c] = (double)JC_unw[start_state * Dj + pcol0 + c] * wj[pcol0 + c];
+    for (int64_t s = 0; s < steps; ++s) {
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < Nwin; ++i) {
+            double aj = 0.0, at = 0.0;
+            const float *jr = JC_unw + i * Dj + pcol0;
+            for (int c = 0; c < jd; ++c) {
+                double x = (double)jr[c] * wj[pcol0 + c];
+                x = x - prev[c];
+                aj = aj + x * x;
+            }
+            for (int k = 0; k < nep; ++k) {
+                const float *f = F_unw + (i + ep[k]) * Dt;
+                const double *q = Q + (s * nep + k) * Dt;
+                for (int c = 0; c < Dt; ++c) {
+                    double x = (double)f[c] * wt[c];
+                    x = x - q[c];
+                    at = at + x * x;
+                }
+            }
+            d2[i] = aj + at;
+        }
+        int64_t arg = 0;
+        for (int64_t i = 1; i < Nwin; ++i) if (d2[i] < d2[arg]) arg = i;
+        path[s] = arg;
+        if (dists) dists[s] = sqrt(d2[arg]);
+        if (d2_out && s == d2_step) memcpy(d2_out, d2, (size_t)Nwin * sizeof(double));
+        for (int c = 0; c < jd; ++c) prev[c] = (double)JC_unw[(crow0 + arg) * Dj + ccol0 + c] * wj[ccol0 + c];
+    }
+    free(prev); free(d2);
+    return 0;
+}

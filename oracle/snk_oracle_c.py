@@ -52,3 +52,31 @@ def viterbi(cand, tdist, JCw):
     n = lib().snko_viterbi(_p(cand, _i64p), _p(tdist, _f64p), _p(J, _f64p), ctypes.c_int64(T), K,
                            ctypes.c_int64(JCw.shape[0] - 1), _p(path, _i64p), ctypes.byref(cost))
     return [int(v) for v in path[:n]], float(cost.value)
+
+
+def greedy_f32(F_unw, JC_unw, wt, wj, unit_features, multiepoch=1, last_frame_as_target=False, join_split_mode=0,
+               start_state=-1, max_steps=None, d2_step=-1):
+    """greedy_joint_search straight from the unweighted float32 database (snko_greedy_f32): same
+    results as snk_oracle.greedy_search on the weighted float64 copies, without materialising them.
+    unit_features: (T, Dt) weighted targets (not yet reshaped).  Returns (path, dists[, d2 of step d2_step])."""
+    F_unw = np.ascontiguousarray(F_unw, np.float32); JC_unw = np.ascontiguousarray(JC_unw, np.float32)
+    wt = np.ascontiguousarray(wt, np.float64); wj = np.ascontiguousarray(wj, np.float64)
+    N, Dt = F_unw.shape
+    assert JC_unw.shape[0] == N + 1 and wt.shape == (Dt,) and wj.shape == (JC_unw.shape[1],)
+    me = int(multiepoch)
+    ep = np.array([0, me - 1] if (last_frame_as_target and me > 1) else list(range(me)), np.int32)
+    U = np.asarray(unit_features, np.float64)
+    steps = U.shape[0] // me
+    if max_steps is not None:
+        steps = min(steps, int(max_steps))
+    Q = np.ascontiguousarray(U[:steps * me].reshape(steps, me, Dt)[:, ep, :].reshape(steps * len(ep), Dt))
+    path = np.empty(steps, np.int64); dists = np.empty(steps, np.float64)
+    d2 = np.empty(N - me + 1, np.float64) if d2_step >= 0 else None
+    lib().snko_greedy_f32(_p(F_unw, ctypes.POINTER(ctypes.c_float)), ctypes.c_int64(N), Dt, _p(wt, _f64p),
+                          _p(JC_unw, ctypes.POINTER(ctypes.c_float)), JC_unw.shape[1], _p(wj, _f64p), me,
+                          _p(ep, _i32p), len(ep), int(join_split_mode), _p(Q, _f64p), ctypes.c_int64(steps),
+                          ctypes.c_int64(start_state), _p(path, _i64p), _p(dists, _f64p), ctypes.c_int64(d2_step),
+                          _p(d2, _f64p) if d2 is not None else None)
+    if d2 is not None:
+        return [int(v) for v in path], dists, d2
+    return [int(v) for v in path], dists
