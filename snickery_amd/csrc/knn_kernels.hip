@@ -459,7 +459,8 @@ size_t knn_pool_bytes(int max_chunks) { return (size_t)max_chunks * POOL_CHUNK *
 // ---------------------------------------------------------------------------
 // bucket: entry pool -> per-row lists.  One workgroup per chunk (grid-stride); the returning
 // atomics on the per-row counters are latency-hidden by thousands of threads in flight.
-// status bit 0: a row list overflowed `cap` (or the pool overflowed).
+// status bit 0: a row list overflowed `cap`; bit 2: the entry pool overflowed (entries of ARBITRARY rows
+// were dropped by the sweep: no row of the call can be trusted, whatever its own list length says).
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__restrict__ pool_ctl,
@@ -472,7 +473,7 @@ knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__rest
     int *hist = bsm;             // [Tpad] count, then base
     int used = (int)pool_ctl[0];
     if (used > max_chunks) used = max_chunks;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && pool_ctl[1]) atomicOr(status, 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && pool_ctl[1]) atomicOr(status, 4);
     constexpr int EPT = POOL_CHUNK / 256;
     for (int c = blockIdx.x; c < used; c += gridDim.x) {
         const int n = chunk_fill[c];
@@ -1091,8 +1092,7 @@ merge_topk_kernel(const double *__restrict__ d2, const int64_t *__restrict__ id,
     while (P < n) P <<= 1;
     double *key = reinterpret_cast<double *>(smem);
     int *idx = reinterpret_cast<int *>(smem + (size_t)P * sizeof(double));
-    // global ids may exceed 31 bits only for > 2^31-unit databases; keep the sort on the
-    // (shard, slot) position and compare ids through it
+    // unit ids travel through 32-bit sort keys: snk_set_shard refuses global_N >= 2^31
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
         if (i < n) {
             const int gsh = i / K, j = i % K;

@@ -124,6 +124,7 @@ struct snk_engine {
     DevBuf frames_spec, frames_fzv, cc_in, cc_out;      // waveform-side gather
     int64_t frames_rows = 0; int frames_W = 0;
     int exact_row_fallbacks = 0;
+    int pool_overflows = 0;               // K-NN calls whose retry still exhausted the entry pool (all rows served exactly)
     // f16-split prefilter state
     DevBuf a16h, a16l, s16h, s16l, b16h, b16l, eps16, thr32, gmin32, fmax2;
     bool f16_ready = false, cls16_ready = false;
@@ -151,6 +152,7 @@ struct snk_engine {
     int n_cus = 256;
     int reserved_cus = 2;
     int batch_rows = 8192;     // rows per K-NN call of the batch entry points (utterances are grouped)
+    int pool_chunk_limit = 0;  // test hook: cap of the entry pool (chunks) in every attempt; 0 = none
     int pool_chunks = 4096;    // entry pool: 4096 chunks x 2048 entries x 16 B = 128 MiB      // left free by the persistent K-NN sweep for Viterbi DP blocks
     int last_retries = 0;
     int tie_overflow = 0;
@@ -225,6 +227,7 @@ static int staged_d2h(snk_engine *h, hipStream_t st, const D2HPart *parts, int n
 }
 
 static int no_batch_in_flight(snk_engine *h, const char *who);
+static int create_streams(snk_engine *h);
 static int roundup(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); }
 #define SNK_KNN_MAX_ROWS 8192       // rows of one K-NN call (batch_rows is capped to it)
 
@@ -261,6 +264,14 @@ int snk_create(int device_id, snk_handle *out)
     h->device = device_id;
     h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (h->slabctr.ensure(64)) { delete h; return 1; }
+    const int rc = create_streams(h);
+    if (rc) { (void)snk_destroy(h); return rc; }
+    *out = h;
+    return 0;
+}
+
+static int create_streams(snk_engine *h)
+{
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     // Two side streams take the T-step recursions of alternate utterance groups.  (ROCm multiplexes
     // the streams of a process onto 4 hardware queues: with more side streams one of them shares a
@@ -275,7 +286,6 @@ int snk_create(int device_id, snk_handle *out)
     HIPCHK(hipEventCreateWithFlags(&h->knn_all_done, hipEventDisableTiming));
     for (auto &b : h->bslot) HIPCHK(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&h->dp_stream[1], hipStreamNonBlocking));
-    *out = h;
     return 0;
 }
 
@@ -283,15 +293,15 @@ int snk_destroy(snk_handle h)
 {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
-    (void)hipStreamSynchronize(h->stream2);
+    (void)hipDeviceSynchronize();
     collect_timers(h);
+    h->tmask.release(); h->mcand.release(); h->mdist.release();
     DevBuf *bufs[] = {&h->F_unw, &h->JC_unw, &h->Fw, &h->fnorm, &h->JCw, &h->wt, &h->wj, &h->unit_class,
                       &h->Qraw, &h->Qp, &h->Qf, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
                       &h->gpath, &h->gdist, &h->gsync, &h->gtiles, &h->cls16_full, &h->cls16_samp};
     for (auto *b : bufs) b->release();
-    (void)hipStreamSynchronize(h->dp_stream[1]); (void)hipStreamDestroy(h->dp_stream[1]);
+    if (h->dp_stream[1]) (void)hipStreamDestroy(h->dp_stream[1]);
     h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
     h->rowflag.release(); h->exact_rows.release(); h->exact_scratch.release();
     h->frames_spec.release(); h->frames_fzv.release(); h->cc_in.release(); h->cc_out.release();
@@ -306,11 +316,11 @@ int snk_destroy(snk_handle h)
         if (s.vit_done) (void)hipEventDestroy(s.vit_done);
     }
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->knn_all_done) (void)hipEventDestroy(h->knn_all_done);
     for (auto &b : h->bslot) { b.Qall.release(); b.cand.release(); b.dist.release(); b.path.release(); b.plen.release(); b.cost.release(); b.status.release(); b.stage.release(); if (b.done) (void)hipEventDestroy(b.done); }
-    (void)hipStreamDestroy(h->stream);
-    (void)hipStreamDestroy(h->stream2);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     delete h;
     return 0;
 }
@@ -364,6 +374,7 @@ int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt, const flo
 int snk_upload_join_only(snk_handle h, const float *JC_unw, int64_t Njc, int Dj)
 {
     if (!h) return fail("null handle");
+    CHK(no_batch_in_flight(h, "snk_upload_join_only"));
     HIPCHK(hipSetDevice(h->device));
     return upload_join(h, JC_unw, Njc, Dj);
 }
@@ -372,6 +383,8 @@ int snk_set_shard(snk_handle h, int64_t global_row_offset, int64_t global_N)
 {
     if (!h) return fail("null handle");
     if (global_row_offset < 0 || global_N < 1) return fail("snk_set_shard: bad arguments");
+    // merged lists carry unit ids through 32-bit sort keys (merge_topk_kernel)
+    if (global_N >= (1LL << 31)) return fail("snk_set_shard: global_N=%lld exceeds the 31-bit unit id range", (long long)global_N);
     h->shard_offset = global_row_offset;
     h->global_N = global_N;
     return 0;
@@ -447,8 +460,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
                                h->Djpad, h->stream);
     }
     HIPCHK(hipGetLastError());
-    // f16-split operands of the prefilter (knn16_kernels.hip): needs three spare padding columns
-    // for the ||f||^2 pieces and values inside the half-precision range
+    // float32 operands of the prefilter (knn16_kernels.hip): ||f||^2 rides in ONE spare padding column
     h->f16_ready = false;
     h->cls16_ready = false;
     if (h->have_db && h->Dpad <= 256 && h->Dpad - h->Dt >= 1) {
@@ -596,6 +608,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         const int64_t need = (Tpad * per_row) / knn_pool_chunk_entries() + 2048;
         if (need > max_chunks) max_chunks = (int)need;
     }
+    if (h->pool_chunk_limit > 0 && max_chunks > h->pool_chunk_limit) max_chunks = h->pool_chunk_limit;
     CHK(h->pool.ensure(knn_pool_bytes(max_chunks)));
     CHK(h->poolctl.ensure(2 * sizeof(unsigned int)));
     CHK(h->chunkfill.ensure((size_t)max_chunks * sizeof(int)));
@@ -699,6 +712,14 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             G = p.a_count * 16;
             CHK(h->gmin.ensure((size_t)Tpad * G * sizeof(double)));
             h->last_retries = 1;
+            // the first attempt may have exhausted the entry pool (mass ties at the thresholds): give the
+            // retry room for a full list per row, so that only the lists themselves can still overflow
+            const int64_t full = (Tpad * (int64_t)cap) / knn_pool_chunk_entries() + 4096;
+            if (full > max_chunks && h->pool_chunk_limit <= 0) {
+                max_chunks = (int)full;
+                CHK(h->pool.ensure(knn_pool_bytes(max_chunks)));
+                CHK(h->chunkfill.ensure((size_t)max_chunks * sizeof(int)));
+            }
         }
         if (G >= K) {       // tiny databases: fewer than K groups cannot bound the K-th neighbour
             {
@@ -737,15 +758,17 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         HIPCHK(hipStreamSynchronize(s));
         HIPCHK(hipGetLastError());
         if (status == 0) return 0;
-        if ((status & 1) && attempt == 0) continue;          // a list overflowed: exact thresholds next
+        if ((status & 5) && attempt == 0) continue;          // a list or the pool overflowed: exact thresholds next
         // Rows the list pipeline cannot serve: more units tied with (or within rounding of) the K-th
         // neighbour than a list or the exact re-rank holds -- mass duplicates.  They get the
-        // one-workgroup-per-row exact selection (slow, exact, ties by lowest id).
+        // one-workgroup-per-row exact selection (slow, exact, ties by lowest id).  If even the enlarged
+        // pool overflowed, the sweep dropped entries of rows that cannot be told apart: every row goes.
         std::vector<int> flags((size_t)T);
         HIPCHK(hipMemcpyAsync(flags.data(), h->rowflag.p, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         std::vector<int> rows;
-        for (int64_t t = 0; t < T; ++t) if (flags[(size_t)t]) rows.push_back((int)t);
+        for (int64_t t = 0; t < T; ++t) if (flags[(size_t)t] || (status & 4)) rows.push_back((int)t);
+        if (status & 4) h->pool_overflows += 1;
         if (status & 2) h->tie_overflow = 1;
         for (size_t r0 = 0; r0 < rows.size(); r0 += 64) {    // 64 rows (x Nalloc doubles of scratch) at a time
             const int n = (int)((rows.size() - r0 < 64) ? rows.size() - r0 : 64);
@@ -808,6 +831,7 @@ static int slot_ensure(snk_engine *h, UttSlot &s, int64_t T, int K)
 int snk_knn(snk_handle h, const double *Q, int64_t T, int D, int K, int64_t *cand_out, double *dist_out)
 {
     CHK(check_ready(h, true, false));
+    CHK(no_batch_in_flight(h, "snk_knn"));
     HIPCHK(hipSetDevice(h->device));
     if (!cand_out || !dist_out) return fail("snk_knn: null output");
     CHK(upload_queries(h, Q, T, D));
@@ -833,6 +857,7 @@ int snk_knn_by_class(snk_handle h, const double *Q, int64_t T, int D, int K, con
                      int64_t *cand_out, double *dist_out)
 {
     CHK(check_ready(h, true, false));
+    CHK(no_batch_in_flight(h, "snk_knn_by_class"));
     HIPCHK(hipSetDevice(h->device));
     if (!h->have_classes) return fail("snk_knn_by_class: unit classes not set (snk_set_unit_classes)");
     if (!query_class || !cand_out || !dist_out) return fail("snk_knn_by_class: null argument");
@@ -904,6 +929,7 @@ static int viterbi_device(snk_engine *h, UttSlot &s, int64_t T, int K, hipStream
 int snk_join_costs(snk_handle h, const int64_t *cand, int64_t T, int K, double *J_out)
 {
     CHK(check_ready(h, false, true));
+    CHK(no_batch_in_flight(h, "snk_join_costs"));
     HIPCHK(hipSetDevice(h->device));
     if (!cand || !J_out) return fail("snk_join_costs: null argument");
     if (T < 2) return fail("snk_join_costs: need at least 2 columns");
@@ -927,6 +953,7 @@ int snk_viterbi(snk_handle h, const int64_t *cand, const double *tdist, int64_t 
                 int64_t *path_out, int64_t *path_len_out, double *cost_out)
 {
     CHK(check_ready(h, false, true));
+    CHK(no_batch_in_flight(h, "snk_viterbi"));
     HIPCHK(hipSetDevice(h->device));
     if (!cand || !tdist || !path_out || !path_len_out) return fail("snk_viterbi: null argument");
     if (T < 1 || K < 1) return fail("snk_viterbi: empty trellis");
@@ -950,6 +977,7 @@ int snk_knn_viterbi(snk_handle h, const double *Q, int64_t T, int D, int K, int6
                     double *dist_out, int64_t *path_out, int64_t *path_len_out, double *cost_out)
 {
     CHK(check_ready(h, true, true));
+    CHK(no_batch_in_flight(h, "snk_knn_viterbi"));
     HIPCHK(hipSetDevice(h->device));
     if (!path_out || !path_len_out) return fail("snk_knn_viterbi: null output");
     if (h->Njc != h->N + 1) return fail("snk_knn_viterbi: join_contexts rows (%lld) != N+1", (long long)h->Njc);
@@ -1490,6 +1518,7 @@ int snk_merge_viterbi_batch_dev(snk_handle h, const double *d2_dev, const int64_
                                 int64_t *path_out, int64_t *path_len_out, double *cost_out)
 {
     CHK(check_ready(h, false, true));
+    CHK(no_batch_in_flight(h, "snk_merge_viterbi_batch_dev"));
     HIPCHK(hipSetDevice(h->device));
     if (!d2_dev || !id_dev || !row_offsets || n_utts < 1 || !path_out || !path_len_out || !cost_out)
         return fail("snk_merge_viterbi_batch_dev: null/empty argument");
@@ -1636,6 +1665,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "batch_rows")) {
         if (value < 0 || value > 8192) return fail("batch_rows must be in 0..8192 (0: one K-NN call per utterance)");
         h->batch_rows = (int)value;
+    } else if (!strcmp(name, "pool_chunk_limit")) {
+        if (value < 0 || value > 1e6) return fail("pool_chunk_limit must be in 0..1e6");
+        h->pool_chunk_limit = (int)value;
     } else if (!strcmp(name, "timers")) {
         h->timers_on = value != 0.0;
     } else {
@@ -1655,6 +1687,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "tie_overflow")) *out = h->tie_overflow;
     else if (!strcmp(name, "exact_row_fallbacks")) *out = h->exact_row_fallbacks;
     else if (!strcmp(name, "batch_redos")) *out = h->batch_redos;
+    else if (!strcmp(name, "pool_overflows")) *out = h->pool_overflows;
     else if (!strcmp(name, "f16_ready")) *out = h->f16_ready ? 1 : 0;
     else if (!strcmp(name, "f16_fallbacks")) *out = h->f16_fallbacks;
     else if (!strcmp(name, "last_f16_status")) *out = h->last_f16_status;

@@ -414,6 +414,31 @@ def test_knn_mass_duplicates(engine):
     assert list(paths[0]) == op and costs[0] == ocst
 
 
+def test_knn_entry_pool_exhausted_is_never_silent(engine):
+    """The filter sweep appends survivors to a global entry pool; when the pool runs out it drops entries
+    of ARBITRARY rows.  The first attempt's overflow must lead to a retry, and a retry that overflows
+    again to the exact per-row selection of EVERY row -- never to rc 0 with truncated lists."""
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(40000, 61, 24, seed=19)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    U = o.synthetic_targets(F_unw, 40, seed=3) * wt
+    oc, od = o.knn_bruteforce(F, U, 30)
+    try:
+        engine.set_option('pool_chunk_limit', 8)        # far fewer chunks than resident wavefronts
+        for precision in (1, 0):
+            engine.set_option('precision', precision)
+            before = engine.info('pool_overflows')
+            cand, dist = engine.knn(U, 30)
+            assert np.array_equal(cand, oc) and np.array_equal(dist, od)
+            assert engine.info('pool_overflows') - before == 1
+        paths, costs = engine.knn_viterbi_batch([U, U[:7]], 30)      # deferred status -> redo at collect
+        op, ocst = o.viterbi(oc, od, E, S)
+        assert list(paths[0]) == op and costs[0] == ocst
+    finally:
+        engine.set_option('pool_chunk_limit', 0)
+        engine.set_option('precision', 1)
+
+
 def test_column_selection_equals_dropped_columns(engine):
     """snk_set_column_selection (stream truncation): full-width queries and matrices with selected-out
     columns against the oracle on arrays with those columns DROPPED, as the reference does
