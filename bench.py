@@ -97,6 +97,9 @@ def main():
     ap.add_argument('--cpu-sample-frames', type=int, default=600,
                     help='frames of the CPU baseline sample (600 = one utterance of the workload, ~15 s on one core)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--viterbi-mode', type=int, default=1, choices=(0, 1),
+                    help='1: f32 matrix lower bounds + sparse exact recursion (default); 0: dense exact float64 join costs')
+    ap.add_argument('--join-beta', type=float, default=None, help='margin of the predecessor sets (speed only)')
     ap.add_argument('--in-flight', type=int, default=1, choices=(1, 2),
                     help='N = 1: steps in flight; 2 submits step i+1 before collecting step i (+2-4 %% frames/s; the '
                          'recursions of a finished step then run beside every filter launch, whose own time grows 3 %%)')
@@ -141,6 +144,9 @@ def main():
     batch = snickery_amd.QueryBatch(utts)
 
     eng = snickery_amd.HipSearchEngine(local_rank)       # raises without libsnkhip.so / gfx950
+    eng.set_option('viterbi_mode', args.viterbi_mode)
+    if args.join_beta is not None:
+        eng.set_option('join_beta', args.join_beta)
     if world == 1:
         eng.upload_db(F_unw, JC_unw)
         eng.set_weights(wt, wj)
@@ -285,6 +291,9 @@ def main():
             'stages_ms_per_step': dict((k, v[0] / args.steps) for k, v in timers.items() if v[1]),
             'stage_launches_per_step': dict((k, v[1] / args.steps) for k, v in timers.items() if v[1]),
         }
+        out['viterbi'] = {'mode': 'f32 matrix lower bounds + verified sparse exact recursion' if args.viterbi_mode == 1 else 'dense exact float64 join costs',
+                          'cells_refined': eng.info('dense_cells'), 'steps_with_refinement': eng.info('dense_steps'),
+                          'exact_costs_in_refinement': eng.info('dense_exact_costs')}
         if two_in_flight is not None:
             out['two_in_flight'] = two_in_flight
         if share_gpu:

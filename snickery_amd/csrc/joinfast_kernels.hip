@@ -1,0 +1,810 @@
+// Join costs off the float64 vector pipe: lower bounds on the matrix pipe, exact values only where the
+// recursion can see them.
+//
+// Replaces, together with viterbi_kernels.hip (which stays as the dense exact path and the A/B partner):
+//   make_on_the_fly_join_lattice_BLOCK_DIRECT / get_natural_distance_vectorised
+//                                               (script/synth_halfphone.py:3206-3322, :2942-2951)
+//   make_target_sausage_lattice / cost_cache_to_compiled_fst / openfst.compose / openfst.shortestpath
+//                                               (script/fst_functions_wrapped.py:28-58,172-217,368,389)
+//
+// The recursion  delta_t[k] = tdist[t,k] + min_k' ( delta_{t-1}[k'] + c(k',k) )  needs the EXACT canonical
+// float64 join cost c only for the predecessors that can win.  Four passes:
+//
+//   1  join_lb_kernel        (all rows in parallel, f32 matrix pipe)  clo(k',k) <= c(k',k), PROVEN:
+//        rows are centred on a per-step reference row m (float64 subtraction, then rounded to f32:
+//        candidates of one step are close to each other, so a plain f32 ||e||^2+||s||^2-2e.s would lose
+//        every digit to cancellation), G = ye~ . ys~ on v_mfma_f32_16x16x4_f32,
+//        c2~ = ne + ns - 2G,  |c2~ - c^2| <= e2 := 2.2 (D+6) 2^-24 (ne + ns),  clo = sqrt(max(c2~ - e2, 0)) (1 - 2^-21).
+//   2  viterbi_lb_kernel     (one workgroup per utterance)  the recursion on clo: dlb_t[k] <= delta_t[k];
+//        per (t,k) the predecessors within theta of the minimum (at most JF_CAP of them; their slots) and
+//        X(t,k) = the smallest lower-bound total among all the OTHER predecessors.
+//   3  join_exact_sparse_kernel (parallel)  canonical float64 c for the recorded predecessors only
+//        (about 1 % of the K x K pairs).
+//   4  viterbi_sparse_kernel (one workgroup per utterance)  the exact recursion over the recorded sets,
+//        with a proof per (t,k) that no other predecessor can win or tie:
+//             X(t,k) + min_k'( delta_{t-1}[k'] - dlb_{t-1}[k'] )  >  best exact total
+//        (every excluded k' has delta[k'] + c >= dlb[k'] + off + clo >= X + off).  Where the proof fails,
+//        or a set overflowed, that (t,k) is recomputed densely on the spot: all K exact join costs of its
+//        column.  Path and cost are therefore bit-identical to the dense exact recursion -- the margins
+//        only decide how often the slow branch runs, never the result.
+#include "snk_internal.h"
+#include <float.h>
+
+namespace snk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define JF_CAP 4              // recorded predecessors per (t,k); more: that column is recomputed densely
+
+__device__ __forceinline__ bool jf_usable(int64_t id, int64_t n_units)
+{
+    return id >= 1 && id < n_units - 1;        // synth_halfphone.py:3238-3268
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass 1
+// One workgroup per pair of consecutive candidate rows (r, r+1); KT wavefronts; wavefront w owns the
+// 16 E rows (unit_end_data of cand[r, 16w .. 16w+15]) and stages the 16 S rows (unit_start_data of
+// cand[r+1, 16w ..]) of its number.  Columns go in chunks of 64 = 4 MFMA blocks of 16:
+//   lane l <-> row l & 15, columns 16 b + 4 (l >> 4) + i, i = 0..3, of block b
+// which is at once the A / B operand map of v_mfma_f32_16x16x4_f32 for the k-steps i = 0..3 (k = l >> 4
+// is then column 4 k + i of the block: a permutation of the sum, the same on both operands).
+// The E fragments stay in registers; the S fragments of all KT tiles go through LDS in fragment order
+// (a wavefront writes / reads 1 KB of consecutive addresses per instruction: conflict-free), double
+// buffered, one barrier per chunk.  The next chunk's rows are in flight during the MFMAs.
+// ---------------------------------------------------------------------------------------------
+#define JF_MAXD 1024           // join columns (padded to 16) the w / m tables in LDS hold
+
+template <int KT>
+__global__ void __launch_bounds__(64 * KT)
+join_lb_kernel(const float *__restrict__ JC_unw, int Jp, int Dj, const double *__restrict__ wj, int64_t n_units,
+               const int64_t *__restrict__ cand, int K, float *__restrict__ Jlo, float *__restrict__ scale_out)
+{
+    __shared__ f32x4 Bs[2][KT][(KT > 8) ? 2 : 4][64];
+    __shared__ double w_s[JF_MAXD], m_s[JF_MAXD];
+    __shared__ float ne_s[16 * KT], ns_s[16 * KT];
+    __shared__ int first_ok, smax_bits;
+    const int64_t r = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row16 = lane & 15, q = lane >> 4;
+    const int DC = (Dj + 15) & ~15;
+    const int n_blocks = DC / 16;
+
+    // this lane's E row and S row
+    const int kk = wave * 16 + row16;
+    const int64_t idE = kk < K ? cand[r * K + kk] : -1;
+    const int64_t idS = kk < K ? cand[(r + 1) * K + kk] : -1;
+    const bool okE = jf_usable(idE, n_units), okS = jf_usable(idS, n_units);
+    const float *const rowE = JC_unw + (okE ? idE + 1 : 0) * (int64_t)Jp;     // unit_end_data[a]   = JC[a+1]
+    const float *const rowS = JC_unw + (okS ? idS : 0) * (int64_t)Jp;         // unit_start_data[b] = JC[b]
+    if (tid == 0) { first_ok = 1 << 30; smax_bits = 0; }
+    __syncthreads();
+    {
+        const unsigned long long bal = __ballot(okS && q == 0);
+        if (lane == 0 && bal) atomicMin(&first_ok, wave * 16 + __builtin_ctzll(bal));
+    }
+    __syncthreads();
+    // reference row m: the start vector of the first usable candidate of row r+1 (any row would do:
+    // the bound below is in terms of the centred norms, whatever m is)
+    {
+        const int k0 = first_ok;
+        const int64_t id0 = (k0 < K) ? cand[(r + 1) * K + k0] : 0;
+        const float *row0 = JC_unw + (k0 < K ? id0 : 0) * (int64_t)Jp;
+        for (int c = tid; c < DC; c += (int)blockDim.x) {
+            const double w = c < Dj ? wj[c] : 0.0;
+            w_s[c] = w;
+            m_s[c] = c < Dj ? __dmul_rn((double)row0[c], w) : 0.0;
+        }
+    }
+    __syncthreads();
+
+    // blocks per chunk: 4 (64 columns); 2 for the widest tiles, whose 4 KT accumulators leave fewer registers
+    constexpr int CB = (KT > 8) ? 2 : 4;
+    f32x4 acc[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float ne = 0.f, ns = 0.f;
+
+    // raw rows of one chunk: CB blocks x 16 bytes per matrix and lane
+    f32x4 rawE[CB], rawS[CB];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int b = 0; b < CB; ++b) {
+            int c0 = (ch * CB + b) * 16 + 4 * q;
+            if (c0 > Jp - 4) c0 = Jp - 4;                  // padded blocks: any readable address (weights are 0 there)
+            rawE[b] = *reinterpret_cast<const f32x4 *>(rowE + c0);
+            rawS[b] = *reinterpret_cast<const f32x4 *>(rowS + c0);
+        }
+    };
+    const int n_chunks = (n_blocks + CB - 1) / CB;
+    fetch(0);
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        // centre in float64, round to float32, norms in float32 -- block by block (the fence keeps the
+        // compiler from hoisting every block's table reads to the top: 64 registers)
+        f32x4 a[CB];
+#pragma unroll
+        for (int b = 0; b < CB; ++b) {
+            const int c0 = (ch * CB + b) * 16 + 4 * q;
+            double w[4], m[4];
+            if (c0 < DC) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { w[i] = w_s[c0 + i]; m[i] = m_s[c0 + i]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { w[i] = 0.0; m[i] = 0.0; }
+            }
+            f32x4 ys;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float e = (float)__dsub_rn(__dmul_rn((double)rawE[b][i], w[i]), m[i]);
+                const float s = (float)__dsub_rn(__dmul_rn((double)rawS[b][i], w[i]), m[i]);
+                const bool live = c0 + i < Dj;             // columns beyond Dj read a neighbour's bytes: force 0
+                a[b][i] = live ? e : 0.f;
+                ys[i] = live ? s : 0.f;
+                ne = __builtin_fmaf(a[b][i], a[b][i], ne);
+                ns = __builtin_fmaf(ys[i], ys[i], ns);
+            }
+            Bs[ch & 1][wave][b][lane] = ys;
+            asm volatile("" ::: "memory");
+        }
+        if (ch + 1 < n_chunks) fetch(ch + 1);
+        __syncthreads();
+        const int nb = (n_blocks - ch * CB) < CB ? (n_blocks - ch * CB) : CB;
+#pragma unroll
+        for (int b = 0; b < CB; ++b) {
+            if (b >= nb) break;                              // uniform
+            // tiles in groups of JG: consecutive MFMAs go to different accumulators (40-cycle dependent
+            // latency against a 32-cycle issue interval), the group's S fragments are all the registers needed
+            constexpr int JG = (KT <= 4) ? KT : 4;
+#pragma unroll
+            for (int j0 = 0; j0 < KT; j0 += JG) {
+                f32x4 bf[JG];
+#pragma unroll
+                for (int j = 0; j < JG; ++j)
+                    if (j0 + j < KT) bf[j] = Bs[ch & 1][j0 + j][b][lane];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < JG; ++j)
+                        if (j0 + j < KT)
+                            acc[j0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][i], bf[j][i], acc[j0 + j], 0, 0, 0);
+            }
+        }
+    }
+    // row norms: the four lanes of a row hold the partial sums of its four column quarters
+    ne += __shfl_xor(ne, 16, 64); ne += __shfl_xor(ne, 32, 64);
+    ns += __shfl_xor(ns, 16, 64); ns += __shfl_xor(ns, 32, 64);
+    if (q == 0) {
+        ne_s[kk] = okE ? ne : __builtin_inff();
+        ns_s[kk] = okS ? ns : __builtin_inff();
+        // scale of the step (margin of pass 2): the largest centred norm among the usable rows
+        const float big = fmaxf(okE ? ne : 0.f, okS ? ns : 0.f);
+        atomicMax(&smax_bits, __float_as_int(big));
+    }
+    __syncthreads();
+    // |c2~ - c^2| <= e2: operand rounding 2^-24 each, two f32 FMA chains of DC terms for the norms, one for
+    // G, two f32 operations in the epilogue, (||ye|| + ||ys||)^2 <= 2 (ne + ns)
+    const float ceps = 2.2f * (float)(DC + 6) * 5.9604644775390625e-08f;
+    float *const out = Jlo + r * (int64_t)K * K;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        const int k = j * 16 + row16;                       // column of the result = S row
+        const float nsv = ns_s[k];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kp = wave * 16 + 4 * q + i;           // row of the result = E row
+            const float nev = ne_s[kp];
+            const float sum = nev + nsv;
+            const float c2 = sum - 2.f * acc[j][i];
+            const float lo2 = c2 - (ceps * sum + 1e-30f);
+            float clo = 0.f;                                 // NaN / overflow: 0 is a valid lower bound
+            if (lo2 > 0.f && lo2 < __builtin_inff()) clo = __builtin_sqrtf(lo2) * (1.f - 4.76837158203125e-07f);
+            if (!(sum < __builtin_inff())) clo = (sum == __builtin_inff()) ? __builtin_inff() : 0.f;   // unusable unit: +inf
+            if (kp < K && k < K) out[(int64_t)kp * K + k] = clo;
+        }
+    }
+    if (tid == 0) scale_out[r] = __builtin_sqrtf(__int_as_float(smax_bits));
+}
+
+template <int KT>
+static void launch_join_lb_t(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
+                             int64_t R, int K, float *Jlo, float *scale, hipStream_t s)
+{
+    hipLaunchKernelGGL((join_lb_kernel<KT>), dim3((unsigned)(R - 1)), dim3(64 * KT), 0, s, JC_unw, Jp, Dj, wj, n_units,
+                       cand, K, Jlo, scale);
+}
+
+bool join_lb_supported(int Dj, int K) { return ((Dj + 15) & ~15) <= JF_MAXD && K >= 1 && K <= 208; }
+
+void launch_join_lb(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
+                    int64_t R, int K, float *Jlo, float *scale, hipStream_t s)
+{
+    if (R < 2) return;
+    const int kt = (K + 15) / 16;
+#define SNK_JLB(KT_) launch_join_lb_t<KT_>(JC_unw, Jp, Dj, wj, n_units, cand, R, K, Jlo, scale, s)
+    if (kt <= 1) SNK_JLB(1);
+    else if (kt <= 2) SNK_JLB(2);
+    else if (kt <= 4) SNK_JLB(4);
+    else if (kt <= 5) SNK_JLB(5);
+    else if (kt <= 7) SNK_JLB(7);
+    else if (kt <= 8) SNK_JLB(8);
+    else if (kt <= 10) SNK_JLB(10);
+    else SNK_JLB(13);
+#undef SNK_JLB
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// pass 2: an APPROXIMATE recursion on the lower bounds, in float32, + the predecessor sets.
+// Pass 4's proof needs no property of d~ itself, only that X is consistent with it:
+//     X(t,k) <= d~_{t-1}[k'] + clo(k',k)   for every k' outside the set, in exact arithmetic on the stored values
+// (then delta[k'] + c >= d~[k'] + off + clo >= X + off with off = min_k'(delta[k'] - d~[k'])).  So d~ runs in
+// float32 (X is lowered by 2 ulp for the rounding of the sum) and is shifted every 64 steps to keep its
+// magnitude near the costs of a step (the shift is common to all columns of a step: off absorbs it).
+// Layout of viterbi_dp_kernel (viterbi_kernels.hip): a wavefront owns 16 columns k, its four 16-lane
+// rows split the predecessors; slabs of the next NB steps in flight in registers (float32: half the
+// stream).  After the minimum a second sweep over the slab registers appends every predecessor within
+// theta of it to the column's list in LDS (the four lanes of a column sit in one wavefront: LDS
+// operations of a wavefront execute in order, no barrier) and reduces the rest to X.
+// theta = beta * scale[t-1] + 4e-7 |min|: scale is the step's largest centred norm (pass 1).
+// Output per cell, 16 bytes: { d~ (f32), X (f32), slots (4 x u8), n }.
+// ---------------------------------------------------------------------------------------------
+template <int KPM, int NB, int NTH>
+__global__ void __launch_bounds__(NTH)
+viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict__ tdist_all,
+                  const float *__restrict__ J_all, const float *__restrict__ scale_all, const DpBatch batch, int K,
+                  int64_t n_units, int KP, float beta, u32x4 *__restrict__ sets_all)
+{
+    const int64_t r0 = batch.off[blockIdx.x];
+    const int64_t T = batch.off[blockIdx.x + 1] - r0;
+    const int64_t *__restrict__ cand = cand_all + r0 * K;
+    const double *__restrict__ tdist = tdist_all + r0 * K;
+    const float *__restrict__ J = J_all + r0 * K * K;
+    const float *__restrict__ scale = scale_all + r0;
+    u32x4 *__restrict__ sets = sets_all + r0 * K;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *delta = reinterpret_cast<float *>(smem);                // [2][KP]
+    int *lcnt = reinterpret_cast<int *>(delta + 2 * KP);           // [KP]
+    unsigned int *lidx = reinterpret_cast<unsigned int *>(lcnt + KP);     // [KP] four slots each
+    float *wmin = reinterpret_cast<float *>(lidx + KP);            // [16] per-wavefront minima (shift steps)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int k = (tid >> 6) * 16 + (lane & 15);
+    const int part = lane >> 4, kp0 = part * KPM;
+    const bool col = k < K;
+    const bool lead = col && part == 0;
+    const float inf = __builtin_inff();
+    const int nwaves = (int)blockDim.x >> 6;
+
+    if (T < 1) return;
+    for (int i = tid; i < 2 * KP; i += (int)blockDim.x) delta[i] = inf;
+    for (int i = tid; i < KP; i += (int)blockDim.x) { lcnt[i] = 0; lidx[i] = 0; }
+    if (tid < 16) wmin[tid] = inf;
+    __syncthreads();
+    if (lead) {
+        const float d0 = jf_usable(cand[k], n_units) ? (float)tdist[k] : inf;
+        delta[k] = d0;
+        sets[k] = (u32x4){__builtin_bit_cast(unsigned int, d0), __builtin_bit_cast(unsigned int, inf), 0u, 0u};
+    }
+    if (T < 2) return;
+
+    const int voff = col ? (kp0 * K + k) * 4 : 0x7ffffffc;
+    float jb[NB][KPM];
+    auto load_slab = [&](int64_t slab, float (&dst)[KPM]) {
+        const __amdgpu_buffer_rsrc_t jres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(J + slab * K * K), 0, K * K * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < KPM; ++i)
+            dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(jres, voff, i * K * 4, 0));
+    };
+    double td_raw[NB];
+    int64_t id_raw[NB];
+    float sc_raw[NB];
+    auto load_target = [&](int64_t t, double &td, int64_t &id, float &sc) {
+        const int64_t tc = t < T ? t : T - 1;
+        const int64_t tn = tc * K + (col ? k : 0);
+        td = tdist[tn];
+        id = cand[tn];
+        sc = scale[tc - 1];
+    };
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+        load_slab(s < T - 2 ? s : T - 2, jb[s]);
+        load_target(1 + s, td_raw[s], id_raw[s], sc_raw[s]);
+    }
+    __syncthreads();
+
+    auto step = [&](int64_t t, float (&jr)[KPM], double &tdr, int64_t &idr, float &scr) {
+        const bool valid = t < T;                       // uniform
+        const float *dprev = delta + ((t - 1) & 1) * KP;
+        float *dcur = delta + (t & 1) * KP;
+        const float td = jf_usable(idr, n_units) ? (float)tdr : inf;
+        const float sc = scr;
+        load_target(t + NB, tdr, idr, scr);
+        // the step after a shift step: every d~ of the previous step is read lowered by the block's minimum
+        float shift = 0.f;
+        if (((t - 1) & 63) == 0 && t > 1) {             // uniform
+            shift = inf;
+            for (int w = 0; w < nwaves; ++w) shift = fminf(shift, wmin[w]);
+            if (!(shift < inf)) shift = 0.f;
+        }
+        float v[KPM];
+        float best = inf;
+#pragma unroll
+        for (int i = 0; i < KPM; ++i) {
+            // predecessors beyond K: d~ stays +inf (and an out-of-range buffer load returns 0)
+            v[i] = (dprev[kp0 + i] - shift) + jr[i];
+            best = fminf(best, v[i]);
+        }
+        load_slab(t - 1 + NB < T - 2 ? t - 1 + NB : T - 2, jr);
+        best = fminf(best, __shfl_xor(best, 16, 64));
+        best = fminf(best, __shfl_xor(best, 32, 64));
+        // second sweep: the set within theta of the minimum, the minimum of the rest
+        const float thr = best + (beta * sc + 4e-7f * fabsf(best));
+        float xmin = inf;
+        if (col && valid && best < inf) {
+#pragma unroll
+            for (int i = 0; i < KPM; ++i) {
+                if (v[i] <= thr) {
+                    const int slot = atomicAdd(&lcnt[k], 1);
+                    if (slot < JF_CAP) reinterpret_cast<unsigned char *>(lidx)[k * JF_CAP + slot] = (unsigned char)(kp0 + i);
+                } else {
+                    xmin = fminf(xmin, v[i]);
+                }
+            }
+        }
+        xmin = fminf(xmin, __shfl_xor(xmin, 16, 64));
+        xmin = fminf(xmin, __shfl_xor(xmin, 32, 64));
+        float d = inf;
+        if (lead && valid) {
+            d = td + best;
+            dcur[k] = d;
+            // X two ulp down: fl32(a + b) may lie above a + b; the shift is applied to the STORED d~ of the
+            // previous step as well (pass 4 sees d~_{t-1} as stored), so it goes back in here
+            float x = xmin < inf ? (xmin + shift) : inf;
+            if (x < inf) x -= 3.6e-7f * fabsf(x) + 3.6e-7f * fabsf(shift) + 1e-37f;
+            const int n = lcnt[k];
+            lcnt[k] = 0;
+            sets[t * K + k] = (u32x4){__builtin_bit_cast(unsigned int, d), __builtin_bit_cast(unsigned int, x), lidx[k],
+                                      (unsigned int)(n > JF_CAP ? JF_CAP + 1 : n)};
+        }
+        if ((t & 63) == 0) {                            // uniform: a shift step publishes the wavefront's minimum
+            float m = lead ? d : inf;
+#pragma unroll
+            for (int s = 1; s <= 8; s <<= 1) m = fminf(m, __shfl_xor(m, s, 64));
+            if (lane == 0) wmin[tid >> 6] = m;
+        }
+        __syncthreads();
+    };
+
+    for (int64_t t = 1; t < T; t += NB) {
+#pragma unroll
+        for (int s = 0; s < NB; ++s) step(t + s, jb[s], td_raw[s], id_raw[s], sc_raw[s]);
+    }
+}
+
+void launch_viterbi_lb(const int64_t *cand, const double *tdist, const float *Jlo, const float *scale, const int64_t *off,
+                       int n_utts, int K, int64_t n_units, float beta, void *sets, hipStream_t s)
+{
+    static_assert(JF_CAP == 4, "the sets travel as one 32-bit word");
+    for (int u0 = 0; u0 < n_utts; u0 += DpBatch::MAX) {
+        const int n = (n_utts - u0 < DpBatch::MAX) ? n_utts - u0 : DpBatch::MAX;
+        DpBatch batch;
+        for (int i = 0; i <= n; ++i) batch.off[i] = off[u0 + i];
+        batch.first = u0;
+        int variant, kpm;
+        if (K <= 64) { variant = 0; kpm = 16; }
+        else if (K <= 100) { variant = 1; kpm = 25; }
+        else if (K <= 128) { variant = 2; kpm = 32; }
+        else { variant = 3; kpm = 52; }
+        const int KP = 4 * kpm;
+        const int nth = 64 * ((K + 15) / 16);
+        const size_t shmem = (size_t)2 * KP * 4 + (size_t)KP * 4 + (size_t)KP * 4 + 64;
+#define SNK_LB(KPM_, NB_, NTH_)                                                                               \
+    hipLaunchKernelGGL((viterbi_lb_kernel<KPM_, NB_, NTH_>), dim3(n), dim3(nth), shmem, s, cand, tdist, Jlo, scale, \
+                       batch, K, n_units, KP, beta, reinterpret_cast<u32x4 *>(sets))
+        if (variant == 0) SNK_LB(16, 4, 256);
+        else if (variant == 1) SNK_LB(25, 4, 448);
+        else if (variant == 2) SNK_LB(32, 3, 512);
+        else SNK_LB(52, 2, 832);
+#undef SNK_LB
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// canonical float64 join cost of one pair (the oracle's order: column by column, separately rounded
+// sub / mul / add on fl64(f32 * w), the values speech_manip.weight() produces)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double jf_exact_cost(const float *__restrict__ JC_unw, int Jp, int Dj,
+                                                const double *__restrict__ wj, int64_t a, int64_t b)
+{
+    const f32x4 *__restrict__ re = reinterpret_cast<const f32x4 *>(JC_unw + (a + 1) * (int64_t)Jp);   // unit_end_data[a]
+    const f32x4 *__restrict__ rs = reinterpret_cast<const f32x4 *>(JC_unw + b * (int64_t)Jp);         // unit_start_data[b]
+    double acc = 0.0;
+    const int n4 = Dj >> 2;
+    int c4 = 0;
+    for (; c4 + 4 <= n4; c4 += 4) {
+        f32x4 e[4], s[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { e[u] = re[c4 + u]; s[u] = rs[c4 + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double w = wj[4 * (c4 + u) + i];
+                const double d = __dsub_rn(__dmul_rn((double)e[u][i], w), __dmul_rn((double)s[u][i], w));
+                acc = __dadd_rn(acc, __dmul_rn(d, d));
+            }
+    }
+    for (int c = 4 * c4; c < Dj; ++c) {
+        const double w = wj[c];
+        const double d = __dsub_rn(__dmul_rn((double)JC_unw[(a + 1) * (int64_t)Jp + c], w),
+                                   __dmul_rn((double)JC_unw[b * (int64_t)Jp + c], w));
+        acc = __dadd_rn(acc, __dmul_rn(d, d));
+    }
+    return __dsqrt_rn(acc);
+}
+
+// pass 3: one lane per (row, column): the exact costs of its recorded predecessors, and the cell's 64-byte
+// record for pass 4:  { td (target cost, +inf for an unusable unit), X, dlb, c[0..3], slots | n << 32 }
+struct __attribute__((aligned(16))) JfRecord { double td, x, lb, c[JF_CAP]; unsigned long long meta; };
+
+__global__ void __launch_bounds__(256)
+join_exact_sparse_kernel(const float *__restrict__ JC_unw, int Jp, int Dj, const double *__restrict__ wj,
+                         int64_t n_units, const int64_t *__restrict__ cand, const double *__restrict__ tdist,
+                         int64_t R, int K, const u32x4 *__restrict__ sets, JfRecord *__restrict__ rec)
+{
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= R * K) return;
+    const u32x4 st = sets[cell];
+    const int n_raw = (int)st[3];
+    const int n = n_raw > JF_CAP ? JF_CAP : n_raw;       // an overflowed set: its first members still start pass 4's refinement
+    const int64_t t = cell / K;                            // n > 0 implies a predecessor row inside the utterance
+    const int64_t b = cand[cell];
+    const unsigned int ix = st[2];
+    // (scalars first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this compiler)
+    const unsigned int w_d = st[0], w_x = st[1];
+    const double lb64 = (double)__builtin_bit_cast(float, w_d), x64 = (double)__builtin_bit_cast(float, w_x);
+    double c[JF_CAP];
+#pragma unroll
+    for (int j = 0; j < JF_CAP; ++j) {
+        c[j] = __builtin_inf();
+        if (j < n) {
+            const int64_t a = cand[(t - 1) * K + ((ix >> (8 * j)) & 0xffu)];
+            if (jf_usable(a, n_units) && jf_usable(b, n_units)) c[j] = jf_exact_cost(JC_unw, Jp, Dj, wj, a, b);
+        }
+    }
+    // four 16-byte pieces, as pass 4's loader streams them
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2 *dst = reinterpret_cast<f64x2 *>(rec + cell);
+    dst[0] = (f64x2){jf_usable(b, n_units) ? tdist[cell] : __builtin_inf(), x64};
+    dst[1] = (f64x2){lb64, c[0]};
+    dst[2] = (f64x2){c[1], c[2]};
+    dst[3] = (f64x2){c[3], __builtin_bit_cast(double, (unsigned long long)ix | ((unsigned long long)n_raw << 32))};
+}
+
+size_t join_record_bytes() { return sizeof(JfRecord); }
+
+void launch_join_exact_sparse(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
+                              const double *tdist, int64_t R, int K, const void *sets, void *rec, hipStream_t s)
+{
+    static_assert(sizeof(JfRecord) == 64, "pass 4 streams 64-byte records");
+    const int64_t cells = R * K;
+    hipLaunchKernelGGL(join_exact_sparse_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, JC_unw, Jp, Dj,
+                       wj, n_units, cand, tdist, R, K, reinterpret_cast<const u32x4 *>(sets), reinterpret_cast<JfRecord *>(rec));
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass 4: the exact recursion over the recorded sets.  One thread per column, ONE barrier per step, no
+// global load in the step: the records of the next steps come through an LDS ring filled by a LOADER
+// wavefront (the last one of the workgroup; batches of BS steps, issued a batch ahead, written to the
+// ring at the end of the batch before).  Every (t,k) is verified (file header); one that cannot be is
+// REFINED: with the exact delta_{t-1} at hand only predecessors with delta[k'] + clo(k',k) <= best so
+// far can win or tie -- those (a handful) get their exact cost, one lane each.
+// stats[0] += cells refined, [1] += steps with a refinement, [2] += exact costs computed there,
+// [3] += cells whose set had overflowed.
+// ---------------------------------------------------------------------------------------------
+// wavefront minimum of a double: rotations inside the 16-lane rows on the DPP path, then the four row
+// results through scalar registers (six ds_bpermute round trips otherwise: the longest piece of a step)
+template <int CTRL>
+__device__ __forceinline__ double jf_dpp_f64(double x)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    lo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+    hi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+__device__ __forceinline__ double jf_readlane_f64(double x, int l)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+__device__ __forceinline__ double jf_wave_min(double x)
+{
+    double o;
+    o = jf_dpp_f64<0x121>(x); x = o < x ? o : x;       // row_ror:1
+    o = jf_dpp_f64<0x122>(x); x = o < x ? o : x;       // row_ror:2
+    o = jf_dpp_f64<0x124>(x); x = o < x ? o : x;       // row_ror:4
+    o = jf_dpp_f64<0x128>(x); x = o < x ? o : x;       // row_ror:8
+    const double a = jf_readlane_f64(x, 0), b = jf_readlane_f64(x, 16), c = jf_readlane_f64(x, 32), d = jf_readlane_f64(x, 48);
+    const double ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+
+template <int BS, bool BPL>
+__global__ void __launch_bounds__(320)
+viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__restrict__ rec_all,
+                      const float *__restrict__ Jlo_all, const float *__restrict__ JC_unw, int Jp, int Dj,
+                      const double *__restrict__ wj, const DpBatch batch, int K, int64_t n_units,
+                      unsigned char *__restrict__ bp_all, int64_t *__restrict__ path_all,
+                      int64_t *__restrict__ path_len_all, double *__restrict__ cost_all,
+                      unsigned long long *__restrict__ stats)
+{
+    const int64_t r0 = batch.off[blockIdx.x];
+    const int64_t T = batch.off[blockIdx.x + 1] - r0;
+    const int64_t *__restrict__ cand = cand_all + r0 * K;
+    const JfRecord *__restrict__ rec = rec_all + r0 * K;
+    const float *__restrict__ Jlo = Jlo_all + r0 * K * K;
+    unsigned char *__restrict__ bp_global = bp_all + r0 * K;
+    int64_t *__restrict__ path = path_all + r0;
+    int64_t *__restrict__ path_len = path_len_all + batch.first + blockIdx.x;
+    double *__restrict__ cost = cost_all + batch.first + blockIdx.x;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *delta = reinterpret_cast<double *>(smem);              // [2][256]
+    double *rbest = delta + 2 * 256;                               // [256] refinement: a failing column's best total
+    double *wrec = rbest + 256;                                    // [2][4] x {minimum of delta - dlb, any column failed} per wavefront
+    int *failw = reinterpret_cast<int *>(wrec + 16);               // [4] scratch; [3] the final slot
+    int *rarg = failw + 4;                                         // [256] ... and its predecessor slot
+    unsigned char *fail_s = reinterpret_cast<unsigned char *>(rarg + 256);   // [256]
+    int *final_slot_p = failw + 3;                                 // (all LDS in one array: a second object can de-pipeline the loader)
+    u32x4 *ring = reinterpret_cast<u32x4 *>(fail_s + 256);         // [3][slot_pieces] records of three batches (4 x 16 bytes per cell)
+    const int pieces = BS * K * 4;                                 // 16-byte pieces of one batch
+    const int slot_pieces = (pieces + 63) & ~63;                   // ring slots are whole 1-KB LDS-DMA writes
+    unsigned char *bp_lds = reinterpret_cast<unsigned char *>(ring + (size_t)3 * slot_pieces);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = (int)blockDim.x >> 6, ncw = nwaves - 1;     // compute wavefronts; the last one loads
+    const bool loader = wave == ncw;
+    const int k = tid;
+    const bool col = !loader && k < K;
+    const double inf = __builtin_inf();
+
+    if (T < 2) {                      // the reference's J has no states for T < 2
+        if (tid == 0) { *path_len = 0; *cost = inf; }
+        return;
+    }
+    for (int i = tid; i < 2 * 256; i += (int)blockDim.x) delta[i] = inf;
+    if (tid < 4) failw[tid] = 0;
+    if (tid < 16) wrec[tid] = 0.0;                                 // off_0 = 0: delta_0 == dlb_0
+    __syncthreads();
+    if (col) delta[k] = rec[k].td;                                 // td of row 0 (+inf for an unusable unit)
+    // Loader: the records of batch j (steps j BS + 1 .. j BS + BS) are consecutive in global memory and go to
+    // ring slot j % 3 by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes to M0 + 16 lane, no registers).
+    // Inline asm: the compiler then neither counts these loads nor drains them at barriers and LDS reads;
+    // the loader waits for them itself (vmcnt(0) at the last step of a batch, with ONE batch outstanding).
+    const u32x4 *const rsrc = reinterpret_cast<const u32x4 *>(rec);
+    const int64_t total_pieces = T * (int64_t)K * 4;
+    const unsigned ring_lds = (unsigned)(size_t)ring;              // LDS byte offset of the ring
+    auto dma_batch = [&](int64_t j) {
+        const int64_t base = (j * BS + 1) * (int64_t)K * 4;
+        const unsigned dst0 = ring_lds + (unsigned)(j % 3) * (unsigned)slot_pieces * 16u;
+        for (int i = 0; i < slot_pieces; i += 64) {
+            int64_t pc = base + i + lane;
+            if (i + lane >= pieces || pc >= total_pieces) pc = 0;  // padding of the slot / beyond the utterance: never read
+            const u32x4 *src = rsrc + pc;
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(dst0 + (unsigned)i * 16u);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
+        }
+    };
+    if (loader) {
+        dma_batch(0); dma_batch(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    double off = 0.0;                                              // min over the columns of delta_{t-1} - d~_{t-1}
+    for (int64_t t = 1; t < T; ++t) {
+        const int64_t bidx = (t - 1) / BS;                         // batch of this step
+        const int sin = (int)((t - 1) % BS);
+        double best = inf, d = inf, diff = inf, td = inf, lbv = inf;
+        int arg = 0;
+        bool fail = false;
+        const double *dprev = delta + ((t - 1) & 1) * 256;
+        double *dcur = delta + (t & 1) * 256;
+        double *wr = wrec + (t & 1) * 8;
+        if (loader) {
+            if (sin == BS - 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // batch bidx + 1 has landed (issued BS steps ago)
+                dma_batch(bidx + 2);                               // into the slot batch bidx - 1 has left
+            }
+        } else {
+            // this step's record
+            const u32x4 *rp = ring + (size_t)(bidx % 3) * slot_pieces + (size_t)sin * K * 4 + (size_t)(col ? k : 0) * 4;
+            const u32x4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+            auto f64 = [](unsigned int lo, unsigned int hi) { return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32)); };
+            td = f64(q0[0], q0[1]);
+            const double xv = f64(q0[2], q0[3]);
+            lbv = f64(q1[0], q1[1]);
+            double c[JF_CAP];
+            c[0] = f64(q1[2], q1[3]);
+            c[1] = f64(q2[0], q2[1]);
+            c[2] = f64(q2[2], q2[3]);
+            c[3] = f64(q3[0], q3[1]);
+            const unsigned int ix = q3[2];
+            const int n_raw = (int)(q3[3] & 0xffu);
+            const int n = n_raw > JF_CAP ? JF_CAP : n_raw;
+#pragma unroll
+            for (int j = 0; j < JF_CAP; ++j) {                     // predicated, no branches
+                const int p = (int)((ix >> (8 * j)) & 0xffu);
+                double tot = __dadd_rn(dprev[p], c[j]);
+                tot = (j < n) ? tot : inf;
+                const bool take = tot < best || (tot == best && p < arg && j < n);
+                best = take ? tot : best;
+                arg = take ? p : arg;
+            }
+            // proof that no predecessor outside the set wins or ties (strict, with room for the roundings)
+            const bool usable = td < inf;
+            bool ok = true;
+            if (n_raw > JF_CAP) ok = false;
+            else if (xv < inf) {
+                const double bound = xv + off - 1e-12 * (fabs(xv) + fabs(off));
+                ok = (off < inf) && (bound > best);
+            }   // xv == inf: every predecessor with a finite lower-bound total is in the set
+            fail = col && usable && !ok;
+            if (col) fail_s[k] = fail ? 1 : 0;
+            d = (col && usable) ? __dadd_rn(td, best) : inf;
+            if (col) dcur[k] = d;
+            diff = (col && d < inf) ? __dsub_rn(d, lbv) : inf;
+            const double wm = jf_wave_min(diff);
+            const bool wfail = __ballot(fail) != 0ull;
+            if (lane == 0) { wr[2 * wave] = wm; wr[2 * wave + 1] = wfail ? 1.0 : 0.0; }
+        }
+        __syncthreads();
+        bool anyfail = false;
+        off = inf;
+        for (int w = 0; w < ncw; ++w) {
+            const double o = wr[2 * w];
+            off = o < off ? o : off;
+            anyfail = anyfail || (wr[2 * w + 1] != 0.0);
+        }
+        if (anyfail) {                                             // rare; every wavefront takes the same barriers
+            if (fail) { rbest[k] = best; rarg[k] = arg; }
+            __syncthreads();
+            int n_failed = 0, n_exact = 0;
+            if (!loader) {
+                for (int kf = 0; kf < K; ++kf) {
+                    if (!fail_s[kf]) continue;                         // uniform (LDS)
+                    if ((n_failed++ % ncw) != wave) continue;          // wave-uniform
+                    const int64_t b = cand[t * K + kf];
+                    const double bS = rbest[kf];
+                    double lb = bS;
+                    int la = rarg[kf];
+                    const float *jcol = Jlo + (t - 1) * (int64_t)K * K + kf;
+                    for (int p = lane; p < K; p += 64) {
+                        const double dp = dprev[p];
+                        const float lo = jcol[(int64_t)p * K];
+                        if (dp < inf && lo < __builtin_inff() && __dadd_rn(dp, (double)lo) <= bS) {
+                            const int64_t a = cand[(t - 1) * K + p];
+                            const double tot = __dadd_rn(dp, jf_exact_cost(JC_unw, Jp, Dj, wj, a, b));
+                            ++n_exact;
+                            if (tot < lb || (tot == lb && p < la)) { lb = tot; la = p; }
+                        }
+                    }
+#pragma unroll
+                    for (int m = 1; m <= 32; m <<= 1) {
+                        const double ob = __shfl_xor(lb, m, 64);
+                        const int oa = __shfl_xor(la, m, 64);
+                        if (ob < lb || (ob == lb && oa < la)) { lb = ob; la = oa; }
+                    }
+                    if (lane == 0) { rbest[kf] = lb; rarg[kf] = la; }
+                }
+            }
+            __syncthreads();
+            if (!loader) {
+                if (fail) {
+                    best = rbest[k]; arg = rarg[k];
+                    d = __dadd_rn(td, best);
+                    dcur[k] = d;
+                    diff = d < inf ? __dsub_rn(d, lbv) : inf;
+                }
+                const double wm = jf_wave_min(diff);
+                if (lane == 0) wr[2 * wave] = wm;
+                if (stats) {
+                    n_exact += __shfl_xor(n_exact, 1, 64); n_exact += __shfl_xor(n_exact, 2, 64); n_exact += __shfl_xor(n_exact, 4, 64);
+                    n_exact += __shfl_xor(n_exact, 8, 64); n_exact += __shfl_xor(n_exact, 16, 64); n_exact += __shfl_xor(n_exact, 32, 64);
+                    if (lane == 0 && n_exact) atomicAdd(&stats[2], (unsigned long long)n_exact);
+                    if (tid == 0) { atomicAdd(&stats[0], (unsigned long long)n_failed); atomicAdd(&stats[1], 1ull); }
+                }
+            }
+            __syncthreads();
+            off = inf;
+            for (int w = 0; w < ncw; ++w) { const double o = wr[2 * w]; off = o < off ? o : off; }
+        }
+        if (col) {
+            if constexpr (BPL) bp_lds[t * K + k] = (unsigned char)arg;
+            else bp_global[t * K + k] = (unsigned char)arg;
+        }
+    }
+    __syncthreads();
+
+    const double *dlast = delta + ((T - 1) & 1) * 256;
+    if (tid == 0) {
+        double best = inf;
+        int slot = 0;
+        for (int kk = 0; kk < K; ++kk)
+            if (dlast[kk] < best) { best = dlast[kk]; slot = kk; }
+        if (best == inf) { *path_len = 0; *cost = inf; *final_slot_p = -1; }
+        else { *path_len = T; *cost = best; *final_slot_p = slot; }
+    }
+    if (!BPL) __threadfence();
+    __syncthreads();
+    // back-trace: one thread walks the back-pointers (LDS when they fit), then ALL threads fetch the unit ids
+    // in parallel (one dependent global load per step would cost a memory round trip each)
+    if (*final_slot_p >= 0) {
+        if constexpr (BPL) {
+            unsigned char *slots = reinterpret_cast<unsigned char *>(ring);       // the ring is free now (T <= its size is checked by the launcher)
+            if (tid == 0) {
+                int slot = *final_slot_p;
+                for (int64_t t = T - 1; t >= 0; --t) {
+                    slots[t] = (unsigned char)slot;
+                    if (t > 0) slot = bp_lds[t * K + slot];
+                }
+            }
+            __syncthreads();
+            for (int64_t t = tid; t < T; t += (int)blockDim.x) path[t] = cand[t * K + slots[t]];
+        } else if (tid == 0) {
+            int slot = *final_slot_p;
+            for (int64_t t = T - 1; t >= 0; --t) {
+                path[t] = cand[t * K + slot];
+                if (t > 0) slot = bp_global[t * K + slot];
+            }
+        }
+    }
+}
+
+void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jlo, const float *JC_unw, int Jp, int Dj,
+                           const double *wj, const int64_t *off, int n_utts, int first_utt, int K, int64_t n_units,
+                           unsigned char *bp_global, int64_t *path, int64_t *path_len, double *cost,
+                           unsigned long long *stats, hipStream_t s)
+{
+    for (int u0 = 0; u0 < n_utts; u0 += DpBatch::MAX) {
+        const int n = (n_utts - u0 < DpBatch::MAX) ? n_utts - u0 : DpBatch::MAX;
+        DpBatch batch;
+        int64_t T = 0;
+        for (int i = 0; i <= n; ++i) batch.off[i] = off[u0 + i];
+        for (int i = 0; i < n; ++i) T = (off[u0 + i + 1] - off[u0 + i] > T) ? off[u0 + i + 1] - off[u0 + i] : T;
+        batch.first = first_utt + u0;
+        const int nth = 64 * 5;                                    // four compute wavefronts (refinement: one per failing column) + the loader
+        const int bs = K <= 104 ? 4 : 2;                           // steps per loader batch (registers: bs K / 16 per lane)
+        const size_t slot_bytes = (((size_t)bs * K * 4 + 63) & ~(size_t)63) * 16;
+        const size_t base = (size_t)(3 * 256 + 16) * 8 + 16 + 256 * 4 + 256 + 3 * slot_bytes;
+        const size_t bp_bytes = (size_t)T * K;
+        const bool bp_in_lds = base + bp_bytes + 64 <= 150 * 1024 && (size_t)T <= 3 * slot_bytes;
+        const size_t shmem = base + (bp_in_lds ? bp_bytes : 0);
+#define SNK_SP(BS_, BPL_)                                                                                         \
+    {                                                                                                             \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&viterbi_sparse_kernel<BS_, BPL_>),                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));                   \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        hipLaunchKernelGGL((viterbi_sparse_kernel<BS_, BPL_>), dim3(n), dim3(nth), shmem, s, cand,                \
+                           reinterpret_cast<const JfRecord *>(rec), Jlo, JC_unw, Jp, Dj, wj, batch, K, n_units,   \
+                           bp_global, path, path_len, cost, stats);                                               \
+    }
+        if (bs == 4) { if (bp_in_lds) SNK_SP(4, true) else SNK_SP(4, false) }
+        else { if (bp_in_lds) SNK_SP(2, true) else SNK_SP(2, false) }
+#undef SNK_SP
+    }
+}
+
+}  // namespace snk

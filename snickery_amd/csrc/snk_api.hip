@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -43,12 +44,13 @@ static int fail(const char *fmt, ...)
 // ---------------------------------------------------------------------------
 enum TimerId {
     TM_H2D = 0, TM_PREP, TM_KNN_MINIMA, TM_KNN_THRESHOLD, TM_KNN_FILTER, TM_KNN_BUCKET, TM_KNN_FINALIZE,
-    TM_JOIN, TM_VITERBI_DP, TM_D2H, TM_GREEDY_TARGET, TM_GREEDY_STEPS, TM_WEIGHTS, TM_MERGE, TM_COUNT
+    TM_JOIN, TM_VITERBI_DP, TM_D2H, TM_GREEDY_TARGET, TM_GREEDY_STEPS, TM_WEIGHTS, TM_MERGE, TM_JOIN_LB, TM_DP_LB,
+    TM_JOIN_SPARSE, TM_DP_SPARSE, TM_COUNT
 };
 static const char *kTimerNames[TM_COUNT] = {
     "h2d_queries", "prepare_queries", "knn_minima", "knn_threshold", "knn_filter", "knn_bucket", "knn_finalize",
     "join_costs", "viterbi_dp", "d2h_results", "greedy_target_gemm", "greedy_steps", "set_weights",
-    "merge_topk"};
+    "merge_topk", "join_lower_bounds", "viterbi_lower_bound", "join_exact_sparse", "viterbi_sparse"};
 
 struct DevBuf {
     void *p = nullptr;
@@ -88,6 +90,7 @@ struct EvPair { hipEvent_t a, b; int id; };
 
 struct UttSlot {      // per in-flight utterance workspace (batch pipeline uses two)
     DevBuf cand, tdist, J, bp, path, plen, cost;
+    DevBuf Jlo, scale, sets, cex;                   // sparse Viterbi path (joinfast_kernels.hip)
     hipEvent_t knn_done = nullptr, vit_done = nullptr;
     bool vit_recorded = false;          // a recursion was queued on this workspace (its event is valid)
 };
@@ -152,6 +155,9 @@ struct snk_engine {
     int n_cus = 256;
     int reserved_cus = 2;
     int batch_rows = 8192;     // rows per K-NN call of the batch entry points (utterances are grouped)
+    int viterbi_mode = 1;      // 1: f32 lower bounds on the matrix pipe + sparse exact recursion; 0: dense exact join + recursion
+    double join_beta = 5e-4;   // pass-2 margin in units of the step's largest centred norm (speed only, never the result)
+    DevBuf vstats;             // [0] cells refined, [1] steps with a refinement, [2] exact costs computed there
     int pool_chunk_limit = 0;  // test hook: cap of the entry pool (chunks) in every attempt; 0 = none
     int pool_chunks = 4096;    // entry pool: 4096 chunks x 2048 entries x 16 B = 128 MiB      // left free by the persistent K-NN sweep for Viterbi DP blocks
     int last_retries = 0;
@@ -228,6 +234,7 @@ static int staged_d2h(snk_engine *h, hipStream_t st, const D2HPart *parts, int n
 
 static int no_batch_in_flight(snk_engine *h, const char *who);
 static int create_streams(snk_engine *h);
+static bool use_sparse_viterbi(const snk_engine *h, int K);
 static int roundup(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); }
 #define SNK_KNN_MAX_ROWS 8192       // rows of one K-NN call (batch_rows is capped to it)
 
@@ -295,7 +302,7 @@ int snk_destroy(snk_handle h)
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     collect_timers(h);
-    h->tmask.release(); h->mcand.release(); h->mdist.release();
+    h->tmask.release(); h->mcand.release(); h->mdist.release(); h->vstats.release();
     DevBuf *bufs[] = {&h->F_unw, &h->JC_unw, &h->Fw, &h->fnorm, &h->JCw, &h->wt, &h->wj, &h->unit_class,
                       &h->Qraw, &h->Qp, &h->Qf, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
@@ -310,7 +317,7 @@ int snk_destroy(snk_handle h)
       for (auto *b : fb) b->release(); }
     for (int i = 0; i < 8; ++i) {
         UttSlot &s = h->slot[i];
-        DevBuf *sb[] = {&s.cand, &s.tdist, &s.J, &s.bp, &s.path, &s.plen, &s.cost};
+        DevBuf *sb[] = {&s.cand, &s.tdist, &s.J, &s.bp, &s.path, &s.plen, &s.cost, &s.Jlo, &s.scale, &s.sets, &s.cex};
         for (auto *b : sb) b->release();
         if (s.knn_done) (void)hipEventDestroy(s.knn_done);
         if (s.vit_done) (void)hipEventDestroy(s.vit_done);
@@ -820,7 +827,7 @@ static int slot_ensure(snk_engine *h, UttSlot &s, int64_t T, int K)
 {
     CHK(s.cand.ensure((size_t)T * K * sizeof(int64_t)));
     CHK(s.tdist.ensure((size_t)T * K * sizeof(double)));
-    CHK(s.J.ensure((size_t)(T > 1 ? T - 1 : 1) * K * K * sizeof(double)));
+    if (!use_sparse_viterbi(h, K)) CHK(s.J.ensure((size_t)(T > 1 ? T - 1 : 1) * K * K * sizeof(double)));
     CHK(s.bp.ensure((size_t)T * K));
     CHK(s.path.ensure((size_t)T * sizeof(int64_t)));
     CHK(s.plen.ensure(sizeof(int64_t)));
@@ -909,9 +916,69 @@ static int64_t join_units(snk_engine *h)
     return h->Njc - 1;
 }
 
+static bool use_sparse_viterbi(const snk_engine *h, int K)
+{
+    return h->viterbi_mode == 1 && join_lb_supported(h->Dj, K);
+}
+
+static int sparse_ensure(snk_engine *h, UttSlot &s, int64_t rows, int K)
+{
+    CHK(s.Jlo.ensure((size_t)(rows > 1 ? rows - 1 : 1) * K * K * sizeof(float)));
+    CHK(s.scale.ensure((size_t)rows * sizeof(float)));
+    CHK(s.sets.ensure((size_t)rows * K * 16));
+    CHK(s.cex.ensure((size_t)rows * K * join_record_bytes() + 4096));
+    CHK(s.bp.ensure((size_t)rows * K));
+    if (!h->vstats.p) {
+        CHK(h->vstats.ensure(128 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(h->vstats.p, 0, 128 * sizeof(unsigned long long)));
+    }
+    return 0;
+}
+
+// Passes 1..4 of joinfast_kernels.hip over `rows` candidate rows holding n_utts utterances (off: n_utts + 1
+// row offsets).  Pass 1 runs on `main` (the whole chip, in parallel over the rows); the three per-utterance
+// passes on `side` behind `knn_done` when the two streams differ.
+static int viterbi_sparse_rows(snk_engine *h, UttSlot &s, const int64_t *cand, const double *tdist, int64_t rows,
+                               const int64_t *off, int n_utts, int first_utt, int K, hipStream_t main, hipStream_t side,
+                               int64_t *path, int64_t *plen, double *cost)
+{
+    const float *JC = h->JC_unw.as<float>();
+    const double *wj = h->wj.as<double>();
+    {
+        StageTimer t(h, main, TM_JOIN_LB);
+        launch_join_lb(JC, h->Jp, h->Dj, wj, join_units(h), cand, rows, K, s.Jlo.as<float>(), s.scale.as<float>(), main);
+    }
+    if (side != main) {
+        HIPCHK(hipEventRecord(s.knn_done, main));
+        HIPCHK(hipStreamWaitEvent(side, s.knn_done, 0));
+    }
+    {
+        StageTimer t(h, side, TM_DP_LB);
+        launch_viterbi_lb(cand, tdist, s.Jlo.as<float>(), s.scale.as<float>(), off, n_utts, K, join_units(h),
+                          (float)h->join_beta, s.sets.p, side);
+    }
+    {
+        StageTimer t(h, side, TM_JOIN_SPARSE);
+        launch_join_exact_sparse(JC, h->Jp, h->Dj, wj, join_units(h), cand, tdist, rows, K, s.sets.p, s.cex.p, side);
+    }
+    {
+        StageTimer t(h, side, TM_DP_SPARSE);
+        launch_viterbi_sparse(cand, s.cex.p, s.Jlo.as<float>(), JC, h->Jp, h->Dj, wj, off, n_utts, first_utt, K,
+                              join_units(h), s.bp.as<unsigned char>(), path, plen, cost,
+                              h->vstats.as<unsigned long long>(), side);
+    }
+    return 0;
+}
+
 static int viterbi_device(snk_engine *h, UttSlot &s, int64_t T, int K, hipStream_t st)
 {
     if (K > 208) return fail("viterbi: n_candidates=%d > 208 not supported", K);
+    if (use_sparse_viterbi(h, K)) {
+        CHK(sparse_ensure(h, s, T, K));
+        const int64_t off[2] = {0, T};
+        return viterbi_sparse_rows(h, s, s.cand.as<int64_t>(), s.tdist.as<double>(), T, off, 1, 0, K, st, st,
+                                   s.path.as<int64_t>(), s.plen.as<int64_t>(), s.cost.as<double>());
+    }
     {
         StageTimer t(h, st, TM_JOIN);
         launch_join_costs(h->JCw.as<double>(), h->Djpad, h->Dj, join_units(h), s.cand.as<int64_t>(), T, K,
@@ -936,6 +1003,7 @@ int snk_join_costs(snk_handle h, const int64_t *cand, int64_t T, int K, double *
     if (K < 1 || K > 208) return fail("snk_join_costs: K=%d outside 1..208", K);
     UttSlot &s = h->slot[0];
     CHK(slot_ensure(h, s, T, K));
+    CHK(s.J.ensure((size_t)(T - 1) * K * K * sizeof(double)));
     HIPCHK(hipMemcpyAsync(s.cand.p, cand, (size_t)T * K * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
     {
         StageTimer t(h, h->stream, TM_JOIN);
@@ -1035,6 +1103,16 @@ static int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u
     // workspace reuse: the join costs of this group overwrite what the last recursion queued on this
     // workspace reads (an earlier group of this batch, or the tail of the batch submitted before)
     if (s.vit_recorded) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));
+    if (use_sparse_viterbi(h, K)) {
+        CHK(sparse_ensure(h, s, rows, K));
+        std::vector<int64_t> off((size_t)(u1 - u0) + 1);
+        for (int u = u0; u <= u1; ++u) off[(size_t)(u - u0)] = row_offsets[u] - r0;
+        CHK(viterbi_sparse_rows(h, s, cand_all + r0 * K, tdist_all + r0 * K, rows, off.data(), u1 - u0, u0, K, h->stream, dps,
+                                res_path + r0, res_plen, res_cost));
+        if (side_stream) { HIPCHK(hipEventRecord(s.vit_done, dps)); s.vit_recorded = true; }
+        else s.vit_recorded = false;
+        return 0;
+    }
     CHK(s.J.ensure((size_t)(rows > 1 ? rows - 1 : 1) * K * K * sizeof(double)));
     CHK(s.bp.ensure((size_t)rows * K));
     {
@@ -1665,6 +1743,13 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "batch_rows")) {
         if (value < 0 || value > 8192) return fail("batch_rows must be in 0..8192 (0: one K-NN call per utterance)");
         h->batch_rows = (int)value;
+    } else if (!strcmp(name, "viterbi_mode")) {
+        if (value != 0.0 && value != 1.0) return fail("viterbi_mode must be 0 (dense exact join + recursion) or 1 (lower bounds + sparse exact recursion)");
+        CHK(no_batch_in_flight(h, "snk_set_option(viterbi_mode)"));
+        h->viterbi_mode = (int)value;
+    } else if (!strcmp(name, "join_beta")) {
+        if (!(value >= 0.0 && value <= 10.0)) return fail("join_beta must be in 0..10");
+        h->join_beta = value;
     } else if (!strcmp(name, "pool_chunk_limit")) {
         if (value < 0 || value > 1e6) return fail("pool_chunk_limit must be in 0..1e6");
         h->pool_chunk_limit = (int)value;
@@ -1688,6 +1773,12 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "exact_row_fallbacks")) *out = h->exact_row_fallbacks;
     else if (!strcmp(name, "batch_redos")) *out = h->batch_redos;
     else if (!strcmp(name, "pool_overflows")) *out = h->pool_overflows;
+    else if (!strcmp(name, "viterbi_mode")) *out = h->viterbi_mode;
+    else if (!strcmp(name, "dense_cells") || !strcmp(name, "dense_steps") || !strcmp(name, "dense_exact_costs") || !strcmp(name, "set_overflows")) {
+        unsigned long long v[4] = {0, 0, 0, 0};
+        if (h->vstats.p) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipMemcpy(v, h->vstats.p, sizeof(v), hipMemcpyDeviceToHost)); }
+        *out = (double)v[!strcmp(name, "dense_steps") ? 1 : (!strcmp(name, "dense_exact_costs") ? 2 : (!strcmp(name, "set_overflows") ? 3 : 0))];
+    }
     else if (!strcmp(name, "f16_ready")) *out = h->f16_ready ? 1 : 0;
     else if (!strcmp(name, "f16_fallbacks")) *out = h->f16_fallbacks;
     else if (!strcmp(name, "last_f16_status")) *out = h->last_f16_status;

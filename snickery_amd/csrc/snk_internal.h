@@ -99,6 +99,20 @@ void launch_viterbi_dp(const int64_t *cand, const double *tdist, const double *J
                        int64_t T, int K, int64_t n_units, unsigned char *bp_global,
                        int64_t *path, int64_t *path_len, double *cost, hipStream_t s);
 
+// ---- join lower bounds + sparse exact recursion (joinfast_kernels.hip) ------------------------
+bool join_lb_supported(int Dj, int K);
+void launch_join_lb(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
+                    int64_t R, int K, float *Jlo, float *scale, hipStream_t s);
+void launch_viterbi_lb(const int64_t *cand, const double *tdist, const float *Jlo, const float *scale, const int64_t *off,
+                       int n_utts, int K, int64_t n_units, float beta, void *sets, hipStream_t s);
+size_t join_record_bytes();
+void launch_join_exact_sparse(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
+                              const double *tdist, int64_t R, int K, const void *sets, void *rec, hipStream_t s);
+void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jlo, const float *JC_unw, int Jp, int Dj,
+                           const double *wj, const int64_t *off, int n_utts, int first_utt, int K, int64_t n_units,
+                           unsigned char *bp_global, int64_t *path, int64_t *path_len, double *cost,
+                           unsigned long long *stats, hipStream_t s);
+
 // ---- greedy ---------------------------------------------------------------
 struct GreedyLayout {
     int me, last_frame_as_target, join_split_mode;

@@ -1,0 +1,131 @@
+"""The Viterbi path that keeps the join costs off the float64 vector pipe (joinfast_kernels.hip: f32 matrix
+lower bounds, predecessor sets, exact float64 costs for the sets only, verified exact recursion) against
+the dense exact path (viterbi_kernels.hip) and the oracle: same path, same cost, bit for bit -- whatever
+the margin, including margins so small that every column is recomputed densely."""
+import numpy as np
+import pytest
+
+import snk_oracle as o
+import snk_oracle_c as oc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def engine():
+    import snickery_amd
+    e = snickery_amd.HipSearchEngine(0)
+    yield e
+    e.set_option('viterbi_mode', 1)
+    e.close()
+
+
+def _db(N, Dt, Dj, seed):
+    F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed)
+    rng = np.random.RandomState(seed + 100)
+    wt = 0.2 + rng.rand(Dt)
+    wj = 0.05 + 0.2 * rng.rand(Dj)
+    return F_unw, JC_unw, wt, wj
+
+
+@pytest.mark.parametrize('N,Dj,T,K', [(4000, 151, 40, 12), (20000, 302, 75, 50), (20000, 151, 60, 100),
+                                      (30000, 40, 33, 16), (20000, 302, 30, 128), (30000, 151, 25, 200),
+                                      (5000, 7, 50, 5), (5000, 19, 20, 1), (9000, 320, 20, 64)])
+def test_sparse_equals_dense_and_oracle(engine, N, Dj, T, K):
+    F_unw, JC_unw, wt, wj = _db(N, 61, Dj, seed=N % 97 + K)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    JCw = o.weight(JC_unw, wj)
+    rng = np.random.RandomState(K)
+    # half the rows follow the database (candidates are time neighbours: tiny, nearly equal join costs),
+    # half are random frames (candidates from all over the database)
+    U = np.vstack([o.synthetic_targets(F_unw, T - T // 2, seed=5), F_unw[rng.randint(0, N, T // 2)] + rng.randn(T // 2, 61)]) * wt
+    engine.set_option('viterbi_mode', 0)
+    path0, cost0, cand, dist = engine.knn_viterbi(U, K, return_candidates=True)
+    opath, ocost = oc.viterbi(cand, dist, JCw)
+    assert path0 == opath and cost0 == ocost
+    engine.set_option('viterbi_mode', 1)
+    for beta in (5e-4, 0.0, 1.0):              # default; nothing but the minimum in the sets; overflowing sets
+        engine.set_option('join_beta', beta)
+        path1, cost1 = engine.viterbi(cand, dist)
+        assert path1 == opath and cost1 == ocost, beta
+    engine.set_option('join_beta', 5e-4)
+    p2, c2 = engine.knn_viterbi(U, K)
+    assert p2 == opath and c2 == ocost
+    paths, costs = engine.knn_viterbi_batch([U, U[:T // 2], U[:1], U[3:9]], K)
+    assert list(paths[0]) == opath and costs[0] == ocost
+    assert len(paths[2]) == 0
+
+
+def test_sparse_with_unusable_duplicate_and_padded_candidates(engine):
+    """Quinphone-style lists: duplicated ids inside a column (exact ties between predecessors: the lower
+    slot must win), -1 padding, units 0 and N-1 (no join state), a column with no usable unit."""
+    N, Dj, T, K = 3000, 151, 30, 24
+    F_unw, JC_unw, wt, wj = _db(N, 61, Dj, seed=3)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    JCw = o.weight(JC_unw, wj)
+    rng = np.random.RandomState(1)
+    base = rng.randint(1, N - 1, size=(T, K)).astype(np.int64)
+    base[:, 1] = base[:, 0]                    # duplicates
+    base[:, 5] = base[:, 2]
+    base[4, 7:] = -1
+    base[9, 0] = 0
+    base[9, 3] = N - 1
+    base[12:14, :] = np.arange(100, 100 + K)   # natural successors between rows 12 -> 13 shifted by one
+    base[13, :] += 1
+    dist = np.sort(rng.rand(T, K), axis=1) + 0.5
+    dist[:, 1] = dist[:, 0]
+    for mode in (0, 1):
+        engine.set_option('viterbi_mode', mode)
+        path, cost = engine.viterbi(base, dist)
+        opath, ocost = oc.viterbi(base, dist, JCw)
+        assert path == opath and cost == ocost
+    dead = base.copy()
+    dead[20, :] = -1                           # no path at all
+    for mode in (0, 1):
+        engine.set_option('viterbi_mode', mode)
+        path, cost = engine.viterbi(dead, dist)
+        assert path == [] and cost == np.inf
+    engine.set_option('viterbi_mode', 1)
+
+
+def test_long_utterances_batch_sparse_equals_dense(engine):
+    """Long utterances (the float32 lower-bound recursion shifts its values every 64 steps; pass 4's loader
+    ring wraps many times; back-pointers beyond the LDS budget) in one batch: sparse == dense, bit for bit."""
+    N, Dj, K = 300000, 302, 100
+    F_unw, JC_unw = o.synthetic_db(N, 61, Dj, seed=14)
+    wt, wj = np.full(61, 0.4), np.full(Dj, 0.05)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    rng = np.random.RandomState(15)
+    utts = [o.synthetic_targets(F_unw, T, seed=20 + i) * wt for i, T in enumerate([600, 257, 1900, 64, 65, 129])]
+    utts.append((F_unw[rng.randint(0, N, 300)] + 0.5 * rng.randn(300, 61)) * wt)      # candidates from all over the database
+    engine.set_option('viterbi_mode', 0)
+    p0, c0 = engine.knn_viterbi_batch(utts, K)
+    engine.set_option('viterbi_mode', 1)
+    for beta in (5e-4, 0.0):
+        engine.set_option('join_beta', beta)
+        p1, c1 = engine.knn_viterbi_batch(utts, K)
+        assert all(np.array_equal(a, b) for a, b in zip(p0, p1)) and np.array_equal(c0, c1), beta
+    engine.set_option('join_beta', 5e-4)
+    path, cost, cand, dist = engine.knn_viterbi(utts[2], K, return_candidates=True)
+    opath, ocost = oc.viterbi(cand, dist, o.weight(JC_unw, wj))
+    assert path == opath and cost == ocost and list(p0[2]) == opath
+
+
+def test_exact_join_costs_are_a_small_fraction(engine):
+    """Speed guard: sets + refinements together evaluate a small fraction of the K x K exact join costs."""
+    N, Dj, T, K = 200000, 302, 300, 100
+    F_unw, JC_unw = o.synthetic_db(N, 61, Dj, seed=4)
+    wt, wj = np.full(61, 0.4), np.full(Dj, 0.05)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    U = o.synthetic_targets(F_unw, T, seed=5) * wt
+    engine.set_option('viterbi_mode', 1)
+    before = engine.info('dense_exact_costs')
+    path, cost, cand, dist = engine.knn_viterbi(U, K, return_candidates=True)
+    refined = engine.info('dense_exact_costs') - before
+    opath, ocost = oc.viterbi(cand, dist, o.weight(JC_unw, wj))
+    assert path == opath and cost == ocost
+    assert refined <= 0.01 * T * K * K, refined
