@@ -51,19 +51,19 @@ def synthetic_targets(F_unw, T, seed, noise=0.3):
     return F_unw[s:s + T].astype(np.float64) + noise * rng.randn(min(T, N - s), Dt)
 
 
-def cpu_baseline(F_unw, JC_unw, wt, wj, K, sample_frames, seed):
-    """The reference's CPU formulation (oracle = test infrastructure, timed here as the
-    reported baseline only): scipy cKDTree preselection (synth_halfphone.py:379,1364), the
-    Python pair loop + numpy gather join costs (:3251-3301), DP Viterbi.  One thread, like
-    the reference's search."""
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import scipy.spatial
-    import snk_oracle as o
-    F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
-    t0 = time.time()
-    tree = scipy.spatial.cKDTree(F, leafsize=100, compact_nodes=False, balanced_tree=False)
-    t_build = time.time() - t0
-    U = synthetic_targets(F_unw, sample_frames, seed) * wt
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _cpu_search(o, tree, E, S, U, K):
+    """One utterance through the reference's CPU formulation; returns (cand, dist, path, cost, (t_knn, t_join, t_dp, n_arcs))."""
     t0 = time.time()
     d, i = tree.query(U, k=K)
     t_knn = time.time() - t0
@@ -74,13 +74,61 @@ def cpu_baseline(F_unw, JC_unw, wt, wj, K, sample_frames, seed):
     t0 = time.time()
     path, cost = o.viterbi(cand, np.asarray(d), E, S)
     t_dp = time.time() - t0
+    return cand, np.asarray(d), path, cost, (t_knn, t_join, t_dp, len(cache))
+
+
+def cpu_baseline(F_unw, JC_unw, wt, wj, K, sample_frames, seed, all_cores=True):
+    """The reference's CPU formulation (oracle = test infrastructure, timed here as the
+    reported baseline only): scipy cKDTree preselection (synth_halfphone.py:379,1364), the
+    Python pair loop + numpy gather join costs (:3251-3301), DP Viterbi.
+    Two figures: ONE thread, like the reference's search (`value`), and every host core with one
+    process per utterance, the reference's own `-p ncores` fan-out (synth_halfphone.py:897-903;
+    `all_cores`).  Runs BEFORE the GPU is initialised (the workers are forked)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import scipy.spatial
+    import snk_oracle as o
+    F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
+    t0 = time.time()
+    tree = scipy.spatial.cKDTree(F, leafsize=100, compact_nodes=False, balanced_tree=False)
+    t_build = time.time() - t0
+    U = synthetic_targets(F_unw, sample_frames, seed) * wt
+    cand, d, path, cost, (t_knn, t_join, t_dp, n_arcs) = _cpu_search(o, tree, E, S, U, K)
     total = t_knn + t_join + t_dp
-    return {
-        'value': sample_frames / total, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+    out = {
+        'value': sample_frames / total, 'unit': 'frames/s', 'cores': 1, 'kind': 'port', 'cpu_model': _cpu_model(),
+        'host_cores': os.cpu_count(),
         'sample': '%d frames of the same workload (K=%d, full %d-unit DB): cKDTree.query %.2fs + '
                   'pair-loop join costs %.2fs (%d arcs) + DP %.2fs; tree build %.1fs not counted'
-                  % (sample_frames, K, F.shape[0], t_knn, t_join, len(cache), t_dp, t_build),
-    }, (cand, np.asarray(d), path, cost, U)
+                  % (sample_frames, K, F.shape[0], t_knn, t_join, n_arcs, t_dp, t_build),
+    }
+    if all_cores:
+        # one forked worker per utterance (the tree and the weighted matrices are shared copy-on-write);
+        # at most 64 workers: a worker's arc cache takes about 1 GB
+        P = max(1, min(os.cpu_count() or 1, 64))
+        pipes, t0 = [], time.time()
+        for w in range(P):
+            r, wfd = os.pipe()
+            pid = os.fork()
+            if pid == 0:
+                try:
+                    os.close(r)
+                    Uw = synthetic_targets(F_unw, sample_frames, seed + 1000 + w) * wt
+                    _cpu_search(o, tree, E, S, Uw, K)
+                    os.write(wfd, b'1')
+                finally:
+                    os._exit(0)
+            os.close(wfd)
+            pipes.append((pid, r))
+        done = 0
+        for pid, r in pipes:
+            done += 1 if os.read(r, 1) == b'1' else 0
+            os.close(r)
+            os.waitpid(pid, 0)
+        t_all = time.time() - t0
+        out['all_cores'] = {'value': done * sample_frames / t_all, 'unit': 'frames/s', 'cores': P,
+                            'sample': '%d utterances of %d frames, one single-threaded worker process each, side by side: %.1fs'
+                                      % (done, sample_frames, t_all)}
+    return out, (cand, d, path, cost, U)
 
 
 def main():
@@ -97,6 +145,7 @@ def main():
     ap.add_argument('--cpu-sample-frames', type=int, default=600,
                     help='frames of the CPU baseline sample (600 = one utterance of the workload, ~15 s on one core)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cpu-all-cores', action='store_true', help='skip the all-cores leg of the CPU baseline')
     ap.add_argument('--viterbi-mode', type=int, default=1, choices=(0, 1),
                     help='1: f32 matrix lower bounds + sparse exact recursion (default); 0: dense exact float64 join costs')
     ap.add_argument('--join-beta', type=float, default=None, help='margin of the predecessor sets (speed only)')
@@ -142,6 +191,11 @@ def main():
     # the batch as the C ABI takes it (one contiguous matrix + row offsets), built once: a tuning loop
     # searches the same tune set every iteration.  Every step still uploads it to the device.
     batch = snickery_amd.QueryBatch(utts)
+
+    cpu_ref = None
+    if world == 1 and not args.no_cpu_baseline:
+        # before the GPU is initialised: the all-cores figure forks its workers
+        cpu_ref = cpu_baseline(F_unw, JC_unw, wt, wj, K, args.cpu_sample_frames, seed=1, all_cores=not args.no_cpu_all_cores)
 
     eng = snickery_amd.HipSearchEngine(local_rank)       # raises without libsnkhip.so / gfx950
     eng.set_option('viterbi_mode', args.viterbi_mode)
@@ -260,12 +314,14 @@ def main():
         kname = ('knn_sweep16<filter> (v_mfma_f32_32x32x2_f32 prefilter; exact f64 re-rank in knn_finalize)'
                  if f32_mode else 'knn_sweep<filter> (v_mfma_f64_16x16x4_f64)')
         traffic = None
+        traffic_source = None
         tfile = os.path.join(ROOT, 'profiles', 'r01_traffic_f32.json' if f32_mode else 'r01_traffic.json')
         if world == 1 and N == 1048576 and Dt == 61 and os.path.isfile(tfile):
             with open(tfile) as f:
                 tj = json.load(f)
             if int(tj.get('rows_per_launch', 600)) == int(round(rows_per_launch)):
                 traffic = tj['hbm_bytes_per_launch']
+                traffic_source = os.path.relpath(tfile, ROOT) + ' (separate --pmc passes of this kernel and shape; not measured in this run)'
         achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             'metric': 'synthesised frames/sec, full-DB K=%d K-NN preselection + Viterbi' % K,
@@ -283,7 +339,7 @@ def main():
                            'db-rows/%d + all-to-all of local top-K' % S + (' x %d replica groups' % n_groups if n_groups > 1 else ''))},
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': traffic,
+                         'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_source,
                          'avg_launch_ms': avg_ms, 'launches': launches,
                          'rows_per_launch': rows_per_launch, 'flops_per_launch': flops,
                          'note': 'peak is the 2.4 GHz datasheet rate; under MFMA load this part holds '
@@ -298,8 +354,8 @@ def main():
             out['two_in_flight'] = two_in_flight
         if share_gpu:
             out['note'] = 'FUNCTIONAL TEST: all ranks share cuda:0, collectives on gloo through host memory; not a measurement'
-        if world == 1 and not args.no_cpu_baseline:
-            base, ref = cpu_baseline(F_unw, JC_unw, wt, wj, K, args.cpu_sample_frames, seed=1)
+        if cpu_ref is not None:
+            base, ref = cpu_ref
             out['cpu_baseline'] = base
             # the same sample through the HIP path must select the same units
             gp, gc, gcand, gdist = eng.knn_viterbi(ref[4], K, return_candidates=True)

@@ -138,33 +138,62 @@ def get_selection_vector(stream_list, stream_dims, truncation_values):
     return selection_vector
 
 
-def load_database(datafile):
-    """The train_simple.py / train_halfphone.py unit database as a dict of arrays.
+DATABASE_DATASETS = ['train_unit_features', 'train_unit_names', 'filenames', 'mean_target', 'std_target',
+                     'mean_join', 'std_join', 'join_contexts', 'unit_index_within_sentence_dset', 'cutpoints',
+                     'duration_monophones', 'duration_stats']
 
-    Tries h5py on the .hdf5 itself; without h5py (the default interpreter of this image has
-    none) falls back to ``<datafile>.npz`` written by tools/hdf5_to_npz.py."""
-    wanted = ['train_unit_features', 'train_unit_names', 'filenames', 'mean_target', 'std_target',
-              'mean_join', 'std_join', 'join_contexts', 'unit_index_within_sentence_dset', 'cutpoints',
-              'duration_monophones', 'duration_stats']
-    try:
-        import h5py
-    except ImportError:
-        h5py = None
-    if h5py is not None and os.path.isfile(datafile):
-        out = {}
-        with h5py.File(datafile, 'r') as f:
-            for k in wanted:
-                if k in f:
-                    out[k] = f[k][...]
-        return out
+
+def load_database(datafile):
+    """The train_simple.py / train_halfphone.py unit database as a dict of arrays, read from
+    the HDF5 file itself as the reference does (synth_simple.py:72-106): with h5py where it is installed,
+    else through libhdf5's C API (snickery_amd.hdf5_io: the target image ships the library but no h5py),
+    else from the ``<datafile>.npz`` sidecar of an older writer."""
+    if os.path.isfile(datafile):
+        try:
+            import h5py
+        except ImportError:
+            h5py = None
+        if h5py is not None:
+            out = {}
+            with h5py.File(datafile, 'r') as f:
+                for k in DATABASE_DATASETS:
+                    if k in f:
+                        out[k] = f[k][...]
+            return out
+        from . import hdf5_io
+        if hdf5_io.available():
+            return hdf5_io.read_datasets(datafile, DATABASE_DATASETS)
     npz = datafile + '.npz'
     if os.path.isfile(npz):
         z = np.load(npz, allow_pickle=False)
         return dict((k, z[k]) for k in z.files)
     if os.path.isfile(datafile):
-        raise RuntimeError('%s exists but this interpreter has no h5py; convert it once with\n'
-                           '  /opt/conda/bin/python3.9 tools/hdf5_to_npz.py %s' % (datafile, datafile))
+        raise RuntimeError('%s exists but this interpreter has neither h5py nor a loadable libhdf5 (set SNK_LIBHDF5); '
+                           'convert it once with\n  /opt/conda/bin/python3.9 tools/hdf5_to_npz.py %s' % (datafile, datafile))
     raise RuntimeError('data: \n   %s   \ndoes not exist -- try other?' % (datafile))
+
+
+def store_database(datafile, db):
+    """Write a unit database as the reference's HDF5 (train_simple.py:95-149: one root-level dataset per
+    array, first dimension resizable): h5py where installed, else libhdf5 through ctypes; the ``.npz``
+    sidecar only where neither exists.  Returns the path written."""
+    try:
+        import h5py
+    except ImportError:
+        h5py = None
+    if h5py is not None:
+        with h5py.File(datafile, 'w') as f:
+            for key, arr in db.items():
+                kind = '|S50' if arr.dtype.kind == 'S' else ('i' if arr.dtype.kind == 'i' else 'f')
+                dset = f.create_dataset(key, arr.shape, dtype=kind, track_times=False)
+                dset[...] = arr
+        return datafile
+    from . import hdf5_io
+    if hdf5_io.available():
+        hdf5_io.write_datasets(datafile, db)
+        return datafile
+    np.savez(datafile + '.npz', **db)
+    return datafile + '.npz'
 
 
 # --------------------------------------------------------------------------

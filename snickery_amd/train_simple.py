@@ -5,8 +5,8 @@
 including the (1, D) shape of the std vectors and the extra first row of ``join_contexts`` (the first
 utterance's first frame doubles as initial history, :215-217).
 
-The arrays are always written to ``<database>.hdf5.npz`` (what ``hostprep.load_database`` reads when
-the interpreter has no h5py) and, when h5py is importable, to the HDF5 file itself.
+The arrays are written to the HDF5 file itself, as the reference does (h5py where installed, else
+libhdf5 through ctypes: ``snickery_amd.hdf5_io``); only an image with neither gets the ``.npz`` sidecar.
 
     python -m snickery_amd.train_simple -c voice.cfg [-X]
 """
@@ -120,18 +120,8 @@ def main_work(config, overwrite_existing_data=False, report=print):
             os.remove(p)
     os.makedirs(os.path.dirname(database_fname), exist_ok=True)
     db = build_database(config, report=report)
-    np.savez(database_fname + '.npz', **db)
-    try:
-        import h5py
-    except ImportError:
-        h5py = None
-    if h5py is not None:
-        with h5py.File(database_fname, 'w') as f:
-            for key, arr in db.items():
-                kind = '|S50' if arr.dtype.kind == 'S' else ('i' if arr.dtype.kind == 'i' else 'f')
-                dset = f.create_dataset(key, arr.shape, dtype=kind, track_times=False)
-                dset[...] = arr
-    report('Stored training data for %s units to %s' % (db['train_unit_features'].shape[0], database_fname))
+    written = hp.store_database(database_fname, db)
+    report('Stored training data for %s units to %s' % (db['train_unit_features'].shape[0], written))
     return database_fname
 
 

@@ -198,3 +198,48 @@ def test_halfphone_database_writer_reproduces_reference_database(tmp_path, tag, 
         assert hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest() == str(ref['%s_%s_sha256' % (tag, key)]), key
     with pytest.raises(SystemExit):                       # existing data is protected (train_halfphone.py:78-82)
         train_halfphone.main_work(config, report=lambda *_: None)
+
+
+def test_hdf5_voice_without_h5py(tmp_path):
+    """The reference keeps its voice in HDF5 (train_simple.py:95-149, read back at synth_simple.py:72-106).
+    This interpreter has no h5py: the file is read and written through libhdf5's C API
+    (snickery_amd.hdf5_io).  The database writers above therefore produced REAL HDF5 files -- checked here
+    by their signature -- whose datasets come back with the reference's bytes; and a file written the
+    reference's way (h5py: resizable, chunked, fixed-length strings) reads the same."""
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import voice_fixture
+    from snickery_amd import hdf5_io, hostprep as hp, train_halfphone
+    if not hdf5_io.available():
+        pytest.skip('no libhdf5 in this image')
+    data = os.path.join(str(tmp_path), 'corpus')
+    voice_fixture.write_halfphone_corpus(data)
+    cfgfile = voice_fixture.halfphone_corpus_config(os.path.join(str(tmp_path), 'hp.cfg'), os.path.join(str(tmp_path), 'work'),
+                                                    data, 'epoch', False)
+    dbfile = train_halfphone.main_work(hp.load_config(cfgfile), report=lambda *_: None)
+    assert os.path.isfile(dbfile) and not os.path.isfile(dbfile + '.npz')         # the HDF5 itself, no sidecar
+    with open(dbfile, 'rb') as f:
+        assert f.read(8) == b'\x89HDF\r\n\x1a\n'
+    db = hp.load_database(dbfile)
+    again = str(tmp_path / 'again.hdf5')
+    hdf5_io.write_datasets(again, db)
+    back = hdf5_io.read_datasets(again)
+    assert sorted(back) == sorted(db)
+    for k in db:
+        assert back[k].dtype == db[k].dtype and np.array_equal(back[k], db[k]), k
+    # a file written the reference's way (h5py, maxshape=(None, d)), when an interpreter with h5py is around
+    conda = '/opt/conda/bin/python3.9'
+    if os.path.exists(conda):
+        other = str(tmp_path / 'ref_style.hdf5')
+        code = ("import h5py, numpy as np\n"
+                "f = h5py.File(%r, 'w')\n"
+                "d = f.create_dataset('train_unit_features', (7, 5), maxshape=(None, 5), dtype='f'); d[:, :] = np.arange(35).reshape(7, 5)\n"
+                "n = f.create_dataset('train_unit_names', (7,), maxshape=(None,), dtype='|S50'); n[:] = np.array(['a/b_%%d' %% i for i in range(7)]).astype('S50')\n"
+                "c = f.create_dataset('cutpoints', (7, 3), maxshape=(None, 3), dtype='i'); c[:, :] = np.arange(21).reshape(7, 3)\n"
+                "f.close()\n" % other)
+        if subprocess.run([conda, '-c', code]).returncode == 0:
+            got = hp.load_database(other)
+            assert np.array_equal(got['train_unit_features'], np.arange(35, dtype=np.float32).reshape(7, 5))
+            assert got['train_unit_names'].dtype == np.dtype('S50') and got['train_unit_names'][3] == b'a/b_3'
+            assert got['cutpoints'].dtype == np.int32 and got['cutpoints'][6, 2] == 20

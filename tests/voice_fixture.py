@@ -62,7 +62,8 @@ def build_voice(tmpdir, golden, greedy=True, multiepoch=6, n_candidates=12, extr
               filenames=np.array(['arctic_a%04d' % (1 + i // 150) for i in range(N)]).astype('S50'),
               unit_index_within_sentence_dset=(np.arange(N) % 150).astype(np.int32))
     db.update(db_override or {})
-    np.savez(hp.get_data_dump_name(config) + '.npz', **db)
+    os.makedirs(os.path.dirname(hp.get_data_dump_name(config)), exist_ok=True)
+    hp.store_database(hp.get_data_dump_name(config), db)      # the reference's HDF5 (h5py or libhdf5), else the .npz sidecar
     return cfgfile, config
 
 
