@@ -14,7 +14,6 @@ pass (no index rebuild) and a Viterbi configuration hands the whole tune set to
 
     python -m snickery_amd.balance_stream_weights -c voice.cfg
 """
-import copy
 from argparse import ArgumentParser
 
 import numpy as np
@@ -32,6 +31,92 @@ def mean_nonzero_contributions(join_scores, target_scores):
     return np.array(means)
 
 
+class SignStepState(object):
+    """Per-weight sign-step rule of the reference's tuning loop (balance_stream_weights.py:143-163): every
+    weight moves against the sign of its error by its own step size, which is multiplied by `grow` while
+    the sign repeats, by `shrink` when it flips, and kept inside [step_min, step_max].  One vectorised
+    update per iteration; the object also keeps the best weights seen and the stall counter that ends the
+    search (:126-141)."""
+
+    def __init__(self, n, step0, grow, shrink, step_min, step_max, floor):
+        self.w = np.ones(n)                      # unweighted streams to begin with (:66)
+        self.step = np.full(n, float(step0))
+        self.last_sign = np.ones(n)
+        self.grow, self.shrink, self.lo, self.hi, self.floor = grow, shrink, step_min, step_max, floor
+        self.best_w, self.best_loss, self.prev_loss, self.stalled = self.w.copy(), np.inf, np.inf, 0
+
+    def observe(self, loss):
+        """Book-keeping of one measured loss; returns the number of iterations without improvement."""
+        self.stalled = 0 if loss < self.prev_loss else self.stalled + 1
+        if loss < self.best_loss:
+            self.best_loss, self.best_w = loss, self.w.copy()
+        return self.stalled
+
+    def advance(self, errors, loss):
+        """Moves the weights one step against `errors`; returns the applied update."""
+        sign = np.sign(-errors)
+        agreement = sign * self.last_sign
+        self.step = np.clip(self.step * np.where(agreement > 0, self.grow, np.where(agreement < 0, self.shrink, 1.0)),
+                            self.lo, self.hi)
+        self.last_sign = sign
+        update = sign * self.step
+        self.w = np.maximum(self.w + update, self.floor)
+        self.prev_loss = loss
+        return update
+
+
+class _Report(object):
+    """The reference script's console lines (same labels and number formats), through one callable."""
+
+    def __init__(self, emit, stream_names):
+        self.emit, self.names = emit, stream_names
+
+    @staticmethod
+    def _row(values):
+        return ' '.join('%f' % v for v in np.asarray(values).tolist())
+
+    def iteration(self, number, loss):
+        self.emit('')
+        self.emit('=== iteration %s | loss %s ===' % (number, loss))
+
+    def stop(self, why):
+        self.emit('\n   ----> %s\n' % why)
+
+    def step(self, before, contrib, goals, errors, update, after):
+        self.emit('')
+        self.emit('     Streams: ' + ' '.join(name.ljust(8) for name in self.names))
+        self.emit('Prev weights: ' + self._row(before))
+        for label, values in (('mean contrib', contrib), ('       goals', goals), ('      errors', errors),
+                              ('      update', update), ('     weights', after)):
+            self.emit('%s: %s' % (label, self._row(values)))
+
+    def summary(self, valid_names, tune_names, validation, njoin, best):
+        self.emit('')
+        self.emit('# ============================================')
+        if valid_names:
+            self.emit('# validate found weights on %s sentences (%s ... %s)' % (len(valid_names), valid_names[0], valid_names[-1]))
+        self.emit('# mean contribution (validation): ' + self._row(validation))
+        self.emit('')
+        self.emit('## Weights found to best balance stream contributions -- you can copy these to config.')
+        if tune_names:
+            self.emit('## Weights were found using %s utterances (%s ... %s)' % (len(tune_names), tune_names[0], tune_names[-1]))
+        self.emit('join_stream_weights = %s' % (best.tolist()[:njoin]))
+        self.emit('target_stream_weights = %s' % (best.tolist()[njoin:]))
+
+
+def _apply(synth, weights, njoin):
+    synth.set_join_weights(weights[:njoin])
+    synth.set_target_weights(weights[njoin:])
+    if synth.config.get('greedy_search', False):
+        synth.get_tree_for_greedy_search()
+
+
+def _measure(synth, names):
+    """Mean non-zero contribution of every stream over the utterances `names`."""
+    scored = _synth_all(synth, names)
+    return mean_nonzero_contributions(np.vstack([j for (_t, j) in scored]), np.vstack([t for (t, _j) in scored]))
+
+
 def balance_stream_weights(synth, n_tune=10, n_valid=10, max_epochs=1000, patience=5, thresh=0.001,
                            eta=0.1, amplifier=1.2, attenuator=0.5, dmax=50.0, dmin=0.000001,
                            weight_floor=0.0, report=print):
@@ -41,101 +126,49 @@ def balance_stream_weights(synth, n_tune=10, n_valid=10, max_epochs=1000, patien
     assert synth.config['join_cost_weight'] == 1.0
     synth.mode_of_operation = 'stream_weight_balancing'
     synth.verbose = False
-    njoin = len(synth.stream_list_join)
-    ntarget = len(synth.stream_list_target)
+    njoin, ntarget = len(synth.stream_list_join), len(synth.stream_list_target)
+    out = _Report(report, synth.stream_list_join + synth.stream_list_target)
+    state = SignStepState(njoin + ntarget, eta, amplifier, attenuator, dmin, dmax, weight_floor)
 
-    weights = np.ones(njoin + ntarget)          # initially, unweighted streams
-    best_weights = copy.copy(weights)
-    best_score = previous_score = float('inf')
-    epochs_without_improvement = 0
-    lrates = np.ones(weights.shape) * eta
-    prev_directions = np.ones(weights.shape)
-    losses, contribs, history = [], [], []
+    names = synth.get_sentence_set('tune')
+    tune = names[:n_tune] if n_tune < len(names) else names
+    valid = names[n_tune:n_tune + n_valid]
 
-    flist = synth.get_sentence_set('tune')
-    tune_flist = flist[:n_tune] if n_tune < len(flist) else flist
-    valid_flist = flist[n_tune:n_tune + n_valid]
-    flist = tune_flist
-
-    def contributions(names):
-        cache = _synth_all(synth, names)
-        jscores = np.vstack([j for (t, j) in cache])
-        tscores = np.vstack([t for (t, j) in cache])
-        return mean_nonzero_contributions(jscores, tscores)
-
-    goals = None
-    i = -1
-    for i in range(max_epochs):
-        synth.set_join_weights(weights[:njoin])
-        synth.set_target_weights(weights[njoin:])
-        if synth.config.get('greedy_search', False):
-            synth.get_tree_for_greedy_search()
-        mean_scores = contributions(flist)
-        if i == 0:
-            # target and join sides contribute equally, streams equally within a side (:115-120)
-            goal_join = (mean_scores.sum() / 2.0) / njoin
-            goal_target = (mean_scores.sum() / 2.0) / ntarget
-            goals = np.array([goal_join] * njoin + [goal_target] * ntarget)
-        errors = mean_scores - goals
+    goals, losses, contribs, history = None, [], [], []
+    exhausted = max_epochs > 0
+    for epoch in range(max_epochs):
+        _apply(synth, state.w, njoin)
+        contrib = _measure(synth, tune)
+        if goals is None:
+            # both sides are to contribute the same, and every stream of a side the same (:115-120)
+            half = contrib.sum() / 2.0
+            goals = np.concatenate([np.full(njoin, half / njoin), np.full(ntarget, half / ntarget)])
+        errors = contrib - goals
         loss = np.abs(errors).sum()
-        report('')
-        report('=== iteration %s | loss %s ===' % (i + 1, loss))
+        out.iteration(epoch + 1, loss)
         losses.append(loss)
-        if loss < previous_score:
-            epochs_without_improvement = 0
-        else:
-            epochs_without_improvement += 1
-        if loss < best_score:
-            best_score = loss
-            best_weights = copy.copy(weights)
-        if epochs_without_improvement == patience:
-            report('\n   ----> converged (or diverged and ran out of patience)\n')
+        if state.observe(loss) == patience:
+            out.stop('converged (or diverged and ran out of patience)')
+            exhausted = False
             break
         if loss < thresh:
-            report('\n   ----> loss approaching 0: stop here\n')
+            out.stop('loss approaching 0: stop here')
+            exhausted = False
             break
-        directions = np.sign(-1.0 * errors)       # change weights in the opposite direction of errors
-        direction_change = directions * prev_directions
-        lrates[direction_change > 0] *= amplifier
-        lrates[direction_change < 0] *= attenuator
-        lrates = np.clip(lrates, dmin, dmax)
-        prev_directions = copy.copy(directions)
-        update = directions * lrates
-        report('')
-        report('     Streams: ' + ' '.join([item.ljust(8) for item in synth.stream_list_join + synth.stream_list_target]))
-        report('Prev weights: ' + ' '.join(['%f' % (val) for val in weights.tolist()]))
-        weights += update
-        weights = np.maximum(weights, weight_floor)
-        previous_score = loss
-        report('mean contrib: ' + ' '.join(['%f' % (val) for val in mean_scores.tolist()]))
-        report('       goals: ' + ' '.join(['%f' % (val) for val in goals.tolist()]))
-        report('      errors: ' + ' '.join(['%f' % (val) for val in errors.tolist()]))
-        report('      update: ' + ' '.join(['%f' % (val) for val in update.tolist()]))
-        report('     weights: ' + ' '.join(['%f' % (val) for val in weights.tolist()]))
-        contribs.append(mean_scores)
-        history.append(weights.copy())
-    if i == max_epochs - 1:
-        report('\n   ----> max epochs reached: stop here\n')
+        before = state.w.copy()
+        update = state.advance(errors, loss)
+        out.step(before, contrib, goals, errors, update, state.w)
+        contribs.append(contrib)
+        history.append(state.w.copy())
+    if exhausted:
+        out.stop('max epochs reached: stop here')
 
-    report('')
-    report('# ============================================')
-    if valid_flist:
-        report('# validate found weights on %s sentences (%s ... %s)' % (len(valid_flist), valid_flist[0], valid_flist[-1]))
-    synth.set_join_weights(best_weights[:njoin])
-    synth.set_target_weights(best_weights[njoin:])
-    if synth.config.get('greedy_search', False):
-        synth.get_tree_for_greedy_search()
-    # the reference scores the TUNE list here as well (balance_stream_weights.py:187)
-    validation = contributions(flist)
-    report('# mean contribution (validation): ' + ' '.join(['%f' % (val) for val in validation.tolist()]))
-    report('')
-    report('## Weights found to best balance stream contributions -- you can copy these to config.')
-    if flist:
-        report('## Weights were found using %s utterances (%s ... %s)' % (len(flist), flist[0], flist[-1]))
-    report('join_stream_weights = %s' % (best_weights.tolist()[:njoin]))
-    report('target_stream_weights = %s' % (best_weights.tolist()[njoin:]))
-    return {'best_weights': best_weights, 'join_stream_weights': best_weights.tolist()[:njoin],
-            'target_stream_weights': best_weights.tolist()[njoin:], 'losses': losses,
+    best = state.best_w
+    _apply(synth, best, njoin)
+    validation = _measure(synth, tune)          # the reference scores the TUNE list here too (:187)
+    out.summary(valid, tune, validation, njoin, best)
+    return {'best_weights': best, 'join_stream_weights': best.tolist()[:njoin],
+            'target_stream_weights': best.tolist()[njoin:], 'losses': losses,
             'contribs': np.vstack(contribs) if contribs else np.zeros((0, njoin + ntarget)),
             'weight_history': history, 'validation_mean_scores': validation}
 
