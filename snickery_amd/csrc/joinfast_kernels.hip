@@ -56,11 +56,11 @@ __device__ __forceinline__ bool jf_usable(int64_t id, int64_t n_units)
 #define JF_MAXD 1024           // join columns (padded to 16) the w / m tables in LDS hold
 
 template <int KT>
-__global__ void __launch_bounds__(64 * KT)
+__global__ void __launch_bounds__(64 * KT, (KT >= 5 && KT <= 8) ? 4 : 0)      // two workgroups per compute unit: the other one's MFMAs cover a chunk's staging
 join_lb_kernel(const float *__restrict__ JC_unw, int Jp, int Dj, const double *__restrict__ wj, int64_t n_units,
                const int64_t *__restrict__ cand, int K, float *__restrict__ Jlo, float *__restrict__ scale_out)
 {
-    __shared__ f32x4 Bs[2][KT][(KT > 8) ? 2 : 4][64];
+    __shared__ f32x4 Bs[2][KT][(KT >= 5) ? 2 : 4][64];
     __shared__ double w_s[JF_MAXD], m_s[JF_MAXD];
     __shared__ float ne_s[16 * KT], ns_s[16 * KT];
     __shared__ int first_ok, smax_bits;
@@ -99,7 +99,7 @@ join_lb_kernel(const float *__restrict__ JC_unw, int Jp, int Dj, const double *_
     __syncthreads();
 
     // blocks per chunk: 4 (64 columns); 2 for the widest tiles, whose 4 KT accumulators leave fewer registers
-    constexpr int CB = (KT > 8) ? 2 : 4;
+    constexpr int CB = (KT >= 5) ? 2 : 4;
     f32x4 acc[KT];
 #pragma unroll
     for (int j = 0; j < KT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -315,6 +315,9 @@ viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
     }
     __syncthreads();
 
+    // Every total is a non-negative float (or +inf): ordered like its bit pattern, so minima are integer
+    // minima (fminf costs a canonicalising v_max per operand) and the sweeps have no branch per element.
+    const unsigned int INFU = 0x7f800000u;
     auto step = [&](int64_t t, float (&jr)[KPM], double &tdr, int64_t &idr, float &scr) {
         const bool valid = t < T;                       // uniform
         const float *dprev = delta + ((t - 1) & 1) * KP;
@@ -324,38 +327,56 @@ viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
         load_target(t + NB, tdr, idr, scr);
         // the step after a shift step: every d~ of the previous step is read lowered by the block's minimum
         float shift = 0.f;
-        if (((t - 1) & 63) == 0 && t > 1) {             // uniform
+        unsigned int vu[KPM];
+        unsigned int bestu = INFU;
+        if (((t - 1) & 63) == 0 && t > 1) {             // uniform, one step in 64
             shift = inf;
-            for (int w = 0; w < nwaves; ++w) shift = fminf(shift, wmin[w]);
+            for (int w = 0; w < nwaves; ++w) { const float o = wmin[w]; shift = o < shift ? o : shift; }
             if (!(shift < inf)) shift = 0.f;
-        }
-        float v[KPM];
-        float best = inf;
-#pragma unroll
-        for (int i = 0; i < KPM; ++i) {
-            // predecessors beyond K: d~ stays +inf (and an out-of-range buffer load returns 0)
-            v[i] = (dprev[kp0 + i] - shift) + jr[i];
-            best = fminf(best, v[i]);
-        }
-        load_slab(t - 1 + NB < T - 2 ? t - 1 + NB : T - 2, jr);
-        best = fminf(best, __shfl_xor(best, 16, 64));
-        best = fminf(best, __shfl_xor(best, 32, 64));
-        // second sweep: the set within theta of the minimum, the minimum of the rest
-        const float thr = best + (beta * sc + 4e-7f * fabsf(best));
-        float xmin = inf;
-        if (col && valid && best < inf) {
 #pragma unroll
             for (int i = 0; i < KPM; ++i) {
-                if (v[i] <= thr) {
-                    const int slot = atomicAdd(&lcnt[k], 1);
-                    if (slot < JF_CAP) reinterpret_cast<unsigned char *>(lidx)[k * JF_CAP + slot] = (unsigned char)(kp0 + i);
-                } else {
-                    xmin = fminf(xmin, v[i]);
-                }
+                vu[i] = __builtin_bit_cast(unsigned int, (dprev[kp0 + i] - shift) + jr[i]);
+                bestu = vu[i] < bestu ? vu[i] : bestu;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPM; ++i) {
+                // predecessors beyond K: d~ stays +inf (and an out-of-range buffer load returns 0)
+                vu[i] = __builtin_bit_cast(unsigned int, dprev[kp0 + i] + jr[i]);
+                bestu = vu[i] < bestu ? vu[i] : bestu;
             }
         }
-        xmin = fminf(xmin, __shfl_xor(xmin, 16, 64));
-        xmin = fminf(xmin, __shfl_xor(xmin, 32, 64));
+        load_slab(t - 1 + NB < T - 2 ? t - 1 + NB : T - 2, jr);
+        {
+            unsigned int o = (unsigned int)__shfl_xor((int)bestu, 16, 64); bestu = o < bestu ? o : bestu;
+            o = (unsigned int)__shfl_xor((int)bestu, 32, 64); bestu = o < bestu ? o : bestu;
+        }
+        const float best = __builtin_bit_cast(float, bestu);
+        // second sweep: the set within theta of the minimum (a bit per element), the minimum of the rest
+        const float thr = best + (beta * sc + 4e-7f * best);
+        const unsigned int thru = bestu < INFU ? __builtin_bit_cast(unsigned int, thr) : 0u;
+        unsigned int xminu = INFU, mem_lo = 0u, mem_hi = 0u;
+#pragma unroll
+        for (int i = 0; i < KPM; ++i) {
+            const bool in = vu[i] <= thru;
+            if (i < 32) mem_lo |= in ? (1u << i) : 0u;
+            else mem_hi |= in ? (1u << (i - 32)) : 0u;
+            const unsigned int out = in ? INFU : vu[i];
+            xminu = out < xminu ? out : xminu;
+        }
+        if (col && valid && (mem_lo | mem_hi)) {         // a handful of lanes, one or two members each
+            for (int word = 0; word < 2; ++word)
+                for (unsigned int m = word ? mem_hi : mem_lo; m; m &= m - 1) {
+                    const int i = 32 * word + __builtin_ctz(m);
+                    const int slot = atomicAdd(&lcnt[k], 1);
+                    if (slot < JF_CAP) reinterpret_cast<unsigned char *>(lidx)[k * JF_CAP + slot] = (unsigned char)(kp0 + i);
+                }
+        }
+        {
+            unsigned int o = (unsigned int)__shfl_xor((int)xminu, 16, 64); xminu = o < xminu ? o : xminu;
+            o = (unsigned int)__shfl_xor((int)xminu, 32, 64); xminu = o < xminu ? o : xminu;
+        }
+        const float xmin = __builtin_bit_cast(float, xminu);
         float d = inf;
         if (lead && valid) {
             d = td + best;
@@ -372,7 +393,7 @@ viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
         if ((t & 63) == 0) {                            // uniform: a shift step publishes the wavefront's minimum
             float m = lead ? d : inf;
 #pragma unroll
-            for (int s = 1; s <= 8; s <<= 1) m = fminf(m, __shfl_xor(m, s, 64));
+            for (int s = 1; s <= 8; s <<= 1) { const float o = __shfl_xor(m, s, 64); m = o < m ? o : m; }
             if (lane == 0) wmin[tid >> 6] = m;
         }
         __syncthreads();
@@ -405,7 +426,7 @@ void launch_viterbi_lb(const int64_t *cand, const double *tdist, const float *Jl
     hipLaunchKernelGGL((viterbi_lb_kernel<KPM_, NB_, NTH_>), dim3(n), dim3(nth), shmem, s, cand, tdist, Jlo, scale, \
                        batch, K, n_units, KP, beta, reinterpret_cast<u32x4 *>(sets))
         if (variant == 0) SNK_LB(16, 4, 256);
-        else if (variant == 1) SNK_LB(25, 4, 448);
+        else if (variant == 1) SNK_LB(25, 6, 448);
         else if (variant == 2) SNK_LB(32, 3, 512);
         else SNK_LB(52, 2, 832);
 #undef SNK_LB
@@ -611,9 +632,13 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
     __syncthreads();
 
     double off = 0.0;                                              // min over the columns of delta_{t-1} - d~_{t-1}
-    for (int64_t t = 1; t < T; ++t) {
-        const int64_t bidx = (t - 1) / BS;                         // batch of this step
-        const int sin = (int)((t - 1) % BS);
+    // step counters kept incrementally in 32 bits (a wavefront issues about one instruction per four cycles
+    // here: the step is as long as its instruction count)
+    const int Ti = (int)T, K4 = K * 4;
+    int bidx = 0, sin = 0, ring_slot = 0;                          // batch of the step, step inside it, ring slot of the batch
+    int rp_off = (col ? k : 0) * 4;                                // this column's record of the step, in 16-byte pieces
+    int bp_off = K + k;
+    for (int t = 1; t < Ti; ++t) {
         double best = inf, d = inf, diff = inf, td = inf, lbv = inf;
         int arg = 0;
         bool fail = false;
@@ -623,11 +648,11 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
         if (loader) {
             if (sin == BS - 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // batch bidx + 1 has landed (issued BS steps ago)
-                dma_batch(bidx + 2);                               // into the slot batch bidx - 1 has left
+                dma_batch((int64_t)bidx + 2);                      // into the slot batch bidx - 1 has left
             }
         } else {
             // this step's record
-            const u32x4 *rp = ring + (size_t)(bidx % 3) * slot_pieces + (size_t)sin * K * 4 + (size_t)(col ? k : 0) * 4;
+            const u32x4 *rp = ring + rp_off;
             const u32x4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
             auto f64 = [](unsigned int lo, unsigned int hi) { return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32)); };
             td = f64(q0[0], q0[1]);
@@ -668,13 +693,11 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
             if (lane == 0) { wr[2 * wave] = wm; wr[2 * wave + 1] = wfail ? 1.0 : 0.0; }
         }
         __syncthreads();
-        bool anyfail = false;
-        off = inf;
-        for (int w = 0; w < ncw; ++w) {
-            const double o = wr[2 * w];
-            off = o < off ? o : off;
-            anyfail = anyfail || (wr[2 * w + 1] != 0.0);
-        }
+        // four compute wavefronts, always (launch_viterbi_sparse): { minimum, failed } x 4
+        const double o0 = wr[0], f0 = wr[1], o1 = wr[2], f1 = wr[3], o2 = wr[4], f2 = wr[5], o3 = wr[6], f3 = wr[7];
+        const double o01 = o0 < o1 ? o0 : o1, o23 = o2 < o3 ? o2 : o3;
+        off = o01 < o23 ? o01 : o23;
+        const bool anyfail = (f0 + f1 + f2 + f3) != 0.0;
         if (anyfail) {                                             // rare; every wavefront takes the same barriers
             if (fail) { rbest[k] = best; rarg[k] = arg; }
             __syncthreads();
@@ -729,8 +752,15 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
             for (int w = 0; w < ncw; ++w) { const double o = wr[2 * w]; off = o < off ? o : off; }
         }
         if (col) {
-            if constexpr (BPL) bp_lds[t * K + k] = (unsigned char)arg;
-            else bp_global[t * K + k] = (unsigned char)arg;
+            if constexpr (BPL) bp_lds[bp_off] = (unsigned char)arg;
+            else bp_global[bp_off] = (unsigned char)arg;
+        }
+        bp_off += K;
+        rp_off += K4;
+        if (++sin == BS) {
+            sin = 0; ++bidx;
+            ring_slot = ring_slot == 2 ? 0 : ring_slot + 1;
+            rp_off = ring_slot * slot_pieces + (col ? k : 0) * 4;
         }
     }
     __syncthreads();

@@ -155,7 +155,7 @@ struct snk_engine {
     int n_cus = 256;
     int reserved_cus = 2;
     int batch_rows = 8192;     // rows per K-NN call of the batch entry points (utterances are grouped)
-    int viterbi_mode = 1;      // 1: f32 lower bounds on the matrix pipe + sparse exact recursion; 0: dense exact join + recursion
+    int viterbi_mode = 2;      // 2: auto; 1: f32 lower bounds on the matrix pipe + sparse exact recursion; 0: dense exact join + recursion
     double join_beta = 5e-4;   // pass-2 margin in units of the step's largest centred norm (speed only, never the result)
     DevBuf vstats;             // [0] cells refined, [1] steps with a refinement, [2] exact costs computed there
     int pool_chunk_limit = 0;  // test hook: cap of the entry pool (chunks) in every attempt; 0 = none
@@ -234,7 +234,7 @@ static int staged_d2h(snk_engine *h, hipStream_t st, const D2HPart *parts, int n
 
 static int no_batch_in_flight(snk_engine *h, const char *who);
 static int create_streams(snk_engine *h);
-static bool use_sparse_viterbi(const snk_engine *h, int K);
+static bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts);
 static int roundup(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); }
 #define SNK_KNN_MAX_ROWS 8192       // rows of one K-NN call (batch_rows is capped to it)
 
@@ -827,7 +827,7 @@ static int slot_ensure(snk_engine *h, UttSlot &s, int64_t T, int K)
 {
     CHK(s.cand.ensure((size_t)T * K * sizeof(int64_t)));
     CHK(s.tdist.ensure((size_t)T * K * sizeof(double)));
-    if (!use_sparse_viterbi(h, K)) CHK(s.J.ensure((size_t)(T > 1 ? T - 1 : 1) * K * K * sizeof(double)));
+    if (!use_sparse_viterbi(h, K, 1)) CHK(s.J.ensure((size_t)(T > 1 ? T - 1 : 1) * K * K * sizeof(double)));
     CHK(s.bp.ensure((size_t)T * K));
     CHK(s.path.ensure((size_t)T * sizeof(int64_t)));
     CHK(s.plen.ensure(sizeof(int64_t)));
@@ -916,9 +916,15 @@ static int64_t join_units(snk_engine *h)
     return h->Njc - 1;
 }
 
-static bool use_sparse_viterbi(const snk_engine *h, int K)
+// viterbi_mode 2 (default): the sparse path where it pays -- batches (its first pass runs over the whole chip
+// while the per-utterance passes hide beside the next group's K-NN; a single utterance is quicker through the
+// dense kernels: 1.7 against 2.4 ms at T = 600, K = 100) up to K = 128 (the K <= 208 variant of pass 2 is
+// register-bound).  1 forces it wherever it is supported, 0 forces the dense exact path.  Same results.
+static bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts = 1)
 {
-    return h->viterbi_mode == 1 && join_lb_supported(h->Dj, K);
+    if (!join_lb_supported(h->Dj, K)) return false;
+    if (h->viterbi_mode == 1) return true;
+    return h->viterbi_mode == 2 && n_utts >= 2 && K <= 128;
 }
 
 static int sparse_ensure(snk_engine *h, UttSlot &s, int64_t rows, int K)
@@ -973,7 +979,7 @@ static int viterbi_sparse_rows(snk_engine *h, UttSlot &s, const int64_t *cand, c
 static int viterbi_device(snk_engine *h, UttSlot &s, int64_t T, int K, hipStream_t st)
 {
     if (K > 208) return fail("viterbi: n_candidates=%d > 208 not supported", K);
-    if (use_sparse_viterbi(h, K)) {
+    if (use_sparse_viterbi(h, K, 1)) {
         CHK(sparse_ensure(h, s, T, K));
         const int64_t off[2] = {0, T};
         return viterbi_sparse_rows(h, s, s.cand.as<int64_t>(), s.tdist.as<double>(), T, off, 1, 0, K, st, st,
@@ -1094,7 +1100,8 @@ static std::vector<int> group_utterances(const snk_engine *h, const int64_t *row
 // where they land on the compute units the persistent K-NN sweep of the next group leaves free.
 static int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u0, int u1, int K,
                          const int64_t *cand_all, const double *tdist_all, bool side_stream,
-                         int64_t *res_path = nullptr, int64_t *res_plen = nullptr, double *res_cost = nullptr)
+                         int64_t *res_path = nullptr, int64_t *res_plen = nullptr, double *res_cost = nullptr,
+                         int n_batch_utts = 2)
 {
     if (!res_path) { res_path = h->res_path.as<int64_t>(); res_plen = h->res_plen.as<int64_t>(); res_cost = h->res_cost.as<double>(); }
     const int64_t r0 = row_offsets[u0], rows = row_offsets[u1] - r0;
@@ -1103,7 +1110,7 @@ static int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u
     // workspace reuse: the join costs of this group overwrite what the last recursion queued on this
     // workspace reads (an earlier group of this batch, or the tail of the batch submitted before)
     if (s.vit_recorded) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));
-    if (use_sparse_viterbi(h, K)) {
+    if (use_sparse_viterbi(h, K, n_batch_utts)) {
         CHK(sparse_ensure(h, s, rows, K));
         std::vector<int64_t> off((size_t)(u1 - u0) + 1);
         for (int u = u0; u <= u1; ++u) off[(size_t)(u - u0)] = row_offsets[u] - r0;
@@ -1199,7 +1206,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
         CHK(knn_device(h, b.Qall.as<double>() + r0 * D, rows, K, nullptr, b.cand.as<int64_t>() + r0 * K,
                        b.dist.as<double>() + r0 * K, nullptr, b.status.as<int>() + g));
         CHK(viterbi_group(h, g, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
-                          b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>()));
+                          b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), n_utts));
     }
     // results -> pinned memory, behind the K-NN status words (main stream) and the last recursions
     HIPCHK(hipEventRecord(h->knn_all_done, h->stream));
@@ -1249,7 +1256,7 @@ int snk_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, i
         h->precision = saved;
         if (rc) return rc;
         CHK(viterbi_group(h, g, b.offs.data(), b.first[g], b.first[g + 1], b.K, b.cand.as<int64_t>(), b.dist.as<double>(), false,
-                          b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>()));
+                          b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), b.n_utts));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->batch_redos += 1;
         redone = true;
@@ -1617,7 +1624,8 @@ int snk_merge_viterbi_batch_dev(snk_handle h, const double *d2_dev, const int64_
     {
         const std::vector<int> first = group_utterances(h, row_offsets, n_utts);
         for (int g = 0; g + 1 < (int)first.size(); ++g)
-            CHK(viterbi_group(h, g, row_offsets, first[g], first[g + 1], K, h->mcand.as<int64_t>(), h->mdist.as<double>(), true));
+            CHK(viterbi_group(h, g, row_offsets, first[g], first[g + 1], K, h->mcand.as<int64_t>(), h->mdist.as<double>(), true,
+                              nullptr, nullptr, nullptr, n_utts));
     }
     for (int i = 0; i < 2; ++i) HIPCHK(hipStreamSynchronize(h->dp_stream[i]));
     HIPCHK(hipGetLastError());
@@ -1744,7 +1752,7 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value < 0 || value > 8192) return fail("batch_rows must be in 0..8192 (0: one K-NN call per utterance)");
         h->batch_rows = (int)value;
     } else if (!strcmp(name, "viterbi_mode")) {
-        if (value != 0.0 && value != 1.0) return fail("viterbi_mode must be 0 (dense exact join + recursion) or 1 (lower bounds + sparse exact recursion)");
+        if (value != 0.0 && value != 1.0 && value != 2.0) return fail("viterbi_mode must be 0 (dense exact join + recursion), 1 (lower bounds + sparse exact recursion) or 2 (auto)");
         CHK(no_batch_in_flight(h, "snk_set_option(viterbi_mode)"));
         h->viterbi_mode = (int)value;
     } else if (!strcmp(name, "join_beta")) {

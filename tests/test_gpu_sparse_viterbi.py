@@ -16,7 +16,7 @@ def engine():
     import snickery_amd
     e = snickery_amd.HipSearchEngine(0)
     yield e
-    e.set_option('viterbi_mode', 1)
+    e.set_option('viterbi_mode', 2)
     e.close()
 
 
@@ -87,6 +87,12 @@ def test_sparse_with_unusable_duplicate_and_padded_candidates(engine):
         engine.set_option('viterbi_mode', mode)
         path, cost = engine.viterbi(dead, dist)
         assert path == [] and cost == np.inf
+    engine.set_option('viterbi_mode', 1)
+    # the default (mode 2) picks the dense kernels for one utterance and the sparse path for a batch
+    engine.set_option('viterbi_mode', 2)
+    before = engine.timers().get('viterbi_sparse', (0, 0))[1]
+    engine.viterbi(base, dist)
+    assert engine.timers().get('viterbi_sparse', (0, 0))[1] == before
     engine.set_option('viterbi_mode', 1)
 
 
