@@ -157,6 +157,9 @@ def main():
                          '(the per-utterance recursions of its last group, the copy of the results) runs beside the K-NN of the '
                          'next one -- how a tuning loop over a tune set drives the engine; every step completes inside the timed '
                          'region.  1: strictly one step at a time (reported as extra field one_in_flight otherwise)')
+    ap.add_argument('--exchange', choices=('library', 'torch'), default='library',
+                    help="N > 1, sharded database: collectives inside libsnkhip.so (snk_comm_init: RCCL on the engine's stream; "
+                         "default) or torch.distributed collectives between the device-pointer entry points (snickery_amd/dist.py)")
     ap.add_argument('--fixed-batch', action='store_true', help='N > 1: keep the batch at --utts (strong scaling)')
     ap.add_argument('--db-shards', type=int, default=0,
                     help='N > 1: shard the database over this many GPUs (a divisor of N; default N) and replicate '
@@ -240,9 +243,19 @@ def main():
             eng.upload_target_only(F_unw[lo:hi])
             eng.upload_join_only(JC_unw)
             eng.set_shard(lo, N)
-            eng.set_weights(wt, wj)
-            search = ShardedSearch(HipShardEngine(eng, torch.device('cuda', local_rank)), rank=sub_rank, world_size=S,
-                                   group=group)
+            if args.exchange == 'library':
+                # collectives inside libsnkhip.so (RCCL on the engine's stream, no host synchronisation between
+                # bounds, exchange and merge); every rank bounds its own share of the rows against a
+                # replicated 1/16 sample of the whole database
+                from snickery_amd.dist import LibraryShardedSearch, global_sample
+                eng.upload_global_sample(global_sample(F_unw, 16))
+                eng.set_weights(wt, wj)
+                search = LibraryShardedSearch(eng, rank=sub_rank, world_size=S, group=group,
+                                              transport='gloo' if share_gpu else 'rccl')
+            else:
+                eng.set_weights(wt, wj)
+                search = ShardedSearch(HipShardEngine(eng, torch.device('cuda', local_rank)), rank=sub_rank, world_size=S,
+                                       group=group)
 
             def step():
                 return search.knn_viterbi_batch(my_utts, K)
@@ -351,7 +364,8 @@ def main():
                        'n_candidates': K, 'steps_in_flight': args.in_flight if world == 1 else 1,
                        'sharding': 'none' if world == 1 else (
                            '%d independent replicas' % world if S == 1 else
-                           'db-rows/%d + all-to-all of local top-K' % S + (' x %d replica groups' % n_groups if n_groups > 1 else ''))},
+                           'db-rows/%d + all-to-all of local top-K' % S + (' x %d replica groups' % n_groups if n_groups > 1 else '')),
+                       'exchange': None if world == 1 or S == 1 else args.exchange},
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_source,

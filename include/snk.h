@@ -211,6 +211,44 @@ int snk_merge_viterbi_batch_dev(snk_handle h, const double *d2_dev, const int64_
 /* upload the FULL join matrix only (ranks that run the Viterbi of an utterance) */
 int snk_upload_join_only(snk_handle h, const float *JC_unw, int64_t Njc, int Dj);
 
+/* ---- collectives inside the library (one process per GPU; RCCL over xGMI) ------------------------
+ * The reference's only fan-out is a multiprocessing.Pool over utterances (synth_halfphone.py:897-903); the
+ * sharded search of SURVEY 8e needs an exchange step, which a C caller gets here without torch:
+ *   rank 0: snk_comm_unique_id -> hand the 128 bytes to every rank (file, MPI, socket ...) ->
+ *   every rank: snk_comm_init(h, nranks, rank, id)  [ncclCommInitRank; librccl is loaded at this call]
+ *   every rank: snk_sharded_knn_viterbi_batch(...) with the SAME batch.
+ * snk_sharded_knn_viterbi_batch, all on the engine's stream with no host synchronisation between its
+ * stages: bounds of the K-th nearest key (own share of the rows against the replicated global sample when
+ * snk_upload_global_sample was called, else all rows against the shard's sample) -> all-reduce MIN ->
+ * filter + re-rank of ALL rows against this rank's shard -> all-to-all of the (R, K) lists to the ranks
+ * that own the utterances (contiguous blocks, snk_shard_plan) -> merge, join costs, Viterbi of the owned
+ * utterances -> all-gather of paths and costs.  Every rank returns the results of ALL utterances.
+ * snk_transport: the same flow over caller-provided collectives on device buffers (the functional tests run
+ * two ranks on ONE GPU, which RCCL refuses); each function returns 0 on success and must be complete (or
+ * ordered on `stream`) when it returns. */
+typedef struct snk_transport {
+    void *ctx;
+    int (*all_reduce_min_f64)(void *ctx, double *buf_dev, int64_t n, void *stream);
+    int (*all_gather)(void *ctx, const void *send_dev, void *recv_dev, int64_t bytes_per_rank, void *stream);
+    /* rank p's block: send_bytes[p] from send_dev + send_off[p]; recv_bytes[p] to recv_dev + recv_off[p] */
+    int (*all_to_all_v)(void *ctx, const void *send_dev, const int64_t *send_off, const int64_t *send_bytes,
+                        void *recv_dev, const int64_t *recv_off, const int64_t *recv_bytes, void *stream);
+} snk_transport;
+int snk_comm_unique_id(void *id_out, int capacity, int *bytes_out);
+int snk_comm_init(snk_handle h, int nranks, int rank, const void *unique_id);
+int snk_comm_init_transport(snk_handle h, int nranks, int rank, const snk_transport *transport);
+int snk_comm_destroy(snk_handle h);
+/* contiguous block [lo, hi) of n items that rank `rank` of `nranks` owns (sizes differ by at most one):
+ * database rows of a shard, utterances of a batch */
+int snk_shard_plan(int64_t n_items, int nranks, int rank, int64_t *lo_out, int64_t *hi_out);
+/* every s-th unit of the WHOLE database, replicated on every rank (see above); before snk_set_weights */
+int snk_upload_global_sample(snk_handle h, const float *F_sample_unw, int64_t n_rows, int Dt);
+int snk_sharded_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
+                                  int64_t *path_out, int64_t *path_len_out, double *cost_out);
+/* plain synchronous copies for transport implementations (device pointers handed to the callbacks) */
+int snk_copy_to_host(void *dst_host, const void *src_dev, int64_t bytes);
+int snk_copy_to_device(void *dst_dev, const void *src_host, int64_t bytes);
+
 /* Waveform side (the step after the search).  Replaces retrieve_magphase_frag
  * (synth_simple.py:538-652) and the overlap-add loop of concatenateMagPhaseEpoch_sep_files
  * (:677-747) up to the call of the external vocoder.

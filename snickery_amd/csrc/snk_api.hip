@@ -3,8 +3,10 @@
 #include "snk_internal.h"
 #include "../../include/snk.h"
 
+#include <dlfcn.h>
 #include <float.h>
 #include <math.h>
+#include <rccl/rccl.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -119,6 +121,16 @@ struct snk_engine {
     DevBuf F_unw, JC_unw, Fw, fnorm, JCw, wt, wj, unit_class;
     bool have_db = false, have_join = false, have_weights = false, have_classes = false;
     int64_t shard_offset = 0, global_N = -1;
+    // in-library collectives (snk_comm_init / snk_comm_init_transport)
+    int comm_ranks = 0, comm_rank = 0;
+    void *nccl_comm = nullptr;            // ncclComm_t
+    snk_transport transport{};            // caller-provided collectives (functional tests)
+    bool have_transport = false;
+    DevBuf sh_d2, sh_id, sh_bound, sh_rd2, sh_rid, sh_res, sh_resall;
+    // replicated global sample (snk_upload_global_sample): stage A of a rank's own rows runs against it
+    DevBuf gs_unw, gs_w, gs_norm, gs_tiles, gs_fmax2;
+    int64_t gs_rows = 0, gs_slabs = 0;
+    bool gs_ready = false;
     // k-nn workspace
     DevBuf Qraw, Qp, Qf, qnorm, thr, gmin, cnt, lkey, lidx, status, qclass, d2tmp, slabctr, pool, poolctl, chunkfill;
     UttSlot slot[8];
@@ -303,6 +315,10 @@ int snk_destroy(snk_handle h)
     (void)hipDeviceSynchronize();
     collect_timers(h);
     h->tmask.release(); h->mcand.release(); h->mdist.release(); h->vstats.release();
+    (void)snk_comm_destroy(h);
+    { DevBuf *cb[] = {&h->sh_d2, &h->sh_id, &h->sh_bound, &h->sh_rd2, &h->sh_rid, &h->sh_res, &h->sh_resall,
+                      &h->gs_unw, &h->gs_w, &h->gs_norm, &h->gs_tiles, &h->gs_fmax2};
+      for (auto *b : cb) b->release(); }
     DevBuf *bufs[] = {&h->F_unw, &h->JC_unw, &h->Fw, &h->fnorm, &h->JCw, &h->wt, &h->wj, &h->unit_class,
                       &h->Qraw, &h->Qp, &h->Qf, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
@@ -373,6 +389,7 @@ int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt, const flo
     h->have_classes = false;
     h->have_glay = false;
     h->gtiles_ready = false;
+    h->gs_rows = 0; h->gs_ready = false;
     if (h->global_N < 0) { h->shard_offset = 0; }
     if (JC_unw) CHK(upload_join(h, JC_unw, Njc, Dj));
     return 0;
@@ -506,9 +523,52 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
             h->f16_ready = true;
         }
     }
+    h->gs_ready = false;
+    if (h->gs_rows > 0 && h->f16_ready) {
+        // the replicated global sample in the operand layout of stage A (groups scattered over the sample)
+        const int nt = h->nt16_eff;
+        h->gs_slabs = h->gs_rows / (32 * nt);
+        if (h->gs_slabs >= 1) {
+            const int64_t rows_alloc = roundup(h->gs_rows, 16) + 16 * SNK_NT_MAX;
+            CHK(h->gs_w.ensure((size_t)rows_alloc * h->Dpad * sizeof(double)));
+            CHK(h->gs_norm.ensure((size_t)rows_alloc * sizeof(double)));
+            CHK(h->gs_fmax2.ensure(sizeof(double)));
+            launch_weight_target(h->gs_unw.as<float>(), h->Fp, h->gs_rows, h->Dt, h->wt.as<double>(), h->gs_w.as<double>(),
+                                 h->gs_norm.as<double>(), rows_alloc, h->Dpad, nullptr, h->stream);
+            launch_fmax(h->gs_norm.as<double>(), h->gs_rows, h->gs_fmax2.as<double>(), h->stream);
+            const int64_t tiles = h->gs_slabs * nt;
+            CHK(h->gs_tiles.ensure((size_t)tiles * 8 * 64 * 16 * (h->Dpad / 64)));
+            launch_build_db16(h->gs_w.as<double>(), h->gs_norm.as<double>(), h->gs_rows, h->Dt, h->Dpad, tiles, 1,
+                              2 * h->gs_slabs, nt, h->gs_tiles.p, h->stream);
+            HIPCHK(hipGetLastError());
+            h->gs_ready = true;
+        }
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     collect_timers(h);
     h->have_weights = true;
+    return 0;
+}
+
+// Row-sharded databases: every rank also keeps a SAMPLE of the whole database (every s-th unit, chosen by the
+// caller: 1/16 of 1 M units x 61 columns is 17 MB) and bounds the K-th nearest key of ITS share of the query
+// rows against it -- the bound a single GPU would compute -- instead of every rank bounding every row against
+// its own shard's sample.  Takes effect with the next snk_set_weights; rows in the database's column layout.
+int snk_upload_global_sample(snk_handle h, const float *F_sample_unw, int64_t n_rows, int Dt)
+{
+    if (!h) return fail("null handle");
+    CHK(no_batch_in_flight(h, "snk_upload_global_sample"));
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->have_db) return fail("snk_upload_global_sample: upload the database shard first");
+    if (!F_sample_unw || n_rows < 1 || Dt != h->Dt) return fail("snk_upload_global_sample: bad sample matrix (rows=%lld Dt=%d, database Dt=%d)", (long long)n_rows, Dt, h->Dt);
+    CHK(h->gs_unw.ensure((size_t)n_rows * h->Fp * sizeof(float)));
+    if (h->Fp != Dt) HIPCHK(hipMemsetAsync(h->gs_unw.p, 0, (size_t)n_rows * h->Fp * sizeof(float), h->stream));
+    HIPCHK(hipMemcpy2DAsync(h->gs_unw.p, (size_t)h->Fp * sizeof(float), F_sample_unw, (size_t)Dt * sizeof(float),
+                            (size_t)Dt * sizeof(float), (size_t)n_rows, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->gs_rows = n_rows;
+    h->gs_ready = false;
+    h->have_weights = false;
     return 0;
 }
 
@@ -567,9 +627,11 @@ static KnnPlan make_plan(snk_engine *h, int K)
 // f32 path cannot give one); `bound_in` != nullptr skips stage A and filters against bound_in + eps --
 // the caller passes the minimum of the bounds of all shards, which still bounds the K-th nearest key
 // of the whole database.  Lists may then hold fewer than K entries (padded with id -1).
+// gs (with bound_out): stage A runs against the replicated GLOBAL sample (snk_upload_global_sample) instead of
+// this shard's own one -- the bound is then that of the whole database, as on a single GPU.
 static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_t *qclass_dev,
                       int64_t *cand_dev, double *dist_dev, double *d2_dev, int *deferred_status = nullptr,
-                      const double *bound_in = nullptr, double *bound_out = nullptr)
+                      const double *bound_in = nullptr, double *bound_out = nullptr, bool gs = false)
 {
     if (K < 1 || K > 208) return fail("K-NN: n_candidates=%d outside the supported range 1..208", K);
     if (T > SNK_KNN_MAX_ROWS) {
@@ -580,7 +642,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             CHK(knn_device(h, Qdev + r0 * h->Dt, rows, K, qclass_dev ? qclass_dev + r0 : nullptr,
                            cand_dev ? cand_dev + r0 * K : nullptr, dist_dev ? dist_dev + r0 * K : nullptr,
                            d2_dev ? d2_dev + r0 * K : nullptr, nullptr, bound_in ? bound_in + r0 : nullptr,
-                           bound_out ? bound_out + r0 : nullptr));
+                           bound_out ? bound_out + r0 : nullptr, gs));
         }
         if (deferred_status) HIPCHK(hipMemsetAsync(deferred_status, 0, sizeof(int), h->stream));
         return 0;
@@ -634,9 +696,10 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
     const int dch16 = h->Dpad / 64;
     const int nt_run = (cls && dch16 == 1) ? 2 : h->nt16_eff;
     const int slab_factor = h->nt16_eff / (nt_run > 0 ? nt_run : 1);
+    const bool use_gs = gs && bound_out && !cls && h->gs_ready && 2 * h->gs_slabs >= K;
     if (h->precision == 1 && h->f16_ready && (!cls || (h->nt16_eff % nt_run) == 0) &&
-        2 * h->n_slabs16_a * slab_factor >= K) {
-        const int64_t n_slabs_a = h->n_slabs16_a * slab_factor, n_slabs_b = h->n_slabs16 * slab_factor;
+        (use_gs || 2 * h->n_slabs16_a * slab_factor >= K)) {
+        const int64_t n_slabs_a = use_gs ? h->gs_slabs : h->n_slabs16_a * slab_factor, n_slabs_b = h->n_slabs16 * slab_factor;
         const int64_t G16 = 2 * n_slabs_a;
         const int32_t *cls_full = nullptr, *cls_samp = nullptr;
         if (cls) {
@@ -662,11 +725,12 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         {
             StageTimer t(h, s, TM_PREP);
             launch_prepare_queries16(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad,
-                                     h->fmax2.as<double>(), h->eps_c, h->b16h.p, h->eps16.as<double>(), s);
+                                     use_gs ? h->gs_fmax2.as<double>() : h->fmax2.as<double>(), h->eps_c, h->b16h.p,
+                                     h->eps16.as<double>(), s);
         }
         if (!bound_in) {
             StageTimer t(h, s, TM_KNN_MINIMA);
-            launch_knn_sweep16(0, nt_run, dch16, (h->Dt + 2) / 2, p0.grid_cus, h->s16h.p, h->b16h.p, cls_samp, qclass_dev,
+            launch_knn_sweep16(0, nt_run, dch16, (h->Dt + 2) / 2, p0.grid_cus, use_gs ? h->gs_tiles.p : h->s16h.p, h->b16h.p, cls_samp, qclass_dev,
                                nullptr, Tpad, n_slabs_a, h->slabctr.as<unsigned int>(), h->gmin32.as<float>(),
                                G16, nullptr, nullptr, nullptr, 0, knn_pool_chunk_entries(), s);
         }
@@ -1514,9 +1578,21 @@ int snk_merge_topk_dev(snk_handle h, const double *d2_dev, const int64_t *id_dev
 // Shared body of the three shard-local batch calls.  bound_out: stage A only (per-row bounds);
 // bound_in: filter against the caller's bounds; Q == nullptr: the rows of the previous call are
 // still resident (the bounds call and the bounded call of one step see the same batch).
+static int upload_batch_queries(snk_engine *h, const double *Q, int64_t total, int D)
+{
+    CHK(h->Qall.ensure((size_t)total * D * sizeof(double)));
+    StageTimer t(h, h->stream, TM_H2D);
+    HIPCHK(hipMemcpyAsync(h->Qall.p, Q, (size_t)total * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (!h->tsel.empty()) launch_mask_columns(h->Qall.as<double>(), total, D, h->tmask.as<double>(), h->stream);
+    h->qall_rows = total;
+    return 0;
+}
+
+// defer != nullptr: nothing is synchronised; *defer receives the number of status words left in
+// h->res_status (the caller checks them when it next touches the host, and redoes the step if any is set).
 static int knn_local_batch(snk_engine *h, const char *who, const double *Q, const int64_t *row_offsets, int n_utts,
                            int D, int K, const double *bound_in, double *bound_out, double *d2_dev_out,
-                           int64_t *id_dev_out)
+                           int64_t *id_dev_out, int *defer = nullptr)
 {
     CHK(check_ready(h, true, false));
     HIPCHK(hipSetDevice(h->device));
@@ -1530,11 +1606,7 @@ static int knn_local_batch(snk_engine *h, const char *who, const double *Q, cons
     const int64_t step = h->batch_rows > 0 ? h->batch_rows : total;
     const int n_groups = (int)((total + step - 1) / step);
     if (Q) {
-        CHK(h->Qall.ensure((size_t)total * D * sizeof(double)));
-        StageTimer t(h, h->stream, TM_H2D);
-        HIPCHK(hipMemcpyAsync(h->Qall.p, Q, (size_t)total * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        if (!h->tsel.empty()) launch_mask_columns(h->Qall.as<double>(), total, D, h->tmask.as<double>(), h->stream);
-        h->qall_rows = total;
+        CHK(upload_batch_queries(h, Q, total, D));
     } else if (h->qall_rows != total) {
         return fail("%s: no query matrix given and the resident one has %lld rows, not %lld", who,
                     (long long)h->qall_rows, (long long)total);
@@ -1546,6 +1618,7 @@ static int knn_local_batch(snk_engine *h, const char *who, const double *Q, cons
                        nullptr, d2_dev_out ? d2_dev_out + r0 * K : nullptr, h->res_status.as<int>() + g,
                        bound_in ? bound_in + r0 : nullptr, bound_out ? bound_out + r0 : nullptr));
     }
+    if (defer) { *defer = n_groups; HIPCHK(hipGetLastError()); return 0; }
     if (bound_out) {
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipGetLastError());
@@ -1637,6 +1710,320 @@ int snk_merge_viterbi_batch_dev(snk_handle h, const double *d2_dev, const int64_
         CHK(staged_d2h(h, h->stream, parts, 3));
     }
     collect_timers(h);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// collectives inside the library: RCCL (loaded when a communicator is first asked for: a single-GPU caller
+// never maps its 500 MB) or caller-provided functions
+// ---------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.lib) return 0;
+    const char *names[] = {getenv("SNK_LIBRCCL"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *n : names) {
+        if (!n || !*n) continue;
+        lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) return fail("snk_comm: cannot load librccl (set SNK_LIBRCCL): %s", dlerror());
+#define SNK_SYM(field, name)                                                                    \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, name));                  \
+    if (!g_rccl.field) return fail("snk_comm: librccl has no symbol %s", name)
+    SNK_SYM(GetUniqueId, "ncclGetUniqueId"); SNK_SYM(CommInitRank, "ncclCommInitRank"); SNK_SYM(CommDestroy, "ncclCommDestroy");
+    SNK_SYM(AllReduce, "ncclAllReduce"); SNK_SYM(AllGather, "ncclAllGather"); SNK_SYM(Send, "ncclSend");
+    SNK_SYM(Recv, "ncclRecv"); SNK_SYM(GroupStart, "ncclGroupStart"); SNK_SYM(GroupEnd, "ncclGroupEnd");
+    SNK_SYM(GetErrorString, "ncclGetErrorString");
+#undef SNK_SYM
+    g_rccl.lib = lib;
+    return 0;
+}
+#define NCCLCHK(expr)                                                                              \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess) return fail("%s failed: %s", #expr, g_rccl.GetErrorString(r_));     \
+    } while (0)
+
+void shard_plan(int64_t n, int G, int r, int64_t *lo, int64_t *hi)
+{
+    const int64_t base = n / G, rem = n % G;
+    *lo = r * base + (r < rem ? r : rem);
+    *hi = *lo + base + (r < rem ? 1 : 0);
+}
+
+// the three collectives of the sharded search, on the engine's stream
+int comm_all_reduce_min(snk_engine *h, double *buf, int64_t n)
+{
+    if (h->comm_ranks <= 1) return 0;
+    if (h->have_transport) {
+        if (h->transport.all_reduce_min_f64(h->transport.ctx, buf, n, h->stream)) return fail("transport all_reduce_min_f64 failed");
+        return 0;
+    }
+    NCCLCHK(g_rccl.AllReduce(buf, buf, (size_t)n, ncclDouble, ncclMin, (ncclComm_t)h->nccl_comm, h->stream));
+    return 0;
+}
+int comm_all_gather(snk_engine *h, const void *send, void *recv, int64_t bytes)
+{
+    if (h->comm_ranks <= 1) { HIPCHK(hipMemcpyAsync(recv, send, (size_t)bytes, hipMemcpyDeviceToDevice, h->stream)); return 0; }
+    if (h->have_transport) {
+        if (h->transport.all_gather(h->transport.ctx, send, recv, bytes, h->stream)) return fail("transport all_gather failed");
+        return 0;
+    }
+    NCCLCHK(g_rccl.AllGather(send, recv, (size_t)bytes, ncclChar, (ncclComm_t)h->nccl_comm, h->stream));
+    return 0;
+}
+int comm_all_to_all_v(snk_engine *h, const void *send, const int64_t *soff, const int64_t *sbytes, void *recv,
+                      const int64_t *roff, const int64_t *rbytes)
+{
+    const int G = h->comm_ranks;
+    if (G <= 1) { HIPCHK(hipMemcpyAsync((char *)recv + roff[0], (const char *)send + soff[0], (size_t)sbytes[0], hipMemcpyDeviceToDevice, h->stream)); return 0; }
+    if (h->have_transport) {
+        if (h->transport.all_to_all_v(h->transport.ctx, send, soff, sbytes, recv, roff, rbytes, h->stream)) return fail("transport all_to_all_v failed");
+        return 0;
+    }
+    // one fused group of point-to-point transfers: xGMI is point to point, every pair has its own link
+    NCCLCHK(g_rccl.GroupStart());
+    for (int p = 0; p < G; ++p) {
+        if (sbytes[p]) NCCLCHK(g_rccl.Send((const char *)send + soff[p], (size_t)sbytes[p], ncclChar, p, (ncclComm_t)h->nccl_comm, h->stream));
+        if (rbytes[p]) NCCLCHK(g_rccl.Recv((char *)recv + roff[p], (size_t)rbytes[p], ncclChar, p, (ncclComm_t)h->nccl_comm, h->stream));
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    return 0;
+}
+}  // namespace
+
+int snk_shard_plan(int64_t n_items, int nranks, int rank, int64_t *lo_out, int64_t *hi_out)
+{
+    if (n_items < 0 || nranks < 1 || rank < 0 || rank >= nranks || !lo_out || !hi_out) return fail("snk_shard_plan: bad arguments");
+    shard_plan(n_items, nranks, rank, lo_out, hi_out);
+    return 0;
+}
+
+int snk_comm_unique_id(void *id_out, int capacity, int *bytes_out)
+{
+    if (!id_out || capacity < (int)sizeof(ncclUniqueId)) return fail("snk_comm_unique_id: need a buffer of %d bytes", (int)sizeof(ncclUniqueId));
+    CHK(rccl_load());
+    ncclUniqueId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    if (bytes_out) *bytes_out = (int)sizeof(id);
+    return 0;
+}
+
+int snk_comm_init(snk_handle h, int nranks, int rank, const void *unique_id)
+{
+    if (!h) return fail("null handle");
+    if (nranks < 1 || rank < 0 || rank >= nranks || !unique_id) return fail("snk_comm_init: bad arguments");
+    CHK(snk_comm_destroy(h));
+    HIPCHK(hipSetDevice(h->device));
+    CHK(rccl_load());
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    NCCLCHK(g_rccl.CommInitRank(&comm, nranks, id, rank));
+    h->nccl_comm = comm;
+    h->comm_ranks = nranks; h->comm_rank = rank; h->have_transport = false;
+    return 0;
+}
+
+int snk_comm_init_transport(snk_handle h, int nranks, int rank, const snk_transport *t)
+{
+    if (!h) return fail("null handle");
+    if (nranks < 1 || rank < 0 || rank >= nranks || !t || !t->all_reduce_min_f64 || !t->all_gather || !t->all_to_all_v)
+        return fail("snk_comm_init_transport: bad arguments");
+    CHK(snk_comm_destroy(h));
+    h->transport = *t;
+    h->have_transport = true;
+    h->comm_ranks = nranks; h->comm_rank = rank;
+    return 0;
+}
+
+int snk_comm_destroy(snk_handle h)
+{
+    if (!h) return 0;
+    if (h->nccl_comm && g_rccl.CommDestroy) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        (void)g_rccl.CommDestroy((ncclComm_t)h->nccl_comm);
+    }
+    h->nccl_comm = nullptr;
+    h->have_transport = false;
+    h->comm_ranks = 0; h->comm_rank = 0;
+    return 0;
+}
+
+int snk_copy_to_host(void *dst_host, const void *src_dev, int64_t bytes)
+{
+    if (bytes < 0 || (bytes && (!dst_host || !src_dev))) return fail("snk_copy_to_host: bad arguments");
+    if (bytes) HIPCHK(hipMemcpy(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int snk_copy_to_device(void *dst_dev, const void *src_host, int64_t bytes)
+{
+    if (bytes < 0 || (bytes && (!dst_dev || !src_host))) return fail("snk_copy_to_device: bad arguments");
+    if (bytes) HIPCHK(hipMemcpy(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// One sharded step (see include/snk.h).  safe: the exact float64 sweep with per-shard thresholds and a host
+// check after every stage -- the path every rank takes again, together, when any rank's fast path reported a
+// list overflow (rare; the decision is made from the gathered status words, so all ranks agree).
+static int sharded_step(snk_engine *h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
+                        int64_t *path_out, int64_t *path_len_out, double *cost_out, bool safe, bool *redo)
+{
+    const int G = h->comm_ranks, me = h->comm_rank;
+    const int64_t R = row_offsets[n_utts];
+    std::vector<int64_t> ulo((size_t)G), uhi((size_t)G), rows_to((size_t)G), row0((size_t)G);
+    for (int r = 0; r < G; ++r) {
+        shard_plan(n_utts, G, r, &ulo[(size_t)r], &uhi[(size_t)r]);
+        row0[(size_t)r] = row_offsets[ulo[(size_t)r]];
+        rows_to[(size_t)r] = row_offsets[uhi[(size_t)r]] - row0[(size_t)r];
+    }
+    const int64_t r_own = rows_to[(size_t)me];
+    const int n_own = (int)(uhi[(size_t)me] - ulo[(size_t)me]);
+    int64_t slots = 0, Lmax = 0;
+    for (int r = 0; r < G; ++r) slots = std::max(slots, uhi[(size_t)r] - ulo[(size_t)r]);
+    for (int u = 0; u < n_utts; ++u) Lmax = std::max(Lmax, row_offsets[u + 1] - row_offsets[u]);
+    const int64_t rec = Lmax + 3;                                  // per slot: path length, cost bits, K-NN status, path
+    CHK(h->sh_d2.ensure((size_t)R * K * sizeof(double)));
+    CHK(h->sh_id.ensure((size_t)R * K * sizeof(int64_t)));
+    CHK(h->sh_bound.ensure((size_t)R * sizeof(double)));
+    CHK(h->sh_rd2.ensure((size_t)G * (r_own > 0 ? r_own : 1) * K * sizeof(double)));
+    CHK(h->sh_rid.ensure((size_t)G * (r_own > 0 ? r_own : 1) * K * sizeof(int64_t)));
+    CHK(h->sh_res.ensure((size_t)slots * rec * sizeof(int64_t)));
+    CHK(h->sh_resall.ensure((size_t)G * slots * rec * sizeof(int64_t)));
+    double *d2 = h->sh_d2.as<double>();
+    int64_t *ids = h->sh_id.as<int64_t>();
+    int n_status = 0;
+    struct PrecisionGuard { snk_engine *e; int v; ~PrecisionGuard() { e->precision = v; } } guard{h, h->precision};
+    if (safe) h->precision = 0;
+    int rc = 0;
+    do {
+        if (G > 1 && !safe) {
+            // bounds of the K-th nearest key, one all-reduce (MIN) of R doubles
+            double *bound = h->sh_bound.as<double>();
+            if (h->gs_ready) {
+                // own share of the rows against the replicated global sample; the others' entries stay +max
+                if (D != h->Dt) { rc = fail("query matrix has %d columns, database has %d", D, h->Dt); break; }
+                if ((rc = upload_batch_queries(h, Q, R, D))) break;
+                launch_fill_threshold(bound, R, R, DBL_MAX, h->stream);
+                const int64_t step = h->batch_rows > 0 ? h->batch_rows : r_own;
+                for (int64_t r0 = 0; r0 < r_own; r0 += step) {
+                    const int64_t rows = (r0 + step <= r_own) ? step : r_own - r0;
+                    const int64_t a = row0[(size_t)me] + r0;
+                    if ((rc = knn_device(h, h->Qall.as<double>() + a * D, rows, K, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                         nullptr, bound + a, true))) break;
+                }
+                if (rc) break;
+            } else {
+                if ((rc = knn_local_batch(h, "snk_sharded_knn_viterbi_batch", Q, row_offsets, n_utts, D, K, nullptr, bound,
+                                          nullptr, nullptr, &n_status))) break;
+            }
+            if ((rc = comm_all_reduce_min(h, bound, R))) break;
+            if ((rc = knn_local_batch(h, "snk_sharded_knn_viterbi_batch", nullptr, row_offsets, n_utts, D, K, bound, nullptr,
+                                      d2, ids, &n_status))) break;
+        } else {
+            if ((rc = knn_local_batch(h, "snk_sharded_knn_viterbi_batch", Q, row_offsets, n_utts, D, K, nullptr, nullptr,
+                                      d2, ids, safe ? nullptr : &n_status))) break;
+        }
+        // exchange: the (R, K) matrices are ordered by destination (contiguous utterance blocks)
+        std::vector<int64_t> soff((size_t)G), sb((size_t)G), roff((size_t)G), rb((size_t)G);
+        for (int p = 0; p < G; ++p) {
+            soff[(size_t)p] = row0[(size_t)p] * K * 8; sb[(size_t)p] = rows_to[(size_t)p] * K * 8;
+            roff[(size_t)p] = (int64_t)p * r_own * K * 8; rb[(size_t)p] = r_own * K * 8;
+        }
+        const double *d2_all = d2;
+        const int64_t *id_all = ids;
+        if (G > 1) {
+            if ((rc = comm_all_to_all_v(h, d2, soff.data(), sb.data(), h->sh_rd2.p, roff.data(), rb.data()))) break;
+            if ((rc = comm_all_to_all_v(h, ids, soff.data(), sb.data(), h->sh_rid.p, roff.data(), rb.data()))) break;
+            d2_all = h->sh_rd2.as<double>(); id_all = h->sh_rid.as<int64_t>();
+        }
+        // owner: merge, join costs, Viterbi of the owned utterances
+        std::vector<int64_t> own_off((size_t)n_own + 1, 0);
+        for (int u = 0; u <= n_own; ++u) own_off[(size_t)u] = row_offsets[ulo[(size_t)me] + u] - row0[(size_t)me];
+        std::vector<int64_t> own_path((size_t)(r_own > 0 ? r_own : 1)), own_len((size_t)(n_own > 0 ? n_own : 1));
+        std::vector<double> own_cost((size_t)(n_own > 0 ? n_own : 1));
+        if (n_own > 0) {
+            if ((rc = snk_merge_viterbi_batch_dev(h, d2_all, id_all, G, own_off.data(), n_own, K, own_path.data(), own_len.data(),
+                                                  own_cost.data()))) break;
+        } else {
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        // this rank's K-NN status words (deferred until here: the first host contact of the step)
+        int status = 0;
+        if (n_status > 0) {
+            std::vector<int> st((size_t)n_status);
+            HIPCHK(hipMemcpy(st.data(), h->res_status.p, (size_t)n_status * sizeof(int), hipMemcpyDeviceToHost));
+            for (int v : st) status |= v;
+        }
+        // results of every utterance to every rank: fixed-size records, one all-gather
+        std::vector<int64_t> mine((size_t)(slots * rec), 0);
+        for (int j = 0; j < n_own; ++j) {
+            int64_t *r = mine.data() + (size_t)j * rec;
+            r[0] = own_len[(size_t)j];
+            memcpy(&r[1], &own_cost[(size_t)j], sizeof(double));
+            r[2] = status;
+            memcpy(&r[3], own_path.data() + own_off[(size_t)j], (size_t)own_len[(size_t)j] * sizeof(int64_t));
+        }
+        if (n_own == 0 && slots > 0) mine[2] = status;
+        HIPCHK(hipMemcpyAsync(h->sh_res.p, mine.data(), mine.size() * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        if ((rc = comm_all_gather(h, h->sh_res.p, h->sh_resall.p, (int64_t)(mine.size() * sizeof(int64_t))))) break;
+        std::vector<int64_t> all((size_t)G * mine.size());
+        HIPCHK(hipMemcpyAsync(all.data(), h->sh_resall.p, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        bool any_bad = false;
+        for (int r = 0; r < G; ++r) {
+            const int64_t *blk = all.data() + (size_t)r * mine.size();
+            if (slots > 0 && blk[2] != 0) any_bad = true;
+            for (int64_t j = 0; j < uhi[(size_t)r] - ulo[(size_t)r]; ++j) {
+                const int64_t *q = blk + (size_t)j * rec;
+                const int64_t u = ulo[(size_t)r] + j;
+                if (q[2] != 0) any_bad = true;
+                path_len_out[u] = q[0];
+                memcpy(&cost_out[u], &q[1], sizeof(double));
+                memcpy(path_out + row_offsets[u], &q[3], (size_t)q[0] * sizeof(int64_t));
+            }
+        }
+        if (redo) *redo = any_bad && !safe;
+    } while (0);
+    collect_timers(h);
+    return rc;
+}
+
+int snk_sharded_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
+                                  int64_t *path_out, int64_t *path_len_out, double *cost_out)
+{
+    CHK(check_ready(h, true, true));
+    CHK(no_batch_in_flight(h, "snk_sharded_knn_viterbi_batch"));
+    HIPCHK(hipSetDevice(h->device));
+    if (h->comm_ranks < 1) return fail("snk_sharded_knn_viterbi_batch: no communicator (snk_comm_init)");
+    if (!Q || !row_offsets || n_utts < 1 || !path_out || !path_len_out || !cost_out)
+        return fail("snk_sharded_knn_viterbi_batch: null/empty argument");
+    bool redo = false;
+    CHK(sharded_step(h, Q, row_offsets, n_utts, D, K, path_out, path_len_out, cost_out, false, &redo));
+    if (redo) {
+        h->batch_redos += 1;
+        CHK(sharded_step(h, Q, row_offsets, n_utts, D, K, path_out, path_len_out, cost_out, true, nullptr));
+    }
     return 0;
 }
 

@@ -187,3 +187,78 @@ class ShardedSearch(object):
                 paths.append(row[2:2 + int(row[0])].astype(np.int64))
                 costs.append(row[1])
         return paths, np.array(costs)
+
+
+# ------------------------------------------------------------------------------------------------
+# The same sharded search with the collectives INSIDE libsnkhip.so (include/snk.h: snk_comm_init,
+# snk_sharded_knn_viterbi_batch): RCCL on the engine's own stream, no host synchronisation between the
+# bounds, the exchange and the merge.  torch.distributed only carries the 128-byte RCCL id to the ranks.
+# ------------------------------------------------------------------------------------------------
+def gloo_transport(world_size, group=None):
+    """A snickery_amd.engine.TransportCallbacks over torch.distributed collectives on HOST tensors: the
+    functional-test transport for several ranks sharing one GPU (RCCL refuses two ranks on one device)."""
+    from .engine import TransportCallbacks
+    G = int(world_size)
+
+    def all_reduce_min(a):
+        t = torch.from_numpy(np.array(a, dtype=np.float64))
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return t.numpy()
+
+    def all_gather(a):
+        t = torch.from_numpy(np.array(a, dtype=np.uint8))
+        outs = [torch.empty_like(t) for _ in range(G)]
+        dist.all_gather(outs, t, group=group)
+        return torch.cat(outs).numpy()
+
+    def all_to_all_v(send, soff, sbytes, roff, rbytes, recv_total):
+        ins = [torch.from_numpy(np.array(send[soff[p]:soff[p] + sbytes[p]], dtype=np.uint8)) for p in range(G)]
+        outs = [torch.empty(rbytes[p], dtype=torch.uint8) for p in range(G)]
+        # gloo has no all_to_all on every build: one broadcast-free exchange from point-to-point pairs
+        me = dist.get_rank(group)
+        reqs = []
+        for p in range(G):
+            if p == me:
+                outs[p].copy_(ins[p])
+                continue
+            dst = dist.get_global_rank(group, p) if group is not None else p
+            if sbytes[p]:
+                reqs.append(dist.isend(ins[p], dst, group=group))
+            if rbytes[p]:
+                reqs.append(dist.irecv(outs[p], dst, group=group))
+        for r in reqs:
+            r.wait()
+        out = np.zeros(recv_total, dtype=np.uint8)
+        for p in range(G):
+            out[roff[p]:roff[p] + rbytes[p]] = outs[p].numpy()
+        return out
+
+    return TransportCallbacks(G, all_reduce_min, all_gather, all_to_all_v, torch.cuda.synchronize)
+
+
+class LibraryShardedSearch(object):
+    """Row-sharded search through snk_sharded_knn_viterbi_batch.  `engine` holds this rank's shard
+    (upload_target_only + set_shard), the full join matrix (upload_join_only) and, optionally, the
+    replicated global sample (upload_global_sample) -- all before set_weights.
+    transport 'rccl': the library's own RCCL communicator (one GPU per rank); 'gloo': host-staged
+    collectives for functional tests."""
+
+    def __init__(self, engine, rank=None, world_size=None, group=None, transport='rccl'):
+        self.engine = engine
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world_size is None else world_size
+        if transport == 'rccl':
+            box = [engine.comm_unique_id() if self.rank == 0 else None]
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+            engine.comm_init(self.world, self.rank, box[0])
+        else:
+            engine.comm_init_transport(self.world, self.rank, gloo_transport(self.world, group))
+
+    def knn_viterbi_batch(self, utterances, K):
+        return self.engine.sharded_knn_viterbi_batch(utterances, K)
+
+
+def global_sample(F_unw, stride=16):
+    """Every stride-th unit of the whole database: what every rank uploads with upload_global_sample."""
+    return np.ascontiguousarray(F_unw[::int(stride)])

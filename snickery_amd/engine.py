@@ -84,6 +84,16 @@ _SIGNATURES = {
     'snk_upload_frames': (ctypes.c_int, [ctypes.c_void_p, _c_f32p, _c_f64p, ctypes.c_int64, ctypes.c_int]),
     'snk_concat_fragments': (ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_i64p, _c_i64p, ctypes.c_int64, ctypes.c_int,
                                             ctypes.c_int, _c_f64p, _c_f64p, _c_f64p]),
+    'snk_comm_unique_id': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    'snk_comm_init': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'snk_comm_init_transport': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'snk_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'snk_shard_plan': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_i64p, _c_i64p]),
+    'snk_upload_global_sample': (ctypes.c_int, [ctypes.c_void_p, _c_f32p, ctypes.c_int64, ctypes.c_int]),
+    'snk_sharded_knn_viterbi_batch': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int, ctypes.c_int,
+                                                     ctypes.c_int, _c_i64p, _c_i64p, _c_f64p]),
+    'snk_copy_to_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+    'snk_copy_to_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     'snk_set_option': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]),
     'snk_get_info': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, _c_f64p]),
     'snk_selftest_mfma': (ctypes.c_int, [ctypes.c_void_p, _c_f64p]),
@@ -460,6 +470,49 @@ class HipSearchEngine(object):
         return [paths[offs[u]:offs[u] + plen[u]].copy() for u in range(len(lengths))], cost
 
     # -- waveform side ----------------------------------------------------------
+    # ---- collectives inside the library (include/snk.h: snk_comm_*) ------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes from ncclGetUniqueId: rank 0 makes them, every rank passes them to comm_init."""
+        lib = load_library()
+        buf = ctypes.create_string_buffer(128)
+        n = ctypes.c_int(0)
+        if lib.snk_comm_unique_id(buf, 128, ctypes.byref(n)):
+            raise SnkError(lib.snk_last_error().decode())
+        return buf.raw[:n.value]
+
+    def comm_init(self, nranks, rank, unique_id):
+        """RCCL communicator of this engine (ncclCommInitRank; librccl is loaded here)."""
+        self._check(self._lib.snk_comm_init(self._h, int(nranks), int(rank), ctypes.c_char_p(bytes(unique_id))))
+
+    def comm_init_transport(self, nranks, rank, transport):
+        """Caller-provided collectives (a TransportCallbacks object); kept alive with the engine."""
+        self._transport = transport
+        self._check(self._lib.snk_comm_init_transport(self._h, int(nranks), int(rank), ctypes.byref(transport.struct)))
+
+    def comm_destroy(self):
+        self._check(self._lib.snk_comm_destroy(self._h))
+        self._transport = None
+
+    def upload_global_sample(self, sample_unweighted):
+        """Every s-th unit of the WHOLE database (replicated on every rank); before set_weights."""
+        S = np.ascontiguousarray(sample_unweighted, dtype=np.float32)
+        self._check(self._lib.snk_upload_global_sample(self._h, _ptr(S, _c_f32p), S.shape[0], S.shape[1]))
+
+    def sharded_knn_viterbi_batch(self, utterances, n_candidates):
+        """snk_sharded_knn_viterbi_batch: every rank passes the same batch; returns the paths and costs of
+        ALL utterances on every rank."""
+        b = _as_batch(utterances)
+        n = len(b)
+        total = int(b.offsets[-1])
+        path = np.empty((max(total, 1),), dtype=np.int64)
+        plen = np.zeros(n, dtype=np.int64)
+        cost = np.zeros(n, dtype=np.float64)
+        self._check(self._lib.snk_sharded_knn_viterbi_batch(self._h, _ptr(b.Q, _c_f64p), _ptr(b.offsets, _c_i64p), n,
+                                                            b.Q.shape[1], int(n_candidates), _ptr(path, _c_i64p),
+                                                            _ptr(plen, _c_i64p), _ptr(cost, _c_f64p)))
+        return [path[int(b.offsets[u]):int(b.offsets[u]) + int(plen[u])].copy() for u in range(n)], cost
+
     def upload_frames(self, spec, fzv):
         """spec (rows, 3*H) float32 = [mag | real | imag], fzv (rows, 2) float64 = [f0_interp, vuv]."""
         spec = np.ascontiguousarray(spec, dtype=np.float32)
@@ -506,3 +559,82 @@ class HipSearchEngine(object):
         v = ctypes.c_double(0.0)
         self._check(self._lib.snk_selftest_mfma(self._h, ctypes.byref(v)))
         return float(v.value)
+
+
+def shard_plan(n_items, nranks, rank):
+    """snk_shard_plan: contiguous block [lo, hi) of rank (the library's own split; dist.shard_bounds is its twin)."""
+    lib = load_library()
+    lo, hi = ctypes.c_int64(0), ctypes.c_int64(0)
+    if lib.snk_shard_plan(int(n_items), int(nranks), int(rank), ctypes.byref(lo), ctypes.byref(hi)):
+        raise SnkError(lib.snk_last_error().decode())
+    return lo.value, hi.value
+
+
+class _TransportStruct(ctypes.Structure):
+    _fields_ = [('ctx', ctypes.c_void_p),
+                ('all_reduce_min_f64', ctypes.c_void_p),
+                ('all_gather', ctypes.c_void_p),
+                ('all_to_all_v', ctypes.c_void_p)]
+
+
+class TransportCallbacks(object):
+    """A snk_transport whose collectives are Python callables working on HOST numpy buffers: the device
+    buffers the library hands over are copied to the host (snk_copy_to_host), given to
+
+        all_reduce_min(array f64) -> array          all_gather(bytes array) -> concatenated bytes array
+        all_to_all_v(send bytes array, send_off, send_bytes, recv_off, recv_bytes, recv_total) -> bytes array
+
+    and the results copied back.  For functional tests (several ranks on one GPU, gloo underneath): the
+    production transport is RCCL on the device buffers (comm_init)."""
+
+    _AR = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+    _AG = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+    _AA = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _c_i64p, _c_i64p, ctypes.c_void_p, _c_i64p,
+                           _c_i64p, ctypes.c_void_p)
+
+    def __init__(self, nranks, all_reduce_min, all_gather, all_to_all_v, device_sync):
+        lib = load_library()
+        G = int(nranks)
+
+        def to_host(ptr, nbytes):
+            a = np.empty(int(nbytes), dtype=np.uint8)
+            if nbytes and lib.snk_copy_to_host(a.ctypes.data_as(ctypes.c_void_p), ptr, int(nbytes)):
+                raise SnkError(lib.snk_last_error().decode())
+            return a
+
+        def to_dev(ptr, a):
+            a = np.ascontiguousarray(a).view(np.uint8)
+            if a.size and lib.snk_copy_to_device(ptr, a.ctypes.data_as(ctypes.c_void_p), a.size):
+                raise SnkError(lib.snk_last_error().decode())
+
+        def guard(fn):
+            def wrapped(*args):
+                try:
+                    device_sync()              # the buffers were produced on the engine's stream
+                    fn(*args)
+                    return 0
+                except Exception:              # an exception must not unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return wrapped
+
+        def ar(_ctx, buf, n, _stream):
+            out = all_reduce_min(to_host(buf, 8 * n).view(np.float64))
+            to_dev(buf, np.asarray(out, dtype=np.float64))
+
+        def ag(_ctx, send, recv, nbytes, _stream):
+            to_dev(recv, all_gather(to_host(send, nbytes)))
+
+        def aa(_ctx, send, soff, sbytes, recv, roff, rbytes, _stream):
+            so = [int(soff[p]) for p in range(G)]; sb = [int(sbytes[p]) for p in range(G)]
+            ro = [int(roff[p]) for p in range(G)]; rb = [int(rbytes[p]) for p in range(G)]
+            send_total = max(o + b for o, b in zip(so, sb))
+            recv_total = max(o + b for o, b in zip(ro, rb))
+            out = all_to_all_v(to_host(send, send_total), so, sb, ro, rb, recv_total)
+            to_dev(recv, out)
+
+        self._keep = (self._AR(guard(ar)), self._AG(guard(ag)), self._AA(guard(aa)))
+        self.struct = _TransportStruct(None, ctypes.cast(self._keep[0], ctypes.c_void_p),
+                                       ctypes.cast(self._keep[1], ctypes.c_void_p),
+                                       ctypes.cast(self._keep[2], ctypes.c_void_p))

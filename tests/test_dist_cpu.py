@@ -140,3 +140,19 @@ def test_sharded_search_gloo_world2():
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     assert out[0] is True and out[1] is True
+
+
+def test_library_shard_plan_is_the_twin_of_dist_shard_bounds():
+    """snk_shard_plan (the split snk_sharded_knn_viterbi_batch uses for database rows and utterance blocks)
+    against dist.shard_bounds (the split of the torch-side path): same blocks for every (n, world, rank),
+    so the two exchange paths move the same rows to the same owners.  No GPU: a pure function of the C ABI."""
+    import snickery_amd
+    from snickery_amd.dist import shard_bounds
+    from snickery_amd.engine import shard_plan
+    for n in (0, 1, 2, 7, 8, 31, 32, 100, 1048576, 1500001):
+        for world in (1, 2, 3, 4, 8):
+            blocks = [shard_plan(n, world, r) for r in range(world)]
+            assert blocks == [shard_bounds(n, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+    with pytest.raises(snickery_amd.SnkError):
+        shard_plan(10, 2, 2)

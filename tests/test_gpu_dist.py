@@ -63,6 +63,100 @@ def test_sharded_search_two_ranks_one_gpu():
     assert out[0] is True and out[1] is True
 
 
+def _lib_worker(rank, world, port, out, use_sample):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import snk_oracle as o
+    import snickery_amd
+    from snickery_amd.dist import HipShardEngine, LibraryShardedSearch, ShardedSearch, global_sample, shard_bounds
+    from snickery_amd.engine import shard_plan
+    N, Dt, Dj, K = 60001, 61, 40, 25
+    F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=5)
+    wt = np.full(Dt, 0.4)
+    wj = np.full(Dj, 0.05)
+    F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
+    lo, hi = shard_bounds(N, world, rank)
+    ok = (lo, hi) == shard_plan(N, world, rank)
+    torch.cuda.set_device(0)
+    eng = snickery_amd.HipSearchEngine(0)
+    eng.upload_target_only(F_unw[lo:hi])
+    eng.upload_join_only(JC_unw)
+    eng.set_shard(lo, N)
+    if use_sample:
+        eng.upload_global_sample(global_sample(F_unw, 4))
+    eng.set_weights(wt, wj)
+    lib_search = LibraryShardedSearch(eng, transport='gloo')
+    utts = [o.synthetic_targets(F_unw, T, seed=s) * wt for s, T in [(1, 40), (2, 25), (3, 33), (4, 2), (5, 61)]]
+    for batch in (utts, utts[1:2]):                      # second batch: rank 1 owns nothing
+        paths, costs = lib_search.knn_viterbi_batch(batch, K)
+        ok = ok and len(paths) == len(batch)
+        for u, U in enumerate(batch):
+            c, dd = o.knn_bruteforce(F, U, K)
+            p, cost = o.viterbi(c, dd, E, S)
+            ok = ok and list(paths[u]) == p and costs[u] == cost
+    # the torch-side path (dist.py collectives) gives the same answer
+    eng.comm_destroy()
+    tpaths, tcosts = ShardedSearch(HipShardEngine(eng, torch.device('cuda', 0))).knn_viterbi_batch(utts, K)
+    lpaths, lcosts = LibraryShardedSearch(eng, transport='gloo').knn_viterbi_batch(utts, K)
+    ok = ok and all(np.array_equal(a, b) for a, b in zip(tpaths, lpaths)) and np.array_equal(tcosts, lcosts)
+    # a list overflow on the fast path of ONE rank makes ALL ranks redo the step together (exact sweep)
+    if rank == 0:
+        eng.set_option('list_capacity', 64)
+        eng.set_option('sample_fraction', 1.0 / 64)
+    before = eng.info('batch_redos')
+    paths, costs = LibraryShardedSearch(eng, transport='gloo').knn_viterbi_batch(utts, K)
+    ok = ok and all(np.array_equal(a, b) for a, b in zip(paths, lpaths)) and np.array_equal(costs, lcosts)
+    redone = eng.info('batch_redos') - before
+    flags = [None] * world
+    dist.all_gather_object(flags, int(redone))
+    ok = ok and len(set(flags)) == 1                     # every rank took the same decision
+    out[rank] = bool(ok)
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('use_sample', [False, True])
+def test_library_collectives_two_ranks_one_gpu(use_sample):
+    """snk_sharded_knn_viterbi_batch (collectives inside libsnkhip.so) over the caller-provided transport
+    (gloo through host memory): two ranks, shards of one GPU, ragged batch, a rank owning nothing, with and
+    without the replicated global sample; equal to the oracle and to the torch-side path of dist.py."""
+    port = 27500 + (os.getpid() % 2000) + int(use_sample)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_lib_worker, args=(2, port, out, use_sample), nprocs=2, join=True)
+    assert out[0] is True and out[1] is True
+
+
+def test_library_rccl_communicator_single_rank():
+    """The RCCL transport itself, as far as one GPU allows: ncclCommInitRank with one rank, then the
+    sharded entry point (its collectives degenerate to copies) against the unsharded search."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import snk_oracle as o
+    import snickery_amd
+    N, Dt, Dj, K = 40000, 61, 40, 20
+    F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=8)
+    wt, wj = np.full(Dt, 0.4), np.full(Dj, 0.05)
+    eng = snickery_amd.HipSearchEngine(0)
+    eng.upload_db(F_unw, JC_unw)
+    eng.set_shard(0, N)
+    eng.set_weights(wt, wj)
+    utts = [o.synthetic_targets(F_unw, T, seed=s) * wt for s, T in [(1, 40), (2, 25)]]
+    ref_paths, ref_costs = eng.knn_viterbi_batch(utts, K)
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128
+    eng.comm_init(1, 0, uid)
+    paths, costs = eng.sharded_knn_viterbi_batch(utts, K)
+    assert all(np.array_equal(a, b) for a, b in zip(paths, ref_paths)) and np.array_equal(costs, ref_costs)
+    eng.comm_destroy()
+    with pytest.raises(snickery_amd.SnkError):
+        eng.sharded_knn_viterbi_batch(utts, K)           # no communicator
+    eng.close()
+
+
 @pytest.mark.parametrize('nproc,shards,sharding', [(2, 0, 'db-rows/2 + all-to-all of local top-K'),
                                                    (4, 2, 'db-rows/2 + all-to-all of local top-K x 2 replica groups'),
                                                    (2, 1, '2 independent replicas')])
