@@ -133,6 +133,44 @@ def cpu_baseline(F_unw, JC_unw, wt, wj, K, sample_frames, seed, all_cores=True):
     return out, (cand, d, path, cost, U)
 
 
+def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')), Dt=61, Dj=151, T=600, me=6):
+    """BASELINE configs[0] / configs[2] (greedy_joint_search, synth_simple.py:458-503) at their workload sizes:
+    B1 = 65 536 units (the README demo voice), B3 = 1.5 M units (IS2018_nick_simplified.cfg), magphase-60 widths,
+    multiepoch 6, search_epsilon 0, one 600-frame utterance = 100 scans of the whole database.  Extra fields of the
+    JSON line (never `value`): device time per step from the engine's HIP events, frames/s from the wall clock,
+    fraction of the 8 TB/s HBM peak on the scan's algorithmic bytes (Dj + Dt) * 4 * N per step."""
+    import snickery_amd
+    out = {}
+    for N, name in configs:
+        F_unw, JC_unw = synthetic_db(N, Dt, Dj, seed=0)
+        wt, wj = np.full(Dt, 0.4), np.full(Dj, 0.05)
+        eng = snickery_amd.HipSearchEngine(device)
+        eng.upload_db(F_unw, JC_unw)
+        eng.set_weights(wt, wj)
+        eng.set_greedy_layout(me, False, 0)
+        U = synthetic_targets(F_unw, T, seed=1) * wt
+        eng.greedy(U)
+        eng.reset_timers()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            path = eng.greedy(U)
+        dt = (time.perf_counter() - t0) / reps
+        steps = T // me
+        ms, launches = eng.timers()['greedy_steps']
+        us_step = ms / max(launches, 1) / steps * 1e3
+        bytes_step = float(N) * (Dj + Dt) * 4.0
+        out[name] = {'units': N, 'multiepoch': me, 'frames': T, 'steps': steps, 'us_per_step': us_step,
+                     'frames_per_s': T / dt, 'ms_per_utterance': dt * 1e3,
+                     'roofline': {'bound': 'hbm', 'achieved': bytes_step / (us_step * 1e-6) / 1e9, 'peak': 8000.0,
+                                  'unit': 'GB/s', 'frac': bytes_step / (us_step * 1e-6) / 8e12,
+                                  'algorithmic_bytes_per_step': bytes_step},
+                     'path_head': [int(v) for v in path[:4]]}
+        eng.close()
+        del F_unw, JC_unw
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -147,6 +185,7 @@ def main():
     ap.add_argument('--cpu-sample-frames', type=int, default=600,
                     help='frames of the CPU baseline sample (600 = one utterance of the workload, ~15 s on one core)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-greedy', action='store_true', help='skip the greedy configs (extra fields greedy_b1 / greedy_b3)')
     ap.add_argument('--no-cpu-all-cores', action='store_true', help='skip the all-cores leg of the CPU baseline')
     ap.add_argument('--viterbi-mode', type=int, default=2, choices=(0, 1, 2),
                     help='2: the engine default (batches: f32 matrix lower bounds + verified sparse exact recursion); '
@@ -392,11 +431,16 @@ def main():
             gp, gc, gcand, gdist = eng.knn_viterbi(ref[4], K, return_candidates=True)
             out['cpu_baseline']['gpu_matches_cpu_path'] = bool(gp == ref[2])
             out['cpu_baseline']['gpu_matches_cpu_candidates'] = bool(np.array_equal(gcand, ref[0]))
+        if world == 1 and not args.no_greedy:
+            eng.close()                     # free the B* database before the greedy voices are built
+            eng = None
+            out['extra'] = greedy_extra(local_rank)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    if eng is not None:
+        eng.close()
 
 
 if __name__ == '__main__':
