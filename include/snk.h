@@ -140,8 +140,12 @@ int snk_set_greedy_layout(snk_handle h, int multiepoch, int last_frame_as_target
  *   Q (T, Dt) float64 weighted targets (NOT yet reshaped by multiepoch)
  *   path_out  (T / multiepoch) int64 indices into the windowed DB
  *   dist_out  (T / multiepoch) float64 Euclidean distance of each pick (may be NULL)
- *   eps: search_epsilon; the engine always returns the exact nearest neighbour, which
- *        satisfies the reference's (1+eps) guarantee for every eps >= 0. */
+ *   eps: search_epsilon (`joint_tree.query(..., eps=...)`, :488-490; shipped as 10.0 in
+ *        config/slt_simplified_mini.cfg:92).  0: the exact nearest neighbour, lowest index on exact ties.
+ *        >= 1e-3 on the float32 scan (option greedy_mode 1, or any batch): the window with the smallest
+ *        FLOAT32 total is returned without re-evaluation -- it lies within 1e-3 of the nearest distance,
+ *        inside the (1 + eps) contract; dist_out still holds the pick's exact distance.  The exact scan
+ *        (one utterance, default) returns the exact neighbour for every eps. */
 int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_state,
                double eps, int64_t *path_out, double *dist_out, int64_t *nsteps_out);
 /* snk_greedy for several utterances in one call (balance_stream_weights.py:82-92 runs the greedy search

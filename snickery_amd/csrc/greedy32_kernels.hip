@@ -1,0 +1,755 @@
+// Greedy joint search, second form: float32 prefilter scan + exact float64 decision, ONE launch per
+// utterance group.
+//
+// Replaces the same reference code as greedy_kernels.hip (greedy_joint_search, script/synth_simple.py:458-503;
+// get_tree_for_greedy_search :190-229).  What changed against greedy_step_kernel:
+//
+//  * The scan accumulates every window's squared distance in FLOAT32 (x*w - ref and the square as two FMAs
+//    per column; the float64 form needs convert + multiply + subtract + multiply + add at a quarter of the
+//    rate and co-limited the HBM stream).  A float32 total d~ lies within a PROVEN distance of the canonical
+//    float64 total d:
+//        |d~ - d| <= E(d) = 6 u V sqrt(d) + (n + 8) u d,   u = 2^-24, n = scan columns, V = ||reference vector||
+//    (operand roundings of w, ref and x*w - ref: |diff~ - diff| <= u (2 |ref| + 2 |diff|); squares and the
+//    n-term FMA chain; Cauchy-Schwarz over the columns).  Only windows with d~ <= tau = min d~ + E(min) + E(tau)
+//    can be the exact nearest neighbour or tie with it.  Usually that is ONE window: it wins without any
+//    float64 arithmetic.  Two or more (duplicated speech, near ties) are decided by their canonical float64
+//    distances, lowest index on exact ties -- the oracle's rule.  Every lane keeps its two best windows and
+//    the value of its third, every workgroup publishes its two best and its third value; if a third value
+//    reaches tau the step cannot be decided from what was kept: the launch stops and reports the step, and
+//    the caller finishes the utterance with the exact scan (mass duplicates: digital silence).
+//  * search_epsilon > 0 (synth_simple.py:488-490: `joint_tree.query(..., eps=...)`, shipped as 10.0 in
+//    config/slt_simplified_mini.cfg:92): any window within (1 + eps) of the nearest distance is a valid
+//    answer, and the float32 minimum is within 2 E of it -- below 1e-3 relative -- so for eps >= 1e-3 the
+//    float32 minimum (lowest index among equal float32 totals) is returned and nothing is re-evaluated.
+//  * ONE persistent launch walks all steps of up to three utterances: between two steps the workgroup that
+//    arrives last decides the step, appends to the path, writes the next step's (weight, reference) table and
+//    releases the others through a generation word (sc1 stores, drained, then the flag; sc1 polls and sc1
+//    table loads on the other side -- MI355X_MICROARCH.md, valid hand-off forms).  A launch per step cost
+//    more than the scan itself at 65 536 units.
+//
+// Data layout, request ring, LDS target blocks and chunk order are those of greedy_kernels.hip.
+#include "greedy_common.h"
+
+namespace snk {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define G32_W 64
+#define G32_MAXW 8
+#define G32_UB 3              // utterances per scan: (w, ref0, ref1, ref2) = 16 table bytes per column
+
+struct G32Rec {               // what a workgroup publishes per utterance and step
+    float v1, v2, v3, pad;
+    int64_t a1, a2;
+};
+
+#define G32_LIST 4096          // candidates one second-phase round can take per utterance
+struct G32Ctl {               // second-phase hand-off (global memory, sc1 accesses)
+    double tau[G32_UB];
+    int64_t pending[G32_UB];
+    unsigned int list_count[G32_UB];
+    unsigned int need, list_over;
+};
+
+struct Top3 {                 // two best windows (value, index) and the third value; indices fit 31 bits (snk_upload_db)
+    float v1, v2, v3;
+    int a1, a2;
+};
+__device__ __forceinline__ void top3_init(Top3 &t) { t.v1 = t.v2 = t.v3 = __builtin_inff(); t.a1 = t.a2 = INT32_MAX; }
+// (value, index) order: smaller value, then smaller index -- so that equal float32 totals keep the lowest index first
+__device__ __forceinline__ bool lt_vi(float va, int64_t ia, float vb, int64_t ib) { return va < vb || (va == vb && ia < ib); }
+__device__ __forceinline__ void top3_push(Top3 &t, float v, int i)
+{
+    if (lt_vi(v, i, t.v1, t.a1)) { t.v3 = t.v2; t.v2 = t.v1; t.a2 = t.a1; t.v1 = v; t.a1 = i; }
+    else if (lt_vi(v, i, t.v2, t.a2)) { t.v3 = t.v2; t.v2 = v; t.a2 = i; }
+    else if (v < t.v3) t.v3 = v;
+}
+__device__ __forceinline__ void top3_merge(Top3 &t, const Top3 &o)
+{
+    top3_push(t, o.v1, o.a1);
+    top3_push(t, o.v2, o.a2);
+    if (o.v3 < t.v3) t.v3 = o.v3;
+}
+__device__ __forceinline__ Top3 top3_shfl_xor(const Top3 &t, int m)
+{
+    Top3 o;
+    o.v1 = __shfl_xor(t.v1, m, 64); o.v2 = __shfl_xor(t.v2, m, 64); o.v3 = __shfl_xor(t.v3, m, 64);
+    o.a1 = __shfl_xor(t.a1, m, 64); o.a2 = __shfl_xor(t.a2, m, 64);
+    return o;
+}
+
+// canonical float64 squared distance of window i to the step's reference of utterance u (the oracle's order:
+// join columns, then target columns epoch by epoch; separately rounded sub / mul / add)
+__device__ double g32_exact_d2(const GreedyArgs &a, int u, int64_t step, int64_t prev_row, bool prev_is_current, int64_t i)
+{
+    double acc_j = 0.0, acc_t = 0.0;
+    const int col0 = prev_is_current ? a.cur_col0 : a.prev_col0;
+    const int64_t row0 = prev_is_current ? a.cur_row0 : a.prev_row0;
+    const float *xr = a.JC_unw + (a.prev_row0 + i) * a.Jp + a.prev_col0;
+    const float *rr = a.JC_unw + (row0 + (prev_row >= 0 ? prev_row : 0)) * a.Jp + col0;
+    for (int c = 0; c < a.jdim; ++c) {
+        const double xw = __dmul_rn((double)xr[c], a.wj[a.prev_col0 + c]);
+        const double ref = prev_row >= 0 ? __dmul_rn((double)rr[c], a.wj[col0 + c]) : 0.0;
+        const double d = __dsub_rn(xw, ref);
+        acc_j = __dadd_rn(acc_j, __dmul_rn(d, d));
+    }
+    for (int k = 0; k < a.nep; ++k) {
+        const float *fr = a.F_unw + (i + a.ep[k]) * a.Fp;
+        const double *q = a.Q + (a.q_off[u] + step * a.me + a.ep[k]) * a.Dt;
+        for (int c = 0; c < a.Dt; ++c) {
+            const double d = __dsub_rn(__dmul_rn((double)fr[c], a.wt[c]), q[c]);
+            acc_t = __dadd_rn(acc_t, __dmul_rn(d, d));
+        }
+    }
+    return __dadd_rn(acc_j, acc_t);
+}
+
+// The same total computed by a whole wavefront: the per-column terms fl(fl(x w - ref)^2) in parallel (coalesced
+// loads), then summed by ONE lane in the canonical order -- bit-identical to g32_exact_d2, without 1 000 dependent
+// memory round trips.  terms: (jdim + nep Dt) doubles of LDS private to the wavefront.
+__device__ double g32_exact_d2_wave(const GreedyArgs &a, int u, int64_t step, int64_t prev_row, bool prev_is_current, int64_t i,
+                                    double *terms, int lane)
+{
+    const int col0 = prev_is_current ? a.cur_col0 : a.prev_col0;
+    const int64_t row0 = prev_is_current ? a.cur_row0 : a.prev_row0;
+    const float *xr = a.JC_unw + (a.prev_row0 + i) * a.Jp + a.prev_col0;
+    const float *rr = a.JC_unw + (row0 + (prev_row >= 0 ? prev_row : 0)) * a.Jp + col0;
+    for (int c = lane; c < a.jdim; c += 64) {
+        const double xw = __dmul_rn((double)xr[c], a.wj[a.prev_col0 + c]);
+        const double ref = prev_row >= 0 ? __dmul_rn((double)rr[c], a.wj[col0 + c]) : 0.0;
+        const double d = __dsub_rn(xw, ref);
+        terms[c] = __dmul_rn(d, d);
+    }
+    for (int k = 0; k < a.nep; ++k) {
+        const float *fr = a.F_unw + (i + a.ep[k]) * a.Fp;
+        const double *q = a.Q + (a.q_off[u] + step * a.me + a.ep[k]) * a.Dt;
+        for (int c = lane; c < a.Dt; c += 64) {
+            const double d = __dsub_rn(__dmul_rn((double)fr[c], a.wt[c]), q[c]);
+            terms[a.jdim + k * a.Dt + c] = __dmul_rn(d, d);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wavefront's own LDS writes, in order
+    __builtin_amdgcn_wave_barrier();
+    double d2 = 0.0;
+    if (lane == 0) {
+        double acc_j = 0.0, acc_t = 0.0;
+        for (int c = 0; c < a.jdim; ++c) acc_j = __dadd_rn(acc_j, terms[c]);
+        const int nt = a.nep * a.Dt;
+        for (int c = 0; c < nt; ++c) acc_t = __dadd_rn(acc_t, terms[a.jdim + c]);
+        d2 = __dadd_rn(acc_j, acc_t);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return __shfl(d2, 0, 64);
+}
+
+// The float32 table of a step: per scan column, in chunk order, (w, ref0, ref1, ref2) -- and behind it, per
+// utterance, the squared norm of the reference vector (float64, for the error bound).  Written with sc1 stores
+// by the workgroup that decides the previous step.
+__device__ void g32_write_table(const GreedyArgs &a, int64_t step, const int64_t (&prev_row)[G32_UB], bool prev_is_current,
+                                float *__restrict__ tab, double *__restrict__ vnorm2, double *red, int tid, int nthreads)
+{
+    const int jch = greedy_join_chunks(a), tch = greedy_target_chunks(a);
+    const int nT = a.nep * tch, n = (jch + nT) * GR_CC;
+    const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(tab, 0, n * 16, 0x00020000);
+    double n2[G32_UB];
+#pragma unroll
+    for (int u = 0; u < G32_UB; ++u) n2[u] = 0.0;
+    for (int e = tid; e < n; e += nthreads) {
+        const int c = e / GR_CC, cc = e % GR_CC;
+        double w = 0.0, ref[G32_UB];
+#pragma unroll
+        for (int u = 0; u < G32_UB; ++u) ref[u] = 0.0;
+        int idx;
+        if (greedy_chunk_slot(a, jch, nT, c, &idx)) {
+            const int col = idx * GR_CC + cc;
+            if (col < a.jdim) {
+                w = a.wj[a.prev_col0 + col];
+                const int col0 = prev_is_current ? a.cur_col0 : a.prev_col0;
+                const int64_t row0 = prev_is_current ? a.cur_row0 : a.prev_row0;
+#pragma unroll
+                for (int u = 0; u < G32_UB; ++u)
+                    if (u < a.nu && step < a.nsteps_u[u] && prev_row[u] >= 0)
+                        ref[u] = __dmul_rn((double)a.JC_unw[(row0 + prev_row[u]) * a.Jp + col0 + col], a.wj[col0 + col]);
+            }
+        } else {
+            const int k = idx / tch, col = (idx % tch) * GR_CC + cc;
+            if (col < a.Dt) {
+                w = a.wt[col];
+#pragma unroll
+                for (int u = 0; u < G32_UB; ++u)
+                    if (u < a.nu && step < a.nsteps_u[u])
+                        ref[u] = a.Q[(a.q_off[u] + step * a.me + a.ep[k]) * a.Dt + col];
+            }
+        }
+        // ONE 16-byte sc1 (agent-scope, write-through) store per column: the readers are other compute units,
+        // moments later, through 16-byte sc1 loads (dword sc1 stores are one fabric write each: 8 704 of them
+        // cost more than the scan of a 65 536-unit voice)
+        u32x4 bits = {__builtin_bit_cast(unsigned int, (float)w), __builtin_bit_cast(unsigned int, (float)ref[0]),
+                      __builtin_bit_cast(unsigned int, (float)ref[1]), __builtin_bit_cast(unsigned int, (float)ref[2])};
+        __builtin_amdgcn_raw_buffer_store_b128(bits, tres, e * 16, 0, 16);
+#pragma unroll
+        for (int u = 0; u < G32_UB; ++u) n2[u] += ref[u] * ref[u];
+    }
+    // squared norms of the references: block sum (any order: it only scales an error bound, +1 % is added there)
+#pragma unroll
+    for (int u = 0; u < G32_UB; ++u) {
+        if (u >= a.nu) break;                                     // uniform
+        red[tid] = n2[u];
+        __syncthreads();
+        for (int off = 256; off > 0; off >>= 1) {
+            if (tid < off && tid + off < nthreads) red[tid] += red[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) __hip_atomic_store(&vnorm2[u], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
+}
+
+// error bound of a float32 total (see the file header); V2 = squared norm of the reference vector
+__device__ __forceinline__ double g32_err(double d, double V2, int ncols)
+{
+    const double u = 5.9604644775390625e-08;
+    return 6.0 * u * sqrt(V2 * d) * 1.01 + (double)(ncols + 8) * u * d;
+}
+
+template <bool IN_LDS>
+__global__ void __launch_bounds__(G32_W * G32_MAXW)
+greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2, int approx, int use_nt, int lds_bytes,
+                float *__restrict__ tabs, double *__restrict__ vnorm2, G32Rec *__restrict__ blk,
+                unsigned int *__restrict__ arrive, unsigned int *__restrict__ arrive2, unsigned int *__restrict__ gen,
+                G32Ctl *__restrict__ ctl, int64_t *__restrict__ clist_g, int64_t *__restrict__ path,
+                int64_t *__restrict__ status)
+{
+    extern __shared__ __align__(16) char lds[];          // table | one target block per wavefront (lds_mode 1)
+    __shared__ int is_last, gen_seen;
+    int collect_rounds = 0;                               // second-phase rounds so far (the same in every workgroup)
+    const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool in_lds = IN_LDS;
+    const int jch = greedy_join_chunks(a), tch = greedy_target_chunks(a);
+    const int nT = a.nep * tch, n_chunks = jch + nT, JQ = jch * 8, FQ = tch * 8;
+    const int ncols = n_chunks * GR_CC;
+    const int pitch = tch * GR_CC + 4;
+    const int nB = a.me > 1 ? tch : 0;
+    const int ring_per_tile = in_lds ? tch + nB + jch : n_chunks;
+    constexpr int NSTG = GR_NSTG;                         // ring stages: two chunks (16 KB per wavefront) requested ahead of the arithmetic
+    const int table_bytes = ncols * 16;
+    float *const Fs = reinterpret_cast<float *>(lds + table_bytes) + (size_t)wave * (G32_W + a.me - 1) * pitch;
+    const int ntiles = (int)((a.Nwin + G32_W - 1) / G32_W);
+    const int wave_id = blockIdx.x * nwaves + wave, wave_stride = gridDim.x * nwaves;
+    const int my_tiles = wave_id < ntiles ? (ntiles - 1 - wave_id) / wave_stride + 1 : 0;
+    const int total = my_tiles * ring_per_tile;
+    const unsigned int nb = gridDim.x;
+    const unsigned off_own = (unsigned)lane * 16u;
+    const unsigned off_extra = (unsigned)(lane < a.me - 1 ? lane : (a.me > 1 ? a.me - 2 : 0)) * 16u;
+    const unsigned jl = (unsigned)lane + (unsigned)a.prev_row0;
+    const unsigned off_join = (jl >> 6) * ((unsigned)JQ << 10) + (jl & 63u) * 16u;
+    const char *const FTb = reinterpret_cast<const char *>(a.FT), *const JTb = reinterpret_cast<const char *>(a.JT);
+    const size_t tab_floats = (size_t)ncols * 4;
+
+    // reduction scratch of the step's tail aliases the table and the target blocks
+    Top3 *red3 = reinterpret_cast<Top3 *>(lds);
+    double *redd = reinterpret_cast<double *>(lds);
+
+    int64_t prev_row[G32_UB] = {s0, s1, s2};               // winners of the previous step (start states first)
+
+    for (int64_t step = 0; step < nsteps; ++step) {
+        // ---- wait for the step's table (written by the workgroup that decided the previous step) ----
+        // generation 2 step + 1: the table of this step is complete (0xffffffff: an earlier step was undecidable)
+        if (tid == 0) {
+            unsigned int g;
+            while ((g = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned int)(2 * step + 1))
+                __builtin_amdgcn_s_sleep(1);
+            gen_seen = (int)g;
+        }
+        __syncthreads();
+        if (step > 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;     // an undecidable step: everybody leaves
+        const float *tab = tabs + (step & 1) * tab_floats;
+
+        int f_tile = wave_id, f_pos = 0;
+        f32x4 stage[NSTG][8];
+        auto fetch = [&](f32x4 (&st)[8], int pin0) {
+            const int t = f_tile < ntiles ? f_tile : ntiles - 1;
+            const char *base;
+            unsigned voff = off_own;
+            if (in_lds) {
+                if (f_pos < tch) base = FTb + (((size_t)t * FQ + f_pos * 8) << 10);
+                else if (f_pos < tch + nB) { base = FTb + (((size_t)(t + 1) * FQ + (f_pos - tch) * 8) << 10); voff = off_extra; }
+                else { base = JTb + (((size_t)t * JQ + (f_pos - tch - nB) * 8) << 10); voff = off_join; }
+            } else if (f_pos < jch) {
+                base = JTb + (((size_t)t * JQ + f_pos * 8) << 10); voff = off_join;
+            } else {
+                const int k = (f_pos - jch) / tch, cc = (f_pos - jch) - k * tch;
+                const unsigned fl = (unsigned)lane + (unsigned)a.ep[k];
+                base = FTb + (((size_t)t * FQ + cc * 8) << 10);
+                voff = (fl >> 6) * ((unsigned)FQ << 10) + (fl & 63u) * 16u;
+            }
+            voff += (unsigned)pin0;
+            // nt for databases that are streamed from HBM every step; small ones stay in L2 / Infinity Cache
+            if (use_nt && (in_lds || f_pos < jch)) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    st[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + voff + 1024 * j));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) st[j] = *reinterpret_cast<const f32x4 *>(base + voff + 1024 * j);
+            }
+            asm volatile("" ::: "memory");
+            if (++f_pos == ring_per_tile) { f_pos = 0; f_tile += wave_stride; }
+        };
+#pragma unroll
+        for (int s = 0; s < NSTG - 1; ++s) fetch(stage[s], 0);
+
+        // the step's table -> LDS (sc1 loads: another compute unit wrote it moments ago)
+        {
+            u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
+            const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tab), 0, ncols * 16, 0x00020000);
+            for (int e = tid; e < ncols; e += blockDim.x) dst[e] = __builtin_amdgcn_raw_buffer_load_b128(tres, e * 16, 0, 16);
+        }
+        __syncthreads();
+
+        Top3 best[G32_UB];
+        float acc[G32_UB];                                    // ONE float32 total per utterance: the bound holds for any order
+#pragma unroll
+        for (int u = 0; u < G32_UB; ++u) { top3_init(best[u]); acc[u] = 0.f; }
+        int c_tile = wave_id, c_pos = 0, t_done = 0, slot = 0;
+        int pin = 0;
+        const f32x4 *const table = reinterpret_cast<const f32x4 *>(lds);
+        // one chunk of arithmetic: x[g] = columns 4g .. 4g+3 of the chunk.  The table entries (w, ref0, ref1, ref2;
+        // the same address in every lane: broadcast reads) come four columns at a time
+        auto chunk = [&](f32x4 (&x)[8]) {
+            const f32x4 *const cur = table + slot * GR_CC;
+            if (++slot == n_chunks) slot = 0;
+            f32x4 tc[4];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tc[i] = cur[4 * g + i];
+                asm volatile("" ::: "memory");              // four columns at a time (the other wavefront of the SIMD covers the read)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float xv = x[g][i];
+                    // column after column (left alone the scheduler interleaves a whole chunk and runs out of registers)
+                    asm volatile("" : "+v"(xv), "+v"(acc[0]), "+v"(acc[G32_UB - 1]));
+#pragma unroll
+                    for (int u = 0; u < G32_UB; ++u) {
+                        const float d = __builtin_fmaf(xv, tc[i][0], -tc[i][1 + u]);
+                        acc[u] = __builtin_fmaf(d, d, acc[u]);    // padded columns: w = ref = 0 adds +0
+                    }
+                }
+            }
+        };
+        auto end_of_window = [&]() {
+            const int i = c_tile * G32_W + lane;
+#pragma unroll
+            for (int u = 0; u < G32_UB; ++u) {
+                if (i < (int)a.Nwin) top3_push(best[u], acc[u], i);
+                acc[u] = 0.f;
+            }
+            c_pos = 0; t_done = 0; c_tile += wave_stride;
+        };
+        auto handle = [&](f32x4 (&st)[8]) {
+            if (!in_lds) {
+                chunk(st);
+                asm volatile("" : "+v"(acc[0]), "+v"(pin));
+            } else if (c_pos < tch + nB) {
+                const bool extra = c_pos >= tch;
+                const int col = (extra ? c_pos - tch : c_pos) * GR_CC;
+                if (!extra || lane < a.me - 1) {
+                    float *dst = Fs + (size_t)(extra ? lane + G32_W : lane) * pitch + col;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4 *>(dst + 4 * j) = st[j];
+                }
+            } else {
+                // join chunk j (from the ring), then its share of the target chunks (from the wavefront's LDS block):
+                // ONE instance of the arithmetic, fed from either source
+                const int j = c_pos - tch - nB;
+                const int t_goal = ((j + 1) * nT) / jch;
+                const int items = 1 + (t_goal - t_done);
+#pragma nounroll
+                for (int it = 0; it < items; ++it) {
+                    f32x4 x[8];
+                    if (it == 0) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) x[q] = st[q];
+                    } else {
+                        const int k = t_done / tch, cc = t_done - k * tch;
+                        const float *row = Fs + (size_t)(lane + a.ep[k]) * pitch + cc * GR_CC;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) x[q] = *reinterpret_cast<const f32x4 *>(row + 4 * q);
+                        ++t_done;
+                    }
+                    chunk(x);
+                    asm volatile("" : "+v"(acc[0]), "+v"(pin));
+                }
+            }
+            if (++c_pos == ring_per_tile) end_of_window();
+        };
+#pragma nounroll
+        for (int g0 = 0; g0 < total; g0 += NSTG) {
+#pragma unroll
+            for (int s = 0; s < NSTG; ++s) {
+                fetch(stage[(s + NSTG - 1) % NSTG], pin);
+                asm volatile("" : "+v"(stage[s][0]), "+v"(pin));
+                if (g0 + s < total) handle(stage[s]);
+            }
+        }
+        __syncthreads();                                      // the reduction arrays alias the table and the target blocks
+
+        // ---- workgroup top-3 per utterance -> global memory (sc1), arrival tree ----
+#pragma unroll
+        for (int u = 0; u < G32_UB; ++u) {
+            if (u >= a.nu) break;                                 // uniform
+            Top3 t = best[u];
+#pragma unroll
+            for (int m = 1; m <= 32; m <<= 1) { const Top3 o = top3_shfl_xor(t, m); top3_merge(t, o); }
+            // (recursive doubling: the partner's set is disjoint from the lane's at every level)
+            if (lane == 0) red3[wave] = t;
+            __syncthreads();
+            if (tid == 0) {
+                Top3 r = red3[0];
+                for (int w = 1; w < nwaves; ++w) top3_merge(r, red3[w]);
+                G32Rec *o = blk + ((size_t)u * nb + blockIdx.x);
+                __hip_atomic_store(&o->v1, r.v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&o->v2, r.v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&o->v3, r.v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&o->a1, (int64_t)r.a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&o->a2, (int64_t)r.a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+        // arrival on a 256 -> 16 -> 1 tree of monotonic counters; true for the workgroup that completes it
+        auto arrive_last = [&](unsigned int *cnt, unsigned int round) -> bool {
+            if (tid == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned int b = blockIdx.x;
+                const unsigned int S1 = nb < GR_S1 ? nb : GR_S1, sl1 = b % S1, q1 = (nb - sl1 + S1 - 1) / S1;
+                bool last = false;
+                if (__hip_atomic_fetch_add(cnt + 32 * sl1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == round * q1 - 1) {
+                    const unsigned int S2 = S1 < GR_S2 ? S1 : GR_S2, sl2 = sl1 % S2, q2 = (S1 - sl2 + S2 - 1) / S2;
+                    if (__hip_atomic_fetch_add(cnt + 32 * (GR_S1 + sl2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == round * q2 - 1)
+                        last = __hip_atomic_fetch_add(cnt + 32 * (GR_S1 + GR_S2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               == round * S2 - 1;
+                }
+                is_last = last;
+            }
+            __syncthreads();
+            const bool r = is_last != 0;
+            __syncthreads();
+            return r;
+        };
+        // winners of the previous step (another workgroup may have decided it): visible since generation 2 step + 1
+        auto load_prev = [&]() {
+            if (step > 0) {
+#pragma unroll
+                for (int u = 0; u < G32_UB; ++u)
+                    prev_row[u] = (u < a.nu && step - 1 < a.nsteps_u[u])
+                                      ? __hip_atomic_load(&path[a.out_off[u] + step - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+            }
+        };
+        // exact decision among n candidates (ids through `get`): a wavefront per candidate, canonical float64 totals,
+        // lowest index on exact ties
+        const int ex_cols = a.jdim + a.nep * a.Dt;
+        int nw_exact = (lds_bytes - 16384) / (ex_cols * 8);           // wavefronts whose term arrays fit the LDS
+        nw_exact = nw_exact > nwaves ? nwaves : nw_exact;
+        double *const terms = reinterpret_cast<double *>(lds + 16384) + (size_t)wave * ex_cols;
+        auto exact_argmin = [&](int u, int n, auto get) -> int64_t {
+            double dbest = DBL_MAX;
+            int64_t ibest = INT64_MAX;
+            for (int p = wave; p < n && wave < nw_exact; p += nw_exact) {
+                const int64_t i = get(p);
+                const double d = g32_exact_d2_wave(a, u, step, prev_row[u], step > 0, i, terms, lane);
+                if (d < dbest || (d == dbest && i < ibest)) { dbest = d; ibest = i; }
+            }
+            __syncthreads();
+            double *rd = reinterpret_cast<double *>(lds + 8192);
+            int64_t *ri = reinterpret_cast<int64_t *>(lds + 8192 + 64);
+            if (lane == 0) { rd[wave] = dbest; ri[wave] = ibest; }
+            __syncthreads();
+            double d0 = rd[0];
+            int64_t i0 = ri[0];
+            for (int w = 1; w < nwaves; ++w) if (rd[w] < d0 || (rd[w] == d0 && ri[w] < i0)) { d0 = rd[w]; i0 = ri[w]; }
+            __syncthreads();
+            return i0;
+        };
+        // end of a step: path, the next step's table, release of generation 2 step + 3
+        auto finalize = [&](const int64_t (&winner)[G32_UB], bool undecided) {
+            if (undecided) {
+                if (tid == 0) __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (tid == 0) {
+#pragma unroll
+                    for (int u = 0; u < G32_UB; ++u)
+                        if (u < a.nu && step < a.nsteps_u[u])
+                            __hip_atomic_store(&path[a.out_off[u] + step], winner[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (step + 1 < nsteps)
+                    g32_write_table(a, step + 1, winner, true, tabs + ((step + 1) & 1) * tab_floats,
+                                    vnorm2 + ((step + 1) & 1) * G32_UB, redd, tid, (int)blockDim.x);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wavefront drains, then ONE flag store
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(gen, (unsigned int)(2 * step + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+
+        if (arrive_last(arrive, (unsigned int)step + 1u)) {
+            // ---- first decision, from the published two best windows of every workgroup ----
+            load_prev();
+            int64_t winner[G32_UB] = {0, 0, 0};
+            unsigned int need = 0u;
+            bool undecided = false;
+#pragma unroll
+            for (int u = 0; u < G32_UB; ++u) {
+                if (!(u < a.nu && step < a.nsteps_u[u])) continue;      // uniform
+                float mv = __builtin_inff();
+                int64_t mi = INT64_MAX;
+                for (unsigned int b = tid; b < nb; b += blockDim.x) {
+                    const G32Rec *r = blk + ((size_t)u * nb + b);
+                    const float v = __hip_atomic_load(&r->v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int64_t i = __hip_atomic_load(&r->a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lt_vi(v, i, mv, mi)) { mv = v; mi = i; }
+                }
+#pragma unroll
+                for (int m = 1; m <= 32; m <<= 1) {
+                    const float ov = __shfl_xor(mv, m, 64); const int64_t oi = __shfl_xor(mi, m, 64);
+                    if (lt_vi(ov, oi, mv, mi)) { mv = ov; mi = oi; }
+                }
+                float *wv = reinterpret_cast<float *>(lds);
+                int64_t *wi = reinterpret_cast<int64_t *>(lds + 64);
+                if (lane == 0) { wv[wave] = mv; wi[wave] = mi; }
+                __syncthreads();
+                mv = wv[0]; mi = wi[0];
+                for (int w = 1; w < nwaves; ++w) if (lt_vi(wv[w], wi[w], mv, mi)) { mv = wv[w]; mi = wi[w]; }
+                __syncthreads();
+                if (approx) { winner[u] = mi; continue; }
+                if (!(mv < __builtin_inff())) { undecided = true; continue; }
+                // tau = the largest solution of tau = M + 2 E(tau), approached from above (E(0) = 0: from below the
+                // iteration would stall at M = 0, where the natural path lives)
+                const double V2 = __hip_atomic_load(&vnorm2[(step & 1) * G32_UB + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double M = (double)mv;
+                double tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300;
+                for (int it = 0; it < 8; ++it) tau = M + 2.0 * g32_err(tau, V2, ncols);
+                tau = tau * (1.0 + 1e-6) + 1e-300;
+                int *ccount = reinterpret_cast<int *>(lds);
+                int *cover = reinterpret_cast<int *>(lds + 32);
+                int64_t *clist = reinterpret_cast<int64_t *>(lds + 128);               // up to 512 candidates
+                if (tid == 0) { *ccount = 0; *cover = 0; }
+                __syncthreads();
+                for (unsigned int b = tid; b < nb; b += blockDim.x) {
+                    const G32Rec *r = blk + ((size_t)u * nb + b);
+                    const float v1 = __hip_atomic_load(&r->v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float v2 = __hip_atomic_load(&r->v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float v3 = __hip_atomic_load(&r->v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((double)v1 <= tau) clist[atomicAdd(ccount, 1)] = __hip_atomic_load(&r->a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((double)v2 <= tau) clist[atomicAdd(ccount, 1)] = __hip_atomic_load(&r->a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((double)v3 <= tau) *cover = 1;          // a window nobody published may matter: second phase
+                }
+                __syncthreads();
+                const int nc = *ccount;
+                const bool cov = *cover != 0;
+                if (cov) {
+                    // every lane still holds its own three best: ask all of them (generation 2 step + 2)
+                    need |= 1u << u;
+                    if (tid == 0) {
+                        __hip_atomic_store(&ctl->tau[u], tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&ctl->list_count[u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    __syncthreads();
+                    continue;
+                }
+                if (nc == 1) { winner[u] = clist[0]; __syncthreads(); continue; }
+                if (tid == 0) status[2] += nc;                  // statistics: windows decided by exact totals
+                winner[u] = exact_argmin(u, nc, [&](int p) { return clist[p]; });
+            }
+            if (need == 0u || undecided) {
+                finalize(winner, undecided);
+            } else {
+                if (tid == 0) {
+#pragma unroll
+                    for (int u = 0; u < G32_UB; ++u) __hip_atomic_store(&ctl->pending[u], winner[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&ctl->need, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&ctl->list_over, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(gen, (unsigned int)(2 * step + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+            }
+        }
+        // ---- everybody: the next generation is either the next step's table or a request for candidates ----
+        if (tid == 0) {
+            unsigned int g;
+            while ((g = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned int)(2 * step + 2))
+                __builtin_amdgcn_s_sleep(1);
+            gen_seen = (int)g;
+        }
+        __syncthreads();
+        if (gen_seen == (int)(2 * step + 2)) {
+            // second phase: every lane offers its two best windows that reach tau; a third one that does is beyond
+            // what was kept (mass ties): the step is then undecidable here
+            const unsigned int need = __hip_atomic_load(&ctl->need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < G32_UB; ++u) {
+                if (!((need >> u) & 1u)) continue;                  // uniform
+                const double tau = __hip_atomic_load(&ctl->tau[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const Top3 &t = best[u];
+                if ((double)t.v1 <= tau) {
+                    const unsigned int p = __hip_atomic_fetch_add(&ctl->list_count[u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (p < G32_LIST) __hip_atomic_store(&clist_g[(size_t)u * G32_LIST + p], (int64_t)t.a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if ((double)t.v2 <= tau) {
+                    const unsigned int p = __hip_atomic_fetch_add(&ctl->list_count[u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (p < G32_LIST) __hip_atomic_store(&clist_g[(size_t)u * G32_LIST + p], (int64_t)t.a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if ((double)t.v3 <= tau) __hip_atomic_store(&ctl->list_over, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wavefront's offers, before the workgroup arrives
+            __syncthreads();
+            ++collect_rounds;
+            if (arrive_last(arrive2, (unsigned int)collect_rounds)) {
+                load_prev();
+                int64_t winner[G32_UB];
+                bool undecided = __hip_atomic_load(&ctl->list_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+#pragma unroll
+                for (int u = 0; u < G32_UB; ++u) {
+                    winner[u] = __hip_atomic_load(&ctl->pending[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!((need >> u) & 1u) || undecided) continue;
+                    const unsigned int n = __hip_atomic_load(&ctl->list_count[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (n < 1u || n > (unsigned int)G32_LIST) { undecided = true; continue; }
+                    if (tid == 0) { status[1] += 1; status[2] += (int64_t)n; }      // statistics: second-phase rounds
+                    winner[u] = exact_argmin(u, (int)n, [&](int p) {
+                        return __hip_atomic_load(&clist_g[(size_t)u * G32_LIST + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
+                }
+                finalize(winner, undecided);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// prologue: counters, generation word, status, the table of step 0
+__global__ void greedy32_init_kernel(GreedyArgs a, int64_t s0, int64_t s1, int64_t s2, float *tabs, double *vnorm2,
+                                     unsigned int *arrive, unsigned int *arrive2, unsigned int *gen, int64_t *status)
+{
+    __shared__ double red[512];
+    for (int i = threadIdx.x; i < 32 * (GR_S1 + GR_S2 + 1); i += blockDim.x) { arrive[i] = 0; arrive2[i] = 0; }
+    const int64_t start[G32_UB] = {s0, s1, s2};
+    g32_write_table(a, 0, start, false, tabs, vnorm2, red, threadIdx.x, blockDim.x);
+    if (threadIdx.x == 0) { *status = 0; *gen = 1u; status[1] = 0; status[2] = 0; }
+}
+
+// exact Euclidean distance of every pick (what the tree query returns beside the index): a wavefront per step
+__global__ void __launch_bounds__(64)
+greedy32_dist_kernel(GreedyArgs a, int u, int64_t start, const int64_t *__restrict__ path, double *__restrict__ dist)
+{
+    extern __shared__ __align__(16) char lds[];
+    const int64_t s = blockIdx.x;
+    if (s >= a.nsteps_u[u]) return;
+    const int64_t prev = s == 0 ? start : path[a.out_off[u] + s - 1];
+    const double d2 = g32_exact_d2_wave(a, u, s, prev, s > 0, path[a.out_off[u] + s], reinterpret_cast<double *>(lds), threadIdx.x);
+    if (threadIdx.x == 0) dist[a.out_off[u] + s] = __dsqrt_rn(d2);
+}
+
+size_t greedy32_table_floats(const GreedyLayout &g, int Dt)
+{
+    const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
+    const int jch = (g.jdim + GR_CC - 1) / GR_CC;
+    return (size_t)(jch + nep * ((Dt + GR_CC - 1) / GR_CC)) * GR_CC * 4;
+}
+// workspace of one launch: block records | second-phase control | candidate lists
+static size_t g32_rec_bytes(int nblk) { return (((size_t)G32_UB * nblk * sizeof(G32Rec)) + 255) & ~(size_t)255; }
+size_t greedy32_block_bytes(int nblk) { return g32_rec_bytes(nblk) + 256 + (size_t)G32_UB * G32_LIST * sizeof(int64_t); }
+int greedy32_max_utts() { return G32_UB; }
+
+static size_t g32_lds_wave_bytes(const GreedyLayout &g, int Dt)
+{
+    return (size_t)(G32_W + g.me - 1) * ((Dt + GR_CC - 1) / GR_CC * GR_CC + 4) * sizeof(float);
+}
+// wavefronts per workgroup / LDS bytes: the table (16 bytes per column) + a target block per wavefront
+static int g32_waves(const GreedyLayout &g, int Dt, int n_cus, bool in_lds)
+{
+    const int64_t ntiles = (g.Nwin + G32_W - 1) / G32_W;
+    int64_t w = (ntiles + n_cus - 1) / n_cus;
+    int wmax = G32_MAXW;
+    if (in_lds) {
+        const size_t fixed = greedy32_table_floats(g, Dt) * 4 + 64;
+        const size_t per = g32_lds_wave_bytes(g, Dt);
+        const size_t fit = fixed < (size_t)(160 * 1024) ? ((size_t)(160 * 1024) - fixed) / per : 0;
+        if ((int64_t)fit < wmax) wmax = (int)fit;
+    }
+    if (w > wmax) w = wmax;
+    return (int)(w < 1 ? 1 : w);
+}
+bool greedy32_supported(const GreedyLayout &g, int Dt)
+{
+    // the table must leave room for the reduction scratch and, in LDS mode, for at least four target blocks
+    const size_t tb = greedy32_table_floats(g, Dt) * 4;
+    if (tb + 16384 > (size_t)(160 * 1024)) return false;
+    if (greedy_lds_mode(g, Dt) && tb + 64 + 4 * g32_lds_wave_bytes(g, Dt) > (size_t)(160 * 1024)) return false;
+    return true;
+}
+int greedy32_blocks(const GreedyLayout &g, int Dt, int n_cus)
+{
+    const bool in_lds = greedy_lds_mode(g, Dt);
+    const int64_t ntiles = (g.Nwin + G32_W - 1) / G32_W;
+    const int waves = g32_waves(g, Dt, n_cus, in_lds);
+    const int64_t need = (ntiles + waves - 1) / waves;
+    return (int)(need < n_cus ? need : n_cus);
+}
+
+// One persistent launch for up to three utterances (q_off / nsteps_u / out_off / start per utterance).
+// approx != 0: search_epsilon mode (float32 minimum, nothing re-evaluated).  *status (device): 0, or 1 + the
+// first step that could not be decided (mass ties); the caller then falls back to the exact scan.
+void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
+                     int Dj, const double *wj, const float *tiles, const double *Q, int nu, const int64_t *q_off,
+                     const int64_t *nsteps_u, const int64_t *out_off, const int64_t *start, int approx, float *tabs,
+                     double *vnorm2, void *blk, int n_cus, unsigned int *arrive, unsigned int *gen, int64_t *status,
+                     int64_t *path, hipStream_t s)
+{
+    GreedyArgs a{};
+    greedy_fill_args(a, g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, Q, true, tiles);
+    const bool in_lds = greedy_lds_mode(g, Dt);
+    a.lds_mode = in_lds ? 1 : 0;
+    a.nu = nu;
+    int64_t nsteps = 0, st3[3] = {-1, -1, -1};
+    for (int u = 0; u < 3; ++u) {
+        a.q_off[u] = u < nu ? q_off[u] : 0;
+        a.nsteps_u[u] = u < nu ? nsteps_u[u] : 0;
+        a.out_off[u] = u < nu ? out_off[u] : 0;
+        if (u < nu) { st3[u] = start[u]; if (nsteps_u[u] > nsteps) nsteps = nsteps_u[u]; }
+    }
+    if (nsteps <= 0) return;
+    unsigned int *arrive2 = arrive + 32 * (GR_S1 + GR_S2 + 1);    // the caller provides 2 x greedy_counter_bytes()
+    hipLaunchKernelGGL(greedy32_init_kernel, dim3(1), dim3(512), 0, s, a, st3[0], st3[1], st3[2], tabs, vnorm2, arrive, arrive2, gen, status);
+    const int waves = g32_waves(g, Dt, n_cus, in_lds);
+    const int nblk = greedy32_blocks(g, Dt, n_cus);
+    size_t lds = greedy32_table_floats(g, Dt) * 4 + (in_lds ? (size_t)waves * g32_lds_wave_bytes(g, Dt) : 0);
+    // the step's tail: 16 KB of reduction scratch + a term array per wavefront for exact decisions
+    const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
+    const size_t tail = 16384 + (size_t)waves * (size_t)(g.jdim + nep * Dt) * 8;
+    if (lds < tail) lds = tail < (size_t)(160 * 1024) ? tail : (size_t)(160 * 1024);
+    // small scans live in L2 / Infinity Cache across the steps of the launch; big ones are streamed
+    const size_t scan_bytes = (size_t)g.Nwin * (size_t)(g.jdim + Dt) * 4;
+    const int use_nt = scan_bytes > ((size_t)192 << 20) ? 1 : 0;
+    auto kernel = in_lds ? greedy32_kernel<true> : greedy32_kernel<false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    char *wb = reinterpret_cast<char *>(blk);
+    G32Ctl *ctl = reinterpret_cast<G32Ctl *>(wb + g32_rec_bytes(nblk));
+    int64_t *clist = reinterpret_cast<int64_t *>(wb + g32_rec_bytes(nblk) + 256);
+    hipLaunchKernelGGL(kernel, dim3(nblk), dim3(G32_W * waves), lds, s, a, nsteps, st3[0], st3[1], st3[2], approx, use_nt, (int)lds,
+                       tabs, vnorm2, reinterpret_cast<G32Rec *>(blk), arrive, arrive2, gen, ctl, clist, path, status);
+}
+
+void launch_greedy32_dist(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
+                          int Dj, const double *wj, const double *Q, int u_slot, int64_t q_off, int64_t nsteps, int64_t out_off,
+                          int64_t start, const int64_t *path, double *dist, hipStream_t s)
+{
+    if (nsteps <= 0) return;
+    GreedyArgs a{};
+    greedy_fill_args(a, g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, Q, true, nullptr);
+    a.nu = 1;
+    (void)u_slot;
+    a.q_off[0] = q_off; a.nsteps_u[0] = nsteps; a.out_off[0] = out_off;
+    const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
+    hipLaunchKernelGGL(greedy32_dist_kernel, dim3((unsigned)nsteps), dim3(64), (size_t)(g.jdim + nep * Dt) * 8, s, a, 0, start, path, dist);
+}
+
+}  // namespace snk

@@ -17,57 +17,9 @@
 // oracle order (column by column, separately rounded sub/mul/add), so the argmin is bit-exact.
 //
 // Per step ONE launch of greedy_step_kernel (see the comment on the kernel).
-#include "snk_internal.h"
-#include <float.h>
+#include "greedy_common.h"
 
 namespace snk {
-
-#define GR_CC 32          // columns per chunk (8 float4 per window)
-#define GR_NSTG 3         // ring stages (chunks) in registers per thread: GR_NSTG - 1 requests ahead of the arithmetic
-#define GR_MAX_EP 16      // max multiepoch
-#define GR_S1 256          // arrival counters of the first / second level (see greedy_finish_step)
-#define GR_S2 16
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct GreedyArgs {
-    const float *JC_unw; int Jp, Dj; const double *wj;   // Jp / Fp: row pitch in floats (multiple of 4,
-    const float *F_unw; int Fp, Dt; const double *wt;    // zero-filled padding columns)
-    const f32x4 *JT, *FT;                 // lane-major tiles of the scan columns (greedy_tile_kernel)
-    int me, nep; int ep[GR_MAX_EP];       // epochs of the window that enter the target term
-    int prev_col0, cur_col0, jdim;
-    int64_t prev_row0, cur_row0, Nwin;
-    int64_t n_jc_rows, n_f_rows;          // matrix heights (clamp for the ragged last workgroup)
-    const double *Q;                      // (rows, Dt) weighted targets of all utterances, row-major
-    int lds_mode;                         // 1: target rows in LDS, interleaved chunk order (greedy_step_kernel)
-    // utterances of this scan (snk_greedy_batch: up to GR_MAXU share one pass over the database)
-    int nu;
-    int64_t q_off[3], nsteps_u[3], out_off[3];      // first query row, steps, first slot in path / dist
-};
-#define GR_MAXU 2          // utterances per scan: one weight and the references share 32 table bytes per column
-
-__device__ __forceinline__ int greedy_join_chunks(const GreedyArgs &a) { return (a.jdim + GR_CC - 1) / GR_CC; }
-__device__ __forceinline__ int greedy_target_chunks(const GreedyArgs &a) { return (a.Dt + GR_CC - 1) / GR_CC; }
-
-// Chunk order of a window's scan.  Plain order (lds_mode 0): the join chunks, then the
-// target chunks epoch by epoch.  Interleaved order (lds_mode 1): join chunk j is followed
-// by the target chunks [j*nT/jch, (j+1)*nT/jch) -- the join chunks come from HBM, the target chunks
-// from LDS, and spreading the first among the second gives every HBM request several chunks of
-// arithmetic to land behind.  The two partial sums are separate accumulators, so only the order
-// within each kind matters for the result.
-// Slot c -> join chunk (returns true, *idx = j) or target chunk (returns false, *idx = k*tch + cc).
-__device__ __forceinline__ bool greedy_chunk_slot(const GreedyArgs &a, int jch, int nT, int c, int *idx)
-{
-    if (!a.lds_mode) {
-        if (c < jch) { *idx = c; return true; }
-        *idx = c - jch; return false;
-    }
-    int j = 0;
-    while (j + 1 < jch && (j + 1) + ((j + 1) * nT) / jch <= c) ++j;      // last join chunk at or before slot c
-    if (c == j + (j * nT) / jch) { *idx = j; return true; }
-    *idx = c - j - 1;
-    return false;
-}
 
 // The table of a step: per column of the scan, in chunk order, the weight and the reference of every
 // utterance of the scan -- join columns against that utterance's `prev`, target columns against its
@@ -487,6 +439,13 @@ static void fill_args(GreedyArgs &a, const GreedyLayout &g, const float *F_unw, 
     a.Q = Q;
     a.JT = reinterpret_cast<const f32x4 *>(tiles);
     a.FT = tiles ? a.JT + greedy_join_tile_elems(g) : nullptr;
+}
+
+void greedy_fill_args(GreedyArgs &a, const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt,
+                      const float *JC_unw, int Jp, int Dj, const double *wj, const double *Q, bool greedy_mode,
+                      const float *tiles)
+{
+    fill_args(a, g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, Q, greedy_mode, tiles);
 }
 
 size_t greedy_counter_bytes() { return (size_t)32 * (GR_S1 + GR_S2 + 1) * sizeof(unsigned int); }

@@ -158,6 +158,10 @@ struct snk_engine {
     std::vector<double> tsel, jsel;       // snk_set_column_selection: 1 = column takes part (empty: all do)
     DevBuf tmask;                         // tsel on the device (query rows are masked after upload)
     DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist, gsync, gtiles;
+    DevBuf g32_tabs, g32_vnorm, g32_blk, g32_ctl;          // float32 persistent scan: tables, norms, block records, {gen, status}
+    int greedy_mode = 2;                  // 2: auto (batches: float32 scan; one utterance: exact scan); 1: float32 prefilter scan in one
+                                          // persistent launch (exact decision); 0: exact float64 scan, a launch per step
+    int greedy_fallbacks = 0;             // utterance groups the float32 scan could not decide (mass ties) and the exact scan finished
     // options
     int cap = 4096;
     double sample_frac = 1.0 / 16.0;
@@ -322,7 +326,8 @@ int snk_destroy(snk_handle h)
     DevBuf *bufs[] = {&h->F_unw, &h->JC_unw, &h->Fw, &h->fnorm, &h->JCw, &h->wt, &h->wj, &h->unit_class,
                       &h->Qraw, &h->Qp, &h->Qf, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
-                      &h->gpath, &h->gdist, &h->gsync, &h->gtiles, &h->cls16_full, &h->cls16_samp};
+                      &h->gpath, &h->gdist, &h->gsync, &h->gtiles, &h->cls16_full, &h->cls16_samp,
+                      &h->g32_tabs, &h->g32_vnorm, &h->g32_blk, &h->g32_ctl};
     for (auto *b : bufs) b->release();
     if (h->dp_stream[1]) (void)hipStreamDestroy(h->dp_stream[1]);
     h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
@@ -1383,6 +1388,49 @@ int snk_set_greedy_layout(snk_handle h, int multiepoch, int last_frame_as_target
     return 0;
 }
 
+// Up to greedy32_max_utts() utterances through the float32 persistent scan (greedy32_kernels.hip).  Returns in
+// *undecided whether the launch stopped at a step it could not decide (the caller then runs the exact scan).
+static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int64_t *ns, const int64_t *oo, const int64_t *st,
+                          bool approx, bool want_dist, bool *undecided)
+{
+    const GreedyLayout &g = h->glay;
+    const int nblk = greedy32_blocks(g, h->Dt, h->n_cus);
+    CHK(h->g32_tabs.ensure(2 * greedy32_table_floats(g, h->Dt) * sizeof(float) + 512));
+    CHK(h->g32_vnorm.ensure(8 * sizeof(double)));
+    CHK(h->g32_blk.ensure(greedy32_block_bytes(nblk)));
+    CHK(h->g32_ctl.ensure(256));
+    CHK(h->gsync.ensure(2 * greedy_counter_bytes()));
+    unsigned int *gen = h->g32_ctl.as<unsigned int>();
+    int64_t *status = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(h->g32_ctl.p) + 16);
+    launch_greedy32(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
+                    h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nu, q_off, ns, oo, st, approx ? 1 : 0,
+                    h->g32_tabs.as<float>(), h->g32_vnorm.as<double>(), h->g32_blk.p, h->n_cus, h->gsync.as<unsigned int>(), gen,
+                    status, h->gpath.as<int64_t>(), h->stream);
+    HIPCHK(hipGetLastError());
+    int64_t stv = 0;
+    HIPCHK(hipMemcpyAsync(&stv, status, sizeof(stv), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *undecided = stv != 0;
+    if (!*undecided && want_dist) {
+        for (int u = 0; u < nu; ++u)
+            launch_greedy32_dist(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
+                                 h->wj.as<double>(), h->Qraw.as<double>(), u, q_off[u], ns[u], oo[u], st[u], h->gpath.as<int64_t>(),
+                                 h->gdist.as<double>(), h->stream);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
+// greedy_mode 2 (default): the float32 scan where it pays -- several utterances share every pass over the database
+// (three per scan: 57 k against 29 k frames/s at 1.5 M units), a single utterance goes through the exact scan
+// (both are bound by the same HBM stream, and at 65 536 units the launch per step is cheaper than the in-kernel
+// hand-off).  Same paths and distances either way.
+static bool use_greedy32(const snk_engine *h, int n_utts)
+{
+    if (!greedy32_supported(h->glay, h->Dt)) return false;
+    return h->greedy_mode == 1 || (h->greedy_mode == 2 && n_utts >= 2);
+}
+
 int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_state, double eps,
                int64_t *path_out, double *dist_out, int64_t *nsteps_out)
 {
@@ -1411,7 +1459,19 @@ int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_st
     CHK(h->gblkarg.ensure((size_t)nblk * sizeof(int64_t)));
     CHK(h->gpath.ensure((size_t)nsteps * sizeof(int64_t)));
     CHK(h->gdist.ensure((size_t)nsteps * sizeof(double)));
-    {
+    bool exact_scan = true;
+    if (use_greedy32(h, 1)) {
+        // float32 prefilter scan, one persistent launch; search_epsilon >= 1e-3: the float32 minimum is the answer
+        const int64_t zero = 0;
+        bool undecided = false;
+        {
+            StageTimer t(h, h->stream, TM_GREEDY_STEPS);
+            CHK(greedy32_group(h, 1, &zero, &nsteps, &zero, &start_state, eps >= 1e-3, dist_out != nullptr, &undecided));
+        }
+        exact_scan = undecided;
+        if (undecided) h->greedy_fallbacks += 1;
+    }
+    if (exact_scan) {
         StageTimer t(h, h->stream, TM_GREEDY_STEPS);
         launch_greedy(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
                       h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nsteps, start_state, h->gprev.as<double>(),
@@ -1474,23 +1534,35 @@ int snk_greedy_batch(snk_handle h, const double *Q, const int64_t *row_offsets, 
     std::vector<int> order((size_t)n_utts);
     for (int u = 0; u < n_utts; ++u) order[(size_t)u] = u;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return nsteps[(size_t)x] > nsteps[(size_t)y]; });
+    const bool g32 = use_greedy32(h, n_utts);
+    const int ub_run = g32 ? greedy32_max_utts() : ub;
     {
         StageTimer t(h, h->stream, TM_GREEDY_STEPS);
-        for (int i = 0; i < n_utts; i += ub) {
+        for (int i = 0; i < n_utts; i += ub_run) {
             int nu = 0;
             int64_t q_off[3], ns[3], oo[3], st[3];
-            for (; nu < ub && i + nu < n_utts; ++nu) {
+            for (; nu < ub_run && i + nu < n_utts; ++nu) {
                 const int u = order[(size_t)(i + nu)];
                 if (nsteps[(size_t)u] == 0) break;             // sorted: the rest have no steps either
                 q_off[nu] = row_offsets[u]; ns[nu] = nsteps[(size_t)u]; oo[nu] = out_off[(size_t)u];
                 st[nu] = start_states ? start_states[u] : -1;
             }
             if (nu == 0) break;
-            launch_greedy_batch(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
-                                h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nu, q_off, ns, oo, st,
-                                h->gprev.as<double>(), h->gblkmin.as<double>(), h->gblkarg.as<int64_t>(),
-                                greedy_blocks(g, h->Dt, h->n_cus, nu), h->n_cus, h->gsync.as<unsigned int>(),
-                                h->gpath.as<int64_t>(), h->gdist.as<double>(), h->stream);
+            if (g32) {
+                bool undecided = false;
+                CHK(greedy32_group(h, nu, q_off, ns, oo, st, eps >= 1e-3, dist_out != nullptr, &undecided));
+                if (!undecided) continue;
+                h->greedy_fallbacks += 1;
+            }
+            // exact scan, a launch per step (two utterances per scan at most)
+            for (int j = 0; j < nu; j += ub) {
+                const int n2 = (nu - j < ub) ? nu - j : ub;
+                launch_greedy_batch(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
+                                    h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), n2, q_off + j, ns + j, oo + j, st + j,
+                                    h->gprev.as<double>(), h->gblkmin.as<double>(), h->gblkarg.as<int64_t>(),
+                                    greedy_blocks(g, h->Dt, h->n_cus, n2), h->n_cus, h->gsync.as<unsigned int>(),
+                                    h->gpath.as<int64_t>(), h->gdist.as<double>(), h->stream);
+            }
         }
     }
     HIPCHK(hipGetLastError());
@@ -2138,6 +2210,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "batch_rows")) {
         if (value < 0 || value > 8192) return fail("batch_rows must be in 0..8192 (0: one K-NN call per utterance)");
         h->batch_rows = (int)value;
+    } else if (!strcmp(name, "greedy_mode")) {
+        if (value != 0.0 && value != 1.0 && value != 2.0) return fail("greedy_mode must be 0 (exact scan, a launch per step), 1 (float32 prefilter scan, one launch) or 2 (auto)");
+        h->greedy_mode = (int)value;
     } else if (!strcmp(name, "viterbi_mode")) {
         if (value != 0.0 && value != 1.0 && value != 2.0) return fail("viterbi_mode must be 0 (dense exact join + recursion), 1 (lower bounds + sparse exact recursion) or 2 (auto)");
         CHK(no_batch_in_flight(h, "snk_set_option(viterbi_mode)"));
@@ -2169,6 +2244,15 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "batch_redos")) *out = h->batch_redos;
     else if (!strcmp(name, "pool_overflows")) *out = h->pool_overflows;
     else if (!strcmp(name, "viterbi_mode")) *out = h->viterbi_mode;
+    else if (!strcmp(name, "greedy_mode")) *out = h->greedy_mode;
+    else if (!strcmp(name, "greedy_fallbacks")) *out = h->greedy_fallbacks;
+    else if (!strcmp(name, "greedy_second_phase_rounds") || !strcmp(name, "greedy_exact_windows")) {
+        // statistics of the most recent float32 scan launch: steps that needed every lane's candidates; windows
+        // whose canonical float64 totals decided a step
+        int64_t v[3] = {0, 0, 0};
+        if (h->g32_ctl.p) HIPCHK(hipMemcpy(v, reinterpret_cast<char *>(h->g32_ctl.p) + 16, sizeof(v), hipMemcpyDeviceToHost));
+        *out = (double)v[!strcmp(name, "greedy_exact_windows") ? 2 : 1];
+    }
     else if (!strcmp(name, "dense_cells") || !strcmp(name, "dense_steps") || !strcmp(name, "dense_exact_costs") || !strcmp(name, "set_overflows")) {
         unsigned long long v[4] = {0, 0, 0, 0};
         if (h->vstats.p) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipMemcpy(v, h->vstats.p, sizeof(v), hipMemcpyDeviceToHost)); }

@@ -141,6 +141,21 @@ void launch_greedy_tiles(const GreedyLayout &g, const float *F_unw, int Fp, int 
 int greedy_blocks(const GreedyLayout &g, int Dt, int n_cus, int ub = 1);
 bool greedy_supported(const GreedyLayout &g, int Dt);
 
+// float32 prefilter scan, one persistent launch per utterance group (greedy32_kernels.hip)
+bool greedy32_supported(const GreedyLayout &g, int Dt);
+int greedy32_max_utts();
+int greedy32_blocks(const GreedyLayout &g, int Dt, int n_cus);
+size_t greedy32_table_floats(const GreedyLayout &g, int Dt);
+size_t greedy32_block_bytes(int nblk);
+void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
+                     int Dj, const double *wj, const float *tiles, const double *Q, int nu, const int64_t *q_off,
+                     const int64_t *nsteps_u, const int64_t *out_off, const int64_t *start, int approx, float *tabs,
+                     double *vnorm2, void *blk, int n_cus, unsigned int *arrive, unsigned int *gen, int64_t *status,
+                     int64_t *path, hipStream_t s);
+void launch_greedy32_dist(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
+                          int Dj, const double *wj, const double *Q, int u_slot, int64_t q_off, int64_t nsteps, int64_t out_off,
+                          int64_t start, const int64_t *path, double *dist, hipStream_t s);
+
 void launch_path_scores(const GreedyLayout &g, int mode, const float *F_unw, int Fp, int Dt, const double *wt,
                         const float *JC_unw, int Jp, int Dj, const double *wj, const double *Q,
                         const int64_t *path, int64_t L, double *tsq, double *jsq, int jcols,
