@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 F64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense FP64 matrix: 256 CU x 4 SIMD x 2048 FLOP / 64 clk x 2.4 GHz
 F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X dense FP32 matrix (MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 clk)
+BF16_MFMA_PEAK_TFLOPS = 2516.8  # dense bf16 matrix: 16 x the f32 rate (same table: v_mfma_f32_32x32x16_bf16, 32 clk)
 FRAMESHIFT_MS = 5.0             # config/slt_simplified_mini.cfg:40
 
 
@@ -377,12 +378,15 @@ def main():
         # which sweep did the filtering: the f32 prefilter (default; results are made exact by the
         # float64 re-rank) or, when it had to fall back / was switched off, the f64 sweep
         f32_mode = eng.info('precision') == 1 and eng.info('f16_ready') == 1 and eng.info('f16_fallbacks') == 0
-        peak = F32_MFMA_PEAK_TFLOPS if f32_mode else F64_MFMA_PEAK_TFLOPS
-        kname = ('knn_sweep16<filter> (v_mfma_f32_32x32x2_f32 prefilter; exact f64 re-rank in knn_finalize)'
+        bf16_mode = f32_mode and eng.info('prefilter_bf16_active') == 1
+        peak = BF16_MFMA_PEAK_TFLOPS if bf16_mode else F32_MFMA_PEAK_TFLOPS if f32_mode else F64_MFMA_PEAK_TFLOPS
+        kname = ('knn_sweep16b<filter> (v_mfma_f32_32x32x16_bf16 prefilter, every operand split into two bf16 pieces: '
+                 '4 MFMA terms per product; exact f64 re-rank in knn_finalize)' if bf16_mode else
+                 'knn_sweep16<filter> (v_mfma_f32_32x32x2_f32 prefilter; exact f64 re-rank in knn_finalize)'
                  if f32_mode else 'knn_sweep<filter> (v_mfma_f64_16x16x4_f64)')
         traffic = None
         traffic_source = None
-        tfile = os.path.join(ROOT, 'profiles', 'r01_traffic_f32.json' if f32_mode else 'r01_traffic.json')
+        tfile = os.path.join(ROOT, 'profiles', 'r02_traffic_bf16.json' if bf16_mode else 'r01_traffic_f32.json' if f32_mode else 'r01_traffic.json')
         if world == 1 and N == 1048576 and Dt == 61 and os.path.isfile(tfile):
             with open(tfile) as f:
                 tj = json.load(f)
@@ -394,7 +398,7 @@ def main():
             'metric': 'synthesised frames/sec, full-DB K=%d K-NN preselection + Viterbi' % K,
             'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if args.fixed_batch else 'weak',
-            'vs_baseline': None, 'dtype': 'f64' if not f32_mode else 'f64 (f32 matrix prefilter + exact f64 re-rank)', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f64' if not f32_mode else 'f64 (bf16-split matrix prefilter + exact f64 re-rank)' if bf16_mode else 'f64 (f32 matrix prefilter + exact f64 re-rank)', 'data': 'synthetic',
             'xRT': (total_frames * FRAMESHIFT_MS / 1e3) / elapsed,
             'config': {'workload': 'B* synthetic magphase-60 (SURVEY 8d): |DB|=%d units, Dt=%d, Dj=%d, '
                                    'T=%d frames x %d utterances per step, K=%d, search_epsilon=0'
@@ -418,6 +422,15 @@ def main():
         out['viterbi'] = {'mode': 'f32 matrix lower bounds + verified sparse exact recursion' if args.viterbi_mode else 'dense exact float64 join costs',
                           'cells_refined': eng.info('dense_cells'), 'steps_with_refinement': eng.info('dense_steps'),
                           'exact_costs_in_refinement': eng.info('dense_exact_costs')}
+        if bf16_mode:
+            # what the matrix pipe executes for those algorithmic flops: 64-column tiles, 4 bf16 terms per product
+            dpad = (Dt + 3 + 63) // 64 * 64
+            issued = 4.0 * 2.0 * rows_per_launch * n_local * dpad
+            out['roofline']['issued'] = {'tflops': issued / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+                                         'frac': issued / (avg_ms * 1e-3) / 1e12 / peak if avg_ms > 0 else 0.0,
+                                         'note': 'float32-accurate keys on the bf16 pipe cost 4 bf16 MFMA terms per product (hi.hi + hi.lo + '
+                                                 'lo.hi + lo.lo) on Dt padded to 64 columns; frac above prices only the algorithmic '
+                                                 '2 N rows Dt flops against the bf16 peak'}
         if two_in_flight is not None:
             out['two_in_flight'] = two_in_flight
         if one_in_flight is not None:

@@ -79,6 +79,14 @@ int snk_set_unit_classes(snk_handle h, const int32_t *unit_class, int64_t N);
 int snk_knn_by_class(snk_handle h, const double *Q, int64_t T, int D, int K,
                      const int32_t *query_class, int64_t *cand_out, double *dist_out);
 
+/* Diagnostic of the K-NN prefilter (no reference counterpart: the reference's KD-tree is exact by construction,
+ * synth_halfphone.py:379): the approximate key ||f||^2 - 2 q.f the prefilter computes is trusted to eps[t]; this
+ * returns the prefilter's MINIMUM key per (query row, slab of *rows_per_slab consecutive units) and eps, so a test
+ * can hold them against float64 keys.  slab_min == NULL: only *n_slabs / *rows_per_slab are written.
+ *   slab_min (T, n_slabs) float32, eps (T) float64 */
+int snk_prefilter_minima(snk_handle h, const double *Q, int64_t T, int D, float *slab_min, int64_t slab_min_len,
+                         double *eps, int64_t *n_slabs, int *rows_per_slab);
+
 /* Distance part of preselect_units_quinphone (synth_halfphone.py:1343-1349): the candidate ids come
  * from the label index on the host (quinphone -> triphone -> diphone -> monophone back-off,
  * :1315-1334); dist_out[t,k] = ||F[cand[t,k]] - Q[t]||_2.  As in the reference's numpy fancy

@@ -471,6 +471,357 @@ bool launch_knn_sweep16(int mode, int nt, int dch, int k_steps, int grid_cus, co
     return false;
 }
 
+// ===========================================================================================================
+// bf16-split prefilter: the same sweep on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate).
+// Every operand value x is carried as two bf16 pieces, x = hi + lo + r with |lo| <= 2^-8 |x| and |r| <= 2^-17 |x|
+// (hi = bf16(x), lo = bf16(x - hi), both round-to-nearest; the subtraction is exact in float64), and a k-block of
+// 16 columns costs FOUR MFMAs (hi.hi + hi.lo + lo.hi + lo.lo) accumulating in float32.  ||f||^2 rides in THREE
+// spare columns as three bf16 pieces against 1.0 (24 bits), which is why the variant needs Dpad - Dt >= 3.
+//     |key~ - key| <= 2 2^-17 (2 ||q|| ||f||)  [dropped residuals r]  +  accumulation of 16 MFMAs per tile, each
+//     assumed no better than 2^-22 of the sum of its |products| and |C| (four times a sequentially rounded float32
+//     sum; the unit's internal order is not documented)  <=  2e-5 (2 ||q|| ||f|| + ||f||^2);  eps_c = 4e-5 (x 2).
+// tests/test_gpu_parity.py measures the real deviation against float64 keys: it must stay below a quarter of that.
+// The k index inside a k-block follows the instruction's operand map: lane l (r = l & 31, h = l >> 5) holds columns
+// 16 kb + 8 h + j, j = 0..7, of row r.  Operand buffers: [tile][kb][piece][lane] x 16 bytes -- 8 KB per tile and
+// 64 columns, the float32 operand's size.
+// ===========================================================================================================
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned int bf16_rne_bits(float x)          // bits of bf16(x), round to nearest even
+{
+    unsigned int u = __builtin_bit_cast(unsigned int, x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf16_bits_to_float(unsigned int b) { return __builtin_bit_cast(float, b << 16); }
+
+// pieces of one value: hi, lo (as bf16 bit patterns)
+__device__ __forceinline__ void bf16_split(double x, unsigned int &hi, unsigned int &lo)
+{
+    hi = bf16_rne_bits((float)x);
+    lo = bf16_rne_bits((float)(x - (double)bf16_bits_to_float(hi)));
+}
+
+// value of column c of database row `row` in the augmented operand: features, then three pieces of ||f||^2
+__device__ __forceinline__ void db16b_column(const double *__restrict__ Fw, const double *__restrict__ fnorm, int64_t N,
+                                             int Dt, int Dpad, int64_t row, int c, unsigned int &hi, unsigned int &lo)
+{
+    hi = 0u; lo = 0u;
+    if (row < N) {
+        if (c < Dt) bf16_split(Fw[row * Dpad + c], hi, lo);
+        else if (c < Dt + 3) {
+            // ||f||^2 = n0 + n1 + n2 (+ 2^-27 relative): each piece exact in bf16, all three in the hi operand
+            const double n = fnorm[row];
+            const unsigned int b0 = bf16_rne_bits((float)n);
+            const double r1 = n - (double)bf16_bits_to_float(b0);
+            const unsigned int b1 = bf16_rne_bits((float)r1);
+            const double r2 = r1 - (double)bf16_bits_to_float(b1);
+            hi = (c == Dt) ? b0 : (c == Dt + 1) ? b1 : bf16_rne_bits((float)r2);
+        }
+    } else if (c == Dt) hi = 0x7f7fu;                      // padding unit: the largest finite bf16, its key never passes
+}
+
+__global__ void build_db16b_kernel(const double *__restrict__ Fw, const double *__restrict__ fnorm, int64_t N,
+                                   int Dt, int Dpad, int64_t n_tiles, int64_t sample_stride, int64_t G, int nt_a,
+                                   u32x4 *__restrict__ A16)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // (tile, kb)
+    const int KB = Dpad / 16;
+    if (item >= n_tiles * KB) return;
+    const int64_t tile = item / KB;
+    const int kb = (int)(item % KB);
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t row = tile_row16(tile, r, sample_stride, G, nt_a);
+    unsigned int hi[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) db16b_column(Fw, fnorm, N, Dt, Dpad, row, 16 * kb + 8 * h + j, hi[j], lo[j]);
+    u32x4 vh, vl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { vh[j] = hi[2 * j] | (hi[2 * j + 1] << 16); vl[j] = lo[2 * j] | (lo[2 * j + 1] << 16); }
+    A16[(item * 2 + 0) * 64 + lane] = vh;
+    A16[(item * 2 + 1) * 64 + lane] = vl;
+}
+
+void launch_build_db16b(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,
+                        int64_t sample_stride, int64_t G, int nt_a, void *A16, hipStream_t s)
+{
+    const int64_t items = n_tiles * (Dpad / 16);
+    hipLaunchKernelGGL(build_db16b_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, Fw, fnorm, N, Dt, Dpad,
+                       n_tiles, sample_stride, G, nt_a, reinterpret_cast<u32x4 *>(A16));
+}
+
+// query operand: -2q in two pieces, 1.0 against the three norm pieces; also eps_t (as prepare_queries16)
+__global__ void prepare_queries16b_kernel(const double *__restrict__ Qp, const double *__restrict__ qnorm, int64_t T,
+                                          int Dt, int Dpad, const double *__restrict__ fmax2, double eps_c,
+                                          u32x4 *__restrict__ B16, double *__restrict__ eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_tiles = (T + 31) / 32;
+    const int KB = Dpad / 16;
+    if (item >= n_tiles * KB) return;
+    const int64_t tile = item / KB;
+    const int kb = (int)(item % KB);
+    const int64_t row = tile * 32 + (lane & 31);
+    const int h = lane >> 5;
+    unsigned int hi[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = 16 * kb + 8 * h + j;
+        hi[j] = 0u; lo[j] = 0u;
+        if (row < T) {
+            if (c < Dt) bf16_split(-2.0 * Qp[row * Dpad + c], hi[j], lo[j]);
+            else if (c < Dt + 3) hi[j] = 0x3f80u;            // 1.0
+        }
+    }
+    u32x4 vh, vl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { vh[j] = hi[2 * j] | (hi[2 * j + 1] << 16); vl[j] = lo[2 * j] | (lo[2 * j + 1] << 16); }
+    B16[(item * 2 + 0) * 64 + lane] = vh;
+    B16[(item * 2 + 1) * 64 + lane] = vl;
+    if (kb == 0 && h == 0) {
+        const double fm = sqrt(*fmax2);
+        const double qn = (row < T) ? sqrt(qnorm[row]) : 0.0;
+        eps[row] = eps_c * (2.0 * qn * fm + fm * fm) + 1e-30;
+    }
+}
+
+void launch_prepare_queries16b(const double *Qp, const double *qnorm, int64_t T, int Dt, int Dpad, const double *fmax2,
+                               double eps_c, void *B16, double *eps, hipStream_t s)
+{
+    const int64_t items = ((T + 31) / 32) * (Dpad / 16);
+    hipLaunchKernelGGL(prepare_queries16b_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, Qp, qnorm, T, Dt,
+                       Dpad, fmax2, eps_c, reinterpret_cast<u32x4 *>(B16), eps);
+}
+
+// The sweep: structure of knn_sweep16 (DB-stationary, persistent wavefronts, results of the previous step tested
+// in the shadow of the current step's MFMAs), 16 MFMAs per 32x32 tile and 64 columns instead of 31-32.
+template <int NT, int MODE, int KB>
+__global__ void __launch_bounds__(256, 1)
+knn_sweep16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const float *__restrict__ thr32, int nQT,
+             int64_t n_slabs, unsigned int *__restrict__ slab_counter, int qsplit, int64_t n_main_slabs, int qsplit_tail,
+             float *__restrict__ gmin32, int64_t G, PoolEntry16 *__restrict__ pool, unsigned int *__restrict__ pool_ctl,
+             int *__restrict__ chunk_fill, int max_chunks, int pool_chunk)
+{
+    constexpr int STAGE_CAP = 768;
+    __shared__ PoolEntry16 stage[(MODE == 1) ? 4 : 1][(MODE == 1) ? STAGE_CAP : 1];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int qcol = lane & 31;
+
+    auto grab = [&]() -> int64_t {
+        unsigned int v = 0;
+        if (lane == 0) v = atomicAdd(slab_counter, 1u);
+        return (int64_t)__builtin_amdgcn_readfirstlane(v);
+    };
+    int chunk_id = -1, cused = pool_chunk, lcount = 0;
+    auto new_chunk = [&]() {
+        if (chunk_id >= 0 && lane == 0) chunk_fill[chunk_id] = cused;
+        unsigned int c = 0;
+        if (lane == 0) c = atomicAdd(&pool_ctl[0], 1u);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if ((int)c >= max_chunks) { if (lane == 0) pool_ctl[1] = 1u; chunk_id = -1; }
+        else chunk_id = (int)c;
+        cused = 0;
+    };
+    auto flush_stage = [&]() {
+        if (cused + lcount > pool_chunk) new_chunk();
+        if (chunk_id >= 0)
+            for (int e = lane; e < lcount; e += 64)
+                pool[(int64_t)chunk_id * pool_chunk + cused + e] = stage[wv][e];
+        cused += lcount;
+        lcount = 0;
+    };
+    auto mfma = [](const u32x4 &a, const u32x4 &b, f16acc c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+
+    const int64_t n_main_items = n_main_slabs * qsplit;
+    const int64_t n_items = n_main_items + (n_slabs - n_main_slabs) * qsplit_tail;
+    int64_t item = grab();
+    while (item < n_items) {
+        const int64_t item_next = grab();
+        const bool tail = item >= n_main_items;
+        const int qs = tail ? qsplit_tail : qsplit;
+        const int64_t rel = tail ? item - n_main_items : item;
+        const int64_t w = (tail ? n_main_slabs : 0) + rel / qs;
+        const int part = (int)(rel % qs);
+        const int qt_lo = (int)(((int64_t)nQT * part) / qs);
+        const int qt_hi = (int)(((int64_t)nQT * (part + 1)) / qs);
+
+        // database fragments of this slab: resident in registers (hi and lo pieces)
+        u32x4 ah[NT][KB], al[NT][KB];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                ah[nt][kb] = A16[(((w * NT + nt) * KB + kb) * 2 + 0) * 64 + lane];
+                al[nt][kb] = A16[(((w * NT + nt) * KB + kb) * 2 + 1) * 64 + lane];
+            }
+        u32x4 bh0[KB], bl0[KB], bh1[KB], bl1[KB];
+        float th_cur = 0.f, th_nxt = 0.f, th_prev = -FLT_MAX;
+        auto load_q = [&](int t, u32x4 (&xh)[KB], u32x4 (&xl)[KB]) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                xh[kb] = B16[(((int64_t)t * KB + kb) * 2 + 0) * 64 + lane];
+                xl[kb] = B16[(((int64_t)t * KB + kb) * 2 + 1) * 64 + lane];
+            }
+            if (MODE == 1) th_nxt = thr32[t * 32 + qcol];
+        };
+        int qt = qt_lo + (int)((w * 3) % (qt_hi - qt_lo));
+        int qt_prev = qt;
+        load_q(qt, bh0, bl0);
+
+        constexpr int CH = (NT >= 2) ? 2 : 1;          // database tiles per step: independent MFMA chains
+        constexpr int NSTEP = NT / CH;
+        f16acc pacc[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pacc[j][r] = 0.0f;
+        float gm = FLT_MAX;
+
+        auto tile_body = [&](u32x4 (&xh)[KB], u32x4 (&xl)[KB], u32x4 (&nh)[KB], u32x4 (&nl)[KB], int it) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) { asm volatile("" : "+v"(xh[kb])); asm volatile("" : "+v"(xl[kb])); }
+            if (MODE == 1) asm volatile("" : "+v"(th_nxt));
+            th_cur = th_nxt;
+            if (MODE == 1 && lcount) flush_stage();      // staged entries leave a whole tile early
+            const int qt_next = (qt + 1 == qt_hi) ? qt_lo : qt + 1;
+            load_q(qt_next, nh, nl);
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                const int pnt = ((st > 0) ? st - 1 : NSTEP - 1) * CH;
+                const float pth = (st > 0) ? th_cur : th_prev;
+                const int pqt = (st > 0) ? qt : qt_prev;
+                f16acc acc[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+                // 4 KB MFMAs per tile (hi.hi, hi.lo, lo.hi, lo.lo per k-block); after each group of MFMAs one group
+                // of four pending results is tested
+                constexpr int NM = 4 * KB;                 // MFMA slots per tile
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const int kb = m >> 2, term = m & 3;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        const u32x4 &a = (term & 2) ? al[st * CH + j][kb] : ah[st * CH + j][kb];
+                        const u32x4 &b = (term & 1) ? xl[kb] : xh[kb];
+                        acc[j] = mfma(a, b, acc[j]);
+                    }
+                    // 16 CH pending results in groups of four, spread over the NM slots
+                    constexpr int NGRP = 4 * CH;
+                    const int g = (m * NGRP) / NM;
+                    const bool fire = ((m + 1) * NGRP) / NM != g || m == NM - 1;
+                    if (fire && g < NGRP) {
+                        const int e0 = 4 * g;
+                        const int j = e0 / 16, r0 = e0 % 16;
+                        const float v4[4] = {pacc[j][r0], pacc[j][r0 + 1], pacc[j][r0 + 2], pacc[j][r0 + 3]};
+                        const float m01 = v4[0] < v4[1] ? v4[0] : v4[1], m23 = v4[2] < v4[3] ? v4[2] : v4[3];
+                        const float m4 = m01 < m23 ? m01 : m23;
+                        if (MODE == 0) gm = m4 < gm ? m4 : gm;
+                        else if (__any(m4 <= pth)) {
+                            if (lcount > STAGE_CAP - 256) flush_stage();
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int r = r0 + q;
+                                const float key = v4[q];
+                                const bool pass = key <= pth;
+                                const unsigned long long mm = __ballot(pass);
+                                if (pass) {
+                                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
+                                    PoolEntry16 en;
+                                    en.key = (double)key;
+                                    en.idx = (int)((w * NT + pnt + j) * 32 + crow32(lane, r));
+                                    en.row = pqt * 32 + qcol;
+                                    stage[wv][lcount + rank] = en;
+                                }
+                                lcount += __popcll(mm);
+                            }
+                        }
+                    }
+                }
+                if (MODE == 0 && st == 0) {
+                    if (it > 0) gmin32[((int64_t)qt_prev * 32 + qcol) * G + 2 * w + (lane >> 5)] = gm;
+                    gm = FLT_MAX;
+                }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) pacc[j] = acc[j];
+            }
+            th_prev = th_cur;
+            qt_prev = qt;
+            qt = qt_next;
+        };
+        const int n_t = qt_hi - qt_lo;
+        for (int it = 0; it < n_t; it += 2) {
+            tile_body(bh0, bl0, bh1, bl1, it);
+            if (it + 1 < n_t) tile_body(bh1, bl1, bh0, bl0, it + 1);
+        }
+        // drain the last pending step of this work item
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float key = pacc[j][r];
+                if (MODE == 0) gm = key < gm ? key : gm;
+                else {
+                    if (lcount > STAGE_CAP - 64) flush_stage();
+                    const bool pass = key <= th_prev;
+                    const unsigned long long mm = __ballot(pass);
+                    if (pass) {
+                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
+                        PoolEntry16 en;
+                        en.key = (double)key;
+                        en.idx = (int)((w * NT + (NSTEP - 1) * CH + j) * 32 + crow32(lane, r));
+                        en.row = qt_prev * 32 + qcol;
+                        stage[wv][lcount + rank] = en;
+                    }
+                    lcount += __popcll(mm);
+                }
+            }
+        if (MODE == 0) gmin32[((int64_t)qt_prev * 32 + qcol) * G + 2 * w + (lane >> 5)] = gm;
+        item = item_next;
+    }
+    if (MODE == 1) {
+        if (lcount) flush_stage();
+        if (chunk_id >= 0 && lane == 0) chunk_fill[chunk_id] = cused;
+    }
+}
+
+// nt / dch as launch_knn_sweep16; instantiated for the reference's own widths: one chunk (Dt <= 61) with four
+// tiles per wavefront, three chunks (Dt <= 189) with one.  Returns false for any other shape (f32 prefilter then).
+bool knn_sweep16b_supported(int nt, int dch, int Dt, int Dpad, bool cls)
+{
+    return !cls && Dpad - Dt >= 3 && ((nt == 4 && dch == 1) || (nt == 1 && dch == 3));
+}
+
+bool launch_knn_sweep16b(int mode, int nt, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32,
+                         int64_t T32, int64_t n_slabs, unsigned int *ctr, float *gmin32, int64_t G, void *pool,
+                         unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s)
+{
+    const int nQT = (int)(T32 / 32);
+    const int64_t max_blocks = grid_cus;
+    int qsplit = 1;
+    while (n_slabs * qsplit < 2 * 4 * max_blocks && qsplit * 2 <= nQT && qsplit < 8) qsplit *= 2;
+    int64_t blocks = (n_slabs * qsplit + 3) / 4;
+    if (blocks > max_blocks) blocks = max_blocks;
+    int64_t n_main = n_slabs;
+    int qtail = qsplit;
+    sweep_tail_split(n_slabs, qsplit, blocks * 4, nQT, &n_main, &qtail);
+#define SNK_L16B(NT_, KB_, MODE_)                                                                            \
+    hipLaunchKernelGGL((knn_sweep16b<NT_, MODE_, KB_>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)A16, \
+                       (const u32x4 *)B16, thr32, nQT, n_slabs, ctr, qsplit, n_main, qtail, gmin32, G,       \
+                       (PoolEntry16 *)pool, pool_ctl, chunk_fill, max_chunks, pool_chunk)
+    if (nt == 4 && dch == 1) { if (mode == 0) SNK_L16B(4, 4, 0); else SNK_L16B(4, 4, 1); return true; }
+    if (nt == 1 && dch == 3) { if (mode == 0) SNK_L16B(1, 12, 0); else SNK_L16B(1, 12, 1); return true; }
+#undef SNK_L16B
+    return false;
+}
+
 #define THR16_GROUPS 1024
 // ---------------------------------------------------------------------------
 // threshold from the f32 group minima: K-th smallest of G values + eps_t, as f32 rounded UP.

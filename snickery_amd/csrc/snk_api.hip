@@ -148,6 +148,10 @@ struct snk_engine {
     int nt16 = 4, nt16_eff = 4;
     int64_t n_slabs16 = 0, n_slabs16_a = 0, stride16 = 16;
     double eps_c = 8e-6;          // 2x the analytical f32 bound (knn16_kernels.hip)
+    int prefilter = 1;            // 1: bf16-split operands on the bf16 matrix pipe where the shape has a variant, 0: float32 operands
+    bool bf16_ready = false;      // a16l / s16l (and gs_tiles_b) hold the bf16-split operands of the current weights
+    double eps_c_bf = 4e-5;       // bound of the bf16-split keys (knn16_kernels.hip)
+    DevBuf gs_tiles_b;
     int f16_fallbacks = 0;
     int last_f16_status = 0;
     HostBuf hstage;
@@ -334,7 +338,7 @@ int snk_destroy(snk_handle h)
     h->rowflag.release(); h->exact_rows.release(); h->exact_scratch.release();
     h->frames_spec.release(); h->frames_fzv.release(); h->cc_in.release(); h->cc_out.release();
     h->res_status.release(); h->hstage.release();
-    { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2};
+    { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b};
       for (auto *b : fb) b->release(); }
     for (int i = 0; i < 8; ++i) {
         UttSlot &s = h->slot[i];
@@ -526,6 +530,20 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
                               2 * h->n_slabs16_a, nt, h->s16h.p, h->stream);
             HIPCHK(hipGetLastError());
             h->f16_ready = true;
+            h->bf16_ready = false;
+            if (h->prefilter == 1 && knn_sweep16b_supported(nt, dch16, h->Dt, h->Dpad, false)) {
+                // representation 2^-15 (1 + 2^-8) of 2 |q| |f| (two dropped residuals of 2^-16 each), accumulation
+                // 2^-22 per MFMA over 4 MFMAs per 16 columns; 1.1 x the sum
+                h->eps_c_bf = 1.1 * (3.07e-5 + 2.4e-7 * (double)(h->Dpad / 4 + 1));
+                CHK(h->a16l.ensure(tiles_b * per_tile));
+                CHK(h->s16l.ensure(tiles_a * per_tile));
+                launch_build_db16b(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_b, 0, 0, nt,
+                                   h->a16l.p, h->stream);
+                launch_build_db16b(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_a, stride,
+                                   2 * h->n_slabs16_a, nt, h->s16l.p, h->stream);
+                HIPCHK(hipGetLastError());
+                h->bf16_ready = true;
+            }
         }
     }
     h->gs_ready = false;
@@ -545,6 +563,11 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
             CHK(h->gs_tiles.ensure((size_t)tiles * 8 * 64 * 16 * (h->Dpad / 64)));
             launch_build_db16(h->gs_w.as<double>(), h->gs_norm.as<double>(), h->gs_rows, h->Dt, h->Dpad, tiles, 1,
                               2 * h->gs_slabs, nt, h->gs_tiles.p, h->stream);
+            if (h->bf16_ready) {
+                CHK(h->gs_tiles_b.ensure((size_t)tiles * 8 * 64 * 16 * (h->Dpad / 64)));
+                launch_build_db16b(h->gs_w.as<double>(), h->gs_norm.as<double>(), h->gs_rows, h->Dt, h->Dpad, tiles, 1,
+                                   2 * h->gs_slabs, nt, h->gs_tiles_b.p, h->stream);
+            }
             HIPCHK(hipGetLastError());
             h->gs_ready = true;
         }
@@ -721,7 +744,9 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             cls_full = h->cls16_full.as<int32_t>();
             cls_samp = h->cls16_samp.as<int32_t>();
         }
-        CHK(h->b16h.ensure((size_t)(Tpad / 32) * 8 * 64 * 16 * (h->Dpad / 64)));
+        const bool bf = h->bf16_ready && h->prefilter == 1 && !cls && nt_run == h->nt16_eff;
+        const double eps_c_run = bf ? h->eps_c_bf : h->eps_c;
+        CHK((bf ? h->b16l : h->b16h).ensure((size_t)(Tpad / 32) * 8 * 64 * 16 * (h->Dpad / 64)));
         CHK(h->eps16.ensure((size_t)Tpad * sizeof(double)));
         CHK(h->thr32.ensure((size_t)Tpad * sizeof(float)));
         CHK(h->gmin32.ensure((size_t)Tpad * G16 * sizeof(float)));
@@ -729,12 +754,22 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
                          h->slabctr.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, s);
         {
             StageTimer t(h, s, TM_PREP);
+            if (bf)
+                launch_prepare_queries16b(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad,
+                                          use_gs ? h->gs_fmax2.as<double>() : h->fmax2.as<double>(), eps_c_run, h->b16l.p,
+                                          h->eps16.as<double>(), s);
+            else
             launch_prepare_queries16(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad,
                                      use_gs ? h->gs_fmax2.as<double>() : h->fmax2.as<double>(), h->eps_c, h->b16h.p,
                                      h->eps16.as<double>(), s);
         }
         if (!bound_in) {
             StageTimer t(h, s, TM_KNN_MINIMA);
+            if (bf)
+                launch_knn_sweep16b(0, nt_run, dch16, p0.grid_cus, use_gs ? h->gs_tiles_b.p : h->s16l.p, h->b16l.p, nullptr, Tpad,
+                                    n_slabs_a, h->slabctr.as<unsigned int>(), h->gmin32.as<float>(), G16, nullptr, nullptr,
+                                    nullptr, 0, knn_pool_chunk_entries(), s);
+            else
             launch_knn_sweep16(0, nt_run, dch16, (h->Dt + 2) / 2, p0.grid_cus, use_gs ? h->gs_tiles.p : h->s16h.p, h->b16h.p, cls_samp, qclass_dev,
                                nullptr, Tpad, n_slabs_a, h->slabctr.as<unsigned int>(), h->gmin32.as<float>(),
                                G16, nullptr, nullptr, nullptr, 0, knn_pool_chunk_entries(), s);
@@ -747,6 +782,11 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         if (bound_out) return 0;             // stage A only
         {
             StageTimer t(h, s, TM_KNN_FILTER);
+            if (bf)
+                launch_knn_sweep16b(1, nt_run, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, h->thr32.as<float>(), Tpad, n_slabs_b,
+                                    h->slabctr.as<unsigned int>() + 1, nullptr, 0, h->pool.p, h->poolctl.as<unsigned int>(),
+                                    h->chunkfill.as<int>(), max_chunks, knn_pool_chunk_entries(), s);
+            else
             launch_knn_sweep16(1, nt_run, dch16, (h->Dt + 2) / 2, p0.grid_cus, h->a16h.p, h->b16h.p, cls_full, qclass_dev,
                                h->thr32.as<float>(), Tpad, n_slabs_b, h->slabctr.as<unsigned int>() + 1, nullptr, 0,
                                h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
@@ -761,7 +801,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             StageTimer t(h, s, TM_KNN_FINALIZE);
             launch_knn_finalize(h->Fw.as<double>(), h->F_unw.as<float>(), h->Fp, h->wt.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
-                                h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), h->eps_c, cand_dev, dist_dev, d2_dev, status_dev, nullptr, s);
+                                h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), eps_c_run, cand_dev, dist_dev, d2_dev, status_dev, nullptr, s);
         }
         if (deferred_status) return 0;       // the batch caller redoes failures with precision 0
         int status = 0;
@@ -926,6 +966,63 @@ int snk_knn(snk_handle h, const double *Q, int64_t T, int D, int K, int64_t *can
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     collect_timers(h);
+    return 0;
+}
+
+// Diagnostic of the prefilter's error bound (include/snk.h): the prefilter's minimum key of every (query row, slab of
+// rows_per_slab consecutive units) pair and the bound eps[t] it is trusted to; the caller compares with float64 keys.
+int snk_prefilter_minima(snk_handle h, const double *Q, int64_t T, int D, float *slab_min, int64_t slab_min_len,
+                         double *eps_out, int64_t *n_slabs_out, int *rows_per_slab_out)
+{
+    CHK(check_ready(h, true, false));
+    CHK(no_batch_in_flight(h, "snk_prefilter_minima"));
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->f16_ready) return fail("snk_prefilter_minima: this database shape has no float32 / bf16 prefilter");
+    if (T < 1 || T > SNK_KNN_MAX_ROWS) return fail("snk_prefilter_minima: T outside 1..%d", (int)SNK_KNN_MAX_ROWS);
+    const int64_t n_slabs = h->n_slabs16;
+    if (n_slabs_out) *n_slabs_out = n_slabs;
+    if (rows_per_slab_out) *rows_per_slab_out = 32 * h->nt16_eff;
+    if (!slab_min) return 0;                   // size query
+    if (slab_min_len < T * n_slabs || !eps_out) return fail("snk_prefilter_minima: output too small");
+    CHK(upload_queries(h, Q, T, D));
+    const int64_t Tpad = roundup(T, 32), G16 = 2 * n_slabs;
+    const bool bf = h->bf16_ready && h->prefilter == 1;
+    const int dch16 = h->Dpad / 64;
+    hipStream_t s = h->stream;
+    CHK(h->Qp.ensure((size_t)Tpad * h->Dpad * sizeof(double)));
+    CHK(h->Qf.ensure((size_t)Tpad * h->Dpad * sizeof(double)));
+    CHK(h->qnorm.ensure((size_t)Tpad * sizeof(double)));
+    CHK((bf ? h->b16l : h->b16h).ensure((size_t)(Tpad / 32) * 8 * 64 * 16 * dch16));
+    CHK(h->eps16.ensure((size_t)Tpad * sizeof(double)));
+    CHK(h->gmin32.ensure((size_t)Tpad * G16 * sizeof(float)));
+    CHK(h->slabctr.ensure(4 * sizeof(unsigned int)));
+    HIPCHK(hipMemsetAsync(h->slabctr.p, 0, 4 * sizeof(unsigned int), s));
+    launch_prepare_queries(h->Qraw.as<double>(), T, h->Dt, h->Qp.as<double>(), h->Qf.as<double>(), h->qnorm.as<double>(),
+                           Tpad, h->Dpad, s);
+    const KnnPlan p0 = make_plan(h, 1);
+    if (bf) {
+        launch_prepare_queries16b(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad, h->fmax2.as<double>(),
+                                  h->eps_c_bf, h->b16l.p, h->eps16.as<double>(), s);
+        launch_knn_sweep16b(0, h->nt16_eff, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, nullptr, Tpad, n_slabs,
+                            h->slabctr.as<unsigned int>(), h->gmin32.as<float>(), G16, nullptr, nullptr, nullptr, 0,
+                            knn_pool_chunk_entries(), s);
+    } else {
+        launch_prepare_queries16(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad, h->fmax2.as<double>(),
+                                 h->eps_c, h->b16h.p, h->eps16.as<double>(), s);
+        launch_knn_sweep16(0, h->nt16_eff, dch16, (h->Dt + 2) / 2, p0.grid_cus, h->a16h.p, h->b16h.p, nullptr, nullptr,
+                           nullptr, Tpad, n_slabs, h->slabctr.as<unsigned int>(), h->gmin32.as<float>(), G16, nullptr,
+                           nullptr, nullptr, 0, knn_pool_chunk_entries(), s);
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<float> g((size_t)T * G16);
+    HIPCHK(hipMemcpyAsync(g.data(), h->gmin32.p, g.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(eps_out, h->eps16.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int64_t t = 0; t < T; ++t)
+        for (int64_t w = 0; w < n_slabs; ++w) {
+            const float a = g[t * G16 + 2 * w], b = g[t * G16 + 2 * w + 1];
+            slab_min[t * n_slabs + w] = a < b ? a : b;
+        }
     return 0;
 }
 
@@ -2204,6 +2301,11 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "precision")) {
         if (value != 0.0 && value != 1.0) return fail("precision must be 0 (f64 sweep) or 1 (f32 prefilter + exact f64 re-rank)");
         h->precision = (int)value;
+    } else if (!strcmp(name, "prefilter")) {
+        if (value != 0.0 && value != 1.0) return fail("prefilter must be 0 (float32 operands) or 1 (bf16-split operands where the shape has a variant)");
+        CHK(no_batch_in_flight(h, "snk_set_option(prefilter)"));
+        h->prefilter = (int)value;
+        h->have_weights = false;          // the bf16 operands are built by set_weights
     } else if (!strcmp(name, "reserved_cus")) {
         if (value < 0 || value > 64) return fail("reserved_cus must be in 0..64");
         h->reserved_cus = (int)value;
@@ -2263,6 +2365,9 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "last_f16_status")) *out = h->last_f16_status;
     else if (!strcmp(name, "pool_chunks_used")) { unsigned int v[2] = {0, 0}; HIPCHK(hipMemcpy(v, h->poolctl.p, sizeof(v), hipMemcpyDeviceToHost)); *out = v[0] + 1e6 * v[1]; }
     else if (!strcmp(name, "precision")) *out = h->precision;
+    else if (!strcmp(name, "prefilter")) *out = h->prefilter;
+    else if (!strcmp(name, "prefilter_bf16_active")) *out = h->bf16_ready ? 1 : 0;
+    else if (!strcmp(name, "prefilter_eps_c")) *out = (h->bf16_ready && h->prefilter == 1) ? h->eps_c_bf : h->eps_c;
     else if (!strcmp(name, "batch_rows")) *out = h->batch_rows;
     else if (!strcmp(name, "last_list_mean") || !strcmp(name, "last_list_max")) {
         // candidate-list lengths of the most recent K-NN call (debug / tuning aid)

@@ -80,6 +80,15 @@ bool launch_knn_sweep16(int mode, int nt, int dch, int k_steps, int grid_cus, co
                         int max_chunks, int pool_chunk, hipStream_t s);
 void launch_knn_threshold16(const float *gmin32, int64_t G, int64_t T, int64_t T32, int K, const double *eps,
                             double *thr, float *thr32, const double *bound_in, double *bound_out, hipStream_t s);
+// bf16-split prefilter (knn16_kernels.hip)
+bool knn_sweep16b_supported(int nt, int dch, int Dt, int Dpad, bool cls);
+void launch_build_db16b(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,
+                        int64_t sample_stride, int64_t G, int nt_a, void *A16, hipStream_t s);
+void launch_prepare_queries16b(const double *Qp, const double *qnorm, int64_t T, int Dt, int Dpad, const double *fmax2,
+                               double eps_c, void *B16, double *eps, hipStream_t s);
+bool launch_knn_sweep16b(int mode, int nt, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32,
+                         int64_t T32, int64_t n_slabs, unsigned int *ctr, float *gmin32, int64_t G, void *pool,
+                         unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s);
 void launch_mfma16_selftest(const float *A, const float *B, float *C, hipStream_t s);
 int knn_pool_chunk_entries();
 void sweep_tail_split(int64_t n_slabs, int qsplit, int64_t waves, int nQT, int64_t *n_main, int *qtail);

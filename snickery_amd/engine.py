@@ -40,6 +40,8 @@ _SIGNATURES = {
     'snk_set_unit_classes': (ctypes.c_int, [ctypes.c_void_p, _c_i32p, ctypes.c_int64]),
     'snk_knn_by_class': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int,
                                         ctypes.c_int, _c_i32p, _c_i64p, _c_f64p]),
+    'snk_prefilter_minima': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int, _c_f32p, ctypes.c_int64,
+                                            _c_f64p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]),
     'snk_candidate_distances': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int, _c_i64p,
                                                ctypes.c_int, _c_f64p]),
     'snk_join_costs': (ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int64, ctypes.c_int, _c_f64p]),
@@ -261,6 +263,19 @@ class HipSearchEngine(object):
         self._check(self._lib.snk_knn_by_class(self._h, _ptr(Q, _c_f64p), T, D, K, _ptr(qc, _c_i32p),
                                                _ptr(cand, _c_i64p), _ptr(dist, _c_f64p)))
         return cand, dist
+
+    def prefilter_minima(self, unit_features):
+        """Diagnostic (include/snk.h snk_prefilter_minima): (slab_min (T, n_slabs) f32, eps (T), rows_per_slab)."""
+        Q = _f64(unit_features)
+        T, D = Q.shape
+        n_slabs, rows = ctypes.c_int64(0), ctypes.c_int(0)
+        self._check(self._lib.snk_prefilter_minima(self._h, _ptr(Q, _c_f64p), T, D, None, 0, None, ctypes.byref(n_slabs),
+                                                   ctypes.byref(rows)))
+        out = np.empty((T, n_slabs.value), dtype=np.float32)
+        eps = np.empty(T, dtype=np.float64)
+        self._check(self._lib.snk_prefilter_minima(self._h, _ptr(Q, _c_f64p), T, D, _ptr(out, _c_f32p), out.size,
+                                                   _ptr(eps, _c_f64p), ctypes.byref(n_slabs), ctypes.byref(rows)))
+        return out, eps, rows.value
 
     def candidate_distances(self, unit_features, candidates):
         """Distance part of preselect_units_quinphone (synth_halfphone.py:1343-1349)."""

@@ -1,0 +1,99 @@
+"""The bf16-split K-NN prefilter (knn16_kernels.hip knn_sweep16b): results stay those of the exact search, and the
+error bound the prefilter is trusted to holds with room against float64 keys.  The prefilter only decides which units
+reach the exact float64 re-rank; a key off by more than eps could drop a true neighbour, so the bound is the thing
+to test, not only the end result."""
+import numpy as np
+import pytest
+
+import snk_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def engine():
+    import snickery_amd
+    e = snickery_amd.HipSearchEngine(0)
+    yield e
+    e.set_option('prefilter', 1)
+    e.close()
+
+
+def setup(engine, N, Dt, seed, offset=0.0, scale=None):
+    F_unw, JC_unw = o.synthetic_db(N, Dt, 24, seed)
+    if scale is not None:
+        F_unw = (F_unw * scale).astype(np.float32)
+    if offset:
+        F_unw = (F_unw + np.float32(offset)).astype(np.float32)
+    rng = np.random.RandomState(seed + 100)
+    wt = 0.2 + rng.rand(Dt)
+    wj = 0.05 + 0.2 * rng.rand(24)
+    F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    return F_unw, wt, F
+
+
+@pytest.mark.parametrize('N,T,K,Dt', [(65536, 96, 100, 61), (40000, 64, 50, 45), (30000, 40, 30, 150), (50000, 33, 200, 189),
+                                      (33333, 70, 16, 20)])
+def test_bf16_prefilter_results_are_the_exact_ones(engine, N, T, K, Dt):
+    engine.set_option('prefilter', 1)
+    F_unw, wt, F = setup(engine, N, Dt, seed=N % 89)
+    assert engine.info('prefilter_bf16_active') == 1
+    U = o.synthetic_targets(F_unw, T, seed=5) * wt
+    before = engine.info('f16_fallbacks')
+    cand, dist = engine.knn(U, K)
+    oc, od = o.knn_bruteforce(F, U, K)
+    assert np.array_equal(cand, oc)
+    assert np.array_equal(dist, od)
+    assert engine.info('f16_fallbacks') == before               # margins held: no exact re-sweep was needed
+    engine.set_option('prefilter', 0)
+    engine.set_weights(wt, np.full(24, 0.1))
+    assert engine.info('prefilter_bf16_active') == 0
+    c0, d0 = engine.knn(U, K)
+    assert np.array_equal(c0, cand) and np.array_equal(d0, dist)
+
+
+def test_shapes_without_a_bf16_variant_keep_float32_operands(engine):
+    engine.set_option('prefilter', 1)
+    for Dt in (100, 63, 191):       # two chunks; no three spare columns
+        F_unw, wt, F = setup(engine, 30000, Dt, seed=Dt)
+        assert engine.info('prefilter_bf16_active') == 0
+        U = o.synthetic_targets(F_unw, 20, seed=5) * wt
+        cand, dist = engine.knn(U, 20)
+        oc, od = o.knn_bruteforce(F, U, 20)
+        assert np.array_equal(cand, oc) and np.array_equal(dist, od)
+
+
+def slab_minima_f64(F, U, rows):
+    n_slabs = (F.shape[0] + rows - 1) // rows
+    keys = (F * F).sum(1)[None, :] - 2.0 * (U @ F.T)                 # (T, N) float64
+    pad = n_slabs * rows - F.shape[0]
+    if pad:
+        keys = np.concatenate([keys, np.full((U.shape[0], pad), np.inf)], axis=1)
+    return keys.reshape(U.shape[0], n_slabs, rows).min(axis=2)
+
+
+@pytest.mark.parametrize('prefilter', [1, 0])
+@pytest.mark.parametrize('Dt,offset,scale', [(61, 0.0, None), (61, 3.0, None), (150, 0.0, None), (189, -2.0, None),
+                                             (61, 0.0, 37.0), (45, 100.0, 0.01)])
+def test_prefilter_keys_stay_inside_their_bound(engine, prefilter, Dt, offset, scale):
+    """|key~ - key| <= eps[t] is what the filter's margins assume.  Offsets make ||f|| large against the
+    distances (cancellation: the hard case for the split operands); scale moves the exponent range."""
+    engine.set_option('prefilter', prefilter)
+    N, T = 32768 + 77, 64
+    F_unw, wt, F = setup(engine, N, Dt, seed=Dt + 1, offset=offset, scale=scale)
+    assert engine.info('prefilter_bf16_active') == prefilter
+    U = o.synthetic_targets(F_unw, T, seed=9) * wt
+    got, eps, rows = engine.prefilter_minima(U)
+    want = slab_minima_f64(F, U, rows)
+    assert got.shape == want.shape
+    ratio = np.abs(got.astype(np.float64) - want) / eps[:, None]
+    # the float32 result itself is rounded once more (2^-24 relative): far inside the bound
+    print('prefilter %d Dt %d offset %g: max |key~ - key| / eps = %.4f (eps_c %.3g)' % (prefilter, Dt, offset, ratio.max(),
+                                                                                     engine.info('prefilter_eps_c')))
+    assert ratio.max() <= 0.5, ratio.max()
+    # and the exact search is still exact on this data
+    cand, dist = engine.knn(U, 40)
+    oc, od = o.knn_bruteforce(F, U, 40)
+    assert np.array_equal(cand, oc) and np.array_equal(dist, od)
