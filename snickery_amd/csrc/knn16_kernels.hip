@@ -21,6 +21,8 @@
 // The k index is permuted: within a chunk lane half h covers columns 32h..32h+31 (step kk -> column
 // 32h+kk), so every lane reads 128 contiguous bytes per tile and chunk.
 #include "snk_internal.h"
+#include <stdlib.h>
+#include <type_traits>
 #include <float.h>
 
 namespace snk {
@@ -475,12 +477,17 @@ bool launch_knn_sweep16(int mode, int nt, int dch, int k_steps, int grid_cus, co
 // bf16-split prefilter: the same sweep on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate).
 // Every operand value x is carried as two bf16 pieces, x = hi + lo + r with |lo| <= 2^-8 |x| and |r| <= 2^-17 |x|
 // (hi = bf16(x), lo = bf16(x - hi), both round-to-nearest; the subtraction is exact in float64), and a k-block of
-// 16 columns costs FOUR MFMAs (hi.hi + hi.lo + lo.hi + lo.lo) accumulating in float32.  ||f||^2 rides in THREE
+// 16 columns costs THREE MFMAs (hi.hi + hi.lo + lo.hi; lo.lo <= 2^-16 |x||y| is dropped like the residuals: the
+// sweep runs at the rate the matrix pipe issues, so a quarter fewer MFMAs is a quarter less time) accumulating in float32.  ||f||^2 rides in THREE
 // spare columns as three bf16 pieces against 1.0 (24 bits), which is why the variant needs Dpad - Dt >= 3.
-//     |key~ - key| <= 2 2^-17 (2 ||q|| ||f||)  [dropped residuals r]  +  accumulation of 16 MFMAs per tile, each
-//     assumed no better than 2^-22 of the sum of its |products| and |C| (four times a sequentially rounded float32
-//     sum; the unit's internal order is not documented)  <=  2e-5 (2 ||q|| ||f|| + ||f||^2);  eps_c = 4e-5 (x 2).
-// tests/test_gpu_parity.py measures the real deviation against float64 keys: it must stay below a quarter of that.
+//     |key~ - key| <= 3 2^-16 (2 ||q|| ||f||)  [x y - (xh yh + xh yl + xl yh) = xl yl + x ry + rx y - ..., each <= 2^-16 |x||y|]
+//                     + accumulation of 3 Dpad / 16 MFMAs per tile, each assumed no better than 2^-22 of the sum of
+//                       its |products| and |C| (four times a sequentially rounded float32 sum; the unit's internal
+//                       order is not documented)
+//     eps_c = 1.1 (4.6e-5 + 2.4e-7 (3 Dpad / 16 + 1))  =  5.4e-5 at Dpad = 64 (snk_api.hip), against 8e-6 of the float32 operands:
+//     a handful more units per row inside the margin, nothing the float64 re-rank notices.
+// tests/test_gpu_prefilter.py measures the real deviation against float64 keys: it must stay below half of that
+// (measured: 4-6 % of it -- rounding errors do not line up).
 // The k index inside a k-block follows the instruction's operand map: lane l (r = l & 31, h = l >> 5) holds columns
 // 16 kb + 8 h + j, j = 0..7, of row r.  Operand buffers: [tile][kb][piece][lane] x 16 bytes -- 8 KB per tile and
 // 64 columns, the float32 operand's size.
@@ -676,14 +683,82 @@ knn_sweep16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const
 
         constexpr int CH = (NT >= 2) ? 2 : 1;          // database tiles per step: independent MFMA chains
         constexpr int NSTEP = NT / CH;
-        f16acc pacc[CH];
+        static_assert(NSTEP <= 2, "the two accumulator sets alternate per step");
+        // two accumulator sets: the MFMAs of a step fill one while the results of the step before are tested out of
+        // the other -- no copies.  NSTEP == 2: set = step of the query tile; NSTEP == 1: set = parity of the tile.
+        f16acc S0[CH], S1[CH];
+        const int idx_lane = 4 * (lane >> 5), idx_wave = (int)(w * NT * 32);
 #pragma unroll
         for (int j = 0; j < CH; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pacc[j][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) { S0[j][r] = 0.0f; S1[j][r] = 0.0f; }
         float gm = FLT_MAX;
 
-        auto tile_body = [&](u32x4 (&xh)[KB], u32x4 (&xl)[KB], u32x4 (&nh)[KB], u32x4 (&nl)[KB], int it) {
+        // one group of four pending results: v4 of database tile pt, result registers r0..r0+3, of query tile pq
+        auto test4 = [&](const f16acc &res, int pt, int r0, float pth, int pq) {
+            const float v0 = res[r0], v1 = res[r0 + 1], v2 = res[r0 + 2], v3 = res[r0 + 3];
+            if (MODE == 0) {
+                asm("v_min3_f32 %0, %0, %1, %2" : "+v"(gm) : "v"(v0), "v"(v1));
+                asm("v_min3_f32 %0, %0, %1, %2" : "+v"(gm) : "v"(v2), "v"(v3));
+            } else {
+                float m4;
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m4) : "v"(v0), "v"(v1), "v"(v2));
+                asm("v_min_f32 %0, %0, %1" : "+v"(m4) : "v"(v3));
+                if (__any(m4 <= pth)) {
+                    if (lcount > STAGE_CAP - 256) flush_stage();
+                    const float v4[4] = {v0, v1, v2, v3};
+                    // the ids are put together here, not hoisted per (tile, register) out of the loop
+                    int ib = idx_lane, wb = idx_wave;
+                    asm volatile("" : "+v"(ib));
+                    asm volatile("" : "+s"(wb));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float key = v4[q];
+                        const bool pass = key <= pth;
+                        const unsigned long long mm = __ballot(pass);
+                        if (pass) {
+                            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
+                            PoolEntry16 en;
+                            en.key = (double)key;
+                            en.idx = wb + ib + (pt * 32 + crow32(0, r0 + q));
+                            en.row = pq * 32 + qcol;
+                            stage[wv][lcount + rank] = en;
+                        }
+                        lcount += __popcll(mm);
+                    }
+                }
+            }
+        };
+        // one step: CH database tiles (first one: t0) against the query tile in (xh, xl) into `cur`, while the CH
+        // results in `prev` (database tiles from pt0 of query tile pq, threshold pth) are tested in the MFMA shadows
+        auto step = [&](f16acc (&cur)[CH], const f16acc (&prev)[CH], int t0, u32x4 (&xh)[KB], u32x4 (&xl)[KB], int pt0, float pth,
+                        int pq) {
+            constexpr int NM = 3 * KB;                     // MFMA slots per tile (hi.hi, hi.lo, lo.hi per k-block)
+            constexpr int NGRP = 4 * CH;                   // groups of four pending results
+            static_assert(NM >= NGRP, "at most one group per slot");
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int kb = m / 3, term = m % 3;        // term 0: hi.hi, 1: hi(db).lo(query), 2: lo(db).hi(query)
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const u32x4 &a = (term & 2) ? al[t0 + j][kb] : ah[t0 + j][kb];
+                    const u32x4 &b = (term & 1) ? xl[kb] : xh[kb];
+                    if (m == 0) {
+                        f16acc z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                        cur[j] = mfma(a, b, z);
+                    } else cur[j] = mfma(a, b, cur[j]);
+                }
+                // group g is tested after slot (g + 1) NM / NGRP - 1: spread evenly over the NM slots
+                {
+                    const int g = ((m + 1) * NGRP + NM - 1) / NM - 1;
+                    if (((g + 1) * NM) / NGRP - 1 == m) test4(prev[(4 * g) / 16], pt0 + (4 * g) / 16, (4 * g) % 16, pth, pq);
+                }
+            }
+        };
+
+        auto tile_body = [&](u32x4 (&xh)[KB], u32x4 (&xl)[KB], u32x4 (&nh)[KB], u32x4 (&nl)[KB], int it, auto PAR) {
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) { asm volatile("" : "+v"(xh[kb])); asm volatile("" : "+v"(xl[kb])); }
             if (MODE == 1) asm volatile("" : "+v"(th_nxt));
@@ -691,66 +766,21 @@ knn_sweep16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const
             if (MODE == 1 && lcount) flush_stage();      // staged entries leave a whole tile early
             const int qt_next = (qt + 1 == qt_hi) ? qt_lo : qt + 1;
             load_q(qt_next, nh, nl);
-#pragma unroll
-            for (int st = 0; st < NSTEP; ++st) {
-                const int pnt = ((st > 0) ? st - 1 : NSTEP - 1) * CH;
-                const float pth = (st > 0) ? th_cur : th_prev;
-                const int pqt = (st > 0) ? qt : qt_prev;
-                f16acc acc[CH];
-#pragma unroll
-                for (int j = 0; j < CH; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-                // 4 KB MFMAs per tile (hi.hi, hi.lo, lo.hi, lo.lo per k-block); after each group of MFMAs one group
-                // of four pending results is tested
-                constexpr int NM = 4 * KB;                 // MFMA slots per tile
-#pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const int kb = m >> 2, term = m & 3;
-#pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        const u32x4 &a = (term & 2) ? al[st * CH + j][kb] : ah[st * CH + j][kb];
-                        const u32x4 &b = (term & 1) ? xl[kb] : xh[kb];
-                        acc[j] = mfma(a, b, acc[j]);
-                    }
-                    // 16 CH pending results in groups of four, spread over the NM slots
-                    constexpr int NGRP = 4 * CH;
-                    const int g = (m * NGRP) / NM;
-                    const bool fire = ((m + 1) * NGRP) / NM != g || m == NM - 1;
-                    if (fire && g < NGRP) {
-                        const int e0 = 4 * g;
-                        const int j = e0 / 16, r0 = e0 % 16;
-                        const float v4[4] = {pacc[j][r0], pacc[j][r0 + 1], pacc[j][r0 + 2], pacc[j][r0 + 3]};
-                        const float m01 = v4[0] < v4[1] ? v4[0] : v4[1], m23 = v4[2] < v4[3] ? v4[2] : v4[3];
-                        const float m4 = m01 < m23 ? m01 : m23;
-                        if (MODE == 0) gm = m4 < gm ? m4 : gm;
-                        else if (__any(m4 <= pth)) {
-                            if (lcount > STAGE_CAP - 256) flush_stage();
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int r = r0 + q;
-                                const float key = v4[q];
-                                const bool pass = key <= pth;
-                                const unsigned long long mm = __ballot(pass);
-                                if (pass) {
-                                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
-                                    PoolEntry16 en;
-                                    en.key = (double)key;
-                                    en.idx = (int)((w * NT + pnt + j) * 32 + crow32(lane, r));
-                                    en.row = pqt * 32 + qcol;
-                                    stage[wv][lcount + rank] = en;
-                                }
-                                lcount += __popcll(mm);
-                            }
-                        }
-                    }
-                }
-                if (MODE == 0 && st == 0) {
+            if (NSTEP == 2) {
+                // step 0 tests the second half of the previous query tile, step 1 the first half of this one
+                step(S0, S1, 0, xh, xl, CH, th_prev, qt_prev);
+                if (MODE == 0) {
                     if (it > 0) gmin32[((int64_t)qt_prev * 32 + qcol) * G + 2 * w + (lane >> 5)] = gm;
                     gm = FLT_MAX;
                 }
-#pragma unroll
-                for (int j = 0; j < CH; ++j) pacc[j] = acc[j];
+                step(S1, S0, CH, xh, xl, 0, th_cur, qt);
+            } else {
+                if (decltype(PAR)::value == 0) step(S0, S1, 0, xh, xl, 0, th_prev, qt_prev);
+                else step(S1, S0, 0, xh, xl, 0, th_prev, qt_prev);
+                if (MODE == 0) {
+                    if (it > 0) gmin32[((int64_t)qt_prev * 32 + qcol) * G + 2 * w + (lane >> 5)] = gm;
+                    gm = FLT_MAX;
+                }
             }
             th_prev = th_cur;
             qt_prev = qt;
@@ -758,31 +788,18 @@ knn_sweep16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const
         };
         const int n_t = qt_hi - qt_lo;
         for (int it = 0; it < n_t; it += 2) {
-            tile_body(bh0, bl0, bh1, bl1, it);
-            if (it + 1 < n_t) tile_body(bh1, bl1, bh0, bl0, it + 1);
+            tile_body(bh0, bl0, bh1, bl1, it, std::integral_constant<int, 0>());
+            if (it + 1 < n_t) tile_body(bh1, bl1, bh0, bl0, it + 1, std::integral_constant<int, 1>());
         }
         // drain the last pending step of this work item
+        auto drain = [&](const f16acc (&res)[CH]) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j)
+            for (int j = 0; j < CH; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float key = pacc[j][r];
-                if (MODE == 0) gm = key < gm ? key : gm;
-                else {
-                    if (lcount > STAGE_CAP - 64) flush_stage();
-                    const bool pass = key <= th_prev;
-                    const unsigned long long mm = __ballot(pass);
-                    if (pass) {
-                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
-                        PoolEntry16 en;
-                        en.key = (double)key;
-                        en.idx = (int)((w * NT + (NSTEP - 1) * CH + j) * 32 + crow32(lane, r));
-                        en.row = qt_prev * 32 + qcol;
-                        stage[wv][lcount + rank] = en;
-                    }
-                    lcount += __popcll(mm);
-                }
-            }
+                for (int r0 = 0; r0 < 16; r0 += 4) test4(res[j], (NSTEP - 1) * CH + j, r0, th_prev, qt_prev);
+        };
+        if (NSTEP == 2 || (n_t & 1) == 0) drain(S1);
+        else drain(S0);
         if (MODE == 0) gmin32[((int64_t)qt_prev * 32 + qcol) * G + 2 * w + (lane >> 5)] = gm;
         item = item_next;
     }

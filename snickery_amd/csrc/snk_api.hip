@@ -532,9 +532,9 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
             h->f16_ready = true;
             h->bf16_ready = false;
             if (h->prefilter == 1 && knn_sweep16b_supported(nt, dch16, h->Dt, h->Dpad, false)) {
-                // representation 2^-15 (1 + 2^-8) of 2 |q| |f| (two dropped residuals of 2^-16 each), accumulation
-                // 2^-22 per MFMA over 4 MFMAs per 16 columns; 1.1 x the sum
-                h->eps_c_bf = 1.1 * (3.07e-5 + 2.4e-7 * (double)(h->Dpad / 4 + 1));
+                // representation 3 2^-16 of 2 |q| |f| (lo.lo and the two residuals, 2^-16 each), accumulation
+                // 2^-22 per MFMA over 3 MFMAs per 16 columns; 1.1 x the sum (knn16_kernels.hip)
+                h->eps_c_bf = 1.1 * (4.6e-5 + 2.4e-7 * (double)(3 * h->Dpad / 16 + 1));
                 CHK(h->a16l.ensure(tiles_b * per_tile));
                 CHK(h->s16l.ensure(tiles_a * per_tile));
                 launch_build_db16b(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_b, 0, 0, nt,
