@@ -191,6 +191,7 @@ def main():
     ap.add_argument('--viterbi-mode', type=int, default=2, choices=(0, 1, 2),
                     help='2: the engine default (batches: f32 matrix lower bounds + verified sparse exact recursion); '
                          '1: force that path; 0: dense exact float64 join costs')
+    ap.add_argument('--opt', action='append', default=[], metavar='NAME=VALUE', help='engine option (snk_set_option), for experiments')
     ap.add_argument('--join-beta', type=float, default=None, help='margin of the predecessor sets (speed only)')
     ap.add_argument('--in-flight', type=int, default=2, choices=(1, 2),
                     help='N = 1: steps in flight; 2 (default) submits step i+1 before collecting step i, so the tail of a step '
@@ -249,6 +250,9 @@ def main():
     eng.set_option('viterbi_mode', args.viterbi_mode)
     if args.join_beta is not None:
         eng.set_option('join_beta', args.join_beta)
+    for kv in args.opt:
+        name, value = kv.split('=')
+        eng.set_option(name, float(value))
     if world == 1:
         eng.upload_db(F_unw, JC_unw)
         eng.set_weights(wt, wj)

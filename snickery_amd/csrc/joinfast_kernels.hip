@@ -255,6 +255,8 @@ viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
                   const float *__restrict__ J_all, const float *__restrict__ scale_all, const DpBatch batch, int K,
                   int64_t n_units, int KP, float beta, u32x4 *__restrict__ sets_all)
 {
+    // a T-step chain on one compute unit beside the K-NN sweep's MFMA wavefronts: its few instructions go first
+    __builtin_amdgcn_s_setprio(3);
     const int64_t r0 = batch.off[blockIdx.x];
     const int64_t T = batch.off[blockIdx.x + 1] - r0;
     const int64_t *__restrict__ cand = cand_all + r0 * K;
@@ -565,6 +567,7 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
                       int64_t *__restrict__ path_len_all, double *__restrict__ cost_all,
                       unsigned long long *__restrict__ stats)
 {
+    __builtin_amdgcn_s_setprio(3);           // as viterbi_lb_kernel
     const int64_t r0 = batch.off[blockIdx.x];
     const int64_t T = batch.off[blockIdx.x + 1] - r0;
     const int64_t *__restrict__ cand = cand_all + r0 * K;

@@ -478,14 +478,15 @@ bool launch_knn_sweep16(int mode, int nt, int dch, int k_steps, int grid_cus, co
 // Every operand value x is carried as two bf16 pieces, x = hi + lo + r with |lo| <= 2^-8 |x| and |r| <= 2^-17 |x|
 // (hi = bf16(x), lo = bf16(x - hi), both round-to-nearest; the subtraction is exact in float64), and a k-block of
 // 16 columns costs THREE MFMAs (hi.hi + hi.lo + lo.hi; lo.lo <= 2^-16 |x||y| is dropped like the residuals: the
-// sweep runs at the rate the matrix pipe issues, so a quarter fewer MFMAs is a quarter less time) accumulating in float32.  ||f||^2 rides in THREE
+// sweep runs at the rate the matrix pipe issues, so a quarter fewer MFMAs is a quarter less time) or FOUR (with
+// lo.lo: a third less key error, for data whose near ties make the exact re-rank the larger cost), accumulating in float32.  ||f||^2 rides in THREE
 // spare columns as three bf16 pieces against 1.0 (24 bits), which is why the variant needs Dpad - Dt >= 3.
-//     |key~ - key| <= 3 2^-16 (2 ||q|| ||f||)  [x y - (xh yh + xh yl + xl yh) = xl yl + x ry + rx y - ..., each <= 2^-16 |x||y|]
-//                     + accumulation of 3 Dpad / 16 MFMAs per tile, each assumed no better than 2^-22 of the sum of
-//                       its |products| and |C| (four times a sequentially rounded float32 sum; the unit's internal
-//                       order is not documented)
-//     eps_c = 1.1 (4.6e-5 + 2.4e-7 (3 Dpad / 16 + 1))  =  5.4e-5 at Dpad = 64 (snk_api.hip), against 8e-6 of the float32 operands:
-//     a handful more units per row inside the margin, nothing the float64 re-rank notices.
+//     |key~ - key| <= cq ||f|| + c_acc (2 ||q|| ||f|| + ||f||^2)
+//     cq: what the split drops, from the norms of the dropped pieces themselves (prepare_queries16b_kernel; worst case
+//         3 2^-16 (2 ||q||) with three terms, 2 2^-16 with four; measured on the data a third of that);
+//     c_acc = 1.02 (2^-22 (MFMAs per tile + 1) + 2^-24): every MFMA assumed no better than 2^-22 of the sum of its
+//         |products| and |C| (four times a sequentially rounded float32 sum; the unit's internal order is not
+//         documented), and the 24 bits of the three norm pieces.
 // tests/test_gpu_prefilter.py measures the real deviation against float64 keys: it must stay below half of that
 // (measured: 4-6 % of it -- rounding errors do not line up).
 // The k index inside a k-block follows the instruction's operand map: lane l (r = l & 31, h = l >> 5) holds columns
@@ -559,10 +560,57 @@ void launch_build_db16b(const double *Fw, const double *fnorm, int64_t N, int Dt
                        n_tiles, sample_stride, G, nt_a, reinterpret_cast<u32x4 *>(A16));
 }
 
-// query operand: -2q in two pieces, 1.0 against the three norm pieces; also eps_t (as prepare_queries16)
+// What the split drops, measured on the data instead of assumed at its worst: with f = fh + fl + rf per element,
+// rho[0] = max_i ||fl_i||^2 / ||f_i||^2 and rho[1] = max_i ||rf_i||^2 / ||f_i||^2 over the rows of the operand
+// (worst case 2^-16 and 2^-32; rounding errors of 61 columns do not line up, so a third of that is typical).
+__global__ void db16b_ratio_kernel(const double *__restrict__ Fw, int64_t N, int Dt, int Dpad,
+                                   unsigned long long *__restrict__ rho)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double rl = 0.0, rr = 0.0;
+    if (row < N) {
+        double sf = 0.0, sl = 0.0, sr = 0.0;
+        for (int c = 0; c < Dt; ++c) {
+            const double x = Fw[row * Dpad + c];
+            unsigned int hb, lb;
+            bf16_split(x, hb, lb);
+            const double l = (double)bf16_bits_to_float(lb);
+            const double r = x - (double)bf16_bits_to_float(hb) - l;          // exact: three float64 with < 53 bits between them
+            sf += x * x; sl += l * l; sr += r * r;
+        }
+        if (sf > 0.0) { rl = sl / sf; rr = sr / sf; }
+    }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = rl; red[1][threadIdx.x] = rr;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] = fmax(red[0][threadIdx.x], red[0][threadIdx.x + off]);
+            red[1][threadIdx.x] = fmax(red[1][threadIdx.x], red[1][threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {           // non-negative doubles order like their bit patterns
+        atomicMax(&rho[0], (unsigned long long)__double_as_longlong(red[0][0]));
+        atomicMax(&rho[1], (unsigned long long)__double_as_longlong(red[1][0]));
+    }
+}
+
+void launch_db16b_ratios(const double *Fw, int64_t N, int Dt, int Dpad, double *rho, hipStream_t s)
+{
+    (void)hipMemsetAsync(rho, 0, 2 * sizeof(double), s);
+    hipLaunchKernelGGL(db16b_ratio_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, Fw, N, Dt, Dpad,
+                       reinterpret_cast<unsigned long long *>(rho));
+}
+
+// query operand: a = -2q in two pieces (a = ah + al + ra), 1.0 against the three norm pieces.  Per row also the
+// coefficient of the representation error and the key bound the filter works with:
+//     a.f - (ah.fh + ah.fl + al.fh) = ah.rf + al.fl + al.rf + ra.f,   |.| <= ||f|| cq,
+//     cq = (||ah|| + ||al||) rho_R + ||al|| rho_L + ||ra||          (norms of THIS row's pieces, rho of the operand)
+//     eps = cq Fmax + c_acc (2 ||q|| Fmax + Fmax^2)                  (c_acc: accumulation + the norm pieces' 2^-24)
 __global__ void prepare_queries16b_kernel(const double *__restrict__ Qp, const double *__restrict__ qnorm, int64_t T,
-                                          int Dt, int Dpad, const double *__restrict__ fmax2, double eps_c,
-                                          u32x4 *__restrict__ B16, double *__restrict__ eps)
+                                          int Dt, int Dpad, const double *__restrict__ fmax2, const double *__restrict__ rho,
+                                          double c_acc, u32x4 *__restrict__ B16, double *__restrict__ eps, double *__restrict__ cq)
 {
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -589,23 +637,37 @@ __global__ void prepare_queries16b_kernel(const double *__restrict__ Qp, const d
     B16[(item * 2 + 0) * 64 + lane] = vh;
     B16[(item * 2 + 1) * 64 + lane] = vl;
     if (kb == 0 && h == 0) {
-        const double fm = sqrt(*fmax2);
-        const double qn = (row < T) ? sqrt(qnorm[row]) : 0.0;
-        eps[row] = eps_c * (2.0 * qn * fm + fm * fm) + 1e-30;
+        double sh = 0.0, sl = 0.0, sr = 0.0;
+        if (row < T)
+            for (int c = 0; c < Dt; ++c) {
+                const double a = -2.0 * Qp[row * Dpad + c];
+                unsigned int hb, lb;
+                bf16_split(a, hb, lb);
+                const double ah = (double)bf16_bits_to_float(hb), al = (double)bf16_bits_to_float(lb);
+                const double ra = a - ah - al;
+                sh += ah * ah; sl += al * al; sr += ra * ra;
+            }
+        const double up = 1.0 + 1e-12;                      // the square roots and sums above round
+        const double nah = sqrt(sh) * up, nal = sqrt(sl) * up, nra = sqrt(sr) * up;
+        const double c = ((nah + nal) * sqrt(rho[1]) + nal * sqrt(rho[0])) * up + nra;
+        const double fm = sqrt(*fmax2) * up;
+        const double qn = (row < T) ? sqrt(qnorm[row]) * up : 0.0;
+        eps[row] = c * fm + c_acc * (2.0 * qn * fm + fm * fm) + 1e-30;
+        cq[row] = c;
     }
 }
 
 void launch_prepare_queries16b(const double *Qp, const double *qnorm, int64_t T, int Dt, int Dpad, const double *fmax2,
-                               double eps_c, void *B16, double *eps, hipStream_t s)
+                               const double *rho, double c_acc, void *B16, double *eps, double *cq, hipStream_t s)
 {
     const int64_t items = ((T + 31) / 32) * (Dpad / 16);
     hipLaunchKernelGGL(prepare_queries16b_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, Qp, qnorm, T, Dt,
-                       Dpad, fmax2, eps_c, reinterpret_cast<u32x4 *>(B16), eps);
+                       Dpad, fmax2, rho, c_acc, reinterpret_cast<u32x4 *>(B16), eps, cq);
 }
 
 // The sweep: structure of knn_sweep16 (DB-stationary, persistent wavefronts, results of the previous step tested
 // in the shadow of the current step's MFMAs), 16 MFMAs per 32x32 tile and 64 columns instead of 31-32.
-template <int NT, int MODE, int KB>
+template <int NT, int MODE, int KB, int TERMS>
 __global__ void __launch_bounds__(256, 1)
 knn_sweep16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const float *__restrict__ thr32, int nQT,
              int64_t n_slabs, unsigned int *__restrict__ slab_counter, int qsplit, int64_t n_main_slabs, int qsplit_tail,
@@ -733,12 +795,12 @@ knn_sweep16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const
         // results in `prev` (database tiles from pt0 of query tile pq, threshold pth) are tested in the MFMA shadows
         auto step = [&](f16acc (&cur)[CH], const f16acc (&prev)[CH], int t0, u32x4 (&xh)[KB], u32x4 (&xl)[KB], int pt0, float pth,
                         int pq) {
-            constexpr int NM = 3 * KB;                     // MFMA slots per tile (hi.hi, hi.lo, lo.hi per k-block)
+            constexpr int NM = TERMS * KB;                 // MFMA slots per tile (hi.hi, hi.lo, lo.hi [, lo.lo] per k-block)
             constexpr int NGRP = 4 * CH;                   // groups of four pending results
             static_assert(NM >= NGRP, "at most one group per slot");
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
-                const int kb = m / 3, term = m % 3;        // term 0: hi.hi, 1: hi(db).lo(query), 2: lo(db).hi(query)
+                const int kb = m / TERMS, term = m % TERMS;   // term 0: hi.hi, 1: hi(db).lo(query), 2: lo(db).hi(query), 3: lo.lo
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     const u32x4 &a = (term & 2) ? al[t0 + j][kb] : ah[t0 + j][kb];
@@ -816,7 +878,7 @@ bool knn_sweep16b_supported(int nt, int dch, int Dt, int Dpad, bool cls)
     return !cls && Dpad - Dt >= 3 && ((nt == 4 && dch == 1) || (nt == 1 && dch == 3));
 }
 
-bool launch_knn_sweep16b(int mode, int nt, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32,
+bool launch_knn_sweep16b(int mode, int terms, int nt, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32,
                          int64_t T32, int64_t n_slabs, unsigned int *ctr, float *gmin32, int64_t G, void *pool,
                          unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s)
 {
@@ -829,13 +891,15 @@ bool launch_knn_sweep16b(int mode, int nt, int dch, int grid_cus, const void *A1
     int64_t n_main = n_slabs;
     int qtail = qsplit;
     sweep_tail_split(n_slabs, qsplit, blocks * 4, nQT, &n_main, &qtail);
-#define SNK_L16B(NT_, KB_, MODE_)                                                                            \
-    hipLaunchKernelGGL((knn_sweep16b<NT_, MODE_, KB_>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)A16, \
+#define SNK_L16T(NT_, KB_, MODE_, TERMS_)                                                                    \
+    hipLaunchKernelGGL((knn_sweep16b<NT_, MODE_, KB_, TERMS_>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)A16, \
                        (const u32x4 *)B16, thr32, nQT, n_slabs, ctr, qsplit, n_main, qtail, gmin32, G,       \
                        (PoolEntry16 *)pool, pool_ctl, chunk_fill, max_chunks, pool_chunk)
+#define SNK_L16B(NT_, KB_, MODE_) do { if (terms == 4) SNK_L16T(NT_, KB_, MODE_, 4); else SNK_L16T(NT_, KB_, MODE_, 3); } while (0)
     if (nt == 4 && dch == 1) { if (mode == 0) SNK_L16B(4, 4, 0); else SNK_L16B(4, 4, 1); return true; }
     if (nt == 1 && dch == 3) { if (mode == 0) SNK_L16B(1, 12, 0); else SNK_L16B(1, 12, 1); return true; }
 #undef SNK_L16B
+#undef SNK_L16T
     return false;
 }
 

@@ -735,7 +735,7 @@ void launch_fill_threshold(double *thr, int64_t T, int64_t Tpad, double value, h
 // ---------------------------------------------------------------------------
 // finalize: sort the row's candidate list, exact re-rank, output
 // ---------------------------------------------------------------------------
-#define SEL_MAX 1024     // candidates re-ranked exactly per row (K + near ties / key error margin)
+#define SEL_MAX 2048     // candidates re-ranked exactly per row (K + near ties / key error margin)
 
 __global__ void __launch_bounds__(256)
 knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_unw, int Fp,
@@ -744,6 +744,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
                     const int *__restrict__ cnt, const double *__restrict__ lkey,
                     const int *__restrict__ lidx, int cap, int64_t id_offset,
                     const double *__restrict__ eps, const double *__restrict__ fnorm, double eps_c,
+                    const double *__restrict__ cq,
                     int64_t *__restrict__ cand, double *__restrict__ dist,
                     double *__restrict__ d2_out, int *__restrict__ status, int *__restrict__ rowflag)
 {
@@ -799,7 +800,8 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
     double margin = 0.0;
     if (eps) {
         const double fm = sqrt(red_fm[0]), qn = sqrt(qnorm[row]);
-        margin = 2.0 * (eps_c * (2.0 * qn * fm + fm * fm) + 1e-30);
+        // (bf16-split keys: cq[row] ||f|| for what the split drops, eps_c for the accumulation -- knn16_kernels.hip)
+        margin = 2.0 * ((cq ? cq[row] * fm : 0.0) + eps_c * (2.0 * qn * fm + fm * fm) + 1e-30);
         if (margin > 2.0 * eps[row]) margin = 2.0 * eps[row];
     }
     const double scale = (kmax > kmin) ? 256.0 / (kmax - kmin) : 0.0;
@@ -912,7 +914,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
 
 void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const double *wt, int Dpad, int D, const double *Qp, const double *qnorm,
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
-                         int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c,
+                         int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c, const double *cq,
                          int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s)
 {
     int P = 2;
@@ -925,7 +927,7 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
         attr = shmem;
     }
     hipLaunchKernelGGL(knn_finalize_kernel, dim3((unsigned)T), dim3(256), shmem, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
-                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cand, dist, d2_out, status, rowflag);
+                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag);
 }
 
 // ---------------------------------------------------------------------------

@@ -148,10 +148,11 @@ struct snk_engine {
     int nt16 = 4, nt16_eff = 4;
     int64_t n_slabs16 = 0, n_slabs16_a = 0, stride16 = 16;
     double eps_c = 8e-6;          // 2x the analytical f32 bound (knn16_kernels.hip)
+    int join_bounds_stream = 1;   // batches: pass 1 of the sparse Viterbi path on 1: the group's side stream, 0: the main (K-NN) stream
     int prefilter = 1;            // 1: bf16-split operands on the bf16 matrix pipe where the shape has a variant, 0: float32 operands
     bool bf16_ready = false;      // a16l / s16l (and gs_tiles_b) hold the bf16-split operands of the current weights
-    double eps_c_bf = 4e-5;       // bound of the bf16-split keys (knn16_kernels.hip)
-    DevBuf gs_tiles_b;
+    double eps_c_bf = 4e-6;       // accumulation part of the bound of the bf16-split keys (knn16_kernels.hip: c_acc)
+    DevBuf gs_tiles_b, cq16, rho16, gs_rho16;   // per-row split coefficient; dropped-piece ratios of the operands
     int f16_fallbacks = 0;
     int last_f16_status = 0;
     HostBuf hstage;
@@ -338,7 +339,7 @@ int snk_destroy(snk_handle h)
     h->rowflag.release(); h->exact_rows.release(); h->exact_scratch.release();
     h->frames_spec.release(); h->frames_fzv.release(); h->cc_in.release(); h->cc_out.release();
     h->res_status.release(); h->hstage.release();
-    { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b};
+    { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b, &h->cq16, &h->rho16, &h->gs_rho16};
       for (auto *b : fb) b->release(); }
     for (int i = 0; i < 8; ++i) {
         UttSlot &s = h->slot[i];
@@ -531,10 +532,13 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
             HIPCHK(hipGetLastError());
             h->f16_ready = true;
             h->bf16_ready = false;
-            if (h->prefilter == 1 && knn_sweep16b_supported(nt, dch16, h->Dt, h->Dpad, false)) {
-                // representation 3 2^-16 of 2 |q| |f| (lo.lo and the two residuals, 2^-16 each), accumulation
-                // 2^-22 per MFMA over 3 MFMAs per 16 columns; 1.1 x the sum (knn16_kernels.hip)
-                h->eps_c_bf = 1.1 * (4.6e-5 + 2.4e-7 * (double)(3 * h->Dpad / 16 + 1));
+            if (h->prefilter >= 1 && knn_sweep16b_supported(nt, dch16, h->Dt, h->Dpad, false)) {
+                // key bound = cq ||f|| (what the split drops: measured, prepare_queries16b_kernel) + c_acc (...):
+                // 2^-22 per MFMA over `terms` MFMAs per 16 columns and the norm pieces' 2^-24 (knn16_kernels.hip)
+                const int terms = h->prefilter == 2 ? 4 : 3;
+                h->eps_c_bf = 1.02 * (2.4e-7 * (double)(terms * h->Dpad / 16 + 1) + 6e-8);
+                CHK(h->rho16.ensure(2 * sizeof(double)));
+                launch_db16b_ratios(h->Fw.as<double>(), h->N, h->Dt, h->Dpad, h->rho16.as<double>(), h->stream);
                 CHK(h->a16l.ensure(tiles_b * per_tile));
                 CHK(h->s16l.ensure(tiles_a * per_tile));
                 launch_build_db16b(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_b, 0, 0, nt,
@@ -564,6 +568,8 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
             launch_build_db16(h->gs_w.as<double>(), h->gs_norm.as<double>(), h->gs_rows, h->Dt, h->Dpad, tiles, 1,
                               2 * h->gs_slabs, nt, h->gs_tiles.p, h->stream);
             if (h->bf16_ready) {
+                CHK(h->gs_rho16.ensure(2 * sizeof(double)));
+                launch_db16b_ratios(h->gs_w.as<double>(), h->gs_rows, h->Dt, h->Dpad, h->gs_rho16.as<double>(), h->stream);
                 CHK(h->gs_tiles_b.ensure((size_t)tiles * 8 * 64 * 16 * (h->Dpad / 64)));
                 launch_build_db16b(h->gs_w.as<double>(), h->gs_norm.as<double>(), h->gs_rows, h->Dt, h->Dpad, tiles, 1,
                                    2 * h->gs_slabs, nt, h->gs_tiles_b.p, h->stream);
@@ -683,7 +689,8 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
     if (cap < 2 * K) cap = 2 * K;
     // the sampled thresholds let ~17 K candidates per row through (mean; 3200 at K = 200): large K needs
     // longer lists and a bigger pool share than the defaults sized for K <= 128
-    if (cap < 32 * K) cap = 32 * K < 8192 ? 32 * K : 8192;
+    // (40 K: the bf16-split prefilter's wider key margin lengthens the lists by a fifth)
+    if (cap < 40 * K) cap = 40 * K < 8192 ? 40 * K : 8192;
     if (K > 4096) return fail("K-NN: K too large");
     KnnPlan p = p0;
     int64_t G = p.a_count * 16;
@@ -744,10 +751,11 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             cls_full = h->cls16_full.as<int32_t>();
             cls_samp = h->cls16_samp.as<int32_t>();
         }
-        const bool bf = h->bf16_ready && h->prefilter == 1 && !cls && nt_run == h->nt16_eff;
+        const bool bf = h->bf16_ready && h->prefilter >= 1 && !cls && nt_run == h->nt16_eff;
         const double eps_c_run = bf ? h->eps_c_bf : h->eps_c;
         CHK((bf ? h->b16l : h->b16h).ensure((size_t)(Tpad / 32) * 8 * 64 * 16 * (h->Dpad / 64)));
         CHK(h->eps16.ensure((size_t)Tpad * sizeof(double)));
+        if (bf) CHK(h->cq16.ensure((size_t)Tpad * sizeof(double)));
         CHK(h->thr32.ensure((size_t)Tpad * sizeof(float)));
         CHK(h->gmin32.ensure((size_t)Tpad * G16 * sizeof(float)));
         launch_knn_reset(h->cnt.as<int>(), Tpad, status_dev, h->poolctl.as<unsigned int>(),
@@ -756,8 +764,9 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             StageTimer t(h, s, TM_PREP);
             if (bf)
                 launch_prepare_queries16b(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad,
-                                          use_gs ? h->gs_fmax2.as<double>() : h->fmax2.as<double>(), eps_c_run, h->b16l.p,
-                                          h->eps16.as<double>(), s);
+                                          use_gs ? h->gs_fmax2.as<double>() : h->fmax2.as<double>(),
+                                          use_gs ? h->gs_rho16.as<double>() : h->rho16.as<double>(), eps_c_run, h->b16l.p,
+                                          h->eps16.as<double>(), h->cq16.as<double>(), s);
             else
             launch_prepare_queries16(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad,
                                      use_gs ? h->gs_fmax2.as<double>() : h->fmax2.as<double>(), h->eps_c, h->b16h.p,
@@ -766,7 +775,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         if (!bound_in) {
             StageTimer t(h, s, TM_KNN_MINIMA);
             if (bf)
-                launch_knn_sweep16b(0, nt_run, dch16, p0.grid_cus, use_gs ? h->gs_tiles_b.p : h->s16l.p, h->b16l.p, nullptr, Tpad,
+                launch_knn_sweep16b(0, h->prefilter == 2 ? 4 : 3, nt_run, dch16, p0.grid_cus, use_gs ? h->gs_tiles_b.p : h->s16l.p, h->b16l.p, nullptr, Tpad,
                                     n_slabs_a, h->slabctr.as<unsigned int>(), h->gmin32.as<float>(), G16, nullptr, nullptr,
                                     nullptr, 0, knn_pool_chunk_entries(), s);
             else
@@ -783,7 +792,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         {
             StageTimer t(h, s, TM_KNN_FILTER);
             if (bf)
-                launch_knn_sweep16b(1, nt_run, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, h->thr32.as<float>(), Tpad, n_slabs_b,
+                launch_knn_sweep16b(1, h->prefilter == 2 ? 4 : 3, nt_run, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, h->thr32.as<float>(), Tpad, n_slabs_b,
                                     h->slabctr.as<unsigned int>() + 1, nullptr, 0, h->pool.p, h->poolctl.as<unsigned int>(),
                                     h->chunkfill.as<int>(), max_chunks, knn_pool_chunk_entries(), s);
             else
@@ -801,7 +810,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             StageTimer t(h, s, TM_KNN_FINALIZE);
             launch_knn_finalize(h->Fw.as<double>(), h->F_unw.as<float>(), h->Fp, h->wt.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
-                                h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), eps_c_run, cand_dev, dist_dev, d2_dev, status_dev, nullptr, s);
+                                h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), eps_c_run, bf ? h->cq16.as<double>() : nullptr, cand_dev, dist_dev, d2_dev, status_dev, nullptr, s);
         }
         if (deferred_status) return 0;       // the batch caller redoes failures with precision 0
         int status = 0;
@@ -866,7 +875,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             StageTimer t(h, s, TM_KNN_FINALIZE);
             launch_knn_finalize(h->Fw.as<double>(), h->F_unw.as<float>(), h->Fp, h->wt.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
-                                h->shard_offset, nullptr, nullptr, 0.0, cand_dev, dist_dev, d2_dev, status_dev, h->rowflag.as<int>(), s);
+                                h->shard_offset, nullptr, nullptr, 0.0, nullptr, cand_dev, dist_dev, d2_dev, status_dev, h->rowflag.as<int>(), s);
         }
         if (deferred_status) return 0;
         int status = 0;
@@ -986,7 +995,7 @@ int snk_prefilter_minima(snk_handle h, const double *Q, int64_t T, int D, float 
     if (slab_min_len < T * n_slabs || !eps_out) return fail("snk_prefilter_minima: output too small");
     CHK(upload_queries(h, Q, T, D));
     const int64_t Tpad = roundup(T, 32), G16 = 2 * n_slabs;
-    const bool bf = h->bf16_ready && h->prefilter == 1;
+    const bool bf = h->bf16_ready && h->prefilter >= 1;
     const int dch16 = h->Dpad / 64;
     hipStream_t s = h->stream;
     CHK(h->Qp.ensure((size_t)Tpad * h->Dpad * sizeof(double)));
@@ -1001,9 +1010,10 @@ int snk_prefilter_minima(snk_handle h, const double *Q, int64_t T, int D, float 
                            Tpad, h->Dpad, s);
     const KnnPlan p0 = make_plan(h, 1);
     if (bf) {
+        CHK(h->cq16.ensure((size_t)Tpad * sizeof(double)));
         launch_prepare_queries16b(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad, h->fmax2.as<double>(),
-                                  h->eps_c_bf, h->b16l.p, h->eps16.as<double>(), s);
-        launch_knn_sweep16b(0, h->nt16_eff, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, nullptr, Tpad, n_slabs,
+                                  h->rho16.as<double>(), h->eps_c_bf, h->b16l.p, h->eps16.as<double>(), h->cq16.as<double>(), s);
+        launch_knn_sweep16b(0, h->prefilter == 2 ? 4 : 3, h->nt16_eff, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, nullptr, Tpad, n_slabs,
                             h->slabctr.as<unsigned int>(), h->gmin32.as<float>(), G16, nullptr, nullptr, nullptr, 0,
                             knn_pool_chunk_entries(), s);
     } else {
@@ -1116,11 +1126,16 @@ static int viterbi_sparse_rows(snk_engine *h, UttSlot &s, const int64_t *cand, c
 {
     const float *JC = h->JC_unw.as<float>();
     const double *wj = h->wj.as<double>();
-    {
-        StageTimer t(h, main, TM_JOIN_LB);
-        launch_join_lb(JC, h->Jp, h->Dj, wj, join_units(h), cand, rows, K, s.Jlo.as<float>(), s.scale.as<float>(), main);
+    const bool lb_side = h->join_bounds_stream == 1 && side != main;
+    if (lb_side) {
+        HIPCHK(hipEventRecord(s.knn_done, main));
+        HIPCHK(hipStreamWaitEvent(side, s.knn_done, 0));
     }
-    if (side != main) {
+    {
+        StageTimer t(h, lb_side ? side : main, TM_JOIN_LB);
+        launch_join_lb(JC, h->Jp, h->Dj, wj, join_units(h), cand, rows, K, s.Jlo.as<float>(), s.scale.as<float>(), lb_side ? side : main);
+    }
+    if (side != main && !lb_side) {
         HIPCHK(hipEventRecord(s.knn_done, main));
         HIPCHK(hipStreamWaitEvent(side, s.knn_done, 0));
     }
@@ -1275,8 +1290,10 @@ static int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u
     hipStream_t dps = side_stream ? h->dp_stream[g & 1] : h->stream;
     // workspace reuse: the join costs of this group overwrite what the last recursion queued on this
     // workspace reads (an earlier group of this batch, or the tail of the batch submitted before)
-    if (s.vit_recorded) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));
-    if (use_sparse_viterbi(h, K, n_batch_utts)) {
+    const bool sparse = use_sparse_viterbi(h, K, n_batch_utts);
+    // (the sparse path with its bounds on the side stream touches the workspace on that stream only: in order)
+    if (s.vit_recorded && !(sparse && side_stream && h->join_bounds_stream == 1)) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));
+    if (sparse) {
         CHK(sparse_ensure(h, s, rows, K));
         std::vector<int64_t> off((size_t)(u1 - u0) + 1);
         for (int u = u0; u <= u1; ++u) off[(size_t)(u - u0)] = row_offsets[u] - r0;
@@ -2302,7 +2319,7 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0) return fail("precision must be 0 (f64 sweep) or 1 (f32 prefilter + exact f64 re-rank)");
         h->precision = (int)value;
     } else if (!strcmp(name, "prefilter")) {
-        if (value != 0.0 && value != 1.0) return fail("prefilter must be 0 (float32 operands) or 1 (bf16-split operands where the shape has a variant)");
+        if (value != 0.0 && value != 1.0 && value != 2.0) return fail("prefilter must be 0 (float32 operands), 1 or 2 (bf16-split operands where the shape has a variant: 3 / 4 MFMA terms per product)");
         CHK(no_batch_in_flight(h, "snk_set_option(prefilter)"));
         h->prefilter = (int)value;
         h->have_weights = false;          // the bf16 operands are built by set_weights
@@ -2319,6 +2336,10 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0 && value != 2.0) return fail("viterbi_mode must be 0 (dense exact join + recursion), 1 (lower bounds + sparse exact recursion) or 2 (auto)");
         CHK(no_batch_in_flight(h, "snk_set_option(viterbi_mode)"));
         h->viterbi_mode = (int)value;
+    } else if (!strcmp(name, "join_bounds_stream")) {
+        if (value != 0.0 && value != 1.0) return fail("join_bounds_stream must be 0 (main stream) or 1 (side stream of the group)");
+        CHK(no_batch_in_flight(h, "snk_set_option(join_bounds_stream)"));
+        h->join_bounds_stream = (int)value;
     } else if (!strcmp(name, "join_beta")) {
         if (!(value >= 0.0 && value <= 10.0)) return fail("join_beta must be in 0..10");
         h->join_beta = value;
@@ -2367,7 +2388,17 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "precision")) *out = h->precision;
     else if (!strcmp(name, "prefilter")) *out = h->prefilter;
     else if (!strcmp(name, "prefilter_bf16_active")) *out = h->bf16_ready ? 1 : 0;
-    else if (!strcmp(name, "prefilter_eps_c")) *out = (h->bf16_ready && h->prefilter == 1) ? h->eps_c_bf : h->eps_c;
+    else if (!strcmp(name, "prefilter_rho_lo") || !strcmp(name, "prefilter_rho_res")) {
+        // sqrt of the largest ||fl||^2 / ||f||^2 (||rf||^2 / ||f||^2) over the database rows: 2^-8 (2^-16) at worst
+        double rho[2] = {0.0, 0.0};
+        if (h->bf16_ready && h->rho16.p) {
+            HIPCHK(hipSetDevice(h->device));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipMemcpy(rho, h->rho16.p, sizeof(rho), hipMemcpyDeviceToHost));
+        }
+        *out = sqrt(rho[name[14] == 'l' ? 0 : 1]);
+    }
+    else if (!strcmp(name, "prefilter_eps_c")) *out = (h->bf16_ready && h->prefilter >= 1) ? h->eps_c_bf : h->eps_c;
     else if (!strcmp(name, "batch_rows")) *out = h->batch_rows;
     else if (!strcmp(name, "last_list_mean") || !strcmp(name, "last_list_max")) {
         // candidate-list lengths of the most recent K-NN call (debug / tuning aid)

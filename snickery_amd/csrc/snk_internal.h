@@ -58,7 +58,7 @@ void launch_knn_exact_rows(const double *Fw, int Dpad, int D, int64_t N, const d
                            double *d2_out, hipStream_t s);
 void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const double *wt, int Dpad, int D, const double *Qp, const double *qnorm,
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
-                         int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c,
+                         int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c, const double *cq,
                          int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s);
 void launch_candidate_dist(const double *Fw, int Dpad, int D, int64_t N, const double *Qp,
                            const int64_t *cand, int64_t T, int K, double *dist, hipStream_t s);
@@ -85,8 +85,9 @@ bool knn_sweep16b_supported(int nt, int dch, int Dt, int Dpad, bool cls);
 void launch_build_db16b(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,
                         int64_t sample_stride, int64_t G, int nt_a, void *A16, hipStream_t s);
 void launch_prepare_queries16b(const double *Qp, const double *qnorm, int64_t T, int Dt, int Dpad, const double *fmax2,
-                               double eps_c, void *B16, double *eps, hipStream_t s);
-bool launch_knn_sweep16b(int mode, int nt, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32,
+                               const double *rho, double c_acc, void *B16, double *eps, double *cq, hipStream_t s);
+void launch_db16b_ratios(const double *Fw, int64_t N, int Dt, int Dpad, double *rho, hipStream_t s);
+bool launch_knn_sweep16b(int mode, int terms, int nt, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32,
                          int64_t T32, int64_t n_slabs, unsigned int *ctr, float *gmin32, int64_t G, void *pool,
                          unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s);
 void launch_mfma16_selftest(const float *A, const float *B, float *C, hipStream_t s);

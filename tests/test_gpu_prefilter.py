@@ -90,8 +90,9 @@ def test_prefilter_keys_stay_inside_their_bound(engine, prefilter, Dt, offset, s
     assert got.shape == want.shape
     ratio = np.abs(got.astype(np.float64) - want) / eps[:, None]
     # the float32 result itself is rounded once more (2^-24 relative): far inside the bound
-    print('prefilter %d Dt %d offset %g: max |key~ - key| / eps = %.4f (eps_c %.3g)' % (prefilter, Dt, offset, ratio.max(),
-                                                                                     engine.info('prefilter_eps_c')))
+    print('prefilter %d Dt %d offset %g: max |key~ - key| / eps = %.4f (c_acc %.3g, rho_lo 2^%.2f, rho_res 2^%.2f)' % (
+        prefilter, Dt, offset, ratio.max(), engine.info('prefilter_eps_c'),
+        np.log2(max(engine.info('prefilter_rho_lo'), 1e-300)), np.log2(max(engine.info('prefilter_rho_res'), 1e-300))))
     assert ratio.max() <= 0.5, ratio.max()
     # and the exact search is still exact on this data
     cand, dist = engine.knn(U, 40)

@@ -1,0 +1,34 @@
+"""Viterbi side of a B* batch step alone (no K-NN beside it): the 32 utterances' lists are computed once, then
+merge (one list) + join bounds + recursions are timed through snk_merge_viterbi_batch_dev."""
+import sys, os, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import snickery_amd
+from bench import synthetic_db, synthetic_targets
+
+N, Dt, Dj, T, K, U = 1048576, 61, 302, 600, 100, 32
+if len(sys.argv) > 1: K = int(sys.argv[1])
+F_unw, JC_unw = synthetic_db(N, Dt, Dj, seed=0)
+wt = np.full(Dt, 0.4); wj = np.full(Dj, 0.05)
+eng = snickery_amd.HipSearchEngine(0)
+eng.upload_db(F_unw, JC_unw); eng.set_weights(wt, wj)
+utts = [synthetic_targets(F_unw, T, seed=1 + s) * wt for s in range(U)]
+dev = torch.device('cuda', 0)
+d2 = torch.empty(U * T, K, dtype=torch.float64, device=dev)
+ids = torch.empty(U * T, K, dtype=torch.int64, device=dev)
+eng.knn_local_batch_dev(utts, K, d2.data_ptr(), ids.data_ptr())
+torch.cuda.synchronize()
+ref = eng.knn_viterbi_batch(utts, K)
+for mode in (1, 0):
+    eng.set_option('viterbi_mode', mode)
+    paths, costs = eng.merge_viterbi_batch_dev(d2.data_ptr(), ids.data_ptr(), 1, [T] * U, K)
+    eng.reset_timers()
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(3):
+        paths, costs = eng.merge_viterbi_batch_dev(d2.data_ptr(), ids.data_ptr(), 1, [T] * U, K)
+    torch.cuda.synchronize(); dt = (time.time() - t0) / 3
+    same = all(np.array_equal(a, b) for a, b in zip(paths, ref[0])) and np.array_equal(costs, ref[1])
+    print('viterbi_mode %d: %.2f ms per 32-utterance batch  same=%s' % (mode, dt * 1e3, same))
+    print('   ', {k: (round(v[0] / 3, 3), v[1] // 3) for k, v in eng.timers().items() if v[1]})
