@@ -175,8 +175,8 @@ def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')),
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--units', type=int, default=1048576)
     ap.add_argument('--frames', type=int, default=600)
     ap.add_argument('--candidates', type=int, default=100)
