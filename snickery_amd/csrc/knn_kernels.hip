@@ -736,7 +736,11 @@ void launch_fill_threshold(double *thr, int64_t T, int64_t Tpad, double value, h
 // finalize: sort the row's candidate list, exact re-rank, output
 // ---------------------------------------------------------------------------
 #define SEL_MAX 2048     // candidates re-ranked exactly per row (K + near ties / key error margin)
+#define FIN_SMALL 512    // lists up to this length go through the small-LDS instance (13 workgroups per compute unit
+                         // instead of 2: the short lists of a row-sharded database are latency-, not LDS-bound)
 
+// CLASS 0: every row; 1: rows with at most FIN_SMALL entries (the others are left to CLASS 2); 2: the longer ones
+template <int CLASS>
 __global__ void __launch_bounds__(256)
 knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_unw, int Fp,
                     const double *__restrict__ wt, int Dpad, int D, const double *__restrict__ Qp,
@@ -749,8 +753,11 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
                     double *__restrict__ d2_out, int *__restrict__ status, int *__restrict__ rowflag)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int SELM = (CLASS == 1) ? FIN_SMALL : SEL_MAX;
     const int64_t row = blockIdx.x;
     const int n_all = cnt[row];
+    if (CLASS == 1 && n_all > FIN_SMALL) return;
+    if (CLASS == 2 && n_all <= FIN_SMALL) return;
     if (rowflag && threadIdx.x == 0) rowflag[row] = 0;
     if (n_all > cap) {                    // list overflowed: host re-tightens and retries
         if (threadIdx.x == 0) { atomicOr(status, 1); if (rowflag) rowflag[row] = 1; }
@@ -761,8 +768,8 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
     while (P < n) P <<= 1;
     double *key = reinterpret_cast<double *>(smem);
     int *idx = reinterpret_cast<int *>(smem + (size_t)P * sizeof(double));
-    __shared__ double ex_key[SEL_MAX];
-    __shared__ int ex_idx[SEL_MAX];
+    __shared__ double ex_key[SELM];
+    __shared__ int ex_idx[SELM];
     __shared__ int n_sel_s, hist[256], cut_bin_s;
     __shared__ double red_min[256], red_max[256];
     const int kk = K < n ? K : n;         // entries that can be returned
@@ -770,7 +777,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
     // ---- fast path: value-binned selection.  256 linear bins between the smallest and the
     // largest key of the list; every entry in the bins up to (and one past) the bin holding the
     // K-th smallest key is re-ranked exactly.  Falls back to the full sort when that set does
-    // not fit SEL_MAX (massive ties).
+    // not fit SELM (massive ties).
     double kmin = DBL_MAX, kmax = -DBL_MAX, fmax2 = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const double v = lkey[row * cap + i];
@@ -825,7 +832,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
             if (cut > 255) cut = 255;
             int tot = 0;
             for (int i = 0; i <= cut; ++i) tot += hist[i];
-            cut_bin_s = (tot <= SEL_MAX) ? cut : -1;
+            cut_bin_s = (tot <= SELM) ? cut : -1;
         }
         __syncthreads();
         fast = cut_bin_s >= 0;
@@ -852,8 +859,8 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
                 // safety margin of the K-th key so that the exact order decides
                 const double kth = key[kk - 1];
                 const double delta = 1e-10 * (fabs(kth) + qnorm[row] + 1.0) + margin;
-                while (ns < n && ns < SEL_MAX && key[ns] <= kth + delta) ++ns;
-                if (ns == SEL_MAX && ns < n && key[ns] <= kth + delta) { atomicOr(status, 2); if (rowflag) rowflag[row] = 2; }
+                while (ns < n && ns < SELM && key[ns] <= kth + delta) ++ns;
+                if (ns == SELM && ns < n && key[ns] <= kth + delta) { atomicOr(status, 2); if (rowflag) rowflag[row] = 2; }
             }
             n_sel_s = ns;
         }
@@ -915,18 +922,28 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
 void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const double *wt, int Dpad, int D, const double *Qp, const double *qnorm,
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
                          int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c, const double *cq,
-                         int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s)
+                         int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s, bool split_short)
 {
     int P = 2;
     while (P < cap) P <<= 1;
     const size_t shmem = (size_t)P * (sizeof(double) + sizeof(int));
     static size_t attr = 0;
     if (shmem > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_finalize_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_finalize_kernel<0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_finalize_kernel<2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         attr = shmem;
     }
-    hipLaunchKernelGGL(knn_finalize_kernel, dim3((unsigned)T), dim3(256), shmem, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
+    if (split_short && K <= FIN_SMALL / 2 && cap > FIN_SMALL) {
+        const size_t small = (size_t)FIN_SMALL * (sizeof(double) + sizeof(int));
+        hipLaunchKernelGGL(knn_finalize_kernel<1>, dim3((unsigned)T), dim3(256), small, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
+                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag);
+        hipLaunchKernelGGL(knn_finalize_kernel<2>, dim3((unsigned)T), dim3(256), shmem, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
+                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag);
+        return;
+    }
+    hipLaunchKernelGGL(knn_finalize_kernel<0>, dim3((unsigned)T), dim3(256), shmem, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
                        qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag);
 }
 

@@ -810,7 +810,8 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             StageTimer t(h, s, TM_KNN_FINALIZE);
             launch_knn_finalize(h->Fw.as<double>(), h->F_unw.as<float>(), h->Fp, h->wt.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
-                                h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), eps_c_run, bf ? h->cq16.as<double>() : nullptr, cand_dev, dist_dev, d2_dev, status_dev, nullptr, s);
+                                h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), eps_c_run, bf ? h->cq16.as<double>() : nullptr, cand_dev, dist_dev, d2_dev, status_dev, nullptr, s,
+                                bound_in != nullptr);        // a shard's lists under the shared bound are short
         }
         if (deferred_status) return 0;       // the batch caller redoes failures with precision 0
         int status = 0;

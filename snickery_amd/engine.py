@@ -102,6 +102,14 @@ _SIGNATURES = {
 }
 
 
+def device_count():
+    """GPUs visible to the process (snk_device_count)."""
+    n = ctypes.c_int(0)
+    if load_library().snk_device_count(ctypes.byref(n)) != 0:
+        raise SnkError(load_library().snk_last_error().decode())
+    return int(n.value)
+
+
 def load_library():
     """Load libsnkhip.so and bind every symbol of include/snk.h.  Raises SnkError when the
     library has not been built (``python -c 'import __graft_entry__ as g; g.build()'`` or

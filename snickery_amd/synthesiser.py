@@ -384,9 +384,51 @@ class Synthesiser(object):
             flist = flist[:limit]
         return flist
 
-    def synth_from_config(self, synth_type='test', outdir=''):
-        """synth_simple.py:279-284: returns {utterance: path}."""
-        return dict((f, self.synth_utt(f, synth_type=synth_type, outdir=outdir)) for f in self.get_sentence_set(synth_type))
+    def synth_from_config(self, inspect_join_weights_only=False, synth_type='test', outdir='', ncores=1, devices=None):
+        """synth_simple.py:279-284 / synth_halfphone.py:891-908: returns {utterance: path}.
+
+        ncores > 1 is the reference's ``multiprocessing.Pool(processes=ncores)`` over the sentences
+        (synth_halfphone.py:897-903), here as utterance-level REPLICAS: `ncores` worker processes, each with
+        its own engine and its own copy of the voice on ``devices[r % len(devices)]`` (default: every visible
+        GPU in turn), worker r taking sentences r, r + ncores, ...  No exchange between them -- a voice is a
+        few GB of the 288 GB of one GPU; the row-sharded database (snickery_amd/dist.py) is the other way to
+        use several GPUs, for one utterance stream."""
+        flist = self.get_sentence_set(synth_type)
+        if ncores <= 1 or len(flist) <= 1:
+            return dict((f, self.synth_utt(f, synth_type=synth_type, outdir=outdir)) for f in flist)
+        import multiprocessing
+        from . import engine as _engine
+        if devices is None:
+            devices = list(range(max(_engine.device_count(), 1)))
+        ncores = min(int(ncores), len(flist))
+        state = self._runtime_state()
+        jobs = [(self.config_file, self.flavour, devices[r % len(devices)], state, flist[r::ncores], synth_type, outdir)
+                for r in range(ncores)]
+        # 'spawn': a forked child inherits an initialised HIP runtime it cannot use
+        pool = multiprocessing.get_context('spawn').Pool(processes=ncores)
+        try:
+            shares = pool.map(_replica_worker, jobs)
+        finally:
+            pool.close()
+            pool.join()
+        done = dict(pair for share in shares for pair in share)
+        return dict((f, done[f]) for f in flist)
+
+    def _runtime_state(self):
+        """What set_*_weights / truncate_* / reconfigure_settings changed since the config file was read."""
+        return {'config': dict(self.config), 'target_weight_vector': self.target_weight_vector.copy(),
+                'join_weight_vector': self.join_weight_vector.copy(), 'target_trunc': self._target_trunc,
+                'join_trunc': self._join_trunc, 'mode_of_operation': self.mode_of_operation}
+
+    def _restore_runtime_state(self, state):
+        self.config = dict(state['config'])
+        self.target_weight_vector = state['target_weight_vector']
+        self.join_weight_vector = state['join_weight_vector']
+        self._target_trunc, self._join_trunc = state['target_trunc'], state['join_trunc']
+        if self._target_trunc is not None:
+            self.target_truncation_vector = self._target_trunc
+        self.mode_of_operation = state['mode_of_operation']
+        self._apply_weights()
 
     def prepare_targets(self, base, synth_type='test', return_names=False):
         """Target preparation of synth_utt (synth_simple.py:370-396, synth_halfphone.py:1478-1552):
@@ -600,3 +642,14 @@ class Synthesiser(object):
         if getattr(self, '_join_engine', None) is not None:
             self._join_engine.close()
             self._join_engine = None
+
+
+def _replica_worker(job):
+    """One replica of synth_from_config(ncores > 1): its own Synthesiser on its own device, its share of the sentences."""
+    config_file, flavour, device, state, fnames, synth_type, outdir = job
+    synth = Synthesiser(config_file, flavour=flavour, device=device, verbose=False)
+    try:
+        synth._restore_runtime_state(state)
+        return [(f, synth.synth_utt(f, synth_type=synth_type, outdir=outdir)) for f in fnames]
+    finally:
+        synth.close()

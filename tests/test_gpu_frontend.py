@@ -408,3 +408,33 @@ def test_bulk_greedy_equals_one_by_one(tmp_path, golden):
     for t, j in synth.synth_utts_bulk(names, synth_type='test'):
         assert np.array_equal(t, one[0]) and np.array_equal(j, one[1])
     synth.close()
+
+
+def test_synth_from_config_replicas_equal_the_serial_loop(tmp_path, golden):
+    """synth_from_config(ncores=2): the reference's multiprocessing.Pool over the sentences
+    (synth_halfphone.py:897-903) as two replica processes with their own engines -- here both on GPU 0 --
+    after the weights were changed at run time (the replicas must see them)."""
+    from snickery_amd.synthesiser import Synthesiser
+    extra = '''
+tune_data_dirs = test_data_dirs
+tune_patterns = ['arctic_b']
+n_tune_utts = 5
+'''
+    cfgfile, config = build_voice(tmp_path, golden, greedy=False, multiepoch=1, n_candidates=12, extra_config=extra)
+    for i, (lo, hi) in enumerate(((10, 97), (30, 140), (0, 60))):
+        for stream in ('mag', 'lf0'):
+            golden['test0_raw_' + stream][lo:hi].astype(np.float32).tofile(
+                os.path.join(config['data'], 'low', stream, 'arctic_b%04d.%s' % (i + 2, stream)))
+    synth = Synthesiser(cfgfile, verbose=False)
+    synth.set_target_weights([0.0, 3.0])          # only lf0 counts: other paths than with the configured weights
+    names = synth.get_sentence_set('tune')
+    assert len(names) == 4
+    serial = synth.synth_from_config(synth_type='tune')
+    replicas = synth.synth_from_config(synth_type='tune', ncores=2, devices=[0, 0])
+    assert list(replicas) == names
+    for n in names:
+        assert np.array_equal(np.asarray(serial[n]), np.asarray(replicas[n]))
+    default_weights = Synthesiser(cfgfile, verbose=False)
+    assert any(not np.array_equal(np.asarray(default_weights.synth_utt(n, synth_type='tune')), np.asarray(serial[n])) for n in names)
+    default_weights.close()
+    synth.close()
