@@ -161,7 +161,20 @@ def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')),
         ms, launches = eng.timers()['greedy_steps']
         us_step = ms / max(launches, 1) / steps * 1e3
         bytes_step = float(N) * (Dj + Dt) * 4.0
-        out[name] = {'units': N, 'multiepoch': me, 'frames': T, 'steps': steps, 'us_per_step': us_step,
+        # a batch through snk_greedy_batch: the float32 prefilter scan, three utterances per scan of the database
+        # (one persistent launch), exact float64 decisions -- the same paths
+        nb = 6
+        ub = [synthetic_targets(F_unw, T, seed=1 + u) * wt for u in range(nb)]
+        eng.greedy_batch(ub)
+        t0 = time.perf_counter()
+        pb = eng.greedy_batch(ub)
+        tb = time.perf_counter() - t0
+        bfrac = bytes_step * steps * nb / 3.0 / tb / 8e12
+        batch = {'utterances': nb, 'frames_per_s': nb * T / tb, 'us_per_step_and_utterance': tb / (nb * steps) * 1e6,
+                 'same_path_as_single': bool(np.array_equal(np.asarray(pb[0]), np.asarray(path))),
+                 'roofline': {'bound': 'hbm', 'achieved': bfrac * 8000.0, 'peak': 8000.0, 'unit': 'GB/s', 'frac': bfrac,
+                              'note': 'one scan of the database serves three utterances: the scan\'s algorithmic bytes / 3 per utterance step'}}
+        out[name] = {'units': N, 'multiepoch': me, 'frames': T, 'steps': steps, 'us_per_step': us_step, 'batch': batch,
                      'frames_per_s': T / dt, 'ms_per_utterance': dt * 1e3,
                      'roofline': {'bound': 'hbm', 'achieved': bytes_step / (us_step * 1e-6) / 1e9, 'peak': 8000.0,
                                   'unit': 'GB/s', 'frac': bytes_step / (us_step * 1e-6) / 8e12,
@@ -384,8 +397,9 @@ def main():
         f32_mode = eng.info('precision') == 1 and eng.info('f16_ready') == 1 and eng.info('f16_fallbacks') == 0
         bf16_mode = f32_mode and eng.info('prefilter_bf16_active') == 1
         peak = BF16_MFMA_PEAK_TFLOPS if bf16_mode else F32_MFMA_PEAK_TFLOPS if f32_mode else F64_MFMA_PEAK_TFLOPS
+        terms = 4 if eng.info('prefilter') == 2 else 3
         kname = ('knn_sweep16b<filter> (v_mfma_f32_32x32x16_bf16 prefilter, every operand split into two bf16 pieces: '
-                 '4 MFMA terms per product; exact f64 re-rank in knn_finalize)' if bf16_mode else
+                 '%d MFMA terms per product; exact f64 re-rank in knn_finalize)' % terms if bf16_mode else
                  'knn_sweep16<filter> (v_mfma_f32_32x32x2_f32 prefilter; exact f64 re-rank in knn_finalize)'
                  if f32_mode else 'knn_sweep<filter> (v_mfma_f64_16x16x4_f64)')
         traffic = None
@@ -429,12 +443,12 @@ def main():
         if bf16_mode:
             # what the matrix pipe executes for those algorithmic flops: 64-column tiles, 4 bf16 terms per product
             dpad = (Dt + 3 + 63) // 64 * 64
-            issued = 4.0 * 2.0 * rows_per_launch * n_local * dpad
+            issued = terms * 2.0 * rows_per_launch * n_local * dpad
             out['roofline']['issued'] = {'tflops': issued / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
                                          'frac': issued / (avg_ms * 1e-3) / 1e12 / peak if avg_ms > 0 else 0.0,
-                                         'note': 'float32-accurate keys on the bf16 pipe cost 4 bf16 MFMA terms per product (hi.hi + hi.lo + '
-                                                 'lo.hi + lo.lo) on Dt padded to 64 columns; frac above prices only the algorithmic '
-                                                 '2 N rows Dt flops against the bf16 peak'}
+                                         'note': 'float32-grade keys on the bf16 pipe cost %d bf16 MFMA terms per product (hi.hi + hi.lo + '
+                                                 'lo.hi%s) on Dt padded to 64 columns; frac above prices only the algorithmic '
+                                                 '2 N rows Dt flops against the bf16 peak' % (terms, ' + lo.lo' if terms == 4 else '')}
         if two_in_flight is not None:
             out['two_in_flight'] = two_in_flight
         if one_in_flight is not None:
