@@ -300,6 +300,7 @@ def main():
             eng.upload_target_only(F_unw[lo:hi])
             eng.upload_join_only(JC_unw)
             eng.set_shard(lo, N)
+            search = None
             if args.exchange == 'library':
                 # collectives inside libsnkhip.so (RCCL on the engine's stream, no host synchronisation between
                 # bounds, exchange and merge); every rank bounds its own share of the rows against a
@@ -307,10 +308,26 @@ def main():
                 from snickery_amd.dist import LibraryShardedSearch, global_sample
                 eng.upload_global_sample(global_sample(F_unw, 16))
                 eng.set_weights(wt, wj)
-                search = LibraryShardedSearch(eng, rank=sub_rank, world_size=S, group=group,
-                                              transport='gloo' if share_gpu else 'rccl')
-            else:
-                eng.set_weights(wt, wj)
+                # the library's own RCCL communicator has only ever been opened with one rank on the one-GPU test boxes:
+                # if it cannot be opened here on ANY rank, every rank takes the exchange through torch.distributed
+                # (the same HIP kernels, the caller's communicator) and the JSON line says so
+                err = ''
+                try:
+                    search = LibraryShardedSearch(eng, rank=sub_rank, world_size=S, group=group,
+                                                  transport='gloo' if share_gpu and os.environ.get('SNK_BENCH_FORCE_RCCL') != '1' else 'rccl')
+                except Exception as e:        # noqa: BLE001
+                    err = str(e)
+                flag = torch.tensor([0 if search is None else 1], dtype=torch.int32, device='cpu' if share_gpu else 'cuda')
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    sys.stderr.write('rank %d: library communicator not available (%s): exchange through torch.distributed\n' % (rank, err or 'another rank failed'))
+                    if search is not None:
+                        eng.comm_destroy()
+                    args.exchange = 'torch (library communicator could not be opened)'
+                    search = None
+            if search is None:
+                if args.exchange == 'torch':
+                    eng.set_weights(wt, wj)
                 search = ShardedSearch(HipShardEngine(eng, torch.device('cuda', local_rank)), rank=sub_rank, world_size=S,
                                        group=group)
 

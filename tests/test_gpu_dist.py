@@ -177,3 +177,20 @@ def test_bench_multi_rank_one_gpu(nproc, shards, sharding):
     assert js['n_gpus'] == nproc and js['value'] > 0 and js['scaling'] == 'weak'
     assert js['config']['utts_per_step'] == 5 * nproc and js['config']['sharding'] == sharding
     assert 'roofline' in js and 'FUNCTIONAL TEST' in js['note']
+
+
+def test_bench_falls_back_to_the_callers_communicator_when_rccl_cannot_open():
+    """Two ranks on ONE device: RCCL refuses the communicator (duplicate GPU).  Every rank must then agree to run the
+    exchange through torch.distributed instead of one rank dying and the other waiting -- the situation the driver's
+    multi-GPU run would be in if the in-library communicator failed for a reason the one-GPU boxes cannot show."""
+    env = dict(os.environ, SNK_BENCH_SHARE_GPU='1', SNK_BENCH_FORCE_RCCL='1')
+    port = 33500 + (os.getpid() % 2000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+           '--gpus', '2', '--steps', '2', '--warmup', '1', '--units', '40000', '--frames', '60', '--utts', '5',
+           '--candidates', '20', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    js = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert js['value'] > 0 and 'could not be opened' in js['config']['exchange']
+    assert 'library communicator not available' in r.stderr
