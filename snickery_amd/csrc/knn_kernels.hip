@@ -516,6 +516,11 @@ void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int
                        int max_chunks, int64_t Tpad, int64_t n_valid, int *cnt, double *lkey, int *lidx,
                        int cap, int *status, hipStream_t s)
 {
+    static size_t attr = 0;
+    if ((size_t)Tpad * sizeof(int) > 65536 && (size_t)Tpad * sizeof(int) > attr) {
+        attr = (size_t)Tpad * sizeof(int);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attr);
+    }
     hipLaunchKernelGGL(knn_bucket_kernel, dim3(1024), dim3(256), (size_t)Tpad * sizeof(int), s,
                        reinterpret_cast<const PoolEntry *>(pool), pool_ctl, chunk_fill, max_chunks,
                        (int)Tpad, (int)n_valid, cnt, lkey, lidx, cap, status);

@@ -175,7 +175,7 @@ struct snk_engine {
     int timers_on = 1;
     int n_cus = 256;
     int reserved_cus = 2;
-    int batch_rows = 8192;     // rows per K-NN call of the batch entry points (utterances are grouped)
+    int batch_rows = 12288;    // rows per K-NN call of the batch entry points (utterances are grouped)
     int viterbi_mode = 2;      // 2: auto; 1: f32 lower bounds on the matrix pipe + sparse exact recursion; 0: dense exact join + recursion
     double join_beta = 5e-4;   // pass-2 margin in units of the step's largest centred norm (speed only, never the result)
     DevBuf vstats;             // [0] cells refined, [1] steps with a refinement, [2] exact costs computed there
@@ -257,7 +257,7 @@ static int no_batch_in_flight(snk_engine *h, const char *who);
 static int create_streams(snk_engine *h);
 static bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts);
 static int roundup(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); }
-#define SNK_KNN_MAX_ROWS 8192       // rows of one K-NN call (batch_rows is capped to it)
+#define SNK_KNN_MAX_ROWS 32768      // rows of one K-NN call (batch_rows is capped to it)
 
 // ---------------------------------------------------------------------------
 extern "C" {
@@ -1265,10 +1265,24 @@ int snk_knn_viterbi(snk_handle h, const double *Q, int64_t T, int D, int K, int6
 static std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offsets, int n_utts)
 {
     std::vector<int> first(1, 0);
+    // as few groups as batch_rows allows, of equal size and an even number of them: two groups of 16 utterances take a
+    // B* step 13 % less time than 13 + 13 + 6 (11.9 against 13.7 ms; three of 11 / 11 / 10: 13.2, four of 8: 12.0,
+    // one of 32: 18.2 -- nothing of its own step to run beside)
+    const int64_t total = row_offsets[n_utts] - row_offsets[0];
+    int64_t target = h->batch_rows;
+    if (h->batch_rows > 0) {
+        int64_t n_groups = (total + h->batch_rows - 1) / h->batch_rows;
+        if (n_groups > 1 && (n_groups & 1)) ++n_groups;       // groups alternate between two workspaces and side streams
+        target = (total + n_groups - 1) / n_groups;
+    }
     int64_t rows = 0;
     for (int u = 0; u < n_utts; ++u) {
         const int64_t T = row_offsets[u + 1] - row_offsets[u];
-        if (u > first.back() && (h->batch_rows <= 0 || rows + T > h->batch_rows)) { first.push_back(u); rows = 0; }
+        // close the group when adding this utterance would overshoot the even share by more than it undershoots
+        if (u > first.back() && (h->batch_rows <= 0 || rows + T > h->batch_rows || rows + T - target > target - rows)) {
+            first.push_back(u);
+            rows = 0;
+        }
         rows += T;
     }
     first.push_back(n_utts);
@@ -2328,7 +2342,7 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value < 0 || value > 64) return fail("reserved_cus must be in 0..64");
         h->reserved_cus = (int)value;
     } else if (!strcmp(name, "batch_rows")) {
-        if (value < 0 || value > 8192) return fail("batch_rows must be in 0..8192 (0: one K-NN call per utterance)");
+        if (value < 0 || value > SNK_KNN_MAX_ROWS) return fail("batch_rows must be in 0..%d (0: one K-NN call per utterance)", (int)SNK_KNN_MAX_ROWS);
         h->batch_rows = (int)value;
     } else if (!strcmp(name, "greedy_mode")) {
         if (value != 0.0 && value != 1.0 && value != 2.0) return fail("greedy_mode must be 0 (exact scan, a launch per step), 1 (float32 prefilter scan, one launch) or 2 (auto)");
