@@ -209,14 +209,14 @@ def test_sharded_batch_pipeline_on_one_gpu(engine):
         paths, costs = engine.merge_viterbi_batch_dev(d2_own.data_ptr(), id_own.data_ptr(), G, lens[a:b], K)
         for j, u in enumerate(range(a, b)):
             assert np.array_equal(paths[j], ref_paths[u]) and costs[j] == ref_costs[u]
-    engine.set_option('batch_rows', 8192)
+    engine.set_option('batch_rows', 12288)
     assert len(ref_paths[3]) == 2
 
 
 def test_very_long_utterance(engine):
-    """An utterance longer than the rows of one K-NN call (8192): the search is cut by rows inside
+    """An utterance longer than the rows of one K-NN call (32768): the search is cut by rows inside
     the library, join costs / recursion run over the whole utterance (back-pointers in global memory)."""
-    N, Dt, Dj, T, K = 20000, 61, 40, 9000, 16
+    N, Dt, Dj, T, K = 20000, 61, 40, 33000, 16
     F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=61)
     wt = np.full(Dt, 0.5)
     wj = np.full(Dj, 0.1)

@@ -220,15 +220,16 @@ def test_viterbi_batch_groups(engine):
     lens = [40, 130, 7, 64, 2, 90, 33, 1, 51, 77, 120]
     utts = [o.synthetic_targets(F_unw, T, seed=30 + i) * wt for i, T in enumerate(lens)]
     single = [engine.knn_viterbi(U, 30) for U in utts]
-    assert engine.info('batch_rows') == 8192
+    default_rows = int(engine.info('batch_rows'))
+    assert default_rows == 12288
     try:
-        for rows in (100, 1, 0, 8192):
+        for rows in (100, 1, 0, 8192, default_rows):
             engine.set_option('batch_rows', rows)
             paths, costs = engine.knn_viterbi_batch(utts, 30)
             for u in range(len(utts)):
                 assert list(paths[u]) == single[u][0] and (costs[u] == single[u][1] or len(single[u][0]) == 0)
     finally:
-        engine.set_option('batch_rows', 8192)
+        engine.set_option('batch_rows', default_rows)
     assert len(paths[7]) == 0 and len(paths[4]) == 2          # T = 1: no path
     assert engine.info('batch_redos') == 0 and engine.info('f16_fallbacks') == 0
 
@@ -307,7 +308,7 @@ def test_viterbi_batch_submit_collect(engine):
         engine.set_option('list_capacity', 4096)
         engine.set_option('sample_fraction', 1.0 / 16)
         engine.set_option('precision', 1)
-        engine.set_option('batch_rows', 8192)
+        engine.set_option('batch_rows', 12288)
 
 
 def test_greedy_golden(mini_engine, golden, mini_voice):
