@@ -527,6 +527,103 @@ void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int
 }
 
 // ---------------------------------------------------------------------------
+// Row-sharded databases, second shared bound.  The bound the shards filter against comes from a sample and lets
+// ~19 K candidates per row through, spread over the shards; every shard would re-rank its part exactly although
+// the owner needs K in all.  Once a shard's list is there it knows better: the K-th smallest key of ITS list (plus
+// the key error) bounds the K-th nearest key of the whole database from above, the minimum of those over the shards
+// (one all-reduce) does too, and everything above it (plus the key error again) can go before the exact re-rank.
+//   knn_local_kth_kernel: one wavefront per row; an upper bound of the K-th smallest list key from a 64-bin
+//                         histogram (the upper edge of the bin the K-th key falls into), +eps[row]; DBL_MAX when the
+//                         list holds fewer than K entries.
+//   knn_list_prune_kernel: keeps the entries with key <= bound[row] + eps[row], in place, order kept.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+knn_local_kth_kernel(const int *__restrict__ cnt, const double *__restrict__ lkey, int cap, int K,
+                     const double *__restrict__ eps, int64_t T, double *__restrict__ kth)
+{
+    __shared__ int hist[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wv;
+    if (row >= T) return;
+    int n = cnt[row];
+    if (n > cap) n = cap;
+    if (n < K) { if (lane == 0) kth[row] = DBL_MAX; return; }
+    const double *key = lkey + row * cap;
+    double kmin = DBL_MAX, kmax = -DBL_MAX;
+    for (int i = lane; i < n; i += 64) { const double v = key[i]; kmin = fmin(kmin, v); kmax = fmax(kmax, v); }
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = fmin(kmin, __shfl_xor(kmin, off));
+        kmax = fmax(kmax, __shfl_xor(kmax, off));
+    }
+    hist[wv][lane] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // one wavefront owns hist[wv]: program order is enough
+    const double scale = (kmax > kmin) ? 64.0 / (kmax - kmin) : 0.0;
+    for (int i = lane; i < n; i += 64) {
+        int b = (int)((key[i] - kmin) * scale);
+        b = b > 63 ? 63 : b;
+        atomicAdd(&hist[wv][b], 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // inclusive prefix over the 64 bins (one per lane)
+    int c = hist[wv][lane];
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(c, off);
+        if (lane >= off) c += o;
+    }
+    const unsigned long long reach = __ballot(c >= K);          // bins at or past the K-th key
+    const int b = __ffsll((long long)reach) - 1;
+    if (lane == 0) {
+        // every key of bins 0..b is below kmin + (b + 1) / scale (+ the rounding of the bin index: one more ulp-sized step)
+        const double edge = (scale > 0.0 && b < 63) ? kmin + ((double)(b + 1) / scale) * (1.0 + 1e-12) + 1e-300 : kmax;
+        kth[row] = edge + eps[row];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+knn_list_prune_kernel(int *__restrict__ cnt, double *__restrict__ lkey, int *__restrict__ lidx, int cap,
+                      const double *__restrict__ bound, const double *__restrict__ eps, int64_t T)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const int n_all = cnt[row];
+    if (n_all > cap) return;                                    // overflowed list: left to the status path of finalize
+    const double lim = bound[row];
+    if (lim >= 0.5 * DBL_MAX) return;
+    const double cut = lim + eps[row];
+    double *key = lkey + row * cap;
+    int *idx = lidx + row * cap;
+    int w = 0;
+    for (int i0 = 0; i0 < n_all; i0 += 64) {
+        const int i = i0 + lane;
+        double v = 0.0;
+        int id = 0;
+        const bool in = i < n_all;
+        if (in) { v = key[i]; id = idx[i]; }
+        const bool keep = in && v <= cut;
+        const unsigned long long m = __ballot(keep);
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        // (the 64 entries of this round are in registers; the write positions lie below the round's own start + 64)
+        if (keep) { key[w + rank] = v; idx[w + rank] = id; }
+        w += __popcll(m);
+    }
+    if (lane == 0) cnt[row] = w;
+}
+
+void launch_knn_local_kth(const int *cnt, const double *lkey, int cap, int K, const double *eps, int64_t T, double *kth,
+                          hipStream_t s)
+{
+    hipLaunchKernelGGL(knn_local_kth_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, s, cnt, lkey, cap, K, eps, T, kth);
+}
+
+void launch_knn_list_prune(int *cnt, double *lkey, int *lidx, int cap, const double *bound, const double *eps, int64_t T,
+                           hipStream_t s)
+{
+    hipLaunchKernelGGL(knn_list_prune_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, s, cnt, lkey, lidx, cap, bound,
+                       eps, T);
+}
+
+// ---------------------------------------------------------------------------
 // query preparation
 // ---------------------------------------------------------------------------
 __global__ void prepare_queries_kernel(const double *__restrict__ Q, int64_t T, int D,

@@ -152,6 +152,8 @@ struct snk_engine {
     int prefilter = 1;            // 1: bf16-split operands on the bf16 matrix pipe where the shape has a variant, 0: float32 operands
     bool bf16_ready = false;      // a16l / s16l (and gs_tiles_b) hold the bf16-split operands of the current weights
     double eps_c_bf = 4e-6;       // accumulation part of the bound of the bf16-split keys (knn16_kernels.hip: c_acc)
+    DevBuf kth16;                 // sharded search: per-row second bound (K-th key of the local list, all-reduced)
+    int shard_refine = 1;         // 1: snk_sharded_knn_viterbi_batch prunes the shards' lists to that bound before the re-rank
     DevBuf gs_tiles_b, cq16, rho16, gs_rho16;   // per-row split coefficient; dropped-piece ratios of the operands
     int f16_fallbacks = 0;
     int last_f16_status = 0;
@@ -339,7 +341,7 @@ int snk_destroy(snk_handle h)
     h->rowflag.release(); h->exact_rows.release(); h->exact_scratch.release();
     h->frames_spec.release(); h->frames_fzv.release(); h->cc_in.release(); h->cc_out.release();
     h->res_status.release(); h->hstage.release();
-    { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b, &h->cq16, &h->rho16, &h->gs_rho16};
+    { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b, &h->cq16, &h->rho16, &h->gs_rho16, &h->kth16};
       for (auto *b : fb) b->release(); }
     for (int i = 0; i < 8; ++i) {
         UttSlot &s = h->slot[i];
@@ -663,9 +665,14 @@ static KnnPlan make_plan(snk_engine *h, int K)
 // of the whole database.  Lists may then hold fewer than K entries (padded with id -1).
 // gs (with bound_out): stage A runs against the replicated GLOBAL sample (snk_upload_global_sample) instead of
 // this shard's own one -- the bound is then that of the whole database, as on a single GPU.
+namespace { int comm_all_reduce_min(snk_engine *h, double *buf, int64_t n); }
+
+// refine (with bound_in, inside snk_sharded_knn_viterbi_batch): between bucket and re-rank the shards agree on a
+// second, tighter bound -- the smallest of their lists' K-th keys (knn_kernels.hip knn_local_kth_kernel) -- with one
+// more all-reduce per call, and prune their lists to it.
 static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_t *qclass_dev,
                       int64_t *cand_dev, double *dist_dev, double *d2_dev, int *deferred_status = nullptr,
-                      const double *bound_in = nullptr, double *bound_out = nullptr, bool gs = false)
+                      const double *bound_in = nullptr, double *bound_out = nullptr, bool gs = false, bool refine = false)
 {
     if (K < 1 || K > 208) return fail("K-NN: n_candidates=%d outside the supported range 1..208", K);
     if (T > SNK_KNN_MAX_ROWS) {
@@ -676,7 +683,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             CHK(knn_device(h, Qdev + r0 * h->Dt, rows, K, qclass_dev ? qclass_dev + r0 : nullptr,
                            cand_dev ? cand_dev + r0 * K : nullptr, dist_dev ? dist_dev + r0 * K : nullptr,
                            d2_dev ? d2_dev + r0 * K : nullptr, nullptr, bound_in ? bound_in + r0 : nullptr,
-                           bound_out ? bound_out + r0 : nullptr, gs));
+                           bound_out ? bound_out + r0 : nullptr, gs, refine));
         }
         if (deferred_status) HIPCHK(hipMemsetAsync(deferred_status, 0, sizeof(int), h->stream));
         return 0;
@@ -806,6 +813,14 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             launch_knn_bucket(h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
                               Tpad, h->N, h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap, status_dev, s);
         }
+        if (refine && bound_in && h->comm_ranks > 1 && h->shard_refine) {
+            StageTimer t(h, s, TM_KNN_BUCKET);
+            CHK(h->kth16.ensure((size_t)Tpad * sizeof(double)));
+            launch_knn_local_kth(h->cnt.as<int>(), h->lkey.as<double>(), cap, K, h->eps16.as<double>(), T, h->kth16.as<double>(), s);
+            CHK(comm_all_reduce_min(h, h->kth16.as<double>(), T));
+            launch_knn_list_prune(h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap, h->kth16.as<double>(),
+                                  h->eps16.as<double>(), T, s);
+        }
         {
             StageTimer t(h, s, TM_KNN_FINALIZE);
             launch_knn_finalize(h->Fw.as<double>(), h->F_unw.as<float>(), h->Fp, h->wt.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
@@ -826,6 +841,13 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
     if (bound_out) {                          // no f32 path for this shape: no bound, nothing is pruned
         launch_fill_threshold(bound_out, T, T, DBL_MAX, s);
         return 0;
+    }
+    if (refine && bound_in && h->comm_ranks > 1 && h->shard_refine) {
+        // this rank's shard has no prefilter lists (shape without a variant): it still takes part in the other
+        // ranks' all-reduce of the second bound, contributing nothing
+        CHK(h->kth16.ensure((size_t)Tpad * sizeof(double)));
+        launch_fill_threshold(h->kth16.as<double>(), T, T, DBL_MAX, s);
+        CHK(comm_all_reduce_min(h, h->kth16.as<double>(), T));
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
         // attempt 0: thresholds from a strided sample of slabs (stage A).
@@ -1793,7 +1815,7 @@ static int upload_batch_queries(snk_engine *h, const double *Q, int64_t total, i
 // h->res_status (the caller checks them when it next touches the host, and redoes the step if any is set).
 static int knn_local_batch(snk_engine *h, const char *who, const double *Q, const int64_t *row_offsets, int n_utts,
                            int D, int K, const double *bound_in, double *bound_out, double *d2_dev_out,
-                           int64_t *id_dev_out, int *defer = nullptr)
+                           int64_t *id_dev_out, int *defer = nullptr, bool refine = false)
 {
     CHK(check_ready(h, true, false));
     HIPCHK(hipSetDevice(h->device));
@@ -1817,7 +1839,7 @@ static int knn_local_batch(snk_engine *h, const char *who, const double *Q, cons
         const int64_t r0 = g * step, rows = (r0 + step <= total) ? step : total - r0;
         CHK(knn_device(h, h->Qall.as<double>() + r0 * D, rows, K, nullptr, id_dev_out ? id_dev_out + r0 * K : nullptr,
                        nullptr, d2_dev_out ? d2_dev_out + r0 * K : nullptr, h->res_status.as<int>() + g,
-                       bound_in ? bound_in + r0 : nullptr, bound_out ? bound_out + r0 : nullptr));
+                       bound_in ? bound_in + r0 : nullptr, bound_out ? bound_out + r0 : nullptr, false, refine));
     }
     if (defer) { *defer = n_groups; HIPCHK(hipGetLastError()); return 0; }
     if (bound_out) {
@@ -2140,7 +2162,7 @@ static int sharded_step(snk_engine *h, const double *Q, const int64_t *row_offse
             }
             if ((rc = comm_all_reduce_min(h, bound, R))) break;
             if ((rc = knn_local_batch(h, "snk_sharded_knn_viterbi_batch", nullptr, row_offsets, n_utts, D, K, bound, nullptr,
-                                      d2, ids, &n_status))) break;
+                                      d2, ids, &n_status, true))) break;
         } else {
             if ((rc = knn_local_batch(h, "snk_sharded_knn_viterbi_batch", Q, row_offsets, n_utts, D, K, nullptr, nullptr,
                                       d2, ids, safe ? nullptr : &n_status))) break;
@@ -2351,6 +2373,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0 && value != 2.0) return fail("viterbi_mode must be 0 (dense exact join + recursion), 1 (lower bounds + sparse exact recursion) or 2 (auto)");
         CHK(no_batch_in_flight(h, "snk_set_option(viterbi_mode)"));
         h->viterbi_mode = (int)value;
+    } else if (!strcmp(name, "shard_refine")) {
+        if (value != 0.0 && value != 1.0) return fail("shard_refine must be 0 or 1 (the same on every rank)");
+        h->shard_refine = (int)value;
     } else if (!strcmp(name, "join_bounds_stream")) {
         if (value != 0.0 && value != 1.0) return fail("join_bounds_stream must be 0 (main stream) or 1 (side stream of the group)");
         CHK(no_batch_in_flight(h, "snk_set_option(join_bounds_stream)"));

@@ -56,6 +56,10 @@ void launch_knn_exact_rows(const double *Fw, int Dpad, int D, int64_t N, const d
                            int n_rows, int K, double *scratch, int64_t scratch_pitch, const int32_t *unit_class,
                            const int32_t *query_class, int64_t id_offset, int64_t *cand, double *dist,
                            double *d2_out, hipStream_t s);
+void launch_knn_local_kth(const int *cnt, const double *lkey, int cap, int K, const double *eps, int64_t T, double *kth,
+                          hipStream_t s);
+void launch_knn_list_prune(int *cnt, double *lkey, int *lidx, int cap, const double *bound, const double *eps, int64_t T,
+                           hipStream_t s);
 void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const double *wt, int Dpad, int D, const double *Qp, const double *qnorm,
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
                          int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c, const double *cq,

@@ -44,6 +44,8 @@ def all_reduce_min(a):
     if state['capture'] is not None:           # capture pass: keep this "rank"'s bounds and abandon the step
         state['capture'] = np.minimum(state['capture'], a)
         raise _Captured()
+    if a.size != state['bounds'].size:         # the second bound of a K-NN call: the other shards hold no neighbours of these rows
+        return a
     return np.minimum(a, state['bounds'])
 
 
