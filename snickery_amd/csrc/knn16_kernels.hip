@@ -937,7 +937,7 @@ knn_threshold16_kernel(const float *__restrict__ gmin32, int64_t G, int64_t T, i
         // K-th smallest of the P values by radix selection on the order-preserving integer image of
         // a float (four passes of an 8-bit histogram); a full bitonic sort of 1024 keys per row took
         // three times as long
-        __shared__ unsigned int hist[256];
+        __shared__ unsigned int hist[256], wsum[4];
         __shared__ unsigned int sel_prefix, sel_rank;
         if (threadIdx.x == 0) { sel_prefix = 0u; sel_rank = (unsigned int)(K - 1); }
         auto image = [](float f) -> unsigned int {
@@ -955,11 +955,25 @@ knn_threshold16_kernel(const float *__restrict__ gmin32, int64_t G, int64_t T, i
                 if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned int rank = sel_rank, b = 0;
-                for (; b < 256u; ++b) { if (rank < hist[b]) break; rank -= hist[b]; }
-                sel_prefix = prefix | (b << shift);
-                sel_rank = rank;
+            {
+                // the bin holding the wanted rank, by a workgroup-wide prefix sum (a thread-0 loop over the bins was
+                // most of this kernel: 4 x 256 dependent LDS reads per row)
+                const unsigned int rank = sel_rank;
+                const unsigned int mine = hist[threadIdx.x];
+                unsigned int c = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned int o = __shfl_up(c, off);
+                    if ((threadIdx.x & 63) >= (unsigned)off) c += o;
+                }
+                if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = c;
+                __syncthreads();
+                for (unsigned int w = 0; w < (threadIdx.x >> 6); ++w) c += wsum[w];
+                __syncthreads();                      // sel_rank is read by every thread above
+                if (rank < c && rank >= c - mine) {
+                    sel_prefix = prefix | (threadIdx.x << shift);
+                    sel_rank = rank - (c - mine);
+                }
             }
             __syncthreads();
         }

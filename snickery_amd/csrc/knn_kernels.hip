@@ -837,6 +837,23 @@ void launch_fill_threshold(double *thr, int64_t T, int64_t Tpad, double value, h
 // ---------------------------------------------------------------------------
 // finalize: sort the row's candidate list, exact re-rank, output
 // ---------------------------------------------------------------------------
+// inclusive prefix sum over the 256 threads of a workgroup (every thread must call it)
+__device__ __forceinline__ int block_incl_scan_256(int v, int *wsum /* LDS [4] */)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int c = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(c, off);
+        if (lane >= off) c += o;
+    }
+    if (lane == 63) wsum[wv] = c;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+    return c + base;
+}
+
 #define SEL_MAX 2048     // candidates re-ranked exactly per row (K + near ties / key error margin)
 #define FIN_SMALL 512    // lists up to this length go through the small-LDS instance (13 workgroups per compute unit
                          // instead of 2: the short lists of a row-sharded database are latency-, not LDS-bound)
@@ -922,9 +939,19 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
             atomicAdd(&hist[b], 1);
         }
         __syncthreads();
+        // prefix sums of the 256 bins by the whole workgroup (a thread-0 loop over the bins, twice, was most of the
+        // kernel's time on lists of ~2000 entries: ~500 dependent LDS reads per row)
+        // (the reduction arrays are free again: no new LDS -- two workgroups of this kernel just fit a compute unit)
+        int *pre = reinterpret_cast<int *>(red_max), *wsum = reinterpret_cast<int *>(red_fm);
+        {
+            const int mine = hist[threadIdx.x];
+            const int incl = block_incl_scan_256(mine, wsum);
+            pre[threadIdx.x] = incl;
+            if (incl >= K && incl - mine < K) cut_bin_s = (int)threadIdx.x;   // the bin holding the K-th smallest key
+        }
+        __syncthreads();
         if (threadIdx.x == 0) {
-            int cum = 0, b = 0;
-            for (; b < 256; ++b) { cum += hist[b]; if (cum >= K) break; }
+            const int b = cut_bin_s;
             int cut = b + 1;                       // one bin past the K-th key's bin (near ties)
             if (margin > 0.0) {                    // ... and everything within the key error margin
                 const double upper = kmin + (double)(b + 1) / scale + margin;
@@ -932,9 +959,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
                 if (cm > cut) cut = cm;
             }
             if (cut > 255) cut = 255;
-            int tot = 0;
-            for (int i = 0; i <= cut; ++i) tot += hist[i];
-            cut_bin_s = (tot <= SELM) ? cut : -1;
+            cut_bin_s = (pre[cut] <= SELM) ? cut : -1;
         }
         __syncthreads();
         fast = cut_bin_s >= 0;
