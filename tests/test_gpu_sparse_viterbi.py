@@ -135,3 +135,22 @@ def test_exact_join_costs_are_a_small_fraction(engine):
     opath, ocost = oc.viterbi(cand, dist, o.weight(JC_unw, wj))
     assert path == opath and cost == ocost
     assert refined <= 0.01 * T * K * K, refined
+
+
+def test_auto_mode_takes_the_sparse_path_for_batches_at_every_k(engine):
+    """viterbi_mode 2: a batch goes through the sparse path also at K = 200 (BASELINE config 4; those instances
+    spill registers and are still 1.5x faster than the dense kernels) and equals the dense result."""
+    N, Dj = 150000, 302
+    F_unw, JC_unw = o.synthetic_db(N, 61, Dj, seed=31)
+    wt, wj = np.full(61, 0.4), np.full(Dj, 0.05)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    utts = [o.synthetic_targets(F_unw, T, seed=40 + i) * wt for i, T in enumerate([120, 77, 200])]
+    for K in (200, 150, 100):
+        engine.set_option('viterbi_mode', 0)
+        p0, c0 = engine.knn_viterbi_batch(utts, K)
+        engine.set_option('viterbi_mode', 2)
+        before = engine.timers().get('viterbi_sparse', (0, 0))[1]
+        p2, c2 = engine.knn_viterbi_batch(utts, K)
+        assert engine.timers().get('viterbi_sparse', (0, 0))[1] > before, K
+        assert all(np.array_equal(a, b) for a, b in zip(p0, p2)) and np.array_equal(c0, c2), K
