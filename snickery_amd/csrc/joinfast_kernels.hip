@@ -430,7 +430,7 @@ void launch_viterbi_lb(const int64_t *cand, const double *tdist, const float *Jl
         if (variant == 0) SNK_LB(16, 4, 256);
         else if (variant == 1) SNK_LB(25, 6, 448);
         else if (variant == 2) SNK_LB(32, 3, 512);
-        else SNK_LB(52, 2, 832);
+        else SNK_LB(52, 1, 832);
 #undef SNK_LB
     }
 }
