@@ -871,11 +871,12 @@ knn_sweep16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const
     }
 }
 
-// nt / dch as launch_knn_sweep16; instantiated for the reference's own widths: one chunk (Dt <= 61) with four
-// tiles per wavefront, three chunks (Dt <= 189) with one.  Returns false for any other shape (f32 prefilter then).
+// nt / dch as launch_knn_sweep16; instantiated for the reference's own widths: one chunk (Dt <= 61: one-point / epoch
+// targets) with four tiles per wavefront, two chunks (Dt <= 125: two-point halfphone targets) with two, three chunks
+// (Dt <= 189: three-point) with one.  Returns false for any other shape (f32 prefilter then).
 bool knn_sweep16b_supported(int nt, int dch, int Dt, int Dpad, bool cls)
 {
-    return !cls && Dpad - Dt >= 3 && ((nt == 4 && dch == 1) || (nt == 1 && dch == 3));
+    return !cls && Dpad - Dt >= 3 && ((nt == 4 && dch == 1) || (nt == 2 && dch == 2) || (nt == 1 && dch == 3));
 }
 
 bool launch_knn_sweep16b(int mode, int terms, int nt, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32,
@@ -897,6 +898,7 @@ bool launch_knn_sweep16b(int mode, int terms, int nt, int dch, int grid_cus, con
                        (PoolEntry16 *)pool, pool_ctl, chunk_fill, max_chunks, pool_chunk)
 #define SNK_L16B(NT_, KB_, MODE_) do { if (terms == 4) SNK_L16T(NT_, KB_, MODE_, 4); else SNK_L16T(NT_, KB_, MODE_, 3); } while (0)
     if (nt == 4 && dch == 1) { if (mode == 0) SNK_L16B(4, 4, 0); else SNK_L16B(4, 4, 1); return true; }
+    if (nt == 2 && dch == 2) { if (mode == 0) SNK_L16B(2, 8, 0); else SNK_L16B(2, 8, 1); return true; }
     if (nt == 1 && dch == 3) { if (mode == 0) SNK_L16B(1, 12, 0); else SNK_L16B(1, 12, 1); return true; }
 #undef SNK_L16B
 #undef SNK_L16T

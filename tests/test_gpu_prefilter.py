@@ -35,7 +35,7 @@ def setup(engine, N, Dt, seed, offset=0.0, scale=None):
 
 
 @pytest.mark.parametrize('N,T,K,Dt', [(65536, 96, 100, 61), (40000, 64, 50, 45), (30000, 40, 30, 150), (50000, 33, 200, 189),
-                                      (33333, 70, 16, 20)])
+                                      (33333, 70, 16, 20), (40000, 50, 50, 123), (30000, 35, 100, 100), (20000, 33, 20, 125)])
 def test_bf16_prefilter_results_are_the_exact_ones(engine, N, T, K, Dt):
     engine.set_option('prefilter', 1)
     F_unw, wt, F = setup(engine, N, Dt, seed=N % 89)
@@ -56,7 +56,7 @@ def test_bf16_prefilter_results_are_the_exact_ones(engine, N, T, K, Dt):
 
 def test_shapes_without_a_bf16_variant_keep_float32_operands(engine):
     engine.set_option('prefilter', 1)
-    for Dt in (100, 63, 191):       # two chunks; no three spare columns
+    for Dt in (250, 63, 127, 191):  # four chunks; no three spare columns (one, two, three chunks)
         F_unw, wt, F = setup(engine, 30000, Dt, seed=Dt)
         assert engine.info('prefilter_bf16_active') == 0
         U = o.synthetic_targets(F_unw, 20, seed=5) * wt
@@ -76,7 +76,7 @@ def slab_minima_f64(F, U, rows):
 
 @pytest.mark.parametrize('prefilter', [1, 0])
 @pytest.mark.parametrize('Dt,offset,scale', [(61, 0.0, None), (61, 3.0, None), (150, 0.0, None), (189, -2.0, None),
-                                             (61, 0.0, 37.0), (45, 100.0, 0.01)])
+                                             (61, 0.0, 37.0), (45, 100.0, 0.01), (123, 1.5, None)])
 def test_prefilter_keys_stay_inside_their_bound(engine, prefilter, Dt, offset, scale):
     """|key~ - key| <= eps[t] is what the filter's margins assume.  Offsets make ||f|| large against the
     distances (cancellation: the hard case for the split operands); scale moves the exponent range."""
