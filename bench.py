@@ -273,6 +273,7 @@ def main():
 
         def step():
             return eng.knn_viterbi_batch(batch, K)
+        pipeline = None
     else:
         from snickery_amd.dist import HipShardEngine, ShardedSearch, shard_bounds
         # ranks [q*S, (q+1)*S) form shard group q: the database is row-sharded over the S ranks of a
@@ -296,6 +297,8 @@ def main():
 
             def step():
                 return eng.knn_viterbi_batch(my_utts, K)
+            # independent replicas: each rank keeps two of its own steps in flight
+            pipeline = (lambda: eng.knn_viterbi_batch_submit(my_utts, K), eng.knn_viterbi_batch_collect)
         else:
             eng.upload_target_only(F_unw[lo:hi])
             eng.upload_join_only(JC_unw)
@@ -333,6 +336,9 @@ def main():
 
             def step():
                 return search.knn_viterbi_batch(my_utts, K)
+            # collectives in the library: two sharded steps in flight (every rank issues the same sequence of submits and
+            # collects); the torch-side exchange synchronises the host between its stages and stays one step at a time
+            pipeline = (lambda: search.submit(my_utts, K), search.collect) if hasattr(search, 'submit') else None
 
     def sync():
         torch.cuda.synchronize()
@@ -358,6 +364,16 @@ def main():
                 paths, costs = eng.knn_viterbi_batch_collect(pending)
             pending = ticket
         paths, costs = eng.knn_viterbi_batch_collect(pending)
+    elif world > 1 and args.in_flight == 2 and pipeline is not None:
+        my_utts.pin()
+        submit, collect = pipeline
+        pending = None
+        for _ in range(args.steps):
+            ticket = submit()
+            if pending is not None:
+                paths, costs = collect(pending)
+            pending = ticket
+        paths, costs = collect(pending)
     else:
         for _ in range(args.steps):
             paths, costs = step()
@@ -439,7 +455,7 @@ def main():
                                    'T=%d frames x %d utterances per step, K=%d, search_epsilon=0'
                                    % (N, Dt, Dj, T, U, K),
                        'units': N, 'target_dim': Dt, 'join_dim': Dj, 'frames': T, 'utts_per_step': U, 'utts_per_gpu': U // world,
-                       'n_candidates': K, 'steps_in_flight': args.in_flight if world == 1 else 1,
+                       'n_candidates': K, 'steps_in_flight': args.in_flight if (world == 1 or pipeline is not None) else 1,
                        'sharding': 'none' if world == 1 else (
                            '%d independent replicas' % world if S == 1 else
                            'db-rows/%d + all-to-all of local top-K' % S + (' x %d replica groups' % n_groups if n_groups > 1 else '')),

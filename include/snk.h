@@ -257,6 +257,14 @@ int snk_shard_plan(int64_t n_items, int nranks, int rank, int64_t *lo_out, int64
 int snk_upload_global_sample(snk_handle h, const float *F_sample_unw, int64_t n_rows, int Dt);
 int snk_sharded_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
                                   int64_t *path_out, int64_t *path_len_out, double *cost_out);
+/* The same step in two halves (as snk_knn_viterbi_batch_submit / _collect on one GPU): submit queues the K-NN of all rows,
+ * the collectives and the recursions of the owned utterances and returns a ticket (0 / 1); collect waits for them,
+ * gathers every rank's results and hands them out.  Two steps may be in flight: submitting step i + 1 before collecting
+ * step i runs the Viterbi side of step i beside the K-NN of step i + 1.  Every rank must issue the same sequence of
+ * submits and collects (the collectives are matched by order); Q must stay valid until its step is collected. */
+int snk_sharded_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
+                                         int *ticket_out);
+int snk_sharded_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, int64_t *path_len_out, double *cost_out);
 /* plain synchronous copies for transport implementations (device pointers handed to the callbacks) */
 int snk_copy_to_host(void *dst_host, const void *src_dev, int64_t bytes);
 int snk_copy_to_device(void *dst_dev, const void *src_host, int64_t bytes);

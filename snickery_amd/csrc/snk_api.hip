@@ -113,6 +113,17 @@ struct BatchSlot {    // one submitted batch (snk_knn_viterbi_batch_submit / _co
     std::vector<int64_t> offs;
 };
 
+struct ShardTicket {   // one submitted step of the sharded search (snk_sharded_knn_viterbi_batch_submit / _collect)
+    bool busy = false, safe = false;
+    int G = 1, me = 0, n_utts = 0, K = 0, D = 0, n_own = 0, n_status = 0;
+    int64_t R = 0, r_own = 0, slots = 0, rec = 0;
+    const double *Q = nullptr;                                   // the caller's query rows (kept valid until collect: a redo reads them)
+    std::vector<int64_t> offs, ulo, uhi, rows_to, row0, own_off;
+    DevBuf mcand, mdist, res_path, res_plen, res_cost, status;
+    HostBuf stage;                                               // own results + status words, pinned: filled by the copy stream
+    hipEvent_t main_done = nullptr, side_done[2] = {nullptr, nullptr}, done = nullptr;
+};
+
 struct snk_engine {
     int device = 0;
     hipStream_t stream = nullptr, stream2 = nullptr, copy_stream = nullptr;
@@ -132,6 +143,8 @@ struct snk_engine {
     snk_transport transport{};            // caller-provided collectives (functional tests)
     bool have_transport = false;
     DevBuf sh_d2, sh_id, sh_bound, sh_rd2, sh_rid, sh_res, sh_resall;
+    ShardTicket sticket[2];
+    int snext = 0;
     // replicated global sample (snk_upload_global_sample): stage A of a rank's own rows runs against it
     DevBuf gs_unw, gs_w, gs_norm, gs_tiles, gs_fmax2;
     int64_t gs_rows = 0, gs_slabs = 0;
@@ -358,6 +371,13 @@ int snk_destroy(snk_handle h)
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->knn_all_done) (void)hipEventDestroy(h->knn_all_done);
+    for (auto &t : h->sticket) {
+        t.mcand.release(); t.mdist.release(); t.res_path.release(); t.res_plen.release(); t.res_cost.release(); t.status.release();
+        t.stage.release();
+        if (t.done) (void)hipEventDestroy(t.done);
+        if (t.main_done) (void)hipEventDestroy(t.main_done);
+        for (int i = 0; i < 2; ++i) if (t.side_done[i]) (void)hipEventDestroy(t.side_done[i]);
+    }
     for (auto &b : h->bslot) { b.Qall.release(); b.cand.release(); b.dist.release(); b.path.release(); b.plen.release(); b.cost.release(); b.status.release(); b.stage.release(); if (b.done) (void)hipEventDestroy(b.done); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
@@ -954,6 +974,8 @@ static int no_batch_in_flight(snk_engine *h, const char *who)
 {
     if (h && (h->bslot[0].busy || h->bslot[1].busy))
         return fail("%s: a submitted batch is still in flight (snk_knn_viterbi_batch_collect it first)", who);
+    if (h && (h->sticket[0].busy || h->sticket[1].busy))
+        return fail("%s: a submitted sharded step is still in flight (snk_sharded_knn_viterbi_batch_collect it first)", who);
     return 0;
 }
 
@@ -2111,148 +2133,252 @@ int snk_copy_to_device(void *dst_dev, const void *src_host, int64_t bytes)
     return 0;
 }
 
-// One sharded step (see include/snk.h).  safe: the exact float64 sweep with per-shard thresholds and a host
-// check after every stage -- the path every rank takes again, together, when any rank's fast path reported a
-// list overflow (rare; the decision is made from the gathered status words, so all ranks agree).
-static int sharded_step(snk_engine *h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
-                        int64_t *path_out, int64_t *path_len_out, double *cost_out, bool safe, bool *redo)
+// One sharded step (see include/snk.h), in two halves so that two steps can be in flight: submit queues everything
+// up to the recursions of the owned utterances (K-NN of all rows, the two all-reduces, the exchange, merge, the four
+// Viterbi passes on the side streams) and returns; collect waits for those recursions, gathers the results of all
+// ranks and hands them out.  A caller that submits step i + 1 before collecting step i runs the Viterbi side of step i
+// -- as long as a third of the step at G = 8 -- beside the K-NN of step i + 1, as the single-GPU batch pipeline does.
+// safe: the exact float64 sweep with per-shard thresholds -- the path every rank takes again, together, when any
+// rank's fast path reported a list overflow (rare; decided from the gathered status words, so all ranks agree).
+static int sharded_submit(snk_engine *h, ShardTicket &t, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
+                          bool safe)
 {
     const int G = h->comm_ranks, me = h->comm_rank;
     const int64_t R = row_offsets[n_utts];
-    std::vector<int64_t> ulo((size_t)G), uhi((size_t)G), rows_to((size_t)G), row0((size_t)G);
+    t.G = G; t.me = me; t.n_utts = n_utts; t.K = K; t.D = D; t.R = R; t.safe = safe; t.Q = Q;
+    t.offs.assign(row_offsets, row_offsets + n_utts + 1);
+    t.ulo.assign((size_t)G, 0); t.uhi.assign((size_t)G, 0); t.rows_to.assign((size_t)G, 0); t.row0.assign((size_t)G, 0);
     for (int r = 0; r < G; ++r) {
-        shard_plan(n_utts, G, r, &ulo[(size_t)r], &uhi[(size_t)r]);
-        row0[(size_t)r] = row_offsets[ulo[(size_t)r]];
-        rows_to[(size_t)r] = row_offsets[uhi[(size_t)r]] - row0[(size_t)r];
+        shard_plan(n_utts, G, r, &t.ulo[(size_t)r], &t.uhi[(size_t)r]);
+        t.row0[(size_t)r] = row_offsets[t.ulo[(size_t)r]];
+        t.rows_to[(size_t)r] = row_offsets[t.uhi[(size_t)r]] - t.row0[(size_t)r];
     }
-    const int64_t r_own = rows_to[(size_t)me];
-    const int n_own = (int)(uhi[(size_t)me] - ulo[(size_t)me]);
+    const int64_t r_own = t.rows_to[(size_t)me];
+    const int n_own = (int)(t.uhi[(size_t)me] - t.ulo[(size_t)me]);
+    t.r_own = r_own; t.n_own = n_own;
     int64_t slots = 0, Lmax = 0;
-    for (int r = 0; r < G; ++r) slots = std::max(slots, uhi[(size_t)r] - ulo[(size_t)r]);
+    for (int r = 0; r < G; ++r) slots = std::max(slots, t.uhi[(size_t)r] - t.ulo[(size_t)r]);
     for (int u = 0; u < n_utts; ++u) Lmax = std::max(Lmax, row_offsets[u + 1] - row_offsets[u]);
-    const int64_t rec = Lmax + 3;                                  // per slot: path length, cost bits, K-NN status, path
+    t.slots = slots; t.rec = Lmax + 3;                             // per slot: path length, cost bits, K-NN status, path
     CHK(h->sh_d2.ensure((size_t)R * K * sizeof(double)));
     CHK(h->sh_id.ensure((size_t)R * K * sizeof(int64_t)));
     CHK(h->sh_bound.ensure((size_t)R * sizeof(double)));
     CHK(h->sh_rd2.ensure((size_t)G * (r_own > 0 ? r_own : 1) * K * sizeof(double)));
     CHK(h->sh_rid.ensure((size_t)G * (r_own > 0 ? r_own : 1) * K * sizeof(int64_t)));
-    CHK(h->sh_res.ensure((size_t)slots * rec * sizeof(int64_t)));
-    CHK(h->sh_resall.ensure((size_t)G * slots * rec * sizeof(int64_t)));
+    // what the recursions of THIS step read and write (the step submitted next has its own)
+    CHK(t.mcand.ensure((size_t)(r_own > 0 ? r_own : 1) * K * sizeof(int64_t)));
+    CHK(t.mdist.ensure((size_t)(r_own > 0 ? r_own : 1) * K * sizeof(double)));
+    CHK(t.res_path.ensure((size_t)(r_own > 0 ? r_own : 1) * sizeof(int64_t)));
+    CHK(t.res_plen.ensure((size_t)(n_own > 0 ? n_own : 1) * sizeof(int64_t)));
+    CHK(t.res_cost.ensure((size_t)(n_own > 0 ? n_own : 1) * sizeof(double)));
     double *d2 = h->sh_d2.as<double>();
     int64_t *ids = h->sh_id.as<int64_t>();
     int n_status = 0;
     struct PrecisionGuard { snk_engine *e; int v; ~PrecisionGuard() { e->precision = v; } } guard{h, h->precision};
     if (safe) h->precision = 0;
-    int rc = 0;
-    do {
-        if (G > 1 && !safe) {
-            // bounds of the K-th nearest key, one all-reduce (MIN) of R doubles
-            double *bound = h->sh_bound.as<double>();
-            if (h->gs_ready) {
-                // own share of the rows against the replicated global sample; the others' entries stay +max
-                if (D != h->Dt) { rc = fail("query matrix has %d columns, database has %d", D, h->Dt); break; }
-                if ((rc = upload_batch_queries(h, Q, R, D))) break;
-                launch_fill_threshold(bound, R, R, DBL_MAX, h->stream);
-                const int64_t step = h->batch_rows > 0 ? h->batch_rows : r_own;
-                for (int64_t r0 = 0; r0 < r_own; r0 += step) {
-                    const int64_t rows = (r0 + step <= r_own) ? step : r_own - r0;
-                    const int64_t a = row0[(size_t)me] + r0;
-                    if ((rc = knn_device(h, h->Qall.as<double>() + a * D, rows, K, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                         nullptr, bound + a, true))) break;
-                }
-                if (rc) break;
-            } else {
-                if ((rc = knn_local_batch(h, "snk_sharded_knn_viterbi_batch", Q, row_offsets, n_utts, D, K, nullptr, bound,
-                                          nullptr, nullptr, &n_status))) break;
+    if (G > 1 && !safe) {
+        // bounds of the K-th nearest key, one all-reduce (MIN) of R doubles
+        double *bound = h->sh_bound.as<double>();
+        if (h->gs_ready) {
+            // own share of the rows against the replicated global sample; the others' entries stay +max
+            if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
+            CHK(upload_batch_queries(h, Q, R, D));
+            launch_fill_threshold(bound, R, R, DBL_MAX, h->stream);
+            const int64_t step = h->batch_rows > 0 ? h->batch_rows : r_own;
+            for (int64_t r0 = 0; r0 < r_own; r0 += step) {
+                const int64_t rows = (r0 + step <= r_own) ? step : r_own - r0;
+                const int64_t a = t.row0[(size_t)me] + r0;
+                CHK(knn_device(h, h->Qall.as<double>() + a * D, rows, K, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               nullptr, bound + a, true));
             }
-            if ((rc = comm_all_reduce_min(h, bound, R))) break;
-            if ((rc = knn_local_batch(h, "snk_sharded_knn_viterbi_batch", nullptr, row_offsets, n_utts, D, K, bound, nullptr,
-                                      d2, ids, &n_status, true))) break;
         } else {
-            if ((rc = knn_local_batch(h, "snk_sharded_knn_viterbi_batch", Q, row_offsets, n_utts, D, K, nullptr, nullptr,
-                                      d2, ids, safe ? nullptr : &n_status))) break;
+            CHK(knn_local_batch(h, "snk_sharded_knn_viterbi_batch", Q, row_offsets, n_utts, D, K, nullptr, bound,
+                                nullptr, nullptr, &n_status));
         }
-        // exchange: the (R, K) matrices are ordered by destination (contiguous utterance blocks)
-        std::vector<int64_t> soff((size_t)G), sb((size_t)G), roff((size_t)G), rb((size_t)G);
-        for (int p = 0; p < G; ++p) {
-            soff[(size_t)p] = row0[(size_t)p] * K * 8; sb[(size_t)p] = rows_to[(size_t)p] * K * 8;
-            roff[(size_t)p] = (int64_t)p * r_own * K * 8; rb[(size_t)p] = r_own * K * 8;
+        CHK(comm_all_reduce_min(h, bound, R));
+        CHK(knn_local_batch(h, "snk_sharded_knn_viterbi_batch", nullptr, row_offsets, n_utts, D, K, bound, nullptr,
+                            d2, ids, &n_status, true));
+    } else {
+        CHK(knn_local_batch(h, "snk_sharded_knn_viterbi_batch", Q, row_offsets, n_utts, D, K, nullptr, nullptr,
+                            d2, ids, safe ? nullptr : &n_status));
+    }
+    // this rank's K-NN status words: kept per step (the next step's K-NN reuses h->res_status)
+    t.n_status = n_status;
+    if (n_status > 0) {
+        CHK(t.status.ensure((size_t)n_status * sizeof(int)));
+        HIPCHK(hipMemcpyAsync(t.status.p, h->res_status.p, (size_t)n_status * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    }
+    // exchange: the (R, K) matrices are ordered by destination (contiguous utterance blocks)
+    std::vector<int64_t> soff((size_t)G), sb((size_t)G), roff((size_t)G), rb((size_t)G);
+    for (int p = 0; p < G; ++p) {
+        soff[(size_t)p] = t.row0[(size_t)p] * K * 8; sb[(size_t)p] = t.rows_to[(size_t)p] * K * 8;
+        roff[(size_t)p] = (int64_t)p * r_own * K * 8; rb[(size_t)p] = r_own * K * 8;
+    }
+    const double *d2_all = d2;
+    const int64_t *id_all = ids;
+    if (G > 1) {
+        CHK(comm_all_to_all_v(h, d2, soff.data(), sb.data(), h->sh_rd2.p, roff.data(), rb.data()));
+        CHK(comm_all_to_all_v(h, ids, soff.data(), sb.data(), h->sh_rid.p, roff.data(), rb.data()));
+        d2_all = h->sh_rd2.as<double>(); id_all = h->sh_rid.as<int64_t>();
+    }
+    // owner: merge, join bounds / costs, Viterbi of the owned utterances -- queued, not waited for
+    t.own_off.assign((size_t)n_own + 1, 0);
+    for (int u = 0; u <= n_own; ++u) t.own_off[(size_t)u] = row_offsets[t.ulo[(size_t)me] + u] - t.row0[(size_t)me];
+    if (n_own > 0) {
+        if ((int64_t)G * K > 8192) return fail("snk_sharded_knn_viterbi_batch: G*K=%d exceeds 8192", G * K);
+        {
+            StageTimer tm(h, h->stream, TM_MERGE);
+            launch_merge_topk(d2_all, id_all, G, r_own, K, t.mcand.as<int64_t>(), t.mdist.as<double>(), h->stream);
         }
-        const double *d2_all = d2;
-        const int64_t *id_all = ids;
-        if (G > 1) {
-            if ((rc = comm_all_to_all_v(h, d2, soff.data(), sb.data(), h->sh_rd2.p, roff.data(), rb.data()))) break;
-            if ((rc = comm_all_to_all_v(h, ids, soff.data(), sb.data(), h->sh_rid.p, roff.data(), rb.data()))) break;
-            d2_all = h->sh_rd2.as<double>(); id_all = h->sh_rid.as<int64_t>();
-        }
-        // owner: merge, join costs, Viterbi of the owned utterances
-        std::vector<int64_t> own_off((size_t)n_own + 1, 0);
-        for (int u = 0; u <= n_own; ++u) own_off[(size_t)u] = row_offsets[ulo[(size_t)me] + u] - row0[(size_t)me];
-        std::vector<int64_t> own_path((size_t)(r_own > 0 ? r_own : 1)), own_len((size_t)(n_own > 0 ? n_own : 1));
-        std::vector<double> own_cost((size_t)(n_own > 0 ? n_own : 1));
+        const std::vector<int> first = group_utterances(h, t.own_off.data(), n_own);
+        for (int g = 0; g + 1 < (int)first.size(); ++g)
+            CHK(viterbi_group(h, g, t.own_off.data(), first[g], first[g + 1], K, t.mcand.as<int64_t>(), t.mdist.as<double>(), true,
+                              t.res_path.as<int64_t>(), t.res_plen.as<int64_t>(), t.res_cost.as<double>(), n_own));
+    }
+    for (int i = 0; i < 2; ++i) HIPCHK(hipEventRecord(t.side_done[i], h->dp_stream[i]));
+    HIPCHK(hipEventRecord(t.main_done, h->stream));
+    // own results and status words -> pinned memory, on the copy stream behind this step's recursions (no host wait, no
+    // default-stream copy: a step submitted next keeps running)
+    {
+        const size_t sz_path = ((size_t)(r_own > 0 ? r_own : 1) * 8 + 63) & ~(size_t)63, sz_u = ((size_t)(n_own > 0 ? n_own : 1) * 8 + 63) & ~(size_t)63;
+        const size_t sz_st = ((size_t)(n_status > 0 ? n_status : 1) * sizeof(int) + 63) & ~(size_t)63;
+        CHK(t.stage.ensure(sz_path + 2 * sz_u + sz_st));
+        HIPCHK(hipStreamWaitEvent(h->copy_stream, t.main_done, 0));
+        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(h->copy_stream, t.side_done[i], 0));
+        char *st = (char *)t.stage.p;
         if (n_own > 0) {
-            if ((rc = snk_merge_viterbi_batch_dev(h, d2_all, id_all, G, own_off.data(), n_own, K, own_path.data(), own_len.data(),
-                                                  own_cost.data()))) break;
-        } else {
-            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipMemcpyAsync(st, t.res_path.p, (size_t)r_own * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
+            HIPCHK(hipMemcpyAsync(st + sz_path, t.res_plen.p, (size_t)n_own * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
+            HIPCHK(hipMemcpyAsync(st + sz_path + sz_u, t.res_cost.p, (size_t)n_own * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
         }
-        // this rank's K-NN status words (deferred until here: the first host contact of the step)
-        int status = 0;
-        if (n_status > 0) {
-            std::vector<int> st((size_t)n_status);
-            HIPCHK(hipMemcpy(st.data(), h->res_status.p, (size_t)n_status * sizeof(int), hipMemcpyDeviceToHost));
-            for (int v : st) status |= v;
+        if (n_status > 0)
+            HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u, t.status.p, (size_t)n_status * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(hipEventRecord(t.done, h->copy_stream));
+    }
+    HIPCHK(hipGetLastError());
+    t.busy = true;
+    return 0;
+}
+
+static int sharded_collect(snk_engine *h, ShardTicket &t, int64_t *path_out, int64_t *path_len_out, double *cost_out, bool *any_bad_out)
+{
+    const int G = t.G, me = t.me, n_own = t.n_own;
+    const int64_t r_own = t.r_own, slots = t.slots, rec = t.rec;
+    // the recursions of this step (side streams) and everything of it on the main stream; a step submitted after it
+    // may still be running
+    HIPCHK(hipEventSynchronize(t.done));
+    HIPCHK(hipGetLastError());
+    t.busy = false;
+    const size_t sz_path = ((size_t)(r_own > 0 ? r_own : 1) * 8 + 63) & ~(size_t)63, sz_u = ((size_t)(n_own > 0 ? n_own : 1) * 8 + 63) & ~(size_t)63;
+    const char *stg = (const char *)t.stage.p;
+    const int64_t *own_path = reinterpret_cast<const int64_t *>(stg);
+    const int64_t *own_len = reinterpret_cast<const int64_t *>(stg + sz_path);
+    const double *own_cost = reinterpret_cast<const double *>(stg + sz_path + sz_u);
+    int status = 0;
+    {
+        const int *st = reinterpret_cast<const int *>(stg + sz_path + 2 * sz_u);
+        for (int i = 0; i < t.n_status; ++i) status |= st[i];
+    }
+    // results of every utterance to every rank: fixed-size records, one all-gather (queued on the main stream: behind
+    // the K-NN and the exchange of a step submitted in the meantime)
+    CHK(h->sh_res.ensure((size_t)slots * rec * sizeof(int64_t)));
+    CHK(h->sh_resall.ensure((size_t)G * slots * rec * sizeof(int64_t)));
+    std::vector<int64_t> mine((size_t)(slots * rec), 0);
+    for (int j = 0; j < n_own; ++j) {
+        int64_t *r = mine.data() + (size_t)j * rec;
+        r[0] = own_len[j];
+        memcpy(&r[1], &own_cost[j], sizeof(double));
+        r[2] = status;
+        memcpy(&r[3], own_path + t.own_off[(size_t)j], (size_t)own_len[j] * sizeof(int64_t));
+    }
+    if (n_own == 0 && slots > 0) mine[2] = status;
+    HIPCHK(hipMemcpyAsync(h->sh_res.p, mine.data(), mine.size() * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    CHK(comm_all_gather(h, h->sh_res.p, h->sh_resall.p, (int64_t)(mine.size() * sizeof(int64_t))));
+    std::vector<int64_t> all((size_t)G * mine.size());
+    HIPCHK(hipMemcpyAsync(all.data(), h->sh_resall.p, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    bool any_bad = false;
+    for (int r = 0; r < G; ++r) {
+        const int64_t *blk = all.data() + (size_t)r * mine.size();
+        if (slots > 0 && blk[2] != 0) any_bad = true;
+        for (int64_t j = 0; j < t.uhi[(size_t)r] - t.ulo[(size_t)r]; ++j) {
+            const int64_t *q = blk + (size_t)j * rec;
+            const int64_t u = t.ulo[(size_t)r] + j;
+            if (q[2] != 0) any_bad = true;
+            path_len_out[u] = q[0];
+            memcpy(&cost_out[u], &q[1], sizeof(double));
+            memcpy(path_out + t.offs[(size_t)u], &q[3], (size_t)q[0] * sizeof(int64_t));
         }
-        // results of every utterance to every rank: fixed-size records, one all-gather
-        std::vector<int64_t> mine((size_t)(slots * rec), 0);
-        for (int j = 0; j < n_own; ++j) {
-            int64_t *r = mine.data() + (size_t)j * rec;
-            r[0] = own_len[(size_t)j];
-            memcpy(&r[1], &own_cost[(size_t)j], sizeof(double));
-            r[2] = status;
-            memcpy(&r[3], own_path.data() + own_off[(size_t)j], (size_t)own_len[(size_t)j] * sizeof(int64_t));
-        }
-        if (n_own == 0 && slots > 0) mine[2] = status;
-        HIPCHK(hipMemcpyAsync(h->sh_res.p, mine.data(), mine.size() * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-        if ((rc = comm_all_gather(h, h->sh_res.p, h->sh_resall.p, (int64_t)(mine.size() * sizeof(int64_t))))) break;
-        std::vector<int64_t> all((size_t)G * mine.size());
-        HIPCHK(hipMemcpyAsync(all.data(), h->sh_resall.p, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        bool any_bad = false;
-        for (int r = 0; r < G; ++r) {
-            const int64_t *blk = all.data() + (size_t)r * mine.size();
-            if (slots > 0 && blk[2] != 0) any_bad = true;
-            for (int64_t j = 0; j < uhi[(size_t)r] - ulo[(size_t)r]; ++j) {
-                const int64_t *q = blk + (size_t)j * rec;
-                const int64_t u = ulo[(size_t)r] + j;
-                if (q[2] != 0) any_bad = true;
-                path_len_out[u] = q[0];
-                memcpy(&cost_out[u], &q[1], sizeof(double));
-                memcpy(path_out + row_offsets[u], &q[3], (size_t)q[0] * sizeof(int64_t));
-            }
-        }
-        if (redo) *redo = any_bad && !safe;
-    } while (0);
+    }
+    if (any_bad_out) *any_bad_out = any_bad && !t.safe;
+    (void)me;
     collect_timers(h);
-    return rc;
+    return 0;
+}
+
+static int sharded_check(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts)
+{
+    CHK(check_ready(h, true, true));
+    HIPCHK(hipSetDevice(h->device));
+    if (h->comm_ranks < 1) return fail("snk_sharded_knn_viterbi_batch: no communicator (snk_comm_init)");
+    if (!Q || !row_offsets || n_utts < 1) return fail("snk_sharded_knn_viterbi_batch: null/empty argument");
+    return 0;
+}
+
+int snk_sharded_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
+                                         int *ticket_out)
+{
+    CHK(sharded_check(h, Q, row_offsets, n_utts));
+    if (h->bslot[0].busy || h->bslot[1].busy)
+        return fail("snk_sharded_knn_viterbi_batch_submit: a submitted batch is still in flight (snk_knn_viterbi_batch_collect it first)");
+    if (!ticket_out) return fail("snk_sharded_knn_viterbi_batch_submit: null ticket");
+    const int slot = h->sticket[h->snext].busy ? (h->snext ^ 1) : h->snext;
+    ShardTicket &t = h->sticket[slot];
+    if (t.busy) return fail("snk_sharded_knn_viterbi_batch_submit: two steps are in flight already (collect one first)");
+    if (!t.main_done) {
+        HIPCHK(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&t.main_done, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&t.side_done[i], hipEventDisableTiming));
+    }
+    CHK(sharded_submit(h, t, Q, row_offsets, n_utts, D, K, false));
+    h->snext = slot ^ 1;
+    *ticket_out = slot;
+    return 0;
+}
+
+int snk_sharded_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, int64_t *path_len_out, double *cost_out)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (ticket < 0 || ticket > 1 || !h->sticket[ticket].busy)
+        return fail("snk_sharded_knn_viterbi_batch_collect: no step behind ticket %d", ticket);
+    if (!path_out || !path_len_out || !cost_out) return fail("snk_sharded_knn_viterbi_batch_collect: null output");
+    ShardTicket &t = h->sticket[ticket];
+    bool redo = false;
+    CHK(sharded_collect(h, t, path_out, path_len_out, cost_out, &redo));
+    if (redo) {
+        // every rank saw the same status words: all of them redo this step in the exact mode, now -- behind whatever
+        // a step submitted in the meantime has queued (its recursions must be through with the shared workspaces first)
+        h->batch_redos += 1;
+        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamSynchronize(h->dp_stream[i]));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        ShardTicket &o = h->sticket[ticket ^ 1];
+        if (o.busy) return fail("snk_sharded_knn_viterbi_batch_collect: a prefilter result of step %d was unsafe while another step is in "
+                                "flight; collect steps one at a time to have it redone exactly", ticket);
+        const std::vector<int64_t> offs = t.offs;
+        CHK(sharded_submit(h, t, t.Q, offs.data(), t.n_utts, t.D, t.K, true));
+        CHK(sharded_collect(h, t, path_out, path_len_out, cost_out, nullptr));
+    }
+    return 0;
 }
 
 int snk_sharded_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
                                   int64_t *path_out, int64_t *path_len_out, double *cost_out)
 {
-    CHK(check_ready(h, true, true));
-    CHK(no_batch_in_flight(h, "snk_sharded_knn_viterbi_batch"));
-    HIPCHK(hipSetDevice(h->device));
-    if (h->comm_ranks < 1) return fail("snk_sharded_knn_viterbi_batch: no communicator (snk_comm_init)");
-    if (!Q || !row_offsets || n_utts < 1 || !path_out || !path_len_out || !cost_out)
-        return fail("snk_sharded_knn_viterbi_batch: null/empty argument");
-    bool redo = false;
-    CHK(sharded_step(h, Q, row_offsets, n_utts, D, K, path_out, path_len_out, cost_out, false, &redo));
-    if (redo) {
-        h->batch_redos += 1;
-        CHK(sharded_step(h, Q, row_offsets, n_utts, D, K, path_out, path_len_out, cost_out, true, nullptr));
-    }
-    return 0;
+    if (!path_out || !path_len_out || !cost_out) return fail("snk_sharded_knn_viterbi_batch: null/empty argument");
+    int ticket = -1;
+    CHK(snk_sharded_knn_viterbi_batch_submit(h, Q, row_offsets, n_utts, D, K, &ticket));
+    return snk_sharded_knn_viterbi_batch_collect(h, ticket, path_out, path_len_out, cost_out);
 }
 
 // ---------------------------------------------------------------------------

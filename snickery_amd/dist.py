@@ -258,6 +258,13 @@ class LibraryShardedSearch(object):
     def knn_viterbi_batch(self, utterances, K):
         return self.engine.sharded_knn_viterbi_batch(utterances, K)
 
+    def submit(self, utterances, K):
+        """Queue a step (at most two in flight, the same sequence on every rank); see collect."""
+        return self.engine.sharded_knn_viterbi_batch_submit(utterances, K)
+
+    def collect(self, ticket):
+        return self.engine.sharded_knn_viterbi_batch_collect(ticket)
+
 
 def global_sample(F_unw, stride=16):
     """Every stride-th unit of the whole database: what every rank uploads with upload_global_sample."""

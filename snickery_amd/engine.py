@@ -94,6 +94,9 @@ _SIGNATURES = {
     'snk_upload_global_sample': (ctypes.c_int, [ctypes.c_void_p, _c_f32p, ctypes.c_int64, ctypes.c_int]),
     'snk_sharded_knn_viterbi_batch': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int, ctypes.c_int,
                                                      ctypes.c_int, _c_i64p, _c_i64p, _c_f64p]),
+    'snk_sharded_knn_viterbi_batch_submit': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int, ctypes.c_int,
+                                                            ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    'snk_sharded_knn_viterbi_batch_collect': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_i64p, _c_i64p, _c_f64p]),
     'snk_copy_to_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     'snk_copy_to_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     'snk_set_option': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]),
@@ -535,6 +538,26 @@ class HipSearchEngine(object):
                                                             b.Q.shape[1], int(n_candidates), _ptr(path, _c_i64p),
                                                             _ptr(plen, _c_i64p), _ptr(cost, _c_f64p)))
         return [path[int(b.offsets[u]):int(b.offsets[u]) + int(plen[u])].copy() for u in range(n)], cost
+
+    def sharded_knn_viterbi_batch_submit(self, utterances, n_candidates):
+        """Queue a sharded step and return a ticket (at most two in flight; every rank issues the same sequence of
+        submits and collects).  Submitting step i + 1 before collecting step i runs step i's Viterbi side beside
+        step i + 1's K-NN."""
+        b = _as_batch(utterances)
+        ticket = ctypes.c_int(-1)
+        self._check(self._lib.snk_sharded_knn_viterbi_batch_submit(self._h, _ptr(b.Q, _c_f64p), _ptr(b.offsets, _c_i64p), len(b),
+                                                                   b.Q.shape[1], int(n_candidates), ctypes.byref(ticket)))
+        return (ticket.value, b)              # the batch (host rows) stays referenced until collected
+
+    def sharded_knn_viterbi_batch_collect(self, ticket):
+        tid, b = ticket
+        offs, n = b.offsets, len(b)
+        path = np.empty((max(int(offs[-1]), 1),), dtype=np.int64)
+        plen = np.zeros(n, dtype=np.int64)
+        cost = np.zeros(n, dtype=np.float64)
+        self._check(self._lib.snk_sharded_knn_viterbi_batch_collect(self._h, int(tid), _ptr(path, _c_i64p), _ptr(plen, _c_i64p),
+                                                                    _ptr(cost, _c_f64p)))
+        return [path[int(offs[u]):int(offs[u]) + int(plen[u])].copy() for u in range(n)], cost
 
     def upload_frames(self, spec, fzv):
         """spec (rows, 3*H) float32 = [mag | real | imag], fzv (rows, 2) float64 = [f0_interp, vuv]."""

@@ -102,6 +102,30 @@ def _lib_worker(rank, world, port, out, use_sample):
     tpaths, tcosts = ShardedSearch(HipShardEngine(eng, torch.device('cuda', 0))).knn_viterbi_batch(utts, K)
     lpaths, lcosts = LibraryShardedSearch(eng, transport='gloo').knn_viterbi_batch(utts, K)
     ok = ok and all(np.array_equal(a, b) for a, b in zip(tpaths, lpaths)) and np.array_equal(tcosts, lcosts)
+    # two steps in flight: step i + 1 is submitted before step i is collected (its Viterbi side then runs beside the
+    # K-NN of step i + 1); different batches in flight, every rank issues the same sequence
+    lib2 = LibraryShardedSearch(eng, transport='gloo')
+    batches = [utts, utts[2:], utts[:3], utts]
+    want = [lib2.knn_viterbi_batch(b, K) for b in batches]
+    got, pending = [], None
+    for b in batches:
+        tk = lib2.submit(b, K)
+        if pending is not None:
+            got.append(lib2.collect(pending))
+        pending = tk
+    got.append(lib2.collect(pending))
+    for (gp, gc), (wp, wc) in zip(got, want):
+        ok = ok and all(np.array_equal(a, b) for a, b in zip(gp, wp)) and np.array_equal(gc, wc)
+    try:                                                  # a third step while two are in flight is refused
+        t1, t2 = lib2.submit(utts, K), lib2.submit(utts, K)
+        try:
+            lib2.submit(utts, K)
+            ok = False
+        except snickery_amd.SnkError:
+            pass
+        lib2.collect(t1); lib2.collect(t2)
+    except snickery_amd.SnkError:
+        ok = False
     # a list overflow on the fast path of ONE rank makes ALL ranks redo the step together (exact sweep)
     if rank == 0:
         eng.set_option('list_capacity', 64)
