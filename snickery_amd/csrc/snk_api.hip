@@ -1852,8 +1852,10 @@ static int knn_local_batch(snk_engine *h, const char *who, const double *Q, cons
     const int64_t total = row_offsets[n_utts];
     for (int u = 0; u < n_utts; ++u)
         if (row_offsets[u + 1] - row_offsets[u] < 1) return fail("%s: utterance %d has no rows", who, u);
-    // the search is per row: fixed-size row groups, whatever the utterance boundaries
-    const int64_t step = h->batch_rows > 0 ? h->batch_rows : total;
+    // the search is per row: fixed-size row groups, whatever the utterance boundaries.  Filtering against a shared
+    // bound (a shard of a row-sharded database: many rows, few units) takes the largest calls there are: every launch
+    // sweeps the shard once, and on 131 072 units a wavefront gets two work items per launch
+    const int64_t step = bound_in ? SNK_KNN_MAX_ROWS : h->batch_rows > 0 ? h->batch_rows : total;
     const int n_groups = (int)((total + step - 1) / step);
     if (Q) {
         CHK(upload_batch_queries(h, Q, total, D));
