@@ -242,7 +242,8 @@ typedef struct snk_transport {
     void *ctx;
     int (*all_reduce_min_f64)(void *ctx, double *buf_dev, int64_t n, void *stream);
     int (*all_gather)(void *ctx, const void *send_dev, void *recv_dev, int64_t bytes_per_rank, void *stream);
-    /* rank p's block: send_bytes[p] from send_dev + send_off[p]; recv_bytes[p] to recv_dev + recv_off[p] */
+    /* rank p's block: send_bytes[p] from send_dev + send_off[p]; recv_bytes[p] to recv_dev + recv_off[p].  Nothing but the
+     * received blocks may be written: send_dev and recv_dev can be the same buffer with disjoint blocks (query rows). */
     int (*all_to_all_v)(void *ctx, const void *send_dev, const int64_t *send_off, const int64_t *send_bytes,
                         void *recv_dev, const int64_t *recv_off, const int64_t *recv_bytes, void *stream);
 } snk_transport;

@@ -171,6 +171,7 @@ struct snk_engine {
     bool bf16_ready = false;      // a16l / s16l (and gs_tiles_b) hold the bf16-split operands of the current weights
     double eps_c_bf = 4e-6;       // accumulation part of the bound of the bf16-split keys (knn16_kernels.hip: c_acc)
     DevBuf kth16;                 // sharded search: per-row second bound (K-th key of the local list, all-reduced)
+    int shard_gather_queries = 1; // sharded steps: 1: every rank uploads the rows of its own utterances and the ranks exchange them, 0: every rank uploads all rows
     int shard_refine = 1;         // 1: snk_sharded_knn_viterbi_batch prunes the shards' lists to that bound before the re-rank
     DevBuf gs_tiles_b, cq16, rho16, gs_rho16;   // per-row split coefficient; dropped-piece ratios of the operands
     int f16_fallbacks = 0;
@@ -2142,6 +2143,30 @@ int snk_copy_to_device(void *dst_dev, const void *src_host, int64_t bytes)
 // -- as long as a third of the step at G = 8 -- beside the K-NN of step i + 1, as the single-GPU batch pipeline does.
 // safe: the exact float64 sweep with per-shard thresholds -- the path every rank takes again, together, when any
 // rank's fast path reported a list overflow (rare; decided from the gathered status words, so all ranks agree).
+// Query rows of a sharded step: every rank needs all of them, and every rank was handed all of them.  Each rank
+// uploads only the rows of the utterances it owns and the ranks pass them on over xGMI (seven links in parallel
+// against one PCIe upload of G times the bytes: 75 MB per rank and step at G = 8, B*).
+static int upload_queries_gathered(snk_engine *h, const ShardTicket &t, const double *Q)
+{
+    const int G = t.G, me = t.me, D = t.D;
+    CHK(h->Qall.ensure((size_t)t.R * D * sizeof(double)));
+    {
+        StageTimer tm(h, h->stream, TM_H2D);
+        const int64_t a = t.row0[(size_t)me];
+        if (t.r_own > 0)
+            HIPCHK(hipMemcpyAsync(h->Qall.as<double>() + a * D, Q + a * D, (size_t)t.r_own * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    std::vector<int64_t> soff((size_t)G), sb((size_t)G), roff((size_t)G), rb((size_t)G);
+    for (int p = 0; p < G; ++p) {
+        soff[(size_t)p] = t.row0[(size_t)me] * D * 8; sb[(size_t)p] = p == me ? 0 : t.r_own * D * 8;
+        roff[(size_t)p] = t.row0[(size_t)p] * D * 8;  rb[(size_t)p] = p == me ? 0 : t.rows_to[(size_t)p] * D * 8;
+    }
+    CHK(comm_all_to_all_v(h, h->Qall.p, soff.data(), sb.data(), h->Qall.p, roff.data(), rb.data()));
+    if (!h->tsel.empty()) launch_mask_columns(h->Qall.as<double>(), t.R, D, h->tmask.as<double>(), h->stream);
+    h->qall_rows = t.R;
+    return 0;
+}
+
 static int sharded_submit(snk_engine *h, ShardTicket &t, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
                           bool safe)
 {
@@ -2178,13 +2203,18 @@ static int sharded_submit(snk_engine *h, ShardTicket &t, const double *Q, const 
     int n_status = 0;
     struct PrecisionGuard { snk_engine *e; int v; ~PrecisionGuard() { e->precision = v; } } guard{h, h->precision};
     if (safe) h->precision = 0;
+    if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
+    const double *Qk = Q;                       // what the K-NN calls are handed: nullptr = the rows are resident already
+    if (G > 1 && h->shard_gather_queries) {
+        CHK(upload_queries_gathered(h, t, Q));
+        Qk = nullptr;
+    }
     if (G > 1 && !safe) {
         // bounds of the K-th nearest key, one all-reduce (MIN) of R doubles
         double *bound = h->sh_bound.as<double>();
         if (h->gs_ready) {
             // own share of the rows against the replicated global sample; the others' entries stay +max
-            if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
-            CHK(upload_batch_queries(h, Q, R, D));
+            if (Qk) CHK(upload_batch_queries(h, Q, R, D));
             launch_fill_threshold(bound, R, R, DBL_MAX, h->stream);
             const int64_t step = h->batch_rows > 0 ? h->batch_rows : r_own;
             for (int64_t r0 = 0; r0 < r_own; r0 += step) {
@@ -2194,14 +2224,14 @@ static int sharded_submit(snk_engine *h, ShardTicket &t, const double *Q, const 
                                nullptr, bound + a, true));
             }
         } else {
-            CHK(knn_local_batch(h, "snk_sharded_knn_viterbi_batch", Q, row_offsets, n_utts, D, K, nullptr, bound,
+            CHK(knn_local_batch(h, "snk_sharded_knn_viterbi_batch", Qk, row_offsets, n_utts, D, K, nullptr, bound,
                                 nullptr, nullptr, &n_status));
         }
         CHK(comm_all_reduce_min(h, bound, R));
         CHK(knn_local_batch(h, "snk_sharded_knn_viterbi_batch", nullptr, row_offsets, n_utts, D, K, bound, nullptr,
                             d2, ids, &n_status, true));
     } else {
-        CHK(knn_local_batch(h, "snk_sharded_knn_viterbi_batch", Q, row_offsets, n_utts, D, K, nullptr, nullptr,
+        CHK(knn_local_batch(h, "snk_sharded_knn_viterbi_batch", Qk, row_offsets, n_utts, D, K, nullptr, nullptr,
                             d2, ids, safe ? nullptr : &n_status));
     }
     // this rank's K-NN status words: kept per step (the next step's K-NN reuses h->res_status)
@@ -2506,6 +2536,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0 && value != 2.0) return fail("viterbi_mode must be 0 (dense exact join + recursion), 1 (lower bounds + sparse exact recursion) or 2 (auto)");
         CHK(no_batch_in_flight(h, "snk_set_option(viterbi_mode)"));
         h->viterbi_mode = (int)value;
+    } else if (!strcmp(name, "shard_gather_queries")) {
+        if (value != 0.0 && value != 1.0) return fail("shard_gather_queries must be 0 or 1 (the same on every rank)");
+        h->shard_gather_queries = (int)value;
     } else if (!strcmp(name, "shard_refine")) {
         if (value != 0.0 && value != 1.0) return fail("shard_refine must be 0 or 1 (the same on every rank)");
         h->shard_refine = (int)value;

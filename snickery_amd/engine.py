@@ -678,7 +678,12 @@ class TransportCallbacks(object):
             send_total = max(o + b for o, b in zip(so, sb))
             recv_total = max(o + b for o, b in zip(ro, rb))
             out = all_to_all_v(to_host(send, send_total), so, sb, ro, rb, recv_total)
-            to_dev(recv, out)
+            # only the received blocks are written: send and receive buffer may be the same array with the blocks
+            # between them untouched (the query rows of a sharded step)
+            base = recv if isinstance(recv, int) else ctypes.cast(recv, ctypes.c_void_p).value
+            for p in range(G):
+                if rb[p]:
+                    to_dev(ctypes.c_void_p(base + ro[p]), out[ro[p]:ro[p] + rb[p]])
 
         self._keep = (self._AR(guard(ar)), self._AG(guard(ag)), self._AA(guard(aa)))
         self.struct = _TransportStruct(None, ctypes.cast(self._keep[0], ctypes.c_void_p),

@@ -32,6 +32,7 @@ eng.upload_join_only(JC_unw)
 eng.set_shard(lo, N)
 eng.upload_global_sample(global_sample(F_unw, 16))
 eng.set_weights(wt, wj)
+eng.set_option('shard_gather_queries', 0)     # the stand-in transport has no other ranks to send their rows: upload all of them
 
 state = {'bounds': None, 'capture': None}
 
