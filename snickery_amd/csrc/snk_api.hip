@@ -278,6 +278,10 @@ static int no_batch_in_flight(snk_engine *h, const char *who);
 static int create_streams(snk_engine *h);
 static bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts);
 static int roundup(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); }
+// error of ONE v_mfma_f32_32x32x16_bf16, as a fraction of the sum of its |products| and |C|, that the bf16-split bound
+// assumes: 2^-20.  Probed (snk_probe_mfma_bf16, tests/test_gpu_prefilter.py): the unit aligns the sixteen products to
+// the largest exponent and cuts them two bits below its float32 unit -- up to 0.55 x 2^-20 on patterns built for it.
+#define SNK_BF16_MFMA_UNIT 9.5367431640625e-07
 #define SNK_KNN_MAX_ROWS 32768      // rows of one K-NN call (batch_rows is capped to it)
 
 // ---------------------------------------------------------------------------
@@ -562,9 +566,10 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
             h->bf16_ready = false;
             if (h->prefilter >= 1 && knn_sweep16b_supported(nt, dch16, h->Dt, h->Dpad, false)) {
                 // key bound = cq ||f|| (what the split drops: measured, prepare_queries16b_kernel) + c_acc (...):
-                // 2^-22 per MFMA over `terms` MFMAs per 16 columns and the norm pieces' 2^-24 (knn16_kernels.hip)
+                // 2^-20 per MFMA over the 4 `terms` MFMAs of a chunk's chain and the norm pieces' 2^-24 (knn16_kernels.hip)
                 const int terms = h->prefilter == 2 ? 4 : 3;
-                h->eps_c_bf = 1.02 * (2.4e-7 * (double)(terms * h->Dpad / 16 + 1) + 6e-8);
+                // (chains of one 64-column chunk: 4 `terms` MFMAs; the chunks' sums are added in float32)
+                h->eps_c_bf = 1.02 * (SNK_BF16_MFMA_UNIT * (double)(terms * 4 + 1) + 6e-8 * (double)(2 * (h->Dpad / 64) + 1));
                 CHK(h->rho16.ensure(2 * sizeof(double)));
                 launch_db16b_ratios(h->Fw.as<double>(), h->N, h->Dt, h->Dpad, h->rho16.as<double>(), h->stream);
                 CHK(h->a16l.ensure(tiles_b * per_tile));
@@ -2604,6 +2609,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
         }
         *out = sqrt(rho[name[14] == 'l' ? 0 : 1]);
     }
+    else if (!strcmp(name, "prefilter_mfma_unit")) *out = SNK_BF16_MFMA_UNIT;
     else if (!strcmp(name, "prefilter_eps_c")) *out = (h->bf16_ready && h->prefilter >= 1) ? h->eps_c_bf : h->eps_c;
     else if (!strcmp(name, "batch_rows")) *out = h->batch_rows;
     else if (!strcmp(name, "last_list_mean") || !strcmp(name, "last_list_max")) {
@@ -2644,6 +2650,26 @@ static int selftest_mfma16(snk_engine *h, double *err_out)
     for (int i = 0; i < 1024; ++i) err = fmax(err, fabs((double)C[i] - (double)R[i]));
     dA.release(); dB.release(); dC.release();
     *err_out = err;
+    return 0;
+}
+
+// One v_mfma_f32_32x32x16_bf16 on the caller's bit patterns (include/snk.h): the probe behind the accumulation term of
+// the bf16-split prefilter's bound.
+int snk_probe_mfma_bf16(snk_handle h, const uint16_t *A, const uint16_t *B, const float *C, float *D_out)
+{
+    if (!h) return fail("null handle");
+    if (!A || !B || !C || !D_out) return fail("snk_probe_mfma_bf16: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    DevBuf dA, dB, dC, dD;
+    CHK(dA.ensure(512 * 2)); CHK(dB.ensure(512 * 2)); CHK(dC.ensure(1024 * 4)); CHK(dD.ensure(1024 * 4));
+    HIPCHK(hipMemcpy(dA.p, A, 512 * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dB.p, B, 512 * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dC.p, C, 1024 * 4, hipMemcpyHostToDevice));
+    launch_mfma_bf16_probe(dA.as<unsigned short>(), dB.as<unsigned short>(), dC.as<float>(), dD.as<float>(), h->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(D_out, dD.p, 1024 * 4, hipMemcpyDeviceToHost));
+    dA.release(); dB.release(); dC.release(); dD.release();
     return 0;
 }
 

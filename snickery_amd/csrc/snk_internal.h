@@ -95,6 +95,7 @@ void launch_db16b_ratios(const double *Fw, int64_t N, int Dt, int Dpad, double *
 bool launch_knn_sweep16b(int mode, int terms, int nt, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32,
                          int64_t T32, int64_t n_slabs, unsigned int *ctr, float *gmin32, int64_t G, void *pool,
                          unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s);
+void launch_mfma_bf16_probe(const unsigned short *A, const unsigned short *B, const float *C, float *D, hipStream_t s);
 void launch_mfma16_selftest(const float *A, const float *B, float *C, hipStream_t s);
 int knn_pool_chunk_entries();
 void sweep_tail_split(int64_t n_slabs, int qsplit, int64_t waves, int nQT, int64_t *n_main, int *qtail);

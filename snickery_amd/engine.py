@@ -101,6 +101,8 @@ _SIGNATURES = {
     'snk_copy_to_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     'snk_set_option': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]),
     'snk_get_info': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, _c_f64p]),
+    'snk_probe_mfma_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint16),
+                                           _c_f32p, _c_f32p]),
     'snk_selftest_mfma': (ctypes.c_int, [ctypes.c_void_p, _c_f64p]),
 }
 
@@ -600,6 +602,17 @@ class HipSearchEngine(object):
         v = ctypes.c_double(0.0)
         self._check(self._lib.snk_get_info(self._h, name.encode(), ctypes.byref(v)))
         return float(v.value)
+
+    def probe_mfma_bf16(self, A_bits, B_bits, C):
+        """One v_mfma_f32_32x32x16_bf16 (snk_probe_mfma_bf16): A (32, 16) / B (16, 32) uint16 bf16 bit patterns,
+        C (32, 32) float32 -> D (32, 32) float32."""
+        A = np.ascontiguousarray(A_bits, dtype=np.uint16).reshape(32, 16)
+        B = np.ascontiguousarray(B_bits, dtype=np.uint16).reshape(16, 32)
+        Cm = np.ascontiguousarray(C, dtype=np.float32).reshape(32, 32)
+        D = np.empty((32, 32), dtype=np.float32)
+        self._check(self._lib.snk_probe_mfma_bf16(self._h, A.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
+                                                  B.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), _ptr(Cm, _c_f32p), _ptr(D, _c_f32p)))
+        return D
 
     def selftest_mfma(self):
         v = ctypes.c_double(0.0)
