@@ -492,7 +492,7 @@ bool launch_knn_sweep16(int mode, int nt, int dch, int k_steps, int grid_cus, co
 //         = 0.6 2^-20 of the largest term by that model, 0.55 2^-20 observed on patterns built for it; a first version
 //         of this bound assumed 2^-22 and the probe refuted it -- and the 24 bits of the three norm pieces.
 // tests/test_gpu_prefilter.py measures the real deviation against float64 keys: it must stay below half of that
-// (measured: 4-6 % of it -- rounding errors do not line up).
+// (measured: 7-12 % of it -- rounding errors do not line up).
 // The k index inside a k-block follows the instruction's operand map: lane l (r = l & 31, h = l >> 5) holds columns
 // 16 kb + 8 h + j, j = 0..7, of row r.  Operand buffers: [tile][kb][piece][lane] x 16 bytes -- 8 KB per tile and
 // 64 columns, the float32 operand's size.
