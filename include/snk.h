@@ -109,6 +109,12 @@ int snk_join_costs(snk_handle h, const int64_t *cand, int64_t T, int K, double *
 int snk_viterbi(snk_handle h, const int64_t *cand, const double *tdist, int64_t T, int K,
                 int64_t *path_out, int64_t *path_len_out, double *cost_out);
 
+/* snk_viterbi for a batch of utterances whose candidates the caller already has (label-driven preselection:
+ * preselect_units_quinphone / _monophone_then_acoustic, synth_halfphone.py:1315-1396, then viterbi_search per utterance
+ * in the reference's tuning loop): cand / tdist (row_offsets[n_utts], K) row-concatenated, outputs as snk_knn_viterbi_batch. */
+int snk_viterbi_batch(snk_handle h, const int64_t *cand, const double *tdist, const int64_t *row_offsets, int n_utts, int K,
+                      int64_t *path_out, int64_t *path_len_out, double *cost_out);
+
 /* snk_knn + snk_viterbi without the host round trip between them (what synth_utt does
  * at synth_halfphone.py:1601-1625).  cand_out / dist_out may be NULL. */
 int snk_knn_viterbi(snk_handle h, const double *Q, int64_t T, int D, int K,

@@ -1971,6 +1971,51 @@ int snk_merge_viterbi_batch_dev(snk_handle h, const double *d2_dev, const int64_
     return 0;
 }
 
+// Viterbi of a batch of utterances whose candidates the caller already has (label-driven preselection:
+// preselect_units_quinphone / monophone_then_acoustic, synth_halfphone.py:1315-1396): what the tail of
+// snk_knn_viterbi_batch does -- join bounds, sparse exact recursion per group on the side streams -- without the K-NN.
+int snk_viterbi_batch(snk_handle h, const int64_t *cand, const double *tdist, const int64_t *row_offsets, int n_utts, int K,
+                      int64_t *path_out, int64_t *path_len_out, double *cost_out)
+{
+    CHK(check_ready(h, false, true));
+    CHK(no_batch_in_flight(h, "snk_viterbi_batch"));
+    HIPCHK(hipSetDevice(h->device));
+    if (!cand || !tdist || !row_offsets || n_utts < 1 || !path_out || !path_len_out || !cost_out)
+        return fail("snk_viterbi_batch: null/empty argument");
+    if (K < 1 || K > 208) return fail("viterbi: n_candidates=%d outside 1..208", K);
+    if (h->Njc != h->N + 1 && h->N > 0) return fail("snk_viterbi_batch: join_contexts rows != N+1");
+    const int64_t total = row_offsets[n_utts];
+    for (int u = 0; u < n_utts; ++u)
+        if (row_offsets[u + 1] - row_offsets[u] < 1) return fail("snk_viterbi_batch: utterance %d has no rows", u);
+    CHK(h->mcand.ensure((size_t)total * K * sizeof(int64_t)));
+    CHK(h->mdist.ensure((size_t)total * K * sizeof(double)));
+    CHK(h->res_path.ensure((size_t)total * sizeof(int64_t)));
+    CHK(h->res_plen.ensure((size_t)n_utts * sizeof(int64_t)));
+    CHK(h->res_cost.ensure((size_t)n_utts * sizeof(double)));
+    {
+        StageTimer t(h, h->stream, TM_H2D);
+        HIPCHK(hipMemcpyAsync(h->mcand.p, cand, (size_t)total * K * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->mdist.p, tdist, (size_t)total * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    {
+        const std::vector<int> first = group_utterances(h, row_offsets, n_utts);
+        for (int g = 0; g + 1 < (int)first.size(); ++g)
+            CHK(viterbi_group(h, g, row_offsets, first[g], first[g + 1], K, h->mcand.as<int64_t>(), h->mdist.as<double>(), true,
+                              nullptr, nullptr, nullptr, n_utts));
+    }
+    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamSynchronize(h->dp_stream[i]));
+    HIPCHK(hipGetLastError());
+    {
+        StageTimer t(h, h->stream, TM_D2H);
+        D2HPart parts[3] = {{path_out, h->res_path.p, (size_t)total * sizeof(int64_t)},
+                            {path_len_out, h->res_plen.p, (size_t)n_utts * sizeof(int64_t)},
+                            {cost_out, h->res_cost.p, (size_t)n_utts * sizeof(double)}};
+        CHK(staged_d2h(h, h->stream, parts, 3));
+    }
+    collect_timers(h);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // collectives inside the library: RCCL (loaded when a communicator is first asked for: a single-GPU caller
 // never maps its 500 MB) or caller-provided functions

@@ -47,6 +47,8 @@ _SIGNATURES = {
     'snk_join_costs': (ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int64, ctypes.c_int, _c_f64p]),
     'snk_viterbi': (ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_f64p, ctypes.c_int64, ctypes.c_int,
                                    _c_i64p, _c_i64p, _c_f64p]),
+    'snk_viterbi_batch': (ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_f64p, _c_i64p, ctypes.c_int, ctypes.c_int,
+                                         _c_i64p, _c_i64p, _c_f64p]),
     'snk_knn_viterbi': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int,
                                        ctypes.c_int, _c_i64p, _c_f64p, _c_i64p, _c_i64p, _c_f64p]),
     'snk_knn_viterbi_batch': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int,
@@ -320,6 +322,26 @@ class HipSearchEngine(object):
         self._check(self._lib.snk_viterbi(self._h, _ptr(cand, _c_i64p), _ptr(tdist, _c_f64p), T, K,
                                           _ptr(path, _c_i64p), ctypes.byref(plen), ctypes.byref(cost)))
         return [int(v) for v in path[:plen.value]], float(cost.value)
+
+    def viterbi_batch(self, candidates, distances):
+        """viterbi_search for a list of utterances with given candidates ((T_u, K) int64 / float64 pairs) in one call:
+        (list of paths, costs)."""
+        cands = [np.ascontiguousarray(c, dtype=np.int64) for c in candidates]
+        dists = [_f64(d) for d in distances]
+        assert len(cands) == len(dists) and len(cands) > 0
+        K = cands[0].shape[1]
+        assert all(c.shape == d.shape and c.shape[1] == K for c, d in zip(cands, dists))
+        offs = np.zeros(len(cands) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([c.shape[0] for c in cands])
+        call = np.ascontiguousarray(np.vstack(cands))
+        dall = np.ascontiguousarray(np.vstack(dists))
+        total = int(offs[-1])
+        path = np.empty((max(total, 1),), dtype=np.int64)
+        plen = np.zeros(len(cands), dtype=np.int64)
+        cost = np.zeros(len(cands), dtype=np.float64)
+        self._check(self._lib.snk_viterbi_batch(self._h, _ptr(call, _c_i64p), _ptr(dall, _c_f64p), _ptr(offs, _c_i64p), len(cands), K,
+                                                _ptr(path, _c_i64p), _ptr(plen, _c_i64p), _ptr(cost, _c_f64p)))
+        return [path[int(offs[u]):int(offs[u]) + int(plen[u])].copy() for u in range(len(cands))], cost
 
     def knn_viterbi(self, unit_features, n_candidates, return_candidates=False):
         Q = _f64(unit_features)

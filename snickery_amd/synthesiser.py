@@ -491,8 +491,30 @@ class Synthesiser(object):
                 return [(self.get_target_scores_per_stream(U, p), self.get_join_scores_per_stream(p))
                         for U, p in zip(feats, paths)]
             return paths
-        batched = (plain and not self.config.get('greedy_search', False)
-                   and self.config.get('preselection_method') == 'acoustic')
+        method = self.config.get('preselection_method')
+        if (plain and len(fnames) > 1 and not self.config.get('greedy_search', False)
+                and method in ('quinphone', 'monophone_then_acoustic')):
+            # label-driven preselection (the reference's own configs use 'quinphone'): candidates per utterance as in
+            # synth_utt, then ONE call for the Viterbi search of all of them (join bounds + sparse exact recursion,
+            # snk_viterbi_batch) instead of a dense join + recursion per utterance
+            t = self.start_clock('Get speech + preselection (bulk)')
+            feats, cands, dists = [], [], []
+            for f in fnames:
+                U, names = self.prepare_targets(f, synth_type, return_names=True)
+                c, d = (self.preselect_units_quinphone(U, names) if method == 'quinphone'
+                        else self.preselect_units_monophone_then_acoustic(U, names))
+                feats.append(U); cands.append(c); dists.append(d)
+            self.stop_clock(t)
+            if len(set(c.shape[1] for c in cands)) == 1:
+                t = self.start_clock('Batched Viterbi')
+                paths, costs = self.engine.viterbi_batch(cands, dists)
+                self.stop_clock(t)
+                paths = [[int(u) for u in p] for p in paths]
+                if self.mode_of_operation == 'stream_weight_balancing':
+                    return [(self.get_target_scores_per_stream(U, p), self.get_join_scores_per_stream(p))
+                            for U, p in zip(feats, paths)]
+                return paths
+        batched = (plain and not self.config.get('greedy_search', False) and method == 'acoustic')
         if not batched or not fnames:
             return [self.synth_utt(f, synth_type=synth_type) for f in fnames]
         t = self.start_clock('Get speech (bulk)')

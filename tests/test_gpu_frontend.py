@@ -182,6 +182,11 @@ def test_halfphone_label_driven_synth_utt(tmp_path, golden, method):
     opath, ocost = o.viterbi(ocand, odist, JCw[1:], JCw[:-1])
     assert synth.synth_utt('arctic_b0001', synth_type='test') == opath
     assert synth.last_path_cost == ocost
+    # a list of utterances: label-driven preselection per utterance, ONE Viterbi call for all (snk_viterbi_batch)
+    before = synth.engine.timers().get('viterbi_sparse', (0, 0))[1]
+    bulk = synth.synth_utts_bulk(['arctic_b0001', 'arctic_b0001', 'arctic_b0001'], synth_type='test')
+    assert bulk == [opath, opath, opath]
+    assert synth.engine.timers().get('viterbi_sparse', (0, 0))[1] > before
     synth.close()
 
 

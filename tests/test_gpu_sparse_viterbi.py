@@ -154,3 +154,29 @@ def test_auto_mode_takes_the_sparse_path_for_batches_at_every_k(engine):
         p2, c2 = engine.knn_viterbi_batch(utts, K)
         assert engine.timers().get('viterbi_sparse', (0, 0))[1] > before, K
         assert all(np.array_equal(a, b) for a, b in zip(p0, p2)) and np.array_equal(c0, c2), K
+
+
+
+def test_viterbi_batch_of_given_candidates_equals_the_single_calls(engine):
+    """snk_viterbi_batch (label-driven preselection: the caller brings the candidates): ragged utterances with
+    padding ids, unusable units, a one-row utterance; equal to snk_viterbi per utterance and to the oracle."""
+    N, Dj, K = 60000, 151, 40
+    F_unw, JC_unw, wt, wj = _db(N, 61, Dj, seed=71)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    JCw = o.weight(JC_unw, wj)
+    rng = np.random.RandomState(72)
+    cands, dists = [], []
+    for T in (50, 1, 33, 120, 2):
+        c = np.sort(rng.randint(1, N - 1, (T, K)), axis=1).astype(np.int64)
+        c[rng.rand(T, K) < 0.05] = -1                      # back-off padding
+        if T > 10:
+            c[7, 3] = 0; c[9, 5] = N - 1                   # first / last unit: never joinable
+        d = np.sort(rng.rand(T, K), axis=1) + 0.3
+        cands.append(c); dists.append(d)
+    engine.set_option('viterbi_mode', 2)
+    paths, costs = engine.viterbi_batch(cands, dists)
+    for u, (c, d) in enumerate(zip(cands, dists)):
+        p1, c1 = engine.viterbi(c, d)
+        op, oc_ = oc.viterbi(c, d, JCw)
+        assert list(paths[u]) == p1 == op and (costs[u] == c1 == oc_ or len(op) == 0)
