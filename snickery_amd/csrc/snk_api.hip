@@ -2442,11 +2442,11 @@ int snk_sharded_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *pat
         // every rank saw the same status words: all of them redo this step in the exact mode, now -- behind whatever
         // a step submitted in the meantime has queued (its recursions must be through with the shared workspaces first)
         h->batch_redos += 1;
+        // a step submitted in the meantime is complete on the device after this (its results wait in its own buffers and
+        // in pinned memory until it is collected); the shared workspaces are free for the redo
         for (int i = 0; i < 2; ++i) HIPCHK(hipStreamSynchronize(h->dp_stream[i]));
         HIPCHK(hipStreamSynchronize(h->stream));
-        ShardTicket &o = h->sticket[ticket ^ 1];
-        if (o.busy) return fail("snk_sharded_knn_viterbi_batch_collect: a prefilter result of step %d was unsafe while another step is in "
-                                "flight; collect steps one at a time to have it redone exactly", ticket);
+        HIPCHK(hipStreamSynchronize(h->copy_stream));
         const std::vector<int64_t> offs = t.offs;
         CHK(sharded_submit(h, t, t.Q, offs.data(), t.n_utts, t.D, t.K, true));
         CHK(sharded_collect(h, t, path_out, path_len_out, cost_out, nullptr));

@@ -137,6 +137,17 @@ def _lib_worker(rank, world, port, out, use_sample):
     flags = [None] * world
     dist.all_gather_object(flags, int(redone))
     ok = ok and len(set(flags)) == 1                     # every rank took the same decision
+    # ... also with two steps in flight: the unsafe step is redone at its collect, the other one is untouched
+    lib3 = LibraryShardedSearch(eng, transport='gloo')
+    before = eng.info('batch_redos')
+    ta, tb = lib3.submit(utts, K), lib3.submit(utts[:3], K)
+    pa, ca = lib3.collect(ta)
+    pb, cb = lib3.collect(tb)
+    ok = ok and all(np.array_equal(a, b) for a, b in zip(pa, lpaths)) and np.array_equal(ca, lcosts)
+    ok = ok and all(np.array_equal(a, b) for a, b in zip(pb, lpaths[:3])) and np.array_equal(cb, lcosts[:3])
+    flags2 = [None] * world
+    dist.all_gather_object(flags2, int(eng.info('batch_redos') - before))
+    ok = ok and len(set(flags2)) == 1 and (flags[0] == 0 or flags2[0] >= 1)
     out[rank] = bool(ok)
     eng.close()
     dist.barrier()
