@@ -25,6 +25,7 @@
 // permuted (lane group g supplies elements 16g..16g+15 of each 64-column chunk) so that every
 // lane loads 128 contiguous bytes per fragment.
 #include "snk_internal.h"
+#include <type_traits>
 #include <float.h>
 
 namespace snk {
@@ -683,7 +684,8 @@ __device__ __forceinline__ bool pair_less(double ka, int ia, double kb, int ib)
     return (ka < kb) || (ka == kb && ia < ib);
 }
 
-__device__ void bitonic_sort_pairs(double *key, int *idx, int P)
+template <typename KeyT>
+__device__ void bitonic_sort_pairs(KeyT *key, int *idx, int P)
 {
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -691,7 +693,7 @@ __device__ void bitonic_sort_pairs(double *key, int *idx, int P)
                 const int ixj = i ^ j;
                 if (ixj > i) {
                     const bool up = ((i & k) == 0);
-                    const double ka = key[i], kb = key[ixj];
+                    const KeyT ka = key[i], kb = key[ixj];
                     const int ia = idx[i], ib = idx[ixj];
                     const bool sw = up ? pair_less(kb, ib, ka, ia) : pair_less(ka, ia, kb, ib);
                     if (sw) { key[i] = kb; key[ixj] = ka; idx[i] = ib; idx[ixj] = ia; }
@@ -859,7 +861,9 @@ __device__ __forceinline__ int block_incl_scan_256(int v, int *wsum /* LDS [4] *
                          // instead of 2: the short lists of a row-sharded database are latency-, not LDS-bound)
 
 // CLASS 0: every row; 1: rows with at most FIN_SMALL entries (the others are left to CLASS 2); 2: the longer ones
-template <int CLASS>
+// F32K: the list keys are float32 values (the matrix prefilter's) and are kept as such in LDS; together with the exact
+// keys living where the list was (it is dead by then) a workgroup needs 47 KB instead of 80 and three fit a compute unit
+template <int CLASS, bool F32K>
 __global__ void __launch_bounds__(256)
 knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_unw, int Fp,
                     const double *__restrict__ wt, int Dpad, int D, const double *__restrict__ Qp,
@@ -885,9 +889,10 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
     const int n = n_all;
     int P = 2;
     while (P < n) P <<= 1;
-    double *key = reinterpret_cast<double *>(smem);
-    int *idx = reinterpret_cast<int *>(smem + (size_t)P * sizeof(double));
-    __shared__ double ex_key[SELM];
+    using KeyT = typename std::conditional<F32K, float, double>::type;
+    KeyT *key = reinterpret_cast<KeyT *>(smem);
+    int *idx = reinterpret_cast<int *>(smem + (size_t)P * sizeof(KeyT));
+    double *ex_key = reinterpret_cast<double *>(smem);      // over key / idx: only written once the selection is in ex_idx
     __shared__ int ex_idx[SELM];
     __shared__ int n_sel_s, hist[256], cut_bin_s;
     __shared__ double red_min[256], red_max[256];
@@ -901,7 +906,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const double v = lkey[row * cap + i];
         const int id = lidx[row * cap + i];
-        key[i] = v; idx[i] = id;
+        key[i] = (KeyT)v; idx[i] = id;
         kmin = fmin(kmin, v); kmax = fmax(kmax, v);
         if (eps) fmax2 = fmax(fmax2, fnorm[id]);       // largest ||f||^2 among THIS row's survivors
     }
@@ -934,7 +939,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
     bool fast = (n > 4 * K && n > 256) && (scale > 0.0) && (kk == K);
     if (fast) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            int b = (int)((key[i] - kmin) * scale);
+            int b = (int)(((double)key[i] - kmin) * scale);
             b = b > 255 ? 255 : b;
             atomicAdd(&hist[b], 1);
         }
@@ -967,7 +972,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
     if (fast) {
         const int cut = cut_bin_s;
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            int b = (int)((key[i] - kmin) * scale);
+            int b = (int)(((double)key[i] - kmin) * scale);
             b = b > 255 ? 255 : b;
             if (b <= cut) {
                 const int slot = atomicAdd(&n_sel_s, 1);
@@ -976,7 +981,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
         }
         __syncthreads();
     } else {
-        for (int i = n + threadIdx.x; i < P; i += blockDim.x) { key[i] = DBL_MAX; idx[i] = 0x7fffffff; }
+        for (int i = n + threadIdx.x; i < P; i += blockDim.x) { key[i] = F32K ? (KeyT)FLT_MAX : (KeyT)DBL_MAX; idx[i] = 0x7fffffff; }
         __syncthreads();
         bitonic_sort_pairs(key, idx, P);
         if (threadIdx.x == 0) {
@@ -984,10 +989,10 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
             if (kk > 0 && kk < n) {
                 // GEMM-form keys carry ~1e-13 relative error: re-rank every candidate within a
                 // safety margin of the K-th key so that the exact order decides
-                const double kth = key[kk - 1];
+                const double kth = (double)key[kk - 1];
                 const double delta = 1e-10 * (fabs(kth) + qnorm[row] + 1.0) + margin;
-                while (ns < n && ns < SELM && key[ns] <= kth + delta) ++ns;
-                if (ns == SELM && ns < n && key[ns] <= kth + delta) { atomicOr(status, 2); if (rowflag) rowflag[row] = 2; }
+                while (ns < n && ns < SELM && (double)key[ns] <= kth + delta) ++ns;
+                if (ns == SELM && ns < n && (double)key[ns] <= kth + delta) { atomicOr(status, 2); if (rowflag) rowflag[row] = 2; }
             }
             n_sel_s = ns;
         }
@@ -1053,25 +1058,29 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
 {
     int P = 2;
     while (P < cap) P <<= 1;
-    const size_t shmem = (size_t)P * (sizeof(double) + sizeof(int));
+    // prefilter keys (eps given) are float32 values: 8 bytes per list entry in LDS instead of 12; the exact keys of the
+    // selection (SEL_MAX / FIN_SMALL doubles) live over the list
+    const bool f32k = eps != nullptr;
+    size_t shmem = (size_t)P * ((f32k ? sizeof(float) : sizeof(double)) + sizeof(int));
+    if (shmem < (size_t)SEL_MAX * sizeof(double)) shmem = (size_t)SEL_MAX * sizeof(double);
     static size_t attr = 0;
     if (shmem > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_finalize_kernel<0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_finalize_kernel<2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+#define SNK_FIN_ATTR(C_, F_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_finalize_kernel<C_, F_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)
+        SNK_FIN_ATTR(0, false); SNK_FIN_ATTR(0, true); SNK_FIN_ATTR(2, false); SNK_FIN_ATTR(2, true);
+#undef SNK_FIN_ATTR
         attr = shmem;
     }
+#define SNK_FIN(C_, F_, SH_) hipLaunchKernelGGL((knn_finalize_kernel<C_, F_>), dim3((unsigned)T), dim3(256), SH_, s, Fw, F_unw, Fp, wt, Dpad, D, Qp, \
+                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag)
     if (split_short && K <= FIN_SMALL / 2 && cap > FIN_SMALL) {
-        const size_t small = (size_t)FIN_SMALL * (sizeof(double) + sizeof(int));
-        hipLaunchKernelGGL(knn_finalize_kernel<1>, dim3((unsigned)T), dim3(256), small, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
-                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag);
-        hipLaunchKernelGGL(knn_finalize_kernel<2>, dim3((unsigned)T), dim3(256), shmem, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
-                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag);
+        const size_t small = (size_t)FIN_SMALL * ((f32k ? sizeof(float) : sizeof(double)) + sizeof(int)) > (size_t)FIN_SMALL * sizeof(double)
+                                 ? (size_t)FIN_SMALL * ((f32k ? sizeof(float) : sizeof(double)) + sizeof(int)) : (size_t)FIN_SMALL * sizeof(double);
+        if (f32k) { SNK_FIN(1, true, small); SNK_FIN(2, true, shmem); }
+        else { SNK_FIN(1, false, small); SNK_FIN(2, false, shmem); }
         return;
     }
-    hipLaunchKernelGGL(knn_finalize_kernel<0>, dim3((unsigned)T), dim3(256), shmem, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
-                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag);
+    if (f32k) SNK_FIN(0, true, shmem); else SNK_FIN(0, false, shmem);
+#undef SNK_FIN
 }
 
 // ---------------------------------------------------------------------------
