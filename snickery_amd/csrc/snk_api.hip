@@ -2747,7 +2747,31 @@ int snk_selftest_mfma(snk_handle h, double *max_abs_err_out)
     dA.release(); dB.release(); dC.release();
     double err16 = 0;
     CHK(selftest_mfma16(h, &err16));          // f16 32x32x16 operand / result maps of the prefilter
-    if (max_abs_err_out) *max_abs_err_out = fmax(err, err16);
+    // the bf16 instruction of the split prefilter: operand map (small integers: exact) and the accumulation assumption
+    // behind its key bound on the pattern that shows the unit's cut (one product of 1, fifteen just under 2^-24)
+    double errbf = 0;
+    {
+        uint16_t A[512], B[512];
+        float C[1024], D[1024];
+        auto bits = [](float x) { unsigned int u; memcpy(&u, &x, 4); return (uint16_t)(u >> 16); };   // exact for the values used
+        for (int i = 0; i < 32; ++i) for (int k = 0; k < 16; ++k) A[i * 16 + k] = bits((float)((3 * i + 5 * k) % 9 - 4));
+        for (int k = 0; k < 16; ++k) for (int j = 0; j < 32; ++j) B[k * 32 + j] = bits((float)((7 * k - 2 * j) % 5));
+        for (int i = 0; i < 1024; ++i) C[i] = (float)(i % 7);
+        CHK(snk_probe_mfma_bf16(h, A, B, C, D));
+        for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) {
+            double acc = (double)C[i * 32 + j];
+            for (int k = 0; k < 16; ++k) acc += (double)((3 * i + 5 * k) % 9 - 4) * (double)((7 * k - 2 * j) % 5);
+            errbf = fmax(errbf, fabs((double)D[i * 32 + j] - acc));
+        }
+        for (int i = 0; i < 32; ++i) for (int k = 0; k < 16; ++k) A[i * 16 + k] = bits(k == 0 ? 1.0f : 0.000244140625f);          // 2^-12
+        for (int k = 0; k < 16; ++k) for (int j = 0; j < 32; ++j) B[k * 32 + j] = bits(k == 0 ? 1.0f : 0.000236511230469f);        // 1.9375 2^-13
+        for (int i = 0; i < 1024; ++i) C[i] = 0.f;
+        CHK(snk_probe_mfma_bf16(h, A, B, C, D));
+        const double small = 0.000244140625 * 0.000236511230469, exact = 1.0 + 15.0 * small, mass = exact;
+        for (int i = 0; i < 1024; ++i)
+            if (fabs((double)D[i] - exact) > SNK_BF16_MFMA_UNIT * mass) errbf = fmax(errbf, fabs((double)D[i] - exact));
+    }
+    if (max_abs_err_out) *max_abs_err_out = fmax(fmax(err, err16), errbf);
     return 0;
 }
 
