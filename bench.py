@@ -214,6 +214,7 @@ def main():
     ap.add_argument('--exchange', choices=('library', 'torch'), default='library',
                     help="N > 1, sharded database: collectives inside libsnkhip.so (snk_comm_init: RCCL on the engine's stream; "
                          "default) or torch.distributed collectives between the device-pointer entry points (snickery_amd/dist.py)")
+    ap.add_argument('--no-replicas-extra', action='store_true', help='N > 1: skip the extra pass that times the GPUs as independent replicas')
     ap.add_argument('--fixed-batch', action='store_true', help='N > 1: keep the batch at --utts (strong scaling)')
     ap.add_argument('--db-shards', type=int, default=0,
                     help='N > 1: shard the database over this many GPUs (a divisor of N; default N) and replicate '
@@ -385,6 +386,43 @@ def main():
         elapsed = float(t.item())
 
     timers = eng.timers()
+    # N > 1, database sharded: the same GPUs as independent replicas (every GPU the whole database -- B* needs 3.5 GB of
+    # 288 -- and its own 32 utterances, no collective), timed the same way: an extra field, never `value`.  Sharding is for
+    # databases beyond one GPU's memory; for one that fits, this is what the exchange costs.
+    replicas = None
+    if world > 1 and S > 1 and not args.fixed_batch and not args.no_replicas_extra:
+        t_rep, err = float('inf'), ''
+        try:
+            eng_r = snickery_amd.HipSearchEngine(local_rank)
+            eng_r.set_option('viterbi_mode', args.viterbi_mode)
+            eng_r.upload_db(F_unw, JC_unw)
+            eng_r.set_weights(wt, wj)
+            mine = batch.subset(*shard_bounds(U, world, rank))
+            mine.pin()
+            eng_r.knn_viterbi_batch(mine, K)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            pending = None
+            for _ in range(args.steps):
+                tk = eng_r.knn_viterbi_batch_submit(mine, K)
+                if pending is not None:
+                    eng_r.knn_viterbi_batch_collect(pending)
+                pending = tk
+            eng_r.knn_viterbi_batch_collect(pending)
+            torch.cuda.synchronize()
+            t_rep = time.perf_counter() - t1
+            eng_r.close()
+        except Exception as e:        # noqa: BLE001 -- every rank still reaches the reduction below
+            err = str(e)
+        tt = torch.tensor([t_rep], dtype=torch.float64, device='cpu' if share_gpu else 'cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if np.isfinite(float(tt.item())):
+            replicas = {'value': frames_per_step * args.steps / float(tt.item()), 'unit': 'frames/s',
+                        'ms_per_step': float(tt.item()) / args.steps * 1e3,
+                        'note': 'the same GPUs as %d independent replicas (whole database on every GPU, no collective), two steps in flight' % world}
+        elif rank == 0:
+            sys.stderr.write('replicas extra skipped: %s\n' % (err or 'a rank failed'))
     # a second, separately timed pass in the OTHER submission mode (an extra field, never `value`)
     two_in_flight = one_in_flight = None
     if world == 1 and args.in_flight == 1:
@@ -486,6 +524,8 @@ def main():
             out['two_in_flight'] = two_in_flight
         if one_in_flight is not None:
             out['one_in_flight'] = one_in_flight
+        if replicas is not None:
+            out['replicas'] = replicas
         if share_gpu:
             out['note'] = 'FUNCTIONAL TEST: all ranks share cuda:0, collectives on gloo through host memory; not a measurement'
         if cpu_ref is not None:
