@@ -166,6 +166,16 @@ def test_library_collectives_two_ranks_one_gpu(use_sample):
     assert out[0] is True and out[1] is True
 
 
+def test_library_collectives_three_ranks_one_gpu():
+    """The same with three ranks (uneven shards of 60 001 units, 5 utterances over 3 owners: blocks of 2 / 2 / 1, and a
+    one-utterance batch that leaves two ranks without any): more of the offset arithmetic of the exchanges."""
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_lib_worker, args=(3, port, out, True), nprocs=3, join=True)
+    assert out[0] is True and out[1] is True and out[2] is True
+
+
 def test_library_rccl_communicator_single_rank():
     """The RCCL transport itself, as far as one GPU allows: ncclCommInitRank with one rank, then the
     sharded entry point (its collectives degenerate to copies) against the unsharded search."""
