@@ -169,7 +169,7 @@ def test_library_collectives_two_ranks_one_gpu(use_sample):
 def test_library_collectives_three_ranks_one_gpu():
     """The same with three ranks (uneven shards of 60 001 units, 5 utterances over 3 owners: blocks of 2 / 2 / 1, and a
     one-utterance batch that leaves two ranks without any): more of the offset arithmetic of the exchanges."""
-    port = 29500 + (os.getpid() % 2000)
+    port = 35500 + (os.getpid() % 2000)
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_lib_worker, args=(3, port, out, True), nprocs=3, join=True)
