@@ -254,8 +254,15 @@ class Synthesiser(object):
             for form in self.break_quinphone(name):
                 self.unit_index.setdefault(form, []).append(i)
 
-    def preselect_units_quinphone(self, unit_features, unit_names):
-        """synth_halfphone.py:1305-1354: label back-off lookup on the host, distances on the GPU."""
+    def preselect_units_quinphone(self, unit_features, unit_names, candidates=None):
+        """synth_halfphone.py:1305-1354: label back-off lookup on the host, distances on the GPU.  `candidates`: the
+        ids of an earlier lookup for the same names (they depend on the labels and n_candidates only, not on the stream
+        weights -- synth_utts_bulk keeps them across the iterations of a tuning loop)."""
+        if candidates is not None:
+            t = self.start_clock('Compute target distances...')
+            distances = self.engine.candidate_distances(np.asarray(unit_features, dtype=np.float64), candidates)
+            self.stop_clock(t)
+            return (candidates, distances)
         t = self.start_clock('Preselect units ')
         if not hasattr(self, 'unit_index'):
             self._setup_unit_index()
@@ -430,7 +437,14 @@ class Synthesiser(object):
         self.mode_of_operation = state['mode_of_operation']
         self._apply_weights()
 
-    def prepare_targets(self, base, synth_type='test', return_names=False):
+    def _weight_targets(self, unit_features):
+        """The tail of prepare_targets: stream weights and truncated columns (what changes between the iterations of
+        a tuning loop; everything before it depends on the files only)."""
+        if self.flavour == 'simple' or self.config['weight_target_data']:
+            unit_features = hp.weight(unit_features, self.target_weight_vector)
+        return self._mask_query(unit_features)
+
+    def prepare_targets(self, base, synth_type='test', return_names=False, _weighted=True):
         """Target preparation of synth_utt (synth_simple.py:370-396, synth_halfphone.py:1478-1552):
         frame-level targets for the epoch representation, one row per halfphone (taken at the
         state-alignment points of the utterance's label) otherwise."""
@@ -463,9 +477,8 @@ class Synthesiser(object):
                     norm_durations = hp.get_norm_durations(unit_names, unit_timings, self.duration_stats)
                     norm_durations *= self.config.get('target_duration_stretch_factor', 1.0)
                     unit_features = np.hstack([unit_features, norm_durations])
-        if self.flavour == 'simple' or self.config['weight_target_data']:
-            unit_features = hp.weight(unit_features, self.target_weight_vector)
-        unit_features = self._mask_query(unit_features)
+        if _weighted:
+            unit_features = self._weight_targets(unit_features)
         return (unit_features, unit_names) if return_names else unit_features
 
     def synth_utts_bulk(self, fnames, synth_type='test'):
@@ -499,10 +512,21 @@ class Synthesiser(object):
             # snk_viterbi_batch) instead of a dense join + recursion per utterance
             t = self.start_clock('Get speech + preselection (bulk)')
             feats, cands, dists = [], [], []
+            cache = self.__dict__.setdefault('_bulk_cache', {})
             for f in fnames:
-                U, names = self.prepare_targets(f, synth_type, return_names=True)
-                c, d = (self.preselect_units_quinphone(U, names) if method == 'quinphone'
-                        else self.preselect_units_monophone_then_acoustic(U, names))
+                # what depends on the files and labels only is kept across calls (a tuning loop searches the same tune
+                # set again and again with other weights): unweighted targets, unit names, quinphone candidate ids
+                key = (synth_type, f, method, self.config['n_candidates'])
+                ent = cache.get(key)
+                if ent is None:
+                    raw, names = self.prepare_targets(f, synth_type, return_names=True, _weighted=False)
+                    ent = cache[key] = {'raw': raw, 'names': names, 'cand': None}
+                U, names = self._weight_targets(ent['raw']), ent['names']
+                if method == 'quinphone':
+                    c, d = self.preselect_units_quinphone(U, names, candidates=ent['cand'])
+                    ent['cand'] = c
+                else:
+                    c, d = self.preselect_units_monophone_then_acoustic(U, names)
                 feats.append(U); cands.append(c); dists.append(d)
             self.stop_clock(t)
             if len(set(c.shape[1] for c in cands)) == 1:

@@ -187,6 +187,23 @@ def test_halfphone_label_driven_synth_utt(tmp_path, golden, method):
     bulk = synth.synth_utts_bulk(['arctic_b0001', 'arctic_b0001', 'arctic_b0001'], synth_type='test')
     assert bulk == [opath, opath, opath]
     assert synth.engine.timers().get('viterbi_sparse', (0, 0))[1] > before
+    # a tuning loop: other stream weights, the same utterances.  The label-dependent preparation (targets before
+    # weighting, names, quinphone candidate ids) is reused; the result is that of a search started from the files.
+    n_streams = len(synth.stream_list_target)
+    synth.set_target_weights(list(0.3 + 0.4 * np.arange(1, n_streams + 1) / n_streams))
+    synth.set_join_weights([0.7] * len(synth.stream_list_join))
+    assert len(synth._bulk_cache) == 1
+    warm = synth.synth_utts_bulk(['arctic_b0001', 'arctic_b0001'], synth_type='test')
+    cold = synth.synth_utt('arctic_b0001', synth_type='test')
+    assert warm == [cold, cold]
+    U2, names2 = synth.prepare_targets('arctic_b0001', 'test', return_names=True)
+    F2 = o.weight(db['train_unit_features'], synth.target_weight_vector)
+    JC2 = o.weight(db['join_contexts'], synth.join_weight_vector)
+    if method == 'quinphone':
+        c2, d2 = o.preselect_units_quinphone(o.build_unit_index(unit_names), F2, U2, list(names2), K)
+    else:
+        c2, d2 = o.knn_by_class(F2, U2, K, np.array([ids[m] for m in monos]), np.array([ids[n.split('/')[2]] for n in names2]))
+    assert cold == o.viterbi(c2, d2, JC2[1:], JC2[:-1])[0]
     synth.close()
 
 
