@@ -35,6 +35,7 @@ namespace snk {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define G32_W 64
 #define G32_MAXW 8
+#define G32_HOIST_NSTG 3      // ring stages of the hoisted scan (little arithmetic to hide requests behind: three chunks ahead)
 #define G32_UB 3              // utterances per scan: (w, ref0, ref1, ref2) = 16 table bytes per column
 
 struct G32Rec {               // what a workgroup publishes per utterance and step
@@ -145,10 +146,10 @@ __device__ double g32_exact_d2_wave(const GreedyArgs &a, int u, int64_t step, in
 // utterance, the squared norm of the reference vector (float64, for the error bound).  Written with sc1 stores
 // by the workgroup that decides the previous step.
 __device__ void g32_write_table(const GreedyArgs &a, int64_t step, const int64_t (&prev_row)[G32_UB], bool prev_is_current,
-                                float *__restrict__ tab, double *__restrict__ vnorm2, double *red, int tid, int nthreads)
+                                float *tab, double *vnorm2, double *red, int tid, int nthreads)
 {
     const int jch = greedy_join_chunks(a), tch = greedy_target_chunks(a);
-    const int nT = a.nep * tch, n = (jch + nT) * GR_CC;
+    const int nT = a.hoist ? 0 : a.nep * tch, n = (jch + nT) * GR_CC;          // hoisted target term: join columns only
     const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(tab, 0, n * 16, 0x00020000);
     double n2[G32_UB];
 #pragma unroll
@@ -211,13 +212,18 @@ __device__ __forceinline__ double g32_err(double d, double V2, int ncols)
     return 6.0 * u * sqrt(V2 * d) * 1.01 + (double)(ncols + 8) * u * d;
 }
 
-template <bool IN_LDS>
+// bound of a hoisted target value (greedy_hoist_kernels.hip): hoist_c (||q|| + ||f||max)^2
+__device__ __forceinline__ double g32_hoist_err(const GreedyArgs &a, int u, int64_t step)
+{
+    const double r = sqrt(a.qn2[u][step]) + sqrt(a.fwmax2);
+    return a.hoist_c * r * r;
+}
+
+template <bool IN_LDS, bool HOIST>
 __global__ void __launch_bounds__(G32_W * G32_MAXW)
 greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2, int approx, int use_nt, int lds_bytes,
-                float *__restrict__ tabs, double *__restrict__ vnorm2, G32Rec *__restrict__ blk,
-                unsigned int *__restrict__ arrive, unsigned int *__restrict__ arrive2, unsigned int *__restrict__ gen,
-                G32Ctl *__restrict__ ctl, int64_t *__restrict__ clist_g, int64_t *__restrict__ path,
-                int64_t *__restrict__ status)
+                float *tabs, double *vnorm2, G32Rec *blk, unsigned int *arrive, unsigned int *arrive2, unsigned int *gen,
+                G32Ctl *ctl, int64_t *clist_g, int64_t *path, int64_t *status)       // shared between workgroups: no restrict
 {
     extern __shared__ __align__(16) char lds[];          // table | one target block per wavefront (lds_mode 1)
     __shared__ int is_last, gen_seen;
@@ -226,12 +232,14 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr bool in_lds = IN_LDS;
     const int jch = greedy_join_chunks(a), tch = greedy_target_chunks(a);
-    const int nT = a.nep * tch, n_chunks = jch + nT, JQ = jch * 8, FQ = tch * 8;
+    const int nT = HOIST ? 0 : a.nep * tch, n_chunks = jch + nT, JQ = jch * 8, FQ = tch * 8;
     const int ncols = n_chunks * GR_CC;
+    const int jq_last = (a.jdim + 3) / 4 - (jch - 1) * 8;   // float4 columns of the last join chunk that hold data
+    const int ecols = ncols + (HOIST ? 2 : 0);            // the bound's chain length: + the addition of the hoisted value
     const int pitch = tch * GR_CC + 4;
     const int nB = a.me > 1 ? tch : 0;
     const int ring_per_tile = in_lds ? tch + nB + jch : n_chunks;
-    constexpr int NSTG = GR_NSTG;                         // ring stages: two chunks (16 KB per wavefront) requested ahead of the arithmetic
+    constexpr int NSTG = HOIST ? G32_HOIST_NSTG : GR_NSTG;                         // ring stages: two chunks (16 KB per wavefront) requested ahead of the arithmetic
     const int table_bytes = ncols * 16;
     float *const Fs = reinterpret_cast<float *>(lds + table_bytes) + (size_t)wave * (G32_W + a.me - 1) * pitch;
     const int ntiles = (int)((a.Nwin + G32_W - 1) / G32_W);
@@ -267,8 +275,22 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
 
         int f_tile = wave_id, f_pos = 0;
         f32x4 stage[NSTG][8];
+        // hoisted target values of the tile in work and of the next one (one float per window and utterance)
+        float wcur[G32_UB] = {0.f, 0.f, 0.f}, wnext[G32_UB] = {0.f, 0.f, 0.f};
+        const float *wrow[G32_UB];
+#pragma unroll
+        for (int u = 0; u < G32_UB; ++u)
+            wrow[u] = (HOIST && u < a.nu && step < a.nsteps_u[u]) ? a.W[u] + step * a.Wp + lane : nullptr;
         auto fetch = [&](f32x4 (&st)[8], int pin0) {
             const int t = f_tile < ntiles ? f_tile : ntiles - 1;
+            if (HOIST && f_pos == 0) {
+                // the first request of a tile is issued before the previous tile's last chunk is summed (jch >= 2)
+#pragma unroll
+                for (int u = 0; u < G32_UB; ++u) {
+                    wcur[u] = wnext[u];
+                    if (wrow[u]) wnext[u] = __builtin_nontemporal_load(wrow[u] + (size_t)t * G32_W);
+                }
+            }
             const char *base;
             unsigned voff = off_own;
             if (in_lds) {
@@ -285,7 +307,16 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
             }
             voff += (unsigned)pin0;
             // nt for databases that are streamed from HBM every step; small ones stay in L2 / Infinity Cache
-            if (use_nt && (in_lds || f_pos < jch)) {
+            if (HOIST && use_nt == 2) {
+                // the last join chunk of a streamed database: float4 columns that are padding altogether (151 columns:
+                // 38 of 40) are not asked from HBM a second time -- their requests repeat the chunk's first column
+                // (weight 0 turns any finite value into +0).  Eight requests either way: the counted waits of the
+                // ring stay static (a conditional number of requests cost 3 us per step at 65 536 units).
+                const int lim = f_pos == jch - 1 ? jq_last : 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    st[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + voff + (j < lim ? 1024 * j : 0)));
+            } else if (use_nt && (in_lds || f_pos < jch)) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     st[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + voff + 1024 * j));
@@ -342,7 +373,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
             const int i = c_tile * G32_W + lane;
 #pragma unroll
             for (int u = 0; u < G32_UB; ++u) {
-                if (i < (int)a.Nwin) top3_push(best[u], acc[u], i);
+                if (i < (int)a.Nwin) top3_push(best[u], HOIST ? acc[u] + wcur[u] : acc[u], i);
                 acc[u] = 0.f;
             }
             c_pos = 0; t_done = 0; c_tile += wave_stride;
@@ -424,7 +455,9 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
                 const unsigned int b = blockIdx.x;
                 const unsigned int S1 = nb < GR_S1 ? nb : GR_S1, sl1 = b % S1, q1 = (nb - sl1 + S1 - 1) / S1;
                 bool last = false;
-                if (__hip_atomic_fetch_add(cnt + 32 * sl1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == round * q1 - 1) {
+                // (a workgroup alone in its first-level slot -- up to 256 workgroups -- goes straight to the second level:
+                // one fabric round trip less on every step's critical path)
+                if (q1 == 1u || __hip_atomic_fetch_add(cnt + 32 * sl1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == round * q1 - 1) {
                     const unsigned int S2 = S1 < GR_S2 ? S1 : GR_S2, sl2 = sl1 % S2, q2 = (S1 - sl2 + S2 - 1) / S2;
                     if (__hip_atomic_fetch_add(cnt + 32 * (GR_S1 + sl2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == round * q2 - 1)
                         last = __hip_atomic_fetch_add(cnt + 32 * (GR_S1 + GR_S2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -502,11 +535,28 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
                 if (!(u < a.nu && step < a.nsteps_u[u])) continue;      // uniform
                 float mv = __builtin_inff();
                 int64_t mi = INT64_MAX;
-                for (unsigned int b = tid; b < nb; b += blockDim.x) {
-                    const G32Rec *r = blk + ((size_t)u * nb + b);
-                    const float v = __hip_atomic_load(&r->v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int64_t i = __hip_atomic_load(&r->a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (lt_vi(v, i, mv, mi)) { mv = v; mi = i; }
+                // the records of all workgroups, read ONCE (four 8-byte agent-scope atomic loads each, in flight together;
+                // at most 256 workgroups and at least 64 threads: four per thread) and kept for the candidate pass
+                // behind the bound.  (Plain 16-byte loads were tried: `blk` is a restrict pointer and nothing orders an
+                // ordinary load against the OTHER workgroups' stores -- the records arrived stale.)
+                float rv1[4], rv2[4], rv3[4];
+                int64_t ra1[4], ra2[4];
+                {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned int b = tid + q * blockDim.x;
+                        rv1[q] = rv2[q] = rv3[q] = __builtin_inff(); ra1[q] = ra2[q] = INT64_MAX;
+                        if (b < nb) {
+                            G32Rec *r = blk + ((size_t)u * nb + b);
+                            const unsigned long long v12 = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&r->v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned long long v3p = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&r->v3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ra1[q] = __hip_atomic_load(&r->a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ra2[q] = __hip_atomic_load(&r->a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            rv1[q] = __builtin_bit_cast(float, (unsigned int)v12); rv2[q] = __builtin_bit_cast(float, (unsigned int)(v12 >> 32));
+                            rv3[q] = __builtin_bit_cast(float, (unsigned int)v3p);
+                        }
+                        if (lt_vi(rv1[q], ra1[q], mv, mi)) { mv = rv1[q]; mi = ra1[q]; }
+                    }
                 }
 #pragma unroll
                 for (int m = 1; m <= 32; m <<= 1) {
@@ -520,28 +570,32 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
                 mv = wv[0]; mi = wi[0];
                 for (int w = 1; w < nwaves; ++w) if (lt_vi(wv[w], wi[w], mv, mi)) { mv = wv[w]; mi = wi[w]; }
                 __syncthreads();
-                if (approx) { winner[u] = mi; continue; }
                 if (!(mv < __builtin_inff())) { undecided = true; continue; }
+                const double EW = HOIST ? g32_hoist_err(a, u, step) : 0.0;
+                // search_epsilon mode: the float32 minimum is the answer -- with a hoisted target term only where its
+                // ABSOLUTE bound is small against the minimum (it is not for near-exact matches: decided exactly then)
+                if (approx && (!HOIST || 4.0 * (g32_err((double)mv, __hip_atomic_load(&vnorm2[(step & 1) * G32_UB + u], __ATOMIC_RELAXED,
+                                                                                     __HIP_MEMORY_SCOPE_AGENT), ecols) + EW) <= 1e-3 * (double)mv)) {
+                    winner[u] = mi;
+                    continue;
+                }
                 // tau = the largest solution of tau = M + 2 E(tau), approached from above (E(0) = 0: from below the
                 // iteration would stall at M = 0, where the natural path lives)
                 const double V2 = __hip_atomic_load(&vnorm2[(step & 1) * G32_UB + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const double M = (double)mv;
+                const double M = (double)mv + 2.0 * EW;
                 double tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300;
-                for (int it = 0; it < 8; ++it) tau = M + 2.0 * g32_err(tau, V2, ncols);
+                for (int it = 0; it < 8; ++it) tau = M + 2.0 * g32_err(tau, V2, ecols);
                 tau = tau * (1.0 + 1e-6) + 1e-300;
                 int *ccount = reinterpret_cast<int *>(lds);
                 int *cover = reinterpret_cast<int *>(lds + 32);
                 int64_t *clist = reinterpret_cast<int64_t *>(lds + 128);               // up to 512 candidates
                 if (tid == 0) { *ccount = 0; *cover = 0; }
                 __syncthreads();
-                for (unsigned int b = tid; b < nb; b += blockDim.x) {
-                    const G32Rec *r = blk + ((size_t)u * nb + b);
-                    const float v1 = __hip_atomic_load(&r->v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const float v2 = __hip_atomic_load(&r->v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const float v3 = __hip_atomic_load(&r->v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((double)v1 <= tau) clist[atomicAdd(ccount, 1)] = __hip_atomic_load(&r->a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((double)v2 <= tau) clist[atomicAdd(ccount, 1)] = __hip_atomic_load(&r->a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((double)v3 <= tau) *cover = 1;          // a window nobody published may matter: second phase
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if ((double)rv1[q] <= tau) clist[atomicAdd(ccount, 1)] = ra1[q];
+                    if ((double)rv2[q] <= tau) clist[atomicAdd(ccount, 1)] = ra2[q];
+                    if ((double)rv3[q] <= tau) *cover = 1;      // a window nobody published may matter: second phase
                 }
                 __syncthreads();
                 const int nc = *ccount;
@@ -648,11 +702,11 @@ greedy32_dist_kernel(GreedyArgs a, int u, int64_t start, const int64_t *__restri
     if (threadIdx.x == 0) dist[a.out_off[u] + s] = __dsqrt_rn(d2);
 }
 
-size_t greedy32_table_floats(const GreedyLayout &g, int Dt)
+size_t greedy32_table_floats(const GreedyLayout &g, int Dt, bool hoist)
 {
     const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
     const int jch = (g.jdim + GR_CC - 1) / GR_CC;
-    return (size_t)(jch + nep * ((Dt + GR_CC - 1) / GR_CC)) * GR_CC * 4;
+    return (size_t)(jch + (hoist ? 0 : nep * ((Dt + GR_CC - 1) / GR_CC))) * GR_CC * 4;
 }
 // workspace of one launch: block records | second-phase control | candidate lists
 static size_t g32_rec_bytes(int nblk) { return (((size_t)G32_UB * nblk * sizeof(G32Rec)) + 255) & ~(size_t)255; }
@@ -664,13 +718,14 @@ static size_t g32_lds_wave_bytes(const GreedyLayout &g, int Dt)
     return (size_t)(G32_W + g.me - 1) * ((Dt + GR_CC - 1) / GR_CC * GR_CC + 4) * sizeof(float);
 }
 // wavefronts per workgroup / LDS bytes: the table (16 bytes per column) + a target block per wavefront
-static int g32_waves(const GreedyLayout &g, int Dt, int n_cus, bool in_lds)
+static int g32_waves(const GreedyLayout &g, int Dt, int n_cus, bool in_lds, bool hoist = false)
 {
+    if (hoist) in_lds = false;
     const int64_t ntiles = (g.Nwin + G32_W - 1) / G32_W;
     int64_t w = (ntiles + n_cus - 1) / n_cus;
     int wmax = G32_MAXW;
     if (in_lds) {
-        const size_t fixed = greedy32_table_floats(g, Dt) * 4 + 64;
+        const size_t fixed = greedy32_table_floats(g, Dt, false) * 4 + 64;
         const size_t per = g32_lds_wave_bytes(g, Dt);
         const size_t fit = fixed < (size_t)(160 * 1024) ? ((size_t)(160 * 1024) - fixed) / per : 0;
         if ((int64_t)fit < wmax) wmax = (int)fit;
@@ -681,18 +736,19 @@ static int g32_waves(const GreedyLayout &g, int Dt, int n_cus, bool in_lds)
 bool greedy32_supported(const GreedyLayout &g, int Dt)
 {
     // the table must leave room for the reduction scratch and, in LDS mode, for at least four target blocks
-    const size_t tb = greedy32_table_floats(g, Dt) * 4;
+    const size_t tb = greedy32_table_floats(g, Dt, false) * 4;
     if (tb + 16384 > (size_t)(160 * 1024)) return false;
     if (greedy_lds_mode(g, Dt) && tb + 64 + 4 * g32_lds_wave_bytes(g, Dt) > (size_t)(160 * 1024)) return false;
     return true;
 }
-int greedy32_blocks(const GreedyLayout &g, int Dt, int n_cus)
+int greedy32_blocks(const GreedyLayout &g, int Dt, int n_cus, bool hoist)
 {
     const bool in_lds = greedy_lds_mode(g, Dt);
     const int64_t ntiles = (g.Nwin + G32_W - 1) / G32_W;
-    const int waves = g32_waves(g, Dt, n_cus, in_lds);
+    const int waves = g32_waves(g, Dt, n_cus, in_lds, hoist);
     const int64_t need = (ntiles + waves - 1) / waves;
-    return (int)(need < n_cus ? need : n_cus);
+    const int cap = n_cus < 256 ? n_cus : 256;              // the deciding workgroup keeps four records per thread
+    return (int)(need < cap ? need : cap);
 }
 
 // One persistent launch for up to three utterances (q_off / nsteps_u / out_off / start per utterance).
@@ -702,13 +758,18 @@ void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, 
                      int Dj, const double *wj, const float *tiles, const double *Q, int nu, const int64_t *q_off,
                      const int64_t *nsteps_u, const int64_t *out_off, const int64_t *start, int approx, float *tabs,
                      double *vnorm2, void *blk, int n_cus, unsigned int *arrive, unsigned int *gen, int64_t *status,
-                     int64_t *path, hipStream_t s)
+                     int64_t *path, const G32Hoist *hst, hipStream_t s)
 {
     GreedyArgs a{};
     greedy_fill_args(a, g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, Q, true, tiles);
-    const bool in_lds = greedy_lds_mode(g, Dt);
+    const bool hoist = hst != nullptr;
+    const bool in_lds = !hoist && greedy_lds_mode(g, Dt);
     a.lds_mode = in_lds ? 1 : 0;
     a.nu = nu;
+    if (hoist) {
+        a.hoist = 1; a.Wp = hst->Wp; a.hoist_c = hst->c; a.fwmax2 = hst->fwmax2;
+        for (int u = 0; u < 3; ++u) { a.W[u] = u < nu ? hst->W[u] : nullptr; a.qn2[u] = u < nu ? hst->qn2[u] : nullptr; }
+    }
     int64_t nsteps = 0, st3[3] = {-1, -1, -1};
     for (int u = 0; u < 3; ++u) {
         a.q_off[u] = u < nu ? q_off[u] : 0;
@@ -719,17 +780,18 @@ void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, 
     if (nsteps <= 0) return;
     unsigned int *arrive2 = arrive + 32 * (GR_S1 + GR_S2 + 1);    // the caller provides 2 x greedy_counter_bytes()
     hipLaunchKernelGGL(greedy32_init_kernel, dim3(1), dim3(512), 0, s, a, st3[0], st3[1], st3[2], tabs, vnorm2, arrive, arrive2, gen, status);
-    const int waves = g32_waves(g, Dt, n_cus, in_lds);
-    const int nblk = greedy32_blocks(g, Dt, n_cus);
-    size_t lds = greedy32_table_floats(g, Dt) * 4 + (in_lds ? (size_t)waves * g32_lds_wave_bytes(g, Dt) : 0);
+    const int waves = g32_waves(g, Dt, n_cus, in_lds, hoist);
+    const int nblk = greedy32_blocks(g, Dt, n_cus, hoist);
+    size_t lds = greedy32_table_floats(g, Dt, hoist) * 4 + (in_lds ? (size_t)waves * g32_lds_wave_bytes(g, Dt) : 0);
     // the step's tail: 16 KB of reduction scratch + a term array per wavefront for exact decisions
     const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
     const size_t tail = 16384 + (size_t)waves * (size_t)(g.jdim + nep * Dt) * 8;
     if (lds < tail) lds = tail < (size_t)(160 * 1024) ? tail : (size_t)(160 * 1024);
     // small scans live in L2 / Infinity Cache across the steps of the launch; big ones are streamed
-    const size_t scan_bytes = (size_t)g.Nwin * (size_t)(g.jdim + Dt) * 4;
-    const int use_nt = scan_bytes > ((size_t)192 << 20) ? 1 : 0;
-    auto kernel = in_lds ? greedy32_kernel<true> : greedy32_kernel<false>;
+    const size_t scan_bytes = (size_t)g.Nwin * (size_t)(g.jdim + (hoist ? 1 : Dt)) * 4;
+    // (2: the hoisted scan sends the requests of all-padding float4 columns to the chunk's first column)
+    const int use_nt = scan_bytes > ((size_t)192 << 20) ? (hoist ? 2 : 1) : 0;
+    auto kernel = hoist ? greedy32_kernel<false, true> : in_lds ? greedy32_kernel<true, false> : greedy32_kernel<false, false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     char *wb = reinterpret_cast<char *>(blk);
     G32Ctl *ctl = reinterpret_cast<G32Ctl *>(wb + g32_rec_bytes(nblk));

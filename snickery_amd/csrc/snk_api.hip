@@ -185,6 +185,15 @@ struct snk_engine {
     DevBuf tmask;                         // tsel on the device (query rows are masked after upload)
     DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist, gsync, gtiles;
     DevBuf g32_tabs, g32_vnorm, g32_blk, g32_ctl;          // float32 persistent scan: tables, norms, block records, {gen, status}
+    // hoisted target term of the float32 scan (greedy_hoist_kernels.hip): window norms (per database, layout and
+    // weights), left operands and products of the utterances in work
+    DevBuf gh_nw, gh_max, gh_aq, gh_qn2, gh_W;
+    bool gh_ready = false;
+    double gh_fwmax2 = 0.0;
+    int64_t greedy_hoist_launches = 0;    // scans that read the hoisted target term
+    int64_t greedy_second_rounds = 0, greedy_exact_windows = 0;     // statistics of the float32 scan's exact decisions
+    int greedy_hoist = 1;                 // 1: the float32 scan reads one precomputed target value per window (default)
+    double greedy_hoist_max_gb = 48.0;    // products of one scan group beyond this many GB: the scan computes the target term itself
     int greedy_mode = 2;                  // 2: auto (batches: float32 scan; one utterance: exact scan); 1: float32 prefilter scan in one
                                           // persistent launch (exact decision); 0: exact float64 scan, a launch per step
     int greedy_fallbacks = 0;             // utterance groups the float32 scan could not decide (mass ties) and the exact scan finished
@@ -357,7 +366,8 @@ int snk_destroy(snk_handle h)
                       &h->Qraw, &h->Qp, &h->Qf, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
                       &h->gpath, &h->gdist, &h->gsync, &h->gtiles, &h->cls16_full, &h->cls16_samp,
-                      &h->g32_tabs, &h->g32_vnorm, &h->g32_blk, &h->g32_ctl};
+                      &h->g32_tabs, &h->g32_vnorm, &h->g32_blk, &h->g32_ctl,
+                      &h->gh_nw, &h->gh_max, &h->gh_aq, &h->gh_qn2, &h->gh_W};
     for (auto *b : bufs) b->release();
     if (h->dp_stream[1]) (void)hipStreamDestroy(h->dp_stream[1]);
     h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
@@ -431,6 +441,7 @@ int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt, const flo
     h->have_classes = false;
     h->have_glay = false;
     h->gtiles_ready = false;
+    h->gh_ready = false;
     h->gs_rows = 0; h->gs_ready = false;
     if (h->global_N < 0) { h->shard_offset = 0; }
     if (JC_unw) CHK(upload_join(h, JC_unw, Njc, Dj));
@@ -526,6 +537,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
                                h->Djpad, h->stream);
     }
     HIPCHK(hipGetLastError());
+    h->gh_ready = false;                  // window norms of the hoisted greedy target term follow the target weights
     // float32 operands of the prefilter (knn16_kernels.hip): ||f||^2 rides in ONE spare padding column
     h->f16_ready = false;
     h->cls16_ready = false;
@@ -1569,6 +1581,7 @@ int snk_set_greedy_layout(snk_handle h, int multiepoch, int last_frame_as_target
     h->glay = g;
     h->have_glay = true;
     h->gtiles_ready = false;
+    h->gh_ready = false;
     return 0;
 }
 
@@ -1578,7 +1591,43 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
                           bool approx, bool want_dist, bool *undecided)
 {
     const GreedyLayout &g = h->glay;
-    const int nblk = greedy32_blocks(g, h->Dt, h->n_cus);
+    // the target term of all steps as one matrix product per utterance; the scan then streams the join columns only
+    G32Hoist hst{};
+    bool hoist = h->greedy_hoist && greedy_hoist_supported(g, h->Dt);
+    if (hoist) {
+        const int64_t Wp = greedy_hoist_pitch(g);
+        const int KA = greedy_hoist_k(g, h->Dt);
+        int64_t rows = 0, prows = 0;
+        for (int u = 0; u < nu; ++u) { rows += ns[u]; prows += greedy_hoist_rows(ns[u]); }
+        if ((double)rows * (double)Wp * 4.0 > h->greedy_hoist_max_gb * 1e9) hoist = false;
+        if (hoist) {
+            if (!h->gh_ready) {
+                CHK(h->gh_nw.ensure((size_t)Wp * sizeof(double)));
+                CHK(h->gh_max.ensure(64));
+                launch_hoist_window_norms(g, h->fnorm.as<double>(), h->gh_nw.as<double>(), h->gh_max.as<unsigned long long>(), h->stream);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(&h->gh_fwmax2, h->gh_max.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                h->gh_ready = true;
+            }
+            CHK(h->gh_aq.ensure((size_t)prows * KA * sizeof(double)));
+            CHK(h->gh_qn2.ensure((size_t)prows * sizeof(double)));
+            CHK(h->gh_W.ensure((size_t)rows * (size_t)Wp * sizeof(float)));
+            int64_t r0 = 0, p0 = 0;
+            for (int u = 0; u < nu; ++u) {
+                float *W = h->gh_W.as<float>() + (size_t)r0 * Wp;
+                double *qn2 = h->gh_qn2.as<double>() + p0;
+                launch_hoist_product(g, h->F_unw.as<float>(), h->Fp, h->N, h->Dt, h->wt.as<double>(), h->Qraw.as<double>(), q_off[u], ns[u],
+                                     h->gh_nw.as<double>(), h->gh_aq.as<double>() + (size_t)p0 * KA, qn2, W, h->stream);
+                hst.W[u] = W; hst.qn2[u] = qn2;
+                r0 += ns[u]; p0 += greedy_hoist_rows(ns[u]);
+            }
+            HIPCHK(hipGetLastError());
+            hst.Wp = Wp; hst.c = greedy_hoist_c(g, h->Dt); hst.fwmax2 = h->gh_fwmax2;
+            h->greedy_hoist_launches += 1;
+        }
+    }
+    const int nblk = greedy32_blocks(g, h->Dt, h->n_cus, hoist);
     CHK(h->g32_tabs.ensure(2 * greedy32_table_floats(g, h->Dt) * sizeof(float) + 512));
     CHK(h->g32_vnorm.ensure(8 * sizeof(double)));
     CHK(h->g32_blk.ensure(greedy32_block_bytes(nblk)));
@@ -1589,12 +1638,14 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
     launch_greedy32(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
                     h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nu, q_off, ns, oo, st, approx ? 1 : 0,
                     h->g32_tabs.as<float>(), h->g32_vnorm.as<double>(), h->g32_blk.p, h->n_cus, h->gsync.as<unsigned int>(), gen,
-                    status, h->gpath.as<int64_t>(), h->stream);
+                    status, h->gpath.as<int64_t>(), hoist ? &hst : nullptr, h->stream);
     HIPCHK(hipGetLastError());
-    int64_t stv = 0;
-    HIPCHK(hipMemcpyAsync(&stv, status, sizeof(stv), hipMemcpyDeviceToHost, h->stream));
+    int64_t stv[3] = {0, 0, 0};            // undecided step + 1 | second-phase rounds | windows decided by exact totals
+    HIPCHK(hipMemcpyAsync(stv, status, sizeof(stv), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    *undecided = stv != 0;
+    *undecided = stv[0] != 0;
+    h->greedy_second_rounds += stv[1];
+    h->greedy_exact_windows += stv[2];
     if (!*undecided && want_dist) {
         for (int u = 0; u < nu; ++u)
             launch_greedy32_dist(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
@@ -1605,14 +1656,15 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
     return 0;
 }
 
-// greedy_mode 2 (default): the float32 scan where it pays -- several utterances share every pass over the database
-// (three per scan: 57 k against 29 k frames/s at 1.5 M units), a single utterance goes through the exact scan
-// (both are bound by the same HBM stream, and at 65 536 units the launch per step is cheaper than the in-kernel
-// hand-off).  Same paths and distances either way.
+// greedy_mode 2 (default): the float32 scan where it pays -- always with the hoisted target term (the scan streams the
+// join columns only: 202 against 262 us per step at 1.5 M units, 22 against 28 at 65 536); without it, when several
+// utterances share every pass over the database (three per scan); a single utterance then goes through the exact
+// scan.  Same paths and distances either way.
 static bool use_greedy32(const snk_engine *h, int n_utts)
 {
     if (!greedy32_supported(h->glay, h->Dt)) return false;
-    return h->greedy_mode == 1 || (h->greedy_mode == 2 && n_utts >= 2);
+    const bool hoist = h->greedy_hoist && greedy_hoist_supported(h->glay, h->Dt);
+    return h->greedy_mode == 1 || (h->greedy_mode == 2 && (n_utts >= 2 || hoist));
 }
 
 int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_state, double eps,
@@ -2579,6 +2631,12 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "batch_rows")) {
         if (value < 0 || value > SNK_KNN_MAX_ROWS) return fail("batch_rows must be in 0..%d (0: one K-NN call per utterance)", (int)SNK_KNN_MAX_ROWS);
         h->batch_rows = (int)value;
+    } else if (!strcmp(name, "greedy_hoist")) {
+        if (value != 0.0 && value != 1.0) return fail("greedy_hoist must be 0 or 1");
+        h->greedy_hoist = (int)value;
+    } else if (!strcmp(name, "greedy_hoist_max_gb")) {
+        if (!(value >= 0.0)) return fail("greedy_hoist_max_gb must be >= 0");
+        h->greedy_hoist_max_gb = value;
     } else if (!strcmp(name, "greedy_mode")) {
         if (value != 0.0 && value != 1.0 && value != 2.0) return fail("greedy_mode must be 0 (exact scan, a launch per step), 1 (float32 prefilter scan, one launch) or 2 (auto)");
         h->greedy_mode = (int)value;
@@ -2624,6 +2682,10 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "pool_overflows")) *out = h->pool_overflows;
     else if (!strcmp(name, "viterbi_mode")) *out = h->viterbi_mode;
     else if (!strcmp(name, "greedy_mode")) *out = h->greedy_mode;
+    else if (!strcmp(name, "greedy_hoist")) *out = h->greedy_hoist;
+    else if (!strcmp(name, "greedy_hoist_launches")) *out = (double)h->greedy_hoist_launches;
+    else if (!strcmp(name, "greedy_exact_windows")) *out = (double)h->greedy_exact_windows;
+    else if (!strcmp(name, "greedy_second_rounds")) *out = (double)h->greedy_second_rounds;
     else if (!strcmp(name, "greedy_fallbacks")) *out = h->greedy_fallbacks;
     else if (!strcmp(name, "greedy_second_phase_rounds") || !strcmp(name, "greedy_exact_windows")) {
         // statistics of the most recent float32 scan launch: steps that needed every lane's candidates; windows

@@ -160,14 +160,29 @@ bool greedy_supported(const GreedyLayout &g, int Dt);
 // float32 prefilter scan, one persistent launch per utterance group (greedy32_kernels.hip)
 bool greedy32_supported(const GreedyLayout &g, int Dt);
 int greedy32_max_utts();
-int greedy32_blocks(const GreedyLayout &g, int Dt, int n_cus);
-size_t greedy32_table_floats(const GreedyLayout &g, int Dt);
+int greedy32_blocks(const GreedyLayout &g, int Dt, int n_cus, bool hoist = false);
+size_t greedy32_table_floats(const GreedyLayout &g, int Dt, bool hoist = false);
+// hoisted target term (greedy_hoist_kernels.hip): what the scan reads instead of the target columns
+struct G32Hoist {
+    const float *W[3];        // per utterance: (nsteps x Wp) float32 target terms
+    const double *qn2[3];     // per utterance: ||target vector of the step||^2
+    int64_t Wp;
+    double c, fwmax2;         // bound |W~ - W| <= 2^-24 W + c (||q|| + sqrt(fwmax2))^2
+};
+int64_t greedy_hoist_pitch(const GreedyLayout &g);
+int greedy_hoist_k(const GreedyLayout &g, int Dt);
+bool greedy_hoist_supported(const GreedyLayout &g, int Dt);
+double greedy_hoist_c(const GreedyLayout &g, int Dt);
+int64_t greedy_hoist_rows(int64_t nsteps);
+void launch_hoist_window_norms(const GreedyLayout &g, const double *fnorm, double *nw, unsigned long long *max_bits, hipStream_t s);
+void launch_hoist_product(const GreedyLayout &g, const float *F_unw, int Fp, int64_t n_f_rows, int Dt, const double *wt, const double *Q,
+                          int64_t q_off, int64_t nsteps, const double *nw, double *Aq, double *qn2, float *W, hipStream_t s);
 size_t greedy32_block_bytes(int nblk);
 void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
                      int Dj, const double *wj, const float *tiles, const double *Q, int nu, const int64_t *q_off,
                      const int64_t *nsteps_u, const int64_t *out_off, const int64_t *start, int approx, float *tabs,
                      double *vnorm2, void *blk, int n_cus, unsigned int *arrive, unsigned int *gen, int64_t *status,
-                     int64_t *path, hipStream_t s);
+                     int64_t *path, const G32Hoist *hoist, hipStream_t s);
 void launch_greedy32_dist(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
                           int Dj, const double *wj, const double *Q, int u_slot, int64_t q_off, int64_t nsteps, int64_t out_off,
                           int64_t start, const int64_t *path, double *dist, hipStream_t s);

@@ -1,0 +1,110 @@
+"""The hoisted target term of the greedy search (greedy_hoist_kernels.hip: ||Q[s] - Fwin[i]||^2 of all steps and
+windows as one float64 matrix product per utterance; the scan then streams the join columns only).  It only
+prefilters: paths and distances must stay the oracle's bit for bit (synth_simple.py:458-503), in every layout, with
+large norms (the expansion cancels), after a change of weights, and when the product is not used at all."""
+import numpy as np
+import pytest
+
+import snk_oracle as o
+import snk_oracle_c as oc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def engine():
+    import snickery_amd
+    e = snickery_amd.HipSearchEngine(0)
+    yield e
+    e.close()
+
+
+def _setup(engine, N, Dt, Dj, seed, me, lfat, mode, offset=0.0):
+    F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed)
+    if offset:
+        F_unw = (F_unw + np.float32(offset)).astype(np.float32)
+    rng = np.random.RandomState(seed + 100)
+    wt, wj = 0.2 + rng.rand(Dt), 0.05 + 0.2 * rng.rand(Dj)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    engine.set_greedy_layout(me, lfat, mode)
+    return F_unw, JC_unw, wt, wj
+
+
+@pytest.mark.parametrize('me,lfat,mode,Dj,Dt,offset', [(6, False, 0, 151, 61, 0.0), (3, True, 0, 100, 61, 0.0), (4, False, 1, 302, 61, 0.0),
+                                                      (1, False, 0, 70, 61, 0.0), (6, False, 0, 151, 61, 8.0), (5, True, 1, 200, 130, -3.0),
+                                                      (2, False, 0, 96, 64, 0.0), (7, False, 0, 151, 65, 0.0)])
+def test_hoisted_scan_equals_oracle(engine, me, lfat, mode, Dj, Dt, offset):
+    N = 30000 + me
+    engine.set_option('greedy_mode', 2)
+    engine.set_option('greedy_hoist', 1)
+    F_unw, JC_unw, wt, wj = _setup(engine, N, Dt, Dj, seed=3 * me + Dt, me=me, lfat=lfat, mode=mode, offset=offset)
+    # 1, 16, 17 and 33 steps (the product works on blocks of 16 steps), an utterance shorter than a window
+    lens = [33 * me + (me - 1), 16 * me, 17 * me, me, max(me - 1, 1)]
+    utts = [o.synthetic_targets(F_unw, T, seed=6 + i) * wt for i, T in enumerate(lens)]
+    starts = [-1, 17, N - me - 3, 0, -1]
+    before = engine.info('greedy_hoist_launches')
+    for U, st in zip(utts[:3], starts[:3]):           # one utterance per call: the hoisted scan in auto mode
+        path, d = engine.greedy(U, start_state=st, return_distances=True)
+        op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, U, me, lfat, mode, st)
+        assert path == op and np.array_equal(d, od)
+    assert engine.info('greedy_hoist_launches') == before + 3
+    paths, dists = engine.greedy_batch(utts, start_states=starts, return_distances=True)
+    for U, st, p, d in zip(utts, starts, paths, dists):
+        op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, U, me, lfat, mode, st)
+        assert p == op and np.array_equal(d, od)
+    assert engine.info('greedy_fallbacks') == 0
+    # other weights: the window norms of the product follow them
+    wt2, wj2 = wt[::-1].copy() * 1.7, wj * 0.3
+    engine.set_weights(wt2, wj2)
+    U2 = o.synthetic_targets(F_unw, 20 * me, seed=77) * wt2
+    path, d = engine.greedy(U2, return_distances=True)
+    op, od = oc.greedy_f32(F_unw, JC_unw, wt2, wj2, U2, me, lfat, mode, -1)
+    assert path == op and np.array_equal(d, od)
+    # the same without the product (switched off; and refused for its size): nothing but the time may change
+    for opt, val in (('greedy_hoist', 0), ('greedy_hoist_max_gb', 1e-6)):
+        engine.set_option('greedy_hoist', 1); engine.set_option('greedy_hoist_max_gb', 48.0)
+        engine.set_option(opt, val)
+        n0 = engine.info('greedy_hoist_launches')
+        p3, d3 = engine.greedy_batch([U2, U2[:7 * me]], return_distances=True)
+        assert engine.info('greedy_hoist_launches') == n0
+        assert p3[0] == op and np.array_equal(d3[0], od) and p3[1] == op[:7] and np.array_equal(d3[1], od[:7])
+    engine.set_option('greedy_hoist', 1); engine.set_option('greedy_hoist_max_gb', 48.0)
+
+
+def test_narrow_join_streams_keep_the_unhoisted_scan(engine):
+    """Fewer than three 32-column join chunks: the scan computes the target term itself (greedy_hoist_supported)."""
+    engine.set_option('greedy_mode', 2)
+    F_unw, JC_unw, wt, wj = _setup(engine, 20000, 61, 40, seed=5, me=4, lfat=False, mode=0)
+    U = o.synthetic_targets(F_unw, 40, seed=1) * wt
+    n0 = engine.info('greedy_hoist_launches')
+    paths, dists = engine.greedy_batch([U, U[:20]], return_distances=True)
+    op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, U, 4, False, 0, -1)
+    assert paths[0] == op and np.array_equal(dists[0], od) and engine.info('greedy_hoist_launches') == n0
+
+
+def test_ties_and_near_ties_with_the_hoisted_term(engine):
+    """Duplicated speech (exact three-way ties: lowest index by float64 totals), clean targets (distance 0: the
+    product's ABSOLUTE bound is all there is) and targets a hair away from the database."""
+    N, Dt, Dj, me = 60000, 61, 151, 6
+    engine.set_option('greedy_mode', 2)
+    F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, 31)
+    for dst in (25000, 47011):
+        F_unw[dst:dst + 400] = F_unw[3000:3400]
+        JC_unw[dst:dst + 401] = JC_unw[3000:3401]
+    rng = np.random.RandomState(131)
+    wt, wj = 0.2 + rng.rand(Dt), 0.05 + 0.2 * rng.rand(Dj)
+    engine.upload_db(F_unw, JC_unw); engine.set_weights(wt, wj); engine.set_greedy_layout(me, False, 0)
+    U = F_unw[3100:3100 + 20 * me].astype(np.float64) * wt
+    n0 = engine.info('greedy_hoist_launches')
+    path, d = engine.greedy(U, start_state=3100, return_distances=True)
+    assert path == list(range(3100, 3100 + 20 * me, me)) and np.all(d == 0.0)
+    Un = (F_unw[3100:3100 + 10 * me].astype(np.float64) + 1e-7 * rng.randn(10 * me, Dt)) * wt
+    path, d = engine.greedy(Un, return_distances=True)
+    op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, Un, me, False, 0, -1)
+    assert path == op and np.array_equal(d, od)
+    assert engine.info('greedy_hoist_launches') == n0 + 2 and engine.info('greedy_fallbacks') == 0
+    # search_epsilon > 0 on clean targets: the float32 minimum may only be taken where the bound is small against it
+    for eps in (10.0, 0.05):
+        pe, de = engine.greedy(U, start_state=3100, search_epsilon=eps, return_distances=True)
+        assert np.all(de == 0.0)                       # nearest distance 0: (1 + eps) 0 leaves no slack at all
