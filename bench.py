@@ -140,7 +140,8 @@ def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')),
     multiepoch 6, search_epsilon 0, one 600-frame utterance = 100 scans of the whole database.  Extra fields of the
     JSON line (never `value`): device time per step from the engine's HIP events, frames/s from the wall clock,
     fraction of the 8 TB/s HBM peak on the scan's algorithmic bytes (Dj + 1) * 4 * N per step (`streamed_frac`
-    on the (Dj + Dt) * 4 * N bytes this kernel actually streams)."""
+    on the bytes the kernels actually move).  The time per step includes the utterance's share of the float64 matrix product
+    that hoists the target term (greedy_hoist_kernels.hip)."""
     import snickery_amd
     out = {}
     for N, name in configs:
@@ -162,10 +163,12 @@ def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')),
         ms, launches = eng.timers()['greedy_steps']
         us_step = ms / max(launches, 1) / steps * 1e3
         # algorithmic bytes per step as SURVEY 8d defines them: the join columns of every window + ONE precomputed target
-        # value per window (target term hoisted into a matrix product over all steps).  This kernel does not hoist it: it
-        # streams the Dt target columns instead (bytes_streamed) -- `frac` is priced on the algorithmic figure.
+        # value per window (target term hoisted into a matrix product over all steps).  Streamed: the join columns rounded
+        # up to whole float4 columns, the target value written once by the product and read once by the scan -- or, where
+        # the product is not used (greedy_hoist 0, narrow join streams), the Dt target columns instead.
+        hoisted = eng.info('greedy_hoist_launches') > 0
         bytes_step = float(N) * (Dj + 1) * 4.0
-        bytes_streamed = float(N) * (Dj + Dt) * 4.0
+        bytes_streamed = float(N) * (((Dj + 3) // 4 * 4 + 2) if hoisted else (Dj + Dt)) * 4.0
         # a batch through snk_greedy_batch: the float32 prefilter scan, three utterances per scan of the database
         # (one persistent launch), exact float64 decisions -- the same paths
         nb = 6
@@ -180,6 +183,7 @@ def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')),
                  'roofline': {'bound': 'hbm', 'achieved': bfrac * 8000.0, 'peak': 8000.0, 'unit': 'GB/s', 'frac': bfrac,
                               'note': 'one scan of the database serves three utterances: the scan\'s algorithmic bytes / 3 per utterance step'}}
         out[name] = {'units': N, 'multiepoch': me, 'frames': T, 'steps': steps, 'us_per_step': us_step, 'batch': batch,
+                     'target_term_hoisted': bool(hoisted),
                      'frames_per_s': T / dt, 'ms_per_utterance': dt * 1e3,
                      'roofline': {'bound': 'hbm', 'achieved': bytes_step / (us_step * 1e-6) / 1e9, 'peak': 8000.0,
                                   'unit': 'GB/s', 'frac': bytes_step / (us_step * 1e-6) / 8e12,

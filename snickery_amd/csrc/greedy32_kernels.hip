@@ -29,6 +29,9 @@
 //
 // Data layout, request ring, LDS target blocks and chunk order are those of greedy_kernels.hip.
 #include "greedy_common.h"
+#include <stdlib.h>
+#include <stdio.h>
+#include <vector>
 
 namespace snk {
 
@@ -36,6 +39,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define G32_W 64
 #define G32_MAXW 8
 #define G32_HOIST_NSTG 3      // ring stages of the hoisted scan (little arithmetic to hide requests behind: three chunks ahead)
+#define G32_TRACE_STEPS 64
 #define G32_UB 3              // utterances per scan: (w, ref0, ref1, ref2) = 16 table bytes per column
 
 struct G32Rec {               // what a workgroup publishes per utterance and step
@@ -223,8 +227,14 @@ template <bool IN_LDS, bool HOIST>
 __global__ void __launch_bounds__(G32_W * G32_MAXW)
 greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2, int approx, int use_nt, int lds_bytes,
                 float *tabs, double *vnorm2, G32Rec *blk, unsigned int *arrive, unsigned int *arrive2, unsigned int *gen,
-                G32Ctl *ctl, int64_t *clist_g, int64_t *path, int64_t *status)       // shared between workgroups: no restrict
+                G32Ctl *ctl, int64_t *clist_g, int64_t *path, int64_t *status,       // shared between workgroups: no restrict
+                unsigned long long *trace)
 {
+    // optional timeline (SNK_G32_TRACE=file): 8 stamps of the 100 MHz clock per step and workgroup, steps 0 .. G32_TRACE_STEPS - 1
+    auto stamp = [&](int64_t st, int k) {
+        if (trace && st < G32_TRACE_STEPS && threadIdx.x == 0)
+            trace[((size_t)st * gridDim.x + blockIdx.x) * 16 + k] = __builtin_amdgcn_s_memrealtime();
+    };
     extern __shared__ __align__(16) char lds[];          // table | one target block per wavefront (lds_mode 1)
     __shared__ int is_last, gen_seen;
     int collect_rounds = 0;                               // second-phase rounds so far (the same in every workgroup)
@@ -260,6 +270,69 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
 
     int64_t prev_row[G32_UB] = {s0, s1, s2};               // winners of the previous step (start states first)
 
+    // request ring
+    int f_tile = wave_id, f_pos = 0;
+    f32x4 stage[NSTG][8];
+    // hoisted target values of the tile in work and of the next one (one float per window and utterance)
+    float wcur[G32_UB] = {0.f, 0.f, 0.f}, wnext[G32_UB] = {0.f, 0.f, 0.f};
+    const float *wrow[G32_UB] = {nullptr, nullptr, nullptr};
+    auto fetch = [&](f32x4 (&st)[8], int pin0) {
+        const int t = f_tile < ntiles ? f_tile : ntiles - 1;
+        if (HOIST && f_pos == 0) {
+            // the first request of a tile is issued before the previous tile's last chunk is summed (jch >= 2)
+#pragma unroll
+            for (int u = 0; u < G32_UB; ++u) {
+                wcur[u] = wnext[u];
+                if (wrow[u]) wnext[u] = __builtin_nontemporal_load(wrow[u] + (size_t)t * G32_W);
+            }
+        }
+        const char *base;
+        unsigned voff = off_own;
+        if (in_lds) {
+            if (f_pos < tch) base = FTb + (((size_t)t * FQ + f_pos * 8) << 10);
+            else if (f_pos < tch + nB) { base = FTb + (((size_t)(t + 1) * FQ + (f_pos - tch) * 8) << 10); voff = off_extra; }
+            else { base = JTb + (((size_t)t * JQ + (f_pos - tch - nB) * 8) << 10); voff = off_join; }
+        } else if (f_pos < jch) {
+            base = JTb + (((size_t)t * JQ + f_pos * 8) << 10); voff = off_join;
+        } else {
+            const int k = (f_pos - jch) / tch, cc = (f_pos - jch) - k * tch;
+            const unsigned fl = (unsigned)lane + (unsigned)a.ep[k];
+            base = FTb + (((size_t)t * FQ + cc * 8) << 10);
+            voff = (fl >> 6) * ((unsigned)FQ << 10) + (fl & 63u) * 16u;
+        }
+        voff += (unsigned)pin0;
+        // nt for databases that are streamed from HBM every step; small ones stay in L2 / Infinity Cache
+        if (HOIST && use_nt == 2) {
+            // the last join chunk of a streamed database: float4 columns that are padding altogether (151 columns:
+            // 38 of 40) are not asked from HBM a second time -- their requests repeat the chunk's first column
+            // (weight 0 turns any finite value into +0).  Eight requests either way: the counted waits of the
+            // ring stay static (a conditional number of requests cost 3 us per step at 65 536 units).
+            const int lim = f_pos == jch - 1 ? jq_last : 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                st[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + voff + (j < lim ? 1024 * j : 0)));
+        } else if (use_nt && (in_lds || f_pos < jch)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                st[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + voff + 1024 * j));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st[j] = *reinterpret_cast<const f32x4 *>(base + voff + 1024 * j);
+        }
+        asm volatile("" ::: "memory");
+        if (++f_pos == ring_per_tile) { f_pos = 0; f_tile += wave_stride; }
+    };
+    // the first NSTG - 1 requests of step st: tile data does not depend on the step's table, only the references do
+    auto start_fetch = [&](int64_t st) {
+        f_tile = wave_id; f_pos = 0;
+#pragma unroll
+        for (int u = 0; u < G32_UB; ++u) {
+            wcur[u] = 0.f; wnext[u] = 0.f;
+            wrow[u] = (HOIST && u < a.nu && st < a.nsteps_u[u]) ? a.W[u] + st * a.Wp + lane : nullptr;
+        }
+#pragma unroll
+        for (int s = 0; s < NSTG - 1; ++s) fetch(stage[s], 0);
+    };
     for (int64_t step = 0; step < nsteps; ++step) {
         // ---- wait for the step's table (written by the workgroup that decided the previous step) ----
         // generation 2 step + 1: the table of this step is complete (0xffffffff: an earlier step was undecidable)
@@ -271,64 +344,10 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
         }
         __syncthreads();
         if (step > 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;     // an undecidable step: everybody leaves
+        stamp(step, 0);
         const float *tab = tabs + (step & 1) * tab_floats;
 
-        int f_tile = wave_id, f_pos = 0;
-        f32x4 stage[NSTG][8];
-        // hoisted target values of the tile in work and of the next one (one float per window and utterance)
-        float wcur[G32_UB] = {0.f, 0.f, 0.f}, wnext[G32_UB] = {0.f, 0.f, 0.f};
-        const float *wrow[G32_UB];
-#pragma unroll
-        for (int u = 0; u < G32_UB; ++u)
-            wrow[u] = (HOIST && u < a.nu && step < a.nsteps_u[u]) ? a.W[u] + step * a.Wp + lane : nullptr;
-        auto fetch = [&](f32x4 (&st)[8], int pin0) {
-            const int t = f_tile < ntiles ? f_tile : ntiles - 1;
-            if (HOIST && f_pos == 0) {
-                // the first request of a tile is issued before the previous tile's last chunk is summed (jch >= 2)
-#pragma unroll
-                for (int u = 0; u < G32_UB; ++u) {
-                    wcur[u] = wnext[u];
-                    if (wrow[u]) wnext[u] = __builtin_nontemporal_load(wrow[u] + (size_t)t * G32_W);
-                }
-            }
-            const char *base;
-            unsigned voff = off_own;
-            if (in_lds) {
-                if (f_pos < tch) base = FTb + (((size_t)t * FQ + f_pos * 8) << 10);
-                else if (f_pos < tch + nB) { base = FTb + (((size_t)(t + 1) * FQ + (f_pos - tch) * 8) << 10); voff = off_extra; }
-                else { base = JTb + (((size_t)t * JQ + (f_pos - tch - nB) * 8) << 10); voff = off_join; }
-            } else if (f_pos < jch) {
-                base = JTb + (((size_t)t * JQ + f_pos * 8) << 10); voff = off_join;
-            } else {
-                const int k = (f_pos - jch) / tch, cc = (f_pos - jch) - k * tch;
-                const unsigned fl = (unsigned)lane + (unsigned)a.ep[k];
-                base = FTb + (((size_t)t * FQ + cc * 8) << 10);
-                voff = (fl >> 6) * ((unsigned)FQ << 10) + (fl & 63u) * 16u;
-            }
-            voff += (unsigned)pin0;
-            // nt for databases that are streamed from HBM every step; small ones stay in L2 / Infinity Cache
-            if (HOIST && use_nt == 2) {
-                // the last join chunk of a streamed database: float4 columns that are padding altogether (151 columns:
-                // 38 of 40) are not asked from HBM a second time -- their requests repeat the chunk's first column
-                // (weight 0 turns any finite value into +0).  Eight requests either way: the counted waits of the
-                // ring stay static (a conditional number of requests cost 3 us per step at 65 536 units).
-                const int lim = f_pos == jch - 1 ? jq_last : 8;
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    st[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + voff + (j < lim ? 1024 * j : 0)));
-            } else if (use_nt && (in_lds || f_pos < jch)) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    st[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + voff + 1024 * j));
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) st[j] = *reinterpret_cast<const f32x4 *>(base + voff + 1024 * j);
-            }
-            asm volatile("" ::: "memory");
-            if (++f_pos == ring_per_tile) { f_pos = 0; f_tile += wave_stride; }
-        };
-#pragma unroll
-        for (int s = 0; s < NSTG - 1; ++s) fetch(stage[s], 0);
+        start_fetch(step);
 
         // the step's table -> LDS (sc1 loads: another compute unit wrote it moments ago)
         {
@@ -337,6 +356,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
             for (int e = tid; e < ncols; e += blockDim.x) dst[e] = __builtin_amdgcn_raw_buffer_load_b128(tres, e * 16, 0, 16);
         }
         __syncthreads();
+        stamp(step, 1);
 
         Top3 best[G32_UB];
         float acc[G32_UB];                                    // ONE float32 total per utterance: the bound holds for any order
@@ -425,6 +445,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
             }
         }
         __syncthreads();                                      // the reduction arrays alias the table and the target blocks
+        stamp(step, 2);
 
         // ---- workgroup top-3 per utterance -> global memory (sc1), arrival tree ----
 #pragma unroll
@@ -524,12 +545,24 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
             if (tid == 0) __hip_atomic_store(gen, (unsigned int)(2 * step + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
 
+        stamp(step, 3);
         if (arrive_last(arrive, (unsigned int)step + 1u)) {
             // ---- first decision, from the published two best windows of every workgroup ----
+            stamp(step, 4);
             load_prev();
             int64_t winner[G32_UB] = {0, 0, 0};
             unsigned int need = 0u;
             bool undecided = false;
+            // everything the decision reads from memory is requested up front (one fabric round trip for the records,
+            // the reference norms and the bound's terms together: they cost 2 - 2.5 us each when asked one by one)
+            double V2r[G32_UB], EWr[G32_UB];
+#pragma unroll
+            for (int u = 0; u < G32_UB; ++u) {
+                V2r[u] = 0.0; EWr[u] = 0.0;
+                if (!(u < a.nu && step < a.nsteps_u[u])) continue;      // uniform
+                V2r[u] = __hip_atomic_load(&vnorm2[(step & 1) * G32_UB + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (HOIST) EWr[u] = g32_hoist_err(a, u, step);
+            }
 #pragma unroll
             for (int u = 0; u < G32_UB; ++u) {
                 if (!(u < a.nu && step < a.nsteps_u[u])) continue;      // uniform
@@ -567,25 +600,26 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
                 int64_t *wi = reinterpret_cast<int64_t *>(lds + 64);
                 if (lane == 0) { wv[wave] = mv; wi[wave] = mi; }
                 __syncthreads();
+                if (u == 0) stamp(step, 8);
                 mv = wv[0]; mi = wi[0];
                 for (int w = 1; w < nwaves; ++w) if (lt_vi(wv[w], wi[w], mv, mi)) { mv = wv[w]; mi = wi[w]; }
                 __syncthreads();
                 if (!(mv < __builtin_inff())) { undecided = true; continue; }
-                const double EW = HOIST ? g32_hoist_err(a, u, step) : 0.0;
+                const double EW = EWr[u];
                 // search_epsilon mode: the float32 minimum is the answer -- with a hoisted target term only where its
                 // ABSOLUTE bound is small against the minimum (it is not for near-exact matches: decided exactly then)
-                if (approx && (!HOIST || 4.0 * (g32_err((double)mv, __hip_atomic_load(&vnorm2[(step & 1) * G32_UB + u], __ATOMIC_RELAXED,
-                                                                                     __HIP_MEMORY_SCOPE_AGENT), ecols) + EW) <= 1e-3 * (double)mv)) {
+                if (approx && (!HOIST || 4.0 * (g32_err((double)mv, V2r[u], ecols) + EW) <= 1e-3 * (double)mv)) {
                     winner[u] = mi;
                     continue;
                 }
                 // tau = the largest solution of tau = M + 2 E(tau), approached from above (E(0) = 0: from below the
                 // iteration would stall at M = 0, where the natural path lives)
-                const double V2 = __hip_atomic_load(&vnorm2[(step & 1) * G32_UB + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double V2 = V2r[u];
                 const double M = (double)mv + 2.0 * EW;
                 double tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300;
                 for (int it = 0; it < 8; ++it) tau = M + 2.0 * g32_err(tau, V2, ecols);
                 tau = tau * (1.0 + 1e-6) + 1e-300;
+                if (u == 0) stamp(step, 9);
                 int *ccount = reinterpret_cast<int *>(lds);
                 int *cover = reinterpret_cast<int *>(lds + 32);
                 int64_t *clist = reinterpret_cast<int64_t *>(lds + 128);               // up to 512 candidates
@@ -600,6 +634,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
                 __syncthreads();
                 const int nc = *ccount;
                 const bool cov = *cover != 0;
+                if (u == 0) stamp(step, 10);
                 if (cov) {
                     // every lane still holds its own three best: ask all of them (generation 2 step + 2)
                     need |= 1u << u;
@@ -614,8 +649,10 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
                 if (tid == 0) status[2] += nc;                  // statistics: windows decided by exact totals
                 winner[u] = exact_argmin(u, nc, [&](int p) { return clist[p]; });
             }
+            stamp(step, 5);
             if (need == 0u || undecided) {
                 finalize(winner, undecided);
+                stamp(step, 6);
             } else {
                 if (tid == 0) {
 #pragma unroll
@@ -628,6 +665,9 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
                 __syncthreads();
             }
         }
+        // (Issuing the next step's first requests here, while this step is decided, was tried: the scan ended 1.4 us
+        // earlier and the deciding workgroup's loads took 0.8 us longer beside everybody's requests -- the step stayed
+        // at 21 us at 65 536 units, 194 us at 1.5 M.)
         // ---- everybody: the next generation is either the next step's table or a request for candidates ----
         if (tid == 0) {
             unsigned int g;
@@ -636,6 +676,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
             gen_seen = (int)g;
         }
         __syncthreads();
+        stamp(step, 7);
         if (gen_seen == (int)(2 * step + 2)) {
             // second phase: every lane offers its two best windows that reach tau; a third one that does is beyond
             // what was kept (mass ties): the step is then undecidable here
@@ -751,6 +792,24 @@ int greedy32_blocks(const GreedyLayout &g, int Dt, int n_cus, bool hoist)
     return (int)(need < cap ? need : cap);
 }
 
+// developer aid: SNK_G32_TRACE=<file> writes the last launch's timeline (see `stamp` in the kernel) after the caller's sync
+static void *g32_trace_dev = nullptr;
+static int g32_trace_blocks = 0;
+void greedy32_trace_dump()
+{
+    const char *fn = getenv("SNK_G32_TRACE");
+    if (!fn || !g32_trace_dev || !g32_trace_blocks) return;
+    const size_t n = (size_t)G32_TRACE_STEPS * g32_trace_blocks * 16;
+    std::vector<unsigned long long> host(n);
+    if (hipMemcpy(host.data(), g32_trace_dev, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (FILE *f = fopen(fn, "wb")) {
+        const long long hdr[2] = {G32_TRACE_STEPS, g32_trace_blocks};
+        fwrite(hdr, sizeof(hdr), 1, f);
+        fwrite(host.data(), sizeof(unsigned long long), n, f);
+        fclose(f);
+    }
+}
+
 // One persistent launch for up to three utterances (q_off / nsteps_u / out_off / start per utterance).
 // approx != 0: search_epsilon mode (float32 minimum, nothing re-evaluated).  *status (device): 0, or 1 + the
 // first step that could not be decided (mass ties); the caller then falls back to the exact scan.
@@ -796,8 +855,16 @@ void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, 
     char *wb = reinterpret_cast<char *>(blk);
     G32Ctl *ctl = reinterpret_cast<G32Ctl *>(wb + g32_rec_bytes(nblk));
     int64_t *clist = reinterpret_cast<int64_t *>(wb + g32_rec_bytes(nblk) + 256);
+    unsigned long long *trace = nullptr;
+    if (getenv("SNK_G32_TRACE")) {
+        const size_t tb = (size_t)G32_TRACE_STEPS * nblk * 16 * sizeof(unsigned long long);
+        if (!g32_trace_dev) (void)hipMalloc(&g32_trace_dev, (size_t)G32_TRACE_STEPS * 1024 * 16 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(g32_trace_dev, 0, tb, s);
+        trace = reinterpret_cast<unsigned long long *>(g32_trace_dev);
+        g32_trace_blocks = nblk;
+    }
     hipLaunchKernelGGL(kernel, dim3(nblk), dim3(G32_W * waves), lds, s, a, nsteps, st3[0], st3[1], st3[2], approx, use_nt, (int)lds,
-                       tabs, vnorm2, reinterpret_cast<G32Rec *>(blk), arrive, arrive2, gen, ctl, clist, path, status);
+                       tabs, vnorm2, reinterpret_cast<G32Rec *>(blk), arrive, arrive2, gen, ctl, clist, path, status, trace);
 }
 
 void launch_greedy32_dist(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,

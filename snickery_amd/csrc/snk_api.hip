@@ -1643,6 +1643,7 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
     int64_t stv[3] = {0, 0, 0};            // undecided step + 1 | second-phase rounds | windows decided by exact totals
     HIPCHK(hipMemcpyAsync(stv, status, sizeof(stv), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    greedy32_trace_dump();
     *undecided = stv[0] != 0;
     h->greedy_second_rounds += stv[1];
     h->greedy_exact_windows += stv[2];

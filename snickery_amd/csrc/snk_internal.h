@@ -178,6 +178,7 @@ void launch_hoist_window_norms(const GreedyLayout &g, const double *fnorm, doubl
 void launch_hoist_product(const GreedyLayout &g, const float *F_unw, int Fp, int64_t n_f_rows, int Dt, const double *wt, const double *Q,
                           int64_t q_off, int64_t nsteps, const double *nw, double *Aq, double *qn2, float *W, hipStream_t s);
 size_t greedy32_block_bytes(int nblk);
+void greedy32_trace_dump();          // developer aid (SNK_G32_TRACE=file): timeline of the last launch
 void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
                      int Dj, const double *wj, const float *tiles, const double *Q, int nu, const int64_t *q_off,
                      const int64_t *nsteps_u, const int64_t *out_off, const int64_t *start, int approx, float *tabs,
