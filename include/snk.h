@@ -156,10 +156,13 @@ int snk_set_greedy_layout(snk_handle h, int multiepoch, int last_frame_as_target
  *   dist_out  (T / multiepoch) float64 Euclidean distance of each pick (may be NULL)
  *   eps: search_epsilon (`joint_tree.query(..., eps=...)`, :488-490; shipped as 10.0 in
  *        config/slt_simplified_mini.cfg:92).  0: the exact nearest neighbour, lowest index on exact ties.
- *        >= 1e-3 on the float32 scan (option greedy_mode 1, or any batch): the window with the smallest
- *        FLOAT32 total is returned without re-evaluation -- it lies within 1e-3 of the nearest distance,
- *        inside the (1 + eps) contract; dist_out still holds the pick's exact distance.  The exact scan
- *        (one utterance, default) returns the exact neighbour for every eps. */
+ *        >= 1e-3 on the float32 scan (the default wherever the hoisted target term applies -- join streams of
+ *        65 columns and more --, any batch, option greedy_mode 1): the window with the smallest FLOAT32 total is
+ *        returned without re-evaluation where its error bound is below 1e-3 of the nearest distance (inside the
+ *        (1 + eps) contract) and decided exactly otherwise; dist_out still holds the pick's exact distance.
+ *        The exact scan (greedy_mode 0) returns the exact neighbour for every eps.
+ *   The target term of all steps is computed up front as one float64 matrix product per utterance
+ *   (greedy_hoist_kernels.hip; T / multiepoch x N floats of device memory, option greedy_hoist_max_gb). */
 int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_state,
                double eps, int64_t *path_out, double *dist_out, int64_t *nsteps_out);
 /* snk_greedy for several utterances in one call (balance_stream_weights.py:82-92 runs the greedy search
