@@ -166,9 +166,9 @@ int snk_set_greedy_layout(snk_handle h, int multiepoch, int last_frame_as_target
 int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_state,
                double eps, int64_t *path_out, double *dist_out, int64_t *nsteps_out);
 /* snk_greedy for several utterances in one call (balance_stream_weights.py:82-92 runs the greedy search
- * over a tune set, iteration after iteration).  Up to three utterances share every scan of the database:
- * the weighted value of a column is computed once per window and compared with each utterance's
- * reference, and the database is read once per step for all of them.  Rows concatenated in Q,
+ * over a tune set, iteration after iteration).  Up to six utterances share every scan of the database (three
+ * where the hoisted target term does not apply): the weighted value of a column is computed once per window
+ * and compared with each utterance's reference, and the database is read once per step for all of them.  Rows concatenated in Q,
  * row_offsets (n_utts+1); start_states (n_utts) may be NULL (= -1 each); path_out / dist_out hold the
  * utterances' steps one after the other (nsteps_out[u] = rows_u / multiepoch each).  Same results as
  * n_utts calls of snk_greedy. */

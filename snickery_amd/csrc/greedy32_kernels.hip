@@ -41,6 +41,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define G32_HOIST_NSTG 3      // ring stages of the hoisted scan (little arithmetic to hide requests behind: three chunks ahead)
 #define G32_TRACE_STEPS 64
 #define G32_UB 3              // utterances per scan: (w, ref0, ref1, ref2) = 16 table bytes per column
+#define G32_UBX 6             // ... of the hoisted scan's wide instance: (w, ref0 .. ref5, -) = 32 table bytes per column
 
 struct G32Rec {               // what a workgroup publishes per utterance and step
     float v1, v2, v3, pad;
@@ -49,9 +50,9 @@ struct G32Rec {               // what a workgroup publishes per utterance and st
 
 #define G32_LIST 4096          // candidates one second-phase round can take per utterance
 struct G32Ctl {               // second-phase hand-off (global memory, sc1 accesses)
-    double tau[G32_UB];
-    int64_t pending[G32_UB];
-    unsigned int list_count[G32_UB];
+    double tau[G32_UBX];
+    int64_t pending[G32_UBX];
+    unsigned int list_count[G32_UBX];
     unsigned int need, list_over;
 };
 
@@ -149,20 +150,22 @@ __device__ double g32_exact_d2_wave(const GreedyArgs &a, int u, int64_t step, in
 // The float32 table of a step: per scan column, in chunk order, (w, ref0, ref1, ref2) -- and behind it, per
 // utterance, the squared norm of the reference vector (float64, for the error bound).  Written with sc1 stores
 // by the workgroup that decides the previous step.
-__device__ void g32_write_table(const GreedyArgs &a, int64_t step, const int64_t (&prev_row)[G32_UB], bool prev_is_current,
+template <int UB>
+__device__ void g32_write_table(const GreedyArgs &a, int64_t step, const int64_t (&prev_row)[UB], bool prev_is_current,
                                 float *tab, double *vnorm2, double *red, int tid, int nthreads)
 {
     const int jch = greedy_join_chunks(a), tch = greedy_target_chunks(a);
     const int nT = a.hoist ? 0 : a.nep * tch, n = (jch + nT) * GR_CC;          // hoisted target term: join columns only
-    const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(tab, 0, n * 16, 0x00020000);
-    double n2[G32_UB];
+    constexpr int TE = UB <= 3 ? 16 : 32;                        // table bytes per column
+    const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(tab, 0, n * TE, 0x00020000);
+    double n2[UB];
 #pragma unroll
-    for (int u = 0; u < G32_UB; ++u) n2[u] = 0.0;
+    for (int u = 0; u < UB; ++u) n2[u] = 0.0;
     for (int e = tid; e < n; e += nthreads) {
         const int c = e / GR_CC, cc = e % GR_CC;
-        double w = 0.0, ref[G32_UB];
+        double w = 0.0, ref[UB];
 #pragma unroll
-        for (int u = 0; u < G32_UB; ++u) ref[u] = 0.0;
+        for (int u = 0; u < UB; ++u) ref[u] = 0.0;
         int idx;
         if (greedy_chunk_slot(a, jch, nT, c, &idx)) {
             const int col = idx * GR_CC + cc;
@@ -171,7 +174,7 @@ __device__ void g32_write_table(const GreedyArgs &a, int64_t step, const int64_t
                 const int col0 = prev_is_current ? a.cur_col0 : a.prev_col0;
                 const int64_t row0 = prev_is_current ? a.cur_row0 : a.prev_row0;
 #pragma unroll
-                for (int u = 0; u < G32_UB; ++u)
+                for (int u = 0; u < UB; ++u)
                     if (u < a.nu && step < a.nsteps_u[u] && prev_row[u] >= 0)
                         ref[u] = __dmul_rn((double)a.JC_unw[(row0 + prev_row[u]) * a.Jp + col0 + col], a.wj[col0 + col]);
             }
@@ -180,7 +183,7 @@ __device__ void g32_write_table(const GreedyArgs &a, int64_t step, const int64_t
             if (col < a.Dt) {
                 w = a.wt[col];
 #pragma unroll
-                for (int u = 0; u < G32_UB; ++u)
+                for (int u = 0; u < UB; ++u)
                     if (u < a.nu && step < a.nsteps_u[u])
                         ref[u] = a.Q[(a.q_off[u] + step * a.me + a.ep[k]) * a.Dt + col];
             }
@@ -190,23 +193,32 @@ __device__ void g32_write_table(const GreedyArgs &a, int64_t step, const int64_t
         // cost more than the scan of a 65 536-unit voice)
         u32x4 bits = {__builtin_bit_cast(unsigned int, (float)w), __builtin_bit_cast(unsigned int, (float)ref[0]),
                       __builtin_bit_cast(unsigned int, (float)ref[1]), __builtin_bit_cast(unsigned int, (float)ref[2])};
-        __builtin_amdgcn_raw_buffer_store_b128(bits, tres, e * 16, 0, 16);
-#pragma unroll
-        for (int u = 0; u < G32_UB; ++u) n2[u] += ref[u] * ref[u];
-    }
-    // squared norms of the references: block sum (any order: it only scales an error bound, +1 % is added there)
-#pragma unroll
-    for (int u = 0; u < G32_UB; ++u) {
-        if (u >= a.nu) break;                                     // uniform
-        red[tid] = n2[u];
-        __syncthreads();
-        for (int off = 256; off > 0; off >>= 1) {
-            if (tid < off && tid + off < nthreads) red[tid] += red[tid + off];
-            __syncthreads();
+        __builtin_amdgcn_raw_buffer_store_b128(bits, tres, e * TE, 0, 16);
+        if (UB > 3) {
+            u32x4 hi = {__builtin_bit_cast(unsigned int, (float)ref[3 % UB]), __builtin_bit_cast(unsigned int, (float)ref[4 % UB]),
+                        __builtin_bit_cast(unsigned int, (float)ref[5 % UB]), 0u};
+            __builtin_amdgcn_raw_buffer_store_b128(hi, tres, e * TE + 16, 0, 16);
         }
-        if (tid == 0) __hip_atomic_store(&vnorm2[u], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UB; ++u) n2[u] += ref[u] * ref[u];
     }
+    // squared norms of the references: block sums (any order: they only scale an error bound, +1 % is added there);
+    // wavefront shuffles, then one pass over the wavefronts' partial sums
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        double v = n2[u];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if (lane == 0) red[wave * UB + u] = v;
+    }
+    __syncthreads();
+    if (tid < UB && tid < a.nu) {
+        double v = 0.0;
+        for (int w = 0; w < nwaves; ++w) v += red[w * UB + tid];
+        __hip_atomic_store(&vnorm2[tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
 }
 
 // error bound of a float32 total (see the file header); V2 = squared norm of the reference vector
@@ -223,9 +235,9 @@ __device__ __forceinline__ double g32_hoist_err(const GreedyArgs &a, int u, int6
     return a.hoist_c * r * r;
 }
 
-template <bool IN_LDS, bool HOIST>
+template <bool IN_LDS, bool HOIST, int UB>
 __global__ void __launch_bounds__(G32_W * G32_MAXW)
-greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2, int approx, int use_nt, int lds_bytes,
+greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_bytes,
                 float *tabs, double *vnorm2, G32Rec *blk, unsigned int *arrive, unsigned int *arrive2, unsigned int *gen,
                 G32Ctl *ctl, int64_t *clist_g, int64_t *path, int64_t *status,       // shared between workgroups: no restrict
                 unsigned long long *trace)
@@ -250,7 +262,8 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
     const int nB = a.me > 1 ? tch : 0;
     const int ring_per_tile = in_lds ? tch + nB + jch : n_chunks;
     constexpr int NSTG = HOIST ? G32_HOIST_NSTG : GR_NSTG;                         // ring stages: two chunks (16 KB per wavefront) requested ahead of the arithmetic
-    const int table_bytes = ncols * 16;
+    constexpr int TE = UB <= 3 ? 1 : 2;                     // 16-byte pieces of a table entry: (w, ref0, ref1, ref2 | ref3, ref4, ref5, -)
+    const int table_bytes = ncols * 16 * TE;
     float *const Fs = reinterpret_cast<float *>(lds + table_bytes) + (size_t)wave * (G32_W + a.me - 1) * pitch;
     const int ntiles = (int)((a.Nwin + G32_W - 1) / G32_W);
     const int wave_id = blockIdx.x * nwaves + wave, wave_stride = gridDim.x * nwaves;
@@ -262,28 +275,32 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
     const unsigned jl = (unsigned)lane + (unsigned)a.prev_row0;
     const unsigned off_join = (jl >> 6) * ((unsigned)JQ << 10) + (jl & 63u) * 16u;
     const char *const FTb = reinterpret_cast<const char *>(a.FT), *const JTb = reinterpret_cast<const char *>(a.JT);
-    const size_t tab_floats = (size_t)ncols * 4;
+    const size_t tab_floats = (size_t)ncols * 4 * TE;
 
     // reduction scratch of the step's tail aliases the table and the target blocks
     Top3 *red3 = reinterpret_cast<Top3 *>(lds);
     double *redd = reinterpret_cast<double *>(lds);
 
-    int64_t prev_row[G32_UB] = {s0, s1, s2};               // winners of the previous step (start states first)
+    int64_t prev_row[UB];                                  // winners of the previous step (start states first)
+#pragma unroll
+    for (int u = 0; u < UB; ++u) prev_row[u] = a.start[u];
 
     // request ring
     int f_tile = wave_id, f_pos = 0;
     f32x4 stage[NSTG][8];
     // hoisted target values of the tile in work and of the next one (one float per window and utterance)
-    float wcur[G32_UB] = {0.f, 0.f, 0.f}, wnext[G32_UB] = {0.f, 0.f, 0.f};
-    const float *wrow[G32_UB] = {nullptr, nullptr, nullptr};
+    float wcur[UB], wnext[UB];
+    const float *wrow[UB];                                 // uniform: W row of the step; the lane adds its window
+#pragma unroll
+    for (int u = 0; u < UB; ++u) { wcur[u] = 0.f; wnext[u] = 0.f; wrow[u] = nullptr; }
     auto fetch = [&](f32x4 (&st)[8], int pin0) {
         const int t = f_tile < ntiles ? f_tile : ntiles - 1;
         if (HOIST && f_pos == 0) {
             // the first request of a tile is issued before the previous tile's last chunk is summed (jch >= 2)
 #pragma unroll
-            for (int u = 0; u < G32_UB; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 wcur[u] = wnext[u];
-                if (wrow[u]) wnext[u] = __builtin_nontemporal_load(wrow[u] + (size_t)t * G32_W);
+                if (wrow[u]) wnext[u] = __builtin_nontemporal_load(wrow[u] + ((unsigned)t * G32_W + (unsigned)lane));
             }
         }
         const char *base;
@@ -326,9 +343,9 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
     auto start_fetch = [&](int64_t st) {
         f_tile = wave_id; f_pos = 0;
 #pragma unroll
-        for (int u = 0; u < G32_UB; ++u) {
+        for (int u = 0; u < UB; ++u) {
             wcur[u] = 0.f; wnext[u] = 0.f;
-            wrow[u] = (HOIST && u < a.nu && st < a.nsteps_u[u]) ? a.W[u] + st * a.Wp + lane : nullptr;
+            wrow[u] = (HOIST && u < a.nu && st < a.nsteps_u[u]) ? a.W[u] + st * a.Wp : nullptr;
         }
 #pragma unroll
         for (int s = 0; s < NSTG - 1; ++s) fetch(stage[s], 0);
@@ -352,38 +369,41 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
         // the step's table -> LDS (sc1 loads: another compute unit wrote it moments ago)
         {
             u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
-            const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tab), 0, ncols * 16, 0x00020000);
-            for (int e = tid; e < ncols; e += blockDim.x) dst[e] = __builtin_amdgcn_raw_buffer_load_b128(tres, e * 16, 0, 16);
+            const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tab), 0, ncols * 16 * TE, 0x00020000);
+            for (int e = tid; e < ncols * TE; e += blockDim.x) dst[e] = __builtin_amdgcn_raw_buffer_load_b128(tres, e * 16, 0, 16);
         }
         __syncthreads();
         stamp(step, 1);
 
-        Top3 best[G32_UB];
-        float acc[G32_UB];                                    // ONE float32 total per utterance: the bound holds for any order
+        Top3 best[UB];
+        float acc[UB];                                    // ONE float32 total per utterance: the bound holds for any order
 #pragma unroll
-        for (int u = 0; u < G32_UB; ++u) { top3_init(best[u]); acc[u] = 0.f; }
+        for (int u = 0; u < UB; ++u) { top3_init(best[u]); acc[u] = 0.f; }
         int c_tile = wave_id, c_pos = 0, t_done = 0, slot = 0;
         int pin = 0;
         const f32x4 *const table = reinterpret_cast<const f32x4 *>(lds);
         // one chunk of arithmetic: x[g] = columns 4g .. 4g+3 of the chunk.  The table entries (w, ref0, ref1, ref2;
         // the same address in every lane: broadcast reads) come four columns at a time
         auto chunk = [&](f32x4 (&x)[8]) {
-            const f32x4 *const cur = table + slot * GR_CC;
+            const f32x4 *const cur = table + slot * GR_CC * TE;
             if (++slot == n_chunks) slot = 0;
-            f32x4 tc[4];
+            f32x4 tc[4], td[4];
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) tc[i] = cur[4 * g + i];
+                for (int i = 0; i < 4; ++i) {
+                    tc[i] = cur[(4 * g + i) * TE];
+                    if (TE == 2) td[i] = cur[(4 * g + i) * TE + 1];
+                }
                 asm volatile("" ::: "memory");              // four columns at a time (the other wavefront of the SIMD covers the read)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float xv = x[g][i];
                     // column after column (left alone the scheduler interleaves a whole chunk and runs out of registers)
-                    asm volatile("" : "+v"(xv), "+v"(acc[0]), "+v"(acc[G32_UB - 1]));
+                    asm volatile("" : "+v"(xv), "+v"(acc[0]), "+v"(acc[UB - 1]));
 #pragma unroll
-                    for (int u = 0; u < G32_UB; ++u) {
-                        const float d = __builtin_fmaf(xv, tc[i][0], -tc[i][1 + u]);
+                    for (int u = 0; u < UB; ++u) {
+                        const float d = __builtin_fmaf(xv, tc[i][0], u < 3 ? -tc[i][1 + (u % 3)] : -td[i][u % 3]);
                         acc[u] = __builtin_fmaf(d, d, acc[u]);    // padded columns: w = ref = 0 adds +0
                     }
                 }
@@ -392,7 +412,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
         auto end_of_window = [&]() {
             const int i = c_tile * G32_W + lane;
 #pragma unroll
-            for (int u = 0; u < G32_UB; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 if (i < (int)a.Nwin) top3_push(best[u], HOIST ? acc[u] + wcur[u] : acc[u], i);
                 acc[u] = 0.f;
             }
@@ -449,26 +469,26 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
 
         // ---- workgroup top-3 per utterance -> global memory (sc1), arrival tree ----
 #pragma unroll
-        for (int u = 0; u < G32_UB; ++u) {
+        for (int u = 0; u < UB; ++u) {
             if (u >= a.nu) break;                                 // uniform
             Top3 t = best[u];
 #pragma unroll
             for (int m = 1; m <= 32; m <<= 1) { const Top3 o = top3_shfl_xor(t, m); top3_merge(t, o); }
             // (recursive doubling: the partner's set is disjoint from the lane's at every level)
-            if (lane == 0) red3[wave] = t;
-            __syncthreads();
-            if (tid == 0) {
-                Top3 r = red3[0];
-                for (int w = 1; w < nwaves; ++w) top3_merge(r, red3[w]);
-                G32Rec *o = blk + ((size_t)u * nb + blockIdx.x);
-                __hip_atomic_store(&o->v1, r.v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&o->v2, r.v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&o->v3, r.v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&o->a1, (int64_t)r.a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&o->a2, (int64_t)r.a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
+            if (lane == 0) red3[u * G32_MAXW + wave] = t;
         }
+        __syncthreads();
+        if (tid < UB && tid < a.nu) {                             // thread u merges the wavefronts' sets of utterance u (all in wavefront 0)
+            Top3 r = red3[tid * G32_MAXW];
+            for (int w = 1; w < nwaves; ++w) top3_merge(r, red3[tid * G32_MAXW + w]);
+            G32Rec *o = blk + ((size_t)tid * nb + blockIdx.x);
+            __hip_atomic_store(&o->v1, r.v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&o->v2, r.v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&o->v3, r.v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&o->a1, (int64_t)r.a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&o->a2, (int64_t)r.a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
         // arrival on a 256 -> 16 -> 1 tree of monotonic counters; true for the workgroup that completes it
         auto arrive_last = [&](unsigned int *cnt, unsigned int round) -> bool {
             if (tid == 0) {
@@ -495,7 +515,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
         auto load_prev = [&]() {
             if (step > 0) {
 #pragma unroll
-                for (int u = 0; u < G32_UB; ++u)
+                for (int u = 0; u < UB; ++u)
                     prev_row[u] = (u < a.nu && step - 1 < a.nsteps_u[u])
                                       ? __hip_atomic_load(&path[a.out_off[u] + step - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
             }
@@ -526,19 +546,19 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
             return i0;
         };
         // end of a step: path, the next step's table, release of generation 2 step + 3
-        auto finalize = [&](const int64_t (&winner)[G32_UB], bool undecided) {
+        auto finalize = [&](const int64_t (&winner)[UB], bool undecided) {
             if (undecided) {
                 if (tid == 0) __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 if (tid == 0) {
 #pragma unroll
-                    for (int u = 0; u < G32_UB; ++u)
+                    for (int u = 0; u < UB; ++u)
                         if (u < a.nu && step < a.nsteps_u[u])
                             __hip_atomic_store(&path[a.out_off[u] + step], winner[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (step + 1 < nsteps)
-                    g32_write_table(a, step + 1, winner, true, tabs + ((step + 1) & 1) * tab_floats,
-                                    vnorm2 + ((step + 1) & 1) * G32_UB, redd, tid, (int)blockDim.x);
+                    g32_write_table<UB>(a, step + 1, winner, true, tabs + ((step + 1) & 1) * tab_floats,
+                                    vnorm2 + ((step + 1) & 1) * G32_UBX, redd, tid, (int)blockDim.x);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wavefront drains, then ONE flag store
             __syncthreads();
@@ -550,22 +570,83 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
             // ---- first decision, from the published two best windows of every workgroup ----
             stamp(step, 4);
             load_prev();
-            int64_t winner[G32_UB] = {0, 0, 0};
+            int64_t winner[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) winner[u] = 0;
             unsigned int need = 0u;
             bool undecided = false;
             // everything the decision reads from memory is requested up front (one fabric round trip for the records,
             // the reference norms and the bound's terms together: they cost 2 - 2.5 us each when asked one by one)
-            double V2r[G32_UB], EWr[G32_UB];
+            double V2r[UB], EWr[UB];
 #pragma unroll
-            for (int u = 0; u < G32_UB; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 V2r[u] = 0.0; EWr[u] = 0.0;
                 if (!(u < a.nu && step < a.nsteps_u[u])) continue;      // uniform
-                V2r[u] = __hip_atomic_load(&vnorm2[(step & 1) * G32_UB + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                V2r[u] = __hip_atomic_load(&vnorm2[(step & 1) * G32_UBX + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (HOIST) EWr[u] = g32_hoist_err(a, u, step);
             }
+            // what the published records alone decide, one wavefront per utterance, side by side (the usual case: ONE
+            // window inside the bound; at 65 536 units the decisions of three utterances one after the other were 18 of
+            // a step's 40 us).  state 1: decided, 2: nothing finite, 0: candidates to weigh -- the workgroup's path below
+            int64_t *const fast_w = reinterpret_cast<int64_t *>(lds + 12288);
+            int *const fast_s = reinterpret_cast<int *>(lds + 12288 + 64);
+            for (int u = wave; u < UB; u += nwaves) {                   // uniform per wavefront
+                if (!(u < a.nu && step < a.nsteps_u[u])) continue;
+                float mv = __builtin_inff();
+                int64_t mi = INT64_MAX;
+                float qv1[4], qv2[4], qv3[4];
 #pragma unroll
-            for (int u = 0; u < G32_UB; ++u) {
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned int b = lane + 64 * q;
+                    qv1[q] = qv2[q] = qv3[q] = __builtin_inff();
+                    int64_t qa1 = INT64_MAX;
+                    if (b < nb) {
+                        G32Rec *r = blk + ((size_t)u * nb + b);
+                        const unsigned long long v12 = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&r->v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long v3p = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&r->v3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        qa1 = __hip_atomic_load(&r->a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        qv1[q] = __builtin_bit_cast(float, (unsigned int)v12); qv2[q] = __builtin_bit_cast(float, (unsigned int)(v12 >> 32));
+                        qv3[q] = __builtin_bit_cast(float, (unsigned int)v3p);
+                    }
+                    if (lt_vi(qv1[q], qa1, mv, mi)) { mv = qv1[q]; mi = qa1; }
+                }
+#pragma unroll
+                for (int m = 1; m <= 32; m <<= 1) {
+                    const float ov = __shfl_xor(mv, m, 64); const int64_t oi = __shfl_xor(mi, m, 64);
+                    if (lt_vi(ov, oi, mv, mi)) { mv = ov; mi = oi; }
+                }
+                int state = 0;
+                if (!(mv < __builtin_inff())) state = 2;
+                else {
+                    const double V2 = __hip_atomic_load(&vnorm2[(step & 1) * G32_UBX + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double EW = HOIST ? g32_hoist_err(a, u, step) : 0.0;
+                    if (approx && (!HOIST || 4.0 * (g32_err((double)mv, V2, ecols) + EW) <= 1e-3 * (double)mv)) state = 1;
+                    else {
+                        const double M = (double)mv + 2.0 * EW;
+                        double tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300;
+                        for (int it = 0; it < 8; ++it) tau = M + 2.0 * g32_err(tau, V2, ecols);
+                        tau = tau * (1.0 + 1e-6) + 1e-300;
+                        int nc = 0;
+                        bool cov = false;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            nc += __popcll(__ballot((double)qv1[q] <= tau)) + __popcll(__ballot((double)qv2[q] <= tau));
+                            cov = cov || __ballot((double)qv3[q] <= tau) != 0ull;
+                        }
+                        if (nc == 1 && !cov) state = 1;           // the only window inside the bound is the float32 minimum itself
+                    }
+                }
+                if (lane == 0) { fast_s[u] = state; fast_w[u] = mi; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
                 if (!(u < a.nu && step < a.nsteps_u[u])) continue;      // uniform
+                {
+                    const int fs = fast_s[u];
+                    if (fs == 1) { winner[u] = fast_w[u]; continue; }
+                    if (fs == 2) { undecided = true; continue; }
+                }
                 float mv = __builtin_inff();
                 int64_t mi = INT64_MAX;
                 // the records of all workgroups, read ONCE (four 8-byte agent-scope atomic loads each, in flight together;
@@ -656,7 +737,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
             } else {
                 if (tid == 0) {
 #pragma unroll
-                    for (int u = 0; u < G32_UB; ++u) __hip_atomic_store(&ctl->pending[u], winner[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int u = 0; u < UB; ++u) __hip_atomic_store(&ctl->pending[u], winner[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&ctl->need, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&ctl->list_over, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -682,7 +763,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
             // what was kept (mass ties): the step is then undecidable here
             const unsigned int need = __hip_atomic_load(&ctl->need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int u = 0; u < G32_UB; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 if (!((need >> u) & 1u)) continue;                  // uniform
                 const double tau = __hip_atomic_load(&ctl->tau[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const Top3 &t = best[u];
@@ -701,10 +782,10 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
             ++collect_rounds;
             if (arrive_last(arrive2, (unsigned int)collect_rounds)) {
                 load_prev();
-                int64_t winner[G32_UB];
+                int64_t winner[UB];
                 bool undecided = __hip_atomic_load(&ctl->list_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 #pragma unroll
-                for (int u = 0; u < G32_UB; ++u) {
+                for (int u = 0; u < UB; ++u) {
                     winner[u] = __hip_atomic_load(&ctl->pending[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (!((need >> u) & 1u) || undecided) continue;
                     const unsigned int n = __hip_atomic_load(&ctl->list_count[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -721,13 +802,16 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int64_t s0, int64_t s1, int64_t s2
 }
 
 // prologue: counters, generation word, status, the table of step 0
-__global__ void greedy32_init_kernel(GreedyArgs a, int64_t s0, int64_t s1, int64_t s2, float *tabs, double *vnorm2,
+template <int UB>
+__global__ void greedy32_init_kernel(GreedyArgs a, float *tabs, double *vnorm2,
                                      unsigned int *arrive, unsigned int *arrive2, unsigned int *gen, int64_t *status)
 {
     __shared__ double red[512];
     for (int i = threadIdx.x; i < 32 * (GR_S1 + GR_S2 + 1); i += blockDim.x) { arrive[i] = 0; arrive2[i] = 0; }
-    const int64_t start[G32_UB] = {s0, s1, s2};
-    g32_write_table(a, 0, start, false, tabs, vnorm2, red, threadIdx.x, blockDim.x);
+    int64_t start[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) start[u] = a.start[u];
+    g32_write_table<UB>(a, 0, start, false, tabs, vnorm2, red, threadIdx.x, blockDim.x);
     if (threadIdx.x == 0) { *status = 0; *gen = 1u; status[1] = 0; status[2] = 0; }
 }
 
@@ -747,12 +831,12 @@ size_t greedy32_table_floats(const GreedyLayout &g, int Dt, bool hoist)
 {
     const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
     const int jch = (g.jdim + GR_CC - 1) / GR_CC;
-    return (size_t)(jch + (hoist ? 0 : nep * ((Dt + GR_CC - 1) / GR_CC))) * GR_CC * 4;
+    return (size_t)(jch + (hoist ? 0 : nep * ((Dt + GR_CC - 1) / GR_CC))) * GR_CC * (hoist ? 8 : 4);      // hoisted: room for the wide entries
 }
 // workspace of one launch: block records | second-phase control | candidate lists
-static size_t g32_rec_bytes(int nblk) { return (((size_t)G32_UB * nblk * sizeof(G32Rec)) + 255) & ~(size_t)255; }
-size_t greedy32_block_bytes(int nblk) { return g32_rec_bytes(nblk) + 256 + (size_t)G32_UB * G32_LIST * sizeof(int64_t); }
-int greedy32_max_utts() { return G32_UB; }
+static size_t g32_rec_bytes(int nblk) { return (((size_t)G32_UBX * nblk * sizeof(G32Rec)) + 255) & ~(size_t)255; }
+size_t greedy32_block_bytes(int nblk) { return g32_rec_bytes(nblk) + 256 + (size_t)G32_UBX * G32_LIST * sizeof(int64_t); }
+int greedy32_max_utts(bool hoist) { return hoist ? G32_UBX : G32_UB; }
 
 static size_t g32_lds_wave_bytes(const GreedyLayout &g, int Dt)
 {
@@ -827,18 +911,21 @@ void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, 
     a.nu = nu;
     if (hoist) {
         a.hoist = 1; a.Wp = hst->Wp; a.hoist_c = hst->c; a.fwmax2 = hst->fwmax2;
-        for (int u = 0; u < 3; ++u) { a.W[u] = u < nu ? hst->W[u] : nullptr; a.qn2[u] = u < nu ? hst->qn2[u] : nullptr; }
+        for (int u = 0; u < G32_UBX; ++u) { a.W[u] = u < nu ? hst->W[u] : nullptr; a.qn2[u] = u < nu ? hst->qn2[u] : nullptr; }
     }
-    int64_t nsteps = 0, st3[3] = {-1, -1, -1};
-    for (int u = 0; u < 3; ++u) {
+    int64_t nsteps = 0;
+    for (int u = 0; u < G32_UBX; ++u) {
         a.q_off[u] = u < nu ? q_off[u] : 0;
         a.nsteps_u[u] = u < nu ? nsteps_u[u] : 0;
         a.out_off[u] = u < nu ? out_off[u] : 0;
-        if (u < nu) { st3[u] = start[u]; if (nsteps_u[u] > nsteps) nsteps = nsteps_u[u]; }
+        a.start[u] = u < nu ? start[u] : -1;
+        if (u < nu && nsteps_u[u] > nsteps) nsteps = nsteps_u[u];
     }
     if (nsteps <= 0) return;
+    const bool wide = hoist && nu > G32_UB;                        // four to six utterances: the wide table entries
     unsigned int *arrive2 = arrive + 32 * (GR_S1 + GR_S2 + 1);    // the caller provides 2 x greedy_counter_bytes()
-    hipLaunchKernelGGL(greedy32_init_kernel, dim3(1), dim3(512), 0, s, a, st3[0], st3[1], st3[2], tabs, vnorm2, arrive, arrive2, gen, status);
+    if (wide) hipLaunchKernelGGL(greedy32_init_kernel<G32_UBX>, dim3(1), dim3(512), 0, s, a, tabs, vnorm2, arrive, arrive2, gen, status);
+    else hipLaunchKernelGGL(greedy32_init_kernel<G32_UB>, dim3(1), dim3(512), 0, s, a, tabs, vnorm2, arrive, arrive2, gen, status);
     const int waves = g32_waves(g, Dt, n_cus, in_lds, hoist);
     const int nblk = greedy32_blocks(g, Dt, n_cus, hoist);
     size_t lds = greedy32_table_floats(g, Dt, hoist) * 4 + (in_lds ? (size_t)waves * g32_lds_wave_bytes(g, Dt) : 0);
@@ -850,7 +937,8 @@ void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, 
     const size_t scan_bytes = (size_t)g.Nwin * (size_t)(g.jdim + (hoist ? 1 : Dt)) * 4;
     // (2: the hoisted scan sends the requests of all-padding float4 columns to the chunk's first column)
     const int use_nt = scan_bytes > ((size_t)192 << 20) ? (hoist ? 2 : 1) : 0;
-    auto kernel = hoist ? greedy32_kernel<false, true> : in_lds ? greedy32_kernel<true, false> : greedy32_kernel<false, false>;
+    auto kernel = wide ? greedy32_kernel<false, true, G32_UBX> : hoist ? greedy32_kernel<false, true, G32_UB>
+                  : in_lds ? greedy32_kernel<true, false, G32_UB> : greedy32_kernel<false, false, G32_UB>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     char *wb = reinterpret_cast<char *>(blk);
     G32Ctl *ctl = reinterpret_cast<G32Ctl *>(wb + g32_rec_bytes(nblk));
@@ -863,7 +951,7 @@ void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, 
         trace = reinterpret_cast<unsigned long long *>(g32_trace_dev);
         g32_trace_blocks = nblk;
     }
-    hipLaunchKernelGGL(kernel, dim3(nblk), dim3(G32_W * waves), lds, s, a, nsteps, st3[0], st3[1], st3[2], approx, use_nt, (int)lds,
+    hipLaunchKernelGGL(kernel, dim3(nblk), dim3(G32_W * waves), lds, s, a, nsteps, approx, use_nt, (int)lds,
                        tabs, vnorm2, reinterpret_cast<G32Rec *>(blk), arrive, arrive2, gen, ctl, clist, path, status, trace);
 }
 

@@ -25,13 +25,14 @@ struct GreedyArgs {
     int lds_mode;                         // 1: target rows in LDS, interleaved chunk order (greedy_step_kernel)
     // utterances of this scan (snk_greedy_batch: up to GR_MAXU share one pass over the database)
     int nu;
-    int64_t q_off[3], nsteps_u[3], out_off[3];      // first query row, steps, first slot in path / dist
+    int64_t q_off[6], nsteps_u[6], out_off[6];      // first query row, steps, first slot in path / dist
+    int64_t start[6];                               // start states of the float32 scan's utterances (-1: none)
     // hoisted target term (greedy_hoist_kernels.hip): W[u][step][window] float32, row pitch Wp; the scan then reads
     // the join columns only.  qn2[u][step] = ||target vector of the step||^2, fwmax2 = max ||window||^2 (weighted),
     // hoist_c: relative constant of the bound |W~ - W| <= hoist_c (||q|| + ||f||max)^2
     int hoist;
-    const float *W[3]; int64_t Wp;
-    const double *qn2[3];
+    const float *W[6]; int64_t Wp;
+    const double *qn2[6];
     double hoist_c, fwmax2;
 };
 #define GR_MAXU 2          // utterances per scan: one weight and the references share 32 table bytes per column

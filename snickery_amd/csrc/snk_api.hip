@@ -1627,9 +1627,18 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
             h->greedy_hoist_launches += 1;
         }
     }
+    if (!hoist && nu > greedy32_max_utts(false)) {
+        // without the product a scan serves three utterances: two launches
+        const int n1 = greedy32_max_utts(false);
+        bool u1 = false, u2 = false;
+        CHK(greedy32_group(h, n1, q_off, ns, oo, st, approx, want_dist, &u1));
+        CHK(greedy32_group(h, nu - n1, q_off + n1, ns + n1, oo + n1, st + n1, approx, want_dist, &u2));
+        *undecided = u1 || u2;
+        return 0;
+    }
     const int nblk = greedy32_blocks(g, h->Dt, h->n_cus, hoist);
     CHK(h->g32_tabs.ensure(2 * greedy32_table_floats(g, h->Dt) * sizeof(float) + 512));
-    CHK(h->g32_vnorm.ensure(8 * sizeof(double)));
+    CHK(h->g32_vnorm.ensure(16 * sizeof(double)));
     CHK(h->g32_blk.ensure(greedy32_block_bytes(nblk)));
     CHK(h->g32_ctl.ensure(256));
     CHK(h->gsync.ensure(2 * greedy_counter_bytes()));
@@ -1772,12 +1781,12 @@ int snk_greedy_batch(snk_handle h, const double *Q, const int64_t *row_offsets, 
     for (int u = 0; u < n_utts; ++u) order[(size_t)u] = u;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return nsteps[(size_t)x] > nsteps[(size_t)y]; });
     const bool g32 = use_greedy32(h, n_utts);
-    const int ub_run = g32 ? greedy32_max_utts() : ub;
+    const int ub_run = g32 ? greedy32_max_utts(h->greedy_hoist && greedy_hoist_supported(g, h->Dt)) : ub;
     {
         StageTimer t(h, h->stream, TM_GREEDY_STEPS);
         for (int i = 0; i < n_utts; i += ub_run) {
             int nu = 0;
-            int64_t q_off[3], ns[3], oo[3], st[3];
+            int64_t q_off[6], ns[6], oo[6], st[6];
             for (; nu < ub_run && i + nu < n_utts; ++nu) {
                 const int u = order[(size_t)(i + nu)];
                 if (nsteps[(size_t)u] == 0) break;             // sorted: the rest have no steps either

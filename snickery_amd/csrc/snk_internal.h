@@ -159,13 +159,13 @@ bool greedy_supported(const GreedyLayout &g, int Dt);
 
 // float32 prefilter scan, one persistent launch per utterance group (greedy32_kernels.hip)
 bool greedy32_supported(const GreedyLayout &g, int Dt);
-int greedy32_max_utts();
+int greedy32_max_utts(bool hoist = false);      // utterances per scan: 3, 6 with the hoisted target term
 int greedy32_blocks(const GreedyLayout &g, int Dt, int n_cus, bool hoist = false);
 size_t greedy32_table_floats(const GreedyLayout &g, int Dt, bool hoist = false);
 // hoisted target term (greedy_hoist_kernels.hip): what the scan reads instead of the target columns
 struct G32Hoist {
-    const float *W[3];        // per utterance: (nsteps x Wp) float32 target terms
-    const double *qn2[3];     // per utterance: ||target vector of the step||^2
+    const float *W[6];        // per utterance: (nsteps x Wp) float32 target terms
+    const double *qn2[6];     // per utterance: ||target vector of the step||^2
     int64_t Wp;
     double c, fwmax2;         // bound |W~ - W| <= 2^-24 W + c (||q|| + sqrt(fwmax2))^2
 };

@@ -432,7 +432,7 @@ class HipSearchEngine(object):
         return p
 
     def greedy_batch(self, utterances, start_states=None, search_epsilon=0.0, return_distances=False):
-        """greedy_joint_search for several utterances in one call; up to three share every scan of the
+        """greedy_joint_search for several utterances in one call; up to six (three without the hoisted target term) share every scan of the
         database.  Returns a list of paths (and a list of distance arrays)."""
         b = _as_batch(utterances)
         n = len(b)

@@ -108,3 +108,26 @@ def test_ties_and_near_ties_with_the_hoisted_term(engine):
     for eps in (10.0, 0.05):
         pe, de = engine.greedy(U, start_state=3100, search_epsilon=eps, return_distances=True)
         assert np.all(de == 0.0)                       # nearest distance 0: (1 + eps) 0 leaves no slack at all
+
+
+def test_six_utterances_share_a_scan(engine):
+    """With the product a scan serves up to six utterances (wide table entries); without it, three: a batch of seven
+    ragged utterances must come out as one by one in both settings."""
+    N, Dt, Dj, me = 40000, 61, 151, 6
+    engine.set_option('greedy_mode', 2); engine.set_option('greedy_hoist', 1)
+    F_unw, JC_unw, wt, wj = _setup(engine, N, Dt, Dj, seed=11, me=me, lfat=False, mode=0)
+    lens = [50 * me, 49 * me + 3, 12 * me, 31 * me, me, 50 * me, 7 * me]
+    utts = [o.synthetic_targets(F_unw, T, seed=40 + i) * wt for i, T in enumerate(lens)]
+    utts[5] = F_unw[7000:7000 + 50 * me].astype(np.float64) * wt          # clean targets: the natural path, distance 0
+    starts = [-1, 5, -1, 39000, 0, 7000, -1]
+    want = [oc.greedy_f32(F_unw, JC_unw, wt, wj, U, me, False, 0, st) for U, st in zip(utts, starts)]
+    for hoist in (1, 0):
+        engine.set_option('greedy_hoist', hoist)
+        n0 = engine.info('greedy_hoist_launches')
+        paths, dists = engine.greedy_batch(utts, start_states=starts, return_distances=True)
+        for (op, od), p, d in zip(want, paths, dists):
+            assert p == op and np.array_equal(d, od)
+        assert engine.info('greedy_hoist_launches') - n0 == (2 if hoist else 0)      # 6 + 1 utterances
+    assert paths[5] == list(range(7000, 7000 + 50 * me, me))
+    assert engine.info('greedy_fallbacks') == 0
+    engine.set_option('greedy_hoist', 1)

@@ -10,14 +10,15 @@ os.environ['SNK_G32_TRACE'] = fn
 import snickery_amd
 from bench import synthetic_db, synthetic_targets
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+NU = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 Dt, Dj, T, me = 61, 151, 600, 6
 F_unw, JC_unw = synthetic_db(N, Dt, Dj, seed=0)
 wt = np.full(Dt, 0.4); wj = np.full(Dj, 0.05)
 eng = snickery_amd.HipSearchEngine(0)
 eng.upload_db(F_unw, JC_unw); eng.set_weights(wt, wj); eng.set_greedy_layout(me, False, 0)
-U = synthetic_targets(F_unw, T, seed=1) * wt
+Us = [synthetic_targets(F_unw, T, seed=1 + u) * wt for u in range(NU)]
 for _ in range(3):
-    eng.greedy(U)
+    eng.greedy(Us[0]) if NU == 1 else eng.greedy_batch(Us)
 raw = open(fn, 'rb').read()
 steps, nb = struct.unpack('qq', raw[:16])
 t = np.frombuffer(raw[16:], dtype=np.uint64).reshape(steps, nb, 16).astype(np.float64) * 0.01      # us
@@ -29,11 +30,11 @@ for s in range(8, 40):
         continue
     t0 = x[:, 0].min()
     rows.append([x[:, 0].max() - t0, np.median(x[:, 1]) - t0, np.median(x[:, 2]) - t0, x[:, 2].max() - t0, x[:, 3].max() - t0,
-                 x[dec, 4] - t0, x[dec, 8] - t0, x[dec, 9] - t0, x[dec, 10] - t0, x[dec, 5] - t0, x[dec, 6] - t0, np.median(t[s + 1][:, 0]) - t0, t[s + 1][:, 0].min() - t0])
+                 x[dec, 4] - t0, x[dec, 5] - t0, x[dec, 6] - t0, np.median(t[s + 1][:, 0]) - t0, t[s + 1][:, 0].min() - t0])
 r = np.array(rows)
 names = ['last wg sees table', 'table in LDS (median)', 'scan done (median)', 'scan done (last)', 'published (last)', 'decider: last arrival',
-         'decider: records read, min', 'decider: bound', 'decider: candidates', 'decider: decided', 'decider: released', 'next step seen (median)', 'next step seen (first)']
-print('N = %d, %d workgroups; microseconds from the first workgroup seeing the step (mean over %d steps)' % (N, nb, len(rows)))
+         'decider: decided', 'decider: released', 'next step seen (median)', 'next step seen (first)']
+print('%d utterance(s) per scan; ' % NU + 'N = %d, %d workgroups; microseconds from the first workgroup seeing the step (mean over %d steps)' % (N, nb, len(rows)))
 for n, v in zip(names, r.mean(0)):
     print('  %-28s %6.2f' % (n, v))
 eng.close()
