@@ -21,11 +21,13 @@
 //    config/slt_simplified_mini.cfg:92): any window within (1 + eps) of the nearest distance is a valid
 //    answer, and the float32 minimum is within 2 E of it -- below 1e-3 relative -- so for eps >= 1e-3 the
 //    float32 minimum (lowest index among equal float32 totals) is returned and nothing is re-evaluated.
-//  * ONE persistent launch walks all steps of up to three utterances: between two steps the workgroup that
-//    arrives last decides the step, appends to the path, writes the next step's (weight, reference) table and
-//    releases the others through a generation word (sc1 stores, drained, then the flag; sc1 polls and sc1
-//    table loads on the other side -- MI355X_MICROARCH.md, valid hand-off forms).  A launch per step cost
-//    more than the scan itself at 65 536 units.
+//  * ONE persistent launch walks all steps of up to three utterances (six with the hoisted target term,
+//    greedy_hoist_kernels.hip: the scan then reads the join columns and one float32 per window and utterance):
+//    between two steps the workgroup that arrives last decides the step and appends the winners to the path --
+//    agent-scope stores that ARE the release: the path entries are -1 before the launch, everybody polls the
+//    step's entries (sc1 loads) and builds the next (weight, reference) table itself in LDS from the winners' join
+//    rows.  A generation word carries the two rare events (a request for every lane's candidates; the end of the
+//    launch at an undecidable step).  A launch per step cost more than the scan itself at 65 536 units.
 //
 // Data layout, request ring, LDS target blocks and chunk order are those of greedy_kernels.hip.
 #include "greedy_common.h"
@@ -147,17 +149,27 @@ __device__ double g32_exact_d2_wave(const GreedyArgs &a, int u, int64_t step, in
     return __shfl(d2, 0, 64);
 }
 
-// The float32 table of a step: per scan column, in chunk order, (w, ref0, ref1, ref2) -- and behind it, per
-// utterance, the squared norm of the reference vector (float64, for the error bound).  Written with sc1 stores
-// by the workgroup that decides the previous step.
+// wavefront-uniform values read from LDS live in scalar registers across the scan
+__device__ __forceinline__ int64_t g32_uniform_i(int64_t v)
+{
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)(unsigned long long)v);
+    const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)((unsigned long long)v >> 32));
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double g32_uniform_d(double v) { return __longlong_as_double(g32_uniform_i(__double_as_longlong(v))); }
+
+// The float32 table of a step, built by EVERY workgroup for itself in its LDS: per scan column, in chunk order,
+// (w, ref0, ref1, ref2) [| ref3, ref4, ref5, -] -- the references are the previous winners' join rows (plain cached loads:
+// read-only data) and the step's target rows -- and, per utterance, the squared norm of the reference vector (float64, for
+// the error bound) in V2.  (Until the hand-off carried the winners themselves, the deciding workgroup wrote this table to
+// global memory and everybody fetched it with sc1 loads: two more fabric round trips per step.)
 template <int UB>
-__device__ void g32_write_table(const GreedyArgs &a, int64_t step, const int64_t (&prev_row)[UB], bool prev_is_current,
-                                float *tab, double *vnorm2, double *red, int tid, int nthreads)
+__device__ void g32_build_table(const GreedyArgs &a, int64_t step, const int64_t (&prev_row)[UB], bool prev_is_current,
+                                u32x4 *dst, double *red, double (&V2)[UB], int tid, int nthreads)
 {
     const int jch = greedy_join_chunks(a), tch = greedy_target_chunks(a);
     const int nT = a.hoist ? 0 : a.nep * tch, n = (jch + nT) * GR_CC;          // hoisted target term: join columns only
-    constexpr int TE = UB <= 3 ? 16 : 32;                        // table bytes per column
-    const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(tab, 0, n * TE, 0x00020000);
+    constexpr int TE = UB <= 3 ? 1 : 2;                          // 16-byte pieces per column
     double n2[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) n2[u] = 0.0;
@@ -188,22 +200,19 @@ __device__ void g32_write_table(const GreedyArgs &a, int64_t step, const int64_t
                         ref[u] = a.Q[(a.q_off[u] + step * a.me + a.ep[k]) * a.Dt + col];
             }
         }
-        // ONE 16-byte sc1 (agent-scope, write-through) store per column: the readers are other compute units,
-        // moments later, through 16-byte sc1 loads (dword sc1 stores are one fabric write each: 8 704 of them
-        // cost more than the scan of a 65 536-unit voice)
-        u32x4 bits = {__builtin_bit_cast(unsigned int, (float)w), __builtin_bit_cast(unsigned int, (float)ref[0]),
-                      __builtin_bit_cast(unsigned int, (float)ref[1]), __builtin_bit_cast(unsigned int, (float)ref[2])};
-        __builtin_amdgcn_raw_buffer_store_b128(bits, tres, e * TE, 0, 16);
+        const u32x4 bits = {__builtin_bit_cast(unsigned int, (float)w), __builtin_bit_cast(unsigned int, (float)ref[0]),
+                            __builtin_bit_cast(unsigned int, (float)ref[1 % UB]), __builtin_bit_cast(unsigned int, (float)ref[2 % UB])};
+        dst[e * TE] = bits;
         if (UB > 3) {
-            u32x4 hi = {__builtin_bit_cast(unsigned int, (float)ref[3 % UB]), __builtin_bit_cast(unsigned int, (float)ref[4 % UB]),
-                        __builtin_bit_cast(unsigned int, (float)ref[5 % UB]), 0u};
-            __builtin_amdgcn_raw_buffer_store_b128(hi, tres, e * TE + 16, 0, 16);
+            const u32x4 hi = {__builtin_bit_cast(unsigned int, (float)ref[3 % UB]), __builtin_bit_cast(unsigned int, (float)ref[4 % UB]),
+                              __builtin_bit_cast(unsigned int, (float)ref[5 % UB]), 0u};
+            dst[e * TE + 1] = hi;
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) n2[u] += ref[u] * ref[u];
     }
     // squared norms of the references: block sums (any order: they only scale an error bound, +1 % is added there);
-    // wavefront shuffles, then one pass over the wavefronts' partial sums
+    // wavefront shuffles, then every thread adds the wavefronts' partial sums
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
@@ -212,13 +221,13 @@ __device__ void g32_write_table(const GreedyArgs &a, int64_t step, const int64_t
         for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
         if (lane == 0) red[wave * UB + u] = v;
     }
-    __syncthreads();
-    if (tid < UB && tid < a.nu) {
+    __syncthreads();                                              // (the table is complete behind this barrier, too)
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
         double v = 0.0;
-        for (int w = 0; w < nwaves; ++w) v += red[w * UB + tid];
-        __hip_atomic_store(&vnorm2[tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int w = 0; w < nwaves; ++w) v += red[w * UB + u];
+        V2[u] = g32_uniform_d(v);
     }
-    __syncthreads();
 }
 
 // error bound of a float32 total (see the file header); V2 = squared norm of the reference vector
@@ -238,7 +247,7 @@ __device__ __forceinline__ double g32_hoist_err(const GreedyArgs &a, int u, int6
 template <bool IN_LDS, bool HOIST, int UB>
 __global__ void __launch_bounds__(G32_W * G32_MAXW)
 greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_bytes,
-                float *tabs, double *vnorm2, G32Rec *blk, unsigned int *arrive, unsigned int *arrive2, unsigned int *gen,
+                G32Rec *blk, unsigned int *arrive, unsigned int *arrive2, unsigned int *gen,
                 G32Ctl *ctl, int64_t *clist_g, int64_t *path, int64_t *status,       // shared between workgroups: no restrict
                 unsigned long long *trace)
 {
@@ -249,6 +258,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
     };
     extern __shared__ __align__(16) char lds[];          // table | one target block per wavefront (lds_mode 1)
     __shared__ int is_last, gen_seen;
+    __shared__ int64_t next_rows[G32_UBX];                 // the step's winners, as the polling thread saw them
     int collect_rounds = 0;                               // second-phase rounds so far (the same in every workgroup)
     const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -275,7 +285,6 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
     const unsigned jl = (unsigned)lane + (unsigned)a.prev_row0;
     const unsigned off_join = (jl >> 6) * ((unsigned)JQ << 10) + (jl & 63u) * 16u;
     const char *const FTb = reinterpret_cast<const char *>(a.FT), *const JTb = reinterpret_cast<const char *>(a.JT);
-    const size_t tab_floats = (size_t)ncols * 4 * TE;
 
     // reduction scratch of the step's tail aliases the table and the target blocks
     Top3 *red3 = reinterpret_cast<Top3 *>(lds);
@@ -351,28 +360,14 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
         for (int s = 0; s < NSTG - 1; ++s) fetch(stage[s], 0);
     };
     for (int64_t step = 0; step < nsteps; ++step) {
-        // ---- wait for the step's table (written by the workgroup that decided the previous step) ----
-        // generation 2 step + 1: the table of this step is complete (0xffffffff: an earlier step was undecidable)
-        if (tid == 0) {
-            unsigned int g;
-            while ((g = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned int)(2 * step + 1))
-                __builtin_amdgcn_s_sleep(1);
-            gen_seen = (int)g;
-        }
-        __syncthreads();
-        if (step > 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;     // an undecidable step: everybody leaves
+        // ---- the step's table: every workgroup builds its own from the previous winners (prev_row) ----
         stamp(step, 0);
-        const float *tab = tabs + (step & 1) * tab_floats;
-
         start_fetch(step);
-
-        // the step's table -> LDS (sc1 loads: another compute unit wrote it moments ago)
-        {
-            u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
-            const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tab), 0, ncols * 16 * TE, 0x00020000);
-            for (int e = tid; e < ncols * TE; e += blockDim.x) dst[e] = __builtin_amdgcn_raw_buffer_load_b128(tres, e * 16, 0, 16);
-        }
-        __syncthreads();
+        double V2w[UB];                                       // squared norms of the step's reference vectors
+        // (the builder's 384 bytes of reduction scratch sit right behind the table: the target blocks that share the
+        // place in LDS mode are filled later, by the scan)
+        g32_build_table<UB>(a, step, prev_row, step > 0, reinterpret_cast<u32x4 *>(lds), reinterpret_cast<double *>(lds + table_bytes),
+                            V2w, tid, (int)blockDim.x);
         stamp(step, 1);
 
         Top3 best[UB];
@@ -511,15 +506,6 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
             __syncthreads();
             return r;
         };
-        // winners of the previous step (another workgroup may have decided it): visible since generation 2 step + 1
-        auto load_prev = [&]() {
-            if (step > 0) {
-#pragma unroll
-                for (int u = 0; u < UB; ++u)
-                    prev_row[u] = (u < a.nu && step - 1 < a.nsteps_u[u])
-                                      ? __hip_atomic_load(&path[a.out_off[u] + step - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-            }
-        };
         // exact decision among n candidates (ids through `get`): a wavefront per candidate, canonical float64 totals,
         // lowest index on exact ties
         const int ex_cols = a.jdim + a.nep * a.Dt;
@@ -545,31 +531,27 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
             __syncthreads();
             return i0;
         };
-        // end of a step: path, the next step's table, release of generation 2 step + 3
+        // end of a step.  The winners ARE the release: every workgroup polls the step's path entries (-1 until
+        // written) and builds the next table itself.  An undecidable step ends the launch through the generation word.
         auto finalize = [&](const int64_t (&winner)[UB], bool undecided) {
             if (undecided) {
-                if (tid == 0) __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
                 if (tid == 0) {
-#pragma unroll
-                    for (int u = 0; u < UB; ++u)
-                        if (u < a.nu && step < a.nsteps_u[u])
-                            __hip_atomic_store(&path[a.out_off[u] + step], winner[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(gen, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (step + 1 < nsteps)
-                    g32_write_table<UB>(a, step + 1, winner, true, tabs + ((step + 1) & 1) * tab_floats,
-                                    vnorm2 + ((step + 1) & 1) * G32_UBX, redd, tid, (int)blockDim.x);
+            } else if (tid == 0) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (u < a.nu && step < a.nsteps_u[u])
+                        __hip_atomic_store(&path[a.out_off[u] + step], winner[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wavefront drains, then ONE flag store
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(gen, (unsigned int)(2 * step + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
 
         stamp(step, 3);
         if (arrive_last(arrive, (unsigned int)step + 1u)) {
             // ---- first decision, from the published two best windows of every workgroup ----
             stamp(step, 4);
-            load_prev();
             int64_t winner[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) winner[u] = 0;
@@ -582,7 +564,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
             for (int u = 0; u < UB; ++u) {
                 V2r[u] = 0.0; EWr[u] = 0.0;
                 if (!(u < a.nu && step < a.nsteps_u[u])) continue;      // uniform
-                V2r[u] = __hip_atomic_load(&vnorm2[(step & 1) * G32_UBX + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                V2r[u] = V2w[u];
                 if (HOIST) EWr[u] = g32_hoist_err(a, u, step);
             }
             // what the published records alone decide, one wavefront per utterance, side by side (the usual case: ONE
@@ -618,7 +600,9 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
                 int state = 0;
                 if (!(mv < __builtin_inff())) state = 2;
                 else {
-                    const double V2 = __hip_atomic_load(&vnorm2[(step & 1) * G32_UBX + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    double V2 = V2w[0];
+#pragma unroll
+                    for (int k = 1; k < UB; ++k) V2 = u == k ? V2w[k] : V2;
                     const double EW = HOIST ? g32_hoist_err(a, u, step) : 0.0;
                     if (approx && (!HOIST || 4.0 * (g32_err((double)mv, V2, ecols) + EW) <= 1e-3 * (double)mv)) state = 1;
                     else {
@@ -749,18 +733,44 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
         // (Issuing the next step's first requests here, while this step is decided, was tried: the scan ended 1.4 us
         // earlier and the deciding workgroup's loads took 0.8 us longer beside everybody's requests -- the step stayed
         // at 21 us at 65 536 units, 194 us at 1.5 M.)
-        // ---- everybody: the next generation is either the next step's table or a request for candidates ----
-        if (tid == 0) {
-            unsigned int g;
-            while ((g = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned int)(2 * step + 2))
-                __builtin_amdgcn_s_sleep(1);
-            gen_seen = (int)g;
-        }
-        __syncthreads();
-        stamp(step, 7);
-        if (gen_seen == (int)(2 * step + 2)) {
+        // ---- everybody: the step's winners (path entries, -1 until written), a request for candidates (generation
+        //      2 step + 2, once per step) or the end of the launch (0xffffffff: the step could not be decided) ----
+        bool second_done = false;
+        for (;;) {
+            if (tid == 0) {
+                int seen;
+                for (;;) {
+                    const unsigned int g = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bool ready = true;
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        int64_t p = -1;
+                        if (u < a.nu && step < a.nsteps_u[u]) {
+                            p = __hip_atomic_load(&path[a.out_off[u] + step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (p < 0) ready = false;
+                        }
+                        next_rows[u] = p;
+                    }
+                    if (g == 0xffffffffu) { seen = -1; break; }
+                    if (ready) { seen = 0; break; }
+                    if (g == (unsigned int)(2 * step + 2) && !second_done) { seen = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                gen_seen = seen;
+            }
+            __syncthreads();
+            const int seen = gen_seen;
+            if (seen < 0) return;                                 // an undecidable step: everybody leaves
+            if (seen == 0) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) prev_row[u] = g32_uniform_i(next_rows[u]);
+                __syncthreads();
+                break;
+            }
+            stamp(step, 7);
             // second phase: every lane offers its two best windows that reach tau; a third one that does is beyond
             // what was kept (mass ties): the step is then undecidable here
+            {
             const unsigned int need = __hip_atomic_load(&ctl->need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
@@ -781,7 +791,6 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
             __syncthreads();
             ++collect_rounds;
             if (arrive_last(arrive2, (unsigned int)collect_rounds)) {
-                load_prev();
                 int64_t winner[UB];
                 bool undecided = __hip_atomic_load(&ctl->list_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 #pragma unroll
@@ -796,23 +805,18 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
                 }
                 finalize(winner, undecided);
             }
+            }
+            second_done = true;
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
-// prologue: counters, generation word, status, the table of step 0
-template <int UB>
-__global__ void greedy32_init_kernel(GreedyArgs a, float *tabs, double *vnorm2,
-                                     unsigned int *arrive, unsigned int *arrive2, unsigned int *gen, int64_t *status)
+// prologue: counters, generation word, status
+__global__ void greedy32_init_kernel(unsigned int *arrive, unsigned int *arrive2, unsigned int *gen, int64_t *status)
 {
-    __shared__ double red[512];
     for (int i = threadIdx.x; i < 32 * (GR_S1 + GR_S2 + 1); i += blockDim.x) { arrive[i] = 0; arrive2[i] = 0; }
-    int64_t start[UB];
-#pragma unroll
-    for (int u = 0; u < UB; ++u) start[u] = a.start[u];
-    g32_write_table<UB>(a, 0, start, false, tabs, vnorm2, red, threadIdx.x, blockDim.x);
-    if (threadIdx.x == 0) { *status = 0; *gen = 1u; status[1] = 0; status[2] = 0; }
+    if (threadIdx.x == 0) { *status = 0; *gen = 0u; status[1] = 0; status[2] = 0; }
 }
 
 // exact Euclidean distance of every pick (what the tree query returns beside the index): a wavefront per step
@@ -850,7 +854,7 @@ static int g32_waves(const GreedyLayout &g, int Dt, int n_cus, bool in_lds, bool
     int64_t w = (ntiles + n_cus - 1) / n_cus;
     int wmax = G32_MAXW;
     if (in_lds) {
-        const size_t fixed = greedy32_table_floats(g, Dt, false) * 4 + 64;
+        const size_t fixed = greedy32_table_floats(g, Dt, false) * 4 + 512;
         const size_t per = g32_lds_wave_bytes(g, Dt);
         const size_t fit = fixed < (size_t)(160 * 1024) ? ((size_t)(160 * 1024) - fixed) / per : 0;
         if ((int64_t)fit < wmax) wmax = (int)fit;
@@ -863,7 +867,7 @@ bool greedy32_supported(const GreedyLayout &g, int Dt)
     // the table must leave room for the reduction scratch and, in LDS mode, for at least four target blocks
     const size_t tb = greedy32_table_floats(g, Dt, false) * 4;
     if (tb + 16384 > (size_t)(160 * 1024)) return false;
-    if (greedy_lds_mode(g, Dt) && tb + 64 + 4 * g32_lds_wave_bytes(g, Dt) > (size_t)(160 * 1024)) return false;
+    if (greedy_lds_mode(g, Dt) && tb + 512 + 4 * g32_lds_wave_bytes(g, Dt) > (size_t)(160 * 1024)) return false;
     return true;
 }
 int greedy32_blocks(const GreedyLayout &g, int Dt, int n_cus, bool hoist)
@@ -899,8 +903,8 @@ void greedy32_trace_dump()
 // first step that could not be decided (mass ties); the caller then falls back to the exact scan.
 void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
                      int Dj, const double *wj, const float *tiles, const double *Q, int nu, const int64_t *q_off,
-                     const int64_t *nsteps_u, const int64_t *out_off, const int64_t *start, int approx, float *tabs,
-                     double *vnorm2, void *blk, int n_cus, unsigned int *arrive, unsigned int *gen, int64_t *status,
+                     const int64_t *nsteps_u, const int64_t *out_off, const int64_t *start, int approx,
+                     void *blk, int n_cus, unsigned int *arrive, unsigned int *gen, int64_t *status,
                      int64_t *path, const G32Hoist *hst, hipStream_t s)
 {
     GreedyArgs a{};
@@ -924,11 +928,13 @@ void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, 
     if (nsteps <= 0) return;
     const bool wide = hoist && nu > G32_UB;                        // four to six utterances: the wide table entries
     unsigned int *arrive2 = arrive + 32 * (GR_S1 + GR_S2 + 1);    // the caller provides 2 x greedy_counter_bytes()
-    if (wide) hipLaunchKernelGGL(greedy32_init_kernel<G32_UBX>, dim3(1), dim3(512), 0, s, a, tabs, vnorm2, arrive, arrive2, gen, status);
-    else hipLaunchKernelGGL(greedy32_init_kernel<G32_UB>, dim3(1), dim3(512), 0, s, a, tabs, vnorm2, arrive, arrive2, gen, status);
+    hipLaunchKernelGGL(greedy32_init_kernel, dim3(1), dim3(512), 0, s, arrive, arrive2, gen, status);
+    // the winners are the hand-off between the steps: a path entry is -1 until its step is decided
+    for (int u = 0; u < nu; ++u)
+        if (nsteps_u[u] > 0) (void)hipMemsetAsync(path + out_off[u], 0xff, (size_t)nsteps_u[u] * sizeof(int64_t), s);
     const int waves = g32_waves(g, Dt, n_cus, in_lds, hoist);
     const int nblk = greedy32_blocks(g, Dt, n_cus, hoist);
-    size_t lds = greedy32_table_floats(g, Dt, hoist) * 4 + (in_lds ? (size_t)waves * g32_lds_wave_bytes(g, Dt) : 0);
+    size_t lds = greedy32_table_floats(g, Dt, hoist) * 4 + 512 + (in_lds ? (size_t)waves * g32_lds_wave_bytes(g, Dt) : 0);
     // the step's tail: 16 KB of reduction scratch + a term array per wavefront for exact decisions
     const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
     const size_t tail = 16384 + (size_t)waves * (size_t)(g.jdim + nep * Dt) * 8;
@@ -952,7 +958,7 @@ void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, 
         g32_trace_blocks = nblk;
     }
     hipLaunchKernelGGL(kernel, dim3(nblk), dim3(G32_W * waves), lds, s, a, nsteps, approx, use_nt, (int)lds,
-                       tabs, vnorm2, reinterpret_cast<G32Rec *>(blk), arrive, arrive2, gen, ctl, clist, path, status, trace);
+                       reinterpret_cast<G32Rec *>(blk), arrive, arrive2, gen, ctl, clist, path, status, trace);
 }
 
 void launch_greedy32_dist(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,

@@ -3,7 +3,7 @@ import csv, glob, collections, sys, os
 src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/ph'
 tag = sys.argv[2] if len(sys.argv) > 2 else 'r02_g'
 N, Dt, Dj, me, steps = 1500000, 61, 151, 6, 100
-KS, KP = 'greedy32_kernel<false, true>', 'hoist_product_kernel'
+KS, KP = 'greedy32_kernel<false, true, 3>', 'hoist_product_kernel'
 
 
 def durations(d, ker):
@@ -40,7 +40,7 @@ K = me * ((Dt + 63) // 64) * 64
 flop = 2.0 * ((steps + 15) // 16 * 16) * ((N - me + 1 + 127) // 128 * 128) * K
 lines = ['# Round 2 -- greedy search with the hoisted target term at N = 1.5 M units, Dt = 61, Dj = 151, multiepoch 6 (B3 shape)', '',
          'Command: `bash tools/prof_hoist.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes, over tools/prof_hoist.py: 600-frame utterances = 100 steps each, one persistent launch per utterance).', '',
-         '* `greedy32_kernel<false, true>` (the scan, all 100 steps in one launch): %d launches, average **%.2f ms** = %.1f us per step' % (len(ds), scan / 1e3, scan / steps),
+         '* `greedy32_kernel<false, true, 3>` (the scan, all 100 steps in one launch): %d launches, average **%.2f ms** = %.1f us per step' % (len(ds), scan / 1e3, scan / steps),
          '* `hoist_product_kernel` (float64 matrix pipe, W = 100 x 1.5 M target terms): %d launches, average **%.2f ms** = %.1f us per step of the utterance; %.3g FLOP (padded) -> %.1f TFLOP/s = %.0f %% of the 78.6 TFLOP/s float64 matrix peak' % (
              len(dp), prod / 1e3, prod / steps, flop, flop / (prod * 1e-6) / 1e12, 100 * flop / (prod * 1e-6) / 78.6e12),
          '* per step, scan + product: **%.1f us**; algorithmic bytes (Dj + 1) x 4 x N = %.0f MB -> %.2f TB/s = **%.0f %% of the 8 TB/s HBM peak** (the scan alone: %.0f %%; on the %.0f MB it requests, 38 float4 join columns + one target value per window: %.0f %%)' % (
