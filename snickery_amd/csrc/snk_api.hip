@@ -184,7 +184,7 @@ struct snk_engine {
     std::vector<double> tsel, jsel;       // snk_set_column_selection: 1 = column takes part (empty: all do)
     DevBuf tmask;                         // tsel on the device (query rows are masked after upload)
     DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist, gsync, gtiles;
-    DevBuf g32_tabs, g32_vnorm, g32_blk, g32_ctl;          // float32 persistent scan: tables, norms, block records, {gen, status}
+    DevBuf g32_blk, g32_ctl;          // float32 persistent scan: block records + candidate lists, {gen, status}
     // hoisted target term of the float32 scan (greedy_hoist_kernels.hip): window norms (per database, layout and
     // weights), left operands and products of the utterances in work
     DevBuf gh_nw, gh_max, gh_aq, gh_qn2, gh_W;
@@ -366,7 +366,7 @@ int snk_destroy(snk_handle h)
                       &h->Qraw, &h->Qp, &h->Qf, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
                       &h->gpath, &h->gdist, &h->gsync, &h->gtiles, &h->cls16_full, &h->cls16_samp,
-                      &h->g32_tabs, &h->g32_vnorm, &h->g32_blk, &h->g32_ctl,
+                      &h->g32_blk, &h->g32_ctl,
                       &h->gh_nw, &h->gh_max, &h->gh_aq, &h->gh_qn2, &h->gh_W};
     for (auto *b : bufs) b->release();
     if (h->dp_stream[1]) (void)hipStreamDestroy(h->dp_stream[1]);
@@ -1599,7 +1599,13 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
         const int KA = greedy_hoist_k(g, h->Dt);
         int64_t rows = 0, prows = 0;
         for (int u = 0; u < nu; ++u) { rows += ns[u]; prows += greedy_hoist_rows(ns[u]); }
-        if ((double)rows * (double)Wp * 4.0 > h->greedy_hoist_max_gb * 1e9) hoist = false;
+        const double w_bytes = (double)rows * (double)Wp * 4.0;
+        if (w_bytes > h->greedy_hoist_max_gb * 1e9) hoist = false;
+        if (hoist && w_bytes > (double)h->gh_W.bytes) {
+            // the product must fit beside the voice: a device that cannot hold it keeps the scan that computes the target term itself
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || 1.125 * w_bytes - (double)h->gh_W.bytes > 0.9 * (double)free_b) hoist = false;      // (ensure() frees, then asks for 9/8)
+        }
         if (hoist) {
             if (!h->gh_ready) {
                 CHK(h->gh_nw.ensure((size_t)Wp * sizeof(double)));
