@@ -237,13 +237,6 @@ __device__ __forceinline__ double g32_err(double d, double V2, int ncols)
     return 6.0 * u * sqrt(V2 * d) * 1.01 + (double)(ncols + 8) * u * d;
 }
 
-// bound of a hoisted target value (greedy_hoist_kernels.hip): hoist_c (||q|| + ||f||max)^2
-__device__ __forceinline__ double g32_hoist_err(const GreedyArgs &a, int u, int64_t step)
-{
-    const double r = sqrt(a.qn2[u][step]) + sqrt(a.fwmax2);
-    return a.hoist_c * r * r;
-}
-
 template <bool IN_LDS, bool HOIST, int UB>
 __global__ void __launch_bounds__(G32_W * G32_MAXW)
 greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_bytes,
@@ -363,11 +356,20 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
         // ---- the step's table: every workgroup builds its own from the previous winners (prev_row) ----
         stamp(step, 0);
         start_fetch(step);
+        double qn2s[UB];                                      // ||target vector||^2 of the step: requested beside the join rows
+#pragma unroll
+        for (int u = 0; u < UB; ++u) qn2s[u] = (HOIST && u < a.nu && step < a.nsteps_u[u]) ? a.qn2[u][step] : 0.0;
         double V2w[UB];                                       // squared norms of the step's reference vectors
         // (the builder's 384 bytes of reduction scratch sit right behind the table: the target blocks that share the
         // place in LDS mode are filled later, by the scan)
         g32_build_table<UB>(a, step, prev_row, step > 0, reinterpret_cast<u32x4 *>(lds), reinterpret_cast<double *>(lds + table_bytes),
                             V2w, tid, (int)blockDim.x);
+        double EWw[UB];                                       // bound of the hoisted values of this step: hoist_c (||q|| + ||f||max)^2
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const double r = sqrt(qn2s[u]) + sqrt(a.fwmax2);
+            EWw[u] = (HOIST && u < a.nu && step < a.nsteps_u[u]) ? g32_uniform_d(a.hoist_c * r * r) : 0.0;
+        }
         stamp(step, 1);
 
         Top3 best[UB];
@@ -565,7 +567,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
                 V2r[u] = 0.0; EWr[u] = 0.0;
                 if (!(u < a.nu && step < a.nsteps_u[u])) continue;      // uniform
                 V2r[u] = V2w[u];
-                if (HOIST) EWr[u] = g32_hoist_err(a, u, step);
+                EWr[u] = EWw[u];
             }
             // what the published records alone decide, one wavefront per utterance, side by side (the usual case: ONE
             // window inside the bound; at 65 536 units the decisions of three utterances one after the other were 18 of
@@ -603,7 +605,9 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
                     double V2 = V2w[0];
 #pragma unroll
                     for (int k = 1; k < UB; ++k) V2 = u == k ? V2w[k] : V2;
-                    const double EW = HOIST ? g32_hoist_err(a, u, step) : 0.0;
+                    double EW = EWw[0];
+#pragma unroll
+                    for (int k = 1; k < UB; ++k) EW = u == k ? EWw[k] : EW;
                     if (approx && (!HOIST || 4.0 * (g32_err((double)mv, V2, ecols) + EW) <= 1e-3 * (double)mv)) state = 1;
                     else {
                         const double M = (double)mv + 2.0 * EW;
