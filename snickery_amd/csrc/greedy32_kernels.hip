@@ -42,6 +42,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define G32_MAXW 8
 #define G32_HOIST_NSTG 3      // ring stages of the hoisted scan (little arithmetic to hide requests behind: three chunks ahead)
 #define G32_TRACE_STEPS 64
+#define G32_STALL_TICKS 300000000ull      // 3 s of the 100 MHz clock
 #define G32_UB 3              // utterances per scan: (w, ref0, ref1, ref2) = 16 table bytes per column
 #define G32_UBX 6             // ... of the hoisted scan's wide instance: (w, ref0 .. ref5, -) = 32 table bytes per column
 
@@ -239,11 +240,13 @@ __device__ __forceinline__ double g32_err(double d, double V2, int ncols)
 
 template <bool IN_LDS, bool HOIST, int UB>
 __global__ void __launch_bounds__(G32_W * G32_MAXW)
-greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_bytes,
+greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_bytes,
                 G32Rec *blk, unsigned int *arrive, unsigned int *arrive2, unsigned int *gen,
                 G32Ctl *ctl, int64_t *clist_g, int64_t *path, int64_t *status,       // shared between workgroups: no restrict
                 unsigned long long *trace)
 {
+    const bool approx = (flags & 1) != 0;                  // search_epsilon mode
+    const bool test_stall = (flags & 256) != 0;            // test hook: workgroup 0 never arrives at step 1 (the watchdog's case)
     // optional timeline (SNK_G32_TRACE=file): 8 stamps of the 100 MHz clock per step and workgroup, steps 0 .. G32_TRACE_STEPS - 1
     auto stamp = [&](int64_t st, int k) {
         if (trace && st < G32_TRACE_STEPS && threadIdx.x == 0)
@@ -551,7 +554,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
         };
 
         stamp(step, 3);
-        if (arrive_last(arrive, (unsigned int)step + 1u)) {
+        if (!(test_stall && step == 1 && blockIdx.x == 0) && arrive_last(arrive, (unsigned int)step + 1u)) {
             // ---- first decision, from the published two best windows of every workgroup ----
             stamp(step, 4);
             int64_t winner[UB];
@@ -745,6 +748,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
         for (;;) {
             if (tid == 0) {
                 int seen;
+                const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
                 for (;;) {
                     const unsigned int g = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     bool ready = true;
@@ -760,6 +764,17 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
                     if (g == 0xffffffffu) { seen = -1; break; }
                     if (ready) { seen = 0; break; }
                     if (g == (unsigned int)(2 * step + 2) && !second_done) { seen = 1; break; }
+                    // watchdog: a step takes microseconds.  Seconds without news mean that some workgroup of the launch is
+                    // not running (the device shared with another spinning launch): end the launch, the caller falls back
+                    // to the exact scan, which never waits inside a kernel
+                    if (__builtin_amdgcn_s_memrealtime() - t_wait > G32_STALL_TICKS) {
+                        __hip_atomic_store(&status[3], (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_store(gen, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        seen = -1;
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 gen_seen = seen;
@@ -822,7 +837,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int approx, int use_nt, int lds_by
 __global__ void greedy32_init_kernel(unsigned int *arrive, unsigned int *arrive2, unsigned int *gen, int64_t *status)
 {
     for (int i = threadIdx.x; i < 32 * (GR_S1 + GR_S2 + 1); i += blockDim.x) { arrive[i] = 0; arrive2[i] = 0; }
-    if (threadIdx.x == 0) { *status = 0; *gen = 0u; status[1] = 0; status[2] = 0; }
+    if (threadIdx.x == 0) { *status = 0; *gen = 0u; status[1] = 0; status[2] = 0; status[3] = 0; }
 }
 
 // exact Euclidean distance of every pick (what the tree query returns beside the index): a wavefront per step
@@ -905,7 +920,7 @@ void greedy32_trace_dump()
 }
 
 // One persistent launch for up to three utterances (q_off / nsteps_u / out_off / start per utterance).
-// approx != 0: search_epsilon mode (float32 minimum, nothing re-evaluated).  *status (device): 0, or 1 + the
+// approx bit 0: search_epsilon mode (float32 minimum, nothing re-evaluated); bit 8: test hook (a workgroup that never arrives).  *status (device): 0, or 1 + the
 // first step that could not be decided (mass ties); the caller then falls back to the exact scan.
 void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
                      int Dj, const double *wj, const float *tiles, const double *Q, int nu, const int64_t *q_off,

@@ -190,6 +190,8 @@ struct snk_engine {
     DevBuf gh_nw, gh_max, gh_aq, gh_qn2, gh_W;
     bool gh_ready = false;
     double gh_fwmax2 = 0.0;
+    int greedy_test_stall = 0;            // test hook (option greedy_test_stall): one workgroup of the float32 scan never arrives at step 1
+    int64_t greedy_stalls = 0;            // launches of the float32 scan ended by their watchdog (a workgroup was not running)
     int64_t greedy_hoist_launches = 0;    // scans that read the hoisted target term
     int64_t greedy_second_rounds = 0, greedy_exact_windows = 0;     // statistics of the float32 scan's exact decisions
     int greedy_hoist = 1;                 // 1: the float32 scan reads one precomputed target value per window (default)
@@ -1649,17 +1651,18 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
     unsigned int *gen = h->g32_ctl.as<unsigned int>();
     int64_t *status = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(h->g32_ctl.p) + 16);
     launch_greedy32(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
-                    h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nu, q_off, ns, oo, st, approx ? 1 : 0,
+                    h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nu, q_off, ns, oo, st, (approx ? 1 : 0) | (h->greedy_test_stall ? 256 : 0),
                     h->g32_blk.p, h->n_cus, h->gsync.as<unsigned int>(), gen,
                     status, h->gpath.as<int64_t>(), hoist ? &hst : nullptr, h->stream);
     HIPCHK(hipGetLastError());
-    int64_t stv[3] = {0, 0, 0};            // undecided step + 1 | second-phase rounds | windows decided by exact totals
+    int64_t stv[4] = {0, 0, 0, 0};         // undecided step + 1 | second-phase rounds | windows decided by exact totals | watchdog
     HIPCHK(hipMemcpyAsync(stv, status, sizeof(stv), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     greedy32_trace_dump();
     *undecided = stv[0] != 0;
     h->greedy_second_rounds += stv[1];
     h->greedy_exact_windows += stv[2];
+    h->greedy_stalls += stv[3];
     if (!*undecided && want_dist) {
         for (int u = 0; u < nu; ++u)
             launch_greedy32_dist(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
@@ -2645,6 +2648,8 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "batch_rows")) {
         if (value < 0 || value > SNK_KNN_MAX_ROWS) return fail("batch_rows must be in 0..%d (0: one K-NN call per utterance)", (int)SNK_KNN_MAX_ROWS);
         h->batch_rows = (int)value;
+    } else if (!strcmp(name, "greedy_test_stall")) {
+        h->greedy_test_stall = value != 0.0;
     } else if (!strcmp(name, "greedy_hoist")) {
         if (value != 0.0 && value != 1.0) return fail("greedy_hoist must be 0 or 1");
         h->greedy_hoist = (int)value;
@@ -2700,6 +2705,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "greedy_hoist_launches")) *out = (double)h->greedy_hoist_launches;
     else if (!strcmp(name, "greedy_exact_windows")) *out = (double)h->greedy_exact_windows;
     else if (!strcmp(name, "greedy_second_rounds")) *out = (double)h->greedy_second_rounds;
+    else if (!strcmp(name, "greedy_stalls")) *out = (double)h->greedy_stalls;
     else if (!strcmp(name, "greedy_fallbacks")) *out = h->greedy_fallbacks;
     else if (!strcmp(name, "greedy_second_phase_rounds") || !strcmp(name, "greedy_exact_windows")) {
         // statistics of the most recent float32 scan launch: steps that needed every lane's candidates; windows

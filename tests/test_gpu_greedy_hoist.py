@@ -132,3 +132,27 @@ def test_six_utterances_share_a_scan(engine):
     assert paths[5] == list(range(7000, 7000 + 50 * me, me))
     assert engine.info('greedy_fallbacks') == 0
     engine.set_option('greedy_hoist', 1)
+
+
+def test_watchdog_ends_a_launch_that_cannot_finish(engine):
+    """The one-launch scan waits inside the kernel for its other workgroups.  If one of them never arrives (a device
+    shared with another spinning launch; here: a test hook), the wait must end by itself -- seconds, not forever --
+    and the exact scan, which never waits inside a kernel, finishes the call with the same result."""
+    import time
+    N, Dt, Dj, me = 30000, 61, 151, 6
+    engine.set_option('greedy_mode', 2); engine.set_option('greedy_hoist', 1)
+    F_unw, JC_unw, wt, wj = _setup(engine, N, Dt, Dj, seed=21, me=me, lfat=False, mode=0)
+    U = o.synthetic_targets(F_unw, 10 * me, seed=3) * wt
+    op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, U, me, False, 0, -1)
+    s0, f0 = engine.info('greedy_stalls'), engine.info('greedy_fallbacks')
+    engine.set_option('greedy_test_stall', 1)
+    t0 = time.time()
+    try:
+        path, d = engine.greedy(U, return_distances=True)
+    finally:
+        engine.set_option('greedy_test_stall', 0)
+    assert time.time() - t0 < 30.0
+    assert path == op and np.array_equal(d, od)
+    assert engine.info('greedy_stalls') == s0 + 1 and engine.info('greedy_fallbacks') == f0 + 1
+    path, d = engine.greedy(U, return_distances=True)                       # and the next launch is a normal one
+    assert path == op and np.array_equal(d, od) and engine.info('greedy_stalls') == s0 + 1
