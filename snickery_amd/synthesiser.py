@@ -409,7 +409,10 @@ class Synthesiser(object):
             devices = list(range(max(_engine.device_count(), 1)))
         ncores = min(int(ncores), len(flist))
         state = self._runtime_state()
-        jobs = [(self.config_file, self.flavour, devices[r % len(devices)], state, flist[r::ncores], synth_type, outdir)
+        # replicas that share a device use the greedy scan that launches per step: the one-launch scan waits inside the
+        # kernel for all of its workgroups, and two such launches on one GPU can keep each other from starting
+        shared = ncores > len(set(devices))
+        jobs = [(self.config_file, self.flavour, devices[r % len(devices)], state, flist[r::ncores], synth_type, outdir, shared)
                 for r in range(ncores)]
         # 'spawn': a forked child inherits an initialised HIP runtime it cannot use
         pool = multiprocessing.get_context('spawn').Pool(processes=ncores)
@@ -692,10 +695,12 @@ class Synthesiser(object):
 
 def _replica_worker(job):
     """One replica of synth_from_config(ncores > 1): its own Synthesiser on its own device, its share of the sentences."""
-    config_file, flavour, device, state, fnames, synth_type, outdir = job
+    config_file, flavour, device, state, fnames, synth_type, outdir, shared = job
     synth = Synthesiser(config_file, flavour=flavour, device=device, verbose=False)
     try:
         synth._restore_runtime_state(state)
+        if shared:
+            synth.engine.set_option('greedy_mode', 0)
         return [(f, synth.synth_utt(f, synth_type=synth_type, outdir=outdir)) for f in fnames]
     finally:
         synth.close()
