@@ -38,6 +38,7 @@
 namespace snk {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 #define G32_W 64
 #define G32_MAXW 8
 #define G32_HOIST_NSTG 3      // ring stages of the hoisted scan (little arithmetic to hide requests behind: three chunks ahead)
@@ -115,37 +116,70 @@ __device__ double g32_exact_d2(const GreedyArgs &a, int u, int64_t step, int64_t
 // The same total computed by a whole wavefront: the per-column terms fl(fl(x w - ref)^2) in parallel (coalesced
 // loads), then summed by ONE lane in the canonical order -- bit-identical to g32_exact_d2, without 1 000 dependent
 // memory round trips.  terms: (jdim + nep Dt) doubles of LDS private to the wavefront.
+// the canonical sum of one candidate's term array: join columns, then target columns, each a chain of dependent additions.
+// The LDS reads in front of the additions are not dependent: eight at a time.  Any number of lanes may run it side by side
+// on different arrays (the chains of eight candidates cost the time of one).
+__device__ __forceinline__ double g32_chain_sum(const double *terms, int jdim, int nt)
+{
+    auto chain = [&](const double *t, int n) {
+        double acc = 0.0;
+        int c = 0;
+        for (; c + 8 <= n; c += 8) {
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = t[c + j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = __dadd_rn(acc, v[j]);
+        }
+        for (; c < n; ++c) acc = __dadd_rn(acc, t[c]);
+        return acc;
+    };
+    const double acc_j = chain(terms, jdim), acc_t = chain(terms + jdim, nt);
+    return __dadd_rn(acc_j, acc_t);
+}
+
 __device__ double g32_exact_d2_wave(const GreedyArgs &a, int u, int64_t step, int64_t prev_row, bool prev_is_current, int64_t i,
-                                    double *terms, int lane)
+                                    double *terms, int lane, bool terms_only = false)
 {
     const int col0 = prev_is_current ? a.cur_col0 : a.prev_col0;
     const int64_t row0 = prev_is_current ? a.cur_row0 : a.prev_row0;
     const float *xr = a.JC_unw + (a.prev_row0 + i) * a.Jp + a.prev_col0;
     const float *rr = a.JC_unw + (row0 + (prev_row >= 0 ? prev_row : 0)) * a.Jp + col0;
-    for (int c = lane; c < a.jdim; c += 64) {
-        const double xw = __dmul_rn((double)xr[c], a.wj[a.prev_col0 + c]);
-        const double ref = prev_row >= 0 ? __dmul_rn((double)rr[c], a.wj[col0 + c]) : 0.0;
-        const double d = __dsub_rn(xw, ref);
-        terms[c] = __dmul_rn(d, d);
-    }
-    for (int k = 0; k < a.nep; ++k) {
-        const float *fr = a.F_unw + (i + a.ep[k]) * a.Fp;
-        const double *q = a.Q + (a.q_off[u] + step * a.me + a.ep[k]) * a.Dt;
-        for (int c = lane; c < a.Dt; c += 64) {
-            const double d = __dsub_rn(__dmul_rn((double)fr[c], a.wt[c]), q[c]);
-            terms[a.jdim + k * a.Dt + c] = __dmul_rn(d, d);
+    // all columns as one index space, 512 per round: the operands of eight columns per lane are requested together
+    // (the rows of a candidate are cold: nine dependent trips to HBM, one per 64 columns, were 25 us per candidate)
+    const int ncol = a.jdim + a.nep * a.Dt;
+    for (int base = 0; base < ncol; base += 512) {
+        float x[8], rx[8];
+        double w[8], rw[8], qv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = base + 64 * j + lane;
+            x[j] = 0.f; rx[j] = 0.f; w[j] = 0.0; rw[j] = 0.0; qv[j] = 0.0;
+            if (idx < a.jdim) {
+                x[j] = xr[idx]; w[j] = a.wj[a.prev_col0 + idx];
+                if (prev_row >= 0) { rx[j] = rr[idx]; rw[j] = a.wj[col0 + idx]; }
+            } else if (idx < ncol) {
+                const int t = idx - a.jdim, k = t / a.Dt, c = t - k * a.Dt;
+                x[j] = a.F_unw[(i + a.ep[k]) * a.Fp + c]; w[j] = a.wt[c];
+                qv[j] = a.Q[(a.q_off[u] + step * a.me + a.ep[k]) * a.Dt + c];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = base + 64 * j + lane;
+            if (idx < ncol) {
+                const double xw = __dmul_rn((double)x[j], w[j]);
+                const double ref = idx < a.jdim ? (prev_row >= 0 ? __dmul_rn((double)rx[j], rw[j]) : 0.0) : qv[j];
+                const double d = __dsub_rn(xw, ref);
+                terms[idx] = __dmul_rn(d, d);
+            }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wavefront's own LDS writes, in order
     __builtin_amdgcn_wave_barrier();
+    if (terms_only) return 0.0;
     double d2 = 0.0;
-    if (lane == 0) {
-        double acc_j = 0.0, acc_t = 0.0;
-        for (int c = 0; c < a.jdim; ++c) acc_j = __dadd_rn(acc_j, terms[c]);
-        const int nt = a.nep * a.Dt;
-        for (int c = 0; c < nt; ++c) acc_t = __dadd_rn(acc_t, terms[a.jdim + c]);
-        d2 = __dadd_rn(acc_j, acc_t);
-    }
+    if (lane == 0) d2 = g32_chain_sum(terms, a.jdim, a.nep * a.Dt);
     __builtin_amdgcn_wave_barrier();
     return __shfl(d2, 0, 64);
 }
@@ -166,9 +200,10 @@ __device__ __forceinline__ double g32_uniform_d(double v) { return __longlong_as
 // global memory and everybody fetched it with sc1 loads: two more fabric round trips per step.)
 template <int UB>
 __device__ void g32_build_table(const GreedyArgs &a, int64_t step, const int64_t (&prev_row)[UB], bool prev_is_current,
-                                u32x4 *dst, double *red, double (&V2)[UB], int tid, int nthreads)
+                                u32x4 *dst, double *red, double (&V2)[UB], int tid, int nthreads, int n_join_only)
 {
-    const int jch = greedy_join_chunks(a), tch = greedy_target_chunks(a);
+    // n_join_only: entries of a join-only table whose chunks are wider than GR_CC (the float16 scan); entry e = column e
+    const int jch = n_join_only ? n_join_only / GR_CC : greedy_join_chunks(a), tch = greedy_target_chunks(a);
     const int nT = a.hoist ? 0 : a.nep * tch, n = (jch + nT) * GR_CC;          // hoisted target term: join columns only
     constexpr int TE = UB <= 3 ? 1 : 2;                          // 16-byte pieces per column
     double n2[UB];
@@ -238,7 +273,16 @@ __device__ __forceinline__ double g32_err(double d, double V2, int ncols)
     return 6.0 * u * sqrt(V2 * d) * 1.01 + (double)(ncols + 8) * u * d;
 }
 
-template <bool IN_LDS, bool HOIST, int UB>
+// ... of a total whose join columns were rounded to float16 first: x~ = x (1 + delta) + eta, |delta| <= 2^-11, |eta| <= 2^-25,
+// so the vector of differences moves by at most D = 2^-11 max_i ||w o S'[i]|| + 2^-25 ||w|| (a.f16_delta), the total by
+// E16(d) = 2 sqrt(d) D + D^2, and the float32 evaluation error applies to a total of at most d + E16(d)
+__device__ __forceinline__ double g32_err16(double d, double V2, int ncols, double D)
+{
+    const double e16 = (2.0 * sqrt(d) * D + D * D) * 1.01;
+    return g32_err(d + e16, V2, ncols) + e16;
+}
+
+template <bool IN_LDS, bool HOIST, int UB, bool F16>
 __global__ void __launch_bounds__(G32_W * G32_MAXW)
 greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_bytes,
                 G32Rec *blk, unsigned int *arrive, unsigned int *arrive2, unsigned int *gen,
@@ -259,14 +303,18 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
     const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr bool in_lds = IN_LDS;
-    const int jch = greedy_join_chunks(a), tch = greedy_target_chunks(a);
+    // F16: the join columns are streamed as float16 (8 columns per 16-byte request, 64 per chunk): half the bytes, a
+    // wider bound (see g32_err16), the same exact decision
+    constexpr int CC = F16 ? 64 : GR_CC;                    // scan columns per chunk of eight 16-byte requests
+    const int jch = F16 ? (a.jdim + 63) / 64 : greedy_join_chunks(a), tch = greedy_target_chunks(a);
     const int nT = HOIST ? 0 : a.nep * tch, n_chunks = jch + nT, JQ = jch * 8, FQ = tch * 8;
-    const int ncols = n_chunks * GR_CC;
-    const int jq_last = (a.jdim + 3) / 4 - (jch - 1) * 8;   // float4 columns of the last join chunk that hold data
+    const int ncols = n_chunks * CC;
+    const int jq_last = (a.jdim + (F16 ? 7 : 3)) / (F16 ? 8 : 4) - (jch - 1) * 8;   // 16-byte columns of the last join chunk that hold data
     const int ecols = ncols + (HOIST ? 2 : 0);            // the bound's chain length: + the addition of the hoisted value
     const int pitch = tch * GR_CC + 4;
     const int nB = a.me > 1 ? tch : 0;
     const int ring_per_tile = in_lds ? tch + nB + jch : n_chunks;
+    auto errf = [&](double d, double V2) { return F16 ? g32_err16(d, V2, ecols, a.f16_delta) : g32_err(d, V2, ecols); };
     constexpr int NSTG = HOIST ? G32_HOIST_NSTG : GR_NSTG;                         // ring stages: two chunks (16 KB per wavefront) requested ahead of the arithmetic
     constexpr int TE = UB <= 3 ? 1 : 2;                     // 16-byte pieces of a table entry: (w, ref0, ref1, ref2 | ref3, ref4, ref5, -)
     const int table_bytes = ncols * 16 * TE;
@@ -280,7 +328,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
     const unsigned off_extra = (unsigned)(lane < a.me - 1 ? lane : (a.me > 1 ? a.me - 2 : 0)) * 16u;
     const unsigned jl = (unsigned)lane + (unsigned)a.prev_row0;
     const unsigned off_join = (jl >> 6) * ((unsigned)JQ << 10) + (jl & 63u) * 16u;
-    const char *const FTb = reinterpret_cast<const char *>(a.FT), *const JTb = reinterpret_cast<const char *>(a.JT);
+    const char *const FTb = reinterpret_cast<const char *>(a.FT), *const JTb = reinterpret_cast<const char *>(F16 ? a.JT16 : a.JT);
 
     // reduction scratch of the step's tail aliases the table and the target blocks
     Top3 *red3 = reinterpret_cast<Top3 *>(lds);
@@ -366,7 +414,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
         // (the builder's 384 bytes of reduction scratch sit right behind the table: the target blocks that share the
         // place in LDS mode are filled later, by the scan)
         g32_build_table<UB>(a, step, prev_row, step > 0, reinterpret_cast<u32x4 *>(lds), reinterpret_cast<double *>(lds + table_bytes),
-                            V2w, tid, (int)blockDim.x);
+                            V2w, tid, (int)blockDim.x, F16 ? ncols : 0);
         double EWw[UB];                                       // bound of the hoisted values of this step: hoist_c (||q|| + ||f||max)^2
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
@@ -385,9 +433,35 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
         // one chunk of arithmetic: x[g] = columns 4g .. 4g+3 of the chunk.  The table entries (w, ref0, ref1, ref2;
         // the same address in every lane: broadcast reads) come four columns at a time
         auto chunk = [&](f32x4 (&x)[8]) {
-            const f32x4 *const cur = table + slot * GR_CC * TE;
+            const f32x4 *const cur = table + slot * CC * TE;
             if (++slot == n_chunks) slot = 0;
             f32x4 tc[4], td[4];
+            if (F16) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const h16x8 hv = __builtin_bit_cast(h16x8, x[g]);
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            tc[i] = cur[(8 * g + 4 * hh + i) * TE];
+                            if (TE == 2) td[i] = cur[(8 * g + 4 * hh + i) * TE + 1];
+                        }
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float xv = (float)hv[4 * hh + i];
+                            asm volatile("" : "+v"(xv), "+v"(acc[0]), "+v"(acc[UB - 1]));
+#pragma unroll
+                            for (int u = 0; u < UB; ++u) {
+                                const float d = __builtin_fmaf(xv, tc[i][0], u < 3 ? -tc[i][1 + (u % 3)] : -td[i][u % 3]);
+                                acc[u] = __builtin_fmaf(d, d, acc[u]);
+                            }
+                        }
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
 #pragma unroll
@@ -514,16 +588,37 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
         // exact decision among n candidates (ids through `get`): a wavefront per candidate, canonical float64 totals,
         // lowest index on exact ties
         const int ex_cols = a.jdim + a.nep * a.Dt;
-        int nw_exact = (lds_bytes - 16384) / (ex_cols * 8);           // wavefronts whose term arrays fit the LDS
-        nw_exact = nw_exact > nwaves ? nwaves : nw_exact;
-        double *const terms = reinterpret_cast<double *>(lds + 16384) + (size_t)wave * ex_cols;
+        // term arrays in LDS behind the 16 KB of scratch: kslots per wavefront (up to four candidates whose chains run side
+        // by side in the lanes) if every wavefront gets one, else one array for as many wavefronts as fit
+        int kslots = (lds_bytes - 16384) / (ex_cols * 8 * nwaves);
+        kslots = kslots > 4 ? 4 : kslots;
+        int nw_exact = kslots >= 1 ? nwaves : (lds_bytes - 16384) / (ex_cols * 8);
+        if (kslots < 1) kslots = 1;
+        double *const terms = reinterpret_cast<double *>(lds + 16384) + (size_t)wave * kslots * ex_cols;
         auto exact_argmin = [&](int u, int n, auto get) -> int64_t {
             double dbest = DBL_MAX;
             int64_t ibest = INT64_MAX;
-            for (int p = wave; p < n && wave < nw_exact; p += nw_exact) {
-                const int64_t i = get(p);
-                const double d = g32_exact_d2_wave(a, u, step, prev_row[u], step > 0, i, terms, lane);
-                if (d < dbest || (d == dbest && i < ibest)) { dbest = d; ibest = i; }
+            for (int p0 = wave; p0 < n && wave < nw_exact; p0 += nw_exact * kslots) {
+                int64_t myid = INT64_MAX;                         // lane k < cnt: the k-th candidate of this round
+                int cnt = 0;
+                for (int k = 0; k < kslots; ++k) {
+                    const int p = p0 + k * nw_exact;
+                    if (p >= n) break;                             // uniform
+                    const int64_t i = get(p);
+                    g32_exact_d2_wave(a, u, step, prev_row[u], step > 0, i, terms + (size_t)k * ex_cols, lane, true);
+                    if (lane == k) myid = i;
+                    ++cnt;
+                }
+                double d = DBL_MAX;
+                if (lane < cnt) d = g32_chain_sum(terms + (size_t)lane * ex_cols, a.jdim, a.nep * a.Dt);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int m = 1; m <= 2; m <<= 1) {                 // kslots <= 4: lanes 0 .. 3
+                    const double od = __shfl_xor(d, m, 64); const int64_t oi = __shfl_xor(myid, m, 64);
+                    if (od < d || (od == d && oi < myid)) { d = od; myid = oi; }
+                }
+                d = __shfl(d, 0, 64); myid = __shfl(myid, 0, 64);
+                if (d < dbest || (d == dbest && myid < ibest)) { dbest = d; ibest = myid; }
             }
             __syncthreads();
             double *rd = reinterpret_cast<double *>(lds + 8192);
@@ -611,11 +706,11 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                     double EW = EWw[0];
 #pragma unroll
                     for (int k = 1; k < UB; ++k) EW = u == k ? EWw[k] : EW;
-                    if (approx && (!HOIST || 4.0 * (g32_err((double)mv, V2, ecols) + EW) <= 1e-3 * (double)mv)) state = 1;
+                    if (approx && (!HOIST || 4.0 * (errf((double)mv, V2) + EW) <= 1e-3 * (double)mv)) state = 1;
                     else {
                         const double M = (double)mv + 2.0 * EW;
-                        double tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300;
-                        for (int it = 0; it < 3; ++it) tau = M + 2.0 * g32_err(tau, V2, ecols);
+                        double tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300 + (F16 ? 64.0 * a.f16_delta * a.f16_delta : 0.0);
+                        for (int it = 0; it < 3; ++it) tau = M + 2.0 * errf(tau, V2);
                         tau = tau * (1.0 + 1e-6) + 1e-300;
                         int nc = 0;
                         bool cov = false;
@@ -680,7 +775,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                 const double EW = EWr[u];
                 // search_epsilon mode: the float32 minimum is the answer -- with a hoisted target term only where its
                 // ABSOLUTE bound is small against the minimum (it is not for near-exact matches: decided exactly then)
-                if (approx && (!HOIST || 4.0 * (g32_err((double)mv, V2r[u], ecols) + EW) <= 1e-3 * (double)mv)) {
+                if (approx && (!HOIST || 4.0 * (errf((double)mv, V2r[u]) + EW) <= 1e-3 * (double)mv)) {
                     winner[u] = mi;
                     continue;
                 }
@@ -690,8 +785,8 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                 // ~1e-5 per round and three rounds leave nothing to gain (eight cost 1 us of float64 square roots)
                 const double V2 = V2r[u];
                 const double M = (double)mv + 2.0 * EW;
-                double tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300;
-                for (int it = 0; it < 3; ++it) tau = M + 2.0 * g32_err(tau, V2, ecols);
+                double tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300 + (F16 ? 64.0 * a.f16_delta * a.f16_delta : 0.0);
+                for (int it = 0; it < 3; ++it) tau = M + 2.0 * errf(tau, V2);
                 tau = tau * (1.0 + 1e-6) + 1e-300;
                 if (u == 0) stamp(step, 9);
                 int *ccount = reinterpret_cast<int *>(lds);
@@ -811,7 +906,9 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wavefront's offers, before the workgroup arrives
             __syncthreads();
             ++collect_rounds;
+            stamp(step, 12);
             if (arrive_last(arrive2, (unsigned int)collect_rounds)) {
+                stamp(step, 13);
                 int64_t winner[UB];
                 bool undecided = __hip_atomic_load(&ctl->list_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 #pragma unroll
@@ -824,6 +921,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                     winner[u] = exact_argmin(u, (int)n, [&](int p) {
                         return __hip_atomic_load(&clist_g[(size_t)u * G32_LIST + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
                 }
+                stamp(step, 14);
                 finalize(winner, undecided);
             }
             }
@@ -958,14 +1056,21 @@ void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, 
     size_t lds = greedy32_table_floats(g, Dt, hoist) * 4 + 512 + (in_lds ? (size_t)waves * g32_lds_wave_bytes(g, Dt) : 0);
     // the step's tail: 16 KB of reduction scratch + a term array per wavefront for exact decisions
     const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
-    const size_t tail = 16384 + (size_t)waves * (size_t)(g.jdim + nep * Dt) * 8;
+    const size_t per_wave = (size_t)(g.jdim + nep * Dt) * 8;
+    size_t tail = 16384 + (size_t)waves * per_wave;
+    for (int k = 4; k >= 2; --k)
+        if (16384 + (size_t)waves * per_wave * k <= (size_t)(144 * 1024)) { tail = 16384 + (size_t)waves * per_wave * k; break; }
     if (lds < tail) lds = tail < (size_t)(160 * 1024) ? tail : (size_t)(160 * 1024);
     // small scans live in L2 / Infinity Cache across the steps of the launch; big ones are streamed
     const size_t scan_bytes = (size_t)g.Nwin * (size_t)(g.jdim + (hoist ? 1 : Dt)) * 4;
     // (2: the hoisted scan sends the requests of all-padding float4 columns to the chunk's first column)
     const int use_nt = scan_bytes > ((size_t)192 << 20) ? (hoist ? 2 : 1) : 0;
-    auto kernel = wide ? greedy32_kernel<false, true, G32_UBX> : hoist ? greedy32_kernel<false, true, G32_UB>
-                  : in_lds ? greedy32_kernel<true, false, G32_UB> : greedy32_kernel<false, false, G32_UB>;
+    // float16 join tiles: databases that are streamed from HBM, up to three utterances per scan
+    const bool f16 = hoist && hst->JT16 != nullptr && !wide && (use_nt != 0 || hst->f16_force);
+    if (f16) { a.JT16 = reinterpret_cast<const f32x4 *>(hst->JT16); a.f16 = 1; a.f16_delta = hst->f16_delta; }
+    auto kernel = f16 ? (nu == 1 ? greedy32_kernel<false, true, 1, true> : greedy32_kernel<false, true, G32_UB, true>)
+                  : wide ? greedy32_kernel<false, true, G32_UBX, false> : hoist ? greedy32_kernel<false, true, G32_UB, false>
+                  : in_lds ? greedy32_kernel<true, false, G32_UB, false> : greedy32_kernel<false, false, G32_UB, false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     char *wb = reinterpret_cast<char *>(blk);
     G32Ctl *ctl = reinterpret_cast<G32Ctl *>(wb + g32_rec_bytes(nblk));

@@ -34,6 +34,8 @@ struct GreedyArgs {
     const float *W[6]; int64_t Wp;
     const double *qn2[6];
     double hoist_c, fwmax2;
+    // float16 copy of the join tiles (8 columns per 16 bytes, chunks of 64 columns) and the bound's term for it
+    const f32x4 *JT16; int f16; double f16_delta;
 };
 #define GR_MAXU 2          // utterances per scan: one weight and the references share 32 table bytes per column
 

@@ -478,6 +478,84 @@ size_t greedy_tile_bytes(const GreedyLayout &g, int Dt)
 }
 
 // Build the lane-major tiles from the row-major unweighted matrices (once per database + layout).
+// float16 copy of the join tiles for the float32 scan with the hoisted target term (greedy32_kernels.hip, F16 instance):
+// tile[row / 64][q][row % 64] = columns 8q .. 8q+7 as eight halves (round to nearest), 8 ceil(jdim / 64) q's per tile.
+// *max_abs_bits: bit pattern of the largest |value| seen (the caller refuses the copy if it leaves the float16 range).
+typedef _Float16 gk_h16x8 __attribute__((ext_vector_type(8)));
+__global__ void greedy_tile16_kernel(const float *__restrict__ src, int pitch, int64_t nrows, int col0, int ncols,
+                                     int Q, int64_t n_elems, gk_h16x8 *__restrict__ dst, unsigned int *__restrict__ max_abs_bits)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_elems) return;
+    const int lane = (int)(idx & 63);
+    const int64_t g = idx >> 6;
+    const int q = (int)(g % Q);
+    const int64_t r = (g / Q) * 64 + lane;
+    gk_h16x8 v;
+    float mx = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int col = 8 * q + e;
+        const float x = (r < nrows && col < ncols) ? src[r * pitch + col0 + col] : 0.f;
+        mx = fmaxf(mx, fabsf(x));
+        v[e] = (_Float16)x;
+    }
+    dst[idx] = v;
+    if (mx > 0.f) atomicMax(max_abs_bits, __float_as_uint(mx));
+}
+size_t greedy_tile16_bytes(const GreedyLayout &g)
+{
+    const int64_t tiles = (g.Nwin + 63) / 64 + (g.prev_row0 + 63) / 64 + 1;
+    return (size_t)tiles * ((g.jdim + 63) / 64 * 8) * 64 * 16;
+}
+void launch_greedy_tiles16(const GreedyLayout &g, const float *JC_unw, int Jp, void *tiles16, unsigned int *max_abs_bits, hipStream_t s)
+{
+    const int Q = (g.jdim + 63) / 64 * 8;
+    const int64_t n = (int64_t)(greedy_tile16_bytes(g) / 16);
+    (void)hipMemsetAsync(max_abs_bits, 0, sizeof(unsigned int), s);
+    hipLaunchKernelGGL(greedy_tile16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, JC_unw, Jp, g.Nwin + g.me, g.prev_col0, g.jdim,
+                       Q, n, reinterpret_cast<gk_h16x8 *>(tiles16), max_abs_bits);
+}
+
+// out[0] = max over the windows' join rows of ||w o S'[i]||^2 (bit pattern of the float64), out[1] = ||w||^2 over the scan
+// columns: what the float16 scan's bound needs, once per set of weights.  One thread per row of the lane-major float32 tiles.
+__global__ void greedy_join_norms_kernel(const f32x4 *__restrict__ JT, int JQ, int64_t row0, int64_t nrows, const double *__restrict__ wj,
+                                         int col0, int jdim, unsigned long long *__restrict__ out)
+{
+    __shared__ double red[256];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double v = 0.0;
+    if (i < nrows) {
+        const int64_t r = row0 + i;
+        const f32x4 *t = JT + ((r >> 6) * JQ << 6) + (r & 63);
+        for (int q = 0; q * 4 < jdim; ++q) {
+            const f32x4 x = t[(int64_t)q << 6];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * q + e < jdim) { const double y = (double)x[e] * wj[col0 + 4 * q + e]; v += y * y; }
+        }
+    }
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(red[0]));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double w2 = 0.0;
+        for (int c = 0; c < jdim; ++c) w2 += wj[col0 + c] * wj[col0 + c];
+        out[1] = (unsigned long long)__double_as_longlong(w2);
+    }
+}
+void launch_greedy_join_norms(const GreedyLayout &g, const float *tiles, const double *wj, unsigned long long *out, hipStream_t s)
+{
+    (void)hipMemsetAsync(out, 0, 2 * sizeof(unsigned long long), s);
+    const int JQ = (g.jdim + GR_CC - 1) / GR_CC * 8;
+    hipLaunchKernelGGL(greedy_join_norms_kernel, dim3((unsigned)((g.Nwin + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(tiles), JQ,
+                       g.prev_row0, g.Nwin, wj, g.prev_col0, g.jdim, out);
+}
+
 void launch_greedy_tiles(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const float *JC_unw, int Jp,
                          float *tiles, hipStream_t s)
 {

@@ -188,6 +188,10 @@ struct snk_engine {
     // hoisted target term of the float32 scan (greedy_hoist_kernels.hip): window norms (per database, layout and
     // weights), left operands and products of the utterances in work
     DevBuf gh_nw, gh_max, gh_aq, gh_qn2, gh_W;
+    DevBuf gtiles16;                      // float16 copy of the join tiles (the hoisted scan of streamed databases)
+    bool gt16_ready = false, gt16_ok = false, gj_ready = false;
+    double g16_delta = 0.0;               // the float16 bound's term: 2^-11 max ||w o S'|| + 2^-25 ||w||
+    int greedy_f16 = 1;                   // 1: float16 join tiles where the database is streamed; 2: always (tests); 0: never
     bool gh_ready = false;
     double gh_fwmax2 = 0.0;
     int greedy_test_stall = 0;            // test hook (option greedy_test_stall): one workgroup of the float32 scan never arrives at step 1
@@ -369,7 +373,7 @@ int snk_destroy(snk_handle h)
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
                       &h->gpath, &h->gdist, &h->gsync, &h->gtiles, &h->cls16_full, &h->cls16_samp,
                       &h->g32_blk, &h->g32_ctl,
-                      &h->gh_nw, &h->gh_max, &h->gh_aq, &h->gh_qn2, &h->gh_W};
+                      &h->gh_nw, &h->gh_max, &h->gh_aq, &h->gh_qn2, &h->gh_W, &h->gtiles16};
     for (auto *b : bufs) b->release();
     if (h->dp_stream[1]) (void)hipStreamDestroy(h->dp_stream[1]);
     h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
@@ -442,8 +446,8 @@ int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt, const flo
     h->have_weights = false;
     h->have_classes = false;
     h->have_glay = false;
-    h->gtiles_ready = false;
-    h->gh_ready = false;
+    h->gtiles_ready = false; h->gt16_ready = false;
+    h->gh_ready = false; h->gj_ready = false;
     h->gs_rows = 0; h->gs_ready = false;
     if (h->global_N < 0) { h->shard_offset = 0; }
     if (JC_unw) CHK(upload_join(h, JC_unw, Njc, Dj));
@@ -539,7 +543,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
                                h->Djpad, h->stream);
     }
     HIPCHK(hipGetLastError());
-    h->gh_ready = false;                  // window norms of the hoisted greedy target term follow the target weights
+    h->gh_ready = false; h->gj_ready = false;                  // window norms of the hoisted greedy target term follow the target weights
     // float32 operands of the prefilter (knn16_kernels.hip): ||f||^2 rides in ONE spare padding column
     h->f16_ready = false;
     h->cls16_ready = false;
@@ -1582,8 +1586,8 @@ int snk_set_greedy_layout(snk_handle h, int multiepoch, int last_frame_as_target
         return fail("snk_set_greedy_layout: too many scan columns for the greedy step's table (join %d + %d epochs x %d)", g.jdim, multiepoch, h->Dt);
     h->glay = g;
     h->have_glay = true;
-    h->gtiles_ready = false;
-    h->gh_ready = false;
+    h->gtiles_ready = false; h->gt16_ready = false;
+    h->gh_ready = false; h->gj_ready = false;
     return 0;
 }
 
@@ -1632,6 +1636,33 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
             }
             HIPCHK(hipGetLastError());
             hst.Wp = Wp; hst.c = greedy_hoist_c(g, h->Dt); hst.fwmax2 = h->gh_fwmax2;
+            if (h->greedy_f16 && nu <= 3) {
+                CHK(h->gh_max.ensure(64));
+                if (!h->gt16_ready) {
+                    // once per database and layout: the float16 tiles (refused if a value leaves the float16 range)
+                    CHK(h->gtiles16.ensure(greedy_tile16_bytes(g)));
+                    unsigned int *mx = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(h->gh_max.p) + 32);
+                    launch_greedy_tiles16(g, h->JC_unw.as<float>(), h->Jp, h->gtiles16.p, mx, h->stream);
+                    HIPCHK(hipGetLastError());
+                    float mabs = 0.f;
+                    HIPCHK(hipMemcpyAsync(&mabs, mx, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+                    HIPCHK(hipStreamSynchronize(h->stream));
+                    h->gt16_ok = mabs < 6.0e4f;
+                    h->gt16_ready = true;
+                }
+                if (h->gt16_ok && !h->gj_ready) {
+                    // once per set of weights: max ||w o S'[i]||^2 and ||w||^2
+                    unsigned long long *o2 = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(h->gh_max.p) + 16);
+                    launch_greedy_join_norms(g, h->gtiles.as<float>(), h->wj.as<double>(), o2, h->stream);
+                    HIPCHK(hipGetLastError());
+                    double v[2] = {0.0, 0.0};
+                    HIPCHK(hipMemcpyAsync(v, o2, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+                    HIPCHK(hipStreamSynchronize(h->stream));
+                    h->g16_delta = 4.8828125e-4 * sqrt(v[0]) + 2.98023223876953125e-8 * sqrt(v[1]);
+                    h->gj_ready = true;
+                }
+                if (h->gt16_ok) { hst.JT16 = h->gtiles16.p; hst.f16_delta = h->g16_delta; hst.f16_force = h->greedy_f16 == 2; }
+            }
             h->greedy_hoist_launches += 1;
         }
     }
@@ -2648,6 +2679,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "batch_rows")) {
         if (value < 0 || value > SNK_KNN_MAX_ROWS) return fail("batch_rows must be in 0..%d (0: one K-NN call per utterance)", (int)SNK_KNN_MAX_ROWS);
         h->batch_rows = (int)value;
+    } else if (!strcmp(name, "greedy_f16")) {
+        if (value != 0.0 && value != 1.0 && value != 2.0) return fail("greedy_f16 must be 0, 1 (streamed databases) or 2 (always)");
+        h->greedy_f16 = (int)value;
     } else if (!strcmp(name, "greedy_test_stall")) {
         h->greedy_test_stall = value != 0.0;
     } else if (!strcmp(name, "greedy_hoist")) {
@@ -2703,6 +2737,8 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "greedy_mode")) *out = h->greedy_mode;
     else if (!strcmp(name, "greedy_hoist")) *out = h->greedy_hoist;
     else if (!strcmp(name, "greedy_hoist_launches")) *out = (double)h->greedy_hoist_launches;
+    else if (!strcmp(name, "greedy_f16")) *out = h->greedy_f16;
+    else if (!strcmp(name, "greedy_f16_delta")) *out = h->g16_delta;
     else if (!strcmp(name, "greedy_exact_windows")) *out = (double)h->greedy_exact_windows;
     else if (!strcmp(name, "greedy_second_rounds")) *out = (double)h->greedy_second_rounds;
     else if (!strcmp(name, "greedy_stalls")) *out = (double)h->greedy_stalls;

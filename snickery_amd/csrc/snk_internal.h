@@ -155,6 +155,10 @@ size_t greedy_tile_bytes(const GreedyLayout &g, int Dt);
 void launch_greedy_tiles(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const float *JC_unw, int Jp,
                          float *tiles, hipStream_t s);
 int greedy_blocks(const GreedyLayout &g, int Dt, int n_cus, int ub = 1);
+// float16 copy of the join tiles and the norms its bound needs (the float32 scan with the hoisted target term)
+size_t greedy_tile16_bytes(const GreedyLayout &g);
+void launch_greedy_tiles16(const GreedyLayout &g, const float *JC_unw, int Jp, void *tiles16, unsigned int *max_abs_bits, hipStream_t s);
+void launch_greedy_join_norms(const GreedyLayout &g, const float *tiles, const double *wj, unsigned long long *out, hipStream_t s);
 bool greedy_supported(const GreedyLayout &g, int Dt);
 
 // float32 prefilter scan, one persistent launch per utterance group (greedy32_kernels.hip)
@@ -168,6 +172,8 @@ struct G32Hoist {
     const double *qn2[6];     // per utterance: ||target vector of the step||^2
     int64_t Wp;
     double c, fwmax2;         // bound |W~ - W| <= 2^-24 W + c (||q|| + sqrt(fwmax2))^2
+    const void *JT16;         // float16 join tiles (nullptr: none) and the bound's term 2^-11 max ||w o S'|| + 2^-25 ||w||
+    double f16_delta; int f16_force;
 };
 int64_t greedy_hoist_pitch(const GreedyLayout &g);
 int greedy_hoist_k(const GreedyLayout &g, int Dt);

@@ -156,3 +156,46 @@ def test_watchdog_ends_a_launch_that_cannot_finish(engine):
     assert engine.info('greedy_stalls') == s0 + 1 and engine.info('greedy_fallbacks') == f0 + 1
     path, d = engine.greedy(U, return_distances=True)                       # and the next launch is a normal one
     assert path == op and np.array_equal(d, od) and engine.info('greedy_stalls') == s0 + 1
+
+
+@pytest.mark.parametrize('me,lfat,mode,Dj,Dt,offset', [(6, False, 0, 151, 61, 0.0), (3, True, 0, 100, 61, 0.0), (4, False, 1, 302, 61, 0.0),
+                                                      (1, False, 0, 70, 61, 2.5), (5, True, 1, 200, 130, -3.0), (2, False, 0, 129, 64, 0.0)])
+def test_float16_join_tiles_keep_the_results(engine, me, lfat, mode, Dj, Dt, offset):
+    """Streamed databases are scanned from a float16 copy of the join tiles (half the bytes; here forced on a small
+    one, greedy_f16 2).  The wider bound lets more windows through to the exact decision; the paths and distances
+    stay the oracle's."""
+    N = 30000 + me
+    engine.set_option('greedy_mode', 2); engine.set_option('greedy_hoist', 1); engine.set_option('greedy_f16', 2)
+    try:
+        F_unw, JC_unw, wt, wj = _setup(engine, N, Dt, Dj, seed=5 * me + Dt, me=me, lfat=lfat, mode=mode, offset=offset)
+        lens = [33 * me + (me - 1), 16 * me, 17 * me, me]
+        utts = [o.synthetic_targets(F_unw, T, seed=16 + i) * wt for i, T in enumerate(lens)]
+        starts = [-1, 17, N - me - 3, 0]
+        f0 = engine.info('greedy_fallbacks')
+        for U, st in zip(utts[:3], starts[:3]):
+            path, d = engine.greedy(U, start_state=st, return_distances=True)
+            op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, U, me, lfat, mode, st)
+            assert path == op and np.array_equal(d, od)
+        assert engine.info('greedy_f16_delta') > 0.0
+        paths, dists = engine.greedy_batch(utts[:3], start_states=starts[:3], return_distances=True)      # three per scan
+        for U, st, p, d in zip(utts, starts, paths, dists):
+            op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, U, me, lfat, mode, st)
+            assert p == op and np.array_equal(d, od)
+        # other join weights: the bound's norm follows them
+        wj2 = wj[::-1].copy() * 3.0
+        engine.set_weights(wt, wj2)
+        d0 = engine.info('greedy_f16_delta')
+        path, d = engine.greedy(utts[1], return_distances=True)
+        op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj2, utts[1], me, lfat, mode, -1)
+        assert path == op and np.array_equal(d, od) and engine.info('greedy_f16_delta') != d0
+        assert engine.info('greedy_fallbacks') == f0
+        # duplicated speech: exact ties through the float16 scan
+        if me == 6:
+            F2, J2 = F_unw.copy(), JC_unw.copy()
+            F2[20000:20300] = F2[3000:3300]; J2[20000:20301] = J2[3000:3301]
+            engine.upload_db(F2, J2); engine.set_weights(wt, wj); engine.set_greedy_layout(me, lfat, mode)
+            U = F2[3100:3100 + 15 * me].astype(np.float64) * wt
+            path, d = engine.greedy(U, start_state=3100, return_distances=True)
+            assert path == list(range(3100, 3100 + 15 * me, me)) and np.all(d == 0.0)
+    finally:
+        engine.set_option('greedy_f16', 1)

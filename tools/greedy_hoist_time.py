@@ -17,8 +17,8 @@ for N in sizes:
     Us = [synthetic_targets(F_unw, T - 6 * i, seed=2 + i) * wt for i in range(6)]
     steps = T // me
     ref = None
-    for name, mode, hoist in (('exact scan', 0, 0), ('float32 scan', 1, 0), ('float32 scan, hoisted', 1, 1)):
-        eng.set_option('greedy_mode', mode); eng.set_option('greedy_hoist', hoist)
+    for name, mode, hoist, f16 in (('exact scan', 0, 0, 0), ('float32 scan', 1, 0, 0), ('float32 scan, hoisted', 1, 1, 0), ('hoisted, float16 tiles', 1, 1, 2)):
+        eng.set_option('greedy_mode', mode); eng.set_option('greedy_hoist', hoist); eng.set_option('greedy_f16', f16)
         p, d = eng.greedy(U, return_distances=True)
         if ref is None:
             ref = (p, d)
@@ -32,11 +32,11 @@ for N in sizes:
         tm = eng.timers()['greedy_steps']
         us = tm[0] / tm[1] / steps * 1e3
         print('N=%d %-24s one utterance: %.2f ms (%.1f us/step) %.0f frames/s; algorithmic (Dj+1)4N: %.2f TB/s; exact windows/step %.2f; fallbacks %d' % (
-            N, name, dt * 1e3, us, T / dt, N * (Dj + 1) * 4.0 / (us * 1e-6) / 1e12,
+            N, name[:24], dt * 1e3, us, T / dt, N * (Dj + 1) * 4.0 / (us * 1e-6) / 1e12,
             (eng.info('greedy_exact_windows') - x0) / 3.0 / steps, eng.info('greedy_fallbacks')), flush=True)
     bref = None
-    for name, mode, hoist in (('exact scan', 0, 0), ('float32 scan', 2, 0), ('float32 scan, hoisted', 2, 1)):
-        eng.set_option('greedy_mode', mode); eng.set_option('greedy_hoist', hoist)
+    for name, mode, hoist, f16 in (('exact scan', 0, 0, 0), ('float32 scan', 2, 0, 0), ('float32 scan, hoisted', 2, 1, 0), ('hoisted, float16 tiles', 2, 1, 2)):
+        eng.set_option('greedy_mode', mode); eng.set_option('greedy_hoist', hoist); eng.set_option('greedy_f16', f16)
         r = eng.greedy_batch(Us)
         if bref is None:
             bref = r
