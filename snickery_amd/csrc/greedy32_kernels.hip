@@ -145,14 +145,15 @@ __device__ double g32_exact_d2_wave(const GreedyArgs &a, int u, int64_t step, in
     const int64_t row0 = prev_is_current ? a.cur_row0 : a.prev_row0;
     const float *xr = a.JC_unw + (a.prev_row0 + i) * a.Jp + a.prev_col0;
     const float *rr = a.JC_unw + (row0 + (prev_row >= 0 ? prev_row : 0)) * a.Jp + col0;
-    // all columns as one index space, 512 per round: the operands of eight columns per lane are requested together
+    // all columns as one index space, 576 per round: the operands of nine columns per lane are requested together
     // (the rows of a candidate are cold: nine dependent trips to HBM, one per 64 columns, were 25 us per candidate)
     const int ncol = a.jdim + a.nep * a.Dt;
-    for (int base = 0; base < ncol; base += 512) {
-        float x[8], rx[8];
-        double w[8], rw[8], qv[8];
+    constexpr int NJ = 9;
+    for (int base = 0; base < ncol; base += 64 * NJ) {
+        float x[NJ], rx[NJ];
+        double w[NJ], rw[NJ], qv[NJ];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int idx = base + 64 * j + lane;
             x[j] = 0.f; rx[j] = 0.f; w[j] = 0.0; rw[j] = 0.0; qv[j] = 0.0;
             if (idx < a.jdim) {
@@ -165,7 +166,7 @@ __device__ double g32_exact_d2_wave(const GreedyArgs &a, int u, int64_t step, in
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int idx = base + 64 * j + lane;
             if (idx < ncol) {
                 const double xw = __dmul_rn((double)x[j], w[j]);
@@ -601,16 +602,36 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
             for (int p0 = wave; p0 < n && wave < nw_exact; p0 += nw_exact * kslots) {
                 int64_t myid = INT64_MAX;                         // lane k < cnt: the k-th candidate of this round
                 int cnt = 0;
-                for (int k = 0; k < kslots; ++k) {
-                    const int p = p0 + k * nw_exact;
-                    if (p >= n) break;                             // uniform
-                    const int64_t i = get(p);
+                int64_t ids[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ids[k] = (k < kslots && p0 + k * nw_exact < n) ? get(p0 + k * nw_exact) : -1;   // one round trip
+                stamp(step, 8);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (ids[k] < 0) break;                         // uniform
+                    const int64_t i = ids[k];
                     g32_exact_d2_wave(a, u, step, prev_row[u], step > 0, i, terms + (size_t)k * ex_cols, lane, true);
                     if (lane == k) myid = i;
                     ++cnt;
                 }
+                stamp(step, 9);
+                // lane 2k sums the join columns of candidate k, lane 2k + 1 its target columns (two independent chains of
+                // the canonical order), then one rounded addition joins them
                 double d = DBL_MAX;
-                if (lane < cnt) d = g32_chain_sum(terms + (size_t)lane * ex_cols, a.jdim, a.nep * a.Dt);
+                {
+                    const int k = lane >> 1;
+                    double part = 0.0;
+                    if (k < cnt) {
+                        // (one loop for both kinds of lanes -- pointer and length differ: a branch would run the two chains
+                        // one after the other)
+                        const double *t = terms + (size_t)k * ex_cols + ((lane & 1) ? a.jdim : 0);
+                        part = g32_chain_sum(t, (lane & 1) ? a.nep * a.Dt : a.jdim, 0);
+                    }
+                    const double other = __shfl_xor(part, 1, 64);
+                    const double tot = (lane & 1) ? __dadd_rn(other, part) : __dadd_rn(part, other);      // acc_j + acc_t
+                    const double dk = __shfl(tot, (lane & 3) << 1, 64);         // lane k < 4 fetches candidate k's total
+                    if (lane < cnt) d = dk;
+                }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int m = 1; m <= 2; m <<= 1) {                 // kslots <= 4: lanes 0 .. 3
@@ -618,6 +639,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                     if (od < d || (od == d && oi < myid)) { d = od; myid = oi; }
                 }
                 d = __shfl(d, 0, 64); myid = __shfl(myid, 0, 64);
+                stamp(step, 10);
                 if (d < dbest || (d == dbest && myid < ibest)) { dbest = d; ibest = myid; }
             }
             __syncthreads();
@@ -633,6 +655,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
         };
         // end of a step.  The winners ARE the release: every workgroup polls the step's path entries (-1 until
         // written) and builds the next table itself.  An undecidable step ends the launch through the generation word.
+        unsigned long long stat_rounds = 0, stat_windows = 0;
         auto finalize = [&](const int64_t (&winner)[UB], bool undecided) {
             if (undecided) {
                 if (tid == 0) {
@@ -645,6 +668,11 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                 for (int u = 0; u < UB; ++u)
                     if (u < a.nu && step < a.nsteps_u[u])
                         __hip_atomic_store(&path[a.out_off[u] + step], winner[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid == 0 && (stat_rounds | stat_windows)) {       // statistics, behind the release
+                __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&status[1]), stat_rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&status[2]), stat_windows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                stat_rounds = 0; stat_windows = 0;
             }
         };
 
@@ -815,7 +843,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                     continue;
                 }
                 if (nc == 1) { winner[u] = clist[0]; __syncthreads(); continue; }
-                if (tid == 0) status[2] += nc;                  // statistics: windows decided by exact totals
+                stat_windows += (unsigned long long)nc;         // statistics: windows decided by exact totals
                 winner[u] = exact_argmin(u, nc, [&](int p) { return clist[p]; });
             }
             stamp(step, 5);
@@ -910,14 +938,21 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
             if (arrive_last(arrive2, (unsigned int)collect_rounds)) {
                 stamp(step, 13);
                 int64_t winner[UB];
-                bool undecided = __hip_atomic_load(&ctl->list_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                unsigned int counts[UB];
+                const unsigned int over = __hip_atomic_load(&ctl->list_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {                     // (requested together: one round trip)
+                    winner[u] = __hip_atomic_load(&ctl->pending[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    counts[u] = __hip_atomic_load(&ctl->list_count[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                bool undecided = over != 0u;
+                stamp(step, 15);
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
-                    winner[u] = __hip_atomic_load(&ctl->pending[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (!((need >> u) & 1u) || undecided) continue;
-                    const unsigned int n = __hip_atomic_load(&ctl->list_count[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned int n = counts[u];
                     if (n < 1u || n > (unsigned int)G32_LIST) { undecided = true; continue; }
-                    if (tid == 0) { status[1] += 1; status[2] += (int64_t)n; }      // statistics: second-phase rounds
+                    stat_rounds += 1; stat_windows += n;          // statistics: second-phase rounds
                     winner[u] = exact_argmin(u, (int)n, [&](int p) {
                         return __hip_atomic_load(&clist_g[(size_t)u * G32_LIST + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
                 }

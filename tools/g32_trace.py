@@ -30,10 +30,10 @@ for s in range(8, 40):
         continue
     t0 = x[:, 0].min()
     rows.append([x[:, 0].max() - t0, np.median(x[:, 1]) - t0, np.median(x[:, 2]) - t0, x[:, 2].max() - t0, x[:, 3].max() - t0,
-                 x[dec, 4] - t0, x[dec, 5] - t0, np.median(x[:, 7]) - t0, x[:, 12].max() - t0, x[:, 13].max() - t0, x[:, 14].max() - t0, x[dec, 6] - t0, np.median(t[s + 1][:, 0]) - t0, t[s + 1][:, 0].min() - t0])
+                 x[dec, 4] - t0, x[dec, 5] - t0, np.median(x[:, 7]) - t0, x[:, 12].max() - t0, x[:, 13].max() - t0, x[:, 15].max() - t0, x[:, 8].max() - t0, x[:, 9].max() - t0, x[:, 10].max() - t0, x[:, 14].max() - t0, x[dec, 6] - t0, np.median(t[s + 1][:, 0]) - t0, t[s + 1][:, 0].min() - t0])
 r = np.array(rows)
 names = ['last wg sees table', 'table in LDS (median)', 'scan done (median)', 'scan done (last)', 'published (last)', 'decider: last arrival',
-         'decider: decided', '2nd phase: entered (median)', '2nd phase: offers made (last)', '2nd phase: last arrival', '2nd phase: decided', 'decider: released', 'next step seen (median)', 'next step seen (first)']
+         'decider: decided', '2nd phase: entered (median)', '2nd phase: offers made (last)', '2nd phase: last arrival', '2nd: control words read', '2nd: candidate ids read', '2nd: terms of the candidates stored', '2nd: chains summed', '2nd phase: decided', 'decider: released', 'next step seen (median)', 'next step seen (first)']
 print('%d utterance(s) per scan; ' % NU + 'N = %d, %d workgroups; microseconds from the first workgroup seeing the step (mean over %d steps)' % (N, nb, len(rows)))
 for n, v in zip(names, r.mean(0)):
     print('  %-28s %6.2f' % (n, v))
