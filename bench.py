@@ -167,8 +167,11 @@ def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')),
         # up to whole float4 columns, the target value written once by the product and read once by the scan -- or, where
         # the product is not used (greedy_hoist 0, narrow join streams), the Dt target columns instead.
         hoisted = eng.info('greedy_hoist_launches') > 0
+        f16 = eng.info('greedy_f16_launches') > 0            # streamed databases: the join columns as float16 (8 per 16 bytes)
         bytes_step = float(N) * (Dj + 1) * 4.0
         bytes_streamed = float(N) * (((Dj + 3) // 4 * 4 + 2) if hoisted else (Dj + Dt)) * 4.0
+        if f16:
+            bytes_streamed = float(N) * ((Dj + 7) // 8 * 8 * 2.0 + 8.0)
         # a batch through snk_greedy_batch: the float32 prefilter scan, six utterances per scan of the database (three
         # where the target term is not hoisted)
         # (one persistent launch), exact float64 decisions -- the same paths
@@ -185,7 +188,7 @@ def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')),
                  'roofline': {'bound': 'hbm', 'achieved': bfrac * 8000.0, 'peak': 8000.0, 'unit': 'GB/s', 'frac': bfrac,
                               'note': 'one scan of the database serves %d utterances: the scan\'s algorithmic bytes / %d per utterance step' % (per_scan, per_scan)}}
         out[name] = {'units': N, 'multiepoch': me, 'frames': T, 'steps': steps, 'us_per_step': us_step, 'batch': batch,
-                     'target_term_hoisted': bool(hoisted),
+                     'target_term_hoisted': bool(hoisted), 'join_tiles': 'float16' if f16 else 'float32',
                      'frames_per_s': T / dt, 'ms_per_utterance': dt * 1e3,
                      'roofline': {'bound': 'hbm', 'achieved': bytes_step / (us_step * 1e-6) / 1e9, 'peak': 8000.0,
                                   'unit': 'GB/s', 'frac': bytes_step / (us_step * 1e-6) / 8e12,

@@ -196,6 +196,7 @@ struct snk_engine {
     double gh_fwmax2 = 0.0;
     int greedy_test_stall = 0;            // test hook (option greedy_test_stall): one workgroup of the float32 scan never arrives at step 1
     int64_t greedy_stalls = 0;            // launches of the float32 scan ended by their watchdog (a workgroup was not running)
+    int64_t greedy_f16_launches = 0;      // ... of them from the float16 join tiles
     int64_t greedy_hoist_launches = 0;    // scans that read the hoisted target term
     int64_t greedy_second_rounds = 0, greedy_exact_windows = 0;     // statistics of the float32 scan's exact decisions
     int greedy_hoist = 1;                 // 1: the float32 scan reads one precomputed target value per window (default)
@@ -1661,7 +1662,11 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
                     h->g16_delta = 4.8828125e-4 * sqrt(v[0]) + 2.98023223876953125e-8 * sqrt(v[1]);
                     h->gj_ready = true;
                 }
-                if (h->gt16_ok) { hst.JT16 = h->gtiles16.p; hst.f16_delta = h->g16_delta; hst.f16_force = h->greedy_f16 == 2; }
+                if (h->gt16_ok) {
+                    hst.JT16 = h->gtiles16.p; hst.f16_delta = h->g16_delta; hst.f16_force = h->greedy_f16 == 2;
+                    // (launch_greedy32 takes the float16 tiles for streamed databases -- scans beyond 192 MB -- or when forced)
+                    if (hst.f16_force || (double)g.Nwin * (double)(g.jdim + 1) * 4.0 > (double)((size_t)192 << 20)) h->greedy_f16_launches += 1;
+                }
             }
             h->greedy_hoist_launches += 1;
         }
@@ -2738,6 +2743,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "greedy_hoist")) *out = h->greedy_hoist;
     else if (!strcmp(name, "greedy_hoist_launches")) *out = (double)h->greedy_hoist_launches;
     else if (!strcmp(name, "greedy_f16")) *out = h->greedy_f16;
+    else if (!strcmp(name, "greedy_f16_launches")) *out = (double)h->greedy_f16_launches;
     else if (!strcmp(name, "greedy_f16_delta")) *out = h->g16_delta;
     else if (!strcmp(name, "greedy_exact_windows")) *out = (double)h->greedy_exact_windows;
     else if (!strcmp(name, "greedy_second_rounds")) *out = (double)h->greedy_second_rounds;

@@ -1,9 +1,9 @@
 """profiles/<tag>_greedy.md from the passes of tools/prof_hoist.sh (gpurun_out/ph)."""
 import csv, glob, collections, sys, os
 src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/ph'
-tag = sys.argv[2] if len(sys.argv) > 2 else 'r02_g'
+tag = sys.argv[2] if len(sys.argv) > 2 else 'r02_h'
 N, Dt, Dj, me, steps = 1500000, 61, 151, 6, 100
-KS, KP = 'greedy32_kernel<false, true, 3>', 'hoist_product_kernel'
+KS, KP = 'greedy32_kernel<false, true, 1, true>', 'hoist_product_kernel'       # one utterance, float16 join tiles
 
 
 def durations(d, ker):
@@ -28,22 +28,22 @@ def counters(ker):
 
 
 ds, dp = durations('stats', KS), durations('stats', KP)
-ds1, dp1 = durations('stats_b1', KS), durations('stats_b1', KP)
+ds1, dp1 = durations('stats_b1', 'greedy32_kernel<false, true, 3, false>'), durations('stats_b1', KP)
 cs, cp = counters(KS), counters(KP)
 scan, prod = sum(ds) / len(ds), sum(dp) / len(dp)
 alg = N * (Dj + 1) * 4.0
-streamed = N * ((Dj + 3) // 4 * 4 + 1) * 4.0
+streamed = N * ((Dj + 7) // 8 * 16 + 4.0)              # 19 16-byte columns of eight halves + one float32 target value per window
 fetch_s = cs['FETCH_SIZE'] * 1024 * 2 / steps          # KB reported, x2: gfx950 correction (MI355X_MICROARCH.md, HBM section)
 write_p = cp.get('WRITE_SIZE', 0.0) * 1024
 fetch_p = cp['FETCH_SIZE'] * 1024 * 2
 K = me * ((Dt + 63) // 64) * 64
 flop = 2.0 * ((steps + 15) // 16 * 16) * ((N - me + 1 + 127) // 128 * 128) * K
-lines = ['# Round 2 -- greedy search with the hoisted target term at N = 1.5 M units, Dt = 61, Dj = 151, multiepoch 6 (B3 shape)', '',
+lines = ['# Round 2 -- greedy search with the hoisted target term and float16 join tiles at N = 1.5 M units, Dt = 61, Dj = 151, multiepoch 6 (B3 shape)', '',
          'Command: `bash tools/prof_hoist.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes, over tools/prof_hoist.py: 600-frame utterances = 100 steps each, one persistent launch per utterance).', '',
-         '* `greedy32_kernel<false, true, 3>` (the scan, all 100 steps in one launch): %d launches, average **%.2f ms** = %.1f us per step' % (len(ds), scan / 1e3, scan / steps),
+         '* `greedy32_kernel<false, true, 1, true>` (the scan over float16 join tiles, all 100 steps in one launch, exact decisions included): %d launches, average **%.2f ms** = %.1f us per step' % (len(ds), scan / 1e3, scan / steps),
          '* `hoist_product_kernel` (float64 matrix pipe, W = 100 x 1.5 M target terms): %d launches, average **%.2f ms** = %.1f us per step of the utterance; %.3g FLOP (padded) -> %.1f TFLOP/s = %.0f %% of the 78.6 TFLOP/s float64 matrix peak' % (
              len(dp), prod / 1e3, prod / steps, flop, flop / (prod * 1e-6) / 1e12, 100 * flop / (prod * 1e-6) / 78.6e12),
-         '* per step, scan + product: **%.1f us**; algorithmic bytes (Dj + 1) x 4 x N = %.0f MB -> %.2f TB/s = **%.0f %% of the 8 TB/s HBM peak** (the scan alone: %.0f %%; on the %.0f MB it requests, 38 float4 join columns + one target value per window: %.0f %%)' % (
+         '* per step, scan + product: **%.1f us**; algorithmic bytes (Dj + 1) x 4 x N = %.0f MB -> %.2f TB/s = **%.0f %% of the 8 TB/s HBM peak** (the scan alone: %.0f %%; on the %.0f MB it requests, 19 16-byte columns of eight float16 join values + one target value per window: %.0f %%)' % (
              (scan + prod) / steps, alg / 1e6, alg / ((scan + prod) / steps * 1e-6) / 1e12, 100 * alg / ((scan + prod) / steps * 1e-6) / 8e12,
              100 * alg / (scan / steps * 1e-6) / 8e12, streamed / 1e6, 100 * streamed / (scan / steps * 1e-6) / 8e12),
          '* HBM traffic of the scan per step: FETCH_SIZE x2 (gfx950 correction) = %.0f MB = %.2fx the algorithmic bytes, %.2fx the requested ones; WRITE_SIZE %.2f MB per step' % (
