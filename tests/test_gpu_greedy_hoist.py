@@ -199,3 +199,23 @@ def test_float16_join_tiles_keep_the_results(engine, me, lfat, mode, Dj, Dt, off
             assert path == list(range(3100, 3100 + 15 * me, me)) and np.all(d == 0.0)
     finally:
         engine.set_option('greedy_f16', 1)
+
+
+def test_values_outside_the_float16_range_keep_float32_tiles(engine):
+    """A join value beyond 65 504 cannot be a float16: the copy is refused and the scan reads the float32 tiles."""
+    N, Dt, Dj, me = 30000, 61, 151, 6
+    engine.set_option('greedy_mode', 2); engine.set_option('greedy_hoist', 1); engine.set_option('greedy_f16', 2)
+    try:
+        F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, 77)
+        JC_unw[12345, 7] = 1.0e5
+        rng = np.random.RandomState(177)
+        wt, wj = 0.2 + rng.rand(Dt), 0.05 + 0.2 * rng.rand(Dj)
+        engine.upload_db(F_unw, JC_unw); engine.set_weights(wt, wj); engine.set_greedy_layout(me, False, 0)
+        U = o.synthetic_targets(F_unw, 12 * me, seed=5) * wt
+        n0 = engine.info('greedy_f16_launches')
+        path, d = engine.greedy(U, return_distances=True)
+        op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, U, me, False, 0, -1)
+        assert path == op and np.array_equal(d, od)
+        assert engine.info('greedy_f16_launches') == n0
+    finally:
+        engine.set_option('greedy_f16', 1)
