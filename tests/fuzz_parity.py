@@ -3,6 +3,7 @@ K-NN, join costs + Viterbi (single and batch) and the greedy search, each compar
 the oracle.  Prints one line per case and a summary; exit code 1 on any mismatch.
 
     python tests/fuzz_parity.py [n_cases] [seed]
+    SNK_FUZZ_OPTS=greedy_f16=2 python tests/fuzz_parity.py ...     (engine options for every case)
 """
 import os
 import sys
@@ -43,6 +44,9 @@ def one_case(rng, idx):
     drop = (lambda U: U[:, tsel]) if tsel is not None else (lambda U: U)
     desc = 'N=%d Dt=%d Dj=%d K=%d T=%d me=%d lfat=%d mode=%d prec=%d sel=%d' % (N, Dt, Dj, K, T, me, lfat, mode, precision, tsel is not None)
     eng = snickery_amd.HipSearchEngine(0)
+    for kv in os.environ.get('SNK_FUZZ_OPTS', '').split(','):      # e.g. SNK_FUZZ_OPTS=greedy_f16=2,greedy_mode=1
+        if '=' in kv:
+            eng.set_option(kv.split('=')[0], float(kv.split('=')[1]))
     bad = []
     try:
         eng.set_option('precision', precision)
