@@ -1,6 +1,11 @@
-"""Timeline of the persistent greedy scan (SNK_G32_TRACE): where a step's time goes at B1 (N = 65 536).
-Stamps per step and workgroup (100 MHz clock): 0 table generation seen, 1 table in LDS, 2 scan done, 3 workgroup record
-published, 4 (decider) last arrival, 5 (decider) decided, 6 (decider) next table written + released, 7 next generation seen."""
+"""Timeline of the persistent greedy scan (SNK_G32_TRACE): where a step's time goes.
+
+    python tools/g32_trace.py [units = 65536] [utterances per scan = 1]
+
+Stamps per step and workgroup (100 MHz clock): 0 step started, 1 table in LDS, 2 scan done, 3 workgroup record
+published, 4 (decider) last arrival, 5 (decider) first decision made, 6 (decider) winners released; second phase (every
+lane offers its candidates; the usual case with float16 join tiles): 7 entered, 12 offers made, 13 (decider) last
+arrival, 15 control words read, 8 candidate ids read, 9 terms of the candidates stored, 10 chains summed, 14 decided."""
 import sys, os, struct
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
