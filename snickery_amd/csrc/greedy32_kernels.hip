@@ -748,10 +748,20 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                             cov = cov || __ballot((double)qv3[q] <= tau) != 0ull;
                         }
                         if (nc == 1 && !cov) state = 1;           // the only window inside the bound is the float32 minimum itself
+                        else if (cov) {
+                            // a window nobody published may matter (the rule with float16 tiles: the best window's
+                            // neighbours sit in one tile): ask every lane, without weighing the published ones first
+                            state = 3;
+                            if (lane == 0) {
+                                __hip_atomic_store(&ctl->tau[u], tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(&ctl->list_count[u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
                     }
                 }
                 if (lane == 0) { fast_s[u] = state; fast_w[u] = mi; }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the requests' words, before the barrier and the generation word)
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
@@ -760,6 +770,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                     const int fs = fast_s[u];
                     if (fs == 1) { winner[u] = fast_w[u]; continue; }
                     if (fs == 2) { undecided = true; continue; }
+                    if (fs == 3) { need |= 1u << u; continue; }
                 }
                 float mv = __builtin_inff();
                 int64_t mi = INT64_MAX;
