@@ -295,7 +295,13 @@ int snk_concat_fragments(snk_handle h, const int64_t *first_row, const int64_t *
                          int64_t n, int multiepoch, int overlap, const double *in_taper,
                          double *spec_out, double *fz_out);
 
-/* Engine tuning / introspection (not part of the reference surface) */
+/* Engine tuning / introspection (not part of the reference surface).  Options of the greedy search:
+ *   greedy_mode 0 / 1 / 2      exact scan, a launch per step / float32 scan in one persistent launch / auto (default)
+ *   greedy_hoist 0 / 1         target term of all steps as one float64 matrix product per utterance (default 1)
+ *   greedy_hoist_max_gb        largest product kept on the device (default 48)
+ *   greedy_f16 0 / 1 / 2       float16 join tiles: never / for databases streamed from HBM (default) / always
+ * infos: greedy_fallbacks, greedy_stalls, greedy_exact_windows, greedy_second_rounds, greedy_hoist_launches,
+ * greedy_f16_launches, greedy_f16_delta.  The other names are listed in INTEGRATION.md. */
 int snk_set_option(snk_handle h, const char *name, double value);
 int snk_get_info(snk_handle h, const char *name, double *value_out);
 /* One v_mfma_f32_32x32x16_bf16 on caller-chosen bit patterns: D = A B + C with A (32, 16) and B (16, 32) bf16 bit
