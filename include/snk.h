@@ -306,8 +306,8 @@ int snk_set_option(snk_handle h, const char *name, double value);
 int snk_get_info(snk_handle h, const char *name, double *value_out);
 /* One v_mfma_f32_32x32x16_bf16 on caller-chosen bit patterns: D = A B + C with A (32, 16) and B (16, 32) bf16 bit
  * patterns, C and D (32, 32) float32, all row-major.  The hardware's internal summation order is not documented; the
- * accumulation term of the bf16-split prefilter's key bound ASSUMES an error of at most 2^-22 of the sum of the
- * |products| and |C| per instruction, and tests/test_gpu_prefilter.py holds this probe against float64 sums on
+ * accumulation term of the bf16-split prefilter's key bound ASSUMES an error of at most 2^-20 of the sum of the
+ * |products| and |C| per instruction (a first version assumed 2^-22; the probe refuted it at 1.6 x that), and tests/test_gpu_prefilter.py holds this probe against float64 sums on
  * adversarial patterns (one large product beside fifteen just below its rounding unit, cancellation, a large C). */
 int snk_probe_mfma_bf16(snk_handle h, const uint16_t *A, const uint16_t *B, const float *C, float *D_out);
 /* gfx950 self-test of the f64 MFMA fragment mapping the K-NN kernel relies on */
