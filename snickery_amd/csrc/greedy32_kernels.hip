@@ -28,6 +28,12 @@
 //    step's entries (sc1 loads) and builds the next (weight, reference) table itself in LDS from the winners' join
 //    rows.  A generation word carries the two rare events (a request for every lane's candidates; the end of the
 //    launch at an undecidable step).  A launch per step cost more than the scan itself at 65 536 units.
+//  * Instances: <target rows in LDS, hoisted target term, utterances per scan, float16 join tiles>.  With the hoisted term
+//    the scan is the join stream alone; databases that do not fit the caches are then read from a float16 copy of the
+//    join tiles (half the bytes) with the bound widened by the rounding of the tiles (g32_err16) -- about fifteen windows
+//    per step inside it at 1.5 M units, the best window's neighbours, decided exactly: a wavefront stores the terms of up
+//    to four candidates and their canonical chains of additions run side by side in its lanes.
+//  * The wait inside the kernel has a watchdog (3 s without news: the launch ends, the caller finishes on the exact scan).
 //
 // Data layout, request ring, LDS target blocks and chunk order are those of greedy_kernels.hip.
 #include "greedy_common.h"
