@@ -193,7 +193,10 @@ def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')),
                      'roofline': {'bound': 'hbm', 'achieved': bytes_step / (us_step * 1e-6) / 1e9, 'peak': 8000.0,
                                   'unit': 'GB/s', 'frac': bytes_step / (us_step * 1e-6) / 8e12,
                                   'algorithmic_bytes_per_step': bytes_step, 'streamed_bytes_per_step': bytes_streamed,
-                                  'streamed_frac': bytes_streamed / (us_step * 1e-6) / 8e12},
+                                  'streamed_frac': bytes_streamed / (us_step * 1e-6) / 8e12,
+                                  'note': 'algorithmic bytes at s = 4 bytes per element (SURVEY 8d: the database as uploaded, float32)'
+                                          + ('; the scan reads a float16 copy of the join columns: at s = 2, (2 Dj + 4) N bytes, frac = %.3f'
+                                             % (float(N) * (2 * Dj + 4) / (us_step * 1e-6) / 8e12) if f16 else '')},
                      'path_head': [int(v) for v in path[:4]]}
         eng.close()
         del F_unw, JC_unw
