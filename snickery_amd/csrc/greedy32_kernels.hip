@@ -605,7 +605,9 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
         auto exact_argmin = [&](int u, int n, auto get) -> int64_t {
             double dbest = DBL_MAX;
             int64_t ibest = INT64_MAX;
-            for (int p0 = wave; p0 < n && wave < nw_exact; p0 += nw_exact * kslots) {
+            const bool single_round = nw_exact == nwaves && n <= nwaves * kslots;     // every wavefront in the loop exactly once, or not at all
+            // (one round: EVERY wavefront runs the body once, with or without candidates -- it holds workgroup barriers)
+            for (int p0 = wave, it = 0; single_round ? it < 1 : (p0 < n && wave < nw_exact); p0 += nw_exact * kslots, ++it) {
                 int64_t myid = INT64_MAX;                         // lane k < cnt: the k-th candidate of this round
                 int cnt = 0;
                 int64_t ids[4];
@@ -621,13 +623,54 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                     ++cnt;
                 }
                 stamp(step, 9);
+                // Which candidates need their canonical total at all?  Any order of adding the same float64 terms lands
+                // within n 2^-53 of the true sum, the canonical one too: a candidate whose tree sum is beyond
+                // (1 + 4 n 2^-53) of the smallest tree sum cannot be the canonical minimum.  With all candidates in LDS
+                // at once (one round) the block compares tree sums first; ONE survivor is the winner without any chain,
+                // ties and near ties go through the chains below.
+                unsigned int surv = 0xfu;                         // bit k: candidate k of this wavefront still matters
+                if (single_round) {
+                    double pmin = DBL_MAX, ps[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        ps[k] = DBL_MAX;
+                        if (k < cnt) {                             // uniform
+                            double v = 0.0;
+                            for (int idx = lane; idx < ex_cols; idx += 64) v += terms[(size_t)k * ex_cols + idx];
+#pragma unroll
+                            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+                            ps[k] = v;
+                            pmin = v < pmin ? v : pmin;
+                        }
+                    }
+                    double *pm = reinterpret_cast<double *>(lds + 8192 + 128);
+                    int *sc = reinterpret_cast<int *>(lds + 8192 + 192);
+                    int64_t *sid = reinterpret_cast<int64_t *>(lds + 8192 + 224);
+                    if (lane == 0) pm[wave] = pmin;
+                    __syncthreads();
+                    double gmin = pm[0];
+                    for (int w = 1; w < nwaves; ++w) gmin = pm[w] < gmin ? pm[w] : gmin;
+                    const double thr = gmin * (1.0 + 4.0 * (double)ex_cols * 1.1102230246251565e-16 * 1.01) + 1e-300;
+                    surv = 0u;
+                    int64_t first = -1;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < cnt && ps[k] <= thr) { surv |= 1u << k; if (first < 0) first = ids[k]; }
+                    if (lane == 0) { sc[wave] = __popc(surv); sid[wave] = first; }
+                    __syncthreads();
+                    int total = 0;
+                    int64_t only = -1;
+                    for (int w = 0; w < nwaves; ++w) { total += sc[w]; if (sc[w] > 0) only = sid[w]; }
+                    __syncthreads();
+                    if (total == 1) return only;                    // uniform over the workgroup
+                }
                 // lane 2k sums the join columns of candidate k, lane 2k + 1 its target columns (two independent chains of
                 // the canonical order), then one rounded addition joins them
                 double d = DBL_MAX;
                 {
                     const int k = lane >> 1;
                     double part = 0.0;
-                    if (k < cnt) {
+                    if (k < cnt && ((surv >> k) & 1u)) {
                         // (one loop for both kinds of lanes -- pointer and length differ: a branch would run the two chains
                         // one after the other)
                         const double *t = terms + (size_t)k * ex_cols + ((lane & 1) ? a.jdim : 0);
@@ -636,7 +679,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                     const double other = __shfl_xor(part, 1, 64);
                     const double tot = (lane & 1) ? __dadd_rn(other, part) : __dadd_rn(part, other);      // acc_j + acc_t
                     const double dk = __shfl(tot, (lane & 3) << 1, 64);         // lane k < 4 fetches candidate k's total
-                    if (lane < cnt) d = dk;
+                    if (lane < cnt && ((surv >> lane) & 1u)) d = dk;
                 }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
