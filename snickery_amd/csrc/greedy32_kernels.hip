@@ -144,6 +144,59 @@ __device__ __forceinline__ double g32_chain_sum(const double *terms, int jdim, i
     return __dadd_rn(acc_j, acc_t);
 }
 
+// The term arrays of up to four candidates at once: weight and reference of a column are the same for all of them, only
+// the database value differs -- so the operands of all candidates are requested together (one trip to HBM for their cold
+// rows instead of one per candidate) in the registers one candidate took.  terms + k * stride: array of candidate k.
+__device__ void g32_terms_multi(const GreedyArgs &a, int u, int64_t step, int64_t prev_row, bool prev_is_current,
+                                const int64_t (&ids)[4], int cnt, double *terms, size_t stride, int lane)
+{
+    const int col0 = prev_is_current ? a.cur_col0 : a.prev_col0;
+    const int64_t row0 = prev_is_current ? a.cur_row0 : a.prev_row0;
+    const float *rr = a.JC_unw + (row0 + (prev_row >= 0 ? prev_row : 0)) * a.Jp + col0;
+    const int ncol = a.jdim + a.nep * a.Dt;
+    constexpr int NJ = 9;
+    for (int base = 0; base < ncol; base += 64 * NJ) {
+        float x[4][NJ], rx[NJ];
+        double w[NJ], rw[NJ], qv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int idx = base + 64 * j + lane;
+            rx[j] = 0.f; w[j] = 0.0; rw[j] = 0.0; qv[j] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k][j] = 0.f;
+            if (idx < a.jdim) {
+                w[j] = a.wj[a.prev_col0 + idx];
+                if (prev_row >= 0) { rx[j] = rr[idx]; rw[j] = a.wj[col0 + idx]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < cnt) x[k][j] = a.JC_unw[(a.prev_row0 + ids[k]) * a.Jp + a.prev_col0 + idx];
+            } else if (idx < ncol) {
+                const int t = idx - a.jdim, e = t / a.Dt, c = t - e * a.Dt;
+                w[j] = a.wt[c];
+                qv[j] = a.Q[(a.q_off[u] + step * a.me + a.ep[e]) * a.Dt + c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < cnt) x[k][j] = a.F_unw[(ids[k] + a.ep[e]) * a.Fp + c];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int idx = base + 64 * j + lane;
+            if (idx < ncol) {
+                const double ref = idx < a.jdim ? (prev_row >= 0 ? __dmul_rn((double)rx[j], rw[j]) : 0.0) : qv[j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < cnt) {
+                        const double d = __dsub_rn(__dmul_rn((double)x[k][j], w[j]), ref);
+                        terms[(size_t)k * stride + idx] = __dmul_rn(d, d);
+                    }
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wavefront's own LDS writes, in order
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ double g32_exact_d2_wave(const GreedyArgs &a, int u, int64_t step, int64_t prev_row, bool prev_is_current, int64_t i,
                                     double *terms, int lane, bool terms_only = false)
 {
@@ -605,7 +658,8 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
         auto exact_argmin = [&](int u, int n, auto get) -> int64_t {
             double dbest = DBL_MAX;
             int64_t ibest = INT64_MAX;
-            const bool single_round = nw_exact == nwaves && n <= nwaves * kslots;     // every wavefront in the loop exactly once, or not at all
+            // (the six-utterance instance has no registers to spare: no tree sums, candidate after candidate)
+            const bool single_round = UB <= 3 && nw_exact == nwaves && n <= nwaves * kslots;     // every wavefront in the loop exactly once
             // (one round: EVERY wavefront runs the body once, with or without candidates -- it holds workgroup barriers)
             for (int p0 = wave, it = 0; single_round ? it < 1 : (p0 < n && wave < nw_exact); p0 += nw_exact * kslots, ++it) {
                 int64_t myid = INT64_MAX;                         // lane k < cnt: the k-th candidate of this round
@@ -617,10 +671,16 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (ids[k] < 0) break;                         // uniform
-                    const int64_t i = ids[k];
-                    g32_exact_d2_wave(a, u, step, prev_row[u], step > 0, i, terms + (size_t)k * ex_cols, lane, true);
-                    if (lane == k) myid = i;
+                    if (lane == k) myid = ids[k];
                     ++cnt;
+                }
+                if constexpr (UB <= 3) {
+                    g32_terms_multi(a, u, step, prev_row[u], step > 0, ids, cnt, terms, (size_t)ex_cols, lane);
+                } else {
+                    // (the six-utterance instance has no registers to spare: candidate after candidate)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < cnt) g32_exact_d2_wave(a, u, step, prev_row[u], step > 0, ids[k], terms + (size_t)k * ex_cols, lane, true);
                 }
                 stamp(step, 9);
                 // Which candidates need their canonical total at all?  Any order of adding the same float64 terms lands
@@ -629,7 +689,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                 // at once (one round) the block compares tree sums first; ONE survivor is the winner without any chain,
                 // ties and near ties go through the chains below.
                 unsigned int surv = 0xfu;                         // bit k: candidate k of this wavefront still matters
-                if (single_round) {
+                if (UB <= 3 && single_round) {
                     double pmin = DBL_MAX, ps[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
