@@ -81,7 +81,10 @@ def test_b3_nick_size(engine, me):
     engine.set_weights(wt, wj)
     engine.set_greedy_layout(me, False, 0)
     U = o.synthetic_targets(F_unw, 600, seed=81) * wt
+    n16, nh = engine.info('greedy_f16_launches'), engine.info('greedy_hoist_launches')
     _check(engine, F_unw, JC_unw, wt, wj, U, me, max_steps=24)
+    # a database of this size is streamed: hoisted target term + float16 join tiles are what has just been checked
+    assert engine.info('greedy_f16_launches') == n16 + 1 and engine.info('greedy_hoist_launches') == nh + 1
     _check(engine, F_unw, JC_unw, wt, wj, U, me, start=1234567, max_steps=20)
     n = 20 * me
     Ud = (F_unw[200300:200300 + n].astype(np.float64)) * wt
