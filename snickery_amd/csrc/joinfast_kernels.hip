@@ -824,11 +824,10 @@ void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jl
         const size_t shmem = base + (bp_in_lds ? bp_bytes : 0);
 #define SNK_SP(BS_, BPL_)                                                                                         \
     {                                                                                                             \
-        static bool attr_set = false;                                                                             \
-        if (!attr_set) {                                                                                          \
+        static size_t attr_set[32] = {0};                                                                   \
+        if (lds_attr_needed(attr_set, 150 * 1024)) {                                                                                          \
             hipFuncSetAttribute(reinterpret_cast<const void *>(&viterbi_sparse_kernel<BS_, BPL_>),                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));                   \
-            attr_set = true;                                                                                      \
         }                                                                                                         \
         hipLaunchKernelGGL((viterbi_sparse_kernel<BS_, BPL_>), dim3(n), dim3(nth), shmem, s, cand,                \
                            reinterpret_cast<const JfRecord *>(rec), Jlo, JC_unw, Jp, Dj, wj, batch, K, n_units,   \

@@ -59,11 +59,27 @@ static const char *kTimerNames[TM_COUNT] = {
     "join_costs", "viterbi_dp", "d2h_results", "greedy_target_gemm", "greedy_steps", "set_weights",
     "merge_topk", "join_lower_bounds", "viterbi_lower_bound", "join_exact_sparse", "viterbi_sparse"};
 
+// Debug allocator (environment SNK_GUARD=1|2, read once): every device buffer gets its own virtual range with an
+// unmapped page after it (1: the buffer ends where the mapping ends, an over-read or over-write of even one 16-byte
+// element faults at once; 2: it starts where the mapping starts) and exactly the bytes asked for -- no growth slack,
+// no reuse, fresh memory filled with 0xFF (a NaN / huge-index pattern).  Every allocation is logged with its call site,
+// so the page address in the runtime's "Memory access fault" line names the buffer that was overrun.  Speed is of no
+// concern in this mode; the product path never sets it.
+static int guard_mode()
+{
+    static int mode = -1;
+    if (mode < 0) { const char *e = getenv("SNK_GUARD"); mode = e ? atoi(e) : 0; if (mode < 0 || mode > 2) mode = 0; }
+    return mode;
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
-    int ensure(size_t need)
+    // guard mode bookkeeping
+    void *va = nullptr; size_t va_bytes = 0, map_bytes = 0; hipMemGenericAllocationHandle_t mh{}; bool guarded = false;
+    int ensure(size_t need, const char *file = __builtin_FILE(), int line = __builtin_LINE())
     {
+        if (guard_mode()) return ensure_guarded(need, file, line);
         if (need <= bytes) return 0;
         if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
         size_t want = need + need / 8 + 256;
@@ -72,7 +88,59 @@ struct DevBuf {
         bytes = want;
         return 0;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    int ensure_guarded(size_t need, const char *file, int line)
+    {
+        if (need == 0) need = 1;
+        if (p && need == bytes) return 0;                       // same request: keep (contents may be live)
+        release();
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+        if (e != hipSuccess || gran == 0) return fail("SNK_GUARD: hipMemGetAllocationGranularity: %s", hipGetErrorString(e));
+        const size_t mapped = ((need + gran - 1) / gran) * gran;
+        e = hipMemAddressReserve(&va, mapped + 2 * gran, gran, nullptr, 0);
+        if (e != hipSuccess) { va = nullptr; return fail("SNK_GUARD: hipMemAddressReserve(%zu): %s", mapped + 2 * gran, hipGetErrorString(e)); }
+        va_bytes = mapped + 2 * gran;
+        e = hipMemCreate(&mh, mapped, &prop, 0);
+        if (e != hipSuccess) { (void)hipMemAddressFree(va, va_bytes); va = nullptr; return fail("SNK_GUARD: hipMemCreate(%zu): %s", mapped, hipGetErrorString(e)); }
+        char *base = (char *)va + gran;
+        e = hipMemMap(base, mapped, 0, mh, 0);
+        if (e != hipSuccess) return fail("SNK_GUARD: hipMemMap: %s", hipGetErrorString(e));
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(base, mapped, &acc, 1);
+        if (e != hipSuccess) return fail("SNK_GUARD: hipMemSetAccess: %s", hipGetErrorString(e));
+        map_bytes = mapped;
+        guarded = true;
+        (void)hipMemset(base, 0xFF, mapped);
+        (void)hipDeviceSynchronize();
+        // mode 1: right-aligned (16-byte granularity: the widest vector access); mode 2: left-aligned
+        const size_t need16 = (need + 15) & ~(size_t)15;
+        p = guard_mode() == 1 ? base + (mapped - need16) : base;
+        bytes = need;
+        fprintf(stderr, "[snk-guard] %p..%p (%zu B, mapping %p..%p) %s:%d\n", p, (char *)p + need, need, (void *)base,
+                (void *)(base + mapped), file, line);
+        return 0;
+    }
+    void release()
+    {
+        if (guarded) {
+            (void)hipDeviceSynchronize();
+            (void)hipMemUnmap((char *)va + (va_bytes - map_bytes) / 2, map_bytes);
+            (void)hipMemRelease(mh);
+            (void)hipMemAddressFree(va, va_bytes);
+            va = nullptr; guarded = false; p = nullptr; bytes = 0;
+            return;
+        }
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+    }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -140,6 +208,7 @@ struct snk_engine {
     // in-library collectives (snk_comm_init / snk_comm_init_transport)
     int comm_ranks = 0, comm_rank = 0;
     void *nccl_comm = nullptr;            // ncclComm_t
+    bool comm_dead = false;               // a local error struck after a collective of a step was queued: the communicator was aborted
     snk_transport transport{};            // caller-provided collectives (functional tests)
     bool have_transport = false;
     DevBuf sh_d2, sh_id, sh_bound, sh_rd2, sh_rid, sh_res, sh_resall;
@@ -420,6 +489,9 @@ static int upload_join(snk_engine *h, const float *JC_unw, int64_t Njc, int Dj)
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_join = true;
     h->have_weights = false;
+    // everything derived from the join matrix (greedy layout, float32 / float16 join tiles, their norms and range check)
+    h->have_glay = false;
+    h->gtiles_ready = false; h->gt16_ready = false; h->gt16_ok = false; h->gj_ready = false;
     return 0;
 }
 
@@ -1442,6 +1514,8 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
                                  int K, int *ticket_out)
 {
     CHK(check_ready(h, true, true));
+    if (h->sticket[0].busy || h->sticket[1].busy)
+        return fail("snk_knn_viterbi_batch_submit: a submitted sharded step is still in flight (snk_sharded_knn_viterbi_batch_collect it first)");
     HIPCHK(hipSetDevice(h->device));
     if (!Q || !row_offsets || n_utts < 1 || !ticket_out)
         return fail("snk_knn_viterbi_batch_submit: null/empty argument");
@@ -1724,6 +1798,7 @@ int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_st
                int64_t *path_out, double *dist_out, int64_t *nsteps_out)
 {
     CHK(check_ready(h, true, true));
+    CHK(no_batch_in_flight(h, "snk_greedy"));
     HIPCHK(hipSetDevice(h->device));
     if (!h->have_glay) return fail("snk_greedy: greedy layout not set (snk_set_greedy_layout)");
     if (!path_out || !nsteps_out) return fail("snk_greedy: null output");
@@ -1786,6 +1861,7 @@ int snk_greedy_batch(snk_handle h, const double *Q, const int64_t *row_offsets, 
                      int64_t *nsteps_out)
 {
     CHK(check_ready(h, true, true));
+    CHK(no_batch_in_flight(h, "snk_greedy_batch"));
     HIPCHK(hipSetDevice(h->device));
     if (!h->have_glay) return fail("snk_greedy_batch: greedy layout not set (snk_set_greedy_layout)");
     if (!Q || !row_offsets || n_utts < 1 || !path_out || !nsteps_out) return fail("snk_greedy_batch: null/empty argument");
@@ -2131,6 +2207,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -2155,7 +2232,7 @@ int rccl_load()
 #define SNK_SYM(field, name)                                                                    \
     g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, name));                  \
     if (!g_rccl.field) return fail("snk_comm: librccl has no symbol %s", name)
-    SNK_SYM(GetUniqueId, "ncclGetUniqueId"); SNK_SYM(CommInitRank, "ncclCommInitRank"); SNK_SYM(CommDestroy, "ncclCommDestroy");
+    SNK_SYM(GetUniqueId, "ncclGetUniqueId"); SNK_SYM(CommInitRank, "ncclCommInitRank"); SNK_SYM(CommDestroy, "ncclCommDestroy"); SNK_SYM(CommAbort, "ncclCommAbort");
     SNK_SYM(AllReduce, "ncclAllReduce"); SNK_SYM(AllGather, "ncclAllGather"); SNK_SYM(Send, "ncclSend");
     SNK_SYM(Recv, "ncclRecv"); SNK_SYM(GroupStart, "ncclGroupStart"); SNK_SYM(GroupEnd, "ncclGroupEnd");
     SNK_SYM(GetErrorString, "ncclGetErrorString");
@@ -2266,7 +2343,7 @@ int snk_comm_init_transport(snk_handle h, int nranks, int rank, const snk_transp
 int snk_comm_destroy(snk_handle h)
 {
     if (!h) return 0;
-    if (h->nccl_comm && g_rccl.CommDestroy) {
+    if (h->nccl_comm && g_rccl.CommDestroy && !h->comm_dead) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         (void)g_rccl.CommDestroy((ncclComm_t)h->nccl_comm);
@@ -2274,6 +2351,7 @@ int snk_comm_destroy(snk_handle h)
     h->nccl_comm = nullptr;
     h->have_transport = false;
     h->comm_ranks = 0; h->comm_rank = 0;
+    h->comm_dead = false;
     return 0;
 }
 
@@ -2358,7 +2436,6 @@ static int sharded_submit(snk_engine *h, ShardTicket &t, const double *Q, const 
     int n_status = 0;
     struct PrecisionGuard { snk_engine *e; int v; ~PrecisionGuard() { e->precision = v; } } guard{h, h->precision};
     if (safe) h->precision = 0;
-    if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
     const double *Qk = Q;                       // what the K-NN calls are handed: nullptr = the rows are resident already
     if (G > 1 && h->shard_gather_queries) {
         CHK(upload_queries_gathered(h, t, Q));
@@ -2412,7 +2489,6 @@ static int sharded_submit(snk_engine *h, ShardTicket &t, const double *Q, const 
     t.own_off.assign((size_t)n_own + 1, 0);
     for (int u = 0; u <= n_own; ++u) t.own_off[(size_t)u] = row_offsets[t.ulo[(size_t)me] + u] - t.row0[(size_t)me];
     if (n_own > 0) {
-        if ((int64_t)G * K > 8192) return fail("snk_sharded_knn_viterbi_batch: G*K=%d exceeds 8192", G * K);
         {
             StageTimer tm(h, h->stream, TM_MERGE);
             launch_merge_topk(d2_all, id_all, G, r_own, K, t.mcand.as<int64_t>(), t.mdist.as<double>(), h->stream);
@@ -2503,19 +2579,44 @@ static int sharded_collect(snk_engine *h, ShardTicket &t, int64_t *path_out, int
     return 0;
 }
 
-static int sharded_check(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts)
+// Everything that does not depend on the rank is checked here, BEFORE the first collective of the step is queued: all
+// ranks then fail together, with nothing in flight.
+static int sharded_check(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K)
 {
     CHK(check_ready(h, true, true));
     HIPCHK(hipSetDevice(h->device));
     if (h->comm_ranks < 1) return fail("snk_sharded_knn_viterbi_batch: no communicator (snk_comm_init)");
+    if (h->comm_dead) return fail("snk_sharded_knn_viterbi_batch: the communicator was aborted after a local error (snk_comm_init again, on every rank)");
     if (!Q || !row_offsets || n_utts < 1) return fail("snk_sharded_knn_viterbi_batch: null/empty argument");
+    if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
+    if (K < 1 || K > 208) return fail("snk_sharded_knn_viterbi_batch: n_candidates=%d outside the supported range 1..208", K);
+    if ((int64_t)h->comm_ranks * K > 8192) return fail("snk_sharded_knn_viterbi_batch: G*K=%d exceeds 8192", h->comm_ranks * K);
+    if (row_offsets[0] != 0) return fail("snk_sharded_knn_viterbi_batch: row_offsets[0] must be 0");
+    for (int u = 0; u < n_utts; ++u)
+        if (row_offsets[u + 1] - row_offsets[u] < 1) return fail("snk_sharded_knn_viterbi_batch: utterance %d has no rows", u);
     return 0;
+}
+
+// A local failure (allocation, launch, transport) after the step's first collective went out: the peers are, or will be,
+// blocked in a collective this rank never joins.  Abort the communicator -- their pending operations then end with an
+// error instead of hanging -- and refuse further sharded steps until a new communicator is set up.
+static int sharded_fail(snk_engine *h, int rc)
+{
+    if (rc == 0) return 0;
+    const std::string msg = g_err;
+    if (h->comm_ranks > 1 && !h->have_transport && h->nccl_comm && g_rccl.CommAbort && !h->comm_dead) {
+        (void)g_rccl.CommAbort((ncclComm_t)h->nccl_comm);
+        h->comm_dead = true;
+        for (auto &t : h->sticket) t.busy = false;
+        (void)fail("%s [communicator aborted: the other ranks see an error instead of waiting]", msg.c_str());
+    }
+    return rc;
 }
 
 int snk_sharded_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
                                          int *ticket_out)
 {
-    CHK(sharded_check(h, Q, row_offsets, n_utts));
+    CHK(sharded_check(h, Q, row_offsets, n_utts, D, K));
     if (h->bslot[0].busy || h->bslot[1].busy)
         return fail("snk_sharded_knn_viterbi_batch_submit: a submitted batch is still in flight (snk_knn_viterbi_batch_collect it first)");
     if (!ticket_out) return fail("snk_sharded_knn_viterbi_batch_submit: null ticket");
@@ -2527,7 +2628,7 @@ int snk_sharded_knn_viterbi_batch_submit(snk_handle h, const double *Q, const in
         HIPCHK(hipEventCreateWithFlags(&t.main_done, hipEventDisableTiming));
         for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&t.side_done[i], hipEventDisableTiming));
     }
-    CHK(sharded_submit(h, t, Q, row_offsets, n_utts, D, K, false));
+    CHK(sharded_fail(h, sharded_submit(h, t, Q, row_offsets, n_utts, D, K, false)));
     h->snext = slot ^ 1;
     *ticket_out = slot;
     return 0;
@@ -2542,7 +2643,7 @@ int snk_sharded_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *pat
     if (!path_out || !path_len_out || !cost_out) return fail("snk_sharded_knn_viterbi_batch_collect: null output");
     ShardTicket &t = h->sticket[ticket];
     bool redo = false;
-    CHK(sharded_collect(h, t, path_out, path_len_out, cost_out, &redo));
+    CHK(sharded_fail(h, sharded_collect(h, t, path_out, path_len_out, cost_out, &redo)));
     if (redo) {
         // every rank saw the same status words: all of them redo this step in the exact mode, now -- behind whatever
         // a step submitted in the meantime has queued (its recursions must be through with the shared workspaces first)
@@ -2553,8 +2654,8 @@ int snk_sharded_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *pat
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipStreamSynchronize(h->copy_stream));
         const std::vector<int64_t> offs = t.offs;
-        CHK(sharded_submit(h, t, t.Q, offs.data(), t.n_utts, t.D, t.K, true));
-        CHK(sharded_collect(h, t, path_out, path_len_out, cost_out, nullptr));
+        CHK(sharded_fail(h, sharded_submit(h, t, t.Q, offs.data(), t.n_utts, t.D, t.K, true)));
+        CHK(sharded_fail(h, sharded_collect(h, t, path_out, path_len_out, cost_out, nullptr)));
     }
     return 0;
 }

@@ -7,7 +7,25 @@
 #define SNK_NT_MAX 8         // max DB tiles (16 rows each) a wave keeps in registers
 #define SNK_VERY_BIG 1000000000000000.0   // const.py:3
 
+#include <mutex>
+
 namespace snk {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the device that is current when it is called: the
+// "already raised to" state of a kernel is kept per device (a process may hold engines on several), under a lock
+// (engines on different devices may be driven from different threads).  Returns true when `want` exceeds what this
+// device's copy of the kernel was given so far -- the caller then sets the attribute.
+inline bool lds_attr_needed(size_t (&per_device)[32], size_t want)
+{
+    static std::mutex m;
+    int d = 0;
+    (void)hipGetDevice(&d);
+    std::lock_guard<std::mutex> lock(m);
+    size_t &have = per_device[d & 31];
+    if (want <= have) return false;
+    have = want;
+    return true;
+}
 
 // ---- database preparation -------------------------------------------------
 void launch_weight_target(const float *F_unw, int Fp, int64_t N, int Dt, const double *wt,

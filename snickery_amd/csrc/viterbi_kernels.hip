@@ -352,11 +352,10 @@ void launch_viterbi_dp_batch(const int64_t *cand, const double *tdist, const dou
         const size_t shmem = base + (bp_in_lds ? bp_bytes : 0);
 #define SNK_DP1(KPM_, NB_, NTH_, BPL_)                                                             \
     {                                                                                              \
-        static bool attr_set = false;                                                              \
-        if (!attr_set) {                                                                           \
+        static size_t attr_set[32] = {0};                                                    \
+        if (lds_attr_needed(attr_set, 150 * 1024)) {                                                                           \
             hipFuncSetAttribute(reinterpret_cast<const void *>(&viterbi_dp_kernel<KPM_, NB_, NTH_, BPL_>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));    \
-            attr_set = true;                                                                       \
         }                                                                                          \
         hipLaunchKernelGGL((viterbi_dp_kernel<KPM_, NB_, NTH_, BPL_>), dim3(n), dim3(nth), shmem, s, cand, \
                            tdist, J, batch, K, n_units, KP, bp_global, path, path_len, cost);      \

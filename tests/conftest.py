@@ -22,6 +22,20 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run by the driver on the GPU box)')
 
 
+def pytest_runtest_logstart(nodeid, location):
+    """Name the test about to run on stderr (unbuffered) and in gpurun_out/current_test.txt: if the process
+    dies inside the runtime, the last line before the runtime's message says where."""
+    sys.stderr.write('\n[snk-test] %s\n' % nodeid)
+    sys.stderr.flush()
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        if os.path.isdir(d):
+            with open(os.path.join(d, 'current_test.txt'), 'w') as f:
+                f.write(nodeid + '\n')
+    except OSError:
+        pass
+
+
 @pytest.fixture(scope='session')
 def golden():
     import numpy as np
