@@ -59,7 +59,7 @@ static const char *kTimerNames[TM_COUNT] = {
     "join_costs", "viterbi_dp", "d2h_results", "greedy_target_gemm", "greedy_steps", "set_weights",
     "merge_topk", "join_lower_bounds", "viterbi_lower_bound", "join_exact_sparse", "viterbi_sparse"};
 
-// Debug allocator (environment SNK_GUARD=1|2, read once): every device buffer gets its own virtual range with an
+// Debug allocator (environment SNK_GUARD=1|2|3, read once): every device buffer gets its own virtual range with an
 // unmapped page after it (1: the buffer ends where the mapping ends, an over-read or over-write of even one 16-byte
 // element faults at once; 2: it starts where the mapping starts) and exactly the bytes asked for -- no growth slack,
 // no reuse, fresh memory filled with 0xFF (a NaN / huge-index pattern).  Every allocation is logged with its call site,
@@ -68,7 +68,7 @@ static const char *kTimerNames[TM_COUNT] = {
 static int guard_mode()
 {
     static int mode = -1;
-    if (mode < 0) { const char *e = getenv("SNK_GUARD"); mode = e ? atoi(e) : 0; if (mode < 0 || mode > 2) mode = 0; }
+    if (mode < 0) { const char *e = getenv("SNK_GUARD"); mode = e ? atoi(e) : 0; if (mode < 0 || mode > 3) mode = 0; }
     return mode;
 }
 
@@ -93,6 +93,16 @@ struct DevBuf {
         if (need == 0) need = 1;
         if (p && need == bytes) return 0;                       // same request: keep (contents may be live)
         release();
+        if (guard_mode() == 3) {
+            // plain allocations of exactly the bytes asked for, filled with 0xFF: separates "relies on fresh memory being
+            // zero / on the growth slack" from what the unmapped neighbours of modes 1 and 2 catch
+            hipError_t e3 = hipMalloc(&p, need);
+            if (e3 != hipSuccess) { p = nullptr; return fail("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e3)); }
+            (void)hipMemset(p, 0xFF, need);
+            (void)hipDeviceSynchronize();
+            bytes = need;
+            return 0;
+        }
         int dev = 0;
         (void)hipGetDevice(&dev);
         hipMemAllocationProp prop{};
@@ -120,8 +130,11 @@ struct DevBuf {
         guarded = true;
         (void)hipMemset(base, 0xFF, mapped);
         (void)hipDeviceSynchronize();
-        // mode 1: right-aligned (16-byte granularity: the widest vector access); mode 2: left-aligned
-        const size_t need16 = (need + 15) & ~(size_t)15;
+        // mode 1: right-aligned, to hipMalloc's own 256-byte alignment (kernels may rely on it; SNK_GUARD_ALIGN
+        // overrides); mode 2: left-aligned
+        static size_t al = 0;
+        if (!al) { const char *e2 = getenv("SNK_GUARD_ALIGN"); al = e2 ? (size_t)atoi(e2) : 256; if (al < 16 || (al & (al - 1))) al = 256; }
+        const size_t need16 = (need + al - 1) & ~(al - 1);
         p = guard_mode() == 1 ? base + (mapped - need16) : base;
         bytes = need;
         fprintf(stderr, "[snk-guard] %p..%p (%zu B, mapping %p..%p) %s:%d\n", p, (char *)p + need, need, (void *)base,
@@ -749,6 +762,38 @@ int snk_set_unit_classes(snk_handle h, const int32_t *unit_class, int64_t N)
 // K-NN pipeline on device.  Q must already be on the device (Qraw).  Results go to the
 // given device buffers.  Synchronises the stream once per attempt to read the status word.
 // ---------------------------------------------------------------------------
+// SNK_TRACE: the entry pool the filter sweep left, checked on the host before the bucket kernel scatters it
+static int debug_check_pool(snk_engine *h, int max_chunks, int64_t Tpad, int64_t idx_limit, hipStream_t s)
+{
+    HIPCHK(hipStreamSynchronize(s));
+    unsigned int ctl[2] = {0, 0};
+    HIPCHK(hipMemcpy(ctl, h->poolctl.p, sizeof(ctl), hipMemcpyDeviceToHost));
+    int used = (int)ctl[0];
+    if (used > max_chunks) used = max_chunks;
+    std::vector<int> fill((size_t)max_chunks);
+    HIPCHK(hipMemcpy(fill.data(), h->chunkfill.p, fill.size() * sizeof(int), hipMemcpyDeviceToHost));
+    struct E { double key; int idx; int row; };
+    const int chunk = knn_pool_chunk_entries();
+    std::vector<E> en((size_t)chunk);
+    int64_t total = 0, bad = 0;
+    for (int c = 0; c < used; ++c) {
+        const int n = fill[(size_t)c];
+        if (n < 0 || n > chunk) { fprintf(stderr, "[snk-trace] pool: chunk %d of %d has fill %d (chunk size %d)\n", c, used, n, chunk); ++bad; continue; }
+        if (n == 0) continue;
+        HIPCHK(hipMemcpy(en.data(), (const char *)h->pool.p + (size_t)c * chunk * sizeof(E), (size_t)n * sizeof(E), hipMemcpyDeviceToHost));
+        for (int e = 0; e < n; ++e) {
+            ++total;
+            if (en[(size_t)e].row < 0 || en[(size_t)e].row >= Tpad || en[(size_t)e].idx < 0 || en[(size_t)e].idx >= idx_limit) {
+                if (bad < 8) fprintf(stderr, "[snk-trace] pool: chunk %d entry %d of %d: row %d idx %d key %g (Tpad %lld, idx limit %lld)\n", c, e, n,
+                                     en[(size_t)e].row, en[(size_t)e].idx, en[(size_t)e].key, (long long)Tpad, (long long)idx_limit);
+                ++bad;
+            }
+        }
+    }
+    fprintf(stderr, "[snk-trace] pool: %u chunks handed out (max %d, overflow %u), %lld entries, %lld bad\n", ctl[0], max_chunks, ctl[1], (long long)total, (long long)bad);
+    return 0;
+}
+
 static KnnPlan make_plan(snk_engine *h, int K)
 {
     KnnPlan p{};
@@ -930,6 +975,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
                                h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
                                knn_pool_chunk_entries(), s);
         }
+        if (trace_on()) CHK(debug_check_pool(h, max_chunks, Tpad, n_slabs_b * 32 * nt_run, s));
         {
             StageTimer t(h, s, TM_KNN_BUCKET);
             launch_knn_bucket(h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,

@@ -3,13 +3,42 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// every launch of the library goes through this form (see trace_launch below)
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel_, grid_, block_, lds_, stream_, ...)                          \
+    do {                                                                                        \
+        kernel_<<<(grid_), (block_), (lds_), (stream_)>>>(__VA_ARGS__);                         \
+        snk::trace_launch(#kernel_, __FILE__, __LINE__, (stream_));                             \
+    } while (0)
+
 #define SNK_DPAD 64          // K-NN feature chunk: columns padded to multiples of 64 doubles
 #define SNK_NT_MAX 8         // max DB tiles (16 rows each) a wave keeps in registers
 #define SNK_VERY_BIG 1000000000000000.0   // const.py:3
 
 #include <mutex>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace snk {
+
+// Debug aid (environment SNK_TRACE=1, read once): every kernel launch of the library is named on stderr and waited for,
+// so the line before the runtime's "Memory access fault" message is the kernel that faulted.  Off: one predictable branch.
+inline bool trace_on()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("SNK_TRACE"); on = (e && *e && *e != '0') ? 1 : 0; }
+    return on == 1;
+}
+inline void trace_launch(const char *kernel, const char *file, int line, hipStream_t s)
+{
+    if (!trace_on()) return;
+    fprintf(stderr, "[snk-trace] %s (%s:%d) ...", kernel, file, line);
+    fflush(stderr);
+    const hipError_t e1 = hipGetLastError();
+    const hipError_t e2 = hipStreamSynchronize(s);
+    fprintf(stderr, " %s\n", e1 != hipSuccess ? hipGetErrorString(e1) : e2 != hipSuccess ? hipGetErrorString(e2) : "ok");
+    fflush(stderr);
+}
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the device that is current when it is called: the
 // "already raised to" state of a kernel is kept per device (a process may hold engines on several), under a lock

@@ -25,8 +25,10 @@ def pytest_configure(config):
 def pytest_runtest_logstart(nodeid, location):
     """Name the test about to run on stderr (unbuffered) and in gpurun_out/current_test.txt: if the process
     dies inside the runtime, the last line before the runtime's message says where."""
-    sys.stderr.write('\n[snk-test] %s\n' % nodeid)
-    sys.stderr.flush()
+    try:
+        os.write(2, ('\n[snk-test] %s\n' % nodeid).encode())      # the descriptor itself: never captured, never buffered
+    except OSError:
+        pass
     try:
         d = os.path.join(ROOT, 'gpurun_out')
         if os.path.isdir(d):

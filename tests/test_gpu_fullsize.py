@@ -206,6 +206,7 @@ def test_sharded_batch_pipeline_on_one_gpu(engine):
         r0, r1 = sum(lens[:a]), sum(lens[:b])
         d2_own = d2[:, r0:r1].contiguous()
         id_own = ids[:, r0:r1].contiguous()
+        torch.cuda.synchronize()                   # the copies ran on torch's stream, the engine has its own
         paths, costs = engine.merge_viterbi_batch_dev(d2_own.data_ptr(), id_own.data_ptr(), G, lens[a:b], K)
         for j, u in enumerate(range(a, b)):
             assert np.array_equal(paths[j], ref_paths[u]) and costs[j] == ref_costs[u]

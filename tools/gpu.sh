@@ -1,0 +1,11 @@
+#!/bin/bash
+# gpurun with retry while the pod's GPU slots are busy (exit code 3: nothing was charged).
+# usage: tools/gpu.sh TIMEOUT_SECONDS 'command'
+t=$1; shift
+for i in $(seq 1 40); do
+    /usr/local/graft/bin/gpurun --timeout "$t" -- "$@"
+    rc=$?
+    if [ $rc -ne 3 ]; then exit $rc; fi
+    sleep 45
+done
+exit 3
