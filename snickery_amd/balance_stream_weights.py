@@ -135,7 +135,7 @@ def balance_stream_weights(synth, n_tune=10, n_valid=10, max_epochs=1000, patien
     valid = names[n_tune:n_tune + n_valid]
 
     goals, losses, contribs, history = None, [], [], []
-    exhausted = max_epochs > 0
+    epoch = -1
     for epoch in range(max_epochs):
         _apply(synth, state.w, njoin)
         contrib = _measure(synth, tune)
@@ -149,18 +149,16 @@ def balance_stream_weights(synth, n_tune=10, n_valid=10, max_epochs=1000, patien
         losses.append(loss)
         if state.observe(loss) == patience:
             out.stop('converged (or diverged and ran out of patience)')
-            exhausted = False
             break
         if loss < thresh:
             out.stop('loss approaching 0: stop here')
-            exhausted = False
             break
         before = state.w.copy()
         update = state.advance(errors, loss)
         out.step(before, contrib, goals, errors, update, state.w)
         contribs.append(contrib)
         history.append(state.w.copy())
-    if exhausted:
+    if epoch == max_epochs - 1:                    # also after a stop on the last epoch, as the reference (:174-175)
         out.stop('max epochs reached: stop here')
 
     best = state.best_w

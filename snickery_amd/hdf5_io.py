@@ -51,7 +51,12 @@ def library():
         except OSError as e:
             err = e
             continue
-        lib.H5open()
+        try:
+            lib.H5open()
+        except AttributeError as e:                # a library of that name without the HDF5 entry points
+            err = e
+            continue
+        bound = True
         for name, res, args in (
                 ('H5Fopen', _hid, [ctypes.c_char_p, ctypes.c_uint, _hid]),
                 ('H5Fcreate', _hid, [ctypes.c_char_p, ctypes.c_uint, _hid, _hid]),
@@ -81,8 +86,19 @@ def library():
                 ('H5Pclose', ctypes.c_int, [_hid]),
                 ('H5Literate', ctypes.c_int, [_hid, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p, ctypes.c_void_p]),
                 ('H5Eset_auto2', ctypes.c_int, [_hid, ctypes.c_void_p, ctypes.c_void_p])):
-            fn = getattr(lib, name)
+            fn = getattr(lib, name, None)
+            if fn is None and name == 'H5Literate':
+                # libhdf5 >= 1.12: H5Literate is a macro over the versioned symbols (H5Literate1 keeps this signature)
+                fn = getattr(lib, 'H5Literate1', None)
+                if fn is not None:
+                    setattr(lib, 'H5Literate', fn)
+            if fn is None:
+                err = Hdf5Error('%s has no symbol %s' % (cand, name))
+                bound = False
+                break
             fn.restype, fn.argtypes = res, args
+        if not bound:
+            continue
         lib.H5Eset_auto2(0, None, None)            # errors come back as return codes, not as stderr dumps
         _lib = lib
         return lib
@@ -149,14 +165,16 @@ def read_datasets(path, names=None):
             if did < 0:
                 continue                           # a group, not a dataset
             sid, tid = lib.H5Dget_space(did), lib.H5Dget_type(did)
+            mem, close_mem = -1, False
             try:
+                if sid < 0 or tid < 0:
+                    raise Hdf5Error('%s: cannot query space / type of dataset %s' % (path, name))
                 nd = lib.H5Sget_simple_extent_ndims(sid)
                 dims = (ctypes.c_uint64 * max(nd, 1))()
                 if nd > 0:
                     lib.H5Sget_simple_extent_dims(sid, dims, None)
                 shape = tuple(int(dims[i]) for i in range(nd))
                 cls, size = lib.H5Tget_class(tid), int(lib.H5Tget_size(tid))
-                close_mem = False
                 if cls == _H5T_FLOAT and size in (4, 8):
                     dtype = np.dtype(np.float32 if size == 4 else np.float64)
                     mem, _ = _mem_type(lib, dtype)
@@ -167,17 +185,22 @@ def read_datasets(path, names=None):
                 elif cls == _H5T_STRING and lib.H5Tis_variable_str(tid) == 0:
                     dtype = np.dtype('S%d' % size)
                     mem, close_mem = lib.H5Tcopy(tid), True
+                    if mem < 0:
+                        close_mem = False
+                        raise Hdf5Error('%s: cannot copy the string type of dataset %s' % (path, name))
                 else:
                     raise Hdf5Error('%s: dataset %s has an unsupported type (class %d, %d bytes)' % (path, name, cls, size))
                 arr = np.empty(shape, dtype=dtype)
                 if arr.size and lib.H5Dread(did, mem, _H5S_ALL, _H5S_ALL, _H5P_DEFAULT, arr.ctypes.data_as(ctypes.c_void_p)) < 0:
                     raise Hdf5Error('%s: reading dataset %s failed' % (path, name))
-                if close_mem:
-                    lib.H5Tclose(mem)
                 out[name] = arr
             finally:
-                lib.H5Tclose(tid)
-                lib.H5Sclose(sid)
+                if close_mem:
+                    lib.H5Tclose(mem)
+                if tid >= 0:
+                    lib.H5Tclose(tid)
+                if sid >= 0:
+                    lib.H5Sclose(sid)
                 lib.H5Dclose(did)
     finally:
         lib.H5Fclose(fid)
@@ -202,15 +225,21 @@ def write_datasets(path, arrays, resizable=True):
             chunked = resizable and nd >= 1 and a.size > 0
             maxd = (ctypes.c_uint64 * max(nd, 1))(*((_H5S_UNLIMITED,) + tuple(a.shape[1:]))) if chunked else None
             sid = lib.H5Screate_simple(nd, dims, maxd)
-            dcpl = _H5P_DEFAULT
-            if chunked:
-                dcpl = lib.H5Pcreate(_native(lib, 'H5P_CLS_DATASET_CREATE_ID_g'))
-                row = int(np.prod(a.shape[1:])) * a.dtype.itemsize if nd > 1 else a.dtype.itemsize
-                rows = max(1, min(a.shape[0], (1 << 20) // max(row, 1)))
-                chunk = (ctypes.c_uint64 * nd)(*((rows,) + tuple(a.shape[1:])))
-                lib.H5Pset_chunk(dcpl, nd, chunk)
-            did = lib.H5Dcreate2(fid, name.encode(), mem, sid, _H5P_DEFAULT, dcpl, _H5P_DEFAULT)
+            dcpl, did = _H5P_DEFAULT, -1
             try:
+                if sid < 0:
+                    raise Hdf5Error('%s: cannot create the data space of %s' % (path, name))
+                if chunked:
+                    dcpl = lib.H5Pcreate(_native(lib, 'H5P_CLS_DATASET_CREATE_ID_g'))
+                    if dcpl < 0:
+                        chunked = False
+                        raise Hdf5Error('%s: cannot create a property list for %s' % (path, name))
+                    row = int(np.prod(a.shape[1:])) * a.dtype.itemsize if nd > 1 else a.dtype.itemsize
+                    rows = max(1, min(a.shape[0], (1 << 20) // max(row, 1)))
+                    chunk = (ctypes.c_uint64 * nd)(*((rows,) + tuple(a.shape[1:])))
+                    if lib.H5Pset_chunk(dcpl, nd, chunk) < 0:
+                        raise Hdf5Error('%s: cannot set the chunk shape of %s' % (path, name))
+                did = lib.H5Dcreate2(fid, name.encode(), mem, sid, _H5P_DEFAULT, dcpl, _H5P_DEFAULT)
                 if did < 0:
                     raise Hdf5Error('%s: cannot create dataset %s' % (path, name))
                 if a.size and lib.H5Dwrite(did, mem, _H5S_ALL, _H5S_ALL, _H5P_DEFAULT, a.ctypes.data_as(ctypes.c_void_p)) < 0:
@@ -218,9 +247,10 @@ def write_datasets(path, arrays, resizable=True):
             finally:
                 if did >= 0:
                     lib.H5Dclose(did)
-                if chunked:
+                if chunked and dcpl >= 0:
                     lib.H5Pclose(dcpl)
-                lib.H5Sclose(sid)
+                if sid >= 0:
+                    lib.H5Sclose(sid)
                 if close_mem:
                     lib.H5Tclose(mem)
     finally:

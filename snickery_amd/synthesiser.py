@@ -399,7 +399,13 @@ class Synthesiser(object):
         its own engine and its own copy of the voice on ``devices[r % len(devices)]`` (default: every visible
         GPU in turn), worker r taking sentences r, r + ncores, ...  No exchange between them -- a voice is a
         few GB of the 288 GB of one GPU; the row-sharded database (snickery_amd/dist.py) is the other way to
-        use several GPUs, for one utterance stream."""
+        use several GPUs, for one utterance stream.
+
+        inspect_join_weights_only: accepted and without effect, as in the reference -- synth_simple.py never reads it
+        (:279-284) and synth_halfphone.py only mentions it in the unreachable ``junk`` method (:911-935)."""
+        if inspect_join_weights_only:
+            import warnings
+            warnings.warn('inspect_join_weights_only has no effect (neither in the reference: synth_halfphone.py:911)')
         flist = self.get_sentence_set(synth_type)
         if ncores <= 1 or len(flist) <= 1:
             return dict((f, self.synth_utt(f, synth_type=synth_type, outdir=outdir)) for f in flist)
@@ -516,10 +522,16 @@ class Synthesiser(object):
             t = self.start_clock('Get speech + preselection (bulk)')
             feats, cands, dists = [], [], []
             cache = self.__dict__.setdefault('_bulk_cache', {})
+            # everything but the stream weights that the unweighted targets, the unit names and the candidate ids depend
+            # on: a changed setting (reconfigure_settings, a caller editing self.config) must not meet a stale entry
+            state = repr(sorted((k, repr(v)) for k, v in self.config.items()
+                                if not k.endswith('_stream_weights') and k != 'join_cost_weight'))
+            if len(cache) > 4096:                              # bounded: a tune set is tens of sentences
+                cache.clear()
             for f in fnames:
                 # what depends on the files and labels only is kept across calls (a tuning loop searches the same tune
                 # set again and again with other weights): unweighted targets, unit names, quinphone candidate ids
-                key = (synth_type, f, method, self.config['n_candidates'])
+                key = (synth_type, f, method, self.config['n_candidates'], state)
                 ent = cache.get(key)
                 if ent is None:
                     raw, names = self.prepare_targets(f, synth_type, return_names=True, _weighted=False)
@@ -660,6 +672,7 @@ class Synthesiser(object):
             if self.config.get(item, default) != changed_config_values[item]:
                 description += '%s: %s -> %s\n' % (item, self.config.get(item, default), changed_config_values[item])
                 self.config[item] = changed_config_values[item]
+        self.__dict__.pop('_bulk_cache', None)             # targets / candidates kept by the bulk path follow the settings
         if rebuild:
             self.set_join_weights(np.array(self.config['join_stream_weights']) * self.config['join_cost_weight'], _apply=False)
             self.set_target_weights(np.array(self.config['target_stream_weights']) * (1.0 - self.config['join_cost_weight']), _apply=False)
