@@ -1,0 +1,369 @@
+// Greedy joint search, third form: the database RESIDENT in LDS for the whole launch.
+//
+// Replaces the same reference code as greedy_kernels.hip / greedy32_kernels.hip (greedy_joint_search,
+// script/synth_simple.py:458-503; get_tree_for_greedy_search :190-229) for voices whose windowed join matrix fits
+// the chip's LDS: 256 compute units x 152 KB hold 65 536 windows x 151 float32 join columns (the README demo voice,
+// config/slt_simplified_mini.cfg).  With the target term hoisted into one float64 matrix product per
+// utterance (greedy_hoist_kernels.hip) a step then touches no database byte outside LDS:
+//
+//   every workgroup owns 256 consecutive windows, one per thread; their join rows are loaded ONCE, lane-major
+//   (xs[q][thread] = float4 of columns 4q .. 4q+3: conflict-free 16-byte LDS reads);
+//   step:  reference row of the previous winner (one 604-byte read per workgroup) -> float32 (w, ref) table in LDS
+//          -> 152 columns of float32 arithmetic per thread out of LDS + the window's hoisted target value
+//          -> workgroup top-3 (three wavefront minima, no sort)
+//          -> ONE 16-byte record per workgroup, two self-validating 8-byte granules {data, step tag} (agent-scope
+//             stores), which EVERY workgroup gathers (256 x 16 B, agent-scope loads, polled until all tags match)
+//          -> every workgroup takes the SAME decision from the same records: no deciding workgroup, no release, no
+//             poll for the winner.
+//   Two dependent trips through the fabric per step (records, reference row) instead of seven.
+//
+// The decision is greedy32_kernels.hip's: a float32 total lies within the proven E(d) of the canonical float64 total;
+// only windows inside tau = M + 2 E(tau) can be the exact nearest neighbour; one such window wins outright, several
+// are settled by their canonical float64 totals (lowest index on exact ties), computed by every workgroup for itself.
+// A third window of ONE workgroup inside tau (mass duplicates: digital silence) is beyond what a record carries:
+// the launch ends and the caller finishes the utterance on greedy32_kernels.hip's scan, as for its own undecidable
+// steps.  search_epsilon >= 1e-3: the float32 minimum is the answer (see greedy32_kernels.hip).
+// The records' hand-off is the form "8-byte agent-scope atomics on both sides" of a data-tagged granule on hipMalloc
+// memory: nothing but the granule itself is handed over, so no fence and no drain is involved.
+#include "greedy32_device.h"
+
+namespace snk {
+
+#define GRES_T 256                                 // threads per workgroup = windows per workgroup
+#define GRES_STALL_TICKS 300000000ull              // 3 s of the 100 MHz clock
+#define GRES_MAXCAND 64                            // windows inside the bound that one step settles exactly
+
+struct GresRec { unsigned long long a, b; };
+// v1 <= v2 <= v3: order-preserving uint32 images (gres_image) of the workgroup's three smallest float32 totals
+// granule a: v1 | thread of the best window << 32 | thread of the second << 40 | tag << 48
+// granule b: v2 | upper 16 bits of v3 (the image truncated: a value at or BELOW v3, conservative) << 32 | tag << 48
+
+// order-preserving map float32 -> uint32 and back
+__device__ __forceinline__ unsigned int gres_image(float f)
+{
+    const unsigned int b = __builtin_bit_cast(unsigned int, f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float gres_value(unsigned int u)
+{
+    return __builtin_bit_cast(float, (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__device__ __forceinline__ unsigned int gres_dpp_min_u32(unsigned int v)
+{
+    // wavefront minimum by DPP: quads, half rows, rows, then row broadcasts; the result is in lane 63
+#define GRES_DPP(ctrl_, rmask_)                                                                       \
+    {                                                                                                 \
+        const unsigned int o = (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl_, rmask_, 0xf, false); \
+        v = o < v ? o : v;                                                                            \
+    }
+    GRES_DPP(0xB1, 0xf)      // quad_perm [1,0,3,2]
+    GRES_DPP(0x4E, 0xf)      // quad_perm [2,3,0,1]
+    GRES_DPP(0x141, 0xf)     // row_half_mirror
+    GRES_DPP(0x140, 0xf)     // row_mirror
+    GRES_DPP(0x142, 0xa)     // row_bcast:15 into rows 1 and 3
+    GRES_DPP(0x143, 0xc)     // row_bcast:31 into rows 2 and 3
+#undef GRES_DPP
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ unsigned long long gres_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int m = 1; m <= 32; m <<= 1) {
+        const unsigned long long o = __shfl_xor(v, m, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(GRES_T, 1)
+greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, GresRec *rec, int64_t *path, int64_t *status)
+{
+    const bool approx = (flags & 1) != 0;
+    const bool test_stall = (flags & 256) != 0;
+    extern __shared__ __align__(16) char lds[];
+    f32x4 *const xs = reinterpret_cast<f32x4 *>(lds);                           // [JQ4][256]
+    f32x4 *const tw = reinterpret_cast<f32x4 *>(lds + (size_t)JQ4 * GRES_T * 16);    // [JQ4] weights (float32)
+    f32x4 *const tr = tw + JQ4;                                                  // [JQ4] references of the step
+    char *const scratch = reinterpret_cast<char *>(tr + JQ4);                    // 512 bytes
+    double *const redd = reinterpret_cast<double *>(scratch);                    // [4] partial norms
+    unsigned int *const redk = reinterpret_cast<unsigned int *>(scratch + 64);   // [4][6] wavefront top-3
+    int64_t *const bcast = reinterpret_cast<int64_t *>(scratch + 192);           // [2] winner, state
+    int64_t *const clist = reinterpret_cast<int64_t *>(scratch + 256);           // candidates (GRES_MAXCAND, behind: terms)
+    double *const terms = reinterpret_cast<double *>(scratch + 256 + GRES_MAXCAND * 8);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned int nb = gridDim.x;
+    const int64_t win = (int64_t)blockIdx.x * GRES_T + tid;
+    const bool valid = win < a.Nwin;
+
+    // ---- once: this workgroup's join rows into LDS, the float32 weights ----
+    {
+        const int64_t r = a.prev_row0 + (valid ? win : 0);
+        const f32x4 *src = a.JT + ((size_t)(r >> 6) * tile_q) * 64 + (r & 63);
+        for (int q = 0; q < JQ4; ++q) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (valid) v = src[(size_t)q * 64];
+            xs[q * GRES_T + tid] = v;
+        }
+        if (tid < JQ4 * 4) {
+            const float w = tid < a.jdim ? (float)a.wj[a.prev_col0 + tid] : 0.f;
+            reinterpret_cast<float *>(tw)[tid] = w;
+            reinterpret_cast<float *>(tr)[tid] = 0.f;
+        }
+    }
+    // weight of this thread's reference column: the winner's row is read from the `current` columns, a start state's
+    // from the `prev` columns (synth_simple.py:467-469,501)
+    const double wref_cur = tid < a.jdim ? a.wj[a.cur_col0 + tid] : 0.0;
+    const double wref_prev = tid < a.jdim ? a.wj[a.prev_col0 + tid] : 0.0;
+    const int ecols = JQ4 * 4 + 4;                       // chain length of the bound: columns, the two partial sums, the hoisted value
+    int64_t prev_row = a.start[0];
+    const float *const Wp0 = a.W[0] + (valid ? win : 0);
+    float w_next = valid ? Wp0[0] : 0.f;
+    unsigned long long stat_rounds = 0, stat_windows = 0;
+    __syncthreads();
+
+    for (int64_t step = 0; step < nsteps; ++step) {
+        const unsigned int tag = (unsigned int)(step % 65535) + 1u;
+        const float w_cur = w_next;
+        if (step + 1 < nsteps && valid) w_next = Wp0[(size_t)(step + 1) * a.Wp];
+        // ---- the step's references: row of the previous winner x weights, float32; squared norm in float64 ----
+        {
+            double ref = 0.0;
+            if (tid < a.jdim && prev_row >= 0) {
+                const bool cur = step > 0;
+                const float x = a.JC_unw[((cur ? a.cur_row0 : a.prev_row0) + prev_row) * a.Jp + (cur ? a.cur_col0 : a.prev_col0) + tid];
+                ref = __dmul_rn((double)x, cur ? wref_cur : wref_prev);
+            }
+            if (tid < JQ4 * 4) reinterpret_cast<float *>(tr)[tid] = (float)ref;
+            double v = ref * ref;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if (lane == 0) redd[wave] = v;
+        }
+        __syncthreads();
+        const double V2 = g32_uniform_d(((redd[0] + redd[1]) + redd[2]) + redd[3]);
+        const double qn2 = a.qn2[0][step];
+        const double rr = sqrt(qn2) + sqrt(a.fwmax2);
+        const double EW = g32_uniform_d(a.hoist_c * rr * rr);
+
+        // ---- scan: this thread's window against the table, out of LDS ----
+        float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 2
+        for (int q = 0; q < JQ4; ++q) {
+            const f32x4 x = xs[q * GRES_T + tid], w = tw[q], r = tr[q];
+            const float d0 = __builtin_fmaf(x[0], w[0], -r[0]), d1 = __builtin_fmaf(x[1], w[1], -r[1]);
+            const float d2 = __builtin_fmaf(x[2], w[2], -r[2]), d3 = __builtin_fmaf(x[3], w[3], -r[3]);
+            acc0 = __builtin_fmaf(d0, d0, acc0); acc1 = __builtin_fmaf(d1, d1, acc1);
+            acc0 = __builtin_fmaf(d2, d2, acc0); acc1 = __builtin_fmaf(d3, d3, acc1);
+        }
+        float key = valid ? (acc0 + acc1) + w_cur : __builtin_inff();
+        if (!(key == key)) key = __builtin_inff();           // a NaN total (non-finite data) never wins
+        // order-preserving image of the float32 key (the hoisted value's rounding can leave a total just below zero)
+        const unsigned int INF = 0xff800000u;
+        const unsigned int kb = gres_image(key);
+        // ---- wavefront top-3: three minima; ties keep the lowest lane = lowest window index ----
+        const unsigned int m1 = gres_dpp_min_u32(kb);
+        const int l1 = __builtin_ctzll(__ballot(kb == m1));
+        const unsigned int kb2 = lane == l1 ? INF : kb;
+        const unsigned int m2 = gres_dpp_min_u32(kb2);
+        const int l2 = m2 < INF ? __builtin_ctzll(__ballot(kb2 == m2 && lane != l1)) : 0;
+        const unsigned int kb3 = (lane == l2 && m2 < INF) ? INF : kb2;
+        const unsigned int m3 = gres_dpp_min_u32(kb3);
+        if (lane == 0) {
+            redk[wave * 6 + 0] = m1; redk[wave * 6 + 1] = (unsigned int)(wave * 64 + l1);
+            redk[wave * 6 + 2] = m2; redk[wave * 6 + 3] = (unsigned int)(wave * 64 + l2);
+            redk[wave * 6 + 4] = m3;
+        }
+        __syncthreads();
+
+        if (wave == 0) {
+            // ---- workgroup top-3 (the wavefronts hold ascending windows: earlier entries win ties) and the record ----
+            if (lane == 0 && !(test_stall && step == 1 && blockIdx.x == 0)) {
+                unsigned int v1 = INF, v2 = INF, v3 = INF, a1 = 0, a2 = 0;
+                auto push = [&](unsigned int v, unsigned int i) {
+                    if (v < v1) { v3 = v2; v2 = v1; a2 = a1; v1 = v; a1 = i; }
+                    else if (v < v2) { v3 = v2; v2 = v; a2 = i; }
+                    else if (v < v3) v3 = v;
+                };
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    push(redk[w * 6 + 0], redk[w * 6 + 1]);
+                    push(redk[w * 6 + 2], redk[w * 6 + 3]);
+                    if (redk[w * 6 + 4] < v3) v3 = redk[w * 6 + 4];
+                }
+                const unsigned long long ga = (unsigned long long)v1 | ((unsigned long long)a1 << 32) | ((unsigned long long)a2 << 40) |
+                                              ((unsigned long long)tag << 48);
+                const unsigned long long gb = (unsigned long long)v2 | ((unsigned long long)(v3 >> 16) << 32) | ((unsigned long long)tag << 48);
+                __hip_atomic_store(&rec[blockIdx.x].a, ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&rec[blockIdx.x].b, gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // ---- gather the records of all workgroups (lane L: workgroups L, L + 64, ...) until every tag is this step's ----
+            unsigned long long ra[4], rb[4];
+            int state = 0;                                   // 0: go on, -1: leave (undecidable / watchdog)
+            {
+                const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned int b = (unsigned int)lane + 64u * q;
+                        ra[q] = 0ull; rb[q] = 0ull;
+                        if (b < nb) {
+                            ra[q] = __hip_atomic_load(&rec[b].a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            rb[q] = __hip_atomic_load(&rec[b].b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = ok && (unsigned int)(ra[q] >> 48) == tag && (unsigned int)(rb[q] >> 48) == tag;
+                        }
+                    }
+                    if (__all(ok)) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t_wait > GRES_STALL_TICKS) {
+                        // a workgroup of the launch is not running (the device shared with another spinning launch)
+                        if (lane == 0) {
+                            __hip_atomic_store(&status[3], (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        state = -1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            int64_t winner = -1;
+            if (state == 0) {
+                // ---- the decision, the same in every workgroup ----
+                unsigned long long best = ~0ull;             // (v1 bits, window) of the float32 minimum: lowest index on ties
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned int b = (unsigned int)lane + 64u * q;
+                    if (b < nb) {
+                        const unsigned long long k = ((ra[q] & 0xffffffffull) << 32) | (unsigned long long)(b * GRES_T + (unsigned int)((ra[q] >> 32) & 0xffu));
+                        best = k < best ? k : best;
+                    }
+                }
+                best = gres_min_u64(best);
+                const unsigned int mvb = (unsigned int)(best >> 32);
+                const int64_t mi = (int64_t)(best & 0xffffffffull);
+                const float mv = gres_value(mvb);
+                if (!(mvb < INF)) {
+                    state = -1;                              // nothing finite
+                    if (lane == 0 && blockIdx.x == 0) __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (approx && 4.0 * (g32_err((double)mv, V2, ecols) + EW) <= 1e-3 * (double)mv) {
+                    winner = mi;
+                } else {
+                    const double M = (double)mv + 2.0 * EW;
+                    double tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300;
+                    for (int it = 0; it < 3; ++it) tau = M + 2.0 * g32_err(tau, V2, ecols);
+                    tau = tau * (1.0 + 1e-6) + 1e-300;
+                    int nc = 0;
+                    bool cov = false;
+                    unsigned long long m1b[4], m2b[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned int b = (unsigned int)lane + 64u * q;
+                        const float v1 = gres_value((unsigned int)ra[q]);
+                        const float v2 = gres_value((unsigned int)rb[q]);
+                        const float v3 = gres_value((unsigned int)((rb[q] >> 32) & 0xffffu) << 16);
+                        m1b[q] = __ballot(b < nb && (double)v1 <= tau);
+                        m2b[q] = __ballot(b < nb && (double)v2 <= tau);
+                        nc += __popcll(m1b[q]) + __popcll(m2b[q]);
+                        cov = cov || __ballot(b < nb && (double)v3 <= tau) != 0ull;
+                    }
+                    if (nc == 1 && !cov) winner = mi;        // the only window inside the bound is the float32 minimum itself
+                    else if (cov || nc > GRES_MAXCAND) {
+                        state = -1;                          // a window no record carries may matter: the caller's other scan
+                        if (lane == 0 && blockIdx.x == 0) __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        // canonical float64 totals of the windows inside the bound, lowest index on exact ties
+                        int pos = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const unsigned int b = (unsigned int)lane + 64u * q;
+                            const unsigned long long below = (1ull << lane) - 1ull;
+                            if ((m1b[q] >> lane) & 1ull) clist[pos + __popcll(m1b[q] & below)] = (int64_t)(b * GRES_T + (unsigned int)((ra[q] >> 32) & 0xffu));
+                            pos += __popcll(m1b[q]);
+                            if ((m2b[q] >> lane) & 1ull) clist[pos + __popcll(m2b[q] & below)] = (int64_t)(b * GRES_T + (unsigned int)((ra[q] >> 40) & 0xffu));
+                            pos += __popcll(m2b[q]);
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                        double dbest = DBL_MAX;
+                        int64_t ibest = INT64_MAX;
+                        for (int p = 0; p < nc; ++p) {
+                            const int64_t id = g32_uniform_i(clist[p]);
+                            const double d = g32_exact_d2_wave(a, 0, step, prev_row, step > 0, id, terms, lane);
+                            if (d < dbest || (d == dbest && id < ibest)) { dbest = d; ibest = id; }
+                        }
+                        winner = ibest;
+                        stat_windows += (unsigned long long)nc;
+                    }
+                }
+            }
+            if (lane == 0) { bcast[0] = winner; bcast[1] = state; }
+        }
+        __syncthreads();
+        if (bcast[1] < 0) break;                             // uniform: everybody leaves
+        prev_row = g32_uniform_i(bcast[0]);
+        if (blockIdx.x == 0 && tid == 0) path[a.out_off[0] + step] = prev_row;
+    }
+    if (blockIdx.x == 0 && tid == 0 && (stat_rounds | stat_windows)) {
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&status[1]), stat_rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&status[2]), stat_windows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ void greedy_res_init_kernel(GresRec *rec, int n, int64_t *status)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { rec[i].a = 0ull; rec[i].b = 0ull; }
+    if (i == 0) { status[0] = 0; status[1] = 0; status[2] = 0; status[3] = 0; }
+}
+
+static size_t gres_lds_bytes(const GreedyLayout &g, int Dt)
+{
+    const int JQ4 = (g.jdim + 3) / 4;
+    const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
+    return (size_t)JQ4 * GRES_T * 16 + (size_t)JQ4 * 32 + 256 + GRES_MAXCAND * 8 + (size_t)(g.jdim + nep * Dt) * 8;
+}
+
+// one workgroup per compute unit holds 256 windows: the whole windowed database must fit the chip
+bool greedy_res_supported(const GreedyLayout &g, int Dt, int n_cus)
+{
+    const int64_t nb = (g.Nwin + GRES_T - 1) / GRES_T;
+    const int cap = n_cus < 256 ? n_cus : 256;
+    return nb >= 1 && nb <= cap && gres_lds_bytes(g, Dt) <= (size_t)(160 * 1024);
+}
+
+size_t greedy_res_record_bytes(const GreedyLayout &g) { return (size_t)((g.Nwin + GRES_T - 1) / GRES_T) * sizeof(GresRec); }
+
+// One utterance, all steps, one launch.  *status (device, 4 words): 0 or 1 + the first step that was not decided here,
+// rounds, windows settled by exact totals, watchdog.  hst: the hoisted target term of the utterance (required).
+void launch_greedy_res(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
+                       int Dj, const double *wj, const float *tiles, const double *Q, int64_t q_off, int64_t nsteps,
+                       int64_t out_off, int64_t start, int flags, void *rec, int64_t *status, int64_t *path,
+                       const G32Hoist *hst, hipStream_t s)
+{
+    if (nsteps <= 0) return;
+    GreedyArgs a{};
+    greedy_fill_args(a, g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, Q, true, tiles);
+    a.lds_mode = 0;
+    a.nu = 1;
+    a.hoist = 1; a.Wp = hst->Wp; a.hoist_c = hst->c; a.fwmax2 = hst->fwmax2;
+    for (int u = 0; u < 6; ++u) {
+        a.W[u] = u == 0 ? hst->W[0] : nullptr; a.qn2[u] = u == 0 ? hst->qn2[0] : nullptr;
+        a.q_off[u] = u == 0 ? q_off : 0; a.nsteps_u[u] = u == 0 ? nsteps : 0; a.out_off[u] = u == 0 ? out_off : 0;
+        a.start[u] = u == 0 ? start : -1;
+    }
+    const int nb = (int)((g.Nwin + GRES_T - 1) / GRES_T);
+    const int JQ4 = (g.jdim + 3) / 4, tile_q = (g.jdim + GR_CC - 1) / GR_CC * 8;
+    const size_t lds = gres_lds_bytes(g, Dt);
+    hipLaunchKernelGGL(greedy_res_init_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, reinterpret_cast<GresRec *>(rec), nb, status);
+    static size_t attr[32] = {0};
+    if (lds_attr_needed(attr, lds))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(greedy_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(greedy_res_kernel, dim3(nb), dim3(GRES_T), lds, s, a, nsteps, flags, JQ4, tile_q,
+                       reinterpret_cast<GresRec *>(rec), path, status);
+}
+
+}  // namespace snk

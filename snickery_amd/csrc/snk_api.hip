@@ -267,6 +267,9 @@ struct snk_engine {
     DevBuf tmask;                         // tsel on the device (query rows are masked after upload)
     DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist, gsync, gtiles;
     DevBuf g32_blk, g32_ctl;          // float32 persistent scan: block records + candidate lists, {gen, status}
+    DevBuf g32_res;                   // resident scan (greedy_res_kernels.hip): one 16-byte record per workgroup
+    int greedy_resident = 1;          // 1: one utterance against a database that fits the chip's LDS takes the resident scan
+    int64_t greedy_resident_launches = 0;
     // hoisted target term of the float32 scan (greedy_hoist_kernels.hip): window norms (per database, layout and
     // weights), left operands and products of the utterances in work
     DevBuf gh_nw, gh_max, gh_aq, gh_qn2, gh_W;
@@ -455,7 +458,7 @@ int snk_destroy(snk_handle h)
                       &h->Qraw, &h->Qp, &h->Qf, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
                       &h->gpath, &h->gdist, &h->gsync, &h->gtiles, &h->cls16_full, &h->cls16_samp,
-                      &h->g32_blk, &h->g32_ctl,
+                      &h->g32_blk, &h->g32_ctl, &h->g32_res,
                       &h->gh_nw, &h->gh_max, &h->gh_aq, &h->gh_qn2, &h->gh_W, &h->gtiles16};
     for (auto *b : bufs) b->release();
     if (h->dp_stream[1]) (void)hipStreamDestroy(h->dp_stream[1]);
@@ -1806,6 +1809,16 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
     CHK(h->gsync.ensure(2 * greedy_counter_bytes()));
     unsigned int *gen = h->g32_ctl.as<unsigned int>();
     int64_t *status = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(h->g32_ctl.p) + 16);
+    // one utterance against a database that fits the chip's LDS: resident scan, every workgroup decides for itself
+    // (float16 tiles forced on by the caller -- tests -- are the streamed scan's)
+    const bool resident = hoist && nu == 1 && h->greedy_resident && greedy_res_supported(g, h->Dt, h->n_cus) && !hst.f16_force;
+    if (resident) {
+        CHK(h->g32_res.ensure(greedy_res_record_bytes(g) + 256));
+        launch_greedy_res(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
+                          h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), q_off[0], ns[0], oo[0], st[0],
+                          (approx ? 1 : 0) | (h->greedy_test_stall ? 256 : 0), h->g32_res.p, status, h->gpath.as<int64_t>(), &hst, h->stream);
+        h->greedy_resident_launches += 1;
+    } else
     launch_greedy32(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
                     h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nu, q_off, ns, oo, st, (approx ? 1 : 0) | (h->greedy_test_stall ? 256 : 0),
                     h->g32_blk.p, h->n_cus, h->gsync.as<unsigned int>(), gen,
@@ -2836,6 +2849,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
         h->greedy_f16 = (int)value;
     } else if (!strcmp(name, "greedy_test_stall")) {
         h->greedy_test_stall = value != 0.0;
+    } else if (!strcmp(name, "greedy_resident")) {
+        if (value != 0.0 && value != 1.0) return fail("greedy_resident must be 0 or 1");
+        h->greedy_resident = (int)value;
     } else if (!strcmp(name, "greedy_hoist")) {
         if (value != 0.0 && value != 1.0) return fail("greedy_hoist must be 0 or 1");
         h->greedy_hoist = (int)value;
@@ -2889,6 +2905,8 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "greedy_mode")) *out = h->greedy_mode;
     else if (!strcmp(name, "greedy_hoist")) *out = h->greedy_hoist;
     else if (!strcmp(name, "greedy_hoist_launches")) *out = (double)h->greedy_hoist_launches;
+    else if (!strcmp(name, "greedy_resident")) *out = h->greedy_resident;
+    else if (!strcmp(name, "greedy_resident_launches")) *out = (double)h->greedy_resident_launches;
     else if (!strcmp(name, "greedy_f16")) *out = h->greedy_f16;
     else if (!strcmp(name, "greedy_f16_launches")) *out = (double)h->greedy_f16_launches;
     else if (!strcmp(name, "greedy_f16_delta")) *out = h->g16_delta;

@@ -236,6 +236,13 @@ void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, 
                      int Dj, const double *wj, const float *tiles, const double *Q, int nu, const int64_t *q_off,
                      const int64_t *nsteps_u, const int64_t *out_off, const int64_t *start, int approx, void *blk, int n_cus, unsigned int *arrive, unsigned int *gen, int64_t *status,
                      int64_t *path, const G32Hoist *hoist, hipStream_t s);
+// database resident in LDS for the whole launch (greedy_res_kernels.hip): one utterance, hoisted target term required
+bool greedy_res_supported(const GreedyLayout &g, int Dt, int n_cus);
+size_t greedy_res_record_bytes(const GreedyLayout &g);
+void launch_greedy_res(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
+                       int Dj, const double *wj, const float *tiles, const double *Q, int64_t q_off, int64_t nsteps,
+                       int64_t out_off, int64_t start, int flags, void *rec, int64_t *status, int64_t *path,
+                       const G32Hoist *hoist, hipStream_t s);
 void launch_greedy32_dist(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
                           int Dj, const double *wj, const double *Q, int u_slot, int64_t q_off, int64_t nsteps, int64_t out_off,
                           int64_t start, const int64_t *path, double *dist, hipStream_t s);

@@ -291,3 +291,14 @@ def test_baseline_shapes_stay_on_the_fast_path(engine, N, Dt, Dj, T, K, U):
         engine.set_option('precision', 1)
     assert all(np.array_equal(a, b) for a, b in zip(paths, paths0)) and np.array_equal(costs, costs0)
     assert np.array_equal(cand, cand0) and np.array_equal(dist, dist0)
+    # the oracle at the configuration's own N (not only the f64 sweep of the same library): sixteen query rows against
+    # the C oracle's brute force over the WHOLE database, and the whole Viterbi of the first utterance against the C
+    # oracle's recursion on the device's candidates
+    F = o.weight(F_unw, wt)
+    rows = np.unique(np.linspace(0, T - 1, 16).astype(np.int64))
+    oc_cand, oc_dist = oc.knn(F, utts[0][rows], K)
+    assert np.array_equal(cand[rows], oc_cand) and np.array_equal(dist[rows], oc_dist)
+    del F
+    JCw = o.weight(JC_unw, wj)
+    opath, ocost = oc.viterbi(cand, dist, JCw)
+    assert [int(v) for v in paths[0]] == opath and costs[0] == ocost

@@ -219,3 +219,42 @@ def test_values_outside_the_float16_range_keep_float32_tiles(engine):
         assert engine.info('greedy_f16_launches') == n0
     finally:
         engine.set_option('greedy_f16', 1)
+
+
+@pytest.mark.parametrize('N,me,lfat,mode,Dj,Dt', [(65536 + 5, 6, False, 0, 151, 61),      # B1: every compute unit holds 256 windows
+                                                 (30011, 4, False, 1, 302, 61),            # half-column join (synth_halfphone epoch voices)
+                                                 (1078, 6, True, 0, 151, 61),              # the golden mini voice's size: five workgroups
+                                                 (777, 1, False, 0, 40, 61)])
+def test_resident_scan_equals_oracle_and_streamed_scan(engine, N, me, lfat, mode, Dj, Dt):
+    """A database whose windowed join matrix fits the chip's LDS is searched by the resident scan (greedy_res_kernels.hip:
+    one utterance per call, every workgroup decides each step for itself from the gathered records).  Same paths and
+    distances as the oracle and as the streamed one-launch scan; the counter says which scan ran."""
+    engine.set_option('greedy_mode', 2); engine.set_option('greedy_hoist', 1); engine.set_option('greedy_resident', 1)
+    F_unw, JC_unw, wt, wj = _setup(engine, N, Dt, Dj, seed=5 * me + 1, me=me, lfat=lfat, mode=mode)
+    # a stretch of speech that occurs twice: exact ties between two workgroups (and inside one: the copy starts 40 windows on)
+    F_unw[300:300 + 30] = F_unw[100:100 + 30]; JC_unw[300:300 + 31] = JC_unw[100:100 + 31]
+    F_unw[140:140 + 20] = F_unw[100:100 + 20]; JC_unw[140:140 + 21] = JC_unw[100:100 + 21]
+    engine.upload_db(F_unw, JC_unw); engine.set_weights(wt, wj); engine.set_greedy_layout(me, lfat, mode)
+    utts = [(o.synthetic_targets(F_unw, 40 * me + (me - 1), seed=9) * wt, -1),
+            (o.synthetic_targets(F_unw, 17 * me, seed=10) * wt, N - me - 3),
+            (F_unw[100:100 + 3 * me].astype(np.float64) * wt, 100),            # noise-free targets inside the stretch: exact three-way ties
+            (F_unw[100:100 + 3 * me].astype(np.float64) * wt, -1)]
+    for U, st in utts:
+        r0, f0 = engine.info('greedy_resident_launches'), engine.info('greedy_fallbacks')
+        path, d = engine.greedy(U, start_state=st, return_distances=True)
+        op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, U, me, lfat, mode, st)
+        assert path == op and np.array_equal(d, od)
+        assert engine.info('greedy_resident_launches') == r0 + 1
+        engine.set_option('greedy_resident', 0)
+        try:
+            path2, d2 = engine.greedy(U, start_state=st, return_distances=True)
+        finally:
+            engine.set_option('greedy_resident', 1)
+        assert path2 == op and np.array_equal(d2, od) and engine.info('greedy_resident_launches') == r0 + 1
+    # search_epsilon: the float32 minimum is within (1 + eps) of the nearest window
+    U, st = utts[0]
+    path, d = engine.greedy(U, start_state=st, search_epsilon=0.05, return_distances=True)
+    op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, U, me, lfat, mode, st)
+    assert len(path) == len(op)
+    # (the (1 + eps) contract itself is checked step by step in test_gpu_greedy32.py::test_search_epsilon_contract, which
+    # runs through this scan as well: one utterance, 30 000 units)
