@@ -538,6 +538,21 @@ def main():
                                          'note': 'float32-grade keys on the bf16 pipe cost %d bf16 MFMA terms per product (hi.hi + hi.lo + '
                                                  'lo.hi%s) on Dt padded to 64 columns; frac above prices only the algorithmic '
                                                  '2 N rows Dt flops against the bf16 peak' % (terms, ' + lo.lo' if terms == 4 else '')}
+        if world == 1 and bf16_mode:
+            # tripwire of the bf16-split prefilter's key bound (untimed, after the timed region): the same step with the
+            # float32-operand prefilter, whose bound is the analytical one of an f32 FMA chain, must select the same units;
+            # and how close the exact K-th keys of the timed steps came to the filter thresholds (include/snk.h)
+            margin_rows, min_margin = eng.info('prefilter_margin_rows'), eng.info('prefilter_min_margin')
+            eng.set_option('prefilter', 0)
+            eng.set_weights(wt, wj)
+            p0, c0 = eng.knn_viterbi_batch(batch, K)
+            eng.set_option('prefilter', 1)
+            eng.set_weights(wt, wj)
+            out['prefilter_tripwire'] = {
+                'gpu_matches_f32_prefilter': bool(all(np.array_equal(a, b) for a, b in zip(p0, paths)) and np.array_equal(c0, costs)),
+                'prefilter_margin_rows': margin_rows, 'prefilter_min_margin': min_margin,
+                'note': 'margin = (filter threshold - exact K-th key) / assumed key error, over every row of the timed steps; '
+                        'rows below 2 would have lost a neighbour had the bf16 accumulation assumption been off by 2x'}
         if two_in_flight is not None:
             out['two_in_flight'] = two_in_flight
         if one_in_flight is not None:

@@ -300,8 +300,15 @@ int snk_concat_fragments(snk_handle h, const int64_t *first_row, const int64_t *
  *   greedy_hoist 0 / 1         target term of all steps as one float64 matrix product per utterance (default 1)
  *   greedy_hoist_max_gb        largest product kept on the device (default 48)
  *   greedy_f16 0 / 1 / 2       float16 join tiles: never / for databases streamed from HBM (default) / always
+ *   greedy_resident 0 / 1      one utterance against a database whose windowed join matrix fits the chip's LDS: the resident
+ *                              scan (greedy_res_kernels.hip; default 1)
  * infos: greedy_fallbacks, greedy_stalls, greedy_exact_windows, greedy_second_rounds, greedy_hoist_launches,
- * greedy_f16_launches, greedy_f16_delta.  The other names are listed in INTEGRATION.md. */
+ * greedy_f16_launches, greedy_f16_delta, greedy_resident_launches.  The other names are listed in INTEGRATION.md.
+ * Tripwire of the K-NN prefilter's key bound (snk_reset_timers clears it): prefilter_margin_rows = rows of prefilter K-NN
+ * calls whose exact K-th key came within 2 eps of the filter threshold (eps: the largest error the approximate keys are
+ * ASSUMED to have -- for the bf16-split operands that rests on the probed accumulation property below);
+ * prefilter_min_margin = the smallest (threshold - exact K-th key) / eps seen.  Rows at 2 or more would have kept every
+ * true neighbour even if the assumption had been off by a factor of two. */
 int snk_set_option(snk_handle h, const char *name, double value);
 int snk_get_info(snk_handle h, const char *name, double *value_out);
 /* One v_mfma_f32_32x32x16_bf16 on caller-chosen bit patterns: D = A B + C with A (32, 16) and B (16, 32) bf16 bit

@@ -667,9 +667,36 @@ void launch_mask_columns(double *Q, int64_t T, int D, const double *mask, hipStr
     if (n > 0) hipLaunchKernelGGL(mask_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Q, n, D, mask);
 }
 
+// rows wider than the sweeps take (Dpad > 256, see snk_api.hip knn_device): only the zero-padded row-major copy that
+// the canonical-distance kernels read, and the squared norm
+__global__ void prepare_queries_wide_kernel(const double *__restrict__ Q, int64_t T, int D, double *__restrict__ Qp,
+                                            double *__restrict__ qnorm, int Dpad)
+{
+    const int64_t row = blockIdx.x;
+    __shared__ double sq[256];
+    double acc = 0.0;
+    for (int c = threadIdx.x; c < Dpad; c += 256) {
+        double v = 0.0;
+        if (row < T && c < D) v = Q[row * D + c];
+        Qp[row * Dpad + c] = v;
+        acc += v * v;
+    }
+    sq[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 256; ++i) t += sq[i];
+        qnorm[row] = t;
+    }
+}
+
 void launch_prepare_queries(const double *Q, int64_t T, int D, double *Qp, double *Qf, double *qnorm,
                             int64_t Tpad, int Dpad, hipStream_t s)
 {
+    if (Dpad > 256) {
+        hipLaunchKernelGGL(prepare_queries_wide_kernel, dim3((unsigned)Tpad), dim3(256), 0, s, Q, T, D, Qp, qnorm, Dpad);
+        return;
+    }
     hipLaunchKernelGGL(prepare_queries_kernel, dim3((unsigned)Tpad), dim3(256), 0, s, Q, T, D, Qp, Qf,
                        qnorm, Tpad, Dpad);
 }
@@ -871,7 +898,8 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
                     const double *__restrict__ eps, const double *__restrict__ fnorm, double eps_c,
                     const double *__restrict__ cq,
                     int64_t *__restrict__ cand, double *__restrict__ dist,
-                    double *__restrict__ d2_out, int *__restrict__ status, int *__restrict__ rowflag)
+                    double *__restrict__ d2_out, int *__restrict__ status, int *__restrict__ rowflag,
+                    const double *__restrict__ thr, unsigned int *__restrict__ margin_stat)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int SELM = (CLASS == 1) ? FIN_SMALL : SEL_MAX;
@@ -1039,6 +1067,21 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
     }
     __syncthreads();
     bitonic_sort_pairs(ex_key, ex_idx, SP);
+    // Tripwire of the prefilter's key bound (include/snk.h: prefilter_margin_rows).  The filter kept every unit whose
+    // approximate key lay under thr = (bound of the K-th nearest key) + eps, eps being the ASSUMED largest error of an
+    // approximate key.  The exact K-th key is known now: room = thr - kth is what the keys of the true neighbours could
+    // have been off by without being dropped.  Rows with room < 2 eps are the rows whose result would have been wrong
+    // had the error assumption been violated by a factor of two; [1] keeps the smallest room / eps seen.
+    if (thr && eps && margin_stat && threadIdx.x == 0 && kk == K && n > K) {
+        const double room = thr[row] - (ex_key[K - 1] - qnorm[row]);
+        const double e = eps[row];
+        if (e > 0.0 && thr[row] < 0.5 * DBL_MAX) {
+            if (room < 2.0 * e) atomicAdd(&margin_stat[0], 1u);
+            float ratio = (float)(room / e);
+            if (!(ratio > 0.f)) ratio = 0.f;
+            atomicMin(&margin_stat[1], __float_as_uint(ratio));
+        }
+    }
     for (int j = threadIdx.x; j < K; j += blockDim.x) {
         int64_t c = -1;
         double d2 = SNK_VERY_BIG * SNK_VERY_BIG, d = SNK_VERY_BIG;
@@ -1052,7 +1095,8 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
 void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const double *wt, int Dpad, int D, const double *Qp, const double *qnorm,
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
                          int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c, const double *cq,
-                         int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s, bool split_short)
+                         int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s, bool split_short,
+                         const double *thr, unsigned int *margin_stat)
 {
     int P = 2;
     while (P < cap) P <<= 1;
@@ -1068,7 +1112,7 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
 #undef SNK_FIN_ATTR
     }
 #define SNK_FIN(C_, F_, SH_) hipLaunchKernelGGL((knn_finalize_kernel<C_, F_>), dim3((unsigned)T), dim3(256), SH_, s, Fw, F_unw, Fp, wt, Dpad, D, Qp, \
-                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag)
+                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat)
     if (split_short && K <= FIN_SMALL / 2 && cap > FIN_SMALL) {
         const size_t small = (size_t)FIN_SMALL * ((f32k ? sizeof(float) : sizeof(double)) + sizeof(int)) > (size_t)FIN_SMALL * sizeof(double)
                                  ? (size_t)FIN_SMALL * ((f32k ? sizeof(float) : sizeof(double)) + sizeof(int)) : (size_t)FIN_SMALL * sizeof(double);

@@ -253,6 +253,7 @@ struct snk_engine {
     bool bf16_ready = false;      // a16l / s16l (and gs_tiles_b) hold the bf16-split operands of the current weights
     double eps_c_bf = 4e-6;       // accumulation part of the bound of the bf16-split keys (knn16_kernels.hip: c_acc)
     DevBuf kth16;                 // sharded search: per-row second bound (K-th key of the local list, all-reduced)
+    DevBuf margin_stat;           // tripwire of the prefilter's key bound: [0] rows with room < 2 eps, [1] smallest room / eps (float bits)
     int shard_gather_queries = 1; // sharded steps: 1: every rank uploads the rows of its own utterances and the ranks exchange them, 0: every rank uploads all rows
     int shard_refine = 1;         // 1: snk_sharded_knn_viterbi_batch prunes the shards' lists to that bound before the re-rank
     DevBuf gs_tiles_b, cq16, rho16, gs_rho16;   // per-row split coefficient; dropped-piece ratios of the operands
@@ -418,6 +419,8 @@ int snk_create(int device_id, snk_handle *out)
     h->device = device_id;
     h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (h->slabctr.ensure(64)) { delete h; return 1; }
+    if (h->margin_stat.ensure(2 * sizeof(unsigned int))) { delete h; return 1; }
+    { const unsigned int init[2] = {0u, 0x7f800000u}; (void)hipMemcpy(h->margin_stat.p, init, sizeof(init), hipMemcpyHostToDevice); }
     const int rc = create_streams(h);
     if (rc) { (void)snk_destroy(h); return rc; }
     *out = h;
@@ -466,7 +469,7 @@ int snk_destroy(snk_handle h)
     h->rowflag.release(); h->exact_rows.release(); h->exact_scratch.release();
     h->frames_spec.release(); h->frames_fzv.release(); h->cc_in.release(); h->cc_out.release();
     h->res_status.release(); h->hstage.release();
-    { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b, &h->cq16, &h->rho16, &h->gs_rho16, &h->kth16};
+    { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b, &h->cq16, &h->rho16, &h->gs_rho16, &h->kth16, &h->margin_stat};
       for (auto *b : fb) b->release(); }
     for (int i = 0; i < 8; ++i) {
         UttSlot &s = h->slot[i];
@@ -518,7 +521,10 @@ int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt, const flo
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
     if (!F_unw || N < 1 || Dt < 1) return fail("snk_upload_db: bad target matrix (N=%lld Dt=%d)", (long long)N, Dt);
-    if (Dt > 256) return fail("snk_upload_db: Dt=%d > 256 columns is not supported", Dt);
+    // up to 256 columns the matrix sweeps serve the K-NN; wider rows (the doubled join rows of an epoch voice from
+    // train_halfphone as a K-NN database: 2 x 151 columns, Synthesiser.join_knn) go through the canonical-distance
+    // selection, a workgroup per query row (knn_device)
+    if (Dt > 512) return fail("snk_upload_db: Dt=%d > 512 columns is not supported", Dt);
     if (N >= (1LL << 31) - 4096) return fail("snk_upload_db: N=%lld exceeds the 31-bit unit id range", (long long)N);
     if (JC_unw && Njc != N + 1) return fail("snk_upload_db: join_contexts must have N+1 rows (got %lld, N=%lld)", (long long)Njc, (long long)N);
     h->N = N; h->Dt = Dt; h->Dpad = roundup(Dt, SNK_DPAD);
@@ -858,6 +864,36 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         if (deferred_status) HIPCHK(hipMemsetAsync(deferred_status, 0, sizeof(int), h->stream));
         return 0;
     }
+    if (h->Dpad > 256) {
+        // Rows wider than a database row's fragments fit a wavefront's registers: every row through the exact selection
+        // (knn_exact_rows_kernel: canonical distances to every unit by one workgroup per query row, radix select, ties by
+        // lowest id) -- the all-pairs join K-NN of active_learning_join.py:184-212 on 302-column join rows.  No bounds
+        // for a sharded caller (nothing is pruned), nothing deferred.
+        if (bound_out) { launch_fill_threshold(bound_out, T, T, DBL_MAX, h->stream); return 0; }
+        const int64_t Tp = roundup(T, 16);
+        CHK(h->Qp.ensure((size_t)Tp * h->Dpad * sizeof(double)));
+        CHK(h->qnorm.ensure((size_t)Tp * sizeof(double)));
+        launch_prepare_queries(Qdev, T, h->Dt, h->Qp.as<double>(), nullptr, h->qnorm.as<double>(), Tp, h->Dpad, h->stream);
+        // rows per launch: as many workgroups as the scratch (one float64 per unit and row) allows within 2 GB
+        int64_t per = ((int64_t)2 << 30) / ((int64_t)h->Nalloc * 8);
+        per = per < 1 ? 1 : per > 512 ? 512 : per;
+        CHK(h->exact_rows.ensure((size_t)per * sizeof(int)));
+        CHK(h->exact_scratch.ensure((size_t)per * h->Nalloc * sizeof(double)));
+        std::vector<int> rows((size_t)per);
+        for (int64_t r0 = 0; r0 < T; r0 += per) {
+            const int n = (int)(T - r0 < per ? T - r0 : per);
+            for (int i = 0; i < n; ++i) rows[(size_t)i] = (int)(r0 + i);
+            HIPCHK(hipMemcpyAsync(h->exact_rows.p, rows.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            launch_knn_exact_rows(h->Fw.as<double>(), h->Dpad, h->Dt, h->N, h->Qp.as<double>(), h->exact_rows.as<int>(), n, K,
+                                  h->exact_scratch.as<double>(), h->Nalloc, qclass_dev ? h->unit_class.as<int32_t>() : nullptr,
+                                  qclass_dev, h->shard_offset, cand_dev, dist_dev, d2_dev, h->stream);
+            HIPCHK(hipStreamSynchronize(h->stream));          // (the host array of row numbers is reused)
+        }
+        HIPCHK(hipGetLastError());
+        if (deferred_status) HIPCHK(hipMemsetAsync(deferred_status, 0, sizeof(int), h->stream));
+        h->last_retries = 0; h->last_T = T;
+        return 0;
+    }
     const int64_t Tpad = roundup(T, 32);
     const KnnPlan p0 = make_plan(h, K);
     const bool cls = qclass_dev != nullptr;
@@ -997,7 +1033,8 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             launch_knn_finalize(h->Fw.as<double>(), h->F_unw.as<float>(), h->Fp, h->wt.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(), h->qnorm.as<double>(), T, K,
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
                                 h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), eps_c_run, bf ? h->cq16.as<double>() : nullptr, cand_dev, dist_dev, d2_dev, status_dev, nullptr, s,
-                                bound_in != nullptr);        // a shard's lists under the shared bound are short
+                                bound_in != nullptr,         // a shard's lists under the shared bound are short
+                                bound_in ? nullptr : h->thr.as<double>(), h->margin_stat.as<unsigned int>());
         }
         if (deferred_status) return 0;       // the batch caller redoes failures with precision 0
         int status = 0;
@@ -2809,6 +2846,12 @@ int snk_reset_timers(snk_handle h)
 {
     if (!h) return fail("null handle");
     for (int i = 0; i < TM_COUNT; ++i) { h->tm_ms[i] = 0; h->tm_n[i] = 0; }
+    if (h->margin_stat.p && !h->bslot[0].busy && !h->bslot[1].busy && !h->sticket[0].busy && !h->sticket[1].busy) {
+        const unsigned int init[2] = {0u, 0x7f800000u};
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(h->margin_stat.p, init, sizeof(init), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -2942,6 +2985,16 @@ int snk_get_info(snk_handle h, const char *name, double *out)
             HIPCHK(hipMemcpy(rho, h->rho16.p, sizeof(rho), hipMemcpyDeviceToHost));
         }
         *out = sqrt(rho[name[14] == 'l' ? 0 : 1]);
+    }
+    else if (!strcmp(name, "prefilter_margin_rows") || !strcmp(name, "prefilter_min_margin")) {
+        // since the engine was created (or the last snk_reset_timers): rows of prefilter K-NN calls whose exact K-th key
+        // came within 2 eps of the filter threshold, and the smallest (threshold - exact K-th key) / eps seen
+        unsigned int v[2] = {0u, 0x7f800000u};
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(v, h->margin_stat.p, sizeof(v), hipMemcpyDeviceToHost));
+        float r; memcpy(&r, &v[1], 4);
+        *out = name[10] == 'm' && name[11] == 'a' ? (double)v[0] : (double)r;
     }
     else if (!strcmp(name, "prefilter_mfma_unit")) *out = SNK_BF16_MFMA_UNIT;
     else if (!strcmp(name, "prefilter_eps_c")) *out = (h->bf16_ready && h->prefilter >= 1) ? h->eps_c_bf : h->eps_c;

@@ -111,7 +111,8 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
                          int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c, const double *cq,
                          int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s,
-                         bool split_short = false);   // split_short: rows of at most 512 entries through the small-LDS instance
+                         bool split_short = false,    // split_short: rows of at most 512 entries through the small-LDS instance
+                         const double *thr = nullptr, unsigned int *margin_stat = nullptr);   // tripwire of the prefilter's key bound
 void launch_candidate_dist(const double *Fw, int Dpad, int D, int64_t N, const double *Qp,
                            const int64_t *cand, int64_t T, int K, double *dist, hipStream_t s);
 void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, int K,

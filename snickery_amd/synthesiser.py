@@ -332,10 +332,11 @@ class Synthesiser(object):
         unit_end_data, queried with unit_start_data) on the GPU engine.  The join matrix takes the
         place of the target database in a second engine; rows are queried in slices.
         Returns (indices (n, k) int64, distances (n, k) float64)."""
-        if self.join_contexts_unweighted.shape[1] > 256:
-            # the K-NN sweep keeps a database row's fragments in registers: 256 columns is its limit.  The doubled
-            # [j_t, j_t+1] join rows of an epoch voice from train_halfphone (2 x 151 columns) do not fit.
-            raise ValueError('join_knn: join vectors of %d columns exceed the 256 columns the K-NN engine supports'
+        if self.join_contexts_unweighted.shape[1] > 512:
+            # up to 256 columns the matrix sweeps serve the search; the doubled [j_t, j_t+1] join rows of an epoch voice
+            # from train_halfphone (2 x 151 columns) go through the engine's canonical-distance selection (snk_api.hip
+            # knn_device: a workgroup per query row) -- exact, slower; beyond 512 columns the engine refuses
+            raise ValueError('join_knn: join vectors of %d columns exceed the 512 columns the K-NN engine supports'
                              % self.join_contexts_unweighted.shape[1])
         if getattr(self, '_join_engine', None) is None:
             self._join_engine = HipSearchEngine(self.engine.device)

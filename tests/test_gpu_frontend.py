@@ -338,7 +338,44 @@ preload_all_magphase_utts = False
     oc, od = o.knn_bruteforce(F, U, 8)
     op, ocost = o.viterbi(oc, od, E, S)
     assert path == op and synth.last_path_cost == ocost
+    # the all-pairs join K-NN (initialise_join_table_with_knn, active_learning_join.py:184-212) on this voice's doubled
+    # [j_t, j_t+1] join rows: 2 x 151 = 302 columns, wider than the matrix sweeps take -- the engine's canonical-distance
+    # selection serves them; bit-exact against the oracle's brute force, natural successors first at distance 0
+    assert S.shape[1] == 302
+    n = min(S.shape[0], 300)
+    idx, dist = synth.join_knn(7, first=1, last=n)
+    oi, od2 = o.knn_bruteforce(E, S[1:n], 7)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od2)
+    assert np.all(idx[:, 0] == np.arange(1, n) - 1) and np.all(dist[:, 0] == 0.0)
     synth.close()
+
+
+def test_wide_rows_take_the_exact_selection():
+    """K-NN on rows of 257 .. 512 columns (wider than the 256 the matrix sweeps take): plain, class-restricted, more
+    query rows than one launch's scratch takes, K = 200, ties by lowest id."""
+    import snickery_amd
+    N, Dt, K = 5000, 302, 200
+    F_unw, JC_unw = o.synthetic_db(N, Dt, 8, seed=91)
+    F_unw[4000:4010] = F_unw[50:60]                      # exact duplicates: ties, the lower id first
+    rng = np.random.RandomState(92)
+    wt = 0.1 + rng.rand(Dt)
+    e = snickery_amd.HipSearchEngine(0)
+    e.upload_db(F_unw, JC_unw)
+    e.set_weights(wt, np.full(8, 0.1))
+    F = o.weight(F_unw, wt)
+    U = np.vstack([o.synthetic_targets(F_unw, 40, seed=93), F_unw[50:60].astype(np.float64)]) * wt
+    cand, dist = e.knn(U, K)
+    oc_, od_ = o.knn_bruteforce(F, U, K)
+    assert np.array_equal(cand, oc_) and np.array_equal(dist, od_)
+    assert list(cand[40:, 0]) == list(range(50, 60)) and list(cand[40:, 1]) == list(range(4000, 4010))
+    cls = rng.randint(0, 7, size=N).astype(np.int32)
+    qc = rng.randint(0, 7, size=U.shape[0]).astype(np.int32)
+    e.set_unit_classes(cls)
+    c2, d2 = e.knn_by_class(U, 30, qc)
+    oc2, od2 = o.knn_by_class(F, U, 30, cls, qc)
+    assert np.array_equal(c2, oc2) and np.array_equal(d2, od2)
+    assert e.info('f16_ready') == 0
+    e.close()
 
 
 def test_monophone_then_acoustic_matches_reference_output(tmp_path, golden, mini_voice):

@@ -279,9 +279,14 @@ def test_baseline_shapes_stay_on_the_fast_path(engine, N, Dt, Dj, T, K, U):
     engine.set_weights(wt, wj)
     utts = [synthetic_targets(F_unw, T, seed=1 + u) * wt for u in range(U)]
     before = (engine.info('f16_fallbacks'), engine.info('batch_redos'), engine.info('exact_row_fallbacks'))
+    engine.reset_timers()                           # (also the tripwire's counters)
     paths, costs = engine.knn_viterbi_batch(utts, K)
     cand, dist = engine.knn(utts[0], K)
     assert (engine.info('f16_fallbacks'), engine.info('batch_redos'), engine.info('exact_row_fallbacks')) == before
+    # tripwire of the prefilter's key bound: no row's exact K-th key came within twice the assumed key error of its
+    # filter threshold -- a 2x violation of the bf16 accumulation assumption would not have changed these results
+    assert engine.info('prefilter_margin_rows') == 0, engine.info('prefilter_min_margin')
+    assert engine.info('prefilter_min_margin') >= 2.0
     engine.set_option('precision', 0)
     try:
         engine.set_weights(wt, wj)
