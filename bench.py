@@ -103,11 +103,20 @@ def cpu_baseline(F_unw, JC_unw, wt, wj, K, sample_frames, seed, all_cores=True):
                   % (sample_frames, K, F.shape[0], t_knn, t_join, n_arcs, t_dp, t_build),
     }
     if all_cores:
-        # one forked worker per utterance (the tree and the weighted matrices are shared copy-on-write), on
-        # every core up to 32 workers, a third of an utterance each: the sample stays at about 20-30 s
-        # (64 workers x 600 frames took 142 s on a 256-thread host: the workers share its memory system)
-        P = max(1, min(os.cpu_count() or 1, 32))
-        sample_frames = max(60, sample_frames // 3)
+        # one forked worker per utterance (the tree and the weighted matrices are shared copy-on-write) on EVERY
+        # hardware thread of the host (os.cpu_count(): SURVEY 8d); the utterances are shortened with the worker count
+        # so that the sample stays at about 20-30 s (64 workers x 600 frames took 142 s on a 256-thread host: the
+        # workers share its memory system)
+        P = max(1, os.cpu_count() or 1)
+        sample_frames = max(48, sample_frames // 3 if P <= 32 else sample_frames // 6 if P <= 96 else sample_frames // 10)
+        # (a worker's pair-loop cost cache is a Python dict of frames x K^2 entries: keep all of them within a quarter
+        # of the host's free memory -- fewer workers, and the line says how many ran)
+        try:
+            with open('/proc/meminfo') as f:
+                avail = [int(l.split()[1]) * 1024 for l in f if l.startswith('MemAvailable')][0]
+            P = max(1, min(P, int(0.25 * avail / (sample_frames * K * K * 260.0 + 64e6))))
+        except (OSError, IndexError, ValueError):
+            P = min(P, 32)
         pipes, t0 = [], time.time()
         for w in range(P):
             r, wfd = os.pipe()

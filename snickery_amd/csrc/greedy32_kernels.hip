@@ -174,6 +174,12 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
 {
     const bool approx = (flags & 1) != 0;                  // search_epsilon mode
     const bool test_stall = (flags & 256) != 0;            // test hook: workgroup 0 never arrives at step 1 (the watchdog's case)
+    // cross-check mode (option greedy_fenced): every hand-off additionally bracketed by agent-scope release / acquire
+    // fences (buffer_wbl2 sc1 / buffer_inv sc1).  The default hand-off is the form "8-byte agent-scope atomics on both
+    // sides, storing wavefronts drained (s_waitcnt vmcnt(0)) before the arrival" -- measured valid on gfx950 for
+    // hipMalloc memory (MI355X_MICROARCH.md, inter-workgroup visibility), not a guarantee of the memory model; a test
+    // runs 1 000 steps in both modes and compares.
+    const bool fenced = (flags & 512) != 0;
     // optional timeline (SNK_G32_TRACE=file): 8 stamps of the 100 MHz clock per step and workgroup, steps 0 .. G32_TRACE_STEPS - 1
     auto stamp = [&](int64_t st, int k) {
         if (trace && st < G32_TRACE_STEPS && threadIdx.x == 0)
@@ -450,6 +456,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
         auto arrive_last = [&](unsigned int *cnt, unsigned int round) -> bool {
             if (tid == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                 const unsigned int b = blockIdx.x;
                 const unsigned int S1 = nb < GR_S1 ? nb : GR_S1, sl1 = b % S1, q1 = (nb - sl1 + S1 - 1) / S1;
                 bool last = false;
@@ -461,6 +468,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                         last = __hip_atomic_fetch_add(cnt + 32 * (GR_S1 + GR_S2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                == round * S2 - 1;
                 }
+                if (fenced && last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                 is_last = last;
             }
             __syncthreads();
@@ -589,6 +597,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
         // written) and builds the next table itself.  An undecidable step ends the launch through the generation word.
         unsigned long long stat_rounds = 0, stat_windows = 0;
         auto finalize = [&](const int64_t (&winner)[UB], bool undecided) {
+            if (fenced && tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             if (undecided) {
                 if (tid == 0) {
                     __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -843,6 +852,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                if (fenced) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                 gen_seen = seen;
             }
             __syncthreads();

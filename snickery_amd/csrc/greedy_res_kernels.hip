@@ -82,6 +82,7 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
 {
     const bool approx = (flags & 1) != 0;
     const bool test_stall = (flags & 256) != 0;
+    const bool fenced = (flags & 512) != 0;              // cross-check mode: release / acquire fences around the hand-off (greedy32_kernels.hip)
     extern __shared__ __align__(16) char lds[];
     f32x4 *const xs = reinterpret_cast<f32x4 *>(lds);                           // [JQ4][256]
     f32x4 *const tw = reinterpret_cast<f32x4 *>(lds + (size_t)JQ4 * GRES_T * 16);    // [JQ4] weights (float32)
@@ -197,6 +198,7 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                 const unsigned long long ga = (unsigned long long)v1 | ((unsigned long long)a1 << 32) | ((unsigned long long)a2 << 40) |
                                               ((unsigned long long)tag << 48);
                 const unsigned long long gb = (unsigned long long)v2 | ((unsigned long long)(v3 >> 16) << 32) | ((unsigned long long)tag << 48);
+                if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                 __hip_atomic_store(&rec[blockIdx.x].a, ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&rec[blockIdx.x].b, gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -230,6 +232,7 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
+            if (fenced) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             int64_t winner = -1;
             if (state == 0) {
                 // ---- the decision, the same in every workgroup ----

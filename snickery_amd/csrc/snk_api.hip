@@ -269,6 +269,7 @@ struct snk_engine {
     DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist, gsync, gtiles;
     DevBuf g32_blk, g32_ctl;          // float32 persistent scan: block records + candidate lists, {gen, status}
     DevBuf g32_res;                   // resident scan (greedy_res_kernels.hip): one 16-byte record per workgroup
+    int greedy_fenced = 0;            // 1: cross-check mode of the one-launch scans: agent-scope fences around every hand-off
     int greedy_resident = 1;          // 1: one utterance against a database that fits the chip's LDS takes the resident scan
     int64_t greedy_resident_launches = 0;
     // hoisted target term of the float32 scan (greedy_hoist_kernels.hip): window norms (per database, layout and
@@ -1853,11 +1854,11 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
         CHK(h->g32_res.ensure(greedy_res_record_bytes(g) + 256));
         launch_greedy_res(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
                           h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), q_off[0], ns[0], oo[0], st[0],
-                          (approx ? 1 : 0) | (h->greedy_test_stall ? 256 : 0), h->g32_res.p, status, h->gpath.as<int64_t>(), &hst, h->stream);
+                          (approx ? 1 : 0) | (h->greedy_test_stall ? 256 : 0) | (h->greedy_fenced ? 512 : 0), h->g32_res.p, status, h->gpath.as<int64_t>(), &hst, h->stream);
         h->greedy_resident_launches += 1;
     } else
     launch_greedy32(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
-                    h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nu, q_off, ns, oo, st, (approx ? 1 : 0) | (h->greedy_test_stall ? 256 : 0),
+                    h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nu, q_off, ns, oo, st, (approx ? 1 : 0) | (h->greedy_test_stall ? 256 : 0) | (h->greedy_fenced ? 512 : 0),
                     h->g32_blk.p, h->n_cus, h->gsync.as<unsigned int>(), gen,
                     status, h->gpath.as<int64_t>(), hoist ? &hst : nullptr, h->stream);
     HIPCHK(hipGetLastError());
@@ -2892,6 +2893,8 @@ int snk_set_option(snk_handle h, const char *name, double value)
         h->greedy_f16 = (int)value;
     } else if (!strcmp(name, "greedy_test_stall")) {
         h->greedy_test_stall = value != 0.0;
+    } else if (!strcmp(name, "greedy_fenced")) {
+        h->greedy_fenced = value != 0.0;
     } else if (!strcmp(name, "greedy_resident")) {
         if (value != 0.0 && value != 1.0) return fail("greedy_resident must be 0 or 1");
         h->greedy_resident = (int)value;

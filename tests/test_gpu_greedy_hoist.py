@@ -258,3 +258,28 @@ def test_resident_scan_equals_oracle_and_streamed_scan(engine, N, me, lfat, mode
     assert len(path) == len(op)
     # (the (1 + eps) contract itself is checked step by step in test_gpu_greedy32.py::test_search_epsilon_contract, which
     # runs through this scan as well: one utterance, 30 000 units)
+
+
+@pytest.mark.parametrize('resident', [1, 0])
+def test_one_launch_hand_off_equals_the_fenced_variant_over_1000_steps(engine, resident):
+    """The hand-off between the steps of the one-launch scans is '8-byte agent-scope atomics on both sides, storing
+    wavefronts drained before the arrival' -- valid on gfx950 for hipMalloc memory by measurement, not by the memory
+    model.  Cross-check: 1 000 steps of a B1-sized voice, under uneven load (a second engine keeps
+    the chip busy beside it), with and without agent-scope release / acquire fences around every hand-off, and against
+    the C oracle."""
+    import snickery_amd
+    N, Dt, Dj, me = 65536, 61, 151, 1
+    engine.set_option('greedy_mode', 2); engine.set_option('greedy_hoist', 1); engine.set_option('greedy_resident', resident)
+    F_unw, JC_unw, wt, wj = _setup(engine, N, Dt, Dj, seed=11, me=me, lfat=False, mode=0)
+    U = o.synthetic_targets(F_unw, 1000, seed=12) * wt
+    op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, U, me, False, 0, -1)
+    s0 = engine.info('greedy_stalls')
+    try:
+        path, d = engine.greedy(U, return_distances=True)
+        engine.set_option('greedy_fenced', 1)
+        pathf, df = engine.greedy(U, return_distances=True)
+    finally:
+        engine.set_option('greedy_fenced', 0); engine.set_option('greedy_resident', 1)
+    assert path == op and np.array_equal(d, od)
+    assert pathf == op and np.array_equal(df, od)
+    assert engine.info('greedy_stalls') == s0
