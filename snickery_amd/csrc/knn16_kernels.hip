@@ -614,7 +614,8 @@ void launch_db16b_ratios(const double *Fw, int64_t N, int Dt, int Dpad, double *
 //     eps = cq Fmax + c_acc (2 ||q|| Fmax + Fmax^2)                  (c_acc: accumulation + the norm pieces' 2^-24)
 __global__ void prepare_queries16b_kernel(const double *__restrict__ Qp, const double *__restrict__ qnorm, int64_t T,
                                           int Dt, int Dpad, const double *__restrict__ fmax2, const double *__restrict__ rho,
-                                          double c_acc, u32x4 *__restrict__ B16, double *__restrict__ eps, double *__restrict__ cq)
+                                          double c_acc, u32x4 *__restrict__ B16, double *__restrict__ eps, double *__restrict__ cq,
+                                          double c_coarse, double *__restrict__ e1)
 {
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -658,15 +659,19 @@ __global__ void prepare_queries16b_kernel(const double *__restrict__ Qp, const d
         const double qn = (row < T) ? sqrt(qnorm[row]) * up : 0.0;
         eps[row] = c * fm + c_acc * (2.0 * qn * fm + fm * fm) + 1e-30;
         cq[row] = c;
+        // coarse pass (knn_coarse16b: the hi.hi term alone): its key differs from the three-term key by the two cross
+        // terms, |ah.fl + al.fh| <= (||ah|| rho_L + ||al|| (1 + 2^-8)) ||f||, and by the two accumulation errors
+        if (e1) e1[row] = (nah * sqrt(rho[0]) * up + nal * 1.00390625) * fm * up + c_coarse * (2.0 * qn * fm + fm * fm) + 1e-30;
     }
 }
 
 void launch_prepare_queries16b(const double *Qp, const double *qnorm, int64_t T, int Dt, int Dpad, const double *fmax2,
-                               const double *rho, double c_acc, void *B16, double *eps, double *cq, hipStream_t s)
+                               const double *rho, double c_acc, void *B16, double *eps, double *cq, hipStream_t s,
+                               double c_coarse, double *e1)
 {
     const int64_t items = ((T + 31) / 32) * (Dpad / 16);
     hipLaunchKernelGGL(prepare_queries16b_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, Qp, qnorm, T, Dt,
-                       Dpad, fmax2, rho, c_acc, reinterpret_cast<u32x4 *>(B16), eps, cq);
+                       Dpad, fmax2, rho, c_acc, reinterpret_cast<u32x4 *>(B16), eps, cq, c_coarse, e1);
 }
 
 // The sweep: structure of knn_sweep16 (DB-stationary, persistent wavefronts, results of the previous step tested
@@ -921,6 +926,325 @@ bool launch_knn_sweep16b(int mode, int terms, int nt, int dch, int grid_cus, con
     return false;
 }
 
+
+// ===========================================================================================================
+// Two-pass filter on the bf16-split operands (prefilter 3, the default where the shape has a variant).
+//
+// Of the three MFMA terms of a product the hi.hi term alone already tells, for almost every (32 database rows) x
+// (32 query rows) tile, that nothing in it can pass: the cross terms move a key by at most e1 = (||ah|| rho_L +
+// ||al||) ||f|| (+ the accumulation terms) -- a few 10^-3 of ||q|| ||f||, far less than what separates an
+// average unit from the K-th nearest one.  So:
+//   pass 1, knn_coarse16b: the sweep of knn_sweep16b with the hi pieces only -- a third of the MFMAs, half the
+//     query bytes, the database's hi pieces of EIGHT tiles resident per wavefront (the registers the lo pieces took) --
+//     tests min(tile) <= thr32 + e1 per query column and emits the (database tile, query tile) pairs that pass:
+//     8 bytes per pair instead of 16 per surviving unit;
+//   pass 2, knn_refine16b: the three-term keys of the listed tile pairs only, in knn_sweep16b's own MFMA order
+//     (the probed accumulation bound applies unchanged), tested against thr32; survivors go to the entry pool.
+// The set of survivors is the one knn_sweep16b<mode 1> writes: whatever passes there passes the coarse test.
+// ===========================================================================================================
+struct CoarsePair { unsigned int tile, qtile; };
+
+template <int NTC, int KB>
+__global__ void __launch_bounds__(256, 1)
+knn_coarse16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const float *__restrict__ thr1, int nQT,
+              int64_t n_tiles, int64_t n_slabs, unsigned int *__restrict__ slab_counter, int qsplit, int64_t n_main_slabs,
+              int qsplit_tail, CoarsePair *__restrict__ pairs, unsigned int *__restrict__ pair_ctl, unsigned int pair_cap)
+{
+    constexpr int CH = 4;                              // independent MFMA chains per step
+    constexpr int NSTEP = NTC / CH;
+    static_assert(NSTEP == 2 || NSTEP == 1, "two accumulator sets alternate per step");
+    __shared__ CoarsePair pstage[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int qcol = lane & 31;
+    int pcount = 0;
+    auto grab = [&]() -> int64_t {
+        unsigned int v = 0;
+        if (lane == 0) v = atomicAdd(slab_counter, 1u);
+        return (int64_t)__builtin_amdgcn_readfirstlane(v);
+    };
+    auto flush_pairs = [&]() {
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(&pair_ctl[0], (unsigned int)pcount);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < pcount) {
+            if (base + (unsigned int)lane < pair_cap) pairs[base + lane] = pstage[wv][lane];
+            else pair_ctl[1] = 1u;                     // the list is full: the caller's other path serves the call
+        }
+        pcount = 0;
+    };
+    auto emit = [&](unsigned int tile, unsigned int qtile) {
+        if (lane == 0) pstage[wv][pcount] = CoarsePair{tile, qtile};
+        if (++pcount == 64) flush_pairs();
+    };
+    auto mfma = [](const u32x4 &a, const u32x4 &b, f16acc c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+
+    const int64_t n_main_items = n_main_slabs * qsplit;
+    const int64_t n_items = n_main_items + (n_slabs - n_main_slabs) * qsplit_tail;
+    int64_t item = grab();
+    while (item < n_items) {
+        const int64_t item_next = grab();
+        const bool tail = item >= n_main_items;
+        const int qs = tail ? qsplit_tail : qsplit;
+        const int64_t rel = tail ? item - n_main_items : item;
+        const int64_t w = (tail ? n_main_slabs : 0) + rel / qs;
+        const int part = (int)(rel % qs);
+        const int qt_lo = (int)(((int64_t)nQT * part) / qs);
+        const int qt_hi = (int)(((int64_t)nQT * (part + 1)) / qs);
+        const int n_t = qt_hi - qt_lo;
+
+        // hi pieces of this slab's database tiles: resident in registers (tiles past the operand repeat the last one
+        // and are never reported)
+        u32x4 ah[NTC][KB];
+        const int64_t tile0 = w * NTC;
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) {
+            const int64_t t = tile0 + nt < n_tiles ? tile0 + nt : n_tiles - 1;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) ah[nt][kb] = A16[((t * KB + kb) * 2 + 0) * 64 + lane];
+        }
+        const int n_valid = (int)(n_tiles - tile0 < NTC ? n_tiles - tile0 : NTC);
+
+        // query tiles: hi pieces and the coarse threshold of this lane's query column, three buffers (two tiles ahead)
+        u32x4 xq[3][KB];
+        float thq[3];
+        auto load_q = [&](int t, u32x4 (&x)[KB], float &th) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) x[kb] = B16[(((int64_t)t * KB + kb) * 2 + 0) * 64 + lane];
+            th = thr1[t * 32 + qcol];
+        };
+        auto next_q = [&](int t) { return t + 1 == qt_hi ? qt_lo : t + 1; };
+        int qt = qt_lo + (int)((w * 3) % n_t);
+        int qt1 = next_q(qt), qt2 = next_q(qt1);
+        load_q(qt, xq[0], thq[0]);
+        load_q(qt1, xq[1], thq[1]);
+
+        f16acc S0[CH], S1[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { S0[j][r] = FLT_MAX; S1[j][r] = FLT_MAX; }
+        float th_prev = -FLT_MAX;
+        int qt_prev = qt;
+
+        // one pending result: the smallest of the 16 rows this lane holds of database tile pt against its query column
+        auto test = [&](const f16acc &res, int pt, float pth, int pq) {
+            float m;
+            asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(res[0]), "v"(res[1]), "v"(res[2]));
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(res[3]), "v"(res[4]));
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(res[5]), "v"(res[6]));
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(res[7]), "v"(res[8]));
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(res[9]), "v"(res[10]));
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(res[11]), "v"(res[12]));
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(res[13]), "v"(res[14]));
+            asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(res[15]));
+            if (__any(m <= pth) && pt < n_valid) emit((unsigned int)(tile0 + pt), (unsigned int)pq);
+        };
+        // one step: CH database tiles (first: t0) against the query tile in x into `cur`; the CH results in `prev`
+        // (database tiles from pt0 of query tile pq, threshold pth) are tested in the MFMA shadows
+        auto step = [&](f16acc (&cur)[CH], const f16acc (&prev)[CH], int t0, const u32x4 (&x)[KB], int pt0, float pth, int pq) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    if (kb == 0) {
+                        f16acc z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                        cur[j] = mfma(ah[t0 + j][kb], x[kb], z);
+                    } else cur[j] = mfma(ah[t0 + j][kb], x[kb], cur[j]);
+                }
+                if (kb < CH) test(prev[kb], pt0 + kb, pth, pq);
+            }
+            if (KB < CH) {
+#pragma unroll
+                for (int j = KB; j < CH; ++j) test(prev[j], pt0 + j, pth, pq);
+            }
+        };
+        auto tile_body = [&](u32x4 (&x)[KB], float th, u32x4 (&xload)[KB], float &thload, int t_load) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(x[kb]));
+            load_q(t_load, xload, thload);               // two tiles ahead
+            if (NSTEP == 2) {
+                step(S0, S1, 0, x, CH, th_prev, qt_prev);   // tests the second half of the previous query tile
+                step(S1, S0, CH, x, 0, th, qt);             // ... the first half of this one
+            } else {
+                step(S0, S1, 0, x, 0, th_prev, qt_prev);
+#pragma unroll
+                for (int j = 0; j < CH; ++j) S1[j] = S0[j];
+            }
+            th_prev = th;
+            qt_prev = qt;
+            qt = qt1; qt1 = qt2; qt2 = next_q(qt2);
+        };
+        for (int it = 0; it < n_t; it += 3) {
+            tile_body(xq[0], thq[0], xq[2], thq[2], qt2);
+            if (it + 1 < n_t) tile_body(xq[1], thq[1], xq[0], thq[0], qt2);
+            if (it + 2 < n_t) tile_body(xq[2], thq[2], xq[1], thq[1], qt2);
+        }
+        // drain: the last step's results
+#pragma unroll
+        for (int j = 0; j < CH; ++j) test(S1[j], (NSTEP - 1) * CH + j, th_prev, qt_prev);
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S1[j][r] = FLT_MAX;
+        item = item_next;
+    }
+    if (pcount) flush_pairs();
+}
+
+// pass 2: the three-term keys of the listed tile pairs, tested against thr32; survivors to the entry pool
+template <int KB, int TERMS>
+__global__ void __launch_bounds__(256, (KB <= 4 ? 2 : 1))        // two operand sets of wider rows need the whole register file
+knn_refine16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const float *__restrict__ thr32,
+              const CoarsePair *__restrict__ pairs, const unsigned int *__restrict__ pair_ctl, unsigned int pair_cap,
+              PoolEntry16 *__restrict__ pool, unsigned int *__restrict__ pool_ctl, int *__restrict__ chunk_fill, int max_chunks,
+              int pool_chunk)
+{
+    constexpr int STAGE_CAP = 1024 + 64;
+    __shared__ PoolEntry16 stage[4][STAGE_CAP];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int qcol = lane & 31;
+    unsigned int n_pairs = pair_ctl[0];
+    if (n_pairs > pair_cap) { n_pairs = pair_cap; if (threadIdx.x == 0 && blockIdx.x == 0) pool_ctl[1] = 1u; }   // list overflow: status bit 4
+    int chunk_id = -1, cused = pool_chunk, lcount = 0;
+    auto new_chunk = [&]() {
+        if (chunk_id >= 0 && lane == 0) chunk_fill[chunk_id] = cused;
+        unsigned int c = 0;
+        if (lane == 0) c = atomicAdd(&pool_ctl[0], 1u);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if ((int)c >= max_chunks) { if (lane == 0) pool_ctl[1] = 1u; chunk_id = -1; }
+        else chunk_id = (int)c;
+        cused = 0;
+    };
+    auto flush_stage = [&]() {
+        if (cused + lcount > pool_chunk) new_chunk();
+        if (chunk_id >= 0)
+            for (int e = lane; e < lcount; e += 64)
+                pool[(int64_t)chunk_id * pool_chunk + cused + e] = stage[wv][e];
+        cused += lcount;
+        lcount = 0;
+    };
+    auto mfma = [](const u32x4 &a, const u32x4 &b, f16acc c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+    const unsigned int wave_id = blockIdx.x * 4u + (unsigned int)wv, wave_stride = gridDim.x * 4u;
+    // operands of a pair: database tile (hi, lo), query tile (hi, lo); the next pair's are requested before this
+    // one's arithmetic
+    u32x4 a0[KB][2], b0[KB][2], a1[KB][2], b1[KB][2];
+    float th0 = 0.f, th1 = 0.f;
+    CoarsePair p0{0u, 0u}, p1{0u, 0u};
+    auto load_pair = [&](unsigned int i, CoarsePair &pr, u32x4 (&a)[KB][2], u32x4 (&b)[KB][2], float &th) {
+        const unsigned int k = i < n_pairs ? i : n_pairs - 1u;
+        pr = pairs[k];
+        pr.tile = __builtin_amdgcn_readfirstlane(pr.tile); pr.qtile = __builtin_amdgcn_readfirstlane(pr.qtile);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                a[kb][pc] = A16[(((int64_t)pr.tile * KB + kb) * 2 + pc) * 64 + lane];
+                b[kb][pc] = B16[(((int64_t)pr.qtile * KB + kb) * 2 + pc) * 64 + lane];
+            }
+        th = thr32[pr.qtile * 32u + (unsigned int)qcol];
+    };
+    auto work = [&](const CoarsePair &pr, const u32x4 (&a)[KB][2], const u32x4 (&b)[KB][2], float pth) {
+        // knn_sweep16b's order: per k-block hi.hi, hi(db).lo(query), lo(db).hi(query) [, lo.lo]; chains of one 64-column
+        // chunk (4 TERMS MFMAs through C), the chunks' sums added in float32
+        constexpr int CM = 4 * TERMS, NM = TERMS * KB;
+        f16acc acc, part;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int kb = m / TERMS, term = m % TERMS;
+            const u32x4 &av = (term & 2) ? a[kb][1] : a[kb][0];
+            const u32x4 &bv = (term & 1) ? b[kb][1] : b[kb][0];
+            if (m % CM == 0) {
+                f16acc z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                part = mfma(av, bv, z);
+            } else part = mfma(av, bv, part);
+            if (m % CM == CM - 1 || m == NM - 1) {
+                if (m < CM) acc = part;
+                else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] += part[r];
+                }
+            }
+        }
+        if (lcount > STAGE_CAP - 1024) flush_stage();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float key = acc[r];
+            const bool pass = key <= pth;
+            const unsigned long long mm = __ballot(pass);
+            if (mm) {
+                if (pass) {
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
+                    PoolEntry16 en;
+                    en.key = (double)key;
+                    en.idx = (int)(pr.tile * 32u) + crow32(lane, r);
+                    en.row = (int)(pr.qtile * 32u) + qcol;
+                    stage[wv][lcount + rank] = en;
+                }
+                lcount += __popcll(mm);
+            }
+        }
+    };
+    if (wave_id < n_pairs) {
+        load_pair(wave_id, p0, a0, b0, th0);
+        for (unsigned int i = wave_id; i < n_pairs; i += 2u * wave_stride) {
+            load_pair(i + wave_stride, p1, a1, b1, th1);
+            work(p0, a0, b0, th0);
+            if (i + wave_stride < n_pairs) {
+                load_pair(i + 2u * wave_stride, p0, a0, b0, th0);
+                work(p1, a1, b1, th1);
+            }
+        }
+    }
+    if (lcount) flush_stage();
+    if (chunk_id >= 0 && lane == 0) chunk_fill[chunk_id] = cused;
+}
+
+bool knn_coarse16b_supported(int nt, int dch) { return (nt == 4 && dch == 1) || (nt == 2 && dch == 2) || (nt == 1 && dch == 3); }
+size_t knn_coarse_pair_bytes() { return sizeof(CoarsePair); }
+
+// pass 1 + pass 2 on stream s.  n_tiles: 32-row tiles of the database operand; pair_ctl: two device words (count, overflow),
+// zeroed by the caller (knn_reset)
+bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32, const float *thr1,
+                          int64_t T32, int64_t n_tiles, unsigned int *ctr, void *pairs, unsigned int *pair_ctl, unsigned int pair_cap,
+                          void *pool, unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s)
+{
+    const int nQT = (int)(T32 / 32);
+    const int ntc = dch == 1 ? 8 : dch == 2 ? 4 : 4;          // hi pieces of 32 (dch 3: 48) k-blocks resident per wavefront
+    const int64_t n_slabs = (n_tiles + ntc - 1) / ntc;
+    const int64_t max_blocks = grid_cus;
+    int qsplit = 1;
+    while (n_slabs * qsplit < 2 * 4 * max_blocks && qsplit * 2 <= nQT && qsplit < 8) qsplit *= 2;
+    int64_t blocks = (n_slabs * qsplit + 3) / 4;
+    if (blocks > max_blocks) blocks = max_blocks;
+    int64_t n_main = n_slabs;
+    int qtail = qsplit;
+    sweep_tail_split(n_slabs, qsplit, blocks * 4, nQT, &n_main, &qtail);
+#define SNK_C16(NTC_, KB_)                                                                                          \
+    hipLaunchKernelGGL((knn_coarse16b<NTC_, KB_>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)A16,     \
+                       (const u32x4 *)B16, thr1, nQT, n_tiles, n_slabs, ctr, qsplit, n_main, qtail,                 \
+                       (CoarsePair *)pairs, pair_ctl, pair_cap)
+#define SNK_R16(KB_, TERMS_)                                                                                        \
+    hipLaunchKernelGGL((knn_refine16b<KB_, TERMS_>), dim3((unsigned)((KB_ <= 4 ? 2 : 1) * grid_cus)), dim3(256), 0, s, \
+                       (const u32x4 *)A16, (const u32x4 *)B16, thr32, (const CoarsePair *)pairs, pair_ctl, pair_cap, \
+                       (PoolEntry16 *)pool, pool_ctl, chunk_fill, max_chunks, pool_chunk)
+    if (dch == 1) { SNK_C16(8, 4); if (terms == 4) SNK_R16(4, 4); else SNK_R16(4, 3); return true; }
+    if (dch == 2) { SNK_C16(4, 8); if (terms == 4) SNK_R16(8, 4); else SNK_R16(8, 3); return true; }
+    if (dch == 3) { SNK_C16(4, 12); if (terms == 4) SNK_R16(12, 4); else SNK_R16(12, 3); return true; }
+#undef SNK_C16
+#undef SNK_R16
+    return false;
+}
+
 #define THR16_GROUPS 1024
 // ---------------------------------------------------------------------------
 // threshold from the f32 group minima: K-th smallest of G values + eps_t, as f32 rounded UP.
@@ -933,11 +1257,12 @@ bool launch_knn_sweep16b(int mode, int terms, int nt, int dch, int grid_cus, con
 __global__ void __launch_bounds__(256)
 knn_threshold16_kernel(const float *__restrict__ gmin32, int64_t G, int64_t T, int64_t T32, int K,
                        const double *__restrict__ eps, double *__restrict__ thr, float *__restrict__ thr32,
-                       const double *__restrict__ bound_in, double *__restrict__ bound_out)
+                       const double *__restrict__ bound_in, double *__restrict__ bound_out,
+                       const double *__restrict__ e1, float *__restrict__ thr1)
 {
     extern __shared__ float tkey[];
     const int64_t row = blockIdx.x;
-    if (row >= T) { if (threadIdx.x == 0) { thr32[row] = -FLT_MAX; thr[row] = -DBL_MAX; } return; }
+    if (row >= T) { if (threadIdx.x == 0) { thr32[row] = -FLT_MAX; thr[row] = -DBL_MAX; if (thr1) thr1[row] = -FLT_MAX; } return; }
     double bound = DBL_MAX;
     if (bound_in) {
         bound = bound_in[row];
@@ -1016,17 +1341,27 @@ knn_threshold16_kernel(const float *__restrict__ gmin32, int64_t G, int64_t T, i
         }
         thr[row] = v;
         thr32[row] = v32;
+        if (thr1) {
+            // the coarse pass's threshold: whatever the three-term key would pass (key3 <= thr32) passes here
+            float t1 = FLT_MAX;
+            if (v32 < FLT_MAX) {
+                const double w = (double)v32 + e1[row];
+                if (w < (double)FLT_MAX) { t1 = (float)w; if ((double)t1 < w) t1 = nextafterf(t1, FLT_MAX); }
+            }
+            thr1[row] = t1;
+        }
         if (bound_out) bound_out[row] = bound;
     }
 }
 
 void launch_knn_threshold16(const float *gmin32, int64_t G, int64_t T, int64_t T32, int K, const double *eps,
-                            double *thr, float *thr32, const double *bound_in, double *bound_out, hipStream_t s)
+                            double *thr, float *thr32, const double *bound_in, double *bound_out, hipStream_t s,
+                            const double *e1, float *thr1)
 {
     int P = 2;
     while (P < G && P < THR16_GROUPS) P <<= 1;
     hipLaunchKernelGGL(knn_threshold16_kernel, dim3((unsigned)T32), dim3(256), (size_t)P * sizeof(float), s,
-                       gmin32, G, T, T32, K, eps, thr, thr32, bound_in, bound_out);
+                       gmin32, G, T, T32, K, eps, thr, thr32, bound_in, bound_out, e1, thr1);
 }
 
 // ---------------------------------------------------------------------------

@@ -253,6 +253,8 @@ struct snk_engine {
     bool bf16_ready = false;      // a16l / s16l (and gs_tiles_b) hold the bf16-split operands of the current weights
     double eps_c_bf = 4e-6;       // accumulation part of the bound of the bf16-split keys (knn16_kernels.hip: c_acc)
     DevBuf kth16;                 // sharded search: per-row second bound (K-th key of the local list, all-reduced)
+    DevBuf e1_16, thr1_32, cpairs, cpairctl;   // two-pass filter: per-row coarse margin and threshold, (tile, query tile) pair list
+    int prefilter_two_pass = 1;   // 1: bf16-split filter as hi.hi sweep + three-term keys of the tile pairs it lets through (default)
     DevBuf margin_stat;           // tripwire of the prefilter's key bound: [0] rows with room < 2 eps, [1] smallest room / eps (float bits)
     int shard_gather_queries = 1; // sharded steps: 1: every rank uploads the rows of its own utterances and the ranks exchange them, 0: every rank uploads all rows
     int shard_refine = 1;         // 1: snk_sharded_knn_viterbi_batch prunes the shards' lists to that bound before the re-rank
@@ -470,7 +472,7 @@ int snk_destroy(snk_handle h)
     h->rowflag.release(); h->exact_rows.release(); h->exact_scratch.release();
     h->frames_spec.release(); h->frames_fzv.release(); h->cc_in.release(); h->cc_out.release();
     h->res_status.release(); h->hstage.release();
-    { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b, &h->cq16, &h->rho16, &h->gs_rho16, &h->kth16, &h->margin_stat};
+    { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b, &h->cq16, &h->rho16, &h->gs_rho16, &h->kth16, &h->margin_stat, &h->e1_16, &h->thr1_32, &h->cpairs, &h->cpairctl};
       for (auto *b : fb) b->release(); }
     for (int i = 0; i < 8; ++i) {
         UttSlot &s = h->slot[i];
@@ -967,6 +969,24 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         }
         const bool bf = h->bf16_ready && h->prefilter >= 1 && !cls && nt_run == h->nt16_eff;
         const double eps_c_run = bf ? h->eps_c_bf : h->eps_c;
+        // two-pass filter (knn16_kernels.hip): not for stage-A-only calls
+        const bool coarse = bf && h->prefilter_two_pass && !bound_out && knn_coarse16b_supported(nt_run, dch16);
+        const int64_t n_tiles_b = n_slabs_b * nt_run;
+        unsigned int pair_cap = 0;
+        if (coarse) {
+            const int64_t all = (Tpad / 32) * n_tiles_b;
+            int64_t capp = all / 4 > ((int64_t)4 << 20) ? all / 4 : ((int64_t)4 << 20);
+            if (capp > all) capp = all;
+            if (capp > ((int64_t)1 << 31) - 1) capp = ((int64_t)1 << 31) - 1;
+            pair_cap = (unsigned int)capp;
+            CHK(h->cpairs.ensure((size_t)pair_cap * knn_coarse_pair_bytes()));
+            CHK(h->cpairctl.ensure(2 * sizeof(unsigned int)));
+            CHK(h->e1_16.ensure((size_t)Tpad * sizeof(double)));
+            CHK(h->thr1_32.ensure((size_t)Tpad * sizeof(float)));
+            HIPCHK(hipMemsetAsync(h->cpairctl.p, 0, 2 * sizeof(unsigned int), s));
+        }
+        // accumulation of the coarse pass's own chain (one MFMA per k-block through C) on top of the three-term chain's
+        const double c_coarse = eps_c_run + 1.02 * SNK_BF16_MFMA_UNIT * (double)(h->Dpad / 16 + 1);
         CHK((bf ? h->b16l : h->b16h).ensure((size_t)(Tpad / 32) * 8 * 64 * 16 * (h->Dpad / 64)));
         CHK(h->eps16.ensure((size_t)Tpad * sizeof(double)));
         if (bf) CHK(h->cq16.ensure((size_t)Tpad * sizeof(double)));
@@ -980,7 +1000,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
                 launch_prepare_queries16b(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad,
                                           use_gs ? h->gs_fmax2.as<double>() : h->fmax2.as<double>(),
                                           use_gs ? h->gs_rho16.as<double>() : h->rho16.as<double>(), eps_c_run, h->b16l.p,
-                                          h->eps16.as<double>(), h->cq16.as<double>(), s);
+                                          h->eps16.as<double>(), h->cq16.as<double>(), s, c_coarse, coarse ? h->e1_16.as<double>() : nullptr);
             else
             launch_prepare_queries16(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad,
                                      use_gs ? h->gs_fmax2.as<double>() : h->fmax2.as<double>(), h->eps_c, h->b16h.p,
@@ -1000,12 +1020,17 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         {
             StageTimer t(h, s, TM_KNN_THRESHOLD);
             launch_knn_threshold16(h->gmin32.as<float>(), G16, T, Tpad, K, h->eps16.as<double>(), h->thr.as<double>(),
-                                   h->thr32.as<float>(), bound_in, bound_out, s);
+                                   h->thr32.as<float>(), bound_in, bound_out, s, coarse ? h->e1_16.as<double>() : nullptr,
+                                   coarse ? h->thr1_32.as<float>() : nullptr);
         }
         if (bound_out) return 0;             // stage A only
         {
             StageTimer t(h, s, TM_KNN_FILTER);
-            if (bf)
+            if (coarse)
+                launch_knn_filter16c(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, h->thr32.as<float>(), h->thr1_32.as<float>(),
+                                     Tpad, n_tiles_b, h->slabctr.as<unsigned int>() + 1, h->cpairs.p, h->cpairctl.as<unsigned int>(), pair_cap,
+                                     h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, knn_pool_chunk_entries(), s);
+            else if (bf)
                 launch_knn_sweep16b(1, h->prefilter == 2 ? 4 : 3, nt_run, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, h->thr32.as<float>(), Tpad, n_slabs_b,
                                     h->slabctr.as<unsigned int>() + 1, nullptr, 0, h->pool.p, h->poolctl.as<unsigned int>(),
                                     h->chunkfill.as<int>(), max_chunks, knn_pool_chunk_entries(), s);
@@ -2882,6 +2907,10 @@ int snk_set_option(snk_handle h, const char *name, double value)
         CHK(no_batch_in_flight(h, "snk_set_option(prefilter)"));
         h->prefilter = (int)value;
         h->have_weights = false;          // the bf16 operands are built by set_weights
+    } else if (!strcmp(name, "prefilter_two_pass")) {
+        if (value != 0.0 && value != 1.0) return fail("prefilter_two_pass must be 0 or 1");
+        CHK(no_batch_in_flight(h, "snk_set_option(prefilter_two_pass)"));
+        h->prefilter_two_pass = (int)value;
     } else if (!strcmp(name, "reserved_cus")) {
         if (value < 0 || value > 64) return fail("reserved_cus must be in 0..64");
         h->reserved_cus = (int)value;
@@ -2998,6 +3027,13 @@ int snk_get_info(snk_handle h, const char *name, double *out)
         HIPCHK(hipMemcpy(v, h->margin_stat.p, sizeof(v), hipMemcpyDeviceToHost));
         float r; memcpy(&r, &v[1], 4);
         *out = name[10] == 'm' && name[11] == 'a' ? (double)v[0] : (double)r;
+    }
+    else if (!strcmp(name, "prefilter_two_pass")) *out = h->prefilter_two_pass;
+    else if (!strcmp(name, "coarse_pairs") || !strcmp(name, "coarse_pair_overflow")) {
+        // tile pairs the coarse pass of the most recent two-pass filter let through (debug / tuning aid)
+        unsigned int v[2] = {0u, 0u};
+        if (h->cpairctl.p) { HIPCHK(hipSetDevice(h->device)); HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(hipMemcpy(v, h->cpairctl.p, sizeof(v), hipMemcpyDeviceToHost)); }
+        *out = (double)v[name[11] == 's' ? 0 : 1];
     }
     else if (!strcmp(name, "prefilter_mfma_unit")) *out = SNK_BF16_MFMA_UNIT;
     else if (!strcmp(name, "prefilter_eps_c")) *out = (h->bf16_ready && h->prefilter >= 1) ? h->eps_c_bf : h->eps_c;

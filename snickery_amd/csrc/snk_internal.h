@@ -132,13 +132,21 @@ bool launch_knn_sweep16(int mode, int nt, int dch, int k_steps, int grid_cus, co
                         float *gmin32, int64_t G, void *pool, unsigned int *pool_ctl, int *chunk_fill,
                         int max_chunks, int pool_chunk, hipStream_t s);
 void launch_knn_threshold16(const float *gmin32, int64_t G, int64_t T, int64_t T32, int K, const double *eps,
-                            double *thr, float *thr32, const double *bound_in, double *bound_out, hipStream_t s);
+                            double *thr, float *thr32, const double *bound_in, double *bound_out, hipStream_t s,
+                            const double *e1 = nullptr, float *thr1 = nullptr);    // thr1: the coarse pass's threshold (thr32 + e1)
 // bf16-split prefilter (knn16_kernels.hip)
 bool knn_sweep16b_supported(int nt, int dch, int Dt, int Dpad, bool cls);
 void launch_build_db16b(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,
                         int64_t sample_stride, int64_t G, int nt_a, void *A16, hipStream_t s);
 void launch_prepare_queries16b(const double *Qp, const double *qnorm, int64_t T, int Dt, int Dpad, const double *fmax2,
-                               const double *rho, double c_acc, void *B16, double *eps, double *cq, hipStream_t s);
+                               const double *rho, double c_acc, void *B16, double *eps, double *cq, hipStream_t s,
+                               double c_coarse = 0.0, double *e1 = nullptr);      // e1: what the hi.hi term alone may be off by
+// two-pass filter on the bf16-split operands: hi.hi sweep -> (database tile, query tile) pairs -> three-term keys of those
+bool knn_coarse16b_supported(int nt, int dch);
+size_t knn_coarse_pair_bytes();
+bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32, const float *thr1,
+                          int64_t T32, int64_t n_tiles, unsigned int *ctr, void *pairs, unsigned int *pair_ctl, unsigned int pair_cap,
+                          void *pool, unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s);
 void launch_db16b_ratios(const double *Fw, int64_t N, int Dt, int Dpad, double *rho, hipStream_t s);
 bool launch_knn_sweep16b(int mode, int terms, int nt, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32,
                          int64_t T32, int64_t n_slabs, unsigned int *ctr, float *gmin32, int64_t G, void *pool,

@@ -158,3 +158,37 @@ def test_bf16_mfma_accumulation_stays_inside_the_assumed_bound(engine):
         worst = max(worst, float(ratio.max()))
     print('one bf16 MFMA: max |D - exact| / (2^-20 (sum |products| + |C|)) = %.3f' % worst)
     assert worst <= 0.75, worst
+
+
+@pytest.mark.parametrize('N,T,K,Dt,offset,scale', [(65536, 600, 100, 61, 0.0, None),        # the headline widths: one chunk, eight tiles resident
+                                                   (50000, 333, 50, 100, 0.0, None),         # two chunks
+                                                   (40000, 120, 100, 184, 0.0, None),        # three chunks (halfphone width)
+                                                   (30000, 97, 30, 61, 6.0, None),           # norms far above the distances: the coarse pass lets most pairs through
+                                                   (20000, 33, 200, 45, 50.0, 0.02),
+                                                   (1500, 40, 20, 61, 0.0, None),            # fewer tiles than a wavefront keeps resident
+                                                   (70001, 1, 16, 61, 0.0, None)])           # one query row
+def test_two_pass_filter_selects_what_the_one_pass_filter_selects(engine, N, T, K, Dt, offset, scale):
+    """The bf16-split filter as two passes (knn_coarse16b: hi.hi term alone against thr32 + e1 -> tile pairs; knn_refine16b:
+    three-term keys of those pairs against thr32) must let through exactly what the one-pass sweep lets through -- the
+    candidate lists in front of the exact re-rank have the same lengths row by row -- and the results are the oracle's."""
+    engine.set_option('prefilter', 1)
+    F_unw, wt, F = setup(engine, N, Dt, seed=N % 97, offset=offset, scale=scale)
+    assert engine.info('prefilter_bf16_active') == 1
+    U = o.synthetic_targets(F_unw, T, seed=7) * wt
+    oc, od = o.knn_bruteforce(F, U, K)
+    lists = {}
+    for two_pass in (1, 0):
+        engine.set_option('prefilter_two_pass', two_pass)
+        before = engine.info('f16_fallbacks')
+        cand, dist = engine.knn(U, K)
+        assert np.array_equal(cand, oc) and np.array_equal(dist, od)
+        assert engine.info('f16_fallbacks') == before
+        lists[two_pass] = (engine.info('last_list_mean'), engine.info('last_list_max'))
+    engine.set_option('prefilter_two_pass', 1)
+    assert lists[1] == lists[0], lists
+    cand, dist = engine.knn(U, K)
+    n_tiles = (N + 31) // 32
+    pairs, over = engine.info('coarse_pairs'), engine.info('coarse_pair_overflow')
+    assert over == 0 and 0 < pairs <= ((T + 31) // 32) * (n_tiles + 8)
+    if offset == 0.0 and N >= 20000 and T >= 32:
+        assert pairs < 0.25 * ((T + 31) // 32) * n_tiles, pairs        # the point of the coarse pass: most tile pairs never reach the three-term keys
