@@ -36,7 +36,7 @@ namespace snk {
 struct GresRec { unsigned long long a, b; };
 // v1 <= v2 <= v3: order-preserving uint32 images (gres_image) of the workgroup's three smallest float32 totals
 // granule a: v1 | thread of the best window << 32 | thread of the second << 40 | tag << 48
-// granule b: v2 | upper 16 bits of v3 (the image truncated: a value at or BELOW v3, conservative) << 32 | tag << 48
+// granule b: v2 | (v3 - v1 as a float32 truncated to its upper 16 bits: at or BELOW the true distance, conservative) << 32 | tag << 48
 
 // order-preserving map float32 -> uint32 and back
 __device__ __forceinline__ unsigned int gres_image(float f)
@@ -78,7 +78,8 @@ __device__ __forceinline__ unsigned long long gres_min_u64(unsigned long long v)
 }
 
 __global__ void __launch_bounds__(GRES_T, 1)
-greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, GresRec *rec, int64_t *path, int64_t *status)
+greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, GresRec *rec, unsigned long long *rec2,
+                  int64_t *path, int64_t *status)
 {
     const bool approx = (flags & 1) != 0;
     const bool test_stall = (flags & 256) != 0;
@@ -197,7 +198,17 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                 }
                 const unsigned long long ga = (unsigned long long)v1 | ((unsigned long long)a1 << 32) | ((unsigned long long)a2 << 40) |
                                               ((unsigned long long)tag << 48);
-                const unsigned long long gb = (unsigned long long)v2 | ((unsigned long long)(v3 >> 16) << 32) | ((unsigned long long)tag << 48);
+                // third value: its distance to the best one, truncated to eight significant bits (never above the true
+                // distance; resolution where it matters: near ties)
+                unsigned int d3 = 0x7f80u;                                   // +inf: no third window
+                if (v3 < INF && v1 < INF) {
+                    const double diff = (double)gres_value(v3) - (double)gres_value(v1);      // >= 0, exact
+                    const float df = (float)diff;
+                    unsigned int db = __builtin_bit_cast(unsigned int, df);
+                    if ((double)df > diff) db -= 1u;                         // the conversion rounded up: one step down
+                    d3 = db >> 16;
+                }
+                const unsigned long long gb = (unsigned long long)v2 | ((unsigned long long)d3 << 32) | ((unsigned long long)tag << 48);
                 if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                 __hip_atomic_store(&rec[blockIdx.x].a, ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&rec[blockIdx.x].b, gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -267,15 +278,26 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                         const unsigned int b = (unsigned int)lane + 64u * q;
                         const float v1 = gres_value((unsigned int)ra[q]);
                         const float v2 = gres_value((unsigned int)rb[q]);
-                        const float v3 = gres_value((unsigned int)((rb[q] >> 32) & 0xffffu) << 16);
+                        // (third value = best + truncated distance: at or below the workgroup's true third value)
+                        const double v3 = (double)v1 + (double)__builtin_bit_cast(float, (unsigned int)((rb[q] >> 32) & 0xffffu) << 16);
                         m1b[q] = __ballot(b < nb && (double)v1 <= tau);
                         m2b[q] = __ballot(b < nb && (double)v2 <= tau);
                         nc += __popcll(m1b[q]) + __popcll(m2b[q]);
-                        cov = cov || __ballot(b < nb && (double)v3 <= tau) != 0ull;
+                        cov = cov || __ballot(b < nb && v3 <= tau) != 0ull;
                     }
                     if (nc == 1 && !cov) winner = mi;        // the only window inside the bound is the float32 minimum itself
-                    else if (cov || nc > GRES_MAXCAND) {
-                        state = -1;                          // a window no record carries may matter: the caller's other scan
+                    else if (cov && nc <= GRES_MAXCAND) {
+                        // a window no record carries may matter (three or more of one workgroup inside the bound: runs of
+                        // near-identical frames): second round -- every workgroup publishes WHICH of its windows lie inside
+                        state = 2;
+                        if (lane == 0) bcast[2] = __double_as_longlong(tau);
+                    } else if (cov || nc > GRES_MAXCAND) {
+                        state = -1;                          // mass ties: the caller's other scan
+                        if (lane == 0 && blockIdx.x == 0) {
+                            // (why, for the developer: status[4..7] = candidates, third-value flag, float32 minimum, tau)
+                            status[4] = nc; status[5] = cov ? 1 : 0;
+                            status[6] = __double_as_longlong((double)mv); status[7] = __double_as_longlong(tau);
+                        }
                         if (lane == 0 && blockIdx.x == 0) __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     } else {
                         // canonical float64 totals of the windows inside the bound, lowest index on exact ties
@@ -306,6 +328,99 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
             if (lane == 0) { bcast[0] = winner; bcast[1] = state; }
         }
         __syncthreads();
+        if (bcast[1] == 2) {                                 // uniform
+            // ---- second round: 256-bit membership mask of every workgroup (8 granules of 32 bits + tag), gathered by all ----
+            const double tau = __longlong_as_double(bcast[2]);
+            const unsigned long long mask = __ballot(valid && (double)key <= tau);
+            if (lane == 0) {
+                if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    __hip_atomic_store(&rec2[(size_t)blockIdx.x * 8 + 2 * wave + hh],
+                                       ((mask >> (32 * hh)) & 0xffffffffull) | ((unsigned long long)tag << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();                                 // (bcast is rewritten below)
+            if (wave == 0) {
+                unsigned long long g2[4][8];
+                int state = 0;
+                const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned int b = (unsigned int)lane + 64u * q;
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            g2[q][g] = 0ull;
+                            if (b < nb) {
+                                g2[q][g] = __hip_atomic_load(&rec2[(size_t)b * 8 + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                ok = ok && (unsigned int)(g2[q][g] >> 48) == tag;
+                            }
+                        }
+                    }
+                    if (__all(ok)) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t_wait > GRES_STALL_TICKS) {
+                        if (lane == 0) {
+                            __hip_atomic_store(&status[3], (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        state = -1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (fenced) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                int64_t winner = -1;
+                if (state == 0) {
+                    int mine = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) mine += __popc((unsigned int)g2[q][g]);
+                    int incl = mine;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int o = __shfl_up(incl, off, 64);
+                        if (lane >= off) incl += o;
+                    }
+                    const int total = __shfl(incl, 63, 64);
+                    if (total < 1 || total > GRES_MAXCAND) {
+                        state = -1;                          // mass ties: the caller's other scan
+                        if (lane == 0 && blockIdx.x == 0) {
+                            status[4] = total; status[5] = 2; status[7] = __double_as_longlong(tau);
+                            __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    } else {
+                        int pos = incl - mine;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int g = 0; g < 8; ++g) {
+                                unsigned int m = (unsigned int)g2[q][g];
+                                while (m) {
+                                    const int bit = __builtin_ctz(m);
+                                    m &= m - 1u;
+                                    clist[pos++] = (int64_t)(((unsigned int)lane + 64u * q) * GRES_T + 32u * g + (unsigned int)bit);
+                                }
+                            }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                        double dbest = DBL_MAX;
+                        int64_t ibest = INT64_MAX;
+                        for (int p = 0; p < total; ++p) {
+                            const int64_t id = g32_uniform_i(clist[p]);
+                            const double d = g32_exact_d2_wave(a, 0, step, prev_row, step > 0, id, terms, lane);
+                            if (d < dbest || (d == dbest && id < ibest)) { dbest = d; ibest = id; }
+                        }
+                        winner = ibest;
+                        stat_windows += (unsigned long long)total;
+                        stat_rounds += 1;
+                    }
+                }
+                if (lane == 0) { bcast[0] = winner; bcast[1] = state; }
+            }
+            __syncthreads();
+        }
         if (bcast[1] < 0) break;                             // uniform: everybody leaves
         prev_row = g32_uniform_i(bcast[0]);
         if (blockIdx.x == 0 && tid == 0) path[a.out_off[0] + step] = prev_row;
@@ -316,10 +431,13 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
     }
 }
 
-__global__ void greedy_res_init_kernel(GresRec *rec, int n, int64_t *status)
+__global__ void greedy_res_init_kernel(GresRec *rec, unsigned long long *rec2, int n, int64_t *status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { rec[i].a = 0ull; rec[i].b = 0ull; }
+    if (i < n) {
+        rec[i].a = 0ull; rec[i].b = 0ull;
+        for (int g = 0; g < 8; ++g) rec2[(size_t)i * 8 + g] = 0ull;
+    }
     if (i == 0) { status[0] = 0; status[1] = 0; status[2] = 0; status[3] = 0; }
 }
 
@@ -338,7 +456,8 @@ bool greedy_res_supported(const GreedyLayout &g, int Dt, int n_cus)
     return nb >= 1 && nb <= cap && gres_lds_bytes(g, Dt) <= (size_t)(160 * 1024);
 }
 
-size_t greedy_res_record_bytes(const GreedyLayout &g) { return (size_t)((g.Nwin + GRES_T - 1) / GRES_T) * sizeof(GresRec); }
+// per workgroup: the step's record (16 bytes) and the second round's membership mask (8 granules)
+size_t greedy_res_record_bytes(const GreedyLayout &g) { return (size_t)((g.Nwin + GRES_T - 1) / GRES_T) * (sizeof(GresRec) + 64); }
 
 // One utterance, all steps, one launch.  *status (device, 4 words): 0 or 1 + the first step that was not decided here,
 // rounds, windows settled by exact totals, watchdog.  hst: the hoisted target term of the utterance (required).
@@ -361,12 +480,13 @@ void launch_greedy_res(const GreedyLayout &g, const float *F_unw, int Fp, int Dt
     const int nb = (int)((g.Nwin + GRES_T - 1) / GRES_T);
     const int JQ4 = (g.jdim + 3) / 4, tile_q = (g.jdim + GR_CC - 1) / GR_CC * 8;
     const size_t lds = gres_lds_bytes(g, Dt);
-    hipLaunchKernelGGL(greedy_res_init_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, reinterpret_cast<GresRec *>(rec), nb, status);
+    unsigned long long *rec2 = reinterpret_cast<unsigned long long *>(reinterpret_cast<GresRec *>(rec) + nb);
+    hipLaunchKernelGGL(greedy_res_init_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, reinterpret_cast<GresRec *>(rec), rec2, nb, status);
     static size_t attr[32] = {0};
     if (lds_attr_needed(attr, lds))
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(greedy_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(greedy_res_kernel, dim3(nb), dim3(GRES_T), lds, s, a, nsteps, flags, JQ4, tile_q,
-                       reinterpret_cast<GresRec *>(rec), path, status);
+                       reinterpret_cast<GresRec *>(rec), rec2, path, status);
 }
 
 }  // namespace snk

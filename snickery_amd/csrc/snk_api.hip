@@ -271,6 +271,7 @@ struct snk_engine {
     DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist, gsync, gtiles;
     DevBuf g32_blk, g32_ctl;          // float32 persistent scan: block records + candidate lists, {gen, status}
     DevBuf g32_res;                   // resident scan (greedy_res_kernels.hip): one 16-byte record per workgroup
+    int64_t greedy_last_status[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // status words of the most recent one-launch scan (undecided step + 1, rounds, exact windows, watchdog)
     int greedy_fenced = 0;            // 1: cross-check mode of the one-launch scans: agent-scope fences around every hand-off
     int greedy_resident = 1;          // 1: one utterance against a database that fits the chip's LDS takes the resident scan
     int64_t greedy_resident_launches = 0;
@@ -1887,11 +1888,12 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
                     h->g32_blk.p, h->n_cus, h->gsync.as<unsigned int>(), gen,
                     status, h->gpath.as<int64_t>(), hoist ? &hst : nullptr, h->stream);
     HIPCHK(hipGetLastError());
-    int64_t stv[4] = {0, 0, 0, 0};         // undecided step + 1 | second-phase rounds | windows decided by exact totals | watchdog
+    int64_t stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};         // undecided step + 1 | second-phase rounds | windows decided by exact totals | watchdog | (resident scan: why)
     HIPCHK(hipMemcpyAsync(stv, status, sizeof(stv), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     greedy32_trace_dump();
     *undecided = stv[0] != 0;
+    for (int i = 0; i < 8; ++i) h->greedy_last_status[i] = stv[i];
     h->greedy_second_rounds += stv[1];
     h->greedy_exact_windows += stv[2];
     h->greedy_stalls += stv[3];
@@ -2980,6 +2982,12 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "greedy_mode")) *out = h->greedy_mode;
     else if (!strcmp(name, "greedy_hoist")) *out = h->greedy_hoist;
     else if (!strcmp(name, "greedy_hoist_launches")) *out = (double)h->greedy_hoist_launches;
+    else if (!strcmp(name, "greedy_last_undecided_step")) *out = (double)h->greedy_last_status[0] - 1.0;     // -1: every step was decided
+    else if (!strcmp(name, "greedy_last_watchdog")) *out = (double)h->greedy_last_status[3];
+    else if (!strcmp(name, "greedy_last_why_candidates")) *out = (double)h->greedy_last_status[4];
+    else if (!strcmp(name, "greedy_last_why_third")) *out = (double)h->greedy_last_status[5];
+    else if (!strcmp(name, "greedy_last_why_min")) { double v; memcpy(&v, &h->greedy_last_status[6], 8); *out = v; }
+    else if (!strcmp(name, "greedy_last_why_tau")) { double v; memcpy(&v, &h->greedy_last_status[7], 8); *out = v; }
     else if (!strcmp(name, "greedy_resident")) *out = h->greedy_resident;
     else if (!strcmp(name, "greedy_resident_launches")) *out = (double)h->greedy_resident_launches;
     else if (!strcmp(name, "greedy_f16")) *out = h->greedy_f16;

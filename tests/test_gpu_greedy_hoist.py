@@ -224,7 +224,7 @@ def test_values_outside_the_float16_range_keep_float32_tiles(engine):
 @pytest.mark.parametrize('N,me,lfat,mode,Dj,Dt', [(65536 + 5, 6, False, 0, 151, 61),      # B1: every compute unit holds 256 windows
                                                  (30011, 4, False, 1, 302, 61),            # half-column join (synth_halfphone epoch voices)
                                                  (1078, 6, True, 0, 151, 61),              # the golden mini voice's size: five workgroups
-                                                 (777, 1, False, 0, 40, 61)])
+                                                 (777, 1, False, 0, 70, 61)])
 def test_resident_scan_equals_oracle_and_streamed_scan(engine, N, me, lfat, mode, Dj, Dt):
     """A database whose windowed join matrix fits the chip's LDS is searched by the resident scan (greedy_res_kernels.hip:
     one utterance per call, every workgroup decides each step for itself from the gathered records).  Same paths and
