@@ -77,18 +77,128 @@ __device__ __forceinline__ unsigned long long gres_min_u64(unsigned long long v)
     return v;
 }
 
+// Tree sums of the float64 terms of up to four windows at once (the operands of all of them requested together: the
+// rows of a candidate are cold).  Any order of adding the same terms lands within n 2^-53 of the true sum, the canonical
+// chain too: a window whose tree sum is beyond (1 + 4 n 2^-53) of the smallest cannot be the canonical minimum.
+static __device__ void gres_tree_sums(const GreedyArgs &a, int64_t step, int64_t prev_row, bool prev_is_current,
+                                      const int64_t (&ids)[4], int cnt, double (&sum)[4], int lane)
+{
+    const int col0 = prev_is_current ? a.cur_col0 : a.prev_col0;
+    const int64_t row0 = prev_is_current ? a.cur_row0 : a.prev_row0;
+    const float *rr = a.JC_unw + (row0 + (prev_row >= 0 ? prev_row : 0)) * a.Jp + col0;
+    const int ncol = a.jdim + a.nep * a.Dt;
+    constexpr int NJ = 9;
+    double part[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int base = 0; base < ncol; base += 64 * NJ) {
+        float x[4][NJ], rx[NJ];
+        double w[NJ], rw[NJ], qv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int idx = base + 64 * j + lane;
+            rx[j] = 0.f; w[j] = 0.0; rw[j] = 0.0; qv[j] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k][j] = 0.f;
+            if (idx < a.jdim) {
+                w[j] = a.wj[a.prev_col0 + idx];
+                if (prev_row >= 0) { rx[j] = rr[idx]; rw[j] = a.wj[col0 + idx]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < cnt) x[k][j] = a.JC_unw[(a.prev_row0 + ids[k]) * a.Jp + a.prev_col0 + idx];
+            } else if (idx < ncol) {
+                const int t = idx - a.jdim, e = t / a.Dt, c = t - e * a.Dt;
+                w[j] = a.wt[c];
+                qv[j] = a.Q[(a.q_off[0] + step * a.me + a.ep[e]) * a.Dt + c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < cnt) x[k][j] = a.F_unw[(ids[k] + a.ep[e]) * a.Fp + c];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int idx = base + 64 * j + lane;
+            if (idx < ncol) {
+                const double ref = idx < a.jdim ? (prev_row >= 0 ? __dmul_rn((double)rx[j], rw[j]) : 0.0) : qv[j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < cnt) {
+                        const double d = __dsub_rn(__dmul_rn((double)x[k][j], w[j]), ref);
+                        part[k] += __dmul_rn(d, d);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double v = part[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        sum[k] = k < cnt ? v : DBL_MAX;
+    }
+}
+
+// the canonical float64 minimum among n listed windows (lowest index on exact ties), by ONE wavefront: tree sums of all of
+// them first; only the windows that the tree sums cannot tell from the smallest get their canonical chain
+static __device__ int64_t gres_exact_argmin(const GreedyArgs &a, int64_t step, int64_t prev_row, const int64_t *clist, int n,
+                                            double *terms, int lane)
+{
+    const int ex_cols = a.jdim + a.nep * a.Dt;
+    double smin = DBL_MAX;
+    for (int p0 = 0; p0 < n; p0 += 4) {
+        int64_t ids[4];
+        const int cnt = n - p0 < 4 ? n - p0 : 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ids[k] = k < cnt ? g32_uniform_i(clist[p0 + k]) : 0;
+        double sum[4];
+        gres_tree_sums(a, step, prev_row, step > 0, ids, cnt, sum, lane);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < cnt && lane == 0) terms[ex_cols + p0 + k] = sum[k];          // (behind the term array: up to GRES_MAXCAND sums)
+            smin = sum[k] < smin ? sum[k] : smin;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const double thr = smin * (1.0 + 4.0 * (double)ex_cols * 1.1102230246251565e-16 * 1.01) + 1e-300;
+    int n_surv = 0;
+    int64_t only = -1;
+    for (int p = 0; p < n; ++p)
+        if (terms[ex_cols + p] <= thr) { ++n_surv; only = clist[p]; }
+    if (n_surv == 1) return g32_uniform_i(only);
+    double dbest = DBL_MAX;
+    int64_t ibest = INT64_MAX;
+    for (int p = 0; p < n; ++p) {
+        if (!(terms[ex_cols + p] <= thr)) continue;                              // uniform
+        const int64_t id = g32_uniform_i(clist[p]);
+        const double d = g32_exact_d2_wave(a, 0, step, prev_row, step > 0, id, terms, lane);
+        if (d < dbest || (d == dbest && id < ibest)) { dbest = d; ibest = id; }
+    }
+    return ibest;
+}
+
+// JQ: float4 columns of a join row the instance is compiled for (the weights live in registers, the loop over the columns
+// is unrolled: the launch picks the smallest instance that holds the voice's join width; the rest is zero padding)
+template <int JQ, bool EXACT>                            // EXACT: the voice's join rows have exactly JQ float4 columns (no bounds tests in the scan)
 __global__ void __launch_bounds__(GRES_T, 1)
 greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, GresRec *rec, unsigned long long *rec2,
-                  int64_t *path, int64_t *status)
+                  int64_t *path, int64_t *status, unsigned long long *trace)
 {
+    // optional timeline (SNK_GRES_TRACE=file): 8 stamps of the 100 MHz clock per step, workgroup 0, steps 0 .. 255
+    auto stamp = [&](int64_t st, int k) {
+        if (trace && st < 256 && blockIdx.x == 0 && threadIdx.x == 0) {
+            trace[st * 8 + k] = __builtin_amdgcn_s_memrealtime();
+            trace[2048 + st * 8 + k] = __builtin_amdgcn_s_memtime();          // shader clock
+        }
+    };
     const bool approx = (flags & 1) != 0;
     const bool test_stall = (flags & 256) != 0;
     const bool fenced = (flags & 512) != 0;              // cross-check mode: release / acquire fences around the hand-off (greedy32_kernels.hip)
     extern __shared__ __align__(16) char lds[];
     f32x4 *const xs = reinterpret_cast<f32x4 *>(lds);                           // [JQ4][256]
-    f32x4 *const tw = reinterpret_cast<f32x4 *>(lds + (size_t)JQ4 * GRES_T * 16);    // [JQ4] weights (float32)
-    f32x4 *const tr = tw + JQ4;                                                  // [JQ4] references of the step
-    char *const scratch = reinterpret_cast<char *>(tr + JQ4);                    // 512 bytes
+    // (written and read as floats: a float store read back through a float4 pointer is undefined behaviour, and the
+    // compiler used it -- every component of a reference became the first one)
+    float *const tw = reinterpret_cast<float *>(lds + (size_t)JQ4 * GRES_T * 16);    // [4 JQ4] weights (float32)
+    float *const tr = tw + 4 * JQ4;                                              // [4 JQ4] references of the step
+    char *const scratch = reinterpret_cast<char *>(tr + 4 * JQ4);                // 512 bytes
     double *const redd = reinterpret_cast<double *>(scratch);                    // [4] partial norms
     unsigned int *const redk = reinterpret_cast<unsigned int *>(scratch + 64);   // [4][6] wavefront top-3
     int64_t *const bcast = reinterpret_cast<int64_t *>(scratch + 192);           // [2] winner, state
@@ -112,23 +222,31 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
         }
         if (tid < JQ4 * 4) {
             const float w = tid < a.jdim ? (float)a.wj[a.prev_col0 + tid] : 0.f;
-            reinterpret_cast<float *>(tw)[tid] = w;
-            reinterpret_cast<float *>(tr)[tid] = 0.f;
+            tw[tid] = w;
+            tr[tid] = 0.f;
         }
     }
     // weight of this thread's reference column: the winner's row is read from the `current` columns, a start state's
     // from the `prev` columns (synth_simple.py:467-469,501)
+    __syncthreads();
+    f32x4 wreg[JQ];                                      // float32 weights of all columns: constant over the launch
+#pragma unroll
+    for (int q = 0; q < JQ; ++q)
+        wreg[q] = q < JQ4 ? (f32x4){tw[4 * q], tw[4 * q + 1], tw[4 * q + 2], tw[4 * q + 3]} : (f32x4){0.f, 0.f, 0.f, 0.f};
     const double wref_cur = tid < a.jdim ? a.wj[a.cur_col0 + tid] : 0.0;
     const double wref_prev = tid < a.jdim ? a.wj[a.prev_col0 + tid] : 0.0;
-    const int ecols = JQ4 * 4 + 4;                       // chain length of the bound: columns, the two partial sums, the hoisted value
+    const int ecols = JQ4 * 4 + 6;                       // chain length of the bound: columns, the four partial sums, the hoisted value
     int64_t prev_row = a.start[0];
     const float *const Wp0 = a.W[0] + (valid ? win : 0);
     float w_next = valid ? Wp0[0] : 0.f;
+    double qn2_next = a.qn2[0][0];
+    const double sq_fw = sqrt(a.fwmax2);
     unsigned long long stat_rounds = 0, stat_windows = 0;
     __syncthreads();
 
     for (int64_t step = 0; step < nsteps; ++step) {
         const unsigned int tag = (unsigned int)(step % 65535) + 1u;
+        stamp(step, 0);
         const float w_cur = w_next;
         if (step + 1 < nsteps && valid) w_next = Wp0[(size_t)(step + 1) * a.Wp];
         // ---- the step's references: row of the previous winner x weights, float32; squared norm in float64 ----
@@ -139,29 +257,44 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                 const float x = a.JC_unw[((cur ? a.cur_row0 : a.prev_row0) + prev_row) * a.Jp + (cur ? a.cur_col0 : a.prev_col0) + tid];
                 ref = __dmul_rn((double)x, cur ? wref_cur : wref_prev);
             }
-            if (tid < JQ4 * 4) reinterpret_cast<float *>(tr)[tid] = (float)ref;
+            if (tid < JQ4 * 4) tr[tid] = (float)ref;
             double v = ref * ref;
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
             if (lane == 0) redd[wave] = v;
         }
         __syncthreads();
+        stamp(step, 1);                                      // table built
         const double V2 = g32_uniform_d(((redd[0] + redd[1]) + redd[2]) + redd[3]);
-        const double qn2 = a.qn2[0][step];
-        const double rr = sqrt(qn2) + sqrt(a.fwmax2);
-        const double EW = g32_uniform_d(a.hoist_c * rr * rr);
+        const double qn2 = qn2_next;                         // (requested a step ahead: a scalar-cache miss is a microsecond)
+        if (step + 1 < nsteps) qn2_next = a.qn2[0][step + 1];
 
-        // ---- scan: this thread's window against the table, out of LDS ----
-        float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll 2
-        for (int q = 0; q < JQ4; ++q) {
-            const f32x4 x = xs[q * GRES_T + tid], w = tw[q], r = tr[q];
-            const float d0 = __builtin_fmaf(x[0], w[0], -r[0]), d1 = __builtin_fmaf(x[1], w[1], -r[1]);
-            const float d2 = __builtin_fmaf(x[2], w[2], -r[2]), d3 = __builtin_fmaf(x[3], w[3], -r[3]);
-            acc0 = __builtin_fmaf(d0, d0, acc0); acc1 = __builtin_fmaf(d1, d1, acc1);
-            acc0 = __builtin_fmaf(d2, d2, acc0); acc1 = __builtin_fmaf(d3, d3, acc1);
+        // ---- scan: this thread's window (LDS) against the references (lane q of every wavefront holds float4 column q
+        //      of the table: one LDS read per step, then a v_readlane per value -- as broadcast LDS reads the table was two
+        //      thirds of the step's LDS traffic, and that traffic was the scan's time) and the weights (registers) ----
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+        {
+            const int lq = 4 * (lane < JQ4 ? lane : 0);
+            const int rl0 = __builtin_bit_cast(int, tr[lq]), rl1 = __builtin_bit_cast(int, tr[lq + 1]);
+            const int rl2 = __builtin_bit_cast(int, tr[lq + 2]), rl3 = __builtin_bit_cast(int, tr[lq + 3]);
+#pragma unroll
+            for (int q = 0; q < JQ; ++q) {
+                if (EXACT || q < JQ4) {                                      // uniform
+                    const f32x4 x = xs[q * GRES_T + tid];
+                    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rl0, q));
+                    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rl1, q));
+                    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rl2, q));
+                    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rl3, q));
+                    const float d0 = __builtin_fmaf(x[0], wreg[q][0], -r0), d1 = __builtin_fmaf(x[1], wreg[q][1], -r1);
+                    const float d2 = __builtin_fmaf(x[2], wreg[q][2], -r2), d3 = __builtin_fmaf(x[3], wreg[q][3], -r3);
+                    acc0 = __builtin_fmaf(d0, d0, acc0); acc1 = __builtin_fmaf(d1, d1, acc1);
+                    acc2 = __builtin_fmaf(d2, d2, acc2); acc3 = __builtin_fmaf(d3, d3, acc3);
+                }
+            }
         }
-        float key = valid ? (acc0 + acc1) + w_cur : __builtin_inff();
+        asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3));
+        stamp(step, 2);                                      // scan done
+        float key = valid ? ((acc0 + acc1) + (acc2 + acc3)) + w_cur : __builtin_inff();
         if (!(key == key)) key = __builtin_inff();           // a NaN total (non-finite data) never wins
         // order-preserving image of the float32 key (the hoisted value's rounding can leave a total just below zero)
         const unsigned int INF = 0xff800000u;
@@ -180,22 +313,24 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
             redk[wave * 6 + 4] = m3;
         }
         __syncthreads();
+        stamp(step, 3);                                      // wavefront top-3 in LDS
 
         if (wave == 0) {
             // ---- workgroup top-3 (the wavefronts hold ascending windows: earlier entries win ties) and the record ----
+            // lane 3w + j holds wavefront w's j-th value (j = 0, 1 with its thread, j = 2 the bare third value): three minima;
+            // ties keep the lowest lane = the lowest window (the wavefronts hold ascending windows)
+            unsigned int cv = INF, ci = 0;
+            if (lane < 12) { const int w = lane / 3, j = lane - 3 * w; cv = redk[w * 6 + 2 * j]; ci = j < 2 ? redk[w * 6 + 2 * j + 1] : 0u; }
+            const unsigned int v1 = gres_dpp_min_u32(cv);
+            const int p1 = __builtin_ctzll(__ballot(cv == v1));
+            const unsigned int a1 = (unsigned int)__builtin_amdgcn_readlane((int)ci, p1);
+            const unsigned int cv2 = lane == p1 ? INF : cv;
+            const unsigned int v2 = gres_dpp_min_u32(cv2);
+            const int p2 = v2 < INF ? __builtin_ctzll(__ballot(cv2 == v2 && lane != p1)) : 0;
+            const unsigned int a2 = (unsigned int)__builtin_amdgcn_readlane((int)ci, p2);
+            const unsigned int cv3 = (lane == p2 && v2 < INF) ? INF : cv2;
+            const unsigned int v3 = gres_dpp_min_u32(cv3);
             if (lane == 0 && !(test_stall && step == 1 && blockIdx.x == 0)) {
-                unsigned int v1 = INF, v2 = INF, v3 = INF, a1 = 0, a2 = 0;
-                auto push = [&](unsigned int v, unsigned int i) {
-                    if (v < v1) { v3 = v2; v2 = v1; a2 = a1; v1 = v; a1 = i; }
-                    else if (v < v2) { v3 = v2; v2 = v; a2 = i; }
-                    else if (v < v3) v3 = v;
-                };
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    push(redk[w * 6 + 0], redk[w * 6 + 1]);
-                    push(redk[w * 6 + 2], redk[w * 6 + 3]);
-                    if (redk[w * 6 + 4] < v3) v3 = redk[w * 6 + 4];
-                }
                 const unsigned long long ga = (unsigned long long)v1 | ((unsigned long long)a1 << 32) | ((unsigned long long)a2 << 40) |
                                               ((unsigned long long)tag << 48);
                 // third value: its distance to the best one, truncated to eight significant bits (never above the true
@@ -213,6 +348,12 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                 __hip_atomic_store(&rec[blockIdx.x].a, ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&rec[blockIdx.x].b, gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            stamp(step, 4);                                  // record published
+            // constants of the bound, while the records travel: E(d) = c1 sqrt(d) + c2 d
+            const double rr = sqrt(qn2) + sq_fw;
+            const double EW = a.hoist_c * rr * rr;
+            const double c1 = 6.0 * 5.9604644775390625e-08 * 1.01 * sqrt(V2) * (1.0 + 1e-12), c2 = (double)(ecols + 8) * 5.9604644775390625e-08;
+            auto errf = [&](double d) { return c1 * sqrt(d) * (1.0 + 1e-12) + c2 * d; };       // >= g32_err(d, V2, ecols)
             // ---- gather the records of all workgroups (lane L: workgroups L, L + 64, ...) until every tag is this step's ----
             unsigned long long ra[4], rb[4];
             int state = 0;                                   // 0: go on, -1: leave (undecidable / watchdog)
@@ -244,6 +385,7 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                 }
             }
             if (fenced) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            stamp(step, 5);                                  // all records seen
             int64_t winner = -1;
             if (state == 0) {
                 // ---- the decision, the same in every workgroup ----
@@ -263,12 +405,14 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                 if (!(mvb < INF)) {
                     state = -1;                              // nothing finite
                     if (lane == 0 && blockIdx.x == 0) __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else if (approx && 4.0 * (g32_err((double)mv, V2, ecols) + EW) <= 1e-3 * (double)mv) {
+                } else if (approx && 4.0 * (errf((double)mv) + EW) <= 1e-3 * (double)mv) {
                     winner = mi;
                 } else {
                     const double M = (double)mv + 2.0 * EW;
+                    // (greedy32_kernels.hip: every iterate of tau = M + 2 E(tau) from above stays above the solution; two
+                    // rounds leave 1e-10 of it to gain)
                     double tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300;
-                    for (int it = 0; it < 3; ++it) tau = M + 2.0 * g32_err(tau, V2, ecols);
+                    for (int it = 0; it < 2; ++it) tau = M + 2.0 * errf(tau);
                     tau = tau * (1.0 + 1e-6) + 1e-300;
                     int nc = 0;
                     bool cov = false;
@@ -313,21 +457,16 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_wave_barrier();
-                        double dbest = DBL_MAX;
-                        int64_t ibest = INT64_MAX;
-                        for (int p = 0; p < nc; ++p) {
-                            const int64_t id = g32_uniform_i(clist[p]);
-                            const double d = g32_exact_d2_wave(a, 0, step, prev_row, step > 0, id, terms, lane);
-                            if (d < dbest || (d == dbest && id < ibest)) { dbest = d; ibest = id; }
-                        }
-                        winner = ibest;
+                        winner = gres_exact_argmin(a, step, prev_row, clist, nc, terms, lane);
                         stat_windows += (unsigned long long)nc;
                     }
                 }
             }
+            stamp(step, 6);                                  // decided
             if (lane == 0) { bcast[0] = winner; bcast[1] = state; }
         }
         __syncthreads();
+        stamp(step, 7);
         if (bcast[1] == 2) {                                 // uniform
             // ---- second round: 256-bit membership mask of every workgroup (8 granules of 32 bits + tag), gathered by all ----
             const double tau = __longlong_as_double(bcast[2]);
@@ -405,14 +544,7 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                             }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_wave_barrier();
-                        double dbest = DBL_MAX;
-                        int64_t ibest = INT64_MAX;
-                        for (int p = 0; p < total; ++p) {
-                            const int64_t id = g32_uniform_i(clist[p]);
-                            const double d = g32_exact_d2_wave(a, 0, step, prev_row, step > 0, id, terms, lane);
-                            if (d < dbest || (d == dbest && id < ibest)) { dbest = d; ibest = id; }
-                        }
-                        winner = ibest;
+                        winner = gres_exact_argmin(a, step, prev_row, clist, total, terms, lane);
                         stat_windows += (unsigned long long)total;
                         stat_rounds += 1;
                     }
@@ -441,11 +573,13 @@ __global__ void greedy_res_init_kernel(GresRec *rec, unsigned long long *rec2, i
     if (i == 0) { status[0] = 0; status[1] = 0; status[2] = 0; status[3] = 0; }
 }
 
+static void *gres_trace_dev = nullptr;
+
 static size_t gres_lds_bytes(const GreedyLayout &g, int Dt)
 {
     const int JQ4 = (g.jdim + 3) / 4;
     const int nep = (g.last_frame_as_target && g.me > 1) ? 2 : g.me;
-    return (size_t)JQ4 * GRES_T * 16 + (size_t)JQ4 * 32 + 256 + GRES_MAXCAND * 8 + (size_t)(g.jdim + nep * Dt) * 8;
+    return (size_t)JQ4 * GRES_T * 16 + (size_t)JQ4 * 32 + 256 + GRES_MAXCAND * 8 + (size_t)(g.jdim + nep * Dt + GRES_MAXCAND) * 8;
 }
 
 // one workgroup per compute unit holds 256 windows: the whole windowed database must fit the chip
@@ -453,7 +587,7 @@ bool greedy_res_supported(const GreedyLayout &g, int Dt, int n_cus)
 {
     const int64_t nb = (g.Nwin + GRES_T - 1) / GRES_T;
     const int cap = n_cus < 256 ? n_cus : 256;
-    return nb >= 1 && nb <= cap && gres_lds_bytes(g, Dt) <= (size_t)(160 * 1024);
+    return nb >= 1 && nb <= cap && (g.jdim + 3) / 4 <= 38 && gres_lds_bytes(g, Dt) <= (size_t)(160 * 1024);
 }
 
 // per workgroup: the step's record (16 bytes) and the second round's membership mask (8 granules)
@@ -482,11 +616,37 @@ void launch_greedy_res(const GreedyLayout &g, const float *F_unw, int Fp, int Dt
     const size_t lds = gres_lds_bytes(g, Dt);
     unsigned long long *rec2 = reinterpret_cast<unsigned long long *>(reinterpret_cast<GresRec *>(rec) + nb);
     hipLaunchKernelGGL(greedy_res_init_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, reinterpret_cast<GresRec *>(rec), rec2, nb, status);
-    static size_t attr[32] = {0};
-    if (lds_attr_needed(attr, lds))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(greedy_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(greedy_res_kernel, dim3(nb), dim3(GRES_T), lds, s, a, nsteps, flags, JQ4, tile_q,
-                       reinterpret_cast<GresRec *>(rec), rec2, path, status);
+    // (every instance is given the largest LDS size once per device)
+    unsigned long long *trace = nullptr;
+    if (getenv("SNK_GRES_TRACE")) {
+        if (!gres_trace_dev) (void)hipMalloc(&gres_trace_dev, 2 * 256 * 8 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(gres_trace_dev, 0, 2 * 256 * 8 * sizeof(unsigned long long), s);
+        trace = reinterpret_cast<unsigned long long *>(gres_trace_dev);
+    }
+#define SNK_GRES(JQ_, EX_)                                                                                         \
+    {                                                                                                              \
+        static size_t attr[32] = {0};                                                                              \
+        if (lds_attr_needed(attr, (size_t)(160 * 1024)))                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(greedy_res_kernel<JQ_, EX_>),                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));              \
+        hipLaunchKernelGGL((greedy_res_kernel<JQ_, EX_>), dim3(nb), dim3(GRES_T), lds, s, a, nsteps, flags, JQ4, tile_q, \
+                           reinterpret_cast<GresRec *>(rec), rec2, path, status, trace);                           \
+    }
+    // magphase-60 join rows (151 columns: 38 float4) have their own instance; other widths the next larger one
+    if (JQ4 == 38) SNK_GRES(38, true)
+    else if (JQ4 <= 10) SNK_GRES(10, false) else if (JQ4 <= 20) SNK_GRES(20, false) else if (JQ4 <= 30) SNK_GRES(30, false)
+    else SNK_GRES(38, false)
+#undef SNK_GRES
+}
+
+// developer aid: SNK_GRES_TRACE=<file> writes the last launch's timeline of workgroup 0 (256 steps x 8 stamps) after the caller's sync
+void greedy_res_trace_dump()
+{
+    const char *fn = getenv("SNK_GRES_TRACE");
+    if (!fn || !gres_trace_dev) return;
+    static unsigned long long host[2 * 256 * 8];
+    if (hipMemcpy(host, gres_trace_dev, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (FILE *f = fopen(fn, "wb")) { fwrite(host, sizeof(host), 1, f); fclose(f); }
 }
 
 }  // namespace snk

@@ -1892,6 +1892,7 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
     HIPCHK(hipMemcpyAsync(stv, status, sizeof(stv), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     greedy32_trace_dump();
+    greedy_res_trace_dump();
     *undecided = stv[0] != 0;
     for (int i = 0; i < 8; ++i) h->greedy_last_status[i] = stv[i];
     h->greedy_second_rounds += stv[1];

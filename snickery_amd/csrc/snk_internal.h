@@ -252,6 +252,7 @@ void launch_greedy_res(const GreedyLayout &g, const float *F_unw, int Fp, int Dt
                        int Dj, const double *wj, const float *tiles, const double *Q, int64_t q_off, int64_t nsteps,
                        int64_t out_off, int64_t start, int flags, void *rec, int64_t *status, int64_t *path,
                        const G32Hoist *hoist, hipStream_t s);
+void greedy_res_trace_dump();
 void launch_greedy32_dist(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
                           int Dj, const double *wj, const double *Q, int u_slot, int64_t q_off, int64_t nsteps, int64_t out_off,
                           int64_t start, const int64_t *path, double *dist, hipStream_t s);
