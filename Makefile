@@ -8,6 +8,9 @@ OBJS  := $(CSRC)/knn_kernels.o $(CSRC)/knn16_kernels.o $(CSRC)/viterbi_kernels.o
 
 all: $(LIB) oracle
 
+# the K-NN prefilter kernels test the matrix results on the vector unit: accumulators in architected registers
+$(CSRC)/knn16_kernels.o: HIPFLAGS += -mllvm -amdgpu-mfma-vgpr-form
+
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/snk_internal.h $(CSRC)/greedy_common.h $(CSRC)/greedy32_device.h include/snk.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -944,15 +944,24 @@ bool launch_knn_sweep16b(int mode, int terms, int nt, int dch, int grid_cus, con
 // ===========================================================================================================
 struct CoarsePair { unsigned int tile, qtile; };
 
-template <int NTC, int KB>
-__global__ void __launch_bounds__(256, 1)
+// WPS: wavefronts per SIMD the instance is built for.  Measured (profiles/r03_*): kernel cycles = matrix-busy cycles
+// + 4 x vector instructions, with one wavefront per SIMD (eight database tiles each) and with two (four each, twice the
+// per-query-tile overhead): the vector instructions of the tests do not hide behind the matrix pipe either way, so the
+// instance with fewer of them per MFMA is the default (SNK_COARSE_WPS=2 selects the other one).
+template <int NTC, int KB, int WPS>
+__global__ void __launch_bounds__(256, WPS)
 knn_coarse16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const float *__restrict__ thr1, int nQT,
               int64_t n_tiles, int64_t n_slabs, unsigned int *__restrict__ slab_counter, int qsplit, int64_t n_main_slabs,
               int qsplit_tail, CoarsePair *__restrict__ pairs, unsigned int *__restrict__ pair_ctl, unsigned int pair_cap)
 {
-    constexpr int CH = 4;                              // independent MFMA chains per step
+    // independent MFMA chains per step, two accumulator sets that alternate by step parity.  Register homes are forced
+    // (Makefile: -amdgpu-mfma-vgpr-form for this file; the "+a" pins below): the resident database pieces in the
+    // accumulation registers, which the matrix instruction reads its A operand from directly, the results in the
+    // architected registers, where the vector unit tests them.  Left to itself the allocator did the opposite and paid
+    // sixteen v_accvgpr_read per tested tile: as many vector instructions as the matrix pipe was busy cycles.
+    constexpr int CH = (NTC >= 8) ? 4 : 2;
     constexpr int NSTEP = NTC / CH;
-    static_assert(NSTEP == 2 || NSTEP == 1, "two accumulator sets alternate per step");
+    static_assert(NTC % CH == 0 && NSTEP % 2 == 0, "the accumulator sets alternate by step parity, a tile has an even number of steps");
     __shared__ CoarsePair pstage[4][64];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -1005,6 +1014,13 @@ knn_coarse16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, cons
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) ah[nt][kb] = A16[((t * KB + kb) * 2 + 0) * 64 + lane];
         }
+        // the resident database pieces live in the ACCUMULATION registers (the matrix instruction reads its A operand from
+        // there as well) so that the results, which the vector unit tests, can stay in the architected ones: left to itself
+        // the allocator did the opposite and paid sixteen v_accvgpr_read per tested tile
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+a"(ah[nt][kb]));
         const int n_valid = (int)(n_tiles - tile0 < NTC ? n_tiles - tile0 : NTC);
 
         // query tiles: hi pieces and the coarse threshold of this lane's query column, three buffers (two tiles ahead)
@@ -1058,6 +1074,9 @@ knn_coarse16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, cons
                 }
                 if (kb < CH) test(prev[kb], pt0 + kb, pth, pq);
             }
+            // the results are tested by the vector unit: architected registers
+#pragma unroll
+            for (int j = 0; j < CH; ++j) asm volatile("" : "+v"(cur[j]));
             if (KB < CH) {
 #pragma unroll
                 for (int j = KB; j < CH; ++j) test(prev[j], pt0 + j, pth, pq);
@@ -1067,13 +1086,12 @@ knn_coarse16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, cons
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(x[kb]));
             load_q(t_load, xload, thload);               // two tiles ahead
-            if (NSTEP == 2) {
-                step(S0, S1, 0, x, CH, th_prev, qt_prev);   // tests the second half of the previous query tile
-                step(S1, S0, CH, x, 0, th, qt);             // ... the first half of this one
-            } else {
-                step(S0, S1, 0, x, 0, th_prev, qt_prev);
+            // step st fills S[st & 1] and tests the step before it (the last step of the previous query tile for st = 0)
+            step(S0, S1, 0, x, (NSTEP - 1) * CH, th_prev, qt_prev);
 #pragma unroll
-                for (int j = 0; j < CH; ++j) S1[j] = S0[j];
+            for (int st = 1; st < NSTEP; ++st) {
+                if (st & 1) step(S1, S0, st * CH, x, (st - 1) * CH, th, qt);
+                else step(S0, S1, st * CH, x, (st - 1) * CH, th, qt);
             }
             th_prev = th;
             qt_prev = qt;
@@ -1194,19 +1212,34 @@ knn_refine16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, cons
             }
         }
     };
-    if (wave_id < n_pairs) {
-        load_pair(wave_id, p0, a0, b0, th0);
-        for (unsigned int i = wave_id; i < n_pairs; i += 2u * wave_stride) {
-            load_pair(i + wave_stride, p1, a1, b1, th1);
+    // a wavefront takes runs of BL consecutive pairs: the coarse sweep lists the pairs of one query tile (and of
+    // neighbouring database tiles) next to each other, so a run re-reads operand tiles this compute unit has just had
+    // (pairs dealt out one by one took 0.46 ms at B*, L2-bound: 16 KB of operands per twelve MFMAs)
+    constexpr unsigned int BL = 8u;
+    auto idx = [&](unsigned int j) { return (wave_id + (j / BL) * wave_stride) * BL + (j % BL); };
+    if (idx(0u) < n_pairs) {
+        load_pair(idx(0u), p0, a0, b0, th0);
+        for (unsigned int j = 0u;; j += 2u) {
+            const unsigned int i1 = idx(j + 1u);
+            load_pair(i1, p1, a1, b1, th1);
             work(p0, a0, b0, th0);
-            if (i + wave_stride < n_pairs) {
-                load_pair(i + 2u * wave_stride, p0, a0, b0, th0);
-                work(p1, a1, b1, th1);
-            }
+            if (i1 >= n_pairs) break;
+            const unsigned int i2 = idx(j + 2u);
+            load_pair(i2, p0, a0, b0, th0);
+            work(p1, a1, b1, th1);
+            if (i2 >= n_pairs) break;
         }
     }
     if (lcount) flush_stage();
     if (chunk_id >= 0 && lane == 0) chunk_fill[chunk_id] = cused;
+}
+
+// developer switch (SNK_COARSE_WPS=1|2, read once): wavefronts per SIMD of the one-chunk coarse sweep
+static int coarse_wps()
+{
+    static int v = 0;
+    if (!v) { const char *e = getenv("SNK_COARSE_WPS"); v = (e && atoi(e) == 2) ? 2 : 1; }
+    return v;
 }
 
 bool knn_coarse16b_supported(int nt, int dch) { return (nt == 4 && dch == 1) || (nt == 2 && dch == 2) || (nt == 1 && dch == 3); }
@@ -1219,9 +1252,10 @@ bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, con
                           void *pool, unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s)
 {
     const int nQT = (int)(T32 / 32);
-    const int ntc = dch == 1 ? 8 : dch == 2 ? 4 : 4;          // hi pieces of 32 (dch 3: 48) k-blocks resident per wavefront
+    const int wps = (dch == 1 && coarse_wps() == 2) ? 2 : 1;
+    const int ntc = dch == 1 ? (wps == 2 ? 4 : 8) : 4;        // hi pieces of 16 / 32 (dch 3: 48) k-blocks resident per wavefront
     const int64_t n_slabs = (n_tiles + ntc - 1) / ntc;
-    const int64_t max_blocks = grid_cus;
+    const int64_t max_blocks = (int64_t)grid_cus * wps;
     int qsplit = 1;
     while (n_slabs * qsplit < 2 * 4 * max_blocks && qsplit * 2 <= nQT && qsplit < 8) qsplit *= 2;
     int64_t blocks = (n_slabs * qsplit + 3) / 4;
@@ -1229,17 +1263,17 @@ bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, con
     int64_t n_main = n_slabs;
     int qtail = qsplit;
     sweep_tail_split(n_slabs, qsplit, blocks * 4, nQT, &n_main, &qtail);
-#define SNK_C16(NTC_, KB_)                                                                                          \
-    hipLaunchKernelGGL((knn_coarse16b<NTC_, KB_>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)A16,     \
+#define SNK_C16(NTC_, KB_, WPS_)                                                                                    \
+    hipLaunchKernelGGL((knn_coarse16b<NTC_, KB_, WPS_>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)A16, \
                        (const u32x4 *)B16, thr1, nQT, n_tiles, n_slabs, ctr, qsplit, n_main, qtail,                 \
                        (CoarsePair *)pairs, pair_ctl, pair_cap)
 #define SNK_R16(KB_, TERMS_)                                                                                        \
     hipLaunchKernelGGL((knn_refine16b<KB_, TERMS_>), dim3((unsigned)((KB_ <= 4 ? 2 : 1) * grid_cus)), dim3(256), 0, s, \
                        (const u32x4 *)A16, (const u32x4 *)B16, thr32, (const CoarsePair *)pairs, pair_ctl, pair_cap, \
                        (PoolEntry16 *)pool, pool_ctl, chunk_fill, max_chunks, pool_chunk)
-    if (dch == 1) { SNK_C16(8, 4); if (terms == 4) SNK_R16(4, 4); else SNK_R16(4, 3); return true; }
-    if (dch == 2) { SNK_C16(4, 8); if (terms == 4) SNK_R16(8, 4); else SNK_R16(8, 3); return true; }
-    if (dch == 3) { SNK_C16(4, 12); if (terms == 4) SNK_R16(12, 4); else SNK_R16(12, 3); return true; }
+    if (dch == 1) { if (wps == 2) SNK_C16(4, 4, 2); else SNK_C16(8, 4, 1); if (terms == 4) SNK_R16(4, 4); else SNK_R16(4, 3); return true; }
+    if (dch == 2) { SNK_C16(4, 8, 1); if (terms == 4) SNK_R16(8, 4); else SNK_R16(8, 3); return true; }
+    if (dch == 3) { SNK_C16(4, 12, 1); if (terms == 4) SNK_R16(12, 4); else SNK_R16(12, 3); return true; }
 #undef SNK_C16
 #undef SNK_R16
     return false;
