@@ -185,7 +185,7 @@ struct UttSlot {      // per in-flight utterance workspace (batch pipeline uses 
 
 struct BatchSlot {    // one submitted batch (snk_knn_viterbi_batch_submit / _collect): two may be in flight
     DevBuf Qall, cand, dist, path, plen, cost, status;
-    HostBuf stage;
+    HostBuf stage, qstage;                // results / query rows of this batch (pinned: the copies are queued, not waited for)
     hipEvent_t done = nullptr;            // results of this batch are in `stage`
     bool busy = false;
     int n_utts = 0, n_groups = 0, K = 0, D = 0;
@@ -202,6 +202,7 @@ struct ShardTicket {   // one submitted step of the sharded search (snk_sharded_
     std::vector<int64_t> offs, ulo, uhi, rows_to, row0, own_off;
     DevBuf mcand, mdist, res_path, res_plen, res_cost, status;
     HostBuf stage;                                               // own results + status words, pinned: filled by the copy stream
+    HostBuf qstage;                                              // the query rows this rank uploads (pinned)
     hipEvent_t main_done = nullptr, side_done[2] = {nullptr, nullptr}, done = nullptr;
 };
 
@@ -262,6 +263,8 @@ struct snk_engine {
     int f16_fallbacks = 0;
     int last_f16_status = 0;
     HostBuf hstage;
+    HostBuf up;                   // upload staging (h2d): pinned, bump-allocated, wraps behind a stream wait
+    size_t up_used = 0;
     // greedy
     GreedyLayout glay{};
     bool have_glay = false, gtiles_ready = false;
@@ -380,6 +383,109 @@ static int staged_d2h(snk_engine *h, hipStream_t st, const D2HPart *parts, int n
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Host <-> device copies.  The GPU (its DMA engines, the runtime's copy kernels) only ever touches page-locked memory
+// that THIS library allocated (hipHostMalloc) or that the caller registered (snk_host_register): caller buffers are
+// ordinary pageable memory (numpy arrays, stack variables), and handing those to hipMemcpyAsync makes the runtime pin
+// and map them on the fly -- a process that frees and reuses such memory all the time (a Python test session, a tuning
+// loop) was seen to die with "Memory access fault by GPU node ... on address <an address of the host heap>" inside an
+// unrelated call.  Uploads go caller -> pinned staging (memcpy) -> device, results device ->
+// pinned staging -> caller (staged_d2h).
+// ---------------------------------------------------------------------------
+static bool host_memory_is_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+// the engine's upload staging: a bump allocator over one pinned buffer; it wraps (after waiting for the stream: the
+// transfers queued so far read it) when full.  Transfers are queued on `st` (always the engine's main stream).
+static int h2d(snk_engine *h, void *dst_dev, const void *src_host, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return 0;
+    if (host_memory_is_pinned(src_host)) {                 // registered by the caller / pinned by us: a plain queued copy
+        HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
+        return 0;
+    }
+    const size_t chunk_max = (size_t)64 << 20;
+    const char *src = static_cast<const char *>(src_host);
+    char *dst = static_cast<char *>(dst_dev);
+    while (bytes) {
+        const size_t n = bytes < chunk_max ? bytes : chunk_max;
+        const size_t need = (n + 255) & ~(size_t)255;
+        if (h->up_used + need > h->up.bytes) {
+            HIPCHK(hipStreamSynchronize(st));              // everything queued out of the buffer has been read
+            h->up_used = 0;
+            if (need > h->up.bytes) CHK(h->up.ensure(need));
+        }
+        char *stage = static_cast<char *>(h->up.p) + h->up_used;
+        memcpy(stage, src, n);
+        HIPCHK(hipMemcpyAsync(dst, stage, n, hipMemcpyHostToDevice, st));
+        h->up_used += need;
+        src += n; dst += n; bytes -= n;
+    }
+    return 0;
+}
+
+// rows of row_bytes at src_pitch -> rows at dst_pitch (zero-filled padding); dst rows are contiguous at dst_pitch
+static int h2d_rows(snk_engine *h, void *dst_dev, size_t dst_pitch, const void *src_host, size_t src_pitch, size_t row_bytes,
+                    size_t n_rows, hipStream_t st)
+{
+    if (!n_rows || !row_bytes) return 0;
+    if (dst_pitch == src_pitch && dst_pitch == row_bytes) return h2d(h, dst_dev, src_host, row_bytes * n_rows, st);
+    size_t per = ((size_t)32 << 20) / dst_pitch;
+    if (per < 1) per = 1;
+    const char *src = static_cast<const char *>(src_host);
+    char *dst = static_cast<char *>(dst_dev);
+    for (size_t r0 = 0; r0 < n_rows; r0 += per) {
+        const size_t n = n_rows - r0 < per ? n_rows - r0 : per;
+        const size_t need = (n * dst_pitch + 255) & ~(size_t)255;
+        if (h->up_used + need > h->up.bytes) {
+            HIPCHK(hipStreamSynchronize(st));
+            h->up_used = 0;
+            if (need > h->up.bytes) CHK(h->up.ensure(need));
+        }
+        char *stage = static_cast<char *>(h->up.p) + h->up_used;
+        for (size_t r = 0; r < n; ++r) {
+            memcpy(stage + r * dst_pitch, src + (r0 + r) * src_pitch, row_bytes);
+            if (dst_pitch > row_bytes) memset(stage + r * dst_pitch + row_bytes, 0, dst_pitch - row_bytes);
+        }
+        HIPCHK(hipMemcpyAsync(dst + r0 * dst_pitch, stage, n * dst_pitch, hipMemcpyHostToDevice, st));
+        h->up_used += need;
+    }
+    return 0;
+}
+
+// small synchronous upload (weights, masks, counters): staged, waited for
+static int h2d_sync(snk_engine *h, void *dst_dev, const void *src_host, size_t bytes)
+{
+    CHK(h2d(h, dst_dev, src_host, bytes, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// one device -> host transfer through the pinned staging, waited for
+static int d2h_sync(snk_engine *h, void *dst_host, const void *src_dev, size_t bytes, hipStream_t st)
+{
+    const D2HPart part = {dst_host, src_dev, bytes};
+    return staged_d2h(h, st, &part, 1);
+}
+
+// an upload whose staging must outlive the call (submit / collect): the caller's own pinned buffer takes the copy
+static int h2d_via(HostBuf &stage, void *dst_dev, const void *src_host, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return 0;
+    if (host_memory_is_pinned(src_host)) {
+        HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
+        return 0;
+    }
+    CHK(stage.ensure(bytes));
+    memcpy(stage.p, src_host, bytes);
+    HIPCHK(hipMemcpyAsync(dst_dev, stage.p, bytes, hipMemcpyHostToDevice, st));
+    return 0;
+}
+
 static int no_batch_in_flight(snk_engine *h, const char *who);
 static int create_streams(snk_engine *h);
 static bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts);
@@ -424,8 +530,8 @@ int snk_create(int device_id, snk_handle *out)
     h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (h->slabctr.ensure(64)) { delete h; return 1; }
     if (h->margin_stat.ensure(2 * sizeof(unsigned int))) { delete h; return 1; }
-    { const unsigned int init[2] = {0u, 0x7f800000u}; (void)hipMemcpy(h->margin_stat.p, init, sizeof(init), hipMemcpyHostToDevice); }
-    const int rc = create_streams(h);
+    int rc = create_streams(h);
+    if (!rc) { const unsigned int init[2] = {0u, 0x7f800000u}; rc = h2d_sync(h, h->margin_stat.p, init, sizeof(init)); }
     if (rc) { (void)snk_destroy(h); return rc; }
     *out = h;
     return 0;
@@ -472,7 +578,7 @@ int snk_destroy(snk_handle h)
     h->res_path.release(); h->res_plen.release(); h->res_cost.release(); h->Qall.release();
     h->rowflag.release(); h->exact_rows.release(); h->exact_scratch.release();
     h->frames_spec.release(); h->frames_fzv.release(); h->cc_in.release(); h->cc_out.release();
-    h->res_status.release(); h->hstage.release();
+    h->res_status.release(); h->hstage.release(); h->up.release();
     { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b, &h->cq16, &h->rho16, &h->gs_rho16, &h->kth16, &h->margin_stat, &h->e1_16, &h->thr1_32, &h->cpairs, &h->cpairctl};
       for (auto *b : fb) b->release(); }
     for (int i = 0; i < 8; ++i) {
@@ -487,12 +593,12 @@ int snk_destroy(snk_handle h)
     if (h->knn_all_done) (void)hipEventDestroy(h->knn_all_done);
     for (auto &t : h->sticket) {
         t.mcand.release(); t.mdist.release(); t.res_path.release(); t.res_plen.release(); t.res_cost.release(); t.status.release();
-        t.stage.release();
+        t.stage.release(); t.qstage.release();
         if (t.done) (void)hipEventDestroy(t.done);
         if (t.main_done) (void)hipEventDestroy(t.main_done);
         for (int i = 0; i < 2; ++i) if (t.side_done[i]) (void)hipEventDestroy(t.side_done[i]);
     }
-    for (auto &b : h->bslot) { b.Qall.release(); b.cand.release(); b.dist.release(); b.path.release(); b.plen.release(); b.cost.release(); b.status.release(); b.stage.release(); if (b.done) (void)hipEventDestroy(b.done); }
+    for (auto &b : h->bslot) { b.Qall.release(); b.cand.release(); b.dist.release(); b.path.release(); b.plen.release(); b.cost.release(); b.status.release(); b.stage.release(); b.qstage.release(); if (b.done) (void)hipEventDestroy(b.done); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     delete h;
@@ -507,8 +613,8 @@ static int upload_join(snk_engine *h, const float *JC_unw, int64_t Njc, int Dj)
     CHK(h->JC_unw.ensure((size_t)Njc * h->Jp * sizeof(float)));
     if (h->Jp != Dj) HIPCHK(hipMemsetAsync(h->JC_unw.p, 0, (size_t)Njc * h->Jp * sizeof(float), h->stream));
     CHK(h->JCw.ensure((size_t)Njc * h->Djpad * sizeof(double)));
-    HIPCHK(hipMemcpy2DAsync(h->JC_unw.p, (size_t)h->Jp * sizeof(float), JC_unw, (size_t)Dj * sizeof(float),
-                            (size_t)Dj * sizeof(float), (size_t)Njc, hipMemcpyHostToDevice, h->stream));
+    CHK(h2d_rows(h, h->JC_unw.p, (size_t)h->Jp * sizeof(float), JC_unw, (size_t)Dj * sizeof(float), (size_t)Dj * sizeof(float),
+                 (size_t)Njc, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_join = true;
     h->have_weights = false;
@@ -538,8 +644,8 @@ int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt, const flo
     if (h->Fp != Dt) HIPCHK(hipMemsetAsync(h->F_unw.p, 0, (size_t)N * h->Fp * sizeof(float), h->stream));
     CHK(h->Fw.ensure((size_t)h->Nalloc * h->Dpad * sizeof(double)));
     CHK(h->fnorm.ensure((size_t)h->Nalloc * sizeof(double)));
-    HIPCHK(hipMemcpy2DAsync(h->F_unw.p, (size_t)h->Fp * sizeof(float), F_unw, (size_t)Dt * sizeof(float),
-                            (size_t)Dt * sizeof(float), (size_t)N, hipMemcpyHostToDevice, h->stream));
+    CHK(h2d_rows(h, h->F_unw.p, (size_t)h->Fp * sizeof(float), F_unw, (size_t)Dt * sizeof(float), (size_t)Dt * sizeof(float),
+                 (size_t)N, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_db = true;
     h->have_weights = false;
@@ -598,7 +704,7 @@ int snk_set_column_selection(snk_handle h, const int *tcols, int nt, const int *
     CHK(build(jcols, nj, h->have_join ? h->Dj : 0, h->jsel, "join"));
     if (!h->tsel.empty()) {
         CHK(h->tmask.ensure(h->tsel.size() * sizeof(double)));
-        HIPCHK(hipMemcpy(h->tmask.p, h->tsel.data(), h->tsel.size() * sizeof(double), hipMemcpyHostToDevice));
+        CHK(h2d_sync(h, h->tmask.p, h->tsel.data(), h->tsel.size() * sizeof(double)));
     }
     h->have_weights = false;                 // takes effect with the next snk_set_weights
     return 0;
@@ -619,7 +725,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
             if ((int)h->tsel.size() != n_wt) return fail("snk_set_weights: the target column selection was made for %d columns", (int)h->tsel.size());
             for (int c = 0; c < n_wt; ++c) eff[(size_t)c] *= h->tsel[(size_t)c];
         }
-        HIPCHK(hipMemcpy(h->wt.p, eff.data(), (size_t)n_wt * sizeof(double), hipMemcpyHostToDevice));
+        CHK(h2d_sync(h, h->wt.p, eff.data(), (size_t)n_wt * sizeof(double)));
     }
     if (h->have_join) {
         if (!wj || n_wj != h->Dj)
@@ -630,7 +736,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
             if ((int)h->jsel.size() != n_wj) return fail("snk_set_weights: the join column selection was made for %d columns", (int)h->jsel.size());
             for (int c = 0; c < n_wj; ++c) eff[(size_t)c] *= h->jsel[(size_t)c];
         }
-        HIPCHK(hipMemcpy(h->wj.p, eff.data(), (size_t)n_wj * sizeof(double), hipMemcpyHostToDevice));
+        CHK(h2d_sync(h, h->wj.p, eff.data(), (size_t)n_wj * sizeof(double)));
     }
     {
         StageTimer t(h, h->stream, TM_WEIGHTS);
@@ -658,8 +764,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
         CHK(h->fmax2.ensure(sizeof(double)));
         launch_fmax(h->fnorm.as<double>(), h->N, h->fmax2.as<double>(), h->stream);
         double fmax2 = 0.0;
-        HIPCHK(hipMemcpyAsync(&fmax2, h->fmax2.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        CHK(d2h_sync(h, &fmax2, h->fmax2.p, sizeof(double), h->stream));
         const int64_t slab_rows = 32 * nt;
         h->n_slabs16 = (h->N + slab_rows - 1) / slab_rows;
         int64_t stride = (int64_t)floor(1.0 / h->sample_frac + 0.5);
@@ -747,8 +852,8 @@ int snk_upload_global_sample(snk_handle h, const float *F_sample_unw, int64_t n_
     if (!F_sample_unw || n_rows < 1 || Dt != h->Dt) return fail("snk_upload_global_sample: bad sample matrix (rows=%lld Dt=%d, database Dt=%d)", (long long)n_rows, Dt, h->Dt);
     CHK(h->gs_unw.ensure((size_t)n_rows * h->Fp * sizeof(float)));
     if (h->Fp != Dt) HIPCHK(hipMemsetAsync(h->gs_unw.p, 0, (size_t)n_rows * h->Fp * sizeof(float), h->stream));
-    HIPCHK(hipMemcpy2DAsync(h->gs_unw.p, (size_t)h->Fp * sizeof(float), F_sample_unw, (size_t)Dt * sizeof(float),
-                            (size_t)Dt * sizeof(float), (size_t)n_rows, hipMemcpyHostToDevice, h->stream));
+    CHK(h2d_rows(h, h->gs_unw.p, (size_t)h->Fp * sizeof(float), F_sample_unw, (size_t)Dt * sizeof(float), (size_t)Dt * sizeof(float),
+                 (size_t)n_rows, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->gs_rows = n_rows;
     h->gs_ready = false;
@@ -764,7 +869,7 @@ int snk_set_unit_classes(snk_handle h, const int32_t *unit_class, int64_t N)
     if (!h->have_db || N != h->N) return fail("snk_set_unit_classes: N=%lld does not match the database (%lld)", (long long)N, (long long)h->N);
     CHK(h->unit_class.ensure((size_t)h->Nalloc * sizeof(int32_t)));
     HIPCHK(hipMemsetAsync(h->unit_class.p, 0xff, (size_t)h->Nalloc * sizeof(int32_t), h->stream));
-    HIPCHK(hipMemcpyAsync(h->unit_class.p, unit_class, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, h->unit_class.p, unit_class, (size_t)N * sizeof(int32_t), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_classes = true;
     h->cls16_ready = false;
@@ -780,11 +885,11 @@ static int debug_check_pool(snk_engine *h, int max_chunks, int64_t Tpad, int64_t
 {
     HIPCHK(hipStreamSynchronize(s));
     unsigned int ctl[2] = {0, 0};
-    HIPCHK(hipMemcpy(ctl, h->poolctl.p, sizeof(ctl), hipMemcpyDeviceToHost));
+    CHK(d2h_sync(h, ctl, h->poolctl.p, sizeof(ctl), s));
     int used = (int)ctl[0];
     if (used > max_chunks) used = max_chunks;
     std::vector<int> fill((size_t)max_chunks);
-    HIPCHK(hipMemcpy(fill.data(), h->chunkfill.p, fill.size() * sizeof(int), hipMemcpyDeviceToHost));
+    CHK(d2h_sync(h, fill.data(), h->chunkfill.p, fill.size() * sizeof(int), s));
     struct E { double key; int idx; int row; };
     const int chunk = knn_pool_chunk_entries();
     std::vector<E> en((size_t)chunk);
@@ -793,7 +898,7 @@ static int debug_check_pool(snk_engine *h, int max_chunks, int64_t Tpad, int64_t
         const int n = fill[(size_t)c];
         if (n < 0 || n > chunk) { fprintf(stderr, "[snk-trace] pool: chunk %d of %d has fill %d (chunk size %d)\n", c, used, n, chunk); ++bad; continue; }
         if (n == 0) continue;
-        HIPCHK(hipMemcpy(en.data(), (const char *)h->pool.p + (size_t)c * chunk * sizeof(E), (size_t)n * sizeof(E), hipMemcpyDeviceToHost));
+        CHK(d2h_sync(h, en.data(), (const char *)h->pool.p + (size_t)c * chunk * sizeof(E), (size_t)n * sizeof(E), s));
         for (int e = 0; e < n; ++e) {
             ++total;
             if (en[(size_t)e].row < 0 || en[(size_t)e].row >= Tpad || en[(size_t)e].idx < 0 || en[(size_t)e].idx >= idx_limit) {
@@ -887,7 +992,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         for (int64_t r0 = 0; r0 < T; r0 += per) {
             const int n = (int)(T - r0 < per ? T - r0 : per);
             for (int i = 0; i < n; ++i) rows[(size_t)i] = (int)(r0 + i);
-            HIPCHK(hipMemcpyAsync(h->exact_rows.p, rows.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            CHK(h2d(h, h->exact_rows.p, rows.data(), (size_t)n * sizeof(int), h->stream));
             launch_knn_exact_rows(h->Fw.as<double>(), h->Dpad, h->Dt, h->N, h->Qp.as<double>(), h->exact_rows.as<int>(), n, K,
                                   h->exact_scratch.as<double>(), h->Nalloc, qclass_dev ? h->unit_class.as<int32_t>() : nullptr,
                                   qclass_dev, h->shard_offset, cand_dev, dist_dev, d2_dev, h->stream);
@@ -1065,8 +1170,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         }
         if (deferred_status) return 0;       // the batch caller redoes failures with precision 0
         int status = 0;
-        HIPCHK(hipMemcpyAsync(&status, h->status.p, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        CHK(d2h_sync(h, &status, h->status.p, sizeof(int), s));
         HIPCHK(hipGetLastError());
         h->last_f16_status = status;
         if (status == 0) return 0;
@@ -1137,8 +1241,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         }
         if (deferred_status) return 0;
         int status = 0;
-        HIPCHK(hipMemcpyAsync(&status, h->status.p, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        CHK(d2h_sync(h, &status, h->status.p, sizeof(int), s));
         HIPCHK(hipGetLastError());
         if (status == 0) return 0;
         if ((status & 5) && attempt == 0) continue;          // a list or the pool overflowed: exact thresholds next
@@ -1147,8 +1250,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         // one-workgroup-per-row exact selection (slow, exact, ties by lowest id).  If even the enlarged
         // pool overflowed, the sweep dropped entries of rows that cannot be told apart: every row goes.
         std::vector<int> flags((size_t)T);
-        HIPCHK(hipMemcpyAsync(flags.data(), h->rowflag.p, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        CHK(d2h_sync(h, flags.data(), h->rowflag.p, (size_t)T * sizeof(int), s));
         std::vector<int> rows;
         for (int64_t t = 0; t < T; ++t) if (flags[(size_t)t] || (status & 4)) rows.push_back((int)t);
         if (status & 4) h->pool_overflows += 1;
@@ -1157,7 +1259,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             const int n = (int)((rows.size() - r0 < 64) ? rows.size() - r0 : 64);
             CHK(h->exact_rows.ensure((size_t)64 * sizeof(int)));
             CHK(h->exact_scratch.ensure((size_t)64 * h->Nalloc * sizeof(double)));
-            HIPCHK(hipMemcpyAsync(h->exact_rows.p, rows.data() + r0, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+            CHK(h2d(h, h->exact_rows.p, rows.data() + r0, (size_t)n * sizeof(int), s));
             launch_knn_exact_rows(h->Fw.as<double>(), h->Dpad, h->Dt, h->N, h->Qp.as<double>(), h->exact_rows.as<int>(), n, K,
                                   h->exact_scratch.as<double>(), h->Nalloc, uc, qclass_dev, h->shard_offset,
                                   cand_dev, dist_dev, d2_dev, s);
@@ -1196,7 +1298,7 @@ static int upload_queries(snk_engine *h, const double *Q, int64_t T, int D)
     if (T < 1) return fail("query matrix has no rows");
     CHK(h->Qraw.ensure((size_t)T * D * sizeof(double)));
     StageTimer t(h, h->stream, TM_H2D);
-    HIPCHK(hipMemcpyAsync(h->Qraw.p, Q, (size_t)T * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, h->Qraw.p, Q, (size_t)T * D * sizeof(double), h->stream));
     if (!h->tsel.empty()) launch_mask_columns(h->Qraw.as<double>(), T, D, h->tmask.as<double>(), h->stream);
     return 0;
 }
@@ -1285,9 +1387,10 @@ int snk_prefilter_minima(snk_handle h, const double *Q, int64_t T, int D, float 
     }
     HIPCHK(hipGetLastError());
     std::vector<float> g((size_t)T * G16);
-    HIPCHK(hipMemcpyAsync(g.data(), h->gmin32.p, g.size() * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(eps_out, h->eps16.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    {
+        D2HPart parts[2] = {{g.data(), h->gmin32.p, g.size() * sizeof(float)}, {eps_out, h->eps16.p, (size_t)T * sizeof(double)}};
+        CHK(staged_d2h(h, s, parts, 2));
+    }
     for (int64_t t = 0; t < T; ++t)
         for (int64_t w = 0; w < n_slabs; ++w) {
             const float a = g[t * G16 + 2 * w], b = g[t * G16 + 2 * w + 1];
@@ -1308,14 +1411,15 @@ int snk_knn_by_class(snk_handle h, const double *Q, int64_t T, int D, int K, con
     const int64_t Tpad = roundup(T, 32);
     CHK(h->qclass.ensure((size_t)Tpad * sizeof(int32_t)));
     HIPCHK(hipMemsetAsync(h->qclass.p, 0xfe, (size_t)Tpad * sizeof(int32_t), h->stream));
-    HIPCHK(hipMemcpyAsync(h->qclass.p, query_class, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, h->qclass.p, query_class, (size_t)T * sizeof(int32_t), h->stream));
     UttSlot &s = h->slot[0];
     CHK(s.cand.ensure((size_t)T * K * sizeof(int64_t)));
     CHK(s.tdist.ensure((size_t)T * K * sizeof(double)));
     CHK(knn_device(h, h->Qraw.as<double>(), T, K, h->qclass.as<int32_t>(), s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
-    HIPCHK(hipMemcpyAsync(cand_out, s.cand.p, (size_t)T * K * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(dist_out, s.tdist.p, (size_t)T * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    {
+        D2HPart parts[2] = {{cand_out, s.cand.p, (size_t)T * K * sizeof(int64_t)}, {dist_out, s.tdist.p, (size_t)T * K * sizeof(double)}};
+        CHK(staged_d2h(h, h->stream, parts, 2));
+    }
     collect_timers(h);
     return 0;
 }
@@ -1336,7 +1440,7 @@ int snk_candidate_distances(snk_handle h, const double *Q, int64_t T, int D, con
     CHK(s.tdist.ensure((size_t)T * K * sizeof(double)));
     launch_prepare_queries(h->Qraw.as<double>(), T, h->Dt, h->Qp.as<double>(), h->Qf.as<double>(), h->qnorm.as<double>(),
                            Tpad, h->Dpad, h->stream);
-    HIPCHK(hipMemcpyAsync(s.cand.p, cand, (size_t)T * K * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, s.cand.p, cand, (size_t)T * K * sizeof(int64_t), h->stream));
     launch_candidate_dist(h->Fw.as<double>(), h->Dpad, h->Dt, h->N, h->Qp.as<double>(), s.cand.as<int64_t>(), T, K,
                           s.tdist.as<double>(), h->stream);
     HIPCHK(hipGetLastError());
@@ -1451,15 +1555,14 @@ int snk_join_costs(snk_handle h, const int64_t *cand, int64_t T, int K, double *
     UttSlot &s = h->slot[0];
     CHK(slot_ensure(h, s, T, K));
     CHK(s.J.ensure((size_t)(T - 1) * K * K * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(s.cand.p, cand, (size_t)T * K * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, s.cand.p, cand, (size_t)T * K * sizeof(int64_t), h->stream));
     {
         StageTimer t(h, h->stream, TM_JOIN);
         launch_join_costs(h->JCw.as<double>(), h->Djpad, h->Dj, join_units(h), s.cand.as<int64_t>(), T, K,
                           s.J.as<double>(), h->stream);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(J_out, s.J.p, (size_t)(T - 1) * K * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(d2h_sync(h, J_out, s.J.p, (size_t)(T - 1) * K * K * sizeof(double), h->stream));
     collect_timers(h);
     return 0;
 }
@@ -1474,15 +1577,16 @@ int snk_viterbi(snk_handle h, const int64_t *cand, const double *tdist, int64_t 
     if (T < 1 || K < 1) return fail("snk_viterbi: empty trellis");
     UttSlot &s = h->slot[0];
     CHK(slot_ensure(h, s, T, K));
-    HIPCHK(hipMemcpyAsync(s.cand.p, cand, (size_t)T * K * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(s.tdist.p, tdist, (size_t)T * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, s.cand.p, cand, (size_t)T * K * sizeof(int64_t), h->stream));
+    CHK(h2d(h, s.tdist.p, tdist, (size_t)T * K * sizeof(double), h->stream));
     CHK(viterbi_device(h, s, T, K, h->stream));
     HIPCHK(hipGetLastError());
     double cost = 0;
-    HIPCHK(hipMemcpyAsync(path_len_out, s.plen.p, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(&cost, s.cost.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(path_out, s.path.p, (size_t)T * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    {
+        D2HPart parts[3] = {{path_len_out, s.plen.p, sizeof(int64_t)}, {&cost, s.cost.p, sizeof(double)},
+                            {path_out, s.path.p, (size_t)T * sizeof(int64_t)}};
+        CHK(staged_d2h(h, h->stream, parts, 3));
+    }
     if (cost_out) *cost_out = cost;
     collect_timers(h);
     return 0;
@@ -1657,7 +1761,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     CHK(b.stage.ensure(sz_path + 2 * sz_u + sz_st));
     {
         StageTimer t(h, h->stream, TM_H2D);
-        HIPCHK(hipMemcpyAsync(b.Qall.p, Q, (size_t)total * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        CHK(h2d_via(b.qstage, b.Qall.p, Q, (size_t)total * D * sizeof(double), h->stream));
         if (!h->tsel.empty()) launch_mask_columns(b.Qall.as<double>(), total, D, h->tmask.as<double>(), h->stream);
     }
     for (int g = 0; g < b.n_groups; ++g) {
@@ -1806,8 +1910,7 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
                 CHK(h->gh_max.ensure(64));
                 launch_hoist_window_norms(g, h->fnorm.as<double>(), h->gh_nw.as<double>(), h->gh_max.as<unsigned long long>(), h->stream);
                 HIPCHK(hipGetLastError());
-                HIPCHK(hipMemcpyAsync(&h->gh_fwmax2, h->gh_max.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(hipStreamSynchronize(h->stream));
+                CHK(d2h_sync(h, &h->gh_fwmax2, h->gh_max.p, sizeof(double), h->stream));
                 h->gh_ready = true;
             }
             CHK(h->gh_aq.ensure((size_t)prows * KA * sizeof(double)));
@@ -1833,8 +1936,7 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
                     launch_greedy_tiles16(g, h->JC_unw.as<float>(), h->Jp, h->gtiles16.p, mx, h->stream);
                     HIPCHK(hipGetLastError());
                     float mabs = 0.f;
-                    HIPCHK(hipMemcpyAsync(&mabs, mx, sizeof(float), hipMemcpyDeviceToHost, h->stream));
-                    HIPCHK(hipStreamSynchronize(h->stream));
+                    CHK(d2h_sync(h, &mabs, mx, sizeof(float), h->stream));
                     h->gt16_ok = mabs < 6.0e4f;
                     h->gt16_ready = true;
                 }
@@ -1844,8 +1946,7 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
                     launch_greedy_join_norms(g, h->gtiles.as<float>(), h->wj.as<double>(), o2, h->stream);
                     HIPCHK(hipGetLastError());
                     double v[2] = {0.0, 0.0};
-                    HIPCHK(hipMemcpyAsync(v, o2, sizeof(v), hipMemcpyDeviceToHost, h->stream));
-                    HIPCHK(hipStreamSynchronize(h->stream));
+                    CHK(d2h_sync(h, v, o2, sizeof(v), h->stream));
                     h->g16_delta = 4.8828125e-4 * sqrt(v[0]) + 2.98023223876953125e-8 * sqrt(v[1]);
                     h->gj_ready = true;
                 }
@@ -1889,8 +1990,7 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
                     status, h->gpath.as<int64_t>(), hoist ? &hst : nullptr, h->stream);
     HIPCHK(hipGetLastError());
     int64_t stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};         // undecided step + 1 | second-phase rounds | windows decided by exact totals | watchdog | (resident scan: why)
-    HIPCHK(hipMemcpyAsync(stv, status, sizeof(stv), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(d2h_sync(h, stv, status, sizeof(stv), h->stream));
     greedy32_trace_dump();
     greedy_res_trace_dump();
     *undecided = stv[0] != 0;
@@ -1970,10 +2070,10 @@ int snk_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_st
     HIPCHK(hipGetLastError());
     {
         StageTimer t(h, h->stream, TM_D2H);
-        HIPCHK(hipMemcpyAsync(path_out, h->gpath.p, (size_t)nsteps * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-        if (dist_out) HIPCHK(hipMemcpyAsync(dist_out, h->gdist.p, (size_t)nsteps * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        D2HPart parts[2] = {{path_out, h->gpath.p, (size_t)nsteps * sizeof(int64_t)},
+                            {dist_out, h->gdist.p, dist_out ? (size_t)nsteps * sizeof(double) : 0}};
+        CHK(staged_d2h(h, h->stream, parts, 2));
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
     collect_timers(h);
     return 0;
 }
@@ -2058,10 +2158,10 @@ int snk_greedy_batch(snk_handle h, const double *Q, const int64_t *row_offsets, 
     HIPCHK(hipGetLastError());
     {
         StageTimer t(h, h->stream, TM_D2H);
-        HIPCHK(hipMemcpyAsync(path_out, h->gpath.p, (size_t)total_steps * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-        if (dist_out) HIPCHK(hipMemcpyAsync(dist_out, h->gdist.p, (size_t)total_steps * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        D2HPart parts[2] = {{path_out, h->gpath.p, (size_t)total_steps * sizeof(int64_t)},
+                            {dist_out, h->gdist.p, dist_out ? (size_t)total_steps * sizeof(double) : 0}};
+        CHK(staged_d2h(h, h->stream, parts, 2));
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
     collect_timers(h);
     return 0;
 }
@@ -2086,17 +2186,18 @@ int snk_path_scores(snk_handle h, const double *Q, const int64_t *path, int64_t 
     const size_t tbytes = (size_t)L * nep * h->Dt * sizeof(double);
     const size_t jbytes = (size_t)(L > 1 ? L - 1 : 1) * jcols * sizeof(double);
     CHK(h->d2tmp.ensure(tbytes + jbytes));
-    HIPCHK(hipMemcpyAsync(h->Qraw.p, Q, qrows * h->Dt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, h->Qraw.p, Q, qrows * h->Dt * sizeof(double), h->stream));
     if (!h->tsel.empty()) launch_mask_columns(h->Qraw.as<double>(), (int64_t)qrows, h->Dt, h->tmask.as<double>(), h->stream);
-    HIPCHK(hipMemcpyAsync(h->gpath.p, path, (size_t)L * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, h->gpath.p, path, (size_t)L * sizeof(int64_t), h->stream));
     double *tsq = h->d2tmp.as<double>();
     double *jsq = reinterpret_cast<double *>(reinterpret_cast<char *>(h->d2tmp.p) + tbytes);
     launch_path_scores(g, mode, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
                        h->wj.as<double>(), h->Qraw.as<double>(), h->gpath.as<int64_t>(), L, tsq, jsq, jcols, h->stream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(tsq_out, tsq, tbytes, hipMemcpyDeviceToHost, h->stream));
-    if (jsq_out && L > 1) HIPCHK(hipMemcpyAsync(jsq_out, jsq, (size_t)(L - 1) * jcols * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    {
+        D2HPart parts[2] = {{tsq_out, tsq, tbytes}, {jsq_out, jsq, (jsq_out && L > 1) ? (size_t)(L - 1) * jcols * sizeof(double) : 0}};
+        CHK(staged_d2h(h, h->stream, parts, 2));
+    }
     return 0;
 }
 
@@ -2128,9 +2229,10 @@ int snk_merge_topk_dev(snk_handle h, const double *d2_dev, const int64_t *id_dev
     CHK(s.tdist.ensure((size_t)T * K * sizeof(double)));
     launch_merge_topk(d2_dev, id_dev, G, T, K, s.cand.as<int64_t>(), s.tdist.as<double>(), h->stream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(cand_out, s.cand.p, (size_t)T * K * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(dist_out, s.tdist.p, (size_t)T * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    {
+        D2HPart parts[2] = {{cand_out, s.cand.p, (size_t)T * K * sizeof(int64_t)}, {dist_out, s.tdist.p, (size_t)T * K * sizeof(double)}};
+        CHK(staged_d2h(h, h->stream, parts, 2));
+    }
     return 0;
 }
 
@@ -2144,7 +2246,7 @@ static int upload_batch_queries(snk_engine *h, const double *Q, int64_t total, i
 {
     CHK(h->Qall.ensure((size_t)total * D * sizeof(double)));
     StageTimer t(h, h->stream, TM_H2D);
-    HIPCHK(hipMemcpyAsync(h->Qall.p, Q, (size_t)total * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, h->Qall.p, Q, (size_t)total * D * sizeof(double), h->stream));
     if (!h->tsel.empty()) launch_mask_columns(h->Qall.as<double>(), total, D, h->tmask.as<double>(), h->stream);
     h->qall_rows = total;
     return 0;
@@ -2190,8 +2292,7 @@ static int knn_local_batch(snk_engine *h, const char *who, const double *Q, cons
         return 0;
     }
     std::vector<int> st((size_t)n_groups);
-    HIPCHK(hipMemcpyAsync(st.data(), h->res_status.p, (size_t)n_groups * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(d2h_sync(h, st.data(), h->res_status.p, (size_t)n_groups * sizeof(int), h->stream));
     HIPCHK(hipGetLastError());
     for (int g = 0; g < n_groups; ++g) {
         if (st[g] == 0) continue;
@@ -2300,8 +2401,8 @@ int snk_viterbi_batch(snk_handle h, const int64_t *cand, const double *tdist, co
     CHK(h->res_cost.ensure((size_t)n_utts * sizeof(double)));
     {
         StageTimer t(h, h->stream, TM_H2D);
-        HIPCHK(hipMemcpyAsync(h->mcand.p, cand, (size_t)total * K * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->mdist.p, tdist, (size_t)total * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        CHK(h2d(h, h->mcand.p, cand, (size_t)total * K * sizeof(int64_t), h->stream));
+        CHK(h2d(h, h->mdist.p, tdist, (size_t)total * K * sizeof(double), h->stream));
     }
     {
         const std::vector<int> first = group_utterances(h, row_offsets, n_utts);
@@ -2480,17 +2581,35 @@ int snk_comm_destroy(snk_handle h)
     return 0;
 }
 
+// (no engine in these two signatures: a process-wide pinned bounce buffer, one transfer at a time)
+static std::mutex g_bounce_lock;
+static HostBuf g_bounce;
+
 int snk_copy_to_host(void *dst_host, const void *src_dev, int64_t bytes)
 {
     if (bytes < 0 || (bytes && (!dst_host || !src_dev))) return fail("snk_copy_to_host: bad arguments");
-    if (bytes) HIPCHK(hipMemcpy(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost));
+    std::lock_guard<std::mutex> lock(g_bounce_lock);
+    const size_t chunk = (size_t)64 << 20;
+    for (size_t off = 0; off < (size_t)bytes; off += chunk) {
+        const size_t n = (size_t)bytes - off < chunk ? (size_t)bytes - off : chunk;
+        CHK(g_bounce.ensure(n));
+        HIPCHK(hipMemcpy(g_bounce.p, (const char *)src_dev + off, n, hipMemcpyDeviceToHost));
+        memcpy((char *)dst_host + off, g_bounce.p, n);
+    }
     return 0;
 }
 
 int snk_copy_to_device(void *dst_dev, const void *src_host, int64_t bytes)
 {
     if (bytes < 0 || (bytes && (!dst_dev || !src_host))) return fail("snk_copy_to_device: bad arguments");
-    if (bytes) HIPCHK(hipMemcpy(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice));
+    std::lock_guard<std::mutex> lock(g_bounce_lock);
+    const size_t chunk = (size_t)64 << 20;
+    for (size_t off = 0; off < (size_t)bytes; off += chunk) {
+        const size_t n = (size_t)bytes - off < chunk ? (size_t)bytes - off : chunk;
+        CHK(g_bounce.ensure(n));
+        memcpy(g_bounce.p, (const char *)src_host + off, n);
+        HIPCHK(hipMemcpy((char *)dst_dev + off, g_bounce.p, n, hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -2512,7 +2631,7 @@ static int upload_queries_gathered(snk_engine *h, const ShardTicket &t, const do
         StageTimer tm(h, h->stream, TM_H2D);
         const int64_t a = t.row0[(size_t)me];
         if (t.r_own > 0)
-            HIPCHK(hipMemcpyAsync(h->Qall.as<double>() + a * D, Q + a * D, (size_t)t.r_own * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            CHK(h2d(h, h->Qall.as<double>() + a * D, Q + a * D, (size_t)t.r_own * D * sizeof(double), h->stream));
     }
     std::vector<int64_t> soff((size_t)G), sb((size_t)G), roff((size_t)G), rb((size_t)G);
     for (int p = 0; p < G; ++p) {
@@ -2680,11 +2799,10 @@ static int sharded_collect(snk_engine *h, ShardTicket &t, int64_t *path_out, int
         memcpy(&r[3], own_path + t.own_off[(size_t)j], (size_t)own_len[j] * sizeof(int64_t));
     }
     if (n_own == 0 && slots > 0) mine[2] = status;
-    HIPCHK(hipMemcpyAsync(h->sh_res.p, mine.data(), mine.size() * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, h->sh_res.p, mine.data(), mine.size() * sizeof(int64_t), h->stream));
     CHK(comm_all_gather(h, h->sh_res.p, h->sh_resall.p, (int64_t)(mine.size() * sizeof(int64_t))));
     std::vector<int64_t> all((size_t)G * mine.size());
-    HIPCHK(hipMemcpyAsync(all.data(), h->sh_resall.p, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(d2h_sync(h, all.data(), h->sh_resall.p, all.size() * sizeof(int64_t), h->stream));
     bool any_bad = false;
     for (int r = 0; r < G; ++r) {
         const int64_t *blk = all.data() + (size_t)r * mine.size();
@@ -2805,8 +2923,8 @@ int snk_upload_frames(snk_handle h, const float *spec, const double *fzv, int64_
     const size_t W = (size_t)3 * H;
     CHK(h->frames_spec.ensure((size_t)rows * W * sizeof(float)));
     CHK(h->frames_fzv.ensure((size_t)rows * 2 * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(h->frames_spec.p, spec, (size_t)rows * W * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->frames_fzv.p, fzv, (size_t)rows * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, h->frames_spec.p, spec, (size_t)rows * W * sizeof(float), h->stream));
+    CHK(h2d(h, h->frames_fzv.p, fzv, (size_t)rows * 2 * sizeof(double), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->frames_rows = rows;
     h->frames_W = (int)W;
@@ -2841,17 +2959,18 @@ int snk_concat_fragments(snk_handle h, const int64_t *first_row, const int64_t *
     CHK(h->cc_out.ensure((size_t)rows_out * (W + 1) * sizeof(double)));
     int64_t *d_first = h->cc_in.as<int64_t>(), *d_lo = d_first + n, *d_hi = d_lo + n;
     double *d_taper = reinterpret_cast<double *>(d_hi + n);
-    HIPCHK(hipMemcpyAsync(d_first, first_row, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d_lo, utt_lo, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d_hi, utt_hi, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    if (overlap > 0) HIPCHK(hipMemcpyAsync(d_taper, in_taper, (size_t)overlap * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, d_first, first_row, (size_t)n * sizeof(int64_t), h->stream));
+    CHK(h2d(h, d_lo, utt_lo, (size_t)n * sizeof(int64_t), h->stream));
+    CHK(h2d(h, d_hi, utt_hi, (size_t)n * sizeof(int64_t), h->stream));
+    if (overlap > 0) CHK(h2d(h, d_taper, in_taper, (size_t)overlap * sizeof(double), h->stream));
     double *d_spec = h->cc_out.as<double>(), *d_fz = d_spec + (size_t)rows_out * W;
     launch_concat_fragments(h->frames_spec.as<float>(), (int)W, h->frames_fzv.as<double>(), d_first, d_lo, d_hi, n,
                             multiepoch, overlap, d_taper, d_spec, d_fz, h->stream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(spec_out, d_spec, (size_t)rows_out * W * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(fz_out, d_fz, (size_t)rows_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    {
+        D2HPart parts[2] = {{spec_out, d_spec, (size_t)rows_out * W * sizeof(double)}, {fz_out, d_fz, (size_t)rows_out * sizeof(double)}};
+        CHK(staged_d2h(h, h->stream, parts, 2));
+    }
     return 0;
 }
 
@@ -2879,7 +2998,7 @@ int snk_reset_timers(snk_handle h)
         const unsigned int init[2] = {0u, 0x7f800000u};
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipMemcpy(h->margin_stat.p, init, sizeof(init), hipMemcpyHostToDevice));
+        CHK(h2d_sync(h, h->margin_stat.p, init, sizeof(init)));
     }
     return 0;
 }
@@ -3002,18 +3121,18 @@ int snk_get_info(snk_handle h, const char *name, double *out)
         // statistics of the most recent float32 scan launch: steps that needed every lane's candidates; windows
         // whose canonical float64 totals decided a step
         int64_t v[3] = {0, 0, 0};
-        if (h->g32_ctl.p) HIPCHK(hipMemcpy(v, reinterpret_cast<char *>(h->g32_ctl.p) + 16, sizeof(v), hipMemcpyDeviceToHost));
+        if (h->g32_ctl.p) CHK(d2h_sync(h, v, reinterpret_cast<char *>(h->g32_ctl.p) + 16, sizeof(v), h->stream));
         *out = (double)v[!strcmp(name, "greedy_exact_windows") ? 2 : 1];
     }
     else if (!strcmp(name, "dense_cells") || !strcmp(name, "dense_steps") || !strcmp(name, "dense_exact_costs") || !strcmp(name, "set_overflows")) {
         unsigned long long v[4] = {0, 0, 0, 0};
-        if (h->vstats.p) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipMemcpy(v, h->vstats.p, sizeof(v), hipMemcpyDeviceToHost)); }
+        if (h->vstats.p) { HIPCHK(hipDeviceSynchronize()); CHK(d2h_sync(h, v, h->vstats.p, sizeof(v), h->stream)); }
         *out = (double)v[!strcmp(name, "dense_steps") ? 1 : (!strcmp(name, "dense_exact_costs") ? 2 : (!strcmp(name, "set_overflows") ? 3 : 0))];
     }
     else if (!strcmp(name, "f16_ready")) *out = h->f16_ready ? 1 : 0;
     else if (!strcmp(name, "f16_fallbacks")) *out = h->f16_fallbacks;
     else if (!strcmp(name, "last_f16_status")) *out = h->last_f16_status;
-    else if (!strcmp(name, "pool_chunks_used")) { unsigned int v[2] = {0, 0}; HIPCHK(hipMemcpy(v, h->poolctl.p, sizeof(v), hipMemcpyDeviceToHost)); *out = v[0] + 1e6 * v[1]; }
+    else if (!strcmp(name, "pool_chunks_used")) { unsigned int v[2] = {0, 0}; CHK(d2h_sync(h, v, h->poolctl.p, sizeof(v), h->stream)); *out = v[0] + 1e6 * v[1]; }
     else if (!strcmp(name, "precision")) *out = h->precision;
     else if (!strcmp(name, "prefilter")) *out = h->prefilter;
     else if (!strcmp(name, "prefilter_bf16_active")) *out = h->bf16_ready ? 1 : 0;
@@ -3023,7 +3142,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
         if (h->bf16_ready && h->rho16.p) {
             HIPCHK(hipSetDevice(h->device));
             HIPCHK(hipStreamSynchronize(h->stream));
-            HIPCHK(hipMemcpy(rho, h->rho16.p, sizeof(rho), hipMemcpyDeviceToHost));
+            CHK(d2h_sync(h, rho, h->rho16.p, sizeof(rho), h->stream));
         }
         *out = sqrt(rho[name[14] == 'l' ? 0 : 1]);
     }
@@ -3033,7 +3152,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
         unsigned int v[2] = {0u, 0x7f800000u};
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipMemcpy(v, h->margin_stat.p, sizeof(v), hipMemcpyDeviceToHost));
+        CHK(d2h_sync(h, v, h->margin_stat.p, sizeof(v), h->stream));
         float r; memcpy(&r, &v[1], 4);
         *out = name[10] == 'm' && name[11] == 'a' ? (double)v[0] : (double)r;
     }
@@ -3041,7 +3160,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "coarse_pairs") || !strcmp(name, "coarse_pair_overflow")) {
         // tile pairs the coarse pass of the most recent two-pass filter let through (debug / tuning aid)
         unsigned int v[2] = {0u, 0u};
-        if (h->cpairctl.p) { HIPCHK(hipSetDevice(h->device)); HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(hipMemcpy(v, h->cpairctl.p, sizeof(v), hipMemcpyDeviceToHost)); }
+        if (h->cpairctl.p) { HIPCHK(hipSetDevice(h->device)); HIPCHK(hipStreamSynchronize(h->stream)); CHK(d2h_sync(h, v, h->cpairctl.p, sizeof(v), h->stream)); }
         *out = (double)v[name[11] == 's' ? 0 : 1];
     }
     else if (!strcmp(name, "prefilter_mfma_unit")) *out = SNK_BF16_MFMA_UNIT;
@@ -3052,7 +3171,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
         const int64_t n = h->last_T;
         if (n <= 0) { *out = 0; return 0; }
         std::vector<int> c((size_t)n);
-        HIPCHK(hipMemcpy(c.data(), h->cnt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        CHK(d2h_sync(h, c.data(), h->cnt.p, (size_t)n * sizeof(int), h->stream));
         double sum = 0, mx = 0;
         for (int64_t i = 0; i < n; ++i) { sum += c[i]; if (c[i] > mx) mx = c[i]; }
         *out = !strcmp(name, "last_list_max") ? mx : sum / (double)n;
@@ -3074,13 +3193,13 @@ static int selftest_mfma16(snk_engine *h, double *err_out)
         float acc = 0; for (int k = 0; k < 2; ++k) acc += A[i * 2 + k] * B[k * 32 + j]; R[i * 32 + j] = acc; }
     DevBuf dA, dB, dC;
     CHK(dA.ensure(sizeof(A))); CHK(dB.ensure(sizeof(B))); CHK(dC.ensure(sizeof(C)));
-    HIPCHK(hipMemcpy(dA.p, A, sizeof(A), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dB.p, B, sizeof(B), hipMemcpyHostToDevice));
+    CHK(h2d_sync(h, dA.p, A, sizeof(A)));
+    CHK(h2d_sync(h, dB.p, B, sizeof(B)));
     HIPCHK(hipMemset(dC.p, 0, sizeof(C)));
     launch_mfma16_selftest(dA.as<float>(), dB.as<float>(), dC.as<float>(), h->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(C, dC.p, sizeof(C), hipMemcpyDeviceToHost));
+    CHK(d2h_sync(h, C, dC.p, sizeof(C), h->stream));
     double err = 0;
     for (int i = 0; i < 1024; ++i) err = fmax(err, fabs((double)C[i] - (double)R[i]));
     dA.release(); dB.release(); dC.release();
@@ -3097,13 +3216,13 @@ int snk_probe_mfma_bf16(snk_handle h, const uint16_t *A, const uint16_t *B, cons
     HIPCHK(hipSetDevice(h->device));
     DevBuf dA, dB, dC, dD;
     CHK(dA.ensure(512 * 2)); CHK(dB.ensure(512 * 2)); CHK(dC.ensure(1024 * 4)); CHK(dD.ensure(1024 * 4));
-    HIPCHK(hipMemcpy(dA.p, A, 512 * 2, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dB.p, B, 512 * 2, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dC.p, C, 1024 * 4, hipMemcpyHostToDevice));
+    CHK(h2d_sync(h, dA.p, A, 512 * 2));
+    CHK(h2d_sync(h, dB.p, B, 512 * 2));
+    CHK(h2d_sync(h, dC.p, C, 1024 * 4));
     launch_mfma_bf16_probe(dA.as<unsigned short>(), dB.as<unsigned short>(), dC.as<float>(), dD.as<float>(), h->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(D_out, dD.p, 1024 * 4, hipMemcpyDeviceToHost));
+    CHK(d2h_sync(h, D_out, dD.p, 1024 * 4, h->stream));
     dA.release(); dB.release(); dC.release(); dD.release();
     return 0;
 }
@@ -3125,13 +3244,13 @@ int snk_selftest_mfma(snk_handle h, double *max_abs_err_out)
         }
     DevBuf dA, dB, dC;
     CHK(dA.ensure(sizeof(A))); CHK(dB.ensure(sizeof(B))); CHK(dC.ensure(sizeof(C)));
-    HIPCHK(hipMemcpy(dA.p, A, sizeof(A), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dB.p, B, sizeof(B), hipMemcpyHostToDevice));
+    CHK(h2d_sync(h, dA.p, A, sizeof(A)));
+    CHK(h2d_sync(h, dB.p, B, sizeof(B)));
     HIPCHK(hipMemset(dC.p, 0, sizeof(C)));
     launch_mfma_selftest(dA.as<double>(), dB.as<double>(), dC.as<double>(), h->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(C, dC.p, sizeof(C), hipMemcpyDeviceToHost));
+    CHK(d2h_sync(h, C, dC.p, sizeof(C), h->stream));
     double err = 0;
     for (int i = 0; i < 256; ++i) err = fmax(err, fabs(C[i] - R[i]));
     dA.release(); dB.release(); dC.release();
