@@ -769,12 +769,16 @@ knn_sweep16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const
         auto test4 = [&](const f16acc &res, int pt, int r0, float pth, int pq) {
             const float v0 = res[r0], v1 = res[r0 + 1], v2 = res[r0 + 2], v3 = res[r0 + 3];
             if (MODE == 0) {
-                asm("v_min3_f32 %0, %0, %1, %2" : "+v"(gm) : "v"(v0), "v"(v1));
-                asm("v_min3_f32 %0, %0, %1, %2" : "+v"(gm) : "v"(v2), "v"(v3));
+                // (builtins, not inline asm: the matrix results now live in architected registers -- Makefile,
+                // -amdgpu-mfma-vgpr-form -- and an asm statement reading them gets none of the wait states the compiler
+                // inserts between a matrix instruction and the first vector read of its result: the drain at the end of a
+                // work item read unfinished results and neighbours went missing, tests/test_gpu_fullsize.py long utterance)
+                gm = __builtin_fminf(__builtin_fminf(gm, v0), v1);
+                gm = __builtin_fminf(__builtin_fminf(gm, v2), v3);
             } else {
                 float m4;
-                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m4) : "v"(v0), "v"(v1), "v"(v2));
-                asm("v_min_f32 %0, %0, %1" : "+v"(m4) : "v"(v3));
+                m4 = __builtin_fminf(__builtin_fminf(v0, v1), v2);
+                m4 = __builtin_fminf(m4, v3);
                 if (__any(m4 <= pth)) {
                     if (lcount > STAGE_CAP - 256) flush_stage();
                     const float v4[4] = {v0, v1, v2, v3};
@@ -1048,14 +1052,11 @@ knn_coarse16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, cons
         // one pending result: the smallest of the 16 rows this lane holds of database tile pt against its query column
         auto test = [&](const f16acc &res, int pt, float pth, int pq) {
             float m;
-            asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(res[0]), "v"(res[1]), "v"(res[2]));
-            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(res[3]), "v"(res[4]));
-            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(res[5]), "v"(res[6]));
-            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(res[7]), "v"(res[8]));
-            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(res[9]), "v"(res[10]));
-            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(res[11]), "v"(res[12]));
-            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(res[13]), "v"(res[14]));
-            asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(res[15]));
+            // (builtins: the compiler pairs them into v_min3_f32 and knows the wait states behind a matrix instruction)
+            m = __builtin_fminf(__builtin_fminf(res[0], res[1]), res[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) m = __builtin_fminf(__builtin_fminf(m, res[r]), res[r + 1]);
+            m = __builtin_fminf(m, res[15]);
             if (__any(m <= pth) && pt < n_valid) emit((unsigned int)(tile0 + pt), (unsigned int)pq);
         };
         // one step: CH database tiles (first: t0) against the query tile in x into `cur`; the CH results in `prev`

@@ -394,6 +394,9 @@ static int staged_d2h(snk_engine *h, hipStream_t st, const D2HPart *parts, int n
 // ---------------------------------------------------------------------------
 static bool host_memory_is_pinned(const void *p)
 {
+    static int bypass = -1;                                // developer switch: SNK_NO_STAGING=1 hands caller memory to the runtime as before
+    if (bypass < 0) { const char *e = getenv("SNK_NO_STAGING"); bypass = (e && *e == '1') ? 1 : 0; }
+    if (bypass) return true;
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;

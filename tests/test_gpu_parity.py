@@ -428,10 +428,18 @@ def test_knn_entry_pool_exhausted_is_never_silent(engine):
         engine.set_option('pool_chunk_limit', 8)        # far fewer chunks than resident wavefronts
         for precision in (1, 0):
             engine.set_option('precision', precision)
-            before = engine.info('pool_overflows')
+            before, fb = engine.info('pool_overflows'), engine.info('f16_fallbacks')
             cand, dist = engine.knn(U, 30)
             assert np.array_equal(cand, oc) and np.array_equal(dist, od)
-            assert engine.info('pool_overflows') - before == 1
+            # what is certain: 40 rows x ~1800 survivors never fit 8 chunks of 2048 entries -- the prefilter path hands the
+            # call to the exact sweep, and the exact sweep's first attempt (sampled thresholds) is retried with exact
+            # thresholds.  Whether that retry overflows as well (then every row goes through the exact per-row selection,
+            # pool_overflows + 1) depends on which wavefronts happen to get the eight chunks: the survivors of these clustered
+            # targets sit in a handful of slabs.
+            if precision == 1:
+                assert engine.info('f16_fallbacks') == fb + 1
+            assert engine.info('last_knn_retries') == 1
+            assert engine.info('pool_overflows') - before in (0, 1)
         paths, costs = engine.knn_viterbi_batch([U, U[:7]], 30)      # deferred status -> redo at collect
         op, ocst = o.viterbi(oc, od, E, S)
         assert list(paths[0]) == op and costs[0] == ocst
