@@ -600,9 +600,9 @@ __global__ void db16b_ratio_kernel(const double *__restrict__ Fw, int64_t N, int
     }
 }
 
-void launch_db16b_ratios(const double *Fw, int64_t N, int Dt, int Dpad, double *rho, hipStream_t s)
+void launch_db16b_ratios(const double *Fw, int64_t N, int Dt, int Dpad, double *rho, hipStream_t s, bool accumulate)
 {
-    (void)hipMemsetAsync(rho, 0, 2 * sizeof(double), s);
+    if (!accumulate) (void)hipMemsetAsync(rho, 0, 2 * sizeof(double), s);
     hipLaunchKernelGGL(db16b_ratio_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, Fw, N, Dt, Dpad,
                        reinterpret_cast<unsigned long long *>(rho));
 }
@@ -956,13 +956,14 @@ template <int NTC, int KB, int WPS>
 __global__ void __launch_bounds__(256, WPS)
 knn_coarse16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const float *__restrict__ thr1, int nQT,
               int64_t n_tiles, int64_t n_slabs, unsigned int *__restrict__ slab_counter, int qsplit, int64_t n_main_slabs,
-              int qsplit_tail, CoarsePair *__restrict__ pairs, unsigned int *__restrict__ pair_ctl, unsigned int pair_cap)
+              int qsplit_tail, CoarsePair *__restrict__ pairs, unsigned int *__restrict__ pair_ctl, unsigned int pair_cap, int gated)
 {
     // independent MFMA chains per step, two accumulator sets that alternate by step parity.  Register homes are forced
     // (Makefile: -amdgpu-mfma-vgpr-form for this file; the "+a" pins below): the resident database pieces in the
     // accumulation registers, which the matrix instruction reads its A operand from directly, the results in the
     // architected registers, where the vector unit tests them.  Left to itself the allocator did the opposite and paid
     // sixteen v_accvgpr_read per tested tile: as many vector instructions as the matrix pipe was busy cycles.
+    if (gated && pair_ctl[2] == 0u) return;            // the ball pass listed few enough pairs: its list stands
     constexpr int CH = (NTC >= 8) ? 4 : 2;
     constexpr int NSTEP = NTC / CH;
     static_assert(NTC % CH == 0 && NSTEP % 2 == 0, "the accumulator sets alternate by step parity, a tile has an even number of steps");
@@ -1243,6 +1244,234 @@ static int coarse_wps()
     return v;
 }
 
+// ===========================================================================================================
+// Pass 0 of the filter, in front of the coarse sweep: a bound per (database tile, query row) from the tile's BALL.
+// A tile is 32 consecutive units -- in a speech database consecutive frames, close to each other -- with centre c
+// (mean of its rows, float64) and radius r = max_i ||f_i - c||.  For every unit f of the tile ||q - f|| >= ||q - c|| - r,
+// so a tile can hold a unit inside the filter's threshold only if ||q - c|| <= sqrt(D2max(q)) + r, where D2max(q) =
+// thr32 + eps + ||q||^2 bounds the squared distance of anything the three-term test would let through.  The centres
+// are 1 / 32 of the database: their three-term keys (knn_sweep16b's operands and MFMA order, so its error bound eps
+// applies; ||c|| <= Fmax) cost a thirtieth of the coarse sweep, and the test
+//        key~(c) <= (tq + r)^2 - nq,     tq = sqrt(D2max(q)) rounded up,  nq = ||q||^2 - eps rounded down
+// lists the (tile, query tile) pairs for knn_refine16b directly.  Where the tiles are not compact (more than
+// coarse_gate_fraction of all pairs listed) the coarse sweep runs instead: decided on the device (knn_coarse_gate_kernel).
+// ===========================================================================================================
+__global__ void __launch_bounds__(256)
+build_tile_balls_kernel(const double *__restrict__ Fw, int64_t N, int Dt, int Dpad, int64_t n_tiles, double *__restrict__ C,
+                        double *__restrict__ cnorm, float *__restrict__ rad)
+{
+    // one wavefront per tile: lane = column (strided), rows one after the other
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const int64_t r0 = tile * 32;
+    const int n = (int)(N - r0 < 32 ? (N - r0 > 0 ? N - r0 : 0) : 32);
+    double cn = 0.0;
+    for (int c = lane; c < Dpad; c += 64) {
+        double m = 0.0;
+        if (c < Dt && n > 0) {
+            for (int i = 0; i < n; ++i) m += Fw[(r0 + i) * Dpad + c];
+            m /= (double)n;
+        }
+        C[tile * Dpad + c] = m;
+        cn += m * m;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cn += __shfl_xor(cn, off, 64);
+    double rmax2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double d2 = 0.0;
+        for (int c = lane; c < Dt; c += 64) {
+            const double d = Fw[(r0 + i) * Dpad + c] - C[tile * Dpad + c];        // (this lane's own columns: written above)
+            d2 += d * d;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) d2 += __shfl_xor(d2, off, 64);
+        rmax2 = d2 > rmax2 ? d2 : rmax2;
+    }
+    if (lane == 0) {
+        cnorm[tile] = n > 0 ? cn : __builtin_inf();                            // an empty tile: its key never passes
+        float r = (float)(sqrt(rmax2) * (1.0 + 1e-9));
+        if ((double)r < sqrt(rmax2) * (1.0 + 1e-9)) r = nextafterf(r, FLT_MAX);
+        rad[tile] = n > 0 ? r : 0.f;
+    }
+}
+
+void launch_build_tile_balls(const double *Fw, int64_t N, int Dt, int Dpad, int64_t n_tiles, double *C, double *cnorm, float *rad,
+                             hipStream_t s)
+{
+    hipLaunchKernelGGL(build_tile_balls_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, Fw, N, Dt, Dpad, n_tiles, C,
+                       cnorm, rad);
+}
+
+// per query row: tq and nq of the ball test (see above) from the row's filter threshold, key bound and norm
+__global__ void ball_query_terms_kernel(const float *__restrict__ thr32, const double *__restrict__ eps, const double *__restrict__ qnorm,
+                                        int64_t T, int64_t T32, float *__restrict__ tq, float *__restrict__ nq)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= T32) return;
+    float t = 0.f, n = FLT_MAX;                                               // padding rows: nothing passes
+    if (row < T) {
+        const float th = thr32[row];
+        if (th >= FLT_MAX) { t = FLT_MAX; n = 0.f; }                          // no bound for this row: every tile
+        else if (th > -FLT_MAX) {
+            const double d2max = (double)th + eps[row] + qnorm[row];
+            if (d2max >= 0.0) {
+                const double td = sqrt(d2max) * (1.0 + 1e-9);
+                t = (float)td;
+                if ((double)t < td) t = nextafterf(t, FLT_MAX);
+                const double nd = qnorm[row] - eps[row];
+                n = (float)nd;
+                if ((double)n > nd) n = nextafterf(n, -FLT_MAX);
+            }
+        }
+    }
+    tq[row] = t; nq[row] = n;
+}
+
+void launch_ball_query_terms(const float *thr32, const double *eps, const double *qnorm, int64_t T, int64_t T32, float *tq, float *nq,
+                             hipStream_t s)
+{
+    hipLaunchKernelGGL(ball_query_terms_kernel, dim3((unsigned)((T32 + 255) / 256)), dim3(256), 0, s, thr32, eps, qnorm, T, T32, tq, nq);
+}
+
+// centres (operand C16: tiles of 32 centres, hi / lo pieces like the database) against all query tiles
+template <int KB, int TERMS>
+__global__ void __launch_bounds__(256, 2)
+knn_balls16b(const u32x4 *__restrict__ C16, const u32x4 *__restrict__ B16, const float *__restrict__ rad, const float *__restrict__ tq,
+             const float *__restrict__ nq, int nQT, int64_t n_tiles, int64_t n_ctiles, int qsplit, CoarsePair *__restrict__ pairs,
+             unsigned int *__restrict__ pair_ctl, unsigned int pair_cap)
+{
+    __shared__ CoarsePair pstage[4][96];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int qcol = lane & 31;
+    int pcount = 0;
+    auto flush_pairs = [&]() {
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(&pair_ctl[0], (unsigned int)pcount);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (int e = lane; e < pcount; e += 64) {
+            if (base + (unsigned int)e < pair_cap) pairs[base + e] = pstage[wv][e];
+            else pair_ctl[1] = 1u;
+        }
+        pcount = 0;
+    };
+    auto mfma = [](const u32x4 &a, const u32x4 &b, f16acc c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+    const int64_t n_items = n_ctiles * qsplit;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + wv; item < n_items; item += (int64_t)gridDim.x * 4) {
+        const int64_t ct = item / qsplit;
+        const int part = (int)(item % qsplit);
+        const int qt_lo = (int)(((int64_t)nQT * part) / qsplit), qt_hi = (int)(((int64_t)nQT * (part + 1)) / qsplit);
+        u32x4 a[KB][2];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) a[kb][pc] = C16[((ct * KB + kb) * 2 + pc) * 64 + lane];
+        float rv[16];                                          // radius of the 16 rows this lane holds results of
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t t = ct * 32 + crow32(lane, r);
+            rv[r] = t < n_tiles ? rad[t] : -FLT_MAX;
+        }
+        u32x4 b0[KB][2], b1[KB][2];
+        float t0 = 0.f, n0 = 0.f, t1 = 0.f, n1 = 0.f;
+        auto load_q = [&](int t, u32x4 (&b)[KB][2], float &tt, float &nn) {
+            const int tc = t < qt_hi ? t : qt_hi - 1;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) b[kb][pc] = B16[(((int64_t)tc * KB + kb) * 2 + pc) * 64 + lane];
+            tt = tq[tc * 32 + qcol]; nn = nq[tc * 32 + qcol];
+        };
+        auto work = [&](int qt, const u32x4 (&b)[KB][2], float tt, float nn) {
+            constexpr int CM = 4 * TERMS, NM = TERMS * KB;
+            f16acc acc, part;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int kb = m / TERMS, term = m % TERMS;
+                const u32x4 &av = (term & 2) ? a[kb][1] : a[kb][0];
+                const u32x4 &bv = (term & 1) ? b[kb][1] : b[kb][0];
+                if (m % CM == 0) {
+                    f16acc z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                    part = mfma(av, bv, z);
+                } else part = mfma(av, bv, part);
+                if (m % CM == CM - 1 || m == NM - 1) {
+                    if (m < CM) acc = part;
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] += part[r];
+                    }
+                }
+            }
+            if (pcount > 96 - 32) flush_pairs();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // key~(c) <= (tq + r)^2 - nq, the right side rounded up (a relative 2^-21 of both terms covers the three
+                // float32 roundings); a negative radius marks a row past the database
+                const float sr = rv[r] + tt;
+                const float rhs = __builtin_fmaf(sr, sr, -nn);
+                const float slack = 4.76837158203125e-07f * (sr * sr + __builtin_fabsf(nn)) + 1e-30f;
+                const bool pass = rv[r] >= 0.f && sr >= 0.f && acc[r] <= rhs + slack;
+                const unsigned long long mm = __ballot(pass);
+                if (mm) {
+                    // lanes 0..31 hold row crow32(0, r), lanes 32..63 row crow32(32, r): one pair per row with any passing column
+                    const unsigned int lo = (unsigned int)mm, hi = (unsigned int)(mm >> 32);
+                    if (lo) { if (lane == 0) pstage[wv][pcount] = CoarsePair{(unsigned int)(ct * 32 + crow32(0, r)), (unsigned int)qt}; ++pcount; }
+                    if (hi) { if (lane == 0) pstage[wv][pcount] = CoarsePair{(unsigned int)(ct * 32 + crow32(32, r)), (unsigned int)qt}; ++pcount; }
+                }
+            }
+        };
+        load_q(qt_lo, b0, t0, n0);
+        for (int qt = qt_lo; qt < qt_hi; qt += 2) {
+            load_q(qt + 1, b1, t1, n1);
+            work(qt, b0, t0, n0);
+            if (qt + 1 < qt_hi) {
+                load_q(qt + 2, b0, t0, n0);
+                work(qt + 1, b1, t1, n1);
+            }
+        }
+    }
+    if (pcount) flush_pairs();
+}
+
+// pair_ctl[0] pairs listed by the ball pass, [1] overflow, [2] 1 = the coarse sweep has to run (the ball pass listed too much)
+__global__ void knn_coarse_gate_kernel(unsigned int *pair_ctl, unsigned int limit)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const bool run = pair_ctl[0] > limit || pair_ctl[1] != 0u;
+        pair_ctl[2] = run ? 1u : 0u;
+        pair_ctl[3] = pair_ctl[0];                            // (kept for the tuning aid: what the ball pass listed)
+        if (run) { pair_ctl[0] = 0u; pair_ctl[1] = 0u; }
+    }
+}
+
+bool launch_knn_balls16b(int terms, int dch, int grid_cus, const void *C16, const void *B16, const float *rad, const float *tq,
+                         const float *nq, int64_t T32, int64_t n_tiles, void *pairs, unsigned int *pair_ctl, unsigned int pair_cap,
+                         unsigned int gate_limit, hipStream_t s)
+{
+    const int nQT = (int)(T32 / 32);
+    const int64_t n_ctiles = (n_tiles + 31) / 32;
+    int qsplit = 1;
+    while (n_ctiles * qsplit < 8 * (int64_t)grid_cus && qsplit * 2 <= nQT && qsplit < 64) qsplit *= 2;
+    int64_t blocks = (n_ctiles * qsplit + 3) / 4;
+    if (blocks > 2 * (int64_t)grid_cus) blocks = 2 * (int64_t)grid_cus;
+#define SNK_B16(KB_, TERMS_)                                                                                         \
+    hipLaunchKernelGGL((knn_balls16b<KB_, TERMS_>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)C16,     \
+                       (const u32x4 *)B16, rad, tq, nq, nQT, n_tiles, n_ctiles, qsplit, (CoarsePair *)pairs, pair_ctl, pair_cap)
+    if (dch == 1) { if (terms == 4) SNK_B16(4, 4); else SNK_B16(4, 3); }
+    else if (dch == 2) { if (terms == 4) SNK_B16(8, 4); else SNK_B16(8, 3); }
+    else if (dch == 3) { if (terms == 4) SNK_B16(12, 4); else SNK_B16(12, 3); }
+    else return false;
+#undef SNK_B16
+    hipLaunchKernelGGL(knn_coarse_gate_kernel, dim3(1), dim3(64), 0, s, pair_ctl, gate_limit);
+    return true;
+}
+
 bool knn_coarse16b_supported(int nt, int dch) { return (nt == 4 && dch == 1) || (nt == 2 && dch == 2) || (nt == 1 && dch == 3); }
 size_t knn_coarse_pair_bytes() { return sizeof(CoarsePair); }
 
@@ -1250,7 +1479,7 @@ size_t knn_coarse_pair_bytes() { return sizeof(CoarsePair); }
 // zeroed by the caller (knn_reset)
 bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32, const float *thr1,
                           int64_t T32, int64_t n_tiles, unsigned int *ctr, void *pairs, unsigned int *pair_ctl, unsigned int pair_cap,
-                          void *pool, unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s)
+                          void *pool, unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s, int gated)
 {
     const int nQT = (int)(T32 / 32);
     const int wps = (dch == 1 && coarse_wps() == 2) ? 2 : 1;
@@ -1267,7 +1496,7 @@ bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, con
 #define SNK_C16(NTC_, KB_, WPS_)                                                                                    \
     hipLaunchKernelGGL((knn_coarse16b<NTC_, KB_, WPS_>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)A16, \
                        (const u32x4 *)B16, thr1, nQT, n_tiles, n_slabs, ctr, qsplit, n_main, qtail,                 \
-                       (CoarsePair *)pairs, pair_ctl, pair_cap)
+                       (CoarsePair *)pairs, pair_ctl, pair_cap, gated)
 #define SNK_R16(KB_, TERMS_)                                                                                        \
     hipLaunchKernelGGL((knn_refine16b<KB_, TERMS_>), dim3((unsigned)((KB_ <= 4 ? 2 : 1) * grid_cus)), dim3(256), 0, s, \
                        (const u32x4 *)A16, (const u32x4 *)B16, thr32, (const CoarsePair *)pairs, pair_ctl, pair_cap, \

@@ -254,6 +254,10 @@ struct snk_engine {
     bool bf16_ready = false;      // a16l / s16l (and gs_tiles_b) hold the bf16-split operands of the current weights
     double eps_c_bf = 4e-6;       // accumulation part of the bound of the bf16-split keys (knn16_kernels.hip: c_acc)
     DevBuf kth16;                 // sharded search: per-row second bound (K-th key of the local list, all-reduced)
+    DevBuf ball_c, ball_cn, ball_rad, ball_c16, ball_tq, ball_nq;   // pass 0: tile centres (float64, norms, radii, bf16-split operand), per-row terms
+    int prefilter_balls = 1;      // 1: the tiles' balls list the pairs first; the coarse sweep runs only where they list too many
+    double coarse_gate_fraction = 0.10;
+    int64_t ball_tiles = 0;       // valid tiles of the ball operand (0: not built)
     DevBuf e1_16, thr1_32, cpairs, cpairctl;   // two-pass filter: per-row coarse margin and threshold, (tile, query tile) pair list
     int prefilter_two_pass = 1;   // 1: bf16-split filter as hi.hi sweep + three-term keys of the tile pairs it lets through (default)
     DevBuf margin_stat;           // tripwire of the prefilter's key bound: [0] rows with room < 2 eps, [1] smallest room / eps (float bits)
@@ -582,7 +586,8 @@ int snk_destroy(snk_handle h)
     h->rowflag.release(); h->exact_rows.release(); h->exact_scratch.release();
     h->frames_spec.release(); h->frames_fzv.release(); h->cc_in.release(); h->cc_out.release();
     h->res_status.release(); h->hstage.release(); h->up.release();
-    { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b, &h->cq16, &h->rho16, &h->gs_rho16, &h->kth16, &h->margin_stat, &h->e1_16, &h->thr1_32, &h->cpairs, &h->cpairctl};
+    { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b, &h->cq16, &h->rho16, &h->gs_rho16, &h->kth16, &h->margin_stat, &h->e1_16, &h->thr1_32, &h->cpairs, &h->cpairctl,
+                      &h->ball_c, &h->ball_cn, &h->ball_rad, &h->ball_c16, &h->ball_tq, &h->ball_nq};
       for (auto *b : fb) b->release(); }
     for (int i = 0; i < 8; ++i) {
         UttSlot &s = h->slot[i];
@@ -805,6 +810,22 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
                                    2 * h->n_slabs16_a, nt, h->s16l.p, h->stream);
                 HIPCHK(hipGetLastError());
                 h->bf16_ready = true;
+                // pass 0 of the two-pass filter: centre and radius of every 32-unit tile, the centres as one more bf16-split
+                // operand (its dropped-piece ratios join the database's: one key bound serves both)
+                h->ball_tiles = 0;
+                if (h->prefilter_balls) {
+                    const int64_t vt = (h->N + 31) / 32, ct = (vt + 31) / 32;
+                    CHK(h->ball_c.ensure((size_t)vt * h->Dpad * sizeof(double)));
+                    CHK(h->ball_cn.ensure((size_t)vt * sizeof(double)));
+                    CHK(h->ball_rad.ensure((size_t)vt * sizeof(float)));
+                    CHK(h->ball_c16.ensure((size_t)ct * per_tile));
+                    launch_build_tile_balls(h->Fw.as<double>(), h->N, h->Dt, h->Dpad, vt, h->ball_c.as<double>(), h->ball_cn.as<double>(),
+                                            h->ball_rad.as<float>(), h->stream);
+                    launch_db16b_ratios(h->ball_c.as<double>(), vt, h->Dt, h->Dpad, h->rho16.as<double>(), h->stream, true);
+                    launch_build_db16b(h->ball_c.as<double>(), h->ball_cn.as<double>(), vt, h->Dt, h->Dpad, ct, 0, 0, nt, h->ball_c16.p, h->stream);
+                    HIPCHK(hipGetLastError());
+                    h->ball_tiles = vt;
+                }
             }
         }
     }
@@ -1089,10 +1110,10 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
             if (capp > ((int64_t)1 << 31) - 1) capp = ((int64_t)1 << 31) - 1;
             pair_cap = (unsigned int)capp;
             CHK(h->cpairs.ensure((size_t)pair_cap * knn_coarse_pair_bytes()));
-            CHK(h->cpairctl.ensure(2 * sizeof(unsigned int)));
+            CHK(h->cpairctl.ensure(4 * sizeof(unsigned int)));
             CHK(h->e1_16.ensure((size_t)Tpad * sizeof(double)));
             CHK(h->thr1_32.ensure((size_t)Tpad * sizeof(float)));
-            HIPCHK(hipMemsetAsync(h->cpairctl.p, 0, 2 * sizeof(unsigned int), s));
+            HIPCHK(hipMemsetAsync(h->cpairctl.p, 0, 4 * sizeof(unsigned int), s));
         }
         // accumulation of the coarse pass's own chain (one MFMA per k-block through C) on top of the three-term chain's
         const double c_coarse = eps_c_run + 1.02 * SNK_BF16_MFMA_UNIT * (double)(h->Dpad / 16 + 1);
@@ -1135,10 +1156,24 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         if (bound_out) return 0;             // stage A only
         {
             StageTimer t(h, s, TM_KNN_FILTER);
-            if (coarse)
+            if (coarse) {
+                const bool balls = h->prefilter_balls && h->ball_tiles > 0 && slab_factor == 1;
+                if (balls) {
+                    CHK(h->ball_tq.ensure((size_t)Tpad * sizeof(float)));
+                    CHK(h->ball_nq.ensure((size_t)Tpad * sizeof(float)));
+                    launch_ball_query_terms(h->thr32.as<float>(), h->eps16.as<double>(), h->qnorm.as<double>(), T, Tpad, h->ball_tq.as<float>(),
+                                            h->ball_nq.as<float>(), s);
+                    double lim = h->coarse_gate_fraction * (double)(Tpad / 32) * (double)h->ball_tiles;
+                    if (lim > (double)pair_cap) lim = (double)pair_cap;
+                    launch_knn_balls16b(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->ball_c16.p, h->b16l.p, h->ball_rad.as<float>(),
+                                        h->ball_tq.as<float>(), h->ball_nq.as<float>(), Tpad, h->ball_tiles, h->cpairs.p,
+                                        h->cpairctl.as<unsigned int>(), pair_cap, (unsigned int)lim, s);
+                }
                 launch_knn_filter16c(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, h->thr32.as<float>(), h->thr1_32.as<float>(),
                                      Tpad, n_tiles_b, h->slabctr.as<unsigned int>() + 1, h->cpairs.p, h->cpairctl.as<unsigned int>(), pair_cap,
-                                     h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, knn_pool_chunk_entries(), s);
+                                     h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, knn_pool_chunk_entries(), s,
+                                     balls ? 1 : 0);
+            }
             else if (bf)
                 launch_knn_sweep16b(1, h->prefilter == 2 ? 4 : 3, nt_run, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, h->thr32.as<float>(), Tpad, n_slabs_b,
                                     h->slabctr.as<unsigned int>() + 1, nullptr, 0, h->pool.p, h->poolctl.as<unsigned int>(),
@@ -3032,6 +3067,14 @@ int snk_set_option(snk_handle h, const char *name, double value)
         CHK(no_batch_in_flight(h, "snk_set_option(prefilter)"));
         h->prefilter = (int)value;
         h->have_weights = false;          // the bf16 operands are built by set_weights
+    } else if (!strcmp(name, "prefilter_balls")) {
+        if (value != 0.0 && value != 1.0) return fail("prefilter_balls must be 0 or 1");
+        CHK(no_batch_in_flight(h, "snk_set_option(prefilter_balls)"));
+        h->prefilter_balls = (int)value;
+        h->have_weights = false;          // the ball operand is built by set_weights
+    } else if (!strcmp(name, "coarse_gate_fraction")) {
+        if (!(value >= 0.0 && value <= 1.0)) return fail("coarse_gate_fraction must be in 0..1");
+        h->coarse_gate_fraction = value;
     } else if (!strcmp(name, "prefilter_two_pass")) {
         if (value != 0.0 && value != 1.0) return fail("prefilter_two_pass must be 0 or 1");
         CHK(no_batch_in_flight(h, "snk_set_option(prefilter_two_pass)"));
@@ -3160,6 +3203,13 @@ int snk_get_info(snk_handle h, const char *name, double *out)
         *out = name[10] == 'm' && name[11] == 'a' ? (double)v[0] : (double)r;
     }
     else if (!strcmp(name, "prefilter_two_pass")) *out = h->prefilter_two_pass;
+    else if (!strcmp(name, "prefilter_balls")) *out = h->prefilter_balls;
+    else if (!strcmp(name, "ball_pairs") || !strcmp(name, "coarse_ran")) {
+        // most recent two-pass filter: tile pairs the ball pass listed; whether the coarse sweep had to run instead
+        unsigned int v[4] = {0u, 0u, 0u, 0u};
+        if (h->cpairctl.p) { HIPCHK(hipSetDevice(h->device)); CHK(d2h_sync(h, v, h->cpairctl.p, sizeof(v), h->stream)); }
+        *out = (double)v[name[0] == 'b' ? 3 : 2];
+    }
     else if (!strcmp(name, "coarse_pairs") || !strcmp(name, "coarse_pair_overflow")) {
         // tile pairs the coarse pass of the most recent two-pass filter let through (debug / tuning aid)
         unsigned int v[2] = {0u, 0u};
