@@ -956,14 +956,13 @@ template <int NTC, int KB, int WPS>
 __global__ void __launch_bounds__(256, WPS)
 knn_coarse16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const float *__restrict__ thr1, int nQT,
               int64_t n_tiles, int64_t n_slabs, unsigned int *__restrict__ slab_counter, int qsplit, int64_t n_main_slabs,
-              int qsplit_tail, CoarsePair *__restrict__ pairs, unsigned int *__restrict__ pair_ctl, unsigned int pair_cap, int gated)
+              int qsplit_tail, CoarsePair *__restrict__ pairs, unsigned int *__restrict__ pair_ctl, unsigned int pair_cap)
 {
     // independent MFMA chains per step, two accumulator sets that alternate by step parity.  Register homes are forced
     // (Makefile: -amdgpu-mfma-vgpr-form for this file; the "+a" pins below): the resident database pieces in the
     // accumulation registers, which the matrix instruction reads its A operand from directly, the results in the
     // architected registers, where the vector unit tests them.  Left to itself the allocator did the opposite and paid
     // sixteen v_accvgpr_read per tested tile: as many vector instructions as the matrix pipe was busy cycles.
-    if (gated && pair_ctl[2] == 0u) return;            // the ball pass listed few enough pairs: its list stands
     constexpr int CH = (NTC >= 8) ? 4 : 2;
     constexpr int NSTEP = NTC / CH;
     static_assert(NTC % CH == 0 && NSTEP % 2 == 0, "the accumulator sets alternate by step parity, a tile has an even number of steps");
@@ -1253,8 +1252,9 @@ static int coarse_wps()
 // are 1 / 32 of the database: their three-term keys (knn_sweep16b's operands and MFMA order, so its error bound eps
 // applies; ||c|| <= Fmax) cost a thirtieth of the coarse sweep, and the test
 //        key~(c) <= (tq + r)^2 - nq,     tq = sqrt(D2max(q)) rounded up,  nq = ||q||^2 - eps rounded down
-// lists the (tile, query tile) pairs for knn_refine16b directly.  Where the tiles are not compact (more than
-// coarse_gate_fraction of all pairs listed) the coarse sweep runs instead: decided on the device (knn_coarse_gate_kernel).
+// lists the (tile, query tile) pairs for knn_refine16b directly.  Either list is a superset of what the three-term test
+// passes, so which pass writes it is a matter of speed only: the engine switches a voice to the coarse sweep once the
+// ball pass has listed more than coarse_gate_fraction of all pairs (tiles that are not compact; snk_api.hip knn_device).
 // ===========================================================================================================
 __global__ void __launch_bounds__(256)
 build_tile_balls_kernel(const double *__restrict__ Fw, int64_t N, int Dt, int Dpad, int64_t n_tiles, double *__restrict__ C,
@@ -1439,20 +1439,9 @@ knn_balls16b(const u32x4 *__restrict__ C16, const u32x4 *__restrict__ B16, const
     if (pcount) flush_pairs();
 }
 
-// pair_ctl[0] pairs listed by the ball pass, [1] overflow, [2] 1 = the coarse sweep has to run (the ball pass listed too much)
-__global__ void knn_coarse_gate_kernel(unsigned int *pair_ctl, unsigned int limit)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const bool run = pair_ctl[0] > limit || pair_ctl[1] != 0u;
-        pair_ctl[2] = run ? 1u : 0u;
-        pair_ctl[3] = pair_ctl[0];                            // (kept for the tuning aid: what the ball pass listed)
-        if (run) { pair_ctl[0] = 0u; pair_ctl[1] = 0u; }
-    }
-}
-
 bool launch_knn_balls16b(int terms, int dch, int grid_cus, const void *C16, const void *B16, const float *rad, const float *tq,
                          const float *nq, int64_t T32, int64_t n_tiles, void *pairs, unsigned int *pair_ctl, unsigned int pair_cap,
-                         unsigned int gate_limit, hipStream_t s)
+                         hipStream_t s)
 {
     const int nQT = (int)(T32 / 32);
     const int64_t n_ctiles = (n_tiles + 31) / 32;
@@ -1468,7 +1457,6 @@ bool launch_knn_balls16b(int terms, int dch, int grid_cus, const void *C16, cons
     else if (dch == 3) { if (terms == 4) SNK_B16(12, 4); else SNK_B16(12, 3); }
     else return false;
 #undef SNK_B16
-    hipLaunchKernelGGL(knn_coarse_gate_kernel, dim3(1), dim3(64), 0, s, pair_ctl, gate_limit);
     return true;
 }
 
@@ -1479,7 +1467,7 @@ size_t knn_coarse_pair_bytes() { return sizeof(CoarsePair); }
 // zeroed by the caller (knn_reset)
 bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32, const float *thr1,
                           int64_t T32, int64_t n_tiles, unsigned int *ctr, void *pairs, unsigned int *pair_ctl, unsigned int pair_cap,
-                          void *pool, unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s, int gated)
+                          void *pool, unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s, bool run_coarse)
 {
     const int nQT = (int)(T32 / 32);
     const int wps = (dch == 1 && coarse_wps() == 2) ? 2 : 1;
@@ -1496,14 +1484,15 @@ bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, con
 #define SNK_C16(NTC_, KB_, WPS_)                                                                                    \
     hipLaunchKernelGGL((knn_coarse16b<NTC_, KB_, WPS_>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)A16, \
                        (const u32x4 *)B16, thr1, nQT, n_tiles, n_slabs, ctr, qsplit, n_main, qtail,                 \
-                       (CoarsePair *)pairs, pair_ctl, pair_cap, gated)
+                       (CoarsePair *)pairs, pair_ctl, pair_cap)
 #define SNK_R16(KB_, TERMS_)                                                                                        \
     hipLaunchKernelGGL((knn_refine16b<KB_, TERMS_>), dim3((unsigned)((KB_ <= 4 ? 2 : 1) * grid_cus)), dim3(256), 0, s, \
                        (const u32x4 *)A16, (const u32x4 *)B16, thr32, (const CoarsePair *)pairs, pair_ctl, pair_cap, \
                        (PoolEntry16 *)pool, pool_ctl, chunk_fill, max_chunks, pool_chunk)
-    if (dch == 1) { if (wps == 2) SNK_C16(4, 4, 2); else SNK_C16(8, 4, 1); if (terms == 4) SNK_R16(4, 4); else SNK_R16(4, 3); return true; }
-    if (dch == 2) { SNK_C16(4, 8, 1); if (terms == 4) SNK_R16(8, 4); else SNK_R16(8, 3); return true; }
-    if (dch == 3) { SNK_C16(4, 12, 1); if (terms == 4) SNK_R16(12, 4); else SNK_R16(12, 3); return true; }
+    // run_coarse false: the pair list is already there (the ball pass wrote it)
+    if (dch == 1) { if (run_coarse) { if (wps == 2) SNK_C16(4, 4, 2); else SNK_C16(8, 4, 1); } if (terms == 4) SNK_R16(4, 4); else SNK_R16(4, 3); return true; }
+    if (dch == 2) { if (run_coarse) SNK_C16(4, 8, 1); if (terms == 4) SNK_R16(8, 4); else SNK_R16(8, 3); return true; }
+    if (dch == 3) { if (run_coarse) SNK_C16(4, 12, 1); if (terms == 4) SNK_R16(12, 4); else SNK_R16(12, 3); return true; }
 #undef SNK_C16
 #undef SNK_R16
     return false;

@@ -189,6 +189,7 @@ struct BatchSlot {    // one submitted batch (snk_knn_viterbi_batch_submit / _co
     hipEvent_t done = nullptr;            // results of this batch are in `stage`
     bool busy = false;
     int n_utts = 0, n_groups = 0, K = 0, D = 0;
+    double ball_limit = -1.0;             // >= 0: the ball pass listed this batch's tile pairs; beyond this many the voice goes to the coarse sweep
     int64_t total = 0;
     std::vector<int> first;
     std::vector<int64_t> offs;
@@ -258,6 +259,10 @@ struct snk_engine {
     int prefilter_balls = 1;      // 1: the tiles' balls list the pairs first; the coarse sweep runs only where they list too many
     double coarse_gate_fraction = 0.10;
     int64_t ball_tiles = 0;       // valid tiles of the ball operand (0: not built)
+    double ball_limit = 0.0;      // pairs beyond which the ball pass of the most recent call listed too many
+    bool ball_pass_ran = false;
+    bool filter_coarse = false;   // this voice's tiles are not compact: the ball pass listed too many pairs once, the coarse sweep lists them since
+    int64_t ball_switches = 0;
     DevBuf e1_16, thr1_32, cpairs, cpairctl;   // two-pass filter: per-row coarse margin and threshold, (tile, query tile) pair list
     int prefilter_two_pass = 1;   // 1: bf16-split filter as hi.hi sweep + three-term keys of the tile pairs it lets through (default)
     DevBuf margin_stat;           // tripwire of the prefilter's key bound: [0] rows with room < 2 eps, [1] smallest room / eps (float bits)
@@ -813,6 +818,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
                 // pass 0 of the two-pass filter: centre and radius of every 32-unit tile, the centres as one more bf16-split
                 // operand (its dropped-piece ratios join the database's: one key bound serves both)
                 h->ball_tiles = 0;
+                h->filter_coarse = false;
                 if (h->prefilter_balls) {
                     const int64_t vt = (h->N + 31) / 32, ct = (vt + 31) / 32;
                     CHK(h->ball_c.ensure((size_t)vt * h->Dpad * sizeof(double)));
@@ -936,6 +942,13 @@ static int debug_check_pool(snk_engine *h, int max_chunks, int64_t Tpad, int64_t
     return 0;
 }
 
+// what the ball pass of a call listed, seen at the call's next host synchronisation: beyond the limit this voice's
+// filter goes back to the coarse sweep (until the weights change)
+static void note_ball_pairs(snk_engine *h, unsigned int listed)
+{
+    if (h->ball_pass_ran && !h->filter_coarse && (double)listed > h->ball_limit) { h->filter_coarse = true; h->ball_switches += 1; }
+}
+
 static KnnPlan make_plan(snk_engine *h, int K)
 {
     KnnPlan p{};
@@ -981,7 +994,8 @@ namespace { int comm_all_reduce_min(snk_engine *h, double *buf, int64_t n); }
 // more all-reduce per call, and prune their lists to it.
 static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_t *qclass_dev,
                       int64_t *cand_dev, double *dist_dev, double *d2_dev, int *deferred_status = nullptr,
-                      const double *bound_in = nullptr, double *bound_out = nullptr, bool gs = false, bool refine = false)
+                      const double *bound_in = nullptr, double *bound_out = nullptr, bool gs = false, bool refine = false,
+                      unsigned int *pairs_listed_dev = nullptr)     // with deferred_status: receives the tile pairs the ball pass listed
 {
     if (K < 1 || K > 208) return fail("K-NN: n_candidates=%d outside the supported range 1..208", K);
     if (T > SNK_KNN_MAX_ROWS) {
@@ -1157,22 +1171,22 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         {
             StageTimer t(h, s, TM_KNN_FILTER);
             if (coarse) {
-                const bool balls = h->prefilter_balls && h->ball_tiles > 0 && slab_factor == 1;
+                const bool balls = h->prefilter_balls && h->ball_tiles > 0 && slab_factor == 1 && !h->filter_coarse;
                 if (balls) {
                     CHK(h->ball_tq.ensure((size_t)Tpad * sizeof(float)));
                     CHK(h->ball_nq.ensure((size_t)Tpad * sizeof(float)));
                     launch_ball_query_terms(h->thr32.as<float>(), h->eps16.as<double>(), h->qnorm.as<double>(), T, Tpad, h->ball_tq.as<float>(),
                                             h->ball_nq.as<float>(), s);
-                    double lim = h->coarse_gate_fraction * (double)(Tpad / 32) * (double)h->ball_tiles;
-                    if (lim > (double)pair_cap) lim = (double)pair_cap;
                     launch_knn_balls16b(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->ball_c16.p, h->b16l.p, h->ball_rad.as<float>(),
                                         h->ball_tq.as<float>(), h->ball_nq.as<float>(), Tpad, h->ball_tiles, h->cpairs.p,
-                                        h->cpairctl.as<unsigned int>(), pair_cap, (unsigned int)lim, s);
+                                        h->cpairctl.as<unsigned int>(), pair_cap, s);
+                    h->ball_limit = h->coarse_gate_fraction * (double)(Tpad / 32) * (double)h->ball_tiles;
                 }
+                h->ball_pass_ran = balls;
                 launch_knn_filter16c(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, h->thr32.as<float>(), h->thr1_32.as<float>(),
                                      Tpad, n_tiles_b, h->slabctr.as<unsigned int>() + 1, h->cpairs.p, h->cpairctl.as<unsigned int>(), pair_cap,
                                      h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, knn_pool_chunk_entries(), s,
-                                     balls ? 1 : 0);
+                                     !balls);
             }
             else if (bf)
                 launch_knn_sweep16b(1, h->prefilter == 2 ? 4 : 3, nt_run, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, h->thr32.as<float>(), Tpad, n_slabs_b,
@@ -1206,9 +1220,21 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
                                 bound_in != nullptr,         // a shard's lists under the shared bound are short
                                 bound_in ? nullptr : h->thr.as<double>(), h->margin_stat.as<unsigned int>());
         }
-        if (deferred_status) return 0;       // the batch caller redoes failures with precision 0
+        if (deferred_status) {               // the batch caller redoes failures with precision 0
+            // (and learns how many tile pairs the ball pass listed)
+            if (pairs_listed_dev) {
+                if (coarse && h->ball_pass_ran) HIPCHK(hipMemcpyAsync(pairs_listed_dev, h->cpairctl.p, sizeof(unsigned int), hipMemcpyDeviceToDevice, s));
+                else HIPCHK(hipMemsetAsync(pairs_listed_dev, 0, sizeof(unsigned int), s));
+            }
+            return 0;
+        }
         int status = 0;
-        CHK(d2h_sync(h, &status, h->status.p, sizeof(int), s));
+        {
+            unsigned int listed = 0;
+            D2HPart parts[2] = {{&status, h->status.p, sizeof(int)}, {&listed, h->cpairctl.p, coarse ? sizeof(unsigned int) : 0}};
+            CHK(staged_d2h(h, s, parts, 2));
+            note_ball_pairs(h, listed);
+        }
         HIPCHK(hipGetLastError());
         h->last_f16_status = status;
         if (status == 0) return 0;
@@ -1793,9 +1819,9 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     CHK(b.path.ensure((size_t)total * sizeof(int64_t)));
     CHK(b.plen.ensure((size_t)n_utts * sizeof(int64_t)));
     CHK(b.cost.ensure((size_t)n_utts * sizeof(double)));
-    CHK(b.status.ensure((size_t)b.n_groups * sizeof(int)));
+    CHK(b.status.ensure((size_t)2 * b.n_groups * sizeof(int)));          // per group: K-NN status word | tile pairs the ball pass listed
     const size_t sz_path = ((size_t)total * sizeof(int64_t) + 63) & ~(size_t)63;
-    const size_t sz_u = ((size_t)n_utts * 8 + 63) & ~(size_t)63, sz_st = ((size_t)b.n_groups * sizeof(int) + 63) & ~(size_t)63;
+    const size_t sz_u = ((size_t)n_utts * 8 + 63) & ~(size_t)63, sz_st = ((size_t)2 * b.n_groups * sizeof(int) + 63) & ~(size_t)63;
     CHK(b.stage.ensure(sz_path + 2 * sz_u + sz_st));
     {
         StageTimer t(h, h->stream, TM_H2D);
@@ -1805,7 +1831,9 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     for (int g = 0; g < b.n_groups; ++g) {
         const int64_t r0 = row_offsets[b.first[g]], rows = row_offsets[b.first[g + 1]] - r0;
         CHK(knn_device(h, b.Qall.as<double>() + r0 * D, rows, K, nullptr, b.cand.as<int64_t>() + r0 * K,
-                       b.dist.as<double>() + r0 * K, nullptr, b.status.as<int>() + g));
+                       b.dist.as<double>() + r0 * K, nullptr, b.status.as<int>() + g, nullptr, nullptr, false, false,
+                       reinterpret_cast<unsigned int *>(b.status.as<int>() + b.n_groups + g)));
+        b.ball_limit = h->ball_pass_ran ? h->ball_limit : -1.0;
         CHK(viterbi_group(h, g, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
                           b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), n_utts));
     }
@@ -1820,7 +1848,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
         HIPCHK(hipMemcpyAsync(st, b.path.p, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
         HIPCHK(hipMemcpyAsync(st + sz_path, b.plen.p, (size_t)n_utts * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
         HIPCHK(hipMemcpyAsync(st + sz_path + sz_u, b.cost.p, (size_t)n_utts * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
-        HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u, b.status.p, (size_t)b.n_groups * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u, b.status.p, (size_t)2 * b.n_groups * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
     }
     HIPCHK(hipEventRecord(b.done, h->copy_stream));
     HIPCHK(hipGetLastError());
@@ -1845,6 +1873,9 @@ int snk_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, i
     char *st = (char *)b.stage.p;
     // deferred K-NN status words: redo the (rare) group whose sampled thresholds overflowed a list
     const int *status = reinterpret_cast<const int *>(st + sz_path + 2 * sz_u);
+    if (b.ball_limit >= 0.0 && !h->filter_coarse)
+        for (int g = 0; g < b.n_groups; ++g)
+            if ((double)(unsigned int)status[b.n_groups + g] > b.ball_limit) { h->filter_coarse = true; h->ball_switches += 1; break; }
     bool redone = false;
     for (int g = 0; g < b.n_groups; ++g) {
         if (status[g] == 0) continue;
@@ -3204,12 +3235,8 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     }
     else if (!strcmp(name, "prefilter_two_pass")) *out = h->prefilter_two_pass;
     else if (!strcmp(name, "prefilter_balls")) *out = h->prefilter_balls;
-    else if (!strcmp(name, "ball_pairs") || !strcmp(name, "coarse_ran")) {
-        // most recent two-pass filter: tile pairs the ball pass listed; whether the coarse sweep had to run instead
-        unsigned int v[4] = {0u, 0u, 0u, 0u};
-        if (h->cpairctl.p) { HIPCHK(hipSetDevice(h->device)); CHK(d2h_sync(h, v, h->cpairctl.p, sizeof(v), h->stream)); }
-        *out = (double)v[name[0] == 'b' ? 3 : 2];
-    }
+    else if (!strcmp(name, "filter_coarse")) *out = h->filter_coarse ? 1 : 0;       // 1: the ball pass listed too many pairs for this voice
+    else if (!strcmp(name, "ball_switches")) *out = (double)h->ball_switches;
     else if (!strcmp(name, "coarse_pairs") || !strcmp(name, "coarse_pair_overflow")) {
         // tile pairs the coarse pass of the most recent two-pass filter let through (debug / tuning aid)
         unsigned int v[2] = {0u, 0u};

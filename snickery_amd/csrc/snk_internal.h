@@ -147,7 +147,7 @@ size_t knn_coarse_pair_bytes();
 bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32, const float *thr1,
                           int64_t T32, int64_t n_tiles, unsigned int *ctr, void *pairs, unsigned int *pair_ctl, unsigned int pair_cap,
                           void *pool, unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s,
-                          int gated = 0);     // gated: the coarse sweep runs only if pair_ctl[2] says so (knn_coarse_gate_kernel)
+                          bool run_coarse = true);     // false: the pair list is already there (the ball pass wrote it)
 // pass 0: the tiles' balls (centre, radius) against the query rows; lists pairs, then gates the coarse sweep
 void launch_build_tile_balls(const double *Fw, int64_t N, int Dt, int Dpad, int64_t n_tiles, double *C, double *cnorm, float *rad,
                              hipStream_t s);
@@ -155,7 +155,7 @@ void launch_ball_query_terms(const float *thr32, const double *eps, const double
                              hipStream_t s);
 bool launch_knn_balls16b(int terms, int dch, int grid_cus, const void *C16, const void *B16, const float *rad, const float *tq,
                          const float *nq, int64_t T32, int64_t n_tiles, void *pairs, unsigned int *pair_ctl, unsigned int pair_cap,
-                         unsigned int gate_limit, hipStream_t s);
+                         hipStream_t s);
 void launch_db16b_ratios(const double *Fw, int64_t N, int Dt, int Dpad, double *rho, hipStream_t s, bool accumulate = false);   // accumulate: max with what rho holds
 bool launch_knn_sweep16b(int mode, int terms, int nt, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32,
                          int64_t T32, int64_t n_slabs, unsigned int *ctr, float *gmin32, int64_t G, void *pool,

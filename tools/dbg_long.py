@@ -19,4 +19,4 @@ bad = np.nonzero((cand != oc_cand).any(1) | (dist != oc_dist).any(1))[0]
 print('bad rows', len(bad), bad[:20], bad[-5:] if len(bad) else '')
 if len(bad):
     r = bad[0]; print(cand[r], oc_cand[r]); print(dist[r], oc_dist[r])
-print("fallbacks", e.info("f16_fallbacks"), "pairs", e.info("coarse_pairs"), e.info("coarse_pair_overflow"), "ball pairs", e.info("ball_pairs"), "coarse ran", e.info("coarse_ran"))
+print("fallbacks", e.info("f16_fallbacks"), "pairs", e.info("coarse_pairs"), e.info("coarse_pair_overflow"), "filter_coarse", e.info("filter_coarse"))

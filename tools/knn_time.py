@@ -30,6 +30,6 @@ for pre, frac in configs:
     st = {k: round(v[0] / 3, 3) for k, v in tm.items() if v[1]}
     print('prefilter %d sample 1/%d: %.2f ms/call  same=%s  list mean %.0f max %.0f  %s' % (pre, round(1 / frac), dt * 1e3,
           np.array_equal(ref[0], cand) and np.array_equal(ref[1], dist), eng.info('last_list_mean'), eng.info('last_list_max'), st),
-          'pairs', eng.info('coarse_pairs'), 'ball pairs', eng.info('ball_pairs'), 'coarse ran', eng.info('coarse_ran'), flush=True)
+          'pairs', eng.info('coarse_pairs'), 'filter_coarse', eng.info('filter_coarse'), flush=True)
     eng.close()
     # (the last engine's tile-pair counts of the two-pass filter)
