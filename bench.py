@@ -238,6 +238,9 @@ def main():
                          '(the per-utterance recursions of its last group, the copy of the results) runs beside the K-NN of the '
                          'next one -- how a tuning loop over a tune set drives the engine; every step completes inside the timed '
                          'region.  1: strictly one step at a time (reported as extra field one_in_flight otherwise)')
+    ap.add_argument('--upload-every-step', action='store_true',
+                    help='N = 1: upload the query rows from the host inside every timed step (default: resident in HBM when the '
+                         'timed region starts; the rate with uploads is then the extra field with_upload)')
     ap.add_argument('--exchange', choices=('library', 'torch'), default='library',
                     help="N > 1, sharded database: collectives inside libsnkhip.so (snk_comm_init: RCCL on the engine's stream; "
                          "default) or torch.distributed collectives between the device-pointer entry points (snickery_amd/dist.py)")
@@ -376,6 +379,23 @@ def main():
 
     for _ in range(args.warmup):
         paths, costs = step()
+    resident = world == 1 and args.in_flight == 2 and not args.upload_every_step
+    if world == 1 and args.in_flight == 2:
+        batch.pin()
+        # the inputs of the timed region are resident in HBM when it starts (task contract): both workspaces of the
+        # two-in-flight pipeline receive the batch's rows here, untimed; the timed steps search them again (Q == NULL,
+        # include/snk.h).  The rate with the rows uploaded from the host in every step is the extra field `with_upload`.
+        for _ in range(2):
+            paths, costs = eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(batch, K))
+
+    def pipelined(steps, res):
+        pending, out = None, None
+        for _ in range(steps):
+            ticket = eng.knn_viterbi_batch_submit(batch, K, resident=res)
+            if pending is not None:
+                out = eng.knn_viterbi_batch_collect(pending)
+            pending = ticket
+        return eng.knn_viterbi_batch_collect(pending)
     eng.reset_timers()
     sync()
     t0 = time.perf_counter()
@@ -384,14 +404,7 @@ def main():
         # (its last recursions, the copy of the results, the host-side hand-over) runs beside the K-NN
         # of the next one -- what a tuning loop over a tune set does.  All K steps complete inside
         # the timed region.
-        batch.pin()
-        pending = None
-        for _ in range(args.steps):
-            ticket = eng.knn_viterbi_batch_submit(batch, K)
-            if pending is not None:
-                paths, costs = eng.knn_viterbi_batch_collect(pending)
-            pending = ticket
-        paths, costs = eng.knn_viterbi_batch_collect(pending)
+        paths, costs = pipelined(args.steps, resident)
     elif world > 1 and args.in_flight == 2 and pipeline is not None:
         my_utts.pin()
         submit, collect = pipeline
@@ -450,6 +463,17 @@ def main():
                         'note': 'the same GPUs as %d independent replicas (whole database on every GPU, no collective), two steps in flight' % world}
         elif rank == 0:
             sys.stderr.write('replicas extra skipped: %s\n' % (err or 'a rank failed'))
+    # the same pipeline with the query rows uploaded from the host in every step (an extra field, never `value`)
+    with_upload = None
+    if world == 1 and args.in_flight == 2 and resident:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pu, cu = pipelined(args.steps, False)
+        torch.cuda.synchronize()
+        eu = time.perf_counter() - t1
+        with_upload = {'value': frames_per_step * args.steps / eu, 'unit': 'frames/s', 'ms_per_step': eu / args.steps * 1e3,
+                       'same_results': bool(all(np.array_equal(a, b) for a, b in zip(pu, paths)) and np.array_equal(cu, costs)),
+                       'note': 'the query rows (%.1f MB per step) cross PCIe inside every timed step, from page-locked host memory' % (batch.Q.nbytes / 1e6)}
     # a second, separately timed pass in the OTHER submission mode (an extra field, never `value`)
     two_in_flight = one_in_flight = None
     if world == 1 and args.in_flight == 1:
@@ -562,6 +586,9 @@ def main():
                 'prefilter_margin_rows': margin_rows, 'prefilter_min_margin': min_margin,
                 'note': 'margin = (filter threshold - exact K-th key) / assumed key error, over every row of the timed steps; '
                         'rows below 2 would have lost a neighbour had the bf16 accumulation assumption been off by 2x'}
+        if with_upload is not None:
+            out['with_upload'] = with_upload
+        out['config']['inputs'] = 'resident in HBM' if resident else 'uploaded from the host every step'
         if two_in_flight is not None:
             out['two_in_flight'] = two_in_flight
         if one_in_flight is not None:

@@ -189,6 +189,8 @@ struct BatchSlot {    // one submitted batch (snk_knn_viterbi_batch_submit / _co
     hipEvent_t done = nullptr;            // results of this batch are in `stage`
     bool busy = false;
     int n_utts = 0, n_groups = 0, K = 0, D = 0;
+    int64_t q_rows = -1; int q_D = 0;     // query rows resident in Qall (a later submit with Q == NULL searches them again)
+    std::vector<int64_t> q_offs;
     double ball_limit = -1.0;             // >= 0: the ball pass listed this batch's tile pairs; beyond this many the voice goes to the coarse sweep
     int64_t total = 0;
     std::vector<int> first;
@@ -1798,7 +1800,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     if (h->sticket[0].busy || h->sticket[1].busy)
         return fail("snk_knn_viterbi_batch_submit: a submitted sharded step is still in flight (snk_sharded_knn_viterbi_batch_collect it first)");
     HIPCHK(hipSetDevice(h->device));
-    if (!Q || !row_offsets || n_utts < 1 || !ticket_out)
+    if (!row_offsets || n_utts < 1 || !ticket_out)
         return fail("snk_knn_viterbi_batch_submit: null/empty argument");
     if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
     if (h->Njc != h->N + 1) return fail("snk_knn_viterbi_batch: join_contexts rows != N+1");
@@ -1813,7 +1815,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     b.n_groups = (int)b.first.size() - 1;
     b.n_utts = n_utts; b.K = K; b.D = D; b.total = total;
     b.offs.assign(row_offsets, row_offsets + n_utts + 1);
-    CHK(b.Qall.ensure((size_t)total * D * sizeof(double)));
+    { void *before = b.Qall.p; CHK(b.Qall.ensure((size_t)total * D * sizeof(double))); if (b.Qall.p != before) b.q_rows = -1; }
     CHK(b.cand.ensure((size_t)total * K * sizeof(int64_t)));
     CHK(b.dist.ensure((size_t)total * K * sizeof(double)));
     CHK(b.path.ensure((size_t)total * sizeof(int64_t)));
@@ -1823,10 +1825,16 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     const size_t sz_path = ((size_t)total * sizeof(int64_t) + 63) & ~(size_t)63;
     const size_t sz_u = ((size_t)n_utts * 8 + 63) & ~(size_t)63, sz_st = ((size_t)2 * b.n_groups * sizeof(int) + 63) & ~(size_t)63;
     CHK(b.stage.ensure(sz_path + 2 * sz_u + sz_st));
-    {
+    if (Q) {
         StageTimer t(h, h->stream, TM_H2D);
         CHK(h2d_via(b.qstage, b.Qall.p, Q, (size_t)total * D * sizeof(double), h->stream));
         if (!h->tsel.empty()) launch_mask_columns(b.Qall.as<double>(), total, D, h->tmask.as<double>(), h->stream);
+        b.q_rows = total; b.q_D = D;
+        b.q_offs.assign(row_offsets, row_offsets + n_utts + 1);
+    } else if (b.q_rows != total || b.q_D != D || b.q_offs.size() != (size_t)n_utts + 1 ||
+               !std::equal(b.q_offs.begin(), b.q_offs.end(), row_offsets)) {
+        return fail("snk_knn_viterbi_batch_submit: no query matrix given and this workspace holds no rows of that shape "
+                    "(the first submit on each of the two workspaces must carry Q)");
     }
     for (int g = 0; g < b.n_groups; ++g) {
         const int64_t r0 = row_offsets[b.first[g]], rows = row_offsets[b.first[g + 1]] - r0;

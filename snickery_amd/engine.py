@@ -391,13 +391,16 @@ class HipSearchEngine(object):
         self._check(self._lib.snk_set_column_selection(self._h, t.ctypes.data_as(ip) if t is not None else None, nt,
                                                        j.ctypes.data_as(ip) if j is not None else None, nj))
 
-    def knn_viterbi_batch_submit(self, utterances, n_candidates):
+    def knn_viterbi_batch_submit(self, utterances, n_candidates, resident=False):
         """Queue a batch and return at once; at most two batches may be in flight.  Returns a ticket
         for knn_viterbi_batch_collect.  Submitting the next batch before collecting this one hides
-        this one's tail (last recursions, copy to the host) behind the next one's K-NN."""
+        this one's tail (last recursions, copy to the host) behind the next one's K-NN.
+        resident: the rows of this very batch are still on the device from the previous submit on the workspace this
+        ticket gets (two workspaces alternate: the first two submits must upload) and are searched again without an
+        upload (include/snk.h)."""
         b = _as_batch(utterances)
         ticket = ctypes.c_int(-1)
-        self._check(self._lib.snk_knn_viterbi_batch_submit(self._h, _ptr(b.Q, _c_f64p), _ptr(b.offsets, _c_i64p), len(b),
+        self._check(self._lib.snk_knn_viterbi_batch_submit(self._h, None if resident else _ptr(b.Q, _c_f64p), _ptr(b.offsets, _c_i64p), len(b),
                                                            b.Q.shape[1], int(n_candidates), ctypes.byref(ticket)))
         return (ticket.value, b)              # the batch (host rows) stays referenced until collected
 

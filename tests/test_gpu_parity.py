@@ -311,6 +311,34 @@ def test_viterbi_batch_submit_collect(engine):
         engine.set_option('batch_rows', 12288)
 
 
+def test_batch_submit_with_resident_rows(engine):
+    """Q == NULL (resident=True): the rows the workspace holds from its previous submit are searched again with the same
+    results; rows of another shape, or a workspace that never received rows, are refused."""
+    import snickery_amd
+    F_unw, JC_unw, wt, wj, F, E, S = synth_setup(30000, 61, 40, seed=23)
+    eng = snickery_amd.HipSearchEngine()         # a fresh engine: its two workspaces hold no rows yet
+    eng.upload_db(F_unw, JC_unw)
+    eng.set_weights(wt, wj)
+    a = snickery_amd.QueryBatch([o.synthetic_targets(F_unw, T, seed=40 + i) * wt for i, T in enumerate((33, 48, 20, 7))])
+    b = snickery_amd.QueryBatch([o.synthetic_targets(F_unw, T, seed=50 + i) * wt for i, T in enumerate((50, 2, 61))])
+    with pytest.raises(snickery_amd.SnkError):
+        eng.knn_viterbi_batch_submit(a, 20, resident=True)
+    want_a = eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(a, 20))        # workspace 0
+    want_b = eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(b, 20))        # workspace 1 (they alternate)
+    ta = eng.knn_viterbi_batch_submit(a, 20, resident=True)
+    tb = eng.knn_viterbi_batch_submit(b, 20, resident=True)
+    for got, want in ((eng.knn_viterbi_batch_collect(ta), want_a), (eng.knn_viterbi_batch_collect(tb), want_b)):
+        assert all(np.array_equal(x, y) for x, y in zip(got[0], want[0])) and np.array_equal(got[1], want[1])
+    with pytest.raises(snickery_amd.SnkError):   # workspace 0 holds the rows of `a`, not of `b`
+        eng.knn_viterbi_batch_submit(b, 20, resident=True)
+    for u in range(len(a)):
+        U = a.Q[a.offsets[u]:a.offsets[u + 1]]
+        oc, od = o.knn_bruteforce(F, U, 20)
+        op, ocst = o.viterbi(oc, od, E, S)
+        assert list(want_a[0][u]) == op and want_a[1][u] == ocst
+    eng.close()
+
+
 def test_greedy_golden(mini_engine, golden, mini_voice):
     for me in (6, 1):
         mini_engine.set_greedy_layout(me, False, 0)
