@@ -29,6 +29,9 @@
 //        only decide how often the slow branch runs, never the result.
 #include "snk_internal.h"
 #include <float.h>
+#include <stdio.h>
+#include <vector>
+#include <algorithm>
 
 namespace snk {
 
@@ -558,6 +561,14 @@ __device__ __forceinline__ double jf_wave_min(double x)
     return ab < cd ? ab : cd;
 }
 
+// -DSNK_JF_TRACE: a debug build whose pass 4 stamps the shader clock at six points of each of the first 1024 steps
+// (wavefront 0 and the loader) behind the statistics words; launch_viterbi_sparse prints the averages.
+#ifdef SNK_JF_TRACE
+#define JF_STAMP(i) do { if (stats && lane == 0 && t < 1024 && (wave == 0 || loader)) stats[128 + (size_t)t * 16 + (loader ? 8 : 0) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define JF_STAMP(i) do { } while (0)
+#endif
+
 template <int BS, bool BPL>
 __global__ void __launch_bounds__(320)
 viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__restrict__ rec_all,
@@ -648,11 +659,13 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
         const double *dprev = delta + ((t - 1) & 1) * 256;
         double *dcur = delta + (t & 1) * 256;
         double *wr = wrec + (t & 1) * 8;
+        JF_STAMP(0);
         if (loader) {
             if (sin == BS - 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // batch bidx + 1 has landed (issued BS steps ago)
                 dma_batch((int64_t)bidx + 2);                      // into the slot batch bidx - 1 has left
             }
+            JF_STAMP(1);
         } else {
             // this step's record
             const u32x4 *rp = ring + rp_off;
@@ -667,6 +680,10 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
             c[2] = f64(q2[2], q2[3]);
             c[3] = f64(q3[0], q3[1]);
             const unsigned int ix = q3[2];
+#ifdef SNK_JF_TRACE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            JF_STAMP(1);
+#endif
             const int n_raw = (int)(q3[3] & 0xffu);
             const int n = n_raw > JF_CAP ? JF_CAP : n_raw;
 #pragma unroll
@@ -678,6 +695,10 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
                 best = take ? tot : best;
                 arg = take ? p : arg;
             }
+#ifdef SNK_JF_TRACE
+            asm volatile("" : "+v"(best));
+            JF_STAMP(2);
+#endif
             // proof that no predecessor outside the set wins or ties (strict, with room for the roundings)
             const bool usable = td < inf;
             bool ok = true;
@@ -694,8 +715,10 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
             const double wm = jf_wave_min(diff);
             const bool wfail = __ballot(fail) != 0ull;
             if (lane == 0) { wr[2 * wave] = wm; wr[2 * wave + 1] = wfail ? 1.0 : 0.0; }
+            JF_STAMP(3);
         }
         __syncthreads();
+        JF_STAMP(4);
         // four compute wavefronts, always (launch_viterbi_sparse): { minimum, failed } x 4
         const double o0 = wr[0], f0 = wr[1], o1 = wr[2], f1 = wr[3], o2 = wr[4], f2 = wr[5], o3 = wr[6], f3 = wr[7];
         const double o01 = o0 < o1 ? o0 : o1, o23 = o2 < o3 ? o2 : o3;
@@ -758,6 +781,7 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
             if constexpr (BPL) bp_lds[bp_off] = (unsigned char)arg;
             else bp_global[bp_off] = (unsigned char)arg;
         }
+        JF_STAMP(5);
         bp_off += K;
         rp_off += K4;
         if (++sin == BS) {
@@ -803,6 +827,462 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// pass 4, one compute wavefront per utterance (the form launch_viterbi_sparse runs; the four-wavefront kernel above is
+// its A/B partner, option viterbi_sparse_waves = 4).  A step of the recursion is a chain of dependent instructions: what
+// it costs is the length of that chain, and with four wavefronts a third of it was the exchange between them (a barrier
+// and an LDS round trip for `off` and the failure flag; the loader's 25 LDS-DMA instructions, issued before the barrier
+// of every fourth step, on top).  Here lane l owns the columns l, l + 64, ... (NC of them):
+//   * delta_{t-1} lives in LDS, written and read by the same wavefront (LDS operations of a wavefront execute in order:
+//     no barrier inside a batch),
+//   * `off` is a DPP minimum over float32 images rounded to below (a LOWER bound of the exact minimum: the proof only
+//     gets stricter, by 1.2e-7 of |off|),
+//   * the loader wavefront meets the compute wavefront at ONE barrier per batch of steps and issues its LDS-DMA loads
+//     right after it, beside the batch's steps; batches are NL KB each, two of them in flight (s_waitcnt vmcnt(NL):
+//     loads return in order),
+//   * a failing cell's candidates get their exact cost from the whole wavefront: squares in parallel (one column of
+//     the join vectors per lane), the canonical ordered sum read back from LDS by every lane.
+// Same arithmetic, same decisions, same statistics as the kernel above.
+// ---------------------------------------------------------------------------------------------
+#define JF1_NL 16              // 1-KB LDS-DMA loads per batch (a ring slot is JF1_NL KB)
+#define JF1_SQ 4096            // doubles: the squares of JF1_SQ / (Dj + 2) exact costs at a time (>= JF_MAXD + 3: one at least)
+#define JF1_PAIRS 512          // pairs listed before their exact costs are taken
+
+__device__ __forceinline__ unsigned int jf_image(float f)       // order-preserving image of a float (no NaN)
+{
+    const unsigned int u = __builtin_bit_cast(unsigned int, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float jf_unimage(unsigned int u)
+{
+    return __builtin_bit_cast(float, (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ unsigned int jf_wave_min_u32(unsigned int v)
+{
+#define JF_DPP(ctrl_, rmask_)                                                                         \
+    {                                                                                                 \
+        const unsigned int o = (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl_, rmask_, 0xf, false); \
+        v = o < v ? o : v;                                                                            \
+    }
+    JF_DPP(0xB1, 0xf)        // quad_perm [1,0,3,2]
+    JF_DPP(0x4E, 0xf)        // quad_perm [2,3,0,1]
+    JF_DPP(0x141, 0xf)       // row_half_mirror
+    JF_DPP(0x140, 0xf)       // row_mirror
+    JF_DPP(0x142, 0xa)       // row_bcast:15 into rows 1 and 3
+    JF_DPP(0x143, 0xc)       // row_bcast:31 into rows 2 and 3
+#undef JF_DPP
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// canonical float64 join cost of (a, b) by the whole wavefront: the same separately rounded operations in the same
+// order as jf_exact_cost (the squares are independent; only their sum is ordered).  sq: LDS, Dj + 1 doubles.
+__device__ __forceinline__ double jf_exact_cost_wave(const float *__restrict__ JC_unw, int Jp, int Dj,
+                                                     const double *__restrict__ wj, int64_t a, int64_t b,
+                                                     double *sq, int lane)
+{
+    const float *__restrict__ re = JC_unw + (a + 1) * (int64_t)Jp;
+    const float *__restrict__ rs = JC_unw + b * (int64_t)Jp;
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < Dj; c += 64) {
+        const double w = wj[c];
+        const double d = __dsub_rn(__dmul_rn((double)re[c], w), __dmul_rn((double)rs[c], w));
+        sq[c] = __dmul_rn(d, d);
+    }
+    if (lane == 0) sq[Dj] = 0.0;                       // the sum runs in pairs: acc + 0.0 == acc (acc >= +0)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const f64x2 *sp = reinterpret_cast<const f64x2 *>(sq);
+    double acc = 0.0;
+    for (int c = 0; c < Dj; c += 2) {
+        const f64x2 v = sp[c >> 1];
+        acc = __dadd_rn(acc, v[0]);
+        acc = __dadd_rn(acc, v[1]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return __dsqrt_rn(acc);
+}
+
+template <int NC, bool BPL>
+__global__ void __launch_bounds__(128)
+viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__restrict__ rec_all,
+                       const float *__restrict__ Jlo_all, const float *__restrict__ JC_unw, int Jp, int Dj,
+                       const double *__restrict__ wj, const DpBatch batch, int K, int BS, int64_t n_units,
+                       unsigned char *__restrict__ bp_all, int64_t *__restrict__ path_all,
+                       int64_t *__restrict__ path_len_all, double *__restrict__ cost_all,
+                       unsigned long long *__restrict__ stats)
+{
+    __builtin_amdgcn_s_setprio(3);           // as viterbi_lb_kernel
+    const int64_t r0 = batch.off[blockIdx.x];
+    const int64_t T = batch.off[blockIdx.x + 1] - r0;
+    const int64_t *__restrict__ cand = cand_all + r0 * K;
+    const JfRecord *__restrict__ rec = rec_all + r0 * K;
+    const float *__restrict__ Jlo = Jlo_all + r0 * K * K;
+    unsigned char *__restrict__ bp_global = bp_all + r0 * K;
+    int64_t *__restrict__ path = path_all + r0;
+    int64_t *__restrict__ path_len = path_len_all + batch.first + blockIdx.x;
+    double *__restrict__ cost = cost_all + batch.first + blockIdx.x;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *delta = reinterpret_cast<double *>(smem);              // [2][256]
+    double *rbest = delta + 2 * 256;                               // [256] refinement: a failing column's best total
+    double *sq = rbest + 256;                                      // [JF1_SQ] squares of a round of exact costs
+    int *rarg = reinterpret_cast<int *>(sq + JF1_SQ);              // [256] ... and its predecessor slot
+    int *final_slot_p = rarg + 256;                                // [4]
+    unsigned short *plist = reinterpret_cast<unsigned short *>(final_slot_p + 4);   // [JF1_PAIRS] (failing column << 8) | predecessor
+    unsigned char *flist = reinterpret_cast<unsigned char *>(plist + JF1_PAIRS);    // [256] the failing columns of a step
+    u32x4 *ring = reinterpret_cast<u32x4 *>(flist + 256);          // [3][JF1_NL * 64] records of three batches (4 x 16 bytes per cell)
+    const int slot_pieces = JF1_NL * 64;
+    unsigned char *bp_lds = reinterpret_cast<unsigned char *>(ring + (size_t)3 * slot_pieces);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave == 1;
+    const double inf = __builtin_inf();
+    int kc[NC];
+    bool col[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { kc[c] = lane + 64 * c; col[c] = !loader && kc[c] < K; }
+
+    if (T < 2) {                      // the reference's J has no states for T < 2
+        if (tid == 0) { *path_len = 0; *cost = inf; }
+        return;
+    }
+    for (int i = tid; i < 2 * 256; i += (int)blockDim.x) delta[i] = inf;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) if (col[c]) delta[kc[c]] = rec[kc[c]].td;      // td of row 0 (+inf for an unusable unit)
+    // Loader: the records of batch j (steps j BS + 1 .. j BS + BS) are consecutive in global memory and go to ring slot
+    // j % 3 by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes to M0 + 16 lane, no registers), always JF1_NL
+    // loads (the tail of a slot beyond BS K cells is never read).  Inline asm: the compiler neither counts these loads
+    // nor drains them; the loader waits for them itself.
+    const u32x4 *const rsrc = reinterpret_cast<const u32x4 *>(rec);
+    const int64_t total_pieces = T * (int64_t)K * 4;
+    const unsigned ring_lds = (unsigned)(size_t)ring;              // LDS byte offset of the ring
+    const int pieces = BS * K * 4;                                 // 16-byte pieces of one batch (<= slot_pieces: the launcher)
+    auto dma_batch = [&](int j) {
+        const int64_t base = ((int64_t)j * BS + 1) * (int64_t)K * 4;
+        const unsigned dst0 = ring_lds + (unsigned)(j % 3) * (unsigned)slot_pieces * 16u;
+#pragma unroll 4
+        for (int i = 0; i < slot_pieces; i += 64) {
+            int64_t pc = base + i + lane;
+            if (i + lane >= pieces || pc >= total_pieces) pc = 0;  // padding of the slot / beyond the utterance: never read
+            const u32x4 *src = rsrc + pc;
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(dst0 + (unsigned)i * 16u);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
+        }
+    };
+    if (loader) {
+        dma_batch(0); dma_batch(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (loader) dma_batch(2);                                      // lands beside batch 0 (slot 2 is free)
+
+    double off = 0.0;                                              // a lower bound of min over the columns of delta_{t-1} - d~_{t-1}; off_0 = 0
+    double off_base = 0.0;                                         // the last finite one
+    const int Ti = (int)T, K4 = K * 4;
+    int bidx = 0, sin = 0, ring_slot = 0;
+    int rp_base = 0;                                               // first piece of this step's records in the ring
+    int bp_off = K;
+    for (int t = 1; t < Ti; ++t) {
+        const bool last_of_batch = sin == BS - 1;
+        if (!loader) {
+            JF_STAMP(0);
+            const double *dprev = delta + ((t - 1) & 1) * 256;
+            double *dcur = delta + (t & 1) * 256;
+            double best[NC], d[NC], td[NC], lbv[NC];
+            int arg[NC];
+            bool fail[NC];
+            float dmin = __builtin_inff();
+            bool anyfail_lane = false;
+            const double offm = off < inf ? off - 1e-12 * fabs(off) : 0.0;
+            u32x4 q[NC][4];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const u32x4 *rp = ring + rp_base + (col[c] ? kc[c] : 0) * 4;
+                q[c][0] = rp[0]; q[c][1] = rp[1]; q[c][2] = rp[2]; q[c][3] = rp[3];
+            }
+#ifdef SNK_JF_TRACE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            JF_STAMP(1);
+#endif
+            auto f64 = [](unsigned int lo, unsigned int hi) { return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32)); };
+            double dp[NC][JF_CAP];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const unsigned int ix = q[c][3][2];
+#pragma unroll
+                for (int j = 0; j < JF_CAP; ++j) dp[c][j] = dprev[(ix >> (8 * j)) & 0xffu];
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const u32x4 q0 = q[c][0], q1 = q[c][1], q2 = q[c][2], q3 = q[c][3];
+                td[c] = f64(q0[0], q0[1]);
+                const double xv = f64(q0[2], q0[3]);
+                lbv[c] = f64(q1[0], q1[1]);
+                double cj[JF_CAP];
+                cj[0] = f64(q1[2], q1[3]);
+                cj[1] = f64(q2[0], q2[1]);
+                cj[2] = f64(q2[2], q2[3]);
+                cj[3] = f64(q3[0], q3[1]);
+                const unsigned int ix = q3[2];
+                const int n_raw = (int)(q3[3] & 0xffu);
+                const int n = n_raw > JF_CAP ? JF_CAP : n_raw;
+                // the record holds +inf costs beyond the set's n members (join_exact_sparse_kernel): their totals are +inf
+                double tot[JF_CAP];
+#pragma unroll
+                for (int j = 0; j < JF_CAP; ++j) tot[j] = __dadd_rn(dp[c][j], cj[j]);
+                const double bst = __builtin_fmin(__builtin_fmin(tot[0], tot[1]), __builtin_fmin(tot[2], tot[3]));
+                unsigned int ag = 0x7fffffffu;                         // among equal totals the lowest slot
+#pragma unroll
+                for (int j = 0; j < JF_CAP; ++j) {
+                    const unsigned int pj = (tot[j] == bst) ? ((ix >> (8 * j)) & 0xffu) : 0x7fffffffu;
+                    ag = pj < ag ? pj : ag;
+                }
+                ag = bst < inf ? ag : 0u;
+                // proof that no predecessor outside the set wins or ties (strict, with room for the roundings)
+                const bool usable = td[c] < inf;
+                const double bound = __dadd_rn(__builtin_fma(-1e-12, fabs(xv), xv), offm);
+                // xv == inf: every predecessor with a finite lower-bound total is in the set
+                const bool ok = (n_raw <= JF_CAP) & (!(xv < inf) | ((off < inf) & (bound > bst)));
+                fail[c] = col[c] & usable & !ok;
+                anyfail_lane |= fail[c];
+                best[c] = bst; arg[c] = (int)ag;
+                d[c] = (col[c] & usable) ? __dadd_rn(td[c], bst) : inf;
+            }
+#ifdef SNK_JF_TRACE
+            asm volatile("" : "+v"(d[0]));
+            JF_STAMP(2);
+#endif
+            const bool anyfail = __ballot(anyfail_lane) != 0ull;
+            if (__builtin_expect(anyfail, 0)) {
+                // Refinement, the whole step at once: (1) the failing columns into a list; (2) every (failing column,
+                // predecessor) pair tested against the column's best total so far (delta[k'] + clo(k',k) <= best: a
+                // handful pass), the loads of all of them in flight together; (3) the exact costs of the pairs that
+                // passed, a few per round: squares by the whole wavefront, the canonical ordered sums one lane each.
+                const unsigned long long lt_mask = (1ull << lane) - 1ull;
+                int nf = 0, n_exact = 0, np = 0;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const unsigned long long fm = __ballot(fail[c]);
+                    if (fail[c]) {
+                        flist[nf + __builtin_popcountll(fm & lt_mask)] = (unsigned char)kc[c];
+                        rbest[kc[c]] = best[c]; rarg[kc[c]] = arg[c];
+                    }
+                    nf += __builtin_popcountll(fm);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int stride = (Dj + 2) | 1;                        // odd: the summing lanes read different banks
+                const int npr = JF1_SQ / stride < 64 ? JF1_SQ / stride : 64;
+                auto flush = [&]() {
+                    for (int r0 = 0; r0 < np; r0 += npr) {
+                        const int nr = np - r0 < npr ? np - r0 : npr;
+                        for (int r = 0; r < nr; ++r) {
+                            const unsigned int e = (unsigned int)__builtin_amdgcn_readfirstlane((int)plist[r0 + r]);
+                            const int64_t a = cand[(int64_t)(t - 1) * K + (e & 0xffu)], b = cand[(int64_t)t * K + (e >> 8)];
+                            const float *__restrict__ re = JC_unw + (a + 1) * (int64_t)Jp;
+                            const float *__restrict__ rs = JC_unw + b * (int64_t)Jp;
+                            double *row = sq + r * stride;
+#pragma unroll 4
+                            for (int cc = lane; cc < Dj; cc += 64) {
+                                const double w = wj[cc];
+                                const double dd = __dsub_rn(__dmul_rn((double)re[cc], w), __dmul_rn((double)rs[cc], w));
+                                row[cc] = __dmul_rn(dd, dd);
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        double totr = inf;
+                        if (lane < nr) {                            // jf_exact_cost's sum, in its order
+                            double acc = 0.0;
+                            const double *row = sq + lane * stride;
+                            int cc = 0;
+                            for (; cc + 8 <= Dj; cc += 8) {
+                                double v[8];
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) v[i] = row[cc + i];
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) acc = __dadd_rn(acc, v[i]);
+                            }
+                            for (; cc < Dj; ++cc) acc = __dadd_rn(acc, row[cc]);
+                            totr = __dadd_rn(dprev[plist[r0 + lane] & 0xffu], __dsqrt_rn(acc));
+                        }
+                        for (int r = 0; r < nr; ++r) {              // in list order: a column's candidates one after the other
+                            const double tr = jf_readlane_f64(totr, r);
+                            const unsigned int e = plist[r0 + r];
+                            const int kf = (int)(e >> 8), pp = (int)(e & 0xffu);
+                            const double cur = rbest[kf];
+                            const int ca = rarg[kf];
+                            __builtin_amdgcn_wave_barrier();
+                            if ((tr < cur || (tr == cur && pp < ca)) && lane == 0) { rbest[kf] = tr; rarg[kf] = pp; }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        }
+                        n_exact += nr;
+                    }
+                    np = 0;
+                };
+                const int total = nf * K;
+                const float *__restrict__ jslab = Jlo + (t - 1) * (int64_t)K * K;
+                for (int base = 0; base < total; base += 256) {     // four rounds of 64 pairs: their loads in flight together
+                    bool want[4];
+                    unsigned int e[4];
+                    float lo[4];
+                    double dpp[4], rb[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int idx = base + 64 * i + lane;
+                        const int ix2 = idx < total ? idx : 0;
+                        const int fi = ix2 / K, pp = ix2 - fi * K, kf = flist[fi];
+                        e[i] = ((unsigned int)kf << 8) | (unsigned int)pp;
+                        lo[i] = jslab[(int64_t)pp * K + kf];
+                        dpp[i] = dprev[pp];
+                        rb[i] = rbest[kf];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        want[i] = base + 64 * i + lane < total && dpp[i] < inf && lo[i] < __builtin_inff() && __dadd_rn(dpp[i], (double)lo[i]) <= rb[i];
+                        const unsigned long long wm = __ballot(want[i]);
+                        if (want[i]) plist[np + __builtin_popcountll(wm & lt_mask)] = (unsigned short)e[i];
+                        np += __builtin_popcountll(wm);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (np > JF1_PAIRS - 256) flush();
+                }
+                flush();
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (fail[c]) { best[c] = rbest[kc[c]]; arg[c] = rarg[kc[c]]; d[c] = __dadd_rn(td[c], best[c]); }
+                if (stats && lane == 0) {
+                    atomicAdd(&stats[0], (unsigned long long)nf); atomicAdd(&stats[1], 1ull);
+                    if (n_exact) atomicAdd(&stats[2], (unsigned long long)n_exact);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (col[c]) {
+                    dcur[kc[c]] = d[c];
+                    if constexpr (BPL) bp_lds[bp_off + kc[c]] = (unsigned char)arg[c];
+                    else bp_global[bp_off + kc[c]] = (unsigned char)arg[c];
+                }
+                // relative to the previous step's bound: d~ is shifted towards 0 every 64 steps while delta grows, so the
+                // differences are large numbers that move by about a step's cost -- THAT is what float32 may round
+                const double diff = (col[c] && d[c] < inf) ? __dsub_rn(__dsub_rn(d[c], lbv[c]), off_base) : inf;
+                const float df = (float)diff;
+                dmin = df < dmin ? df : dmin;
+            }
+            const float m32 = jf_unimage(jf_wave_min_u32(jf_image(dmin)));
+            // float32 rounding is monotone: the minimum of the rounded values is the rounded minimum, within 2^-24 of it;
+            // the subtraction and the addition of off_base round once each (1e-15 of the magnitudes)
+            if (m32 < __builtin_inff()) {
+                const double o = off_base + ((double)m32 - 1.2e-7 * fabs((double)m32));
+                off = o - 4e-16 * (fabs(o) + fabs(off_base));
+                off_base = off;
+            } else off = inf;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                       // delta_t is in LDS before the next step reads it
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            JF_STAMP(3);
+        } else if (last_of_batch) {
+            // batch bidx + 1 has landed when at most the JF1_NL loads of batch bidx + 2 are still in flight
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(JF1_NL) : "memory");
+        }
+        bp_off += K;
+        rp_base += K4;
+        if (++sin == BS) {
+            __syncthreads();                                       // the compute wavefront has left batch bidx; batch bidx + 1 is in the ring
+            sin = 0; ++bidx;
+            ring_slot = ring_slot == 2 ? 0 : ring_slot + 1;
+            rp_base = ring_slot * slot_pieces;
+            if (loader) dma_batch(bidx + 2);                       // into the slot batch bidx - 1 has left
+            JF_STAMP(4);
+        }
+    }
+    if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing in flight into LDS past this point (the ring is reused below)
+    __syncthreads();
+
+    const double *dlast = delta + ((T - 1) & 1) * 256;
+    if (tid == 0) {
+        double best = inf;
+        int slot = 0;
+        for (int kk = 0; kk < K; ++kk)
+            if (dlast[kk] < best) { best = dlast[kk]; slot = kk; }
+        if (best == inf) { *path_len = 0; *cost = inf; *final_slot_p = -1; }
+        else { *path_len = T; *cost = best; *final_slot_p = slot; }
+    }
+    if (!BPL) __threadfence();
+    __syncthreads();
+    // back-trace as above
+    if (*final_slot_p >= 0) {
+        if constexpr (BPL) {
+            unsigned char *slots = reinterpret_cast<unsigned char *>(ring);       // the ring is free now (T <= its size is checked by the launcher)
+            if (tid == 0) {
+                int slot = *final_slot_p;
+                for (int64_t t = T - 1; t >= 0; --t) {
+                    slots[t] = (unsigned char)slot;
+                    if (t > 0) slot = bp_lds[t * K + slot];
+                }
+            }
+            __syncthreads();
+            for (int64_t t = tid; t < T; t += (int)blockDim.x) path[t] = cand[t * K + slots[t]];
+        } else if (tid == 0) {
+            int slot = *final_slot_p;
+            for (int64_t t = T - 1; t >= 0; --t) {
+                path[t] = cand[t * K + slot];
+                if (t > 0) slot = bp_global[t * K + slot];
+            }
+        }
+    }
+}
+
+static int g_sparse_waves = 1;
+void set_viterbi_sparse_waves(int w) { g_sparse_waves = w == 4 ? 4 : 1; }
+
+static void jf_trace_dump(unsigned long long *stats, int n, int64_t T, hipStream_t s)
+{
+#ifdef SNK_JF_TRACE
+    if (!stats || n != 1) return;
+    static std::vector<unsigned long long> tr(16 * 1024);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(tr.data(), stats + 128, tr.size() * 8, hipMemcpyDeviceToHost);
+    const int64_t n_t = T < 1024 ? T : 1024;
+    double seg[8] = {0};
+    const int last = g_sparse_waves == 1 ? 3 : 5;
+    for (int64_t t = 2; t + 1 < n_t; ++t) {
+        const unsigned long long *a = &tr[(size_t)t * 16], *b = &tr[(size_t)(t + 1) * 16];
+        for (int i = 0; i < last; ++i) seg[i] += (double)(a[i + 1] - a[i]);
+        seg[5] += (double)(b[0] - a[last]);
+        seg[7] += (double)(b[0] - a[0]);
+    }
+    {
+        std::vector<double> v;
+        for (int i = 0; i <= last; ++i) {
+            v.clear();
+            for (int64_t t = 2; t + 1 < n_t; ++t) {
+                const unsigned long long *a = &tr[(size_t)t * 16], *b = &tr[(size_t)(t + 1) * 16];
+                v.push_back(i < last ? (double)(a[i + 1] - a[i]) : (double)(b[0] - a[last]));
+            }
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "[jf-trace] segment %d: median %.0f, p90 %.0f, max %.0f\n", i, v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+        }
+    }
+    fprintf(stderr, "[jf-trace] clocks per step %.0f: segments %.0f %.0f %.0f %.0f %.0f, loop %.0f\n", seg[7] / (n_t - 3), seg[0] / (n_t - 3),
+            seg[1] / (n_t - 3), seg[2] / (n_t - 3), seg[3] / (n_t - 3), seg[4] / (n_t - 3), seg[5] / (n_t - 3));
+#else
+    (void)stats; (void)n; (void)T; (void)s;
+#endif
+}
+
 void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jlo, const float *JC_unw, int Jp, int Dj,
                            const double *wj, const int64_t *off, int n_utts, int first_utt, int K, int64_t n_units,
                            unsigned char *bp_global, int64_t *path, int64_t *path_len, double *cost,
@@ -815,6 +1295,33 @@ void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jl
         for (int i = 0; i <= n; ++i) batch.off[i] = off[u0 + i];
         for (int i = 0; i < n; ++i) T = (off[u0 + i + 1] - off[u0 + i] > T) ? off[u0 + i + 1] - off[u0 + i] : T;
         batch.first = first_utt + u0;
+        if (g_sparse_waves == 1) {
+            const int nc = (K + 63) / 64;
+            int bs1 = (JF1_NL * 1024) / (K * 64);                  // steps per batch: what a JF1_NL-KB slot holds
+            if (bs1 < 1) bs1 = 1;
+            const size_t base1 = (size_t)(3 * 256 + JF1_SQ) * 8 + 256 * 4 + 16 + JF1_PAIRS * 2 + 256 + (size_t)3 * JF1_NL * 1024;
+            const size_t bp_bytes1 = (size_t)T * K;
+            const bool bpl1 = base1 + bp_bytes1 + 64 <= 150 * 1024 && (size_t)T <= (size_t)3 * JF1_NL * 1024;
+            const size_t shmem1 = base1 + (bpl1 ? bp_bytes1 : 0);
+#define SNK_SP1(NC_, BPL_)                                                                                        \
+    {                                                                                                             \
+        static size_t attr_set[32] = {0};                                                                         \
+        if (lds_attr_needed(attr_set, 150 * 1024)) {                                                              \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&viterbi_sparse1_kernel<NC_, BPL_>),               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));                   \
+        }                                                                                                         \
+        hipLaunchKernelGGL((viterbi_sparse1_kernel<NC_, BPL_>), dim3(n), dim3(128), shmem1, s, cand,              \
+                           reinterpret_cast<const JfRecord *>(rec), Jlo, JC_unw, Jp, Dj, wj, batch, K, bs1, n_units, \
+                           bp_global, path, path_len, cost, stats);                                               \
+    }
+            if (nc == 1) { if (bpl1) SNK_SP1(1, true) else SNK_SP1(1, false) }
+            else if (nc == 2) { if (bpl1) SNK_SP1(2, true) else SNK_SP1(2, false) }
+            else if (nc == 3) { if (bpl1) SNK_SP1(3, true) else SNK_SP1(3, false) }
+            else { if (bpl1) SNK_SP1(4, true) else SNK_SP1(4, false) }
+#undef SNK_SP1
+            jf_trace_dump(stats, n, T, s);
+            continue;
+        }
         const int nth = 64 * 5;                                    // four compute wavefronts (refinement: one per failing column) + the loader
         const int bs = K <= 104 ? 4 : 2;                           // steps per loader batch (registers: bs K / 16 per lane)
         const size_t slot_bytes = (((size_t)bs * K * 4 + 63) & ~(size_t)63) * 16;
@@ -836,6 +1343,7 @@ void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jl
         if (bs == 4) { if (bp_in_lds) SNK_SP(4, true) else SNK_SP(4, false) }
         else { if (bp_in_lds) SNK_SP(2, true) else SNK_SP(2, false) }
 #undef SNK_SP
+        jf_trace_dump(stats, n, T, s);
     }
 }
 

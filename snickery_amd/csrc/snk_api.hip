@@ -1541,7 +1541,7 @@ static int sparse_ensure(snk_engine *h, UttSlot &s, int64_t rows, int K)
     CHK(s.cex.ensure((size_t)rows * K * join_record_bytes() + 4096));
     CHK(s.bp.ensure((size_t)rows * K));
     if (!h->vstats.p) {
-        CHK(h->vstats.ensure(128 * sizeof(unsigned long long)));
+        CHK(h->vstats.ensure((128 + 16 * 1024) * sizeof(unsigned long long)));    // + the stamps of a -DSNK_JF_TRACE build
         HIPCHK(hipMemset(h->vstats.p, 0, 128 * sizeof(unsigned long long)));
     }
     return 0;
@@ -3147,6 +3147,11 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0 && value != 2.0) return fail("viterbi_mode must be 0 (dense exact join + recursion), 1 (lower bounds + sparse exact recursion) or 2 (auto)");
         CHK(no_batch_in_flight(h, "snk_set_option(viterbi_mode)"));
         h->viterbi_mode = (int)value;
+    } else if (!strcmp(name, "viterbi_sparse_waves")) {
+        // process-wide (a debugging / A-B switch): which form of the sparse exact recursion runs; same results
+        if (value != 1.0 && value != 4.0) return fail("viterbi_sparse_waves must be 1 (one compute wavefront per utterance) or 4");
+        CHK(no_batch_in_flight(h, "snk_set_option(viterbi_sparse_waves)"));
+        set_viterbi_sparse_waves((int)value);
     } else if (!strcmp(name, "shard_gather_queries")) {
         if (value != 0.0 && value != 1.0) return fail("shard_gather_queries must be 0 or 1 (the same on every rank)");
         h->shard_gather_queries = (int)value;
