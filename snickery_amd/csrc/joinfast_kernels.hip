@@ -256,7 +256,7 @@ template <int KPM, int NB, int NTH>
 __global__ void __launch_bounds__(NTH)
 viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict__ tdist_all,
                   const float *__restrict__ J_all, const float *__restrict__ scale_all, const DpBatch batch, int K,
-                  int64_t n_units, int KP, float beta, u32x4 *__restrict__ sets_all)
+                  int64_t n_units, int KP, float beta, u32x4 *__restrict__ sets_all, int64_t chunk_len, int warm)
 {
     // a T-step chain on one compute unit beside the K-NN sweep's MFMA wavefronts: its few instructions go first
     __builtin_amdgcn_s_setprio(3);
@@ -283,14 +283,27 @@ viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
     const int nwaves = (int)blockDim.x >> 6;
 
     if (T < 1) return;
+    // Chunks in time (blockIdx.y; chunk_len >= T: one chunk, the whole utterance).  Chunk c owns the records of the steps
+    // t0 .. t1 - 1 and starts `warm` steps earlier from d~ = the target costs of row ts - 1, as if the utterance began
+    // there: d~ needs no property of its own (above), only X must be consistent with the STORED d~ of the step before.
+    // So the record of step t0 - 1 is shared: its d~ is written by chunk c (the value its X of step t0 was computed
+    // against), its X / set by chunk c - 1 (computed against that chunk's own d~ of step t0 - 2, stored by it).
+    // After a few dozen steps the two d~ differ by nearly a constant (the paths into step t0 - 1 have merged), which
+    // pass 4's `off` absorbs; what remains only decides how often pass 4 refines.
+    const int chunk = (int)blockIdx.y;
+    const int64_t t0 = 1 + chunk * chunk_len;
+    if (chunk > 0 && t0 >= T) return;
+    const int64_t t1 = t0 + chunk_len < T ? t0 + chunk_len : T;
+    const bool last_chunk = t1 >= T;
+    const int64_t ts = (chunk == 0 || t0 - warm < 1) ? 1 : t0 - warm;
     for (int i = tid; i < 2 * KP; i += (int)blockDim.x) delta[i] = inf;
     for (int i = tid; i < KP; i += (int)blockDim.x) { lcnt[i] = 0; lidx[i] = 0; }
     if (tid < 16) wmin[tid] = inf;
     __syncthreads();
     if (lead) {
-        const float d0 = jf_usable(cand[k], n_units) ? (float)tdist[k] : inf;
-        delta[k] = d0;
-        sets[k] = (u32x4){__builtin_bit_cast(unsigned int, d0), __builtin_bit_cast(unsigned int, inf), 0u, 0u};
+        const float d0 = jf_usable(cand[(ts - 1) * K + k], n_units) ? (float)tdist[(ts - 1) * K + k] : inf;
+        delta[((ts - 1) & 1) * KP + k] = d0;
+        if (chunk == 0) sets[k] = (u32x4){__builtin_bit_cast(unsigned int, d0), __builtin_bit_cast(unsigned int, inf), 0u, 0u};
     }
     if (T < 2) return;
 
@@ -315,8 +328,8 @@ viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
     };
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
-        load_slab(s < T - 2 ? s : T - 2, jb[s]);
-        load_target(1 + s, td_raw[s], id_raw[s], sc_raw[s]);
+        load_slab(ts - 1 + s < T - 2 ? ts - 1 + s : T - 2, jb[s]);
+        load_target(ts + s, td_raw[s], id_raw[s], sc_raw[s]);
     }
     __syncthreads();
 
@@ -324,7 +337,7 @@ viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
     // minima (fminf costs a canonicalising v_max per operand) and the sweeps have no branch per element.
     const unsigned int INFU = 0x7f800000u;
     auto step = [&](int64_t t, float (&jr)[KPM], double &tdr, int64_t &idr, float &scr) {
-        const bool valid = t < T;                       // uniform
+        const bool valid = t < t1;                      // uniform
         const float *dprev = delta + ((t - 1) & 1) * KP;
         float *dcur = delta + (t & 1) * KP;
         const float td = jf_usable(idr, n_units) ? (float)tdr : inf;
@@ -392,8 +405,14 @@ viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
             if (x < inf) x -= 3.6e-7f * fabsf(x) + 3.6e-7f * fabsf(shift) + 1e-37f;
             const int n = lcnt[k];
             lcnt[k] = 0;
-            sets[t * K + k] = (u32x4){__builtin_bit_cast(unsigned int, d), __builtin_bit_cast(unsigned int, x), lidx[k],
-                                      (unsigned int)(n > JF_CAP ? JF_CAP + 1 : n)};
+            unsigned int *cell = reinterpret_cast<unsigned int *>(sets + t * K + k);
+            if (t < t0) {
+                if (t == t0 - 1) cell[0] = __builtin_bit_cast(unsigned int, d);          // the shared record: this chunk's d~
+            } else if (t == t1 - 1 && !last_chunk) {                                    // ... and the chunk before's X and set
+                cell[1] = __builtin_bit_cast(unsigned int, x); cell[2] = lidx[k]; cell[3] = (unsigned int)(n > JF_CAP ? JF_CAP + 1 : n);
+            } else
+                sets[t * K + k] = (u32x4){__builtin_bit_cast(unsigned int, d), __builtin_bit_cast(unsigned int, x), lidx[k],
+                                          (unsigned int)(n > JF_CAP ? JF_CAP + 1 : n)};
         }
         if ((t & 63) == 0) {                            // uniform: a shift step publishes the wavefront's minimum
             float m = lead ? d : inf;
@@ -404,20 +423,24 @@ viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
         __syncthreads();
     };
 
-    for (int64_t t = 1; t < T; t += NB) {
+    for (int64_t t = ts; t < t1; t += NB) {
 #pragma unroll
         for (int s = 0; s < NB; ++s) step(t + s, jb[s], td_raw[s], id_raw[s], sc_raw[s]);
     }
 }
 
 void launch_viterbi_lb(const int64_t *cand, const double *tdist, const float *Jlo, const float *scale, const int64_t *off,
-                       int n_utts, int K, int64_t n_units, float beta, void *sets, hipStream_t s)
+                       int n_utts, int K, int64_t n_units, float beta, void *sets, hipStream_t s, int chunk_len, int warm)
 {
     static_assert(JF_CAP == 4, "the sets travel as one 32-bit word");
     for (int u0 = 0; u0 < n_utts; u0 += DpBatch::MAX) {
         const int n = (n_utts - u0 < DpBatch::MAX) ? n_utts - u0 : DpBatch::MAX;
         DpBatch batch;
+        int64_t Tmax = 1;
         for (int i = 0; i <= n; ++i) batch.off[i] = off[u0 + i];
+        for (int i = 0; i < n; ++i) Tmax = off[u0 + i + 1] - off[u0 + i] > Tmax ? off[u0 + i + 1] - off[u0 + i] : Tmax;
+        const int64_t clen = chunk_len > 0 ? chunk_len : (int64_t)1 << 40;
+        const unsigned n_chunks = chunk_len > 0 && Tmax > 1 ? (unsigned)((Tmax - 1 + clen - 1) / clen) : 1u;
         batch.first = u0;
         int variant, kpm;
         if (K <= 64) { variant = 0; kpm = 16; }
@@ -428,8 +451,8 @@ void launch_viterbi_lb(const int64_t *cand, const double *tdist, const float *Jl
         const int nth = 64 * ((K + 15) / 16);
         const size_t shmem = (size_t)2 * KP * 4 + (size_t)KP * 4 + (size_t)KP * 4 + 64;
 #define SNK_LB(KPM_, NB_, NTH_)                                                                               \
-    hipLaunchKernelGGL((viterbi_lb_kernel<KPM_, NB_, NTH_>), dim3(n), dim3(nth), shmem, s, cand, tdist, Jlo, scale, \
-                       batch, K, n_units, KP, beta, reinterpret_cast<u32x4 *>(sets))
+    hipLaunchKernelGGL((viterbi_lb_kernel<KPM_, NB_, NTH_>), dim3(n, n_chunks), dim3(nth), shmem, s, cand, tdist, Jlo, scale, \
+                       batch, K, n_units, KP, beta, reinterpret_cast<u32x4 *>(sets), clen, warm)
         if (variant == 0) SNK_LB(16, 4, 256);
         else if (variant == 1) SNK_LB(25, 6, 448);
         else if (variant == 2) SNK_LB(32, 3, 512);

@@ -1,8 +1,3 @@
-// viterbi_mode 2 (default): the sparse path where it pays -- batches (its first pass runs over the whole chip
-// while the per-utterance passes hide beside the next group's K-NN; a single utterance is quicker through the
-// dense kernels: 1.7 against 2.4 ms at T = 600, K = 100), every supported K (the K > 128 instances of passes 1 and 2
-// spill registers and still take 23 against 35 ms per 32 utterances at K = 200).  1 forces it wherever it is
-// supported, 0 forces the dense exact path.  Same results.
 // C ABI of libsnkhip.so (include/snk.h): host-side engine around the gfx950 kernels.
 // Device memory, streams and events are plain HIP; there is no CPU compute fallback.
 #include "snk_internal.h"
@@ -319,6 +314,12 @@ struct snk_engine {
     int batch_rows = 12288;    // rows per K-NN call of the batch entry points (utterances are grouped)
     int viterbi_mode = 2;      // 2: auto; 1: f32 lower bounds on the matrix pipe + sparse exact recursion; 0: dense exact join + recursion
     double join_beta = 5e-4;   // pass-2 margin in units of the step's largest centred norm (speed only, never the result)
+    // pass 2 (approximate recursion) in chunks of viterbi_lb_chunk steps side by side (0: one chain per utterance), each
+    // started viterbi_lb_warm steps early; launches of up to viterbi_lb_chunk_max_utts utterances (24 = all).  A single
+    // utterance (T = 600, K = 100) 0.93 -> 0.10 ms; a B* step 5.98 -> 5.60 ms.  Up to four utterances: chunks of 32 at most.
+    int lb_chunk = 48;
+    int lb_chunk_max_utts = 24;
+    int lb_warm = 16;
     DevBuf vstats;             // [0] cells refined, [1] steps with a refinement, [2] exact costs computed there
     int pool_chunk_limit = 0;  // test hook: cap of the entry pool (chunks) in every attempt; 0 = none
     int pool_chunks = 4096;    // entry pool: 4096 chunks x 2048 entries x 16 B = 128 MiB      // left free by the persistent K-NN sweep for Viterbi DP blocks
@@ -1522,15 +1523,15 @@ static int64_t join_units(snk_engine *h)
     return h->Njc - 1;
 }
 
-// viterbi_mode 2 (default): the sparse path where it pays -- batches (its first pass runs over the whole chip
-// while the per-utterance passes hide beside the next group's K-NN; a single utterance is quicker through the
-// dense kernels: 1.7 against 2.4 ms at T = 600, K = 100) up to K = 128 (the K <= 208 variant of pass 2 is
-// register-bound).  1 forces it wherever it is supported, 0 forces the dense exact path.  Same results.
+// viterbi_mode 2 (default): the sparse path wherever it is supported -- batches (its first pass runs over the whole
+// chip while the per-utterance passes hide beside the next group's K-NN) and, since pass 2 runs in chunks side by
+// side and pass 4 on one wavefront, a single utterance too (T = 600, K = 100: 0.75 ms against 1.65 ms through the
+// dense kernels).  1 forces it, 0 forces the dense exact path.  Same results.
 static bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts = 1)
 {
+    (void)n_utts;
     if (!join_lb_supported(h->Dj, K)) return false;
-    if (h->viterbi_mode == 1) return true;
-    return h->viterbi_mode == 2 && n_utts >= 2;
+    return h->viterbi_mode == 1 || h->viterbi_mode == 2;
 }
 
 static int sparse_ensure(snk_engine *h, UttSlot &s, int64_t rows, int K)
@@ -1572,7 +1573,8 @@ static int viterbi_sparse_rows(snk_engine *h, UttSlot &s, const int64_t *cand, c
     {
         StageTimer t(h, side, TM_DP_LB);
         launch_viterbi_lb(cand, tdist, s.Jlo.as<float>(), s.scale.as<float>(), off, n_utts, K, join_units(h),
-                          (float)h->join_beta, s.sets.p, side);
+                          (float)h->join_beta, s.sets.p, side,
+                          n_utts <= h->lb_chunk_max_utts ? (n_utts <= 4 && h->lb_chunk > 32 ? 32 : h->lb_chunk) : 0, h->lb_warm);
     }
     {
         StageTimer t(h, side, TM_JOIN_SPARSE);
@@ -3147,6 +3149,11 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0 && value != 2.0) return fail("viterbi_mode must be 0 (dense exact join + recursion), 1 (lower bounds + sparse exact recursion) or 2 (auto)");
         CHK(no_batch_in_flight(h, "snk_set_option(viterbi_mode)"));
         h->viterbi_mode = (int)value;
+    } else if (!strcmp(name, "viterbi_lb_chunk") || !strcmp(name, "viterbi_lb_warm") || !strcmp(name, "viterbi_lb_chunk_max_utts")) {
+        if (!(value >= 0.0 && value <= 1e6) || value != (double)(int)value) return fail("%s must be a small non-negative integer", name);
+        if (!strcmp(name, "viterbi_lb_warm") && value < 1.0) return fail("viterbi_lb_warm must be >= 1");
+        CHK(no_batch_in_flight(h, "snk_set_option(viterbi_lb_*)"));
+        (!strcmp(name, "viterbi_lb_chunk") ? h->lb_chunk : !strcmp(name, "viterbi_lb_warm") ? h->lb_warm : h->lb_chunk_max_utts) = (int)value;
     } else if (!strcmp(name, "viterbi_sparse_waves")) {
         // process-wide (a debugging / A-B switch): which form of the sparse exact recursion runs; same results
         if (value != 1.0 && value != 4.0) return fail("viterbi_sparse_waves must be 1 (one compute wavefront per utterance) or 4");

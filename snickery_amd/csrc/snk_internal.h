@@ -185,7 +185,8 @@ bool join_lb_supported(int Dj, int K);
 void launch_join_lb(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
                     int64_t R, int K, float *Jlo, float *scale, hipStream_t s);
 void launch_viterbi_lb(const int64_t *cand, const double *tdist, const float *Jlo, const float *scale, const int64_t *off,
-                       int n_utts, int K, int64_t n_units, float beta, void *sets, hipStream_t s);
+                       int n_utts, int K, int64_t n_units, float beta, void *sets, hipStream_t s,
+                       int chunk_len = 0, int warm = 32);   // chunk_len > 0: the approximate recursion in chunks of that many steps, side by side
 size_t join_record_bytes();
 void launch_join_exact_sparse(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
                               const double *tdist, int64_t R, int K, const void *sets, void *rec, hipStream_t s);

@@ -57,6 +57,46 @@ def test_sparse_equals_dense_and_oracle(engine, N, Dj, T, K):
     assert len(paths[2]) == 0
 
 
+@pytest.mark.parametrize('waves', [1, 4])
+def test_chunked_lower_bound_recursion_and_both_exact_recursions(engine, waves):
+    """Pass 2 in chunks side by side (viterbi_lb_chunk / viterbi_lb_warm: chunk lengths around the shift period of 64,
+    chunks of one step, a warm-up of one step, a warm-up longer than the utterance) and pass 4 on one or on four compute
+    wavefronts: path and cost equal the oracle's bit for bit; only the number of refined cells may move."""
+    N, Dj, K = 20000, 151, 40
+    F_unw, JC_unw, wt, wj = _db(N, 61, Dj, seed=211)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    JCw = o.weight(JC_unw, wj)
+    rng = np.random.RandomState(9)
+    T = 200
+    U = np.vstack([o.synthetic_targets(F_unw, 120, seed=6), F_unw[rng.randint(0, N, T - 120)] + rng.randn(T - 120, 61)]) * wt
+    engine.set_option('viterbi_mode', 0)
+    path0, cost0, cand, dist = engine.knn_viterbi(U, K, return_candidates=True)
+    opath, ocost = oc.viterbi(cand, dist, JCw)
+    assert path0 == opath and cost0 == ocost
+    # an unusable unit and a duplicate in the middle of a chunk and on a chunk boundary
+    cand = cand.copy(); cand[64, 3] = 0; cand[65, 5] = cand[65, 6]; cand[97, :] = np.roll(cand[97, :], 1)
+    opath, ocost = oc.viterbi(cand, dist, JCw)
+    engine.set_option('viterbi_mode', 1)
+    engine.set_option('viterbi_sparse_waves', waves)
+    try:
+        for chunk, warm in ((0, 16), (1, 1), (7, 3), (32, 16), (63, 5), (64, 64), (65, 1), (48, 500), (199, 16), (500, 16)):
+            engine.set_option('viterbi_lb_chunk', chunk)
+            engine.set_option('viterbi_lb_warm', warm)
+            path1, cost1 = engine.viterbi(cand, dist)
+            assert path1 == opath and cost1 == ocost, (chunk, warm)
+            paths, costs = engine.viterbi_batch([cand, cand[:70], cand[:1], cand[60:131]], [dist, dist[:70], dist[:1], dist[60:131]])
+            assert list(paths[0]) == opath and costs[0] == ocost, (chunk, warm)
+            p70, c70 = oc.viterbi(cand[:70], dist[:70], JCw)
+            assert list(paths[1]) == p70 and costs[1] == c70, (chunk, warm)
+            pm, cm = oc.viterbi(cand[60:131], dist[60:131], JCw)
+            assert list(paths[3]) == pm and costs[3] == cm, (chunk, warm)
+    finally:
+        engine.set_option('viterbi_lb_chunk', 48)
+        engine.set_option('viterbi_lb_warm', 16)
+        engine.set_option('viterbi_sparse_waves', 1)
+
+
 def test_sparse_with_unusable_duplicate_and_padded_candidates(engine):
     """Quinphone-style lists: duplicated ids inside a column (exact ties between predecessors: the lower
     slot must win), -1 padding, units 0 and N-1 (no join state), a column with no usable unit."""
@@ -88,11 +128,11 @@ def test_sparse_with_unusable_duplicate_and_padded_candidates(engine):
         path, cost = engine.viterbi(dead, dist)
         assert path == [] and cost == np.inf
     engine.set_option('viterbi_mode', 1)
-    # the default (mode 2) picks the dense kernels for one utterance and the sparse path for a batch
+    # the default (mode 2) picks the sparse path for one utterance too (chunked pass 2, one-wavefront pass 4)
     engine.set_option('viterbi_mode', 2)
     before = engine.timers().get('viterbi_sparse', (0, 0))[1]
     engine.viterbi(base, dist)
-    assert engine.timers().get('viterbi_sparse', (0, 0))[1] == before
+    assert engine.timers().get('viterbi_sparse', (0, 0))[1] == before + 1
     engine.set_option('viterbi_mode', 1)
 
 

@@ -14,9 +14,12 @@ U = synthetic_targets(F_unw, T, seed=1) * wt
 eng = snickery_amd.HipSearchEngine(0)
 eng.upload_db(F_unw, JC_unw); eng.set_weights(wt, wj)
 ref = None
-for mode, waves in ((0, 1), (1, 4), (1, 1)):
+import itertools
+for mode, waves, chunk, warm in [(0, 1, 0, 32), (1, 4, 0, 32), (1, 1, 0, 32)] + [(1, 1, c, w) for c in (32, 48, 64, 96) for w in (8, 16, 32, 48)]:
     eng.set_option('viterbi_mode', mode)
     eng.set_option('viterbi_sparse_waves', waves)
+    eng.set_option('viterbi_lb_chunk', chunk)
+    eng.set_option('viterbi_lb_warm', warm)
     out = eng.knn_viterbi(U, K)
     if ref is None: ref = out
     for _ in range(3): eng.knn_viterbi(U, K)
@@ -30,5 +33,5 @@ for mode, waves in ((0, 1), (1, 4), (1, 1)):
     st = {k: round(v[0] / n, 3) for k, v in tm.items() if v[1]}
     same = all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(out, ref))
     st1 = [eng.info(x) for x in ('dense_cells', 'dense_steps', 'dense_exact_costs', 'set_overflows')]
-    print('viterbi_mode %d waves %d: %.3f ms/call same=%s %s' % (mode, waves, dt * 1e3, same, st), 'per call: refined cells %.1f, steps with a refinement %.1f, exact costs there %.1f, set overflows %.1f' % tuple((b - a) / n for a, b in zip(st0, st1)), flush=True)
+    print('viterbi_mode %d waves %d chunk %d warm %d: %.3f ms/call same=%s %s' % (mode, waves, chunk, warm, dt * 1e3, same, st), 'per call: refined cells %.1f, steps with a refinement %.1f, exact costs there %.1f, set overflows %.1f' % tuple((b - a) / n for a, b in zip(st0, st1)), flush=True)
 eng.close()
