@@ -520,13 +520,20 @@ def main():
         bf16_mode = f32_mode and eng.info('prefilter_bf16_active') == 1
         peak = BF16_MFMA_PEAK_TFLOPS if bf16_mode else F32_MFMA_PEAK_TFLOPS if f32_mode else F64_MFMA_PEAK_TFLOPS
         terms = 4 if eng.info('prefilter') == 2 else 3
-        kname = ('knn_sweep16b<filter> (v_mfma_f32_32x32x16_bf16 prefilter, every operand split into two bf16 pieces: '
+        two_pass = bf16_mode and eng.info('prefilter_two_pass') == 1
+        coarse_now = two_pass and eng.info('filter_coarse') == 1
+        kname = (('knn_coarse16b + knn_refine16b' if coarse_now else 'knn_balls16b + knn_refine16b') +
+                 ' (the filter stage, v_mfma_f32_32x32x16_bf16: %s lists the (32 units x 32 rows) tile pairs that can hold a key under '
+                 'the row thresholds, the refine pass takes the %d-term bf16-split keys of those pairs only; exact f64 re-rank in '
+                 'knn_finalize)' % ('a one-term hi.hi sweep' if coarse_now else 'a bound from the tiles\' centres and radii', terms)
+                 if two_pass else
+                 'knn_sweep16b<filter> (v_mfma_f32_32x32x16_bf16 prefilter, every operand split into two bf16 pieces: '
                  '%d MFMA terms per product; exact f64 re-rank in knn_finalize)' % terms if bf16_mode else
                  'knn_sweep16<filter> (v_mfma_f32_32x32x2_f32 prefilter; exact f64 re-rank in knn_finalize)'
                  if f32_mode else 'knn_sweep<filter> (v_mfma_f64_16x16x4_f64)')
         traffic = None
         traffic_source = None
-        tfile = os.path.join(ROOT, 'profiles', 'r02_traffic_bf16.json' if bf16_mode else 'r01_traffic_f32.json' if f32_mode else 'r01_traffic.json')
+        tfile = os.path.join(ROOT, 'profiles', 'r03_traffic_filter.json' if two_pass else 'r02_traffic_bf16.json' if bf16_mode else 'r01_traffic_f32.json' if f32_mode else 'r01_traffic.json')
         if world == 1 and N == 1048576 and Dt == 61 and os.path.isfile(tfile):
             with open(tfile) as f:
                 tj = json.load(f)
@@ -562,15 +569,40 @@ def main():
         out['viterbi'] = {'mode': 'f32 matrix lower bounds + verified sparse exact recursion' if args.viterbi_mode else 'dense exact float64 join costs',
                           'cells_refined': eng.info('dense_cells'), 'steps_with_refinement': eng.info('dense_steps'),
                           'exact_costs_in_refinement': eng.info('dense_exact_costs')}
+        if args.viterbi_mode and 'join_lower_bounds' in timers and timers['join_lower_bounds'][1]:
+            # the largest single kernel of the Viterbi side (rocprof: profiles/r03_*): lower bounds of all K x K join costs
+            # of consecutive rows on the f32 matrix pipe (v_mfma_f32_16x16x4_f32), centred rows, 2 K^2 Dj flops per row pair
+            jms, jl = timers['join_lower_bounds']
+            jrows = rows_swept / max(jl, 1)
+            jfl = 2.0 * jrows * K * K * Dj
+            jbytes = jrows * K * 2 * Dj * 4 + jrows * K * K * 4        # gathered E and S rows (each read once per row pair) + the bounds written
+            javg = jms / max(jl, 1)
+            out['roofline_join_lb'] = {'bound': 'mfma', 'kernel': 'join_lb_kernel (v_mfma_f32_16x16x4_f32)', 'achieved': jfl / (javg * 1e-3) / 1e12,
+                                       'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': jfl / (javg * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                       'avg_launch_ms': javg, 'launches': jl, 'rows_per_launch': jrows, 'flops_per_launch': jfl,
+                                       'algorithmic_bytes_per_launch': jbytes, 'hbm_frac': jbytes / (javg * 1e-3) / 1e9 / 8000.0,
+                                       'note': 'timed with HIP events on its side stream while the K-NN of the next group shares the chip'}
         if bf16_mode:
             # what the matrix pipe executes for those algorithmic flops: 64-column tiles, 4 bf16 terms per product
             dpad = (Dt + 3 + 63) // 64 * 64
             issued = terms * 2.0 * rows_per_launch * n_local * dpad
+            if two_pass:
+                # first pass: one product per (tile of 32 units, row) -- the centres -- or the hi.hi term of every unit;
+                # second pass: the listed tile pairs (the most recent launch's count)
+                pairs = eng.info('coarse_pairs')
+                first = (2.0 * rows_per_launch * n_local * dpad) if coarse_now else (terms * 2.0 * rows_per_launch * (n_local / 32.0) * dpad)
+                issued = first + terms * 2.0 * pairs * 32 * 32 * dpad
+                out['roofline']['tile_pairs_listed'] = {'last_launch': pairs, 'of': (rows_per_launch / 32.0) * (n_local / 32.0),
+                                                        'fraction': pairs / max((rows_per_launch / 32.0) * (n_local / 32.0), 1.0)}
             out['roofline']['issued'] = {'tflops': issued / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
                                          'frac': issued / (avg_ms * 1e-3) / 1e12 / peak if avg_ms > 0 else 0.0,
-                                         'note': 'float32-grade keys on the bf16 pipe cost %d bf16 MFMA terms per product (hi.hi + hi.lo + '
-                                                 'lo.hi%s) on Dt padded to 64 columns; frac above prices only the algorithmic '
-                                                 '2 N rows Dt flops against the bf16 peak' % (terms, ' + lo.lo' if terms == 4 else '')}
+                                         'note': ('what the matrix pipe executes: the first pass plus %d bf16 MFMA terms (hi.hi + hi.lo + lo.hi%s) for the listed '
+                                                  'tile pairs, on Dt padded to 64 columns; frac above prices the algorithmic 2 N rows Dt flops -- the '
+                                                  'distance evaluations the reference\'s tree query stands for -- against the bf16 peak, so skipping '
+                                                  'tiles raises it' if two_pass else
+                                                  'float32-grade keys on the bf16 pipe cost %d bf16 MFMA terms per product (hi.hi + hi.lo + '
+                                                  'lo.hi%s) on Dt padded to 64 columns; frac above prices only the algorithmic '
+                                                  '2 N rows Dt flops against the bf16 peak') % (terms, ' + lo.lo' if terms == 4 else '')}
         if world == 1 and bf16_mode:
             # tripwire of the bf16-split prefilter's key bound (untimed, after the timed region): the same step with the
             # float32-operand prefilter, whose bound is the analytical one of an f32 FMA chain, must select the same units;

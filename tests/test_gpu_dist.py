@@ -97,6 +97,24 @@ def _lib_worker(rank, world, port, out, use_sample):
             c, dd = o.knn_bruteforce(F, U, K)
             p, cost = o.viterbi(c, dd, E, S)
             ok = ok and list(paths[u]) == p and costs[u] == cost
+    # arguments every rank can judge alone are refused BEFORE the first collective is queued: nobody waits for a rank
+    # that left, and the next step runs as if nothing had happened
+    for bad_K in (500, 0):
+        try:
+            lib_search.knn_viterbi_batch(utts, bad_K)
+            ok = False
+        except snickery_amd.SnkError:
+            pass
+    try:
+        lib_search.knn_viterbi_batch([u[:, :30] for u in utts], K)           # wrong number of columns
+        ok = False
+    except snickery_amd.SnkError:
+        pass
+    paths, costs = lib_search.knn_viterbi_batch(utts[:2], K)
+    for u, U in enumerate(utts[:2]):
+        c, dd = o.knn_bruteforce(F, U, K)
+        p, cost = o.viterbi(c, dd, E, S)
+        ok = ok and list(paths[u]) == p and costs[u] == cost
     # the torch-side path (dist.py collectives) gives the same answer
     eng.comm_destroy()
     tpaths, tcosts = ShardedSearch(HipShardEngine(eng, torch.device('cuda', 0))).knn_viterbi_batch(utts, K)
