@@ -306,6 +306,16 @@ int snk_concat_fragments(snk_handle h, const int64_t *first_row, const int64_t *
  *   greedy_f16 0 / 1 / 2       float16 join tiles: never / for databases streamed from HBM (default) / always
  *   greedy_resident 0 / 1      one utterance against a database whose windowed join matrix fits the chip's LDS: the resident
  *                              scan (greedy_res_kernels.hip; default 1)
+ *   greedy_fenced 0 / 1        release / acquire fences around every hand-off of the one-launch scans (cross-check; default 0)
+ * Options of the Viterbi search:
+ *   viterbi_mode 0 / 1 / 2     dense float64 join + recursion / bounds + sparse exact recursion / sparse wherever supported (default)
+ *   viterbi_lb_chunk, viterbi_lb_warm, viterbi_lb_chunk_max_utts
+ *                              the approximate recursion (pass 2) in chunks of that many steps side by side (default 48; 0: one
+ *                              chain per utterance), each started viterbi_lb_warm steps early (default 16), for launches of up to
+ *                              that many utterances (default 24 = all)
+ *   viterbi_sparse_waves 1 / 4 which form of the exact sparse recursion runs (process-wide; default 1)
+ * Options of the K-NN filter: prefilter 0 / 1 / 2, prefilter_two_pass 0 / 1, prefilter_balls 0 / 1, coarse_gate_fraction
+ * (INTEGRATION.md).  None of these changes a result.
  * infos: greedy_fallbacks, greedy_stalls, greedy_exact_windows, greedy_second_rounds, greedy_hoist_launches,
  * greedy_f16_launches, greedy_f16_delta, greedy_resident_launches.  The other names are listed in INTEGRATION.md.
  * Tripwire of the K-NN prefilter's key bound (snk_reset_timers clears it): prefilter_margin_rows = rows of prefilter K-NN
