@@ -220,6 +220,16 @@ def test_library_rccl_communicator_single_rank():
     eng.close()
 
 
+def _child_report(r):
+    """What a failed child run said: the lines that are not the launcher's boilerplate (the runtime's own last words --
+    'Memory access fault ...', 'terminate called ...', a Python traceback of bench.py -- come long before the launcher's
+    summary), then the tail."""
+    lines = r.stderr.splitlines()
+    keep = [l for l in lines if not l.startswith(('E1', 'W1', 'I1')) and 'torch/distributed' not in l and 'amdgpu.ids' not in l]
+    return 'returncode %s\n--- stderr without launcher lines (first 80) ---\n%s\n--- stderr tail ---\n%s' % (
+        r.returncode, '\n'.join(keep[:80]), r.stderr[-1500:])
+
+
 @pytest.mark.parametrize('nproc,shards,sharding', [(2, 0, 'db-rows/2 + all-to-all of local top-K'),
                                                    (4, 2, 'db-rows/2 + all-to-all of local top-K x 2 replica groups'),
                                                    (2, 1, '2 independent replicas')])
@@ -233,7 +243,7 @@ def test_bench_multi_rank_one_gpu(nproc, shards, sharding):
            '--gpus', str(nproc), '--steps', '2', '--warmup', '1', '--units', '40000', '--frames', '60', '--utts', '5',
            '--candidates', '20', '--no-cpu-baseline', '--db-shards', str(shards)]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, _child_report(r)
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
     js = json.loads(lines[0])
@@ -253,7 +263,7 @@ def test_bench_falls_back_to_the_callers_communicator_when_rccl_cannot_open():
            '--gpus', '2', '--steps', '2', '--warmup', '1', '--units', '40000', '--frames', '60', '--utts', '5',
            '--candidates', '20', '--no-cpu-baseline']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, _child_report(r)
     js = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     assert js['value'] > 0 and 'could not be opened' in js['config']['exchange']
     assert 'library communicator not available' in r.stderr

@@ -5,7 +5,7 @@ first=$1; count=$2
 mkdir -p gpurun_out/r3/clean
 for i in $(seq $first $((first + count - 1))); do
     log=gpurun_out/r3/clean/run_$(printf %02d $i).log
-    timeout 900 python -m pytest tests/ -q -m gpu -p no:cacheprovider > $log 2>&1
+    timeout 900 python -m pytest tests/ -q -m gpu -p no:cacheprovider --durations=6 > $log 2>&1
     rc=$?
     echo "run $i rc=$rc $(grep -a ' passed\| failed\| error' $log | tail -1)" | tee -a gpurun_out/r3/clean/summary_$first.txt
 done
