@@ -187,7 +187,7 @@ def test_library_collectives_two_ranks_one_gpu(use_sample):
 def test_library_collectives_three_ranks_one_gpu():
     """The same with three ranks (uneven shards of 60 001 units, 5 utterances over 3 owners: blocks of 2 / 2 / 1, and a
     one-utterance batch that leaves two ranks without any): more of the offset arithmetic of the exchanges."""
-    port = 35500 + (os.getpid() % 2000)
+    port = 21500 + (os.getpid() % 2000)
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_lib_worker, args=(3, port, out, True), nprocs=3, join=True)
@@ -237,7 +237,7 @@ def test_bench_multi_rank_one_gpu(nproc, shards, sharding):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run), ranks sharing the GPU:
     database sharded over all ranks (default), shard groups x replica groups, independent replicas."""
     env = dict(os.environ, SNK_BENCH_SHARE_GPU='1')
-    port = 31500 + (os.getpid() % 2000) + nproc * 3 + shards
+    port = 23500 + (os.getpid() % 2000) + nproc * 3 + shards
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
            '--gpus', str(nproc), '--steps', '2', '--warmup', '1', '--units', '40000', '--frames', '60', '--utts', '5',
@@ -257,7 +257,7 @@ def test_bench_falls_back_to_the_callers_communicator_when_rccl_cannot_open():
     exchange through torch.distributed instead of one rank dying and the other waiting -- the situation the driver's
     multi-GPU run would be in if the in-library communicator failed for a reason the one-GPU boxes cannot show."""
     env = dict(os.environ, SNK_BENCH_SHARE_GPU='1', SNK_BENCH_FORCE_RCCL='1')
-    port = 33500 + (os.getpid() % 2000)
+    port = 25500 + (os.getpid() % 2000)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
            '--gpus', '2', '--steps', '2', '--warmup', '1', '--units', '40000', '--frames', '60', '--utts', '5',
