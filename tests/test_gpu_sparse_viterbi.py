@@ -57,12 +57,12 @@ def test_sparse_equals_dense_and_oracle(engine, N, Dj, T, K):
     assert len(paths[2]) == 0
 
 
-@pytest.mark.parametrize('waves', [1, 4])
-def test_chunked_lower_bound_recursion_and_both_exact_recursions(engine, waves):
+@pytest.mark.parametrize('waves,K', [(1, 40), (4, 40), (1, 120)])
+def test_chunked_lower_bound_recursion_and_both_exact_recursions(engine, waves, K):
     """Pass 2 in chunks side by side (viterbi_lb_chunk / viterbi_lb_warm: chunk lengths around the shift period of 64,
     chunks of one step, a warm-up of one step, a warm-up longer than the utterance) and pass 4 on one or on four compute
     wavefronts: path and cost equal the oracle's bit for bit; only the number of refined cells may move."""
-    N, Dj, K = 20000, 151, 40
+    N, Dj = 20000, 151                                     # K = 40 and 120: the <= 64 and the <= 128 column instances of pass 2
     F_unw, JC_unw, wt, wj = _db(N, 61, Dj, seed=211)
     engine.upload_db(F_unw, JC_unw)
     engine.set_weights(wt, wj)
