@@ -616,8 +616,9 @@ def main():
             out['prefilter_tripwire'] = {
                 'gpu_matches_f32_prefilter': bool(all(np.array_equal(a, b) for a, b in zip(p0, paths)) and np.array_equal(c0, costs)),
                 'prefilter_margin_rows': margin_rows, 'prefilter_min_margin': min_margin,
-                'note': 'margin = (filter threshold - exact K-th key) / assumed key error, over every row of the timed steps; '
-                        'rows below 2 would have lost a neighbour had the bf16 accumulation assumption been off by 2x'}
+                'note': 'margin = (filter threshold - exact K-th key) / assumed key error eps, over every row of the timed steps: '
+                        'the factor by which the true key errors could exceed eps before a row could lose a neighbour; '
+                        'prefilter_margin_rows counts the rows under 2 (include/snk.h, DESIGN.md 4.1a)'}
         if with_upload is not None:
             out['with_upload'] = with_upload
         out['config']['inputs'] = 'resident in HBM' if resident else 'uploaded from the host every step'

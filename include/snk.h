@@ -321,8 +321,9 @@ int snk_concat_fragments(snk_handle h, const int64_t *first_row, const int64_t *
  * Tripwire of the K-NN prefilter's key bound (snk_reset_timers clears it): prefilter_margin_rows = rows of prefilter K-NN
  * calls whose exact K-th key came within 2 eps of the filter threshold (eps: the largest error the approximate keys are
  * ASSUMED to have -- for the bf16-split operands that rests on the probed accumulation property below);
- * prefilter_min_margin = the smallest (threshold - exact K-th key) / eps seen.  Rows at 2 or more would have kept every
- * true neighbour even if the assumption had been off by a factor of two. */
+ * prefilter_min_margin = the smallest (threshold - exact K-th key) / eps seen: the factor by which the true key errors could
+ * exceed eps before a row could lose a neighbour (the threshold is a sampled approximate key + 2 eps, so a row whose
+ * threshold came from its K-th neighbour itself sits between 1 and 3; rows bounded by the sample sit far above). */
 int snk_set_option(snk_handle h, const char *name, double value);
 int snk_get_info(snk_handle h, const char *name, double *value_out);
 /* One v_mfma_f32_32x32x16_bf16 on caller-chosen bit patterns: D = A B + C with A (32, 16) and B (16, 32) bf16 bit
