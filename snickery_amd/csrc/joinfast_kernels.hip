@@ -897,36 +897,6 @@ __device__ __forceinline__ unsigned int jf_wave_min_u32(unsigned int v)
     return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// canonical float64 join cost of (a, b) by the whole wavefront: the same separately rounded operations in the same
-// order as jf_exact_cost (the squares are independent; only their sum is ordered).  sq: LDS, Dj + 1 doubles.
-__device__ __forceinline__ double jf_exact_cost_wave(const float *__restrict__ JC_unw, int Jp, int Dj,
-                                                     const double *__restrict__ wj, int64_t a, int64_t b,
-                                                     double *sq, int lane)
-{
-    const float *__restrict__ re = JC_unw + (a + 1) * (int64_t)Jp;
-    const float *__restrict__ rs = JC_unw + b * (int64_t)Jp;
-    __builtin_amdgcn_wave_barrier();
-    for (int c = lane; c < Dj; c += 64) {
-        const double w = wj[c];
-        const double d = __dsub_rn(__dmul_rn((double)re[c], w), __dmul_rn((double)rs[c], w));
-        sq[c] = __dmul_rn(d, d);
-    }
-    if (lane == 0) sq[Dj] = 0.0;                       // the sum runs in pairs: acc + 0.0 == acc (acc >= +0)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    typedef double f64x2 __attribute__((ext_vector_type(2)));
-    const f64x2 *sp = reinterpret_cast<const f64x2 *>(sq);
-    double acc = 0.0;
-    for (int c = 0; c < Dj; c += 2) {
-        const f64x2 v = sp[c >> 1];
-        acc = __dadd_rn(acc, v[0]);
-        acc = __dadd_rn(acc, v[1]);
-    }
-    __builtin_amdgcn_wave_barrier();
-    return __dsqrt_rn(acc);
-}
-
 template <int NC, bool BPL>
 __global__ void __launch_bounds__(128)
 viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__restrict__ rec_all,
