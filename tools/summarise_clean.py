@@ -20,7 +20,7 @@ for f in sorted(glob.glob(os.path.join(src, 'run_*.log'))):
     shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 head = subprocess.run(['git', 'log', '-1', '--format=%h %s', '--', 'snickery_amd/csrc', 'snickery_amd/engine.py', 'tests'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 lines = ['# Round 3: consecutive full runs of `python -m pytest tests/ -q -m gpu` on MI355X boxes', '',
-         'Library and tests as of commit `%s`.  `tools/clean_loop.sh` runs the whole GPU suite again and again in fresh Python' % head,
+         'Last commit touching library or tests: `%s` (see the text below for which runs used which).  `tools/clean_loop.sh` runs the whole GPU suite again and again in fresh Python' % head,
          'processes (ten runs per box, a fresh box per ten); every log names each test on stderr before it starts (`[snk-test] <nodeid>`),',
          'so a process abort would read as the last test named + the runtime\'s message.  **%d of %d runs clean.**' % (clean, len(rows)),
          'Run 01 (the first run on its box) failed ONE test: `test_bench_multi_rank_one_gpu[2-0-...]` starts bench.py under',
