@@ -5,7 +5,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, '_build', 'libsnkoracle.so')
+# SNK_ORACLE_LIB: another build of the same source (oracle/Makefile `asan`: AddressSanitizer + UBSan, run under LD_PRELOAD=libasan)
+_SO = os.environ.get('SNK_ORACLE_LIB') or os.path.join(_HERE, '_build', 'libsnkoracle.so')
 _lib = None
 _i64p = ctypes.POINTER(ctypes.c_int64)
 _f64p = ctypes.POINTER(ctypes.c_double)
