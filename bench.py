@@ -282,7 +282,8 @@ def main():
     utts = [synthetic_targets(F_unw, T, seed=1 + u) * wt for u in range(U)]
     frames_per_step = sum(u.shape[0] for u in utts)
     # the batch as the C ABI takes it (one contiguous matrix + row offsets), built once: a tuning loop
-    # searches the same tune set every iteration.  Every step still uploads it to the device.
+    # searches the same tune set every iteration.  On one GPU the timed steps search the rows where the two priming
+    # submits left them, in HBM (--upload-every-step: uploaded in every step, the `with_upload` figure).
     batch = snickery_amd.QueryBatch(utts)
 
     cpu_ref = None
