@@ -140,7 +140,8 @@ def get_selection_vector(stream_list, stream_dims, truncation_values):
 
 DATABASE_DATASETS = ['train_unit_features', 'train_unit_names', 'filenames', 'mean_target', 'std_target',
                      'mean_join', 'std_join', 'join_contexts', 'unit_index_within_sentence_dset', 'cutpoints',
-                     'duration_monophones', 'duration_stats']
+                     'duration_monophones', 'duration_stats',
+                     'start_join_feats', 'end_join_feats']       # the .joindata.hdf5 file of dump_join_data (train_halfphone.py:277-282)
 
 
 def load_database(datafile):

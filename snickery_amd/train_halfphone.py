@@ -12,8 +12,12 @@ selection, statistics, arrays, names, dtypes and shapes as the reference, includ
   row ``m`` (the unit count of the LAST utterance, :552) and the last row of ``join_contexts`` stays
   zero.  Readers depend on the file, so the file is reproduced as it is.
 
-Not covered: ``target_representation = 'sample'`` (waveform-sample voices), ``dump_join_data`` and
-``store_full_magphase``.
+``dump_join_data`` (halfphone voices; :277-282, :484, :529-531, :620-627, ``get_join_data_AL`` :1207-1242) writes the
+second file ``<condition>.joindata.hdf5`` with ``start_join_feats`` / ``end_join_feats``: ``join_cost_halfwidth``
+pitch-synchronous join frames after each unit's first and before each unit's last cut point -- the data
+``active_learning_join.py`` trains a join cost on -- including the reference's index arithmetic at the utterance edges.
+
+Not covered: ``target_representation = 'sample'`` (waveform-sample voices) and ``store_full_magphase``.
 
     python -m snickery_amd.train_halfphone -c voice.cfg [-X]
 """
@@ -27,12 +31,12 @@ from . import hostprep as hp
 from .train_simple import select_utterances
 
 
-def get_data_dump_name(config):
+def get_data_dump_name(config, joindata=False):
     """train_halfphone.py:878-904 (the default of target_representation differs from file_naming.py)."""
     name = '%s_utts_jstreams-%s_tstreams-%s_rep-%s' % (
         config['n_train_utts'], '-'.join(config['stream_list_join']), '-'.join(config['stream_list_target']),
         config.get('target_representation', 'twopoint'))
-    return os.path.join(config['workdir'], 'data_dumps', name + '.hdf5')
+    return os.path.join(config['workdir'], 'data_dumps', name + ('.joindata.hdf5' if joindata else '.hdf5'))
 
 
 def segment_rows(a, length):
@@ -42,11 +46,37 @@ def segment_rows(a, length):
     return np.stack([a[i:i + n] for i in range(length)], axis=1)
 
 
-def build_database(config, report=print):
-    """The arrays of the database as a dict (train_halfphone.py:63-600)."""
+def get_join_data_AL(speech, pm_indices, halfwidth):
+    """train_halfphone.py:1207-1242: per unit the `halfwidth` join frames from its first cut point on and the
+    `halfwidth` frames ending halfwidth + 1 ... 2 rows before its last one, flattened.  The reference pads the
+    utterance by repeating its last (first) row when the last unit's window (the first unit's) would leave it and
+    then indexes with the shifted cut points as they are -- a negative index wraps around, as numpy does; kept."""
+    starts = pm_indices[:, 0]
+    ends = pm_indices[:, 1].copy()
+    start_speech = speech
+    if starts[-1] + halfwidth > ends[-1]:
+        difference = int(starts[-1] + halfwidth - ends[-1])
+        start_speech = np.vstack([speech] + difference * [speech[-1, :].reshape((1, -1))])
+    start_contexts = segment_rows(start_speech, halfwidth)[starts, :, :].reshape((len(starts), -1))
+    end_speech = speech
+    if ends[0] - (halfwidth + 1) < 0:
+        difference = int((ends[0] - (halfwidth + 1)) * -1)
+        end_speech = np.vstack(difference * [speech[0, :].reshape((1, -1))] + [speech])
+    ends = ends - (halfwidth + 1)
+    end_contexts = segment_rows(end_speech, halfwidth)[ends, :, :].reshape((len(ends), -1))
+    return start_contexts, end_contexts
+
+
+def build_database(config, report=print, joindata=None):
+    """The arrays of the database as a dict (train_halfphone.py:63-600).  joindata: a dict that receives
+    start_join_feats / end_join_feats when the config asks for dump_join_data."""
     rep = config['target_representation']
-    if rep == 'sample' or config.get('dump_join_data', False) or config.get('store_full_magphase', False):
-        raise NotImplementedError('sample voices, dump_join_data and store_full_magphase are not covered')
+    if rep == 'sample' or config.get('store_full_magphase', False):
+        raise NotImplementedError('sample voices and store_full_magphase are not covered')
+    dump_join = bool(config.get('dump_join_data', False))
+    if dump_join and rep == 'epoch':
+        raise NotImplementedError('dump_join_data needs unit cut points: halfphone voices only '
+                                  '(the reference reads an undefined name here for epoch voices, train_halfphone.py:485)')
     epoch = rep == 'epoch'
     stream_list_target, datadims_target = config['stream_list_target'], config['datadims_target']
     stream_list_join, datadims_join = config['stream_list_join'], config['datadims_join']
@@ -80,6 +110,7 @@ def build_database(config, report=print):
             duration_stats[name] = (vals.mean(), max(vals.std(), 0.001))        # variance floor
 
     features, contexts, names, filenames, indices, cuts = [], [], [], [], [], []
+    start_feats, end_feats = [], []
     last_context, last_m = None, 0
     for base in flist:
         pm_file = os.path.join(config['pm_datadir'], base + '.pm')
@@ -124,6 +155,10 @@ def build_database(config, report=print):
                 unit_features = np.hstack([unit_features, hp.get_norm_durations(unit_names, timings, duration_stats)])
             cutpoints, cutpoint_indices = hp.get_cutpoints(timings, pms_seconds, sample_rate)
             context_data = hp.get_contexts_for_pitch_synchronous_joincost(j_speech, cutpoint_indices)
+            if dump_join:
+                sj, ej = get_join_data_AL(j_speech, cutpoint_indices, config['join_cost_halfwidth'])
+                start_feats.append(sj)
+                end_feats.append(ej)
         m = unit_features.shape[0]
         assert context_data.shape[0] == m + 1, (context_data.shape[0], m)
         features.append(unit_features)
@@ -153,6 +188,9 @@ def build_database(config, report=print):
         'mean_join': np.asarray(mean_vec_join, dtype=np.float32),
         'std_join': np.asarray(std_vec_join, dtype=np.float32),
     }
+    if dump_join and joindata is not None:
+        joindata['start_join_feats'] = np.vstack(start_feats).astype(np.float32)
+        joindata['end_join_feats'] = np.vstack(end_feats).astype(np.float32)
     if add_duration:
         keys = sorted(duration_stats)
         db['duration_monophones'] = np.array(keys).astype('S50')
@@ -170,9 +208,16 @@ def main_work(config, overwrite_existing_data=False, report=print):
         for p in present:
             os.remove(p)
     os.makedirs(os.path.dirname(database_fname), exist_ok=True)
-    db = build_database(config, report=report)
+    joindata = {}
+    db = build_database(config, report=report, joindata=joindata)
     written = hp.store_database(database_fname, db)
     report('Stored training data for %s units to %s' % (db['train_unit_features'].shape[0], written))
+    if joindata:                                              # train_halfphone.py:277-282, :620-627
+        join_fname = get_data_dump_name(config, joindata=True)
+        for p in (join_fname, join_fname + '.npz'):
+            if os.path.isfile(p):
+                os.remove(p)
+        report('Storing data for learning join cost: %s' % hp.store_database(join_fname, joindata))
     return database_fname
 
 

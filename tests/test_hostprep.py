@@ -200,6 +200,41 @@ def test_halfphone_database_writer_reproduces_reference_database(tmp_path, tag, 
         train_halfphone.main_work(config, report=lambda *_: None)
 
 
+@pytest.mark.parametrize('tag,rep,duration', [('twopoint', 'twopoint', True), ('threepoint', 'threepoint', False)])
+def test_halfphone_writer_dump_join_data_reproduces_reference_files(tmp_path, tag, rep, duration):
+    """dump_join_data (train_halfphone.py:277-282, get_join_data_AL :1207-1242): the second file the reference writes for
+    active_learning_join.py -- name, datasets, shapes, dtypes and bytes (sha256) equal to what the reference itself wrote
+    on the same corpus (tools/make_golden_joindata.py), and the voice file beside it unchanged by the option."""
+    import hashlib
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import voice_fixture
+    from snickery_amd import hostprep as hp, train_halfphone
+    ref = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_joindata.npz'), allow_pickle=True)
+    data = os.path.join(str(tmp_path), 'corpus')
+    voice_fixture.write_halfphone_corpus(data)
+    cfgfile = voice_fixture.halfphone_corpus_config(os.path.join(str(tmp_path), 'hp.cfg'), os.path.join(str(tmp_path), 'work'),
+                                                    data, rep, duration)
+    config = hp.load_config(cfgfile)
+    config['dump_join_data'] = True
+    config['join_cost_halfwidth'] = int(ref[tag + '_halfwidth'])
+    dbfile = train_halfphone.main_work(config, report=lambda *_: None)
+    for kind, fname in (('join', train_halfphone.get_data_dump_name(config, joindata=True)), ('voice', dbfile)):
+        assert os.path.basename(fname) == str(ref['%s_%s_basename' % (tag, kind)])
+        db = hp.load_database(fname)
+        assert sorted(db.keys()) == sorted(k.decode() for k in ref['%s_%s_keys' % (tag, kind)])
+        for key, arr in db.items():
+            arr = np.asarray(arr)
+            assert list(arr.shape) == list(ref['%s_%s_%s_shape' % (tag, kind, key)]), key
+            assert arr.dtype.str == str(ref['%s_%s_%s_dtype' % (tag, kind, key)]), key
+            if kind == 'join':
+                assert np.array_equal(arr[[0, arr.shape[0] // 2, -1], :8], ref['%s_%s_%s_rows' % (tag, kind, key)]), key
+            assert hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest() == str(ref['%s_%s_%s_sha256' % (tag, kind, key)]), (kind, key)
+    config['target_representation'] = 'epoch'
+    with pytest.raises(NotImplementedError):
+        train_halfphone.build_database(config, report=lambda *_: None)
+
+
 def test_hdf5_voice_without_h5py(tmp_path):
     """The reference keeps its voice in HDF5 (train_simple.py:95-149, read back at synth_simple.py:72-106).
     This interpreter has no h5py: the file is read and written through libhdf5's C API
