@@ -141,7 +141,22 @@ def get_selection_vector(stream_list, stream_dims, truncation_values):
 DATABASE_DATASETS = ['train_unit_features', 'train_unit_names', 'filenames', 'mean_target', 'std_target',
                      'mean_join', 'std_join', 'join_contexts', 'unit_index_within_sentence_dset', 'cutpoints',
                      'duration_monophones', 'duration_stats',
-                     'start_join_feats', 'end_join_feats']       # the .joindata.hdf5 file of dump_join_data (train_halfphone.py:277-282)
+                     'start_join_feats', 'end_join_feats',       # the .joindata.hdf5 file of dump_join_data (train_halfphone.py:277-282)
+                     'mp_mag', 'mp_imag', 'mp_real', 'mp_fz']    # store_full_magphase (train_simple.py:145-149, synth_simple.py:100-104)
+
+
+def full_magphase_rows(config, base, m):
+    """store_full_magphase (train_simple.py:260-275 = train_halfphone.py:504-517): the utterance's full-resolution analysis
+    frames `<full_magphase_dir>/<stream>_full/<base>.<stream>` (mag / imag / real 513 wide, f0 1 wide) without their first
+    and last row, in the order (mag, imag, real, f0).  One row per unit is what the reference's HDF5 assignment needs."""
+    parts = []
+    for extn in ('mag', 'imag', 'real', 'f0'):
+        full = get_speech(os.path.join(config['full_magphase_dir'], extn + '_full', base + '.' + extn), 1 if extn == 'f0' else 513)[1:-1, :]
+        if full.shape[0] != m:
+            raise ValueError('store_full_magphase: %s_full/%s has %d rows without its first and last one, the utterance has %d units'
+                             % (extn, base, full.shape[0], m))
+        parts.append(full)
+    return parts
 
 
 def load_database(datafile):
@@ -172,6 +187,17 @@ def load_database(datafile):
         raise RuntimeError('%s exists but this interpreter has neither h5py nor a loadable libhdf5 (set SNK_LIBHDF5); '
                            'convert it once with\n  /opt/conda/bin/python3.9 tools/hdf5_to_npz.py %s' % (datafile, datafile))
     raise RuntimeError('data: \n   %s   \ndoes not exist -- try other?' % (datafile))
+
+
+def gather_stored_magphase(mp_mag, mp_imag, mp_real, mp_fz, path, fzero=None):
+    """concatenateMagPhaseEpoch (synth_simple.py:655-674) up to the vocoder call: the analysis frames stored with the
+    voice (store_full_magphase), one per selected unit -- (mag, real, imag, fz), what the reference hands to
+    magphase.synthesis_from_lossless; a non-empty fzero replaces the stored f0 track."""
+    path = np.asarray(path, dtype=np.int64)
+    fz = np.asarray(mp_fz)[path, :].reshape((-1, 1))
+    if fzero is not None and np.size(fzero) > 0:
+        fz = fzero
+    return np.asarray(mp_mag)[path, :], np.asarray(mp_real)[path, :], np.asarray(mp_imag)[path, :], fz
 
 
 def store_database(datafile, db):

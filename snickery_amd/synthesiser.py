@@ -56,6 +56,8 @@ class Synthesiser(object):
         self.join_contexts_unweighted = np.asarray(db['join_contexts'])
         self.unit_index_within_sentence = db.get('unit_index_within_sentence_dset')
         self.train_cutpoints = db.get('cutpoints')      # absent from train_simple DBs
+        if self.config.get('store_full_magphase', False):  # synth_simple.py:100-104 = synth_halfphone.py:215-219
+            self.mp_mag, self.mp_imag, self.mp_real, self.mp_fz = db['mp_mag'], db['mp_imag'], db['mp_real'], db['mp_fz']
         self.number_of_units = self.train_unit_features_unweighted.shape[0]
         if self.config.get('add_duration_as_target', False):
             # synth_halfphone.py:206-211
@@ -302,6 +304,11 @@ class Synthesiser(object):
                 names.append(fn)
         spec, fzv, self._frame_spans = hp.load_full_spectra(self.config['full_magphase_dir'], names, fft_half_len)
         self.engine.upload_frames(spec, fzv)
+
+    def concatenate_magphase_stored(self, path, fzero=None):
+        """concatenateMagPhaseEpoch (synth_simple.py:655-674; the `store_full_magphase` branch of synth_utt, :439-441):
+        (mag, real, imag, fz) of the selected units from the frames stored with the voice."""
+        return hp.gather_stored_magphase(self.mp_mag, self.mp_imag, self.mp_real, self.mp_fz, path, fzero)
 
     def concatenate_magphase(self, path, overlap=None, fzero=None):
         """retrieve_magphase_frag + the overlap-add of concatenateMagPhaseEpoch_sep_files

@@ -17,7 +17,10 @@ second file ``<condition>.joindata.hdf5`` with ``start_join_feats`` / ``end_join
 pitch-synchronous join frames after each unit's first and before each unit's last cut point -- the data
 ``active_learning_join.py`` trains a join cost on -- including the reference's index arithmetic at the utterance edges.
 
-Not covered: ``target_representation = 'sample'`` (waveform-sample voices) and ``store_full_magphase``.
+``store_full_magphase`` (:269-273, :504-543) adds ``mp_mag`` / ``mp_imag`` / ``mp_real`` / ``mp_fz``, one full-resolution
+analysis frame per unit (epoch voices: the files must hold one row per pitch mark).
+
+Not covered: ``target_representation = 'sample'`` (waveform-sample voices).
 
     python -m snickery_amd.train_halfphone -c voice.cfg [-X]
 """
@@ -71,8 +74,10 @@ def build_database(config, report=print, joindata=None):
     """The arrays of the database as a dict (train_halfphone.py:63-600).  joindata: a dict that receives
     start_join_feats / end_join_feats when the config asks for dump_join_data."""
     rep = config['target_representation']
-    if rep == 'sample' or config.get('store_full_magphase', False):
-        raise NotImplementedError('sample voices and store_full_magphase are not covered')
+    if rep == 'sample':
+        raise NotImplementedError('sample voices are not covered')
+    store_mp = bool(config.get('store_full_magphase', False))
+    mp = ([], [], [], [])
     dump_join = bool(config.get('dump_join_data', False))
     if dump_join and rep == 'epoch':
         raise NotImplementedError('dump_join_data needs unit cut points: halfphone voices only '
@@ -161,6 +166,9 @@ def build_database(config, report=print, joindata=None):
                 end_feats.append(ej)
         m = unit_features.shape[0]
         assert context_data.shape[0] == m + 1, (context_data.shape[0], m)
+        if store_mp:                                        # :504-517, :537-543 (one analysis frame per unit: epoch voices)
+            for acc, part in zip(mp, hp.full_magphase_rows(config, base, m)):
+                acc.append(part)
         features.append(unit_features)
         contexts.append(context_data[:-1, :])
         names.extend(list(unit_names))
@@ -188,6 +196,9 @@ def build_database(config, report=print, joindata=None):
         'mean_join': np.asarray(mean_vec_join, dtype=np.float32),
         'std_join': np.asarray(std_vec_join, dtype=np.float32),
     }
+    if store_mp:
+        for key, acc in zip(('mp_mag', 'mp_imag', 'mp_real', 'mp_fz'), mp):
+            db[key] = np.vstack(acc).astype(np.float32)
     if dump_join and joindata is not None:
         joindata['start_join_feats'] = np.vstack(start_feats).astype(np.float32)
         joindata['end_join_feats'] = np.vstack(end_feats).astype(np.float32)

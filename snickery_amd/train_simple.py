@@ -5,6 +5,9 @@
 including the (1, D) shape of the std vectors and the extra first row of ``join_contexts`` (the first
 utterance's first frame doubles as initial history, :215-217).
 
+``store_full_magphase`` adds ``mp_mag`` / ``mp_imag`` / ``mp_real`` / ``mp_fz``: one full-resolution analysis frame per unit
+(:145-149, :260-299), the arrays ``synth_simple.py:100-104`` reads back.
+
 The arrays are written to the HDF5 file itself, as the reference does (h5py where installed, else
 libhdf5 through ctypes: ``snickery_amd.hdf5_io``); only an image with neither gets the ``.npz`` sidecar.
 
@@ -62,6 +65,8 @@ def build_database(config, report=print):
 
     replicate = config.get('REPLICATE_IS2018_EXP', False)
     features, contexts, names, filenames, indices = [], [], [], [], []
+    store_mp = bool(config.get('store_full_magphase', False))
+    mp = ([], [], [], [])
     first_base = flist[0] if flist else None
     for base in flist:
         t_speech = hp.compose_speech(target_stream_dirs, base, stream_list_target, datadims_target)
@@ -85,6 +90,9 @@ def build_database(config, report=print):
             # join_contexts carries one extra leading row of history: the first frame, assumed silent
             context_data = np.vstack([j_speech[0, :].reshape((1, -1)), j_speech]) if first_sentence_in_corpus else j_speech
         m = unit_features.shape[0]
+        if store_mp:                                        # :260-275, :292-299
+            for acc, part in zip(mp, hp.full_magphase_rows(config, base, m)):
+                acc.append(part)
         features.append(unit_features)
         contexts.append(context_data)
         names.extend(['_'] * m)
@@ -96,7 +104,7 @@ def build_database(config, report=print):
         # the reference writes rows start+1.. for every utterance but the first of the LIST: with the
         # first utterance skipped, row 0 of join_contexts would stay unset there; refuse rather than guess
         raise RuntimeError('the first training utterance (%s) could not be used' % first_base)
-    return {
+    db = {
         'train_unit_features': np.vstack(features).astype(np.float32),
         'train_unit_names': np.array(names).astype('S50'),
         'filenames': np.array(filenames).astype('S50'),
@@ -107,6 +115,10 @@ def build_database(config, report=print):
         'mean_join': np.asarray(mean_vec_join, dtype=np.float32),
         'std_join': np.asarray(std_vec_join, dtype=np.float32),
     }
+    if store_mp:
+        for key, acc in zip(('mp_mag', 'mp_imag', 'mp_real', 'mp_fz'), mp):
+            db[key] = np.vstack(acc).astype(np.float32)
+    return db
 
 
 def main_work(config, overwrite_existing_data=False, report=print):

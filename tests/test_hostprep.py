@@ -235,6 +235,67 @@ def test_halfphone_writer_dump_join_data_reproduces_reference_files(tmp_path, ta
         train_halfphone.build_database(config, report=lambda *_: None)
 
 
+def test_writers_store_full_magphase_reproduces_reference_voices(tmp_path):
+    """store_full_magphase (train_simple.py:145-149,260-299; train_halfphone.py:269-273,504-543): both writers on corpora
+    with `<stream>_full` analysis files -- every dataset of the voice, the four mp_* arrays included, has the name, shape,
+    dtype and bytes (sha256) of what the reference itself wrote (tools/make_golden_fullmag.py); files that do not hold
+    one row per unit are refused."""
+    import hashlib
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import voice_fixture
+    from make_golden import write_voice
+    from snickery_amd import hostprep as hp, train_halfphone, train_simple
+    ref = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_fullmag.npz'), allow_pickle=True)
+
+    def check(tag, dbfile):
+        assert os.path.basename(dbfile) == str(ref[tag + '_basename'])
+        db = hp.load_database(dbfile)
+        assert sorted(db.keys()) == sorted(k.decode() for k in ref[tag + '_keys'])
+        assert {'mp_mag', 'mp_imag', 'mp_real', 'mp_fz'} <= set(db.keys())
+        for key, arr in db.items():
+            arr = np.asarray(arr)
+            assert list(arr.shape) == list(ref['%s_%s_shape' % (tag, key)]), key
+            assert arr.dtype.str == str(ref['%s_%s_dtype' % (tag, key)]), key
+            assert hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest() == str(ref['%s_%s_sha256' % (tag, key)]), key
+
+    data = os.path.join(str(tmp_path), 'voice')
+    write_voice(data, np.random.RandomState(20240))
+    names = sorted(f[:-4] for f in os.listdir(os.path.join(data, 'low', 'mag')))
+    voice_fixture.write_full_magphase_for_writers(os.path.join(data, 'high'), os.path.join(data, 'low'), names, 2)
+    cfgfile = os.path.join(str(tmp_path), 'voice.cfg')
+    with open(cfgfile, 'w') as f:
+        f.write(voice_fixture.CFG % dict(workdir=os.path.join(str(tmp_path), 'work_simple'), data=data, greedy='True', multiepoch=6,
+                                         n_candidates=12))
+        f.write("store_full_magphase = True\nfull_magphase_dir = data + '/high/'\n")
+    config = hp.load_config(cfgfile)
+    dbfile = train_simple.main_work(config, report=lambda *_: None)
+    check('simple', dbfile)
+    # the reader's side (synth_simple.py:100-104, concatenateMagPhaseEpoch :655-674): frames of the selected units
+    db = hp.load_database(dbfile)
+    first = names[0]
+    full = dict((e, hp.get_speech(os.path.join(data, 'high', e + '_full', first + '.' + e), 1 if e == 'f0' else 513)) for e in ('mag', 'imag', 'real', 'f0'))
+    path = [5, 0, 17, 5]                                     # units of the first utterance: unit k <-> row k + 1 of its files
+    mag, real, imag, fz = hp.gather_stored_magphase(db['mp_mag'], db['mp_imag'], db['mp_real'], db['mp_fz'], path)
+    for got, e in ((mag, 'mag'), (real, 'real'), (imag, 'imag'), (fz, 'f0')):
+        assert np.array_equal(got, full[e][[k + 1 for k in path], :]), e
+    assert hp.gather_stored_magphase(db['mp_mag'], db['mp_imag'], db['mp_real'], db['mp_fz'], path, fzero=np.ones((4, 1)))[3].sum() == 4.0
+
+    data = os.path.join(str(tmp_path), 'corpus')
+    names = voice_fixture.write_halfphone_corpus(data)
+    voice_fixture.write_full_magphase_for_writers(os.path.join(data, 'high'), os.path.join(data, 'low'), names, 0)
+    cfgfile = voice_fixture.halfphone_corpus_config(os.path.join(str(tmp_path), 'hp.cfg'), os.path.join(str(tmp_path), 'work_hp'),
+                                                    data, 'epoch', False)
+    config = hp.load_config(cfgfile)
+    config['store_full_magphase'] = True
+    config['full_magphase_dir'] = data + '/high/'
+    check('hpepoch', train_halfphone.main_work(config, report=lambda *_: None))
+    config['target_representation'] = 'twopoint'           # a halfphone voice has fewer units than analysis frames
+    with pytest.raises(ValueError):
+        train_halfphone.build_database(config, report=lambda *_: None)
+
+
 def test_hdf5_voice_without_h5py(tmp_path):
     """The reference keeps its voice in HDF5 (train_simple.py:95-149, read back at synth_simple.py:72-106).
     This interpreter has no h5py: the file is read and written through libhdf5's C API

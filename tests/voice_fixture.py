@@ -144,6 +144,21 @@ def write_full_spectra(root, frames_per_utt, H, seed=77):
         f0.astype(np.float32).reshape(-1, 1).tofile(os.path.join(root, 'f0', name + '.f0'))
 
 
+def write_full_magphase_for_writers(root, low_dir, names, extra_rows, seed=909):
+    """The `<stream>_full` directories the database writers read with store_full_magphase (train_simple.py:260-275,
+    train_halfphone.py:504-517): per utterance mag / imag / real (rows, 513) and f0 (rows, 1), rows = the utterance's
+    frame count (taken from its `mag` stream file under low_dir) + extra_rows -- the writers drop the first and the
+    last row and need one row per unit.  Shared by tools/make_golden_fullmag.py and tests/test_hostprep.py."""
+    rng = np.random.RandomState(seed)
+    for extn in ('mag', 'imag', 'real', 'f0'):
+        os.makedirs(os.path.join(root, extn + '_full'), exist_ok=True)
+    for name in names:
+        n = np.fromfile(os.path.join(low_dir, 'mag', name + '.mag'), dtype=np.float32).size // 60 + extra_rows
+        for extn in ('mag', 'imag', 'real'):
+            (rng.randn(n, 513) * 0.5).astype(np.float32).tofile(os.path.join(root, extn + '_full', name + '.' + extn))
+        (100.0 + 20.0 * rng.rand(n, 1)).astype(np.float32).tofile(os.path.join(root, 'f0_full', name + '.f0'))
+
+
 # --------------------------------------------------------------------------------------------------
 # A small pitch-synchronous corpus for the database writers of train_halfphone.py: stream files,
 # pitch marks (.pm, EST track text) and state-aligned labels.  Shared by tools/make_golden.py (input
