@@ -865,7 +865,9 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
 //     loads return in order),
 //   * a failing cell's candidates get their exact cost from the whole wavefront: squares in parallel (one column of
 //     the join vectors per lane), the canonical ordered sum read back from LDS by every lane.
-// Same arithmetic, same decisions, same statistics as the kernel above.
+// Same arithmetic and the same decisions as the kernel above (path, cost and back-pointers bit for bit); the counters may
+// differ by a few exact costs (a column's later candidates are tested against its best total SO FAR, and the bound
+// `off` is a hair lower).
 // ---------------------------------------------------------------------------------------------
 #define JF1_NL 16              // 1-KB LDS-DMA loads per batch (a ring slot is JF1_NL KB)
 #define JF1_SQ 4096            // doubles: the squares of JF1_SQ / (Dj + 2) exact costs at a time (>= JF_MAXD + 3: one at least)
