@@ -100,6 +100,14 @@ int snk_candidate_distances(snk_handle h, const double *Q, int64_t T, int D, con
  *   +inf where either unit is unusable (id == -1, id < 1 or id >= N-1, :3238-3268). */
 int snk_join_costs(snk_handle h, const int64_t *cand, int64_t T, int K, double *J_out);
 
+/* Diagnostic of the sparse Viterbi path (no reference counterpart: the reference computes every join cost exactly,
+ * synth_halfphone.py:2942-2951): the float32 LOWER BOUNDS of the join costs that pass 1 computes on the matrix pipe
+ * (option join_lb_variant: 1 = bf16 pieces of a weighted float32 copy, 0 = float32 operands weighted per gather), so a
+ * test can hold lo[t,a,b] <= J[t,a,b] of snk_join_costs for every cell and measure how tight they are.
+ *   lo_out (T-1, K, K) float32 (+inf where either unit is unusable), scale_out (T-1) float32: the step's largest
+ *   centred norm (the unit of the pass-2 margin join_beta). */
+int snk_join_bounds(snk_handle h, const int64_t *cand, int64_t T, int K, float *lo_out, float *scale_out);
+
 /* Replaces viterbi_search (synth_halfphone.py:1399-1436): target sausage lattice
  * (fst_functions_wrapped.py:28-58) o join lattice (:172-217), openfst.compose (:368)
  * and openfst.shortestpath (:389), as one dynamic programme over the T x K trellis.
@@ -314,8 +322,17 @@ int snk_concat_fragments(snk_handle h, const int64_t *first_row, const int64_t *
  *                              chain per utterance), each started viterbi_lb_warm steps early (default 16), for launches of up to
  *                              that many utterances (default 24 = all)
  *   viterbi_sparse_waves 1 / 4 which form of the exact sparse recursion runs (process-wide; default 1)
+ *   join_lb_variant 0 / 1      pass 1 of the sparse path: float32 matrix pipe, weights applied per gathered row / bf16 matrix pipe
+ *                              over a float32 copy of the weighted join rows built once per snk_set_weights (default 1)
+ *   viterbi_weights 0 / 1      0 (default): float64 recursion, the restatement every bit-exact test refers to.  1: the
+ *                              reference's own arithmetic -- OpenFST's float32 tropical weights (fst_functions_wrapped.py:47,201:
+ *                              every lattice weight is parsed into float32; :368 compose adds the two arc weights, :389
+ *                              shortestpath accumulates them from the start state, all in float32): arc weight
+ *                              fl32(fl32(tdist[t-1,k']) + fl32(c(k',k))), totals accumulated in float32, the last row's target
+ *                              cost on the exit arc; ties as before.  This IS a different result on near ties (the cost returned
+ *                              is the float32 total); it runs on the dense kernels.
  * Options of the K-NN filter: prefilter 0 / 1 / 2, prefilter_two_pass 0 / 1, prefilter_balls 0 / 1, coarse_gate_fraction
- * (INTEGRATION.md).  None of these changes a result.
+ * (INTEGRATION.md).  None of these changes a result (viterbi_weights excepted, which selects the arithmetic).
  * infos: greedy_fallbacks, greedy_stalls, greedy_exact_windows, greedy_second_rounds, greedy_hoist_launches,
  * greedy_f16_launches, greedy_f16_delta, greedy_resident_launches.  The other names are listed in INTEGRATION.md.
  * Tripwire of the K-NN prefilter's key bound (snk_reset_timers clears it): prefilter_margin_rows = rows of prefilter K-NN

@@ -345,8 +345,11 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                 }
                 const unsigned long long gb = (unsigned long long)v2 | ((unsigned long long)d3 << 32) | ((unsigned long long)tag << 48);
                 if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                __hip_atomic_store(&rec[blockIdx.x].a, ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&rec[blockIdx.x].b, gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // records are double-buffered by step parity: a workgroup that has gathered step s publishes step s + 1 at
+                // once, while a slower one may still be polling the records of step s -- nobody can be two steps ahead (step
+                // s + 2 is published only after every record of step s + 1, hence every gather of step s, is done)
+                __hip_atomic_store(&rec[(size_t)(step & 1) * nb + blockIdx.x].a, ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&rec[(size_t)(step & 1) * nb + blockIdx.x].b, gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             stamp(step, 4);                                  // record published
             // constants of the bound, while the records travel: E(d) = c1 sqrt(d) + c2 d
@@ -366,8 +369,8 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                         const unsigned int b = (unsigned int)lane + 64u * q;
                         ra[q] = 0ull; rb[q] = 0ull;
                         if (b < nb) {
-                            ra[q] = __hip_atomic_load(&rec[b].a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            rb[q] = __hip_atomic_load(&rec[b].b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ra[q] = __hip_atomic_load(&rec[(size_t)(step & 1) * nb + b].a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            rb[q] = __hip_atomic_load(&rec[(size_t)(step & 1) * nb + b].b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             ok = ok && (unsigned int)(ra[q] >> 48) == tag && (unsigned int)(rb[q] >> 48) == tag;
                         }
                     }
@@ -568,6 +571,7 @@ __global__ void greedy_res_init_kernel(GresRec *rec, unsigned long long *rec2, i
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         rec[i].a = 0ull; rec[i].b = 0ull;
+        rec[n + i].a = 0ull; rec[n + i].b = 0ull;              // both parities (greedy_res_kernel)
         for (int g = 0; g < 8; ++g) rec2[(size_t)i * 8 + g] = 0ull;
     }
     if (i == 0) { status[0] = 0; status[1] = 0; status[2] = 0; status[3] = 0; }
@@ -590,8 +594,10 @@ bool greedy_res_supported(const GreedyLayout &g, int Dt, int n_cus)
     return nb >= 1 && nb <= cap && (g.jdim + 3) / 4 <= 38 && gres_lds_bytes(g, Dt) <= (size_t)(160 * 1024);
 }
 
-// per workgroup: the step's record (16 bytes) and the second round's membership mask (8 granules)
-size_t greedy_res_record_bytes(const GreedyLayout &g) { return (size_t)((g.Nwin + GRES_T - 1) / GRES_T) * (sizeof(GresRec) + 64); }
+// per workgroup: the step's record (16 bytes) for each step parity and the second round's membership mask (8 granules; it
+// needs no second copy: a workgroup reaches the second round of a later step only after gathering that step's first-round
+// records of everybody, which are published after the masks of the earlier step were read)
+size_t greedy_res_record_bytes(const GreedyLayout &g) { return (size_t)((g.Nwin + GRES_T - 1) / GRES_T) * (2 * sizeof(GresRec) + 64); }
 
 // One utterance, all steps, one launch.  *status (device, 4 words): 0 or 1 + the first step that was not decided here,
 // rounds, windows settled by exact totals, watchdog.  hst: the hoisted target term of the utterance (required).
@@ -614,7 +620,7 @@ void launch_greedy_res(const GreedyLayout &g, const float *F_unw, int Fp, int Dt
     const int nb = (int)((g.Nwin + GRES_T - 1) / GRES_T);
     const int JQ4 = (g.jdim + 3) / 4, tile_q = (g.jdim + GR_CC - 1) / GR_CC * 8;
     const size_t lds = gres_lds_bytes(g, Dt);
-    unsigned long long *rec2 = reinterpret_cast<unsigned long long *>(reinterpret_cast<GresRec *>(rec) + nb);
+    unsigned long long *rec2 = reinterpret_cast<unsigned long long *>(reinterpret_cast<GresRec *>(rec) + 2 * nb);
     hipLaunchKernelGGL(greedy_res_init_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, reinterpret_cast<GresRec *>(rec), rec2, nb, status);
     // (every instance is given the largest LDS size once per device)
     unsigned long long *trace = nullptr;
@@ -626,9 +632,9 @@ void launch_greedy_res(const GreedyLayout &g, const float *F_unw, int Fp, int Dt
 #define SNK_GRES(JQ_, EX_)                                                                                         \
     {                                                                                                              \
         static size_t attr[32] = {0};                                                                              \
-        if (lds_attr_needed(attr, (size_t)(160 * 1024)))                                                           \
+        lds_attr_ensure(attr, (size_t)(160 * 1024), [] {                                                           \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(greedy_res_kernel<JQ_, EX_>),                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });          \
         hipLaunchKernelGGL((greedy_res_kernel<JQ_, EX_>), dim3(nb), dim3(GRES_T), lds, s, a, nsteps, flags, JQ4, tile_q, \
                            reinterpret_cast<GresRec *>(rec), rec2, path, status, trace);                           \
     }

@@ -518,8 +518,9 @@ void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int
                        int cap, int *status, hipStream_t s)
 {
     static size_t attr[32] = {0};
-    if ((size_t)Tpad * sizeof(int) > 65536 && lds_attr_needed(attr, (size_t)Tpad * sizeof(int)))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)Tpad * sizeof(int)));
+    if ((size_t)Tpad * sizeof(int) > 65536)
+        lds_attr_ensure(attr, (size_t)Tpad * sizeof(int), [&] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)Tpad * sizeof(int))); });
     hipLaunchKernelGGL(knn_bucket_kernel, dim3(1024), dim3(256), (size_t)Tpad * sizeof(int), s,
                        reinterpret_cast<const PoolEntry *>(pool), pool_ctl, chunk_fill, max_chunks,
                        (int)Tpad, (int)n_valid, cnt, lkey, lidx, cap, status);
@@ -1106,11 +1107,11 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
     size_t shmem = (size_t)P * ((f32k ? sizeof(float) : sizeof(double)) + sizeof(int));
     if (shmem < (size_t)SEL_MAX * sizeof(double)) shmem = (size_t)SEL_MAX * sizeof(double);
     static size_t attr[32] = {0};
-    if (lds_attr_needed(attr, shmem)) {
+    lds_attr_ensure(attr, shmem, [&] {
 #define SNK_FIN_ATTR(C_, F_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_finalize_kernel<C_, F_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)
         SNK_FIN_ATTR(0, false); SNK_FIN_ATTR(0, true); SNK_FIN_ATTR(2, false); SNK_FIN_ATTR(2, true);
 #undef SNK_FIN_ATTR
-    }
+    });
 #define SNK_FIN(C_, F_, SH_) hipLaunchKernelGGL((knn_finalize_kernel<C_, F_>), dim3((unsigned)T), dim3(256), SH_, s, Fw, F_unw, Fp, wt, Dpad, D, Qp, \
                        qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat)
     if (split_short && K <= FIN_SMALL / 2 && cap > FIN_SMALL) {
@@ -1313,9 +1314,9 @@ void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, in
     while (P < G * K) P <<= 1;
     const size_t shmem = (size_t)P * (sizeof(double) + sizeof(int));
     static size_t attr[32] = {0};
-    if (lds_attr_needed(attr, shmem))
+    lds_attr_ensure(attr, shmem, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_topk_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); });
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)T), dim3(256), shmem, s, d2, id, G, T, K,
                        cand, dist);
 }

@@ -312,6 +312,7 @@ struct snk_engine {
     int n_cus = 256;
     int reserved_cus = 2;
     int batch_rows = 12288;    // rows per K-NN call of the batch entry points (utterances are grouped)
+    int viterbi_weights = 0;   // 0: float64 recursion (default); 1: OpenFST's float32 weight chain (fst_functions_wrapped.py:47,201,368,389), dense kernels
     int viterbi_mode = 2;      // 2: auto; 1: f32 lower bounds on the matrix pipe + sparse exact recursion; 0: dense exact join + recursion
     double join_beta = 5e-4;   // pass-2 margin in units of the step's largest centred norm (speed only, never the result)
     // pass 2 (approximate recursion) in chunks of viterbi_lb_chunk steps side by side (0: one chain per utterance), each
@@ -321,6 +322,11 @@ struct snk_engine {
     int lb_chunk_max_utts = 24;
     int lb_warm = 16;
     DevBuf vstats;             // [0] cells refined, [1] steps with a refinement, [2] exact costs computed there
+    // pass 1 of the sparse path, second form (joinfast_kernels.hip: join_lb2_kernel): float32 copy of the weighted join rows,
+    // built at the first sparse recursion after snk_set_weights; [0] of jw_umax: bits of the largest row norm
+    DevBuf JW32, jw_umax;
+    bool jw32_ready = false;
+    int join_lb_variant = 1;   // 1: bf16 matrix pipe over the weighted float32 copy (default); 0: float32 matrix pipe, weights applied per gather
     int pool_chunk_limit = 0;  // test hook: cap of the entry pool (chunks) in every attempt; 0 = none
     int pool_chunks = 4096;    // entry pool: 4096 chunks x 2048 entries x 16 B = 128 MiB      // left free by the persistent K-NN sweep for Viterbi DP blocks
     int last_retries = 0;
@@ -582,7 +588,7 @@ int snk_destroy(snk_handle h)
     { DevBuf *cb[] = {&h->sh_d2, &h->sh_id, &h->sh_bound, &h->sh_rd2, &h->sh_rid, &h->sh_res, &h->sh_resall,
                       &h->gs_unw, &h->gs_w, &h->gs_norm, &h->gs_tiles, &h->gs_fmax2};
       for (auto *b : cb) b->release(); }
-    DevBuf *bufs[] = {&h->F_unw, &h->JC_unw, &h->Fw, &h->fnorm, &h->JCw, &h->wt, &h->wj, &h->unit_class,
+    DevBuf *bufs[] = {&h->F_unw, &h->JC_unw, &h->Fw, &h->fnorm, &h->JCw, &h->wt, &h->wj, &h->unit_class, &h->JW32, &h->jw_umax,
                       &h->Qraw, &h->Qp, &h->Qf, &h->qnorm, &h->thr, &h->gmin, &h->cnt, &h->lkey, &h->lidx,
                       &h->status, &h->qclass, &h->d2tmp, &h->slabctr, &h->pool, &h->poolctl, &h->chunkfill, &h->Dm, &h->gprev, &h->gblkmin, &h->gblkarg,
                       &h->gpath, &h->gdist, &h->gsync, &h->gtiles, &h->cls16_full, &h->cls16_samp,
@@ -637,6 +643,7 @@ static int upload_join(snk_engine *h, const float *JC_unw, int64_t Njc, int Dj)
     // everything derived from the join matrix (greedy layout, float32 / float16 join tiles, their norms and range check)
     h->have_glay = false;
     h->gtiles_ready = false; h->gt16_ready = false; h->gt16_ok = false; h->gj_ready = false;
+    h->jw32_ready = false;
     return 0;
 }
 
@@ -666,6 +673,7 @@ int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt, const flo
     h->have_db = true;
     h->have_weights = false;
     h->have_classes = false;
+    h->bslot[0].q_rows = -1; h->bslot[1].q_rows = -1;      // a new voice: the next batch submit carries its query rows
     h->have_glay = false;
     h->gtiles_ready = false; h->gt16_ready = false;
     h->gh_ready = false; h->gj_ready = false;
@@ -723,6 +731,8 @@ int snk_set_column_selection(snk_handle h, const int *tcols, int nt, const int *
         CHK(h2d_sync(h, h->tmask.p, h->tsel.data(), h->tsel.size() * sizeof(double)));
     }
     h->have_weights = false;                 // takes effect with the next snk_set_weights
+    // rows resident in the batch workspaces were masked with the selection of their upload: the next submit must carry Q
+    h->bslot[0].q_rows = -1; h->bslot[1].q_rows = -1;
     return 0;
 }
 
@@ -765,6 +775,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
     }
     HIPCHK(hipGetLastError());
     h->gh_ready = false; h->gj_ready = false;                  // window norms of the hoisted greedy target term follow the target weights
+    h->jw32_ready = false;                                     // ... and the float32 copy of the weighted join rows the join weights
     // float32 operands of the prefilter (knn16_kernels.hip): ||f||^2 rides in ONE spare padding column
     h->f16_ready = false;
     h->cls16_ready = false;
@@ -1530,6 +1541,7 @@ static int64_t join_units(snk_engine *h)
 static bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts = 1)
 {
     (void)n_utts;
+    if (h->viterbi_weights == 1) return false;          // the float32 weight chain runs on the dense kernels
     if (!join_lb_supported(h->Dj, K)) return false;
     return h->viterbi_mode == 1 || h->viterbi_mode == 2;
 }
@@ -1548,6 +1560,29 @@ static int sparse_ensure(snk_engine *h, UttSlot &s, int64_t rows, int K)
     return 0;
 }
 
+static int ensure_jw32(snk_engine *h, hipStream_t st)
+{
+    if (h->jw32_ready) return 0;
+    // once per set of weights; waited for: the groups of a batch launch pass 1 on different streams
+    const int Jq = join_lb2_pitch(h->Dj);
+    CHK(h->JW32.ensure((size_t)h->Njc * Jq * sizeof(float)));
+    CHK(h->jw_umax.ensure(64));
+    launch_join_weight32(h->JC_unw.as<float>(), h->Jp, h->Njc, h->Dj, h->wj.as<double>(), h->JW32.as<float>(), Jq,
+                         h->jw_umax.as<unsigned int>(), st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    h->jw32_ready = true;
+    return 0;
+}
+
+static void join_bounds_launch(snk_engine *h, const int64_t *cand, int64_t rows, int K, float *Jlo, float *scale, hipStream_t st)
+{
+    if (h->join_lb_variant == 1)
+        launch_join_lb2(h->JW32.as<float>(), h->Dj, h->jw_umax.as<unsigned int>(), join_units(h), cand, rows, K, Jlo, scale, st);
+    else
+        launch_join_lb(h->JC_unw.as<float>(), h->Jp, h->Dj, h->wj.as<double>(), join_units(h), cand, rows, K, Jlo, scale, st);
+}
+
 // Passes 1..4 of joinfast_kernels.hip over `rows` candidate rows holding n_utts utterances (off: n_utts + 1
 // row offsets).  Pass 1 runs on `main` (the whole chip, in parallel over the rows); the three per-utterance
 // passes on `side` behind `knn_done` when the two streams differ.
@@ -1558,13 +1593,14 @@ static int viterbi_sparse_rows(snk_engine *h, UttSlot &s, const int64_t *cand, c
     const float *JC = h->JC_unw.as<float>();
     const double *wj = h->wj.as<double>();
     const bool lb_side = h->join_bounds_stream == 1 && side != main;
+    if (h->join_lb_variant == 1) CHK(ensure_jw32(h, main));
     if (lb_side) {
         HIPCHK(hipEventRecord(s.knn_done, main));
         HIPCHK(hipStreamWaitEvent(side, s.knn_done, 0));
     }
     {
         StageTimer t(h, lb_side ? side : main, TM_JOIN_LB);
-        launch_join_lb(JC, h->Jp, h->Dj, wj, join_units(h), cand, rows, K, s.Jlo.as<float>(), s.scale.as<float>(), lb_side ? side : main);
+        join_bounds_launch(h, cand, rows, K, s.Jlo.as<float>(), s.scale.as<float>(), lb_side ? side : main);
     }
     if (side != main && !lb_side) {
         HIPCHK(hipEventRecord(s.knn_done, main));
@@ -1607,7 +1643,7 @@ static int viterbi_device(snk_engine *h, UttSlot &s, int64_t T, int K, hipStream
         StageTimer t(h, st, TM_VITERBI_DP);
         launch_viterbi_dp(s.cand.as<int64_t>(), s.tdist.as<double>(), s.J.as<double>(), T, K, join_units(h),
                           s.bp.as<unsigned char>(), s.path.as<int64_t>(), s.plen.as<int64_t>(),
-                          s.cost.as<double>(), st);
+                          s.cost.as<double>(), st, h->viterbi_weights == 1);
     }
     return 0;
 }
@@ -1631,6 +1667,27 @@ int snk_join_costs(snk_handle h, const int64_t *cand, int64_t T, int K, double *
     }
     HIPCHK(hipGetLastError());
     CHK(d2h_sync(h, J_out, s.J.p, (size_t)(T - 1) * K * K * sizeof(double), h->stream));
+    collect_timers(h);
+    return 0;
+}
+
+int snk_join_bounds(snk_handle h, const int64_t *cand, int64_t T, int K, float *lo_out, float *scale_out)
+{
+    CHK(check_ready(h, false, true));
+    CHK(no_batch_in_flight(h, "snk_join_bounds"));
+    HIPCHK(hipSetDevice(h->device));
+    if (!cand || !lo_out || !scale_out) return fail("snk_join_bounds: null argument");
+    if (T < 2) return fail("snk_join_bounds: need at least 2 columns");
+    if (!join_lb_supported(h->Dj, K)) return fail("snk_join_bounds: no bounds variant for %d join columns, K=%d", h->Dj, K);
+    UttSlot &s = h->slot[0];
+    CHK(slot_ensure(h, s, T, K));
+    CHK(sparse_ensure(h, s, T, K));
+    CHK(h2d(h, s.cand.p, cand, (size_t)T * K * sizeof(int64_t), h->stream));
+    if (h->join_lb_variant == 1) CHK(ensure_jw32(h, h->stream));
+    join_bounds_launch(h, s.cand.as<int64_t>(), T, K, s.Jlo.as<float>(), s.scale.as<float>(), h->stream);
+    HIPCHK(hipGetLastError());
+    D2HPart parts[2] = {{lo_out, s.Jlo.p, (size_t)(T - 1) * K * K * sizeof(float)}, {scale_out, s.scale.p, (size_t)(T - 1) * sizeof(float)}};
+    CHK(staged_d2h(h, h->stream, parts, 2));
     collect_timers(h);
     return 0;
 }
@@ -1765,7 +1822,8 @@ static int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u
     {
         StageTimer t(h, dps, TM_VITERBI_DP);
         launch_viterbi_dp_batch(cand_all + r0 * K, tdist_all + r0 * K, s.J.as<double>(), off.data(), u1 - u0, u0, K,
-                                join_units(h), s.bp.as<unsigned char>(), res_path + r0, res_plen, res_cost, dps);
+                                join_units(h), s.bp.as<unsigned char>(), res_path + r0, res_plen, res_cost, dps,
+                                h->viterbi_weights == 1);
     }
     if (side_stream) { HIPCHK(hipEventRecord(s.vit_done, dps)); s.vit_recorded = true; }
     else s.vit_recorded = false;             // ran on the main stream: ordered with everything that follows
@@ -1807,6 +1865,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
     if (h->Njc != h->N + 1) return fail("snk_knn_viterbi_batch: join_contexts rows != N+1");
     if (K > 208) return fail("viterbi: n_candidates=%d > 208 not supported", K);
+    if (row_offsets[0] != 0) return fail("snk_knn_viterbi_batch: row_offsets[0] must be 0 (got %lld)", (long long)row_offsets[0]);
     const int64_t total = row_offsets[n_utts];
     for (int u = 0; u < n_utts; ++u)
         if (row_offsets[u + 1] - row_offsets[u] < 1) return fail("snk_knn_viterbi_batch: utterance %d has no rows", u);
@@ -3169,6 +3228,13 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0) return fail("join_bounds_stream must be 0 (main stream) or 1 (side stream of the group)");
         CHK(no_batch_in_flight(h, "snk_set_option(join_bounds_stream)"));
         h->join_bounds_stream = (int)value;
+    } else if (!strcmp(name, "viterbi_weights")) {
+        if (value != 0.0 && value != 1.0) return fail("viterbi_weights must be 0 (float64) or 1 (OpenFST's float32 weights)");
+        CHK(no_batch_in_flight(h, "snk_set_option(viterbi_weights)"));
+        h->viterbi_weights = (int)value;
+    } else if (!strcmp(name, "join_lb_variant")) {
+        if (value != 0.0 && value != 1.0) return fail("join_lb_variant must be 0 or 1");
+        h->join_lb_variant = (int)value;
     } else if (!strcmp(name, "join_beta")) {
         if (!(value >= 0.0 && value <= 10.0)) return fail("join_beta must be in 0..10");
         h->join_beta = value;
@@ -3196,6 +3262,8 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "batch_redos")) *out = h->batch_redos;
     else if (!strcmp(name, "pool_overflows")) *out = h->pool_overflows;
     else if (!strcmp(name, "viterbi_mode")) *out = h->viterbi_mode;
+    else if (!strcmp(name, "join_lb_variant")) *out = h->join_lb_variant;
+    else if (!strcmp(name, "viterbi_weights")) *out = h->viterbi_weights;
     else if (!strcmp(name, "greedy_mode")) *out = h->greedy_mode;
     else if (!strcmp(name, "greedy_hoist")) *out = h->greedy_hoist;
     else if (!strcmp(name, "greedy_hoist_launches")) *out = (double)h->greedy_hoist_launches;

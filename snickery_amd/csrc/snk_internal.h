@@ -42,18 +42,19 @@ inline void trace_launch(const char *kernel, const char *file, int line, hipStre
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the device that is current when it is called: the
 // "already raised to" state of a kernel is kept per device (a process may hold engines on several), under a lock
-// (engines on different devices may be driven from different threads).  Returns true when `want` exceeds what this
-// device's copy of the kernel was given so far -- the caller then sets the attribute.
-inline bool lds_attr_needed(size_t (&per_device)[32], size_t want)
+// (engines on different devices may be driven from different threads).  `set` raises the attribute(s) and runs UNDER the
+// lock, before the new state is recorded: a second thread never sees "raised" ahead of the call that raises it.
+template <typename F>
+inline void lds_attr_ensure(size_t (&per_device)[32], size_t want, F &&set)
 {
     static std::mutex m;
     int d = 0;
     (void)hipGetDevice(&d);
     std::lock_guard<std::mutex> lock(m);
     size_t &have = per_device[d & 31];
-    if (want <= have) return false;
+    if (want <= have) return;
+    set();
     have = want;
-    return true;
 }
 
 // ---- database preparation -------------------------------------------------
@@ -175,15 +176,23 @@ struct DpBatch {                      // kernel-argument descriptor of one batch
 };
 void launch_viterbi_dp_batch(const int64_t *cand, const double *tdist, const double *J, const int64_t *off,
                              int n_utts, int first_utt, int K, int64_t n_units, unsigned char *bp_global,
-                             int64_t *path, int64_t *path_len, double *cost, hipStream_t s);
+                             int64_t *path, int64_t *path_len, double *cost, hipStream_t s,
+                             bool fst32 = false);    // fst32: OpenFST's float32 weight chain (option viterbi_weights 1)
 void launch_viterbi_dp(const int64_t *cand, const double *tdist, const double *J,
                        int64_t T, int K, int64_t n_units, unsigned char *bp_global,
-                       int64_t *path, int64_t *path_len, double *cost, hipStream_t s);
+                       int64_t *path, int64_t *path_len, double *cost, hipStream_t s, bool fst32 = false);
 
 // ---- join lower bounds + sparse exact recursion (joinfast_kernels.hip) ------------------------
 bool join_lb_supported(int Dj, int K);
 void launch_join_lb(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
                     int64_t R, int K, float *Jlo, float *scale, hipStream_t s);
+// second form of pass 1: bf16 matrix pipe over a float32 copy of the weighted join rows (built once per set of weights)
+int join_lb2_pitch(int Dj);
+double join_lb2_ceps(int Dj);
+void launch_join_weight32(const float *JC_unw, int Jp, int64_t Njc, int Dj, const double *wj, float *JW, int Jq,
+                          unsigned int *umax_bits, hipStream_t s);
+void launch_join_lb2(const float *JW, int Dj, const unsigned int *umax_bits, int64_t n_units, const int64_t *cand, int64_t R,
+                     int K, float *Jlo, float *scale, hipStream_t s);
 void launch_viterbi_lb(const int64_t *cand, const double *tdist, const float *Jlo, const float *scale, const int64_t *off,
                        int n_utts, int K, int64_t n_units, float beta, void *sets, hipStream_t s,
                        int chunk_len = 0, int warm = 32);   // chunk_len > 0: the approximate recursion in chunks of that many steps, side by side

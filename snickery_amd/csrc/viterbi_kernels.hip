@@ -189,7 +189,14 @@ void launch_join_costs(const double *JCw, int Djpad, int /*Dj*/, int64_t n_units
 // ---------------------------------------------------------------------------
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-template <int KPM, int NB, int NTH, bool BPL>
+// FST32 (option viterbi_weights 1): the float32 chain of the reference's OpenFST lattices instead of the float64 recursion
+// (fst_functions_wrapped.py:47,201: every arc weight is parsed into a float32 tropical weight; :368,389: compose adds the
+// T arc's and the J arc's weights, shortestpath accumulates from the start state -- oracle/snk_oracle.py _viterbi_fst32):
+//           acc_0[k] = 0                                     (free epsilon entry, :195-196)
+//           acc_t[k] = min_k' fl32( acc_{t-1}[k'] + fl32( fl32(tdist[t-1,k']) + fl32(J[t-1,k',k]) ) )
+//           final[k] = fl32( acc_{T-1}[k] + fl32(tdist[T-1,k]) )   (the exit arc carries the last target cost)
+// same tie rule.  delta then holds float32 values (widened), tdp the float32 target costs of the previous row.
+template <int KPM, int NB, int NTH, bool BPL, bool FST32>
 __global__ void __launch_bounds__(NTH)
 viterbi_dp_kernel(const int64_t *__restrict__ cand_all, const double *__restrict__ tdist_all,
                   const double *__restrict__ J_all, const DpBatch batch, int K, int64_t n_units, int KP,
@@ -212,7 +219,8 @@ viterbi_dp_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
     double *delta = reinterpret_cast<double *>(smem);              // [2][KP], KP >= 4*KPM
     // back-pointers [T][K]: in LDS when they fit, else in global memory (two typed pointers: a
     // flat store would turn every later wait into a full vmcnt(0)/lgkmcnt(0))
-    unsigned char *bp_lds = reinterpret_cast<unsigned char *>(delta + 2 * KP);
+    float *tdp = reinterpret_cast<float *>(delta + 2 * KP);        // FST32: [2][KP] float32 target costs of a row
+    unsigned char *bp_lds = reinterpret_cast<unsigned char *>(delta + 2 * KP) + (FST32 ? 2 * KP * 4 : 0);
     __shared__ int final_slot;
 
     const int tid = threadIdx.x;
@@ -228,9 +236,12 @@ viterbi_dp_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
         if (tid == 0) { *path_len = 0; *cost = inf; }
         return;
     }
-    for (int i = tid; i < 2 * KP; i += (int)blockDim.x) delta[i] = inf;
+    for (int i = tid; i < 2 * KP; i += (int)blockDim.x) { delta[i] = inf; if constexpr (FST32) tdp[i] = 0.f; }
     __syncthreads();
-    if (lead) delta[k] = unit_usable(cand[k], n_units) ? tdist[k] : inf;
+    if (lead) {
+        if constexpr (FST32) { delta[k] = unit_usable(cand[k], n_units) ? 0.0 : inf; tdp[k] = (float)tdist[k]; }
+        else delta[k] = unit_usable(cand[k], n_units) ? tdist[k] : inf;
+    }
 
     // idle columns (k >= K) run the same convergent code with an out-of-range offset: their loads
     // return 0 without touching memory and their results are never stored
@@ -270,12 +281,17 @@ viterbi_dp_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
         const double *dprev = delta + ((t - 1) & 1) * KP;
         double *dcur = delta + (t & 1) * KP;
         const double td = unit_usable(idr, n_units) ? tdr : inf;
+        const float td32 = (float)tdr;
         load_target(t + NB, tdr, idr);
         double best = inf;
         int arg = 0;
 #pragma unroll
         for (int i = 0; i < KPM; ++i) {
-            const double tot = __dadd_rn(dprev[kp0 + i], jr[i]);
+            double tot;
+            if constexpr (FST32) {
+                const float arcw = tdp[((t - 1) & 1) * KP + kp0 + i] + (float)jr[i];        // composed arc weight
+                tot = (double)((float)dprev[kp0 + i] + arcw);
+            } else tot = __dadd_rn(dprev[kp0 + i], jr[i]);
             if (tot < best) { best = tot; arg = i; }
         }
         arg += kp0;
@@ -288,7 +304,8 @@ viterbi_dp_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
             if (ob < best || (ob == best && oa < arg)) { best = ob; arg = oa; }
         }
         if (lead && valid) {
-            dcur[k] = __dadd_rn(td, best);
+            if constexpr (FST32) { dcur[k] = td < inf ? best : inf; tdp[(t & 1) * KP + k] = td32; }
+            else dcur[k] = __dadd_rn(td, best);
             if constexpr (BPL) bp_lds[t * K + k] = (unsigned char)arg;
             else bp_global[t * K + k] = (unsigned char)arg;
         }
@@ -304,8 +321,11 @@ viterbi_dp_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
     if (tid == 0) {
         double best = inf;
         int slot = 0;
-        for (int kk = 0; kk < K; ++kk)
-            if (dlast[kk] < best) { best = dlast[kk]; slot = kk; }
+        for (int kk = 0; kk < K; ++kk) {
+            double v = dlast[kk];
+            if constexpr (FST32) v = (double)((float)v + tdp[((T - 1) & 1) * KP + kk]);
+            if (v < best) { best = v; slot = kk; }
+        }
         if (best == inf) { *path_len = 0; *cost = inf; final_slot = -1; }
         else { *path_len = T; *cost = best; final_slot = slot; }
     }
@@ -327,7 +347,7 @@ viterbi_dp_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
 // in the kernel arguments.  path_len / cost are indexed by first_utt + i.
 void launch_viterbi_dp_batch(const int64_t *cand, const double *tdist, const double *J, const int64_t *off,
                              int n_utts, int first_utt, int K, int64_t n_units, unsigned char *bp_global,
-                             int64_t *path, int64_t *path_len, double *cost, hipStream_t s)
+                             int64_t *path, int64_t *path_len, double *cost, hipStream_t s, bool fst32)
 {
     for (int u0 = 0; u0 < n_utts; u0 += DpBatch::MAX) {
         const int n = (n_utts - u0 < DpBatch::MAX) ? n_utts - u0 : DpBatch::MAX;
@@ -346,23 +366,23 @@ void launch_viterbi_dp_batch(const int64_t *cand, const double *tdist, const dou
         else { variant = 3; kpm = 52; }
         const int KP = 4 * kpm;
         const int nth = 64 * ((K + 15) / 16);
-        const size_t base = (size_t)2 * KP * 8;
+        const size_t base = (size_t)2 * KP * 8 + (fst32 ? (size_t)2 * KP * 4 : 0);
         const size_t bp_bytes = (size_t)T * K;
         const int bp_in_lds = (base + bp_bytes + 64 <= 150 * 1024) ? 1 : 0;
         const size_t shmem = base + (bp_in_lds ? bp_bytes : 0);
-#define SNK_DP1(KPM_, NB_, NTH_, BPL_)                                                             \
+#define SNK_DP1(KPM_, NB_, NTH_, BPL_, F32_)                                                       \
     {                                                                                              \
         static size_t attr_set[32] = {0};                                                    \
-        if (lds_attr_needed(attr_set, 150 * 1024)) {                                                                           \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&viterbi_dp_kernel<KPM_, NB_, NTH_, BPL_>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));    \
-        }                                                                                          \
-        hipLaunchKernelGGL((viterbi_dp_kernel<KPM_, NB_, NTH_, BPL_>), dim3(n), dim3(nth), shmem, s, cand, \
+        lds_attr_ensure(attr_set, 150 * 1024, [] {                                                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&viterbi_dp_kernel<KPM_, NB_, NTH_, BPL_, F32_>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024)); });  \
+        hipLaunchKernelGGL((viterbi_dp_kernel<KPM_, NB_, NTH_, BPL_, F32_>), dim3(n), dim3(nth), shmem, s, cand, \
                            tdist, J, batch, K, n_units, KP, bp_global, path, path_len, cost);      \
     }
 #define SNK_DP(KPM_, NB_, NTH_)                                                                    \
     {                                                                                              \
-        if (bp_in_lds) SNK_DP1(KPM_, NB_, NTH_, true) else SNK_DP1(KPM_, NB_, NTH_, false)         \
+        if (fst32) { if (bp_in_lds) SNK_DP1(KPM_, NB_, NTH_, true, true) else SNK_DP1(KPM_, NB_, NTH_, false, true) }   \
+        else { if (bp_in_lds) SNK_DP1(KPM_, NB_, NTH_, true, false) else SNK_DP1(KPM_, NB_, NTH_, false, false) }       \
     }
         if (variant == 0) SNK_DP(16, 4, 256)
         else if (variant == 1) SNK_DP(25, 3, 448)
@@ -375,10 +395,10 @@ void launch_viterbi_dp_batch(const int64_t *cand, const double *tdist, const dou
 
 void launch_viterbi_dp(const int64_t *cand, const double *tdist, const double *J, int64_t T, int K,
                        int64_t n_units, unsigned char *bp_global, int64_t *path, int64_t *path_len,
-                       double *cost, hipStream_t s)
+                       double *cost, hipStream_t s, bool fst32)
 {
     const int64_t off[2] = {0, T};
-    launch_viterbi_dp_batch(cand, tdist, J, off, 1, 0, K, n_units, bp_global, path, path_len, cost, s);
+    launch_viterbi_dp_batch(cand, tdist, J, off, 1, 0, K, n_units, bp_global, path, path_len, cost, s, fst32);
 }
 
 }  // namespace snk

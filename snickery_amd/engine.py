@@ -45,6 +45,7 @@ _SIGNATURES = {
     'snk_candidate_distances': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int, _c_i64p,
                                                ctypes.c_int, _c_f64p]),
     'snk_join_costs': (ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int64, ctypes.c_int, _c_f64p]),
+    'snk_join_bounds': (ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int64, ctypes.c_int, _c_f32p, _c_f32p]),
     'snk_viterbi': (ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_f64p, ctypes.c_int64, ctypes.c_int,
                                    _c_i64p, _c_i64p, _c_f64p]),
     'snk_viterbi_batch': (ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_f64p, _c_i64p, ctypes.c_int, ctypes.c_int,
@@ -309,6 +310,16 @@ class HipSearchEngine(object):
         J = np.empty((T - 1, K, K), dtype=np.float64)
         self._check(self._lib.snk_join_costs(self._h, _ptr(cand, _c_i64p), T, K, _ptr(J, _c_f64p)))
         return J
+
+    def join_bounds(self, candidates):
+        """Diagnostic: pass 1 of the sparse Viterbi path, the float32 lower bounds of join_costs(candidates) and the
+        per-step scale (snk_join_bounds)."""
+        cand = np.ascontiguousarray(candidates, dtype=np.int64)
+        T, K = cand.shape
+        lo = np.empty((T - 1, K, K), dtype=np.float32)
+        scale = np.empty((T - 1,), dtype=np.float32)
+        self._check(self._lib.snk_join_bounds(self._h, _ptr(cand, _c_i64p), T, K, _ptr(lo, _c_f32p), _ptr(scale, _c_f32p)))
+        return lo, scale
 
     def viterbi(self, candidates, distances):
         """viterbi_search (synth_halfphone.py:1399-1436): (path list[int], cost)."""

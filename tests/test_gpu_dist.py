@@ -232,12 +232,14 @@ def _child_report(r):
 
 def _run_bench_child(cmd, env):
     """bench.py under torch.distributed.run with the ranks SHARING the one GPU of the test box (never a production
-    layout).  One of ten full-suite runs of round 3 lost such a child to SIGABRT in rank 1 (240 runs of these tests alone
-    did not); a child killed by a signal is therefore reported on stderr -- the evidence stays in the log -- and run once
-    more; a second death, or any ordinary failure, fails the test."""
+    layout).  A child that dies -- by a signal or otherwise -- FAILS the test, with what it said (_child_report) in the
+    message.  (Round 3 re-ran a child killed by a signal once; that hid exactly the class of failure these tests exist to
+    show.  SNK_TEST_RETRY_SIGNALLED_CHILD=1 restores the retry for triage loops; the driver does not set it, and a retried
+    run is still reported on stderr.)"""
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    if r.returncode != 0 and any(t in r.stderr for t in ('Signal 6', 'SIGABRT', 'Signal 11', 'SIGSEGV', 'Memory access fault')):
-        os.write(2, ('[snk-test] multi-rank child died with a signal; its report, then ONE retry:\n%s\n' % _child_report(r)).encode())
+    if (r.returncode != 0 and os.environ.get('SNK_TEST_RETRY_SIGNALLED_CHILD') == '1'
+            and any(t in r.stderr for t in ('Signal 6', 'SIGABRT', 'Signal 11', 'SIGSEGV', 'Memory access fault'))):
+        os.write(2, ('[snk-test] multi-rank child died with a signal; its report, then ONE retry (triage mode):\n%s\n' % _child_report(r)).encode())
         r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     return r
 

@@ -1,0 +1,96 @@
+"""Option viterbi_weights 1: the recursion in the reference's own arithmetic -- OpenFST's float32 tropical weights
+(script/fst_functions_wrapped.py:47,201: lattice weights are parsed into float32; :368 compose, :389 shortestpath) -- against
+the oracle's restatement of that chain (oracle/snk_oracle.py _viterbi_fst32; on the golden voice its path is pinned to the
+reference's own lattice text, tests/test_oracle_golden.py).  Path AND the float32 total must be equal, bit for bit; float64
+stays the default and is unchanged by a round trip through the option."""
+import numpy as np
+import pytest
+
+import snk_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def engine():
+    import snickery_amd
+    e = snickery_amd.HipSearchEngine(0)
+    yield e
+    e.set_option('viterbi_weights', 0)
+    e.close()
+
+
+def _fst32(engine, cand, dist):
+    engine.set_option('viterbi_weights', 1)
+    try:
+        return engine.viterbi(cand, dist)
+    finally:
+        engine.set_option('viterbi_weights', 0)
+
+
+def test_fst32_on_the_golden_voice(engine, golden, mini_voice):
+    engine.upload_db(mini_voice['F_unw'], mini_voice['JC_unw'])
+    engine.set_weights(mini_voice['wt'], mini_voice['wj'])
+    cand, dist = golden['join_candidates'], golden['knn_distances']
+    opath, ocost = o.viterbi(cand, dist, mini_voice['E'], mini_voice['S'], mode='fst32')
+    path, cost = _fst32(engine, cand, dist)
+    assert path == opath and cost == ocost and np.float32(cost) == cost
+    p64, c64 = engine.viterbi(cand, dist)                         # the default is back, and is the float64 recursion
+    o64, oc64 = o.viterbi(cand, dist, mini_voice['E'], mini_voice['S'])
+    assert p64 == o64 and c64 == oc64
+    assert _fst32(engine, cand[:1], dist[:1]) == ([], float('inf'))           # T < 2
+    dead = cand.copy()
+    dead[5, :] = -1
+    assert _fst32(engine, dead, dist) == ([], float('inf'))
+
+
+@pytest.mark.parametrize('N,T,K,Dj', [(4000, 60, 50, 151), (2500, 30, 100, 302), (2000, 25, 13, 40), (3000, 20, 200, 151),
+                                      (3000, 40, 128, 151), (3000, 300, 64, 40)])
+def test_fst32_synthetic(engine, N, T, K, Dj):
+    F_unw, JC_unw = o.synthetic_db(N, 61, Dj, K)
+    rng = np.random.RandomState(K + 100)
+    wt = 0.2 + rng.rand(61)
+    wj = 0.05 + 0.2 * rng.rand(Dj)
+    F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    U = o.synthetic_targets(F_unw, T, seed=5) * wt
+    cand, dist = o.knn_bruteforce(F, U, K)
+    cand[2, 1] = -1
+    cand[3, 0] = 0
+    cand[4, 2] = N - 1
+    cand[6, 3] = cand[6, 0]; dist[6, 3] = dist[6, 0]              # a duplicate: exact tie between two slots
+    opath, ocost = o.viterbi(cand, dist, E, S, mode='fst32')
+    path, cost = _fst32(engine, cand, dist)
+    assert path == opath and cost == ocost
+    # the batch entry points take the same option
+    engine.set_option('viterbi_weights', 1)
+    try:
+        paths, costs = engine.viterbi_batch([cand, cand[:7], cand[:1]], [dist, dist[:7], dist[:1]])
+        p7, c7 = o.viterbi(cand[:7], dist[:7], E, S, mode='fst32')
+        assert list(paths[0]) == opath and costs[0] == ocost and list(paths[1]) == p7 and costs[1] == c7 and len(paths[2]) == 0
+        pk, ck, candk, distk = engine.knn_viterbi(U, K, return_candidates=True)
+        opk, ock = o.viterbi(candk, distk, E, S, mode='fst32')
+        assert pk == opk and ck == ock
+    finally:
+        engine.set_option('viterbi_weights', 0)
+
+
+def test_fst32_on_a_baseline_sized_utterance(engine):
+    """One B*-shaped utterance (T 600, K 100, 302 join columns) on a 300 k-unit walk: near ties everywhere, where the
+    float32 chain and the float64 recursion part ways (profiles/r02_fst32_statistic.json) -- the device follows the
+    float32 chain exactly."""
+    N, Dj, T, K = 300000, 302, 600, 100
+    F_unw, JC_unw = o.synthetic_db(N, 61, Dj, seed=14)
+    wt, wj = np.full(61, 0.4), np.full(Dj, 0.05)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    U = o.synthetic_targets(F_unw, T, seed=21) * wt
+    cand, dist = engine.knn(U, K)
+    J = engine.join_costs(cand)            # (T-1, K, K) exact float64 (bit-equal to the oracle's: test_gpu_parity.py)
+    ok = o.valid_mask(cand, N)
+    opath, ocost = o._viterbi_fst32(cand, dist.astype(np.float32), J.astype(np.float32), ok)
+    path, cost = _fst32(engine, cand, dist)
+    assert path == opath and cost == ocost
+    p64, _ = engine.viterbi(cand, dist)
+    print('fst32 vs float64 on this utterance: %d of %d frames differ' % (int(np.sum(np.asarray(p64) != np.asarray(path))), T))

@@ -21,8 +21,10 @@ ids = torch.empty(U * T, K, dtype=torch.int64, device=dev)
 eng.knn_local_batch_dev(utts, K, d2.data_ptr(), ids.data_ptr())
 torch.cuda.synchronize()
 ref = eng.knn_viterbi_batch(utts, K)
-for mode in (1, 0):
+for mode, variant in ((1, 1), (1, 0), (0, 1)):
     eng.set_option('viterbi_mode', mode)
+    eng.set_option('join_lb_variant', variant)
+    stats0 = [eng.info(k) for k in ('dense_cells', 'dense_steps', 'dense_exact_costs', 'set_overflows')]
     paths, costs = eng.merge_viterbi_batch_dev(d2.data_ptr(), ids.data_ptr(), 1, [T] * U, K)
     eng.reset_timers()
     torch.cuda.synchronize(); t0 = time.time()
@@ -30,5 +32,7 @@ for mode in (1, 0):
         paths, costs = eng.merge_viterbi_batch_dev(d2.data_ptr(), ids.data_ptr(), 1, [T] * U, K)
     torch.cuda.synchronize(); dt = (time.time() - t0) / 3
     same = all(np.array_equal(a, b) for a, b in zip(paths, ref[0])) and np.array_equal(costs, ref[1])
-    print('viterbi_mode %d: %.2f ms per 32-utterance batch  same=%s' % (mode, dt * 1e3, same))
+    stats1 = [eng.info(k) for k in ('dense_cells', 'dense_steps', 'dense_exact_costs', 'set_overflows')]
+    print('viterbi_mode %d join_lb_variant %d: %.2f ms per 32-utterance batch  same=%s  refined cells/steps/exact costs/overflows per batch %s'
+          % (mode, variant, dt * 1e3, same, [round((b - a) / 4) for a, b in zip(stats0, stats1)]))
     print('   ', {k: (round(v[0] / 3, 3), v[1] // 3) for k, v in eng.timers().items() if v[1]})
