@@ -219,239 +219,7 @@ static void launch_join_lb_t(const float *JC_unw, int Jp, int Dj, const double *
 
 bool join_lb_supported(int Dj, int K) { return ((Dj + 15) & ~15) <= JF_MAXD && K >= 1 && K <= 208; }
 
-// ---------------------------------------------------------------------------------------------
-// pass 1, second form (the default, option join_lb_variant 1): the same proven lower bounds from a float32 copy of the
-// WEIGHTED join rows (join_weight32_kernel, built once per set of weights: (N + 1) x Jq floats, padding columns 0) on the
-// bf16 matrix pipe.  What the first form spends per gathered element -- a float64 multiply by the weight, a float64
-// subtraction, two conversions, on the vector unit, beside float32 MFMAs that issue at 1/16 of the bf16 rate -- becomes
-// one float32 subtraction and a split into two bf16 pieces; the kernel is then bound by the gather itself.
-//
-//   u~ = fl32(u), u = fl64(x w) the canonical weighted value;   y = fl32(u~ - m~), m~ = u~ of the step's reference row
-//   (the start vector of the first candidate of row r + 1: any row of the matrix would do);   y = h + l + rr,
-//   h = bf16(y), l = bf16(y - h) (round to nearest: |l| <= 2^-9 (1 + 2^-8) |y|, |rr| <= 2^-18 |y|);
-//   G~ = sum over k-blocks of 16 columns of  he.ls + le.hs + he.hs   (v_mfma_f32_32x32x16_bf16, float32 accumulation);
-//   ne~, ns~ = float32 sums of squares of ye, ys (8-term chains per k-block, the k-blocks added in order).
-// Bound.  (i) representation:  || (ye - ys) - (ue - us) || <= eta := 2^-24 (||ue|| + ||us||) + 2^-24 (1 + 2^-23)(||ye|| + ||ys||)
-//   (the two roundings of every element; m~ cancels), so c = ||ue - us|| >= ||ye - ys|| - eta, with ||u|| <= Umax, the largest
-//   row norm of the copy (measured when it is built).  (ii) || ye - ys ||^2 = ne + ns - 2 ye.ys against c2~ = ne~ + ns~ - 2 G~:
-//     |G~ - ye.ys| <= [3.02 2^-18 (what the split drops: le.ls + rre.ys + (he + le).rrs)
-//                      + 1.01 (3 n_kb + 1) 2^-20 (every MFMA off by at most 2^-20 of its |products| + |C|: the probed
-//                        property of this instruction, knn16_kernels.hip / snk_probe_mfma_bf16)] ||ye|| ||ys||,
-//     ||ye|| ||ys|| <= (ne + ns) / 2,   |ne~ - ne| <= (n_kb + 12) 2^-24 ne,   four float32 operations in the epilogue,
-//   together e2 = ceps (ne~ + ns~) with ceps from launch_join_lb2 (7.1e-5 at 302 columns; the first form's 2.2 (D + 6) 2^-24
-//   is 4.1e-5 there).  clo = sqrt(max(c2~ - e2, 0)) (1 - 2^-21) - eta (1 + 1e-4), clamped at 0.
-// One workgroup per row pair; KT = ceil(K / 32) wavefronts; wavefront w keeps the pieces of its 32 E rows in registers (the A
-// operand: lane l <-> row l & 31, columns 16 kb + 8 (l >> 5) + 0..7) and stages those of its 32 S rows in LDS for everybody
-// (fragment order, double buffered, one barrier per k-block).  The rows of the next PF k-blocks are in flight in registers
-// (16-byte loads; a row's 64 bytes of a k-block are two lanes' 32 bytes each), the reference row rides along in the same
-// ring (every lane of a half reads the same 32 bytes: one request).
-// ---------------------------------------------------------------------------------------------
-typedef __bf16 jf_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 jf_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float jf_f32x2 __attribute__((ext_vector_type(2)));
-typedef float jf_f32x16 __attribute__((ext_vector_type(16)));
-
-__global__ void __launch_bounds__(256)
-join_weight32_kernel(const float *__restrict__ JC_unw, int Jp, int64_t Njc, int Dj, const double *__restrict__ wj,
-                     float *__restrict__ JW, int Jq, unsigned int *__restrict__ umax_bits)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= Njc) return;
-    double n2 = 0.0;
-    for (int c = lane; c < Jq; c += 64) {
-        const float v = c < Dj ? (float)__dmul_rn((double)JC_unw[row * Jp + c], wj[c]) : 0.f;
-        JW[row * Jq + c] = v;
-        n2 += (double)v * (double)v;
-    }
-#pragma unroll
-    for (int m = 1; m <= 32; m <<= 1) n2 += __shfl_xor(n2, m, 64);
-    if (lane == 0) {
-        const float nf = (float)sqrt(n2) * 1.000001f;          // rounded up; non-negative floats order like their bit patterns
-        atomicMax(umax_bits, nf == nf ? __float_as_uint(nf) : 0x7f800000u);      // NaN: +inf (every bound becomes 0)
-    }
-}
-
-void launch_join_weight32(const float *JC_unw, int Jp, int64_t Njc, int Dj, const double *wj, float *JW, int Jq,
-                          unsigned int *umax_bits, hipStream_t s)
-{
-    (void)hipMemsetAsync(umax_bits, 0, sizeof(unsigned int), s);
-    hipLaunchKernelGGL(join_weight32_kernel, dim3((unsigned)((Njc + 3) / 4)), dim3(256), 0, s, JC_unw, Jp, Njc, Dj, wj, JW, Jq,
-                       umax_bits);
-}
-
-int join_lb2_pitch(int Dj) { return (Dj + 15) & ~15; }
-
-// eight float32 values into two bf16 pieces each (packed pairs, v_cvt_pk_bf16_f32: round to nearest even)
-__device__ __forceinline__ void jf_split8(const float (&y)[8], u32x4 &hi, u32x4 &lo)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const jf_f32x2 v = {y[2 * j], y[2 * j + 1]};
-        const unsigned int hb = __builtin_bit_cast(unsigned int, __builtin_convertvector(v, jf_bf16x2));
-        const float h0 = __builtin_bit_cast(float, hb << 16), h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
-        const jf_f32x2 rest = {y[2 * j] - h0, y[2 * j + 1] - h1};      // exact
-        hi[j] = hb;
-        lo[j] = __builtin_bit_cast(unsigned int, __builtin_convertvector(rest, jf_bf16x2));
-    }
-}
-
-template <int KT>
-__global__ void __launch_bounds__(64 * KT, 2)
-join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned int *__restrict__ umax_bits, float ceps,
-                int64_t n_units, const int64_t *__restrict__ cand, int K, float *__restrict__ Jlo,
-                float *__restrict__ scale_out)
-{
-    __shared__ u32x4 Bs[2][KT][2][64];                        // [buffer][S tile][hi, lo][lane]
-    __shared__ float ne_s[32 * KT], ns_s[32 * KT], sne_s[32 * KT], sns_s[32 * KT];
-    __shared__ int smax_bits;
-    const int64_t r = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row32 = lane & 31, half = lane >> 5;
-    const int kk = wave * 32 + row32;
-    const int64_t idE = kk < K ? cand[r * K + kk] : -1;
-    const int64_t idS = kk < K ? cand[(r + 1) * K + kk] : -1;
-    const int64_t id0 = cand[(r + 1) * K];
-    const bool okE = jf_usable(idE, n_units), okS = jf_usable(idS, n_units);
-    const float *const pE = JW + (okE ? idE + 1 : 0) * (int64_t)Jq + 8 * half;      // unit_end_data[a]   = JC[a+1]
-    const float *const pS = JW + (okS ? idS : 0) * (int64_t)Jq + 8 * half;          // unit_start_data[b] = JC[b]
-    const float *const pM = JW + ((id0 >= 0 && id0 <= n_units) ? id0 : 0) * (int64_t)Jq + 8 * half;
-    if (tid == 0) smax_bits = 0;
-
-    constexpr int PF = (KT <= 4) ? 3 : 2;                     // k-blocks in flight
-    f32x4 rE[PF][2], rS[PF][2], rM[PF][2];
-    auto fetch = [&](int kb, f32x4 (&e)[2], f32x4 (&s)[2], f32x4 (&m)[2]) {
-        const int c = kb * 16;
-        e[0] = *reinterpret_cast<const f32x4 *>(pE + c); e[1] = *reinterpret_cast<const f32x4 *>(pE + c + 4);
-        s[0] = *reinterpret_cast<const f32x4 *>(pS + c); s[1] = *reinterpret_cast<const f32x4 *>(pS + c + 4);
-        m[0] = *reinterpret_cast<const f32x4 *>(pM + c); m[1] = *reinterpret_cast<const f32x4 *>(pM + c + 4);
-    };
-#pragma unroll
-    for (int p = 0; p < PF; ++p) fetch(p < n_kb ? p : n_kb - 1, rE[p], rS[p], rM[p]);
-
-    jf_f32x16 acc[KT];
-#pragma unroll
-    for (int j = 0; j < KT; ++j)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-    float ne = 0.f, ns = 0.f;
-    auto mfma = [](const u32x4 &a, const u32x4 &b, jf_f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jf_bf16x8, a), __builtin_bit_cast(jf_bf16x8, b), c, 0, 0, 0);
-    };
-
-    for (int kb0 = 0; kb0 < n_kb; kb0 += PF) {
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const int kb = kb0 + p;
-            if (kb >= n_kb) break;                            // uniform
-            float ye[8], ys[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ye[i] = rE[p][0][i] - rM[p][0][i]; ye[4 + i] = rE[p][1][i] - rM[p][1][i];
-                ys[i] = rS[p][0][i] - rM[p][0][i]; ys[4 + i] = rS[p][1][i] - rM[p][1][i];
-            }
-            if (kb + PF < n_kb) fetch(kb + PF, rE[p], rS[p], rM[p]);      // uniform
-            float te = ye[0] * ye[0], ts = ys[0] * ys[0];
-#pragma unroll
-            for (int i = 1; i < 8; ++i) { te = __builtin_fmaf(ye[i], ye[i], te); ts = __builtin_fmaf(ys[i], ys[i], ts); }
-            ne += te; ns += ts;
-            u32x4 he, le, hs, ls;
-            jf_split8(ye, he, le);
-            jf_split8(ys, hs, ls);
-            Bs[kb & 1][wave][0][lane] = hs;
-            Bs[kb & 1][wave][1][lane] = ls;
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < KT; ++j) {
-                const u32x4 bh = Bs[kb & 1][j][0][lane], bl = Bs[kb & 1][j][1][lane];
-                acc[j] = mfma(he, bl, acc[j]);
-                acc[j] = mfma(le, bh, acc[j]);
-                acc[j] = mfma(he, bh, acc[j]);
-            }
-        }
-    }
-    // row norms: the two lanes of a row hold the sums of its two column halves
-    ne += __shfl_xor(ne, 32, 64);
-    ns += __shfl_xor(ns, 32, 64);
-    if (half == 0) {
-        ne_s[kk] = okE ? ne : __builtin_inff();
-        ns_s[kk] = okS ? ns : __builtin_inff();
-        sne_s[kk] = okE ? __builtin_sqrtf(ne) : 0.f;
-        sns_s[kk] = okS ? __builtin_sqrtf(ns) : 0.f;
-        // scale of the step (margin of pass 2): the largest centred norm among the usable rows
-        const float big = fmaxf(okE ? ne : 0.f, okS ? ns : 0.f);
-        atomicMax(&smax_bits, __float_as_int(big));
-    }
-    __syncthreads();
-    const float umax2 = 2.f * __uint_as_float(*umax_bits);
-    const float c24 = 5.9604644775390625e-08f * 1.0001f;
-    float nev[16], sev[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int kp = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;       // row of the result = E row (crow32)
-        nev[i] = ne_s[kp];
-        sev[i] = sne_s[kp];
-    }
-    float *const out = Jlo + r * (int64_t)K * K;
-#pragma unroll
-    for (int j = 0; j < KT; ++j) {
-        const int k = j * 32 + row32;                           // column of the result = S row
-        const float nsv = ns_s[k], ssv = sns_s[k];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int kp = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-            const float sum = nev[i] + nsv;
-            const float c2 = sum - 2.f * acc[j][i];
-            const float lo2 = c2 - (ceps * sum + 1e-30f);
-            float clo = 0.f;                                     // NaN / overflow: 0 is a valid lower bound
-            if (lo2 > 0.f && lo2 < __builtin_inff()) {
-                const float v = __builtin_sqrtf(lo2) * (1.f - 4.76837158203125e-07f) - c24 * (umax2 + sev[i] + ssv);
-                clo = v > 0.f ? v : 0.f;
-            }
-            if (!(sum < __builtin_inff())) clo = (sum == __builtin_inff()) ? __builtin_inff() : 0.f;   // unusable unit: +inf
-            if (kp < K && k < K) out[(int64_t)kp * K + k] = clo;
-        }
-    }
-    if (tid == 0) scale_out[r] = __builtin_sqrtf(__int_as_float(smax_bits));
-}
-
-template <int KT>
-static void launch_join_lb2_t(const float *JW, int Jq, int n_kb, const unsigned int *umax_bits, float ceps, int64_t n_units,
-                              const int64_t *cand, int64_t R, int K, float *Jlo, float *scale, hipStream_t s)
-{
-    hipLaunchKernelGGL((join_lb2_kernel<KT>), dim3((unsigned)(R - 1)), dim3(64 * KT), 0, s, JW, Jq, n_kb, umax_bits, ceps, n_units,
-                       cand, K, Jlo, scale);
-}
-
-double join_lb2_ceps(int Dj)
-{
-    const double n_kb = (double)(join_lb2_pitch(Dj) / 16);
-    const double u24 = 5.9604644775390625e-08;
-    const double cg = 1.02 * (3.02 * 3.814697265625e-06 + (3.0 * n_kb + 1.0) * 9.5367431640625e-07);      // 2^-18, 2^-20
-    const double gam = (n_kb + 12.0) * u24;
-    return (gam + cg * (1.0 + gam) + 4.0 * u24) * 1.0001;
-}
-
-void launch_join_lb2(const float *JW, int Dj, const unsigned int *umax_bits, int64_t n_units, const int64_t *cand, int64_t R,
-                     int K, float *Jlo, float *scale, hipStream_t s)
-{
-    if (R < 2) return;
-    const int Jq = join_lb2_pitch(Dj), n_kb = Jq / 16;
-    const float ceps = (float)join_lb2_ceps(Dj);
-    const int kt = (K + 31) / 32;
-#define SNK_JLB2(KT_) launch_join_lb2_t<KT_>(JW, Jq, n_kb, umax_bits, ceps, n_units, cand, R, K, Jlo, scale, s)
-    switch (kt) {
-    case 1: SNK_JLB2(1); break;
-    case 2: SNK_JLB2(2); break;
-    case 3: SNK_JLB2(3); break;
-    case 4: SNK_JLB2(4); break;
-    case 5: SNK_JLB2(5); break;
-    case 6: SNK_JLB2(6); break;
-    default: SNK_JLB2(7); break;
-    }
-#undef SNK_JLB2
-}
+// (pass 1, second form -- bf16 matrix pipe over a weighted float32 copy of the join rows: joinlb2_kernels.hip)
 
 void launch_join_lb(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
                     int64_t R, int K, float *Jlo, float *scale, hipStream_t s)

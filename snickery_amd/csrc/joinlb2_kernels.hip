@@ -1,0 +1,300 @@
+// Pass 1 of the sparse Viterbi path (joinfast_kernels.hip), second form -- the default, option join_lb_variant 1:
+// proven float32 lower bounds of the join costs
+//   make_on_the_fly_join_lattice_BLOCK_DIRECT / get_natural_distance_vectorised (script/synth_halfphone.py:3206-3322, :2942-2951)
+// from a float32 copy of the WEIGHTED join rows (join_weight32_kernel, built once per set of weights: (N + 1) x Jq floats,
+// padding columns 0) on the bf16 matrix pipe.  What the first form (join_lb_kernel) spends per gathered element -- a float64
+// multiply by the weight, a float64 subtraction, two conversions, on the vector unit, beside float32 MFMAs that issue at
+// 1/16 of the bf16 rate -- becomes one float32 subtraction and a split into two bf16 pieces.
+//
+//   u~ = fl32(u), u = fl64(x w) the canonical weighted value;   y = fl32(u~ - m~), m~ = u~ of the step's reference row
+//   (the start vector of the first candidate of row r + 1: any row of the matrix would do);   y = h + l + rr,
+//   h = bf16(y), l = bf16(y - h) (round to nearest even, v_cvt_pk_bf16_f32: |l| <= 2^-9 (1 + 2^-8) |y|, |rr| <= 2^-18 |y|);
+//   G~ = Ghh + Gx,  Ghh = sum over the k-blocks of 16 columns of he.hs,  Gx = sum of he.ls + le.hs
+//   (v_mfma_f32_32x32x16_bf16, float32 accumulation; with K <= 128 the two sums have accumulators of their own, so the
+//   long chain -- the one whose running sum is of the size of the products -- is n_kb MFMAs, not 3 n_kb);
+//   ne~, ns~ = float32 sums of squares of ye, ys (8-term chains per k-block, the k-blocks added in order).
+// Bound.  (i) representation:  || (ye - ys) - (ue - us) || <= eta := 2^-24 (||ue|| + ||us||) + 2^-24 (1 + 2^-23)(||ye|| + ||ys||)
+//   (the two roundings of every element; m~ cancels), so c = ||ue - us|| >= ||ye - ys|| - eta, with ||u|| <= Umax, the largest
+//   row norm of the copy (measured when it is built).  (ii) || ye - ys ||^2 = ne + ns - 2 ye.ys against c2~ = ne~ + ns~ - 2 G~:
+//     |G~ - ye.ys| <= cG ||ye|| ||ys||,  cG = 1.02 [ 3.02 2^-18   (what the split drops: le.ls + rre.ys + (he + le).rrs)
+//                      + (n_kb + 1) 2^-20 + (2 n_kb + 1) 2^-28 + 2^-24   (two accumulator sets: every MFMA off by at most
+//                        2^-20 of its |products| + |C| -- the probed property of this instruction, knn16_kernels.hip /
+//                        snk_probe_mfma_bf16 --, the cross terms' sums are 2^-8 of the product of the norms; one float32 addition)
+//                      or (3 n_kb + 1) 2^-20   (one set, K > 128) ],
+//     ||ye|| ||ys|| <= (ne + ns) / 2,   |ne~ - ne| <= (n_kb + 12) 2^-24 ne,   four float32 operations in the epilogue,
+//   together e2 = ceps (ne~ + ns~), ceps from join_lb2_ceps: 3.4e-5 at 302 columns with two sets (7.1e-5 with one; the first
+//   form's 2.2 (D + 6) 2^-24 is 4.1e-5 there).  clo = sqrt(max(c2~ - e2, 0)) (1 - 2^-21) - eta (1 + 1e-4), clamped at 0
+//   (v_sqrt_f32, 1 ulp: the factor leaves 8).
+// One workgroup per row pair; KT = ceil(K / 32) wavefronts; wavefront w keeps the pieces of its 32 E rows in registers (the A
+// operand: lane l <-> row l & 31, columns 16 kb + 8 (l >> 5) + 0..7) and stages those of its 32 S rows in LDS for everybody
+// (fragment order, double buffered, one barrier per k-block).  The rows of the next PF k-blocks are in flight in registers
+// (16-byte loads; a row's 64 bytes of a k-block are two lanes' 32 bytes each); the reference row sits in LDS.
+#include "snk_internal.h"
+#include <float.h>
+
+namespace snk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 jf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 jf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float jf_f32x2 __attribute__((ext_vector_type(2)));
+typedef float jf_f32x16 __attribute__((ext_vector_type(16)));
+#define JF2_MAXD 1024          // join columns (padded to 16) the reference row in LDS holds
+
+__device__ __forceinline__ bool jf2_usable(int64_t id, int64_t n_units)
+{
+    return id >= 1 && id < n_units - 1;        // synth_halfphone.py:3238-3268
+}
+
+__global__ void __launch_bounds__(256)
+join_weight32_kernel(const float *__restrict__ JC_unw, int Jp, int64_t Njc, int Dj, const double *__restrict__ wj,
+                     float *__restrict__ JW, int Jq, unsigned int *__restrict__ umax_bits)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Njc) return;
+    double n2 = 0.0;
+    for (int c = lane; c < Jq; c += 64) {
+        const float v = c < Dj ? (float)__dmul_rn((double)JC_unw[row * Jp + c], wj[c]) : 0.f;
+        JW[row * Jq + c] = v;
+        n2 += (double)v * (double)v;
+    }
+#pragma unroll
+    for (int m = 1; m <= 32; m <<= 1) n2 += __shfl_xor(n2, m, 64);
+    if (lane == 0) {
+        const float nf = (float)sqrt(n2) * 1.000001f;          // rounded up; non-negative floats order like their bit patterns
+        atomicMax(umax_bits, nf == nf ? __float_as_uint(nf) : 0x7f800000u);      // NaN: +inf (every bound becomes 0)
+    }
+}
+
+void launch_join_weight32(const float *JC_unw, int Jp, int64_t Njc, int Dj, const double *wj, float *JW, int Jq,
+                          unsigned int *umax_bits, hipStream_t s)
+{
+    (void)hipMemsetAsync(umax_bits, 0, sizeof(unsigned int), s);
+    hipLaunchKernelGGL(join_weight32_kernel, dim3((unsigned)((Njc + 3) / 4)), dim3(256), 0, s, JC_unw, Jp, Njc, Dj, wj, JW, Jq,
+                       umax_bits);
+}
+
+int join_lb2_pitch(int Dj) { return (Dj + 15) & ~15; }
+bool join_lb2_supported(int Dj, int K) { return join_lb2_pitch(Dj) <= JF2_MAXD && K >= 1 && K <= 208; }
+
+// one pair of float32 values into two bf16 pieces each (v_cvt_pk_bf16_f32: round to nearest even); the pair's share of the
+// row's sum of squares is added to n2 (lane-wise: even and odd columns have chains of their own)
+__device__ __forceinline__ void jf_split2(jf_f32x2 y, unsigned int &hi, unsigned int &lo, jf_f32x2 &n2)
+{
+    n2 = __builtin_elementwise_fma(y, y, n2);
+    const unsigned int hb = __builtin_bit_cast(unsigned int, __builtin_convertvector(y, jf_bf16x2));
+    const jf_f32x2 hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+    hi = hb;
+    lo = __builtin_bit_cast(unsigned int, __builtin_convertvector(y - hf, jf_bf16x2));      // y - hf is exact
+}
+
+template <int KT>
+__global__ void __launch_bounds__(64 * KT, 2)
+join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned int *__restrict__ umax_bits, float ceps,
+                int64_t n_units, const int64_t *__restrict__ cand, int K, float *__restrict__ Jlo,
+                float *__restrict__ scale_out)
+{
+    constexpr bool TWO = KT <= 4;                             // accumulators of their own for the cross terms
+    constexpr int PF = (KT <= 3) ? 3 : 2;                     // k-blocks in flight
+    __shared__ u32x4 Bs[2][KT][2][64];                        // [buffer][S tile][hi, lo][lane]
+    __shared__ __align__(16) float m_s[JF2_MAXD];
+    __shared__ float ne_s[32 * KT], ns_s[32 * KT], sne_s[32 * KT], sns_s[32 * KT], pen_s[32 * KT], pns_s[32 * KT];
+    __shared__ int smax_bits;
+    const int64_t r = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row32 = lane & 31, half = lane >> 5;
+    const int kk = wave * 32 + row32;
+    const int64_t idE = kk < K ? cand[r * K + kk] : -1;
+    const int64_t idS = kk < K ? cand[(r + 1) * K + kk] : -1;
+    const int64_t id0 = cand[(r + 1) * K];
+    const bool okE = jf2_usable(idE, n_units), okS = jf2_usable(idS, n_units);
+    const float *const pE = JW + (okE ? idE + 1 : 0) * (int64_t)Jq + 8 * half;      // unit_end_data[a]   = JC[a+1]
+    const float *const pS = JW + (okS ? idS : 0) * (int64_t)Jq + 8 * half;          // unit_start_data[b] = JC[b]
+    const int DC = n_kb * 16;
+
+    f32x4 rE[PF][2], rS[PF][2];
+    auto fetch = [&](int kb, f32x4 (&e)[2], f32x4 (&s)[2]) {
+        const int c = kb * 16;
+        e[0] = *reinterpret_cast<const f32x4 *>(pE + c); e[1] = *reinterpret_cast<const f32x4 *>(pE + c + 4);
+        s[0] = *reinterpret_cast<const f32x4 *>(pS + c); s[1] = *reinterpret_cast<const f32x4 *>(pS + c + 4);
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) fetch(p < n_kb ? p : n_kb - 1, rE[p], rS[p]);
+    {
+        const float *const row0 = JW + ((id0 >= 0 && id0 <= n_units) ? id0 : 0) * (int64_t)Jq;
+        for (int c = tid; c < DC; c += 64 * KT) m_s[c] = row0[c];
+    }
+    if (tid == 0) smax_bits = 0;
+
+    jf_f32x16 acc[KT], accx[TWO ? KT : 1];
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[j][i] = 0.f; if (TWO) accx[j][i] = 0.f; }
+    float ne = 0.f, ns = 0.f;
+    auto mfma = [](const u32x4 &a, const u32x4 &b, jf_f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jf_bf16x8, a), __builtin_bit_cast(jf_bf16x8, b), c, 0, 0, 0);
+    };
+    __syncthreads();                                          // the reference row is in LDS
+
+    // one k-block: rows out of the ring slot, the slot refilled with the k-block `next` (the caller clamps it: a clamped
+    // re-load is never consumed), pieces, this wavefront's S pieces to LDS, barrier, 3 KT MFMAs
+    auto block = [&](int kb, int next, f32x4 (&e)[2], f32x4 (&s)[2]) {
+        const f32x4 m0 = *reinterpret_cast<const f32x4 *>(&m_s[kb * 16 + 8 * half]);
+        const f32x4 m1 = *reinterpret_cast<const f32x4 *>(&m_s[kb * 16 + 8 * half + 4]);
+        // (explicit pairs: left to itself the vectoriser pairs E with S elements and pays for it in register moves)
+        jf_f32x2 ye[4], ys[4];
+        ye[0] = __builtin_shufflevector(e[0], e[0], 0, 1) - __builtin_shufflevector(m0, m0, 0, 1);
+        ye[1] = __builtin_shufflevector(e[0], e[0], 2, 3) - __builtin_shufflevector(m0, m0, 2, 3);
+        ye[2] = __builtin_shufflevector(e[1], e[1], 0, 1) - __builtin_shufflevector(m1, m1, 0, 1);
+        ye[3] = __builtin_shufflevector(e[1], e[1], 2, 3) - __builtin_shufflevector(m1, m1, 2, 3);
+        ys[0] = __builtin_shufflevector(s[0], s[0], 0, 1) - __builtin_shufflevector(m0, m0, 0, 1);
+        ys[1] = __builtin_shufflevector(s[0], s[0], 2, 3) - __builtin_shufflevector(m0, m0, 2, 3);
+        ys[2] = __builtin_shufflevector(s[1], s[1], 0, 1) - __builtin_shufflevector(m1, m1, 0, 1);
+        ys[3] = __builtin_shufflevector(s[1], s[1], 2, 3) - __builtin_shufflevector(m1, m1, 2, 3);
+        if (next >= 0) fetch(next, e, s);                     // (a compile-time decision at every call site)
+        jf_f32x2 te = {0.f, 0.f}, ts = {0.f, 0.f};
+        u32x4 he, le, hs, ls;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned int a, b, c, d;
+            jf_split2(ye[j], a, b, te); jf_split2(ys[j], c, d, ts);
+            he[j] = a; le[j] = b; hs[j] = c; ls[j] = d;
+        }
+        ne += te[0] + te[1]; ns += ts[0] + ts[1];
+        Bs[kb & 1][wave][0][lane] = hs;
+        Bs[kb & 1][wave][1][lane] = ls;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            const u32x4 bh = Bs[kb & 1][j][0][lane], bl = Bs[kb & 1][j][1][lane];
+            if (TWO) {
+                accx[j] = mfma(he, bl, accx[j]);
+                accx[j] = mfma(le, bh, accx[j]);
+            } else {
+                acc[j] = mfma(he, bl, acc[j]);
+                acc[j] = mfma(le, bh, acc[j]);
+            }
+            acc[j] = mfma(he, bh, acc[j]);
+        }
+    };
+    int kb = 0;
+    for (; kb + PF <= n_kb; kb += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int nx = kb + p + PF;
+            block(kb + p, nx < n_kb ? nx : n_kb - 1, rE[p], rS[p]);
+        }
+    }
+    if (kb < n_kb) {                                          // the last n_kb % PF k-blocks: nothing left to fetch
+        block(kb, -1, rE[0], rS[0]);
+        if (PF > 2 && kb + 1 < n_kb) block(kb + 1, -1, rE[1], rS[1]);
+    }
+    // row norms: the two lanes of a row hold the sums of its two column halves
+    ne += __shfl_xor(ne, 32, 64);
+    ns += __shfl_xor(ns, 32, 64);
+    if (half == 0) {
+        ne_s[kk] = ne;
+        ns_s[kk] = ns;
+        sne_s[kk] = __builtin_amdgcn_sqrtf(ne) * 1.000001f;
+        sns_s[kk] = __builtin_amdgcn_sqrtf(ns) * 1.000001f;
+        pen_s[kk] = okE ? 0.f : __builtin_inff();             // an unusable unit: every cell of its row / column is +inf
+        pns_s[kk] = okS ? 0.f : __builtin_inff();
+        // scale of the step (margin of pass 2): the largest centred norm among the usable rows
+        const float big = fmaxf(okE ? ne : 0.f, okS ? ns : 0.f);
+        atomicMax(&smax_bits, __float_as_int(big));
+    }
+    __syncthreads();
+    // ---- epilogue, branch-free: 16 KT cells per lane; stores through a buffer descriptor of the step's K x K slab (the row
+    // part of the address in the scalar offset, a lane whose column lies beyond K points out of range and is dropped).
+    // Overflowed float32 norms end as NaN or -inf under the maxima (v_max returns the other operand for a NaN): bound 0.
+    const float umax2 = 2.f * __uint_as_float(*umax_bits);
+    const float c24 = 5.9604644775390625e-08f * 1.0001f;
+    float nev[16], sev[16], pev[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int kp = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;       // row of the result = E row (crow32)
+        nev[i] = ne_s[kp];
+        sev[i] = sne_s[kp] + umax2;
+        pev[i] = pen_s[kp];
+    }
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(Jlo + r * (int64_t)K * K, 0, K * K * 4, 0x00020000);
+    auto cell = [&](int j, int i, float nsv, float ssv, float psv) {
+        const float sum = nev[i] + nsv;
+        const float g = TWO ? acc[j][i] + accx[j][i] : acc[j][i];
+        const float c2 = __builtin_fmaf(-2.f, g, sum);                       // (2 g is exact: one rounding)
+        const float lo2 = __builtin_fmaf(-ceps, sum, c2) - 1e-30f;
+        const float sq = __builtin_amdgcn_sqrtf(__builtin_fmaxf(lo2, 0.f)) * (1.f - 4.76837158203125e-07f);
+        const float clo = __builtin_fmaxf(__builtin_fmaf(-c24, sev[i] + ssv, sq), 0.f);
+        return __builtin_fmaxf(__builtin_fmaxf(clo, pev[i]), psv);           // an unusable unit on either side: +inf
+    };
+    if (wave * 32 + 32 <= K) {                                // uniform: every row of this wavefront's tile exists
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            const int k = j * 32 + row32;                       // column of the result = S row
+            const float nsv = ns_s[k], ssv = sns_s[k], psv = pns_s[k];
+            const int voff = k < K ? ((wave * 32 + 4 * half) * K + k) * 4 : 0x7ffffffc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, cell(j, i, nsv, ssv, psv)), ores, voff,
+                                                      ((i & 3) + 8 * (i >> 2)) * K * 4, 0);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            const int k = j * 32 + row32;
+            const float nsv = ns_s[k], ssv = sns_s[k], psv = pns_s[k];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kp = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, cell(j, i, nsv, ssv, psv)), ores,
+                                                      (kp < K && k < K) ? (kp * K + k) * 4 : 0x7ffffffc, 0, 0);
+            }
+        }
+    }
+    if (tid == 0) scale_out[r] = __builtin_amdgcn_sqrtf(__int_as_float(smax_bits)) * 1.000001f;
+}
+
+template <int KT>
+static void launch_join_lb2_t(const float *JW, int Jq, int n_kb, const unsigned int *umax_bits, float ceps, int64_t n_units,
+                              const int64_t *cand, int64_t R, int K, float *Jlo, float *scale, hipStream_t s)
+{
+    hipLaunchKernelGGL((join_lb2_kernel<KT>), dim3((unsigned)(R - 1)), dim3(64 * KT), 0, s, JW, Jq, n_kb, umax_bits, ceps, n_units,
+                       cand, K, Jlo, scale);
+}
+
+double join_lb2_ceps(int Dj, int K)
+{
+    const double n_kb = (double)(join_lb2_pitch(Dj) / 16);
+    const double u24 = 5.9604644775390625e-08, u20 = 9.5367431640625e-07, u18 = 3.814697265625e-06;
+    const bool two = (K + 31) / 32 <= 4;
+    const double acc = two ? (n_kb + 1.0) * u20 + (2.0 * n_kb + 1.0) * u20 / 256.0 + u24 : (3.0 * n_kb + 1.0) * u20;
+    const double cg = 1.02 * (3.02 * u18 + acc);
+    const double gam = (n_kb + 12.0) * u24;
+    return (gam + cg * (1.0 + gam) + 4.0 * u24) * 1.0001;
+}
+
+void launch_join_lb2(const float *JW, int Dj, const unsigned int *umax_bits, int64_t n_units, const int64_t *cand, int64_t R,
+                     int K, float *Jlo, float *scale, hipStream_t s)
+{
+    if (R < 2) return;
+    const int Jq = join_lb2_pitch(Dj), n_kb = Jq / 16;
+    const float ceps = (float)join_lb2_ceps(Dj, K);
+    const int kt = (K + 31) / 32;
+#define SNK_JLB2(KT_) launch_join_lb2_t<KT_>(JW, Jq, n_kb, umax_bits, ceps, n_units, cand, R, K, Jlo, scale, s)
+    switch (kt) {
+    case 1: SNK_JLB2(1); break;
+    case 2: SNK_JLB2(2); break;
+    case 3: SNK_JLB2(3); break;
+    case 4: SNK_JLB2(4); break;
+    case 5: SNK_JLB2(5); break;
+    case 6: SNK_JLB2(6); break;
+    default: SNK_JLB2(7); break;
+    }
+#undef SNK_JLB2
+}
+
+}  // namespace snk

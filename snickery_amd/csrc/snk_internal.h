@@ -188,7 +188,8 @@ void launch_join_lb(const float *JC_unw, int Jp, int Dj, const double *wj, int64
                     int64_t R, int K, float *Jlo, float *scale, hipStream_t s);
 // second form of pass 1: bf16 matrix pipe over a float32 copy of the weighted join rows (built once per set of weights)
 int join_lb2_pitch(int Dj);
-double join_lb2_ceps(int Dj);
+double join_lb2_ceps(int Dj, int K);
+bool join_lb2_supported(int Dj, int K);
 void launch_join_weight32(const float *JC_unw, int Jp, int64_t Njc, int Dj, const double *wj, float *JW, int Jq,
                           unsigned int *umax_bits, hipStream_t s);
 void launch_join_lb2(const float *JW, int Dj, const unsigned int *umax_bits, int64_t n_units, const int64_t *cand, int64_t R,
