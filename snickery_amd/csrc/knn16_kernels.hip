@@ -1460,6 +1460,185 @@ bool launch_knn_balls16b(int terms, int dch, int grid_cus, const void *C16, cons
     return true;
 }
 
+// ===========================================================================================================
+// Stage A' of the thresholds: an upper bound of the K-th nearest key from the tiles' balls (no reference counterpart: the
+// reference's KD-tree needs no threshold, script/synth_halfphone.py:1364).  Every unit f of a FULL tile (32 units, centre c,
+// radius r) has  key(f) = ||q - f||^2 - ||q||^2 <= (||q - c|| + r)^2 - ||q||^2 =: U(tile, q),  so the kk-th smallest U over
+// kk = ceil(K / 32) distinct tiles bounds the K-th nearest key of the database from above -- where the tiles are compact
+// (consecutive frames of speech) by little more than the K-th key itself, while stage A's bound from a 1/16 sample lets
+// about sixteen times K units through.  The centres' keys are the ball pass's (same operands, MFMA order and bound eps):
+//        ||q - c||^2 <= key~(c) + eps + ||q||^2 =: d2,     U = (sqrt(d2) + r)^2 - ||q||^2      (rounded up)
+// Query-stationary: a wavefront keeps one query tile's operand and walks a range of centre tiles; lane (query row, half)
+// keeps the minimum of U per result register, i.e. per tile position mod 32 -- the tiles of one minimum are 32 tiles apart,
+// so neighbouring tiles (where the neighbours of a frame cluster) fall into different groups and the kk smallest group
+// minima are kk distinct, typically the kk best, tiles.  gminb: [row][csplit * 32] group minima.
+// ===========================================================================================================
+__global__ void ballmin_query_terms_kernel(const double *__restrict__ eps, const double *__restrict__ qnorm, int64_t T, int64_t T32,
+                                           float *__restrict__ aq, float *__restrict__ nql)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= T32) return;
+    float a = 0.f, n = 0.f;
+    if (row < T) {
+        const double ad = eps[row] + qnorm[row];
+        a = (float)ad;
+        if ((double)a < ad) a = nextafterf(a, FLT_MAX);
+        n = (float)qnorm[row];
+        if ((double)n > qnorm[row]) n = nextafterf(n, -FLT_MAX);
+    }
+    aq[row] = a; nql[row] = n;
+}
+
+template <int KB, int TERMS>
+__global__ void __launch_bounds__(256, 2)
+knn_ballmin16b(const u32x4 *__restrict__ C16, const u32x4 *__restrict__ B16, const float *__restrict__ rad, const float *__restrict__ aq,
+               const float *__restrict__ nql, int nQT, int64_t n_full_tiles, int64_t n_ctiles, int csplit, float *__restrict__ gminb)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int qcol = lane & 31;
+    auto mfma = [](const u32x4 &a, const u32x4 &b, f16acc c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+    const int64_t n_items = (int64_t)nQT * csplit;
+    const int Gb = csplit * 32;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + wv; item < n_items; item += (int64_t)gridDim.x * 4) {
+        const int qt = (int)(item / csplit), part = (int)(item % csplit);
+        const int64_t c_lo = (n_ctiles * part) / csplit, c_hi = (n_ctiles * (part + 1)) / csplit;
+        u32x4 b[KB][2];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) b[kb][pc] = B16[(((int64_t)qt * KB + kb) * 2 + pc) * 64 + lane];
+        const float aqv = aq[qt * 32 + qcol], nlv = nql[qt * 32 + qcol];
+        float mn[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mn[r] = FLT_MAX;
+        u32x4 a0[KB][2], a1[KB][2];
+        float rv0[16], rv1[16];
+        auto load_c = [&](int64_t ct, u32x4 (&a)[KB][2], float (&rv)[16]) {
+            const int64_t cc = ct < c_hi ? ct : c_hi - 1;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) a[kb][pc] = C16[((cc * KB + kb) * 2 + pc) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t t = cc * 32 + crow32(lane, r);
+                rv[r] = t < n_full_tiles ? rad[t] : -1.f;       // a partial (or no) tile does not count 32 units
+            }
+        };
+        auto work = [&](const u32x4 (&a)[KB][2], const float (&rv)[16]) {
+            // the ball pass's chain: per k-block hi.hi, hi(centre).lo(query), lo(centre).hi(query) [, lo.lo]; chains of one
+            // 64-column chunk, the chunks' sums added in float32 (the key bound eps is for this order)
+            constexpr int CM = 4 * TERMS, NM = TERMS * KB;
+            f16acc acc, part_;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int kb = m / TERMS, term = m % TERMS;
+                const u32x4 &av = (term & 2) ? a[kb][1] : a[kb][0];
+                const u32x4 &bv = (term & 1) ? b[kb][1] : b[kb][0];
+                if (m % CM == 0) {
+                    f16acc z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                    part_ = mfma(av, bv, z);
+                } else part_ = mfma(av, bv, part_);
+                if (m % CM == CM - 1 || m == NM - 1) {
+                    if (m < CM) acc = part_;
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] += part_[r];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // U rounded up: the addition, the square root (v_sqrt_f32, 1 ulp) and s each within 2^-23; the last two
+                // float32 operations inside the relative 2^-21 of both terms
+                const float d2 = __builtin_fmaxf(acc[r] + aqv, 0.f);
+                const float sr = __builtin_amdgcn_sqrtf(d2) * 1.0000005f + rv[r];
+                const float u = __builtin_fmaf(sr, sr, -nlv) + (4.76837158203125e-07f * (sr * sr + __builtin_fabsf(nlv)) + 1e-30f);
+                const float v = rv[r] >= 0.f ? u : FLT_MAX;
+                mn[r] = __builtin_fminf(mn[r], v == v ? v : FLT_MAX);
+            }
+        };
+        load_c(c_lo, a0, rv0);
+        for (int64_t ct = c_lo; ct < c_hi; ct += 2) {
+            load_c(ct + 1, a1, rv1);
+            work(a0, rv0);
+            if (ct + 1 < c_hi) {
+                load_c(ct + 2, a0, rv0);
+                work(a1, rv1);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gminb[((int64_t)qt * 32 + qcol) * Gb + part * 32 + crow32(lane, r)] = mn[r];
+    }
+}
+
+int knn_ballmin_groups(int64_t T32, int64_t n_tiles)
+{
+    const int nQT = (int)(T32 / 32);
+    const int64_t n_ctiles = (n_tiles + 31) / 32;
+    int csplit = 1;
+    while ((int64_t)nQT * csplit < 2048 && csplit < 8 && 2 * csplit <= n_ctiles) csplit *= 2;
+    return csplit * 32;
+}
+
+bool launch_knn_ballmin16b(int terms, int dch, int grid_cus, const void *C16, const void *B16, const float *rad, const double *eps,
+                           const double *qnorm, int64_t T, int64_t T32, int64_t n_tiles, int64_t n_units, float *aq, float *nql,
+                           float *gminb, hipStream_t s)
+{
+    const int nQT = (int)(T32 / 32);
+    const int64_t n_ctiles = (n_tiles + 31) / 32;
+    const int csplit = knn_ballmin_groups(T32, n_tiles) / 32;
+    hipLaunchKernelGGL(ballmin_query_terms_kernel, dim3((unsigned)((T32 + 255) / 256)), dim3(256), 0, s, eps, qnorm, T, T32, aq, nql);
+    int64_t blocks = ((int64_t)nQT * csplit + 3) / 4;
+    if (blocks > 2 * (int64_t)grid_cus) blocks = 2 * (int64_t)grid_cus;
+#define SNK_BM16(KB_, TERMS_)                                                                                        \
+    hipLaunchKernelGGL((knn_ballmin16b<KB_, TERMS_>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)C16,   \
+                       (const u32x4 *)B16, rad, aq, nql, nQT, n_units / 32, n_ctiles, csplit, gminb)
+    if (dch == 1) { if (terms == 4) SNK_BM16(4, 4); else SNK_BM16(4, 3); }
+    else if (dch == 2) { if (terms == 4) SNK_BM16(8, 4); else SNK_BM16(8, 3); }
+    else if (dch == 3) { if (terms == 4) SNK_BM16(12, 4); else SNK_BM16(12, 3); }
+    else return false;
+#undef SNK_BM16
+    return true;
+}
+
+// kk-th smallest of a row's Gb group minima (one wavefront per row; kk <= 7): the ball bound of the row, +DBL_MAX when
+// fewer than kk groups hold a full tile
+__global__ void __launch_bounds__(256)
+knn_ball_bound_kernel(const float *__restrict__ gminb, int Gb, int64_t T, int kk, double *__restrict__ ballb)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (lane + 64 * i < Gb) ? gminb[row * Gb + lane + 64 * i] : FLT_MAX;
+    float kth = FLT_MAX;
+    for (int it = 0; it < kk; ++it) {
+        float m = __builtin_fminf(__builtin_fminf(v[0], v[1]), __builtin_fminf(v[2], v[3]));
+#pragma unroll
+        for (int o = 1; o <= 32; o <<= 1) m = __builtin_fminf(m, __shfl_xor(m, o, 64));
+        kth = m;
+        // one instance of the minimum leaves: the lowest lane that holds it, its first slot
+        const unsigned long long has = __ballot(v[0] == m || v[1] == m || v[2] == m || v[3] == m);
+        if (has && lane == __builtin_ctzll(has)) {
+            if (v[0] == m) v[0] = FLT_MAX; else if (v[1] == m) v[1] = FLT_MAX; else if (v[2] == m) v[2] = FLT_MAX; else v[3] = FLT_MAX;
+        }
+    }
+    if (lane == 0) ballb[row] = kth < FLT_MAX ? (double)kth : DBL_MAX;
+}
+
+void launch_knn_ball_bound(const float *gminb, int Gb, int64_t T, int K, double *ballb, hipStream_t s)
+{
+    const int kk = (K + 31) / 32;
+    hipLaunchKernelGGL(knn_ball_bound_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, s, gminb, Gb, T, kk, ballb);
+}
+
 bool knn_coarse16b_supported(int nt, int dch) { return (nt == 4 && dch == 1) || (nt == 2 && dch == 2) || (nt == 1 && dch == 3); }
 size_t knn_coarse_pair_bytes() { return sizeof(CoarsePair); }
 
@@ -1511,7 +1690,7 @@ __global__ void __launch_bounds__(256)
 knn_threshold16_kernel(const float *__restrict__ gmin32, int64_t G, int64_t T, int64_t T32, int K,
                        const double *__restrict__ eps, double *__restrict__ thr, float *__restrict__ thr32,
                        const double *__restrict__ bound_in, double *__restrict__ bound_out,
-                       const double *__restrict__ e1, float *__restrict__ thr1)
+                       const double *__restrict__ e1, float *__restrict__ thr1, const double *__restrict__ bound2)
 {
     extern __shared__ float tkey[];
     const int64_t row = blockIdx.x;
@@ -1582,6 +1761,8 @@ knn_threshold16_kernel(const float *__restrict__ gmin32, int64_t G, int64_t T, i
         // group minima are approximate: + eps makes the K-th smallest a true upper bound
         if (G >= K && P >= K && tkey[K - 1] < FLT_MAX) bound = (double)tkey[K - 1] + eps[row];
     }
+    // a second upper bound of the K-th nearest key (the tiles' balls, stage A'): the smaller one serves
+    if (bound2 && bound2[row] < bound) bound = bound2[row];
     if (threadIdx.x == 0) {
         double v = DBL_MAX;
         float v32 = FLT_MAX;
@@ -1609,12 +1790,12 @@ knn_threshold16_kernel(const float *__restrict__ gmin32, int64_t G, int64_t T, i
 
 void launch_knn_threshold16(const float *gmin32, int64_t G, int64_t T, int64_t T32, int K, const double *eps,
                             double *thr, float *thr32, const double *bound_in, double *bound_out, hipStream_t s,
-                            const double *e1, float *thr1)
+                            const double *e1, float *thr1, const double *bound2)
 {
     int P = 2;
     while (P < G && P < THR16_GROUPS) P <<= 1;
     hipLaunchKernelGGL(knn_threshold16_kernel, dim3((unsigned)T32), dim3(256), (size_t)P * sizeof(float), s,
-                       gmin32, G, T, T32, K, eps, thr, thr32, bound_in, bound_out, e1, thr1);
+                       gmin32, G, T, T32, K, eps, thr, thr32, bound_in, bound_out, e1, thr1, bound2);
 }
 
 // ---------------------------------------------------------------------------

@@ -47,12 +47,12 @@ static int fail(const char *fmt, ...)
 enum TimerId {
     TM_H2D = 0, TM_PREP, TM_KNN_MINIMA, TM_KNN_THRESHOLD, TM_KNN_FILTER, TM_KNN_BUCKET, TM_KNN_FINALIZE,
     TM_JOIN, TM_VITERBI_DP, TM_D2H, TM_GREEDY_TARGET, TM_GREEDY_STEPS, TM_WEIGHTS, TM_MERGE, TM_JOIN_LB, TM_DP_LB,
-    TM_JOIN_SPARSE, TM_DP_SPARSE, TM_COUNT
+    TM_JOIN_SPARSE, TM_DP_SPARSE, TM_KNN_BALLMIN, TM_COUNT
 };
 static const char *kTimerNames[TM_COUNT] = {
     "h2d_queries", "prepare_queries", "knn_minima", "knn_threshold", "knn_filter", "knn_bucket", "knn_finalize",
     "join_costs", "viterbi_dp", "d2h_results", "greedy_target_gemm", "greedy_steps", "set_weights",
-    "merge_topk", "join_lower_bounds", "viterbi_lower_bound", "join_exact_sparse", "viterbi_sparse"};
+    "merge_topk", "join_lower_bounds", "viterbi_lower_bound", "join_exact_sparse", "viterbi_sparse", "knn_ball_bound"};
 
 // Debug allocator (environment SNK_GUARD=1|2|3, read once): every device buffer gets its own virtual range with an
 // unmapped page after it (1: the buffer ends where the mapping ends, an over-read or over-write of even one 16-byte
@@ -253,6 +253,8 @@ struct snk_engine {
     double eps_c_bf = 4e-6;       // accumulation part of the bound of the bf16-split keys (knn16_kernels.hip: c_acc)
     DevBuf kth16;                 // sharded search: per-row second bound (K-th key of the local list, all-reduced)
     DevBuf ball_c, ball_cn, ball_rad, ball_c16, ball_tq, ball_nq;   // pass 0: tile centres (float64, norms, radii, bf16-split operand), per-row terms
+    DevBuf ball_aq, ball_nql, ball_gmin, ball_bound;                // stage A': per-row terms, group minima of the tiles' upper bounds, the row's bound
+    int prefilter_ball_bound = 1; // 1: the thresholds also take the upper bound the tiles' balls give (stage A'; where the ball pass runs)
     int prefilter_balls = 1;      // 1: the tiles' balls list the pairs first; the coarse sweep runs only where they list too many
     double coarse_gate_fraction = 0.10;
     int64_t ball_tiles = 0;       // valid tiles of the ball operand (0: not built)
@@ -601,7 +603,8 @@ int snk_destroy(snk_handle h)
     h->frames_spec.release(); h->frames_fzv.release(); h->cc_in.release(); h->cc_out.release();
     h->res_status.release(); h->hstage.release(); h->up.release();
     { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b, &h->cq16, &h->rho16, &h->gs_rho16, &h->kth16, &h->margin_stat, &h->e1_16, &h->thr1_32, &h->cpairs, &h->cpairctl,
-                      &h->ball_c, &h->ball_cn, &h->ball_rad, &h->ball_c16, &h->ball_tq, &h->ball_nq};
+                      &h->ball_c, &h->ball_cn, &h->ball_rad, &h->ball_c16, &h->ball_tq, &h->ball_nq,
+                      &h->ball_aq, &h->ball_nql, &h->ball_gmin, &h->ball_bound};
       for (auto *b : fb) b->release(); }
     for (int i = 0; i < 8; ++i) {
         UttSlot &s = h->slot[i];
@@ -1175,17 +1178,31 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
                                nullptr, Tpad, n_slabs_a, h->slabctr.as<unsigned int>(), h->gmin32.as<float>(),
                                G16, nullptr, nullptr, nullptr, 0, knn_pool_chunk_entries(), s);
         }
+        // stage A': where the ball pass is going to list the tile pairs, the balls also bound the K-th nearest key
+        const bool balls = coarse && h->prefilter_balls && h->ball_tiles > 0 && slab_factor == 1 && !h->filter_coarse;
+        const bool ball_bound = balls && h->prefilter_ball_bound && !bound_in && h->N / 32 >= (K + 31) / 32;
+        if (ball_bound) {
+            StageTimer t(h, s, TM_KNN_BALLMIN);
+            const int Gb = knn_ballmin_groups(Tpad, h->ball_tiles);
+            CHK(h->ball_aq.ensure((size_t)Tpad * sizeof(float)));
+            CHK(h->ball_nql.ensure((size_t)Tpad * sizeof(float)));
+            CHK(h->ball_gmin.ensure((size_t)Tpad * Gb * sizeof(float)));
+            CHK(h->ball_bound.ensure((size_t)Tpad * sizeof(double)));
+            launch_knn_ballmin16b(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->ball_c16.p, h->b16l.p, h->ball_rad.as<float>(),
+                                  h->eps16.as<double>(), h->qnorm.as<double>(), T, Tpad, h->ball_tiles, h->N, h->ball_aq.as<float>(),
+                                  h->ball_nql.as<float>(), h->ball_gmin.as<float>(), s);
+            launch_knn_ball_bound(h->ball_gmin.as<float>(), Gb, T, K, h->ball_bound.as<double>(), s);
+        }
         {
             StageTimer t(h, s, TM_KNN_THRESHOLD);
             launch_knn_threshold16(h->gmin32.as<float>(), G16, T, Tpad, K, h->eps16.as<double>(), h->thr.as<double>(),
                                    h->thr32.as<float>(), bound_in, bound_out, s, coarse ? h->e1_16.as<double>() : nullptr,
-                                   coarse ? h->thr1_32.as<float>() : nullptr);
+                                   coarse ? h->thr1_32.as<float>() : nullptr, ball_bound ? h->ball_bound.as<double>() : nullptr);
         }
         if (bound_out) return 0;             // stage A only
         {
             StageTimer t(h, s, TM_KNN_FILTER);
             if (coarse) {
-                const bool balls = h->prefilter_balls && h->ball_tiles > 0 && slab_factor == 1 && !h->filter_coarse;
                 if (balls) {
                     CHK(h->ball_tq.ensure((size_t)Tpad * sizeof(float)));
                     CHK(h->ball_nq.ensure((size_t)Tpad * sizeof(float)));
@@ -3172,6 +3189,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
         CHK(no_batch_in_flight(h, "snk_set_option(prefilter_balls)"));
         h->prefilter_balls = (int)value;
         h->have_weights = false;          // the ball operand is built by set_weights
+    } else if (!strcmp(name, "prefilter_ball_bound")) {
+        if (value != 0.0 && value != 1.0) return fail("prefilter_ball_bound must be 0 or 1");
+        h->prefilter_ball_bound = (int)value;
     } else if (!strcmp(name, "coarse_gate_fraction")) {
         if (!(value >= 0.0 && value <= 1.0)) return fail("coarse_gate_fraction must be in 0..1");
         h->coarse_gate_fraction = value;
@@ -3323,6 +3343,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     }
     else if (!strcmp(name, "prefilter_two_pass")) *out = h->prefilter_two_pass;
     else if (!strcmp(name, "prefilter_balls")) *out = h->prefilter_balls;
+    else if (!strcmp(name, "prefilter_ball_bound")) *out = h->prefilter_ball_bound;
     else if (!strcmp(name, "filter_coarse")) *out = h->filter_coarse ? 1 : 0;       // 1: the ball pass listed too many pairs for this voice
     else if (!strcmp(name, "ball_switches")) *out = (double)h->ball_switches;
     else if (!strcmp(name, "coarse_pairs") || !strcmp(name, "coarse_pair_overflow")) {
