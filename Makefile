@@ -20,8 +20,31 @@ $(LIB): $(OBJS)
 oracle:
 	$(MAKE) -C oracle
 
+# ---- host orchestration under AddressSanitizer + UBSan, in the CPU container (no GPU): the library's own translation
+# units compiled for the HOST only and linked against tools/fakehip (allocation bookkeeping, no device; kernels never run).
+# Drives: tests/test_host_asan.py.  The sanitizer runtime is clang's shared one (preloaded into python by the test).
+ASAN_DIR   := build/asan
+ASAN_CXX   := /opt/rocm/lib/llvm/bin/clang++
+ASAN_FLAGS := --cuda-host-only -O1 -g -fPIC -std=c++17 -ffp-contract=off -Wno-unused-value -Iinclude \
+              -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -shared-libasan
+ASAN_OBJS  := $(patsubst $(CSRC)/%.o,$(ASAN_DIR)/%.o,$(OBJS)) $(ASAN_DIR)/fake_hip.o
+asan-host: $(ASAN_DIR)/libsnkhip_host_asan.so
+$(ASAN_DIR)/%.o: $(CSRC)/%.hip $(CSRC)/snk_internal.h $(CSRC)/greedy_common.h $(CSRC)/greedy32_device.h include/snk.h
+	@mkdir -p $(ASAN_DIR)
+	$(HIPCC) $(ASAN_FLAGS) -c $< -o $@
+$(ASAN_DIR)/fake_hip.o: tools/fakehip/fake_hip.cpp
+	@mkdir -p $(ASAN_DIR)
+	$(HIPCC) $(ASAN_FLAGS) -c $< -o $@
+# every host object refers to the device code object it was NOT given (__hip_fatbin_<hash>): empty stand-ins
+$(ASAN_DIR)/fatbins.c: $(ASAN_OBJS)
+	nm -u $(ASAN_OBJS) | grep -o '__hip_fatbin_[0-9a-f]*' | sort -u | sed 's/.*/const char &[64] = {0};/' > $@
+$(ASAN_DIR)/libsnkhip_host_asan.so: $(ASAN_OBJS) $(ASAN_DIR)/fatbins.c
+	gcc -fPIC -c $(ASAN_DIR)/fatbins.c -o $(ASAN_DIR)/fatbins.o
+	$(ASAN_CXX) -shared -fPIC -fsanitize=address,undefined -shared-libasan -o $@ $(ASAN_OBJS) $(ASAN_DIR)/fatbins.o -ldl -lpthread
+
 clean:
+	rm -rf $(ASAN_DIR)
 	rm -f $(OBJS) $(LIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean asan-host

@@ -103,43 +103,46 @@ def cpu_baseline(F_unw, JC_unw, wt, wj, K, sample_frames, seed, all_cores=True):
                   % (sample_frames, K, F.shape[0], t_knn, t_join, n_arcs, t_dp, t_build),
     }
     if all_cores:
-        # one forked worker per utterance (the tree and the weighted matrices are shared copy-on-write) on EVERY
-        # hardware thread of the host (os.cpu_count(): SURVEY 8d); the utterances are shortened with the worker count
-        # so that the sample stays at about 20-30 s (64 workers x 600 frames took 142 s on a 256-thread host: the
-        # workers share its memory system)
-        P = max(1, os.cpu_count() or 1)
-        sample_frames = max(48, sample_frames // 3 if P <= 32 else sample_frames // 6 if P <= 96 else sample_frames // 10)
-        # (a worker's pair-loop cost cache is a Python dict of frames x K^2 entries: keep all of them within a quarter
-        # of the host's free memory -- fewer workers, and the line says how many ran)
+        # one forked worker per utterance (the tree and the weighted matrices are shared copy-on-write), the reference's own
+        # `-p ncores` fan-out; the best of a few worker counts up to every hardware thread of the host (os.cpu_count():
+        # SURVEY 8d) -- on a 256-thread host 256 workers share the memory system and are SLOWER than 32.
+        # Short utterances keep each trial at about 10 s.
+        ncpu = max(1, os.cpu_count() or 1)
+        frames_w = 60
         try:
             with open('/proc/meminfo') as f:
                 avail = [int(l.split()[1]) * 1024 for l in f if l.startswith('MemAvailable')][0]
-            P = max(1, min(P, int(0.25 * avail / (sample_frames * K * K * 260.0 + 64e6))))
+            pmax = max(1, int(0.25 * avail / (frames_w * K * K * 260.0 + 64e6)))    # a worker's cost cache is a dict of frames x K^2 entries
         except (OSError, IndexError, ValueError):
-            P = min(P, 32)
-        pipes, t0 = [], time.time()
-        for w in range(P):
-            r, wfd = os.pipe()
-            pid = os.fork()
-            if pid == 0:
-                try:
-                    os.close(r)
-                    Uw = synthetic_targets(F_unw, sample_frames, seed + 1000 + w) * wt
-                    _cpu_search(o, tree, E, S, Uw, K)
-                    os.write(wfd, b'1')
-                finally:
-                    os._exit(0)
-            os.close(wfd)
-            pipes.append((pid, r))
-        done = 0
-        for pid, r in pipes:
-            done += 1 if os.read(r, 1) == b'1' else 0
-            os.close(r)
-            os.waitpid(pid, 0)
-        t_all = time.time() - t0
-        out['all_cores'] = {'value': done * sample_frames / t_all, 'unit': 'frames/s', 'cores': P,
-                            'sample': '%d utterances of %d frames, one single-threaded worker process each, side by side: %.1fs'
-                                      % (done, sample_frames, t_all)}
+            pmax = 32
+        trials = []
+        for P in sorted(set(min(ncpu, pmax, p) for p in (32, 64, 128, ncpu))):
+            pipes, t0 = [], time.time()
+            for w in range(P):
+                r, wfd = os.pipe()
+                pid = os.fork()
+                if pid == 0:
+                    try:
+                        os.close(r)
+                        Uw = synthetic_targets(F_unw, frames_w, seed + 1000 + w) * wt
+                        _cpu_search(o, tree, E, S, Uw, K)
+                        os.write(wfd, b'1')
+                    finally:
+                        os._exit(0)
+                os.close(wfd)
+                pipes.append((pid, r))
+            done = 0
+            for pid, r in pipes:
+                done += 1 if os.read(r, 1) == b'1' else 0
+                os.close(r)
+                os.waitpid(pid, 0)
+            t_all = time.time() - t0
+            trials.append({'workers': P, 'value': done * frames_w / t_all, 'seconds': t_all, 'utterances': done})
+        best = max(trials, key=lambda t: t['value'])
+        out['all_cores'] = {'value': best['value'], 'unit': 'frames/s', 'cores': best['workers'], 'host_threads': ncpu,
+                            'trials': trials,
+                            'sample': 'best of %s single-threaded worker processes side by side, one %d-frame utterance each: %d workers, %.1fs'
+                                      % ([t['workers'] for t in trials], frames_w, best['workers'], best['seconds'])}
     return out, (cand, d, path, cost, U)
 
 
@@ -196,20 +199,85 @@ def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')),
                  'same_path_as_single': bool(np.array_equal(np.asarray(pb[0]), np.asarray(path))),
                  'roofline': {'bound': 'hbm', 'achieved': bfrac * 8000.0, 'peak': 8000.0, 'unit': 'GB/s', 'frac': bfrac,
                               'note': 'one scan of the database serves %d utterances: the scan\'s algorithmic bytes / %d per utterance step' % (per_scan, per_scan)}}
+        resident = eng.info('greedy_resident_launches') > 0
+        if resident:
+            # the windowed join matrix sits in LDS for the whole launch (greedy_res_kernels.hip): a step is two fabric round
+            # trips (publish -> gather) + a scan out of LDS, no HBM or L2 stream -- a latency figure, not a bandwidth one
+            roof = {'bound': 'latency', 'us_per_step': us_step, 'budget_us_per_step': 10.0,
+                    'note': 'database resident in LDS (%d KB per compute unit): per step table 0.9 + LDS scan 1.7 + top-3 0.4 + publish 0.55 + '
+                            'gather 1.7 + decide 1.5 us (DESIGN.md 4.4d) + the utterance\'s share of the hoisted product; dividing its bytes by '
+                            '8 TB/s would mean nothing' % (int(N * Dj * 4 / 256 / 1024),),
+                    'algorithmic_bytes_per_step': bytes_step}
+        else:
+            s_elem = 2.0 if f16 else 4.0                          # bytes per element of the join columns AS STORED for the scan (s)
+            bytes_s = float(N) * (Dj * s_elem + 4.0)
+            roof = {'bound': 'hbm', 'achieved': bytes_s / (us_step * 1e-6) / 1e9, 'peak': 8000.0,
+                    'unit': 'GB/s', 'frac': bytes_s / (us_step * 1e-6) / 8e12, 'bytes_per_element': s_elem,
+                    'algorithmic_bytes_per_step': bytes_s, 'streamed_bytes_per_step': bytes_streamed,
+                    'streamed_frac': bytes_streamed / (us_step * 1e-6) / 8e12,
+                    'frac_at_4_bytes_per_element': bytes_step / (us_step * 1e-6) / 8e12,
+                    'note': 'algorithmic bytes (s Dj + 4) N per step with s = bytes per element of the join columns as the scan reads them '
+                            '(SURVEY 8d): %s; frac_at_4_bytes_per_element prices the float32 database as uploaded'
+                            % ('float16 tiles, s = 2' if f16 else 'float32 tiles, s = 4')}
         out[name] = {'units': N, 'multiepoch': me, 'frames': T, 'steps': steps, 'us_per_step': us_step, 'batch': batch,
                      'target_term_hoisted': bool(hoisted), 'join_tiles': 'float16' if f16 else 'float32',
-                     'frames_per_s': T / dt, 'ms_per_utterance': dt * 1e3,
-                     'roofline': {'bound': 'hbm', 'achieved': bytes_step / (us_step * 1e-6) / 1e9, 'peak': 8000.0,
-                                  'unit': 'GB/s', 'frac': bytes_step / (us_step * 1e-6) / 8e12,
-                                  'algorithmic_bytes_per_step': bytes_step, 'streamed_bytes_per_step': bytes_streamed,
-                                  'streamed_frac': bytes_streamed / (us_step * 1e-6) / 8e12,
-                                  'note': 'algorithmic bytes at s = 4 bytes per element (SURVEY 8d: the database as uploaded, float32)'
-                                          + ('; the scan reads a float16 copy of the join columns: at s = 2, (2 Dj + 4) N bytes, frac = %.3f'
-                                             % (float(N) * (2 * Dj + 4) / (us_step * 1e-6) / 8e12) if f16 else '')},
+                     'frames_per_s': T / dt, 'ms_per_utterance': dt * 1e3, 'roofline': roof,
                      'path_head': [int(v) for v in path[:4]]}
         eng.close()
         del F_unw, JC_unw
     return out
+
+
+def variant_database(kind, N, Dt, F_unw, JC_unw, seed=0):
+    """Databases of the B* shape whose 32-unit tiles are NOT the compact balls SURVEY 8d's generator makes of them
+    (cumsum(randn) / global std: consecutive units 0.002 apart per column against neighbour distances of 0.3):
+      'permuted'    the same units in random order: a tile holds 32 unrelated frames (the ball pass is useless, the engine
+                    switches the voice to the one-term coarse sweep);
+      'speechlike'  a stationary AR(1) walk per column whose step has 0.2 of the global standard deviation (consecutive
+                    speech frames differ by a sizeable fraction of the spread of the data)."""
+    rng = np.random.RandomState(seed + 17)
+    if kind == 'permuted':
+        perm = rng.permutation(N)
+        return F_unw[perm], JC_unw[np.concatenate([perm, [N]])]
+    from scipy.signal import lfilter
+    rho = 0.98                                   # var(step) = 2 (1 - rho) = 0.04
+    F = lfilter([np.sqrt(1.0 - rho * rho)], [1.0, -rho], rng.randn(N + 2000, Dt), axis=0)[2000:]
+    return (F / F.std()).astype(np.float32), JC_unw
+
+
+def variant_leg(eng, kind, N, Dt, Dj, T, U, K, wt, wj, F_unw, JC_unw, steps):
+    """B* on one of the variant databases, two steps in flight, rows resident: an extra field, never `value`."""
+    import snickery_amd
+    Fv, JCv = variant_database(kind, N, Dt, F_unw, JC_unw)
+    eng.upload_db(Fv, JCv)
+    eng.set_weights(wt, wj)
+    batch = snickery_amd.QueryBatch([synthetic_targets(Fv, T, seed=1 + u) * wt for u in range(U)])
+    batch.pin()
+    for _ in range(3):                           # primes both workspaces; the engine decides ball pass / coarse sweep for the voice
+        eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(batch, K))
+    before = (eng.info('f16_fallbacks'), eng.info('batch_redos'))
+    eng.reset_timers()
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pending = None
+    for _ in range(steps):
+        tk = eng.knn_viterbi_batch_submit(batch, K, resident=True)
+        if pending is not None:
+            eng.knn_viterbi_batch_collect(pending)
+        pending = tk
+    eng.knn_viterbi_batch_collect(pending)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tm = eng.timers()
+    rows_per_launch = T * U / max(tm['knn_filter'][1] / steps, 1)
+    pairs = eng.info('coarse_pairs')
+    return {'database': kind, 'frames_per_s': T * U * steps / dt, 'ms_per_step': dt / steps * 1e3, 'steps': steps,
+            'filter_coarse': bool(eng.info('filter_coarse')),
+            'tile_pairs_listed': {'last_launch': pairs, 'fraction': pairs / max((rows_per_launch / 32.0) * (N / 32.0), 1.0)},
+            'list_mean': eng.info('last_list_mean'), 'list_max': eng.info('last_list_max'),
+            'prefilter_fallbacks': eng.info('f16_fallbacks') - before[0], 'batch_redos': eng.info('batch_redos') - before[1],
+            'stages_ms_per_step': dict((k, v[0] / steps) for k, v in tm.items() if v[1])}
 
 
 def main():
@@ -228,6 +296,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-greedy', action='store_true', help='skip the greedy configs (extra fields greedy_b1 / greedy_b3)')
     ap.add_argument('--no-cpu-all-cores', action='store_true', help='skip the all-cores leg of the CPU baseline')
+    ap.add_argument('--no-variants', action='store_true', help='skip the B* legs on the non-compact databases (extra field noncompact)')
     ap.add_argument('--viterbi-mode', type=int, default=2, choices=(0, 1, 2),
                     help='2: the engine default (batches: f32 matrix lower bounds + verified sparse exact recursion); '
                          '1: force that path; 0: dense exact float64 join costs')
@@ -557,32 +626,60 @@ def main():
                            '%d independent replicas' % world if S == 1 else
                            'db-rows/%d + all-to-all of local top-K' % S + (' x %d replica groups' % n_groups if n_groups > 1 else '')),
                        'exchange': None if world == 1 or S == 1 else args.exchange},
-            'roofline': {'bound': 'mfma', 'kernel': kname,
-                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_source,
-                         'avg_launch_ms': avg_ms, 'launches': launches,
-                         'rows_per_launch': rows_per_launch, 'flops_per_launch': flops,
-                         'note': 'peak is the 2.4 GHz datasheet rate; under MFMA load this part holds '
-                                 '1.9-2.0 GHz (MI355X_MICROARCH.md, DVFS give-back)'},
+            'value_includes_query_upload': not resident,
+            'filter_stage': {'bound': 'mfma', 'kernel': kname,
+                             'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                             'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_source,
+                             'avg_launch_ms': avg_ms, 'launches': launches,
+                             'rows_per_launch': rows_per_launch, 'flops_per_launch': flops,
+                             'note': 'NOT the dominant kernel (see `roofline`).  achieved / frac price the ALGORITHMIC 2 N rows Dt flops -- the '
+                                     'distance evaluations the reference\'s tree query stands for -- of a stage that skips most tile pairs; '
+                                     'what the matrix pipe executes is `issued`, what it is busy `mfma_busy`'},
             'stages_ms_per_step': dict((k, v[0] / args.steps) for k, v in timers.items() if v[1]),
             'stage_launches_per_step': dict((k, v[1] / args.steps) for k, v in timers.items() if v[1]),
         }
         out['viterbi'] = {'mode': 'f32 matrix lower bounds + verified sparse exact recursion' if args.viterbi_mode else 'dense exact float64 join costs',
                           'cells_refined': eng.info('dense_cells'), 'steps_with_refinement': eng.info('dense_steps'),
                           'exact_costs_in_refinement': eng.info('dense_exact_costs')}
+        for key, tname in (('us_per_step_exact_recursion', 'viterbi_sparse'), ('us_per_step_bounds_recursion', 'viterbi_lower_bound')):
+            if tname in timers and timers[tname][1]:
+                # latency chains: launch duration / the longest utterance's steps (the utterances of a launch run side by side)
+                out['viterbi'][key] = timers[tname][0] / timers[tname][1] / max(T - 1, 1) * 1e3
+        variant1 = eng.info('join_lb_variant') == 1
         if args.viterbi_mode and 'join_lower_bounds' in timers and timers['join_lower_bounds'][1]:
-            # the largest single kernel of the Viterbi side (rocprof: profiles/r03_*): lower bounds of all K x K join costs
-            # of consecutive rows on the f32 matrix pipe (v_mfma_f32_16x16x4_f32), centred rows, 2 K^2 Dj flops per row pair
+            # `roofline`: the whole-chip kernel with the largest total time in the round's rocprof stats
+            # (profiles/r04_*_kernel_stats.csv) -- pass 1 of the sparse Viterbi path, lower bounds of all K x K join costs of
+            # consecutive candidate rows.  It gathers the 2 K candidate rows of a step (2 (T-1) K Dj s bytes per
+            # utterance, s = 4) and writes K x K bounds; its matrix work (3 bf16 MFMA terms) is a twentieth of the pipe's
+            # rate at that byte rate: HBM-bound.  (The T-step recursions viterbi_sparse1_kernel / viterbi_lb_kernel are
+            # latency chains on one or a few wavefronts per utterance: `viterbi.us_per_step_*`, no roofline claim.)
             jms, jl = timers['join_lower_bounds']
             jrows = rows_swept / max(jl, 1)
-            jfl = 2.0 * jrows * K * K * Dj
             jbytes = jrows * K * 2 * Dj * 4 + jrows * K * K * 4        # gathered E and S rows (each read once per row pair) + the bounds written
             javg = jms / max(jl, 1)
-            out['roofline_join_lb'] = {'bound': 'mfma', 'kernel': 'join_lb_kernel (v_mfma_f32_16x16x4_f32)', 'achieved': jfl / (javg * 1e-3) / 1e12,
-                                       'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': jfl / (javg * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                                       'avg_launch_ms': javg, 'launches': jl, 'rows_per_launch': jrows, 'flops_per_launch': jfl,
-                                       'algorithmic_bytes_per_launch': jbytes, 'hbm_frac': jbytes / (javg * 1e-3) / 1e9 / 8000.0,
-                                       'note': 'timed with HIP events on its side stream while the K-NN of the next group shares the chip'}
+            jfl = 2.0 * jrows * K * K * Dj
+            jtraffic, jsrc = None, None
+            jfile = os.path.join(ROOT, 'profiles', 'r04_traffic_joinlb2.json')
+            if variant1 and world == 1 and N == 1048576 and Dj == 302 and K == 100 and os.path.isfile(jfile):
+                with open(jfile) as f:
+                    tj = json.load(f)
+                if abs(tj.get('rows_per_launch', 0) - jrows) < 1.0:
+                    jtraffic, jsrc = tj['hbm_bytes_per_launch'], 'profiles/r04_traffic_joinlb2.json (separate --pmc passes of this kernel and shape; not measured in this run)'
+            out['roofline'] = {
+                'bound': 'hbm',
+                'kernel': ('join_lb2_kernel (joinlb2_kernels.hip: gather of the weighted float32 join rows of 2 K candidates per step, bf16-split '
+                           'K x K x Dj product on v_mfma_f32_32x32x16_bf16, proven lower bounds written as float32)' if variant1 else
+                           'join_lb_kernel (joinfast_kernels.hip: v_mfma_f32_16x16x4_f32, rows weighted in float64 per gather)'),
+                'achieved': jbytes / (javg * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': jbytes / (javg * 1e-3) / 1e9 / 8000.0,
+                'traffic': jtraffic, 'traffic_source': jsrc,
+                'avg_launch_ms': javg, 'launches': jl, 'rows_per_launch': jrows, 'algorithmic_bytes_per_launch': jbytes,
+                'flops_per_launch': jfl, 'mfma_tflops': jfl / (javg * 1e-3) / 1e12,
+                'rule': 'the whole-chip kernel with the largest total time under rocprofv3 (profiles/r04_*_kernel_stats.csv); timed here with '
+                        'HIP events on the stream it is launched on, inside the timed region, while the K-NN of the next group shares the chip',
+                'note': 'algorithmic bytes per SURVEY 8d: every candidate row gathered once per row pair (2 K rows of Dj float32) + K^2 float32 bounds; '
+                        'rows that consecutive steps share are served from L2, so `traffic` lies below them'}
+        else:
+            out['roofline'] = dict(out['filter_stage'])
         if bf16_mode:
             # what the matrix pipe executes for those algorithmic flops: 64-column tiles, 4 bf16 terms per product
             dpad = (Dt + 3 + 63) // 64 * 64
@@ -593,9 +690,9 @@ def main():
                 pairs = eng.info('coarse_pairs')
                 first = (2.0 * rows_per_launch * n_local * dpad) if coarse_now else (terms * 2.0 * rows_per_launch * (n_local / 32.0) * dpad)
                 issued = first + terms * 2.0 * pairs * 32 * 32 * dpad
-                out['roofline']['tile_pairs_listed'] = {'last_launch': pairs, 'of': (rows_per_launch / 32.0) * (n_local / 32.0),
+                out['filter_stage']['tile_pairs_listed'] = {'last_launch': pairs, 'of': (rows_per_launch / 32.0) * (n_local / 32.0),
                                                         'fraction': pairs / max((rows_per_launch / 32.0) * (n_local / 32.0), 1.0)}
-            out['roofline']['issued'] = {'tflops': issued / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+            out['filter_stage']['issued'] = {'tflops': issued / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
                                          'frac': issued / (avg_ms * 1e-3) / 1e12 / peak if avg_ms > 0 else 0.0,
                                          'note': ('what the matrix pipe executes: the first pass plus %d bf16 MFMA terms (hi.hi + hi.lo + lo.hi%s) for the listed '
                                                   'tile pairs, on Dt padded to 64 columns; frac above prices the algorithmic 2 N rows Dt flops -- the '
@@ -609,10 +706,11 @@ def main():
             # float32-operand prefilter, whose bound is the analytical one of an f32 FMA chain, must select the same units;
             # and how close the exact K-th keys of the timed steps came to the filter thresholds (include/snk.h)
             margin_rows, min_margin = eng.info('prefilter_margin_rows'), eng.info('prefilter_min_margin')
+            pre_was = eng.info('prefilter')
             eng.set_option('prefilter', 0)
             eng.set_weights(wt, wj)
             p0, c0 = eng.knn_viterbi_batch(batch, K)
-            eng.set_option('prefilter', 1)
+            eng.set_option('prefilter', pre_was)
             eng.set_weights(wt, wj)
             out['prefilter_tripwire'] = {
                 'gpu_matches_f32_prefilter': bool(all(np.array_equal(a, b) for a, b in zip(p0, paths)) and np.array_equal(c0, costs)),
@@ -621,7 +719,12 @@ def main():
                         'the factor by which the true key errors could exceed eps before a row could lose a neighbour; '
                         'prefilter_margin_rows counts the rows under 2 (include/snk.h, DESIGN.md 4.1a)'}
         if with_upload is not None:
+            # SURVEY 8d's wall time (target matrix on host -> path on host): the same pipeline with the query rows crossing
+            # PCIe inside every timed step.  `value` follows the bench contract (inputs resident in HBM when the timed region
+            # starts; value_includes_query_upload says which); this is the host-to-host rate beside it.
             out['with_upload'] = with_upload
+            out['host_to_host'] = {'value': with_upload['value'], 'unit': 'frames/s', 'ms_per_step': with_upload['ms_per_step'],
+                                   'note': 'SURVEY 8d host -> host: query rows uploaded and paths downloaded inside every timed step (= with_upload)'}
         out['config']['inputs'] = 'resident in HBM' if resident else 'uploaded from the host every step'
         if two_in_flight is not None:
             out['two_in_flight'] = two_in_flight
@@ -638,6 +741,11 @@ def main():
             gp, gc, gcand, gdist = eng.knn_viterbi(ref[4], K, return_candidates=True)
             out['cpu_baseline']['gpu_matches_cpu_path'] = bool(gp == ref[2])
             out['cpu_baseline']['gpu_matches_cpu_candidates'] = bool(np.array_equal(gcand, ref[0]))
+        if world == 1 and not args.no_variants and N >= 65536:
+            # the same workload on databases whose tiles are not compact balls: what the fallback of the ball
+            # pass costs, driver-visible
+            out['noncompact'] = [variant_leg(eng, kind, N, Dt, Dj, T, U, K, wt, wj, F_unw, JC_unw, max(4, args.steps // 4))
+                                 for kind in ('permuted', 'speechlike')]
         if world == 1 and not args.no_greedy:
             eng.close()                     # free the B* database before the greedy voices are built
             eng = None

@@ -1461,38 +1461,30 @@ bool launch_knn_balls16b(int terms, int dch, int grid_cus, const void *C16, cons
 }
 
 // ===========================================================================================================
-// Stage A' of the thresholds: an upper bound of the K-th nearest key from the tiles' balls (no reference counterpart: the
-// reference's KD-tree needs no threshold, script/synth_halfphone.py:1364).  Every unit f of a FULL tile (32 units, centre c,
-// radius r) has  key(f) = ||q - f||^2 - ||q||^2 <= (||q - c|| + r)^2 - ||q||^2 =: U(tile, q),  so the kk-th smallest U over
-// kk = ceil(K / 32) distinct tiles bounds the K-th nearest key of the database from above -- where the tiles are compact
-// (consecutive frames of speech) by little more than the K-th key itself, while stage A's bound from a 1/16 sample lets
-// about sixteen times K units through.  The centres' keys are the ball pass's (same operands, MFMA order and bound eps):
-//        ||q - c||^2 <= key~(c) + eps + ||q||^2 =: d2,     U = (sqrt(d2) + r)^2 - ||q||^2      (rounded up)
-// Query-stationary: a wavefront keeps one query tile's operand and walks a range of centre tiles; lane (query row, half)
-// keeps the minimum of U per result register, i.e. per tile position mod 32 -- the tiles of one minimum are 32 tiles apart,
-// so neighbouring tiles (where the neighbours of a frame cluster) fall into different groups and the kk smallest group
-// minima are kk distinct, typically the kk best, tiles.  gminb: [row][csplit * 32] group minima.
+// Stage A' of the thresholds: the K-th smallest key among the units of the few tiles nearest to a query row (no reference
+// counterpart: the reference's KD-tree needs no threshold, script/synth_halfphone.py:1364).
+// Stage A bounds the K-th nearest key by the K-th smallest key of a 1/16 sample, which lets about sixteen times K units
+// through the filter; the bound the tiles' balls give, (||q - c|| + r)^2 - ||q||^2 for the ceil(K / 32)-th tile, was built
+// and measured no better (its slack 2 r ||q - c|| is wider than the key window that holds 17 K units: lists 1785 -> 1575).
+// Any K distinct units bound the K-th nearest key by their K-th smallest key -- so take units that are likely to BE the
+// neighbours: in a speech database the neighbours of a frame are frames of the same stretch of signal, i.e. of the tiles
+// (32 consecutive units) whose centres are nearest and of the tiles next to them.
+//   S1 knn_scout16b       centres against query tiles (the ball pass's operands), query-stationary: per (query row, tile
+//                         position mod 32, range of centre tiles) the smallest centre key with the centre tile's number in
+//                         its low mantissa bits -- a hint, no bound: precision is irrelevant
+//   S2 knn_scout_pick     per query tile: per group the best hint over its 32 rows (consecutive frames share their stretch of
+//                         the database), the tiles of the SCOUT_SLOTS best groups
+//   S3 knn_scout_keys16b  the three-term keys of those (tile, query tile) pairs -- knn_refine16b's arithmetic: the filter's
+//                         own keys and error bound -- into gkeys[row][slot * 32 + unit]
+// and the threshold kernel takes the K-th smallest of a row's keys + eps as a second bound (bound2).  Valid whatever the
+// hint picks; where a row's tiles hold fewer than K units the row keeps stage A's bound.
 // ===========================================================================================================
-__global__ void ballmin_query_terms_kernel(const double *__restrict__ eps, const double *__restrict__ qnorm, int64_t T, int64_t T32,
-                                           float *__restrict__ aq, float *__restrict__ nql)
-{
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= T32) return;
-    float a = 0.f, n = 0.f;
-    if (row < T) {
-        const double ad = eps[row] + qnorm[row];
-        a = (float)ad;
-        if ((double)a < ad) a = nextafterf(a, FLT_MAX);
-        n = (float)qnorm[row];
-        if ((double)n > qnorm[row]) n = nextafterf(n, -FLT_MAX);
-    }
-    aq[row] = a; nql[row] = n;
-}
+#define SCOUT_SLOTS 64
 
 template <int KB, int TERMS>
 __global__ void __launch_bounds__(256, 2)
-knn_ballmin16b(const u32x4 *__restrict__ C16, const u32x4 *__restrict__ B16, const float *__restrict__ rad, const float *__restrict__ aq,
-               const float *__restrict__ nql, int nQT, int64_t n_full_tiles, int64_t n_ctiles, int csplit, float *__restrict__ gminb)
+knn_scout16b(const u32x4 *__restrict__ C16, const u32x4 *__restrict__ B16, int nQT, int64_t n_tiles, int64_t n_ctiles, int csplit,
+             int ct_bits, float *__restrict__ smin)
 {
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -1501,142 +1493,218 @@ knn_ballmin16b(const u32x4 *__restrict__ C16, const u32x4 *__restrict__ B16, con
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     };
     const int64_t n_items = (int64_t)nQT * csplit;
-    const int Gb = csplit * 32;
+    const int Gb = csplit * 64;
+    const unsigned int keep = ~((1u << ct_bits) - 1u);
     for (int64_t item = (int64_t)blockIdx.x * 4 + wv; item < n_items; item += (int64_t)gridDim.x * 4) {
         const int qt = (int)(item / csplit), part = (int)(item % csplit);
-        const int64_t c_lo = (n_ctiles * part) / csplit, c_hi = (n_ctiles * (part + 1)) / csplit;
+        // (ranges start at even centre tiles: the two operand buffers below then are the two parities)
+        const int64_t c_lo = ((n_ctiles * part) / csplit) & ~(int64_t)1;
+        const int64_t c_hi = part + 1 == csplit ? n_ctiles : (((n_ctiles * (part + 1)) / csplit) & ~(int64_t)1);
         u32x4 b[KB][2];
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc) b[kb][pc] = B16[(((int64_t)qt * KB + kb) * 2 + pc) * 64 + lane];
-        const float aqv = aq[qt * 32 + qcol], nlv = nql[qt * 32 + qcol];
-        float mn[16];
+        // minima per (parity of the centre tile, result register): the tiles of one minimum are 64 tiles apart
+        float mn0[16], mn1[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mn[r] = FLT_MAX;
+        for (int r = 0; r < 16; ++r) { mn0[r] = FLT_MAX; mn1[r] = FLT_MAX; }
         u32x4 a0[KB][2], a1[KB][2];
-        float rv0[16], rv1[16];
-        auto load_c = [&](int64_t ct, u32x4 (&a)[KB][2], float (&rv)[16]) {
+        auto load_c = [&](int64_t ct, u32x4 (&a)[KB][2]) {
             const int64_t cc = ct < c_hi ? ct : c_hi - 1;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                 for (int pc = 0; pc < 2; ++pc) a[kb][pc] = C16[((cc * KB + kb) * 2 + pc) * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t t = cc * 32 + crow32(lane, r);
-                rv[r] = t < n_full_tiles ? rad[t] : -1.f;       // a partial (or no) tile does not count 32 units
-            }
         };
-        auto work = [&](const u32x4 (&a)[KB][2], const float (&rv)[16]) {
-            // the ball pass's chain: per k-block hi.hi, hi(centre).lo(query), lo(centre).hi(query) [, lo.lo]; chains of one
-            // 64-column chunk, the chunks' sums added in float32 (the key bound eps is for this order)
-            constexpr int CM = 4 * TERMS, NM = TERMS * KB;
-            f16acc acc, part_;
+        auto work = [&](int64_t ct, const u32x4 (&a)[KB][2], float (&mn)[16]) {
+            constexpr int NM = TERMS * KB;
+            f16acc acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 const int kb = m / TERMS, term = m % TERMS;
-                const u32x4 &av = (term & 2) ? a[kb][1] : a[kb][0];
-                const u32x4 &bv = (term & 1) ? b[kb][1] : b[kb][0];
-                if (m % CM == 0) {
-                    f16acc z;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-                    part_ = mfma(av, bv, z);
-                } else part_ = mfma(av, bv, part_);
-                if (m % CM == CM - 1 || m == NM - 1) {
-                    if (m < CM) acc = part_;
-                    else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] += part_[r];
-                    }
-                }
+                acc = mfma((term & 2) ? a[kb][1] : a[kb][0], (term & 1) ? b[kb][1] : b[kb][0], acc);
             }
+            const unsigned int tag = (unsigned int)ct;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                // U rounded up: the addition, the square root (v_sqrt_f32, 1 ulp) and s each within 2^-23; the last two
-                // float32 operations inside the relative 2^-21 of both terms
-                const float d2 = __builtin_fmaxf(acc[r] + aqv, 0.f);
-                const float sr = __builtin_amdgcn_sqrtf(d2) * 1.0000005f + rv[r];
-                const float u = __builtin_fmaf(sr, sr, -nlv) + (4.76837158203125e-07f * (sr * sr + __builtin_fabsf(nlv)) + 1e-30f);
-                const float v = rv[r] >= 0.f ? u : FLT_MAX;
-                mn[r] = __builtin_fminf(mn[r], v == v ? v : FLT_MAX);
+                const bool ok = ct * 32 + crow32(lane, r) < n_tiles && __builtin_fabsf(acc[r]) < FLT_MAX;
+                const float v = __uint_as_float((__float_as_uint(acc[r]) & keep) | tag);
+                mn[r] = __builtin_fminf(mn[r], ok ? v : FLT_MAX);
             }
         };
-        load_c(c_lo, a0, rv0);
-        for (int64_t ct = c_lo; ct < c_hi; ct += 2) {
-            load_c(ct + 1, a1, rv1);
-            work(a0, rv0);
-            if (ct + 1 < c_hi) {
-                load_c(ct + 2, a0, rv0);
-                work(a1, rv1);
+        if (c_lo < c_hi) {
+            load_c(c_lo, a0);
+            for (int64_t ct = c_lo; ct < c_hi; ct += 2) {
+                load_c(ct + 1, a1);
+                work(ct, a0, mn0);
+                if (ct + 1 < c_hi) {
+                    load_c(ct + 2, a0);
+                    work(ct + 1, a1, mn1);
+                }
             }
         }
+        float *const out = smin + ((int64_t)qt * 32 + qcol) * Gb + part * 64;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gminb[((int64_t)qt * 32 + qcol) * Gb + part * 32 + crow32(lane, r)] = mn[r];
+        for (int r = 0; r < 16; ++r) { out[crow32(lane, r)] = mn0[r]; out[32 + crow32(lane, r)] = mn1[r]; }
     }
 }
 
-int knn_ballmin_groups(int64_t T32, int64_t n_tiles)
+// one wavefront per query tile: per group the smallest hint over the tile's rows, then the SCOUT_SLOTS best groups' tiles
+// (groups are disjoint sets of tiles: the tiles of a list are distinct)
+__global__ void __launch_bounds__(64)
+knn_scout_pick_kernel(const float *__restrict__ smin, int Gb, int ct_bits, int64_t T, unsigned int *__restrict__ list)
+{
+    const int lane = threadIdx.x;
+    const int64_t qt = blockIdx.x;
+    const unsigned int tagm = (1u << ct_bits) - 1u;
+    constexpr int PER = 8;                                    // Gb <= 512 groups: eight per lane
+    // a group's score: the smallest EXCESS of its hint over the row's best hint, over the tile's rows -- every row has its
+    // own key offset (-||q||^2) and its own landscape; the excess treats them alike
+    float v[PER];
+    unsigned int tl[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { v[k] = FLT_MAX; tl[k] = 0xffffffffu; }
+    for (int i = 0; i < 32; ++i) {
+        const int64_t row = qt * 32 + i;
+        if (row >= T) break;                                  // uniform
+        float x[PER], rm = FLT_MAX;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int g = lane + 64 * k;
+            x[k] = g < Gb ? smin[row * Gb + g] : FLT_MAX;
+            rm = __builtin_fminf(rm, x[k]);
+        }
+#pragma unroll
+        for (int o = 1; o <= 32; o <<= 1) rm = __builtin_fminf(rm, __shfl_xor(rm, o, 64));
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const float e = x[k] < FLT_MAX ? x[k] - rm : FLT_MAX;
+            if (e < v[k]) { v[k] = e; tl[k] = (__float_as_uint(x[k]) & tagm) * 32u + (unsigned int)((lane + 64 * k) & 31); }
+        }
+    }
+    for (int s = 0; s < SCOUT_SLOTS; ++s) {
+        float m = v[0];
+#pragma unroll
+        for (int k = 1; k < PER; ++k) m = __builtin_fminf(m, v[k]);
+#pragma unroll
+        for (int o = 1; o <= 32; o <<= 1) m = __builtin_fminf(m, __shfl_xor(m, o, 64));
+        // one holder of the minimum hands its tile over and leaves
+        bool mine = false;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) mine = mine || v[k] == m;
+        const unsigned long long has = __ballot(mine && m < FLT_MAX);
+        unsigned int tile = 0xffffffffu;
+        if (has) {
+            const int src = __builtin_ctzll(has);
+            unsigned int t = 0xffffffffu;
+            if (lane == src) {
+                bool done = false;
+#pragma unroll
+                for (int k = 0; k < PER; ++k)
+                    if (!done && v[k] == m) { t = tl[k]; v[k] = FLT_MAX; done = true; }
+            }
+            tile = (unsigned int)__shfl((int)t, src, 64);
+        }
+        if (lane == 0) list[qt * SCOUT_SLOTS + s] = tile;
+    }
+}
+
+// one wavefront per (query tile, slot): the three-term keys of the pair, knn_refine16b's arithmetic
+template <int KB, int TERMS>
+__global__ void __launch_bounds__(256, 2)
+knn_scout_keys16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const unsigned int *__restrict__ list, int nQT,
+                  float *__restrict__ gkeys)
+{
+    const int lane = threadIdx.x & 63, qcol = lane & 31;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (int64_t)nQT * SCOUT_SLOTS) return;
+    const int64_t qt = item / SCOUT_SLOTS;
+    const int slot = (int)(item % SCOUT_SLOTS);
+    const unsigned int tile = __builtin_amdgcn_readfirstlane(list[item]);
+    float *const out = gkeys + (qt * 32 + qcol) * (int64_t)(SCOUT_SLOTS * 32) + slot * 32;
+    if (tile == 0xffffffffu) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[crow32(lane, r)] = FLT_MAX;
+        return;
+    }
+    auto mfma = [](const u32x4 &a, const u32x4 &b, f16acc c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+    u32x4 a[KB][2], b[KB][2];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            a[kb][pc] = A16[(((int64_t)tile * KB + kb) * 2 + pc) * 64 + lane];
+            b[kb][pc] = B16[((qt * KB + kb) * 2 + pc) * 64 + lane];
+        }
+    // knn_sweep16b's order: per k-block hi.hi, hi(db).lo(query), lo(db).hi(query) [, lo.lo]; chains of one 64-column chunk,
+    // the chunks' sums added in float32 (the key bound eps is for this order)
+    constexpr int CM = 4 * TERMS, NM = TERMS * KB;
+    f16acc acc, part;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int kb = m / TERMS, term = m % TERMS;
+        const u32x4 &av = (term & 2) ? a[kb][1] : a[kb][0];
+        const u32x4 &bv = (term & 1) ? b[kb][1] : b[kb][0];
+        if (m % CM == 0) {
+            f16acc z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+            part = mfma(av, bv, z);
+        } else part = mfma(av, bv, part);
+        if (m % CM == CM - 1 || m == NM - 1) {
+            if (m < CM) acc = part;
+            else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += part[r];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[crow32(lane, r)] = acc[r] == acc[r] ? acc[r] : FLT_MAX;
+}
+
+int knn_scout_groups(int64_t T32, int64_t n_tiles)
 {
     const int nQT = (int)(T32 / 32);
     const int64_t n_ctiles = (n_tiles + 31) / 32;
     int csplit = 1;
-    while ((int64_t)nQT * csplit < 2048 && csplit < 8 && 2 * csplit <= n_ctiles) csplit *= 2;
-    return csplit * 32;
+    while ((int64_t)nQT * csplit < 2048 && csplit < 8 && 4 * csplit <= n_ctiles) csplit *= 2;
+    return csplit * 64;
 }
+int knn_scout_keys_per_row() { return SCOUT_SLOTS * 32; }
+size_t knn_scout_list_bytes(int64_t T32) { return (size_t)(T32 / 32) * SCOUT_SLOTS * sizeof(unsigned int); }
 
-bool launch_knn_ballmin16b(int terms, int dch, int grid_cus, const void *C16, const void *B16, const float *rad, const double *eps,
-                           const double *qnorm, int64_t T, int64_t T32, int64_t n_tiles, int64_t n_units, float *aq, float *nql,
-                           float *gminb, hipStream_t s)
+// smin: T32 x knn_scout_groups floats; list: knn_scout_list_bytes; gkeys: T32 x knn_scout_keys_per_row floats
+bool launch_knn_scout16b(int terms, int dch, int grid_cus, const void *C16, const void *A16, const void *B16, int64_t T, int64_t T32,
+                         int64_t n_tiles, float *smin, unsigned int *list, float *gkeys, hipStream_t s)
 {
     const int nQT = (int)(T32 / 32);
     const int64_t n_ctiles = (n_tiles + 31) / 32;
-    const int csplit = knn_ballmin_groups(T32, n_tiles) / 32;
-    hipLaunchKernelGGL(ballmin_query_terms_kernel, dim3((unsigned)((T32 + 255) / 256)), dim3(256), 0, s, eps, qnorm, T, T32, aq, nql);
+    const int Gb = knn_scout_groups(T32, n_tiles), csplit = Gb / 64;
+    int ct_bits = 1;
+    while (((int64_t)1 << ct_bits) < n_ctiles) ++ct_bits;
+    if (ct_bits > 20 || dch < 1 || dch > 3) return false;
     int64_t blocks = ((int64_t)nQT * csplit + 3) / 4;
     if (blocks > 2 * (int64_t)grid_cus) blocks = 2 * (int64_t)grid_cus;
-#define SNK_BM16(KB_, TERMS_)                                                                                        \
-    hipLaunchKernelGGL((knn_ballmin16b<KB_, TERMS_>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)C16,   \
-                       (const u32x4 *)B16, rad, aq, nql, nQT, n_units / 32, n_ctiles, csplit, gminb)
-    if (dch == 1) { if (terms == 4) SNK_BM16(4, 4); else SNK_BM16(4, 3); }
-    else if (dch == 2) { if (terms == 4) SNK_BM16(8, 4); else SNK_BM16(8, 3); }
-    else if (dch == 3) { if (terms == 4) SNK_BM16(12, 4); else SNK_BM16(12, 3); }
-    else return false;
-#undef SNK_BM16
-    return true;
-}
-
-// kk-th smallest of a row's Gb group minima (one wavefront per row; kk <= 7): the ball bound of the row, +DBL_MAX when
-// fewer than kk groups hold a full tile
-__global__ void __launch_bounds__(256)
-knn_ball_bound_kernel(const float *__restrict__ gminb, int Gb, int64_t T, int kk, double *__restrict__ ballb)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= T) return;
-    float v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (lane + 64 * i < Gb) ? gminb[row * Gb + lane + 64 * i] : FLT_MAX;
-    float kth = FLT_MAX;
-    for (int it = 0; it < kk; ++it) {
-        float m = __builtin_fminf(__builtin_fminf(v[0], v[1]), __builtin_fminf(v[2], v[3]));
-#pragma unroll
-        for (int o = 1; o <= 32; o <<= 1) m = __builtin_fminf(m, __shfl_xor(m, o, 64));
-        kth = m;
-        // one instance of the minimum leaves: the lowest lane that holds it, its first slot
-        const unsigned long long has = __ballot(v[0] == m || v[1] == m || v[2] == m || v[3] == m);
-        if (has && lane == __builtin_ctzll(has)) {
-            if (v[0] == m) v[0] = FLT_MAX; else if (v[1] == m) v[1] = FLT_MAX; else if (v[2] == m) v[2] = FLT_MAX; else v[3] = FLT_MAX;
-        }
+    const unsigned kblocks = (unsigned)(((int64_t)nQT * SCOUT_SLOTS + 3) / 4);
+#define SNK_SC16(KB_, TERMS_)                                                                                        \
+    {                                                                                                                \
+        hipLaunchKernelGGL((knn_scout16b<KB_, TERMS_>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)C16, \
+                           (const u32x4 *)B16, nQT, n_tiles, n_ctiles, csplit, ct_bits, smin);                       \
+        hipLaunchKernelGGL(knn_scout_pick_kernel, dim3((unsigned)nQT), dim3(64), 0, s, smin, Gb, ct_bits, T, list); \
+        hipLaunchKernelGGL((knn_scout_keys16b<KB_, TERMS_>), dim3(kblocks), dim3(256), 0, s, (const u32x4 *)A16,     \
+                           (const u32x4 *)B16, list, nQT, gkeys);                                                    \
     }
-    if (lane == 0) ballb[row] = kth < FLT_MAX ? (double)kth : DBL_MAX;
-}
-
-void launch_knn_ball_bound(const float *gminb, int Gb, int64_t T, int K, double *ballb, hipStream_t s)
-{
-    const int kk = (K + 31) / 32;
-    hipLaunchKernelGGL(knn_ball_bound_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, s, gminb, Gb, T, kk, ballb);
+    if (dch == 1) { if (terms == 4) SNK_SC16(4, 4) else SNK_SC16(4, 3) }
+    else if (dch == 2) { if (terms == 4) SNK_SC16(8, 4) else SNK_SC16(8, 3) }
+    else { if (terms == 4) SNK_SC16(12, 4) else SNK_SC16(12, 3) }
+#undef SNK_SC16
+    return true;
 }
 
 bool knn_coarse16b_supported(int nt, int dch) { return (nt == 4 && dch == 1) || (nt == 2 && dch == 2) || (nt == 1 && dch == 3); }
@@ -1677,7 +1745,7 @@ bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, con
     return false;
 }
 
-#define THR16_GROUPS 1024
+#define THR16_GROUPS 2048
 // ---------------------------------------------------------------------------
 // threshold from the f32 group minima: K-th smallest of G values + eps_t, as f32 rounded UP.
 // bound = (K-th smallest group minimum) + eps is a true upper bound of the K-th nearest key of THIS

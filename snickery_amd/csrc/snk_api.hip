@@ -253,8 +253,8 @@ struct snk_engine {
     double eps_c_bf = 4e-6;       // accumulation part of the bound of the bf16-split keys (knn16_kernels.hip: c_acc)
     DevBuf kth16;                 // sharded search: per-row second bound (K-th key of the local list, all-reduced)
     DevBuf ball_c, ball_cn, ball_rad, ball_c16, ball_tq, ball_nq;   // pass 0: tile centres (float64, norms, radii, bf16-split operand), per-row terms
-    DevBuf ball_aq, ball_nql, ball_gmin, ball_bound;                // stage A': per-row terms, group minima of the tiles' upper bounds, the row's bound
-    int prefilter_ball_bound = 1; // 1: the thresholds also take the upper bound the tiles' balls give (stage A'; where the ball pass runs)
+    DevBuf ball_aq, ball_nql, ball_gmin, ball_bound;                // stage A' (scout): tile list per query tile, keys of their units per row, centre-key minima, the row's bound
+    int prefilter_ball_bound = 1; // 1: the thresholds also take the K-th smallest key of the units of the nearest tiles (stage A'; where the ball pass runs)
     int prefilter_balls = 1;      // 1: the tiles' balls list the pairs first; the coarse sweep runs only where they list too many
     double coarse_gate_fraction = 0.10;
     int64_t ball_tiles = 0;       // valid tiles of the ball operand (0: not built)
@@ -1178,20 +1178,22 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
                                nullptr, Tpad, n_slabs_a, h->slabctr.as<unsigned int>(), h->gmin32.as<float>(),
                                G16, nullptr, nullptr, nullptr, 0, knn_pool_chunk_entries(), s);
         }
-        // stage A': where the ball pass is going to list the tile pairs, the balls also bound the K-th nearest key
+        // stage A': where the ball pass is going to list the tile pairs (compact tiles), the K-th smallest key among the units
+        // of the tiles nearest to a row is a second, much tighter bound of its K-th nearest key
         const bool balls = coarse && h->prefilter_balls && h->ball_tiles > 0 && slab_factor == 1 && !h->filter_coarse;
-        const bool ball_bound = balls && h->prefilter_ball_bound && !bound_in && h->N / 32 >= (K + 31) / 32;
+        const bool ball_bound = balls && h->prefilter_ball_bound && !bound_in && knn_scout_keys_per_row() >= K;
         if (ball_bound) {
             StageTimer t(h, s, TM_KNN_BALLMIN);
-            const int Gb = knn_ballmin_groups(Tpad, h->ball_tiles);
-            CHK(h->ball_aq.ensure((size_t)Tpad * sizeof(float)));
-            CHK(h->ball_nql.ensure((size_t)Tpad * sizeof(float)));
+            const int Gb = knn_scout_groups(Tpad, h->ball_tiles), G2 = knn_scout_keys_per_row();
             CHK(h->ball_gmin.ensure((size_t)Tpad * Gb * sizeof(float)));
+            CHK(h->ball_aq.ensure(knn_scout_list_bytes(Tpad)));
+            CHK(h->ball_nql.ensure((size_t)Tpad * G2 * sizeof(float)));
             CHK(h->ball_bound.ensure((size_t)Tpad * sizeof(double)));
-            launch_knn_ballmin16b(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->ball_c16.p, h->b16l.p, h->ball_rad.as<float>(),
-                                  h->eps16.as<double>(), h->qnorm.as<double>(), T, Tpad, h->ball_tiles, h->N, h->ball_aq.as<float>(),
-                                  h->ball_nql.as<float>(), h->ball_gmin.as<float>(), s);
-            launch_knn_ball_bound(h->ball_gmin.as<float>(), Gb, T, K, h->ball_bound.as<double>(), s);
+            launch_knn_scout16b(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->ball_c16.p, h->a16l.p, h->b16l.p, T, Tpad, h->ball_tiles,
+                                h->ball_gmin.as<float>(), h->ball_aq.as<unsigned int>(), h->ball_nql.as<float>(), s);
+            // K-th smallest of the row's keys + eps -> ball_bound (thr / thr32 are written again below)
+            launch_knn_threshold16(h->ball_nql.as<float>(), G2, T, Tpad, K, h->eps16.as<double>(), h->thr.as<double>(),
+                                   h->thr32.as<float>(), nullptr, h->ball_bound.as<double>(), s);
         }
         {
             StageTimer t(h, s, TM_KNN_THRESHOLD);

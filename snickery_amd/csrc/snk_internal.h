@@ -136,12 +136,12 @@ void launch_knn_threshold16(const float *gmin32, int64_t G, int64_t T, int64_t T
                             double *thr, float *thr32, const double *bound_in, double *bound_out, hipStream_t s,
                             const double *e1 = nullptr, float *thr1 = nullptr,     // thr1: the coarse pass's threshold (thr32 + e1)
                             const double *bound2 = nullptr);                       // a second upper bound per row (stage A'): the smaller one serves
-// stage A': upper bound of the K-th nearest key from the tiles' balls (knn16_kernels.hip)
-int knn_ballmin_groups(int64_t T32, int64_t n_tiles);
-bool launch_knn_ballmin16b(int terms, int dch, int grid_cus, const void *C16, const void *B16, const float *rad, const double *eps,
-                           const double *qnorm, int64_t T, int64_t T32, int64_t n_tiles, int64_t n_units, float *aq, float *nql,
-                           float *gminb, hipStream_t s);
-void launch_knn_ball_bound(const float *gminb, int Gb, int64_t T, int K, double *ballb, hipStream_t s);
+// stage A': keys of the units of the tiles nearest to each query row (knn16_kernels.hip): a second bound per row
+int knn_scout_groups(int64_t T32, int64_t n_tiles);
+int knn_scout_keys_per_row();
+size_t knn_scout_list_bytes(int64_t T32);
+bool launch_knn_scout16b(int terms, int dch, int grid_cus, const void *C16, const void *A16, const void *B16, int64_t T, int64_t T32,
+                         int64_t n_tiles, float *smin, unsigned int *list, float *gkeys, hipStream_t s);
 // bf16-split prefilter (knn16_kernels.hip)
 bool knn_sweep16b_supported(int nt, int dch, int Dt, int Dpad, bool cls);
 void launch_build_db16b(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,

@@ -17,7 +17,9 @@ class SnkError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, 'libsnkhip.so')
+    # SNK_LIBRARY: another BUILD of the same library (the sanitizer build of `make asan-host`, tests/test_host_asan.py);
+    # there is no other implementation to point it at
+    return os.environ.get('SNK_LIBRARY') or os.path.join(_HERE, 'libsnkhip.so')
 
 
 _c_i64p = ctypes.POINTER(ctypes.c_int64)

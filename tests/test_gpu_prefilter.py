@@ -172,6 +172,7 @@ def test_two_pass_filter_selects_what_the_one_pass_filter_selects(engine, N, T, 
     three-term keys of those pairs against thr32) must let through exactly what the one-pass sweep lets through -- the
     candidate lists in front of the exact re-rank have the same lengths row by row -- and the results are the oracle's."""
     engine.set_option('prefilter', 1)
+    engine.set_option('prefilter_ball_bound', 0)        # the same thresholds for both filters (stage A' belongs to the two-pass form)
     F_unw, wt, F = setup(engine, N, Dt, seed=N % 97, offset=offset, scale=scale)
     assert engine.info('prefilter_bf16_active') == 1
     U = o.synthetic_targets(F_unw, T, seed=7) * wt
@@ -196,3 +197,13 @@ def test_two_pass_filter_selects_what_the_one_pass_filter_selects(engine, N, T, 
     if offset == 0.0 and N >= 20000 and T >= 32:
         # the point of the coarse pass: most tile pairs never reach the three-term keys (4.5 % at B*, tools/knn_time.py)
         assert pairs < 0.5 * ((T + 31) // 32) * n_tiles, pairs
+    # stage A' (the K-th smallest key among the units of the tiles nearest to a row as a second bound): same results, and
+    # the lists in front of the exact re-rank do not get longer
+    engine.set_option('prefilter_ball_bound', 1)
+    before = engine.info('f16_fallbacks')
+    cand, dist = engine.knn(U, K)
+    assert np.array_equal(cand, oc) and np.array_equal(dist, od)
+    if engine.info('f16_fallbacks') == before and lists[1] is not None:
+        assert engine.info('last_list_mean') <= lists[1][0] + 1e-9 and engine.info('last_list_max') <= lists[1][1]
+        print('lists N=%d T=%d K=%d: mean %.0f -> %.0f, max %.0f -> %.0f with the scout bound'
+              % (N, T, K, lists[1][0], engine.info('last_list_mean'), lists[1][1], engine.info('last_list_max')))
