@@ -470,6 +470,9 @@ void launch_viterbi_lb(const int64_t *cand, const double *tdist, const float *Jl
 __device__ __forceinline__ double jf_exact_cost(const float *__restrict__ JC_unw, int Jp, int Dj,
                                                 const double *__restrict__ wj, int64_t a, int64_t b)
 {
+    // the natural successor: unit_end_data[a] and unit_start_data[a + 1] are the SAME row of join_contexts, every
+    // difference is exactly 0.0 and so is the canonical sum -- the common winner of a column needs no gather at all
+    if (a + 1 == b) return 0.0;
     const f32x4 *__restrict__ re = reinterpret_cast<const f32x4 *>(JC_unw + (a + 1) * (int64_t)Jp);   // unit_end_data[a]
     const f32x4 *__restrict__ rs = reinterpret_cast<const f32x4 *>(JC_unw + b * (int64_t)Jp);         // unit_start_data[b]
     double acc = 0.0;

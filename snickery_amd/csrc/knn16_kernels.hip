@@ -1745,6 +1745,154 @@ bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, con
     return false;
 }
 
+// ===========================================================================================================
+// Rows of 257 .. 512 columns (the doubled join rows of an epoch voice from train_halfphone, 2 x 151 columns, as a K-NN
+// database: initialise_join_table_with_knn, script/active_learning_join.py:184-212; script/train_halfphone.py:263-266).
+// A database tile's fragments of that many k-blocks do not stay in registers, so this is an ordinary blocked product:
+// a workgroup of four wavefronts takes 4 database tiles x 4 query tiles; wavefront w keeps the accumulators of ITS database
+// tile against the four query tiles (64 registers), loads its tile's pieces of a k-block from global memory and stages
+// query tile w's pieces in LDS for everybody (double buffered, one barrier per k-block); 4 TERMS MFMAs per k-block and
+// wavefront.  Same operands (build_db16b / prepare_queries16b: [tile][kb][piece][lane]), same MFMA order and chains (one
+// 64-column chunk through C, the chunks' sums added in float32) as knn_sweep16b: its key bound eps applies unchanged.
+// MODE 0: stage A on the sample operand (one group per (tile, lane half): gmin32[row][2 tile + half]);
+// MODE 1: the filter -- keys under the row threshold go to the entry pool like knn_refine16b's.
+// ===========================================================================================================
+template <int MODE, int TERMS>
+__global__ void __launch_bounds__(256, 2)
+knn_wide16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, int KB, const float *__restrict__ thr32, int nQT,
+            int64_t n_tiles, float *__restrict__ gmin32, int64_t G, PoolEntry16 *__restrict__ pool,
+            unsigned int *__restrict__ pool_ctl, int *__restrict__ chunk_fill, int max_chunks, int pool_chunk)
+{
+    constexpr int STAGE_CAP = (MODE == 1) ? 1024 + 64 : 1;
+    __shared__ PoolEntry16 stage[(MODE == 1) ? 4 : 1][STAGE_CAP];
+    __shared__ u32x4 Qs[2][4][2][64];                          // [buffer][query tile of the group][hi, lo][lane]
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qcol = lane & 31;
+    int chunk_id = -1, cused = pool_chunk, lcount = 0;
+    auto new_chunk = [&]() {
+        if (chunk_id >= 0 && lane == 0) chunk_fill[chunk_id] = cused;
+        unsigned int c = 0;
+        if (lane == 0) c = atomicAdd(&pool_ctl[0], 1u);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if ((int)c >= max_chunks) { if (lane == 0) pool_ctl[1] = 1u; chunk_id = -1; }
+        else chunk_id = (int)c;
+        cused = 0;
+    };
+    auto flush_stage = [&]() {
+        if (cused + lcount > pool_chunk) new_chunk();
+        if (chunk_id >= 0)
+            for (int e = lane; e < lcount; e += 64)
+                pool[(int64_t)chunk_id * pool_chunk + cused + e] = stage[wv][e];
+        cused += lcount;
+        lcount = 0;
+    };
+    auto mfma = [](const u32x4 &a, const u32x4 &b, f16acc c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+    const int64_t n_tg = (n_tiles + 3) / 4;
+    const int n_qg = (nQT + 3) / 4;
+    const int64_t n_items = n_tg * n_qg;
+    // consecutive items of a workgroup share the database tiles (query groups innermost)
+    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int64_t tg = item / n_qg;
+        const int qg = (int)(item % n_qg);
+        int64_t tile = tg * 4 + wv;
+        const bool tile_ok = tile < n_tiles;
+        if (!tile_ok) tile = n_tiles - 1;                      // (loads stay in range; nothing of it is kept)
+        int qt_mine = qg * 4 + wv;
+        if (qt_mine >= nQT) qt_mine = nQT - 1;
+        f16acc acc[4], part[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[j][r] = 0.0f; part[j][r] = 0.0f; }
+        u32x4 ah = A16[((tile * KB + 0) * 2 + 0) * 64 + lane], al = A16[((tile * KB + 0) * 2 + 1) * 64 + lane];
+        u32x4 qh = B16[(((int64_t)qt_mine * KB + 0) * 2 + 0) * 64 + lane], ql = B16[(((int64_t)qt_mine * KB + 0) * 2 + 1) * 64 + lane];
+        for (int kb = 0; kb < KB; ++kb) {
+            const u32x4 ahc = ah, alc = al;
+            Qs[kb & 1][wv][0][lane] = qh;
+            Qs[kb & 1][wv][1][lane] = ql;
+            if (kb + 1 < KB) {
+                ah = A16[((tile * KB + kb + 1) * 2 + 0) * 64 + lane]; al = A16[((tile * KB + kb + 1) * 2 + 1) * 64 + lane];
+                qh = B16[(((int64_t)qt_mine * KB + kb + 1) * 2 + 0) * 64 + lane]; ql = B16[(((int64_t)qt_mine * KB + kb + 1) * 2 + 1) * 64 + lane];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 bh = Qs[kb & 1][j][0][lane], bl = Qs[kb & 1][j][1][lane];
+                // per k-block: hi.hi, hi(db).lo(query), lo(db).hi(query) [, lo.lo]
+                part[j] = mfma(ahc, bh, part[j]);
+                part[j] = mfma(ahc, bl, part[j]);
+                part[j] = mfma(alc, bh, part[j]);
+                if (TERMS == 4) part[j] = mfma(alc, bl, part[j]);
+            }
+            if ((kb & 3) == 3 || kb == KB - 1) {               // a 64-column chunk is complete: its sum joins the total
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc[j][r] += part[j][r]; part[j][r] = 0.0f; }
+            }
+        }
+        __syncthreads();                                       // (the next item writes Qs[0])
+        if (!tile_ok) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int qt = qg * 4 + j;
+            if (qt >= nQT) break;                               // uniform
+            if (MODE == 0) {
+                float gm = FLT_MAX;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gm = fminf(gm, acc[j][r]);
+                gmin32[((int64_t)qt * 32 + qcol) * G + 2 * tile + (lane >> 5)] = gm;
+            } else {
+                const float pth = thr32[qt * 32 + qcol];
+                if (lcount > STAGE_CAP - 1024) flush_stage();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float key = acc[j][r];
+                    const bool pass = key <= pth;
+                    const unsigned long long mm = __ballot(pass);
+                    if (mm) {
+                        if (pass) {
+                            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
+                            PoolEntry16 en;
+                            en.key = (double)key;
+                            en.idx = (int)(tile * 32) + crow32(lane, r);
+                            en.row = qt * 32 + qcol;
+                            stage[wv][lcount + rank] = en;
+                        }
+                        lcount += __popcll(mm);
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 1) {
+        if (lcount) flush_stage();
+        if (chunk_id >= 0 && lane == 0) chunk_fill[chunk_id] = cused;
+    }
+}
+
+bool knn_wide16b_supported(int Dt, int Dpad) { return Dpad > 256 && Dpad <= 512 && Dpad - Dt >= 3; }
+
+void launch_knn_wide16b(int mode, int terms, int grid_cus, const void *A16, const void *B16, int Dpad, const float *thr32, int64_t T32,
+                        int64_t n_tiles, float *gmin32, int64_t G, void *pool, unsigned int *pool_ctl, int *chunk_fill,
+                        int max_chunks, int pool_chunk, hipStream_t s)
+{
+    const int nQT = (int)(T32 / 32), KB = Dpad / 16;
+    const int64_t n_items = ((n_tiles + 3) / 4) * ((nQT + 3) / 4);
+    int64_t blocks = 2 * (int64_t)grid_cus;
+    if (blocks > n_items) blocks = n_items;
+#define SNK_W16(MODE_, TERMS_)                                                                                        \
+    hipLaunchKernelGGL((knn_wide16b<MODE_, TERMS_>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)A16,     \
+                       (const u32x4 *)B16, KB, thr32, nQT, n_tiles, gmin32, G, (PoolEntry16 *)pool, pool_ctl, chunk_fill, \
+                       max_chunks, pool_chunk)
+    if (mode == 0) { if (terms == 4) SNK_W16(0, 4); else SNK_W16(0, 3); }
+    else { if (terms == 4) SNK_W16(1, 4); else SNK_W16(1, 3); }
+#undef SNK_W16
+}
+
 #define THR16_GROUPS 2048
 // ---------------------------------------------------------------------------
 // threshold from the f32 group minima: K-th smallest of G values + eps_t, as f32 rounded UP.

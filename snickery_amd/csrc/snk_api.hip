@@ -242,6 +242,8 @@ struct snk_engine {
     // f16-split prefilter state
     DevBuf a16h, a16l, s16h, s16l, b16h, b16l, eps16, thr32, gmin32, fmax2;
     bool f16_ready = false, cls16_ready = false;
+    bool wide16_ready = false;    // rows of 257 .. 512 columns: bf16-split operands for the blocked product (knn_wide16b)
+    int64_t wide_launches = 0;    // K-NN calls served by it
     DevBuf cls16_full, cls16_samp;      // class id per tile row of the two f32 operands
     int precision = 1;            // 1: f32 prefilter + exact f64 re-rank (default), 0: f64 sweep only
     int nt16 = 4, nt16_eff = 4;
@@ -254,7 +256,9 @@ struct snk_engine {
     DevBuf kth16;                 // sharded search: per-row second bound (K-th key of the local list, all-reduced)
     DevBuf ball_c, ball_cn, ball_rad, ball_c16, ball_tq, ball_nq;   // pass 0: tile centres (float64, norms, radii, bf16-split operand), per-row terms
     DevBuf ball_aq, ball_nql, ball_gmin, ball_bound;                // stage A' (scout): tile list per query tile, keys of their units per row, centre-key minima, the row's bound
-    int prefilter_ball_bound = 1; // 1: the thresholds also take the K-th smallest key of the units of the nearest tiles (stage A'; where the ball pass runs)
+    int prefilter_ball_bound = 0; // 1: the thresholds also take the K-th smallest key of the units of the nearest tiles (stage A'; where the ball pass
+                                  // runs).  Off by default: at B* it shortens the lists 1785 -> 568 entries per row and costs more (0.48 ms per 9 600 rows)
+                                  // than bucket + refine save (0.17 ms); DESIGN.md 4.1c
     int prefilter_balls = 1;      // 1: the tiles' balls list the pairs first; the coarse sweep runs only where they list too many
     double coarse_gate_fraction = 0.10;
     int64_t ball_tiles = 0;       // valid tiles of the ball operand (0: not built)
@@ -852,6 +856,37 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
             }
         }
     }
+    h->wide16_ready = false;
+    if (h->have_db && h->prefilter >= 1 && knn_wide16b_supported(h->Dt, h->Dpad)) {
+        // rows of 257 .. 512 columns (Synthesiser.join_knn on the doubled join rows of an epoch voice): bf16-split operands
+        // of the whole database and of the stage-A sample, one tile per slab; the blocked product of knn_wide16b serves
+        // both stages, the exact float64 re-rank is the one of every other width
+        const int terms = h->prefilter == 2 ? 4 : 3;
+        h->nt16_eff = 1;
+        CHK(h->fmax2.ensure(sizeof(double)));
+        launch_fmax(h->fnorm.as<double>(), h->N, h->fmax2.as<double>(), h->stream);
+        double fmax2 = 0.0;
+        CHK(d2h_sync(h, &fmax2, h->fmax2.p, sizeof(double), h->stream));
+        h->n_slabs16 = (h->N + 31) / 32;
+        int64_t stride = (int64_t)floor(1.0 / h->sample_frac + 0.5);
+        if (stride < 1) stride = 1;
+        while (stride > 1 && (h->N / stride) / 32 < h->min_sample_slabs) --stride;
+        h->stride16 = stride;
+        h->n_slabs16_a = (h->N / stride) / 32;
+        if (fmax2 < 1.0e30 && h->n_slabs16_a >= 1) {
+            const size_t per_tile = (size_t)8 * 64 * 16 * (h->Dpad / 64);
+            h->eps_c_bf = 1.02 * (SNK_BF16_MFMA_UNIT * (double)(terms * 4 + 1) + 6e-8 * (double)(2 * (h->Dpad / 64) + 1));
+            CHK(h->rho16.ensure(2 * sizeof(double)));
+            launch_db16b_ratios(h->Fw.as<double>(), h->N, h->Dt, h->Dpad, h->rho16.as<double>(), h->stream);
+            CHK(h->a16l.ensure(h->n_slabs16 * per_tile));
+            CHK(h->s16l.ensure(h->n_slabs16_a * per_tile));
+            launch_build_db16b(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, h->n_slabs16, 0, 0, 1, h->a16l.p, h->stream);
+            launch_build_db16b(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, h->n_slabs16_a, stride,
+                               2 * h->n_slabs16_a, 1, h->s16l.p, h->stream);
+            HIPCHK(hipGetLastError());
+            h->wide16_ready = true;
+        }
+    }
     h->gs_ready = false;
     if (h->gs_rows > 0 && h->f16_ready) {
         // the replicated global sample in the operand layout of stage A (groups scattered over the sample)
@@ -1027,6 +1062,82 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         }
         if (deferred_status) HIPCHK(hipMemsetAsync(deferred_status, 0, sizeof(int), h->stream));
         return 0;
+    }
+    if (h->Dpad > 256 && h->wide16_ready && h->precision == 1 && !qclass_dev && !bound_out && !bound_in && !deferred_status &&
+        2 * h->n_slabs16_a >= K) {
+        // 257 .. 512 columns: stage A and the filter as a blocked bf16-split product (knn_wide16b), bucket and the exact
+        // float64 re-rank as for every other width; a list or pool overflow sends the call to the exact selection below
+        const int64_t Tpad = roundup(T, 32);
+        const KnnPlan p0 = make_plan(h, K);
+        int cap = h->cap;
+        if (cap < 40 * K) cap = 40 * K < 8192 ? 40 * K : 8192;
+        const int64_t G16 = 2 * h->n_slabs16_a;
+        const int terms = h->prefilter == 2 ? 4 : 3;
+        CHK(h->Qp.ensure((size_t)Tpad * h->Dpad * sizeof(double)));
+        CHK(h->qnorm.ensure((size_t)Tpad * sizeof(double)));
+        CHK(h->thr.ensure((size_t)Tpad * sizeof(double)));
+        CHK(h->cnt.ensure((size_t)Tpad * sizeof(int)));
+        CHK(h->lkey.ensure((size_t)Tpad * cap * sizeof(double)));
+        CHK(h->lidx.ensure((size_t)Tpad * cap * sizeof(int)));
+        CHK(h->status.ensure(sizeof(int)));
+        int max_chunks = h->pool_chunks;
+        {
+            const int64_t want_row = 20 * (int64_t)K > 3072 ? 20 * (int64_t)K : 3072;
+            const int64_t need = (Tpad * (cap < want_row ? cap : want_row)) / knn_pool_chunk_entries() + 2048;
+            if (need > max_chunks) max_chunks = (int)need;
+        }
+        if (h->pool_chunk_limit > 0 && max_chunks > h->pool_chunk_limit) max_chunks = h->pool_chunk_limit;
+        CHK(h->pool.ensure(knn_pool_bytes(max_chunks)));
+        CHK(h->poolctl.ensure(2 * sizeof(unsigned int)));
+        CHK(h->chunkfill.ensure((size_t)max_chunks * sizeof(int)));
+        CHK(h->b16l.ensure((size_t)(Tpad / 32) * 8 * 64 * 16 * (h->Dpad / 64)));
+        CHK(h->eps16.ensure((size_t)Tpad * sizeof(double)));
+        CHK(h->cq16.ensure((size_t)Tpad * sizeof(double)));
+        CHK(h->thr32.ensure((size_t)Tpad * sizeof(float)));
+        CHK(h->gmin32.ensure((size_t)Tpad * G16 * sizeof(float)));
+        hipStream_t s = h->stream;
+        {
+            StageTimer t(h, s, TM_PREP);
+            launch_prepare_queries(Qdev, T, h->Dt, h->Qp.as<double>(), nullptr, h->qnorm.as<double>(), Tpad, h->Dpad, s);
+            launch_knn_reset(h->cnt.as<int>(), Tpad, h->status.as<int>(), h->poolctl.as<unsigned int>(), h->slabctr.as<unsigned int>(),
+                             h->chunkfill.as<int>(), max_chunks, s);
+            launch_prepare_queries16b(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad, h->fmax2.as<double>(),
+                                      h->rho16.as<double>(), h->eps_c_bf, h->b16l.p, h->eps16.as<double>(), h->cq16.as<double>(), s);
+        }
+        {
+            StageTimer t(h, s, TM_KNN_MINIMA);
+            launch_knn_wide16b(0, terms, p0.grid_cus, h->s16l.p, h->b16l.p, h->Dpad, nullptr, Tpad, h->n_slabs16_a, h->gmin32.as<float>(), G16,
+                               nullptr, nullptr, nullptr, 0, knn_pool_chunk_entries(), s);
+        }
+        {
+            StageTimer t(h, s, TM_KNN_THRESHOLD);
+            launch_knn_threshold16(h->gmin32.as<float>(), G16, T, Tpad, K, h->eps16.as<double>(), h->thr.as<double>(), h->thr32.as<float>(),
+                                   nullptr, nullptr, s);
+        }
+        {
+            StageTimer t(h, s, TM_KNN_FILTER);
+            launch_knn_wide16b(1, terms, p0.grid_cus, h->a16l.p, h->b16l.p, h->Dpad, h->thr32.as<float>(), Tpad, h->n_slabs16, nullptr, 0,
+                               h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, knn_pool_chunk_entries(), s);
+        }
+        {
+            StageTimer t(h, s, TM_KNN_BUCKET);
+            launch_knn_bucket(h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, Tpad, h->N, h->cnt.as<int>(),
+                              h->lkey.as<double>(), h->lidx.as<int>(), cap, h->status.as<int>(), s);
+        }
+        {
+            StageTimer t(h, s, TM_KNN_FINALIZE);
+            launch_knn_finalize(h->Fw.as<double>(), h->F_unw.as<float>(), h->Fp, h->wt.as<double>(), h->Dpad, h->Dt, h->Qp.as<double>(),
+                                h->qnorm.as<double>(), T, K, h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap, h->shard_offset,
+                                h->eps16.as<double>(), h->fnorm.as<double>(), h->eps_c_bf, h->cq16.as<double>(), cand_dev, dist_dev, d2_dev,
+                                h->status.as<int>(), nullptr, s, false, h->thr.as<double>(), h->margin_stat.as<unsigned int>());
+        }
+        int status = 0;
+        CHK(d2h_sync(h, &status, h->status.p, sizeof(int), s));
+        HIPCHK(hipGetLastError());
+        h->last_retries = 0; h->last_T = T;
+        h->last_f16_status = status;
+        if (status == 0) { h->wide_launches += 1; return 0; }
+        h->f16_fallbacks += 1;               // overflow or too many near ties: the exact selection below serves the call
     }
     if (h->Dpad > 256) {
         // Rows wider than a database row's fragments fit a wavefront's registers: every row through the exact selection
@@ -3346,6 +3457,8 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "prefilter_two_pass")) *out = h->prefilter_two_pass;
     else if (!strcmp(name, "prefilter_balls")) *out = h->prefilter_balls;
     else if (!strcmp(name, "prefilter_ball_bound")) *out = h->prefilter_ball_bound;
+    else if (!strcmp(name, "wide_launches")) *out = (double)h->wide_launches;
+    else if (!strcmp(name, "wide_ready")) *out = h->wide16_ready ? 1 : 0;
     else if (!strcmp(name, "filter_coarse")) *out = h->filter_coarse ? 1 : 0;       // 1: the ball pass listed too many pairs for this voice
     else if (!strcmp(name, "ball_switches")) *out = (double)h->ball_switches;
     else if (!strcmp(name, "coarse_pairs") || !strcmp(name, "coarse_pair_overflow")) {

@@ -142,6 +142,11 @@ int knn_scout_keys_per_row();
 size_t knn_scout_list_bytes(int64_t T32);
 bool launch_knn_scout16b(int terms, int dch, int grid_cus, const void *C16, const void *A16, const void *B16, int64_t T, int64_t T32,
                          int64_t n_tiles, float *smin, unsigned int *list, float *gkeys, hipStream_t s);
+// rows of 257 .. 512 columns: blocked bf16-split product (knn16_kernels.hip)
+bool knn_wide16b_supported(int Dt, int Dpad);
+void launch_knn_wide16b(int mode, int terms, int grid_cus, const void *A16, const void *B16, int Dpad, const float *thr32, int64_t T32,
+                        int64_t n_tiles, float *gmin32, int64_t G, void *pool, unsigned int *pool_ctl, int *chunk_fill,
+                        int max_chunks, int pool_chunk, hipStream_t s);
 // bf16-split prefilter (knn16_kernels.hip)
 bool knn_sweep16b_supported(int nt, int dch, int Dt, int Dpad, bool cls);
 void launch_build_db16b(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,

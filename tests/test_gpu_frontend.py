@@ -339,20 +339,23 @@ preload_all_magphase_utts = False
     op, ocost = o.viterbi(oc, od, E, S)
     assert path == op and synth.last_path_cost == ocost
     # the all-pairs join K-NN (initialise_join_table_with_knn, active_learning_join.py:184-212) on this voice's doubled
-    # [j_t, j_t+1] join rows: 2 x 151 = 302 columns, wider than the matrix sweeps take -- the engine's canonical-distance
-    # selection serves them; bit-exact against the oracle's brute force, natural successors first at distance 0
+    # [j_t, j_t+1] join rows: 2 x 151 = 302 columns -- the blocked bf16-split product of knn_wide16b + the exact re-rank
+    # (the matrix path: asserted below); bit-exact against the oracle's brute force, natural successors first at distance 0
     assert S.shape[1] == 302
     n = min(S.shape[0], 300)
     idx, dist = synth.join_knn(7, first=1, last=n)
     oi, od2 = o.knn_bruteforce(E, S[1:n], 7)
     assert np.array_equal(idx, oi) and np.array_equal(dist, od2)
     assert np.all(idx[:, 0] == np.arange(1, n) - 1) and np.all(dist[:, 0] == 0.0)
+    assert synth._join_engine.info('wide_launches') >= 1 and synth._join_engine.info('exact_row_fallbacks') == 0
     synth.close()
 
 
-def test_wide_rows_take_the_exact_selection():
-    """K-NN on rows of 257 .. 512 columns (wider than the 256 the matrix sweeps take): plain, class-restricted, more
-    query rows than one launch's scratch takes, K = 200, ties by lowest id."""
+def test_wide_rows_take_the_matrix_path():
+    """K-NN on rows of 257 .. 512 columns (the doubled join rows of an epoch voice as a database: initialise_join_table_with_knn,
+    active_learning_join.py:184-212): the blocked bf16-split product (knn_wide16b) + exact float64 re-rank serves the plain
+    search -- asserted through the wide_launches counter --, the canonical-distance selection the class-restricted one and
+    `precision 0`; K = 200, exact duplicates (ties: the lower id first), the oracle's candidates and distances bit for bit."""
     import snickery_amd
     N, Dt, K = 5000, 302, 200
     F_unw, JC_unw = o.synthetic_db(N, Dt, 8, seed=91)
@@ -362,12 +365,19 @@ def test_wide_rows_take_the_exact_selection():
     e = snickery_amd.HipSearchEngine(0)
     e.upload_db(F_unw, JC_unw)
     e.set_weights(wt, np.full(8, 0.1))
+    assert e.info('wide_ready') == 1
     F = o.weight(F_unw, wt)
     U = np.vstack([o.synthetic_targets(F_unw, 40, seed=93), F_unw[50:60].astype(np.float64)]) * wt
+    before = e.info('wide_launches')
     cand, dist = e.knn(U, K)
+    assert e.info('wide_launches') == before + 1 and e.info('f16_fallbacks') == 0
     oc_, od_ = o.knn_bruteforce(F, U, K)
     assert np.array_equal(cand, oc_) and np.array_equal(dist, od_)
     assert list(cand[40:, 0]) == list(range(50, 60)) and list(cand[40:, 1]) == list(range(4000, 4010))
+    e.set_option('precision', 0)                         # the exact selection (a workgroup per query row): same results
+    c0, d0 = e.knn(U, K)
+    assert e.info('wide_launches') == before + 1 and np.array_equal(c0, oc_) and np.array_equal(d0, od_)
+    e.set_option('precision', 1)
     cls = rng.randint(0, 7, size=N).astype(np.int32)
     qc = rng.randint(0, 7, size=U.shape[0]).astype(np.int32)
     e.set_unit_classes(cls)
@@ -375,6 +385,28 @@ def test_wide_rows_take_the_exact_selection():
     oc2, od2 = o.knn_by_class(F, U, 30, cls, qc)
     assert np.array_equal(c2, oc2) and np.array_equal(d2, od2)
     assert e.info('f16_ready') == 0
+    e.close()
+
+
+@pytest.mark.parametrize('N,Dt,T,K', [(60000, 302, 700, 100), (20000, 257, 33, 7), (40000, 509, 100, 50), (9000, 317, 64, 1)])
+def test_wide_rows_against_the_c_oracle(N, Dt, T, K):
+    """The blocked product at database sizes where stage A works on a sample (stride > 1), at the widths' edges (257: five
+    k-blocks of a 320-column pad; 317 and 509: the last widths with three spare columns in their pads) and K = 1."""
+    import snickery_amd
+    import snk_oracle_c as oc
+    F_unw, JC_unw = o.synthetic_db(N, Dt, 8, seed=N % 71)
+    rng = np.random.RandomState(5)
+    wt = 0.1 + rng.rand(Dt)
+    e = snickery_amd.HipSearchEngine(0)
+    e.upload_db(F_unw, JC_unw)
+    e.set_weights(wt, np.full(8, 0.1))
+    assert e.info('wide_ready') == 1
+    F = o.weight(F_unw, wt)
+    U = np.vstack([o.synthetic_targets(F_unw, T - T // 3, seed=3), F_unw[rng.randint(0, N, T // 3)] + 0.2 * rng.randn(T // 3, Dt)]) * wt
+    cand, dist = e.knn(U, K)
+    assert e.info('wide_launches') == 1 and e.info('f16_fallbacks') == 0
+    oc_, od_ = oc.knn(F, U, K)
+    assert np.array_equal(cand, oc_) and np.array_equal(dist, od_)
     e.close()
 
 

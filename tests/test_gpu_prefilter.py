@@ -199,7 +199,7 @@ def test_two_pass_filter_selects_what_the_one_pass_filter_selects(engine, N, T, 
         assert pairs < 0.5 * ((T + 31) // 32) * n_tiles, pairs
     # stage A' (the K-th smallest key among the units of the tiles nearest to a row as a second bound): same results, and
     # the lists in front of the exact re-rank do not get longer
-    engine.set_option('prefilter_ball_bound', 1)
+    engine.set_option('prefilter_ball_bound', 1)         # (an option: off by default)
     before = engine.info('f16_fallbacks')
     cand, dist = engine.knn(U, K)
     assert np.array_equal(cand, oc) and np.array_equal(dist, od)
@@ -207,3 +207,4 @@ def test_two_pass_filter_selects_what_the_one_pass_filter_selects(engine, N, T, 
         assert engine.info('last_list_mean') <= lists[1][0] + 1e-9 and engine.info('last_list_max') <= lists[1][1]
         print('lists N=%d T=%d K=%d: mean %.0f -> %.0f, max %.0f -> %.0f with the scout bound'
               % (N, T, K, lists[1][0], engine.info('last_list_mean'), lists[1][1], engine.info('last_list_max')))
+    engine.set_option('prefilter_ball_bound', 0)
