@@ -701,6 +701,15 @@ def main():
                                                   'float32-grade keys on the bf16 pipe cost %d bf16 MFMA terms per product (hi.hi + hi.lo + '
                                                   'lo.hi%s) on Dt padded to 64 columns; frac above prices only the algorithmic '
                                                   '2 N rows Dt flops against the bf16 peak') % (terms, ' + lo.lo' if terms == 4 else '')}
+        cfile = os.path.join(ROOT, 'profiles', 'r04_filter_counters.json')
+        if world == 1 and N == 1048576 and Dt == 61 and two_pass and os.path.isfile(cfile):
+            with open(cfile) as f:
+                cj = json.load(f)
+            if int(cj.get('rows_per_launch', 0)) == int(round(rows_per_launch)):
+                out['filter_stage']['traffic'] = cj['hbm_bytes_per_launch']
+                out['filter_stage']['traffic_ratio'] = cj['traffic_ratio']
+                out['filter_stage']['mfma_busy'] = cj['mfma_busy']
+                out['filter_stage']['traffic_source'] = 'profiles/r04_filter_counters.json (separate --pmc passes of these kernels and this shape; not measured in this run)'
         if world == 1 and bf16_mode:
             # tripwire of the bf16-split prefilter's key bound (untimed, after the timed region): the same step with the
             # float32-operand prefilter, whose bound is the analytical one of an f32 FMA chain, must select the same units;

@@ -1374,7 +1374,7 @@ knn_balls16b(const u32x4 *__restrict__ C16, const u32x4 *__restrict__ B16, const
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t t = ct * 32 + crow32(lane, r);
-            rv[r] = t < n_tiles ? rad[t] : -FLT_MAX;
+            rv[r] = t < n_tiles ? rad[t] : __builtin_nanf("");
         }
         u32x4 b0[KB][2], b1[KB][2];
         float t0 = 0.f, n0 = 0.f, t1 = 0.f, n1 = 0.f;
@@ -1409,14 +1409,14 @@ knn_balls16b(const u32x4 *__restrict__ C16, const u32x4 *__restrict__ B16, const
                 }
             }
             if (pcount > 96 - 32) flush_pairs();
+            // key~(c) <= (tq + r)^2 - nq, the right side rounded up: (tq + r)^2 (1 + 2^-21) - nq + 2^-21 |nq| + 1e-30 (a relative
+            // 2^-21 of both terms covers the three float32 roundings); the column's part is taken once per query tile.  A row
+            // past the database carries a NaN radius: its comparison is false.
+            const float kq = __builtin_fmaf(4.76837158203125e-07f, __builtin_fabsf(nn), -nn) + 1e-30f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                // key~(c) <= (tq + r)^2 - nq, the right side rounded up (a relative 2^-21 of both terms covers the three
-                // float32 roundings); a negative radius marks a row past the database
                 const float sr = rv[r] + tt;
-                const float rhs = __builtin_fmaf(sr, sr, -nn);
-                const float slack = 4.76837158203125e-07f * (sr * sr + __builtin_fabsf(nn)) + 1e-30f;
-                const bool pass = rv[r] >= 0.f && sr >= 0.f && acc[r] <= rhs + slack;
+                const bool pass = acc[r] <= __builtin_fmaf(sr * sr, 1.f + 4.76837158203125e-07f, kq);
                 const unsigned long long mm = __ballot(pass);
                 if (mm) {
                     // lanes 0..31 hold row crow32(0, r), lanes 32..63 row crow32(32, r): one pair per row with any passing column

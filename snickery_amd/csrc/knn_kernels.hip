@@ -954,7 +954,10 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
         const int id = lidx[row * cap + i];
         key[i] = (KeyT)v; idx[i] = id;
         kmin = fmin(kmin, v); kmax = fmax(kmax, v);
-        if (eps) fmax2 = fmax(fmax2, fnorm[id]);       // largest ||f||^2 among THIS row's survivors
+        // (the margin below used the largest ||f||^2 among THIS row's survivors: a dependent 8-byte gather per list entry,
+        // 16 M of them per B* launch and the longest part of the row's critical path; the row's eps -- the same bound with
+        // the largest norm of the database -- is what the filter assumed anyway)
+        (void)id;
     }
     red_min[threadIdx.x] = kmin; red_max[threadIdx.x] = kmax;
     __shared__ double red_fm[256];
@@ -975,12 +978,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
     // margin is widened by 2 max_i e_i over the survivors of THIS row (their norms, not the largest
     // norm of the whole database that the filter threshold has to assume)
     double margin = 0.0;
-    if (eps) {
-        const double fm = sqrt(red_fm[0]), qn = sqrt(qnorm[row]);
-        // (bf16-split keys: cq[row] ||f|| for what the split drops, eps_c for the accumulation -- knn16_kernels.hip)
-        margin = 2.0 * ((cq ? cq[row] * fm : 0.0) + eps_c * (2.0 * qn * fm + fm * fm) + 1e-30);
-        if (margin > 2.0 * eps[row]) margin = 2.0 * eps[row];
-    }
+    if (eps) margin = 2.0 * eps[row];         // |key~ - key| <= eps[row] for every unit of the database (prepare_queries16[b])
     const double scale = (kmax > kmin) ? 256.0 / (kmax - kmin) : 0.0;
     bool fast = (n > 4 * K && n > 256) && (scale > 0.0) && (kk == K);
     if (fast) {
