@@ -1152,23 +1152,29 @@ knn_refine16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, cons
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     };
     const unsigned int wave_id = blockIdx.x * 4u + (unsigned int)wv, wave_stride = gridDim.x * 4u;
-    // operands of a pair: database tile (hi, lo), query tile (hi, lo); the next pair's are requested before this
-    // one's arithmetic
-    u32x4 a0[KB][2], b0[KB][2], a1[KB][2], b1[KB][2];
-    float th0 = 0.f, th1 = 0.f;
+    // operands of a pair: database tile (hi, lo), query tile (hi, lo).  The database tiles alternate between two register
+    // sets (the next pair's is requested before this one's arithmetic); the QUERY tile is loaded only when it changes -- the
+    // ball pass lists the pairs of one (stretch of the database, query tile) next to each other, so runs of pairs share it
+    // (every pair re-reading both tiles made the stage L2-bound: 8 x the algorithmic bytes, profiles/r03_traffic_filter.json)
+    // -- into the set that is not in use, so that its load too lies behind arithmetic.
+    u32x4 a0[KB][2], a1[KB][2], qA[KB][2], qB[KB][2];
+    float thA = 0.f, thB = 0.f;
     CoarsePair p0{0u, 0u}, p1{0u, 0u};
-    auto load_pair = [&](unsigned int i, CoarsePair &pr, u32x4 (&a)[KB][2], u32x4 (&b)[KB][2], float &th) {
+    auto load_a = [&](unsigned int i, CoarsePair &pr, u32x4 (&a)[KB][2]) {
         const unsigned int k = i < n_pairs ? i : n_pairs - 1u;
         pr = pairs[k];
         pr.tile = __builtin_amdgcn_readfirstlane(pr.tile); pr.qtile = __builtin_amdgcn_readfirstlane(pr.qtile);
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {
-                a[kb][pc] = A16[(((int64_t)pr.tile * KB + kb) * 2 + pc) * 64 + lane];
-                b[kb][pc] = B16[(((int64_t)pr.qtile * KB + kb) * 2 + pc) * 64 + lane];
-            }
-        th = thr32[pr.qtile * 32u + (unsigned int)qcol];
+            for (int pc = 0; pc < 2; ++pc) a[kb][pc] = A16[(((int64_t)pr.tile * KB + kb) * 2 + pc) * 64 + lane];
+    };
+    auto load_q = [&](unsigned int qtile, u32x4 (&b)[KB][2], float &th) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) b[kb][pc] = B16[(((int64_t)qtile * KB + kb) * 2 + pc) * 64 + lane];
+        th = thr32[qtile * 32u + (unsigned int)qcol];
     };
     auto work = [&](const CoarsePair &pr, const u32x4 (&a)[KB][2], const u32x4 (&b)[KB][2], float pth) {
         // knn_sweep16b's order: per k-block hi.hi, hi(db).lo(query), lo(db).hi(query) [, lo.lo]; chains of one 64-column
@@ -1219,16 +1225,47 @@ knn_refine16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, cons
     constexpr unsigned int BL = 8u;
     auto idx = [&](unsigned int j) { return (wave_id + (j / BL) * wave_stride) * BL + (j % BL); };
     if (idx(0u) < n_pairs) {
-        load_pair(idx(0u), p0, a0, b0, th0);
-        for (unsigned int j = 0u;; j += 2u) {
-            const unsigned int i1 = idx(j + 1u);
-            load_pair(i1, p1, a1, b1, th1);
-            work(p0, a0, b0, th0);
-            if (i1 >= n_pairs) break;
-            const unsigned int i2 = idx(j + 2u);
-            load_pair(i2, p0, a0, b0, th0);
-            work(p1, a1, b1, th1);
-            if (i2 >= n_pairs) break;
+        load_a(idx(0u), p0, a0);
+        load_q(p0.qtile, qA, thA);
+        if constexpr (KB <= 4) {
+            int cur = 0;                                       // which query set holds the tile of the pair in work (uniform)
+            unsigned int cur_qt = p0.qtile;
+            // one pair out of (a, p) while the next pair's database tile -- and its query tile, if another -- are requested
+            auto pair_step = [&](const CoarsePair &p, const u32x4 (&a)[KB][2], unsigned int i_next, CoarsePair &pn, u32x4 (&an)[KB][2]) {
+                load_a(i_next, pn, an);
+                const bool sw = pn.qtile != cur_qt;            // uniform
+                if (cur == 0) {
+                    if (sw) load_q(pn.qtile, qB, thB);
+                    work(p, a, qA, thA);
+                } else {
+                    if (sw) load_q(pn.qtile, qA, thA);
+                    work(p, a, qB, thB);
+                }
+                if (sw) { cur ^= 1; cur_qt = pn.qtile; }
+            };
+            for (unsigned int j = 0u;; j += 2u) {
+                const unsigned int i1 = idx(j + 1u);
+                pair_step(p0, a0, i1, p1, a1);
+                if (i1 >= n_pairs) break;
+                const unsigned int i2 = idx(j + 2u);
+                pair_step(p1, a1, i2, p0, a0);
+                if (i2 >= n_pairs) break;
+            }
+        } else {
+            // wider rows: the two-way choice of the query set costs registers these instances do not have (KB = 12 spilled
+            // 161): every pair brings both tiles, into the set of its parity
+            for (unsigned int j = 0u;; j += 2u) {
+                const unsigned int i1 = idx(j + 1u);
+                load_a(i1, p1, a1);
+                load_q(p1.qtile, qB, thB);
+                work(p0, a0, qA, thA);
+                if (i1 >= n_pairs) break;
+                const unsigned int i2 = idx(j + 2u);
+                load_a(i2, p0, a0);
+                load_q(p0.qtile, qA, thA);
+                work(p1, a1, qB, thB);
+                if (i2 >= n_pairs) break;
+            }
         }
     }
     if (lcount) flush_stage();
