@@ -531,7 +531,12 @@ void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int
     if ((size_t)Tpad * sizeof(int) > 65536)
         lds_attr_ensure(attr, (size_t)Tpad * sizeof(int), [&] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)Tpad * sizeof(int))); });
-    hipLaunchKernelGGL(knn_bucket_kernel, dim3(1024), dim3(256), (size_t)Tpad * sizeof(int), s,
+    // one workgroup per compute unit and LDS share: with 128 KB of histogram (32 768 rows: the sharded search's calls) a
+    // compute unit holds one workgroup, and 1 024 of them were four rounds of clearing it
+    const size_t lds = (size_t)Tpad * sizeof(int);
+    int per_cu = (int)((size_t)(160 * 1024) / (lds + 1024));
+    per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
+    hipLaunchKernelGGL(knn_bucket_kernel, dim3(256 * per_cu), dim3(256), lds, s,
                        reinterpret_cast<const PoolEntry *>(pool), pool_ctl, chunk_fill, max_chunks,
                        (int)Tpad, (int)n_valid, cnt, lkey, lidx, cap, status);
 }
