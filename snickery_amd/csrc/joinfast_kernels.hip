@@ -538,6 +538,159 @@ join_exact_sparse_kernel(const float *__restrict__ JC_unw, int Jp, int Dj, const
     dst[3] = (f64x2){c[3], __builtin_bit_cast(double, (unsigned long long)ix | ((unsigned long long)n_raw << 32))};
 }
 
+// pass 3, cooperative form (the default; g_exact_form 0 selects the kernel above): the same records, the same canonical
+// costs.  The kernel above gives a lane a cell and walks its rows with 16-byte loads: every load instruction of a wavefront
+// touches 64 different rows, and the address unit serves one line per cycle -- 0.40 ms per 9 600 rows at B*, address-bound
+// with half the lanes idle (a cell has one to four predecessors).  Here a workgroup (two wavefronts, 128 cells) first lists
+// its REAL costs (predecessor usable, not the natural successor -- whose cost is exactly 0 without a look at the rows), then
+// takes them 128 at a time, one cost per lane: the rows of a wavefront's 64 costs come in 16-column chunks by loads in which
+// four neighbouring lanes read 64 consecutive bytes of ONE row (16 rows per instruction instead of 64), go through a
+// wavefront-private LDS tile (pitch 20 floats: conflict-free both ways) and come back to the cost's own lane for the
+// canonical column-by-column sum; the next chunk's loads are in flight meanwhile.
+#define JX_T 128               // threads = cells per workgroup
+#define JX_PITCH 20            // floats per row of the transposition tile (16 + 4: bank-conflict-free 16-byte accesses)
+__global__ void __launch_bounds__(JX_T)
+join_exact_sparse2_kernel(const float *__restrict__ JC_unw, int Jp, int Dj, const double *__restrict__ wj,
+                          int64_t n_units, const int64_t *__restrict__ cand, const double *__restrict__ tdist,
+                          int64_t R, int K, const u32x4 *__restrict__ sets, JfRecord *__restrict__ rec)
+{
+    __shared__ __align__(16) float tile[JX_T / 64][2][64 * JX_PITCH];        // [wavefront][E, S][cost][column of the chunk]
+    __shared__ double c_s[JX_T][JF_CAP];
+    __shared__ int a_s[JX_T][JF_CAP], b_s[JX_T];
+    __shared__ unsigned short item_s[JX_T * JF_CAP];
+    __shared__ int wtot[JX_T / 64], total_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t cell = (int64_t)blockIdx.x * JX_T + tid;
+    const bool live = cell < R * K;
+    // ---- this cell: set, predecessors, which of its costs need the rows ----
+    u32x4 st = {0u, 0u, 0u, 0u};
+    int64_t b = -1;
+    if (live) { st = sets[cell]; b = cand[cell]; }
+    const int n_raw = (int)st[3];
+    const int n = n_raw > JF_CAP ? JF_CAP : n_raw;
+    const int64_t t = live ? cell / K : 0;
+    const unsigned int ix = st[2];
+    const bool okb = jf_usable(b, n_units);
+    int mine = 0;
+    unsigned int need = 0u;
+#pragma unroll
+    for (int j = 0; j < JF_CAP; ++j) {
+        double c = __builtin_inf();
+        if (j < n) {
+            const int64_t a = cand[(t - 1) * K + ((ix >> (8 * j)) & 0xffu)];
+            if (jf_usable(a, n_units) && okb) {
+                if (a + 1 == b) c = 0.0;             // the natural successor: the same row of join_contexts on both sides
+                else { need |= 1u << j; ++mine; a_s[tid][j] = (int)a; }
+            }
+        }
+        c_s[tid][j] = c;
+    }
+    b_s[tid] = (int)b;
+    // ---- the workgroup's list of costs (prefix sum over the threads) ----
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    int base = incl - mine;
+    for (int w = 0; w < wv; ++w) base += wtot[w];
+    if (tid == JX_T - 1) total_s = base + mine;
+#pragma unroll
+    for (int j = 0; j < JF_CAP; ++j)
+        if (need & (1u << j)) item_s[base++] = (unsigned short)((tid << 2) | j);
+    __syncthreads();
+    const int total = total_s;
+    const int n_chunks = (Dj + 15) / 16;
+    const int g4 = lane >> 2, q = lane & 3;                 // loader role: rows 4 g4 + i, columns 4 q .. 4 q + 3 of the chunk
+    float *const tE = tile[wv][0], *const tS = tile[wv][1];
+    for (int r0 = 0; r0 < total; r0 += JX_T) {
+        // this lane's cost
+        const int it = r0 + tid;
+        const bool have = it < total;
+        const unsigned int code = have ? item_s[it] : 0u;
+        // rows of the four costs this lane loads for: items r0 + 64 wv + 4 g4 + i
+        const float *pe[4], *ps[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int it2 = r0 + 64 * wv + 4 * g4 + i;
+            const unsigned int cd = it2 < total ? item_s[it2] : 0u;
+            const int64_t a2 = it2 < total ? a_s[cd >> 2][cd & 3u] : 0, b2 = it2 < total ? b_s[cd >> 2] : 0;
+            pe[i] = JC_unw + (a2 + 1) * (int64_t)Jp;        // unit_end_data[a]   = JC[a+1]
+            ps[i] = JC_unw + b2 * (int64_t)Jp;              // unit_start_data[b] = JC[b]
+        }
+        f32x4 ge[4], gs[4];
+        auto fetch = [&](int ch) {
+            int c0 = ch * 16 + 4 * q;
+            if (c0 > Jp - 4) c0 = Jp - 4;                    // a quad beyond the row: any readable address (its columns are not used)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ge[i] = *reinterpret_cast<const f32x4 *>(pe[i] + c0);
+                gs[i] = *reinterpret_cast<const f32x4 *>(ps[i] + c0);
+            }
+        };
+        fetch(0);
+        double acc = 0.0;
+        for (int ch = 0; ch < n_chunks; ++ch) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f32x4 *>(tE + (4 * g4 + i) * JX_PITCH + 4 * q) = ge[i];
+                *reinterpret_cast<f32x4 *>(tS + (4 * g4 + i) * JX_PITCH + 4 * q) = gs[i];
+            }
+            if (ch + 1 < n_chunks) fetch(ch + 1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                 // the tile is this wavefront's own: LDS operations of a wavefront execute in order
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            f32x4 e[4], sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                e[u] = *reinterpret_cast<const f32x4 *>(tE + lane * JX_PITCH + 4 * u);
+                sv[u] = *reinterpret_cast<const f32x4 *>(tS + lane * JX_PITCH + 4 * u);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                 // ... read before the next chunk is written
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int c0 = ch * 16;
+            if (c0 + 16 <= Dj) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double w = wj[c0 + 4 * u + i];
+                        const double d = __dsub_rn(__dmul_rn((double)e[u][i], w), __dmul_rn((double)sv[u][i], w));
+                        acc = __dadd_rn(acc, __dmul_rn(d, d));
+                    }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (c0 + 4 * u + i < Dj) {           // uniform
+                            const double w = wj[c0 + 4 * u + i];
+                            const double d = __dsub_rn(__dmul_rn((double)e[u][i], w), __dmul_rn((double)sv[u][i], w));
+                            acc = __dadd_rn(acc, __dmul_rn(d, d));
+                        }
+            }
+        }
+        if (have) c_s[code >> 2][code & 3u] = __dsqrt_rn(acc);
+    }
+    __syncthreads();
+    if (!live) return;
+    const unsigned int w_d = st[0], w_x = st[1];
+    const double lb64 = (double)__builtin_bit_cast(float, w_d), x64 = (double)__builtin_bit_cast(float, w_x);
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2 *dst = reinterpret_cast<f64x2 *>(rec + cell);
+    dst[0] = (f64x2){okb ? tdist[cell] : __builtin_inf(), x64};
+    dst[1] = (f64x2){lb64, c_s[tid][0]};
+    dst[2] = (f64x2){c_s[tid][1], c_s[tid][2]};
+    dst[3] = (f64x2){c_s[tid][3], __builtin_bit_cast(double, (unsigned long long)ix | ((unsigned long long)n_raw << 32))};
+}
+
+static int g_exact_form = 1;
+void set_join_exact_form(int f) { g_exact_form = f ? 1 : 0; }
+
 size_t join_record_bytes() { return sizeof(JfRecord); }
 
 void launch_join_exact_sparse(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
@@ -545,6 +698,11 @@ void launch_join_exact_sparse(const float *JC_unw, int Jp, int Dj, const double 
 {
     static_assert(sizeof(JfRecord) == 64, "pass 4 streams 64-byte records");
     const int64_t cells = R * K;
+    if (g_exact_form == 1 && n_units < ((int64_t)1 << 31) && K <= 256) {
+        hipLaunchKernelGGL(join_exact_sparse2_kernel, dim3((unsigned)((cells + JX_T - 1) / JX_T)), dim3(JX_T), 0, s, JC_unw, Jp, Dj,
+                           wj, n_units, cand, tdist, R, K, reinterpret_cast<const u32x4 *>(sets), reinterpret_cast<JfRecord *>(rec));
+        return;
+    }
     hipLaunchKernelGGL(join_exact_sparse_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, JC_unw, Jp, Dj,
                        wj, n_units, cand, tdist, R, K, reinterpret_cast<const u32x4 *>(sets), reinterpret_cast<JfRecord *>(rec));
 }

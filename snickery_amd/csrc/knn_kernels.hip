@@ -953,7 +953,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
     // largest key of the list; every entry in the bins up to (and one past) the bin holding the
     // K-th smallest key is re-ranked exactly.  Falls back to the full sort when that set does
     // not fit SELM (massive ties).
-    double kmin = DBL_MAX, kmax = -DBL_MAX, fmax2 = 0.0;
+    double kmin = DBL_MAX, kmax = -DBL_MAX;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const double v = lkey[row * cap + i];
         const int id = lidx[row * cap + i];
@@ -964,20 +964,22 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
         // the largest norm of the database -- is what the filter assumed anyway)
         (void)id;
     }
-    red_min[threadIdx.x] = kmin; red_max[threadIdx.x] = kmax;
     __shared__ double red_fm[256];
-    red_fm[threadIdx.x] = fmax2;
+    // (wavefront minima / maxima by shuffles, the four wavefronts' through LDS: two barriers instead of nine)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = fmin(kmin, __shfl_xor(kmin, off, 64));
+        kmax = fmax(kmax, __shfl_xor(kmax, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { red_min[threadIdx.x >> 6] = kmin; red_max[threadIdx.x >> 6] = kmax; }
     hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) n_sel_s = 0;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
-            red_min[threadIdx.x] = fmin(red_min[threadIdx.x], red_min[threadIdx.x + off]);
-            red_max[threadIdx.x] = fmax(red_max[threadIdx.x], red_max[threadIdx.x + off]);
-            red_fm[threadIdx.x] = fmax(red_fm[threadIdx.x], red_fm[threadIdx.x + off]);
-        }
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        red_min[0] = fmin(fmin(red_min[0], red_min[1]), fmin(red_min[2], red_min[3]));
+        red_max[0] = fmax(fmax(red_max[0], red_max[1]), fmax(red_max[2], red_max[3]));
     }
+    __syncthreads();
     kmin = red_min[0]; kmax = red_max[0];
     // keys from the f32 prefilter are only good to +-e_i = c (2 |q| |f_i| + |f_i|^2): every selection
     // margin is widened by 2 max_i e_i over the survivors of THIS row (their norms, not the largest
@@ -1089,6 +1091,43 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
         ex_idx[e] = id;
     }
     __syncthreads();
+    if (n_sel <= 512) {
+        // the usual case (K + a bin of near ties): every entry counts the entries in front of it -- (key, id) pairs are
+        // distinct, so the counts are the sorted positions -- and writes its own output; no sort, no barrier (the bitonic
+        // sort of 256 pairs was 36 barrier-separated stages on a row's critical path)
+        for (int e = threadIdx.x; e < n_sel; e += blockDim.x) {
+            const double k = ex_key[e];
+            const int id = ex_idx[e];
+            int r = 0;
+            for (int f = 0; f < n_sel; ++f) {
+                const double kf = ex_key[f];
+                const int idf = ex_idx[f];
+                r += (kf < k || (kf == k && idf < id)) ? 1 : 0;
+            }
+            if (r < K) {
+                if (cand) cand[row * K + r] = (int64_t)id + id_offset;
+                if (dist) dist[row * K + r] = __dsqrt_rn(k);
+                if (d2_out) d2_out[row * K + r] = k;
+            }
+            if (r == K - 1 && thr && eps && margin_stat && kk == K && n > K) {
+                // Tripwire of the prefilter's key bound (see below)
+                const double room = thr[row] - (k - qnorm[row]);
+                const double ee = eps[row];
+                if (ee > 0.0 && thr[row] < 0.5 * DBL_MAX) {
+                    if (room < 2.0 * ee) atomicAdd(&margin_stat[0], 1u);
+                    float ratio = (float)(room / ee);
+                    if (!(ratio > 0.f)) ratio = 0.f;
+                    atomicMin(&margin_stat[1], __float_as_uint(ratio));
+                }
+            }
+        }
+        for (int j = kk + threadIdx.x; j < K; j += blockDim.x) {      // fewer than K units exist: padding
+            if (cand) cand[row * K + j] = -1;
+            if (dist) dist[row * K + j] = SNK_VERY_BIG;
+            if (d2_out) d2_out[row * K + j] = SNK_VERY_BIG * SNK_VERY_BIG;
+        }
+        return;
+    }
     bitonic_sort_pairs(ex_key, ex_idx, SP);
     // Tripwire of the prefilter's key bound (include/snk.h: prefilter_margin_rows).  The filter kept every unit whose
     // approximate key lay under thr = (bound of the K-th nearest key) + eps, eps being the ASSUMED largest error of an

@@ -3361,6 +3361,10 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0) return fail("join_bounds_stream must be 0 (main stream) or 1 (side stream of the group)");
         CHK(no_batch_in_flight(h, "snk_set_option(join_bounds_stream)"));
         h->join_bounds_stream = (int)value;
+    } else if (!strcmp(name, "join_exact_form")) {
+        if (value != 0.0 && value != 1.0) return fail("join_exact_form must be 0 or 1");
+        CHK(no_batch_in_flight(h, "snk_set_option(join_exact_form)"));
+        set_join_exact_form((int)value);
     } else if (!strcmp(name, "viterbi_weights")) {
         if (value != 0.0 && value != 1.0) return fail("viterbi_weights must be 0 (float64) or 1 (OpenFST's float32 weights)");
         CHK(no_batch_in_flight(h, "snk_set_option(viterbi_weights)"));

@@ -212,6 +212,7 @@ void launch_viterbi_lb(const int64_t *cand, const double *tdist, const float *Jl
 size_t join_record_bytes();
 void launch_join_exact_sparse(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
                               const double *tdist, int64_t R, int K, const void *sets, void *rec, hipStream_t s);
+void set_join_exact_form(int f);           // 1 (default): cooperative pass 3 (rows in coalesced chunks through LDS); 0: a lane per cell
 void set_viterbi_sparse_waves(int w);      // 1 (default) or 4: which form of pass 4 launch_viterbi_sparse runs (same results)
 void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jlo, const float *JC_unw, int Jp, int Dj,
                            const double *wj, const int64_t *off, int n_utts, int first_utt, int K, int64_t n_units,

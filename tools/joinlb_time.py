@@ -1,6 +1,6 @@
 """The Viterbi side of one group of a B* batch (16 utterances x 600 rows, K = 100, 302 join columns) on its own, from
 candidates computed once: stage times per form of the bounds pass (join_lb_variant) and what pass 4 refines.
-    python tools/joinlb_time.py [variant ...] [--utts U] [--reps R]"""
+    python tools/joinlb_time.py [variant ...] [x0] [x1] [--utts U] [--reps R]      (x0 / x1: form of the exact sparse costs)"""
 import sys, os, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,8 +23,10 @@ for s in range(U):
     cands.append(c); dists.append(d)
 eng.set_option('viterbi_mode', 1)
 ref = None
-for v in variants:
+forms = [int(a[1:]) for a in args if a in ('x0', 'x1')] or [1]
+for v, form in [(v, f) for v in variants for f in forms]:
     eng.set_option('join_lb_variant', v)
+    eng.set_option('join_exact_form', form)
     out = eng.viterbi_batch(cands, dists)
     if ref is None: ref = out
     same = all(np.array_equal(a, b) for a, b in zip(out[0], ref[0])) and np.array_equal(out[1], ref[1])
@@ -34,7 +36,7 @@ for v in variants:
     for _ in range(R): eng.viterbi_batch(cands, dists)
     dt = (time.time() - t0) / R
     st1 = [eng.info(x) for x in ('dense_cells', 'dense_steps', 'dense_exact_costs', 'set_overflows')]
-    print('join_lb_variant %d: %.2f ms per call (with the upload of the candidates) same=%s stages %s refined cells / steps / exact costs / overflows per call %s'
-          % (v, dt * 1e3, same, {k: round(x[0] / R, 3) for k, x in eng.timers().items() if x[1]},
+    print('join_lb_variant %d join_exact_form %d: %.2f ms per call (with the upload of the candidates) same=%s stages %s refined cells / steps / exact costs / overflows per call %s'
+          % (v, form, dt * 1e3, same, {k: round(x[0] / R, 3) for k, x in eng.timers().items() if x[1]},
              [round((b - a) / R) for a, b in zip(st0, st1)]), flush=True)
 eng.close()
