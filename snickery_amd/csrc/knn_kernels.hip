@@ -1091,43 +1091,8 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
         ex_idx[e] = id;
     }
     __syncthreads();
-    if (n_sel <= 512) {
-        // the usual case (K + a bin of near ties): every entry counts the entries in front of it -- (key, id) pairs are
-        // distinct, so the counts are the sorted positions -- and writes its own output; no sort, no barrier (the bitonic
-        // sort of 256 pairs was 36 barrier-separated stages on a row's critical path)
-        for (int e = threadIdx.x; e < n_sel; e += blockDim.x) {
-            const double k = ex_key[e];
-            const int id = ex_idx[e];
-            int r = 0;
-            for (int f = 0; f < n_sel; ++f) {
-                const double kf = ex_key[f];
-                const int idf = ex_idx[f];
-                r += (kf < k || (kf == k && idf < id)) ? 1 : 0;
-            }
-            if (r < K) {
-                if (cand) cand[row * K + r] = (int64_t)id + id_offset;
-                if (dist) dist[row * K + r] = __dsqrt_rn(k);
-                if (d2_out) d2_out[row * K + r] = k;
-            }
-            if (r == K - 1 && thr && eps && margin_stat && kk == K && n > K) {
-                // Tripwire of the prefilter's key bound (see below)
-                const double room = thr[row] - (k - qnorm[row]);
-                const double ee = eps[row];
-                if (ee > 0.0 && thr[row] < 0.5 * DBL_MAX) {
-                    if (room < 2.0 * ee) atomicAdd(&margin_stat[0], 1u);
-                    float ratio = (float)(room / ee);
-                    if (!(ratio > 0.f)) ratio = 0.f;
-                    atomicMin(&margin_stat[1], __float_as_uint(ratio));
-                }
-            }
-        }
-        for (int j = kk + threadIdx.x; j < K; j += blockDim.x) {      // fewer than K units exist: padding
-            if (cand) cand[row * K + j] = -1;
-            if (dist) dist[row * K + j] = SNK_VERY_BIG;
-            if (d2_out) d2_out[row * K + j] = SNK_VERY_BIG * SNK_VERY_BIG;
-        }
-        return;
-    }
+    // (rank-by-counting instead of the sort -- every entry counting the entries in front of it, no barriers -- was tried:
+    // 0.45 -> 0.52 ms per 9 600 rows, the selections of 200-500 entries make it quadratic work on LDS reads)
     bitonic_sort_pairs(ex_key, ex_idx, SP);
     // Tripwire of the prefilter's key bound (include/snk.h: prefilter_margin_rows).  The filter kept every unit whose
     // approximate key lay under thr = (bound of the K-th nearest key) + eps, eps being the ASSUMED largest error of an
@@ -1184,6 +1149,130 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
     }
     if (f32k) SNK_FIN(0, true, shmem); else SNK_FIN(0, false, shmem);
 #undef SNK_FIN
+}
+
+// ---------------------------------------------------------------------------
+// Row-sharded databases: the exchange of the shards' lists, compacted.  Under the shared bound a shard keeps about K / G
+// candidates per row (a row's neighbours mostly sit in one shard); the (rows, K) matrices the owners are sent were 86 % padding
+// (215 MB per rank and B* step at G = 8).  A destination's block now is
+//        [ counts: one byte per row, padded to 16 ][ d2: tot x 8 bytes ][ ids: tot x 8 bytes ]
+// with the rows' valid entries (the lists are (distance, id)-ordered with the -1 padding at the end) back to back.
+//   shard_count_kernel   valid entries per row
+//   shard_scan_kernel    one workgroup per block: exclusive prefix of the counts (the row's first entry), the block's total
+//   shard_pack_kernel    entries to their places in the send buffer
+//   shard_unpack_kernel  the owner's side: a received block back into (rows, K) lists with padding, what merge_topk reads
+// The block sizes have to be on the host for the transfers: one all-gather of the G totals and one device -> host copy per step.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+shard_count_kernel(const int64_t *__restrict__ ids, int64_t R, int K, unsigned char *__restrict__ cnt)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    int n = 0;
+    while (n < K && ids[r * K + n] >= 0) ++n;
+    cnt[r] = (unsigned char)n;
+}
+
+// block p: counts at cnt + cnt_off[p], rows[p] of them; offsets to off + off_off[p]; tot[p]
+__global__ void __launch_bounds__(256)
+shard_scan_kernel(const unsigned char *__restrict__ cnt, const int64_t *__restrict__ cnt_off, const int64_t *__restrict__ rows,
+                  int *__restrict__ off, const int64_t *__restrict__ off_off, int64_t *__restrict__ tot)
+{
+    __shared__ int wsum[4];
+    __shared__ int carry_s;
+    const int p = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned char *c = cnt + cnt_off[p];
+    int *o = off + off_off[p];
+    const int64_t n = rows[p];
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < n; i0 += 256) {
+        const int64_t i = i0 + threadIdx.x;
+        const int v = i < n ? (int)c[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int x = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += x;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int base = carry_s;
+        for (int w = 0; w < wv; ++w) base += wsum[w];
+        if (i < n) o[i] = base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tot[p] = carry_s;
+}
+
+// row r of the (R, K) lists belongs to destination block p = dest[r]'s ... found by the row ranges: row0[p] <= r < row0[p] + rows[p]
+__global__ void __launch_bounds__(256)
+shard_pack_kernel(const double *__restrict__ d2, const int64_t *__restrict__ ids, const unsigned char *__restrict__ cnt,
+                  const int *__restrict__ off, const int64_t *__restrict__ row0, const int64_t *__restrict__ rows,
+                  const int64_t *__restrict__ poff, const int64_t *__restrict__ tot, int G, int64_t R, int K,
+                  unsigned char *__restrict__ out)
+{
+    // one wavefront per row
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    int p = 0;
+    while (p + 1 < G && r >= row0[p] + rows[p]) ++p;
+    const int64_t i = r - row0[p];
+    unsigned char *blk = out + poff[p];
+    const int64_t hdr = (rows[p] + 15) & ~(int64_t)15;
+    const int n = cnt[r];
+    if (lane == 0) blk[i] = (unsigned char)n;
+    double *pd = reinterpret_cast<double *>(blk + hdr) + off[r];
+    int64_t *pi = reinterpret_cast<int64_t *>(blk + hdr + tot[p] * 8) + off[r];
+    for (int k = lane; k < n; k += 64) { pd[k] = d2[r * K + k]; pi[k] = ids[r * K + k]; }
+}
+
+// source block q: counts at in + roff[q] (r_own of them), entries behind them; offq[q * r_own + i] from shard_scan_kernel
+__global__ void __launch_bounds__(256)
+shard_unpack_kernel(const unsigned char *__restrict__ in, const int64_t *__restrict__ roff, const int64_t *__restrict__ totq,
+                    const int *__restrict__ offq, int64_t r_own, int K, double *__restrict__ d2_out, int64_t *__restrict__ id_out)
+{
+    const int lane = threadIdx.x & 63, q = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= r_own) return;
+    const unsigned char *blk = in + roff[q];
+    const int64_t hdr = (r_own + 15) & ~(int64_t)15;
+    int n = blk[i];
+    if (n > K) n = K;
+    const double *pd = reinterpret_cast<const double *>(blk + hdr) + offq[q * r_own + i];
+    const int64_t *pi = reinterpret_cast<const int64_t *>(blk + hdr + totq[q] * 8) + offq[q * r_own + i];
+    double *od = d2_out + ((int64_t)q * r_own + i) * K;
+    int64_t *oi = id_out + ((int64_t)q * r_own + i) * K;
+    for (int k = lane; k < K; k += 64) {
+        od[k] = k < n ? pd[k] : SNK_VERY_BIG * SNK_VERY_BIG;
+        oi[k] = k < n ? pi[k] : -1;
+    }
+}
+
+void launch_shard_count(const int64_t *ids, int64_t R, int K, unsigned char *cnt, hipStream_t s)
+{
+    hipLaunchKernelGGL(shard_count_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, ids, R, K, cnt);
+}
+void launch_shard_scan(const unsigned char *cnt, const int64_t *cnt_off, const int64_t *rows, int *off, const int64_t *off_off,
+                       int64_t *tot, int G, hipStream_t s)
+{
+    hipLaunchKernelGGL(shard_scan_kernel, dim3((unsigned)G), dim3(256), 0, s, cnt, cnt_off, rows, off, off_off, tot);
+}
+void launch_shard_pack(const double *d2, const int64_t *ids, const unsigned char *cnt, const int *off, const int64_t *row0,
+                       const int64_t *rows, const int64_t *poff, const int64_t *tot, int G, int64_t R, int K, unsigned char *out,
+                       hipStream_t s)
+{
+    hipLaunchKernelGGL(shard_pack_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, d2, ids, cnt, off, row0, rows, poff, tot, G, R, K, out);
+}
+void launch_shard_unpack(const unsigned char *in, const int64_t *roff, const int64_t *totq, const int *offq, int64_t r_own, int K, int G,
+                         double *d2_out, int64_t *id_out, hipStream_t s)
+{
+    if (r_own < 1) return;
+    hipLaunchKernelGGL(shard_unpack_kernel, dim3((unsigned)((r_own + 3) / 4), (unsigned)G), dim3(256), 0, s, in, roff, totq, offq, r_own, K,
+                       d2_out, id_out);
 }
 
 // ---------------------------------------------------------------------------

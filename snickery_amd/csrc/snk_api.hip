@@ -271,6 +271,9 @@ struct snk_engine {
     DevBuf margin_stat;           // tripwire of the prefilter's key bound: [0] rows with room < 2 eps, [1] smallest room / eps (float bits)
     int shard_gather_queries = 1; // sharded steps: 1: every rank uploads the rows of its own utterances and the ranks exchange them, 0: every rank uploads all rows
     int shard_refine = 1;         // 1: snk_sharded_knn_viterbi_batch prunes the shards' lists to that bound before the re-rank
+    int shard_compact = 1;        // 1: the lists travel compacted (counts + valid entries; one device -> host copy of the block sizes per step)
+    DevBuf sh_cnt, sh_off, sh_tot, sh_totall, sh_plan, sh_pack, sh_rpack, sh_offq;
+    double shard_last_sent_mb = 0.0, shard_last_padded_mb = 0.0;   // exchange payload of the most recent sharded step: sent / what the padded lists would have been
     DevBuf gs_tiles_b, cq16, rho16, gs_rho16;   // per-row split coefficient; dropped-piece ratios of the operands
     int f16_fallbacks = 0;
     int last_f16_status = 0;
@@ -608,7 +611,8 @@ int snk_destroy(snk_handle h)
     h->res_status.release(); h->hstage.release(); h->up.release();
     { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b, &h->cq16, &h->rho16, &h->gs_rho16, &h->kth16, &h->margin_stat, &h->e1_16, &h->thr1_32, &h->cpairs, &h->cpairctl,
                       &h->ball_c, &h->ball_cn, &h->ball_rad, &h->ball_c16, &h->ball_tq, &h->ball_nq,
-                      &h->ball_aq, &h->ball_nql, &h->ball_gmin, &h->ball_bound};
+                      &h->ball_aq, &h->ball_nql, &h->ball_gmin, &h->ball_bound,
+                      &h->sh_cnt, &h->sh_off, &h->sh_tot, &h->sh_totall, &h->sh_plan, &h->sh_pack, &h->sh_rpack, &h->sh_offq};
       for (auto *b : fb) b->release(); }
     for (int i = 0; i < 8; ++i) {
         UttSlot &s = h->slot[i];
@@ -2992,9 +2996,58 @@ static int sharded_submit(snk_engine *h, ShardTicket &t, const double *Q, const 
     }
     const double *d2_all = d2;
     const int64_t *id_all = ids;
-    if (G > 1) {
+    if (G > 1 && h->shard_compact) {
+        // compacted exchange (knn_kernels.hip shard_*): counts + valid entries per destination.  The block sizes must be on
+        // the host for the transfers: an all-gather of every rank's G totals, ONE device -> host copy (the host waits for this
+        // step's K-NN here; what was queued for the step before keeps running)
+        auto pad16 = [](int64_t v) { return (v + 15) & ~(int64_t)15; };
+        CHK(h->sh_cnt.ensure((size_t)R + 64));
+        CHK(h->sh_off.ensure((size_t)R * sizeof(int) + 64));
+        CHK(h->sh_tot.ensure((size_t)G * sizeof(int64_t)));
+        CHK(h->sh_totall.ensure((size_t)G * G * sizeof(int64_t)));
+        CHK(h->sh_plan.ensure((size_t)8 * G * sizeof(int64_t)));
+        CHK(h->sh_pack.ensure((size_t)R * K * 16 + (size_t)R + (size_t)16 * G + 64));
+        CHK(h->sh_rpack.ensure((size_t)G * ((size_t)(r_own > 0 ? r_own : 1) * K * 16 + (size_t)r_own + 32) + 64));
+        CHK(h->sh_offq.ensure((size_t)G * (r_own > 0 ? r_own : 1) * sizeof(int) + 64));
+        // plan arrays on the device: [0] row0, [1] rows_to, [2] send offsets, [3] totals sent, [4] receive offsets, [5] totals received,
+        // [6] offsets of the received counts (= [4]), [7] q * r_own
+        std::vector<int64_t> plan((size_t)8 * G, 0);
+        for (int p = 0; p < G; ++p) { plan[(size_t)p] = t.row0[(size_t)p]; plan[(size_t)G + p] = t.rows_to[(size_t)p]; plan[(size_t)7 * G + p] = (int64_t)p * r_own; }
+        int64_t *pl = h->sh_plan.as<int64_t>();
+        CHK(h2d(h, pl, plan.data(), (size_t)2 * G * sizeof(int64_t), h->stream));
+        launch_shard_count(ids, R, K, h->sh_cnt.as<unsigned char>(), h->stream);
+        launch_shard_scan(h->sh_cnt.as<unsigned char>(), pl, pl + G, h->sh_off.as<int>(), pl, h->sh_tot.as<int64_t>(), G, h->stream);
+        CHK(comm_all_gather(h, h->sh_tot.p, h->sh_totall.p, (int64_t)G * 8));
+        std::vector<int64_t> totall((size_t)G * G);
+        CHK(d2h_sync(h, totall.data(), h->sh_totall.p, (size_t)G * G * sizeof(int64_t), h->stream));
+        int64_t so = 0, ro = 0;
+        for (int p = 0; p < G; ++p) {
+            const int64_t ts = totall[(size_t)me * G + p], tr = totall[(size_t)p * G + me];
+            if (ts < 0 || ts > t.rows_to[(size_t)p] * K || tr < 0 || tr > r_own * K) return fail("sharded exchange: inconsistent list totals between ranks");
+            soff[(size_t)p] = so; sb[(size_t)p] = pad16(t.rows_to[(size_t)p]) + 16 * ts; so += sb[(size_t)p];
+            roff[(size_t)p] = ro; rb[(size_t)p] = pad16(r_own) + 16 * tr; ro += rb[(size_t)p];
+            plan[(size_t)2 * G + p] = soff[(size_t)p]; plan[(size_t)3 * G + p] = ts;
+            plan[(size_t)4 * G + p] = roff[(size_t)p]; plan[(size_t)5 * G + p] = tr; plan[(size_t)6 * G + p] = roff[(size_t)p];
+        }
+        CHK(h2d(h, pl + 2 * G, plan.data() + (size_t)2 * G, (size_t)6 * G * sizeof(int64_t), h->stream));
+        launch_shard_pack(d2, ids, h->sh_cnt.as<unsigned char>(), h->sh_off.as<int>(), pl, pl + G, pl + 2 * G, pl + 3 * G, G, R, K,
+                          h->sh_pack.as<unsigned char>(), h->stream);
+        CHK(comm_all_to_all_v(h, h->sh_pack.p, soff.data(), sb.data(), h->sh_rpack.p, roff.data(), rb.data()));
+        if (r_own > 0) {
+            std::vector<int64_t> rows_q((size_t)G, r_own);
+            CHK(h2d(h, pl + G, rows_q.data(), (size_t)G * sizeof(int64_t), h->stream));     // (the send side's row counts are no longer needed)
+            launch_shard_scan(h->sh_rpack.as<unsigned char>(), pl + 6 * G, pl + G, h->sh_offq.as<int>(), pl + 7 * G, h->sh_tot.as<int64_t>(), G, h->stream);
+            launch_shard_unpack(h->sh_rpack.as<unsigned char>(), pl + 4 * G, pl + 5 * G, h->sh_offq.as<int>(), r_own, K, G,
+                                h->sh_rd2.as<double>(), h->sh_rid.as<int64_t>(), h->stream);
+        }
+        HIPCHK(hipGetLastError());
+        h->shard_last_sent_mb = (double)(so - sb[(size_t)me]) / 1e6;
+        h->shard_last_padded_mb = (double)(R - t.rows_to[(size_t)me]) * K * 16 / 1e6;
+        d2_all = h->sh_rd2.as<double>(); id_all = h->sh_rid.as<int64_t>();
+    } else if (G > 1) {
         CHK(comm_all_to_all_v(h, d2, soff.data(), sb.data(), h->sh_rd2.p, roff.data(), rb.data()));
         CHK(comm_all_to_all_v(h, ids, soff.data(), sb.data(), h->sh_rid.p, roff.data(), rb.data()));
+        h->shard_last_sent_mb = h->shard_last_padded_mb = (double)(R - t.rows_to[(size_t)me]) * K * 16 / 1e6;
         d2_all = h->sh_rd2.as<double>(); id_all = h->sh_rid.as<int64_t>();
     }
     // owner: merge, join bounds / costs, Viterbi of the owned utterances -- queued, not waited for
@@ -3354,6 +3407,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "shard_gather_queries")) {
         if (value != 0.0 && value != 1.0) return fail("shard_gather_queries must be 0 or 1 (the same on every rank)");
         h->shard_gather_queries = (int)value;
+    } else if (!strcmp(name, "shard_compact")) {
+        if (value != 0.0 && value != 1.0) return fail("shard_compact must be 0 or 1 (the same on every rank)");
+        h->shard_compact = (int)value;
     } else if (!strcmp(name, "shard_refine")) {
         if (value != 0.0 && value != 1.0) return fail("shard_refine must be 0 or 1 (the same on every rank)");
         h->shard_refine = (int)value;
@@ -3462,6 +3518,9 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "prefilter_balls")) *out = h->prefilter_balls;
     else if (!strcmp(name, "prefilter_ball_bound")) *out = h->prefilter_ball_bound;
     else if (!strcmp(name, "wide_launches")) *out = (double)h->wide_launches;
+    else if (!strcmp(name, "shard_compact")) *out = h->shard_compact;
+    else if (!strcmp(name, "shard_last_sent_mb")) *out = h->shard_last_sent_mb;
+    else if (!strcmp(name, "shard_last_padded_mb")) *out = h->shard_last_padded_mb;
     else if (!strcmp(name, "wide_ready")) *out = h->wide16_ready ? 1 : 0;
     else if (!strcmp(name, "filter_coarse")) *out = h->filter_coarse ? 1 : 0;       // 1: the ball pass listed too many pairs for this voice
     else if (!strcmp(name, "ball_switches")) *out = (double)h->ball_switches;

@@ -118,6 +118,15 @@ void launch_candidate_dist(const double *Fw, int Dpad, int D, int64_t N, const d
                            const int64_t *cand, int64_t T, int K, double *dist, hipStream_t s);
 void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, int K,
                        int64_t *cand, double *dist, hipStream_t s);
+// compacted exchange of the shards' lists (knn_kernels.hip)
+void launch_shard_count(const int64_t *ids, int64_t R, int K, unsigned char *cnt, hipStream_t s);
+void launch_shard_scan(const unsigned char *cnt, const int64_t *cnt_off, const int64_t *rows, int *off, const int64_t *off_off,
+                       int64_t *tot, int G, hipStream_t s);
+void launch_shard_pack(const double *d2, const int64_t *ids, const unsigned char *cnt, const int *off, const int64_t *row0,
+                       const int64_t *rows, const int64_t *poff, const int64_t *tot, int G, int64_t R, int K, unsigned char *out,
+                       hipStream_t s);
+void launch_shard_unpack(const unsigned char *in, const int64_t *roff, const int64_t *totq, const int *offq, int64_t r_own, int K, int G,
+                         double *d2_out, int64_t *id_out, hipStream_t s);
 
 // ---- float32 prefilter (knn16_kernels.hip) ---------------------------------------------
 void launch_build_db16(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,

@@ -159,16 +159,24 @@ def _a2a(send, so, sb, ro, rb, rt):
     return out
 
 
-tr = TransportCallbacks(2, lambda a: (calls.append('ar'), a)[1], lambda a: (calls.append('ag'), np.tile(a, 2))[1], _a2a, lambda: None)
+def _ag(a):
+    calls.append('ag')
+    if a.size == 16:                         # the compacted exchange's totals (2 ranks x int64): the partner sends nothing
+        return np.concatenate([a, np.zeros(16, dtype=a.dtype)])
+    return np.tile(a, 2)
+
+
+tr = TransportCallbacks(2, lambda a: (calls.append('ar'), a)[1], _ag, _a2a, lambda: None)
 e3 = snickery_amd.HipSearchEngine(0)
 JC2 = rng.randn(2 * N + 1, Dj).astype(np.float32)
 e3.upload_target_only(F); e3.upload_join_only(JC2); e3.set_shard(0, 2 * N); e3.set_weights(wt, wj)
 e3.comm_init_transport(2, 0, tr)
 assert refused(e3.sharded_knn_viterbi_batch, [rng.randn(4, Dt + 1)], 10) and not calls      # refused BEFORE the first collective
 assert refused(e3.sharded_knn_viterbi_batch, utts, 300) and not calls
-for opt in ((1, 1), (0, 1), (1, 0)):
-    e3.set_option('shard_gather_queries', opt[0]); e3.set_option('shard_refine', opt[1])
+for opt in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0)):
+    e3.set_option('shard_gather_queries', opt[0]); e3.set_option('shard_refine', opt[1]); e3.set_option('shard_compact', opt[2])
     e3.sharded_knn_viterbi_batch(utts, 10)
+e3.set_option('shard_compact', 1)
 assert 'ar' in calls and 'aa' in calls and 'ag' in calls
 s0 = e3.sharded_knn_viterbi_batch_submit(utts, 10)
 s1 = e3.sharded_knn_viterbi_batch_submit(utts[:3], 10)

@@ -18,8 +18,9 @@ from snickery_amd.dist import global_sample, shard_bounds
 from snickery_amd.engine import TransportCallbacks
 from bench import synthetic_db, synthetic_targets
 
-G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-UPG = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+_pos = [a for a in sys.argv[1:] if not a.startswith('--')]
+G = int(_pos[0]) if len(_pos) > 0 else 8
+UPG = int(_pos[1]) if len(_pos) > 1 else 32
 N, Dt, Dj, T, K = 1048576, 61, 302, 600, 100
 F_unw, JC_unw = synthetic_db(N, Dt, Dj, seed=0)
 wt, wj = np.full(Dt, 0.4), np.full(Dj, 0.05)
@@ -35,6 +36,8 @@ eng.set_weights(wt, wj)
 eng.set_option('shard_gather_queries', 0)     # the stand-in transport has no other ranks to send their rows: upload all of them
 
 state = {'bounds': None, 'capture': None}
+COMPACT = '--padded' not in sys.argv
+eng.set_option('shard_compact', 1 if COMPACT else 0)
 
 
 class _Captured(Exception):
@@ -51,6 +54,8 @@ def all_reduce_min(a):
 
 
 def all_gather(a):
+    if a.size == 8 * G:                      # the compacted exchange's totals: the other shards hold nothing of the owned rows
+        return np.concatenate([a, np.zeros(a.size * (G - 1), dtype=a.dtype)])
     return np.tile(a, G)
 
 
@@ -58,6 +63,8 @@ def all_to_all_v(send, soff, sbytes, roff, rbytes, recv_total):
     out = np.zeros(recv_total, dtype=np.uint8)
     own = send[soff[0]:soff[0] + sbytes[0]]
     out[roff[0]:roff[0] + rbytes[0]] = own
+    if COMPACT:                              # compacted blocks of the other shards: counts of zero, no entries
+        return out
     # the other shards' lists of the owned rows: padding (id -1 / +inf) -- recognisable from the dtype of the payload
     is_ids = np.frombuffer(own[:8].tobytes(), dtype=np.int64)[0] < (1 << 40) if own.size >= 8 else True
     pad = np.frombuffer((np.int64(-1) if is_ids else np.float64(np.inf)).tobytes(), dtype=np.uint8)
@@ -89,5 +96,6 @@ main = sum(tm.get(k, 0) for k in ('h2d_queries', 'prepare_queries', 'knn_minima'
                                   'knn_finalize', 'merge_topk', 'join_lower_bounds', 'join_costs'))
 print('G=%d rank 0, %d rows per step (%d owned): stages ms %s' % (G, R, R // G, tm))
 wire = (G - 1) / G * R * K * 16 / 1e9
-print('main-stream device time %.1f ms per step of %d frames; exchange payload %.0f MB per rank' % (main, R, wire * 1e3))
+print('main-stream device time %.1f ms per step of %d frames; exchange payload %.0f MB per rank padded, %.1f MB sent (shard_compact %d)'
+      % (main, R, wire * 1e3, eng.info('shard_last_sent_mb'), eng.info('shard_compact')))
 print('redone steps: %d, f32 fallbacks: %d' % (eng.info('batch_redos') - redo0, eng.info('f16_fallbacks')))
