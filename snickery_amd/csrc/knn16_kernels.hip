@@ -1341,6 +1341,63 @@ void launch_build_tile_balls(const double *Fw, int64_t N, int Dt, int Dpad, int6
                        cnorm, rad);
 }
 
+// One level up: the ball of 32 consecutive tiles (1 024 units) -- centre C = mean of its units, radius <= max_t (||c_t - C|| + r_t).
+// The ball pass tests these first (1 / 32 of its products) and visits a (centre tile, query tile) block only where the super
+// ball passes for some row of the query tile: the same inequality, the same operands and key bound one level up.
+__global__ void __launch_bounds__(256)
+build_super_balls_kernel(const double *__restrict__ C, const float *__restrict__ rad, int64_t N, int64_t n_tiles, int Dt, int Dpad,
+                         int64_t n_super, double *__restrict__ C2, double *__restrict__ cnorm2, float *__restrict__ rad2)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t sidx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sidx >= n_super) return;
+    const int64_t t0 = sidx * 32;
+    const int nt = (int)(n_tiles - t0 < 32 ? (n_tiles - t0 > 0 ? n_tiles - t0 : 0) : 32);
+    double wsum = 0.0;
+    for (int i = 0; i < nt; ++i) { const int64_t u = N - (t0 + i) * 32; wsum += (double)(u < 32 ? (u > 0 ? u : 0) : 32); }
+    double cn = 0.0;
+    for (int c = lane; c < Dpad; c += 64) {
+        double m = 0.0;
+        if (c < Dt && wsum > 0.0) {
+            for (int i = 0; i < nt; ++i) {
+                const int64_t u = N - (t0 + i) * 32;
+                m += C[(t0 + i) * Dpad + c] * (double)(u < 32 ? (u > 0 ? u : 0) : 32);
+            }
+            m /= wsum;
+        }
+        C2[sidx * Dpad + c] = m;
+        cn += m * m;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cn += __shfl_xor(cn, off, 64);
+    double rmax = 0.0;
+    for (int i = 0; i < nt; ++i) {
+        if (N - (t0 + i) * 32 <= 0) continue;
+        double d2 = 0.0;
+        for (int c = lane; c < Dt; c += 64) {
+            const double d = C[(t0 + i) * Dpad + c] - C2[sidx * Dpad + c];       // (this lane's own columns: written above)
+            d2 += d * d;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) d2 += __shfl_xor(d2, off, 64);
+        const double r = sqrt(d2) * (1.0 + 1e-9) + (double)rad[t0 + i];
+        rmax = r > rmax ? r : rmax;
+    }
+    if (lane == 0) {
+        cnorm2[sidx] = wsum > 0.0 ? cn : __builtin_inf();
+        float r = (float)(rmax * (1.0 + 1e-9));
+        if ((double)r < rmax * (1.0 + 1e-9)) r = nextafterf(r, FLT_MAX);
+        rad2[sidx] = wsum > 0.0 ? r : 0.f;
+    }
+}
+
+void launch_build_super_balls(const double *C, const float *rad, int64_t N, int64_t n_tiles, int Dt, int Dpad, int64_t n_super, double *C2,
+                              double *cnorm2, float *rad2, hipStream_t s)
+{
+    hipLaunchKernelGGL(build_super_balls_kernel, dim3((unsigned)((n_super + 3) / 4)), dim3(256), 0, s, C, rad, N, n_tiles, Dt, Dpad, n_super,
+                       C2, cnorm2, rad2);
+}
+
 // per query row: tq and nq of the ball test (see above) from the row's filter threshold, key bound and norm
 __global__ void ball_query_terms_kernel(const float *__restrict__ thr32, const double *__restrict__ eps, const double *__restrict__ qnorm,
                                         int64_t T, int64_t T32, float *__restrict__ tq, float *__restrict__ nq)
@@ -1373,12 +1430,15 @@ void launch_ball_query_terms(const float *thr32, const double *eps, const double
 }
 
 // centres (operand C16: tiles of 32 centres, hi / lo pieces like the database) against all query tiles
-template <int KB, int TERMS>
+// BITS: the super-ball pass -- instead of pairs, a bit per (row of the centre operand = super ball, query tile) in `mask`;
+// the tile-level pass is handed that mask as `visit` and skips the (centre tile, query tile) blocks whose bit is clear
+template <int KB, int TERMS, bool BITS>
 __global__ void __launch_bounds__(256, 2)
 knn_balls16b(const u32x4 *__restrict__ C16, const u32x4 *__restrict__ B16, const float *__restrict__ rad, const float *__restrict__ tq,
              const float *__restrict__ nq, int nQT, int64_t n_tiles, int64_t n_ctiles, int qsplit, CoarsePair *__restrict__ pairs,
-             unsigned int *__restrict__ pair_ctl, unsigned int pair_cap)
+             unsigned int *__restrict__ pair_ctl, unsigned int pair_cap, unsigned int *__restrict__ mask, const unsigned int *__restrict__ visit)
 {
+    const int nQTw = (nQT + 31) >> 5;
     __shared__ CoarsePair pstage[4][96];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -1402,6 +1462,19 @@ knn_balls16b(const u32x4 *__restrict__ C16, const u32x4 *__restrict__ B16, const
         const int64_t ct = item / qsplit;
         const int part = (int)(item % qsplit);
         const int qt_lo = (int)(((int64_t)nQT * part) / qsplit), qt_hi = (int)(((int64_t)nQT * (part + 1)) / qsplit);
+        // the query tiles of this block's range that are to be visited: all of them, or the set bits of the super pass's row
+        const unsigned int *const vrow = (!BITS && visit) ? visit + ct * nQTw : nullptr;
+        auto next_qt = [&](int qq) -> int {
+            if (!vrow) return qq < qt_hi ? qq : qt_hi;
+            while (qq < qt_hi) {
+                const unsigned int w = __builtin_amdgcn_readfirstlane(vrow[qq >> 5]) >> (qq & 31);
+                if (w) { qq += __builtin_ctz(w); return qq < qt_hi ? qq : qt_hi; }
+                qq = (qq | 31) + 1;
+            }
+            return qt_hi;
+        };
+        int q0 = next_qt(qt_lo);
+        if (q0 >= qt_hi) continue;
         u32x4 a[KB][2];
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
@@ -1458,28 +1531,40 @@ knn_balls16b(const u32x4 *__restrict__ C16, const u32x4 *__restrict__ B16, const
                 if (mm) {
                     // lanes 0..31 hold row crow32(0, r), lanes 32..63 row crow32(32, r): one pair per row with any passing column
                     const unsigned int lo = (unsigned int)mm, hi = (unsigned int)(mm >> 32);
-                    if (lo) { if (lane == 0) pstage[wv][pcount] = CoarsePair{(unsigned int)(ct * 32 + crow32(0, r)), (unsigned int)qt}; ++pcount; }
-                    if (hi) { if (lane == 0) pstage[wv][pcount] = CoarsePair{(unsigned int)(ct * 32 + crow32(32, r)), (unsigned int)qt}; ++pcount; }
+                    if (BITS) {
+                        if (lane == 0) {
+                            if (lo) atomicOr(&mask[(ct * 32 + crow32(0, r)) * nQTw + (qt >> 5)], 1u << (qt & 31));
+                            if (hi) atomicOr(&mask[(ct * 32 + crow32(32, r)) * nQTw + (qt >> 5)], 1u << (qt & 31));
+                        }
+                    } else {
+                        if (lo) { if (lane == 0) pstage[wv][pcount] = CoarsePair{(unsigned int)(ct * 32 + crow32(0, r)), (unsigned int)qt}; ++pcount; }
+                        if (hi) { if (lane == 0) pstage[wv][pcount] = CoarsePair{(unsigned int)(ct * 32 + crow32(32, r)), (unsigned int)qt}; ++pcount; }
+                    }
                 }
             }
         };
-        load_q(qt_lo, b0, t0, n0);
-        for (int qt = qt_lo; qt < qt_hi; qt += 2) {
-            load_q(qt + 1, b1, t1, n1);
-            work(qt, b0, t0, n0);
-            if (qt + 1 < qt_hi) {
-                load_q(qt + 2, b0, t0, n0);
-                work(qt + 1, b1, t1, n1);
-            }
+        load_q(q0, b0, t0, n0);
+        for (;;) {
+            const int q1 = next_qt(q0 + 1);
+            load_q(q1, b1, t1, n1);                            // (clamped inside: a load past the range is never used)
+            work(q0, b0, t0, n0);
+            if (q1 >= qt_hi) break;
+            const int q2 = next_qt(q1 + 1);
+            load_q(q2, b0, t0, n0);
+            work(q1, b1, t1, n1);
+            if (q2 >= qt_hi) break;
+            q0 = q2;
         }
     }
-    if (pcount) flush_pairs();
+    if (!BITS && pcount) flush_pairs();
 }
 
 bool launch_knn_balls16b(int terms, int dch, int grid_cus, const void *C16, const void *B16, const float *rad, const float *tq,
                          const float *nq, int64_t T32, int64_t n_tiles, void *pairs, unsigned int *pair_ctl, unsigned int pair_cap,
-                         hipStream_t s)
+                         hipStream_t s, unsigned int *mask_out, const unsigned int *visit)
 {
+    // mask_out: the super pass (bits instead of pairs; the caller zeroed ceil(T32 / 1024) words per row of the operand);
+    // visit: the tile pass, restricted to the blocks the super pass marked
     const int nQT = (int)(T32 / 32);
     const int64_t n_ctiles = (n_tiles + 31) / 32;
     int qsplit = 1;
@@ -1487,11 +1572,17 @@ bool launch_knn_balls16b(int terms, int dch, int grid_cus, const void *C16, cons
     int64_t blocks = (n_ctiles * qsplit + 3) / 4;
     if (blocks > 2 * (int64_t)grid_cus) blocks = 2 * (int64_t)grid_cus;
 #define SNK_B16(KB_, TERMS_)                                                                                         \
-    hipLaunchKernelGGL((knn_balls16b<KB_, TERMS_>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)C16,     \
-                       (const u32x4 *)B16, rad, tq, nq, nQT, n_tiles, n_ctiles, qsplit, (CoarsePair *)pairs, pair_ctl, pair_cap)
-    if (dch == 1) { if (terms == 4) SNK_B16(4, 4); else SNK_B16(4, 3); }
-    else if (dch == 2) { if (terms == 4) SNK_B16(8, 4); else SNK_B16(8, 3); }
-    else if (dch == 3) { if (terms == 4) SNK_B16(12, 4); else SNK_B16(12, 3); }
+    {                                                                                                                \
+        if (mask_out)                                                                                                \
+            hipLaunchKernelGGL((knn_balls16b<KB_, TERMS_, true>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)C16, \
+                               (const u32x4 *)B16, rad, tq, nq, nQT, n_tiles, n_ctiles, qsplit, (CoarsePair *)pairs, pair_ctl, pair_cap, mask_out, visit); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((knn_balls16b<KB_, TERMS_, false>), dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4 *)C16, \
+                               (const u32x4 *)B16, rad, tq, nq, nQT, n_tiles, n_ctiles, qsplit, (CoarsePair *)pairs, pair_ctl, pair_cap, mask_out, visit); \
+    }
+    if (dch == 1) { if (terms == 4) SNK_B16(4, 4) else SNK_B16(4, 3) }
+    else if (dch == 2) { if (terms == 4) SNK_B16(8, 4) else SNK_B16(8, 3) }
+    else if (dch == 3) { if (terms == 4) SNK_B16(12, 4) else SNK_B16(12, 3) }
     else return false;
 #undef SNK_B16
     return true;

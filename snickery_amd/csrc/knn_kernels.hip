@@ -904,7 +904,11 @@ __device__ __forceinline__ int block_incl_scan_256(int v, int *wsum /* LDS [4] *
 // CLASS 0: every row; 1: rows with at most FIN_SMALL entries (the others are left to CLASS 2); 2: the longer ones
 // F32K: the list keys are float32 values (the matrix prefilter's) and are kept as such in LDS; together with the exact
 // keys living where the list was (it is dead by then) a workgroup needs 47 KB instead of 80 and three fit a compute unit
-template <int CLASS, bool F32K>
+// LEAN: only the float32 keys of the list live in LDS (16 KB for lists of up to 4 096 entries instead of 32: six workgroups per
+// compute unit instead of three -- a row is a 40 us critical path, so the kernel's time goes with the occupancy); the unit ids
+// of the selected entries are read from the list in global memory.  Rows the value-binned selection cannot serve (short lists,
+// one-valued lists, more near ties than the selection holds) are flagged in `retry` and left to a second launch of the full form.
+template <int CLASS, bool F32K, bool LEAN = false>
 __global__ void __launch_bounds__(256)
 knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_unw, int Fp,
                     const double *__restrict__ wt, int Dpad, int D, const double *__restrict__ Qp,
@@ -915,11 +919,12 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
                     const double *__restrict__ cq,
                     int64_t *__restrict__ cand, double *__restrict__ dist,
                     double *__restrict__ d2_out, int *__restrict__ status, int *__restrict__ rowflag,
-                    const double *__restrict__ thr, unsigned int *__restrict__ margin_stat)
+                    const double *__restrict__ thr, unsigned int *__restrict__ margin_stat, int *__restrict__ retry)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int SELM = (CLASS == 1) ? FIN_SMALL : SEL_MAX;
     const int64_t row = blockIdx.x;
+    if (!LEAN && retry && !retry[row]) return;              // second launch: only the rows the lean form left
     const int n_all = cnt[row];
     if (CLASS == 1 && n_all > FIN_SMALL) return;
     if (CLASS == 2 && n_all <= FIN_SMALL) return;
@@ -945,8 +950,8 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
     int *idx = reinterpret_cast<int *>(smem + (size_t)P * sizeof(KeyT));
     double *ex_key = reinterpret_cast<double *>(smem);      // over key / idx: only written once the selection is in ex_idx
     __shared__ int ex_idx[SELM];
-    __shared__ int n_sel_s, hist[256], cut_bin_s;
-    __shared__ double red_min[256], red_max[256];
+    __shared__ int n_sel_s, hist[256], cut_bin_s, pre_s[256], wsum_s[4];
+    __shared__ double red_min[4], red_max[4];
     const int kk = K < n ? K : n;         // entries that can be returned
 
     // ---- fast path: value-binned selection.  256 linear bins between the smallest and the
@@ -956,15 +961,13 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
     double kmin = DBL_MAX, kmax = -DBL_MAX;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const double v = lkey[row * cap + i];
-        const int id = lidx[row * cap + i];
-        key[i] = (KeyT)v; idx[i] = id;
+        key[i] = (KeyT)v;
+        if (!LEAN) idx[i] = lidx[row * cap + i];
         kmin = fmin(kmin, v); kmax = fmax(kmax, v);
         // (the margin below used the largest ||f||^2 among THIS row's survivors: a dependent 8-byte gather per list entry,
-        // 16 M of them per B* launch and the longest part of the row's critical path; the row's eps -- the same bound with
-        // the largest norm of the database -- is what the filter assumed anyway)
-        (void)id;
+        // 16 M of them per B* launch; the row's eps -- the same bound with the largest norm of the database -- is what the
+        // filter assumed anyway)
     }
-    __shared__ double red_fm[256];
     // (wavefront minima / maxima by shuffles, the four wavefronts' through LDS: two barriers instead of nine)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -997,8 +1000,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
         __syncthreads();
         // prefix sums of the 256 bins by the whole workgroup (a thread-0 loop over the bins, twice, was most of the
         // kernel's time on lists of ~2000 entries: ~500 dependent LDS reads per row)
-        // (the reduction arrays are free again: no new LDS -- two workgroups of this kernel just fit a compute unit)
-        int *pre = reinterpret_cast<int *>(red_max), *wsum = reinterpret_cast<int *>(red_fm);
+        int *pre = pre_s, *wsum = wsum_s;
         {
             const int mine = hist[threadIdx.x];
             const int incl = block_incl_scan_256(mine, wsum);
@@ -1020,6 +1022,10 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
         __syncthreads();
         fast = cut_bin_s >= 0;
     }
+    if (LEAN && !fast) {                  // uniform: the full form takes this row
+        if (threadIdx.x == 0) retry[row] = 1;
+        return;
+    }
     if (fast) {
         const int cut = cut_bin_s;
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -1027,7 +1033,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
             b = b > 255 ? 255 : b;
             if (b <= cut) {
                 const int slot = atomicAdd(&n_sel_s, 1);
-                ex_idx[slot] = idx[i];
+                ex_idx[slot] = LEAN ? lidx[row * cap + i] : idx[i];
             }
         }
         __syncthreads();
@@ -1123,7 +1129,7 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
                          int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c, const double *cq,
                          int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s, bool split_short,
-                         const double *thr, unsigned int *margin_stat)
+                         const double *thr, unsigned int *margin_stat, int *retry)
 {
     int P = 2;
     while (P < cap) P <<= 1;
@@ -1139,7 +1145,18 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
 #undef SNK_FIN_ATTR
     });
 #define SNK_FIN(C_, F_, SH_) hipLaunchKernelGGL((knn_finalize_kernel<C_, F_>), dim3((unsigned)T), dim3(256), SH_, s, Fw, F_unw, Fp, wt, Dpad, D, Qp, \
-                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat)
+                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, nullptr)
+    if (f32k && retry && !split_short && !rowflag) {
+        // the lean form for (nearly) every row, the full form for the rows it flags
+        size_t lean = (size_t)P * sizeof(float);
+        if (lean < (size_t)SEL_MAX * sizeof(double)) lean = (size_t)SEL_MAX * sizeof(double);
+        (void)hipMemsetAsync(retry, 0, (size_t)T * sizeof(int), s);
+        hipLaunchKernelGGL((knn_finalize_kernel<0, true, true>), dim3((unsigned)T), dim3(256), lean, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
+                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry);
+        hipLaunchKernelGGL((knn_finalize_kernel<0, true, false>), dim3((unsigned)T), dim3(256), shmem, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
+                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry);
+        return;
+    }
     if (split_short && K <= FIN_SMALL / 2 && cap > FIN_SMALL) {
         const size_t small = (size_t)FIN_SMALL * ((f32k ? sizeof(float) : sizeof(double)) + sizeof(int)) > (size_t)FIN_SMALL * sizeof(double)
                                  ? (size_t)FIN_SMALL * ((f32k ? sizeof(float) : sizeof(double)) + sizeof(int)) : (size_t)FIN_SMALL * sizeof(double);

@@ -255,6 +255,9 @@ struct snk_engine {
     double eps_c_bf = 4e-6;       // accumulation part of the bound of the bf16-split keys (knn16_kernels.hip: c_acc)
     DevBuf kth16;                 // sharded search: per-row second bound (K-th key of the local list, all-reduced)
     DevBuf ball_c, ball_cn, ball_rad, ball_c16, ball_tq, ball_nq;   // pass 0: tile centres (float64, norms, radii, bf16-split operand), per-row terms
+    DevBuf ball_c2, ball_cn2, ball_rad2, ball_s16, ball_mask;       // the balls of 32 consecutive tiles (centres, norms, radii, bf16-split operand), (super ball, query tile) bits
+    int64_t ball_supers = 0;      // super balls of the operand (0: not built)
+    int prefilter_super_balls = 1;   // 1: the ball pass tests the balls of 32 tiles first and visits the blocks they mark
     DevBuf ball_aq, ball_nql, ball_gmin, ball_bound;                // stage A' (scout): tile list per query tile, keys of their units per row, centre-key minima, the row's bound
     int prefilter_ball_bound = 0; // 1: the thresholds also take the K-th smallest key of the units of the nearest tiles (stage A'; where the ball pass
                                   // runs).  Off by default: at B* it shortens the lists 1785 -> 568 entries per row and costs more (0.48 ms per 9 600 rows)
@@ -612,6 +615,7 @@ int snk_destroy(snk_handle h)
     { DevBuf *fb[] = {&h->a16h, &h->a16l, &h->s16h, &h->s16l, &h->b16h, &h->b16l, &h->eps16, &h->thr32, &h->gmin32, &h->fmax2, &h->gs_tiles_b, &h->cq16, &h->rho16, &h->gs_rho16, &h->kth16, &h->margin_stat, &h->e1_16, &h->thr1_32, &h->cpairs, &h->cpairctl,
                       &h->ball_c, &h->ball_cn, &h->ball_rad, &h->ball_c16, &h->ball_tq, &h->ball_nq,
                       &h->ball_aq, &h->ball_nql, &h->ball_gmin, &h->ball_bound,
+                      &h->ball_c2, &h->ball_cn2, &h->ball_rad2, &h->ball_s16, &h->ball_mask,
                       &h->sh_cnt, &h->sh_off, &h->sh_tot, &h->sh_totall, &h->sh_plan, &h->sh_pack, &h->sh_rpack, &h->sh_offq};
       for (auto *b : fb) b->release(); }
     for (int i = 0; i < 8; ++i) {
@@ -856,6 +860,21 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
                     launch_build_db16b(h->ball_c.as<double>(), h->ball_cn.as<double>(), vt, h->Dt, h->Dpad, ct, 0, 0, nt, h->ball_c16.p, h->stream);
                     HIPCHK(hipGetLastError());
                     h->ball_tiles = vt;
+                    // one level up: the balls of 32 consecutive tiles, as one more operand in the same format
+                    h->ball_supers = 0;
+                    if (ct >= 64) {
+                        const int64_t ct2 = (ct + 31) / 32;
+                        CHK(h->ball_c2.ensure((size_t)ct * h->Dpad * sizeof(double)));
+                        CHK(h->ball_cn2.ensure((size_t)ct * sizeof(double)));
+                        CHK(h->ball_rad2.ensure((size_t)ct * sizeof(float)));
+                        CHK(h->ball_s16.ensure((size_t)ct2 * per_tile));
+                        launch_build_super_balls(h->ball_c.as<double>(), h->ball_rad.as<float>(), h->N, vt, h->Dt, h->Dpad, ct, h->ball_c2.as<double>(),
+                                                 h->ball_cn2.as<double>(), h->ball_rad2.as<float>(), h->stream);
+                        launch_db16b_ratios(h->ball_c2.as<double>(), ct, h->Dt, h->Dpad, h->rho16.as<double>(), h->stream, true);
+                        launch_build_db16b(h->ball_c2.as<double>(), h->ball_cn2.as<double>(), ct, h->Dt, h->Dpad, ct2, 0, 0, nt, h->ball_s16.p, h->stream);
+                        HIPCHK(hipGetLastError());
+                        h->ball_supers = ct;
+                    }
                 }
             }
         }
@@ -1325,9 +1344,20 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
                     CHK(h->ball_nq.ensure((size_t)Tpad * sizeof(float)));
                     launch_ball_query_terms(h->thr32.as<float>(), h->eps16.as<double>(), h->qnorm.as<double>(), T, Tpad, h->ball_tq.as<float>(),
                                             h->ball_nq.as<float>(), s);
+                    const unsigned int *visit = nullptr;
+                    if (h->prefilter_super_balls && h->ball_supers > 0) {
+                        // the balls of 32 tiles first: a bit per (super ball, query tile); the tile pass visits the marked blocks
+                        const size_t words = (size_t)h->ball_supers * ((Tpad / 32 + 31) / 32);
+                        CHK(h->ball_mask.ensure(words * sizeof(unsigned int)));
+                        HIPCHK(hipMemsetAsync(h->ball_mask.p, 0, words * sizeof(unsigned int), s));
+                        launch_knn_balls16b(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->ball_s16.p, h->b16l.p, h->ball_rad2.as<float>(),
+                                            h->ball_tq.as<float>(), h->ball_nq.as<float>(), Tpad, h->ball_supers, nullptr, nullptr, 0u, s,
+                                            h->ball_mask.as<unsigned int>(), nullptr);
+                        visit = h->ball_mask.as<unsigned int>();
+                    }
                     launch_knn_balls16b(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->ball_c16.p, h->b16l.p, h->ball_rad.as<float>(),
                                         h->ball_tq.as<float>(), h->ball_nq.as<float>(), Tpad, h->ball_tiles, h->cpairs.p,
-                                        h->cpairctl.as<unsigned int>(), pair_cap, s);
+                                        h->cpairctl.as<unsigned int>(), pair_cap, s, nullptr, visit);
                     h->ball_limit = h->coarse_gate_fraction * (double)(Tpad / 32) * (double)h->ball_tiles;
                 }
                 h->ball_pass_ran = balls;
@@ -1366,7 +1396,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
                                 h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), eps_c_run, bf ? h->cq16.as<double>() : nullptr, cand_dev, dist_dev, d2_dev, status_dev, nullptr, s,
                                 bound_in != nullptr,         // a shard's lists under the shared bound are short
-                                bound_in ? nullptr : h->thr.as<double>(), h->margin_stat.as<unsigned int>());
+                                bound_in ? nullptr : h->thr.as<double>(), h->margin_stat.as<unsigned int>(), h->rowflag.as<int>());
         }
         if (deferred_status) {               // the batch caller redoes failures with precision 0
             // (and learns how many tile pairs the ball pass listed)
@@ -3355,6 +3385,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
         CHK(no_batch_in_flight(h, "snk_set_option(prefilter_balls)"));
         h->prefilter_balls = (int)value;
         h->have_weights = false;          // the ball operand is built by set_weights
+    } else if (!strcmp(name, "prefilter_super_balls")) {
+        if (value != 0.0 && value != 1.0) return fail("prefilter_super_balls must be 0 or 1");
+        h->prefilter_super_balls = (int)value;
     } else if (!strcmp(name, "prefilter_ball_bound")) {
         if (value != 0.0 && value != 1.0) return fail("prefilter_ball_bound must be 0 or 1");
         h->prefilter_ball_bound = (int)value;
@@ -3517,6 +3550,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "prefilter_two_pass")) *out = h->prefilter_two_pass;
     else if (!strcmp(name, "prefilter_balls")) *out = h->prefilter_balls;
     else if (!strcmp(name, "prefilter_ball_bound")) *out = h->prefilter_ball_bound;
+    else if (!strcmp(name, "prefilter_super_balls")) *out = h->prefilter_super_balls;
     else if (!strcmp(name, "wide_launches")) *out = (double)h->wide_launches;
     else if (!strcmp(name, "shard_compact")) *out = h->shard_compact;
     else if (!strcmp(name, "shard_last_sent_mb")) *out = h->shard_last_sent_mb;

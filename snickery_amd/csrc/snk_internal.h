@@ -113,7 +113,8 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
                          int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c, const double *cq,
                          int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s,
                          bool split_short = false,    // split_short: rows of at most 512 entries through the small-LDS instance
-                         const double *thr = nullptr, unsigned int *margin_stat = nullptr);   // tripwire of the prefilter's key bound
+                         const double *thr = nullptr, unsigned int *margin_stat = nullptr,    // tripwire of the prefilter's key bound
+                         int *retry = nullptr);     // T ints of scratch: the lean form (keys only in LDS) first, the full form for the rows it flags
 void launch_candidate_dist(const double *Fw, int Dpad, int D, int64_t N, const double *Qp,
                            const int64_t *cand, int64_t T, int K, double *dist, hipStream_t s);
 void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, int K,
@@ -177,7 +178,10 @@ void launch_ball_query_terms(const float *thr32, const double *eps, const double
                              hipStream_t s);
 bool launch_knn_balls16b(int terms, int dch, int grid_cus, const void *C16, const void *B16, const float *rad, const float *tq,
                          const float *nq, int64_t T32, int64_t n_tiles, void *pairs, unsigned int *pair_ctl, unsigned int pair_cap,
-                         hipStream_t s);
+                         hipStream_t s, unsigned int *mask_out = nullptr, const unsigned int *visit = nullptr);
+// the balls of 32 consecutive tiles: the ball pass's own first level (mask_out / visit above)
+void launch_build_super_balls(const double *C, const float *rad, int64_t N, int64_t n_tiles, int Dt, int Dpad, int64_t n_super, double *C2,
+                              double *cnorm2, float *rad2, hipStream_t s);
 void launch_db16b_ratios(const double *Fw, int64_t N, int Dt, int Dpad, double *rho, hipStream_t s, bool accumulate = false);   // accumulate: max with what rho holds
 bool launch_knn_sweep16b(int mode, int terms, int nt, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32,
                          int64_t T32, int64_t n_slabs, unsigned int *ctr, float *gmin32, int64_t G, void *pool,
