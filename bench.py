@@ -220,7 +220,8 @@ def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')),
                             '(SURVEY 8d): %s; frac_at_4_bytes_per_element prices the float32 database as uploaded'
                             % ('float16 tiles, s = 2' if f16 else 'float32 tiles, s = 4')}
         out[name] = {'units': N, 'multiepoch': me, 'frames': T, 'steps': steps, 'us_per_step': us_step, 'batch': batch,
-                     'target_term_hoisted': bool(hoisted), 'join_tiles': 'float16' if f16 else 'float32',
+                     'target_term_hoisted': bool(hoisted), 'target_term_pipe': ('bf16 x 3 pieces' if eng.info('greedy_hoist16_launches') > 0 else 'float64') if hoisted else None,
+                     'join_tiles': 'float16' if f16 else 'float32',
                      'frames_per_s': T / dt, 'ms_per_utterance': dt * 1e3, 'roofline': roof,
                      'path_head': [int(v) for v in path[:4]]}
         eng.close()

@@ -311,6 +311,8 @@ struct snk_engine {
     int64_t greedy_hoist_launches = 0;    // scans that read the hoisted target term
     int64_t greedy_second_rounds = 0, greedy_exact_windows = 0;     // statistics of the float32 scan's exact decisions
     int greedy_hoist = 1;                 // 1: the float32 scan reads one precomputed target value per window (default)
+    int greedy_hoist_fast = 1;            // 1: scans of float16 join tiles take the target values from the bf16 matrix pipe (default)
+    int64_t greedy_hoist16_launches = 0;
     double greedy_hoist_max_gb = 48.0;    // products of one scan group beyond this many GB: the scan computes the target term itself
     int greedy_mode = 2;                  // 2: auto (batches: float32 scan; one utterance: exact scan); 1: float32 prefilter scan in one
                                           // persistent launch (exact decision); 0: exact float64 scan, a launch per step
@@ -2215,20 +2217,9 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
                 CHK(d2h_sync(h, &h->gh_fwmax2, h->gh_max.p, sizeof(double), h->stream));
                 h->gh_ready = true;
             }
-            CHK(h->gh_aq.ensure((size_t)prows * KA * sizeof(double)));
-            CHK(h->gh_qn2.ensure((size_t)prows * sizeof(double)));
-            CHK(h->gh_W.ensure((size_t)rows * (size_t)Wp * sizeof(float)));
-            int64_t r0 = 0, p0 = 0;
-            for (int u = 0; u < nu; ++u) {
-                float *W = h->gh_W.as<float>() + (size_t)r0 * Wp;
-                double *qn2 = h->gh_qn2.as<double>() + p0;
-                launch_hoist_product(g, h->F_unw.as<float>(), h->Fp, h->N, h->Dt, h->wt.as<double>(), h->Qraw.as<double>(), q_off[u], ns[u],
-                                     h->gh_nw.as<double>(), h->gh_aq.as<double>() + (size_t)p0 * KA, qn2, W, h->stream);
-                hst.W[u] = W; hst.qn2[u] = qn2;
-                r0 += ns[u]; p0 += greedy_hoist_rows(ns[u]);
-            }
-            HIPCHK(hipGetLastError());
-            hst.Wp = Wp; hst.c = greedy_hoist_c(g, h->Dt); hst.fwmax2 = h->gh_fwmax2;
+            // float16 join tiles: databases that are streamed from HBM (scans beyond 192 MB; or forced), up to three utterances
+            // per scan.  Decided before the product: such a scan takes the target values from the bf16 pipe
+            bool scan16 = false;
             if (h->greedy_f16 && nu <= 3) {
                 CHK(h->gh_max.ensure(64));
                 if (!h->gt16_ready) {
@@ -2254,10 +2245,27 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
                 }
                 if (h->gt16_ok) {
                     hst.JT16 = h->gtiles16.p; hst.f16_delta = h->g16_delta; hst.f16_force = h->greedy_f16 == 2;
-                    // (launch_greedy32 takes the float16 tiles for streamed databases -- scans beyond 192 MB -- or when forced)
-                    if (hst.f16_force || (double)g.Nwin * (double)(g.jdim + 1) * 4.0 > (double)((size_t)192 << 20)) h->greedy_f16_launches += 1;
+                    // (launch_greedy32 takes the float16 tiles under the same condition)
+                    scan16 = hst.f16_force || (double)g.Nwin * (double)(g.jdim + 1) * 4.0 > (double)((size_t)192 << 20);
+                    if (scan16) h->greedy_f16_launches += 1;
                 }
             }
+            const bool fast = scan16 && h->greedy_hoist_fast && greedy_hoist16_supported(g, h->Dt);
+            CHK(h->gh_aq.ensure((size_t)prows * KA * sizeof(double)));
+            CHK(h->gh_qn2.ensure((size_t)prows * sizeof(double)));
+            CHK(h->gh_W.ensure((size_t)rows * (size_t)Wp * sizeof(float)));
+            int64_t r0 = 0, p0 = 0;
+            for (int u = 0; u < nu; ++u) {
+                float *W = h->gh_W.as<float>() + (size_t)r0 * Wp;
+                double *qn2 = h->gh_qn2.as<double>() + p0;
+                (fast ? launch_hoist_product16 : launch_hoist_product)(g, h->F_unw.as<float>(), h->Fp, h->N, h->Dt, h->wt.as<double>(),
+                                     h->Qraw.as<double>(), q_off[u], ns[u], h->gh_nw.as<double>(), h->gh_aq.as<double>() + (size_t)p0 * KA, qn2, W, h->stream);
+                hst.W[u] = W; hst.qn2[u] = qn2;
+                r0 += ns[u]; p0 += greedy_hoist_rows(ns[u]);
+            }
+            HIPCHK(hipGetLastError());
+            hst.Wp = Wp; hst.c = fast ? greedy_hoist_c16(g, h->Dt) : greedy_hoist_c(g, h->Dt); hst.fwmax2 = h->gh_fwmax2;
+            if (fast) h->greedy_hoist16_launches += 1;
             h->greedy_hoist_launches += 1;
         }
     }
@@ -3417,6 +3425,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "greedy_hoist")) {
         if (value != 0.0 && value != 1.0) return fail("greedy_hoist must be 0 or 1");
         h->greedy_hoist = (int)value;
+    } else if (!strcmp(name, "greedy_hoist_fast")) {
+        if (value != 0.0 && value != 1.0) return fail("greedy_hoist_fast must be 0 or 1");
+        h->greedy_hoist_fast = (int)value;
     } else if (!strcmp(name, "greedy_hoist_max_gb")) {
         if (!(value >= 0.0)) return fail("greedy_hoist_max_gb must be >= 0");
         h->greedy_hoist_max_gb = value;
@@ -3493,6 +3504,8 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "greedy_mode")) *out = h->greedy_mode;
     else if (!strcmp(name, "greedy_hoist")) *out = h->greedy_hoist;
     else if (!strcmp(name, "greedy_hoist_launches")) *out = (double)h->greedy_hoist_launches;
+    else if (!strcmp(name, "greedy_hoist_fast")) *out = h->greedy_hoist_fast;
+    else if (!strcmp(name, "greedy_hoist16_launches")) *out = (double)h->greedy_hoist16_launches;
     else if (!strcmp(name, "greedy_last_undecided_step")) *out = (double)h->greedy_last_status[0] - 1.0;     // -1: every step was decided
     else if (!strcmp(name, "greedy_last_watchdog")) *out = (double)h->greedy_last_status[3];
     else if (!strcmp(name, "greedy_last_why_candidates")) *out = (double)h->greedy_last_status[4];

@@ -282,9 +282,13 @@ int64_t greedy_hoist_pitch(const GreedyLayout &g);
 int greedy_hoist_k(const GreedyLayout &g, int Dt);
 bool greedy_hoist_supported(const GreedyLayout &g, int Dt);
 double greedy_hoist_c(const GreedyLayout &g, int Dt);
+bool greedy_hoist16_supported(const GreedyLayout &g, int Dt);      // the product on the bf16 pipe (scans of float16 join tiles)
+double greedy_hoist_c16(const GreedyLayout &g, int Dt);
 int64_t greedy_hoist_rows(int64_t nsteps);
 void launch_hoist_window_norms(const GreedyLayout &g, const double *fnorm, double *nw, unsigned long long *max_bits, hipStream_t s);
 void launch_hoist_product(const GreedyLayout &g, const float *F_unw, int Fp, int64_t n_f_rows, int Dt, const double *wt, const double *Q,
+                          int64_t q_off, int64_t nsteps, const double *nw, double *Aq, double *qn2, float *W, hipStream_t s);
+void launch_hoist_product16(const GreedyLayout &g, const float *F_unw, int Fp, int64_t n_f_rows, int Dt, const double *wt, const double *Q,
                           int64_t q_off, int64_t nsteps, const double *nw, double *Aq, double *qn2, float *W, hipStream_t s);
 size_t greedy32_block_bytes(int nblk);
 void greedy32_trace_dump();          // developer aid (SNK_G32_TRACE=file): timeline of the last launch

@@ -172,10 +172,16 @@ def test_float16_join_tiles_keep_the_results(engine, me, lfat, mode, Dj, Dt, off
         utts = [o.synthetic_targets(F_unw, T, seed=16 + i) * wt for i, T in enumerate(lens)]
         starts = [-1, 17, N - me - 3, 0]
         f0 = engine.info('greedy_fallbacks')
-        for U, st in zip(utts[:3], starts[:3]):
-            path, d = engine.greedy(U, start_state=st, return_distances=True)
-            op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, U, me, lfat, mode, st)
-            assert path == op and np.array_equal(d, od)
+        # scans of float16 tiles take the target values from the bf16 matrix pipe (three exact bf16 pieces per operand,
+        # hoist_product16_kernel); greedy_hoist_fast 0 keeps the float64 product
+        for fast in (0, 1):
+            engine.set_option('greedy_hoist_fast', fast)
+            n16 = engine.info('greedy_hoist16_launches')
+            for U, st in zip(utts[:3], starts[:3]):
+                path, d = engine.greedy(U, start_state=st, return_distances=True)
+                op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, U, me, lfat, mode, st)
+                assert path == op and np.array_equal(d, od)
+            assert engine.info('greedy_hoist16_launches') == n16 + 3 * fast
         assert engine.info('greedy_f16_delta') > 0.0
         paths, dists = engine.greedy_batch(utts[:3], start_states=starts[:3], return_distances=True)      # three per scan
         for U, st, p, d in zip(utts, starts, paths, dists):
@@ -198,7 +204,7 @@ def test_float16_join_tiles_keep_the_results(engine, me, lfat, mode, Dj, Dt, off
             path, d = engine.greedy(U, start_state=3100, return_distances=True)
             assert path == list(range(3100, 3100 + 15 * me, me)) and np.all(d == 0.0)
     finally:
-        engine.set_option('greedy_f16', 1)
+        engine.set_option('greedy_f16', 1); engine.set_option('greedy_hoist_fast', 1)
 
 
 def test_values_outside_the_float16_range_keep_float32_tiles(engine):
