@@ -22,12 +22,13 @@
 //    answer, and the float32 minimum is within 2 E of it -- below 1e-3 relative -- so for eps >= 1e-3 the
 //    float32 minimum (lowest index among equal float32 totals) is returned and nothing is re-evaluated.
 //  * ONE persistent launch walks all steps of up to three utterances (six with the hoisted target term,
-//    greedy_hoist_kernels.hip: the scan then reads the join columns and one float32 per window and utterance):
-//    between two steps the workgroup that arrives last decides the step and appends the winners to the path --
-//    agent-scope stores that ARE the release: the path entries are -1 before the launch, everybody polls the
-//    step's entries (sc1 loads) and builds the next (weight, reference) table itself in LDS from the winners' join
-//    rows.  A generation word carries the two rare events (a request for every lane's candidates; the end of the
-//    launch at an undecidable step).  A launch per step cost more than the scan itself at 65 536 units.
+//    greedy_hoist_kernels.hip: the scan then reads the join columns and one float32 per window and utterance).  Between two
+//    steps every workgroup publishes its record and gathers everybody's (two trips through the fabric; tagged 8-byte granules,
+//    see the step's tail): all of them derive the same minimum, bound and holders, so the usual step is settled everywhere at
+//    once and the next (weight, reference) table is built by every workgroup for itself, in LDS, from the winners' join rows;
+//    otherwise the workgroup that published the minimum decides and its path entry (-1 before the launch) is the release.  A
+//    generation word carries the end of the launch at an undecidable step.  A launch per step cost more than the scan itself
+//    at 65 536 units.
 //  * Instances: <target rows in LDS, hoisted target term, utterances per scan, float16 join tiles>.  With the hoisted term
 //    the scan is the join stream alone; databases that do not fit the caches are then read from a float16 copy of the
 //    join tiles (half the bytes) with the bound widened by the rounding of the tiles (g32_err16) -- about fifteen windows
@@ -54,17 +55,13 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 #define G32_UB 3              // utterances per scan: (w, ref0, ref1, ref2) = 16 table bytes per column
 #define G32_UBX 6             // ... of the hoisted scan's wide instance: (w, ref0 .. ref5, -) = 32 table bytes per column
 
-struct G32Rec {               // what a workgroup publishes per utterance and step
-    float v1, v2, v3, pad;
-    int64_t a1, a2;
-};
-
-#define G32_LIST 4096          // candidates one second-phase round can take per utterance
-struct G32Ctl {               // second-phase hand-off (global memory, sc1 accesses)
-    double tau[G32_UBX];
-    int64_t pending[G32_UBX];
-    unsigned int list_count[G32_UBX];
-    unsigned int need, list_over;
+#define G32_SEND 63            // windows a holder's slot takes (+ the count granule)
+#define G32_CAND 768           // windows the deciding workgroup weighs (LDS list)
+struct G32Info {              // what the gather found for an utterance (LDS; the same in every workgroup)
+    int state;                // 0 not active | 1 settled: winner | 2 nothing finite | 3 the workgroup D decides | 4 the launch was ended
+    int D, nH, sender;        // who decides | holders of windows inside the bound | this workgroup sends its lanes' windows
+    int64_t winner;
+    double tau;
 };
 
 struct Top3 {                 // two best windows (value, index) and the third value; indices fit 31 bits (snk_upload_db)
@@ -168,8 +165,8 @@ __device__ void g32_build_table(const GreedyArgs &a, int64_t step, const int64_t
 template <bool IN_LDS, bool HOIST, int UB, bool F16>
 __global__ void __launch_bounds__(G32_W * G32_MAXW)
 greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_bytes,
-                G32Rec *blk, unsigned int *arrive, unsigned int *arrive2, unsigned int *gen,
-                G32Ctl *ctl, int64_t *clist_g, int64_t *path, int64_t *status,       // shared between workgroups: no restrict
+                unsigned long long *pub, unsigned long long *send, unsigned int *gen,
+                int64_t *path, int64_t *status,                                       // shared between workgroups: no restrict
                 unsigned long long *trace)
 {
     const bool approx = (flags & 1) != 0;                  // search_epsilon mode
@@ -186,9 +183,8 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
             trace[((size_t)st * gridDim.x + blockIdx.x) * 16 + k] = __builtin_amdgcn_s_memrealtime();
     };
     extern __shared__ __align__(16) char lds[];          // table | one target block per wavefront (lds_mode 1)
-    __shared__ int is_last, gen_seen;
+    __shared__ int gen_seen;
     __shared__ int64_t next_rows[G32_UBX];                 // the step's winners, as the polling thread saw them
-    int collect_rounds = 0;                               // second-phase rounds so far (the same in every workgroup)
     const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr bool in_lds = IN_LDS;
@@ -209,7 +205,9 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
     const int table_bytes = ncols * 16 * TE;
     float *const Fs = reinterpret_cast<float *>(lds + table_bytes) + (size_t)wave * (G32_W + a.me - 1) * pitch;
     const int ntiles = (int)((a.Nwin + G32_W - 1) / G32_W);
-    const int wave_id = blockIdx.x * nwaves + wave, wave_stride = gridDim.x * nwaves;
+    // tile t belongs to wavefront (t mod wave_stride); consecutive ids run over the WORKGROUPS first: the tiles that do not
+    // divide evenly (11.4 per wavefront at 1.5 M units) then spread over all compute units instead of filling the first ones
+    const int wave_id = wave * gridDim.x + blockIdx.x, wave_stride = gridDim.x * nwaves;
     const int my_tiles = wave_id < ntiles ? (ntiles - 1 - wave_id) / wave_stride + 1 : 0;
     const int total = my_tiles * ring_per_tile;
     const unsigned int nb = gridDim.x;
@@ -430,7 +428,36 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
         __syncthreads();                                      // the reduction arrays alias the table and the target blocks
         stamp(step, 2);
 
-        // ---- workgroup top-3 per utterance -> global memory (sc1), arrival tree ----
+        // ---- the step's tail: two trips through the fabric.  Every workgroup PUBLISHES its record (three 8-byte granules
+        //      per utterance: value | window | tag bit; double buffered by the step's parity, the tag bit flips every second
+        //      step: a granule proves its own step), every workgroup GATHERS all records (a wavefront per utterance) and
+        //      derives the same facts from them: the float32 minimum, the bound tau, who holds windows inside it.  Usually
+        //      that settles the step everywhere at once (one window inside the bound; search_epsilon mode).  Otherwise the
+        //      workgroup that published the minimum decides -- from its own lanes' candidates (the float16 scan's usual case:
+        //      the best window's neighbours sit in one tile), from the other holders' published windows, and from the lists
+        //      of those that hold more than they published (tagged granules in a slot of their own: no ordering needed) -- and
+        //      its path entry is the release the others poll.  (Until round 4 the step went through two counter trees, a
+        //      deciding workgroup that read the records, a generation word, every lane's offers through global atomics and a
+        //      second tree: seven dependent trips and more.)
+        //      LDS: [0, 1024) wavefront records | [1024, 1536) what the gather found | [2048, 8192) the decider's candidates |
+        //      [8192, 16384) exact decision | term arrays
+        const unsigned int tagbit = (unsigned int)((step >> 1) & 1);
+        const unsigned int stag = (unsigned int)step + 1u;             // tag of the senders' lists
+        unsigned long long *const pub_s = pub + (size_t)(step & 1) * G32_UBX * nb * 4;
+        G32Info *const info = reinterpret_cast<G32Info *>(lds + 1024);
+        int *const ccount = reinterpret_cast<int *>(lds + 1024 + 384);   // [0] candidates, [1] more than anybody kept
+        unsigned long long *const clist = reinterpret_cast<unsigned long long *>(lds + 2048);
+        auto pack = [&](float v, int i) {
+            return (unsigned long long)__builtin_bit_cast(unsigned int, v) | ((unsigned long long)(((unsigned int)i << 1) | tagbit) << 32);
+        };
+        auto ld64 = [](unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        auto st64 = [](unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        auto give_up = [&]() {                                        // watchdog: the launch ends, the caller falls back to the exact scan
+            __hip_atomic_store(&status[3], (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(gen, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             if (u >= a.nu) break;                                 // uniform
@@ -440,42 +467,147 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
             // (recursive doubling: the partner's set is disjoint from the lane's at every level)
             if (lane == 0) red3[u * G32_MAXW + wave] = t;
         }
+        if (tid < G32_UBX) info[tid].state = 0;
         __syncthreads();
-        if (tid < UB && tid < a.nu) {                             // thread u merges the wavefronts' sets of utterance u (all in wavefront 0)
+        // publish (thread u merges the wavefronts' sets of utterance u; a test hook keeps workgroup 0 silent at step 1)
+        if (tid < UB && tid < a.nu && step < a.nsteps_u[tid] && !(test_stall && step == 1 && blockIdx.x == 0)) {
             Top3 r = red3[tid * G32_MAXW];
             for (int w = 1; w < nwaves; ++w) top3_merge(r, red3[tid * G32_MAXW + w]);
-            G32Rec *o = blk + ((size_t)tid * nb + blockIdx.x);
-            __hip_atomic_store(&o->v1, r.v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&o->v2, r.v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&o->v3, r.v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&o->a1, (int64_t)r.a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&o->a2, (int64_t)r.a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            unsigned long long *o = pub_s + ((size_t)tid * nb + blockIdx.x) * 4;
+            st64(o, pack(r.v1, r.a1));
+            st64(o + 1, pack(r.v2, r.a2));
+            st64(o + 2, pack(r.v3, 0));
+        }
+        stamp(step, 3);
+        // gather and classify: a wavefront per utterance, four records per lane
+        for (int u = wave; u < UB; u += nwaves) {                     // uniform per wavefront
+            if (!(u < a.nu && step < a.nsteps_u[u])) continue;
+            float rv1[4], rv2[4], rv3[4];
+            int ra1[4], ra2[4];
+            bool got = false;
+            const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned int b = lane + 64 * q;
+                    rv1[q] = rv2[q] = rv3[q] = __builtin_inff(); ra1[q] = ra2[q] = INT32_MAX;
+                    if (b < nb) {
+                        unsigned long long *o = pub_s + ((size_t)u * nb + b) * 4;
+                        const unsigned long long g0 = ld64(o), g1 = ld64(o + 1), g2 = ld64(o + 2);
+                        ok = ok && ((unsigned int)(g0 >> 32) & 1u) == tagbit && ((unsigned int)(g1 >> 32) & 1u) == tagbit
+                                && ((unsigned int)(g2 >> 32) & 1u) == tagbit;
+                        rv1[q] = __builtin_bit_cast(float, (unsigned int)g0); ra1[q] = (int)((unsigned int)(g0 >> 32) >> 1);
+                        rv2[q] = __builtin_bit_cast(float, (unsigned int)g1); ra2[q] = (int)((unsigned int)(g1 >> 32) >> 1);
+                        rv3[q] = __builtin_bit_cast(float, (unsigned int)g2);
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) { got = true; break; }
+                if (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0xffffffffu) break;
+                // watchdog: a step takes microseconds.  Seconds without news mean that some workgroup of the launch is not
+                // running (the device shared with another spinning launch)
+                if (__builtin_amdgcn_s_memrealtime() - t_wait > G32_STALL_TICKS) { if (lane == 0) give_up(); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (fenced) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (!got) { if (lane == 0) info[u].state = 4; continue; }
+            float mv = __builtin_inff();
+            int mi = INT32_MAX, mb = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (lt_vi(rv1[q], ra1[q], mv, mi)) { mv = rv1[q]; mi = ra1[q]; mb = lane + 64 * q; }
+#pragma unroll
+            for (int m = 1; m <= 32; m <<= 1) {
+                const float ov = __shfl_xor(mv, m, 64); const int oi = __shfl_xor(mi, m, 64), ob = __shfl_xor(mb, m, 64);
+                if (lt_vi(ov, oi, mv, mi)) { mv = ov; mi = oi; mb = ob; }
+            }
+            int state = 3, nH = 0, sender = 0;
+            double tau = 0.0;
+            if (!(mv < __builtin_inff())) state = 2;
+            else {
+                double V2 = V2w[0];
+#pragma unroll
+                for (int k = 1; k < UB; ++k) V2 = u == k ? V2w[k] : V2;
+                double EW = EWw[0];
+#pragma unroll
+                for (int k = 1; k < UB; ++k) EW = u == k ? EWw[k] : EW;
+                // search_epsilon mode: the float32 minimum is the answer -- with a hoisted target term only where its
+                // ABSOLUTE bound is small against the minimum (it is not for near-exact matches: decided exactly then)
+                if (approx && (!HOIST || 4.0 * (errf((double)mv, V2) + EW) <= 1e-3 * (double)mv)) state = 1;
+                else {
+                    // tau = the largest solution of tau = M + 2 E(tau), approached from above (E(0) = 0: from below the
+                    // iteration would stall at M = 0, where the natural path lives).  E is increasing and concave: every
+                    // iterate stays above the solution, so any number of rounds gives a valid bound; the map contracts by
+                    // ~1e-5 per round and three rounds leave nothing to gain (eight cost 1 us of float64 square roots)
+                    const double M = (double)mv + 2.0 * EW;
+                    tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300 + (F16 ? 64.0 * a.f16_delta * a.f16_delta : 0.0);
+                    for (int it = 0; it < 3; ++it) tau = M + 2.0 * errf(tau, V2);
+                    tau = tau * (1.0 + 1e-6) + 1e-300;
+                    int nc = 0;
+                    bool cov = false;
+                    float v3me = __builtin_inff();
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned long long h1 = __builtin_amdgcn_ballot_w64((double)rv1[q] <= tau);
+                        nH += __popcll(h1);
+                        nc += __popcll(h1) + __popcll(__builtin_amdgcn_ballot_w64((double)rv2[q] <= tau));
+                        cov = cov || __builtin_amdgcn_ballot_w64((double)rv3[q] <= tau) != 0ull;
+                        if ((int)(blockIdx.x >> 6) == q) v3me = __shfl(rv3[q], (int)(blockIdx.x & 63u), 64);
+                    }
+                    if (nc == 1 && !cov) state = 1;               // the only window inside the bound is the float32 minimum itself
+                    else sender = (mb != (int)blockIdx.x && (double)v3me <= tau) ? 1 : 0;
+                }
+            }
+            if (lane == 0) {
+                G32Info x;
+                x.state = state; x.D = mb; x.nH = nH; x.sender = sender; x.winner = (int64_t)mi; x.tau = tau;
+                info[u] = x;
+            }
         }
         __syncthreads();
-        // arrival on a 256 -> 16 -> 1 tree of monotonic counters; true for the workgroup that completes it
-        auto arrive_last = [&](unsigned int *cnt, unsigned int round) -> bool {
-            if (tid == 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                const unsigned int b = blockIdx.x;
-                const unsigned int S1 = nb < GR_S1 ? nb : GR_S1, sl1 = b % S1, q1 = (nb - sl1 + S1 - 1) / S1;
-                bool last = false;
-                // (a workgroup alone in its first-level slot -- up to 256 workgroups -- goes straight to the second level:
-                // one fabric round trip less on every step's critical path)
-                if (q1 == 1u || __hip_atomic_fetch_add(cnt + 32 * sl1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == round * q1 - 1) {
-                    const unsigned int S2 = S1 < GR_S2 ? S1 : GR_S2, sl2 = sl1 % S2, q2 = (S1 - sl2 + S2 - 1) / S2;
-                    if (__hip_atomic_fetch_add(cnt + 32 * (GR_S1 + sl2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == round * q2 - 1)
-                        last = __hip_atomic_fetch_add(cnt + 32 * (GR_S1 + GR_S2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                               == round * S2 - 1;
-                }
-                if (fenced && last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                is_last = last;
+        stamp(step, 4);
+        int st[UB];
+        {
+            bool leave = false, none = false;
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                st[u] = (u < a.nu && step < a.nsteps_u[u]) ? info[u].state : 0;
+                leave = leave || st[u] == 4;
+                none = none || st[u] == 2;
             }
-            __syncthreads();
-            const bool r = is_last != 0;
-            __syncthreads();
-            return r;
+            if (leave) return;                                    // the launch was ended (watchdog, an undecidable step)
+            if (none) {                                           // nothing finite: every workgroup sees it, one reports it
+                if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+        // the lanes' windows inside the bound -> the candidate list in LDS (cap entries); a third one that reaches tau is
+        // beyond what was kept (mass ties): the step is then undecidable here
+        auto offer = [&](int u, double tau, int cap) {
+            const Top3 &t = best[u];
+            if ((double)t.v1 <= tau) { const int p = atomicAdd(ccount, 1); if (p < cap) clist[p] = (unsigned long long)(unsigned int)t.a1; }
+            if ((double)t.v2 <= tau) { const int p = atomicAdd(ccount, 1); if (p < cap) clist[p] = (unsigned long long)(unsigned int)t.a2; }
+            if ((double)t.v3 <= tau) ccount[1] = 1;
         };
+        // a holder of more windows than it published, and not the one who decides: its lanes' windows go to its slot
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (st[u] != 3 || !info[u].sender) continue;            // uniform
+            const double tau = info[u].tau;
+            if (tid == 0) { ccount[0] = 0; ccount[1] = 0; }
+            __syncthreads();
+            offer(u, tau, G32_SEND);
+            __syncthreads();
+            const int n = ccount[0];
+            const bool over = ccount[1] != 0 || n > G32_SEND;
+            unsigned long long *slot = send + ((size_t)u * nb + blockIdx.x) * (G32_SEND + 1);
+            if (fenced && tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (tid < n && tid < G32_SEND) st64(slot + 1 + tid, clist[tid] | ((unsigned long long)stag << 32));
+            if (tid == 0) st64(slot, (unsigned long long)(over ? 0xffffu : (unsigned int)n) | ((unsigned long long)stag << 32));
+            __syncthreads();
+            stamp(step, 7);
+        }
         // exact decision among n candidates (ids through `get`): a wavefront per candidate, canonical float64 totals,
         // lowest index on exact ties
         const int ex_cols = a.jdim + a.nep * a.Dt;
@@ -593,336 +725,130 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
             __syncthreads();
             return i0;
         };
-        // end of a step.  The winners ARE the release: every workgroup polls the step's path entries (-1 until
-        // written) and builds the next table itself.  An undecidable step ends the launch through the generation word.
         unsigned long long stat_rounds = 0, stat_windows = 0;
-        auto finalize = [&](const int64_t (&winner)[UB], bool undecided) {
-            if (fenced && tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        int64_t winner[UB];
+        bool pending[UB];
+        bool any_pending = false;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { winner[u] = 0; pending[u] = false; }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (st[u] == 1) {                                     // settled everywhere; workgroup 0 writes the path
+                winner[u] = info[u].winner;
+                if (blockIdx.x == 0 && tid == 0)
+                    __hip_atomic_store(&path[a.out_off[u] + step], winner[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }
+            if (st[u] != 3) continue;
+            if (info[u].D != (int)blockIdx.x) { pending[u] = true; any_pending = true; continue; }
+            // ---- this workgroup published the minimum: it decides ----
+            const double tau = info[u].tau;
+            const int nH = info[u].nH;
+            if (tid == 0) { ccount[0] = 0; ccount[1] = 0; }
+            __syncthreads();
+            offer(u, tau, G32_CAND);
+            if (nH > 1) {
+                // other holders: the published windows of those that kept nothing more, the lists of the others
+                for (unsigned int b = tid; b < nb; b += blockDim.x) {
+                    if (b == blockIdx.x) continue;
+                    unsigned long long *o = pub_s + ((size_t)u * nb + b) * 4;
+                    const unsigned long long g0 = ld64(o), g1 = ld64(o + 1), g2 = ld64(o + 2);
+                    const float v1 = __builtin_bit_cast(float, (unsigned int)g0), v2 = __builtin_bit_cast(float, (unsigned int)g1),
+                                v3 = __builtin_bit_cast(float, (unsigned int)g2);
+                    if (!((double)v1 <= tau)) continue;
+                    if (!((double)v3 <= tau)) {
+                        { const int p = atomicAdd(ccount, 1); if (p < G32_CAND) clist[p] = (unsigned long long)((unsigned int)(g0 >> 32) >> 1); }
+                        if ((double)v2 <= tau) { const int p = atomicAdd(ccount, 1); if (p < G32_CAND) clist[p] = (unsigned long long)((unsigned int)(g1 >> 32) >> 1); }
+                        continue;
+                    }
+                    unsigned long long *slot = send + ((size_t)u * nb + b) * (G32_SEND + 1);
+                    const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+                    unsigned int cnt = 0xffffu;
+                    for (int i = -1; i < (int)(cnt == 0xffffu ? 0 : cnt); ) {
+                        const unsigned long long g = ld64(slot + 1 + i);
+                        if ((unsigned int)(g >> 32) == stag) {
+                            if (i < 0) { cnt = (unsigned int)g & 0xffffu; if (cnt == 0xffffu) break; }
+                            else { const int p = atomicAdd(ccount, 1); if (p < G32_CAND) clist[p] = g & 0xffffffffull; }
+                            ++i;
+                            continue;
+                        }
+                        if (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0xffffffffu
+                            || __builtin_amdgcn_s_memrealtime() - t_wait > G32_STALL_TICKS) { cnt = 0xffffu; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (cnt == 0xffffu) ccount[1] = 1;              // more than the slot takes, or no news
+                }
+                if (fenced) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            }
+            __syncthreads();
+            const int n = ccount[0];
+            const bool undecided = ccount[1] != 0 || n > G32_CAND || n < 1;
+            __syncthreads();
+            stamp(step, 5);
             if (undecided) {
                 if (tid == 0) {
                     __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __hip_atomic_store(gen, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-            } else if (tid == 0) {
-#pragma unroll
-                for (int u = 0; u < UB; ++u)
-                    if (u < a.nu && step < a.nsteps_u[u])
-                        __hip_atomic_store(&path[a.out_off[u] + step], winner[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;                                           // uniform over the workgroup; the others see the generation word
             }
-            if (tid == 0 && (stat_rounds | stat_windows)) {       // statistics, behind the release
-                __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&status[1]), stat_rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&status[2]), stat_windows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                stat_rounds = 0; stat_windows = 0;
+            if (n == 1) winner[u] = (int64_t)clist[0];
+            else {
+                stat_rounds += 1; stat_windows += (unsigned long long)n;      // statistics: decisions by exact totals, their windows
+                winner[u] = exact_argmin(u, n, [&](int p) { return (int64_t)clist[p]; });
             }
-        };
-
-        stamp(step, 3);
-        if (!(test_stall && step == 1 && blockIdx.x == 0) && arrive_last(arrive, (unsigned int)step + 1u)) {
-            // ---- first decision, from the published two best windows of every workgroup ----
-            stamp(step, 4);
-            int64_t winner[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) winner[u] = 0;
-            unsigned int need = 0u;
-            bool undecided = false;
-            // everything the decision reads from memory is requested up front (one fabric round trip for the records,
-            // the reference norms and the bound's terms together: they cost 2 - 2.5 us each when asked one by one)
-            double V2r[UB], EWr[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                V2r[u] = 0.0; EWr[u] = 0.0;
-                if (!(u < a.nu && step < a.nsteps_u[u])) continue;      // uniform
-                V2r[u] = V2w[u];
-                EWr[u] = EWw[u];
-            }
-            // what the published records alone decide, one wavefront per utterance, side by side (the usual case: ONE
-            // window inside the bound; at 65 536 units the decisions of three utterances one after the other were 18 of
-            // a step's 40 us).  state 1: decided, 2: nothing finite, 0: candidates to weigh -- the workgroup's path below
-            int64_t *const fast_w = reinterpret_cast<int64_t *>(lds + 12288);
-            int *const fast_s = reinterpret_cast<int *>(lds + 12288 + 64);
-            for (int u = wave; u < UB; u += nwaves) {                   // uniform per wavefront
-                if (!(u < a.nu && step < a.nsteps_u[u])) continue;
-                float mv = __builtin_inff();
-                int64_t mi = INT64_MAX;
-                float qv1[4], qv2[4], qv3[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned int b = lane + 64 * q;
-                    qv1[q] = qv2[q] = qv3[q] = __builtin_inff();
-                    int64_t qa1 = INT64_MAX;
-                    if (b < nb) {
-                        G32Rec *r = blk + ((size_t)u * nb + b);
-                        const unsigned long long v12 = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&r->v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long v3p = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&r->v3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        qa1 = __hip_atomic_load(&r->a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        qv1[q] = __builtin_bit_cast(float, (unsigned int)v12); qv2[q] = __builtin_bit_cast(float, (unsigned int)(v12 >> 32));
-                        qv3[q] = __builtin_bit_cast(float, (unsigned int)v3p);
-                    }
-                    if (lt_vi(qv1[q], qa1, mv, mi)) { mv = qv1[q]; mi = qa1; }
-                }
-#pragma unroll
-                for (int m = 1; m <= 32; m <<= 1) {
-                    const float ov = __shfl_xor(mv, m, 64); const int64_t oi = __shfl_xor(mi, m, 64);
-                    if (lt_vi(ov, oi, mv, mi)) { mv = ov; mi = oi; }
-                }
-                int state = 0;
-                if (!(mv < __builtin_inff())) state = 2;
-                else {
-                    double V2 = V2w[0];
-#pragma unroll
-                    for (int k = 1; k < UB; ++k) V2 = u == k ? V2w[k] : V2;
-                    double EW = EWw[0];
-#pragma unroll
-                    for (int k = 1; k < UB; ++k) EW = u == k ? EWw[k] : EW;
-                    if (approx && (!HOIST || 4.0 * (errf((double)mv, V2) + EW) <= 1e-3 * (double)mv)) state = 1;
-                    else {
-                        const double M = (double)mv + 2.0 * EW;
-                        double tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300 + (F16 ? 64.0 * a.f16_delta * a.f16_delta : 0.0);
-                        for (int it = 0; it < 3; ++it) tau = M + 2.0 * errf(tau, V2);
-                        tau = tau * (1.0 + 1e-6) + 1e-300;
-                        int nc = 0;
-                        bool cov = false;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            nc += __popcll(__ballot((double)qv1[q] <= tau)) + __popcll(__ballot((double)qv2[q] <= tau));
-                            cov = cov || __ballot((double)qv3[q] <= tau) != 0ull;
-                        }
-                        if (nc == 1 && !cov) state = 1;           // the only window inside the bound is the float32 minimum itself
-                        else if (cov) {
-                            // a window nobody published may matter (the rule with float16 tiles: the best window's
-                            // neighbours sit in one tile): ask every lane, without weighing the published ones first
-                            state = 3;
-                            if (lane == 0) {
-                                __hip_atomic_store(&ctl->tau[u], tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                __hip_atomic_store(&ctl->list_count[u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                        }
-                    }
-                }
-                if (lane == 0) { fast_s[u] = state; fast_w[u] = mi; }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the requests' words, before the barrier and the generation word)
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                if (!(u < a.nu && step < a.nsteps_u[u])) continue;      // uniform
-                {
-                    const int fs = fast_s[u];
-                    if (fs == 1) { winner[u] = fast_w[u]; continue; }
-                    if (fs == 2) { undecided = true; continue; }
-                    if (fs == 3) { need |= 1u << u; continue; }
-                }
-                float mv = __builtin_inff();
-                int64_t mi = INT64_MAX;
-                // the records of all workgroups, read ONCE (four 8-byte agent-scope atomic loads each, in flight together;
-                // at most 256 workgroups and at least 64 threads: four per thread) and kept for the candidate pass
-                // behind the bound.  (Plain 16-byte loads were tried: `blk` is a restrict pointer and nothing orders an
-                // ordinary load against the OTHER workgroups' stores -- the records arrived stale.)
-                float rv1[4], rv2[4], rv3[4];
-                int64_t ra1[4], ra2[4];
-                {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const unsigned int b = tid + q * blockDim.x;
-                        rv1[q] = rv2[q] = rv3[q] = __builtin_inff(); ra1[q] = ra2[q] = INT64_MAX;
-                        if (b < nb) {
-                            G32Rec *r = blk + ((size_t)u * nb + b);
-                            const unsigned long long v12 = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&r->v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const unsigned long long v3p = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&r->v3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ra1[q] = __hip_atomic_load(&r->a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ra2[q] = __hip_atomic_load(&r->a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            rv1[q] = __builtin_bit_cast(float, (unsigned int)v12); rv2[q] = __builtin_bit_cast(float, (unsigned int)(v12 >> 32));
-                            rv3[q] = __builtin_bit_cast(float, (unsigned int)v3p);
-                        }
-                        if (lt_vi(rv1[q], ra1[q], mv, mi)) { mv = rv1[q]; mi = ra1[q]; }
-                    }
-                }
-#pragma unroll
-                for (int m = 1; m <= 32; m <<= 1) {
-                    const float ov = __shfl_xor(mv, m, 64); const int64_t oi = __shfl_xor(mi, m, 64);
-                    if (lt_vi(ov, oi, mv, mi)) { mv = ov; mi = oi; }
-                }
-                float *wv = reinterpret_cast<float *>(lds);
-                int64_t *wi = reinterpret_cast<int64_t *>(lds + 64);
-                if (lane == 0) { wv[wave] = mv; wi[wave] = mi; }
-                __syncthreads();
-                if (u == 0) stamp(step, 8);
-                mv = wv[0]; mi = wi[0];
-                for (int w = 1; w < nwaves; ++w) if (lt_vi(wv[w], wi[w], mv, mi)) { mv = wv[w]; mi = wi[w]; }
-                __syncthreads();
-                if (!(mv < __builtin_inff())) { undecided = true; continue; }
-                const double EW = EWr[u];
-                // search_epsilon mode: the float32 minimum is the answer -- with a hoisted target term only where its
-                // ABSOLUTE bound is small against the minimum (it is not for near-exact matches: decided exactly then)
-                if (approx && (!HOIST || 4.0 * (errf((double)mv, V2r[u]) + EW) <= 1e-3 * (double)mv)) {
-                    winner[u] = mi;
-                    continue;
-                }
-                // tau = the largest solution of tau = M + 2 E(tau), approached from above (E(0) = 0: from below the
-                // iteration would stall at M = 0, where the natural path lives).  E is increasing and concave: every
-                // iterate stays above the solution, so any number of rounds gives a valid bound; the map contracts by
-                // ~1e-5 per round and three rounds leave nothing to gain (eight cost 1 us of float64 square roots)
-                const double V2 = V2r[u];
-                const double M = (double)mv + 2.0 * EW;
-                double tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300 + (F16 ? 64.0 * a.f16_delta * a.f16_delta : 0.0);
-                for (int it = 0; it < 3; ++it) tau = M + 2.0 * errf(tau, V2);
-                tau = tau * (1.0 + 1e-6) + 1e-300;
-                if (u == 0) stamp(step, 9);
-                int *ccount = reinterpret_cast<int *>(lds);
-                int *cover = reinterpret_cast<int *>(lds + 32);
-                int64_t *clist = reinterpret_cast<int64_t *>(lds + 128);               // up to 512 candidates
-                if (tid == 0) { *ccount = 0; *cover = 0; }
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if ((double)rv1[q] <= tau) clist[atomicAdd(ccount, 1)] = ra1[q];
-                    if ((double)rv2[q] <= tau) clist[atomicAdd(ccount, 1)] = ra2[q];
-                    if ((double)rv3[q] <= tau) *cover = 1;      // a window nobody published may matter: second phase
-                }
-                __syncthreads();
-                const int nc = *ccount;
-                const bool cov = *cover != 0;
-                if (u == 0) stamp(step, 10);
-                if (cov) {
-                    // every lane still holds its own three best: ask all of them (generation 2 step + 2)
-                    need |= 1u << u;
-                    if (tid == 0) {
-                        __hip_atomic_store(&ctl->tau[u], tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&ctl->list_count[u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    __syncthreads();
-                    continue;
-                }
-                if (nc == 1) { winner[u] = clist[0]; __syncthreads(); continue; }
-                stat_windows += (unsigned long long)nc;         // statistics: windows decided by exact totals
-                winner[u] = exact_argmin(u, nc, [&](int p) { return clist[p]; });
-            }
-            stamp(step, 5);
-            if (need == 0u || undecided) {
-                finalize(winner, undecided);
-                stamp(step, 6);
-            } else {
-                if (tid == 0) {
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) __hip_atomic_store(&ctl->pending[u], winner[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&ctl->need, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&ctl->list_over, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(gen, (unsigned int)(2 * step + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __syncthreads();
-            }
-        }
-        // (Issuing the next step's first requests here, while this step is decided, was tried: the scan ended 1.4 us
-        // earlier and the deciding workgroup's loads took 0.8 us longer beside everybody's requests -- the step stayed
-        // at 21 us at 65 536 units, 194 us at 1.5 M.)
-        // ---- everybody: the step's winners (path entries, -1 until written), a request for candidates (generation
-        //      2 step + 2, once per step) or the end of the launch (0xffffffff: the step could not be decided) ----
-        bool second_done = false;
-        for (;;) {
+            // the winner IS the release
             if (tid == 0) {
-                int seen;
+                if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                __hip_atomic_store(&path[a.out_off[u] + step], winner[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            stamp(step, 6);
+        }
+        if (tid == 0 && (stat_rounds | stat_windows)) {           // statistics, behind the release
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&status[1]), stat_rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&status[2]), stat_windows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // winners decided elsewhere: the path entries (-1 until written), or the end of the launch (generation word)
+        if (any_pending) {
+            if (tid == 0) {
+                int seen = 0;
                 const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
                 for (;;) {
                     const unsigned int g = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     bool ready = true;
 #pragma unroll
                     for (int u = 0; u < UB; ++u) {
-                        int64_t p = -1;
-                        if (u < a.nu && step < a.nsteps_u[u]) {
+                        int64_t p = 0;
+                        if (pending[u]) {
                             p = __hip_atomic_load(&path[a.out_off[u] + step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (p < 0) ready = false;
                         }
                         next_rows[u] = p;
                     }
                     if (g == 0xffffffffu) { seen = -1; break; }
-                    if (ready) { seen = 0; break; }
-                    if (g == (unsigned int)(2 * step + 2) && !second_done) { seen = 1; break; }
-                    // watchdog: a step takes microseconds.  Seconds without news mean that some workgroup of the launch is
-                    // not running (the device shared with another spinning launch): end the launch, the caller falls back
-                    // to the exact scan, which never waits inside a kernel
-                    if (__builtin_amdgcn_s_memrealtime() - t_wait > G32_STALL_TICKS) {
-                        __hip_atomic_store(&status[3], (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __hip_atomic_store(gen, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        seen = -1;
-                        break;
-                    }
+                    if (ready) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t_wait > G32_STALL_TICKS) { give_up(); seen = -1; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (fenced) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                 gen_seen = seen;
             }
             __syncthreads();
-            const int seen = gen_seen;
-            if (seen < 0) return;                                 // an undecidable step: everybody leaves
-            if (seen == 0) {
+            if (gen_seen < 0) return;                             // an undecidable step: everybody leaves
 #pragma unroll
-                for (int u = 0; u < UB; ++u) prev_row[u] = g32_uniform_i(next_rows[u]);
-                __syncthreads();
-                break;
-            }
-            stamp(step, 7);
-            // second phase: every lane offers its two best windows that reach tau; a third one that does is beyond
-            // what was kept (mass ties): the step is then undecidable here
-            {
-            const unsigned int need = __hip_atomic_load(&ctl->need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                if (!((need >> u) & 1u)) continue;                  // uniform
-                const double tau = __hip_atomic_load(&ctl->tau[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const Top3 &t = best[u];
-                if ((double)t.v1 <= tau) {
-                    const unsigned int p = __hip_atomic_fetch_add(&ctl->list_count[u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (p < G32_LIST) __hip_atomic_store(&clist_g[(size_t)u * G32_LIST + p], (int64_t)t.a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if ((double)t.v2 <= tau) {
-                    const unsigned int p = __hip_atomic_fetch_add(&ctl->list_count[u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (p < G32_LIST) __hip_atomic_store(&clist_g[(size_t)u * G32_LIST + p], (int64_t)t.a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if ((double)t.v3 <= tau) __hip_atomic_store(&ctl->list_over, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wavefront's offers, before the workgroup arrives
-            __syncthreads();
-            ++collect_rounds;
-            stamp(step, 12);
-            if (arrive_last(arrive2, (unsigned int)collect_rounds)) {
-                stamp(step, 13);
-                int64_t winner[UB];
-                unsigned int counts[UB];
-                const unsigned int over = __hip_atomic_load(&ctl->list_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int u = 0; u < UB; ++u) {                     // (requested together: one round trip)
-                    winner[u] = __hip_atomic_load(&ctl->pending[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    counts[u] = __hip_atomic_load(&ctl->list_count[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                bool undecided = over != 0u;
-                stamp(step, 15);
-#pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    if (!((need >> u) & 1u) || undecided) continue;
-                    const unsigned int n = counts[u];
-                    if (n < 1u || n > (unsigned int)G32_LIST) { undecided = true; continue; }
-                    stat_rounds += 1; stat_windows += n;          // statistics: second-phase rounds
-                    winner[u] = exact_argmin(u, (int)n, [&](int p) {
-                        return __hip_atomic_load(&clist_g[(size_t)u * G32_LIST + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
-                }
-                stamp(step, 14);
-                finalize(winner, undecided);
-            }
-            }
-            second_done = true;
-            __syncthreads();
+            for (int u = 0; u < UB; ++u) if (pending[u]) winner[u] = next_rows[u];
         }
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+            if (u < a.nu && step < a.nsteps_u[u]) prev_row[u] = g32_uniform_i(winner[u]);
+        __syncthreads();                                          // the next table is built over this step's scratch
     }
 }
 
-// prologue: counters, generation word, status
-__global__ void greedy32_init_kernel(unsigned int *arrive, unsigned int *arrive2, unsigned int *gen, int64_t *status)
+// prologue: generation word, status
+__global__ void greedy32_init_kernel(unsigned int *gen, int64_t *status)
 {
-    for (int i = threadIdx.x; i < 32 * (GR_S1 + GR_S2 + 1); i += blockDim.x) { arrive[i] = 0; arrive2[i] = 0; }
     if (threadIdx.x == 0) { *status = 0; *gen = 0u; status[1] = 0; status[2] = 0; status[3] = 0; }
 }
 
@@ -944,9 +870,11 @@ size_t greedy32_table_floats(const GreedyLayout &g, int Dt, bool hoist)
     const int jch = (g.jdim + GR_CC - 1) / GR_CC;
     return (size_t)(jch + (hoist ? 0 : nep * ((Dt + GR_CC - 1) / GR_CC))) * GR_CC * (hoist ? 8 : 4);      // hoisted: room for the wide entries
 }
-// workspace of one launch: block records | second-phase control | candidate lists
-static size_t g32_rec_bytes(int nblk) { return (((size_t)G32_UBX * nblk * sizeof(G32Rec)) + 255) & ~(size_t)255; }
-size_t greedy32_block_bytes(int nblk) { return g32_rec_bytes(nblk) + 256 + (size_t)G32_UBX * G32_LIST * sizeof(int64_t); }
+// workspace of one launch: the published records (two step parities x utterances x workgroups x four granules; all bits set
+// before the launch: the tag bit of steps 0 and 1 is 0) | the holders' slots (zero before the launch: no tag is 0)
+static size_t g32_pub_bytes(int nblk) { return (size_t)2 * G32_UBX * nblk * 4 * sizeof(unsigned long long); }
+static size_t g32_send_bytes(int nblk) { return (size_t)G32_UBX * nblk * (G32_SEND + 1) * sizeof(unsigned long long); }
+size_t greedy32_block_bytes(int nblk) { return g32_pub_bytes(nblk) + g32_send_bytes(nblk); }
 int greedy32_max_utts(bool hoist) { return hoist ? G32_UBX : G32_UB; }
 
 static size_t g32_lds_wave_bytes(const GreedyLayout &g, int Dt)
@@ -1011,7 +939,7 @@ void greedy32_trace_dump()
 void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
                      int Dj, const double *wj, const float *tiles, const double *Q, int nu, const int64_t *q_off,
                      const int64_t *nsteps_u, const int64_t *out_off, const int64_t *start, int approx,
-                     void *blk, int n_cus, unsigned int *arrive, unsigned int *gen, int64_t *status,
+                     void *blk, int n_cus, unsigned int *gen, int64_t *status,
                      int64_t *path, const G32Hoist *hst, hipStream_t s)
 {
     GreedyArgs a{};
@@ -1034,8 +962,7 @@ void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, 
     }
     if (nsteps <= 0) return;
     const bool wide = hoist && nu > G32_UB;                        // four to six utterances: the wide table entries
-    unsigned int *arrive2 = arrive + 32 * (GR_S1 + GR_S2 + 1);    // the caller provides 2 x greedy_counter_bytes()
-    hipLaunchKernelGGL(greedy32_init_kernel, dim3(1), dim3(512), 0, s, arrive, arrive2, gen, status);
+    hipLaunchKernelGGL(greedy32_init_kernel, dim3(1), dim3(64), 0, s, gen, status);
     // the winners are the hand-off between the steps: a path entry is -1 until its step is decided
     for (int u = 0; u < nu; ++u)
         if (nsteps_u[u] > 0) (void)hipMemsetAsync(path + out_off[u], 0xff, (size_t)nsteps_u[u] * sizeof(int64_t), s);
@@ -1061,8 +988,10 @@ void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, 
                   : in_lds ? greedy32_kernel<true, false, G32_UB, false> : greedy32_kernel<false, false, G32_UB, false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     char *wb = reinterpret_cast<char *>(blk);
-    G32Ctl *ctl = reinterpret_cast<G32Ctl *>(wb + g32_rec_bytes(nblk));
-    int64_t *clist = reinterpret_cast<int64_t *>(wb + g32_rec_bytes(nblk) + 256);
+    unsigned long long *pub = reinterpret_cast<unsigned long long *>(wb);
+    unsigned long long *send = reinterpret_cast<unsigned long long *>(wb + g32_pub_bytes(nblk));
+    (void)hipMemsetAsync(pub, 0xff, g32_pub_bytes(nblk), s);
+    (void)hipMemsetAsync(send, 0, g32_send_bytes(nblk), s);
     unsigned long long *trace = nullptr;
     if (getenv("SNK_G32_TRACE")) {
         const size_t tb = (size_t)G32_TRACE_STEPS * nblk * 16 * sizeof(unsigned long long);
@@ -1072,7 +1001,7 @@ void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, 
         g32_trace_blocks = nblk;
     }
     hipLaunchKernelGGL(kernel, dim3(nblk), dim3(G32_W * waves), lds, s, a, nsteps, approx, use_nt, (int)lds,
-                       reinterpret_cast<G32Rec *>(blk), arrive, arrive2, gen, ctl, clist, path, status, trace);
+                       pub, send, gen, path, status, trace);
 }
 
 void launch_greedy32_dist(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,

@@ -2281,7 +2281,6 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
     const int nblk = greedy32_blocks(g, h->Dt, h->n_cus, hoist);
     CHK(h->g32_blk.ensure(greedy32_block_bytes(nblk)));
     CHK(h->g32_ctl.ensure(256));
-    CHK(h->gsync.ensure(2 * greedy_counter_bytes()));
     unsigned int *gen = h->g32_ctl.as<unsigned int>();
     int64_t *status = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(h->g32_ctl.p) + 16);
     // one utterance against a database that fits the chip's LDS: resident scan, every workgroup decides for itself
@@ -2296,7 +2295,7 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
     } else
     launch_greedy32(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
                     h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nu, q_off, ns, oo, st, (approx ? 1 : 0) | (h->greedy_test_stall ? 256 : 0) | (h->greedy_fenced ? 512 : 0),
-                    h->g32_blk.p, h->n_cus, h->gsync.as<unsigned int>(), gen,
+                    h->g32_blk.p, h->n_cus, gen,
                     status, h->gpath.as<int64_t>(), hoist ? &hst : nullptr, h->stream);
     HIPCHK(hipGetLastError());
     int64_t stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};         // undecided step + 1 | second-phase rounds | windows decided by exact totals | watchdog | (resident scan: why)

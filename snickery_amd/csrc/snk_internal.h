@@ -294,7 +294,7 @@ size_t greedy32_block_bytes(int nblk);
 void greedy32_trace_dump();          // developer aid (SNK_G32_TRACE=file): timeline of the last launch
 void launch_greedy32(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
                      int Dj, const double *wj, const float *tiles, const double *Q, int nu, const int64_t *q_off,
-                     const int64_t *nsteps_u, const int64_t *out_off, const int64_t *start, int approx, void *blk, int n_cus, unsigned int *arrive, unsigned int *gen, int64_t *status,
+                     const int64_t *nsteps_u, const int64_t *out_off, const int64_t *start, int approx, void *blk, int n_cus, unsigned int *gen, int64_t *status,
                      int64_t *path, const G32Hoist *hoist, hipStream_t s);
 // database resident in LDS for the whole launch (greedy_res_kernels.hip): one utterance, hoisted target term required
 bool greedy_res_supported(const GreedyLayout &g, int Dt, int n_cus);

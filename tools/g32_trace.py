@@ -2,10 +2,9 @@
 
     python tools/g32_trace.py [units = 65536] [utterances per scan = 1]
 
-Stamps per step and workgroup (100 MHz clock): 0 step started, 1 table in LDS, 2 scan done, 3 workgroup record
-published, 4 (decider) last arrival, 5 (decider) first decision made, 6 (decider) winners released; second phase (every
-lane offers its candidates; the usual case with float16 join tiles): 7 entered, 12 offers made, 13 (decider) last
-arrival, 15 control words read, 8 candidate ids read, 9 terms of the candidates stored, 10 chains summed, 14 decided."""
+Stamps per step and workgroup (100 MHz clock): 0 step started, 1 table in LDS, 2 scan done, 3 record published, 4 all records
+gathered and classified; where a workgroup has to decide: 7 (a holder) its lanes' windows sent, 5 (decider) candidates collected,
+8 candidate ids read, 9 terms of the candidates stored, 10 chains summed, 6 winner released."""
 import sys, os, struct
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,16 +29,28 @@ t = np.frombuffer(raw[16:], dtype=np.uint64).reshape(steps, nb, 16).astype(np.fl
 rows = []
 for s in range(8, 40):
     x = t[s]
-    dec = int(np.argmax(x[:, 4]))                     # the deciding workgroup: the only one with stamps 4..6
-    if x[dec, 4] == 0:
-        continue
     t0 = x[:, 0].min()
+    dec = int(np.argmax(x[:, 6]))                     # the deciding workgroup (if any): the only one with stamp 6
+    has = x[dec, 6] > 0
+    f = lambda v: (v - t0) if has else np.nan
     rows.append([x[:, 0].max() - t0, np.median(x[:, 1]) - t0, np.median(x[:, 2]) - t0, x[:, 2].max() - t0, x[:, 3].max() - t0,
-                 x[dec, 4] - t0, x[dec, 5] - t0, np.median(x[:, 7]) - t0, x[:, 12].max() - t0, x[:, 13].max() - t0, x[:, 15].max() - t0, x[:, 8].max() - t0, x[:, 9].max() - t0, x[:, 10].max() - t0, x[:, 14].max() - t0, x[dec, 6] - t0, np.median(t[s + 1][:, 0]) - t0, t[s + 1][:, 0].min() - t0])
+                 np.median(x[:, 4]) - t0, x[:, 4].max() - t0, f(x[:, 7].max()) if x[:, 7].max() > 0 else np.nan, f(x[dec, 5]), f(x[dec, 8]), f(x[dec, 9]), f(x[dec, 10]), f(x[dec, 6]),
+                 np.median(t[s + 1][:, 0]) - t0, t[s + 1][:, 0].min() - t0])
 r = np.array(rows)
-names = ['last wg sees table', 'table in LDS (median)', 'scan done (median)', 'scan done (last)', 'published (last)', 'decider: last arrival',
-         'decider: decided', '2nd phase: entered (median)', '2nd phase: offers made (last)', '2nd phase: last arrival', '2nd: control words read', '2nd: candidate ids read', '2nd: terms of the candidates stored', '2nd: chains summed', '2nd phase: decided', 'decider: released', 'next step seen (median)', 'next step seen (first)']
-print('%d utterance(s) per scan; ' % NU + 'N = %d, %d workgroups; microseconds from the first workgroup seeing the step (mean over %d steps)' % (N, nb, len(rows)))
-for n, v in zip(names, r.mean(0)):
-    print('  %-28s %6.2f' % (n, v))
+names = ['last wg sees the step', 'table in LDS (median)', 'scan done (median)', 'scan done (last)', 'published (last)', 'gathered (median)', 'gathered (last)',
+         'holders: lists sent (last)', 'decider: candidates collected', 'decider: candidate ids read', 'decider: terms stored', 'decider: chains summed', 'decider: released',
+         'next step seen (median)', 'next step seen (first)']
+print('%d utterance(s) per scan; ' % NU + 'N = %d, %d workgroups; microseconds from the first workgroup seeing the step (mean over %d steps; %d with a deciding workgroup)' % (N, nb, len(rows), int(np.sum(~np.isnan(r[:, 12])))))
+for n, v in zip(names, np.nanmean(r, 0) if len(rows) else []):
+    print('  %-32s %6.2f' % (n, v))
 eng.close()
+if os.environ.get('SNK_G32_DETAIL'):
+    # where the scan ends late: per XCD (workgroup id mod 8) and the percentiles over workgroups, mean over the steps
+    d = np.array([t[s][:, 2] - t[s][:, 0].min() for s in range(8, 40)])            # steps x workgroups
+    m = d.mean(0)
+    print('scan done, per workgroup (mean over steps): percentiles 0 10 50 90 100:', np.round(np.percentile(m, [0, 10, 50, 90, 100]), 2))
+    print('  by workgroup id mod 8:', np.round([m[k::8].mean() for k in range(8)], 2))
+    print('  by workgroup id // 32:', np.round([m[k * 32:(k + 1) * 32].mean() for k in range(8)], 2))
+    print('  per step: spread (last - median):', np.round(np.mean(d.max(1) - np.median(d, 1)), 2), ' the same workgroup last every step?', np.bincount(d.argmax(1)).max(), 'of', d.shape[0])
+    st = np.array([t[s][:, 0] - t[s][:, 0].min() for s in range(8, 40)])
+    print('step start per workgroup: percentiles', np.round(np.percentile(st.mean(0), [0, 50, 100]), 2), ' table done:', np.round(np.percentile(np.array([t[s][:, 1] - t[s][:, 0].min() for s in range(8, 40)]).mean(0), [0, 50, 100]), 2))
