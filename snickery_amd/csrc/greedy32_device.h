@@ -59,6 +59,10 @@ __device__ __forceinline__ double g32_chain_sum(const double *terms, int jdim, i
     return __dadd_rn(acc_j, acc_t);
 }
 
+// epoch e of the window (GreedyArgs::ep, greedy_fill_args) without indexing the argument block by a lane's value: all frames of
+// the window, or the first and the last one
+__device__ __forceinline__ int g32_ep(const GreedyArgs &a, int e) { return a.nep == a.me ? e : (e ? a.me - 1 : 0); }
+
 // The term arrays of up to four candidates at once: weight and reference of a column are the same for all of them, only
 // the database value differs -- so the operands of all candidates are requested together (one trip to HBM for their cold
 // rows instead of one per candidate) in the registers one candidate took.  terms + k * stride: array of candidate k.
@@ -88,10 +92,11 @@ static __device__ void g32_terms_multi(const GreedyArgs &a, int u, int64_t step,
             } else if (idx < ncol) {
                 const int t = idx - a.jdim, e = t / a.Dt, c = t - e * a.Dt;
                 w[j] = a.wt[c];
-                qv[j] = a.Q[(a.q_off[u] + step * a.me + a.ep[e]) * a.Dt + c];
+                const int epe = g32_ep(a, e);
+                qv[j] = a.Q[(a.q_off[u] + step * a.me + epe) * a.Dt + c];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (k < cnt) x[k][j] = a.F_unw[(ids[k] + a.ep[e]) * a.Fp + c];
+                    if (k < cnt) x[k][j] = a.F_unw[(ids[k] + epe) * a.Fp + c];
             }
         }
 #pragma unroll
@@ -135,8 +140,9 @@ static __device__ double g32_exact_d2_wave(const GreedyArgs &a, int u, int64_t s
                 if (prev_row >= 0) { rx[j] = rr[idx]; rw[j] = a.wj[col0 + idx]; }
             } else if (idx < ncol) {
                 const int t = idx - a.jdim, k = t / a.Dt, c = t - k * a.Dt;
-                x[j] = a.F_unw[(i + a.ep[k]) * a.Fp + c]; w[j] = a.wt[c];
-                qv[j] = a.Q[(a.q_off[u] + step * a.me + a.ep[k]) * a.Dt + c];
+                const int epk = g32_ep(a, k);
+                x[j] = a.F_unw[(i + epk) * a.Fp + c]; w[j] = a.wt[c];
+                qv[j] = a.Q[(a.q_off[u] + step * a.me + epk) * a.Dt + c];
             }
         }
 #pragma unroll
