@@ -664,8 +664,9 @@ def main():
             if variant1 and world == 1 and N == 1048576 and Dj == 302 and K == 100 and os.path.isfile(jfile):
                 with open(jfile) as f:
                     tj = json.load(f)
-                if abs(tj.get('rows_per_launch', 0) - jrows) < 1.0:
-                    jtraffic, jsrc = tj['hbm_bytes_per_launch'], 'profiles/r04_traffic_joinlb2.json (separate --pmc passes of this kernel and shape; not measured in this run)'
+                if abs(tj.get('rows_per_launch', 0) - jrows) <= 0.01 * jrows:      # (the profiled call counts row PAIRS of one group: 9 599)
+                    jtraffic = tj['hbm_bytes_per_launch'] * jrows / tj['rows_per_launch']
+                    jsrc = 'profiles/r04_traffic_joinlb2.json (separate --pmc passes of this kernel and shape, scaled by the rows; not measured in this run)'
             out['roofline'] = {
                 'bound': 'hbm',
                 'kernel': ('join_lb2_kernel (joinlb2_kernels.hip: gather of the weighted float32 join rows of 2 K candidates per step, bf16-split '
@@ -675,10 +676,22 @@ def main():
                 'traffic': jtraffic, 'traffic_source': jsrc,
                 'avg_launch_ms': javg, 'launches': jl, 'rows_per_launch': jrows, 'algorithmic_bytes_per_launch': jbytes,
                 'flops_per_launch': jfl, 'mfma_tflops': jfl / (javg * 1e-3) / 1e12,
-                'rule': 'the whole-chip kernel with the largest total time under rocprofv3 (profiles/r04_*_kernel_stats.csv); timed here with '
+                'rule': 'the whole-chip kernel with the largest total time under rocprofv3 (profiles/r04_*_kernel_stats.csv; the largest of all is a '
+                        'latency chain on 16 workgroups: `largest_total_time_kernel`); timed here with '
                         'HIP events on the stream it is launched on, inside the timed region, while the K-NN of the next group shares the chip',
                 'note': 'algorithmic bytes per SURVEY 8d: every candidate row gathered once per row pair (2 K rows of Dj float32) + K^2 float32 bounds; '
                         'rows that consecutive steps share are served from L2, so `traffic` lies below them'}
+            if 'viterbi_sparse' in timers and timers['viterbi_sparse'][1]:
+                # the kernel with the largest TOTAL time in the stats is not a whole-chip one: said here, with its own figures
+                vms, vl = timers['viterbi_sparse']
+                out['roofline']['largest_total_time_kernel'] = {
+                    'kernel': 'viterbi_sparse1_kernel (the exact recursion over T steps)', 'avg_launch_ms': vms / max(vl, 1), 'launches': vl,
+                    'workgroups_per_launch': U // max(vl // max(args.steps, 1), 1) if vl else None, 'compute_units': 256,
+                    'us_per_recursion_step': out['viterbi'].get('us_per_step_exact_recursion'),
+                    'why_no_roofline': 'a chain of T dependent steps on ONE wavefront per utterance (16 workgroups per launch on 256 compute units): its time is '
+                                       'T x the latency of a step (K candidates: minima over the kept predecessors, refinement of the step on the spot), it moves '
+                                       '0.1 GB per launch and issues no matrix work; it runs beside the next group\'s K-NN and does not gate the step -- the '
+                                       'whole-chip kernels do (sum of their stand-alone times 4.1 of the 4.6 ms step, DESIGN.md 5)'}
         else:
             out['roofline'] = dict(out['filter_stage'])
         if bf16_mode:
