@@ -183,7 +183,8 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
             trace[((size_t)st * gridDim.x + blockIdx.x) * 16 + k] = __builtin_amdgcn_s_memrealtime();
     };
     extern __shared__ __align__(16) char lds[];          // table | one target block per wavefront (lds_mode 1)
-    __shared__ int gen_seen;
+    __shared__ int gen_seen, spec_go[G32_UBX], spec_a[G32_UBX];
+    __shared__ float spec_v[G32_UBX][2];                   // the workgroup's two best values of the step, per utterance
     __shared__ int64_t next_rows[G32_UBX];                 // the step's winners, as the polling thread saw them
     const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -205,10 +206,19 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
     const int table_bytes = ncols * 16 * TE;
     float *const Fs = reinterpret_cast<float *>(lds + table_bytes) + (size_t)wave * (G32_W + a.me - 1) * pitch;
     const int ntiles = (int)((a.Nwin + G32_W - 1) / G32_W);
-    // tile t belongs to wavefront (t mod wave_stride); consecutive ids run over the WORKGROUPS first: the tiles that do not
-    // divide evenly (11.4 per wavefront at 1.5 M units) then spread over all compute units instead of filling the first ones
-    const int wave_id = wave * gridDim.x + blockIdx.x, wave_stride = gridDim.x * nwaves;
-    const int my_tiles = wave_id < ntiles ? (ntiles - 1 - wave_id) / wave_stride + 1 : 0;
+    // Tiles are dealt out in rounds of wave_stride: in a full round workgroup b takes the nwaves ADJACENT tiles b nwaves .. b nwaves
+    // + nwaves - 1 (the windows inside a step's bound are the best window's neighbours: adjacent tiles in one workgroup mean one
+    // holder, and a single holder can decide before the gather, see the step's tail; dealt out tile by tile across the workgroups,
+    // two steps of three had several holders), and the tiles of the last, partial round go to ALL workgroups in groups of
+    // ceil(rest / workgroups) adjacent ones (given to the first workgroups only -- eight more tiles each on 114 of 256 compute units
+    // at 1.5 M units -- the last workgroup finished 10 us behind the median one).
+    const int wave_stride = gridDim.x * nwaves;
+    const int full_rounds = ntiles / wave_stride, rest_base = full_rounds * wave_stride, rest = ntiles - rest_base;
+    const int rest_group = rest > 0 ? (rest + (int)gridDim.x - 1) / (int)gridDim.x : 1;
+    const int rest_tile = rest_base + (int)blockIdx.x * rest_group + wave;
+    const bool has_rest = wave < rest_group && rest_tile < ntiles;
+    auto tile_of = [&](int k) { return k < full_rounds ? k * wave_stride + (int)blockIdx.x * nwaves + wave : (has_rest ? rest_tile : ntiles); };
+    const int my_tiles = full_rounds + (has_rest ? 1 : 0);
     const int total = my_tiles * ring_per_tile;
     const unsigned int nb = gridDim.x;
     const unsigned off_own = (unsigned)lane * 16u;
@@ -226,7 +236,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
     for (int u = 0; u < UB; ++u) prev_row[u] = a.start[u];
 
     // request ring
-    int f_tile = wave_id, f_pos = 0;
+    int f_k = 0, f_tile = 0, f_pos = 0;
     f32x4 stage[NSTG][8];
     // hoisted target values of the tile in work and of the next one (one float per window and utterance)
     float wcur[UB], wnext[UB];
@@ -277,11 +287,11 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
             for (int j = 0; j < 8; ++j) st[j] = *reinterpret_cast<const f32x4 *>(base + voff + 1024 * j);
         }
         asm volatile("" ::: "memory");
-        if (++f_pos == ring_per_tile) { f_pos = 0; f_tile += wave_stride; }
+        if (++f_pos == ring_per_tile) { f_pos = 0; f_tile = tile_of(++f_k); }
     };
     // the first NSTG - 1 requests of step st: tile data does not depend on the step's table, only the references do
     auto start_fetch = [&](int64_t st) {
-        f_tile = wave_id; f_pos = 0;
+        f_k = 0; f_tile = tile_of(0); f_pos = 0;
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             wcur[u] = 0.f; wnext[u] = 0.f;
@@ -314,7 +324,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
         float acc[UB];                                    // ONE float32 total per utterance: the bound holds for any order
 #pragma unroll
         for (int u = 0; u < UB; ++u) { top3_init(best[u]); acc[u] = 0.f; }
-        int c_tile = wave_id, c_pos = 0, t_done = 0, slot = 0;
+        int c_k = 0, c_tile = tile_of(0), c_pos = 0, t_done = 0, slot = 0;
         int pin = 0;
         const f32x4 *const table = reinterpret_cast<const f32x4 *>(lds);
         // one chunk of arithmetic: x[g] = columns 4g .. 4g+3 of the chunk.  The table entries (w, ref0, ref1, ref2;
@@ -377,7 +387,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                 if (i < (int)a.Nwin) top3_push(best[u], HOIST ? acc[u] + wcur[u] : acc[u], i);
                 acc[u] = 0.f;
             }
-            c_pos = 0; t_done = 0; c_tile += wave_stride;
+            c_pos = 0; t_done = 0; c_tile = tile_of(++c_k);
         };
         auto handle = [&](f32x4 (&st)[8]) {
             if (!in_lds) {
@@ -458,130 +468,16 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(gen, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            if (u >= a.nu) break;                                 // uniform
-            Top3 t = best[u];
-#pragma unroll
-            for (int m = 1; m <= 32; m <<= 1) { const Top3 o = top3_shfl_xor(t, m); top3_merge(t, o); }
-            // (recursive doubling: the partner's set is disjoint from the lane's at every level)
-            if (lane == 0) red3[u * G32_MAXW + wave] = t;
-        }
-        if (tid < G32_UBX) info[tid].state = 0;
-        __syncthreads();
-        // publish (thread u merges the wavefronts' sets of utterance u; a test hook keeps workgroup 0 silent at step 1)
-        if (tid < UB && tid < a.nu && step < a.nsteps_u[tid] && !(test_stall && step == 1 && blockIdx.x == 0)) {
-            Top3 r = red3[tid * G32_MAXW];
-            for (int w = 1; w < nwaves; ++w) top3_merge(r, red3[tid * G32_MAXW + w]);
-            if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            unsigned long long *o = pub_s + ((size_t)tid * nb + blockIdx.x) * 4;
-            st64(o, pack(r.v1, r.a1));
-            st64(o + 1, pack(r.v2, r.a2));
-            st64(o + 2, pack(r.v3, 0));
-        }
-        stamp(step, 3);
-        // gather and classify: a wavefront per utterance, four records per lane
-        for (int u = wave; u < UB; u += nwaves) {                     // uniform per wavefront
-            if (!(u < a.nu && step < a.nsteps_u[u])) continue;
-            float rv1[4], rv2[4], rv3[4];
-            int ra1[4], ra2[4];
-            bool got = false;
-            const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
-            for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned int b = lane + 64 * q;
-                    rv1[q] = rv2[q] = rv3[q] = __builtin_inff(); ra1[q] = ra2[q] = INT32_MAX;
-                    if (b < nb) {
-                        unsigned long long *o = pub_s + ((size_t)u * nb + b) * 4;
-                        const unsigned long long g0 = ld64(o), g1 = ld64(o + 1), g2 = ld64(o + 2);
-                        ok = ok && ((unsigned int)(g0 >> 32) & 1u) == tagbit && ((unsigned int)(g1 >> 32) & 1u) == tagbit
-                                && ((unsigned int)(g2 >> 32) & 1u) == tagbit;
-                        rv1[q] = __builtin_bit_cast(float, (unsigned int)g0); ra1[q] = (int)((unsigned int)(g0 >> 32) >> 1);
-                        rv2[q] = __builtin_bit_cast(float, (unsigned int)g1); ra2[q] = (int)((unsigned int)(g1 >> 32) >> 1);
-                        rv3[q] = __builtin_bit_cast(float, (unsigned int)g2);
-                    }
-                }
-                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) { got = true; break; }
-                if (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0xffffffffu) break;
-                // watchdog: a step takes microseconds.  Seconds without news mean that some workgroup of the launch is not
-                // running (the device shared with another spinning launch)
-                if (__builtin_amdgcn_s_memrealtime() - t_wait > G32_STALL_TICKS) { if (lane == 0) give_up(); break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (fenced) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            if (!got) { if (lane == 0) info[u].state = 4; continue; }
-            float mv = __builtin_inff();
-            int mi = INT32_MAX, mb = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (lt_vi(rv1[q], ra1[q], mv, mi)) { mv = rv1[q]; mi = ra1[q]; mb = lane + 64 * q; }
-#pragma unroll
-            for (int m = 1; m <= 32; m <<= 1) {
-                const float ov = __shfl_xor(mv, m, 64); const int oi = __shfl_xor(mi, m, 64), ob = __shfl_xor(mb, m, 64);
-                if (lt_vi(ov, oi, mv, mi)) { mv = ov; mi = oi; mb = ob; }
-            }
-            int state = 3, nH = 0, sender = 0;
-            double tau = 0.0;
-            if (!(mv < __builtin_inff())) state = 2;
-            else {
-                double V2 = V2w[0];
-#pragma unroll
-                for (int k = 1; k < UB; ++k) V2 = u == k ? V2w[k] : V2;
-                double EW = EWw[0];
-#pragma unroll
-                for (int k = 1; k < UB; ++k) EW = u == k ? EWw[k] : EW;
-                // search_epsilon mode: the float32 minimum is the answer -- with a hoisted target term only where its
-                // ABSOLUTE bound is small against the minimum (it is not for near-exact matches: decided exactly then)
-                if (approx && (!HOIST || 4.0 * (errf((double)mv, V2) + EW) <= 1e-3 * (double)mv)) state = 1;
-                else {
-                    // tau = the largest solution of tau = M + 2 E(tau), approached from above (E(0) = 0: from below the
-                    // iteration would stall at M = 0, where the natural path lives).  E is increasing and concave: every
-                    // iterate stays above the solution, so any number of rounds gives a valid bound; the map contracts by
-                    // ~1e-5 per round and three rounds leave nothing to gain (eight cost 1 us of float64 square roots)
-                    const double M = (double)mv + 2.0 * EW;
-                    tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300 + (F16 ? 64.0 * a.f16_delta * a.f16_delta : 0.0);
-                    for (int it = 0; it < 3; ++it) tau = M + 2.0 * errf(tau, V2);
-                    tau = tau * (1.0 + 1e-6) + 1e-300;
-                    int nc = 0;
-                    bool cov = false;
-                    float v3me = __builtin_inff();
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const unsigned long long h1 = __builtin_amdgcn_ballot_w64((double)rv1[q] <= tau);
-                        nH += __popcll(h1);
-                        nc += __popcll(h1) + __popcll(__builtin_amdgcn_ballot_w64((double)rv2[q] <= tau));
-                        cov = cov || __builtin_amdgcn_ballot_w64((double)rv3[q] <= tau) != 0ull;
-                        if ((int)(blockIdx.x >> 6) == q) v3me = __shfl(rv3[q], (int)(blockIdx.x & 63u), 64);
-                    }
-                    if (nc == 1 && !cov) state = 1;               // the only window inside the bound is the float32 minimum itself
-                    else sender = (mb != (int)blockIdx.x && (double)v3me <= tau) ? 1 : 0;
-                }
-            }
-            if (lane == 0) {
-                G32Info x;
-                x.state = state; x.D = mb; x.nH = nH; x.sender = sender; x.winner = (int64_t)mi; x.tau = tau;
-                info[u] = x;
-            }
-        }
-        __syncthreads();
-        stamp(step, 4);
-        int st[UB];
-        {
-            bool leave = false, none = false;
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                st[u] = (u < a.nu && step < a.nsteps_u[u]) ? info[u].state : 0;
-                leave = leave || st[u] == 4;
-                none = none || st[u] == 2;
-            }
-            if (leave) return;                                    // the launch was ended (watchdog, an undecidable step)
-            if (none) {                                           // nothing finite: every workgroup sees it, one reports it
-                if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
-        }
+        // tau = the largest solution of tau = M + 2 E(tau), approached from above (E(0) = 0: from below the
+        // iteration would stall at M = 0, where the natural path lives).  E is increasing and concave: every
+        // iterate stays above the solution, so any number of rounds gives a valid bound; the map contracts by
+        // ~1e-5 per round and three rounds leave nothing to gain (eight cost 1 us of float64 square roots)
+        auto tau_of = [&](float mv, double V2, double EW) {
+            const double M = (double)mv + 2.0 * EW;
+            double tau = 2.0 * M + 64.0 * 36.0 * 3.5527136788005009e-15 * V2 + 1e-300 + (F16 ? 64.0 * a.f16_delta * a.f16_delta : 0.0);
+            for (int it = 0; it < 3; ++it) tau = M + 2.0 * errf(tau, V2);
+            return tau * (1.0 + 1e-6) + 1e-300;
+        };
         // the lanes' windows inside the bound -> the candidate list in LDS (cap entries); a third one that reaches tau is
         // beyond what was kept (mass ties): the step is then undecidable here
         auto offer = [&](int u, double tau, int cap) {
@@ -590,24 +486,6 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
             if ((double)t.v2 <= tau) { const int p = atomicAdd(ccount, 1); if (p < cap) clist[p] = (unsigned long long)(unsigned int)t.a2; }
             if ((double)t.v3 <= tau) ccount[1] = 1;
         };
-        // a holder of more windows than it published, and not the one who decides: its lanes' windows go to its slot
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            if (st[u] != 3 || !info[u].sender) continue;            // uniform
-            const double tau = info[u].tau;
-            if (tid == 0) { ccount[0] = 0; ccount[1] = 0; }
-            __syncthreads();
-            offer(u, tau, G32_SEND);
-            __syncthreads();
-            const int n = ccount[0];
-            const bool over = ccount[1] != 0 || n > G32_SEND;
-            unsigned long long *slot = send + ((size_t)u * nb + blockIdx.x) * (G32_SEND + 1);
-            if (fenced && tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            if (tid < n && tid < G32_SEND) st64(slot + 1 + tid, clist[tid] | ((unsigned long long)stag << 32));
-            if (tid == 0) st64(slot, (unsigned long long)(over ? 0xffffu : (unsigned int)n) | ((unsigned long long)stag << 32));
-            __syncthreads();
-            stamp(step, 7);
-        }
         // exact decision among n candidates (ids through `get`): a wavefront per candidate, canonical float64 totals,
         // lowest index on exact ties
         const int ex_cols = a.jdim + a.nep * a.Dt;
@@ -725,6 +603,204 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
             __syncthreads();
             return i0;
         };
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (u >= a.nu) break;                                 // uniform
+            Top3 t = best[u];
+#pragma unroll
+            for (int m = 1; m <= 32; m <<= 1) { const Top3 o = top3_shfl_xor(t, m); top3_merge(t, o); }
+            // (recursive doubling: the partner's set is disjoint from the lane's at every level)
+            if (lane == 0) red3[u * G32_MAXW + wave] = t;
+        }
+        if (tid < G32_UBX) info[tid].state = 0;
+        __syncthreads();
+        // publish (thread u merges the wavefronts' sets of utterance u; a test hook keeps workgroup 0 silent at step 1)
+        if (tid < UB && tid < a.nu && step < a.nsteps_u[tid] && !(test_stall && step == 1 && blockIdx.x == 0)) {
+            Top3 r = red3[tid * G32_MAXW];
+            for (int w = 1; w < nwaves; ++w) top3_merge(r, red3[tid * G32_MAXW + w]);
+            if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            unsigned long long *o = pub_s + ((size_t)tid * nb + blockIdx.x) * 4;
+            st64(o, pack(r.v1, r.a1));
+            st64(o + 1, pack(r.v2, r.a2));
+            st64(o + 2, pack(r.v3, 0));
+            spec_v[tid][0] = r.v1; spec_v[tid][1] = r.v2; spec_a[tid] = r.a1;
+        }
+        stamp(step, 3);
+        // ---- float16 scans decide exactly at every step (the best window's neighbours are inside the bound), and the workgroup that
+        //      will decide has usually been waiting for the last one to finish its scan: 8 us for the median workgroup, + the trip
+        //      of the gather.  So a workgroup that finds the records incomplete decides on ITS OWN windows meanwhile -- the bound
+        //      from its own minimum, its lanes' windows inside it, the exact decision among them.  If the gather then names it the
+        //      only holder, its minimum was the minimum, its bound the bound (the same arithmetic on the same numbers: compared
+        //      bit for bit) and its decision is the step's: released at once.  Everybody else's speculation is thrown away (18 KB
+        //      of cold rows per workgroup and step, 1 % of the scan's bytes).
+        bool spec_valid[UB];
+        double spec_tau[UB];
+        int64_t spec_win[UB];
+        int spec_n[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { spec_valid[u] = false; spec_tau[u] = 0.0; spec_win[u] = 0; spec_n[u] = 0; }
+        if constexpr (F16) {
+            if (!approx) {
+                // a first look at the records (a wavefront per utterance).  All there: nothing to hide behind.  Somebody has
+                // published a smaller minimum: this workgroup will not decide.  Otherwise -- its minimum is the smallest so far --
+                // it decides on its own windows now.  (Without the second test every early workgroup speculated: 255 useless
+                // decisions per step disturbed the last scans by 8 us and made late speculators miss the release.  With it about
+                // ln 256 = 6 workgroups per step do, and one that is overtaken later is released no earlier than it is done:
+                // the one that overtakes it publishes later and needs as long.)
+                __syncthreads();                                      // spec_v / spec_a of this step
+                for (int u = wave; u < UB; u += nwaves) {             // uniform per wavefront
+                    if (!(u < a.nu && step < a.nsteps_u[u])) continue;
+                    const float myv = spec_v[u][0];
+                    const int mya = spec_a[u];
+                    bool in = true, smaller = false;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned int b = lane + 64 * q;
+                        if (b < nb) {
+                            const unsigned long long g0 = ld64(pub_s + ((size_t)u * nb + b) * 4);
+                            const bool valid = ((unsigned int)(g0 >> 32) & 1u) == tagbit;
+                            in = in && valid;
+                            smaller = smaller || (valid && lt_vi(__builtin_bit_cast(float, (unsigned int)g0), (int)((unsigned int)(g0 >> 32) >> 1), myv, mya));
+                        }
+                    }
+                    const bool all_in = __builtin_amdgcn_ballot_w64(!in) == 0ull, overtaken = __builtin_amdgcn_ballot_w64(smaller) != 0ull;
+                    if (lane == 0) spec_go[u] = (!all_in && !overtaken) ? 1 : 0;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    if (!(u < a.nu && step < a.nsteps_u[u]) || !spec_go[u]) continue;      // uniform
+                    const float mvl = spec_v[u][0], v2l = spec_v[u][1];
+                    if (!(mvl < __builtin_inff())) continue;
+                    const double tau = tau_of(mvl, V2w[u], EWw[u]);
+                    if (!((double)v2l <= tau)) continue;                    // one window of its own inside the bound: nothing to weigh
+                    if (tid == 0) { ccount[0] = 0; ccount[1] = 0; }
+                    __syncthreads();
+                    offer(u, tau, G32_CAND);
+                    __syncthreads();
+                    const int n = ccount[0];
+                    const bool over = ccount[1] != 0 || n > G32_CAND;
+                    __syncthreads();
+                    if (over || n < 2) continue;
+                    spec_win[u] = exact_argmin(u, n, [&](int p) { return (int64_t)clist[p]; });
+                    spec_tau[u] = tau; spec_n[u] = n; spec_valid[u] = true;
+                }
+                __syncthreads();
+            }
+        }
+        // gather and classify: a wavefront per utterance, four records per lane
+        for (int u = wave; u < UB; u += nwaves) {                     // uniform per wavefront
+            if (!(u < a.nu && step < a.nsteps_u[u])) continue;
+            float rv1[4], rv2[4], rv3[4];
+            int ra1[4], ra2[4];
+            bool got = false;
+            const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned int b = lane + 64 * q;
+                    rv1[q] = rv2[q] = rv3[q] = __builtin_inff(); ra1[q] = ra2[q] = INT32_MAX;
+                    if (b < nb) {
+                        unsigned long long *o = pub_s + ((size_t)u * nb + b) * 4;
+                        const unsigned long long g0 = ld64(o), g1 = ld64(o + 1), g2 = ld64(o + 2);
+                        ok = ok && ((unsigned int)(g0 >> 32) & 1u) == tagbit && ((unsigned int)(g1 >> 32) & 1u) == tagbit
+                                && ((unsigned int)(g2 >> 32) & 1u) == tagbit;
+                        rv1[q] = __builtin_bit_cast(float, (unsigned int)g0); ra1[q] = (int)((unsigned int)(g0 >> 32) >> 1);
+                        rv2[q] = __builtin_bit_cast(float, (unsigned int)g1); ra2[q] = (int)((unsigned int)(g1 >> 32) >> 1);
+                        rv3[q] = __builtin_bit_cast(float, (unsigned int)g2);
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) { got = true; break; }
+                if (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0xffffffffu) break;
+                // watchdog: a step takes microseconds.  Seconds without news mean that some workgroup of the launch is not
+                // running (the device shared with another spinning launch)
+                if (__builtin_amdgcn_s_memrealtime() - t_wait > G32_STALL_TICKS) { if (lane == 0) give_up(); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (fenced) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (!got) { if (lane == 0) info[u].state = 4; continue; }
+            float mv = __builtin_inff();
+            int mi = INT32_MAX, mb = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (lt_vi(rv1[q], ra1[q], mv, mi)) { mv = rv1[q]; mi = ra1[q]; mb = lane + 64 * q; }
+#pragma unroll
+            for (int m = 1; m <= 32; m <<= 1) {
+                const float ov = __shfl_xor(mv, m, 64); const int oi = __shfl_xor(mi, m, 64), ob = __shfl_xor(mb, m, 64);
+                if (lt_vi(ov, oi, mv, mi)) { mv = ov; mi = oi; mb = ob; }
+            }
+            int state = 3, nH = 0, sender = 0;
+            double tau = 0.0;
+            if (!(mv < __builtin_inff())) state = 2;
+            else {
+                double V2 = V2w[0];
+#pragma unroll
+                for (int k = 1; k < UB; ++k) V2 = u == k ? V2w[k] : V2;
+                double EW = EWw[0];
+#pragma unroll
+                for (int k = 1; k < UB; ++k) EW = u == k ? EWw[k] : EW;
+                // search_epsilon mode: the float32 minimum is the answer -- with a hoisted target term only where its
+                // ABSOLUTE bound is small against the minimum (it is not for near-exact matches: decided exactly then)
+                if (approx && (!HOIST || 4.0 * (errf((double)mv, V2) + EW) <= 1e-3 * (double)mv)) state = 1;
+                else {
+                    tau = tau_of(mv, V2, EW);
+                    int nc = 0;
+                    bool cov = false;
+                    float v3me = __builtin_inff();
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned long long h1 = __builtin_amdgcn_ballot_w64((double)rv1[q] <= tau);
+                        nH += __popcll(h1);
+                        nc += __popcll(h1) + __popcll(__builtin_amdgcn_ballot_w64((double)rv2[q] <= tau));
+                        cov = cov || __builtin_amdgcn_ballot_w64((double)rv3[q] <= tau) != 0ull;
+                        if ((int)(blockIdx.x >> 6) == q) v3me = __shfl(rv3[q], (int)(blockIdx.x & 63u), 64);
+                    }
+                    if (nc == 1 && !cov) state = 1;               // the only window inside the bound is the float32 minimum itself
+                    else sender = (mb != (int)blockIdx.x && (double)v3me <= tau) ? 1 : 0;
+                }
+            }
+            if (lane == 0) {
+                G32Info x;
+                x.state = state; x.D = mb; x.nH = nH; x.sender = sender; x.winner = (int64_t)mi; x.tau = tau;
+                info[u] = x;
+            }
+        }
+        __syncthreads();
+        stamp(step, 4);
+        int st[UB];
+        {
+            bool leave = false, none = false;
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                st[u] = (u < a.nu && step < a.nsteps_u[u]) ? info[u].state : 0;
+                leave = leave || st[u] == 4;
+                none = none || st[u] == 2;
+            }
+            if (leave) return;                                    // the launch was ended (watchdog, an undecidable step)
+            if (none) {                                           // nothing finite: every workgroup sees it, one reports it
+                if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(status, (int64_t)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+        // a holder of more windows than it published, and not the one who decides: its lanes' windows go to its slot
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (st[u] != 3 || !info[u].sender) continue;            // uniform
+            const double tau = info[u].tau;
+            if (tid == 0) { ccount[0] = 0; ccount[1] = 0; }
+            __syncthreads();
+            offer(u, tau, G32_SEND);
+            __syncthreads();
+            const int n = ccount[0];
+            const bool over = ccount[1] != 0 || n > G32_SEND;
+            unsigned long long *slot = send + ((size_t)u * nb + blockIdx.x) * (G32_SEND + 1);
+            if (fenced && tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (tid < n && tid < G32_SEND) st64(slot + 1 + tid, clist[tid] | ((unsigned long long)stag << 32));
+            if (tid == 0) st64(slot, (unsigned long long)(over ? 0xffffu : (unsigned int)n) | ((unsigned long long)stag << 32));
+            __syncthreads();
+            stamp(step, 7);
+        }
         unsigned long long stat_rounds = 0, stat_windows = 0;
         int64_t winner[UB];
         bool pending[UB];
@@ -744,6 +820,19 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
             // ---- this workgroup published the minimum: it decides ----
             const double tau = info[u].tau;
             const int nH = info[u].nH;
+            if (F16 && nH == 1 && spec_valid[u] && spec_tau[u] == tau) {
+                // decided while the others were still scanning
+                winner[u] = spec_win[u];
+                if (tid == 0) __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&status[4]), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                stat_rounds += 1; stat_windows += (unsigned long long)spec_n[u];
+                if (tid == 0) {
+                    if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                    __hip_atomic_store(&path[a.out_off[u] + step], winner[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                stamp(step, 6);
+                continue;
+            }
+            if (tid == 0 && nH > 1) { __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&status[5]), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             if (tid == 0) { ccount[0] = 0; ccount[1] = 0; }
             __syncthreads();
             offer(u, tau, G32_CAND);
@@ -849,7 +938,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
 // prologue: generation word, status
 __global__ void greedy32_init_kernel(unsigned int *gen, int64_t *status)
 {
-    if (threadIdx.x == 0) { *status = 0; *gen = 0u; status[1] = 0; status[2] = 0; status[3] = 0; }
+    if (threadIdx.x == 0) { *status = 0; *gen = 0u; status[1] = 0; status[2] = 0; status[3] = 0; status[4] = 0; status[5] = 0; }
 }
 
 // exact Euclidean distance of every pick (what the tree query returns beside the index): a wavefront per step

@@ -3507,6 +3507,8 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "greedy_hoist16_launches")) *out = (double)h->greedy_hoist16_launches;
     else if (!strcmp(name, "greedy_last_undecided_step")) *out = (double)h->greedy_last_status[0] - 1.0;     // -1: every step was decided
     else if (!strcmp(name, "greedy_last_watchdog")) *out = (double)h->greedy_last_status[3];
+    else if (!strcmp(name, "greedy_last_speculated")) *out = (double)h->greedy_last_status[4];         // streamed scan: steps decided before the gather
+    else if (!strcmp(name, "greedy_last_several_holders")) *out = (double)h->greedy_last_status[5];   // streamed scan: steps with windows inside the bound in several workgroups
     else if (!strcmp(name, "greedy_last_why_candidates")) *out = (double)h->greedy_last_status[4];
     else if (!strcmp(name, "greedy_last_why_third")) *out = (double)h->greedy_last_status[5];
     else if (!strcmp(name, "greedy_last_why_min")) { double v; memcpy(&v, &h->greedy_last_status[6], 8); *out = v; }

@@ -30,5 +30,5 @@ for fast in (0, 1, 0, 1):
     us = tm[0] / tm[1] / steps * 1e3
     print('fast %d: %.2f ms per utterance, %.1f us/step (device), same path %s; exact windows/step %.1f, second rounds/step %.2f, f16 launches %d, bf16 products %d, fallbacks %d'
           % (fast, dt * 1e3, us, same, (eng.info('greedy_exact_windows') - x0) / 3.0 / steps, (eng.info('greedy_second_rounds') - r0) / 3.0 / steps,
-             eng.info('greedy_f16_launches'), eng.info('greedy_hoist16_launches'), eng.info('greedy_fallbacks')), flush=True)
+             eng.info('greedy_f16_launches'), eng.info('greedy_hoist16_launches'), eng.info('greedy_fallbacks')), 'last launch: speculation used %d, several holders %d of %d steps' % (eng.info('greedy_last_speculated'), eng.info('greedy_last_several_holders'), steps), flush=True)
 eng.close()
