@@ -26,7 +26,8 @@
 //    steps every workgroup publishes its record and gathers everybody's (two trips through the fabric; tagged 8-byte granules,
 //    see the step's tail): all of them derive the same minimum, bound and holders, so the usual step is settled everywhere at
 //    once and the next (weight, reference) table is built by every workgroup for itself, in LDS, from the winners' join rows;
-//    otherwise the workgroup that published the minimum decides and its path entry (-1 before the launch) is the release.  A
+//    otherwise the workgroup that published the minimum decides -- in float16 scans usually BEFORE the gather, on its own windows,
+//    while the slower workgroups still scan (see the step's tail) -- and its path entry (-1 before the launch) is the release.  A
 //    generation word carries the end of the launch at an undecidable step.  A launch per step cost more than the scan itself
 //    at 65 536 units.
 //  * Instances: <target rows in LDS, hoisted target term, utterances per scan, float16 join tiles>.  With the hoisted term
