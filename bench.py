@@ -274,7 +274,7 @@ def variant_leg(eng, kind, N, Dt, Dj, T, U, K, wt, wj, F_unw, JC_unw, steps):
     rows_per_launch = T * U / max(tm['knn_filter'][1] / steps, 1)
     pairs = eng.info('coarse_pairs')
     return {'database': kind, 'frames_per_s': T * U * steps / dt, 'ms_per_step': dt / steps * 1e3, 'steps': steps,
-            'filter_coarse': bool(eng.info('filter_coarse')),
+            'filter_coarse': bool(eng.info('filter_coarse')), 'filter_onepass': bool(eng.info('filter_onepass')),
             'tile_pairs_listed': {'last_launch': pairs, 'fraction': pairs / max((rows_per_launch / 32.0) * (N / 32.0), 1.0)},
             'list_mean': eng.info('last_list_mean'), 'list_max': eng.info('last_list_max'),
             'prefilter_fallbacks': eng.info('f16_fallbacks') - before[0], 'batch_redos': eng.info('batch_redos') - before[1],

@@ -187,6 +187,7 @@ struct BatchSlot {    // one submitted batch (snk_knn_viterbi_batch_submit / _co
     int64_t q_rows = -1; int q_D = 0;     // query rows resident in Qall (a later submit with Q == NULL searches them again)
     std::vector<int64_t> q_offs;
     double ball_limit = -1.0;             // >= 0: the ball pass listed this batch's tile pairs; beyond this many the voice goes to the coarse sweep
+    double coarse_limit = -1.0;           // >= 0: the coarse sweep listed them; beyond this many the voice goes to the one-pass sweep
     int64_t total = 0;
     std::vector<int> first;
     std::vector<int64_t> offs;
@@ -268,6 +269,13 @@ struct snk_engine {
     double ball_limit = 0.0;      // pairs beyond which the ball pass of the most recent call listed too many
     bool ball_pass_ran = false;
     bool filter_coarse = false;   // this voice's tiles are not compact: the ball pass listed too many pairs once, the coarse sweep lists them since
+    // ... and where the coarse sweep lists most pairs too (units in no order at all: a tile holds 32 unrelated frames, nearly every
+    // (tile, query tile) pair has SOME unit under SOME row's threshold) the voice goes on to the one-pass three-term sweep: nothing
+    // to list, nothing to overflow (an overflowing pair list sent every group of every step through the exact float64 redo)
+    bool filter_onepass = false;
+    double onepass_gate_fraction = 0.5, coarse_limit = 0.0;
+    bool coarse_pass_ran = false;
+    int onepass_switches = 0;
     int64_t ball_switches = 0;
     DevBuf e1_16, thr1_32, cpairs, cpairctl;   // two-pass filter: per-row coarse margin and threshold, (tile, query tile) pair list
     int prefilter_two_pass = 1;   // 1: bf16-split filter as hi.hi sweep + three-term keys of the tile pairs it lets through (default)
@@ -849,7 +857,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
                 // pass 0 of the two-pass filter: centre and radius of every 32-unit tile, the centres as one more bf16-split
                 // operand (its dropped-piece ratios join the database's: one key bound serves both)
                 h->ball_tiles = 0;
-                h->filter_coarse = false;
+                h->filter_coarse = false; h->filter_onepass = false;
                 if (h->prefilter_balls) {
                     const int64_t vt = (h->N + 31) / 32, ct = (vt + 31) / 32;
                     CHK(h->ball_c.ensure((size_t)vt * h->Dpad * sizeof(double)));
@@ -1024,6 +1032,7 @@ static int debug_check_pool(snk_engine *h, int max_chunks, int64_t Tpad, int64_t
 static void note_ball_pairs(snk_engine *h, unsigned int listed)
 {
     if (h->ball_pass_ran && !h->filter_coarse && (double)listed > h->ball_limit) { h->filter_coarse = true; h->ball_switches += 1; }
+    if (h->coarse_pass_ran && !h->filter_onepass && (double)listed > h->coarse_limit) { h->filter_onepass = true; h->onepass_switches += 1; }
 }
 
 static KnnPlan make_plan(snk_engine *h, int K)
@@ -1267,7 +1276,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         const bool bf = h->bf16_ready && h->prefilter >= 1 && !cls && nt_run == h->nt16_eff;
         const double eps_c_run = bf ? h->eps_c_bf : h->eps_c;
         // two-pass filter (knn16_kernels.hip): not for stage-A-only calls
-        const bool coarse = bf && h->prefilter_two_pass && !bound_out && knn_coarse16b_supported(nt_run, dch16);
+        const bool coarse = bf && h->prefilter_two_pass && !bound_out && knn_coarse16b_supported(nt_run, dch16) && !h->filter_onepass;
         const int64_t n_tiles_b = n_slabs_b * nt_run;
         unsigned int pair_cap = 0;
         if (coarse) {
@@ -1363,6 +1372,12 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
                     h->ball_limit = h->coarse_gate_fraction * (double)(Tpad / 32) * (double)h->ball_tiles;
                 }
                 h->ball_pass_ran = balls;
+                h->coarse_pass_ran = !balls;
+                if (!balls) {
+                    // beyond half of all pairs the one-pass sweep is the cheaper filter; the list must not overflow either
+                    const double all = (double)(Tpad / 32) * (double)n_tiles_b;
+                    h->coarse_limit = h->onepass_gate_fraction * all < 0.9 * (double)pair_cap ? h->onepass_gate_fraction * all : 0.9 * (double)pair_cap;
+                }
                 launch_knn_filter16c(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, h->thr32.as<float>(), h->thr1_32.as<float>(),
                                      Tpad, n_tiles_b, h->slabctr.as<unsigned int>() + 1, h->cpairs.p, h->cpairctl.as<unsigned int>(), pair_cap,
                                      h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, knn_pool_chunk_entries(), s,
@@ -1403,7 +1418,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         if (deferred_status) {               // the batch caller redoes failures with precision 0
             // (and learns how many tile pairs the ball pass listed)
             if (pairs_listed_dev) {
-                if (coarse && h->ball_pass_ran) HIPCHK(hipMemcpyAsync(pairs_listed_dev, h->cpairctl.p, sizeof(unsigned int), hipMemcpyDeviceToDevice, s));
+                if (coarse) HIPCHK(hipMemcpyAsync(pairs_listed_dev, h->cpairctl.p, sizeof(unsigned int), hipMemcpyDeviceToDevice, s));
                 else HIPCHK(hipMemsetAsync(pairs_listed_dev, 0, sizeof(unsigned int), s));
             }
             return 0;
@@ -2069,6 +2084,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
                        b.dist.as<double>() + r0 * K, nullptr, b.status.as<int>() + g, nullptr, nullptr, false, false,
                        reinterpret_cast<unsigned int *>(b.status.as<int>() + b.n_groups + g)));
         b.ball_limit = h->ball_pass_ran ? h->ball_limit : -1.0;
+        b.coarse_limit = h->coarse_pass_ran ? h->coarse_limit : -1.0;
         CHK(viterbi_group(h, g, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
                           b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), n_utts));
     }
@@ -2111,6 +2127,9 @@ int snk_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, i
     if (b.ball_limit >= 0.0 && !h->filter_coarse)
         for (int g = 0; g < b.n_groups; ++g)
             if ((double)(unsigned int)status[b.n_groups + g] > b.ball_limit) { h->filter_coarse = true; h->ball_switches += 1; break; }
+    if (b.coarse_limit >= 0.0 && !h->filter_onepass)
+        for (int g = 0; g < b.n_groups; ++g)
+            if ((double)(unsigned int)status[b.n_groups + g] > b.coarse_limit) { h->filter_onepass = true; h->onepass_switches += 1; break; }
     bool redone = false;
     for (int g = 0; g < b.n_groups; ++g) {
         if (status[g] == 0) continue;
@@ -3570,6 +3589,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "shard_last_sent_mb")) *out = h->shard_last_sent_mb;
     else if (!strcmp(name, "shard_last_padded_mb")) *out = h->shard_last_padded_mb;
     else if (!strcmp(name, "wide_ready")) *out = h->wide16_ready ? 1 : 0;
+    else if (!strcmp(name, "filter_onepass")) *out = h->filter_onepass ? 1 : 0;     // 1: the coarse sweep listed most pairs for this voice: one-pass sweep since
     else if (!strcmp(name, "filter_coarse")) *out = h->filter_coarse ? 1 : 0;       // 1: the ball pass listed too many pairs for this voice
     else if (!strcmp(name, "ball_switches")) *out = (double)h->ball_switches;
     else if (!strcmp(name, "coarse_pairs") || !strcmp(name, "coarse_pair_overflow")) {

@@ -208,3 +208,34 @@ def test_two_pass_filter_selects_what_the_one_pass_filter_selects(engine, N, T, 
         print('lists N=%d T=%d K=%d: mean %.0f -> %.0f, max %.0f -> %.0f with the scout bound'
               % (N, T, K, lists[1][0], engine.info('last_list_mean'), lists[1][1], engine.info('last_list_max')))
     engine.set_option('prefilter_ball_bound', 0)
+
+
+def test_units_in_no_order_go_to_the_one_pass_sweep(engine):
+    """A database whose units stand in random order: a tile of 32 holds unrelated frames, so the ball pass lists (nearly) every
+    tile pair -> the voice goes to the coarse sweep; that one lists most pairs too -> the voice goes on to the one-pass
+    three-term sweep (`filter_onepass`), which lists nothing.  Results are the oracle's at every stage of the descent, and once
+    there the calls run without an overflowing list (no fallback to the exact sweep)."""
+    engine.set_option('prefilter', 1); engine.set_option('prefilter_two_pass', 1); engine.set_option('prefilter_ball_bound', 0)
+    N, Dt, K, T = 65536, 61, 100, 600
+    F0, JC0 = o.synthetic_db(N, Dt, 24, 5)
+    perm = np.random.RandomState(3).permutation(N)
+    F_unw, JC_unw = F0[perm], JC0[np.concatenate([perm, [N]])]
+    rng = np.random.RandomState(105)
+    wt, wj = 0.2 + rng.rand(Dt), 0.05 + 0.2 * rng.rand(24)
+    F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    assert engine.info('filter_coarse') == 0 and engine.info('filter_onepass') == 0
+    U = o.synthetic_targets(F_unw, T, seed=7) * wt
+    oc, od = o.knn_bruteforce(F, U, K)
+    seen = []
+    for call in range(5):
+        before = engine.info('f16_fallbacks')
+        cand, dist = engine.knn(U, K)
+        assert np.array_equal(cand, oc) and np.array_equal(dist, od)
+        seen.append((int(engine.info('filter_coarse')), int(engine.info('filter_onepass')), int(engine.info('f16_fallbacks') - before)))
+    assert seen[-1][:2] == (1, 1), seen                       # both latches set ...
+    assert seen[-1][2] == 0 and seen[-2][2] == 0, seen         # ... and the calls behind them do not fall back
+    # new weights: the voice is judged afresh
+    engine.set_weights(wt * 1.5, wj)
+    assert engine.info('filter_coarse') == 0 and engine.info('filter_onepass') == 0
