@@ -615,16 +615,26 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
         }
         if (tid < G32_UBX) info[tid].state = 0;
         __syncthreads();
-        // publish (thread u merges the wavefronts' sets of utterance u; a test hook keeps workgroup 0 silent at step 1)
-        if (tid < UB && tid < a.nu && step < a.nsteps_u[tid] && !(test_stall && step == 1 && blockIdx.x == 0)) {
-            Top3 r = red3[tid * G32_MAXW];
-            for (int w = 1; w < nwaves; ++w) top3_merge(r, red3[tid * G32_MAXW + w]);
-            if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            unsigned long long *o = pub_s + ((size_t)tid * nb + blockIdx.x) * 4;
-            st64(o, pack(r.v1, r.a1));
-            st64(o + 1, pack(r.v2, r.a2));
-            st64(o + 2, pack(r.v3, 0));
-            spec_v[tid][0] = r.v1; spec_v[tid][1] = r.v2; spec_a[tid] = r.a1;
+        // publish: wavefront (u mod nwaves) merges the wavefronts' sets of utterance u -- a lane per wavefront, three levels of
+        // exchanges (one thread merging them one after the other was 1.3 us of dependent instructions) -- and its lane 0 stores
+        // the record; a test hook keeps workgroup 0 silent at step 1
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (!(u < a.nu && step < a.nsteps_u[u]) || (test_stall && step == 1 && blockIdx.x == 0)) continue;      // uniform
+            if (wave != u % nwaves) continue;
+            Top3 r;
+            top3_init(r);
+            if (lane < nwaves) r = red3[u * G32_MAXW + lane];
+#pragma unroll
+            for (int m = 1; m < G32_MAXW; m <<= 1) { const Top3 o = top3_shfl_xor(r, m); top3_merge(r, o); }
+            if (lane == 0) {
+                if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                unsigned long long *o = pub_s + ((size_t)u * nb + blockIdx.x) * 4;
+                st64(o, pack(r.v1, r.a1));
+                st64(o + 1, pack(r.v2, r.a2));
+                st64(o + 2, pack(r.v3, 0));
+                spec_v[u][0] = r.v1; spec_v[u][1] = r.v2; spec_a[u] = r.a1;
+            }
         }
         stamp(step, 3);
         // ---- float16 scans decide exactly at every step (the best window's neighbours are inside the bound), and the workgroup that
