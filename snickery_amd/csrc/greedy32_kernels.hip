@@ -844,9 +844,11 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                 continue;
             }
             if (tid == 0 && nH > 1) { __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&status[5]), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            if (tid == 0) { ccount[0] = 0; ccount[1] = 0; }
+            // (several holders, but this workgroup has decided among its OWN windows already: only that winner goes on)
+            const bool own_known = F16 && spec_valid[u] && spec_tau[u] == tau;
+            if (tid == 0) { ccount[0] = own_known ? 1 : 0; ccount[1] = 0; if (own_known) clist[0] = (unsigned long long)spec_win[u]; }
             __syncthreads();
-            offer(u, tau, G32_CAND);
+            if (!own_known) offer(u, tau, G32_CAND);
             if (nH > 1) {
                 // other holders: the published windows of those that kept nothing more, the lists of the others
                 for (unsigned int b = tid; b < nb; b += blockDim.x) {
