@@ -4,7 +4,8 @@
 
 Stamps per step and workgroup (100 MHz clock): 0 step started, 1 table in LDS, 2 scan done, 3 record published, 4 all records
 gathered and classified; where a workgroup has to decide: 7 (a holder) its lanes' windows sent, 5 (decider) candidates collected,
-8 candidate ids read, 9 terms of the candidates stored, 10 chains summed, 6 winner released."""
+8 candidate ids read, 9 terms of the candidates stored, 10 chains summed, 6 winner released.  In float16 scans the deciding workgroup
+has usually decided BEFORE the gather (stamps 8 / 9 are then those of its speculation, 5 and 10 are missing)."""
 import sys, os, struct
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,7 +33,7 @@ for s in range(8, 40):
     t0 = x[:, 0].min()
     dec = int(np.argmax(x[:, 6]))                     # the deciding workgroup (if any): the only one with stamp 6
     has = x[dec, 6] > 0
-    f = lambda v: (v - t0) if has else np.nan
+    f = lambda v: (v - t0) if (has and v > 0) else np.nan        # (a stamp that was not taken in this step -- e.g. a step decided before the gather -- is 0)
     rows.append([x[:, 0].max() - t0, np.median(x[:, 1]) - t0, np.median(x[:, 2]) - t0, x[:, 2].max() - t0, x[:, 3].max() - t0,
                  np.median(x[:, 4]) - t0, x[:, 4].max() - t0, f(x[:, 7].max()) if x[:, 7].max() > 0 else np.nan, f(x[dec, 5]), f(x[dec, 8]), f(x[dec, 9]), f(x[dec, 10]), f(x[dec, 6]),
                  np.median(t[s + 1][:, 0]) - t0, t[s + 1][:, 0].min() - t0])
