@@ -331,10 +331,14 @@ int snk_concat_fragments(snk_handle h, const int64_t *first_row, const int64_t *
  *                              fl32(fl32(tdist[t-1,k']) + fl32(c(k',k))), totals accumulated in float32, the last row's target
  *                              cost on the exit arc; ties as before.  This IS a different result on near ties (the cost returned
  *                              is the float32 total); it runs on the dense kernels.
- * Options of the K-NN filter: prefilter 0 / 1 / 2, prefilter_two_pass 0 / 1, prefilter_balls 0 / 1, coarse_gate_fraction
- * (INTEGRATION.md).  None of these changes a result (viterbi_weights excepted, which selects the arithmetic).
- * infos: greedy_fallbacks, greedy_stalls, greedy_exact_windows, greedy_second_rounds, greedy_hoist_launches,
- * greedy_f16_launches, greedy_f16_delta, greedy_resident_launches.  The other names are listed in INTEGRATION.md.
+ *   join_exact_form 0 / 1      pass 3 of the sparse path: a lane per cell / a cooperative workgroup per step (default 1)
+ * Options of the K-NN filter: prefilter 0 / 1 / 2, prefilter_two_pass 0 / 1, prefilter_balls 0 / 1, prefilter_super_balls 0 / 1,
+ * prefilter_ball_bound 0 / 1, coarse_gate_fraction; of the sharded search: shard_compact 0 / 1; of the greedy search:
+ * greedy_hoist 0 / 1, greedy_hoist_fast 0 / 1, greedy_f16 0 / 1 / 2, greedy_resident 0 / 1, greedy_fenced 0 / 1.
+ * None of these changes a result (viterbi_weights excepted, which selects the arithmetic).
+ * infos: greedy_fallbacks, greedy_stalls, greedy_exact_windows, greedy_second_rounds, greedy_hoist_launches, greedy_hoist16_launches,
+ * greedy_f16_launches, greedy_f16_delta, greedy_resident_launches, greedy_last_speculated, greedy_last_several_holders, filter_coarse,
+ * filter_onepass, shard_last_sent_mb.  The other names are listed in INTEGRATION.md.
  * Tripwire of the K-NN prefilter's key bound (snk_reset_timers clears it): prefilter_margin_rows = rows of prefilter K-NN
  * calls whose exact K-th key came within 2 eps of the filter threshold (eps: the largest error the approximate keys are
  * ASSUMED to have -- for the bf16-split operands that rests on the probed accumulation property below);
