@@ -85,6 +85,9 @@ def test_b3_nick_size(engine, me):
     _check(engine, F_unw, JC_unw, wt, wj, U, me, max_steps=24)
     # a database of this size is streamed: hoisted target term + float16 join tiles are what has just been checked
     assert engine.info('greedy_f16_launches') == n16 + 1 and engine.info('greedy_hoist_launches') == nh + 1
+    # ... with the target values from the bf16 pipe, and steps decided before the gather by the workgroup whose minimum was the smallest
+    # published so far (greedy32_kernels.hip, the step's tail): both paths were part of what was compared with the oracle
+    assert engine.info('greedy_hoist16_launches') >= 1 and engine.info('greedy_last_speculated') >= 1
     _check(engine, F_unw, JC_unw, wt, wj, U, me, start=1234567, max_steps=20)
     n = 20 * me
     Ud = (F_unw[200300:200300 + n].astype(np.float64)) * wt
