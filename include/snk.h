@@ -334,7 +334,8 @@ int snk_concat_fragments(snk_handle h, const int64_t *first_row, const int64_t *
  *   join_exact_form 0 / 1      pass 3 of the sparse path: a lane per cell / a cooperative workgroup per step (default 1)
  * Options of the K-NN filter: prefilter 0 / 1 / 2, prefilter_two_pass 0 / 1, prefilter_balls 0 / 1, prefilter_super_balls 0 / 1,
  * prefilter_ball_bound 0 / 1, coarse_gate_fraction; of the sharded search: shard_compact 0 / 1; of the greedy search:
- * greedy_hoist 0 / 1, greedy_hoist_fast 0 / 1, greedy_f16 0 / 1 / 2, greedy_resident 0 / 1, greedy_fenced 0 / 1.
+ * greedy_hoist 0 / 1, greedy_hoist_fast 0 / 1, greedy_f16 0 / 1 / 2, greedy_resident 0 / 1, greedy_speculate 0 / 1, greedy_fenced 0 / 1
+ * (INTEGRATION.md).
  * None of these changes a result (viterbi_weights excepted, which selects the arithmetic).
  * infos: greedy_fallbacks, greedy_stalls, greedy_exact_windows, greedy_second_rounds, greedy_hoist_launches, greedy_hoist16_launches,
  * greedy_f16_launches, greedy_f16_delta, greedy_resident_launches, greedy_last_speculated, greedy_last_several_holders, filter_coarse,

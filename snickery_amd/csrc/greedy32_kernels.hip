@@ -178,6 +178,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
     // hipMalloc memory (MI355X_MICROARCH.md, inter-workgroup visibility), not a guarantee of the memory model; a test
     // runs 1 000 steps in both modes and compares.
     const bool fenced = (flags & 512) != 0;
+    const bool speculate = (flags & 2048) == 0;             // option greedy_speculate: the decision before the gather (float16 scans)
     // optional timeline (SNK_G32_TRACE=file): 8 stamps of the 100 MHz clock per step and workgroup, steps 0 .. G32_TRACE_STEPS - 1
     auto stamp = [&](int64_t st, int k) {
         if (trace && st < G32_TRACE_STEPS && threadIdx.x == 0)
@@ -651,7 +652,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
 #pragma unroll
         for (int u = 0; u < UB; ++u) { spec_valid[u] = false; spec_tau[u] = 0.0; spec_win[u] = 0; spec_n[u] = 0; }
         if constexpr (F16) {
-            if (!approx) {
+            if (!approx && speculate) {
                 // a first look at the records (a wavefront per utterance).  All there: nothing to hide behind.  Somebody has
                 // published a smaller minimum: this workgroup will not decide.  Otherwise -- its minimum is the smallest so far --
                 // it decides on its own windows now.  (Without the second test every early workgroup speculated: 255 useless

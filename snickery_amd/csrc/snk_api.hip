@@ -319,6 +319,7 @@ struct snk_engine {
     int64_t greedy_hoist_launches = 0;    // scans that read the hoisted target term
     int64_t greedy_second_rounds = 0, greedy_exact_windows = 0;     // statistics of the float32 scan's exact decisions
     int greedy_hoist = 1;                 // 1: the float32 scan reads one precomputed target value per window (default)
+    int greedy_speculate = 1;             // 1: in float16 scans the workgroup whose minimum is the smallest published so far decides before the gather (default)
     int greedy_hoist_fast = 1;            // 1: scans of float16 join tiles take the target values from the bf16 matrix pipe (default)
     int64_t greedy_hoist16_launches = 0;
     double greedy_hoist_max_gb = 48.0;    // products of one scan group beyond this many GB: the scan computes the target term itself
@@ -2313,7 +2314,7 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
         h->greedy_resident_launches += 1;
     } else
     launch_greedy32(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
-                    h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nu, q_off, ns, oo, st, (approx ? 1 : 0) | (h->greedy_test_stall ? 256 : 0) | (h->greedy_fenced ? 512 : 0),
+                    h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nu, q_off, ns, oo, st, (approx ? 1 : 0) | (h->greedy_test_stall ? 256 : 0) | (h->greedy_fenced ? 512 : 0) | (h->greedy_speculate ? 0 : 2048),
                     h->g32_blk.p, h->n_cus, gen,
                     status, h->gpath.as<int64_t>(), hoist ? &hst : nullptr, h->stream);
     HIPCHK(hipGetLastError());
@@ -3443,6 +3444,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "greedy_hoist")) {
         if (value != 0.0 && value != 1.0) return fail("greedy_hoist must be 0 or 1");
         h->greedy_hoist = (int)value;
+    } else if (!strcmp(name, "greedy_speculate")) {
+        if (value != 0.0 && value != 1.0) return fail("greedy_speculate must be 0 or 1");
+        h->greedy_speculate = (int)value;
     } else if (!strcmp(name, "greedy_hoist_fast")) {
         if (value != 0.0 && value != 1.0) return fail("greedy_hoist_fast must be 0 or 1");
         h->greedy_hoist_fast = (int)value;
@@ -3523,6 +3527,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "greedy_hoist")) *out = h->greedy_hoist;
     else if (!strcmp(name, "greedy_hoist_launches")) *out = (double)h->greedy_hoist_launches;
     else if (!strcmp(name, "greedy_hoist_fast")) *out = h->greedy_hoist_fast;
+    else if (!strcmp(name, "greedy_speculate")) *out = h->greedy_speculate;
     else if (!strcmp(name, "greedy_hoist16_launches")) *out = (double)h->greedy_hoist16_launches;
     else if (!strcmp(name, "greedy_last_undecided_step")) *out = (double)h->greedy_last_status[0] - 1.0;     // -1: every step was decided
     else if (!strcmp(name, "greedy_last_watchdog")) *out = (double)h->greedy_last_status[3];

@@ -172,6 +172,7 @@ def test_float16_join_tiles_keep_the_results(engine, me, lfat, mode, Dj, Dt, off
         utts = [o.synthetic_targets(F_unw, T, seed=16 + i) * wt for i, T in enumerate(lens)]
         starts = [-1, 17, N - me - 3, 0]
         f0 = engine.info('greedy_fallbacks')
+        ref0 = oc.greedy_f32(F_unw, JC_unw, wt, wj, utts[0], me, lfat, mode, starts[0])
         # scans of float16 tiles take the target values from the bf16 matrix pipe (three exact bf16 pieces per operand,
         # hoist_product16_kernel); greedy_hoist_fast 0 keeps the float64 product
         for fast in (0, 1):
@@ -183,6 +184,12 @@ def test_float16_join_tiles_keep_the_results(engine, me, lfat, mode, Dj, Dt, off
                 assert path == op and np.array_equal(d, od)
             assert engine.info('greedy_hoist16_launches') == n16 + 3 * fast
         assert engine.info('greedy_f16_delta') > 0.0
+        # the decision before the gather (greedy_speculate, default on) against the plain hand-off: the same results either way
+        for spec in (0, 1):
+            engine.set_option('greedy_speculate', spec)
+            path, d = engine.greedy(utts[0], start_state=starts[0], return_distances=True)
+            assert path == ref0[0] and np.array_equal(d, ref0[1])
+            assert spec == 1 or engine.info('greedy_last_speculated') == 0
         paths, dists = engine.greedy_batch(utts[:3], start_states=starts[:3], return_distances=True)      # three per scan
         for U, st, p, d in zip(utts, starts, paths, dists):
             op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, U, me, lfat, mode, st)
@@ -204,7 +211,7 @@ def test_float16_join_tiles_keep_the_results(engine, me, lfat, mode, Dj, Dt, off
             path, d = engine.greedy(U, start_state=3100, return_distances=True)
             assert path == list(range(3100, 3100 + 15 * me, me)) and np.all(d == 0.0)
     finally:
-        engine.set_option('greedy_f16', 1); engine.set_option('greedy_hoist_fast', 1)
+        engine.set_option('greedy_f16', 1); engine.set_option('greedy_hoist_fast', 1); engine.set_option('greedy_speculate', 1)
 
 
 def test_values_outside_the_float16_range_keep_float32_tiles(engine):
