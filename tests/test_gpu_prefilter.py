@@ -239,3 +239,31 @@ def test_units_in_no_order_go_to_the_one_pass_sweep(engine):
     # new weights: the voice is judged afresh
     engine.set_weights(wt * 1.5, wj)
     assert engine.info('filter_coarse') == 0 and engine.info('filter_onepass') == 0
+
+
+def test_batches_on_units_in_no_order_settle_on_the_one_pass_sweep(engine):
+    """The same descent (ball pass -> coarse sweep -> one-pass sweep) through the batch entry point, where the pairs a group listed
+    are seen at the batch's collect: after a few batches the voice sits on the one-pass sweep and no group is redone any more;
+    paths and costs equal the single-utterance calls' at every stage."""
+    engine.set_option('prefilter', 1); engine.set_option('prefilter_two_pass', 1); engine.set_option('prefilter_ball_bound', 0)
+    N, Dt, Dj, K = 65536, 61, 24, 50
+    F0, JC0 = o.synthetic_db(N, Dt, Dj, 8)
+    perm = np.random.RandomState(4).permutation(N)
+    F_unw, JC_unw = F0[perm], JC0[np.concatenate([perm, [N]])]
+    rng = np.random.RandomState(108)
+    wt, wj = 0.2 + rng.rand(Dt), 0.05 + 0.2 * rng.rand(Dj)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    utts = [o.synthetic_targets(F_unw, T, seed=40 + i) * wt for i, T in enumerate([300, 280, 320, 300])]
+    single = None
+    redos = []
+    for call in range(5):
+        before = engine.info('batch_redos')
+        paths, costs = engine.knn_viterbi_batch(utts, K)
+        redos.append(int(engine.info('batch_redos') - before))
+        if single is None:
+            single = [engine.knn_viterbi(U, K) for U in utts]
+        for u in range(len(utts)):
+            assert list(paths[u]) == single[u][0] and costs[u] == single[u][1]
+    assert engine.info('filter_coarse') == 1 and engine.info('filter_onepass') == 1, redos
+    assert redos[-1] == 0 and redos[-2] == 0, redos
