@@ -1280,6 +1280,7 @@ static int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const
         const bool coarse = bf && h->prefilter_two_pass && !bound_out && knn_coarse16b_supported(nt_run, dch16) && !h->filter_onepass;
         const int64_t n_tiles_b = n_slabs_b * nt_run;
         unsigned int pair_cap = 0;
+        if (!coarse) { h->ball_pass_ran = false; h->coarse_pass_ran = false; }      // (nothing listed by this call: nothing to judge the voice by)
         if (coarse) {
             const int64_t all = (Tpad / 32) * n_tiles_b;
             int64_t capp = all / 4 > ((int64_t)4 << 20) ? all / 4 : ((int64_t)4 << 20);
@@ -2623,6 +2624,11 @@ static int knn_local_batch(snk_engine *h, const char *who, const double *Q, cons
     std::vector<int> st((size_t)n_groups);
     CHK(d2h_sync(h, st.data(), h->res_status.p, (size_t)n_groups * sizeof(int), h->stream));
     HIPCHK(hipGetLastError());
+    if ((h->ball_pass_ran || h->coarse_pass_ran) && h->cpairctl.p) {
+        unsigned int listed = 0;                  // (of the last group's call: enough to judge the voice)
+        CHK(d2h_sync(h, &listed, h->cpairctl.p, sizeof(listed), h->stream));
+        note_ball_pairs(h, listed);
+    }
     for (int g = 0; g < n_groups; ++g) {
         if (st[g] == 0) continue;
         if (st[g] & 2) h->tie_overflow = 1;
@@ -3077,6 +3083,12 @@ static int sharded_submit(snk_engine *h, ShardTicket &t, const double *Q, const 
         CHK(comm_all_gather(h, h->sh_tot.p, h->sh_totall.p, (int64_t)G * 8));
         std::vector<int64_t> totall((size_t)G * G);
         CHK(d2h_sync(h, totall.data(), h->sh_totall.p, (size_t)G * G * sizeof(int64_t), h->stream));
+        if ((h->ball_pass_ran || h->coarse_pass_ran) && h->cpairctl.p) {
+            // (the host is waiting here anyway: what the step's last K-NN call listed decides whether this voice keeps its filter)
+            unsigned int listed = 0;
+            CHK(d2h_sync(h, &listed, h->cpairctl.p, sizeof(listed), h->stream));
+            note_ball_pairs(h, listed);
+        }
         int64_t so = 0, ro = 0;
         for (int p = 0; p < G; ++p) {
             const int64_t ts = totall[(size_t)me * G + p], tr = totall[(size_t)p * G + me];
