@@ -4,18 +4,18 @@ ARCH  ?= gfx950
 CSRC  := snickery_amd/csrc
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -ffp-contract=off -Wno-unused-value -Iinclude
 LIB   := snickery_amd/libsnkhip.so
-OBJS  := $(CSRC)/knn_kernels.o $(CSRC)/knn16_kernels.o $(CSRC)/viterbi_kernels.o $(CSRC)/joinfast_kernels.o $(CSRC)/joinlb2_kernels.o $(CSRC)/greedy_kernels.o $(CSRC)/greedy32_kernels.o $(CSRC)/greedy_hoist_kernels.o $(CSRC)/greedy_res_kernels.o $(CSRC)/concat_kernels.o $(CSRC)/snk_api.o
+OBJS  := $(CSRC)/knn_kernels.o $(CSRC)/knn16_kernels.o $(CSRC)/viterbi_kernels.o $(CSRC)/joinfast_kernels.o $(CSRC)/joinlb2_kernels.o $(CSRC)/greedy_kernels.o $(CSRC)/greedy32_kernels.o $(CSRC)/greedy_hoist_kernels.o $(CSRC)/greedy_res_kernels.o $(CSRC)/concat_kernels.o $(CSRC)/api_core.o $(CSRC)/api_knn.o $(CSRC)/api_viterbi.o $(CSRC)/api_greedy.o $(CSRC)/api_shard.o $(CSRC)/api_options.o
 
 all: $(LIB) oracle
 
 # the K-NN prefilter kernels test the matrix results on the vector unit: accumulators in architected registers
 $(CSRC)/knn16_kernels.o: HIPFLAGS += -mllvm -amdgpu-mfma-vgpr-form
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/snk_internal.h $(CSRC)/greedy_common.h $(CSRC)/greedy32_device.h include/snk.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/snk_internal.h $(CSRC)/snk_engine.h $(CSRC)/greedy_common.h $(CSRC)/greedy32_device.h include/snk.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+$(LIB): $(OBJS) $(CSRC)/libsnkhip.map
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--version-script=$(CSRC)/libsnkhip.map -o $@ $(OBJS)
 
 oracle:
 	$(MAKE) -C oracle
@@ -29,7 +29,7 @@ ASAN_FLAGS := --cuda-host-only -O1 -g -fPIC -std=c++17 -ffp-contract=off -Wno-un
               -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -shared-libasan
 ASAN_OBJS  := $(patsubst $(CSRC)/%.o,$(ASAN_DIR)/%.o,$(OBJS)) $(ASAN_DIR)/fake_hip.o
 asan-host: $(ASAN_DIR)/libsnkhip_host_asan.so
-$(ASAN_DIR)/%.o: $(CSRC)/%.hip $(CSRC)/snk_internal.h $(CSRC)/greedy_common.h $(CSRC)/greedy32_device.h include/snk.h
+$(ASAN_DIR)/%.o: $(CSRC)/%.hip $(CSRC)/snk_internal.h $(CSRC)/snk_engine.h $(CSRC)/greedy_common.h $(CSRC)/greedy32_device.h include/snk.h
 	@mkdir -p $(ASAN_DIR)
 	$(HIPCC) $(ASAN_FLAGS) -c $< -o $@
 $(ASAN_DIR)/fake_hip.o: tools/fakehip/fake_hip.cpp

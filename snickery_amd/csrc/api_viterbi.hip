@@ -1,0 +1,505 @@
+// C ABI of libsnkhip.so, part 3: join costs, Viterbi (viterbi_search, synth_halfphone.py:1399-1436) and the batch pipeline
+// (K-NN of a group on the main stream, the recursions of the group before on a side stream).
+#include "snk_engine.h"
+
+static int slot_ensure(snk_engine *h, UttSlot &s, int64_t T, int K)
+{
+    CHK(s.cand.ensure((size_t)T * K * sizeof(int64_t)));
+    CHK(s.tdist.ensure((size_t)T * K * sizeof(double)));
+    if (!use_sparse_viterbi(h, K, 1)) CHK(s.J.ensure((size_t)(T > 1 ? T - 1 : 1) * K * K * sizeof(double)));
+    CHK(s.bp.ensure((size_t)T * K));
+    CHK(s.path.ensure((size_t)T * sizeof(int64_t)));
+    CHK(s.plen.ensure(sizeof(int64_t)));
+    CHK(s.cost.ensure(sizeof(double)));
+    return 0;
+}
+
+static int64_t join_units(snk_engine *h)
+{
+    // data_frames of unit_end_data = rows of join_contexts - 1 (synth_halfphone.py:3227)
+    return h->Njc - 1;
+}
+
+// viterbi_mode 2 (default): the sparse path wherever it is supported -- batches (its first pass runs over the whole
+// chip while the per-utterance passes hide beside the next group's K-NN) and, since pass 2 runs in chunks side by
+// side and pass 4 on one wavefront, a single utterance too (T = 600, K = 100: 0.75 ms against 1.65 ms through the
+// dense kernels).  1 forces it, 0 forces the dense exact path.  Same results.
+bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts)
+{
+    (void)n_utts;
+    if (h->viterbi_weights == 1) return false;          // the float32 weight chain runs on the dense kernels
+    if (!join_lb_supported(h->Dj, K)) return false;
+    return h->viterbi_mode == 1 || h->viterbi_mode == 2;
+}
+
+static int sparse_ensure(snk_engine *h, UttSlot &s, int64_t rows, int K)
+{
+    CHK(s.Jlo.ensure((size_t)(rows > 1 ? rows - 1 : 1) * K * K * sizeof(float)));
+    CHK(s.scale.ensure((size_t)rows * sizeof(float)));
+    CHK(s.sets.ensure((size_t)rows * K * 16));
+    CHK(s.cex.ensure((size_t)rows * K * join_record_bytes() + 4096));
+    CHK(s.bp.ensure((size_t)rows * K));
+    if (!h->vstats.p) {
+        CHK(h->vstats.ensure((128 + 16 * 1024) * sizeof(unsigned long long)));    // + the stamps of a -DSNK_JF_TRACE build
+        HIPCHK(hipMemset(h->vstats.p, 0, 128 * sizeof(unsigned long long)));
+    }
+    return 0;
+}
+
+static int ensure_jw32(snk_engine *h, hipStream_t st)
+{
+    if (h->jw32_ready) return 0;
+    // once per set of weights; waited for: the groups of a batch launch pass 1 on different streams
+    const int Jq = join_lb2_pitch(h->Dj);
+    CHK(h->JW32.ensure((size_t)h->Njc * Jq * sizeof(float)));
+    CHK(h->jw_umax.ensure(64));
+    launch_join_weight32(h->JC_unw.as<float>(), h->Jp, h->Njc, h->Dj, h->wj.as<double>(), h->JW32.as<float>(), Jq,
+                         h->jw_umax.as<unsigned int>(), st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    h->jw32_ready = true;
+    return 0;
+}
+
+static void join_bounds_launch(snk_engine *h, const int64_t *cand, int64_t rows, int K, float *Jlo, float *scale, hipStream_t st)
+{
+    if (h->join_lb_variant == 1)
+        launch_join_lb2(h->JW32.as<float>(), h->Dj, h->jw_umax.as<unsigned int>(), join_units(h), cand, rows, K, Jlo, scale, st);
+    else
+        launch_join_lb(h->JC_unw.as<float>(), h->Jp, h->Dj, h->wj.as<double>(), join_units(h), cand, rows, K, Jlo, scale, st);
+}
+
+// Passes 1..4 of joinfast_kernels.hip over `rows` candidate rows holding n_utts utterances (off: n_utts + 1
+// row offsets).  Pass 1 runs on `main` (the whole chip, in parallel over the rows); the three per-utterance
+// passes on `side` behind `knn_done` when the two streams differ.
+static int viterbi_sparse_rows(snk_engine *h, UttSlot &s, const int64_t *cand, const double *tdist, int64_t rows,
+                               const int64_t *off, int n_utts, int first_utt, int K, hipStream_t main, hipStream_t side,
+                               int64_t *path, int64_t *plen, double *cost)
+{
+    const float *JC = h->JC_unw.as<float>();
+    const double *wj = h->wj.as<double>();
+    const bool lb_side = h->join_bounds_stream == 1 && side != main;
+    if (h->join_lb_variant == 1) CHK(ensure_jw32(h, main));
+    if (lb_side) {
+        HIPCHK(hipEventRecord(s.knn_done, main));
+        HIPCHK(hipStreamWaitEvent(side, s.knn_done, 0));
+    }
+    {
+        StageTimer t(h, lb_side ? side : main, TM_JOIN_LB);
+        join_bounds_launch(h, cand, rows, K, s.Jlo.as<float>(), s.scale.as<float>(), lb_side ? side : main);
+    }
+    if (side != main && !lb_side) {
+        HIPCHK(hipEventRecord(s.knn_done, main));
+        HIPCHK(hipStreamWaitEvent(side, s.knn_done, 0));
+    }
+    {
+        StageTimer t(h, side, TM_DP_LB);
+        launch_viterbi_lb(cand, tdist, s.Jlo.as<float>(), s.scale.as<float>(), off, n_utts, K, join_units(h),
+                          (float)h->join_beta, s.sets.p, side,
+                          n_utts <= h->lb_chunk_max_utts ? (n_utts <= 4 && h->lb_chunk > 32 ? 32 : h->lb_chunk) : 0, h->lb_warm);
+    }
+    {
+        StageTimer t(h, side, TM_JOIN_SPARSE);
+        launch_join_exact_sparse(JC, h->Jp, h->Dj, wj, join_units(h), cand, tdist, rows, K, s.sets.p, s.cex.p, side);
+    }
+    {
+        StageTimer t(h, side, TM_DP_SPARSE);
+        launch_viterbi_sparse(cand, s.cex.p, s.Jlo.as<float>(), JC, h->Jp, h->Dj, wj, off, n_utts, first_utt, K,
+                              join_units(h), s.bp.as<unsigned char>(), path, plen, cost,
+                              h->vstats.as<unsigned long long>(), side);
+    }
+    return 0;
+}
+
+static int viterbi_device(snk_engine *h, UttSlot &s, int64_t T, int K, hipStream_t st)
+{
+    if (K > 208) return fail("viterbi: n_candidates=%d > 208 not supported", K);
+    if (use_sparse_viterbi(h, K, 1)) {
+        CHK(sparse_ensure(h, s, T, K));
+        const int64_t off[2] = {0, T};
+        return viterbi_sparse_rows(h, s, s.cand.as<int64_t>(), s.tdist.as<double>(), T, off, 1, 0, K, st, st,
+                                   s.path.as<int64_t>(), s.plen.as<int64_t>(), s.cost.as<double>());
+    }
+    {
+        StageTimer t(h, st, TM_JOIN);
+        launch_join_costs(h->JCw.as<double>(), h->Djpad, h->Dj, join_units(h), s.cand.as<int64_t>(), T, K,
+                          s.J.as<double>(), st);
+    }
+    {
+        StageTimer t(h, st, TM_VITERBI_DP);
+        launch_viterbi_dp(s.cand.as<int64_t>(), s.tdist.as<double>(), s.J.as<double>(), T, K, join_units(h),
+                          s.bp.as<unsigned char>(), s.path.as<int64_t>(), s.plen.as<int64_t>(),
+                          s.cost.as<double>(), st, h->viterbi_weights == 1);
+    }
+    return 0;
+}
+
+int snk_join_costs(snk_handle h, const int64_t *cand, int64_t T, int K, double *J_out)
+{
+    CHK(check_ready(h, false, true));
+    CHK(no_batch_in_flight(h, "snk_join_costs"));
+    HIPCHK(hipSetDevice(h->device));
+    if (!cand || !J_out) return fail("snk_join_costs: null argument");
+    if (T < 2) return fail("snk_join_costs: need at least 2 columns");
+    if (K < 1 || K > 208) return fail("snk_join_costs: K=%d outside 1..208", K);
+    UttSlot &s = h->slot[0];
+    CHK(slot_ensure(h, s, T, K));
+    CHK(s.J.ensure((size_t)(T - 1) * K * K * sizeof(double)));
+    CHK(h2d(h, s.cand.p, cand, (size_t)T * K * sizeof(int64_t), h->stream));
+    {
+        StageTimer t(h, h->stream, TM_JOIN);
+        launch_join_costs(h->JCw.as<double>(), h->Djpad, h->Dj, join_units(h), s.cand.as<int64_t>(), T, K,
+                          s.J.as<double>(), h->stream);
+    }
+    HIPCHK(hipGetLastError());
+    CHK(d2h_sync(h, J_out, s.J.p, (size_t)(T - 1) * K * K * sizeof(double), h->stream));
+    collect_timers(h);
+    return 0;
+}
+
+int snk_join_bounds(snk_handle h, const int64_t *cand, int64_t T, int K, float *lo_out, float *scale_out)
+{
+    CHK(check_ready(h, false, true));
+    CHK(no_batch_in_flight(h, "snk_join_bounds"));
+    HIPCHK(hipSetDevice(h->device));
+    if (!cand || !lo_out || !scale_out) return fail("snk_join_bounds: null argument");
+    if (T < 2) return fail("snk_join_bounds: need at least 2 columns");
+    if (!join_lb_supported(h->Dj, K)) return fail("snk_join_bounds: no bounds variant for %d join columns, K=%d", h->Dj, K);
+    UttSlot &s = h->slot[0];
+    CHK(slot_ensure(h, s, T, K));
+    CHK(sparse_ensure(h, s, T, K));
+    CHK(h2d(h, s.cand.p, cand, (size_t)T * K * sizeof(int64_t), h->stream));
+    if (h->join_lb_variant == 1) CHK(ensure_jw32(h, h->stream));
+    join_bounds_launch(h, s.cand.as<int64_t>(), T, K, s.Jlo.as<float>(), s.scale.as<float>(), h->stream);
+    HIPCHK(hipGetLastError());
+    D2HPart parts[2] = {{lo_out, s.Jlo.p, (size_t)(T - 1) * K * K * sizeof(float)}, {scale_out, s.scale.p, (size_t)(T - 1) * sizeof(float)}};
+    CHK(staged_d2h(h, h->stream, parts, 2));
+    collect_timers(h);
+    return 0;
+}
+
+int snk_viterbi(snk_handle h, const int64_t *cand, const double *tdist, int64_t T, int K,
+                int64_t *path_out, int64_t *path_len_out, double *cost_out)
+{
+    CHK(check_ready(h, false, true));
+    CHK(no_batch_in_flight(h, "snk_viterbi"));
+    HIPCHK(hipSetDevice(h->device));
+    if (!cand || !tdist || !path_out || !path_len_out) return fail("snk_viterbi: null argument");
+    if (T < 1 || K < 1) return fail("snk_viterbi: empty trellis");
+    UttSlot &s = h->slot[0];
+    CHK(slot_ensure(h, s, T, K));
+    CHK(h2d(h, s.cand.p, cand, (size_t)T * K * sizeof(int64_t), h->stream));
+    CHK(h2d(h, s.tdist.p, tdist, (size_t)T * K * sizeof(double), h->stream));
+    CHK(viterbi_device(h, s, T, K, h->stream));
+    HIPCHK(hipGetLastError());
+    double cost = 0;
+    {
+        D2HPart parts[3] = {{path_len_out, s.plen.p, sizeof(int64_t)}, {&cost, s.cost.p, sizeof(double)},
+                            {path_out, s.path.p, (size_t)T * sizeof(int64_t)}};
+        CHK(staged_d2h(h, h->stream, parts, 3));
+    }
+    if (cost_out) *cost_out = cost;
+    collect_timers(h);
+    return 0;
+}
+
+int snk_knn_viterbi(snk_handle h, const double *Q, int64_t T, int D, int K, int64_t *cand_out,
+                    double *dist_out, int64_t *path_out, int64_t *path_len_out, double *cost_out)
+{
+    CHK(check_ready(h, true, true));
+    CHK(no_batch_in_flight(h, "snk_knn_viterbi"));
+    HIPCHK(hipSetDevice(h->device));
+    if (!path_out || !path_len_out) return fail("snk_knn_viterbi: null output");
+    if (h->Njc != h->N + 1) return fail("snk_knn_viterbi: join_contexts rows (%lld) != N+1", (long long)h->Njc);
+    CHK(upload_queries(h, Q, T, D));
+    UttSlot &s = h->slot[0];
+    CHK(slot_ensure(h, s, T, K));
+    CHK(knn_device(h, h->Qraw.as<double>(), T, K, nullptr, s.cand.as<int64_t>(), s.tdist.as<double>(), nullptr));
+    CHK(viterbi_device(h, s, T, K, h->stream));
+    HIPCHK(hipGetLastError());
+    double cost = 0;
+    {
+        StageTimer t(h, h->stream, TM_D2H);
+        D2HPart parts[5] = {{cand_out, s.cand.p, cand_out ? (size_t)T * K * sizeof(int64_t) : 0},
+                            {dist_out, s.tdist.p, dist_out ? (size_t)T * K * sizeof(double) : 0},
+                            {path_len_out, s.plen.p, sizeof(int64_t)},
+                            {&cost, s.cost.p, sizeof(double)},
+                            {path_out, s.path.p, (size_t)T * sizeof(int64_t)}};
+        CHK(staged_d2h(h, h->stream, parts, 5));
+    }
+    if (cost_out) *cost_out = cost;
+    collect_timers(h);
+    return 0;
+}
+
+// Groups consecutive utterances into K-NN calls of about h->batch_rows rows: the search is per row,
+// so one sweep over the database serves every utterance of the group and the per-call stages
+// (sample minima, thresholds, bucket, re-rank) amortise.  first[g] .. first[g+1] are the utterances
+// of group g.
+std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offsets, int n_utts)
+{
+    std::vector<int> first(1, 0);
+    // as few groups as batch_rows allows, of equal size and an even number of them: two groups of 16 utterances take a
+    // B* step 13 % less time than 13 + 13 + 6 (11.9 against 13.7 ms; three of 11 / 11 / 10: 13.2, four of 8: 12.0,
+    // one of 32: 18.2 -- nothing of its own step to run beside)
+    const int64_t total = row_offsets[n_utts] - row_offsets[0];
+    int64_t target = h->batch_rows;
+    if (h->batch_rows > 0) {
+        int64_t n_groups = (total + h->batch_rows - 1) / h->batch_rows;
+        if (n_groups > 1 && (n_groups & 1)) ++n_groups;       // groups alternate between two workspaces and side streams
+        target = (total + n_groups - 1) / n_groups;
+    }
+    int64_t rows = 0;
+    for (int u = 0; u < n_utts; ++u) {
+        const int64_t T = row_offsets[u + 1] - row_offsets[u];
+        // close the group when adding this utterance would overshoot the even share by more than it undershoots
+        if (u > first.back() && (h->batch_rows <= 0 || rows + T > h->batch_rows || rows + T - target > target - rows)) {
+            first.push_back(u);
+            rows = 0;
+        }
+        rows += T;
+    }
+    first.push_back(n_utts);
+    return first;
+}
+
+// Join costs and recursions of the utterances [u0, u1) whose candidate rows are resident in
+// cand_all / tdist_all (batch row numbering).  The join costs of the whole group are ONE launch on
+// the main stream (its rows form one long sequence; the slab between two utterances is never read),
+// the recursions ONE launch (a workgroup per utterance) on the side stream of the group's parity,
+// where they land on the compute units the persistent K-NN sweep of the next group leaves free.
+int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u0, int u1, int K,
+                         const int64_t *cand_all, const double *tdist_all, bool side_stream,
+                         int64_t *res_path, int64_t *res_plen, double *res_cost, int n_batch_utts)
+{
+    if (!res_path) { res_path = h->res_path.as<int64_t>(); res_plen = h->res_plen.as<int64_t>(); res_cost = h->res_cost.as<double>(); }
+    const int64_t r0 = row_offsets[u0], rows = row_offsets[u1] - r0;
+    UttSlot &s = h->slot[g & 1];
+    hipStream_t dps = side_stream ? h->dp_stream[g & 1] : h->stream;
+    // workspace reuse: the join costs of this group overwrite what the last recursion queued on this
+    // workspace reads (an earlier group of this batch, or the tail of the batch submitted before)
+    const bool sparse = use_sparse_viterbi(h, K, n_batch_utts);
+    // (the sparse path with its bounds on the side stream touches the workspace on that stream only: in order)
+    if (s.vit_recorded && !(sparse && side_stream && h->join_bounds_stream == 1)) HIPCHK(hipStreamWaitEvent(h->stream, s.vit_done, 0));
+    if (sparse) {
+        CHK(sparse_ensure(h, s, rows, K));
+        std::vector<int64_t> off((size_t)(u1 - u0) + 1);
+        for (int u = u0; u <= u1; ++u) off[(size_t)(u - u0)] = row_offsets[u] - r0;
+        CHK(viterbi_sparse_rows(h, s, cand_all + r0 * K, tdist_all + r0 * K, rows, off.data(), u1 - u0, u0, K, h->stream, dps,
+                                res_path + r0, res_plen, res_cost));
+        if (side_stream) { HIPCHK(hipEventRecord(s.vit_done, dps)); s.vit_recorded = true; }
+        else s.vit_recorded = false;
+        return 0;
+    }
+    CHK(s.J.ensure((size_t)(rows > 1 ? rows - 1 : 1) * K * K * sizeof(double)));
+    CHK(s.bp.ensure((size_t)rows * K));
+    {
+        StageTimer t(h, h->stream, TM_JOIN);
+        launch_join_costs(h->JCw.as<double>(), h->Djpad, h->Dj, join_units(h), cand_all + r0 * K, rows, K,
+                          s.J.as<double>(), h->stream);
+    }
+    if (side_stream) {
+        HIPCHK(hipEventRecord(s.knn_done, h->stream));
+        HIPCHK(hipStreamWaitEvent(dps, s.knn_done, 0));
+    }
+    std::vector<int64_t> off((size_t)(u1 - u0) + 1);
+    for (int u = u0; u <= u1; ++u) off[(size_t)(u - u0)] = row_offsets[u] - r0;
+    {
+        StageTimer t(h, dps, TM_VITERBI_DP);
+        launch_viterbi_dp_batch(cand_all + r0 * K, tdist_all + r0 * K, s.J.as<double>(), off.data(), u1 - u0, u0, K,
+                                join_units(h), s.bp.as<unsigned char>(), res_path + r0, res_plen, res_cost, dps,
+                                h->viterbi_weights == 1);
+    }
+    if (side_stream) { HIPCHK(hipEventRecord(s.vit_done, dps)); s.vit_recorded = true; }
+    else s.vit_recorded = false;             // ran on the main stream: ordered with everything that follows
+    return 0;
+}
+
+// Batch pipeline.  The main stream runs the K-NN of a group of utterances and their join costs; the
+// T-step recursions run on a side stream, overlapping the K-NN of the next group.  All results stay
+// on the device until the end of the batch; a copy stream moves them to pinned host memory behind
+// the last recursions.  submit() only queues work (two batches may be in flight, each with its own
+// query / candidate / result buffers), collect() waits for one batch: a caller that submits batch
+// i+1 before collecting batch i hides the tail of batch i (its last group's recursions, the copy
+// and the host-side hand-over) behind the K-NN of batch i+1.
+int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D,
+                                 int K, int *ticket_out)
+{
+    CHK(check_ready(h, true, true));
+    if (h->sticket[0].busy || h->sticket[1].busy)
+        return fail("snk_knn_viterbi_batch_submit: a submitted sharded step is still in flight (snk_sharded_knn_viterbi_batch_collect it first)");
+    HIPCHK(hipSetDevice(h->device));
+    if (!row_offsets || n_utts < 1 || !ticket_out)
+        return fail("snk_knn_viterbi_batch_submit: null/empty argument");
+    if (D != h->Dt) return fail("query matrix has %d columns, database has %d", D, h->Dt);
+    if (h->Njc != h->N + 1) return fail("snk_knn_viterbi_batch: join_contexts rows != N+1");
+    if (K > 208) return fail("viterbi: n_candidates=%d > 208 not supported", K);
+    if (row_offsets[0] != 0) return fail("snk_knn_viterbi_batch: row_offsets[0] must be 0 (got %lld)", (long long)row_offsets[0]);
+    const int64_t total = row_offsets[n_utts];
+    for (int u = 0; u < n_utts; ++u)
+        if (row_offsets[u + 1] - row_offsets[u] < 1) return fail("snk_knn_viterbi_batch: utterance %d has no rows", u);
+    const int slot = h->bslot[h->bnext].busy ? (h->bnext ^ 1) : h->bnext;
+    BatchSlot &b = h->bslot[slot];
+    if (b.busy) return fail("snk_knn_viterbi_batch_submit: two batches are in flight already (collect one first)");
+    b.first = group_utterances(h, row_offsets, n_utts);
+    b.n_groups = (int)b.first.size() - 1;
+    b.n_utts = n_utts; b.K = K; b.D = D; b.total = total;
+    b.offs.assign(row_offsets, row_offsets + n_utts + 1);
+    { void *before = b.Qall.p; CHK(b.Qall.ensure((size_t)total * D * sizeof(double))); if (b.Qall.p != before) b.q_rows = -1; }
+    CHK(b.cand.ensure((size_t)total * K * sizeof(int64_t)));
+    CHK(b.dist.ensure((size_t)total * K * sizeof(double)));
+    CHK(b.path.ensure((size_t)total * sizeof(int64_t)));
+    CHK(b.plen.ensure((size_t)n_utts * sizeof(int64_t)));
+    CHK(b.cost.ensure((size_t)n_utts * sizeof(double)));
+    CHK(b.status.ensure((size_t)2 * b.n_groups * sizeof(int)));          // per group: K-NN status word | tile pairs the ball pass listed
+    const size_t sz_path = ((size_t)total * sizeof(int64_t) + 63) & ~(size_t)63;
+    const size_t sz_u = ((size_t)n_utts * 8 + 63) & ~(size_t)63, sz_st = ((size_t)2 * b.n_groups * sizeof(int) + 63) & ~(size_t)63;
+    CHK(b.stage.ensure(sz_path + 2 * sz_u + sz_st));
+    if (Q) {
+        StageTimer t(h, h->stream, TM_H2D);
+        CHK(h2d_via(b.qstage, b.Qall.p, Q, (size_t)total * D * sizeof(double), h->stream));
+        if (!h->tsel.empty()) launch_mask_columns(b.Qall.as<double>(), total, D, h->tmask.as<double>(), h->stream);
+        b.q_rows = total; b.q_D = D;
+        b.q_offs.assign(row_offsets, row_offsets + n_utts + 1);
+    } else if (b.q_rows != total || b.q_D != D || b.q_offs.size() != (size_t)n_utts + 1 ||
+               !std::equal(b.q_offs.begin(), b.q_offs.end(), row_offsets)) {
+        return fail("snk_knn_viterbi_batch_submit: no query matrix given and this workspace holds no rows of that shape "
+                    "(the first submit on each of the two workspaces must carry Q)");
+    }
+    for (int g = 0; g < b.n_groups; ++g) {
+        const int64_t r0 = row_offsets[b.first[g]], rows = row_offsets[b.first[g + 1]] - r0;
+        CHK(knn_device(h, b.Qall.as<double>() + r0 * D, rows, K, nullptr, b.cand.as<int64_t>() + r0 * K,
+                       b.dist.as<double>() + r0 * K, nullptr, b.status.as<int>() + g, nullptr, nullptr, false, false,
+                       reinterpret_cast<unsigned int *>(b.status.as<int>() + b.n_groups + g)));
+        b.ball_limit = h->ball_pass_ran ? h->ball_limit : -1.0;
+        b.coarse_limit = h->coarse_pass_ran ? h->coarse_limit : -1.0;
+        CHK(viterbi_group(h, g, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
+                          b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), n_utts));
+    }
+    // results -> pinned memory, behind the K-NN status words (main stream) and the last recursions
+    HIPCHK(hipEventRecord(h->knn_all_done, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->knn_all_done, 0));
+    for (int i = 0; i < 2; ++i)
+        if (h->slot[i].vit_recorded) HIPCHK(hipStreamWaitEvent(h->copy_stream, h->slot[i].vit_done, 0));
+    {
+        StageTimer t(h, h->copy_stream, TM_D2H);
+        char *st = (char *)b.stage.p;
+        HIPCHK(hipMemcpyAsync(st, b.path.p, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path, b.plen.p, (size_t)n_utts * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path + sz_u, b.cost.p, (size_t)n_utts * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u, b.status.p, (size_t)2 * b.n_groups * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
+    }
+    HIPCHK(hipEventRecord(b.done, h->copy_stream));
+    HIPCHK(hipGetLastError());
+    b.busy = true;
+    h->bnext = slot ^ 1;
+    *ticket_out = slot;
+    return 0;
+}
+
+int snk_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, int64_t *path_len_out, double *cost_out)
+{
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (ticket < 0 || ticket > 1 || !h->bslot[ticket].busy) return fail("snk_knn_viterbi_batch_collect: no batch behind ticket %d", ticket);
+    if (!path_out || !path_len_out || !cost_out) return fail("snk_knn_viterbi_batch_collect: null output");
+    BatchSlot &b = h->bslot[ticket];
+    const size_t sz_path = ((size_t)b.total * sizeof(int64_t) + 63) & ~(size_t)63;
+    const size_t sz_u = ((size_t)b.n_utts * 8 + 63) & ~(size_t)63;
+    HIPCHK(hipEventSynchronize(b.done));          // this batch only: the one submitted after it may still run
+    HIPCHK(hipGetLastError());
+    b.busy = false;
+    char *st = (char *)b.stage.p;
+    // deferred K-NN status words: redo the (rare) group whose sampled thresholds overflowed a list
+    const int *status = reinterpret_cast<const int *>(st + sz_path + 2 * sz_u);
+    if (b.ball_limit >= 0.0 && !h->filter_coarse)
+        for (int g = 0; g < b.n_groups; ++g)
+            if ((double)(unsigned int)status[b.n_groups + g] > b.ball_limit) { h->filter_coarse = true; h->ball_switches += 1; break; }
+    if (b.coarse_limit >= 0.0 && !h->filter_onepass)
+        for (int g = 0; g < b.n_groups; ++g)
+            if ((double)(unsigned int)status[b.n_groups + g] > b.coarse_limit) { h->filter_onepass = true; h->onepass_switches += 1; break; }
+    bool redone = false;
+    for (int g = 0; g < b.n_groups; ++g) {
+        if (status[g] == 0) continue;
+        if (status[g] & 2) h->tie_overflow = 1;
+        const int64_t r0 = b.offs[b.first[g]], rows = b.offs[b.first[g + 1]] - r0;
+        const int saved = h->precision;
+        h->precision = 0;
+        const int rc = knn_device(h, b.Qall.as<double>() + r0 * b.D, rows, b.K, nullptr,
+                                  b.cand.as<int64_t>() + r0 * b.K, b.dist.as<double>() + r0 * b.K, nullptr);
+        h->precision = saved;
+        if (rc) return rc;
+        CHK(viterbi_group(h, g, b.offs.data(), b.first[g], b.first[g + 1], b.K, b.cand.as<int64_t>(), b.dist.as<double>(), false,
+                          b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), b.n_utts));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->batch_redos += 1;
+        redone = true;
+    }
+    if (redone) {
+        HIPCHK(hipMemcpyAsync(st, b.path.p, (size_t)b.total * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path, b.plen.p, (size_t)b.n_utts * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path + sz_u, b.cost.p, (size_t)b.n_utts * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    memcpy(path_out, st, (size_t)b.total * sizeof(int64_t));
+    memcpy(path_len_out, st + sz_path, (size_t)b.n_utts * sizeof(int64_t));
+    memcpy(cost_out, st + sz_path + sz_u, (size_t)b.n_utts * sizeof(double));
+    collect_timers(h);
+    return 0;
+}
+
+int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D,
+                          int K, int64_t *path_out, int64_t *path_len_out, double *cost_out)
+{
+    if (!path_out || !path_len_out || !cost_out) return fail("snk_knn_viterbi_batch: null/empty argument");
+    if (h && (h->bslot[0].busy || h->bslot[1].busy))
+        return fail("snk_knn_viterbi_batch: a submitted batch is still in flight (collect it first)");
+    int ticket = -1;
+    CHK(snk_knn_viterbi_batch_submit(h, Q, row_offsets, n_utts, D, K, &ticket));
+    return snk_knn_viterbi_batch_collect(h, ticket, path_out, path_len_out, cost_out);
+}
+
+// Viterbi of a batch of utterances whose candidates the caller already has (label-driven preselection:
+// preselect_units_quinphone / monophone_then_acoustic, synth_halfphone.py:1315-1396): what the tail of
+// snk_knn_viterbi_batch does -- join bounds, sparse exact recursion per group on the side streams -- without the K-NN.
+int snk_viterbi_batch(snk_handle h, const int64_t *cand, const double *tdist, const int64_t *row_offsets, int n_utts, int K,
+                      int64_t *path_out, int64_t *path_len_out, double *cost_out)
+{
+    CHK(check_ready(h, false, true));
+    CHK(no_batch_in_flight(h, "snk_viterbi_batch"));
+    HIPCHK(hipSetDevice(h->device));
+    if (!cand || !tdist || !row_offsets || n_utts < 1 || !path_out || !path_len_out || !cost_out)
+        return fail("snk_viterbi_batch: null/empty argument");
+    if (K < 1 || K > 208) return fail("viterbi: n_candidates=%d outside 1..208", K);
+    if (h->Njc != h->N + 1 && h->N > 0) return fail("snk_viterbi_batch: join_contexts rows != N+1");
+    const int64_t total = row_offsets[n_utts];
+    for (int u = 0; u < n_utts; ++u)
+        if (row_offsets[u + 1] - row_offsets[u] < 1) return fail("snk_viterbi_batch: utterance %d has no rows", u);
+    CHK(h->mcand.ensure((size_t)total * K * sizeof(int64_t)));
+    CHK(h->mdist.ensure((size_t)total * K * sizeof(double)));
+    CHK(h->res_path.ensure((size_t)total * sizeof(int64_t)));
+    CHK(h->res_plen.ensure((size_t)n_utts * sizeof(int64_t)));
+    CHK(h->res_cost.ensure((size_t)n_utts * sizeof(double)));
+    {
+        StageTimer t(h, h->stream, TM_H2D);
+        CHK(h2d(h, h->mcand.p, cand, (size_t)total * K * sizeof(int64_t), h->stream));
+        CHK(h2d(h, h->mdist.p, tdist, (size_t)total * K * sizeof(double), h->stream));
+    }
+    {
+        const std::vector<int> first = group_utterances(h, row_offsets, n_utts);
+        for (int g = 0; g + 1 < (int)first.size(); ++g)
+            CHK(viterbi_group(h, g, row_offsets, first[g], first[g + 1], K, h->mcand.as<int64_t>(), h->mdist.as<double>(), true,
+                              nullptr, nullptr, nullptr, n_utts));
+    }
+    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamSynchronize(h->dp_stream[i]));
+    HIPCHK(hipGetLastError());
+    {
+        StageTimer t(h, h->stream, TM_D2H);
+        D2HPart parts[3] = {{path_out, h->res_path.p, (size_t)total * sizeof(int64_t)},
+                            {path_len_out, h->res_plen.p, (size_t)n_utts * sizeof(int64_t)},
+                            {cost_out, h->res_cost.p, (size_t)n_utts * sizeof(double)}};
+        CHK(staged_d2h(h, h->stream, parts, 3));
+    }
+    collect_timers(h);
+    return 0;
+}

@@ -1291,7 +1291,7 @@ static int coarse_wps()
 //        key~(c) <= (tq + r)^2 - nq,     tq = sqrt(D2max(q)) rounded up,  nq = ||q||^2 - eps rounded down
 // lists the (tile, query tile) pairs for knn_refine16b directly.  Either list is a superset of what the three-term test
 // passes, so which pass writes it is a matter of speed only: the engine switches a voice to the coarse sweep once the
-// ball pass has listed more than coarse_gate_fraction of all pairs (tiles that are not compact; snk_api.hip knn_device).
+// ball pass has listed more than coarse_gate_fraction of all pairs (tiles that are not compact; api_knn.hip knn_device).
 // ===========================================================================================================
 __global__ void __launch_bounds__(256)
 build_tile_balls_kernel(const double *__restrict__ Fw, int64_t N, int Dt, int Dpad, int64_t n_tiles, double *__restrict__ C,

@@ -683,7 +683,7 @@ void launch_mask_columns(double *Q, int64_t T, int D, const double *mask, hipStr
     if (n > 0) hipLaunchKernelGGL(mask_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Q, n, D, mask);
 }
 
-// rows wider than the sweeps take (Dpad > 256, see snk_api.hip knn_device): only the zero-padded row-major copy that
+// rows wider than the sweeps take (Dpad > 256, see api_knn.hip knn_device): only the zero-padded row-major copy that
 // the canonical-distance kernels read, and the squared norm
 __global__ void prepare_queries_wide_kernel(const double *__restrict__ Q, int64_t T, int D, double *__restrict__ Qp,
                                             double *__restrict__ qnorm, int Dpad)

@@ -341,7 +341,7 @@ class Synthesiser(object):
         Returns (indices (n, k) int64, distances (n, k) float64)."""
         if self.join_contexts_unweighted.shape[1] > 512:
             # up to 256 columns the matrix sweeps serve the search; the doubled [j_t, j_t+1] join rows of an epoch voice
-            # from train_halfphone (2 x 151 columns) go through the engine's canonical-distance selection (snk_api.hip
+            # from train_halfphone (2 x 151 columns) go through the engine's canonical-distance selection (api_knn.hip
             # knn_device: a workgroup per query row) -- exact, slower; beyond 512 columns the engine refuses
             raise ValueError('join_knn: join vectors of %d columns exceed the 512 columns the K-NN engine supports'
                              % self.join_contexts_unweighted.shape[1])

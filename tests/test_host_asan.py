@@ -1,4 +1,4 @@
-"""The library's host orchestration (snk_api.hip: 3 400 lines of argument checks, grouping, in-flight state machines, staging
+"""The library's host orchestration (the api_*.hip translation units: 3 700 lines of argument checks, grouping, in-flight state machines, staging
 ring, shard plans) under AddressSanitizer + UndefinedBehaviorSanitizer, in the CPU container: `make asan-host` compiles the
 library's own translation units for the host only and links them against tools/fakehip (no device; allocation bookkeeping),
 tests/host_asan_driver.py drives every entry point's orderings and refusals.  Any sanitizer report fails the test."""

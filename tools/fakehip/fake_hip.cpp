@@ -1,6 +1,6 @@
 // A stand-in for libamdhip64 with NO device behind it: allocation bookkeeping only.  `make asan-host` links the library's
 // own translation units, compiled for the host with -fsanitize=address,undefined, against this file, so that the 3 400 lines
-// of host orchestration in snk_api.hip (argument checks, utterance grouping, the two-batches-in-flight state machine, the
+// of host orchestration in api_*.hip (argument checks, utterance grouping, the two-batches-in-flight state machine, the
 // staging ring, shard plans, the fail() paths in front of a collective) run in the CPU container where sanitizers exist
 // (tests/test_host_asan.py).  "Device" memory is zero-filled host memory with the sanitizer's red zones around it, copies
 // are memcpy, kernels are never run (a launch is a no-op: every device result reads as zero), streams and events complete
