@@ -262,6 +262,7 @@ int snk_destroy(snk_handle h)
         if (s.vit_done) (void)hipEventDestroy(s.vit_done);
     }
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 4; ++i) { if (h->vit_t0[i]) (void)hipEventDestroy(h->vit_t0[i]); if (h->vit_t1[i]) (void)hipEventDestroy(h->vit_t1[i]); }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->knn_all_done) (void)hipEventDestroy(h->knn_all_done);
     for (auto &t : h->sticket) {
@@ -430,6 +431,8 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
     // float32 operands of the prefilter (knn16_kernels.hip): ||f||^2 rides in ONE spare padding column
     h->f16_ready = false;
     h->cls16_ready = false;
+    h->knn_level = 0;
+    h->vit = snk_engine::VitLatch();                         // a new set of weights: the Viterbi latch starts over
     if (h->have_db && h->Dpad <= 256 && h->Dpad - h->Dt >= 1) {
         // tiles per wavefront: the database fragments of a slab stay in registers (32 * Dpad / 64
         // floats per tile and lane), so wider rows leave room for fewer tiles
@@ -484,6 +487,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
                 // operand (its dropped-piece ratios join the database's: one key bound serves both)
                 h->ball_tiles = 0;
                 h->filter_coarse = false; h->filter_onepass = false;
+                h->filter_calls = 0; h->probe_next = 16; h->probe_period = 16; h->probe_ran = 0;
                 if (h->prefilter_balls) {
                     const int64_t vt = (h->N + 31) / 32, ct = (vt + 31) / 32;
                     CHK(h->ball_c.ensure((size_t)vt * h->Dpad * sizeof(double)));

@@ -147,12 +147,15 @@ static int greedy32_group(snk_engine *h, int nu, const int64_t *q_off, const int
                     h->g32_blk.p, h->n_cus, gen,
                     status, h->gpath.as<int64_t>(), hoist ? &hst : nullptr, h->stream);
     HIPCHK(hipGetLastError());
-    int64_t stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};         // undecided step + 1 | second-phase rounds | windows decided by exact totals | watchdog | (resident scan: why)
+    int64_t stv[16] = {0};         // undecided step + 1 | second-phase rounds | windows decided by exact totals | watchdog | [4..7] per kernel | [8], [9] the bound's tripwire
     CHK(d2h_sync(h, stv, status, sizeof(stv), h->stream));
     greedy32_trace_dump();
     greedy_res_trace_dump();
     *undecided = stv[0] != 0;
-    for (int i = 0; i < 8; ++i) h->greedy_last_status[i] = stv[i];
+    for (int i = 0; i < 16; ++i) h->greedy_last_status[i] = stv[i];
+    h->greedy_last_kernel = resident ? 2 : 1;
+    h->greedy_bound_violations += stv[8];
+    { float uf; const unsigned int ub = (unsigned int)(unsigned long long)stv[9]; memcpy(&uf, &ub, 4); if ((double)uf > h->greedy_bound_max_used) h->greedy_bound_max_used = (double)uf; }
     h->greedy_second_rounds += stv[1];
     h->greedy_exact_windows += stv[2];
     h->greedy_stalls += stv[3];

@@ -40,10 +40,29 @@ static int debug_check_pool(snk_engine *h, int max_chunks, int64_t Tpad, int64_t
 
 // what the ball pass of a call listed, seen at the call's next host synchronisation: beyond the limit this voice's
 // filter goes back to the coarse sweep (until the weights change)
+void judge_filter(snk_engine *h, bool ran_balls, double ball_limit, bool ran_coarse, double coarse_limit, unsigned int listed,
+                  int probe_kind, double probe_limit, unsigned int probe_listed)
+{
+    auto left = [&]() { h->probe_period = 16; h->probe_next = h->filter_calls + 16; };
+    if (ran_balls && !h->filter_coarse && (double)listed > ball_limit) { h->filter_coarse = true; h->ball_switches += 1; left(); }
+    if (ran_coarse && !h->filter_onepass && (double)listed > coarse_limit) { h->filter_onepass = true; h->onepass_switches += 1; left(); }
+    // the counting probe of the pass the voice left (snk_engine.h: latch_rearm)
+    const bool applies = (probe_kind == 1 && h->filter_coarse && !h->filter_onepass) || (probe_kind == 2 && h->filter_onepass);
+    if (!applies) return;
+    if ((double)probe_listed <= probe_limit) {
+        if (probe_kind == 1) h->filter_coarse = false; else h->filter_onepass = false;
+        h->filter_rearms += 1;
+        left();
+    } else {
+        h->probe_period = h->probe_period < 128 ? 2 * h->probe_period : 256;
+        h->probe_next = h->filter_calls + h->probe_period;
+    }
+}
+
+// sync paths that read the first control word only: what the most recent call listed
 void note_ball_pairs(snk_engine *h, unsigned int listed)
 {
-    if (h->ball_pass_ran && !h->filter_coarse && (double)listed > h->ball_limit) { h->filter_coarse = true; h->ball_switches += 1; }
-    if (h->coarse_pass_ran && !h->filter_onepass && (double)listed > h->coarse_limit) { h->filter_onepass = true; h->onepass_switches += 1; }
+    judge_filter(h, h->ball_pass_ran, h->ball_limit, h->coarse_pass_ran, h->coarse_limit, listed, 0, 0.0, 0u);
 }
 
 KnnPlan make_plan(snk_engine *h, int K)
@@ -91,7 +110,7 @@ KnnPlan make_plan(snk_engine *h, int K)
 int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_t *qclass_dev,
                int64_t *cand_dev, double *dist_dev, double *d2_dev, int *deferred_status,
                const double *bound_in, double *bound_out, bool gs, bool refine,
-               unsigned int *pairs_listed_dev)     // with deferred_status: receives the tile pairs the ball pass listed
+               unsigned int *pairs_listed_dev, unsigned int *probe_listed_dev)
 {
     if (K < 1 || K > 208) return fail("K-NN: n_candidates=%d outside the supported range 1..208", K);
     if (T > SNK_KNN_MAX_ROWS) {
@@ -223,6 +242,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
     // longer lists and a bigger pool share than the defaults sized for K <= 128
     // (40 K: the bf16-split prefilter's wider key margin lengthens the lists by a fifth)
     if (cap < 40 * K) cap = 40 * K < 8192 ? 40 * K : 8192;
+    if (h->knn_level >= 1 && cap < 8192) cap = 8192;          // this voice's lists overflowed before (snk_engine.h: knn_level)
     if (K > 4096) return fail("K-NN: K too large");
     KnnPlan p = p0;
     int64_t G = p.a_count * 16;
@@ -283,13 +303,32 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
             cls_full = h->cls16_full.as<int32_t>();
             cls_samp = h->cls16_samp.as<int32_t>();
         }
-        const bool bf = h->bf16_ready && h->prefilter >= 1 && !cls && nt_run == h->nt16_eff;
+        const bool bf = h->bf16_ready && h->prefilter >= 1 && !cls && nt_run == h->nt16_eff && h->knn_level < 2;
         const double eps_c_run = bf ? h->eps_c_bf : h->eps_c;
         // two-pass filter (knn16_kernels.hip): not for stage-A-only calls
-        const bool coarse = bf && h->prefilter_two_pass && !bound_out && knn_coarse16b_supported(nt_run, dch16) && !h->filter_onepass;
+        const bool twopass_ok = bf && h->prefilter_two_pass && !bound_out && knn_coarse16b_supported(nt_run, dch16);
+        const bool coarse = twopass_ok && !h->filter_onepass;
         const int64_t n_tiles_b = n_slabs_b * nt_run;
         unsigned int pair_cap = 0;
         if (!coarse) { h->ball_pass_ran = false; h->coarse_pass_ran = false; }      // (nothing listed by this call: nothing to judge the voice by)
+        // a voice on a slower filter: now and then the pass it left runs beside it as a probe that only counts (snk_engine.h)
+        int probe = 0;
+        h->probe_ran = 0;
+        if (twopass_ok && h->latch_rearm && h->prefilter_balls && (h->filter_coarse || h->filter_onepass)) {
+            h->filter_calls += 1;
+            if (h->filter_calls >= h->probe_next) {
+                probe = h->filter_onepass ? 2 : 1;
+                if (probe == 1 && !(h->ball_tiles > 0 && nt_run == h->nt16_eff)) probe = 0;
+                h->probe_next = h->filter_calls + h->probe_period;        // (until this probe is judged)
+            }
+        }
+        if (probe && !coarse) {
+            CHK(h->cpairs.ensure(64));
+            CHK(h->cpairctl.ensure(4 * sizeof(unsigned int)));
+            HIPCHK(hipMemsetAsync(h->cpairctl.p, 0, 4 * sizeof(unsigned int), s));
+            if (probe == 2) { CHK(h->e1_16.ensure((size_t)Tpad * sizeof(double))); CHK(h->thr1_32.ensure((size_t)Tpad * sizeof(float))); }
+        }
+        const bool want_thr1 = coarse || probe == 2;
         if (coarse) {
             const int64_t all = (Tpad / 32) * n_tiles_b;
             int64_t capp = all / 4 > ((int64_t)4 << 20) ? all / 4 : ((int64_t)4 << 20);
@@ -317,7 +356,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
                 launch_prepare_queries16b(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad,
                                           use_gs ? h->gs_fmax2.as<double>() : h->fmax2.as<double>(),
                                           use_gs ? h->gs_rho16.as<double>() : h->rho16.as<double>(), eps_c_run, h->b16l.p,
-                                          h->eps16.as<double>(), h->cq16.as<double>(), s, c_coarse, coarse ? h->e1_16.as<double>() : nullptr);
+                                          h->eps16.as<double>(), h->cq16.as<double>(), s, c_coarse, want_thr1 ? h->e1_16.as<double>() : nullptr);
             else
             launch_prepare_queries16(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad,
                                      use_gs ? h->gs_fmax2.as<double>() : h->fmax2.as<double>(), h->eps_c, h->b16h.p,
@@ -354,8 +393,8 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
         {
             StageTimer t(h, s, TM_KNN_THRESHOLD);
             launch_knn_threshold16(h->gmin32.as<float>(), G16, T, Tpad, K, h->eps16.as<double>(), h->thr.as<double>(),
-                                   h->thr32.as<float>(), bound_in, bound_out, s, coarse ? h->e1_16.as<double>() : nullptr,
-                                   coarse ? h->thr1_32.as<float>() : nullptr, ball_bound ? h->ball_bound.as<double>() : nullptr);
+                                   h->thr32.as<float>(), bound_in, bound_out, s, want_thr1 ? h->e1_16.as<double>() : nullptr,
+                                   want_thr1 ? h->thr1_32.as<float>() : nullptr, ball_bound ? h->ball_bound.as<double>() : nullptr);
         }
         if (bound_out) return 0;             // stage A only
         {
@@ -404,6 +443,38 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
                                h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
                                knn_pool_chunk_entries(), s);
         }
+        if (probe == 1) {
+            // the ball pass as a counting probe: pair_cap 0, its count in word 2 of the control block
+            CHK(h->ball_tq.ensure((size_t)Tpad * sizeof(float)));
+            CHK(h->ball_nq.ensure((size_t)Tpad * sizeof(float)));
+            launch_ball_query_terms(h->thr32.as<float>(), h->eps16.as<double>(), h->qnorm.as<double>(), T, Tpad, h->ball_tq.as<float>(),
+                                    h->ball_nq.as<float>(), s);
+            const unsigned int *visit = nullptr;
+            if (h->prefilter_super_balls && h->ball_supers > 0) {
+                const size_t words = (size_t)h->ball_supers * ((Tpad / 32 + 31) / 32);
+                CHK(h->ball_mask.ensure(words * sizeof(unsigned int)));
+                HIPCHK(hipMemsetAsync(h->ball_mask.p, 0, words * sizeof(unsigned int), s));
+                launch_knn_balls16b(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->ball_s16.p, h->b16l.p, h->ball_rad2.as<float>(),
+                                    h->ball_tq.as<float>(), h->ball_nq.as<float>(), Tpad, h->ball_supers, nullptr, nullptr, 0u, s,
+                                    h->ball_mask.as<unsigned int>(), nullptr);
+                visit = h->ball_mask.as<unsigned int>();
+            }
+            launch_knn_balls16b(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->ball_c16.p, h->b16l.p, h->ball_rad.as<float>(),
+                                h->ball_tq.as<float>(), h->ball_nq.as<float>(), Tpad, h->ball_tiles, h->cpairs.p,
+                                h->cpairctl.as<unsigned int>() + 2, 0u, s, nullptr, visit);
+            h->probe_limit = 0.5 * h->coarse_gate_fraction * (double)(Tpad / 32) * (double)h->ball_tiles;
+        } else if (probe == 2) {
+            // the coarse sweep as a counting probe (its own slab dispenser: word 2)
+            HIPCHK(hipMemsetAsync(h->slabctr.as<unsigned int>() + 2, 0, sizeof(unsigned int), s));
+            launch_knn_filter16c(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, h->thr32.as<float>(), h->thr1_32.as<float>(),
+                                 Tpad, n_tiles_b, h->slabctr.as<unsigned int>() + 2, h->cpairs.p, h->cpairctl.as<unsigned int>() + 2, 0u,
+                                 nullptr, nullptr, nullptr, 0, knn_pool_chunk_entries(), s, true, false);
+            const double all = (double)(Tpad / 32) * (double)n_tiles_b;
+            int64_t capp = (int64_t)all / 4 > ((int64_t)4 << 20) ? (int64_t)all / 4 : ((int64_t)4 << 20);
+            if ((double)capp > all) capp = (int64_t)all;
+            h->probe_limit = 0.5 * (h->onepass_gate_fraction * all < 0.9 * (double)capp ? h->onepass_gate_fraction * all : 0.9 * (double)capp);
+        }
+        h->probe_ran = probe;
         if (trace_on()) CHK(debug_check_pool(h, max_chunks, Tpad, n_slabs_b * 32 * nt_run, s));
         {
             StageTimer t(h, s, TM_KNN_BUCKET);
@@ -424,7 +495,8 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
                                 h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap,
                                 h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), eps_c_run, bf ? h->cq16.as<double>() : nullptr, cand_dev, dist_dev, d2_dev, status_dev, nullptr, s,
                                 bound_in != nullptr,         // a shard's lists under the shared bound are short
-                                bound_in ? nullptr : h->thr.as<double>(), h->margin_stat.as<unsigned int>(), h->rowflag.as<int>());
+                                bound_in ? nullptr : h->thr.as<double>(), h->margin_stat.as<unsigned int>(), h->rowflag.as<int>(),
+                                h->knn_level >= 1);
         }
         if (deferred_status) {               // the batch caller redoes failures with precision 0
             // (and learns how many tile pairs the ball pass listed)
@@ -432,18 +504,29 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
                 if (coarse) HIPCHK(hipMemcpyAsync(pairs_listed_dev, h->cpairctl.p, sizeof(unsigned int), hipMemcpyDeviceToDevice, s));
                 else HIPCHK(hipMemsetAsync(pairs_listed_dev, 0, sizeof(unsigned int), s));
             }
+            if (probe_listed_dev) {
+                if (probe) HIPCHK(hipMemcpyAsync(probe_listed_dev, h->cpairctl.as<unsigned int>() + 2, sizeof(unsigned int), hipMemcpyDeviceToDevice, s));
+                else HIPCHK(hipMemsetAsync(probe_listed_dev, 0xff, sizeof(unsigned int), s));
+            }
             return 0;
         }
         int status = 0;
         {
-            unsigned int listed = 0;
-            D2HPart parts[2] = {{&status, h->status.p, sizeof(int)}, {&listed, h->cpairctl.p, coarse ? sizeof(unsigned int) : 0}};
+            unsigned int ctl[4] = {0u, 0u, 0u, 0u};
+            D2HPart parts[2] = {{&status, h->status.p, sizeof(int)}, {ctl, h->cpairctl.p, (coarse || probe) ? sizeof(ctl) : 0}};
             CHK(staged_d2h(h, s, parts, 2));
-            note_ball_pairs(h, listed);
+            judge_filter(h, h->ball_pass_ran, h->ball_limit, h->coarse_pass_ran, h->coarse_limit, ctl[0], probe, h->probe_limit, ctl[2]);
         }
         HIPCHK(hipGetLastError());
         h->last_f16_status = status;
         if (status == 0) return 0;
+        if ((status & ~3) == 0 && h->knn_level < 2 && !refine) {
+            // a candidate list overflowed, or a row held more near ties than the exact re-rank takes, and nothing else went wrong:
+            // the next rung of the voice's ladder (longer lists + a re-rank tier for 8 192 ties, then the float32 operands) serves
+            // this call and every later one
+            h->knn_level += 1; h->knn_escalations += 1;
+            return knn_device(h, Qdev, T, K, qclass_dev, cand_dev, dist_dev, d2_dev, nullptr, bound_in, nullptr, gs, false, nullptr, nullptr);
+        }
         h->f16_fallbacks += 1;               // overflow or too many near ties: exact f64 sweep below
     }
 

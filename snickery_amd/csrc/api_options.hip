@@ -89,11 +89,17 @@ int snk_reset_timers(snk_handle h)
 {
     if (!h) return fail("null handle");
     for (int i = 0; i < TM_COUNT; ++i) { h->tm_ms[i] = 0; h->tm_n[i] = 0; }
+    h->greedy_bound_violations = 0; h->greedy_bound_max_used = 0.0;
     if (h->margin_stat.p && !h->bslot[0].busy && !h->bslot[1].busy && !h->sticket[0].busy && !h->sticket[1].busy) {
         const unsigned int init[2] = {0u, 0x7f800000u};
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipStreamSynchronize(h->stream));
         CHK(h2d_sync(h, h->margin_stat.p, init, sizeof(init)));
+        if (h->vstats.p) {                                     // ... and the tripwire of the join bounds (joinfast_kernels.hip: stats[4], [5])
+            for (int i = 0; i < 2; ++i) HIPCHK(hipStreamSynchronize(h->dp_stream[i]));
+            const unsigned long long init2[2] = {0ull, 0xffffffffull};
+            CHK(h2d_sync(h, reinterpret_cast<char *>(h->vstats.p) + 4 * sizeof(unsigned long long), init2, sizeof(init2)));
+        }
     }
     return 0;
 }
@@ -177,6 +183,14 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0 && value != 2.0) return fail("viterbi_mode must be 0 (dense exact join + recursion), 1 (lower bounds + sparse exact recursion) or 2 (auto)");
         CHK(no_batch_in_flight(h, "snk_set_option(viterbi_mode)"));
         h->viterbi_mode = (int)value;
+    } else if (!strcmp(name, "viterbi_latch") || !strcmp(name, "latch_rearm")) {
+        if (value != 0.0 && value != 1.0) return fail("%s must be 0 or 1", name);
+        CHK(no_batch_in_flight(h, "snk_set_option(latch)"));
+        if (name[0] == 'v') { h->viterbi_latch = (int)value; h->vit = snk_engine::VitLatch(); }
+        else h->latch_rearm = (int)value;
+    } else if (!strcmp(name, "viterbi_refine_gate")) {
+        if (!(value >= 0.0 && value <= 1.0)) return fail("viterbi_refine_gate must be in 0..1");
+        h->vit_refine_gate = value;
     } else if (!strcmp(name, "viterbi_lb_chunk") || !strcmp(name, "viterbi_lb_warm") || !strcmp(name, "viterbi_lb_chunk_max_utts")) {
         if (!(value >= 0.0 && value <= 1e6) || value != (double)(int)value) return fail("%s must be a small non-negative integer", name);
         if (!strcmp(name, "viterbi_lb_warm") && value < 1.0) return fail("viterbi_lb_warm must be >= 1");
@@ -211,6 +225,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "join_lb_variant")) {
         if (value != 0.0 && value != 1.0) return fail("join_lb_variant must be 0 or 1");
         h->join_lb_variant = (int)value;
+    } else if (!strcmp(name, "join_lb_test_scale")) {
+        if (!(value >= 0.0 && value <= 100.0)) return fail("join_lb_test_scale must be in 0..100");
+        h->join_lb_test_scale = value;
     } else if (!strcmp(name, "join_beta")) {
         if (!(value >= 0.0 && value <= 10.0)) return fail("join_beta must be in 0..10");
         h->join_beta = value;
@@ -248,12 +265,17 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "greedy_hoist16_launches")) *out = (double)h->greedy_hoist16_launches;
     else if (!strcmp(name, "greedy_last_undecided_step")) *out = (double)h->greedy_last_status[0] - 1.0;     // -1: every step was decided
     else if (!strcmp(name, "greedy_last_watchdog")) *out = (double)h->greedy_last_status[3];
-    else if (!strcmp(name, "greedy_last_speculated")) *out = (double)h->greedy_last_status[4];         // streamed scan: steps decided before the gather
-    else if (!strcmp(name, "greedy_last_several_holders")) *out = (double)h->greedy_last_status[5];   // streamed scan: steps with windows inside the bound in several workgroups
-    else if (!strcmp(name, "greedy_last_why_candidates")) *out = (double)h->greedy_last_status[4];
-    else if (!strcmp(name, "greedy_last_why_third")) *out = (double)h->greedy_last_status[5];
-    else if (!strcmp(name, "greedy_last_why_min")) { double v; memcpy(&v, &h->greedy_last_status[6], 8); *out = v; }
-    else if (!strcmp(name, "greedy_last_why_tau")) { double v; memcpy(&v, &h->greedy_last_status[7], 8); *out = v; }
+    // (words 4 .. 7 belong to the kernel that served the last launch: the streamed scan's counters read 0 after a resident launch,
+    // the resident scan's `why` words 0 / NaN after a streamed one)
+    else if (!strcmp(name, "greedy_last_kernel")) *out = h->greedy_last_kernel;                       // 1 streamed scan, 2 resident scan, 0 none yet
+    else if (!strcmp(name, "greedy_last_speculated")) *out = h->greedy_last_kernel == 1 ? (double)h->greedy_last_status[4] : 0.0;         // streamed scan: steps decided before the gather
+    else if (!strcmp(name, "greedy_last_several_holders")) *out = h->greedy_last_kernel == 1 ? (double)h->greedy_last_status[5] : 0.0;   // streamed scan: steps with windows inside the bound in several workgroups
+    else if (!strcmp(name, "greedy_last_why_candidates")) *out = h->greedy_last_kernel == 2 ? (double)h->greedy_last_status[4] : 0.0;
+    else if (!strcmp(name, "greedy_last_why_third")) *out = h->greedy_last_kernel == 2 ? (double)h->greedy_last_status[5] : 0.0;
+    else if (!strcmp(name, "greedy_last_why_min")) { double v; memcpy(&v, &h->greedy_last_status[6], 8); *out = h->greedy_last_kernel == 2 ? v : (double)NAN; }
+    else if (!strcmp(name, "greedy_last_why_tau")) { double v; memcpy(&v, &h->greedy_last_status[7], 8); *out = h->greedy_last_kernel == 2 ? v : (double)NAN; }
+    else if (!strcmp(name, "greedy_bound_violations")) *out = (double)h->greedy_bound_violations;     // tripwire of the float32 scans' bound (snk_engine.h)
+    else if (!strcmp(name, "greedy_bound_max_used")) *out = h->greedy_bound_max_used;
     else if (!strcmp(name, "greedy_resident")) *out = h->greedy_resident;
     else if (!strcmp(name, "greedy_resident_launches")) *out = (double)h->greedy_resident_launches;
     else if (!strcmp(name, "greedy_f16")) *out = h->greedy_f16;
@@ -275,8 +297,24 @@ int snk_get_info(snk_handle h, const char *name, double *out)
         if (h->vstats.p) { HIPCHK(hipDeviceSynchronize()); CHK(d2h_sync(h, v, h->vstats.p, sizeof(v), h->stream)); }
         *out = (double)v[!strcmp(name, "dense_steps") ? 1 : (!strcmp(name, "dense_exact_costs") ? 2 : (!strcmp(name, "set_overflows") ? 3 : 0))];
     }
+    else if (!strcmp(name, "join_bound_violations") || !strcmp(name, "join_bound_min_margin")) {
+        // tripwire of pass 1's bounds (joinfast_kernels.hip), since the engine was created or the last snk_reset_timers: exact join
+        // costs that came out BELOW their float32 bound (must be 0), and the smallest (exact^2 - lo^2) / (2 ceps scale^2) seen
+        // (+inf: no exact cost was compared yet)
+        unsigned long long v[6] = {0, 0, 0, 0, 0, 0xffffffffull};
+        if (h->vstats.p) { HIPCHK(hipSetDevice(h->device)); HIPCHK(hipDeviceSynchronize()); CHK(d2h_sync(h, v, h->vstats.p, sizeof(v), h->stream)); }
+        if (name[11] == 'v') *out = (double)v[4];
+        else {
+            const unsigned int im = (unsigned int)v[5];
+            const unsigned int bits = (im & 0x80000000u) ? (im & 0x7fffffffu) : ~im;
+            float f; memcpy(&f, &bits, 4);
+            *out = im == 0xffffffffu ? (double)INFINITY : (double)f;
+        }
+    }
     else if (!strcmp(name, "f16_ready")) *out = h->f16_ready ? 1 : 0;
     else if (!strcmp(name, "f16_fallbacks")) *out = h->f16_fallbacks;
+    else if (!strcmp(name, "knn_level")) *out = h->knn_level;                       // rung of the voice's list-overflow ladder (snk_engine.h)
+    else if (!strcmp(name, "knn_escalations")) *out = (double)h->knn_escalations;
     else if (!strcmp(name, "last_f16_status")) *out = h->last_f16_status;
     else if (!strcmp(name, "pool_chunks_used")) { unsigned int v[2] = {0, 0}; CHK(d2h_sync(h, v, h->poolctl.p, sizeof(v), h->stream)); *out = v[0] + 1e6 * v[1]; }
     else if (!strcmp(name, "precision")) *out = h->precision;
@@ -314,6 +352,16 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "filter_onepass")) *out = h->filter_onepass ? 1 : 0;     // 1: the coarse sweep listed most pairs for this voice: one-pass sweep since
     else if (!strcmp(name, "filter_coarse")) *out = h->filter_coarse ? 1 : 0;       // 1: the ball pass listed too many pairs for this voice
     else if (!strcmp(name, "ball_switches")) *out = (double)h->ball_switches;
+    else if (!strcmp(name, "onepass_switches")) *out = (double)h->onepass_switches;
+    else if (!strcmp(name, "filter_rearms")) *out = (double)h->filter_rearms;        // times a counting probe took the voice back to a faster filter
+    else if (!strcmp(name, "filter_probe_period")) *out = h->probe_period;
+    else if (!strcmp(name, "latch_rearm")) *out = h->latch_rearm;
+    else if (!strcmp(name, "viterbi_latch")) *out = h->viterbi_latch;
+    else if (!strcmp(name, "viterbi_latch_mode")) *out = h->vit.mode;                 // 0: batches take the sparse path, 1: the dense kernels (judged, snk_engine.h)
+    else if (!strcmp(name, "viterbi_latch_switches")) *out = (double)h->vit.switches;
+    else if (!strcmp(name, "viterbi_latch_trials")) *out = (double)h->vit.trials;
+    else if (!strcmp(name, "viterbi_latch_ms_row_sparse")) *out = h->vit.ms_row[0];
+    else if (!strcmp(name, "viterbi_latch_ms_row_dense")) *out = h->vit.ms_row[1];
     else if (!strcmp(name, "coarse_pairs") || !strcmp(name, "coarse_pair_overflow")) {
         // tile pairs the coarse pass of the most recent two-pass filter let through (debug / tuning aid)
         unsigned int v[2] = {0u, 0u};

@@ -97,17 +97,17 @@ static int knn_local_batch(snk_engine *h, const char *who, const double *Q, cons
     std::vector<int> st((size_t)n_groups);
     CHK(d2h_sync(h, st.data(), h->res_status.p, (size_t)n_groups * sizeof(int), h->stream));
     HIPCHK(hipGetLastError());
-    if ((h->ball_pass_ran || h->coarse_pass_ran) && h->cpairctl.p) {
-        unsigned int listed = 0;                  // (of the last group's call: enough to judge the voice)
-        CHK(d2h_sync(h, &listed, h->cpairctl.p, sizeof(listed), h->stream));
-        note_ball_pairs(h, listed);
+    if ((h->ball_pass_ran || h->coarse_pass_ran || h->probe_ran) && h->cpairctl.p) {
+        unsigned int ctl[4] = {0u, 0u, 0u, 0u};   // (of the last group's call: enough to judge the voice)
+        CHK(d2h_sync(h, ctl, h->cpairctl.p, sizeof(ctl), h->stream));
+        judge_filter(h, h->ball_pass_ran, h->ball_limit, h->coarse_pass_ran, h->coarse_limit, ctl[0], h->probe_ran, h->probe_limit, ctl[2]);
     }
     for (int g = 0; g < n_groups; ++g) {
         if (st[g] == 0) continue;
         if (st[g] & 2) h->tie_overflow = 1;
         const int64_t r0 = g * step, rows = (r0 + step <= total) ? step : total - r0;
         const int saved = h->precision;
-        h->precision = 0;
+        if (!((st[g] & ~3) == 0 && h->knn_level < 2)) h->precision = 0;      // (a lone list overflow: the voice's ladder, as in the batch pipeline)
         const int rc = knn_device(h, h->Qall.as<double>() + r0 * D, rows, K, nullptr, id_dev_out + r0 * K, nullptr,
                                   d2_dev_out + r0 * K);
         h->precision = saved;
@@ -513,11 +513,11 @@ static int sharded_submit(snk_engine *h, ShardTicket &t, const double *Q, const 
         CHK(comm_all_gather(h, h->sh_tot.p, h->sh_totall.p, (int64_t)G * 8));
         std::vector<int64_t> totall((size_t)G * G);
         CHK(d2h_sync(h, totall.data(), h->sh_totall.p, (size_t)G * G * sizeof(int64_t), h->stream));
-        if ((h->ball_pass_ran || h->coarse_pass_ran) && h->cpairctl.p) {
+        if ((h->ball_pass_ran || h->coarse_pass_ran || h->probe_ran) && h->cpairctl.p) {
             // (the host is waiting here anyway: what the step's last K-NN call listed decides whether this voice keeps its filter)
-            unsigned int listed = 0;
-            CHK(d2h_sync(h, &listed, h->cpairctl.p, sizeof(listed), h->stream));
-            note_ball_pairs(h, listed);
+            unsigned int ctl[4] = {0u, 0u, 0u, 0u};
+            CHK(d2h_sync(h, ctl, h->cpairctl.p, sizeof(ctl), h->stream));
+            judge_filter(h, h->ball_pass_ran, h->ball_limit, h->coarse_pass_ran, h->coarse_limit, ctl[0], h->probe_ran, h->probe_limit, ctl[2]);
         }
         int64_t so = 0, ro = 0;
         for (int p = 0; p < G; ++p) {
@@ -605,6 +605,7 @@ static int sharded_collect(snk_engine *h, ShardTicket &t, int64_t *path_out, int
     {
         const int *st = reinterpret_cast<const int *>(stg + sz_path + 2 * sz_u);
         for (int i = 0; i < t.n_status; ++i) status |= st[i];
+        if (status != 0 && (status & ~3) == 0 && h->knn_level < 2) { h->knn_level += 1; h->knn_escalations += 1; }     // this rank's later steps: longer lists (snk_engine.h)
     }
     // results of every utterance to every rank: fixed-size records, one all-gather (queued on the main stream: behind
     // the K-NN and the exchange of a step submitted in the meantime)

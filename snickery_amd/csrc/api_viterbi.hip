@@ -29,6 +29,7 @@ bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts)
     (void)n_utts;
     if (h->viterbi_weights == 1) return false;          // the float32 weight chain runs on the dense kernels
     if (!join_lb_supported(h->Dj, K)) return false;
+    if (h->viterbi_mode == 2 && h->vit_now_dense) return false;       // this voice's batches were judged faster through the dense kernels (snk_engine.h: vit)
     return h->viterbi_mode == 1 || h->viterbi_mode == 2;
 }
 
@@ -42,6 +43,7 @@ static int sparse_ensure(snk_engine *h, UttSlot &s, int64_t rows, int K)
     if (!h->vstats.p) {
         CHK(h->vstats.ensure((128 + 16 * 1024) * sizeof(unsigned long long)));    // + the stamps of a -DSNK_JF_TRACE build
         HIPCHK(hipMemset(h->vstats.p, 0, 128 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(reinterpret_cast<char *>(h->vstats.p) + 5 * sizeof(unsigned long long), 0xff, 4));     // [5]: smallest margin of the bounds' tripwire (image of +inf and beyond)
     }
     return 0;
 }
@@ -79,6 +81,7 @@ static int viterbi_sparse_rows(snk_engine *h, UttSlot &s, const int64_t *cand, c
     const float *JC = h->JC_unw.as<float>();
     const double *wj = h->wj.as<double>();
     const bool lb_side = h->join_bounds_stream == 1 && side != main;
+    const float ceps = (float)join_lb_ceps(h->join_lb_variant, h->Dj, K);       // unit of the bounds' tripwire (joinfast_kernels.hip)
     if (h->join_lb_variant == 1) CHK(ensure_jw32(h, main));
     if (lb_side) {
         HIPCHK(hipEventRecord(s.knn_done, main));
@@ -87,6 +90,8 @@ static int viterbi_sparse_rows(snk_engine *h, UttSlot &s, const int64_t *cand, c
     {
         StageTimer t(h, lb_side ? side : main, TM_JOIN_LB);
         join_bounds_launch(h, cand, rows, K, s.Jlo.as<float>(), s.scale.as<float>(), lb_side ? side : main);
+        if (h->join_lb_test_scale != 1.0 && rows > 1)
+            launch_scale_f32(s.Jlo.as<float>(), (rows - 1) * (int64_t)K * K, (float)h->join_lb_test_scale, lb_side ? side : main);
     }
     if (side != main && !lb_side) {
         HIPCHK(hipEventRecord(s.knn_done, main));
@@ -100,13 +105,14 @@ static int viterbi_sparse_rows(snk_engine *h, UttSlot &s, const int64_t *cand, c
     }
     {
         StageTimer t(h, side, TM_JOIN_SPARSE);
-        launch_join_exact_sparse(JC, h->Jp, h->Dj, wj, join_units(h), cand, tdist, rows, K, s.sets.p, s.cex.p, side);
+        launch_join_exact_sparse(JC, h->Jp, h->Dj, wj, join_units(h), cand, tdist, rows, K, s.sets.p, s.cex.p, side,
+                                 s.Jlo.as<float>(), s.scale.as<float>(), ceps, h->vstats.as<unsigned long long>());
     }
     {
         StageTimer t(h, side, TM_DP_SPARSE);
         launch_viterbi_sparse(cand, s.cex.p, s.Jlo.as<float>(), JC, h->Jp, h->Dj, wj, off, n_utts, first_utt, K,
                               join_units(h), s.bp.as<unsigned char>(), path, plen, cost,
-                              h->vstats.as<unsigned long long>(), side);
+                              h->vstats.as<unsigned long long>(), side, s.scale.as<float>(), ceps);
     }
     return 0;
 }
@@ -351,10 +357,31 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     CHK(b.path.ensure((size_t)total * sizeof(int64_t)));
     CHK(b.plen.ensure((size_t)n_utts * sizeof(int64_t)));
     CHK(b.cost.ensure((size_t)n_utts * sizeof(double)));
-    CHK(b.status.ensure((size_t)2 * b.n_groups * sizeof(int)));          // per group: K-NN status word | tile pairs the ball pass listed
+    CHK(b.status.ensure((size_t)3 * b.n_groups * sizeof(int)));          // per group: K-NN status word | tile pairs the first pass listed | pairs its probe counted
     const size_t sz_path = ((size_t)total * sizeof(int64_t) + 63) & ~(size_t)63;
-    const size_t sz_u = ((size_t)n_utts * 8 + 63) & ~(size_t)63, sz_st = ((size_t)2 * b.n_groups * sizeof(int) + 63) & ~(size_t)63;
-    CHK(b.stage.ensure(sz_path + 2 * sz_u + sz_st));
+    const size_t sz_u = ((size_t)n_utts * 8 + 63) & ~(size_t)63, sz_st = ((size_t)3 * b.n_groups * sizeof(int) + 63) & ~(size_t)63;
+    CHK(b.stage.ensure(sz_path + 2 * sz_u + sz_st + 64));                 // + the Viterbi statistics words
+    // the Viterbi latch (snk_engine.h: vit): which exact path this batch takes, and the events its period is read from
+    const bool vit_auto = h->viterbi_mode == 2 && h->viterbi_latch && h->viterbi_weights == 0 && join_lb_supported(h->Dj, K) && n_utts >= 2;
+    b.vit_trial = vit_auto && h->vit.trial_left > 0;
+    b.vit_dense = vit_auto && (b.vit_trial ? h->vit.trial_mode : h->vit.mode) == 1;
+    b.vit_judged = vit_auto;
+    b.seq = h->vit_seq++;
+    if (!h->vit_t0[0])
+        for (int i = 0; i < 4; ++i) { HIPCHK(hipEventCreate(&h->vit_t0[i])); HIPCHK(hipEventCreate(&h->vit_t1[i])); }
+    HIPCHK(hipEventRecord(h->vit_t0[b.seq & 3], h->stream));
+    struct DenseGuard { snk_engine *e; ~DenseGuard() { e->vit_now_dense = false; } } dense_guard{h};
+    h->vit_now_dense = b.vit_dense;
+    if (b.vit_dense || !h->vstats.p) {
+        // (the statistics words are copied below whichever path runs)
+        if (!h->vstats.p) {
+            CHK(h->vstats.ensure((128 + 16 * 1024) * sizeof(unsigned long long)));
+            HIPCHK(hipMemset(h->vstats.p, 0, 128 * sizeof(unsigned long long)));
+            HIPCHK(hipMemset(reinterpret_cast<char *>(h->vstats.p) + 5 * sizeof(unsigned long long), 0xff, 4));
+        }
+    }
+    b.probe_kind.assign((size_t)b.n_groups, 0);
+    b.probe_limit.assign((size_t)b.n_groups, 0.0);
     if (Q) {
         StageTimer t(h, h->stream, TM_H2D);
         CHK(h2d_via(b.qstage, b.Qall.p, Q, (size_t)total * D * sizeof(double), h->stream));
@@ -370,9 +397,11 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
         const int64_t r0 = row_offsets[b.first[g]], rows = row_offsets[b.first[g + 1]] - r0;
         CHK(knn_device(h, b.Qall.as<double>() + r0 * D, rows, K, nullptr, b.cand.as<int64_t>() + r0 * K,
                        b.dist.as<double>() + r0 * K, nullptr, b.status.as<int>() + g, nullptr, nullptr, false, false,
-                       reinterpret_cast<unsigned int *>(b.status.as<int>() + b.n_groups + g)));
+                       reinterpret_cast<unsigned int *>(b.status.as<int>() + b.n_groups + g),
+                       reinterpret_cast<unsigned int *>(b.status.as<int>() + 2 * b.n_groups + g)));
         b.ball_limit = h->ball_pass_ran ? h->ball_limit : -1.0;
         b.coarse_limit = h->coarse_pass_ran ? h->coarse_limit : -1.0;
+        b.probe_kind[(size_t)g] = h->probe_ran; b.probe_limit[(size_t)g] = h->probe_limit;
         CHK(viterbi_group(h, g, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
                           b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), n_utts));
     }
@@ -387,8 +416,10 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
         HIPCHK(hipMemcpyAsync(st, b.path.p, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
         HIPCHK(hipMemcpyAsync(st + sz_path, b.plen.p, (size_t)n_utts * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
         HIPCHK(hipMemcpyAsync(st + sz_path + sz_u, b.cost.p, (size_t)n_utts * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
-        HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u, b.status.p, (size_t)2 * b.n_groups * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u, b.status.p, (size_t)3 * b.n_groups * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u + sz_st, h->vstats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->copy_stream));
     }
+    HIPCHK(hipEventRecord(h->vit_t1[b.seq & 3], h->copy_stream));
     HIPCHK(hipEventRecord(b.done, h->copy_stream));
     HIPCHK(hipGetLastError());
     b.busy = true;
@@ -412,19 +443,58 @@ int snk_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, i
     char *st = (char *)b.stage.p;
     // deferred K-NN status words: redo the (rare) group whose sampled thresholds overflowed a list
     const int *status = reinterpret_cast<const int *>(st + sz_path + 2 * sz_u);
-    if (b.ball_limit >= 0.0 && !h->filter_coarse)
-        for (int g = 0; g < b.n_groups; ++g)
-            if ((double)(unsigned int)status[b.n_groups + g] > b.ball_limit) { h->filter_coarse = true; h->ball_switches += 1; break; }
-    if (b.coarse_limit >= 0.0 && !h->filter_onepass)
-        for (int g = 0; g < b.n_groups; ++g)
-            if ((double)(unsigned int)status[b.n_groups + g] > b.coarse_limit) { h->filter_onepass = true; h->onepass_switches += 1; break; }
+    for (int g = 0; g < b.n_groups; ++g)
+        judge_filter(h, b.ball_limit >= 0.0, b.ball_limit, b.coarse_limit >= 0.0, b.coarse_limit, (unsigned int)status[b.n_groups + g],
+                     (unsigned int)status[2 * b.n_groups + g] != 0xffffffffu ? b.probe_kind[(size_t)g] : 0, b.probe_limit[(size_t)g],
+                     (unsigned int)status[2 * b.n_groups + g]);
+    // ---- the Viterbi latch (snk_engine.h: vit): this batch's period in stream time, per row ----
+    if (b.vit_judged && h->viterbi_mode == 2 && h->viterbi_latch) {
+        const size_t sz_st = ((size_t)3 * b.n_groups * sizeof(int) + 63) & ~(size_t)63;
+        const unsigned long long *vs = reinterpret_cast<const unsigned long long *>(st + sz_path + 2 * sz_u + sz_st);
+        float lat = 0.f, per = 0.f;
+        double ms = -1.0;
+        if (hipEventElapsedTime(&lat, h->vit_t0[b.seq & 3], h->vit_t1[b.seq & 3]) == hipSuccess) ms = lat;
+        if (b.seq > 0 && h->vit_last_collected == b.seq - 1 &&
+            hipEventElapsedTime(&per, h->vit_t1[(b.seq - 1) & 3], h->vit_t1[b.seq & 3]) == hipSuccess && per > 0.f && (ms < 0.0 || per < ms)) ms = per;
+        (void)hipGetLastError();
+        h->vit_last_collected = b.seq;
+        const double cells = (double)(vs[0] - h->vit_cells_prev);
+        h->vit_cells_prev = vs[0];
+        snk_engine::VitLatch &v = h->vit;
+        if (ms > 0.0 && b.total > 0) {
+            const double row_ms = ms / (double)b.total;
+            const int m = b.vit_dense ? 1 : 0;
+            v.batches += 1;
+            if (b.vit_trial && m == v.trial_mode) {
+                // a batch of a trial: the first one overlaps a batch of the other path, the best of the rest counts
+                if (v.trial_left <= 2) v.trial_best = (v.trial_best <= 0.0 || row_ms < v.trial_best) ? row_ms : v.trial_best;
+                if (--v.trial_left == 0) {
+                    if (v.trial_best > 0.0 && v.ms_row[v.mode] > 0.0 && v.trial_best < 0.95 * v.ms_row[v.mode]) {
+                        v.ms_row[v.trial_mode] = v.trial_best;
+                        v.mode = v.trial_mode; v.switches += 1; v.period = 32;
+                    } else v.period = v.period < 512 ? 2 * v.period : 1024;
+                    v.next_probe = v.batches + v.period;
+                    v.trial_mode = -1;
+                }
+            } else if (!b.vit_trial && m == v.mode) {
+                v.ms_row[m] = v.ms_row[m] > 0.0 ? 0.75 * v.ms_row[m] + 0.25 * row_ms : row_ms;
+                // a trial of the other path: from the sparse path only where its bounds do not prune (cells refined in pass 4)
+                const bool gate = v.mode == 1 || cells > h->vit_refine_gate * (double)b.total * (double)b.K;
+                if (v.trial_left == 0 && v.batches >= v.next_probe && gate) {
+                    v.trial_mode = 1 - v.mode; v.trial_left = 3; v.trial_best = 0.0; v.trials += 1;
+                }
+            }
+        }
+    }
     bool redone = false;
     for (int g = 0; g < b.n_groups; ++g) {
         if (status[g] == 0) continue;
         if (status[g] & 2) h->tie_overflow = 1;
         const int64_t r0 = b.offs[b.first[g]], rows = b.offs[b.first[g + 1]] - r0;
         const int saved = h->precision;
-        h->precision = 0;
+        // a lone list overflow: the fast path once more, non-deferred -- it takes the voice up its ladder (longer lists, float32
+        // operands: snk_engine.h knn_level) and later batches start there; anything else: the exact float64 sweep
+        if (!((status[g] & ~3) == 0 && h->knn_level < 2)) h->precision = 0;
         const int rc = knn_device(h, b.Qall.as<double>() + r0 * b.D, rows, b.K, nullptr,
                                   b.cand.as<int64_t>() + r0 * b.K, b.dist.as<double>() + r0 * b.K, nullptr);
         h->precision = saved;

@@ -190,5 +190,20 @@ __device__ __forceinline__ double g32_err16(double d, double V2, int ncols, doub
     return g32_err(d + e16, V2, ncols) + e16;
 }
 
+// Tripwire of the float32 scans' bound (status words 8 and 9 of a launch).  Whenever a step is decided by exact totals, every
+// window weighed has d~ >= M (M: the float32 minimum the bound tau was built from) and, if the bound holds, an exact total
+// d >= M - (E(d) + EW).  used = (M - d) / (E(d) + EW) is the share of the bound a window consumed: > 1 is a VIOLATION (the
+// scan's approximate total of some window was off by more than the proven -- for the hoisted bf16 product: probed -- bound).
+// status[8] += violations, status[9] = max used (float bits; non-negative floats order like their bit patterns).
+__device__ __forceinline__ void g32_trip(int64_t *status, double M, double d, double bound, float &seen)
+{
+    const double used = bound > 0.0 ? (M - d) / bound : 0.0;
+    const float uf = used > 0.0 ? (float)used : 0.f;
+    if (uf > seen) {                                            // rare after the first steps: the lane's own running maximum gates the atomics
+        seen = uf;
+        atomicMax(reinterpret_cast<unsigned int *>(&status[9]), __builtin_bit_cast(unsigned int, uf));
+        if (used > 1.0) atomicAdd(reinterpret_cast<unsigned long long *>(&status[8]), 1ull);
+    }
+}
 
 }  // namespace snk

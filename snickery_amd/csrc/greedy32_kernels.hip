@@ -63,6 +63,7 @@ struct G32Info {              // what the gather found for an utterance (LDS; th
     int D, nH, sender;        // who decides | holders of windows inside the bound | this workgroup sends its lanes' windows
     int64_t winner;
     double tau;
+    float mv, pad_;           // the float32 minimum the bound was built from (tripwire of the bound: g32_trip)
 };
 
 struct Top3 {                 // two best windows (value, index) and the third value; indices fit 31 bits (snk_upload_db)
@@ -233,6 +234,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
     Top3 *red3 = reinterpret_cast<Top3 *>(lds);
     double *redd = reinterpret_cast<double *>(lds);
 
+    float trip_seen = 0.f;                                 // tripwire of the bound: the largest share of it this lane has reported
     int64_t prev_row[UB];                                  // winners of the previous step (start states first)
 #pragma unroll
     for (int u = 0; u < UB; ++u) prev_row[u] = a.start[u];
@@ -498,7 +500,9 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
         int nw_exact = kslots >= 1 ? nwaves : (lds_bytes - 16384) / (ex_cols * 8);
         if (kslots < 1) kslots = 1;
         double *const terms = reinterpret_cast<double *>(lds + 16384) + (size_t)wave * kslots * ex_cols;
-        auto exact_argmin = [&](int u, int n, auto get) -> int64_t {
+        // M / V2 / EW: the float32 minimum, the reference norm and the hoisted values' bound the step's tau was built from -- every
+        // total computed here is held against them (g32_trip: the tripwire of the scan's bound)
+        auto exact_argmin = [&](int u, int n, auto get, float Mf, double V2t, double EWt) -> int64_t {
             double dbest = DBL_MAX;
             int64_t ibest = INT64_MAX;
             // (the six-utterance instance has no registers to spare: no tree sums, candidate after candidate)
@@ -544,6 +548,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                             for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
                             ps[k] = v;
                             pmin = v < pmin ? v : pmin;
+                            if (lane == 0) g32_trip(status, (double)Mf, v, errf(v, V2t) + EWt, trip_seen);
                         }
                     }
                     double *pm = reinterpret_cast<double *>(lds + 8192 + 128);
@@ -582,7 +587,10 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                     const double other = __shfl_xor(part, 1, 64);
                     const double tot = (lane & 1) ? __dadd_rn(other, part) : __dadd_rn(part, other);      // acc_j + acc_t
                     const double dk = __shfl(tot, (lane & 3) << 1, 64);         // lane k < 4 fetches candidate k's total
-                    if (lane < cnt && ((surv >> lane) & 1u)) d = dk;
+                    if (lane < cnt && ((surv >> lane) & 1u)) {
+                        d = dk;
+                        if (!(UB <= 3 && single_round)) g32_trip(status, (double)Mf, dk, errf(dk, V2t) + EWt, trip_seen);      // (else: done on the tree sums)
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -694,7 +702,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
                     const bool over = ccount[1] != 0 || n > G32_CAND;
                     __syncthreads();
                     if (over || n < 2) continue;
-                    spec_win[u] = exact_argmin(u, n, [&](int p) { return (int64_t)clist[p]; });
+                    spec_win[u] = exact_argmin(u, n, [&](int p) { return (int64_t)clist[p]; }, mvl, V2w[u], EWw[u]);
                     spec_tau[u] = tau; spec_n[u] = n; spec_valid[u] = true;
                 }
                 __syncthreads();
@@ -774,7 +782,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
             }
             if (lane == 0) {
                 G32Info x;
-                x.state = state; x.D = mb; x.nH = nH; x.sender = sender; x.winner = (int64_t)mi; x.tau = tau;
+                x.state = state; x.D = mb; x.nH = nH; x.sender = sender; x.winner = (int64_t)mi; x.tau = tau; x.mv = mv; x.pad_ = 0.f;
                 info[u] = x;
             }
         }
@@ -899,7 +907,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
             if (n == 1) winner[u] = (int64_t)clist[0];
             else {
                 stat_rounds += 1; stat_windows += (unsigned long long)n;      // statistics: decisions by exact totals, their windows
-                winner[u] = exact_argmin(u, n, [&](int p) { return (int64_t)clist[p]; });
+                winner[u] = exact_argmin(u, n, [&](int p) { return (int64_t)clist[p]; }, info[u].mv, V2w[u], EWw[u]);
             }
             // the winner IS the release
             if (tid == 0) {
@@ -952,7 +960,7 @@ greedy32_kernel(GreedyArgs a, int64_t nsteps, int flags, int use_nt, int lds_byt
 // prologue: generation word, status
 __global__ void greedy32_init_kernel(unsigned int *gen, int64_t *status)
 {
-    if (threadIdx.x == 0) { *status = 0; *gen = 0u; status[1] = 0; status[2] = 0; status[3] = 0; status[4] = 0; status[5] = 0; }
+    if (threadIdx.x == 0) { *status = 0; *gen = 0u; for (int i = 1; i < 16; ++i) status[i] = 0; }
 }
 
 // exact Euclidean distance of every pick (what the tree query returns beside the index): a wavefront per step

@@ -138,8 +138,11 @@ static __device__ void gres_tree_sums(const GreedyArgs &a, int64_t step, int64_t
 
 // the canonical float64 minimum among n listed windows (lowest index on exact ties), by ONE wavefront: tree sums of all of
 // them first; only the windows that the tree sums cannot tell from the smallest get their canonical chain
+// M / c1 / c2 / EW: the float32 minimum and the bound E(d) = c1 sqrt(d) + c2 d (+ EW for the hoisted values) the step's tau was built
+// from; report != nullptr (one workgroup): every tree sum is held against them (g32_trip, the tripwire of the scan's bound)
 static __device__ int64_t gres_exact_argmin(const GreedyArgs &a, int64_t step, int64_t prev_row, const int64_t *clist, int n,
-                                            double *terms, int lane)
+                                            double *terms, int lane, double M, double c1, double c2, double EW, int64_t *report,
+                                            float &trip_seen)
 {
     const int ex_cols = a.jdim + a.nep * a.Dt;
     double smin = DBL_MAX;
@@ -152,7 +155,10 @@ static __device__ int64_t gres_exact_argmin(const GreedyArgs &a, int64_t step, i
         gres_tree_sums(a, step, prev_row, step > 0, ids, cnt, sum, lane);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (k < cnt && lane == 0) terms[ex_cols + p0 + k] = sum[k];          // (behind the term array: up to GRES_MAXCAND sums)
+            if (k < cnt && lane == 0) {
+                terms[ex_cols + p0 + k] = sum[k];          // (behind the term array: up to GRES_MAXCAND sums)
+                if (report) g32_trip(report, M, sum[k], c1 * sqrt(sum[k]) * (1.0 + 1e-12) + c2 * sum[k] + EW, trip_seen);
+            }
             smin = sum[k] < smin ? sum[k] : smin;
         }
     }
@@ -201,7 +207,8 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
     char *const scratch = reinterpret_cast<char *>(tr + 4 * JQ4);                // 512 bytes
     double *const redd = reinterpret_cast<double *>(scratch);                    // [4] partial norms
     unsigned int *const redk = reinterpret_cast<unsigned int *>(scratch + 64);   // [4][6] wavefront top-3
-    int64_t *const bcast = reinterpret_cast<int64_t *>(scratch + 192);           // [2] winner, state
+    int64_t *const bcast = reinterpret_cast<int64_t *>(scratch + 192);           // [8] winner, state, tau | minimum, c1, c2, EW of the step's bound
+    float trip_seen = 0.f;                                                       // tripwire of the bound (g32_trip)
     int64_t *const clist = reinterpret_cast<int64_t *>(scratch + 256);           // candidates (GRES_MAXCAND, behind: terms)
     double *const terms = reinterpret_cast<double *>(scratch + 256 + GRES_MAXCAND * 8);
 
@@ -437,7 +444,12 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                         // a window no record carries may matter (three or more of one workgroup inside the bound: runs of
                         // near-identical frames): second round -- every workgroup publishes WHICH of its windows lie inside
                         state = 2;
-                        if (lane == 0) bcast[2] = __double_as_longlong(tau);
+                        if (lane == 0) {
+                            bcast[2] = __double_as_longlong(tau);
+                            // (for the tripwire of the bound in the second round: the minimum and the bound's constants)
+                            bcast[3] = __double_as_longlong((double)mv); bcast[4] = __double_as_longlong(c1); bcast[5] = __double_as_longlong(c2);
+                            bcast[6] = __double_as_longlong(EW);
+                        }
                     } else if (cov || nc > GRES_MAXCAND) {
                         state = -1;                          // mass ties: the caller's other scan
                         if (lane == 0 && blockIdx.x == 0) {
@@ -460,7 +472,8 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_wave_barrier();
-                        winner = gres_exact_argmin(a, step, prev_row, clist, nc, terms, lane);
+                        winner = gres_exact_argmin(a, step, prev_row, clist, nc, terms, lane, (double)mv, c1, c2, EW,
+                                                   blockIdx.x == 0 ? status : nullptr, trip_seen);
                         stat_windows += (unsigned long long)nc;
                     }
                 }
@@ -473,6 +486,8 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
         if (bcast[1] == 2) {                                 // uniform
             // ---- second round: 256-bit membership mask of every workgroup (8 granules of 32 bits + tag), gathered by all ----
             const double tau = __longlong_as_double(bcast[2]);
+            const double tm_ = __longlong_as_double(bcast[3]), tc1_ = __longlong_as_double(bcast[4]), tc2_ = __longlong_as_double(bcast[5]),
+                         tew_ = __longlong_as_double(bcast[6]);
             const unsigned long long mask = __ballot(valid && (double)key <= tau);
             if (lane == 0) {
                 if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -547,7 +562,8 @@ greedy_res_kernel(GreedyArgs a, int64_t nsteps, int flags, int JQ4, int tile_q, 
                             }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_wave_barrier();
-                        winner = gres_exact_argmin(a, step, prev_row, clist, total, terms, lane);
+                        winner = gres_exact_argmin(a, step, prev_row, clist, total, terms, lane, tm_, tc1_, tc2_, tew_,
+                                                   blockIdx.x == 0 ? status : nullptr, trip_seen);
                         stat_windows += (unsigned long long)total;
                         stat_rounds += 1;
                     }
@@ -574,7 +590,7 @@ __global__ void greedy_res_init_kernel(GresRec *rec, unsigned long long *rec2, i
         rec[n + i].a = 0ull; rec[n + i].b = 0ull;              // both parities (greedy_res_kernel)
         for (int g = 0; g < 8; ++g) rec2[(size_t)i * 8 + g] = 0ull;
     }
-    if (i == 0) { status[0] = 0; status[1] = 0; status[2] = 0; status[3] = 0; }
+    if (i == 0) for (int w = 0; w < 16; ++w) status[w] = 0;
 }
 
 static void *gres_trace_dev = nullptr;

@@ -219,6 +219,14 @@ static void launch_join_lb_t(const float *JC_unw, int Jp, int Dj, const double *
 
 bool join_lb_supported(int Dj, int K) { return ((Dj + 15) & ~15) <= JF_MAXD && K >= 1 && K <= 208; }
 
+// the error budget of the squared cost, as a fraction of the two centred norms' sum, of the form of pass 1 in use (the unit of the
+// tripwire's margin): the float32 form's 2.2 (DC + 6) 2^-24 (join_lb_kernel), the bf16 form's join_lb2_ceps
+double join_lb_ceps(int variant, int Dj, int K)
+{
+    if (variant == 1) return join_lb2_ceps(Dj, K);
+    return 2.2 * (double)(((Dj + 15) & ~15) + 6) * 5.9604644775390625e-08;
+}
+
 // (pass 1, second form -- bf16 matrix pipe over a weighted float32 copy of the join rows: joinlb2_kernels.hip)
 
 void launch_join_lb(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
@@ -500,6 +508,46 @@ __device__ __forceinline__ double jf_exact_cost(const float *__restrict__ JC_unw
     return __dsqrt_rn(acc);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tripwire of pass 1's bounds.  The bf16 form's proof (joinlb2_kernels.hip) rests on a PROBED property of
+// v_mfma_f32_32x32x16_bf16 (off by at most 2^-20 of |products| + |C| per instruction); a bound that is not a bound does not
+// crash -- it silently drops the optimal predecessor.  Every exact join cost this path computes anyway (pass 3: the members
+// of the predecessor sets; pass 4: the refinements) is therefore held against the float32 bound pass 1 gave that cell:
+//   stats[4] += cells with lo > exact  (must stay 0),
+//   stats[5] (low word: order-preserving image of a float) = the smallest (exact^2 - lo^2) / (2 ceps scale^2) over the cells
+//   with lo > 0 -- ceps (ne + ns) <= 2 ceps scale^2 is the error budget of the squared cost, scale the step's largest centred
+//   norm: what is left of the budget, in units of (an upper bound of) the budget; negative = a violation.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int jf_trip_image(float f)
+{
+    const unsigned int u = __builtin_bit_cast(unsigned int, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ void jf_trip_check(double c, float lo, double unit, int &viol, float &mmin)
+{
+    if ((double)lo > c) ++viol;
+    if (lo > 0.f && lo < __builtin_inff() && unit > 0.0) {
+        const float m = (float)((c * c - (double)lo * (double)lo) / unit);
+        mmin = m < mmin ? m : mmin;
+    }
+}
+// whole wavefront (every lane active): one atomic per wavefront at most, none in the steady state
+__device__ __forceinline__ void jf_trip_commit(unsigned long long *stats, int viol, float mmin)
+{
+#pragma unroll
+    for (int m = 1; m <= 32; m <<= 1) {
+        viol += __shfl_xor(viol, m, 64);
+        const float o = __shfl_xor(mmin, m, 64);
+        mmin = o < mmin ? o : mmin;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (viol) atomicAdd(&stats[4], (unsigned long long)viol);
+        unsigned int *slot = reinterpret_cast<unsigned int *>(&stats[5]);
+        const unsigned int im = jf_trip_image(mmin);
+        if (mmin < __builtin_inff() && im < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, im);
+    }
+}
+
 // pass 3: one lane per (row, column): the exact costs of its recorded predecessors, and the cell's 64-byte
 // record for pass 4:  { td (target cost, +inf for an unusable unit), X, dlb, c[0..3], slots | n << 32 }
 struct __attribute__((aligned(16))) JfRecord { double td, x, lb, c[JF_CAP]; unsigned long long meta; };
@@ -507,7 +555,9 @@ struct __attribute__((aligned(16))) JfRecord { double td, x, lb, c[JF_CAP]; unsi
 __global__ void __launch_bounds__(256)
 join_exact_sparse_kernel(const float *__restrict__ JC_unw, int Jp, int Dj, const double *__restrict__ wj,
                          int64_t n_units, const int64_t *__restrict__ cand, const double *__restrict__ tdist,
-                         int64_t R, int K, const u32x4 *__restrict__ sets, JfRecord *__restrict__ rec)
+                         int64_t R, int K, const u32x4 *__restrict__ sets, JfRecord *__restrict__ rec,
+                         const float *__restrict__ Jlo, const float *__restrict__ scale, float ceps,
+                         unsigned long long *__restrict__ stats)
 {
     const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= R * K) return;
@@ -536,6 +586,16 @@ join_exact_sparse_kernel(const float *__restrict__ JC_unw, int Jp, int Dj, const
     dst[1] = (f64x2){lb64, c[0]};
     dst[2] = (f64x2){c[1], c[2]};
     dst[3] = (f64x2){c[3], __builtin_bit_cast(double, (unsigned long long)ix | ((unsigned long long)n_raw << 32))};
+    if (stats && n > 0) {                                     // tripwire (above); this form is the A/B partner: plain atomics
+        const float *slab = Jlo + (t - 1) * (int64_t)K * K + (cell - t * K);
+        const double sc = (double)scale[t - 1], unit = 2.0 * (double)ceps * sc * sc;
+        int viol = 0;
+        float mmin = __builtin_inff();
+        for (int j = 0; j < n; ++j)
+            if (c[j] < __builtin_inf()) jf_trip_check(c[j], slab[(int64_t)((ix >> (8 * j)) & 0xffu) * K], unit, viol, mmin);
+        if (viol) atomicAdd(&stats[4], (unsigned long long)viol);
+        if (mmin < __builtin_inff()) atomicMin(reinterpret_cast<unsigned int *>(&stats[5]), jf_trip_image(mmin));
+    }
 }
 
 // pass 3, cooperative form (the default; g_exact_form 0 selects the kernel above): the same records, the same canonical
@@ -552,7 +612,9 @@ join_exact_sparse_kernel(const float *__restrict__ JC_unw, int Jp, int Dj, const
 __global__ void __launch_bounds__(JX_T)
 join_exact_sparse2_kernel(const float *__restrict__ JC_unw, int Jp, int Dj, const double *__restrict__ wj,
                           int64_t n_units, const int64_t *__restrict__ cand, const double *__restrict__ tdist,
-                          int64_t R, int K, const u32x4 *__restrict__ sets, JfRecord *__restrict__ rec)
+                          int64_t R, int K, const u32x4 *__restrict__ sets, JfRecord *__restrict__ rec,
+                          const float *__restrict__ Jlo, const float *__restrict__ scale, float ceps,
+                          unsigned long long *__restrict__ stats)
 {
     __shared__ __align__(16) float tile[JX_T / 64][2][64 * JX_PITCH];        // [wavefront][E, S][cost][column of the chunk]
     __shared__ double c_s[JX_T][JF_CAP];
@@ -677,15 +739,42 @@ join_exact_sparse2_kernel(const float *__restrict__ JC_unw, int Jp, int Dj, cons
         if (have) c_s[code >> 2][code & 3u] = __dsqrt_rn(acc);
     }
     __syncthreads();
-    if (!live) return;
-    const unsigned int w_d = st[0], w_x = st[1];
-    const double lb64 = (double)__builtin_bit_cast(float, w_d), x64 = (double)__builtin_bit_cast(float, w_x);
-    typedef double f64x2 __attribute__((ext_vector_type(2)));
-    f64x2 *dst = reinterpret_cast<f64x2 *>(rec + cell);
-    dst[0] = (f64x2){okb ? tdist[cell] : __builtin_inf(), x64};
-    dst[1] = (f64x2){lb64, c_s[tid][0]};
-    dst[2] = (f64x2){c_s[tid][1], c_s[tid][2]};
-    dst[3] = (f64x2){c_s[tid][3], __builtin_bit_cast(double, (unsigned long long)ix | ((unsigned long long)n_raw << 32))};
+    if (live) {
+        const unsigned int w_d = st[0], w_x = st[1];
+        const double lb64 = (double)__builtin_bit_cast(float, w_d), x64 = (double)__builtin_bit_cast(float, w_x);
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        f64x2 *dst = reinterpret_cast<f64x2 *>(rec + cell);
+        dst[0] = (f64x2){okb ? tdist[cell] : __builtin_inf(), x64};
+        dst[1] = (f64x2){lb64, c_s[tid][0]};
+        dst[2] = (f64x2){c_s[tid][1], c_s[tid][2]};
+        dst[3] = (f64x2){c_s[tid][3], __builtin_bit_cast(double, (unsigned long long)ix | ((unsigned long long)n_raw << 32))};
+    }
+    if (stats) {                                              // tripwire of pass 1's bounds (above): the costs of this cell against them
+        int viol = 0;
+        float mmin = __builtin_inff();
+        if (live && n > 0) {
+            const float *slab = Jlo + (t - 1) * (int64_t)K * K + (cell - t * K);
+            const double sc = (double)scale[t - 1], unit = 2.0 * (double)ceps * sc * sc;
+            float lo[JF_CAP];
+#pragma unroll
+            for (int j = 0; j < JF_CAP; ++j) lo[j] = j < n ? slab[(int64_t)((ix >> (8 * j)) & 0xffu) * K] : 0.f;
+#pragma unroll
+            for (int j = 0; j < JF_CAP; ++j)
+                if (j < n && c_s[tid][j] < __builtin_inf()) jf_trip_check(c_s[tid][j], lo[j], unit, viol, mmin);
+        }
+        jf_trip_commit(stats, viol, mmin);
+    }
+}
+
+// test hook of the bounds' tripwire (option join_lb_test_scale): pass 1's bounds multiplied by a factor > 1 are no bounds any more
+__global__ void jf_scale_kernel(float *__restrict__ x, int64_t n, float f)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= f;
+}
+void launch_scale_f32(float *x, int64_t n, float f, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(jf_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, f);
 }
 
 static int g_exact_form = 1;
@@ -694,17 +783,21 @@ void set_join_exact_form(int f) { g_exact_form = f ? 1 : 0; }
 size_t join_record_bytes() { return sizeof(JfRecord); }
 
 void launch_join_exact_sparse(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
-                              const double *tdist, int64_t R, int K, const void *sets, void *rec, hipStream_t s)
+                              const double *tdist, int64_t R, int K, const void *sets, void *rec, hipStream_t s,
+                              const float *Jlo, const float *scale, float ceps, unsigned long long *stats)
 {
+    if (!Jlo || !scale) stats = nullptr;
     static_assert(sizeof(JfRecord) == 64, "pass 4 streams 64-byte records");
     const int64_t cells = R * K;
     if (g_exact_form == 1 && n_units < ((int64_t)1 << 31) && K <= 256) {
         hipLaunchKernelGGL(join_exact_sparse2_kernel, dim3((unsigned)((cells + JX_T - 1) / JX_T)), dim3(JX_T), 0, s, JC_unw, Jp, Dj,
-                           wj, n_units, cand, tdist, R, K, reinterpret_cast<const u32x4 *>(sets), reinterpret_cast<JfRecord *>(rec));
+                           wj, n_units, cand, tdist, R, K, reinterpret_cast<const u32x4 *>(sets), reinterpret_cast<JfRecord *>(rec),
+                           Jlo, scale, ceps, stats);
         return;
     }
     hipLaunchKernelGGL(join_exact_sparse_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, JC_unw, Jp, Dj,
-                       wj, n_units, cand, tdist, R, K, reinterpret_cast<const u32x4 *>(sets), reinterpret_cast<JfRecord *>(rec));
+                       wj, n_units, cand, tdist, R, K, reinterpret_cast<const u32x4 *>(sets), reinterpret_cast<JfRecord *>(rec),
+                       Jlo, scale, ceps, stats);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -762,7 +855,7 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
                       const double *__restrict__ wj, const DpBatch batch, int K, int64_t n_units,
                       unsigned char *__restrict__ bp_all, int64_t *__restrict__ path_all,
                       int64_t *__restrict__ path_len_all, double *__restrict__ cost_all,
-                      unsigned long long *__restrict__ stats)
+                      unsigned long long *__restrict__ stats, const float *__restrict__ scale_all, float ceps)
 {
     __builtin_amdgcn_s_setprio(3);           // as viterbi_lb_kernel
     const int64_t r0 = batch.off[blockIdx.x];
@@ -770,6 +863,7 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
     const int64_t *__restrict__ cand = cand_all + r0 * K;
     const JfRecord *__restrict__ rec = rec_all + r0 * K;
     const float *__restrict__ Jlo = Jlo_all + r0 * K * K;
+    const float *__restrict__ scale = scale_all + r0;
     unsigned char *__restrict__ bp_global = bp_all + r0 * K;
     int64_t *__restrict__ path = path_all + r0;
     int64_t *__restrict__ path_len = path_len_all + batch.first + blockIdx.x;
@@ -913,7 +1007,9 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
         if (anyfail) {                                             // rare; every wavefront takes the same barriers
             if (fail) { rbest[k] = best; rarg[k] = arg; }
             __syncthreads();
-            int n_failed = 0, n_exact = 0;
+            int n_failed = 0, n_exact = 0, tviol = 0;
+            float tmin = __builtin_inff();
+            const double tsc = (double)scale[t - 1], tunit = 2.0 * (double)ceps * tsc * tsc;
             if (!loader) {
                 for (int kf = 0; kf < K; ++kf) {
                     if (!fail_s[kf]) continue;                         // uniform (LDS)
@@ -928,7 +1024,9 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
                         const float lo = jcol[(int64_t)p * K];
                         if (dp < inf && lo < __builtin_inff() && __dadd_rn(dp, (double)lo) <= bS) {
                             const int64_t a = cand[(t - 1) * K + p];
-                            const double tot = __dadd_rn(dp, jf_exact_cost(JC_unw, Jp, Dj, wj, a, b));
+                            const double cex = jf_exact_cost(JC_unw, Jp, Dj, wj, a, b);
+                            const double tot = __dadd_rn(dp, cex);
+                            if (stats) jf_trip_check(cex, lo, tunit, tviol, tmin);        // tripwire of pass 1's bounds
                             ++n_exact;
                             if (tot < lb || (tot == lb && p < la)) { lb = tot; la = p; }
                         }
@@ -957,6 +1055,7 @@ viterbi_sparse_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__re
                     n_exact += __shfl_xor(n_exact, 8, 64); n_exact += __shfl_xor(n_exact, 16, 64); n_exact += __shfl_xor(n_exact, 32, 64);
                     if (lane == 0 && n_exact) atomicAdd(&stats[2], (unsigned long long)n_exact);
                     if (tid == 0) { atomicAdd(&stats[0], (unsigned long long)n_failed); atomicAdd(&stats[1], 1ull); }
+                    jf_trip_commit(stats, tviol, tmin);
                 }
             }
             __syncthreads();
@@ -1069,7 +1168,7 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
                        const double *__restrict__ wj, const DpBatch batch, int K, int BS, int64_t n_units,
                        unsigned char *__restrict__ bp_all, int64_t *__restrict__ path_all,
                        int64_t *__restrict__ path_len_all, double *__restrict__ cost_all,
-                       unsigned long long *__restrict__ stats)
+                       unsigned long long *__restrict__ stats, const float *__restrict__ scale_all, float ceps)
 {
     __builtin_amdgcn_s_setprio(3);           // as viterbi_lb_kernel
     const int64_t r0 = batch.off[blockIdx.x];
@@ -1077,6 +1176,7 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
     const int64_t *__restrict__ cand = cand_all + r0 * K;
     const JfRecord *__restrict__ rec = rec_all + r0 * K;
     const float *__restrict__ Jlo = Jlo_all + r0 * K * K;
+    const float *__restrict__ scale = scale_all + r0;
     unsigned char *__restrict__ bp_global = bp_all + r0 * K;
     int64_t *__restrict__ path = path_all + r0;
     int64_t *__restrict__ path_len = path_len_all + batch.first + blockIdx.x;
@@ -1238,6 +1338,10 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const int stride = (Dj + 2) | 1;                        // odd: the summing lanes read different banks
                 const int npr = JF1_SQ / stride < 64 ? JF1_SQ / stride : 64;
+                const float *__restrict__ jslab = Jlo + (t - 1) * (int64_t)K * K;
+                int tviol = 0;                                          // tripwire of pass 1's bounds: every exact cost against its bound
+                float tmin = __builtin_inff();
+                const double tsc = (double)scale[t - 1], tunit = 2.0 * (double)ceps * tsc * tsc;
                 auto flush = [&]() {
                     for (int r0 = 0; r0 < np; r0 += npr) {
                         const int nr = np - r0 < npr ? np - r0 : npr;
@@ -1270,7 +1374,10 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
                                 for (int i = 0; i < 8; ++i) acc = __dadd_rn(acc, v[i]);
                             }
                             for (; cc < Dj; ++cc) acc = __dadd_rn(acc, row[cc]);
-                            totr = __dadd_rn(dprev[plist[r0 + lane] & 0xffu], __dsqrt_rn(acc));
+                            const double cex = __dsqrt_rn(acc);
+                            const unsigned int pe = plist[r0 + lane];
+                            totr = __dadd_rn(dprev[pe & 0xffu], cex);
+                            if (stats) jf_trip_check(cex, jslab[(int64_t)(pe & 0xffu) * K + (pe >> 8)], tunit, tviol, tmin);
                         }
                         for (int r = 0; r < nr; ++r) {              // in list order: a column's candidates one after the other
                             const double tr = jf_readlane_f64(totr, r);
@@ -1289,7 +1396,6 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
                     np = 0;
                 };
                 const int total = nf * K;
-                const float *__restrict__ jslab = Jlo + (t - 1) * (int64_t)K * K;
                 for (int base = 0; base < total; base += 256) {     // four rounds of 64 pairs: their loads in flight together
                     bool want[4];
                     unsigned int e[4];
@@ -1321,9 +1427,12 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
                     if (fail[c]) { best[c] = rbest[kc[c]]; arg[c] = rarg[kc[c]]; d[c] = __dadd_rn(td[c], best[c]); }
-                if (stats && lane == 0) {
-                    atomicAdd(&stats[0], (unsigned long long)nf); atomicAdd(&stats[1], 1ull);
-                    if (n_exact) atomicAdd(&stats[2], (unsigned long long)n_exact);
+                if (stats) {
+                    if (lane == 0) {
+                        atomicAdd(&stats[0], (unsigned long long)nf); atomicAdd(&stats[1], 1ull);
+                        if (n_exact) atomicAdd(&stats[2], (unsigned long long)n_exact);
+                    }
+                    jf_trip_commit(stats, tviol, tmin);
                 }
             }
 #pragma unroll
@@ -1444,7 +1553,7 @@ static void jf_trace_dump(unsigned long long *stats, int n, int64_t T, hipStream
 void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jlo, const float *JC_unw, int Jp, int Dj,
                            const double *wj, const int64_t *off, int n_utts, int first_utt, int K, int64_t n_units,
                            unsigned char *bp_global, int64_t *path, int64_t *path_len, double *cost,
-                           unsigned long long *stats, hipStream_t s)
+                           unsigned long long *stats, hipStream_t s, const float *scale, float ceps)
 {
     for (int u0 = 0; u0 < n_utts; u0 += DpBatch::MAX) {
         const int n = (n_utts - u0 < DpBatch::MAX) ? n_utts - u0 : DpBatch::MAX;
@@ -1469,7 +1578,7 @@ void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jl
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024)); });         \
         hipLaunchKernelGGL((viterbi_sparse1_kernel<NC_, BPL_>), dim3(n), dim3(128), shmem1, s, cand,              \
                            reinterpret_cast<const JfRecord *>(rec), Jlo, JC_unw, Jp, Dj, wj, batch, K, bs1, n_units, \
-                           bp_global, path, path_len, cost, stats);                                               \
+                           bp_global, path, path_len, cost, stats, scale, ceps);                                  \
     }
             if (nc == 1) { if (bpl1) SNK_SP1(1, true) else SNK_SP1(1, false) }
             else if (nc == 2) { if (bpl1) SNK_SP1(2, true) else SNK_SP1(2, false) }
@@ -1494,7 +1603,7 @@ void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jl
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024)); });         \
         hipLaunchKernelGGL((viterbi_sparse_kernel<BS_, BPL_>), dim3(n), dim3(nth), shmem, s, cand,                \
                            reinterpret_cast<const JfRecord *>(rec), Jlo, JC_unw, Jp, Dj, wj, batch, K, n_units,   \
-                           bp_global, path, path_len, cost, stats);                                               \
+                           bp_global, path, path_len, cost, stats, scale, ceps);                                  \
     }
         if (bs == 4) { if (bp_in_lds) SNK_SP(4, true) else SNK_SP(4, false) }
         else { if (bp_in_lds) SNK_SP(2, true) else SNK_SP(2, false) }

@@ -1842,7 +1842,8 @@ size_t knn_coarse_pair_bytes() { return sizeof(CoarsePair); }
 // zeroed by the caller (knn_reset)
 bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32, const float *thr1,
                           int64_t T32, int64_t n_tiles, unsigned int *ctr, void *pairs, unsigned int *pair_ctl, unsigned int pair_cap,
-                          void *pool, unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s, bool run_coarse)
+                          void *pool, unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s, bool run_coarse,
+                          bool run_refine)
 {
     const int nQT = (int)(T32 / 32);
     const int wps = (dch == 1 && coarse_wps() == 2) ? 2 : 1;
@@ -1865,9 +1866,10 @@ bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, con
                        (const u32x4 *)A16, (const u32x4 *)B16, thr32, (const CoarsePair *)pairs, pair_ctl, pair_cap, \
                        (PoolEntry16 *)pool, pool_ctl, chunk_fill, max_chunks, pool_chunk)
     // run_coarse false: the pair list is already there (the ball pass wrote it)
-    if (dch == 1) { if (run_coarse) { if (wps == 2) SNK_C16(4, 4, 2); else SNK_C16(8, 4, 1); } if (terms == 4) SNK_R16(4, 4); else SNK_R16(4, 3); return true; }
-    if (dch == 2) { if (run_coarse) SNK_C16(4, 8, 1); if (terms == 4) SNK_R16(8, 4); else SNK_R16(8, 3); return true; }
-    if (dch == 3) { if (run_coarse) SNK_C16(4, 12, 1); if (terms == 4) SNK_R16(12, 4); else SNK_R16(12, 3); return true; }
+    // run_refine false: the coarse sweep alone, as a probe that only COUNTS the pairs it would list (pair_cap 0)
+    if (dch == 1) { if (run_coarse) { if (wps == 2) SNK_C16(4, 4, 2); else SNK_C16(8, 4, 1); } if (!run_refine) return true; if (terms == 4) SNK_R16(4, 4); else SNK_R16(4, 3); return true; }
+    if (dch == 2) { if (run_coarse) SNK_C16(4, 8, 1); if (!run_refine) return true; if (terms == 4) SNK_R16(8, 4); else SNK_R16(8, 3); return true; }
+    if (dch == 3) { if (run_coarse) SNK_C16(4, 12, 1); if (!run_refine) return true; if (terms == 4) SNK_R16(12, 4); else SNK_R16(12, 3); return true; }
 #undef SNK_C16
 #undef SNK_R16
     return false;

@@ -908,7 +908,10 @@ __device__ __forceinline__ int block_incl_scan_256(int v, int *wsum /* LDS [4] *
 // compute unit instead of three -- a row is a 40 us critical path, so the kernel's time goes with the occupancy); the unit ids
 // of the selected entries are read from the list in global memory.  Rows the value-binned selection cannot serve (short lists,
 // one-valued lists, more near ties than the selection holds) are flagged in `retry` and left to a second launch of the full form.
-template <int CLASS, bool F32K, bool LEAN = false>
+// SELX > 0: the instance for the rows that hold more near ties than SEL_MAX (retry[row] == 2, left by the full form when the
+// launch has a big tier): a selection of SELX entries -- every list fits -- on 97 KB of LDS, for the few rows of a voice whose
+// units are so dense in key space that thousands of them lie inside the key margin (12 M units of SURVEY 8d's walk).
+template <int CLASS, bool F32K, bool LEAN = false, int SELX = 0>
 __global__ void __launch_bounds__(256)
 knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_unw, int Fp,
                     const double *__restrict__ wt, int Dpad, int D, const double *__restrict__ Qp,
@@ -919,12 +922,13 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
                     const double *__restrict__ cq,
                     int64_t *__restrict__ cand, double *__restrict__ dist,
                     double *__restrict__ d2_out, int *__restrict__ status, int *__restrict__ rowflag,
-                    const double *__restrict__ thr, unsigned int *__restrict__ margin_stat, int *__restrict__ retry)
+                    const double *__restrict__ thr, unsigned int *__restrict__ margin_stat, int *__restrict__ retry,
+                    int big_tier)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int SELM = (CLASS == 1) ? FIN_SMALL : SEL_MAX;
+    constexpr int SELM = SELX ? SELX : (CLASS == 1) ? FIN_SMALL : SEL_MAX;
     const int64_t row = blockIdx.x;
-    if (!LEAN && retry && !retry[row]) return;              // second launch: only the rows the lean form left
+    if (!LEAN && retry && (SELX ? retry[row] != 2 : retry[row] != 1)) return;     // second / third launch: only the rows the form before left
     const int n_all = cnt[row];
     if (CLASS == 1 && n_all > FIN_SMALL) return;
     if (CLASS == 2 && n_all <= FIN_SMALL) return;
@@ -1049,11 +1053,15 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
                 const double kth = (double)key[kk - 1];
                 const double delta = 1e-10 * (fabs(kth) + qnorm[row] + 1.0) + margin;
                 while (ns < n && ns < SELM && (double)key[ns] <= kth + delta) ++ns;
-                if (ns == SELM && ns < n && (double)key[ns] <= kth + delta) { atomicOr(status, 2); if (rowflag) rowflag[row] = 2; }
+                if (ns == SELM && ns < n && (double)key[ns] <= kth + delta) {
+                    if (!SELX && big_tier && retry) { retry[row] = 2; ns = -1; }      // more near ties than this form holds: the big tier's row
+                    else { atomicOr(status, 2); if (rowflag) rowflag[row] = 2; }
+                }
             }
             n_sel_s = ns;
         }
         __syncthreads();
+        if (n_sel_s < 0) return;                                                  // uniform
         for (int e = threadIdx.x; e < n_sel_s; e += blockDim.x) ex_idx[e] = idx[e];
         __syncthreads();
     }
@@ -1129,7 +1137,7 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
                          int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c, const double *cq,
                          int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s, bool split_short,
-                         const double *thr, unsigned int *margin_stat, int *retry)
+                         const double *thr, unsigned int *margin_stat, int *retry, bool big_tier)
 {
     int P = 2;
     while (P < cap) P <<= 1;
@@ -1145,16 +1153,28 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
 #undef SNK_FIN_ATTR
     });
 #define SNK_FIN(C_, F_, SH_) hipLaunchKernelGGL((knn_finalize_kernel<C_, F_>), dim3((unsigned)T), dim3(256), SH_, s, Fw, F_unw, Fp, wt, Dpad, D, Qp, \
-                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, nullptr)
+                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, nullptr, 0)
     if (f32k && retry && !split_short && !rowflag) {
         // the lean form for (nearly) every row, the full form for the rows it flags
         size_t lean = (size_t)P * sizeof(float);
         if (lean < (size_t)SEL_MAX * sizeof(double)) lean = (size_t)SEL_MAX * sizeof(double);
         (void)hipMemsetAsync(retry, 0, (size_t)T * sizeof(int), s);
         hipLaunchKernelGGL((knn_finalize_kernel<0, true, true>), dim3((unsigned)T), dim3(256), lean, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
-                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry);
+                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, 0);
+        const int big = (big_tier && cap <= 8192) ? 1 : 0;
         hipLaunchKernelGGL((knn_finalize_kernel<0, true, false>), dim3((unsigned)T), dim3(256), shmem, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
-                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry);
+                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, big);
+        if (big) {
+            // third tier (a voice that has overflowed before: api_knn.hip knn_level): the rows with more near ties than SEL_MAX
+            size_t shbig = (size_t)P * (sizeof(float) + sizeof(int));
+            if (shbig < (size_t)8192 * sizeof(double)) shbig = (size_t)8192 * sizeof(double);
+            static size_t attr_big[32] = {0};
+            lds_attr_ensure(attr_big, shbig, [&] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_finalize_kernel<0, true, false, 8192>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shbig); });
+            hipLaunchKernelGGL((knn_finalize_kernel<0, true, false, 8192>), dim3((unsigned)T), dim3(256), shbig, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
+                               qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, 0);
+        }
         return;
     }
     if (split_short && K <= FIN_SMALL / 2 && cap > FIN_SMALL) {

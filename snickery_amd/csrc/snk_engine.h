@@ -178,6 +178,10 @@ struct BatchSlot {    // one submitted batch (snk_knn_viterbi_batch_submit / _co
     std::vector<int64_t> q_offs;
     double ball_limit = -1.0;             // >= 0: the ball pass listed this batch's tile pairs; beyond this many the voice goes to the coarse sweep
     double coarse_limit = -1.0;           // >= 0: the coarse sweep listed them; beyond this many the voice goes to the one-pass sweep
+    std::vector<int> probe_kind;          // per group: the counting probe its K-NN call carried (0 none, 1 ball pass, 2 coarse sweep)
+    std::vector<double> probe_limit;
+    int64_t seq = -1;                     // number of this batch (timing events of the Viterbi latch)
+    bool vit_dense = false, vit_trial = false, vit_judged = false;
     int64_t total = 0;
     std::vector<int> first;
     std::vector<int64_t> offs;
@@ -264,6 +268,15 @@ struct snk_engine {
     // to list, nothing to overflow (an overflowing pair list sent every group of every step through the exact float64 redo)
     bool filter_onepass = false;
     double onepass_gate_fraction = 0.5, coarse_limit = 0.0;
+    // The two latches are re-armable (option latch_rearm, default 1).  A voice that sits on a slower filter is probed now and then
+    // with the pass it left, in a form that only COUNTS the tile pairs it would list (pair_cap 0: no list, no refine pass): the ball
+    // pass for a voice on the coarse sweep (a thirtieth of the database), the coarse sweep for a voice on the one-pass sweep.  A count
+    // under half the limit that made the voice leave takes it back; a count above doubles the probe period (16 .. 256 calls).
+    int latch_rearm = 1;
+    int64_t filter_calls = 0, probe_next = 16;
+    int probe_period = 16, probe_ran = 0;
+    double probe_limit = 0.0;
+    int64_t filter_rearms = 0;
     bool coarse_pass_ran = false;
     int onepass_switches = 0;
     int64_t ball_switches = 0;
@@ -278,6 +291,13 @@ struct snk_engine {
     DevBuf gs_tiles_b, cq16, rho16, gs_rho16;   // per-row split coefficient; dropped-piece ratios of the operands
     int f16_fallbacks = 0;
     int last_f16_status = 0;
+    // A voice whose candidate lists overflow under the prefilter's thresholds (status bit 1) climbs a ladder instead of going to
+    // the float64 sweep call after call: 0 = the shape's default (bf16-split operands, lists of 40 K entries, 2 048 near ties in the exact
+    // re-rank), 1 = lists of 8 192 entries and a re-rank tier that takes 8 192 near ties, 2 = the float32 operands (their key error is a third of the bf16-split one: fewer units inside the margin) with
+    // lists of 8 192.  Seen at N = 12 M units of SURVEY 8d's generator: consecutive units are 3e-6 apart in d^2 there, the lists
+    // grow with the units inside the key margin (2 082 entries at most at 1 M, 3 614 at 8 M, > 4 000 at 12 M).  Per set of weights.
+    int knn_level = 0;
+    int64_t knn_escalations = 0;
     HostBuf hstage;
     HostBuf up;                   // upload staging (h2d): pinned, bump-allocated, wraps behind a stream wait
     size_t up_used = 0;
@@ -290,7 +310,12 @@ struct snk_engine {
     DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist, gsync, gtiles;
     DevBuf g32_blk, g32_ctl;          // float32 persistent scan: block records + candidate lists, {gen, status}
     DevBuf g32_res;                   // resident scan (greedy_res_kernels.hip): one 16-byte record per workgroup
-    int64_t greedy_last_status[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // status words of the most recent one-launch scan (undecided step + 1, rounds, exact windows, watchdog)
+    int64_t greedy_last_status[16] = {0};   // status words of the most recent one-launch scan (undecided step + 1, rounds, exact windows, watchdog, ...)
+    int greedy_last_kernel = 0;             // which scan wrote them: 1 streamed (greedy32_kernel: [4] speculated, [5] several holders), 2 resident (greedy_res_kernel: [4..7] why)
+    // tripwire of the float32 scans' bound (greedy32_device.h g32_trip; cleared by snk_reset_timers): exact totals that came out further
+    // below the float32 minimum than the bound allows, and the largest share of the bound any weighed window consumed
+    int64_t greedy_bound_violations = 0;
+    double greedy_bound_max_used = 0.0;
     int greedy_fenced = 0;            // 1: cross-check mode of the one-launch scans: agent-scope fences around every hand-off
     int greedy_resident = 1;          // 1: one utterance against a database that fits the chip's LDS takes the resident scan
     int64_t greedy_resident_launches = 0;
@@ -327,6 +352,23 @@ struct snk_engine {
     int batch_rows = 12288;    // rows per K-NN call of the batch entry points (utterances are grouped)
     int viterbi_weights = 0;   // 0: float64 recursion (default); 1: OpenFST's float32 weight chain (fst_functions_wrapped.py:47,201,368,389), dense kernels
     int viterbi_mode = 2;      // 2: auto; 1: f32 lower bounds on the matrix pipe + sparse exact recursion; 0: dense exact join + recursion
+    // viterbi_mode 2, batches: which of the two exact paths a voice's batches take is JUDGED (option viterbi_latch, default 1).  Where
+    // the bounds do not prune -- more than vit_refine_gate of a batch's cells refined in pass 4: join rows with no natural successors --
+    // the dense kernels are tried for three batches and kept if the batch period (stream time between the completions of consecutive
+    // batches) is 5 % shorter; the path not in use is tried again after 32, 64 .. 1 024 batches.  Same results either way.
+    int viterbi_latch = 1;
+    double vit_refine_gate = 0.01;
+    struct VitLatch {
+        int mode = 0, trial_mode = -1, trial_left = 0;      // 0 sparse, 1 dense
+        double ms_row[2] = {0.0, 0.0}, trial_best = 0.0;
+        int64_t batches = 0, next_probe = 4, switches = 0, trials = 0;
+        int period = 32;
+    } vit;
+    bool vit_now_dense = false;                             // the batch being submitted takes the dense kernels
+    hipEvent_t vit_t0[4] = {nullptr, nullptr, nullptr, nullptr}, vit_t1[4] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t vit_seq = 0;                                    // batches submitted (ring index of the timing events)
+    int64_t vit_last_collected = -1;
+    unsigned long long vit_cells_prev = 0;
     double join_beta = 5e-4;   // pass-2 margin in units of the step's largest centred norm (speed only, never the result)
     // pass 2 (approximate recursion) in chunks of viterbi_lb_chunk steps side by side (0: one chain per utterance), each
     // started viterbi_lb_warm steps early; launches of up to viterbi_lb_chunk_max_utts utterances (24 = all).  A single
@@ -339,6 +381,7 @@ struct snk_engine {
     // built at the first sparse recursion after snk_set_weights; [0] of jw_umax: bits of the largest row norm
     DevBuf JW32, jw_umax;
     bool jw32_ready = false;
+    double join_lb_test_scale = 1.0;   // test hook: pass 1's bounds times this factor (> 1: no bounds any more -- the tripwire must fire)
     int join_lb_variant = 1;   // 1: bf16 matrix pipe over the weighted float32 copy (default); 0: float32 matrix pipe, weights applied per gather
     int pool_chunk_limit = 0;  // test hook: cap of the entry pool (chunks) in every attempt; 0 = none
     int pool_chunks = 4096;    // entry pool: 4096 chunks x 2048 entries x 16 B = 128 MiB      // left free by the persistent K-NN sweep for Viterbi DP blocks
@@ -402,11 +445,15 @@ inline int roundup(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); 
 // K-NN pipeline on the device (api_knn.hip)
 KnnPlan make_plan(snk_engine *h, int K);
 void note_ball_pairs(snk_engine *h, unsigned int listed);
+// what a call's filter listed (listed) and what its counting probe would have (probe_listed; kind 0: none), judged at a host wait
+void judge_filter(snk_engine *h, bool ran_balls, double ball_limit, bool ran_coarse, double coarse_limit, unsigned int listed,
+                  int probe_kind, double probe_limit, unsigned int probe_listed);
 int upload_queries(snk_engine *h, const double *Q, int64_t T, int D);
 int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_t *qclass_dev,
                int64_t *cand_dev, double *dist_dev, double *d2_dev, int *deferred_status = nullptr,
                const double *bound_in = nullptr, double *bound_out = nullptr, bool gs = false, bool refine = false,
-               unsigned int *pairs_listed_dev = nullptr);
+               unsigned int *pairs_listed_dev = nullptr,      // with deferred_status: receives the tile pairs the first pass listed
+               unsigned int *probe_listed_dev = nullptr);     // ... and what the call's counting probe would have listed (0xffffffff: no probe)
 
 // Viterbi side of a group of utterances (api_viterbi.hip)
 bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts = 1);

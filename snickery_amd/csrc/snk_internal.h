@@ -114,7 +114,8 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
                          int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s,
                          bool split_short = false,    // split_short: rows of at most 512 entries through the small-LDS instance
                          const double *thr = nullptr, unsigned int *margin_stat = nullptr,    // tripwire of the prefilter's key bound
-                         int *retry = nullptr);     // T ints of scratch: the lean form (keys only in LDS) first, the full form for the rows it flags
+                         int *retry = nullptr,      // T ints of scratch: the lean form (keys only in LDS) first, the full form for the rows it flags
+                         bool big_tier = false);    // ... and a third form (selection of 8 192) for the rows with more near ties than the full form holds
 void launch_candidate_dist(const double *Fw, int Dpad, int D, int64_t N, const double *Qp,
                            const int64_t *cand, int64_t T, int K, double *dist, hipStream_t s);
 void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, int K,
@@ -170,7 +171,8 @@ size_t knn_coarse_pair_bytes();
 bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, const void *B16, const float *thr32, const float *thr1,
                           int64_t T32, int64_t n_tiles, unsigned int *ctr, void *pairs, unsigned int *pair_ctl, unsigned int pair_cap,
                           void *pool, unsigned int *pool_ctl, int *chunk_fill, int max_chunks, int pool_chunk, hipStream_t s,
-                          bool run_coarse = true);     // false: the pair list is already there (the ball pass wrote it)
+                          bool run_coarse = true,      // false: the pair list is already there (the ball pass wrote it)
+                          bool run_refine = true);     // false: the first pass alone (a probe that counts pairs: pair_cap 0)
 // pass 0: the tiles' balls (centre, radius) against the query rows; lists pairs, then gates the coarse sweep
 void launch_build_tile_balls(const double *Fw, int64_t N, int Dt, int Dpad, int64_t n_tiles, double *C, double *cnorm, float *rad,
                              hipStream_t s);
@@ -223,14 +225,19 @@ void launch_viterbi_lb(const int64_t *cand, const double *tdist, const float *Jl
                        int n_utts, int K, int64_t n_units, float beta, void *sets, hipStream_t s,
                        int chunk_len = 0, int warm = 32);   // chunk_len > 0: the approximate recursion in chunks of that many steps, side by side
 size_t join_record_bytes();
+// Jlo / scale / ceps / stats (pass 3 and pass 4): the tripwire of pass 1's bounds -- every exact cost computed is held against the
+// bound of its cell: stats[4] += cells with lo > exact, stats[5] = smallest margin (joinfast_kernels.hip); ceps from join_lb_ceps
+double join_lb_ceps(int variant, int Dj, int K);
+void launch_scale_f32(float *x, int64_t n, float f, hipStream_t s);      // test hook (option join_lb_test_scale)
 void launch_join_exact_sparse(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
-                              const double *tdist, int64_t R, int K, const void *sets, void *rec, hipStream_t s);
+                              const double *tdist, int64_t R, int K, const void *sets, void *rec, hipStream_t s,
+                              const float *Jlo = nullptr, const float *scale = nullptr, float ceps = 0.f, unsigned long long *stats = nullptr);
 void set_join_exact_form(int f);           // 1 (default): cooperative pass 3 (rows in coalesced chunks through LDS); 0: a lane per cell
 void set_viterbi_sparse_waves(int w);      // 1 (default) or 4: which form of pass 4 launch_viterbi_sparse runs (same results)
 void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jlo, const float *JC_unw, int Jp, int Dj,
                            const double *wj, const int64_t *off, int n_utts, int first_utt, int K, int64_t n_units,
                            unsigned char *bp_global, int64_t *path, int64_t *path_len, double *cost,
-                           unsigned long long *stats, hipStream_t s);
+                           unsigned long long *stats, hipStream_t s, const float *scale, float ceps);
 
 // ---- greedy ---------------------------------------------------------------
 struct GreedyLayout {

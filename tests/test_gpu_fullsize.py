@@ -287,6 +287,10 @@ def test_baseline_shapes_stay_on_the_fast_path(engine, N, Dt, Dj, T, K, U):
     # filter threshold -- a 2x violation of the bf16 accumulation assumption would not have changed these results
     assert engine.info('prefilter_margin_rows') == 0, engine.info('prefilter_min_margin')
     assert engine.info('prefilter_min_margin') >= 2.0
+    # ... and of the join bounds of the sparse Viterbi path (joinfast_kernels.hip): every exact join cost the recursion computed was
+    # held against the float32 lower bound of its cell -- none came out below it, and the smallest margin is positive
+    assert engine.info('join_bound_violations') == 0, engine.info('join_bound_min_margin')
+    assert engine.info('join_bound_min_margin') > 0.0
     engine.set_option('precision', 0)
     try:
         engine.set_weights(wt, wj)

@@ -70,6 +70,8 @@ def test_b1_full_utterance(engine):
     for u, st, p, d in zip(utts, starts, paths, dists):
         op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, u, 6, False, 0, st)
         assert p == op and np.array_equal(d, od)
+    assert engine.info('greedy_bound_violations') == 0, engine.info('greedy_bound_max_used')      # (resident + streamed scans of this test)
+    assert engine.info('greedy_bound_max_used') <= 1.0
 
 
 @pytest.mark.parametrize('me', [6, 5])
@@ -79,6 +81,7 @@ def test_b3_nick_size(engine, me):
     F_unw, JC_unw, wt, wj = _voice(N, 80 + me, dup=(200000, 1100000, 900))
     engine.upload_db(F_unw, JC_unw)
     engine.set_weights(wt, wj)
+    engine.reset_timers()                         # (also the tripwire of the scan's bound)
     engine.set_greedy_layout(me, False, 0)
     U = o.synthetic_targets(F_unw, 600, seed=81) * wt
     n16, nh = engine.info('greedy_f16_launches'), engine.info('greedy_hoist_launches')
@@ -99,3 +102,7 @@ def test_b3_nick_size(engine, me):
     for u, st, p, d in zip(utts, starts, paths, dists):
         op, od = oc.greedy_f32(F_unw, JC_unw, wt, wj, u, me, False, 0, st)
         assert p == op and np.array_equal(d, od)
+    # tripwire of the scan's bound (float16 tiles + target values from the bf16 pipe: the probed accumulation property): every exact
+    # total weighed in these steps stayed within the bound of the float32 minimum, and windows WERE weighed
+    assert engine.info('greedy_bound_violations') == 0, engine.info('greedy_bound_max_used')
+    assert 0.0 < engine.info('greedy_bound_max_used') <= 1.0

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import snk_oracle as o
+import snk_oracle_c as oc
 
 pytestmark = pytest.mark.gpu
 
@@ -84,3 +85,38 @@ def test_natural_successors_and_repeated_calls(engine):
         assert (np.diagonal(J, axis1=1, axis2=2) == 0.0).all()
         assert (np.diagonal(lo, axis1=1, axis2=2) == 0.0).all()
         assert (lo.astype(np.float64) <= J).all()
+
+
+def test_tripwire_of_the_join_bounds_counts_what_it_should(engine):
+    """Every exact join cost the sparse recursion computes is held against the float32 bound of its cell
+    (joinfast_kernels.hip: join_bound_violations, join_bound_min_margin).  Honest bounds: no violation, a positive margin, over
+    shapes and both forms of pass 1.  Bounds multiplied by 1.5 (test hook) are no bounds: the tripwire must say so."""
+    N, Dj, T, K = 60000, 302, 200, 100
+    F_unw, JC_unw = o.synthetic_db(N, 61, Dj, seed=9)
+    wt, wj = np.full(61, 0.4), np.full(Dj, 0.05)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    rng = np.random.RandomState(3)
+    U = np.vstack([o.synthetic_targets(F_unw, T // 2, seed=5), F_unw[rng.randint(0, N, T // 2)] + rng.randn(T // 2, 61)]) * wt
+    engine.set_option('viterbi_mode', 1)
+    try:
+        for variant in (1, 0):
+            engine.set_option('join_lb_variant', variant)
+            engine.reset_timers()
+            assert engine.info('join_bound_violations') == 0 and engine.info('join_bound_min_margin') == np.inf
+            path, cost, cand, dist = engine.knn_viterbi(U, K, return_candidates=True)
+            opath, ocost = oc.viterbi(cand, dist, o.weight(JC_unw, wj))
+            assert path == opath and cost == ocost
+            assert engine.info('join_bound_violations') == 0, (variant, engine.info('join_bound_min_margin'))
+            m = engine.info('join_bound_min_margin')
+            assert 0.0 < m < np.inf, (variant, m)
+        engine.set_option('join_lb_variant', 1)
+        engine.set_option('join_lb_test_scale', 1.5)
+        engine.reset_timers()
+        engine.knn_viterbi(U, K)
+        assert engine.info('join_bound_violations') > 0 and engine.info('join_bound_min_margin') < 0.0
+    finally:
+        engine.set_option('join_lb_test_scale', 1.0)
+        engine.set_option('join_lb_variant', 1)
+        engine.set_option('viterbi_mode', 2)
+        engine.reset_timers()

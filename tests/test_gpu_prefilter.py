@@ -267,3 +267,43 @@ def test_batches_on_units_in_no_order_settle_on_the_one_pass_sweep(engine):
             assert list(paths[u]) == single[u][0] and costs[u] == single[u][1]
     assert engine.info('filter_coarse') == 1 and engine.info('filter_onepass') == 1, redos
     assert redos[-1] == 0 and redos[-2] == 0, redos
+
+
+def test_the_filter_latches_are_rearmable(engine):
+    """A voice does not stay on a slower filter for ever (the latches were one-way).  Queries far from every unit make the
+    ball pass list most tile pairs -> the voice goes to the coarse sweep (and on, if that lists most pairs too); queries that follow
+    the database then list next to nothing, and a counting probe of the pass the voice left (every 16 calls) takes it back, one
+    rung at a time.  Results are the oracle's at every stage; `latch_rearm 0` keeps the voice where it is."""
+    engine.set_option('prefilter', 1); engine.set_option('prefilter_two_pass', 1); engine.set_option('prefilter_ball_bound', 0)
+    N, Dt, K, T = 200000, 61, 50, 320
+    F_unw, JC_unw = o.synthetic_db(N, Dt, 8, 11)
+    rng = np.random.RandomState(12)
+    wt, wj = 0.2 + rng.rand(Dt), np.full(8, 0.1)
+    F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    far = (F_unw[rng.randint(0, N, T)] + 6.0 * rng.randn(T, Dt)) * wt          # the K-th neighbour of such a row is far away: wide thresholds
+    near = o.synthetic_targets(F_unw, T, seed=13) * wt
+    for _ in range(3):
+        cand, dist = engine.knn(far, K)
+    oc, od = o.knn_bruteforce(F, far[:24], K)
+    assert np.array_equal(cand[:24], oc) and np.array_equal(dist[:24], od)
+    assert engine.info('filter_coarse') == 1                                   # the ball pass listed too much
+    down = (engine.info('filter_coarse'), engine.info('filter_onepass'))
+    oc, od = o.knn_bruteforce(F, near[:24], K)
+    engine.set_option('latch_rearm', 0)
+    for _ in range(40):
+        cand, dist = engine.knn(near, K)
+    assert (engine.info('filter_coarse'), engine.info('filter_onepass')) == down and engine.info('filter_rearms') == 0
+    engine.set_option('latch_rearm', 1)
+    states = []
+    for _ in range(80):
+        cand, dist = engine.knn(near, K)
+        assert np.array_equal(cand[:24], oc) and np.array_equal(dist[:24], od)
+        states.append((int(engine.info('filter_coarse')), int(engine.info('filter_onepass'))))
+    assert states[-1] == (0, 0), states[::8]                                   # back on the ball pass
+    assert engine.info('filter_rearms') >= 1
+    # ... and down again when the far rows come back
+    for _ in range(3):
+        engine.knn(far, K)
+    assert engine.info('filter_coarse') == 1

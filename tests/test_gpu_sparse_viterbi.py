@@ -220,3 +220,43 @@ def test_viterbi_batch_of_given_candidates_equals_the_single_calls(engine):
         p1, c1 = engine.viterbi(c, d)
         op, oc_ = oc.viterbi(c, d, JCw)
         assert list(paths[u]) == p1 == op and (costs[u] == c1 == oc_ or len(op) == 0)
+
+
+def test_viterbi_latch_judges_the_two_exact_paths_and_keeps_the_results(engine):
+    """viterbi_mode 2, batches (snk_engine.h: vit).  On join rows with natural successors the bounds prune and no trial of the dense
+    kernels is ever started; on join rows in random order (no natural successors: pass 4 refines instead of pruning) the dense
+    kernels are tried and whichever path has the shorter batch period is kept -- paths and costs are the dense path's bit for bit
+    at every stage, and a later trial can bring the other path back (re-armable)."""
+    N, Dj, K = 60000, 151, 60
+    F_unw, JC_unw = o.synthetic_db(N, 61, Dj, seed=17)
+    wt, wj = np.full(61, 0.4), np.full(Dj, 0.05)
+    utts = [o.synthetic_targets(F_unw, T, seed=60 + i) * wt for i, T in enumerate([150, 90, 200, 120])]
+    engine.set_option('viterbi_mode', 2)
+
+    def run(JC, n_batches):
+        engine.upload_db(F_unw, JC)
+        engine.set_weights(wt, wj)
+        engine.set_option('viterbi_mode', 0)
+        ref = engine.knn_viterbi_batch(utts, K)
+        engine.set_option('viterbi_mode', 2)
+        engine.set_weights(wt, wj)                    # the latch starts over
+        pending = None
+        for _ in range(n_batches):
+            tk = engine.knn_viterbi_batch_submit(utts, K)
+            if pending is not None:
+                p, c = engine.knn_viterbi_batch_collect(pending)
+                assert all(np.array_equal(a, b) for a, b in zip(p, ref[0])) and np.array_equal(c, ref[1])
+            pending = tk
+        p, c = engine.knn_viterbi_batch_collect(pending)
+        assert all(np.array_equal(a, b) for a, b in zip(p, ref[0])) and np.array_equal(c, ref[1])
+        return engine.info('viterbi_latch_trials'), engine.info('viterbi_latch_mode')
+
+    trials, mode = run(JC_unw, 24)
+    assert trials == 0 and mode == 0                  # natural successors: the sparse path is never questioned
+    perm = np.random.RandomState(5).permutation(N + 1)
+    trials, mode = run(JC_unw[perm], 48)
+    assert trials >= 1, (trials, mode)                # no natural successors: the dense kernels got their trial (either may win)
+    engine.set_option('viterbi_latch', 0)
+    trials, mode = run(JC_unw[perm], 12)
+    assert trials == 0 and mode == 0
+    engine.set_option('viterbi_latch', 1)

@@ -135,8 +135,8 @@ def main():
             oc_cand, oc_dist = oc.knn(F, U[rows], K)
             t_or = time.time() - t0
             knn_ok = bool(np.array_equal(cand[rows], oc_cand) and np.array_equal(dist[rows], oc_dist))
-            assert not np.any((cand == 0) | (cand == N - 1)), 'a candidate at either end of the database: the compact renumbering would change its status'
             JCc, pos = compact_join(JC_unw, wj, cand)
+            pos[(cand < 1) | (cand >= N - 1)] = 0          # unusable in the reference (first / last unit): unusable after the renumbering too
             opath, ocost = oc.viterbi(pos, dist, JCc)
             back = dict(zip(pos.reshape(-1).tolist(), cand.reshape(-1).tolist()))
             opath = [back[p] for p in opath]
