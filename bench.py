@@ -52,6 +52,29 @@ def synthetic_targets(F_unw, T, seed, noise=0.3):
     return F_unw[s:s + T].astype(np.float64) + noise * rng.randn(min(T, N - s), Dt)
 
 
+def _sha256(path):
+    import hashlib
+    try:
+        with open(path, 'rb') as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None
+
+
+def profiled_counters(json_name, kernel_source):
+    """Counters of a committed rocprofv3 --pmc pass (profiles/<json_name>; separate passes of the kernel and shape named there, never
+    measured in the bench run itself).  They describe the kernel AS IT WAS PROFILED: the file carries the sha256 of the kernel's
+    source at that time (`source_sha256`), and only while the source is still that one do the values count as this build's
+    (`fresh`); otherwise the caller reports them under `profiled_reference` and leaves `traffic` null."""
+    path = os.path.join(ROOT, 'profiles', json_name)
+    if not os.path.isfile(path):
+        return None, False
+    with open(path) as f:
+        tj = json.load(f)
+    now = _sha256(os.path.join(ROOT, 'snickery_amd', 'csrc', kernel_source))
+    return tj, bool(tj.get('source_sha256')) and tj.get('source_sha256') == now
+
+
 def _cpu_model():
     try:
         with open('/proc/cpuinfo') as f:
@@ -220,6 +243,7 @@ def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')),
                             '(SURVEY 8d): %s; frac_at_4_bytes_per_element prices the float32 database as uploaded'
                             % ('float16 tiles, s = 2' if f16 else 'float32 tiles, s = 4')}
         out[name] = {'units': N, 'multiepoch': me, 'frames': T, 'steps': steps, 'us_per_step': us_step, 'batch': batch,
+                     'bound_violations': eng.info('greedy_bound_violations'), 'bound_max_used': eng.info('greedy_bound_max_used'),
                      'target_term_hoisted': bool(hoisted), 'target_term_pipe': ('bf16 x 3 pieces' if eng.info('greedy_hoist16_launches') > 0 else 'float64') if hoisted else None,
                      'join_tiles': 'float16' if f16 else 'float32',
                      'frames_per_s': T / dt, 'ms_per_utterance': dt * 1e3, 'roofline': roof,
@@ -246,39 +270,107 @@ def variant_database(kind, N, Dt, F_unw, JC_unw, seed=0):
     return (F / F.std()).astype(np.float32), JC_unw
 
 
-def variant_leg(eng, kind, N, Dt, Dj, T, U, K, wt, wj, F_unw, JC_unw, steps):
-    """B* on one of the variant databases, two steps in flight, rows resident: an extra field, never `value`."""
+def leg_roofline(tm, steps, rows_per_step, N, Dt, Dj, K, eng):
+    """Roofline of the dominant whole-chip kernel of a leg, from the engine's HIP-event stage timers (each stage timed on the stream
+    it is launched on, inside the timed steps): the larger, by time per step, of
+      * the filter stage (matrix pipe): what the bf16 pipe ISSUES -- the one-pass sweep 3 terms x 2 rows N Dpad; the coarse sweep one
+        term of that + 3 terms for the listed tile pairs; the ball pass the centres (N / 32) + the listed pairs -- over its time,
+        against the dense bf16 peak;
+      * join_lb2_kernel (HBM): 2 K rows of Dj float32 gathered + K^2 float32 bounds written per row pair, against 8 TB/s.
+    The T-step recursions are latency chains (no roofline); `largest_stage` names the stage with the largest time per step of all."""
+    def per_step(name):
+        return tm[name][0] / steps if name in tm and tm[name][1] else 0.0
+    def per_launch(name):
+        return tm[name][0] / tm[name][1] if name in tm and tm[name][1] else 0.0
+    out = {}
+    dpad = (Dt + 3 + 63) // 64 * 64
+    f_ms, f_n = per_launch('knn_filter'), (tm['knn_filter'][1] / steps if 'knn_filter' in tm and tm['knn_filter'][1] else 0)
+    filt = None
+    if f_ms > 0 and eng.info('prefilter_bf16_active') == 1:
+        rows = rows_per_step / max(f_n, 1)
+        onepass, coarse = eng.info('filter_onepass') == 1, eng.info('filter_coarse') == 1
+        pairs = 0.0 if onepass else eng.info('coarse_pairs')
+        if onepass:
+            issued, kname = 3 * 2.0 * rows * N * dpad, 'knn_sweep16b<filter> (one-pass three-term sweep)'
+        elif coarse:
+            issued, kname = 2.0 * rows * N * dpad + 3 * 2.0 * pairs * 1024 * dpad, 'knn_coarse16b + knn_refine16b'
+        else:
+            issued, kname = 3 * 2.0 * rows * (N / 32.0) * dpad + 3 * 2.0 * pairs * 1024 * dpad, 'knn_balls16b + knn_refine16b'
+        tf = issued / (f_ms * 1e-3) / 1e12
+        filt = {'kernel': kname, 'bound': 'mfma', 'achieved': tf, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s (issued)', 'frac': tf / BF16_MFMA_PEAK_TFLOPS,
+                'algorithmic_tflops': 2.0 * rows * N * Dt / (f_ms * 1e-3) / 1e12, 'avg_launch_ms': f_ms, 'ms_per_step': per_step('knn_filter'),
+                'tile_pairs_fraction': None if onepass else pairs / max((rows / 32.0) * (N / 32.0), 1.0)}
+    j_ms = per_launch('join_lower_bounds')
+    join = None
+    if j_ms > 0:
+        jn = tm['join_lower_bounds'][1] / steps
+        jrows = rows_per_step / max(jn, 1)
+        jbytes = jrows * K * 2 * Dj * 4 + jrows * K * K * 4
+        gbs = jbytes / (j_ms * 1e-3) / 1e9
+        join = {'kernel': 'join_lb2_kernel', 'bound': 'hbm', 'achieved': gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0,
+                'avg_launch_ms': j_ms, 'ms_per_step': per_step('join_lower_bounds')}
+    cands = [c for c in (filt, join) if c]
+    if cands:
+        out = dict(max(cands, key=lambda c: c['ms_per_step']))
+        other = [c for c in cands if c is not out and c['kernel'] != out['kernel']]
+        if other:
+            out['other'] = {'kernel': other[0]['kernel'], 'frac': other[0]['frac'], 'ms_per_step': other[0]['ms_per_step']}
+    stages = dict((k, v[0] / steps) for k, v in tm.items() if v[1])
+    if stages:
+        big = max(stages, key=stages.get)
+        out['largest_stage'] = {'stage': big, 'ms_per_step': stages[big],
+                                'note': 'a T-step latency chain on one wavefront per utterance: no roofline' if big in ('viterbi_sparse', 'viterbi_lower_bound', 'viterbi_dp') else None}
+    return out
+
+
+def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', host_to_host=False):
+    """One BASELINE shape (or B* on a variant database) through the batch pipeline, two steps in flight, rows resident in HBM: frames/s,
+    stage times, the dominant kernel's roofline, fallbacks and tripwires.  An extra field of the JSON line, never `value`."""
     import snickery_amd
-    Fv, JCv = variant_database(kind, N, Dt, F_unw, JC_unw)
-    eng.upload_db(Fv, JCv)
-    eng.set_weights(wt, wj)
-    batch = snickery_amd.QueryBatch([synthetic_targets(Fv, T, seed=1 + u) * wt for u in range(U)])
-    batch.pin()
-    for _ in range(3):                           # primes both workspaces; the engine decides ball pass / coarse sweep for the voice
-        eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(batch, K))
-    before = (eng.info('f16_fallbacks'), eng.info('batch_redos'))
-    eng.reset_timers()
     import torch
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pending = None
-    for _ in range(steps):
-        tk = eng.knn_viterbi_batch_submit(batch, K, resident=True)
-        if pending is not None:
-            eng.knn_viterbi_batch_collect(pending)
-        pending = tk
-    eng.knn_viterbi_batch_collect(pending)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    N, Dt = F_unw.shape
+    Dj = JC_unw.shape[1]
+    eng.upload_db(F_unw, JC_unw)
+    eng.set_weights(wt, wj)
+    batch = snickery_amd.QueryBatch([synthetic_targets(F_unw, T, seed=1 + u) * wt for u in range(U)])
+    batch.pin()
+    for _ in range(4):                           # primes both workspaces; the engine judges the voice (filter passes, Viterbi path)
+        eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(batch, K))
+    before = (eng.info('f16_fallbacks'), eng.info('batch_redos'), eng.info('exact_row_fallbacks'))
+    eng.reset_timers()
+
+    def run(resident):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pending = None
+        for _ in range(steps):
+            tk = eng.knn_viterbi_batch_submit(batch, K, resident=resident)
+            if pending is not None:
+                eng.knn_viterbi_batch_collect(pending)
+            pending = tk
+        res = eng.knn_viterbi_batch_collect(pending)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, res
+    dt, _ = run(True)
     tm = eng.timers()
-    rows_per_launch = T * U / max(tm['knn_filter'][1] / steps, 1)
     pairs = eng.info('coarse_pairs')
-    return {'database': kind, 'frames_per_s': T * U * steps / dt, 'ms_per_step': dt / steps * 1e3, 'steps': steps,
-            'filter_coarse': bool(eng.info('filter_coarse')), 'filter_onepass': bool(eng.info('filter_onepass')),
-            'tile_pairs_listed': {'last_launch': pairs, 'fraction': pairs / max((rows_per_launch / 32.0) * (N / 32.0), 1.0)},
-            'list_mean': eng.info('last_list_mean'), 'list_max': eng.info('last_list_max'),
-            'prefilter_fallbacks': eng.info('f16_fallbacks') - before[0], 'batch_redos': eng.info('batch_redos') - before[1],
-            'stages_ms_per_step': dict((k, v[0] / steps) for k, v in tm.items() if v[1])}
+    rows_per_launch = T * U / max(tm['knn_filter'][1] / steps, 1)
+    out = {'shape': name, 'database': kind, 'units': N, 'target_dim': Dt, 'join_dim': Dj, 'frames': T, 'utts_per_step': U, 'n_candidates': K,
+           'frames_per_s': T * U * steps / dt, 'ms_per_step': dt / steps * 1e3, 'steps': steps,
+           'roofline': leg_roofline(tm, steps, T * U, N, Dt, Dj, K, eng),
+           'filter_coarse': bool(eng.info('filter_coarse')), 'filter_onepass': bool(eng.info('filter_onepass')),
+           'viterbi_path': 'dense' if eng.info('viterbi_latch_mode') == 1 else 'sparse',
+           'tile_pairs_listed': {'last_launch': pairs, 'fraction': pairs / max((rows_per_launch / 32.0) * (N / 32.0), 1.0)},
+           'list_mean': eng.info('last_list_mean'), 'list_max': eng.info('last_list_max'), 'knn_level': eng.info('knn_level'),
+           'prefilter_fallbacks': eng.info('f16_fallbacks') - before[0], 'batch_redos': eng.info('batch_redos') - before[1],
+           'exact_row_fallbacks': eng.info('exact_row_fallbacks') - before[2],
+           'tripwires': {'prefilter_margin_rows': eng.info('prefilter_margin_rows'), 'prefilter_min_margin': eng.info('prefilter_min_margin'),
+                         'join_bound_violations': eng.info('join_bound_violations'), 'join_bound_min_margin': eng.info('join_bound_min_margin')},
+           'stages_ms_per_step': dict((k, v[0] / steps) for k, v in tm.items() if v[1])}
+    if host_to_host:
+        dth, _ = run(False)
+        out['host_to_host_frames_per_s'] = T * U * steps / dth
+    return out
 
 
 def main():
@@ -298,6 +390,7 @@ def main():
     ap.add_argument('--no-greedy', action='store_true', help='skip the greedy configs (extra fields greedy_b1 / greedy_b3)')
     ap.add_argument('--no-cpu-all-cores', action='store_true', help='skip the all-cores leg of the CPU baseline')
     ap.add_argument('--no-variants', action='store_true', help='skip the B* legs on the non-compact databases (extra field noncompact)')
+    ap.add_argument('--no-shapes', action='store_true', help='skip the legs on the other BASELINE shapes B2 / B4 / B5 (extra field shapes)')
     ap.add_argument('--viterbi-mode', type=int, default=2, choices=(0, 1, 2),
                     help='2: the engine default (batches: f32 matrix lower bounds + verified sparse exact recursion); '
                          '1: force that path; 0: dense exact float64 join costs')
@@ -604,13 +697,6 @@ def main():
                  if f32_mode else 'knn_sweep<filter> (v_mfma_f64_16x16x4_f64)')
         traffic = None
         traffic_source = None
-        tfile = os.path.join(ROOT, 'profiles', 'r03_traffic_filter.json' if two_pass else 'r02_traffic_bf16.json' if bf16_mode else 'r01_traffic_f32.json' if f32_mode else 'r01_traffic.json')
-        if world == 1 and N == 1048576 and Dt == 61 and os.path.isfile(tfile):
-            with open(tfile) as f:
-                tj = json.load(f)
-            if int(tj.get('rows_per_launch', 600)) == int(round(rows_per_launch)):
-                traffic = tj['hbm_bytes_per_launch']
-                traffic_source = os.path.relpath(tfile, ROOT) + ' (separate --pmc passes of this kernel and shape; not measured in this run)'
         achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             'metric': 'synthesised frames/sec, full-DB K=%d K-NN preselection + Viterbi' % K,
@@ -659,21 +745,27 @@ def main():
             jbytes = jrows * K * 2 * Dj * 4 + jrows * K * K * 4        # gathered E and S rows (each read once per row pair) + the bounds written
             javg = jms / max(jl, 1)
             jfl = 2.0 * jrows * K * K * Dj
-            jtraffic, jsrc = None, None
-            jfile = os.path.join(ROOT, 'profiles', 'r04_traffic_joinlb2.json')
-            if variant1 and world == 1 and N == 1048576 and Dj == 302 and K == 100 and os.path.isfile(jfile):
-                with open(jfile) as f:
-                    tj = json.load(f)
-                if abs(tj.get('rows_per_launch', 0) - jrows) <= 0.01 * jrows:      # (the profiled call counts row PAIRS of one group: 9 599)
-                    jtraffic = tj['hbm_bytes_per_launch'] * jrows / tj['rows_per_launch']
-                    jsrc = 'profiles/r04_traffic_joinlb2.json (separate --pmc passes of this kernel and shape, scaled by the rows; not measured in this run)'
+            jtraffic, jsrc, jref = None, None, None
+            if variant1 and world == 1 and N == 1048576 and Dj == 302 and K == 100:
+                for jname in ('r05_traffic_joinlb2.json', 'r04_traffic_joinlb2.json'):
+                    tj, fresh = profiled_counters(jname, 'joinlb2_kernels.hip')
+                    if tj is None or abs(tj.get('rows_per_launch', 0) - jrows) > 0.01 * jrows:      # (the profiled call counts row PAIRS of one group: 9 599)
+                        continue
+                    scaled = tj['hbm_bytes_per_launch'] * jrows / tj['rows_per_launch']
+                    if fresh:
+                        jtraffic = scaled
+                        jsrc = 'profiles/%s (separate --pmc passes of this kernel and shape, the kernel source unchanged since; scaled by the rows)' % jname
+                    else:
+                        jref = {'file': 'profiles/' + jname, 'hbm_bytes_per_launch': scaled,
+                                'note': 'counters of an EARLIER build of this kernel (its source has changed since the pass): not this run\'s traffic'}
+                    break
             out['roofline'] = {
                 'bound': 'hbm',
                 'kernel': ('join_lb2_kernel (joinlb2_kernels.hip: gather of the weighted float32 join rows of 2 K candidates per step, bf16-split '
                            'K x K x Dj product on v_mfma_f32_32x32x16_bf16, proven lower bounds written as float32)' if variant1 else
                            'join_lb_kernel (joinfast_kernels.hip: v_mfma_f32_16x16x4_f32, rows weighted in float64 per gather)'),
                 'achieved': jbytes / (javg * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': jbytes / (javg * 1e-3) / 1e9 / 8000.0,
-                'traffic': jtraffic, 'traffic_source': jsrc,
+                'traffic': jtraffic, 'traffic_source': jsrc, 'profiled_reference': jref,
                 'avg_launch_ms': javg, 'launches': jl, 'rows_per_launch': jrows, 'algorithmic_bytes_per_launch': jbytes,
                 'flops_per_launch': jfl, 'mfma_tflops': jfl / (javg * 1e-3) / 1e12,
                 'rule': 'the whole-chip kernel with the largest total time under rocprofv3 (profiles/r04_*_kernel_stats.csv; the largest of all is a '
@@ -715,15 +807,19 @@ def main():
                                                   'float32-grade keys on the bf16 pipe cost %d bf16 MFMA terms per product (hi.hi + hi.lo + '
                                                   'lo.hi%s) on Dt padded to 64 columns; frac above prices only the algorithmic '
                                                   '2 N rows Dt flops against the bf16 peak') % (terms, ' + lo.lo' if terms == 4 else '')}
-        cfile = os.path.join(ROOT, 'profiles', 'r04_filter_counters.json')
-        if world == 1 and N == 1048576 and Dt == 61 and two_pass and os.path.isfile(cfile):
-            with open(cfile) as f:
-                cj = json.load(f)
-            if int(cj.get('rows_per_launch', 0)) == int(round(rows_per_launch)):
-                out['filter_stage']['traffic'] = cj['hbm_bytes_per_launch']
-                out['filter_stage']['traffic_ratio'] = cj['traffic_ratio']
-                out['filter_stage']['mfma_busy'] = cj['mfma_busy']
-                out['filter_stage']['traffic_source'] = 'profiles/r04_filter_counters.json (separate --pmc passes of these kernels and this shape; not measured in this run)'
+        if world == 1 and N == 1048576 and Dt == 61 and two_pass:
+            for cname in ('r05_filter_counters.json', 'r04_filter_counters.json'):
+                cj, fresh = profiled_counters(cname, 'knn16_kernels.hip')
+                if cj is None or int(cj.get('rows_per_launch', 0)) != int(round(rows_per_launch)):
+                    continue
+                vals = {'traffic': cj['hbm_bytes_per_launch'], 'traffic_ratio': cj['traffic_ratio'], 'mfma_busy': cj['mfma_busy']}
+                if fresh:
+                    out['filter_stage'].update(vals)
+                    out['filter_stage']['traffic_source'] = 'profiles/%s (separate --pmc passes of these kernels and this shape, their source unchanged since)' % cname
+                else:
+                    vals.update({'file': 'profiles/' + cname, 'note': 'counters of an EARLIER build of these kernels: not this run\'s'})
+                    out['filter_stage']['profiled_reference'] = vals
+                break
         if world == 1 and bf16_mode:
             # tripwire of the bf16-split prefilter's key bound (untimed, after the timed region): the same step with the
             # float32-operand prefilter, whose bound is the analytical one of an f32 FMA chain, must select the same units;
@@ -764,15 +860,64 @@ def main():
             gp, gc, gcand, gdist = eng.knn_viterbi(ref[4], K, return_candidates=True)
             out['cpu_baseline']['gpu_matches_cpu_path'] = bool(gp == ref[2])
             out['cpu_baseline']['gpu_matches_cpu_candidates'] = bool(np.array_equal(gcand, ref[0]))
+        # the three tripwires of the probed MFMA accumulation bound, over the timed B* steps (before any other voice is uploaded)
+        tripwires = {'prefilter_margin_rows': eng.info('prefilter_margin_rows'), 'prefilter_min_margin': eng.info('prefilter_min_margin'),
+                     'join_bound_violations': eng.info('join_bound_violations'), 'join_bound_min_margin': eng.info('join_bound_min_margin')}
+        if 'prefilter_tripwire' in out:
+            tripwires['gpu_matches_f32_prefilter'] = out['prefilter_tripwire']['gpu_matches_f32_prefilter']
+        leg_steps = max(4, args.steps // 4)
         if world == 1 and not args.no_variants and N >= 65536:
-            # the same workload on databases whose tiles are not compact balls: what the fallback of the ball
-            # pass costs, driver-visible
-            out['noncompact'] = [variant_leg(eng, kind, N, Dt, Dj, T, U, K, wt, wj, F_unw, JC_unw, max(4, args.steps // 4))
-                                 for kind in ('permuted', 'speechlike')]
+            # the same workload on databases whose tiles are not compact balls: what the fallbacks of the ball
+            # pass cost, each leg with the roofline of its dominant kernel
+            legs = []
+            for kind in ('permuted', 'speechlike'):
+                Fv, JCv = variant_database(kind, N, Dt, F_unw, JC_unw)
+                legs.append(shape_leg(eng, 'B*', Fv, JCv, wt, wj, T, U, K, leg_steps, kind=kind))
+                del Fv, JCv
+            out['noncompact'] = legs
+        if world == 1 and not args.no_shapes:
+            # SURVEY 8d's other Viterbi shapes, one GPU: B2 (slt full, K 50), B4 (Nick, K 200), B5 (halfphone width, Dt 184) -- the
+            # latter also with its units in random order (halfphone databases are where consecutive units are least alike)
+            del F_unw, JC_unw
+            shapes = []
+            for sname, sN, sDt, sDj, sT, sU, sK, kinds in (('B2', 700000, 61, 302, 600, 32, 50, ('compact',)),
+                                                            ('B4 (1 GPU)', 1500000, 61, 302, 600, 8, 200, ('compact',)),
+                                                            ('B5', 1300000, 184, 151, 120, 64, 100, ('compact', 'permuted'))):
+                Fs, JCs = synthetic_db(sN, sDt, sDj, seed=0)
+                wts, wjs = np.full(sDt, 0.4), np.full(sDj, 0.05)
+                for kind in kinds:
+                    Fk, JCk = (Fs, JCs) if kind == 'compact' else variant_database(kind, sN, sDt, Fs, JCs)
+                    shapes.append(shape_leg(eng, sname, Fk, JCk, wts, wjs, sT, sU, sK, leg_steps, kind=kind))
+                del Fs, JCs
+            out['shapes'] = shapes
         if world == 1 and not args.no_greedy:
-            eng.close()                     # free the B* database before the greedy voices are built
+            eng.close()                     # free the last database before the greedy voices are built
             eng = None
             out['extra'] = greedy_extra(local_rank)
+            for g in ('greedy_b1', 'greedy_b3'):
+                tripwires[g + '_bound_violations'] = out['extra'][g].get('bound_violations')
+                tripwires[g + '_bound_max_used'] = out['extra'][g].get('bound_max_used')
+        # ---- LAST key, compact: what SURVEY 8d asks for, where a tail of the line still shows it ----
+        def brief(leg):
+            r = leg.get('roofline', {})
+            return {'frames_per_s': round(leg['frames_per_s']), 'ms_per_step': round(leg['ms_per_step'], 3), 'kernel': r.get('kernel'),
+                    'bound': r.get('bound'), 'frac': None if r.get('frac') is None else round(r['frac'], 3),
+                    'redos': leg['batch_redos'] + leg['prefilter_fallbacks']}
+        summary = {'B*': {'frames_per_s_resident': round(value), 'host_to_host': None if with_upload is None else round(with_upload['value']),
+                          'kernel': out['roofline'].get('kernel', '')[:16].split(' ')[0], 'bound': out['roofline'].get('bound'),
+                          'frac': round(out['roofline'].get('frac', 0.0), 3)},
+                   'tripwires': tripwires}
+        for leg in out.get('noncompact', []):
+            summary['B* ' + leg['database']] = brief(leg)
+        for leg in out.get('shapes', []):
+            summary[leg['shape'] + ('' if leg['database'] == 'compact' else ' ' + leg['database'])] = brief(leg)
+        if 'extra' in out:
+            summary['greedy_us_per_step'] = {'B1': round(out['extra']['greedy_b1']['us_per_step'], 2), 'B3': round(out['extra']['greedy_b3']['us_per_step'], 2),
+                                             'B3_frac_hbm': round(out['extra']['greedy_b3']['roofline'].get('frac', 0.0), 3)}
+        if cpu_ref is not None:
+            summary['cpu_frames_per_s'] = {'one_core': round(out['cpu_baseline']['value'], 1),
+                                           'all_cores': round(out['cpu_baseline'].get('all_cores', {}).get('value', 0.0), 1)}
+        out['summary'] = summary
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

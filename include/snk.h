@@ -330,13 +330,20 @@ int snk_concat_fragments(snk_handle h, const int64_t *first_row, const int64_t *
  *                              shortestpath accumulates them from the start state, all in float32): arc weight
  *                              fl32(fl32(tdist[t-1,k']) + fl32(c(k',k))), totals accumulated in float32, the last row's target
  *                              cost on the exit arc; ties as before.  This IS a different result on near ties (the cost returned
- *                              is the float32 total); it runs on the dense kernels.
+ *                              is the float32 total).  Runs wherever the float64 recursion does: on the dense kernels (viterbi_mode
+ *                              0) and on the sparse path, whose proof folds the float32 roundings in (joinfast_kernels.hip).
  *   join_exact_form 0 / 1      pass 3 of the sparse path: a lane per cell / a cooperative workgroup per step (default 1)
  * Options of the K-NN filter: prefilter 0 / 1 / 2, prefilter_two_pass 0 / 1, prefilter_balls 0 / 1, prefilter_super_balls 0 / 1,
  * prefilter_ball_bound 0 / 1, coarse_gate_fraction; of the sharded search: shard_compact 0 / 1; of the greedy search:
  * greedy_hoist 0 / 1, greedy_hoist_fast 0 / 1, greedy_f16 0 / 1 / 2, greedy_resident 0 / 1, greedy_speculate 0 / 1, greedy_fenced 0 / 1
  * (INTEGRATION.md).
  * None of these changes a result (viterbi_weights excepted, which selects the arithmetic).
+ * Latches (none changes a result): viterbi_latch 0 / 1 (batches in viterbi_mode 2: the dense kernels are tried where the bounds do not
+ * prune, the faster path is kept, the other one re-tried after 32 .. 1 024 batches), viterbi_refine_gate, latch_rearm 0 / 1 (a voice on
+ * the coarse / one-pass filter is probed with a counting form of the pass it left every 16 .. 256 calls).
+ * Tripwires of the probed MFMA accumulation bound (snk_reset_timers clears them): prefilter_margin_rows / prefilter_min_margin (below),
+ * join_bound_violations / join_bound_min_margin (exact join costs against pass 1's bounds), greedy_bound_violations /
+ * greedy_bound_max_used (exact totals against the float32 scans' bound).
  * infos: greedy_fallbacks, greedy_stalls, greedy_exact_windows, greedy_second_rounds, greedy_hoist_launches, greedy_hoist16_launches,
  * greedy_f16_launches, greedy_f16_delta, greedy_resident_launches, greedy_last_speculated, greedy_last_several_holders, filter_coarse,
  * filter_onepass, shard_last_sent_mb.  The other names are listed in INTEGRATION.md.

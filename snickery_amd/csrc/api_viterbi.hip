@@ -27,7 +27,6 @@ static int64_t join_units(snk_engine *h)
 bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts)
 {
     (void)n_utts;
-    if (h->viterbi_weights == 1) return false;          // the float32 weight chain runs on the dense kernels
     if (!join_lb_supported(h->Dj, K)) return false;
     if (h->viterbi_mode == 2 && h->vit_now_dense) return false;       // this voice's batches were judged faster through the dense kernels (snk_engine.h: vit)
     return h->viterbi_mode == 1 || h->viterbi_mode == 2;
@@ -112,7 +111,7 @@ static int viterbi_sparse_rows(snk_engine *h, UttSlot &s, const int64_t *cand, c
         StageTimer t(h, side, TM_DP_SPARSE);
         launch_viterbi_sparse(cand, s.cex.p, s.Jlo.as<float>(), JC, h->Jp, h->Dj, wj, off, n_utts, first_utt, K,
                               join_units(h), s.bp.as<unsigned char>(), path, plen, cost,
-                              h->vstats.as<unsigned long long>(), side, s.scale.as<float>(), ceps);
+                              h->vstats.as<unsigned long long>(), side, s.scale.as<float>(), ceps, h->viterbi_weights == 1);
     }
     return 0;
 }
@@ -362,7 +361,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     const size_t sz_u = ((size_t)n_utts * 8 + 63) & ~(size_t)63, sz_st = ((size_t)3 * b.n_groups * sizeof(int) + 63) & ~(size_t)63;
     CHK(b.stage.ensure(sz_path + 2 * sz_u + sz_st + 64));                 // + the Viterbi statistics words
     // the Viterbi latch (snk_engine.h: vit): which exact path this batch takes, and the events its period is read from
-    const bool vit_auto = h->viterbi_mode == 2 && h->viterbi_latch && h->viterbi_weights == 0 && join_lb_supported(h->Dj, K) && n_utts >= 2;
+    const bool vit_auto = h->viterbi_mode == 2 && h->viterbi_latch && join_lb_supported(h->Dj, K) && n_utts >= 2;
     b.vit_trial = vit_auto && h->vit.trial_left > 0;
     b.vit_dense = vit_auto && (b.vit_trial ? h->vit.trial_mode : h->vit.mode) == 1;
     b.vit_judged = vit_auto;

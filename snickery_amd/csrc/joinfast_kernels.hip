@@ -1161,7 +1161,14 @@ __device__ __forceinline__ unsigned int jf_wave_min_u32(unsigned int v)
     return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-template <int NC, bool BPL>
+// FST32 (option viterbi_weights 1): the reference's own arithmetic -- OpenFST's float32 tropical weights (viterbi_kernels.hip,
+// fst_functions_wrapped.py:47,201,368,389): acc_t[k] = min_k' fl32(acc_{t-1}[k'] + fl32(fl32(td[t-1,k']) + fl32(c(k',k)))), the last row's
+// target cost on the exit arc.  In exact arithmetic acc + td IS the float64 recursion's delta, so passes 1-3 serve unchanged (pass 2's
+// d~ needs no property of its own) and only the proof changes: float32 rounding is monotone and clo <= c is a float32 value, so an
+// excluded predecessor's total is at least fl32(acc + fl32(td + clo)) >= (acc + td + clo)(1 - 2^-24)^2 >= (off' + X)(1 - 2^-23) with
+// off' = min (acc + td - d~); the refinement tests fl32(acc + fl32(td + clo)) <= best, exact by the same monotonicity.  delta holds the
+// float32 totals (widened), tdp the float32 target costs of the previous row; same tie rule.
+template <int NC, bool BPL, bool FST32>
 __global__ void __launch_bounds__(128)
 viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__restrict__ rec_all,
                        const float *__restrict__ Jlo_all, const float *__restrict__ JC_unw, int Jp, int Dj,
@@ -1190,7 +1197,8 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
     int *final_slot_p = rarg + 256;                                // [4]
     unsigned short *plist = reinterpret_cast<unsigned short *>(final_slot_p + 4);   // [JF1_PAIRS] (failing column << 8) | predecessor
     unsigned char *flist = reinterpret_cast<unsigned char *>(plist + JF1_PAIRS);    // [256] the failing columns of a step
-    u32x4 *ring = reinterpret_cast<u32x4 *>(flist + 256);          // [3][JF1_NL * 64] records of three batches (4 x 16 bytes per cell)
+    float *tdp = reinterpret_cast<float *>(flist + 256);           // [2][256] FST32: float32 target costs of a row
+    u32x4 *ring = reinterpret_cast<u32x4 *>(tdp + 2 * 256);        // [3][JF1_NL * 64] records of three batches (4 x 16 bytes per cell)
     const int slot_pieces = JF1_NL * 64;
     unsigned char *bp_lds = reinterpret_cast<unsigned char *>(ring + (size_t)3 * slot_pieces);
 
@@ -1207,10 +1215,15 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
         if (tid == 0) { *path_len = 0; *cost = inf; }
         return;
     }
-    for (int i = tid; i < 2 * 256; i += (int)blockDim.x) delta[i] = inf;
+    for (int i = tid; i < 2 * 256; i += (int)blockDim.x) { delta[i] = inf; tdp[i] = 0.f; }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < NC; ++c) if (col[c]) delta[kc[c]] = rec[kc[c]].td;      // td of row 0 (+inf for an unusable unit)
+    for (int c = 0; c < NC; ++c)
+        if (col[c]) {
+            const double td0 = rec[kc[c]].td;                                   // td of row 0 (+inf for an unusable unit)
+            if constexpr (FST32) { delta[kc[c]] = td0 < inf ? 0.0 : inf; tdp[kc[c]] = (float)td0; }
+            else delta[kc[c]] = td0;
+        }
     // Loader: the records of batch j (steps j BS + 1 .. j BS + BS) are consecutive in global memory and go to ring slot
     // j % 3 by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes to M0 + 16 lane, no registers), always JF1_NL
     // loads (the tail of a slot beyond BS K cells is never read).  Inline asm: the compiler neither counts these loads
@@ -1252,6 +1265,8 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
             JF_STAMP(0);
             const double *dprev = delta + ((t - 1) & 1) * 256;
             double *dcur = delta + (t & 1) * 256;
+            const float *tprev = tdp + ((t - 1) & 1) * 256;
+            float *tcur = tdp + (t & 1) * 256;
             double best[NC], d[NC], td[NC], lbv[NC];
             int arg[NC];
             bool fail[NC];
@@ -1270,11 +1285,15 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
 #endif
             auto f64 = [](unsigned int lo, unsigned int hi) { return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32)); };
             double dp[NC][JF_CAP];
+            float tp[FST32 ? NC : 1][JF_CAP];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const unsigned int ix = q[c][3][2];
 #pragma unroll
-                for (int j = 0; j < JF_CAP; ++j) dp[c][j] = dprev[(ix >> (8 * j)) & 0xffu];
+                for (int j = 0; j < JF_CAP; ++j) {
+                    dp[c][j] = dprev[(ix >> (8 * j)) & 0xffu];
+                    if constexpr (FST32) tp[c][j] = tprev[(ix >> (8 * j)) & 0xffu];
+                }
             }
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -1293,7 +1312,10 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
                 // the record holds +inf costs beyond the set's n members (join_exact_sparse_kernel): their totals are +inf
                 double tot[JF_CAP];
 #pragma unroll
-                for (int j = 0; j < JF_CAP; ++j) tot[j] = __dadd_rn(dp[c][j], cj[j]);
+                for (int j = 0; j < JF_CAP; ++j) {
+                    if constexpr (FST32) tot[j] = (double)((float)dp[c][j] + (tp[c][j] + (float)cj[j]));       // the composed arc weight, then the path weight
+                    else tot[j] = __dadd_rn(dp[c][j], cj[j]);
+                }
                 const double bst = __builtin_fmin(__builtin_fmin(tot[0], tot[1]), __builtin_fmin(tot[2], tot[3]));
                 unsigned int ag = 0x7fffffffu;                         // among equal totals the lowest slot
 #pragma unroll
@@ -1304,13 +1326,16 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
                 ag = bst < inf ? ag : 0u;
                 // proof that no predecessor outside the set wins or ties (strict, with room for the roundings)
                 const bool usable = td[c] < inf;
-                const double bound = __dadd_rn(__builtin_fma(-1e-12, fabs(xv), xv), offm);
+                // (FST32: two float32 roundings of positive sums sit between an excluded predecessor's total and off' + X)
+                const double bound = FST32 ? __builtin_fma(-2.4e-7, fabs(xv + offm), xv + offm) - 1e-30
+                                           : __dadd_rn(__builtin_fma(-1e-12, fabs(xv), xv), offm);
                 // xv == inf: every predecessor with a finite lower-bound total is in the set
                 const bool ok = (n_raw <= JF_CAP) & (!(xv < inf) | ((off < inf) & (bound > bst)));
                 fail[c] = col[c] & usable & !ok;
                 anyfail_lane |= fail[c];
                 best[c] = bst; arg[c] = (int)ag;
-                d[c] = (col[c] & usable) ? __dadd_rn(td[c], bst) : inf;
+                // (FST32: d is acc + td in exact arithmetic -- what pass 2's d~ follows; the stored total is best itself)
+                d[c] = (col[c] & usable) ? (FST32 ? bst + (double)(float)td[c] : __dadd_rn(td[c], bst)) : inf;
             }
 #ifdef SNK_JF_TRACE
             asm volatile("" : "+v"(d[0]));
@@ -1376,7 +1401,8 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
                             for (; cc < Dj; ++cc) acc = __dadd_rn(acc, row[cc]);
                             const double cex = __dsqrt_rn(acc);
                             const unsigned int pe = plist[r0 + lane];
-                            totr = __dadd_rn(dprev[pe & 0xffu], cex);
+                            if constexpr (FST32) totr = (double)((float)dprev[pe & 0xffu] + (tprev[pe & 0xffu] + (float)cex));
+                            else totr = __dadd_rn(dprev[pe & 0xffu], cex);
                             if (stats) jf_trip_check(cex, jslab[(int64_t)(pe & 0xffu) * K + (pe >> 8)], tunit, tviol, tmin);
                         }
                         for (int r = 0; r < nr; ++r) {              // in list order: a column's candidates one after the other
@@ -1399,7 +1425,7 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
                 for (int base = 0; base < total; base += 256) {     // four rounds of 64 pairs: their loads in flight together
                     bool want[4];
                     unsigned int e[4];
-                    float lo[4];
+                    float lo[4], tpp[4];
                     double dpp[4], rb[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -1409,11 +1435,14 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
                         e[i] = ((unsigned int)kf << 8) | (unsigned int)pp;
                         lo[i] = jslab[(int64_t)pp * K + kf];
                         dpp[i] = dprev[pp];
+                        tpp[i] = FST32 ? tprev[pp] : 0.f;
                         rb[i] = rbest[kf];
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        want[i] = base + 64 * i + lane < total && dpp[i] < inf && lo[i] < __builtin_inff() && __dadd_rn(dpp[i], (double)lo[i]) <= rb[i];
+                        // (FST32: the float32 total with the bound in place of the cost -- rounding is monotone, so it bounds the real one)
+                        const double tlo = FST32 ? (double)((float)dpp[i] + (tpp[i] + lo[i])) : __dadd_rn(dpp[i], (double)lo[i]);
+                        want[i] = base + 64 * i + lane < total && dpp[i] < inf && lo[i] < __builtin_inff() && tlo <= rb[i];
                         const unsigned long long wm = __ballot(want[i]);
                         if (want[i]) plist[np + __builtin_popcountll(wm & lt_mask)] = (unsigned short)e[i];
                         np += __builtin_popcountll(wm);
@@ -1426,7 +1455,7 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
                 flush();
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
-                    if (fail[c]) { best[c] = rbest[kc[c]]; arg[c] = rarg[kc[c]]; d[c] = __dadd_rn(td[c], best[c]); }
+                    if (fail[c]) { best[c] = rbest[kc[c]]; arg[c] = rarg[kc[c]]; d[c] = FST32 ? best[c] + (double)(float)td[c] : __dadd_rn(td[c], best[c]); }
                 if (stats) {
                     if (lane == 0) {
                         atomicAdd(&stats[0], (unsigned long long)nf); atomicAdd(&stats[1], 1ull);
@@ -1438,7 +1467,8 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 if (col[c]) {
-                    dcur[kc[c]] = d[c];
+                    if constexpr (FST32) { dcur[kc[c]] = td[c] < inf ? best[c] : inf; tcur[kc[c]] = td[c] < inf ? (float)td[c] : 0.f; }
+                    else dcur[kc[c]] = d[c];
                     if constexpr (BPL) bp_lds[bp_off + kc[c]] = (unsigned char)arg[c];
                     else bp_global[bp_off + kc[c]] = (unsigned char)arg[c];
                 }
@@ -1482,8 +1512,11 @@ viterbi_sparse1_kernel(const int64_t *__restrict__ cand_all, const JfRecord *__r
     if (tid == 0) {
         double best = inf;
         int slot = 0;
-        for (int kk = 0; kk < K; ++kk)
-            if (dlast[kk] < best) { best = dlast[kk]; slot = kk; }
+        const float *tlast = tdp + ((T - 1) & 1) * 256;
+        for (int kk = 0; kk < K; ++kk) {
+            const double v = FST32 ? (double)((float)dlast[kk] + tlast[kk]) : dlast[kk];      // (FST32: the exit arc carries the last target cost)
+            if (v < best) { best = v; slot = kk; }
+        }
         if (best == inf) { *path_len = 0; *cost = inf; *final_slot_p = -1; }
         else { *path_len = T; *cost = best; *final_slot_p = slot; }
     }
@@ -1553,7 +1586,7 @@ static void jf_trace_dump(unsigned long long *stats, int n, int64_t T, hipStream
 void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jlo, const float *JC_unw, int Jp, int Dj,
                            const double *wj, const int64_t *off, int n_utts, int first_utt, int K, int64_t n_units,
                            unsigned char *bp_global, int64_t *path, int64_t *path_len, double *cost,
-                           unsigned long long *stats, hipStream_t s, const float *scale, float ceps)
+                           unsigned long long *stats, hipStream_t s, const float *scale, float ceps, bool fst32)
 {
     for (int u0 = 0; u0 < n_utts; u0 += DpBatch::MAX) {
         const int n = (n_utts - u0 < DpBatch::MAX) ? n_utts - u0 : DpBatch::MAX;
@@ -1562,29 +1595,31 @@ void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jl
         for (int i = 0; i <= n; ++i) batch.off[i] = off[u0 + i];
         for (int i = 0; i < n; ++i) T = (off[u0 + i + 1] - off[u0 + i] > T) ? off[u0 + i + 1] - off[u0 + i] : T;
         batch.first = first_utt + u0;
-        if (g_sparse_waves == 1) {
+        if (g_sparse_waves == 1 || fst32) {
             const int nc = (K + 63) / 64;
             int bs1 = (JF1_NL * 1024) / (K * 64);                  // steps per batch: what a JF1_NL-KB slot holds
             if (bs1 < 1) bs1 = 1;
-            const size_t base1 = (size_t)(3 * 256 + JF1_SQ) * 8 + 256 * 4 + 16 + JF1_PAIRS * 2 + 256 + (size_t)3 * JF1_NL * 1024;
+            const size_t base1 = (size_t)(3 * 256 + JF1_SQ) * 8 + 256 * 4 + 16 + JF1_PAIRS * 2 + 256 + 2 * 256 * 4 + (size_t)3 * JF1_NL * 1024;
             const size_t bp_bytes1 = (size_t)T * K;
             const bool bpl1 = base1 + bp_bytes1 + 64 <= 150 * 1024 && (size_t)T <= (size_t)3 * JF1_NL * 1024;
             const size_t shmem1 = base1 + (bpl1 ? bp_bytes1 : 0);
-#define SNK_SP1(NC_, BPL_)                                                                                        \
+#define SNK_SP1F(NC_, BPL_, F_)                                                                                   \
     {                                                                                                             \
         static size_t attr_set[32] = {0};                                                                         \
         lds_attr_ensure(attr_set, 150 * 1024, [] {                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&viterbi_sparse1_kernel<NC_, BPL_>),         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&viterbi_sparse1_kernel<NC_, BPL_, F_>),     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024)); });         \
-        hipLaunchKernelGGL((viterbi_sparse1_kernel<NC_, BPL_>), dim3(n), dim3(128), shmem1, s, cand,              \
+        hipLaunchKernelGGL((viterbi_sparse1_kernel<NC_, BPL_, F_>), dim3(n), dim3(128), shmem1, s, cand,          \
                            reinterpret_cast<const JfRecord *>(rec), Jlo, JC_unw, Jp, Dj, wj, batch, K, bs1, n_units, \
                            bp_global, path, path_len, cost, stats, scale, ceps);                                  \
     }
+#define SNK_SP1(NC_, BPL_) { if (fst32) SNK_SP1F(NC_, BPL_, true) else SNK_SP1F(NC_, BPL_, false) }
             if (nc == 1) { if (bpl1) SNK_SP1(1, true) else SNK_SP1(1, false) }
             else if (nc == 2) { if (bpl1) SNK_SP1(2, true) else SNK_SP1(2, false) }
             else if (nc == 3) { if (bpl1) SNK_SP1(3, true) else SNK_SP1(3, false) }
             else { if (bpl1) SNK_SP1(4, true) else SNK_SP1(4, false) }
 #undef SNK_SP1
+#undef SNK_SP1F
             jf_trace_dump(stats, n, T, s);
             continue;
         }

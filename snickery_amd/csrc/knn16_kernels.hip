@@ -791,15 +791,19 @@ knn_sweep16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const
                         const float key = v4[q];
                         const bool pass = key <= pth;
                         const unsigned long long mm = __ballot(pass);
-                        if (pass) {
-                            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
-                            PoolEntry16 en;
-                            en.key = (double)key;
-                            en.idx = wb + ib + (pt * 32 + crow32(0, r0 + q));
-                            en.row = pq * 32 + qcol;
-                            stage[wv][lcount + rank] = en;
+                        // (a uniform branch per result: where the units stand in no order a third of the groups hold a key under the
+                        // threshold, but only one result in ten does -- the other three of such a group cost a compare and a branch)
+                        if (mm) {
+                            if (pass) {
+                                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
+                                PoolEntry16 en;
+                                en.key = (double)key;
+                                en.idx = wb + ib + (pt * 32 + crow32(0, r0 + q));
+                                en.row = pq * 32 + qcol;
+                                stage[wv][lcount + rank] = en;
+                            }
+                            lcount += __popcll(mm);
                         }
-                        lcount += __popcll(mm);
                     }
                 }
             }

@@ -237,7 +237,8 @@ void set_viterbi_sparse_waves(int w);      // 1 (default) or 4: which form of pa
 void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jlo, const float *JC_unw, int Jp, int Dj,
                            const double *wj, const int64_t *off, int n_utts, int first_utt, int K, int64_t n_units,
                            unsigned char *bp_global, int64_t *path, int64_t *path_len, double *cost,
-                           unsigned long long *stats, hipStream_t s, const float *scale, float ceps);
+                           unsigned long long *stats, hipStream_t s, const float *scale, float ceps,
+                           bool fst32 = false);    // fst32: OpenFST's float32 weight chain (option viterbi_weights 1; the one-wavefront form)
 
 // ---- greedy ---------------------------------------------------------------
 struct GreedyLayout {

@@ -21,11 +21,22 @@ def engine():
 
 
 def _fst32(engine, cand, dist):
+    """Both homes of the float32 chain: the dense kernels (viterbi_mode 0) and, since round 5, the sparse path (bounds, predecessor
+    sets, exact costs for the sets, a proof with the float32 roundings folded in) -- same path, same float32 total."""
     engine.set_option('viterbi_weights', 1)
     try:
-        return engine.viterbi(cand, dist)
+        engine.set_option('viterbi_mode', 0)
+        dense = engine.viterbi(cand, dist)
+        engine.set_option('viterbi_mode', 2)
+        before = engine.timers().get('viterbi_sparse', (0, 0))[1]
+        sparse = engine.viterbi(cand, dist)
+        if cand.shape[0] >= 2 and cand.shape[1] <= 208:
+            assert engine.timers().get('viterbi_sparse', (0, 0))[1] > before           # the sparse recursion did run
+        assert sparse == dense
+        return sparse
     finally:
         engine.set_option('viterbi_weights', 0)
+        engine.set_option('viterbi_mode', 2)
 
 
 def test_fst32_on_the_golden_voice(engine, golden, mini_voice):
@@ -94,3 +105,43 @@ def test_fst32_on_a_baseline_sized_utterance(engine):
     assert path == opath and cost == ocost
     p64, _ = engine.viterbi(cand, dist)
     print('fst32 vs float64 on this utterance: %d of %d frames differ' % (int(np.sum(np.asarray(p64) != np.asarray(path))), T))
+
+
+def test_fst32_batches_on_the_sparse_path_at_the_headline_shape(engine):
+    """viterbi_weights 1 through snk_knn_viterbi_batch with viterbi_mode 2: a batch of B*-shaped utterances
+    (T 600, K 100, 302 join columns) on the sparse path equals the oracle's float32 chain utterance by utterance, the margins of
+    the proof do not make pass 4 refine everything (a small fraction of the K x K costs is computed exactly), and the step costs
+    at most 1.2 x the float64 step."""
+    import time
+    N, Dj, T, K, U = 400000, 302, 600, 100, 8
+    F_unw, JC_unw = o.synthetic_db(N, 61, Dj, seed=15)
+    wt, wj = np.full(61, 0.4), np.full(Dj, 0.05)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    utts = [o.synthetic_targets(F_unw, T, seed=30 + u) * wt for u in range(U)]
+    engine.set_option('viterbi_latch', 0)
+    try:
+        def timed():
+            engine.knn_viterbi_batch(utts, K)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                res = engine.knn_viterbi_batch(utts, K)
+            return (time.perf_counter() - t0) / 3, res
+        t64, (p64, c64) = timed()
+        engine.set_option('viterbi_weights', 1)
+        before = engine.info('dense_exact_costs')
+        n_sparse = engine.timers().get('viterbi_sparse', (0, 0))[1]
+        t32, (p32, c32) = timed()
+        assert engine.timers().get('viterbi_sparse', (0, 0))[1] > n_sparse
+        refined = (engine.info('dense_exact_costs') - before) / 4.0
+        assert refined <= 0.02 * U * T * K * K, refined
+        for u in (0, 3, U - 1):
+            cand, dist = engine.knn(utts[u], K)
+            J = engine.join_costs(cand)
+            opath, ocost = o._viterbi_fst32(cand, dist.astype(np.float32), J.astype(np.float32), o.valid_mask(cand, N))
+            assert list(p32[u]) == opath and c32[u] == ocost, u
+        print('float64 step %.2f ms, float32-weights step %.2f ms; exact costs in refinements per batch %d' % (t64 * 1e3, t32 * 1e3, refined))
+        assert t32 <= 1.2 * t64 + 0.3e-3, (t32, t64)
+    finally:
+        engine.set_option('viterbi_weights', 0)
+        engine.set_option('viterbi_latch', 1)
