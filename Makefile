@@ -4,7 +4,7 @@ ARCH  ?= gfx950
 CSRC  := snickery_amd/csrc
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -ffp-contract=off -Wno-unused-value -Iinclude
 LIB   := snickery_amd/libsnkhip.so
-OBJS  := $(CSRC)/knn_kernels.o $(CSRC)/knn16_kernels.o $(CSRC)/viterbi_kernels.o $(CSRC)/joinfast_kernels.o $(CSRC)/joinlb2_kernels.o $(CSRC)/greedy_kernels.o $(CSRC)/greedy32_kernels.o $(CSRC)/greedy_hoist_kernels.o $(CSRC)/greedy_res_kernels.o $(CSRC)/concat_kernels.o $(CSRC)/api_core.o $(CSRC)/api_knn.o $(CSRC)/api_viterbi.o $(CSRC)/api_greedy.o $(CSRC)/api_shard.o $(CSRC)/api_options.o
+OBJS  := $(CSRC)/knn_kernels.o $(CSRC)/knn16_kernels.o $(CSRC)/viterbi_kernels.o $(CSRC)/joinfast_kernels.o $(CSRC)/joinlb2_kernels.o $(CSRC)/greedy_kernels.o $(CSRC)/greedy32_kernels.o $(CSRC)/greedy_hoist_kernels.o $(CSRC)/greedy_res_kernels.o $(CSRC)/concat_kernels.o $(CSRC)/kmeans_kernels.o $(CSRC)/api_core.o $(CSRC)/api_knn.o $(CSRC)/api_viterbi.o $(CSRC)/api_greedy.o $(CSRC)/api_shard.o $(CSRC)/api_options.o
 
 all: $(LIB) oracle
 

@@ -865,7 +865,7 @@ def main():
                      'join_bound_violations': eng.info('join_bound_violations'), 'join_bound_min_margin': eng.info('join_bound_min_margin')}
         if 'prefilter_tripwire' in out:
             tripwires['gpu_matches_f32_prefilter'] = out['prefilter_tripwire']['gpu_matches_f32_prefilter']
-        leg_steps = max(4, args.steps // 4)
+        leg_steps = max(10, args.steps // 2)            # (a timed region's first and last step run without a neighbour: 2 ms per region)
         if world == 1 and not args.no_variants and N >= 65536:
             # the same workload on databases whose tiles are not compact balls: what the fallbacks of the ball
             # pass cost, each leg with the roofline of its dominant kernel

@@ -231,7 +231,7 @@ int snk_destroy(snk_handle h)
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     collect_timers(h);
-    h->tmask.release(); h->mcand.release(); h->mdist.release(); h->vstats.release();
+    h->tmask.release(); h->mcand.release(); h->mdist.release(); h->vstats.release(); h->perm.release(); h->perm2.release(); h->km_ws.release();
     (void)snk_comm_destroy(h);
     { DevBuf *cb[] = {&h->sh_d2, &h->sh_id, &h->sh_bound, &h->sh_rd2, &h->sh_rid, &h->sh_res, &h->sh_resall,
                       &h->gs_unw, &h->gs_w, &h->gs_norm, &h->gs_tiles, &h->gs_fmax2};
@@ -330,6 +330,7 @@ int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt, const flo
     h->gtiles_ready = false; h->gt16_ready = false;
     h->gh_ready = false; h->gj_ready = false;
     h->gs_rows = 0; h->gs_ready = false;
+    h->perm_ready = false; h->reorder_useless = false; h->reorder_done = false; h->reorder_pending = false;      // a new voice: the database order again
     if (h->global_N < 0) { h->shard_offset = 0; }
     if (JC_unw) CHK(upload_join(h, JC_unw, Njc, Dj));
     return 0;
@@ -388,6 +389,152 @@ int snk_set_column_selection(snk_handle h, const int *tcols, int nt, const int *
     return 0;
 }
 
+// The operands of the K-NN prefilter for the current weights (knn16_kernels.hip): float32 and bf16-split copies of the weighted
+// database and of its stage-A sample, tile balls and the balls of 32 tiles -- in the database's order, or in the order the engine
+// gave the voice (h->perm: kmeans_kernels.hip).  Resets the filter's latches: the voice is judged afresh on these operands.
+int build_prefilter_operands(snk_engine *h)
+{
+    const int32_t *perm = h->perm_ready ? h->perm.as<int32_t>() : nullptr;
+    h->f16_ready = false;
+    h->cls16_ready = false;
+    h->operand_gen += 1;
+    if (h->have_db && h->Dpad <= 256 && h->Dpad - h->Dt >= 1) {
+        // tiles per wavefront: the database fragments of a slab stay in registers (32 * Dpad / 64
+        // floats per tile and lane), so wider rows leave room for fewer tiles
+        const int dch16 = h->Dpad / 64;
+        const int nt = (dch16 == 1) ? h->nt16 : (dch16 == 2) ? 2 : 1;
+        h->nt16_eff = nt;
+        // |key~ - key| <= c (2 |q| Fmax + Fmax^2): operand rounding 2^-24 each and an f32 FMA chain of
+        // Dpad + 1 terms; c = 2 x that (8e-6 at Dpad = 64)
+        h->eps_c = 2.0 * (double)(h->Dpad + 3) * 5.9604644775390625e-08;
+        CHK(h->fmax2.ensure(sizeof(double)));
+        launch_fmax(h->fnorm.as<double>(), h->N, h->fmax2.as<double>(), h->stream);
+        double fmax2 = 0.0;
+        CHK(d2h_sync(h, &fmax2, h->fmax2.p, sizeof(double), h->stream));
+        const int64_t slab_rows = 32 * nt;
+        h->n_slabs16 = (h->N + slab_rows - 1) / slab_rows;
+        int64_t stride = (int64_t)floor(1.0 / h->sample_frac + 0.5);
+        if (stride < 1) stride = 1;
+        // small databases (one rank's shard of a row-sharded one): keep >= 512 sample groups so the
+        // K-th smallest group minimum stays close to the K-th nearest sampled unit
+        while (stride > 1 && (h->N / stride) / slab_rows < h->min_sample_slabs) --stride;
+        h->stride16 = stride;
+        h->n_slabs16_a = (h->N / stride) / slab_rows;
+        if (fmax2 < 1.0e30 && h->n_slabs16_a >= 1) {
+            const int64_t tiles_b = h->n_slabs16 * nt, tiles_a = h->n_slabs16_a * nt;
+            const size_t per_tile = (size_t)8 * 64 * 16 * dch16;
+            CHK(h->a16h.ensure(tiles_b * per_tile));
+            CHK(h->s16h.ensure(tiles_a * per_tile));
+            launch_build_db16(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_b, 0, 0, nt,
+                              h->a16h.p, h->stream, perm);
+            launch_build_db16(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_a, stride,
+                              2 * h->n_slabs16_a, nt, h->s16h.p, h->stream, perm);
+            HIPCHK(hipGetLastError());
+            h->f16_ready = true;
+            h->bf16_ready = false;
+            if (h->prefilter >= 1 && knn_sweep16b_supported(nt, dch16, h->Dt, h->Dpad, false)) {
+                // key bound = cq ||f|| (what the split drops: measured, prepare_queries16b_kernel) + c_acc (...):
+                // 2^-20 per MFMA over the 4 `terms` MFMAs of a chunk's chain and the norm pieces' 2^-24 (knn16_kernels.hip)
+                const int terms = h->prefilter == 2 ? 4 : 3;
+                // (chains of one 64-column chunk: 4 `terms` MFMAs; the chunks' sums are added in float32)
+                h->eps_c_bf = 1.02 * (SNK_BF16_MFMA_UNIT * (double)(terms * 4 + 1) + 6e-8 * (double)(2 * (h->Dpad / 64) + 1));
+                CHK(h->rho16.ensure(2 * sizeof(double)));
+                launch_db16b_ratios(h->Fw.as<double>(), h->N, h->Dt, h->Dpad, h->rho16.as<double>(), h->stream);
+                CHK(h->a16l.ensure(tiles_b * per_tile));
+                CHK(h->s16l.ensure(tiles_a * per_tile));
+                launch_build_db16b(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_b, 0, 0, nt,
+                                   h->a16l.p, h->stream, perm);
+                launch_build_db16b(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_a, stride,
+                                   2 * h->n_slabs16_a, nt, h->s16l.p, h->stream, perm);
+                HIPCHK(hipGetLastError());
+                h->bf16_ready = true;
+                // pass 0 of the two-pass filter: centre and radius of every 32-unit tile, the centres as one more bf16-split
+                // operand (its dropped-piece ratios join the database's: one key bound serves both)
+                h->ball_tiles = 0;
+                h->filter_coarse = false; h->filter_onepass = false;
+                h->filter_calls = 0; h->probe_next = 16; h->probe_period = 16; h->probe_ran = 0;
+                if (h->prefilter_balls) {
+                    const int64_t vt = (h->N + 31) / 32, ct = (vt + 31) / 32;
+                    CHK(h->ball_c.ensure((size_t)vt * h->Dpad * sizeof(double)));
+                    CHK(h->ball_cn.ensure((size_t)vt * sizeof(double)));
+                    CHK(h->ball_rad.ensure((size_t)vt * sizeof(float)));
+                    CHK(h->ball_c16.ensure((size_t)ct * per_tile));
+                    launch_build_tile_balls(h->Fw.as<double>(), h->N, h->Dt, h->Dpad, vt, h->ball_c.as<double>(), h->ball_cn.as<double>(),
+                                            h->ball_rad.as<float>(), h->stream, perm);
+                    launch_db16b_ratios(h->ball_c.as<double>(), vt, h->Dt, h->Dpad, h->rho16.as<double>(), h->stream, true);
+                    launch_build_db16b(h->ball_c.as<double>(), h->ball_cn.as<double>(), vt, h->Dt, h->Dpad, ct, 0, 0, nt, h->ball_c16.p, h->stream);
+                    HIPCHK(hipGetLastError());
+                    h->ball_tiles = vt;
+                    // one level up: the balls of 32 consecutive tiles, as one more operand in the same format
+                    h->ball_supers = 0;
+                    if (ct >= 64) {
+                        const int64_t ct2 = (ct + 31) / 32;
+                        CHK(h->ball_c2.ensure((size_t)ct * h->Dpad * sizeof(double)));
+                        CHK(h->ball_cn2.ensure((size_t)ct * sizeof(double)));
+                        CHK(h->ball_rad2.ensure((size_t)ct * sizeof(float)));
+                        CHK(h->ball_s16.ensure((size_t)ct2 * per_tile));
+                        launch_build_super_balls(h->ball_c.as<double>(), h->ball_rad.as<float>(), h->N, vt, h->Dt, h->Dpad, ct, h->ball_c2.as<double>(),
+                                                 h->ball_cn2.as<double>(), h->ball_rad2.as<float>(), h->stream);
+                        launch_db16b_ratios(h->ball_c2.as<double>(), ct, h->Dt, h->Dpad, h->rho16.as<double>(), h->stream, true);
+                        launch_build_db16b(h->ball_c2.as<double>(), h->ball_cn2.as<double>(), ct, h->Dt, h->Dpad, ct2, 0, 0, nt, h->ball_s16.p, h->stream);
+                        HIPCHK(hipGetLastError());
+                        h->ball_supers = ct;
+                    }
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+// A voice whose tiles are not compact (the ball pass listed more than coarse_gate_fraction of all tile pairs): cluster its units
+// and lay the prefilter's operands out cluster by cluster.  Once per set of weights; a voice the clustering does not help (the
+// ball pass lists too much again: units spread like a cloud, not like a curve) is not clustered again until a new database comes.
+// mean radius of the tiles' balls of the operands as they stand (0: no balls)
+static int mean_tile_radius(snk_engine *h, double *out)
+{
+    *out = 0.0;
+    if (h->ball_tiles < 1) return 0;
+    std::vector<float> r((size_t)h->ball_tiles);
+    CHK(d2h_sync(h, r.data(), h->ball_rad.p, r.size() * sizeof(float), h->stream));
+    double s = 0.0;
+    for (float v : r) s += (double)v;
+    *out = s / (double)r.size();
+    return 0;
+}
+
+int reorder_units(snk_engine *h)
+{
+    h->reorder_pending = false;
+    h->reorder_done = true;
+    if (!h->have_db || !h->have_weights || !kmeans_supported(h->Dt) || h->N < 4096 || h->ball_tiles < 1) return 0;
+    double r_old = 0.0, r_new = 0.0;
+    CHK(mean_tile_radius(h, &r_old));
+    CHK(h->perm2.ensure((size_t)h->N * sizeof(int32_t)));
+    CHK(h->km_ws.ensure(kmeans_workspace_bytes(h->N, h->Dt)));
+    {
+        StageTimer t(h, h->stream, TM_WEIGHTS);
+        launch_kmeans_order(h->Fw.as<double>(), h->N, h->Dt, h->Dpad, h->reorder_iters, h->km_ws.p, h->perm2.as<int32_t>(), h->stream);
+    }
+    HIPCHK(hipGetLastError());
+    const bool had = h->perm_ready;
+    std::swap(h->perm, h->perm2);
+    h->perm_ready = true;
+    CHK(build_prefilter_operands(h));
+    HIPCHK(hipGetLastError());
+    CHK(mean_tile_radius(h, &r_new));
+    h->reorder_radius_before = r_old; h->reorder_radius_after = r_new;
+    if (r_new < 0.8 * r_old) { h->reorders += 1; return 0; }
+    // the clusters' tiles are no tighter than the order the voice had (consecutive frames of a frame-level voice questioned by a
+    // batch of far-away rows; units spread like a cloud): that order stays, and the voice is not clustered again
+    std::swap(h->perm, h->perm2);
+    h->perm_ready = had;
+    h->reorder_useless = true;
+    CHK(build_prefilter_operands(h));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, int n_wj)
 {
     CHK(no_batch_in_flight(h, "snk_set_weights"));
@@ -429,96 +576,10 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
     h->gh_ready = false; h->gj_ready = false;                  // window norms of the hoisted greedy target term follow the target weights
     h->jw32_ready = false;                                     // ... and the float32 copy of the weighted join rows the join weights
     // float32 operands of the prefilter (knn16_kernels.hip): ||f||^2 rides in ONE spare padding column
-    h->f16_ready = false;
-    h->cls16_ready = false;
     h->knn_level = 0;
+    h->reorder_done = false; h->reorder_pending = false;     // (the order a voice was given stays: any order is valid, and usually still a good one)
     h->vit = snk_engine::VitLatch();                         // a new set of weights: the Viterbi latch starts over
-    if (h->have_db && h->Dpad <= 256 && h->Dpad - h->Dt >= 1) {
-        // tiles per wavefront: the database fragments of a slab stay in registers (32 * Dpad / 64
-        // floats per tile and lane), so wider rows leave room for fewer tiles
-        const int dch16 = h->Dpad / 64;
-        const int nt = (dch16 == 1) ? h->nt16 : (dch16 == 2) ? 2 : 1;
-        h->nt16_eff = nt;
-        // |key~ - key| <= c (2 |q| Fmax + Fmax^2): operand rounding 2^-24 each and an f32 FMA chain of
-        // Dpad + 1 terms; c = 2 x that (8e-6 at Dpad = 64)
-        h->eps_c = 2.0 * (double)(h->Dpad + 3) * 5.9604644775390625e-08;
-        CHK(h->fmax2.ensure(sizeof(double)));
-        launch_fmax(h->fnorm.as<double>(), h->N, h->fmax2.as<double>(), h->stream);
-        double fmax2 = 0.0;
-        CHK(d2h_sync(h, &fmax2, h->fmax2.p, sizeof(double), h->stream));
-        const int64_t slab_rows = 32 * nt;
-        h->n_slabs16 = (h->N + slab_rows - 1) / slab_rows;
-        int64_t stride = (int64_t)floor(1.0 / h->sample_frac + 0.5);
-        if (stride < 1) stride = 1;
-        // small databases (one rank's shard of a row-sharded one): keep >= 512 sample groups so the
-        // K-th smallest group minimum stays close to the K-th nearest sampled unit
-        while (stride > 1 && (h->N / stride) / slab_rows < h->min_sample_slabs) --stride;
-        h->stride16 = stride;
-        h->n_slabs16_a = (h->N / stride) / slab_rows;
-        if (fmax2 < 1.0e30 && h->n_slabs16_a >= 1) {
-            const int64_t tiles_b = h->n_slabs16 * nt, tiles_a = h->n_slabs16_a * nt;
-            const size_t per_tile = (size_t)8 * 64 * 16 * dch16;
-            CHK(h->a16h.ensure(tiles_b * per_tile));
-            CHK(h->s16h.ensure(tiles_a * per_tile));
-            launch_build_db16(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_b, 0, 0, nt,
-                              h->a16h.p, h->stream);
-            launch_build_db16(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_a, stride,
-                              2 * h->n_slabs16_a, nt, h->s16h.p, h->stream);
-            HIPCHK(hipGetLastError());
-            h->f16_ready = true;
-            h->bf16_ready = false;
-            if (h->prefilter >= 1 && knn_sweep16b_supported(nt, dch16, h->Dt, h->Dpad, false)) {
-                // key bound = cq ||f|| (what the split drops: measured, prepare_queries16b_kernel) + c_acc (...):
-                // 2^-20 per MFMA over the 4 `terms` MFMAs of a chunk's chain and the norm pieces' 2^-24 (knn16_kernels.hip)
-                const int terms = h->prefilter == 2 ? 4 : 3;
-                // (chains of one 64-column chunk: 4 `terms` MFMAs; the chunks' sums are added in float32)
-                h->eps_c_bf = 1.02 * (SNK_BF16_MFMA_UNIT * (double)(terms * 4 + 1) + 6e-8 * (double)(2 * (h->Dpad / 64) + 1));
-                CHK(h->rho16.ensure(2 * sizeof(double)));
-                launch_db16b_ratios(h->Fw.as<double>(), h->N, h->Dt, h->Dpad, h->rho16.as<double>(), h->stream);
-                CHK(h->a16l.ensure(tiles_b * per_tile));
-                CHK(h->s16l.ensure(tiles_a * per_tile));
-                launch_build_db16b(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_b, 0, 0, nt,
-                                   h->a16l.p, h->stream);
-                launch_build_db16b(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, tiles_a, stride,
-                                   2 * h->n_slabs16_a, nt, h->s16l.p, h->stream);
-                HIPCHK(hipGetLastError());
-                h->bf16_ready = true;
-                // pass 0 of the two-pass filter: centre and radius of every 32-unit tile, the centres as one more bf16-split
-                // operand (its dropped-piece ratios join the database's: one key bound serves both)
-                h->ball_tiles = 0;
-                h->filter_coarse = false; h->filter_onepass = false;
-                h->filter_calls = 0; h->probe_next = 16; h->probe_period = 16; h->probe_ran = 0;
-                if (h->prefilter_balls) {
-                    const int64_t vt = (h->N + 31) / 32, ct = (vt + 31) / 32;
-                    CHK(h->ball_c.ensure((size_t)vt * h->Dpad * sizeof(double)));
-                    CHK(h->ball_cn.ensure((size_t)vt * sizeof(double)));
-                    CHK(h->ball_rad.ensure((size_t)vt * sizeof(float)));
-                    CHK(h->ball_c16.ensure((size_t)ct * per_tile));
-                    launch_build_tile_balls(h->Fw.as<double>(), h->N, h->Dt, h->Dpad, vt, h->ball_c.as<double>(), h->ball_cn.as<double>(),
-                                            h->ball_rad.as<float>(), h->stream);
-                    launch_db16b_ratios(h->ball_c.as<double>(), vt, h->Dt, h->Dpad, h->rho16.as<double>(), h->stream, true);
-                    launch_build_db16b(h->ball_c.as<double>(), h->ball_cn.as<double>(), vt, h->Dt, h->Dpad, ct, 0, 0, nt, h->ball_c16.p, h->stream);
-                    HIPCHK(hipGetLastError());
-                    h->ball_tiles = vt;
-                    // one level up: the balls of 32 consecutive tiles, as one more operand in the same format
-                    h->ball_supers = 0;
-                    if (ct >= 64) {
-                        const int64_t ct2 = (ct + 31) / 32;
-                        CHK(h->ball_c2.ensure((size_t)ct * h->Dpad * sizeof(double)));
-                        CHK(h->ball_cn2.ensure((size_t)ct * sizeof(double)));
-                        CHK(h->ball_rad2.ensure((size_t)ct * sizeof(float)));
-                        CHK(h->ball_s16.ensure((size_t)ct2 * per_tile));
-                        launch_build_super_balls(h->ball_c.as<double>(), h->ball_rad.as<float>(), h->N, vt, h->Dt, h->Dpad, ct, h->ball_c2.as<double>(),
-                                                 h->ball_cn2.as<double>(), h->ball_rad2.as<float>(), h->stream);
-                        launch_db16b_ratios(h->ball_c2.as<double>(), ct, h->Dt, h->Dpad, h->rho16.as<double>(), h->stream, true);
-                        launch_build_db16b(h->ball_c2.as<double>(), h->ball_cn2.as<double>(), ct, h->Dt, h->Dpad, ct2, 0, 0, nt, h->ball_s16.p, h->stream);
-                        HIPCHK(hipGetLastError());
-                        h->ball_supers = ct;
-                    }
-                }
-            }
-        }
-    }
+    CHK(build_prefilter_operands(h));
     h->wide16_ready = false;
     if (h->have_db && h->prefilter >= 1 && knn_wide16b_supported(h->Dt, h->Dpad)) {
         // rows of 257 .. 512 columns (Synthesiser.join_knn on the doubled join rows of an epoch voice): bf16-split operands

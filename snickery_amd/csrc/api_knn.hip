@@ -44,7 +44,12 @@ void judge_filter(snk_engine *h, bool ran_balls, double ball_limit, bool ran_coa
                   int probe_kind, double probe_limit, unsigned int probe_listed)
 {
     auto left = [&]() { h->probe_period = 16; h->probe_next = h->filter_calls + 16; };
-    if (ran_balls && !h->filter_coarse && (double)listed > ball_limit) { h->filter_coarse = true; h->ball_switches += 1; left(); }
+    if (ran_balls && !h->filter_coarse && (double)listed > ball_limit) {
+        h->filter_coarse = true; h->ball_switches += 1; left();
+        // the tiles are not compact: give the voice an order of its own before the next call (once per set of weights; a voice the
+        // clustering did not help stays as it is)
+        if (h->reorder && !h->reorder_useless && !h->reorder_done) h->reorder_pending = true;
+    }
     if (ran_coarse && !h->filter_onepass && (double)listed > coarse_limit) { h->filter_onepass = true; h->onepass_switches += 1; left(); }
     // the counting probe of the pass the voice left (snk_engine.h: latch_rearm)
     const bool applies = (probe_kind == 1 && h->filter_coarse && !h->filter_onepass) || (probe_kind == 2 && h->filter_onepass);
@@ -232,6 +237,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
         h->last_retries = 0; h->last_T = T;
         return 0;
     }
+    if (h->reorder_pending && h->precision == 1) CHK(reorder_units(h));      // (queued on this stream: behind every call that still reads the old operands)
     const int64_t Tpad = roundup(T, 32);
     const KnnPlan p0 = make_plan(h, K);
     const bool cls = qclass_dev != nullptr;
@@ -294,10 +300,11 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
                 const int64_t tiles_b = h->n_slabs16 * h->nt16_eff, tiles_a = h->n_slabs16_a * h->nt16_eff;
                 CHK(h->cls16_full.ensure((size_t)tiles_b * 32 * sizeof(int32_t)));
                 CHK(h->cls16_samp.ensure((size_t)tiles_a * 32 * sizeof(int32_t)));
+                const int32_t *perm = h->perm_ready ? h->perm.as<int32_t>() : nullptr;
                 launch_build_class16(h->unit_class.as<int32_t>(), h->N, tiles_b, 0, 0, h->nt16_eff,
-                                     h->cls16_full.as<int32_t>(), s);
+                                     h->cls16_full.as<int32_t>(), s, perm);
                 launch_build_class16(h->unit_class.as<int32_t>(), h->N, tiles_a, h->stride16, 2 * h->n_slabs16_a,
-                                     h->nt16_eff, h->cls16_samp.as<int32_t>(), s);
+                                     h->nt16_eff, h->cls16_samp.as<int32_t>(), s, perm);
                 h->cls16_ready = true;
             }
             cls_full = h->cls16_full.as<int32_t>();
@@ -479,7 +486,8 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
         {
             StageTimer t(h, s, TM_KNN_BUCKET);
             launch_knn_bucket(h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
-                              Tpad, h->N, h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap, status_dev, s);
+                              Tpad, h->N, h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap, status_dev, s,
+                              h->perm_ready ? h->perm.as<int32_t>() : nullptr);
         }
         if (refine && bound_in && h->comm_ranks > 1 && h->shard_refine) {
             StageTimer t(h, s, TM_KNN_BUCKET);
@@ -671,6 +679,7 @@ int snk_prefilter_minima(snk_handle h, const double *Q, int64_t T, int D, float 
     CHK(no_batch_in_flight(h, "snk_prefilter_minima"));
     HIPCHK(hipSetDevice(h->device));
     if (!h->f16_ready) return fail("snk_prefilter_minima: this database shape has no float32 / bf16 prefilter");
+    if (h->perm_ready) return fail("snk_prefilter_minima: the engine gave this voice an order of its own (slabs are not runs of consecutive units; option reorder 0)");
     if (T < 1 || T > SNK_KNN_MAX_ROWS) return fail("snk_prefilter_minima: T outside 1..%d", (int)SNK_KNN_MAX_ROWS);
     const int64_t n_slabs = h->n_slabs16;
     if (n_slabs_out) *n_slabs_out = n_slabs;

@@ -183,6 +183,14 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0 && value != 2.0) return fail("viterbi_mode must be 0 (dense exact join + recursion), 1 (lower bounds + sparse exact recursion) or 2 (auto)");
         CHK(no_batch_in_flight(h, "snk_set_option(viterbi_mode)"));
         h->viterbi_mode = (int)value;
+    } else if (!strcmp(name, "reorder")) {
+        if (value != 0.0 && value != 1.0) return fail("reorder must be 0 or 1");
+        CHK(no_batch_in_flight(h, "snk_set_option(reorder)"));
+        h->reorder = (int)value;
+        if (!h->reorder && h->perm_ready) { h->perm_ready = false; h->have_weights = false; }     // back to the database order with the next snk_set_weights
+    } else if (!strcmp(name, "reorder_iterations")) {
+        if (!(value >= 1.0 && value <= 64.0)) return fail("reorder_iterations must be in 1..64");
+        h->reorder_iters = (int)value;
     } else if (!strcmp(name, "viterbi_latch") || !strcmp(name, "latch_rearm")) {
         if (value != 0.0 && value != 1.0) return fail("%s must be 0 or 1", name);
         CHK(no_batch_in_flight(h, "snk_set_option(latch)"));
@@ -353,6 +361,12 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "filter_coarse")) *out = h->filter_coarse ? 1 : 0;       // 1: the ball pass listed too many pairs for this voice
     else if (!strcmp(name, "ball_switches")) *out = (double)h->ball_switches;
     else if (!strcmp(name, "onepass_switches")) *out = (double)h->onepass_switches;
+    else if (!strcmp(name, "reorder")) *out = h->reorder;
+    else if (!strcmp(name, "reordered")) *out = h->perm_ready ? 1 : 0;               // 1: the prefilter's operands stand in an order the engine chose (kmeans_kernels.hip)
+    else if (!strcmp(name, "reorders")) *out = (double)h->reorders;
+    else if (!strcmp(name, "reorder_useless")) *out = h->reorder_useless ? 1 : 0;
+    else if (!strcmp(name, "reorder_radius_before")) *out = h->reorder_radius_before;
+    else if (!strcmp(name, "reorder_radius_after")) *out = h->reorder_radius_after;
     else if (!strcmp(name, "filter_rearms")) *out = (double)h->filter_rearms;        // times a counting probe took the voice back to a faster filter
     else if (!strcmp(name, "filter_probe_period")) *out = h->probe_period;
     else if (!strcmp(name, "latch_rearm")) *out = h->latch_rearm;

@@ -401,6 +401,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
         b.ball_limit = h->ball_pass_ran ? h->ball_limit : -1.0;
         b.coarse_limit = h->coarse_pass_ran ? h->coarse_limit : -1.0;
         b.probe_kind[(size_t)g] = h->probe_ran; b.probe_limit[(size_t)g] = h->probe_limit;
+        b.operand_gen = h->operand_gen;
         CHK(viterbi_group(h, g, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
                           b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), n_utts));
     }
@@ -442,7 +443,7 @@ int snk_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, i
     char *st = (char *)b.stage.p;
     // deferred K-NN status words: redo the (rare) group whose sampled thresholds overflowed a list
     const int *status = reinterpret_cast<const int *>(st + sz_path + 2 * sz_u);
-    for (int g = 0; g < b.n_groups; ++g)
+    for (int g = 0; g < b.n_groups && b.operand_gen == h->operand_gen; ++g)       // (a batch that ran on operands since rebuilt says nothing about the new ones)
         judge_filter(h, b.ball_limit >= 0.0, b.ball_limit, b.coarse_limit >= 0.0, b.coarse_limit, (unsigned int)status[b.n_groups + g],
                      (unsigned int)status[2 * b.n_groups + g] != 0xffffffffu ? b.probe_kind[(size_t)g] : 0, b.probe_limit[(size_t)g],
                      (unsigned int)status[2 * b.n_groups + g]);

@@ -53,28 +53,35 @@ __device__ __forceinline__ int64_t tile_row16(int64_t tile, int r, int64_t sampl
     const int64_t m = (int64_t)nt * 16 + reg;
     return (m * G + (2 * w + hh)) * sample_stride;
 }
+// ... and the unit that stands at that POSITION of the operand: the database order, or the order the engine gave a voice whose
+// own order says nothing about closeness (kmeans_kernels.hip; perm[position] = unit, positions >= N are padding either way)
+__device__ __forceinline__ int64_t unit_at(const int32_t *__restrict__ perm, int64_t pos, int64_t N)
+{
+    return (perm && pos < N) ? (int64_t)perm[pos] : pos;
+}
 
 // class id of every tile row in tile order (-1 beyond the database): what the class-restricted sweep
 // compares with the query's class
 __global__ void build_class16_kernel(const int32_t *__restrict__ unit_class, int64_t N, int64_t n_tiles,
-                                     int64_t sample_stride, int64_t G, int nt_a, int32_t *__restrict__ out)
+                                     int64_t sample_stride, int64_t G, int nt_a, int32_t *__restrict__ out,
+                                     const int32_t *__restrict__ perm)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tiles * 32) return;
     const int64_t row = tile_row16(i >> 5, (int)(i & 31), sample_stride, G, nt_a);
-    out[i] = (row < N) ? unit_class[row] : -1;
+    out[i] = (row < N) ? unit_class[unit_at(perm, row, N)] : -1;
 }
 
 void launch_build_class16(const int32_t *unit_class, int64_t N, int64_t n_tiles, int64_t sample_stride, int64_t G,
-                          int nt_a, int32_t *out, hipStream_t s)
+                          int nt_a, int32_t *out, hipStream_t s, const int32_t *perm)
 {
     hipLaunchKernelGGL(build_class16_kernel, dim3((unsigned)((n_tiles * 32 + 255) / 256)), dim3(256), 0, s,
-                       unit_class, N, n_tiles, sample_stride, G, nt_a, out);
+                       unit_class, N, n_tiles, sample_stride, G, nt_a, out, perm);
 }
 
 __global__ void build_db16_kernel(const double *__restrict__ Fw, const double *__restrict__ fnorm, int64_t N,
                                   int Dt, int Dpad, int64_t n_tiles, int64_t sample_stride, int64_t G,
-                                  int nt_a, f32x4 *__restrict__ A32)
+                                  int nt_a, f32x4 *__restrict__ A32, const int32_t *__restrict__ perm)
 {
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -83,14 +90,15 @@ __global__ void build_db16_kernel(const double *__restrict__ Fw, const double *_
     const int64_t tile = item / per_tile;
     const int j4 = (int)(item % per_tile);            // chunk * 8 + j4
     const int r = lane & 31, h = lane >> 5;
-    const int64_t row = tile_row16(tile, r, sample_stride, G, nt_a);
+    const int64_t pos = tile_row16(tile, r, sample_stride, G, nt_a);
+    const int64_t row = unit_at(perm, pos, N);
     f32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = 64 * (j4 >> 3) + 2 * (4 * (j4 & 7) + i) + h;       // k-step kk = 4 (j4 & 7) + i multiplies columns 2kk, 2kk+1:
                                                                        // padding columns gather in the last k-steps
         float x = 0.0f;
-        if (row < N) {
+        if (pos < N) {
             if (c < Dt) x = (float)Fw[row * Dpad + c];
             else if (c == Dt) x = (float)fnorm[row];
         } else if (c == Dt) x = 3.0e38f;           // padding unit: key never passes
@@ -116,11 +124,11 @@ __global__ void fmax_kernel(const double *__restrict__ fnorm, int64_t N, double 
 }
 
 void launch_build_db16(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,
-                       int64_t sample_stride, int64_t G, int nt_a, void *A32, hipStream_t s)
+                       int64_t sample_stride, int64_t G, int nt_a, void *A32, hipStream_t s, const int32_t *perm)
 {
     const int64_t items = n_tiles * 8 * (Dpad / 64);
     hipLaunchKernelGGL(build_db16_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, Fw, fnorm, N, Dt,
-                       Dpad, n_tiles, sample_stride, G, nt_a, reinterpret_cast<f32x4 *>(A32));
+                       Dpad, n_tiles, sample_stride, G, nt_a, reinterpret_cast<f32x4 *>(A32), perm);
 }
 
 void launch_fmax(const double *fnorm, int64_t N, double *out, hipStream_t s)
@@ -536,7 +544,7 @@ __device__ __forceinline__ void db16b_column(const double *__restrict__ Fw, cons
 
 __global__ void build_db16b_kernel(const double *__restrict__ Fw, const double *__restrict__ fnorm, int64_t N,
                                    int Dt, int Dpad, int64_t n_tiles, int64_t sample_stride, int64_t G, int nt_a,
-                                   u32x4 *__restrict__ A16)
+                                   u32x4 *__restrict__ A16, const int32_t *__restrict__ perm)
 {
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // (tile, kb)
@@ -545,7 +553,8 @@ __global__ void build_db16b_kernel(const double *__restrict__ Fw, const double *
     const int64_t tile = item / KB;
     const int kb = (int)(item % KB);
     const int r = lane & 31, h = lane >> 5;
-    const int64_t row = tile_row16(tile, r, sample_stride, G, nt_a);
+    const int64_t pos = tile_row16(tile, r, sample_stride, G, nt_a);
+    const int64_t row = pos < N ? unit_at(perm, pos, N) : pos;          // (a position past the database stays one: padding unit)
     unsigned int hi[8], lo[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) db16b_column(Fw, fnorm, N, Dt, Dpad, row, 16 * kb + 8 * h + j, hi[j], lo[j]);
@@ -557,11 +566,11 @@ __global__ void build_db16b_kernel(const double *__restrict__ Fw, const double *
 }
 
 void launch_build_db16b(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,
-                        int64_t sample_stride, int64_t G, int nt_a, void *A16, hipStream_t s)
+                        int64_t sample_stride, int64_t G, int nt_a, void *A16, hipStream_t s, const int32_t *perm)
 {
     const int64_t items = n_tiles * (Dpad / 16);
     hipLaunchKernelGGL(build_db16b_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, Fw, fnorm, N, Dt, Dpad,
-                       n_tiles, sample_stride, G, nt_a, reinterpret_cast<u32x4 *>(A16));
+                       n_tiles, sample_stride, G, nt_a, reinterpret_cast<u32x4 *>(A16), perm);
 }
 
 // What the split drops, measured on the data instead of assumed at its worst: with f = fh + fl + rf per element,
@@ -1299,7 +1308,7 @@ static int coarse_wps()
 // ===========================================================================================================
 __global__ void __launch_bounds__(256)
 build_tile_balls_kernel(const double *__restrict__ Fw, int64_t N, int Dt, int Dpad, int64_t n_tiles, double *__restrict__ C,
-                        double *__restrict__ cnorm, float *__restrict__ rad)
+                        double *__restrict__ cnorm, float *__restrict__ rad, const int32_t *__restrict__ perm)
 {
     // one wavefront per tile: lane = column (strided), rows one after the other
     const int lane = threadIdx.x & 63;
@@ -1311,7 +1320,7 @@ build_tile_balls_kernel(const double *__restrict__ Fw, int64_t N, int Dt, int Dp
     for (int c = lane; c < Dpad; c += 64) {
         double m = 0.0;
         if (c < Dt && n > 0) {
-            for (int i = 0; i < n; ++i) m += Fw[(r0 + i) * Dpad + c];
+            for (int i = 0; i < n; ++i) m += Fw[unit_at(perm, r0 + i, N) * Dpad + c];
             m /= (double)n;
         }
         C[tile * Dpad + c] = m;
@@ -1323,7 +1332,7 @@ build_tile_balls_kernel(const double *__restrict__ Fw, int64_t N, int Dt, int Dp
     for (int i = 0; i < n; ++i) {
         double d2 = 0.0;
         for (int c = lane; c < Dt; c += 64) {
-            const double d = Fw[(r0 + i) * Dpad + c] - C[tile * Dpad + c];        // (this lane's own columns: written above)
+            const double d = Fw[unit_at(perm, r0 + i, N) * Dpad + c] - C[tile * Dpad + c];        // (this lane's own columns: written above)
             d2 += d * d;
         }
 #pragma unroll
@@ -1339,10 +1348,10 @@ build_tile_balls_kernel(const double *__restrict__ Fw, int64_t N, int Dt, int Dp
 }
 
 void launch_build_tile_balls(const double *Fw, int64_t N, int Dt, int Dpad, int64_t n_tiles, double *C, double *cnorm, float *rad,
-                             hipStream_t s)
+                             hipStream_t s, const int32_t *perm)
 {
     hipLaunchKernelGGL(build_tile_balls_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, Fw, N, Dt, Dpad, n_tiles, C,
-                       cnorm, rad);
+                       cnorm, rad, perm);
 }
 
 // One level up: the ball of 32 consecutive tiles (1 024 units) -- centre C = mean of its units, radius <= max_t (||c_t - C|| + r_t).

@@ -466,7 +466,8 @@ size_t knn_pool_bytes(int max_chunks) { return (size_t)max_chunks * POOL_CHUNK *
 __global__ void __launch_bounds__(256)
 knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__restrict__ pool_ctl,
                   const int *__restrict__ chunk_fill, int max_chunks, int Tpad, int n_valid, int *__restrict__ cnt,
-                  double *__restrict__ lkey, int *__restrict__ lidx, int cap, int *__restrict__ status)
+                  double *__restrict__ lkey, int *__restrict__ lidx, int cap, int *__restrict__ status,
+                  const int32_t *__restrict__ perm)
 {
     // per chunk: LDS histogram by row -> one global atomic per (chunk, row) reserves a run of
     // list slots -> entries of one row land contiguously
@@ -511,7 +512,8 @@ knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__rest
                 const int slot = hist[en[k].row] + rank[k];
                 if (slot < cap) {
                     lkey[(int64_t)en[k].row * cap + slot] = en[k].key;
-                    lidx[(int64_t)en[k].row * cap + slot] = en[k].idx;
+                    // (a reordered operand -- kmeans_kernels.hip -- hands out positions: everything behind this line sees unit ids)
+                    lidx[(int64_t)en[k].row * cap + slot] = perm ? perm[en[k].idx] : en[k].idx;
                 }
             }
         }
@@ -525,7 +527,7 @@ knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__rest
 
 void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int *chunk_fill,
                        int max_chunks, int64_t Tpad, int64_t n_valid, int *cnt, double *lkey, int *lidx,
-                       int cap, int *status, hipStream_t s)
+                       int cap, int *status, hipStream_t s, const int32_t *perm)
 {
     static size_t attr[32] = {0};
     if ((size_t)Tpad * sizeof(int) > 65536)
@@ -538,7 +540,7 @@ void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int
     per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
     hipLaunchKernelGGL(knn_bucket_kernel, dim3(256 * per_cu), dim3(256), lds, s,
                        reinterpret_cast<const PoolEntry *>(pool), pool_ctl, chunk_fill, max_chunks,
-                       (int)Tpad, (int)n_valid, cnt, lkey, lidx, cap, status);
+                       (int)Tpad, (int)n_valid, cnt, lkey, lidx, cap, status, perm);
 }
 
 // ---------------------------------------------------------------------------

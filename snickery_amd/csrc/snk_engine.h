@@ -181,6 +181,7 @@ struct BatchSlot {    // one submitted batch (snk_knn_viterbi_batch_submit / _co
     std::vector<int> probe_kind;          // per group: the counting probe its K-NN call carried (0 none, 1 ball pass, 2 coarse sweep)
     std::vector<double> probe_limit;
     int64_t seq = -1;                     // number of this batch (timing events of the Viterbi latch)
+    int64_t operand_gen = -1;             // generation of the prefilter's operands its K-NN ran on
     bool vit_dense = false, vit_trial = false, vit_judged = false;
     int64_t total = 0;
     std::vector<int> first;
@@ -272,6 +273,15 @@ struct snk_engine {
     // with the pass it left, in a form that only COUNTS the tile pairs it would list (pair_cap 0: no list, no refine pass): the ball
     // pass for a voice on the coarse sweep (a thirtieth of the database), the coarse sweep for a voice on the one-pass sweep.  A count
     // under half the limit that made the voice leave takes it back; a count above doubles the probe period (16 .. 256 calls).
+    // ... and a voice whose tiles are not compact is given an ORDER of its own (option reorder, default 1; kmeans_kernels.hip): when
+    // the ball pass lists too many pairs the units are clustered once (per set of weights) and the prefilter's operands rebuilt cluster
+    // by cluster; perm[position] = unit, applied by the operand builders and undone by the bucket kernel -- no result changes
+    int reorder = 1, reorder_iters = 4;
+    DevBuf perm, perm2, km_ws;
+    double reorder_radius_before = 0.0, reorder_radius_after = 0.0;      // mean radius of the tiles' balls around the last clustering
+    bool perm_ready = false, reorder_pending = false, reorder_done = false, reorder_useless = false;
+    int64_t reorders = 0;
+    int64_t operand_gen = 0;              // generation of the prefilter's operands: what a batch listed is judged only against the operands it ran on
     int latch_rearm = 1;
     int64_t filter_calls = 0, probe_next = 16;
     int probe_period = 16, probe_ran = 0;
@@ -430,6 +440,10 @@ int h2d_rows(snk_engine *h, void *dst_dev, size_t dst_pitch, const void *src_hos
 int h2d_sync(snk_engine *h, void *dst_dev, const void *src_host, size_t bytes);
 int d2h_sync(snk_engine *h, void *dst_host, const void *src_dev, size_t bytes, hipStream_t st);
 int h2d_via(HostBuf &stage, void *dst_dev, const void *src_host, size_t bytes, hipStream_t st);
+
+// the prefilter's operands for the current weights / an order for a voice whose tiles are not compact (api_core.hip)
+int build_prefilter_operands(snk_engine *h);
+int reorder_units(snk_engine *h);
 
 // state checks (api_core.hip)
 int check_ready(snk_engine *h, bool need_target, bool need_join);

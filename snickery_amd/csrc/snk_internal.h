@@ -98,7 +98,7 @@ void launch_knn_reset(int *cnt, int64_t Tpad, int *status, unsigned int *pool_ct
                       unsigned int *slab_counter, int *chunk_fill, int max_chunks, hipStream_t s);
 void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int *chunk_fill,
                        int max_chunks, int64_t Tpad, int64_t n_valid, int *cnt, double *lkey, int *lidx,
-                       int cap, int *status, hipStream_t s);
+                       int cap, int *status, hipStream_t s, const int32_t *perm = nullptr);     // perm: the entries carry POSITIONS of a reordered operand
 // stage C: per-row select + exact re-rank in canonical order + sort
 void launch_knn_exact_rows(const double *Fw, int Dpad, int D, int64_t N, const double *Qp, const int *rows,
                            int n_rows, int K, double *scratch, int64_t scratch_pitch, const int32_t *unit_class,
@@ -131,13 +131,19 @@ void launch_shard_unpack(const unsigned char *in, const int64_t *roff, const int
                          double *d2_out, int64_t *id_out, hipStream_t s);
 
 // ---- float32 prefilter (knn16_kernels.hip) ---------------------------------------------
+// perm (nullable, here and below): the order the engine gave the prefilter's operands (kmeans_kernels.hip): position -> unit
 void launch_build_db16(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,
-                       int64_t sample_stride, int64_t G, int nt_a, void *A32, hipStream_t s);
+                       int64_t sample_stride, int64_t G, int nt_a, void *A32, hipStream_t s, const int32_t *perm = nullptr);
+// an order for the units of a voice whose tiles are not compact: k-means clusters laid out one after the other (kmeans_kernels.hip)
+int kmeans_clusters(int64_t N);
+bool kmeans_supported(int Dt);
+size_t kmeans_workspace_bytes(int64_t N, int Dt);
+void launch_kmeans_order(const double *Fw, int64_t N, int Dt, int Dpad, int iters, void *workspace, int *perm, hipStream_t s);
 void launch_fmax(const double *fnorm, int64_t N, double *out, hipStream_t s);
 void launch_prepare_queries16(const double *Qp, const double *qnorm, int64_t T, int Dt, int Dpad,
                               const double *fmax2, double eps_c, void *B32, double *eps, hipStream_t s);
 void launch_build_class16(const int32_t *unit_class, int64_t N, int64_t n_tiles, int64_t sample_stride, int64_t G,
-                          int nt_a, int32_t *out, hipStream_t s);
+                          int nt_a, int32_t *out, hipStream_t s, const int32_t *perm = nullptr);
 bool launch_knn_sweep16(int mode, int nt, int dch, int k_steps, int grid_cus, const void *A32, const void *B32,
                         const int32_t *tile_class, const int32_t *query_class,
                         const float *thr32, int64_t T32, int64_t n_slabs, unsigned int *ctr,
@@ -161,7 +167,7 @@ void launch_knn_wide16b(int mode, int terms, int grid_cus, const void *A16, cons
 // bf16-split prefilter (knn16_kernels.hip)
 bool knn_sweep16b_supported(int nt, int dch, int Dt, int Dpad, bool cls);
 void launch_build_db16b(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,
-                        int64_t sample_stride, int64_t G, int nt_a, void *A16, hipStream_t s);
+                        int64_t sample_stride, int64_t G, int nt_a, void *A16, hipStream_t s, const int32_t *perm = nullptr);
 void launch_prepare_queries16b(const double *Qp, const double *qnorm, int64_t T, int Dt, int Dpad, const double *fmax2,
                                const double *rho, double c_acc, void *B16, double *eps, double *cq, hipStream_t s,
                                double c_coarse = 0.0, double *e1 = nullptr);      // e1: what the hi.hi term alone may be off by
@@ -175,7 +181,7 @@ bool launch_knn_filter16c(int terms, int dch, int grid_cus, const void *A16, con
                           bool run_refine = true);     // false: the first pass alone (a probe that counts pairs: pair_cap 0)
 // pass 0: the tiles' balls (centre, radius) against the query rows; lists pairs, then gates the coarse sweep
 void launch_build_tile_balls(const double *Fw, int64_t N, int Dt, int Dpad, int64_t n_tiles, double *C, double *cnorm, float *rad,
-                             hipStream_t s);
+                             hipStream_t s, const int32_t *perm = nullptr);
 void launch_ball_query_terms(const float *thr32, const double *eps, const double *qnorm, int64_t T, int64_t T32, float *tq, float *nq,
                              hipStream_t s);
 bool launch_knn_balls16b(int terms, int dch, int grid_cus, const void *C16, const void *B16, const float *rad, const float *tq,

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import snk_oracle as o
+import snk_oracle_c as oc
 
 pytestmark = pytest.mark.gpu
 
@@ -214,8 +215,10 @@ def test_units_in_no_order_go_to_the_one_pass_sweep(engine):
     """A database whose units stand in random order: a tile of 32 holds unrelated frames, so the ball pass lists (nearly) every
     tile pair -> the voice goes to the coarse sweep; that one lists most pairs too -> the voice goes on to the one-pass
     three-term sweep (`filter_onepass`), which lists nothing.  Results are the oracle's at every stage of the descent, and once
-    there the calls run without an overflowing list (no fallback to the exact sweep)."""
+    there the calls run without an overflowing list (no fallback to the exact sweep).  (`reorder 0`: the engine's own answer to such
+    a voice -- an order of its own, test_a_voice_in_no_order_is_given_one -- is switched off to see the descent.)"""
     engine.set_option('prefilter', 1); engine.set_option('prefilter_two_pass', 1); engine.set_option('prefilter_ball_bound', 0)
+    engine.set_option('reorder', 0)
     N, Dt, K, T = 65536, 61, 100, 600
     F0, JC0 = o.synthetic_db(N, Dt, 24, 5)
     perm = np.random.RandomState(3).permutation(N)
@@ -239,6 +242,7 @@ def test_units_in_no_order_go_to_the_one_pass_sweep(engine):
     # new weights: the voice is judged afresh
     engine.set_weights(wt * 1.5, wj)
     assert engine.info('filter_coarse') == 0 and engine.info('filter_onepass') == 0
+    engine.set_option('reorder', 1)
 
 
 def test_batches_on_units_in_no_order_settle_on_the_one_pass_sweep(engine):
@@ -246,6 +250,7 @@ def test_batches_on_units_in_no_order_settle_on_the_one_pass_sweep(engine):
     are seen at the batch's collect: after a few batches the voice sits on the one-pass sweep and no group is redone any more;
     paths and costs equal the single-utterance calls' at every stage."""
     engine.set_option('prefilter', 1); engine.set_option('prefilter_two_pass', 1); engine.set_option('prefilter_ball_bound', 0)
+    engine.set_option('reorder', 0)
     N, Dt, Dj, K = 65536, 61, 24, 50
     F0, JC0 = o.synthetic_db(N, Dt, Dj, 8)
     perm = np.random.RandomState(4).permutation(N)
@@ -267,6 +272,63 @@ def test_batches_on_units_in_no_order_settle_on_the_one_pass_sweep(engine):
             assert list(paths[u]) == single[u][0] and costs[u] == single[u][1]
     assert engine.info('filter_coarse') == 1 and engine.info('filter_onepass') == 1, redos
     assert redos[-1] == 0 and redos[-2] == 0, redos
+    engine.set_option('reorder', 1)
+
+
+def test_a_voice_in_no_order_is_given_one(engine):
+    """The engine's answer to units in no order (kmeans_kernels.hip): when the ball pass lists too many tile pairs the units are
+    clustered and the prefilter's operands laid out cluster by cluster -- tiles are compact again, the ball pass serves the voice,
+    nothing of the permutation reaches a result (candidates, distances, tie order: the oracle's on the database order).  A voice
+    whose own order is already the better one (consecutive frames) keeps it even when a batch of far rows questions it."""
+    engine.set_option('prefilter', 1); engine.set_option('prefilter_two_pass', 1); engine.set_option('prefilter_ball_bound', 0)
+    engine.set_option('reorder', 1)
+    N, Dt, K, T = 262144, 61, 100, 600
+    F0, JC0 = o.synthetic_db(N, Dt, 8, 5)
+    perm = np.random.RandomState(3).permutation(N)
+    F_unw, JC_unw = F0[perm], JC0[np.concatenate([perm, [N]])]
+    dup = np.random.RandomState(9).randint(0, N, 50)
+    F_unw[dup] = F_unw[(dup + 7777) % N]                       # exact duplicates: ties must still go to the lower unit id
+    rng = np.random.RandomState(105)
+    wt, wj = 0.2 + rng.rand(Dt), np.full(8, 0.1)
+    F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    U = o.synthetic_targets(F_unw, T, seed=7) * wt
+    U[:50] = F_unw[dup] * wt                                   # rows that ARE duplicated units
+    rows = np.unique(np.concatenate([np.arange(0, 50, 7), np.linspace(50, T - 1, 12).astype(np.int64)]))
+    oc_, od_ = oc.knn(F, U[rows], K)
+    for call in range(4):
+        cand, dist = engine.knn(U, K)
+        assert np.array_equal(cand[rows], oc_) and np.array_equal(dist[rows], od_), call
+    assert engine.info('reordered') == 1 and engine.info('reorders') == 1
+    assert engine.info('reorder_radius_after') < 0.5 * engine.info('reorder_radius_before')
+    assert engine.info('filter_coarse') == 0 and engine.info('filter_onepass') == 0       # the ball pass serves the voice again
+    # the batch pipeline on the reordered voice, class-restricted search included
+    utts = [U[:300], U[300:]]
+    paths, costs = engine.knn_viterbi_batch(utts, K)
+    for u, Uu in enumerate(utts):
+        p1, c1 = engine.knn_viterbi(Uu, K)
+        assert list(paths[u]) == p1 and costs[u] == c1
+    cls = np.random.RandomState(4).randint(0, 7, N).astype(np.int32)
+    engine.set_unit_classes(cls)
+    qc = np.random.RandomState(5).randint(0, 7, T).astype(np.int32)
+    cc, cd = engine.knn_by_class(U, K, qc)
+    occ, ocd = o.knn_by_class(F, U[rows], K, cls, qc[rows])
+    assert np.array_equal(cc[rows], occ) and np.array_equal(cd[rows], ocd)
+    # new weights: the order stays (any order is valid), the voice is judged afresh and stays on the ball pass
+    engine.set_weights(wt * 1.3, wj)
+    cand, dist = engine.knn(U * 1.3, K)
+    oc2, od2 = oc.knn(F * 1.3, (U * 1.3)[rows], K)
+    assert np.array_equal(cand[rows], oc2) and np.array_equal(dist[rows], od2)
+    assert engine.info('reordered') == 1 and engine.info('reorders') == 1 and engine.info('filter_coarse') == 0
+    # a voice whose own order is the better one keeps it
+    engine.upload_db(F0, JC0)
+    engine.set_weights(wt, wj)
+    far = (F0[rng.randint(0, N, 320)] + 6.0 * rng.randn(320, Dt)) * wt
+    for _ in range(3):
+        engine.knn(far, 50)
+    assert engine.info('reordered') == 0 and engine.info('reorder_useless') == 1
+    assert engine.info('reorder_radius_after') > engine.info('reorder_radius_before')
 
 
 def test_the_filter_latches_are_rearmable(engine):
