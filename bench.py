@@ -228,7 +228,7 @@ def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')),
             # trips (publish -> gather) + a scan out of LDS, no HBM or L2 stream -- a latency figure, not a bandwidth one
             roof = {'bound': 'latency', 'us_per_step': us_step, 'budget_us_per_step': 10.0,
                     'note': 'database resident in LDS (%d KB per compute unit): per step table 0.9 + LDS scan 1.7 + top-3 0.4 + publish 0.55 + '
-                            'gather 1.7 + decide 1.5 us (DESIGN.md 4.4d) + the utterance\'s share of the hoisted product; dividing its bytes by '
+                            'gather 1.7 + decide 1.5 us (HISTORY.md 4.4d) + the utterance\'s share of the hoisted product; dividing its bytes by '
                             '8 TB/s would mean nothing' % (int(N * Dj * 4 / 256 / 1024),),
                     'algorithmic_bytes_per_step': bytes_step}
         else:
@@ -256,8 +256,10 @@ def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')),
 def variant_database(kind, N, Dt, F_unw, JC_unw, seed=0):
     """Databases of the B* shape whose 32-unit tiles are NOT the compact balls SURVEY 8d's generator makes of them
     (cumsum(randn) / global std: consecutive units 0.002 apart per column against neighbour distances of 0.3):
-      'permuted'    the same units in random order: a tile holds 32 unrelated frames (the ball pass is useless, the engine
-                    switches the voice to the one-term coarse sweep);
+      'permuted'    the same units in random order: a tile holds 32 unrelated frames, the ball pass of the database order is useless --
+                    the engine gives such a voice an order of its own (kmeans_kernels.hip).  The utterances of this leg follow the
+                    speech the units were cut from (until round 4 they followed the ROW order of the permuted matrix: consecutive
+                    target frames with nothing in common, which no utterance has);
       'speechlike'  a stationary AR(1) walk per column whose step has 0.2 of the global standard deviation (consecutive
                     speech frames differ by a sizeable fraction of the spread of the data)."""
     rng = np.random.RandomState(seed + 17)
@@ -323,7 +325,7 @@ def leg_roofline(tm, steps, rows_per_step, N, Dt, Dj, K, eng):
     return out
 
 
-def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', host_to_host=False):
+def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', host_to_host=False, targets_from=None):
     """One BASELINE shape (or B* on a variant database) through the batch pipeline, two steps in flight, rows resident in HBM: frames/s,
     stage times, the dominant kernel's roofline, fallbacks and tripwires.  An extra field of the JSON line, never `value`."""
     import snickery_amd
@@ -332,9 +334,10 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
     Dj = JC_unw.shape[1]
     eng.upload_db(F_unw, JC_unw)
     eng.set_weights(wt, wj)
-    batch = snickery_amd.QueryBatch([synthetic_targets(F_unw, T, seed=1 + u) * wt for u in range(U)])
+    # targets_from: the matrix the utterances follow (a permuted database: the speech its units were cut from, not its row order)
+    batch = snickery_amd.QueryBatch([synthetic_targets(F_unw if targets_from is None else targets_from, T, seed=1 + u) * wt for u in range(U)])
     batch.pin()
-    for _ in range(4):                           # primes both workspaces; the engine judges the voice (filter passes, Viterbi path)
+    for _ in range(4):                           # primes both workspaces; the engine judges the voice (filter passes, unit order, Viterbi path)
         eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(batch, K))
     before = (eng.info('f16_fallbacks'), eng.info('batch_redos'), eng.info('exact_row_fallbacks'))
     eng.reset_timers()
@@ -359,6 +362,7 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
            'frames_per_s': T * U * steps / dt, 'ms_per_step': dt / steps * 1e3, 'steps': steps,
            'roofline': leg_roofline(tm, steps, T * U, N, Dt, Dj, K, eng),
            'filter_coarse': bool(eng.info('filter_coarse')), 'filter_onepass': bool(eng.info('filter_onepass')),
+           'reordered': bool(eng.info('reordered')), 'tile_radius_before_after': [eng.info('reorder_radius_before'), eng.info('reorder_radius_after')],
            'viterbi_path': 'dense' if eng.info('viterbi_latch_mode') == 1 else 'sparse',
            'tile_pairs_listed': {'last_launch': pairs, 'fraction': pairs / max((rows_per_launch / 32.0) * (N / 32.0), 1.0)},
            'list_mean': eng.info('last_list_mean'), 'list_max': eng.info('last_list_max'), 'knn_level': eng.info('knn_level'),
@@ -783,7 +787,7 @@ def main():
                     'why_no_roofline': 'a chain of T dependent steps on ONE wavefront per utterance (16 workgroups per launch on 256 compute units): its time is '
                                        'T x the latency of a step (K candidates: minima over the kept predecessors, refinement of the step on the spot), it moves '
                                        '0.1 GB per launch and issues no matrix work; it runs beside the next group\'s K-NN and does not gate the step -- the '
-                                       'whole-chip kernels do (sum of their stand-alone times 4.1 of the 4.6 ms step, DESIGN.md 5)'}
+                                       'whole-chip kernels do (sum of their stand-alone times 4.1 of the 4.6 ms step, DESIGN.md 4.3)'}
         else:
             out['roofline'] = dict(out['filter_stage'])
         if bf16_mode:
@@ -836,7 +840,7 @@ def main():
                 'prefilter_margin_rows': margin_rows, 'prefilter_min_margin': min_margin,
                 'note': 'margin = (filter threshold - exact K-th key) / assumed key error eps, over every row of the timed steps: '
                         'the factor by which the true key errors could exceed eps before a row could lose a neighbour; '
-                        'prefilter_margin_rows counts the rows under 2 (include/snk.h, DESIGN.md 4.1a)'}
+                        'prefilter_margin_rows counts the rows under 2 (include/snk.h, DESIGN.md 4.1a, 6.1)'}
         if with_upload is not None:
             # SURVEY 8d's wall time (target matrix on host -> path on host): the same pipeline with the query rows crossing
             # PCIe inside every timed step.  `value` follows the bench contract (inputs resident in HBM when the timed region
@@ -872,7 +876,7 @@ def main():
             legs = []
             for kind in ('permuted', 'speechlike'):
                 Fv, JCv = variant_database(kind, N, Dt, F_unw, JC_unw)
-                legs.append(shape_leg(eng, 'B*', Fv, JCv, wt, wj, T, U, K, leg_steps, kind=kind))
+                legs.append(shape_leg(eng, 'B*', Fv, JCv, wt, wj, T, U, K, leg_steps, kind=kind, targets_from=F_unw if kind == 'permuted' else None))
                 del Fv, JCv
             out['noncompact'] = legs
         if world == 1 and not args.no_shapes:
@@ -887,7 +891,7 @@ def main():
                 wts, wjs = np.full(sDt, 0.4), np.full(sDj, 0.05)
                 for kind in kinds:
                     Fk, JCk = (Fs, JCs) if kind == 'compact' else variant_database(kind, sN, sDt, Fs, JCs)
-                    shapes.append(shape_leg(eng, sname, Fk, JCk, wts, wjs, sT, sU, sK, leg_steps, kind=kind))
+                    shapes.append(shape_leg(eng, sname, Fk, JCk, wts, wjs, sT, sU, sK, leg_steps, kind=kind, targets_from=Fs if kind == 'permuted' else None))
                 del Fs, JCs
             out['shapes'] = shapes
         if world == 1 and not args.no_greedy:

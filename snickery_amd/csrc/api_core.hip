@@ -66,7 +66,7 @@ int staged_d2h(snk_engine *h, hipStream_t st, const D2HPart *parts, int n)
 // ordinary pageable memory (numpy arrays, stack variables), and handing those to hipMemcpyAsync makes the runtime pin
 // and map them on the fly -- a process that frees and reuses such memory all the time (a Python test session, a tuning
 // loop) was seen to die with "Memory access fault by GPU node ... on address <an address of the host heap>" inside an
-// unrelated call.  Uploads go caller -> pinned staging (memcpy) -> device, results device ->
+// unrelated call (HISTORY.md section 8.1).  Uploads go caller -> pinned staging (memcpy) -> device, results device ->
 // pinned staging -> caller (staged_d2h).
 // ---------------------------------------------------------------------------
 bool host_memory_is_pinned(const void *p)
@@ -389,6 +389,47 @@ int snk_set_column_selection(snk_handle h, const int *tcols, int nt, const int *
     return 0;
 }
 
+// Rows of 257 .. 512 columns: the operands of the blocked bf16-split product (knn_wide16b), built at the FIRST call that can take
+// that path -- plain snk_knn calls; batch, sharded and class-restricted engines never pay the memory (N x Dpad x 4 bytes) or the
+// host synchronisation.  (nt16_eff, n_slabs16, stride16, eps_c_bf are shared with the narrow-row plan: a database is one
+// or the other.)
+int ensure_wide_operands(snk_engine *h)
+{
+    if (h->wide16_ready || h->wide16_tried) return 0;
+    h->wide16_tried = true;
+    if (h->have_db && h->prefilter >= 1 && knn_wide16b_supported(h->Dt, h->Dpad)) {
+        // rows of 257 .. 512 columns (Synthesiser.join_knn on the doubled join rows of an epoch voice): bf16-split operands
+        // of the whole database and of the stage-A sample, one tile per slab; the blocked product of knn_wide16b serves
+        // both stages, the exact float64 re-rank is the one of every other width
+        const int terms = h->prefilter == 2 ? 4 : 3;
+        h->nt16_eff = 1;
+        CHK(h->fmax2.ensure(sizeof(double)));
+        launch_fmax(h->fnorm.as<double>(), h->N, h->fmax2.as<double>(), h->stream);
+        double fmax2 = 0.0;
+        CHK(d2h_sync(h, &fmax2, h->fmax2.p, sizeof(double), h->stream));
+        h->n_slabs16 = (h->N + 31) / 32;
+        int64_t stride = (int64_t)floor(1.0 / h->sample_frac + 0.5);
+        if (stride < 1) stride = 1;
+        while (stride > 1 && (h->N / stride) / 32 < h->min_sample_slabs) --stride;
+        h->stride16 = stride;
+        h->n_slabs16_a = (h->N / stride) / 32;
+        if (fmax2 < 1.0e30 && h->n_slabs16_a >= 1) {
+            const size_t per_tile = (size_t)8 * 64 * 16 * (h->Dpad / 64);
+            h->eps_c_bf = 1.02 * (SNK_BF16_MFMA_UNIT * (double)(terms * 4 + 1) + 6e-8 * (double)(2 * (h->Dpad / 64) + 1));
+            CHK(h->rho16.ensure(2 * sizeof(double)));
+            launch_db16b_ratios(h->Fw.as<double>(), h->N, h->Dt, h->Dpad, h->rho16.as<double>(), h->stream);
+            CHK(h->a16l.ensure(h->n_slabs16 * per_tile));
+            CHK(h->s16l.ensure(h->n_slabs16_a * per_tile));
+            launch_build_db16b(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, h->n_slabs16, 0, 0, 1, h->a16l.p, h->stream);
+            launch_build_db16b(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, h->n_slabs16_a, stride,
+                               2 * h->n_slabs16_a, 1, h->s16l.p, h->stream);
+            HIPCHK(hipGetLastError());
+            h->wide16_ready = true;
+        }
+    }
+    return 0;
+}
+
 // The operands of the K-NN prefilter for the current weights (knn16_kernels.hip): float32 and bf16-split copies of the weighted
 // database and of its stage-A sample, tile balls and the balls of 32 tiles -- in the database's order, or in the order the engine
 // gave the voice (h->perm: kmeans_kernels.hip).  Resets the filter's latches: the voice is judged afresh on these operands.
@@ -580,37 +621,7 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
     h->reorder_done = false; h->reorder_pending = false;     // (the order a voice was given stays: any order is valid, and usually still a good one)
     h->vit = snk_engine::VitLatch();                         // a new set of weights: the Viterbi latch starts over
     CHK(build_prefilter_operands(h));
-    h->wide16_ready = false;
-    if (h->have_db && h->prefilter >= 1 && knn_wide16b_supported(h->Dt, h->Dpad)) {
-        // rows of 257 .. 512 columns (Synthesiser.join_knn on the doubled join rows of an epoch voice): bf16-split operands
-        // of the whole database and of the stage-A sample, one tile per slab; the blocked product of knn_wide16b serves
-        // both stages, the exact float64 re-rank is the one of every other width
-        const int terms = h->prefilter == 2 ? 4 : 3;
-        h->nt16_eff = 1;
-        CHK(h->fmax2.ensure(sizeof(double)));
-        launch_fmax(h->fnorm.as<double>(), h->N, h->fmax2.as<double>(), h->stream);
-        double fmax2 = 0.0;
-        CHK(d2h_sync(h, &fmax2, h->fmax2.p, sizeof(double), h->stream));
-        h->n_slabs16 = (h->N + 31) / 32;
-        int64_t stride = (int64_t)floor(1.0 / h->sample_frac + 0.5);
-        if (stride < 1) stride = 1;
-        while (stride > 1 && (h->N / stride) / 32 < h->min_sample_slabs) --stride;
-        h->stride16 = stride;
-        h->n_slabs16_a = (h->N / stride) / 32;
-        if (fmax2 < 1.0e30 && h->n_slabs16_a >= 1) {
-            const size_t per_tile = (size_t)8 * 64 * 16 * (h->Dpad / 64);
-            h->eps_c_bf = 1.02 * (SNK_BF16_MFMA_UNIT * (double)(terms * 4 + 1) + 6e-8 * (double)(2 * (h->Dpad / 64) + 1));
-            CHK(h->rho16.ensure(2 * sizeof(double)));
-            launch_db16b_ratios(h->Fw.as<double>(), h->N, h->Dt, h->Dpad, h->rho16.as<double>(), h->stream);
-            CHK(h->a16l.ensure(h->n_slabs16 * per_tile));
-            CHK(h->s16l.ensure(h->n_slabs16_a * per_tile));
-            launch_build_db16b(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, h->n_slabs16, 0, 0, 1, h->a16l.p, h->stream);
-            launch_build_db16b(h->Fw.as<double>(), h->fnorm.as<double>(), h->N, h->Dt, h->Dpad, h->n_slabs16_a, stride,
-                               2 * h->n_slabs16_a, 1, h->s16l.p, h->stream);
-            HIPCHK(hipGetLastError());
-            h->wide16_ready = true;
-        }
-    }
+    h->wide16_ready = false; h->wide16_tried = false;              // (built at the first call that can use them: ensure_wide_operands)
     h->gs_ready = false;
     if (h->gs_rows > 0 && h->f16_ready) {
         // the replicated global sample in the operand layout of stage A (groups scattered over the sample)

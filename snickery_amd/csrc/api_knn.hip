@@ -131,6 +131,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
         if (deferred_status) HIPCHK(hipMemsetAsync(deferred_status, 0, sizeof(int), h->stream));
         return 0;
     }
+    if (h->Dpad > 256 && h->precision == 1 && !qclass_dev && !bound_out && !bound_in && !deferred_status) CHK(ensure_wide_operands(h));
     if (h->Dpad > 256 && h->wide16_ready && h->precision == 1 && !qclass_dev && !bound_out && !bound_in && !deferred_status &&
         2 * h->n_slabs16_a >= K) {
         // 257 .. 512 columns: stage A and the filter as a blocked bf16-split product (knn_wide16b), bucket and the exact

@@ -188,6 +188,8 @@ int snk_set_option(snk_handle h, const char *name, double value)
         CHK(no_batch_in_flight(h, "snk_set_option(reorder)"));
         h->reorder = (int)value;
         if (!h->reorder && h->perm_ready) { h->perm_ready = false; h->have_weights = false; }     // back to the database order with the next snk_set_weights
+    } else if (!strcmp(name, "reorder_now")) {
+        h->reorder_pending = value != 0.0; h->reorder_done = false; h->reorder_useless = false;      // developer aid: cluster at the next K-NN call
     } else if (!strcmp(name, "reorder_iterations")) {
         if (!(value >= 1.0 && value <= 64.0)) return fail("reorder_iterations must be in 1..64");
         h->reorder_iters = (int)value;
@@ -365,6 +367,8 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "reordered")) *out = h->perm_ready ? 1 : 0;               // 1: the prefilter's operands stand in an order the engine chose (kmeans_kernels.hip)
     else if (!strcmp(name, "reorders")) *out = (double)h->reorders;
     else if (!strcmp(name, "reorder_useless")) *out = h->reorder_useless ? 1 : 0;
+    else if (!strcmp(name, "debug_perm_ptr")) *out = (double)(uintptr_t)(h->perm_ready ? h->perm.p : nullptr);     // developer aid: snk_copy_to_host reads it
+    else if (!strcmp(name, "debug_ball_rad_ptr")) *out = (double)(uintptr_t)h->ball_rad.p;
     else if (!strcmp(name, "reorder_radius_before")) *out = h->reorder_radius_before;
     else if (!strcmp(name, "reorder_radius_after")) *out = h->reorder_radius_after;
     else if (!strcmp(name, "filter_rearms")) *out = (double)h->filter_rearms;        // times a counting probe took the voice back to a faster filter

@@ -519,10 +519,17 @@ static int sharded_submit(snk_engine *h, ShardTicket &t, const double *Q, const 
             CHK(d2h_sync(h, ctl, h->cpairctl.p, sizeof(ctl), h->stream));
             judge_filter(h, h->ball_pass_ran, h->ball_limit, h->coarse_pass_ran, h->coarse_limit, ctl[0], h->probe_ran, h->probe_limit, ctl[2]);
         }
+        // The verdict on the totals is COLLECTIVE: every rank holds the same G x G matrix (it was all-gathered) and the same plan, so
+        // every rank checks every (sender, destination) pair and all of them refuse together, here, with the all-to-all not yet
+        // queued anywhere (a rank that failed alone between the two collectives left its peers blocked in the second)
+        for (int q = 0; q < G; ++q)
+            for (int p = 0; p < G; ++p) {
+                const int64_t v = totall[(size_t)q * G + p];
+                if (v < 0 || v > t.rows_to[(size_t)p] * K) return fail("sharded exchange: inconsistent list totals between ranks (rank %d -> %d: %lld)", q, p, (long long)v);
+            }
         int64_t so = 0, ro = 0;
         for (int p = 0; p < G; ++p) {
             const int64_t ts = totall[(size_t)me * G + p], tr = totall[(size_t)p * G + me];
-            if (ts < 0 || ts > t.rows_to[(size_t)p] * K || tr < 0 || tr > r_own * K) return fail("sharded exchange: inconsistent list totals between ranks");
             soff[(size_t)p] = so; sb[(size_t)p] = pad16(t.rows_to[(size_t)p]) + 16 * ts; so += sb[(size_t)p];
             roff[(size_t)p] = ro; rb[(size_t)p] = pad16(r_own) + 16 * tr; ro += rb[(size_t)p];
             plan[(size_t)2 * G + p] = soff[(size_t)p]; plan[(size_t)3 * G + p] = ts;

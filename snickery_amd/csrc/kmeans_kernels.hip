@@ -7,9 +7,13 @@
 // whose consecutive units are different phone halves; any voice whose utterances were shuffled -- nearly every ball reaches every
 // query, the filter falls back to sweeping the whole database (one-pass three-term sweep: 4.3 ms per 9 600 rows at B* against 0.48 ms
 // with compact tiles) and nothing is pruned.  So the engine may PERMUTE the prefilter's operands: units are clustered (Lloyd's
-// k-means on the weighted vectors, about 256 units per cluster, a few iterations, float32 -- it is a heuristic, nothing of it
-// reaches a result) and laid out cluster by cluster; tiles then hold units of one cluster and their balls are as small as the
-// data allows.  Only the prefilter sees the permutation: operand builders read row perm[position], and the bucket kernel maps a
+// k-means on the weighted vectors, a few hundred units per cluster -- what fits a compute unit's LDS --, a few iterations, float32:
+// a heuristic, nothing of it reaches a result), every cluster is put in the order of a nearest-neighbour CHAIN (from the member
+// farthest from the centroid, always on to the nearest member not yet taken: along a stretch of speech that is its time order,
+// which is what made the tiles of a frame-level voice compact in the first place) and the clusters are laid out one after the
+// other; a tile of 32 consecutive positions then holds neighbours.  (Clusters alone were tried first: a tile drawn at random from
+// a cluster of 256 has the cluster's radius, and the ball pass listed a quarter of all pairs again.)  Only the prefilter sees the
+// permutation: operand builders read row perm[position], and the bucket kernel maps a
 // survivor's position back to its unit id before anything is ranked -- the exact float64 re-rank, its (distance, id) order and
 // every result are those of the database order.
 //
@@ -19,6 +23,8 @@
 //   km_scan      exclusive prefix of the sizes (one workgroup)
 //   km_scatter   perm[start[c] + k] = the k-th unit of cluster c (order inside a cluster: as the atomics fall -- any order is valid)
 //   km_means     centroid = mean of its members (one workgroup per cluster, members through perm); empty clusters keep theirs
+//   km_chain     one workgroup per cluster: its members' rows in LDS (float32, column-major), n steps of "nearest member not yet
+//                taken" (a workgroup-wide argmin per step); clusters larger than the LDS holds are chained piece by piece
 #include "snk_internal.h"
 #include <float.h>
 
@@ -154,33 +160,177 @@ km_means_kernel(const double *__restrict__ Fw, int Dt, int Dpad, int Dp, const i
     if (threadIdx.x == 0) cnorm[c] = red[0];
 }
 
-int kmeans_clusters(int64_t N)
+// members of a cluster whose rows fit the chain kernel's LDS at once (120 KB of float32 columns), a multiple of 32, at most 480
+int kmeans_chain_capacity(int Dt)
 {
-    int64_t c = (N / 256 + 63) / 64 * 64;
+    const int Dp = (Dt + 3) & ~3;
+    int cap = (120 * 1024) / (Dp * 4);
+    cap = cap / 32 * 32;
+    return cap > 480 ? 480 : cap < 32 ? 32 : cap;
+}
+
+int kmeans_clusters(int64_t N, int Dt)
+{
+    int64_t c = (N / kmeans_chain_capacity(Dt) + 63) / 64 * 64;
     if (c < 64) c = 64;
-    if (c > 8192) c = 8192;
+    if (c > 16384) c = 16384;
     return (int)c;
 }
 
-// workspace: centroids C x Dp floats | norms C floats | assign N ints | count C + 1 ints | start C + 1 ints | cursor C ints
+// The order of the CLUSTERS: a nearest-neighbour chain over the centroids (one workgroup; C steps of a workgroup-wide argmin), so
+// that a cluster's neighbours in the layout are its neighbours in space and the tile that straddles two clusters holds units of
+// adjoining regions (laid out in any order, one tile in fourteen straddled two unrelated clusters and had their distance as its
+// radius).  prev[c] = the cluster in front of c (-1: the first), ostart[c] = first position of c's segment in that order.
+__global__ void __launch_bounds__(256)
+km_order_kernel(const float *__restrict__ cen, const int *__restrict__ count, int C, int Dp, int *__restrict__ prev, int *__restrict__ ostart,
+                unsigned char *__restrict__ taken)
+{
+    __shared__ float red_v[4];
+    __shared__ int red_i[4], cur_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += 256) taken[c] = 0;
+    if (tid == 0) cur_s = 0;
+    __syncthreads();
+    int run = 0, last = -1;
+    for (int step = 0; step < C; ++step) {
+        const int cur = cur_s;
+        if (tid == 0) { taken[cur] = 1; prev[cur] = last; ostart[cur] = run; }
+        run += count[cur];
+        last = cur;
+        __syncthreads();
+        if (step + 1 == C) break;
+        float v = FLT_MAX;
+        int ii = 0x7fffffff;
+        for (int c = tid; c < C; c += 256) {
+            if (taken[c]) continue;
+            float acc = 0.f;
+            for (int d = 0; d < Dp; ++d) { const float df = cen[(int64_t)c * Dp + d] - cen[(int64_t)cur * Dp + d]; acc = __builtin_fmaf(df, df, acc); }
+            if (acc < v) { v = acc; ii = c; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(v, off, 64); const int oi = __shfl_xor(ii, off, 64);
+            if (ov < v || (ov == v && oi < ii)) { v = ov; ii = oi; }
+        }
+        if (lane == 0) { red_v[wave] = v; red_i[wave] = ii; }
+        __syncthreads();
+        if (tid == 0) {
+            float vv = red_v[0]; int jj = red_i[0];
+            for (int w = 1; w < 4; ++w) if (red_v[w] < vv || (red_v[w] == vv && red_i[w] < jj)) { vv = red_v[w]; jj = red_i[w]; }
+            cur_s = jj;
+        }
+        __syncthreads();
+    }
+}
+
+// The chain.  xs[d][i]: column d of member i (i < m <= cap); a step = the squared distance of every free member to the current one
+// (a thread takes members tid, tid + 256, ...), the workgroup's argmin, the winner's id to the output.
+__global__ void __launch_bounds__(256)
+km_chain_kernel(const double *__restrict__ Fw, int Dt, int Dpad, int Dp, int cap, const int *__restrict__ start, const float *__restrict__ cen,
+                const int *__restrict__ perm_in, int *__restrict__ perm_out, const int *__restrict__ prev, const int *__restrict__ ostart)
+{
+    extern __shared__ __align__(16) float kc_lds[];
+    float *xs = kc_lds;                               // [Dp][cap]
+    int *ids = reinterpret_cast<int *>(xs + (size_t)Dp * cap);      // [cap] unit of member i; -1 once taken
+    __shared__ float red_v[4];
+    __shared__ int red_i[4], cur_s;
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s0 = start[c], n = start[c + 1] - s0, o0 = ostart[c];
+    // the chain starts at the member nearest to the centroid of the cluster in front of this one (the layout runs on from there);
+    // the first cluster's at the member farthest from its own centroid (an end of the stretch, not its middle)
+    const int pc = prev[c];
+    const float *const ref = cen + (int64_t)(pc >= 0 ? pc : c) * Dp;
+    const float sign = pc >= 0 ? -1.f : 1.f;
+    for (int p0 = 0; p0 < n; p0 += cap) {
+        const int m = n - p0 < cap ? n - p0 : cap;
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) ids[i] = perm_in[s0 + p0 + i];
+        __syncthreads();
+        // rows in: a wavefront reads consecutive columns of one member
+        for (int i = wave; i < m; i += 4) {
+            const int64_t u = ids[i];
+            for (int d = lane; d < Dp; d += 64) xs[(size_t)d * cap + i] = d < Dt ? (float)Fw[u * Dpad + d] : 0.f;
+        }
+        __syncthreads();
+        float bv = -FLT_MAX;
+        int bi = 0;
+        for (int i = tid; i < m; i += 256) {
+            float acc = 0.f;
+            for (int d = 0; d < Dp; ++d) { const float df = xs[(size_t)d * cap + i] - ref[d]; acc = __builtin_fmaf(df, df, acc); }
+            acc *= sign;                              // nearest to the cluster in front = largest negated distance
+            if (acc > bv) { bv = acc; bi = i; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64); const int oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = red_v[0]; int ii = red_i[0];
+            for (int w = 1; w < 4; ++w) if (red_v[w] > v || (red_v[w] == v && red_i[w] < ii)) { v = red_v[w]; ii = red_i[w]; }
+            cur_s = ii;
+        }
+        __syncthreads();
+        for (int step = 0; step < m; ++step) {
+            const int cur = cur_s;
+            if (tid == 0) { perm_out[o0 + p0 + step] = ids[cur]; ids[cur] = -1; }
+            __syncthreads();
+            if (step + 1 == m) break;
+            // nearest free member (members tid and tid + 256: cap <= 480)
+            const int i0 = tid, i1 = tid + 256;
+            const bool f0 = i0 < m && ids[i0] >= 0, f1 = i1 < m && ids[i1] >= 0;
+            float a0 = 0.f, a1 = 0.f;
+            for (int d = 0; d < Dp; ++d) {
+                const float cv = xs[(size_t)d * cap + cur];
+                const float d0 = xs[(size_t)d * cap + (f0 ? i0 : cur)] - cv, d1 = xs[(size_t)d * cap + (f1 ? i1 : cur)] - cv;
+                a0 = __builtin_fmaf(d0, d0, a0); a1 = __builtin_fmaf(d1, d1, a1);
+            }
+            float v = f0 ? a0 : FLT_MAX;
+            int ii = i0;
+            if (f1 && a1 < v) { v = a1; ii = i1; }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ov = __shfl_xor(v, off, 64); const int oi = __shfl_xor(ii, off, 64);
+                if (ov < v || (ov == v && oi < ii)) { v = ov; ii = oi; }
+            }
+            if (lane == 0) { red_v[wave] = v; red_i[wave] = ii; }
+            __syncthreads();
+            if (tid == 0) {
+                float vv = red_v[0]; int jj = red_i[0];
+                for (int w = 1; w < 4; ++w) if (red_v[w] < vv || (red_v[w] == vv && red_i[w] < jj)) { vv = red_v[w]; jj = red_i[w]; }
+                cur_s = jj;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// workspace: centroids C x Dp floats | norms C floats | assign N ints | count C + 2 ints | start C + 2 ints | cursor C ints | the
+// clusters' members before the chain N ints | prev, ostart C + 2 ints each | taken C bytes
 size_t kmeans_workspace_bytes(int64_t N, int Dt)
 {
-    const int C = kmeans_clusters(N), Dp = (Dt + 3) & ~3;
-    return (size_t)C * Dp * 4 + (size_t)C * 4 + (size_t)N * 4 + (size_t)(3 * C + 8) * 4 + 256;
+    const int C = kmeans_clusters(N, Dt), Dp = (Dt + 3) & ~3;
+    return (size_t)C * Dp * 4 + (size_t)C * 4 + (size_t)N * 4 + (size_t)(3 * C + 8) * 4 + (size_t)N * 4 + (size_t)(3 * C + 8) * 4 + 256;
 }
 
 bool kmeans_supported(int Dt) { return Dt >= 1 && Dt <= 256; }
 
 void launch_kmeans_order(const double *Fw, int64_t N, int Dt, int Dpad, int iters, void *workspace, int *perm, hipStream_t s)
 {
-    const int C = kmeans_clusters(N), Dp = (Dt + 3) & ~3;
+    const int C = kmeans_clusters(N, Dt), Dp = (Dt + 3) & ~3;
     char *w = static_cast<char *>(workspace);
     float *cen = reinterpret_cast<float *>(w); w += (size_t)C * Dp * 4;
     float *cnorm = reinterpret_cast<float *>(w); w += (size_t)C * 4;
     int *assign = reinterpret_cast<int *>(w); w += (size_t)N * 4;
     int *count = reinterpret_cast<int *>(w); w += (size_t)(C + 2) * 4;
     int *start = reinterpret_cast<int *>(w); w += (size_t)(C + 2) * 4;
-    int *cursor = reinterpret_cast<int *>(w);
+    int *cursor = reinterpret_cast<int *>(w); w += (size_t)(C + 2) * 4;
+    int *members = reinterpret_cast<int *>(w); w += (size_t)N * 4;
+    int *prev = reinterpret_cast<int *>(w); w += (size_t)(C + 2) * 4;
+    int *ostart = reinterpret_cast<int *>(w); w += (size_t)(C + 2) * 4;
+    unsigned char *taken = reinterpret_cast<unsigned char *>(w);
     const size_t lds = ((size_t)Dp * KM_UB + (size_t)Dp * KM_CJ) * sizeof(float);
     static size_t attr[32] = {0};
     if (lds > 65536)
@@ -192,10 +342,19 @@ void launch_kmeans_order(const double *Fw, int64_t N, int Dt, int Dpad, int iter
         hipLaunchKernelGGL(km_assign_kernel, dim3((unsigned)((N + KM_UB - 1) / KM_UB)), dim3(KM_UB), lds, s, Fw, N, Dt, Dpad, C, Dp, cen, cnorm,
                            assign, count);
         hipLaunchKernelGGL(km_scan_kernel, dim3(1), dim3(1024), 0, s, count, C, start, cursor);
-        hipLaunchKernelGGL(km_scatter_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, assign, N, start, cursor, perm);
+        hipLaunchKernelGGL(km_scatter_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, assign, N, start, cursor, members);
         if (it + 1 < iters)
-            hipLaunchKernelGGL(km_means_kernel, dim3(C), dim3(256), 0, s, Fw, Dt, Dpad, Dp, start, perm, cen, cnorm, count);
+            hipLaunchKernelGGL(km_means_kernel, dim3(C), dim3(256), 0, s, Fw, Dt, Dpad, Dp, start, members, cen, cnorm, count);
     }
+    // every cluster in the order of a nearest-neighbour chain
+    const int cap = kmeans_chain_capacity(Dt);
+    const size_t lds_c = (size_t)Dp * cap * sizeof(float) + (size_t)cap * sizeof(int);
+    static size_t attr_c[32] = {0};
+    if (lds_c > 65536)
+        lds_attr_ensure(attr_c, lds_c, [&] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&km_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c); });
+    hipLaunchKernelGGL(km_order_kernel, dim3(1), dim3(256), 0, s, cen, count, C, Dp, prev, ostart, taken);
+    hipLaunchKernelGGL(km_chain_kernel, dim3(C), dim3(256), lds_c, s, Fw, Dt, Dpad, Dp, cap, start, cen, members, perm, prev, ostart);
 }
 
 }  // namespace snk

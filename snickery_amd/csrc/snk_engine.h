@@ -238,6 +238,7 @@ struct snk_engine {
     // f16-split prefilter state
     DevBuf a16h, a16l, s16h, s16l, b16h, b16l, eps16, thr32, gmin32, fmax2;
     bool f16_ready = false, cls16_ready = false;
+    bool wide16_tried = false;    // ... were asked for since the last snk_set_weights (built lazily: api_core.hip ensure_wide_operands)
     bool wide16_ready = false;    // rows of 257 .. 512 columns: bf16-split operands for the blocked product (knn_wide16b)
     int64_t wide_launches = 0;    // K-NN calls served by it
     DevBuf cls16_full, cls16_samp;      // class id per tile row of the two f32 operands
@@ -257,7 +258,7 @@ struct snk_engine {
     DevBuf ball_aq, ball_nql, ball_gmin, ball_bound;                // stage A' (scout): tile list per query tile, keys of their units per row, centre-key minima, the row's bound
     int prefilter_ball_bound = 0; // 1: the thresholds also take the K-th smallest key of the units of the nearest tiles (stage A'; where the ball pass
                                   // runs).  Off by default: at B* it shortens the lists 1785 -> 568 entries per row and costs more (0.48 ms per 9 600 rows)
-                                  // than bucket + refine save (0.17 ms); DESIGN.md 4.1c
+                                  // than bucket + refine save (0.17 ms); HISTORY.md 4.1c
     int prefilter_balls = 1;      // 1: the tiles' balls list the pairs first; the coarse sweep runs only where they list too many
     double coarse_gate_fraction = 0.10;
     int64_t ball_tiles = 0;       // valid tiles of the ball operand (0: not built)
@@ -443,6 +444,7 @@ int h2d_via(HostBuf &stage, void *dst_dev, const void *src_host, size_t bytes, h
 
 // the prefilter's operands for the current weights / an order for a voice whose tiles are not compact (api_core.hip)
 int build_prefilter_operands(snk_engine *h);
+int ensure_wide_operands(snk_engine *h);
 int reorder_units(snk_engine *h);
 
 // state checks (api_core.hip)

@@ -135,7 +135,7 @@ void launch_shard_unpack(const unsigned char *in, const int64_t *roff, const int
 void launch_build_db16(const double *Fw, const double *fnorm, int64_t N, int Dt, int Dpad, int64_t n_tiles,
                        int64_t sample_stride, int64_t G, int nt_a, void *A32, hipStream_t s, const int32_t *perm = nullptr);
 // an order for the units of a voice whose tiles are not compact: k-means clusters laid out one after the other (kmeans_kernels.hip)
-int kmeans_clusters(int64_t N);
+int kmeans_clusters(int64_t N, int Dt);
 bool kmeans_supported(int Dt);
 size_t kmeans_workspace_bytes(int64_t N, int Dt);
 void launch_kmeans_order(const double *Fw, int64_t N, int Dt, int Dpad, int iters, void *workspace, int *perm, hipStream_t s);

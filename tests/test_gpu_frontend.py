@@ -365,11 +365,12 @@ def test_wide_rows_take_the_matrix_path():
     e = snickery_amd.HipSearchEngine(0)
     e.upload_db(F_unw, JC_unw)
     e.set_weights(wt, np.full(8, 0.1))
-    assert e.info('wide_ready') == 1
+    assert e.info('wide_ready') == 0                      # built at the first call that can take the path, not by snk_set_weights
     F = o.weight(F_unw, wt)
     U = np.vstack([o.synthetic_targets(F_unw, 40, seed=93), F_unw[50:60].astype(np.float64)]) * wt
     before = e.info('wide_launches')
     cand, dist = e.knn(U, K)
+    assert e.info('wide_ready') == 1
     assert e.info('wide_launches') == before + 1 and e.info('f16_fallbacks') == 0
     oc_, od_ = o.knn_bruteforce(F, U, K)
     assert np.array_equal(cand, oc_) and np.array_equal(dist, od_)
@@ -400,10 +401,10 @@ def test_wide_rows_against_the_c_oracle(N, Dt, T, K):
     e = snickery_amd.HipSearchEngine(0)
     e.upload_db(F_unw, JC_unw)
     e.set_weights(wt, np.full(8, 0.1))
-    assert e.info('wide_ready') == 1
     F = o.weight(F_unw, wt)
     U = np.vstack([o.synthetic_targets(F_unw, T - T // 3, seed=3), F_unw[rng.randint(0, N, T // 3)] + 0.2 * rng.randn(T // 3, Dt)]) * wt
     cand, dist = e.knn(U, K)
+    assert e.info('wide_ready') == 1
     assert e.info('wide_launches') == 1 and e.info('f16_fallbacks') == 0
     oc_, od_ = oc.knn(F, U, K)
     assert np.array_equal(cand, oc_) and np.array_equal(dist, od_)

@@ -200,7 +200,7 @@ def test_two_pass_filter_selects_what_the_one_pass_filter_selects(engine, N, T, 
         assert pairs < 0.5 * ((T + 31) // 32) * n_tiles, pairs
     # stage A' (the K-th smallest key among the units of the tiles nearest to a row as a second bound): same results, and
     # the lists in front of the exact re-rank do not get longer
-    engine.set_option('prefilter_ball_bound', 1)         # (an option: off by default)
+    engine.set_option('prefilter_ball_bound', 1)         # (an option: off by default, HISTORY.md 4.1c)
     before = engine.info('f16_fallbacks')
     cand, dist = engine.knn(U, K)
     assert np.array_equal(cand, oc) and np.array_equal(dist, od)
@@ -293,7 +293,7 @@ def test_a_voice_in_no_order_is_given_one(engine):
     F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
     engine.upload_db(F_unw, JC_unw)
     engine.set_weights(wt, wj)
-    U = o.synthetic_targets(F_unw, T, seed=7) * wt
+    U = o.synthetic_targets(F0, T, seed=7) * wt                # an utterance follows the speech the units were cut from, whatever their order
     U[:50] = F_unw[dup] * wt                                   # rows that ARE duplicated units
     rows = np.unique(np.concatenate([np.arange(0, 50, 7), np.linspace(50, T - 1, 12).astype(np.int64)]))
     oc_, od_ = oc.knn(F, U[rows], K)
