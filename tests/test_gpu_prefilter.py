@@ -316,9 +316,12 @@ def test_a_voice_in_no_order_is_given_one(engine):
     occ, ocd = o.knn_by_class(F, U[rows], K, cls, qc[rows])
     assert np.array_equal(cc[rows], occ) and np.array_equal(cd[rows], ocd)
     # new weights: the order stays (any order is valid), the voice is judged afresh and stays on the ball pass
-    engine.set_weights(wt * 1.3, wj)
-    cand, dist = engine.knn(U * 1.3, K)
-    oc2, od2 = oc.knn(F * 1.3, (U * 1.3)[rows], K)
+    wt2 = wt * 1.3
+    engine.set_weights(wt2, wj)
+    U2 = o.synthetic_targets(F0, T, seed=7) * wt2
+    U2[:50] = F_unw[dup] * wt2
+    cand, dist = engine.knn(U2, K)
+    oc2, od2 = oc.knn(o.weight(F_unw, wt2), U2[rows], K)
     assert np.array_equal(cand[rows], oc2) and np.array_equal(dist[rows], od2)
     assert engine.info('reordered') == 1 and engine.info('reorders') == 1 and engine.info('filter_coarse') == 0
     # a voice whose own order is the better one keeps it
