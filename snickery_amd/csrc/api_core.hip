@@ -331,6 +331,7 @@ int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt, const flo
     h->gh_ready = false; h->gj_ready = false;
     h->gs_rows = 0; h->gs_ready = false;
     h->perm_ready = false; h->reorder_useless = false; h->reorder_done = false; h->reorder_pending = false;      // a new voice: the database order again
+    h->reorder_radius_before = 0.0; h->reorder_radius_after = 0.0;
     if (h->global_N < 0) { h->shard_offset = 0; }
     if (JC_unw) CHK(upload_join(h, JC_unw, Njc, Dj));
     return 0;
