@@ -418,8 +418,8 @@ def test_knn_mass_duplicates(engine):
     come back in the reference order -- distance, then lowest unit id."""
     F_unw, JC_unw, wt, wj, F, E, S = synth_setup(30000, 61, 24, seed=17)
     F_unw = F_unw.copy()
-    F_unw[2000:9000] = F_unw[1234]                 # 7000 identical "silence" frames (> list capacity 4096)
-    F_unw[9000:9050] = F_unw[1234] + 1e-4          # and a few near them
+    F_unw[2000:11500] = F_unw[1234]                # 9500 identical "silence" frames (> the longest list, 8192: the ladder's level 1)
+    F_unw[11500:11550] = F_unw[1234] + 1e-4        # and a few near them
     engine.upload_db(F_unw, JC_unw)
     engine.set_weights(wt, wj)
     F = o.weight(F_unw, wt)
