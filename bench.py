@@ -885,7 +885,7 @@ def main():
             del F_unw, JC_unw
             shapes = []
             for sname, sN, sDt, sDj, sT, sU, sK, kinds in (('B2', 700000, 61, 302, 600, 32, 50, ('compact',)),
-                                                            ('B4 (1 GPU)', 1500000, 61, 302, 600, 8, 200, ('compact',)),
+                                                            ('B4 (1 GPU)', 1500000, 61, 302, 600, 32, 200, ('compact',)),
                                                             ('B5', 1300000, 184, 151, 120, 64, 100, ('compact', 'permuted'))):
                 Fs, JCs = synthetic_db(sN, sDt, sDj, seed=0)
                 wts, wjs = np.full(sDt, 0.4), np.full(sDj, 0.05)

@@ -707,6 +707,7 @@ int snk_prefilter_minima(snk_handle h, const double *Q, int64_t T, int D, float 
         CHK(h->cq16.ensure((size_t)Tpad * sizeof(double)));
         launch_prepare_queries16b(h->Qp.as<double>(), h->qnorm.as<double>(), T, h->Dt, h->Dpad, h->fmax2.as<double>(),
                                   h->rho16.as<double>(), h->eps_c_bf, h->b16l.p, h->eps16.as<double>(), h->cq16.as<double>(), s);
+        StageTimer tm(h, s, TM_KNN_MINIMA);
         launch_knn_sweep16b(0, h->prefilter == 2 ? 4 : 3, h->nt16_eff, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, nullptr, Tpad, n_slabs,
                             h->slabctr.as<unsigned int>(), h->gmin32.as<float>(), G16, nullptr, nullptr, nullptr, 0,
                             knn_pool_chunk_entries(), s);
@@ -723,6 +724,7 @@ int snk_prefilter_minima(snk_handle h, const double *Q, int64_t T, int D, float 
         D2HPart parts[2] = {{g.data(), h->gmin32.p, g.size() * sizeof(float)}, {eps_out, h->eps16.p, (size_t)T * sizeof(double)}};
         CHK(staged_d2h(h, s, parts, 2));
     }
+    collect_timers(h);
     for (int64_t t = 0; t < T; ++t)
         for (int64_t w = 0; w < n_slabs; ++w) {
             const float a = g[t * G16 + 2 * w], b = g[t * G16 + 2 * w + 1];

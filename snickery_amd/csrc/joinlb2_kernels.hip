@@ -243,14 +243,20 @@ join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned i
                                                       ((i & 3) + 8 * (i >> 2)) * K * 4, 0);
         }
     } else {
+        // the wavefront of the last, partly filled tile (K = 100: rows 96..127, four of them candidates): result registers whose
+        // row lies beyond K in BOTH halves are skipped (a uniform test per register: 12 of its 16 at K = 100)
+        float nsv[KT], ssv[KT], psv[KT];
 #pragma unroll
-        for (int j = 0; j < KT; ++j) {
-            const int k = j * 32 + row32;
-            const float nsv = ns_s[k], ssv = sns_s[k], psv = pns_s[k];
+        for (int j = 0; j < KT; ++j) { const int k = j * 32 + row32; nsv[j] = ns_s[k]; ssv[j] = sns_s[k]; psv[j] = pns_s[k]; }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int kp = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, cell(j, i, nsv, ssv, psv)), ores,
+        for (int i = 0; i < 16; ++i) {
+            const int kp0 = wave * 32 + (i & 3) + 8 * (i >> 2);
+            if (kp0 >= K) continue;
+            const int kp = kp0 + 4 * half;
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                const int k = j * 32 + row32;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, cell(j, i, nsv[j], ssv[j], psv[j])), ores,
                                                       (kp < K && k < K) ? (kp * K + k) * 4 : 0x7ffffffc, 0, 0);
             }
         }

@@ -2087,8 +2087,10 @@ knn_threshold16_kernel(const float *__restrict__ gmin32, int64_t G, int64_t T, i
         }
         if (P >= K && G >= K) {
             unsigned int prefix = 0u, rank = (unsigned int)(K - 1);
+            int alive = 64 * nv;                                  // values that agree with the prefix so far (padding included)
+            int b = 31;
 #pragma unroll 1
-            for (int b = 31; b >= 0; --b) {
+            for (; b >= 0 && alive > 1; --b) {
                 const unsigned int hi_mask = b == 31 ? 0u : (0xffffffffu << (b + 1));
                 int c0 = 0;
 #pragma unroll
@@ -2096,7 +2098,20 @@ knn_threshold16_kernel(const float *__restrict__ gmin32, int64_t G, int64_t T, i
                     if (j < nv) c0 += ((v[j] & hi_mask) == prefix && !((v[j] >> b) & 1u)) ? 1 : 0;
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) c0 += __shfl_xor(c0, off, 64);
-                if (rank >= (unsigned int)c0) { rank -= (unsigned int)c0; prefix |= 1u << b; }
+                if (rank >= (unsigned int)c0) { rank -= (unsigned int)c0; prefix |= 1u << b; alive -= c0; }
+                else alive = c0;
+            }
+            if (b >= 0) {
+                // one value left under the prefix (rank is 0 then): it is the K-th smallest -- its low bits need no more rounds
+                // (1 024 minima part after some 18 of the 32 bits; rows with equal minima at the K-th place run all rounds)
+                const unsigned int hi_mask = 0xffffffffu << (b + 1);
+                unsigned int found = 0u;
+#pragma unroll
+                for (int j = 0; j < NVMAX; ++j)
+                    if (j < nv && (v[j] & hi_mask) == prefix) found = v[j];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) found |= __shfl_xor(found, off, 64);
+                prefix = found;
             }
             const unsigned int bits = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
             const float kth = __uint_as_float(bits);

@@ -14,11 +14,14 @@ F0, JC0 = synthetic_db(N, Dt, Dj, seed=0)
 wt = np.full(Dt, 0.4); wj = np.full(Dj, 0.05)
 for kind in ('compact', 'permuted', 'speechlike'):
     F_unw, JC_unw = (F0, JC0) if kind == 'compact' else variant_database(kind, N, Dt, F0, JC0)
-    U = np.vstack([synthetic_targets(F_unw, 600, seed=1 + s) * wt for s in range((rows + 599) // 600)])[:rows]
+    # a permuted voice keeps the speech its units were cut from: the rows follow the walk through the ORIGINAL order
+    src = F0 if kind == 'permuted' else F_unw
+    U = np.vstack([synthetic_targets(src, 600, seed=1 + s) * wt for s in range((rows + 599) // 600)])[:rows]
     ref = None
     for two_pass in (0, 1):
         eng = snickery_amd.HipSearchEngine(0)
         eng.set_option('prefilter_two_pass', two_pass)
+        eng.set_option('reorder', 0)          # the kernel on the voice AS STORED (the engine would otherwise reorder a permuted one)
         eng.upload_db(F_unw, JC_unw); eng.set_weights(wt, wj)
         for _ in range(4):
             cand, dist = eng.knn(U, K)
