@@ -80,14 +80,19 @@ int join_lb2_pitch(int Dj) { return (Dj + 15) & ~15; }
 bool join_lb2_supported(int Dj, int K) { return join_lb2_pitch(Dj) <= JF2_MAXD && K >= 1 && K <= 208; }
 
 // one pair of float32 values into two bf16 pieces each (v_cvt_pk_bf16_f32: round to nearest even); the pair's share of the
-// row's sum of squares is added to n2 (lane-wise: even and odd columns have chains of their own)
-__device__ __forceinline__ void jf_split2(jf_f32x2 y, unsigned int &hi, unsigned int &lo, jf_f32x2 &n2)
+// row's sum of squares is added to n2 (lane-wise: even and odd columns have chains of their own).  Scalar float32 arithmetic on
+// purpose (and -fno-slp-vectorize in the Makefile): beside MFMAs a v_pk_add_f32 / v_pk_fma_f32 costs the issue port more than the
+// two scalar instructions it replaces (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'), and this kernel is issue-bound
+__device__ __forceinline__ void jf_split2(float y0, float y1, unsigned int &hi, unsigned int &lo, float &n0, float &n1)
 {
-    n2 = __builtin_elementwise_fma(y, y, n2);
+    n0 = __builtin_fmaf(y0, y0, n0);
+    n1 = __builtin_fmaf(y1, y1, n1);
+    const jf_f32x2 y = {y0, y1};
     const unsigned int hb = __builtin_bit_cast(unsigned int, __builtin_convertvector(y, jf_bf16x2));
-    const jf_f32x2 hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+    const float r0 = y0 - __builtin_bit_cast(float, hb << 16), r1 = y1 - __builtin_bit_cast(float, hb & 0xffff0000u);      // exact
     hi = hb;
-    lo = __builtin_bit_cast(unsigned int, __builtin_convertvector(y - hf, jf_bf16x2));      // y - hf is exact
+    const jf_f32x2 rr = {r0, r1};
+    lo = __builtin_bit_cast(unsigned int, __builtin_convertvector(rr, jf_bf16x2));
 }
 
 template <int KT>
@@ -145,26 +150,22 @@ join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned i
     auto block = [&](int kb, int next, f32x4 (&e)[2], f32x4 (&s)[2]) {
         const f32x4 m0 = *reinterpret_cast<const f32x4 *>(&m_s[kb * 16 + 8 * half]);
         const f32x4 m1 = *reinterpret_cast<const f32x4 *>(&m_s[kb * 16 + 8 * half + 4]);
-        // (explicit pairs: left to itself the vectoriser pairs E with S elements and pays for it in register moves)
-        jf_f32x2 ye[4], ys[4];
-        ye[0] = __builtin_shufflevector(e[0], e[0], 0, 1) - __builtin_shufflevector(m0, m0, 0, 1);
-        ye[1] = __builtin_shufflevector(e[0], e[0], 2, 3) - __builtin_shufflevector(m0, m0, 2, 3);
-        ye[2] = __builtin_shufflevector(e[1], e[1], 0, 1) - __builtin_shufflevector(m1, m1, 0, 1);
-        ye[3] = __builtin_shufflevector(e[1], e[1], 2, 3) - __builtin_shufflevector(m1, m1, 2, 3);
-        ys[0] = __builtin_shufflevector(s[0], s[0], 0, 1) - __builtin_shufflevector(m0, m0, 0, 1);
-        ys[1] = __builtin_shufflevector(s[0], s[0], 2, 3) - __builtin_shufflevector(m0, m0, 2, 3);
-        ys[2] = __builtin_shufflevector(s[1], s[1], 0, 1) - __builtin_shufflevector(m1, m1, 0, 1);
-        ys[3] = __builtin_shufflevector(s[1], s[1], 2, 3) - __builtin_shufflevector(m1, m1, 2, 3);
+        const float mm[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+        const float ee[8] = {e[0][0], e[0][1], e[0][2], e[0][3], e[1][0], e[1][1], e[1][2], e[1][3]};
+        const float ss[8] = {s[0][0], s[0][1], s[0][2], s[0][3], s[1][0], s[1][1], s[1][2], s[1][3]};
+        float ye[8], ys[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ye[j] = ee[j] - mm[j]; ys[j] = ss[j] - mm[j]; }
         if (next >= 0) fetch(next, e, s);                     // (a compile-time decision at every call site)
-        jf_f32x2 te = {0.f, 0.f}, ts = {0.f, 0.f};
+        float te0 = 0.f, te1 = 0.f, ts0 = 0.f, ts1 = 0.f;
         u32x4 he, le, hs, ls;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             unsigned int a, b, c, d;
-            jf_split2(ye[j], a, b, te); jf_split2(ys[j], c, d, ts);
+            jf_split2(ye[2 * j], ye[2 * j + 1], a, b, te0, te1); jf_split2(ys[2 * j], ys[2 * j + 1], c, d, ts0, ts1);
             he[j] = a; le[j] = b; hs[j] = c; ls[j] = d;
         }
-        ne += te[0] + te[1]; ns += ts[0] + ts[1];
+        ne += te0 + te1; ns += ts0 + ts1;
         Bs[kb & 1][wave][0][lane] = hs;
         Bs[kb & 1][wave][1][lane] = ls;
         __syncthreads();
