@@ -470,17 +470,24 @@ knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__rest
                   const int32_t *__restrict__ perm)
 {
     // per chunk: LDS histogram by row -> one global atomic per (chunk, row) reserves a run of
-    // list slots -> entries of one row land contiguously
+    // list slots -> entries of one row land contiguously.
+    // The histogram holds 16-bit counters, two rows per word (a chunk has 2 048 entries; 32-bit atomics add 1 << 16 for the odd
+    // row of a word and never carry): 64 KB for the 32 768 rows of a sharded search's calls instead of 128 -- two workgroups per
+    // compute unit hide each other's atomics' round trips.  The run's base (32 bits) does not fit the counter: the row's first
+    // entry keeps it in `base[its own index]` and leaves that index in the row's counter for the others.
     extern __shared__ int bsm[];
-    int *hist = bsm;             // [Tpad] count, then base
+    unsigned int *hist = reinterpret_cast<unsigned int *>(bsm);                         // [(Tpad + 1) / 2]
+    unsigned short *hist16 = reinterpret_cast<unsigned short *>(bsm);                   // the same, per row
+    int *base = bsm + (Tpad + 1) / 2;                                                   // [POOL_CHUNK]
     int used = (int)pool_ctl[0];
     if (used > max_chunks) used = max_chunks;
     if (blockIdx.x == 0 && threadIdx.x == 0 && pool_ctl[1]) atomicOr(status, 4);
     constexpr int EPT = POOL_CHUNK / 256;
+    static_assert(POOL_CHUNK < 65536, "entry indices and counts of a chunk travel in 16 bits");
     // the histogram is cleared ONCE; a chunk touches the slots of the rows it holds entries of and puts them back to zero
     // (clearing and scanning all Tpad slots per chunk made the kernel's time proportional to chunks x rows: 2.2 ms per
     // sharded step of 153 600 rows whatever the lists held)
-    for (int i = threadIdx.x; i < Tpad; i += 256) hist[i] = 0;
+    for (int i = threadIdx.x; i < (Tpad + 1) / 2; i += 256) hist[i] = 0u;
     __syncthreads();
     for (int c = blockIdx.x; c < used; c += gridDim.x) {
         const int n = chunk_fill[c];
@@ -493,23 +500,28 @@ knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__rest
             rank[k] = -1;
             if (e < n) {
                 en[k] = pool[(int64_t)c * POOL_CHUNK + e];
-                if (en[k].idx < n_valid) rank[k] = atomicAdd(&hist[en[k].row], 1);   // padding units never count
+                if (en[k].idx < n_valid) {                                              // padding units never count
+                    const int sh = 16 * (en[k].row & 1);
+                    rank[k] = (int)((atomicAdd(&hist[en[k].row >> 1], 1u << sh) >> sh) & 0xffffu);
+                }
             }
         }
         __syncthreads();
-        // the first entry of a row in this chunk reserves the row's run of list slots: count -> base
+        // the first entry of a row in this chunk reserves the row's run of list slots
 #pragma unroll
         for (int k = 0; k < EPT; ++k)
             if (rank[k] == 0) {
-                const int h = hist[en[k].row];
-                hist[en[k].row] = atomicAdd(&cnt[en[k].row], h);
+                const int e = threadIdx.x + k * 256;
+                const int h = (int)hist16[en[k].row];
+                base[e] = atomicAdd(&cnt[en[k].row], h);
+                hist16[en[k].row] = (unsigned short)e;
             }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
             const int e = threadIdx.x + k * 256;
             if (e < n && rank[k] >= 0) {
-                const int slot = hist[en[k].row] + rank[k];
+                const int slot = base[hist16[en[k].row]] + rank[k];
                 if (slot < cap) {
                     lkey[(int64_t)en[k].row * cap + slot] = en[k].key;
                     // (a reordered operand -- kmeans_kernels.hip -- hands out positions: everything behind this line sees unit ids)
@@ -520,7 +532,7 @@ knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__rest
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < EPT; ++k)
-            if (rank[k] == 0) hist[en[k].row] = 0;
+            if (rank[k] == 0) hist16[en[k].row] = 0;
         __syncthreads();
     }
 }
@@ -530,14 +542,13 @@ void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int
                        int cap, int *status, hipStream_t s, const int32_t *perm)
 {
     static size_t attr[32] = {0};
-    if ((size_t)Tpad * sizeof(int) > 65536)
-        lds_attr_ensure(attr, (size_t)Tpad * sizeof(int), [&] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)Tpad * sizeof(int))); });
-    // one workgroup per compute unit and LDS share: with 128 KB of histogram (32 768 rows: the sharded search's calls) a
-    // compute unit holds one workgroup, and 1 024 of them were four rounds of clearing it
-    const size_t lds = (size_t)Tpad * sizeof(int);
+    const size_t lds = (size_t)((Tpad + 1) / 2) * sizeof(int) + (size_t)POOL_CHUNK * sizeof(int);
+    if (lds > 65536)
+        lds_attr_ensure(attr, lds, [&] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    // as many workgroups per compute unit as its LDS holds (at most 6: 1 536 threads)
     int per_cu = (int)((size_t)(160 * 1024) / (lds + 1024));
-    per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
+    per_cu = per_cu < 1 ? 1 : per_cu > 6 ? 6 : per_cu;
     hipLaunchKernelGGL(knn_bucket_kernel, dim3(256 * per_cu), dim3(256), lds, s,
                        reinterpret_cast<const PoolEntry *>(pool), pool_ctl, chunk_fill, max_chunks,
                        (int)Tpad, (int)n_valid, cnt, lkey, lidx, cap, status, perm);
@@ -1496,11 +1507,123 @@ merge_topk_kernel(const double *__restrict__ d2, const int64_t *__restrict__ id,
     }
 }
 
+// The lists a shard sends are SORTED (knn_finalize_kernel writes a row's neighbours in the canonical order, padding last), so
+// the merge is a tree of two-way merges of which only the first K outputs matter: one WAVEFRONT per row, every output position
+// finds its element by a binary search along the merge path (7 steps at K = 100), log2(G) levels, no workgroup barrier.  The
+// bitonic sort above took 0.84 ms per 19 200 rows at G = 8; a caller's lists that are NOT sorted (the entry point
+// snk_merge_topk_dev does not promise it) are noticed while they are loaded and that row is sorted by its wavefront instead.
+__device__ __forceinline__ void merge_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ void __launch_bounds__(256)
+merge_topk_path_kernel(const double *__restrict__ d2, const int64_t *__restrict__ id, int G, int Gp, int P2, int64_t T,
+                       int K, int64_t *__restrict__ cand, double *__restrict__ dist)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * wpb + wv;
+    if (row >= T) return;
+    const int nB = (Gp / 2) * K;
+    // per wavefront: keys A (P2), keys B (nB), ids A (P2), ids B (nB)
+    const size_t per_wave = ((size_t)(P2 + nB) * (sizeof(double) + sizeof(int)) + 15) & ~(size_t)15;
+    double *keyA = reinterpret_cast<double *>(smem + (size_t)wv * per_wave);
+    double *keyB = keyA + P2;
+    int *idA = reinterpret_cast<int *>(keyB + nB);
+    int *idB = idA + P2;
+    const int n = G * K;
+    for (int i = lane; i < P2; i += 64) {
+        double k = DBL_MAX;
+        int x = 0x7fffffff;
+        if (i < n) {
+            const int gsh = i / K, j = i - gsh * K;
+            const int64_t gi = id[((int64_t)gsh * T + row) * K + j];
+            if (gi >= 0) { k = d2[((int64_t)gsh * T + row) * K + j]; x = (int)gi; }
+        }
+        keyA[i] = k; idA[i] = x;
+    }
+    merge_wave_sync();
+    bool bad = false;
+    for (int i = lane; i < n; i += 64)
+        if (i % K != 0 && pair_less(keyA[i], idA[i], keyA[i - 1], idA[i - 1])) bad = true;
+    if (__any(bad)) {
+        // not what a shard's re-rank writes: this row through a sort of its own (one wavefront, P2 entries)
+        for (int k = 2; k <= P2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = lane; i < P2; i += 64) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const bool up = ((i & k) == 0);
+                        const double ka = keyA[i], kb = keyA[ixj];
+                        const int ia = idA[i], ib = idA[ixj];
+                        const bool sw = up ? pair_less(kb, ib, ka, ia) : pair_less(ka, ia, kb, ib);
+                        if (sw) { keyA[i] = kb; keyA[ixj] = ka; idA[i] = ib; idA[ixj] = ia; }
+                    }
+                }
+                merge_wave_sync();
+            }
+    } else {
+        double *ks = keyA, *kd = keyB;
+        int *is = idA, *id_ = idB;
+        for (int lists = Gp; lists > 1; lists >>= 1) {
+            const int items = (lists >> 1) * K;
+            for (int it = lane; it < items; it += 64) {
+                const int m = it / K, o = it - m * K;
+                const double *ak = ks + (size_t)(2 * m) * K, *bk = ak + K;
+                const int *ai = is + (size_t)(2 * m) * K, *bi = ai + K;
+                int lo = 0, hi = o;                 // elements of list a among the first o outputs
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (!pair_less(bk[o - 1 - mid], bi[o - 1 - mid], ak[mid], ai[mid])) lo = mid + 1;
+                    else hi = mid;
+                }
+                const int i = lo, j = o - lo;
+                const bool from_a = !pair_less(bk[j], bi[j], ak[i], ai[i]);
+                kd[(size_t)m * K + o] = from_a ? ak[i] : bk[j];
+                id_[(size_t)m * K + o] = from_a ? ai[i] : bi[j];
+            }
+            merge_wave_sync();
+            double *tk = ks; ks = kd; kd = tk;
+            int *ti = is; is = id_; id_ = ti;
+        }
+        if (ks != keyA) {                       // (an odd number of levels left the result in B)
+            for (int j = lane; j < K; j += 64) { keyA[j] = ks[j]; idA[j] = is[j]; }
+            merge_wave_sync();
+        }
+    }
+    for (int j = lane; j < K; j += 64) {
+        const bool ok = keyA[j] < DBL_MAX;
+        cand[row * K + j] = ok ? (int64_t)idA[j] : -1;
+        dist[row * K + j] = ok ? __dsqrt_rn(keyA[j]) : SNK_VERY_BIG;
+    }
+}
+
 void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, int K, int64_t *cand,
                        double *dist, hipStream_t s)
 {
     int P = 2;
     while (P < G * K) P <<= 1;
+    {
+        int Gp = 1;
+        while (Gp < G) Gp <<= 1;
+        int P2 = 2;
+        while (P2 < Gp * K) P2 <<= 1;
+        const size_t per_wave = ((size_t)(P2 + (Gp / 2) * K) * (sizeof(double) + sizeof(int)) + 15) & ~(size_t)15;
+        int wpb = (int)((size_t)65536 / per_wave);
+        if (wpb > 4) wpb = 4;
+        if (wpb >= 1 && Gp >= 2) {
+            const size_t shmem = per_wave * wpb;
+            static size_t attr2[32] = {0};
+            lds_attr_ensure(attr2, shmem, [&] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_topk_path_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); });
+            hipLaunchKernelGGL(merge_topk_path_kernel, dim3((unsigned)((T + wpb - 1) / wpb)), dim3(64 * wpb), shmem, s, d2, id, G, Gp,
+                               P2, T, K, cand, dist);
+            return;
+        }
+    }
     const size_t shmem = (size_t)P * (sizeof(double) + sizeof(int));
     static size_t attr[32] = {0};
     lds_attr_ensure(attr, shmem, [&] {

@@ -25,5 +25,6 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS
 python3 tools/knn_time.py 9600 > $T/knn_alone.log 2>&1; grep -a "^prefilter" $T/knn_alone.log | cut -c1-500
 python3 tools/single_time.py 600 > $T/single.log 2>&1; grep -a "chunk 48 warm 16\|mode 0" $T/single.log | cut -c1-420
 python3 tools/onepass_time.py 9600 > $T/onepass.log 2>&1; grep -a "two_pass" $T/onepass.log | cut -c1-300
+python3 tools/minima_time.py 600 > $T/minima.log 2>&1; tail -1 $T/minima.log
 find $T -name "*.csv" | wc -l
 head -c 400 $T/bench.json

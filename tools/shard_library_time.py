@@ -92,11 +92,14 @@ redo0 = eng.info('batch_redos')
 eng.reset_timers()
 paths, costs = eng.sharded_knn_viterbi_batch(utts, K)
 tm = {k: round(v[0], 2) for k, v in eng.timers().items() if v[1]}
-main = sum(tm.get(k, 0) for k in ('h2d_queries', 'prepare_queries', 'knn_minima', 'knn_threshold', 'knn_filter', 'knn_bucket',
-                                  'knn_finalize', 'merge_topk', 'join_lower_bounds', 'join_costs'))
+MAIN = ('h2d_queries', 'prepare_queries', 'knn_minima', 'knn_threshold', 'knn_filter', 'knn_bucket', 'knn_finalize', 'merge_topk')
+main = sum(tm.get(k, 0) for k in MAIN)                                   # what the main stream carries
+side = tm.get('join_lower_bounds', 0) + tm.get('join_exact_sparse', 0) + tm.get('join_costs', 0)   # whole-chip passes of the side streams
+own = tm.get('h2d_queries', 0) * (1.0 - 1.0 / G)                          # the stand-in uploads all rows, a rank its own share
 print('G=%d rank 0, %d rows per step (%d owned): stages ms %s' % (G, R, R // G, tm))
 wire = (G - 1) / G * R * K * 16 / 1e9
-print('main-stream device time %.1f ms per step of %d frames (%.1f ms with the upload of the rank\'s own eighth of the rows instead of the stand-in\'s upload of all); '
+print('whole-chip kernels of one rank\'s step of %d frames: main stream %.2f ms (with the upload of the rank\'s own share of the rows: the stand-in '
+      'uploads all, %.2f ms) + side streams %.2f ms (bounds and exact costs of the owned rows; here on lists that are mostly padding) = %.2f ms; '
       'exchange payload %.0f MB per rank padded, %.1f MB sent (shard_compact %d)'
-      % (main, R, main - tm.get('h2d_queries', 0) * (1.0 - 1.0 / G), wire * 1e3, eng.info('shard_last_sent_mb'), eng.info('shard_compact')))
+      % (R, main - own, main, side, main - own + side, wire * 1e3, eng.info('shard_last_sent_mb'), eng.info('shard_compact')))
 print('redone steps: %d, f32 fallbacks: %d' % (eng.info('batch_redos') - redo0, eng.info('f16_fallbacks')))

@@ -140,6 +140,9 @@ if os.path.isfile(os.path.join(src, 'onepass.log')):
     shutil.copy(os.path.join(src, 'onepass.log'), os.path.join(out, 'r05_onepass.log'))
     lines += ['', '## The one-pass three-term sweep alone (tools/onepass_time.py: 9 600 rows, B* database as generated / permuted / AR(1))', '', '```'] + \
              [l[:400] for l in open(os.path.join(src, 'onepass.log'), errors='replace').read().splitlines() if 'two_pass' in l] + ['```']
+if os.path.isfile(os.path.join(src, 'minima.log')):
+    lines += ['', '## The minima sweep (the kernel of stage A) alone over the whole database (tools/minima_time.py)', '', '```'] + \
+             [l[:300] for l in open(os.path.join(src, 'minima.log'), errors='replace').read().splitlines() if l.startswith('minima sweep')] + ['```']
 if os.path.isfile(os.path.join(src, 'single.log')):
     lines += ['', '## One utterance per call (snk_knn_viterbi, T = 600; tools/single_time.py)', '', '```'] + \
              [l[:700] for l in open(os.path.join(src, 'single.log'), errors='replace').read().splitlines() if 'viterbi_mode' in l and ('chunk 48 warm 16' in l or 'chunk 0' in l)] + ['```']
