@@ -201,6 +201,9 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "viterbi_refine_gate")) {
         if (!(value >= 0.0 && value <= 1.0)) return fail("viterbi_refine_gate must be in 0..1");
         h->vit_refine_gate = value;
+    } else if (!strcmp(name, "viterbi_fst32_slack")) {
+        if (!(value >= 0.0 && value <= 1e-3)) return fail("viterbi_fst32_slack must be in 0..1e-3");
+        h->fst32_slack = value;
     } else if (!strcmp(name, "viterbi_lb_chunk") || !strcmp(name, "viterbi_lb_warm") || !strcmp(name, "viterbi_lb_chunk_max_utts")) {
         if (!(value >= 0.0 && value <= 1e6) || value != (double)(int)value) return fail("%s must be a small non-negative integer", name);
         if (!strcmp(name, "viterbi_lb_warm") && value < 1.0) return fail("viterbi_lb_warm must be >= 1");
@@ -375,6 +378,8 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "filter_probe_period")) *out = h->probe_period;
     else if (!strcmp(name, "latch_rearm")) *out = h->latch_rearm;
     else if (!strcmp(name, "viterbi_latch")) *out = h->viterbi_latch;
+    else if (!strcmp(name, "viterbi_fst32_slack")) *out = h->fst32_slack;
+    else if (!strcmp(name, "viterbi_refine_gate")) *out = h->vit_refine_gate;
     else if (!strcmp(name, "viterbi_latch_mode")) *out = h->vit.mode;                 // 0: batches take the sparse path, 1: the dense kernels (judged, snk_engine.h)
     else if (!strcmp(name, "viterbi_latch_switches")) *out = (double)h->vit.switches;
     else if (!strcmp(name, "viterbi_latch_trials")) *out = (double)h->vit.trials;

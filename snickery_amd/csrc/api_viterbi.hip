@@ -100,7 +100,8 @@ static int viterbi_sparse_rows(snk_engine *h, UttSlot &s, const int64_t *cand, c
         StageTimer t(h, side, TM_DP_LB);
         launch_viterbi_lb(cand, tdist, s.Jlo.as<float>(), s.scale.as<float>(), off, n_utts, K, join_units(h),
                           (float)h->join_beta, s.sets.p, side,
-                          n_utts <= h->lb_chunk_max_utts ? (n_utts <= 4 && h->lb_chunk > 32 ? 32 : h->lb_chunk) : 0, h->lb_warm);
+                          n_utts <= h->lb_chunk_max_utts ? (n_utts <= 4 && h->lb_chunk > 32 ? 32 : h->lb_chunk) : 0, h->lb_warm,
+                          h->viterbi_weights == 1 ? (float)h->fst32_slack : 0.f);
     }
     {
         StageTimer t(h, side, TM_JOIN_SPARSE);

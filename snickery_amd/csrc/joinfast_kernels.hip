@@ -266,7 +266,7 @@ template <int KPM, int NB, int NTH>
 __global__ void __launch_bounds__(NTH)
 viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict__ tdist_all,
                   const float *__restrict__ J_all, const float *__restrict__ scale_all, const DpBatch batch, int K,
-                  int64_t n_units, int KP, float beta, u32x4 *__restrict__ sets_all, int64_t chunk_len, int warm)
+                  int64_t n_units, int KP, float beta, u32x4 *__restrict__ sets_all, int64_t chunk_len, int warm, float slack32)
 {
     // a T-step chain on one compute unit beside the K-NN sweep's MFMA wavefronts: its few instructions go first
     __builtin_amdgcn_s_setprio(3);
@@ -346,6 +346,12 @@ viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
     // Every total is a non-negative float (or +inf): ordered like its bit pattern, so minima are integer
     // minima (fminf costs a canonicalising v_max per operand) and the sweeps have no branch per element.
     const unsigned int INFU = 0x7f800000u;
+    // viterbi_weights 1 (slack32 > 0): pass 4 then runs OpenFST's float32 chain, where an excluded predecessor must exceed the
+    // best total by two float32 roundings of the ABSOLUTE total (2.4e-7 of it: 7e-4 at the end of a B* utterance, several times
+    // theta) for the proof to hold -- the sets are widened by that much.  A chunk knows its totals only since its own start
+    // (`cum`: the shifts it has applied): the absolute total is estimated from their growth per step.  Heuristic on purpose:
+    // the sets decide how often pass 4 refines, never what it returns.
+    float cum = 0.f;
     auto step = [&](int64_t t, float (&jr)[KPM], double &tdr, int64_t &idr, float &scr) {
         const bool valid = t < t1;                      // uniform
         const float *dprev = delta + ((t - 1) & 1) * KP;
@@ -361,6 +367,7 @@ viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
             shift = inf;
             for (int w = 0; w < nwaves; ++w) { const float o = wmin[w]; shift = o < shift ? o : shift; }
             if (!(shift < inf)) shift = 0.f;
+            cum += shift;
 #pragma unroll
             for (int i = 0; i < KPM; ++i) {
                 vu[i] = __builtin_bit_cast(unsigned int, (dprev[kp0 + i] - shift) + jr[i]);
@@ -381,7 +388,9 @@ viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
         }
         const float best = __builtin_bit_cast(float, bestu);
         // second sweep: the set within theta of the minimum (a bit per element), the minimum of the rest
-        const float thr = best + (beta * sc + 4e-7f * best);
+        float theta = beta * sc + 4e-7f * best;
+        if (slack32 > 0.f) theta += slack32 * ((best + cum) * ((float)t / (float)(t - ts + 1)));
+        const float thr = best + theta;
         const unsigned int thru = bestu < INFU ? __builtin_bit_cast(unsigned int, thr) : 0u;
         unsigned int xminu = INFU, mem_lo = 0u, mem_hi = 0u;
 #pragma unroll
@@ -440,7 +449,7 @@ viterbi_lb_kernel(const int64_t *__restrict__ cand_all, const double *__restrict
 }
 
 void launch_viterbi_lb(const int64_t *cand, const double *tdist, const float *Jlo, const float *scale, const int64_t *off,
-                       int n_utts, int K, int64_t n_units, float beta, void *sets, hipStream_t s, int chunk_len, int warm)
+                       int n_utts, int K, int64_t n_units, float beta, void *sets, hipStream_t s, int chunk_len, int warm, float slack32)
 {
     static_assert(JF_CAP == 4, "the sets travel as one 32-bit word");
     for (int u0 = 0; u0 < n_utts; u0 += DpBatch::MAX) {
@@ -462,7 +471,7 @@ void launch_viterbi_lb(const int64_t *cand, const double *tdist, const float *Jl
         const size_t shmem = (size_t)2 * KP * 4 + (size_t)KP * 4 + (size_t)KP * 4 + 64;
 #define SNK_LB(KPM_, NB_, NTH_)                                                                               \
     hipLaunchKernelGGL((viterbi_lb_kernel<KPM_, NB_, NTH_>), dim3(n, n_chunks), dim3(nth), shmem, s, cand, tdist, Jlo, scale, \
-                       batch, K, n_units, KP, beta, reinterpret_cast<u32x4 *>(sets), clen, warm)
+                       batch, K, n_units, KP, beta, reinterpret_cast<u32x4 *>(sets), clen, warm, slack32)
         if (variant == 0) SNK_LB(16, 4, 256);
         else if (variant == 1) SNK_LB(25, 6, 448);
         else if (variant == 2) SNK_LB(32, 3, 512);

@@ -369,6 +369,10 @@ struct snk_engine {
     // batches) is 5 % shorter; the path not in use is tried again after 32, 64 .. 1 024 batches.  Same results either way.
     int viterbi_latch = 1;
     double vit_refine_gate = 0.01;
+    // viterbi_weights 1 on the sparse path: pass 2's predecessor sets are wider by this fraction of the (estimated) absolute
+    // total -- two float32 roundings of it sit between an excluded predecessor and the proof (joinfast_kernels.hip).  Speed
+    // only; measured at B*: 24.4 ms per batch at 0, 6.3 at 3e-7, 13.8 at 6e-7 (beyond it the four-member sets overflow)
+    double fst32_slack = 3e-7;
     struct VitLatch {
         int mode = 0, trial_mode = -1, trial_left = 0;      // 0 sparse, 1 dense
         double ms_row[2] = {0.0, 0.0}, trial_best = 0.0;

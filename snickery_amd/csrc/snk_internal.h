@@ -229,7 +229,8 @@ void launch_join_lb2(const float *JW, int Dj, const unsigned int *umax_bits, int
                      int K, float *Jlo, float *scale, hipStream_t s);
 void launch_viterbi_lb(const int64_t *cand, const double *tdist, const float *Jlo, const float *scale, const int64_t *off,
                        int n_utts, int K, int64_t n_units, float beta, void *sets, hipStream_t s,
-                       int chunk_len = 0, int warm = 32);   // chunk_len > 0: the approximate recursion in chunks of that many steps, side by side
+                       int chunk_len = 0, int warm = 32,
+                       float slack32 = 0.f);        // viterbi_weights 1: sets wider by this fraction of the (estimated) absolute total   // chunk_len > 0: the approximate recursion in chunks of that many steps, side by side
 size_t join_record_bytes();
 // Jlo / scale / ceps / stats (pass 3 and pass 4): the tripwire of pass 1's bounds -- every exact cost computed is held against the
 // bound of its cell: stats[4] += cells with lo > exact, stats[5] = smallest margin (joinfast_kernels.hip); ceps from join_lb_ceps

@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 for o in "prefilter=1"; do
 python bench.py --steps 40 --warmup 2 --no-greedy --no-cpu-baseline --opt $o 2>/dev/null | python -c "
 import json,sys

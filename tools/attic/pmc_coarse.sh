@@ -1,5 +1,5 @@
 # PMC passes of the two-pass filter alone (one K-NN call of 9600 rows against the B* database, nothing else on the GPU)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/${1:-r3c}
 mkdir -p $O

@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r02a
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d gpurun_out/r02a/mfma -- python3 tools/knn_time.py 6400 1 16 > gpurun_out/r02a/mfma.log 2>&1

@@ -1,6 +1,6 @@
 # B3 greedy search (tools/b3_time.py) under rocprofv3: kernel times, then FETCH_SIZE / WRITE_SIZE / MFMA-busy in separate passes.
 # usage on the GPU box: bash tools/prof_b3.sh   -> gpurun_out/b3prof/summary.txt
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 T=gpurun_out/b3prof
 mkdir -p $T

@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/kprof
 rocprofv3 --kernel-trace --stats -d gpurun_out/kprof/s --output-format csv -- python3 tools/prof_knn.py > gpurun_out/kprof/log.txt 2>&1

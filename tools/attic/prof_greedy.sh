@@ -1,5 +1,5 @@
 # PMC passes over the greedy step kernel (tools/prof_greedy.py: N = 1.5 M, me = 6, 100 steps); run through gpurun
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pg
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pg/stats -- python3 tools/prof_greedy.py > /dev/null 2>&1

@@ -1,5 +1,5 @@
 # rocprofv3 passes over the hoisted greedy search (tools/prof_hoist.py: B3 shape, N = 1.5 M, me = 6, 100 steps per launch); run through gpurun
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/ph
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ph/stats -- python3 tools/prof_hoist.py > /dev/null 2>&1

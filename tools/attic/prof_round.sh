@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r01d
 python bench.py --steps 5 --warmup 1 > gpurun_out/r01d/bench.json 2> gpurun_out/r01d/bench.err

@@ -1,5 +1,5 @@
 # round-3 profile set; usage (on the GPU box): bash tools/prof_round3.sh r03a
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 T=gpurun_out/$1
 mkdir -p $T

@@ -1,5 +1,5 @@
 # round-4 profile set; usage (on the GPU box): bash tools/prof_round4.sh r04a [quick]
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 T=gpurun_out/$1
 mkdir -p $T

@@ -9,11 +9,15 @@ import snickery_amd
 from bench import synthetic_db, synthetic_targets
 
 N, Dt, Dj, T, K, U = 1048576, 61, 302, 600, 100, 32
-if len(sys.argv) > 1: K = int(sys.argv[1])
+FST32 = '--fst32' in sys.argv          # viterbi_weights 1: OpenFST's float32 chain on both exact paths
+_pos = [a for a in sys.argv[1:] if not a.startswith('--')]
+if _pos: K = int(_pos[0])
 F_unw, JC_unw = synthetic_db(N, Dt, Dj, seed=0)
 wt = np.full(Dt, 0.4); wj = np.full(Dj, 0.05)
 eng = snickery_amd.HipSearchEngine(0)
 eng.upload_db(F_unw, JC_unw); eng.set_weights(wt, wj)
+eng.set_option('viterbi_latch', 0)
+if FST32: eng.set_option('viterbi_weights', 1)
 utts = [synthetic_targets(F_unw, T, seed=1 + s) * wt for s in range(U)]
 dev = torch.device('cuda', 0)
 d2 = torch.empty(U * T, K, dtype=torch.float64, device=dev)
