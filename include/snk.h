@@ -287,6 +287,16 @@ int snk_sharded_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *
 int snk_sharded_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts, int D, int K,
                                          int *ticket_out);
 int snk_sharded_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, int64_t *path_len_out, double *cost_out);
+/* greedy_joint_search (synth_simple.py:458-503, the loop :486-501) with the scan of every step split over the ranks of
+ * the communicator (snk_comm_init / snk_comm_init_transport): every rank holds the WHOLE database (snk_upload_db,
+ * snk_set_weights, snk_set_greedy_layout as for snk_greedy -- the scan is bound by the bytes a step streams, not by
+ * memory: 12 M units are 15 GB of the 288) and scans the windows of its share; per step one all-gather of 16 bytes per
+ * rank (squared distance, window), every rank picks the same winner (lowest window on exact ties, as one scan does) and
+ * writes the next step's reference itself.  The exact float64 scan, one launch per step and rank.  Every rank calls it
+ * with the same arguments and receives the whole path; results equal snk_greedy's bit for bit.  No reference
+ * counterpart (SURVEY 8e marks it optional). */
+int snk_sharded_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_state,
+                       int64_t *path_out, double *dist_out, int64_t *nsteps_out);
 /* plain synchronous copies for transport implementations (device pointers handed to the callbacks) */
 int snk_copy_to_host(void *dst_host, const void *src_dev, int64_t bytes);
 int snk_copy_to_device(void *dst_dev, const void *src_host, int64_t bytes);

@@ -739,3 +739,79 @@ int snk_sharded_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *
     CHK(snk_sharded_knn_viterbi_batch_submit(h, Q, row_offsets, n_utts, D, K, &ticket));
     return snk_sharded_knn_viterbi_batch_collect(h, ticket, path_out, path_len_out, cost_out);
 }
+
+// greedy search with the scan of every step split over the ranks (include/snk.h).  Host-driven: a step is the rank's scan
+// launch, one all-gather of 16 bytes per rank, the pick launch -- queued on the engine's stream without a host wait between
+// them over RCCL (a transport's callbacks synchronise themselves).
+int snk_sharded_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_state,
+                       int64_t *path_out, double *dist_out, int64_t *nsteps_out)
+{
+    CHK(check_ready(h, true, true));
+    CHK(no_batch_in_flight(h, "snk_sharded_greedy"));
+    HIPCHK(hipSetDevice(h->device));
+    if (h->comm_ranks < 1) return fail("snk_sharded_greedy: no communicator (snk_comm_init)");
+    if (!h->have_glay) return fail("snk_sharded_greedy: greedy layout not set (snk_set_greedy_layout)");
+    if (h->shard_offset != 0 || (h->global_N > 0 && h->global_N != h->N))
+        return fail("snk_sharded_greedy: every rank holds the whole database (this engine holds a shard of it)");
+    if (!path_out || !nsteps_out) return fail("snk_sharded_greedy: null output");
+    const GreedyLayout &g = h->glay;
+    if (start_state >= g.Nwin) return fail("snk_sharded_greedy: start_state %lld out of range", (long long)start_state);
+    CHK(upload_queries(h, Q, T, D));
+    const int64_t nsteps = T / g.me;
+    *nsteps_out = nsteps;
+    if (nsteps == 0) { HIPCHK(hipStreamSynchronize(h->stream)); collect_timers(h); return 0; }
+    if (!h->gtiles_ready) {
+        CHK(h->gtiles.ensure(greedy_tile_bytes(g, h->Dt)));
+        launch_greedy_tiles(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->JC_unw.as<float>(), h->Jp, h->gtiles.as<float>(), h->stream);
+        HIPCHK(hipGetLastError());
+        h->gtiles_ready = true;
+    }
+    const int G = h->comm_ranks, me = h->comm_rank;
+    const int64_t ntiles = (g.Nwin + 63) / 64;
+    int64_t tlo = 0, thi = 0;
+    shard_plan(ntiles, G, me, &tlo, &thi);
+    const int64_t tile_n = thi - tlo;
+    const int nblk = greedy_shard_blocks(g, h->Dt, h->n_cus, tile_n > 0 ? tile_n : 1);
+    CHK(h->gprev.ensure(2 * greedy_table_doubles(g, h->Dt) * sizeof(double) + 512));
+    CHK(h->gsync.ensure(greedy_counter_bytes()));
+    CHK(h->gblkmin.ensure((size_t)nblk * sizeof(double)));
+    CHK(h->gblkarg.ensure((size_t)nblk * sizeof(int64_t)));
+    CHK(h->gpath.ensure((size_t)nsteps * sizeof(int64_t)));
+    CHK(h->gdist.ensure((size_t)nsteps * sizeof(double)));
+    CHK(h->gshard.ensure((size_t)16 * (G + 1)));
+    double *mine = h->gshard.as<double>(), *all = mine + 2;
+    {
+        // a rank without tiles (more ranks than tiles) contributes "nothing found"
+        const double none_d = DBL_MAX;
+        const int64_t none_i = INT64_MAX;
+        unsigned char init[16];
+        memcpy(init, &none_d, 8); memcpy(init + 8, &none_i, 8);
+        CHK(h2d(h, mine, init, 16, h->stream));
+    }
+    {
+        StageTimer t(h, h->stream, TM_GREEDY_STEPS);
+        launch_greedy_shard_init(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
+                                 h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), nsteps, start_state,
+                                 h->gprev.as<double>(), h->gsync.as<unsigned int>(), h->stream);
+        for (int64_t st = 0; st < nsteps; ++st) {
+            if (tile_n > 0)
+                launch_greedy_shard_step(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
+                                         h->wj.as<double>(), h->gtiles.as<float>(), h->Qraw.as<double>(), st, nsteps, tlo, tile_n,
+                                         h->gprev.as<double>(), h->gblkmin.as<double>(), h->gblkarg.as<int64_t>(), nblk, h->n_cus,
+                                         h->gsync.as<unsigned int>(), mine, h->stream);
+            CHK(comm_all_gather(h, mine, all, 16));
+            launch_greedy_shard_pick(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->wt.as<double>(), h->JC_unw.as<float>(), h->Jp, h->Dj,
+                                     h->wj.as<double>(), h->Qraw.as<double>(), st, nsteps, all, G, h->gprev.as<double>(),
+                                     h->gpath.as<int64_t>(), h->gdist.as<double>(), h->stream);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    {
+        StageTimer t(h, h->stream, TM_D2H);
+        D2HPart parts[2] = {{path_out, h->gpath.p, (size_t)nsteps * sizeof(int64_t)},
+                            {dist_out, h->gdist.p, dist_out ? (size_t)nsteps * sizeof(double) : 0}};
+        CHK(staged_d2h(h, h->stream, parts, 2));
+    }
+    collect_timers(h);
+    return 0;
+}

@@ -36,6 +36,11 @@ struct GreedyArgs {
     double hoist_c, fwmax2;
     // float16 copy of the join tiles (8 columns per 16 bytes, chunks of 64 columns) and the bound's term for it
     const f32x4 *JT16; int f16; double f16_delta;
+    // scan range of the exact step kernel in 64-window tiles (tile_n 0: every tile): a rank of snk_sharded_greedy scans its share
+    // of the windows; its winner then goes to shard_out ({float64 squared distance, int64 window}) instead of the path, and the
+    // next step's table is written by greedy_shard_pick_kernel once every rank's winner is there
+    int64_t tile_lo, tile_n;
+    double *shard_out;
 };
 #define GR_MAXU 2          // utterances per scan: one weight and the references share 32 table bytes per column
 

@@ -170,13 +170,16 @@ __device__ void greedy_finish_step(const GreedyArgs &a, int64_t step, int64_t ns
         }
         block_reduce(best, arg);
         winner[u] = red_i[0];
-        if (tid == 0 && u < a.nu && step < a.nsteps_u[u]) {
+        if (a.shard_out) {
+            // this rank's share of the windows only: the winner travels (greedy_shard_pick_kernel decides and writes the table)
+            if (tid == 0 && u == 0) { a.shard_out[0] = red_v[0]; reinterpret_cast<int64_t *>(a.shard_out)[1] = red_i[0]; }
+        } else if (tid == 0 && u < a.nu && step < a.nsteps_u[u]) {
             path[a.out_off[u] + step] = red_i[0];
             if (dist) dist[a.out_off[u] + step] = __dsqrt_rn(red_v[0]);
         }
         __syncthreads();
     }
-    if (step + 1 < nsteps) greedy_write_table<UB>(a, step + 1, winner, true, tab_next, tid, (int)blockDim.x);
+    if (!a.shard_out && step + 1 < nsteps) greedy_write_table<UB>(a, step + 1, winner, true, tab_next, tid, (int)blockDim.x);
 }
 
 // One step of the greedy search = ONE launch of a persistent grid: one workgroup of up to 8 wavefronts
@@ -243,7 +246,8 @@ greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__r
     constexpr int NSTG = (UB == 1) ? GR_NSTG : 2;
     const int table_bytes = n_chunks * GR_CC * TS * 8;
     float *const Fs = reinterpret_cast<float *>(lds + table_bytes) + (size_t)wave * (GR_W + a.me - 1) * pitch;
-    const int ntiles = (int)((a.Nwin + GR_W - 1) / GR_W);
+    const int ntiles = a.tile_n > 0 ? (int)a.tile_n : (int)((a.Nwin + GR_W - 1) / GR_W);       // (of this launch's range)
+    const int tile0 = (int)a.tile_lo;
     const int wave_id = blockIdx.x * nwaves + wave, wave_stride = gridDim.x * nwaves;
     const int my_tiles = wave_id < ntiles ? (ntiles - 1 - wave_id) / wave_stride + 1 : 0;
     const int total = my_tiles * ring_per_tile;          // ring chunks this wavefront consumes
@@ -260,7 +264,7 @@ greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__r
     const char *const FTb = reinterpret_cast<const char *>(a.FT), *const JTb = reinterpret_cast<const char *>(a.JT);
     f32x4 stage[NSTG][8];
     auto fetch = [&](f32x4 (&st)[8], int pin0) {
-        const int t = f_tile < ntiles ? f_tile : ntiles - 1;      // surplus request: re-read, never consumed
+        const int t = tile0 + (f_tile < ntiles ? f_tile : ntiles - 1);      // surplus request: re-read, never consumed
         const char *base;
         unsigned voff = off_own;
         if (in_lds) {
@@ -353,7 +357,7 @@ greedy_step_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__r
         }
     };
     auto end_of_window = [&]() {
-        const int64_t i = (int64_t)c_tile * GR_W + lane;
+        const int64_t i = (int64_t)(tile0 + c_tile) * GR_W + lane;
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const double d = __dadd_rn(acc_j[u], acc_t[u]);
@@ -662,6 +666,85 @@ void launch_greedy(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, co
     const int64_t zero = 0;
     launch_greedy_batch(g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, tiles, Q, 1, &zero, &nsteps, &zero, &start_state,
                         tables, blk_min, blk_arg, nblk, n_cus, arrive, path, dist, s);
+}
+
+// ---------------------------------------------------------------------------
+// snk_sharded_greedy: the scan of a step split over the ranks (every rank holds the whole database; a rank scans the windows
+// of its tiles [tile_lo, tile_lo + tile_n)), one all-gather of 16 bytes per rank and step, then every rank picks the same
+// winner -- smallest distance, lowest window on exact ties: what one scan over all windows returns -- and writes the next table.
+// ---------------------------------------------------------------------------
+__global__ void greedy_shard_pick_kernel(GreedyArgs a, int64_t step, int64_t nsteps, const double *__restrict__ gathered, int G,
+                                         double *__restrict__ tab_next, int64_t *__restrict__ path, double *__restrict__ dist)
+{
+    __shared__ int64_t win_s;
+    if (threadIdx.x == 0) {
+        double best = DBL_MAX;
+        int64_t arg = INT64_MAX;
+        for (int r = 0; r < G; ++r) {
+            const double v = gathered[2 * r];
+            const int64_t i = reinterpret_cast<const int64_t *>(gathered)[2 * r + 1];
+            if (v < best || (v == best && i < arg)) { best = v; arg = i; }
+        }
+        win_s = arg;
+        path[step] = arg;
+        if (dist) dist[step] = __dsqrt_rn(best);
+    }
+    __syncthreads();
+    const int64_t winner[1] = {win_s};
+    if (step + 1 < nsteps) greedy_write_table<1>(a, step + 1, winner, true, tab_next, threadIdx.x, blockDim.x);
+}
+
+int greedy_shard_blocks(const GreedyLayout &g, int Dt, int n_cus, int64_t tile_n)
+{
+    const int waves = greedy_waves(g, Dt, n_cus, 1);
+    const int64_t need = (tile_n + waves - 1) / waves;
+    return (int)(need < 1 ? 1 : need < n_cus ? need : n_cus);
+}
+
+// table of step 0 + counters (once per utterance)
+void launch_greedy_shard_init(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
+                              int Dj, const double *wj, const float *tiles, const double *Q, int64_t nsteps, int64_t start_state,
+                              double *tables, unsigned int *arrive, hipStream_t s)
+{
+    GreedyArgs a{};
+    fill_args(a, g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, Q, true, tiles);
+    a.lds_mode = greedy_lds_mode(g, Dt) ? 1 : 0;
+    a.nu = 1; a.nsteps_u[0] = nsteps;
+    hipLaunchKernelGGL(greedy_init_kernel<1>, dim3(1), dim3(256), 0, s, a, start_state, (int64_t)-1, (int64_t)-1, tables, arrive);
+}
+
+// one step of this rank's share: the local winner -> shard_out (16 bytes)
+void launch_greedy_shard_step(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
+                              int Dj, const double *wj, const float *tiles, const double *Q, int64_t step, int64_t nsteps,
+                              int64_t tile_lo, int64_t tile_n, double *tables, double *blk_min, int64_t *blk_arg, int nblk, int n_cus,
+                              unsigned int *arrive, double *shard_out, hipStream_t s)
+{
+    GreedyArgs a{};
+    fill_args(a, g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, Q, true, tiles);
+    a.lds_mode = greedy_lds_mode(g, Dt) ? 1 : 0;
+    a.nu = 1; a.nsteps_u[0] = nsteps;
+    a.tile_lo = tile_lo; a.tile_n = tile_n; a.shard_out = shard_out;
+    double *tab[2] = {tables, tables + greedy_table_doubles(g, Dt, 1)};
+    const int waves = greedy_waves(g, Dt, n_cus, 1);
+    const size_t lds = greedy_lds_bytes(g, Dt, waves, 1);
+    void (*kernel)(GreedyArgs, int64_t, int64_t, const double *, double *, double *, int64_t *, unsigned int *, int64_t *, double *) =
+        a.lds_mode ? greedy_step_kernel<true, 1> : greedy_step_kernel<false, 1>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3(nblk), dim3(GR_W * waves), lds, s, a, step, nsteps, tab[step & 1], tab[(step + 1) & 1], blk_min,
+                       blk_arg, arrive, (int64_t *)nullptr, (double *)nullptr);
+}
+
+// every rank's winner is there: path, distance, the next step's table
+void launch_greedy_shard_pick(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
+                              int Dj, const double *wj, const double *Q, int64_t step, int64_t nsteps, const double *gathered, int G,
+                              double *tables, int64_t *path, double *dist, hipStream_t s)
+{
+    GreedyArgs a{};
+    fill_args(a, g, F_unw, Fp, Dt, wt, JC_unw, Jp, Dj, wj, Q, true, nullptr);
+    a.lds_mode = greedy_lds_mode(g, Dt) ? 1 : 0;
+    a.nu = 1; a.nsteps_u[0] = nsteps;
+    double *tab[2] = {tables, tables + greedy_table_doubles(g, Dt, 1)};
+    hipLaunchKernelGGL(greedy_shard_pick_kernel, dim3(1), dim3(256), 0, s, a, step, nsteps, gathered, G, tab[(step + 1) & 1], path, dist);
 }
 
 // Persistent grid: one workgroup per compute unit (fewer when there are fewer tiles).

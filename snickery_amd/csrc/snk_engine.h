@@ -319,6 +319,7 @@ struct snk_engine {
     std::vector<double> tsel, jsel;       // snk_set_column_selection: 1 = column takes part (empty: all do)
     DevBuf tmask;                         // tsel on the device (query rows are masked after upload)
     DevBuf Dm, gprev, gblkmin, gblkarg, gpath, gdist, gsync, gtiles;
+    DevBuf gshard;            // snk_sharded_greedy: this rank's winner of a step (16 bytes) and the ranks' winners (16 bytes each)
     DevBuf g32_blk, g32_ctl;          // float32 persistent scan: block records + candidate lists, {gen, status}
     DevBuf g32_res;                   // resident scan (greedy_res_kernels.hip): one 16-byte record per workgroup
     int64_t greedy_last_status[16] = {0};   // status words of the most recent one-launch scan (undecided step + 1, rounds, exact windows, watchdog, ...)

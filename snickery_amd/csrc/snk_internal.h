@@ -268,6 +268,18 @@ void launch_greedy_batch(const GreedyLayout &g, const float *F_unw, int Fp, int 
                          const int64_t *start, double *tables, double *blk_min,
                          int64_t *blk_arg, int nblk, int n_cus, unsigned int *arrive, int64_t *path, double *dist, hipStream_t s);
 size_t greedy_counter_bytes();
+// snk_sharded_greedy (greedy_kernels.hip): a rank's share of a step's scan, then the pick among the ranks' winners
+int greedy_shard_blocks(const GreedyLayout &g, int Dt, int n_cus, int64_t tile_n);
+void launch_greedy_shard_init(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
+                              int Dj, const double *wj, const float *tiles, const double *Q, int64_t nsteps, int64_t start_state,
+                              double *tables, unsigned int *arrive, hipStream_t s);
+void launch_greedy_shard_step(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
+                              int Dj, const double *wj, const float *tiles, const double *Q, int64_t step, int64_t nsteps,
+                              int64_t tile_lo, int64_t tile_n, double *tables, double *blk_min, int64_t *blk_arg, int nblk, int n_cus,
+                              unsigned int *arrive, double *shard_out, hipStream_t s);
+void launch_greedy_shard_pick(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const double *wt, const float *JC_unw, int Jp,
+                              int Dj, const double *wj, const double *Q, int64_t step, int64_t nsteps, const double *gathered, int G,
+                              double *tables, int64_t *path, double *dist, hipStream_t s);
 // lane-major copy of the scan columns (built once per database + layout, read by the scan)
 size_t greedy_tile_bytes(const GreedyLayout &g, int Dt);
 void launch_greedy_tiles(const GreedyLayout &g, const float *F_unw, int Fp, int Dt, const float *JC_unw, int Jp,

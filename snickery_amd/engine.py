@@ -68,6 +68,8 @@ _SIGNATURES = {
     'snk_set_greedy_layout': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'snk_greedy': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
                                   ctypes.c_double, _c_i64p, _c_f64p, _c_i64p]),
+    'snk_sharded_greedy': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
+                                          _c_i64p, _c_f64p, ctypes.POINTER(ctypes.c_int64)]),
     'snk_path_scores': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, _c_i64p, ctypes.c_int64, ctypes.c_int,
                                        _c_f64p, _c_f64p]),
     'snk_get_timers': (ctypes.c_int, [ctypes.c_void_p, _c_f64p, ctypes.c_int]),
@@ -564,6 +566,21 @@ class HipSearchEngine(object):
         """Every s-th unit of the WHOLE database (replicated on every rank); before set_weights."""
         S = np.ascontiguousarray(sample_unweighted, dtype=np.float32)
         self._check(self._lib.snk_upload_global_sample(self._h, _ptr(S, _c_f32p), S.shape[0], S.shape[1]))
+
+    def sharded_greedy(self, unit_features, start_state=-1, return_distances=False):
+        """snk_sharded_greedy: greedy_joint_search with every step's scan split over the ranks of the communicator (every rank
+        holds the whole database and passes the same arguments); the whole path on every rank."""
+        Q = _f64(unit_features)
+        T, D = Q.shape
+        path = np.empty((max(T, 1),), dtype=np.int64)
+        dist = np.empty((max(T, 1),), dtype=np.float64)
+        n = ctypes.c_int64(0)
+        self._check(self._lib.snk_sharded_greedy(self._h, _ptr(Q, _c_f64p), T, D, int(start_state), _ptr(path, _c_i64p),
+                                                 _ptr(dist, _c_f64p), ctypes.byref(n)))
+        p = [int(v) for v in path[:n.value]]
+        if return_distances:
+            return p, dist[:n.value].copy()
+        return p
 
     def sharded_knn_viterbi_batch(self, utterances, n_candidates):
         """snk_sharded_knn_viterbi_batch: every rank passes the same batch; returns the paths and costs of

@@ -194,6 +194,56 @@ def test_library_collectives_three_ranks_one_gpu():
     assert out[0] is True and out[1] is True and out[2] is True
 
 
+def _greedy_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import snk_oracle as o
+    import snickery_amd
+    from snickery_amd.dist import gloo_transport
+    torch.cuda.set_device(0)
+    ok = True
+    # (units, Dt, Dj, multiepoch, last_frame_as_target, join_split_mode): several tiles per rank, a last tile that is not full,
+    # fewer tiles than ranks (130 units: three tiles of 64 windows at me = 1 -- two at me = 6 -- for three ranks)
+    for N, Dt, Dj, me, lfat, mode in ((5000, 61, 151, 6, False, 0), (3001, 61, 40, 1, False, 1), (130, 20, 16, 6, True, 0), (4097, 90, 33, 3, False, 0)):
+        F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=me + Dj)
+        wt = np.full(Dt, 0.4); wj = np.full(Dj, 0.05)
+        F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
+        # a few exact duplicates of units in different ranks' shares: ties of the distance across ranks (lowest window wins)
+        if N >= 3000:
+            F_unw[N - 200:N - 190] = F_unw[100:110]; JC_unw[N - 200:N - 189] = JC_unw[100:111]
+            F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
+        eng = snickery_amd.HipSearchEngine(0)
+        eng.upload_db(F_unw, JC_unw); eng.set_weights(wt, wj)
+        eng.set_greedy_layout(me, lfat, mode)
+        eng.comm_init_transport(world, rank, gloo_transport(world))
+        pr, cr, Fwin = o.greedy_layout(F, E, S, me, lfat, mode)
+        for T, start in ((63, -1), (40, 17), (me, -1), (max(me - 1, 1), -1)):
+            U = o.synthetic_targets(F_unw, T, seed=9 + T) * wt
+            if N >= 3000 and T == 63: U[:me * 3] = (F_unw[100:100 + me * 3] * wt)          # the duplicated units' own rows
+            path, d = eng.sharded_greedy(U, start_state=start, return_distances=True)
+            op, od = o.greedy_search(pr, cr, Fwin, o.greedy_queries(U, me, lfat), start_state=start)
+            sp, sd = eng.greedy(U, start_state=start, return_distances=True)
+            ok = ok and path == op and np.array_equal(d, od) and path == sp and np.array_equal(d, sd)
+        eng.close()
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_greedy_ranks_on_one_gpu(world):
+    """snk_sharded_greedy: every step's scan split over the ranks (each scans the windows of its tiles), one all-gather of the
+    ranks' winners per step; the path and the distances equal the oracle's and snk_greedy's bit for bit."""
+    port = 29500 + ((os.getpid() + 7 * world) % 2000)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_greedy_worker, args=(world, port, out), nprocs=world, join=True)
+    assert all(out[r] is True for r in range(world))
+
+
 def test_library_rccl_communicator_single_rank():
     """The RCCL transport itself, as far as one GPU allows: ncclCommInitRank with one rank, then the
     sharded entry point (its collectives degenerate to copies) against the unsharded search."""
