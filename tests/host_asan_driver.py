@@ -74,7 +74,22 @@ for mode in (0, 1, 2):
         e.knn_viterbi(U, 12)
 e.set_option('viterbi_weights', 1)
 e.viterbi(c2, d2)
+e.set_option('viterbi_fst32_slack', 5e-7); assert e.info('viterbi_fst32_slack') == 5e-7
+e.knn_viterbi(U, 12)
+assert refused(e.set_option, 'viterbi_fst32_slack', 1.0)
 e.set_option('viterbi_weights', 0)
+# round 5's options and infos: the ladder, the latches, the engine's own order, the tripwires
+for name, val in (('reorder', 0), ('reorder', 1), ('reorder_iterations', 2), ('latch_rearm', 0), ('latch_rearm', 1),
+                  ('viterbi_latch', 0), ('viterbi_latch', 1), ('viterbi_refine_gate', 0.02), ('join_lb_test_scale', 1.0)):
+    e.set_option(name, val)
+assert refused(e.set_option, 'viterbi_refine_gate', 2.0)
+for name in ('knn_level', 'knn_escalations', 'join_bound_violations', 'join_bound_min_margin', 'greedy_bound_violations',
+             'greedy_bound_max_used', 'filter_rearms', 'filter_probe_period', 'viterbi_latch_mode', 'viterbi_latch_switches',
+             'reordered', 'reorders', 'reorder_useless', 'reorder_radius_before', 'reorder_radius_after', 'viterbi_refine_gate'):
+    e.info(name)
+e.set_option('reorder_now', 1)               # the engine's own order at the next K-NN call (no-op kernels: host logic and sizes)
+e.knn(U, 12)
+e.knn_viterbi_batch([U, U[:9]], 12)
 assert refused(e.viterbi, c2, d2[:5])
 assert refused(e.join_costs, c2[:1])
 assert refused(e.join_bounds, c2[:1])
@@ -184,9 +199,22 @@ assert refused(e3.sharded_knn_viterbi_batch_submit, utts, 10)
 assert refused(e3.knn_viterbi_batch_submit, utts, 10)                   # a sharded step is in flight
 e3.sharded_knn_viterbi_batch_collect(s0)
 e3.sharded_knn_viterbi_batch_collect(s1)
+assert refused(e3.sharded_greedy, rng.randn(12, Dt))                    # this engine holds a shard
 e3.comm_destroy()
 assert refused(e3.sharded_knn_viterbi_batch, utts, 10)
 e3.close()
+# the greedy search with every step's scan split over the ranks: whole database on the rank, one all-gather per step
+e4 = snickery_amd.HipSearchEngine(0)
+e4.upload_db(F, JC); e4.set_weights(wt, wj)
+assert refused(e4.sharded_greedy, rng.randn(12, Dt))                    # no communicator, no layout
+e4.comm_init_transport(2, 1, tr)
+assert refused(e4.sharded_greedy, rng.randn(12, Dt))                    # no layout
+e4.set_greedy_layout(3, False, 0)
+n_ag = calls.count('ag')
+e4.sharded_greedy(rng.randn(12, Dt), return_distances=True)
+assert calls.count('ag') == n_ag + 4                                    # one all-gather per step
+e4.sharded_greedy(rng.randn(2, Dt))                                     # shorter than one window: no step
+e4.close()
 
 # ---- waveform-side gather ----
 H = 9
