@@ -772,11 +772,14 @@ def main():
                 'traffic': jtraffic, 'traffic_source': jsrc, 'profiled_reference': jref,
                 'avg_launch_ms': javg, 'launches': jl, 'rows_per_launch': jrows, 'algorithmic_bytes_per_launch': jbytes,
                 'flops_per_launch': jfl, 'mfma_tflops': jfl / (javg * 1e-3) / 1e12,
-                'rule': 'the whole-chip kernel with the largest total time under rocprofv3 (profiles/r04_*_kernel_stats.csv; the largest of all is a '
+                'rule': 'the whole-chip kernel with the largest total time under rocprofv3 (profiles/r05_d_kernel_stats.csv; the largest of all is a '
                         'latency chain on 16 workgroups: `largest_total_time_kernel`); timed here with '
                         'HIP events on the stream it is launched on, inside the timed region, while the K-NN of the next group shares the chip',
                 'note': 'algorithmic bytes per SURVEY 8d: every candidate row gathered once per row pair (2 K rows of Dj float32) + K^2 float32 bounds; '
-                        'rows that consecutive steps share are served from L2, so `traffic` lies below them'}
+                        'rows that consecutive steps share are served from L2, so `traffic` lies below them',
+                'what_bounds_it': 'the vector-issue port, not HBM (DESIGN.md 4.3, ablations on this chip: 0.50 ms per launch as built, 0.34 with '
+                                  'every gather replaced by a constant, 0.45 without its MFMAs; unchanged by an XCD-aware row order): 93 vector '
+                                  'instructions + 12 MFMAs per k-block and wavefront -- `frac` is the share of a ceiling the kernel does not touch'}
             if 'viterbi_sparse' in timers and timers['viterbi_sparse'][1]:
                 # the kernel with the largest TOTAL time in the stats is not a whole-chip one: said here, with its own figures
                 vms, vl = timers['viterbi_sparse']

@@ -678,6 +678,8 @@ join_exact_sparse2_kernel(const float *__restrict__ JC_unw, int Jp, int Dj, cons
     const int g4 = lane >> 2, q = lane & 3;                 // loader role: rows 4 g4 + i, columns 4 q .. 4 q + 3 of the chunk
     float *const tE = tile[wv][0], *const tS = tile[wv][1];
     for (int r0 = 0; r0 < total; r0 += JX_T) {
+        // (a wavefront loads and sums for its own 64 items: one without items has nothing to do)
+        if (r0 + 64 * wv >= total) continue;
         // this lane's cost
         const int it = r0 + tid;
         const bool have = it < total;
