@@ -95,11 +95,11 @@ __device__ __forceinline__ void jf_split2(float y0, float y1, unsigned int &hi, 
     lo = __builtin_bit_cast(unsigned int, __builtin_convertvector(rr, jf_bf16x2));
 }
 
-template <int KT>
+template <int KT, bool QUAD>
 __global__ void __launch_bounds__(64 * KT, 2)
 join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned int *__restrict__ umax_bits, float ceps,
                 int64_t n_units, const int64_t *__restrict__ cand, int K, float *__restrict__ Jlo,
-                float *__restrict__ scale_out)
+                float *__restrict__ scale_out, int Kq)
 {
     constexpr bool TWO = KT <= 4;                             // accumulators of their own for the cross terms
     constexpr int PF = (KT <= 3) ? 3 : 2;                     // k-blocks in flight
@@ -112,8 +112,14 @@ join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned i
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row32 = lane & 31, half = lane >> 5;
     const int kk = wave * 32 + row32;
-    const int64_t idE = kk < K ? cand[r * K + kk] : -1;
-    const int64_t idS = kk < K ? cand[(r + 1) * K + kk] : -1;
+    // Kq > 0 (K > 128): the K x K matrix of a step in 2 x 2 QUADRANTS of Kq x Kq, one workgroup each (blockIdx.y): E rows
+    // e0 .. e0 + Ke - 1 against S rows s0 .. s0 + Ks - 1, the step's reference row the same for all four.  Four workgroups of
+    // four wavefronts with two accumulator sets each (the tighter bound) instead of one of seven with one set that leaves a
+    // compute unit no room for a second workgroup, at twice the pieces split (join_lb2_quadrant below: when it pays).
+    const int e0 = QUAD ? (int)(blockIdx.y >> 1) * Kq : 0, s0 = QUAD ? (int)(blockIdx.y & 1) * Kq : 0;
+    const int Ke = QUAD ? (K - e0 < Kq ? K - e0 : Kq) : K, Ks = QUAD ? (K - s0 < Kq ? K - s0 : Kq) : K;
+    const int64_t idE = kk < Ke ? cand[r * K + e0 + kk] : -1;
+    const int64_t idS = kk < Ks ? cand[(r + 1) * K + s0 + kk] : -1;
     const int64_t id0 = cand[(r + 1) * K];
     const bool okE = jf2_usable(idE, n_units), okS = jf2_usable(idS, n_units);
     const float *const pE = JW + (okE ? idE + 1 : 0) * (int64_t)Jq + 8 * half;      // unit_end_data[a]   = JC[a+1]
@@ -232,12 +238,12 @@ join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned i
         const float clo = __builtin_fmaxf(__builtin_fmaf(-c24, sev[i] + ssv, sq), 0.f);
         return __builtin_fmaxf(__builtin_fmaxf(clo, pev[i]), psv);           // an unusable unit on either side: +inf
     };
-    if (wave * 32 + 32 <= K) {                                // uniform: every row of this wavefront's tile exists
+    if (wave * 32 + 32 <= Ke) {                               // uniform: every row of this wavefront's tile exists
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
             const int k = j * 32 + row32;                       // column of the result = S row
             const float nsv = ns_s[k], ssv = sns_s[k], psv = pns_s[k];
-            const int voff = k < K ? ((wave * 32 + 4 * half) * K + k) * 4 : 0x7ffffffc;
+            const int voff = k < Ks ? ((e0 + wave * 32 + 4 * half) * K + s0 + k) * 4 : 0x7ffffffc;
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, cell(j, i, nsv, ssv, psv)), ores, voff,
@@ -252,32 +258,53 @@ join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned i
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int kp0 = wave * 32 + (i & 3) + 8 * (i >> 2);
-            if (kp0 >= K) continue;
+            if (kp0 >= Ke) continue;
             const int kp = kp0 + 4 * half;
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
                 const int k = j * 32 + row32;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, cell(j, i, nsv[j], ssv[j], psv[j])), ores,
-                                                      (kp < K && k < K) ? (kp * K + k) * 4 : 0x7ffffffc, 0, 0);
+                                                      (kp < Ke && k < Ks) ? ((e0 + kp) * K + s0 + k) * 4 : 0x7ffffffc, 0, 0);
             }
         }
     }
-    if (tid == 0) scale_out[r] = __builtin_amdgcn_sqrtf(__int_as_float(smax_bits)) * 1.000001f;
+    if (tid == 0) {
+        const float sc = __builtin_amdgcn_sqrtf(__int_as_float(smax_bits)) * 1.000001f;
+        if (QUAD) atomicMax(reinterpret_cast<unsigned int *>(scale_out) + r, __float_as_uint(sc));      // (zeroed before the launch; non-negative floats order like their bits)
+        else scale_out[r] = sc;
+    }
 }
 
 template <int KT>
 static void launch_join_lb2_t(const float *JW, int Jq, int n_kb, const unsigned int *umax_bits, float ceps, int64_t n_units,
-                              const int64_t *cand, int64_t R, int K, float *Jlo, float *scale, hipStream_t s)
+                              const int64_t *cand, int64_t R, int K, float *Jlo, float *scale, hipStream_t s, int Kq)
 {
-    hipLaunchKernelGGL((join_lb2_kernel<KT>), dim3((unsigned)(R - 1)), dim3(64 * KT), 0, s, JW, Jq, n_kb, umax_bits, ceps, n_units,
-                       cand, K, Jlo, scale);
+    if (Kq > 0) {
+        if constexpr (KT <= 4)
+            hipLaunchKernelGGL((join_lb2_kernel<KT, true>), dim3((unsigned)(R - 1), 4u), dim3(64 * KT), 0, s, JW, Jq, n_kb, umax_bits, ceps,
+                               n_units, cand, K, Jlo, scale, Kq);
+        return;
+    }
+    hipLaunchKernelGGL((join_lb2_kernel<KT, false>), dim3((unsigned)(R - 1), 1u), dim3(64 * KT), 0, s, JW, Jq, n_kb, umax_bits, ceps,
+                       n_units, cand, K, Jlo, scale, 0);
 }
+
+// rows of a quadrant (0: the matrix in one piece).  Process-wide switch, option join_lb_quadrants (default 0).  Measured at B4
+// (1.5 M units, K 200, 32 utterances per step): the pass 2.97 -> 2.2 ms per launch and, with the two accumulator sets' tighter
+// bounds, half the refinements in pass 4 (8.8 -> 6.0 ms per step) -- but inside the batch pipeline the K-NN stream's persistent
+// sweeps no longer find room beside four times as many workgroups of 246 registers (stage A 0.5 -> 2 ms per launch) and the step
+// as a whole gets slower (9.2 -> 10.2 ms): on for callers that run the Viterbi side alone, off where the K-NN runs beside it.
+static int g_quadrants = 0;
+void set_join_lb_quadrants(int q) { g_quadrants = q ? 1 : 0; }
+int get_join_lb_quadrants() { return g_quadrants; }
+static int join_lb2_quadrant(int K) { return (g_quadrants && K > 128) ? (K + 1) / 2 : 0; }
 
 double join_lb2_ceps(int Dj, int K)
 {
     const double n_kb = (double)(join_lb2_pitch(Dj) / 16);
     const double u24 = 5.9604644775390625e-08, u20 = 9.5367431640625e-07, u18 = 3.814697265625e-06;
-    const bool two = (K + 31) / 32 <= 4;
+    const int Kt = join_lb2_quadrant(K) > 0 ? join_lb2_quadrant(K) : K;
+    const bool two = (Kt + 31) / 32 <= 4;
     const double acc = two ? (n_kb + 1.0) * u20 + (2.0 * n_kb + 1.0) * u20 / 256.0 + u24 : (3.0 * n_kb + 1.0) * u20;
     const double cg = 1.02 * (3.02 * u18 + acc);
     const double gam = (n_kb + 12.0) * u24;
@@ -290,8 +317,10 @@ void launch_join_lb2(const float *JW, int Dj, const unsigned int *umax_bits, int
     if (R < 2) return;
     const int Jq = join_lb2_pitch(Dj), n_kb = Jq / 16;
     const float ceps = (float)join_lb2_ceps(Dj, K);
-    const int kt = (K + 31) / 32;
-#define SNK_JLB2(KT_) launch_join_lb2_t<KT_>(JW, Jq, n_kb, umax_bits, ceps, n_units, cand, R, K, Jlo, scale, s)
+    const int Kq = join_lb2_quadrant(K);
+    const int kt = ((Kq > 0 ? Kq : K) + 31) / 32;
+    if (Kq > 0) (void)hipMemsetAsync(scale, 0, (size_t)(R - 1) * sizeof(float), s);       // the quadrants' workgroups take the maximum
+#define SNK_JLB2(KT_) launch_join_lb2_t<KT_>(JW, Jq, n_kb, umax_bits, ceps, n_units, cand, R, K, Jlo, scale, s, Kq)
     switch (kt) {
     case 1: SNK_JLB2(1); break;
     case 2: SNK_JLB2(2); break;

@@ -239,6 +239,8 @@ void launch_scale_f32(float *x, int64_t n, float f, hipStream_t s);      // test
 void launch_join_exact_sparse(const float *JC_unw, int Jp, int Dj, const double *wj, int64_t n_units, const int64_t *cand,
                               const double *tdist, int64_t R, int K, const void *sets, void *rec, hipStream_t s,
                               const float *Jlo = nullptr, const float *scale = nullptr, float ceps = 0.f, unsigned long long *stats = nullptr);
+void set_join_lb_quadrants(int q);         // 1: pass 1 of K > 128 as 2 x 2 quadrants (joinlb2_kernels.hip); 0 (default): one workgroup per row pair
+int get_join_lb_quadrants();
 void set_join_exact_form(int f);           // 1 (default): cooperative pass 3 (rows in coalesced chunks through LDS); 0: a lane per cell
 void set_viterbi_sparse_waves(int w);      // 1 (default) or 4: which form of pass 4 launch_viterbi_sparse runs (same results)
 void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jlo, const float *JC_unw, int Jp, int Dj,

@@ -72,6 +72,40 @@ def test_bounds_are_lower_bounds_of_the_exact_join_costs(engine, N, Dj, T, K, of
         assert tight[1] >= 0.9 * tight[0] - 0.02, tight
 
 
+@pytest.mark.parametrize('K', [129, 160, 200, 208])
+def test_quadrants_of_wide_candidate_sets(engine, K):
+    """Option join_lb_quadrants: pass 1 of K > 128 as 2 x 2 quadrants (four workgroups of four wavefronts with two accumulator
+    sets instead of one of seven with one): still lower bounds, +inf in the same cells, the same scale of the step, at least as
+    tight; the search through them returns what the dense recursion returns."""
+    N, Dj, T = 9000, 302, 14
+    cand = _case(engine, N, Dj, T, K, seed=K)
+    J = engine.join_costs(cand)
+    fin = np.isfinite(J)
+    res = {}
+    try:
+        for q in (0, 1):
+            engine.set_option('join_lb_quadrants', q)
+            assert engine.info('join_lb_quadrants') == q
+            lo, sc = engine.join_bounds(cand)
+            assert np.array_equal(np.isinf(lo), ~fin)
+            l64 = lo.astype(np.float64)
+            assert (l64[fin] >= 0).all() and not (l64[fin] > J[fin]).any(), q
+            res[q] = (l64, sc)
+        assert np.array_equal(res[0][1], res[1][1])                 # the step's scale: the maximum over the quadrants
+        gap0, gap1 = (J[fin] - res[0][0][fin]).mean(), (J[fin] - res[1][0][fin]).mean()
+        assert gap1 <= gap0 * 1.001, (gap0, gap1)                   # two accumulator sets: the smaller error constant
+        rng = np.random.RandomState(K)
+        td = np.sort(rng.rand(T, K), axis=1)
+        engine.set_option('viterbi_mode', 0)
+        ref = engine.viterbi(cand, td)
+        engine.set_option('viterbi_mode', 1)
+        assert engine.viterbi(cand, td) == ref
+        assert engine.info('join_bound_violations') == 0
+    finally:
+        engine.set_option('join_lb_quadrants', 0)
+        engine.set_option('viterbi_mode', 2)
+
+
 def test_natural_successors_and_repeated_calls(engine):
     """b = a + 1 joins at exactly 0.0: the bound of such a cell must be 0; a second call after new weights rebuilds the copy."""
     N, Dj, K = 5000, 151, 20
