@@ -191,7 +191,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
         {
             StageTimer t(h, s, TM_KNN_BUCKET);
             launch_knn_bucket(h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, Tpad, h->N, h->cnt.as<int>(),
-                              h->lkey.as<double>(), h->lidx.as<int>(), cap, h->status.as<int>(), s);
+                              h->lkey.as<double>(), h->lidx.as<int>(), cap, h->status.as<int>(), s, nullptr, true);
         }
         {
             StageTimer t(h, s, TM_KNN_FINALIZE);
@@ -488,7 +488,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
             StageTimer t(h, s, TM_KNN_BUCKET);
             launch_knn_bucket(h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
                               Tpad, h->N, h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap, status_dev, s,
-                              h->perm_ready ? h->perm.as<int32_t>() : nullptr);
+                              h->perm_ready ? h->perm.as<int32_t>() : nullptr, true);
         }
         if (refine && bound_in && h->comm_ranks > 1 && h->shard_refine) {
             StageTimer t(h, s, TM_KNN_BUCKET);

@@ -30,7 +30,10 @@ namespace snk {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f16acc __attribute__((ext_vector_type(16)));
 
-struct __attribute__((aligned(16))) PoolEntry16 { double key; int idx; int row; };   // == PoolEntry
+// PoolEntry's 16 bytes with the key as the float32 the matrix pipe produced (low half of PoolEntry's float64 key field, the high
+// half unused): knn_bucket_kernel converts (keys_f32) -- a v_cvt_f64_f32 per tested result is an 8-cycle instruction on the issue
+// port the survivors' path of these kernels is bound by, the bucket's eight per thread are not
+struct __attribute__((aligned(16))) PoolEntry16 { float key; int unused; int idx; int row; };
 
 // C/D layout of the 32x32 f32 MFMA results: lane l holds column (l & 31) and, in register r, row
 //   (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
@@ -359,7 +362,7 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
                                         const int rank = __builtin_amdgcn_mbcnt_hi(
                                             (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                                         PoolEntry16 en;
-                                        en.key = (double)key;
+                                        en.key = key; en.unused = 0;
                                         en.idx = (int)((w * NT + pnt + j) * 32 + crow32(lane, r));
                                         en.row = pqt * 32 + qcol;
                                         stage[wv][lcount + rank] = en;
@@ -405,7 +408,7 @@ knn_sweep16(const f32x4 *__restrict__ A32, const f32x4 *__restrict__ B32,
                     if (pass) {
                         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                         PoolEntry16 en;
-                        en.key = (double)key;
+                        en.key = key; en.unused = 0;
                         en.idx = (int)((w * NT + (NSTEP - 1) * CH + j) * 32 + crow32(lane, r));
                         en.row = qt_prev * 32 + qcol;
                         stage[wv][lcount + rank] = en;
@@ -806,7 +809,7 @@ knn_sweep16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, const
                             if (pass) {
                                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
                                 PoolEntry16 en;
-                                en.key = (double)key;
+                                en.key = key; en.unused = 0;
                                 en.idx = wb + ib + (pt * 32 + crow32(0, r0 + q));
                                 en.row = pq * 32 + qcol;
                                 stage[wv][lcount + rank] = en;
@@ -1223,7 +1226,7 @@ knn_refine16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, cons
                 if (pass) {
                     const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
                     PoolEntry16 en;
-                    en.key = (double)key;
+                    en.key = key; en.unused = 0;
                     en.idx = (int)(pr.tile * 32u) + crow32(lane, r);
                     en.row = (int)(pr.qtile * 32u) + qcol;
                     stage[wv][lcount + rank] = en;
@@ -2000,7 +2003,7 @@ knn_wide16b(const u32x4 *__restrict__ A16, const u32x4 *__restrict__ B16, int KB
                         if (pass) {
                             const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
                             PoolEntry16 en;
-                            en.key = (double)key;
+                            en.key = key; en.unused = 0;
                             en.idx = (int)(tile * 32) + crow32(lane, r);
                             en.row = qt * 32 + qcol;
                             stage[wv][lcount + rank] = en;

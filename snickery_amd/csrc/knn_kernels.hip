@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(256)
 knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__restrict__ pool_ctl,
                   const int *__restrict__ chunk_fill, int max_chunks, int Tpad, int n_valid, int *__restrict__ cnt,
                   double *__restrict__ lkey, int *__restrict__ lidx, int cap, int *__restrict__ status,
-                  const int32_t *__restrict__ perm)
+                  const int32_t *__restrict__ perm, int keys_f32)
 {
     // per chunk: LDS histogram by row -> one global atomic per (chunk, row) reserves a run of
     // list slots -> entries of one row land contiguously.
@@ -523,7 +523,9 @@ knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__rest
             if (e < n && rank[k] >= 0) {
                 const int slot = base[hist16[en[k].row]] + rank[k];
                 if (slot < cap) {
-                    lkey[(int64_t)en[k].row * cap + slot] = en[k].key;
+                    // (keys_f32: the entry's key field holds the prefilter's float32 key in its low half -- knn16_kernels.hip PoolEntry16)
+                    lkey[(int64_t)en[k].row * cap + slot] =
+                        keys_f32 ? (double)__uint_as_float((unsigned int)(unsigned long long)__double_as_longlong(en[k].key)) : en[k].key;
                     // (a reordered operand -- kmeans_kernels.hip -- hands out positions: everything behind this line sees unit ids)
                     lidx[(int64_t)en[k].row * cap + slot] = perm ? perm[en[k].idx] : en[k].idx;
                 }
@@ -539,7 +541,7 @@ knn_bucket_kernel(const PoolEntry *__restrict__ pool, const unsigned int *__rest
 
 void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int *chunk_fill,
                        int max_chunks, int64_t Tpad, int64_t n_valid, int *cnt, double *lkey, int *lidx,
-                       int cap, int *status, hipStream_t s, const int32_t *perm)
+                       int cap, int *status, hipStream_t s, const int32_t *perm, bool keys_f32)
 {
     static size_t attr[32] = {0};
     const size_t lds = (size_t)((Tpad + 1) / 2) * sizeof(int) + (size_t)POOL_CHUNK * sizeof(int);
@@ -551,7 +553,7 @@ void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int
     per_cu = per_cu < 1 ? 1 : per_cu > 6 ? 6 : per_cu;
     hipLaunchKernelGGL(knn_bucket_kernel, dim3(256 * per_cu), dim3(256), lds, s,
                        reinterpret_cast<const PoolEntry *>(pool), pool_ctl, chunk_fill, max_chunks,
-                       (int)Tpad, (int)n_valid, cnt, lkey, lidx, cap, status, perm);
+                       (int)Tpad, (int)n_valid, cnt, lkey, lidx, cap, status, perm, keys_f32 ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------

@@ -98,7 +98,8 @@ void launch_knn_reset(int *cnt, int64_t Tpad, int *status, unsigned int *pool_ct
                       unsigned int *slab_counter, int *chunk_fill, int max_chunks, hipStream_t s);
 void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int *chunk_fill,
                        int max_chunks, int64_t Tpad, int64_t n_valid, int *cnt, double *lkey, int *lidx,
-                       int cap, int *status, hipStream_t s, const int32_t *perm = nullptr);     // perm: the entries carry POSITIONS of a reordered operand
+                       int cap, int *status, hipStream_t s, const int32_t *perm = nullptr,      // perm: the entries carry POSITIONS of a reordered operand
+                       bool keys_f32 = false);                                                  // the entries' keys are float32 (the knn16_kernels.hip filters)
 // stage C: per-row select + exact re-rank in canonical order + sort
 void launch_knn_exact_rows(const double *Fw, int Dpad, int D, int64_t N, const double *Qp, const int *rows,
                            int n_rows, int K, double *scratch, int64_t scratch_pitch, const int32_t *unit_class,
