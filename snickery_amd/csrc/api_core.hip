@@ -265,6 +265,7 @@ int snk_destroy(snk_handle h)
     for (int i = 0; i < 4; ++i) { if (h->vit_t0[i]) (void)hipEventDestroy(h->vit_t0[i]); if (h->vit_t1[i]) (void)hipEventDestroy(h->vit_t1[i]); }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->knn_all_done) (void)hipEventDestroy(h->knn_all_done);
+    if (h->knn_mid) (void)hipEventDestroy(h->knn_mid);
     for (auto &t : h->sticket) {
         t.mcand.release(); t.mdist.release(); t.res_path.release(); t.res_plen.release(); t.res_cost.release(); t.status.release();
         t.stage.release(); t.qstage.release();
@@ -272,7 +273,7 @@ int snk_destroy(snk_handle h)
         if (t.main_done) (void)hipEventDestroy(t.main_done);
         for (int i = 0; i < 2; ++i) if (t.side_done[i]) (void)hipEventDestroy(t.side_done[i]);
     }
-    for (auto &b : h->bslot) { b.Qall.release(); b.cand.release(); b.dist.release(); b.path.release(); b.plen.release(); b.cost.release(); b.status.release(); b.stage.release(); b.qstage.release(); if (b.done) (void)hipEventDestroy(b.done); }
+    for (auto &b : h->bslot) { b.Qall.release(); b.cand.release(); b.dist.release(); b.path.release(); b.plen.release(); b.cost.release(); b.status.release(); b.stage.release(); b.qstage.release(); if (b.done) (void)hipEventDestroy(b.done); if (b.knn_end) (void)hipEventDestroy(b.knn_end); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     delete h;

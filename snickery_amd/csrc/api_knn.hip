@@ -405,6 +405,12 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
                                    want_thr1 ? h->thr1_32.as<float>() : nullptr, ball_bound ? h->ball_bound.as<double>() : nullptr);
         }
         if (bound_out) return 0;             // stage A only
+        h->knn_mid_recorded = false;
+        if (h->join_bounds_delay == 1 && deferred_status) {
+            if (!h->knn_mid) HIPCHK(hipEventCreateWithFlags(&h->knn_mid, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(h->knn_mid, s));
+            h->knn_mid_recorded = true;
+        }
         {
             StageTimer t(h, s, TM_KNN_FILTER);
             if (coarse) {
@@ -489,6 +495,11 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
             launch_knn_bucket(h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks,
                               Tpad, h->N, h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap, status_dev, s,
                               h->perm_ready ? h->perm.as<int32_t>() : nullptr, true);
+        }
+        if (h->join_bounds_delay == 2 && deferred_status) {
+            if (!h->knn_mid) HIPCHK(hipEventCreateWithFlags(&h->knn_mid, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(h->knn_mid, s));
+            h->knn_mid_recorded = true;
         }
         if (refine && bound_in && h->comm_ranks > 1 && h->shard_refine) {
             StageTimer t(h, s, TM_KNN_BUCKET);

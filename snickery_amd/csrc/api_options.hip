@@ -227,6 +227,10 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0) return fail("join_bounds_stream must be 0 (main stream) or 1 (side stream of the group)");
         CHK(no_batch_in_flight(h, "snk_set_option(join_bounds_stream)"));
         h->join_bounds_stream = (int)value;
+    } else if (!strcmp(name, "join_bounds_delay")) {
+        if (value != 0.0 && value != 1.0 && value != 2.0) return fail("join_bounds_delay must be 0, 1 or 2");
+        CHK(no_batch_in_flight(h, "snk_set_option(join_bounds_delay)"));
+        h->join_bounds_delay = (int)value;
     } else if (!strcmp(name, "join_lb_quadrants")) {
         if (value != 0.0 && value != 1.0) return fail("join_lb_quadrants must be 0 or 1");
         CHK(no_batch_in_flight(h, "snk_set_option(join_lb_quadrants)"));
@@ -384,6 +388,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "viterbi_latch")) *out = h->viterbi_latch;
     else if (!strcmp(name, "viterbi_fst32_slack")) *out = h->fst32_slack;
     else if (!strcmp(name, "join_lb_quadrants")) *out = get_join_lb_quadrants();
+    else if (!strcmp(name, "join_bounds_delay")) *out = h->join_bounds_delay;
     else if (!strcmp(name, "viterbi_refine_gate")) *out = h->vit_refine_gate;
     else if (!strcmp(name, "viterbi_latch_mode")) *out = h->vit.mode;                 // 0: batches take the sparse path, 1: the dense kernels (judged, snk_engine.h)
     else if (!strcmp(name, "viterbi_latch_switches")) *out = (double)h->vit.switches;

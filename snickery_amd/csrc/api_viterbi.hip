@@ -75,7 +75,7 @@ static void join_bounds_launch(snk_engine *h, const int64_t *cand, int64_t rows,
 // passes on `side` behind `knn_done` when the two streams differ.
 static int viterbi_sparse_rows(snk_engine *h, UttSlot &s, const int64_t *cand, const double *tdist, int64_t rows,
                                const int64_t *off, int n_utts, int first_utt, int K, hipStream_t main, hipStream_t side,
-                               int64_t *path, int64_t *plen, double *cost)
+                               int64_t *path, int64_t *plen, double *cost, bool knn_done_recorded = false, hipEvent_t also_behind = nullptr)
 {
     const float *JC = h->JC_unw.as<float>();
     const double *wj = h->wj.as<double>();
@@ -83,8 +83,9 @@ static int viterbi_sparse_rows(snk_engine *h, UttSlot &s, const int64_t *cand, c
     const float ceps = (float)join_lb_ceps(h->join_lb_variant, h->Dj, K);       // unit of the bounds' tripwire (joinfast_kernels.hip)
     if (h->join_lb_variant == 1) CHK(ensure_jw32(h, main));
     if (lb_side) {
-        HIPCHK(hipEventRecord(s.knn_done, main));
+        if (!knn_done_recorded) HIPCHK(hipEventRecord(s.knn_done, main));
         HIPCHK(hipStreamWaitEvent(side, s.knn_done, 0));
+        if (also_behind) HIPCHK(hipStreamWaitEvent(side, also_behind, 0));          // (join_bounds_delay: where the next group's K-NN stands)
     }
     {
         StageTimer t(h, lb_side ? side : main, TM_JOIN_LB);
@@ -276,7 +277,8 @@ std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offset
 // where they land on the compute units the persistent K-NN sweep of the next group leaves free.
 int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u0, int u1, int K,
                          const int64_t *cand_all, const double *tdist_all, bool side_stream,
-                         int64_t *res_path, int64_t *res_plen, double *res_cost, int n_batch_utts)
+                         int64_t *res_path, int64_t *res_plen, double *res_cost, int n_batch_utts,
+                         bool knn_done_recorded, hipEvent_t also_behind)
 {
     if (!res_path) { res_path = h->res_path.as<int64_t>(); res_plen = h->res_plen.as<int64_t>(); res_cost = h->res_cost.as<double>(); }
     const int64_t r0 = row_offsets[u0], rows = row_offsets[u1] - r0;
@@ -292,7 +294,7 @@ int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u0, int 
         std::vector<int64_t> off((size_t)(u1 - u0) + 1);
         for (int u = u0; u <= u1; ++u) off[(size_t)(u - u0)] = row_offsets[u] - r0;
         CHK(viterbi_sparse_rows(h, s, cand_all + r0 * K, tdist_all + r0 * K, rows, off.data(), u1 - u0, u0, K, h->stream, dps,
-                                res_path + r0, res_plen, res_cost));
+                                res_path + r0, res_plen, res_cost, knn_done_recorded, also_behind));
         if (side_stream) { HIPCHK(hipEventRecord(s.vit_done, dps)); s.vit_recorded = true; }
         else s.vit_recorded = false;
         return 0;
@@ -319,6 +321,46 @@ int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u0, int 
     if (side_stream) { HIPCHK(hipEventRecord(s.vit_done, dps)); s.vit_recorded = true; }
     else s.vit_recorded = false;             // ran on the main stream: ordered with everything that follows
     return 0;
+}
+
+// results of a batch -> pinned memory, behind its K-NN status words (main stream) and its last recursions
+static int batch_queue_results(snk_engine *h, BatchSlot &b)
+{
+    const int64_t total = b.total;
+    const int n_utts = b.n_utts;
+    const size_t sz_path = ((size_t)total * sizeof(int64_t) + 63) & ~(size_t)63;
+    const size_t sz_u = ((size_t)n_utts * 8 + 63) & ~(size_t)63, sz_st = ((size_t)3 * b.n_groups * sizeof(int) + 63) & ~(size_t)63;
+    HIPCHK(hipStreamWaitEvent(h->copy_stream, b.knn_end, 0));
+    for (int i = 0; i < 2; ++i)
+        if (h->slot[i].vit_recorded) HIPCHK(hipStreamWaitEvent(h->copy_stream, h->slot[i].vit_done, 0));
+    {
+        StageTimer t(h, h->copy_stream, TM_D2H);
+        char *st = (char *)b.stage.p;
+        HIPCHK(hipMemcpyAsync(st, b.path.p, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path, b.plen.p, (size_t)n_utts * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path + sz_u, b.cost.p, (size_t)n_utts * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u, b.status.p, (size_t)3 * b.n_groups * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u + sz_st, h->vstats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->copy_stream));
+    }
+    HIPCHK(hipEventRecord(h->vit_t1[b.seq & 3], h->copy_stream));
+    HIPCHK(hipEventRecord(b.done, h->copy_stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// join_bounds_delay: the Viterbi side of a batch's last group, left unqueued by its submit (BatchSlot::tail_pending), and the
+// copy of the batch's results behind it.  also_behind: the point inside the NEXT batch's first K-NN call it starts behind
+// (nullptr: a collect came first -- it starts where it stands).
+static int batch_flush_tail(snk_engine *h, BatchSlot &b, hipEvent_t also_behind)
+{
+    if (!b.busy || !b.tail_pending) return 0;
+    b.tail_pending = false;
+    const int g = b.n_groups - 1;
+    struct Restore { snk_engine *e; bool v; ~Restore() { e->vit_now_dense = v; } } restore{h, h->vit_now_dense};
+    h->vit_now_dense = false;                  // (a batch with a pending tail took the sparse path)
+    CHK(viterbi_group(h, g, b.offs.data(), b.first[g], b.first[g + 1], b.K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
+                      b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), b.n_utts, true, also_behind));
+    return batch_queue_results(h, b);
 }
 
 // Batch pipeline.  The main stream runs the K-NN of a group of utterances and their join costs; the
@@ -393,6 +435,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
         return fail("snk_knn_viterbi_batch_submit: no query matrix given and this workspace holds no rows of that shape "
                     "(the first submit on each of the two workspaces must carry Q)");
     }
+    bool tail = false;
     for (int g = 0; g < b.n_groups; ++g) {
         const int64_t r0 = row_offsets[b.first[g]], rows = row_offsets[b.first[g + 1]] - r0;
         CHK(knn_device(h, b.Qall.as<double>() + r0 * D, rows, K, nullptr, b.cand.as<int64_t>() + r0 * K,
@@ -403,25 +446,28 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
         b.coarse_limit = h->coarse_pass_ran ? h->coarse_limit : -1.0;
         b.probe_kind[(size_t)g] = h->probe_ran; b.probe_limit[(size_t)g] = h->probe_limit;
         b.operand_gen = h->operand_gen;
+        // join_bounds_delay: the Viterbi side of group g - 1 is queued only now, behind a point inside THIS group's K-NN; its
+        // candidates' event was recorded when they were queued (sparse path with pass 1 on the side stream only: nothing of it
+        // touches the main stream)
+        const bool delay = h->join_bounds_delay > 0 && h->join_bounds_stream == 1 && !b.vit_dense && use_sparse_viterbi(h, K, n_utts);
+        if (g == 0) CHK(batch_flush_tail(h, h->bslot[slot ^ 1], h->knn_mid_recorded ? h->knn_mid : nullptr));      // the batch before this one
+        if (delay) {
+            if (g > 0)
+                CHK(viterbi_group(h, g - 1, row_offsets, b.first[g - 1], b.first[g], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
+                                  b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), n_utts, true,
+                                  h->knn_mid_recorded ? h->knn_mid : nullptr));
+            HIPCHK(hipEventRecord(h->slot[g & 1].knn_done, h->stream));
+            if (g == b.n_groups - 1) tail = true;             // queued by the next submit, or by this batch's collect
+            continue;
+        }
         CHK(viterbi_group(h, g, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
                           b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), n_utts));
     }
-    // results -> pinned memory, behind the K-NN status words (main stream) and the last recursions
-    HIPCHK(hipEventRecord(h->knn_all_done, h->stream));
-    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->knn_all_done, 0));
-    for (int i = 0; i < 2; ++i)
-        if (h->slot[i].vit_recorded) HIPCHK(hipStreamWaitEvent(h->copy_stream, h->slot[i].vit_done, 0));
-    {
-        StageTimer t(h, h->copy_stream, TM_D2H);
-        char *st = (char *)b.stage.p;
-        HIPCHK(hipMemcpyAsync(st, b.path.p, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
-        HIPCHK(hipMemcpyAsync(st + sz_path, b.plen.p, (size_t)n_utts * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
-        HIPCHK(hipMemcpyAsync(st + sz_path + sz_u, b.cost.p, (size_t)n_utts * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
-        HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u, b.status.p, (size_t)3 * b.n_groups * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
-        HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u + sz_st, h->vstats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->copy_stream));
-    }
-    HIPCHK(hipEventRecord(h->vit_t1[b.seq & 3], h->copy_stream));
-    HIPCHK(hipEventRecord(b.done, h->copy_stream));
+    if (!b.knn_end) HIPCHK(hipEventCreateWithFlags(&b.knn_end, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(b.knn_end, h->stream));
+    b.busy = true;                                 // (batch_flush_tail looks at it)
+    b.tail_pending = tail;
+    if (!tail) CHK(batch_queue_results(h, b));
     HIPCHK(hipGetLastError());
     b.busy = true;
     h->bnext = slot ^ 1;
@@ -438,6 +484,7 @@ int snk_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, i
     BatchSlot &b = h->bslot[ticket];
     const size_t sz_path = ((size_t)b.total * sizeof(int64_t) + 63) & ~(size_t)63;
     const size_t sz_u = ((size_t)b.n_utts * 8 + 63) & ~(size_t)63;
+    CHK(batch_flush_tail(h, b, nullptr));           // (no batch was submitted behind this one: its last group starts where it stands)
     HIPCHK(hipEventSynchronize(b.done));          // this batch only: the one submitted after it may still run
     HIPCHK(hipGetLastError());
     b.busy = false;

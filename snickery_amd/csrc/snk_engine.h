@@ -183,6 +183,10 @@ struct BatchSlot {    // one submitted batch (snk_knn_viterbi_batch_submit / _co
     int64_t seq = -1;                     // number of this batch (timing events of the Viterbi latch)
     int64_t operand_gen = -1;             // generation of the prefilter's operands its K-NN ran on
     bool vit_dense = false, vit_trial = false, vit_judged = false;
+    // join_bounds_delay: the Viterbi side of the batch's LAST group and the copy of its results are not queued yet -- the next
+    // submit queues them behind a point inside its own first K-NN call, a collect that comes first queues them as they are
+    bool tail_pending = false;
+    hipEvent_t knn_end = nullptr;         // everything this batch queued on the main stream
     int64_t total = 0;
     std::vector<int> first;
     std::vector<int64_t> offs;
@@ -247,6 +251,12 @@ struct snk_engine {
     int64_t n_slabs16 = 0, n_slabs16_a = 0, stride16 = 16;
     double eps_c = 8e-6;          // 2x the analytical f32 bound (knn16_kernels.hip)
     int join_bounds_stream = 1;   // batches: pass 1 of the sparse Viterbi path on 1: the group's side stream, 0: the main (K-NN) stream
+    // batches: the Viterbi side of group g starts 0: as soon as its candidates are there (beside stage A of group g + 1),
+    // 1: behind the thresholds of group g + 1, 2: behind its bucket pass (beside its re-rank) -- groups that have a successor in the
+    // SAME batch only (the side stream cannot wait for what is not queued yet).  knn_mid: where group g + 1 stands (api_knn.hip)
+    int join_bounds_delay = 1;
+    hipEvent_t knn_mid = nullptr;
+    bool knn_mid_recorded = false;
     int prefilter = 1;            // 1: bf16-split operands on the bf16 matrix pipe where the shape has a variant, 0: float32 operands
     bool bf16_ready = false;      // a16l / s16l (and gs_tiles_b) hold the bf16-split operands of the current weights
     double eps_c_bf = 4e-6;       // accumulation part of the bound of the bf16-split keys (knn16_kernels.hip: c_acc)
@@ -482,7 +492,9 @@ std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offset
 int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u0, int u1, int K,
                   const int64_t *cand_all, const double *tdist_all, bool side_stream,
                   int64_t *res_path = nullptr, int64_t *res_plen = nullptr, double *res_cost = nullptr,
-                  int n_batch_utts = 2);
+                  int n_batch_utts = 2,
+                  bool knn_done_recorded = false,        // the slot's knn_done event already marks the end of the group's K-NN
+                  hipEvent_t also_behind = nullptr);     // the side stream waits for this one too (join_bounds_delay)
 
 // collectives of the sharded search, on the engine's stream (api_shard.hip)
 int comm_all_reduce_min(snk_engine *h, double *buf, int64_t n);

@@ -119,6 +119,23 @@ e.knn_viterbi_batch_collect(t0)
 e.knn_viterbi_batch_collect(t2)
 assert refused(e.knn_viterbi_batch_collect, t0)                         # collected already
 assert refused(e.knn_viterbi_batch_collect, (7, t0[1]))                 # no such ticket
+# where the Viterbi side of a group starts (join_bounds_delay): the last group of a batch is queued by the NEXT submit or by
+# its own collect, whichever comes first -- every order of submits and collects, one group and several per batch
+for delay in (0, 1, 2):
+    e.set_option('join_bounds_delay', delay); assert e.info('join_bounds_delay') == delay
+    for rows in (12288, 64):
+        e.set_option('batch_rows', rows)
+        a = e.knn_viterbi_batch_submit(utts, 10); e.knn_viterbi_batch_collect(a)                  # collect flushes its own tail
+        a = e.knn_viterbi_batch_submit(utts, 10); b2 = e.knn_viterbi_batch_submit(utts[:2], 10)     # the second submit flushes the first's
+        e.knn_viterbi_batch_collect(b2); e.knn_viterbi_batch_collect(a)                            # out of order
+        a = e.knn_viterbi_batch_submit(utts, 10); b2 = e.knn_viterbi_batch_submit(utts[:1], 10)
+        e.knn_viterbi_batch_collect(a); c3 = e.knn_viterbi_batch_submit(utts[1:], 10)              # a third behind a pending tail
+        e.knn_viterbi_batch_collect(b2); e.knn_viterbi_batch_collect(c3)
+assert refused(e.set_option, 'join_bounds_delay', 3)
+a = e.knn_viterbi_batch_submit(utts, 10)
+assert refused(e.set_option, 'join_bounds_delay', 0)                       # not under a batch in flight
+e.knn_viterbi_batch_collect(a)
+e.set_option('join_bounds_delay', 1); e.set_option('batch_rows', 12288)
 # resident submits: refused until a workspace holds rows of that shape, and again after a new column selection
 e2 = snickery_amd.HipSearchEngine(0)
 e2.upload_db(F, JC); e2.set_weights(wt, wj)
