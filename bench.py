@@ -872,6 +872,28 @@ def main():
                      'join_bound_violations': eng.info('join_bound_violations'), 'join_bound_min_margin': eng.info('join_bound_min_margin')}
         if 'prefilter_tripwire' in out:
             tripwires['gpu_matches_f32_prefilter'] = out['prefilter_tripwire']['gpu_matches_f32_prefilter']
+        if world == 1 and args.viterbi_mode and isinstance(out.get('roofline'), dict) and 'join_lb2' in str(out['roofline'].get('kernel', '')):
+            # the roofline kernel ALONE, live: the Viterbi side of one group (half the batch) from resident candidates, nothing beside
+            # it -- `frac` above is its duration inside the pipeline, where it shares the chip with the next group's filter passes
+            # (since round 5 it starts behind that group's thresholds instead of starving its stage A: DESIGN.md 4.3)
+            try:
+                grp = utts[:max(1, U // 2)]
+                cd = [eng.knn(u, K) for u in grp]
+                eng.set_option('viterbi_mode', 1)
+                eng.viterbi_batch([c for c, _ in cd], [d for _, d in cd])
+                eng.reset_timers()
+                for _ in range(3): eng.viterbi_batch([c for c, _ in cd], [d for _, d in cd])
+                ta = eng.timers().get('join_lower_bounds')
+                eng.set_option('viterbi_mode', args.viterbi_mode)
+                if ta and ta[1]:
+                    a_ms = ta[0] / ta[1]
+                    rows_a = sum(len(u) for u in grp)
+                    a_bytes = out['roofline']['algorithmic_bytes_per_launch'] * rows_a / max(out['roofline']['rows_per_launch'], 1.0)
+                    out['roofline']['alone'] = {'avg_launch_ms': a_ms, 'launches': ta[1], 'rows_per_launch': rows_a,
+                                                'achieved': a_bytes / (a_ms * 1e-3) / 1e9, 'frac': a_bytes / (a_ms * 1e-3) / 1e9 / 8000.0,
+                                                'note': 'the same kernel on the same rows with nothing beside it, HIP events, this run'}
+            except Exception as ex:          # (an extra: never the reason a bench line is missing)
+                out['roofline']['alone'] = {'error': str(ex)[:200]}
         leg_steps = max(10, args.steps // 2)            # (a timed region's first and last step run without a neighbour: 2 ms per region)
         if world == 1 and not args.no_variants and N >= 65536:
             # the same workload on databases whose tiles are not compact balls: what the fallbacks of the ball
@@ -912,7 +934,8 @@ def main():
                     'redos': leg['batch_redos'] + leg['prefilter_fallbacks']}
         summary = {'B*': {'frames_per_s_resident': round(value), 'host_to_host': None if with_upload is None else round(with_upload['value']),
                           'kernel': out['roofline'].get('kernel', '')[:16].split(' ')[0], 'bound': out['roofline'].get('bound'),
-                          'frac': round(out['roofline'].get('frac', 0.0), 3)},
+                          'frac': round(out['roofline'].get('frac', 0.0), 3),
+                          'frac_alone': round(out['roofline'].get('alone', {}).get('frac', 0.0), 3) or None},
                    'tripwires': tripwires}
         for leg in out.get('noncompact', []):
             summary['B* ' + leg['database']] = brief(leg)

@@ -406,7 +406,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
         }
         if (bound_out) return 0;             // stage A only
         h->knn_mid_recorded = false;
-        if (h->join_bounds_delay == 1 && deferred_status) {
+        if ((h->join_bounds_delay == 1 || h->join_bounds_delay == 3) && deferred_status) {
             if (!h->knn_mid) HIPCHK(hipEventCreateWithFlags(&h->knn_mid, hipEventDisableTiming));
             HIPCHK(hipEventRecord(h->knn_mid, s));
             h->knn_mid_recorded = true;
@@ -496,7 +496,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
                               Tpad, h->N, h->cnt.as<int>(), h->lkey.as<double>(), h->lidx.as<int>(), cap, status_dev, s,
                               h->perm_ready ? h->perm.as<int32_t>() : nullptr, true);
         }
-        if (h->join_bounds_delay == 2 && deferred_status) {
+        if ((h->join_bounds_delay == 2 || h->join_bounds_delay == 4) && deferred_status) {
             if (!h->knn_mid) HIPCHK(hipEventCreateWithFlags(&h->knn_mid, hipEventDisableTiming));
             HIPCHK(hipEventRecord(h->knn_mid, s));
             h->knn_mid_recorded = true;

@@ -449,7 +449,15 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
         // join_bounds_delay: the Viterbi side of group g - 1 is queued only now, behind a point inside THIS group's K-NN; its
         // candidates' event was recorded when they were queued (sparse path with pass 1 on the side stream only: nothing of it
         // touches the main stream)
-        const bool delay = h->join_bounds_delay > 0 && h->join_bounds_stream == 1 && !b.vit_dense && use_sparse_viterbi(h, K, n_utts);
+        // Where it pays (measured, DESIGN.md 4.3: B*, B2 and the reordered voices gain 3-7 %; B5 loses 15 %, the AR(1) voice 6 %,
+        // K = 200 1 %): batches of several long groups (a batch of one group is all tail: every Viterbi side would wait for the
+        // next submit, and a short step leaves that tail no slack before the host must submit again), a voice on the ball filter
+        // (behind a whole-database sweep pass 1 would share the chip with that sweep instead of with stage A), K <= 128 (beyond it
+        // the Viterbi side is what a step waits for).  join_bounds_delay 3 / 4: 1 / 2 whatever the shape.
+        const int64_t rows_per_group = total / (b.n_groups > 0 ? b.n_groups : 1);
+        const bool fits = h->join_bounds_delay >= 3 ||
+                          (b.n_groups >= 2 && rows_per_group >= 4096 && K <= 128 && !h->filter_coarse && !h->filter_onepass);
+        const bool delay = h->join_bounds_delay > 0 && fits && h->join_bounds_stream == 1 && !b.vit_dense && use_sparse_viterbi(h, K, n_utts);
         if (g == 0) CHK(batch_flush_tail(h, h->bslot[slot ^ 1], h->knn_mid_recorded ? h->knn_mid : nullptr));      // the batch before this one
         if (delay) {
             if (g > 0)

@@ -253,7 +253,8 @@ struct snk_engine {
     int join_bounds_stream = 1;   // batches: pass 1 of the sparse Viterbi path on 1: the group's side stream, 0: the main (K-NN) stream
     // batches: the Viterbi side of group g starts 0: as soon as its candidates are there (beside stage A of group g + 1),
     // 1: behind the thresholds of group g + 1, 2: behind its bucket pass (beside its re-rank) -- groups that have a successor in the
-    // SAME batch only (the side stream cannot wait for what is not queued yet).  knn_mid: where group g + 1 stands (api_knn.hip)
+    // SAME batch only (the side stream cannot wait for what is not queued yet) -- where the shape makes it pay (api_viterbi.hip);
+    // 3 / 4: 1 / 2 whatever the shape.  knn_mid: where group g + 1 stands (api_knn.hip)
     int join_bounds_delay = 1;
     hipEvent_t knn_mid = nullptr;
     bool knn_mid_recorded = false;

@@ -259,15 +259,19 @@ def test_viterbi_batch_redo_on_overflow(engine):
         assert list(paths[u]) == op and costs[u] == ocst
 
 
-def test_viterbi_batch_submit_collect(engine):
+@pytest.mark.parametrize('delay', [0, 3, 4])
+def test_viterbi_batch_submit_collect(engine, delay):
     """Two batches in flight (submit i+1 before collect i): results equal the one-call form and the
     oracle, in submission order or not; a third submit and a one-call batch are refused while two /
-    any are pending; an overflowed group is redone at collect time."""
+    any are pending; an overflowed group is redone at collect time.  delay 3 / 4: the Viterbi side of a group queued
+    behind a point inside the next group's K-NN call, a batch's last group by the next submit or its own collect
+    (join_bounds_delay, forced whatever the shape)."""
     import snickery_amd
     F_unw, JC_unw, wt, wj, F, E, S = synth_setup(30000, 61, 40, seed=17)
     engine.upload_db(F_unw, JC_unw)
     engine.set_weights(wt, wj)
     engine.set_option('batch_rows', 64)                  # several groups per batch
+    engine.set_option('join_bounds_delay', delay)
     try:
         batches = [[o.synthetic_targets(F_unw, T, seed=10 * b + i) * wt for i, T in enumerate(lens)]
                    for b, lens in enumerate([(33, 48, 20, 7), (50, 2, 61), (40, 40, 40, 40, 9)])]
@@ -309,6 +313,7 @@ def test_viterbi_batch_submit_collect(engine):
         engine.set_option('sample_fraction', 1.0 / 16)
         engine.set_option('precision', 1)
         engine.set_option('batch_rows', 12288)
+        engine.set_option('join_bounds_delay', 1)
 
 
 def test_batch_submit_with_resident_rows(engine):
