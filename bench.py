@@ -23,6 +23,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before anything starts the ROCm runtime (snickery_amd/engine.py load_library: why)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -133,6 +133,10 @@ def load_library():
     if not os.path.isfile(path):
         raise SnkError('%s not found: build it with `make` (hipcc --offload-arch=gfx950); '
                        'there is no CPU fallback' % path)
+    # An engine works on four streams (K-NN, two Viterbi sides, copies) and the ROCm runtime maps a process's streams onto four
+    # hardware queues by default -- beside a framework's own streams two of them then share one.  Eight queues, unless the caller
+    # chose a number (read when the runtime starts: effective if nothing has touched the GPU yet; measured +1..3 % on the B* step).
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the export is missing
