@@ -1,5 +1,7 @@
 """Stress of the two-batches-in-flight API: random ragged batches, random collect order, compared with
-the one-call form.  python tests/stress_async.py [iterations] [seed]"""
+the one-call form.  python tests/stress_async.py [iterations] [seed] [join_bounds_delay]
+(join_bounds_delay 3 / 4: the Viterbi side of every group behind a point inside the next group's K-NN call whatever the shape,
+a batch's last group queued by the next submit or by its own collect -- the orders this script draws at random)."""
 import os
 import sys
 import numpy as np
@@ -16,6 +18,7 @@ F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=9)
 wt = np.full(Dt, 0.4); wj = np.full(Dj, 0.05)
 eng = snickery_amd.HipSearchEngine(0)
 eng.upload_db(F_unw, JC_unw); eng.set_weights(wt, wj)
+if len(sys.argv) > 3: eng.set_option('join_bounds_delay', int(sys.argv[3]))
 pending = []        # (ticket, reference result)
 bad = 0
 for it in range(n_iter):
