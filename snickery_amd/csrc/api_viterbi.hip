@@ -436,6 +436,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
                     "(the first submit on each of the two workspaces must carry Q)");
     }
     bool tail = false;
+    const bool pipelined = h->bslot[slot ^ 1].busy;
     for (int g = 0; g < b.n_groups; ++g) {
         const int64_t r0 = row_offsets[b.first[g]], rows = row_offsets[b.first[g + 1]] - r0;
         CHK(knn_device(h, b.Qall.as<double>() + r0 * D, rows, K, nullptr, b.cand.as<int64_t>() + r0 * K,
@@ -465,7 +466,14 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
                                   b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), n_utts, true,
                                   h->knn_mid_recorded ? h->knn_mid : nullptr));
             HIPCHK(hipEventRecord(h->slot[g & 1].knn_done, h->stream));
-            if (g == b.n_groups - 1) tail = true;             // queued by the next submit, or by this batch's collect
+            if (g == b.n_groups - 1) {
+                // The last group: left to the next submit (or to this batch's collect) where the caller keeps two batches in
+                // flight -- the other workspace is busy right now, so the next thing it does is very likely another submit.  A
+                // caller with one batch at a time (host work between submit and collect) gets it queued here, as before.
+                if (pipelined) tail = true;
+                else CHK(viterbi_group(h, g, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
+                                       b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), n_utts, true, nullptr));
+            }
             continue;
         }
         CHK(viterbi_group(h, g, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
