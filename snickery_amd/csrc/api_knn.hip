@@ -406,7 +406,8 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
         }
         if (bound_out) return 0;             // stage A only
         h->knn_mid_recorded = false;
-        if ((h->join_bounds_delay == 1 || h->join_bounds_delay == 3) && deferred_status) {
+        // (a voice on the coarse sweep: behind that sweep instead -- below)
+        if (((h->join_bounds_delay == 1 && !(coarse && !balls)) || h->join_bounds_delay == 3) && deferred_status) {
             if (!h->knn_mid) HIPCHK(hipEventCreateWithFlags(&h->knn_mid, hipEventDisableTiming));
             HIPCHK(hipEventRecord(h->knn_mid, s));
             h->knn_mid_recorded = true;
@@ -442,6 +443,22 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
                     const double all = (double)(Tpad / 32) * (double)n_tiles_b;
                     h->coarse_limit = h->onepass_gate_fraction * all < 0.9 * (double)pair_cap ? h->onepass_gate_fraction * all : 0.9 * (double)pair_cap;
                 }
+                if (!balls && (h->join_bounds_delay == 1 || h->join_bounds_delay == 5) && deferred_status) {
+                    // the Viterbi side of the group before starts behind this group's COARSE sweep (a persistent whole-database
+                    // sweep like stage A: pass 1's workgroups would starve it; behind the thresholds the AR(1) voice lost 6 %,
+                    // here it gains 3 %)
+                    launch_knn_filter16c(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, h->thr32.as<float>(), h->thr1_32.as<float>(),
+                                         Tpad, n_tiles_b, h->slabctr.as<unsigned int>() + 1, h->cpairs.p, h->cpairctl.as<unsigned int>(), pair_cap,
+                                         h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, knn_pool_chunk_entries(), s,
+                                         true, false);
+                    if (!h->knn_mid) HIPCHK(hipEventCreateWithFlags(&h->knn_mid, hipEventDisableTiming));
+                    HIPCHK(hipEventRecord(h->knn_mid, s));
+                    h->knn_mid_recorded = true;
+                    launch_knn_filter16c(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, h->thr32.as<float>(), h->thr1_32.as<float>(),
+                                         Tpad, n_tiles_b, h->slabctr.as<unsigned int>() + 1, h->cpairs.p, h->cpairctl.as<unsigned int>(), pair_cap,
+                                         h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, knn_pool_chunk_entries(), s,
+                                         false, true);
+                } else
                 launch_knn_filter16c(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->a16l.p, h->b16l.p, h->thr32.as<float>(), h->thr1_32.as<float>(),
                                      Tpad, n_tiles_b, h->slabctr.as<unsigned int>() + 1, h->cpairs.p, h->cpairctl.as<unsigned int>(), pair_cap,
                                      h->pool.p, h->poolctl.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, knn_pool_chunk_entries(), s,

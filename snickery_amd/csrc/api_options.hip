@@ -228,7 +228,7 @@ int snk_set_option(snk_handle h, const char *name, double value)
         CHK(no_batch_in_flight(h, "snk_set_option(join_bounds_stream)"));
         h->join_bounds_stream = (int)value;
     } else if (!strcmp(name, "join_bounds_delay")) {
-        if (!(value >= 0.0 && value <= 4.0) || value != (double)(int)value) return fail("join_bounds_delay must be 0 .. 4");
+        if (!(value >= 0.0 && value <= 5.0) || value != (double)(int)value) return fail("join_bounds_delay must be 0 .. 5");
         CHK(no_batch_in_flight(h, "snk_set_option(join_bounds_delay)"));
         h->join_bounds_delay = (int)value;
     } else if (!strcmp(name, "join_lb_quadrants")) {

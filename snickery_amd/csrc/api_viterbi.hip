@@ -452,12 +452,12 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
         // touches the main stream)
         // Where it pays (measured, DESIGN.md 4.3: B*, B2 and the reordered voices gain 3-7 %; B5 loses 15 %, the AR(1) voice 6 %,
         // K = 200 1 %): batches of several long groups (a batch of one group is all tail: every Viterbi side would wait for the
-        // next submit, and a short step leaves that tail no slack before the host must submit again), a voice on the ball filter
-        // (behind a whole-database sweep pass 1 would share the chip with that sweep instead of with stage A), K <= 128 (beyond it
-        // the Viterbi side is what a step waits for).  join_bounds_delay 3 / 4: 1 / 2 whatever the shape.
+        // next submit, and a short step leaves that tail no slack before the host must submit again), not behind a one-pass
+        // sweep of the whole database (api_knn.hip: a voice on the COARSE sweep starts it behind that sweep), K <= 128 (beyond it
+        // the Viterbi side is what a step waits for).  join_bounds_delay 3 / 4: 1 / 2 whatever the shape, 5: the coarse point only.
         const int64_t rows_per_group = total / (b.n_groups > 0 ? b.n_groups : 1);
-        const bool fits = h->join_bounds_delay >= 3 ||
-                          (b.n_groups >= 2 && rows_per_group >= 4096 && K <= 128 && !h->filter_coarse && !h->filter_onepass);
+        const bool fits = h->join_bounds_delay == 3 || h->join_bounds_delay == 4 || (h->join_bounds_delay == 5 && h->filter_coarse) ||
+                          (b.n_groups >= 2 && rows_per_group >= 4096 && K <= 128 && !h->filter_onepass);
         const bool delay = h->join_bounds_delay > 0 && fits && h->join_bounds_stream == 1 && !b.vit_dense && use_sparse_viterbi(h, K, n_utts);
         if (g == 0) CHK(batch_flush_tail(h, h->bslot[slot ^ 1], h->knn_mid_recorded ? h->knn_mid : nullptr));      // the batch before this one
         if (delay) {

@@ -121,7 +121,7 @@ assert refused(e.knn_viterbi_batch_collect, t0)                         # collec
 assert refused(e.knn_viterbi_batch_collect, (7, t0[1]))                 # no such ticket
 # where the Viterbi side of a group starts (join_bounds_delay): the last group of a batch is queued by the NEXT submit or by
 # its own collect, whichever comes first -- every order of submits and collects, one group and several per batch
-for delay in (0, 1, 2, 3, 4):
+for delay in (0, 1, 2, 3, 4, 5):
     e.set_option('join_bounds_delay', delay); assert e.info('join_bounds_delay') == delay
     for rows in (12288, 64):
         e.set_option('batch_rows', rows)
@@ -131,7 +131,7 @@ for delay in (0, 1, 2, 3, 4):
         a = e.knn_viterbi_batch_submit(utts, 10); b2 = e.knn_viterbi_batch_submit(utts[:1], 10)
         e.knn_viterbi_batch_collect(a); c3 = e.knn_viterbi_batch_submit(utts[1:], 10)              # a third behind a pending tail
         e.knn_viterbi_batch_collect(b2); e.knn_viterbi_batch_collect(c3)
-assert refused(e.set_option, 'join_bounds_delay', 5)
+assert refused(e.set_option, 'join_bounds_delay', 6)
 a = e.knn_viterbi_batch_submit(utts, 10)
 assert refused(e.set_option, 'join_bounds_delay', 0)                       # not under a batch in flight
 e.knn_viterbi_batch_collect(a)
