@@ -254,6 +254,9 @@ std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offset
     if (h->batch_rows > 0) {
         int64_t n_groups = (total + h->batch_rows - 1) / h->batch_rows;
         if (n_groups > 1 && (n_groups & 1)) ++n_groups;       // groups alternate between two workspaces and side streams
+        // a batch that fits one group, but is long: two, so that the first one's Viterbi side runs beside the second one's K-NN
+        // (B5, 64 x 120 rows: 1.86 -> 1.91 M frames/s)
+        if (n_groups == 1 && total >= 6144 && n_utts >= 2) n_groups = 2;
         target = (total + n_groups - 1) / n_groups;
     }
     int64_t rows = 0;
