@@ -23,7 +23,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before anything starts the ROCm runtime (snickery_amd/engine.py load_library: why)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # = snickery_amd.configure_runtime(), before anything starts the ROCm runtime (engine.py: why); recorded in config.hw_queues
 
 import numpy as np
 
@@ -68,7 +68,7 @@ def profiled_counters(json_name, kernel_source):
     measured in the bench run itself).  They describe the kernel AS IT WAS PROFILED: the file carries the sha256 of the kernel's
     source at that time (`source_sha256`), and only while the source is still that one do the values count as this build's
     (`fresh`); otherwise the caller reports them under `profiled_reference` and leaves `traffic` null."""
-    path = os.path.join(ROOT, 'profiles', json_name)
+    path = os.path.join(os.environ.get('SNK_PROFILES_DIR') or os.path.join(ROOT, 'profiles'), json_name)      # (SNK_PROFILES_DIR: tools/prof_round6.sh, counters taken minutes before on the same box)
     if not os.path.isfile(path):
         return None, False
     with open(path) as f:
@@ -255,23 +255,41 @@ def greedy_extra(device, configs=((65536, 'greedy_b1'), (1500000, 'greedy_b3')),
     return out
 
 
+def speechlike_voice(N, Dt, Dj, seed=0, rho=0.98):
+    """A voice whose frames relate to each other the way speech frames do, more than SURVEY 8d's cumsum(randn) / global std does
+    (consecutive units 0.002 apart per column there, against neighbour distances of 0.3): a stationary AR(1) walk per column whose
+    step has 0.2 of the global standard deviation (var(step) = 2 (1 - rho) = 0.04) -- for the target features AND for the join
+    features (until round 5 this leg kept the random-walk join matrix: smooth join rows, near-contiguous candidates, traffic
+    below the algorithmic bytes).  Returns F_unw (N x Dt), JC_unw ((N + 1) x Dj) and held_out(T, u): utterance u
+    of T frames from a walk of the SAME process that the database never saw (not database rows + noise): its nearest units are as
+    far as any stranger's in that cloud."""
+    from scipy.signal import lfilter
+    rng = np.random.RandomState(seed + 17)
+    g = np.sqrt(1.0 - rho * rho)
+    F = lfilter([g], [1.0, -rho], rng.randn(N + 2000, Dt), axis=0)[2000:]
+    sF = F.std()
+    F = (F / sF).astype(np.float32)
+    JC = lfilter([g], [1.0, -rho], rng.randn(N + 1 + 2000, Dj), axis=0)[2000:]
+    JC = (JC / JC.std()).astype(np.float32)
+
+    def held_out(T, u):
+        r = np.random.RandomState(seed + 1000 + u)
+        return lfilter([g], [1.0, -rho], r.randn(T + 2000, Dt), axis=0)[2000:] / sF
+    return F, JC, held_out
+
+
 def variant_database(kind, N, Dt, F_unw, JC_unw, seed=0):
-    """Databases of the B* shape whose 32-unit tiles are NOT the compact balls SURVEY 8d's generator makes of them
-    (cumsum(randn) / global std: consecutive units 0.002 apart per column against neighbour distances of 0.3):
+    """Databases of the B* shape whose 32-unit tiles are NOT the compact balls SURVEY 8d's generator makes of them:
       'permuted'    the same units in random order: a tile holds 32 unrelated frames, the ball pass of the database order is useless --
                     the engine gives such a voice an order of its own (kmeans_kernels.hip).  The utterances of this leg follow the
-                    speech the units were cut from (until round 4 they followed the ROW order of the permuted matrix: consecutive
-                    target frames with nothing in common, which no utterance has);
-      'speechlike'  a stationary AR(1) walk per column whose step has 0.2 of the global standard deviation (consecutive
-                    speech frames differ by a sizeable fraction of the spread of the data)."""
-    rng = np.random.RandomState(seed + 17)
+                    speech the units were cut from;
+      'speechlike'  speechlike_voice(): AR(1) target AND join features, utterances from a held-out walk.
+    Returns (F, JC, targets) -- targets(T, u) or None (the leg then follows `targets_from` + noise)."""
     if kind == 'permuted':
+        rng = np.random.RandomState(seed + 17)
         perm = rng.permutation(N)
-        return F_unw[perm], JC_unw[np.concatenate([perm, [N]])]
-    from scipy.signal import lfilter
-    rho = 0.98                                   # var(step) = 2 (1 - rho) = 0.04
-    F = lfilter([np.sqrt(1.0 - rho * rho)], [1.0, -rho], rng.randn(N + 2000, Dt), axis=0)[2000:]
-    return (F / F.std()).astype(np.float32), JC_unw
+        return F_unw[perm], JC_unw[np.concatenate([perm, [N]])], None
+    return speechlike_voice(N, Dt, JC_unw.shape[1], seed)
 
 
 def leg_roofline(tm, steps, rows_per_step, N, Dt, Dj, K, eng):
@@ -327,7 +345,7 @@ def leg_roofline(tm, steps, rows_per_step, N, Dt, Dj, K, eng):
     return out
 
 
-def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', host_to_host=False, targets_from=None):
+def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', host_to_host=False, targets_from=None, targets=None):
     """One BASELINE shape (or B* on a variant database) through the batch pipeline, two steps in flight, rows resident in HBM: frames/s,
     stage times, the dominant kernel's roofline, fallbacks and tripwires.  An extra field of the JSON line, never `value`."""
     import snickery_amd
@@ -337,12 +355,15 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
     eng.upload_db(F_unw, JC_unw)
     eng.set_weights(wt, wj)
     # targets_from: the matrix the utterances follow (a permuted database: the speech its units were cut from, not its row order)
-    batch = snickery_amd.QueryBatch([synthetic_targets(F_unw if targets_from is None else targets_from, T, seed=1 + u) * wt for u in range(U)])
+    # targets: utterance u from the caller's generator (a held-out walk) instead
+    batch = snickery_amd.QueryBatch([(targets(T, u) if targets is not None else
+                                      synthetic_targets(F_unw if targets_from is None else targets_from, T, seed=1 + u)) * wt for u in range(U)])
     batch.pin()
     for _ in range(4):                           # primes both workspaces; the engine judges the voice (filter passes, unit order, Viterbi path)
         eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(batch, K))
     before = (eng.info('f16_fallbacks'), eng.info('batch_redos'), eng.info('exact_row_fallbacks'))
     eng.reset_timers()
+    cells0 = eng.info('dense_cells')
 
     def run(resident):
         torch.cuda.synchronize()
@@ -366,6 +387,7 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
            'filter_coarse': bool(eng.info('filter_coarse')), 'filter_onepass': bool(eng.info('filter_onepass')),
            'reordered': bool(eng.info('reordered')), 'tile_radius_before_after': [eng.info('reorder_radius_before'), eng.info('reorder_radius_after')],
            'viterbi_path': 'dense' if eng.info('viterbi_latch_mode') == 1 else 'sparse',
+           'cells_refined_per_step': (eng.info('dense_cells') - cells0) / steps, 'cells_per_step': T * U * K,
            'tile_pairs_listed': {'last_launch': pairs, 'fraction': pairs / max((rows_per_launch / 32.0) * (N / 32.0), 1.0)},
            'list_mean': eng.info('last_list_mean'), 'list_max': eng.info('last_list_max'), 'knn_level': eng.info('knn_level'),
            'prefilter_fallbacks': eng.info('f16_fallbacks') - before[0], 'batch_redos': eng.info('batch_redos') - before[1],
@@ -376,7 +398,109 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
     if host_to_host:
         dth, _ = run(False)
         out['host_to_host_frames_per_s'] = T * U * steps / dth
+        out['host_to_host_ms_per_step'] = dth / steps * 1e3
     return out
+
+
+def other_rooflines(timers, counts, rows, K, Dt, Dj):
+    """Rooflines of the two whole-chip kernels that had none until round 5, from the engine's HIP-event stage
+    timers over the timed steps and the kernels' own counters (snk_get_info):
+      join_exact_sparse2_kernel (pass 3): per exact cost two float32 rows of Dj columns (the rows are read in 64-byte pieces by
+        four neighbouring lanes and pass through LDS once; nothing is shared between costs) + per cell its set (16 B), candidate
+        (8 B), target distance (8 B) read and its record (64 B) written; beside the bytes, 5 separately rounded float64 operations
+        per column and cost (2 mul, sub, mul, add: the canonical order) against the non-FMA float64 vector rate (39.3 T op/s);
+      knn_finalize_kernel: per list entry its 8-byte key, per re-ranked entry its id (4 B) and its float32 row (Dt columns padded
+        to 4), per row K results (16 B each) and the query row (8 B per column).
+    `traffic` (counter bytes) is added by tools/summarise_round6.py from --pmc passes (profiles/r06_*_summary.md)."""
+    out = {}
+    def stage(name):
+        return (timers[name][0] / timers[name][1], timers[name][1]) if name in timers and timers[name][1] else (0.0, 0)
+    ms, n = stage('join_exact_sparse')
+    if n and counts.get('sparse_exact_costs', 0) > 0:
+        costs = counts['sparse_exact_costs'] / n
+        cells = rows * K / n
+        b = costs * 2 * Dj * 4 + cells * (16 + 8 + 8 + 64)
+        ops = costs * Dj * 5.0
+        out['join_exact_sparse2_kernel'] = {
+            'bound': 'hbm', 'achieved': b / (ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': b / (ms * 1e-3) / 8e12,
+            'avg_launch_ms': ms, 'launches': n, 'exact_costs_per_launch': costs, 'set_members_per_launch': counts.get('sparse_set_members', 0) / n,
+            'cells_per_launch': cells, 'algorithmic_bytes_per_launch': b, 'f64_vector_ops_per_launch': ops,
+            'f64_vector_frac': ops / (ms * 1e-3) / 39.3e12, 'traffic': None}
+    ms, n = stage('knn_finalize')
+    if n and counts.get('finalize_list_entries', 0) > 0:
+        ent, sel = counts['finalize_list_entries'] / n, counts['finalize_reranked'] / n
+        rpl = rows / n
+        fp = (Dt + 3) // 4 * 4
+        b = ent * 8 + sel * (4 + fp * 4) + rpl * (K * 16 + Dt * 8)
+        out['knn_finalize_kernel'] = {
+            'bound': 'hbm', 'achieved': b / (ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': b / (ms * 1e-3) / 8e12,
+            'avg_launch_ms': ms, 'launches': n, 'rows_per_launch': rpl, 'list_entries_per_row': ent / rpl, 'reranked_per_row': sel / rpl,
+            'algorithmic_bytes_per_launch': b, 'traffic': None,
+            'binds': 'a row is one workgroup\'s chain of barriers (selection by value bins, exact distances, a bitonic sort of 256): latency, six workgroups per compute unit'}
+    return out
+
+
+def check_rooflines(obj, where='', found=None):
+    """Every `frac` of every roofline-shaped object of the record must lie in [0, 1]: a fraction of a peak above 1 is a wrong
+    byte count or a wrong time, not evidence (r05's summary printed 1.38 after a regrouping halved the rows of a launch).
+    An offender is NOT printed as a number: frac / achieved become None, `invalid` says why, and its path is returned."""
+    found = [] if found is None else found
+    if isinstance(obj, dict):
+        f = obj.get('frac')
+        if 'peak' in obj and isinstance(f, (int, float)) and not (0.0 <= f <= 1.0):
+            obj['invalid'] = 'frac %.3f outside [0, 1]: withheld' % f
+            obj['frac'] = obj['achieved'] = None
+            found.append(where or '.')
+        for k, v in obj.items():
+            check_rooflines(v, where + '/' + str(k), found)
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            check_rooflines(v, where + '/%d' % i, found)
+    return found
+
+
+def _r(x, n=4):
+    return None if x is None else round(float(x), n) if isinstance(x, (int, float)) else x
+
+
+def compact_line(out):
+    """The record the driver parses: the contract's keys, `roofline` and `cpu_baseline` as flat objects of numbers and short
+    strings, a `summary` of the extra legs.  No notes, no stage tables (they are in --detail-out)."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+            'dtype', 'data', 'xRT')
+    line = dict((k, out[k]) for k in keep if k in out)
+    line['config'] = dict((k, v) for k, v in out['config'].items() if v is not None)
+    r = out.get('roofline', {})
+    ro = {'kernel': str(r.get('kernel', '')).split(' ')[0], 'bound': r.get('bound'), 'achieved': _r(r.get('achieved'), 1), 'peak': r.get('peak'),
+          'unit': r.get('unit'), 'frac': _r(r.get('frac')), 'traffic': r.get('traffic'), 'traffic_source': r.get('traffic_source_short'),
+          'avg_launch_ms': _r(r.get('avg_launch_ms')), 'launches': r.get('launches'), 'rows_per_launch': r.get('rows_per_launch'),
+          'algorithmic_bytes_per_launch': r.get('algorithmic_bytes_per_launch'), 'timed_by': 'HIP events on the kernel\'s stream, inside the timed region'}
+    for k in ('issue_frac', 'issue_frac_source', 'binds', 'invalid'):
+        if r.get(k) is not None:
+            ro[k] = r[k] if isinstance(r[k], str) else _r(r[k])
+    if isinstance(r.get('alone'), dict) and 'avg_launch_ms' in r['alone']:
+        ro['alone'] = {'avg_launch_ms': _r(r['alone']['avg_launch_ms']), 'frac': _r(r['alone'].get('frac')), 'rows_per_launch': r['alone'].get('rows_per_launch')}
+    line['roofline'] = ro
+    fs = out.get('filter_stage')
+    if isinstance(fs, dict) and fs is not r and 'join_lb' in ro['kernel']:
+        line['filter_stage'] = {'kernel': str(fs.get('kernel', '')).split(' (')[0], 'bound': 'mfma', 'issued_frac': _r(fs.get('issued', {}).get('frac')),
+                                'avg_launch_ms': _r(fs.get('avg_launch_ms')), 'traffic_ratio': _r(fs.get('traffic_ratio'), 2),
+                                'mfma_busy': fs.get('mfma_busy') if not isinstance(fs.get('mfma_busy'), dict) else
+                                dict((k, _r(v, 3)) for k, v in fs['mfma_busy'].items())}
+    c = out.get('cpu_baseline')
+    if isinstance(c, dict):
+        line['cpu_baseline'] = {'value': _r(c['value'], 2), 'unit': c['unit'], 'cores': c['cores'], 'kind': c['kind'], 'sample': c['sample'][:200],
+                                'cpu_model': c.get('cpu_model'), 'host_cores': c.get('host_cores'),
+                                'gpu_matches_cpu_path': c.get('gpu_matches_cpu_path'), 'gpu_matches_cpu_candidates': c.get('gpu_matches_cpu_candidates')}
+        if 'all_cores' in c:
+            line['cpu_baseline']['all_cores'] = {'value': _r(c['all_cores']['value'], 1), 'cores': c['all_cores']['cores']}
+    for k in ('replicas', 'note'):
+        if k in out:
+            line[k] = out[k] if isinstance(out[k], str) else dict((a, _r(b, 3)) for a, b in out[k].items() if a != 'note')
+    line['stages_ms_per_step'] = dict((k, _r(v, 3)) for k, v in out.get('stages_ms_per_step', {}).items())
+    line['roofline_check'] = out.get('roofline_check')
+    line['summary'] = out.get('summary')
+    return line
 
 
 def main():
@@ -407,9 +531,15 @@ def main():
                          '(the per-utterance recursions of its last group, the copy of the results) runs beside the K-NN of the '
                          'next one -- how a tuning loop over a tune set drives the engine; every step completes inside the timed '
                          'region.  1: strictly one step at a time (reported as extra field one_in_flight otherwise)')
-    ap.add_argument('--upload-every-step', action='store_true',
-                    help='N = 1: upload the query rows from the host inside every timed step (default: resident in HBM when the '
-                         'timed region starts; the rate with uploads is then the extra field with_upload)')
+    ap.add_argument('--resident-rows', action='store_true',
+                    help='N = 1, experiments: `value` = the rate with the query rows left in HBM by two untimed priming submits '
+                         '(default: `value` is the host -> host rate of SURVEY 8d -- the query rows are uploaded from and the paths '
+                         'returned to host memory inside every timed step, as every caller in the package does; the resident-rows rate '
+                         'is then the extra field `resident_rows`)')
+    ap.add_argument('--upload-every-step', action='store_true', help='(the default since round 6; kept so that old command lines still run)')
+    ap.add_argument('--detail-out', default=os.path.join('gpurun_out', 'bench_detail.json'), metavar='PATH',
+                    help='where the full record goes (stage tables, every leg, the notes); the LAST stdout line is the compact '
+                         'record (< 6 KB) the driver parses.  "" = do not write it')
     ap.add_argument('--exchange', choices=('library', 'torch'), default='library',
                     help="N > 1, sharded database: collectives inside libsnkhip.so (snk_comm_init: RCCL on the engine's stream; "
                          "default) or torch.distributed collectives between the device-pointer entry points (snickery_amd/dist.py)")
@@ -549,13 +679,14 @@ def main():
 
     for _ in range(args.warmup):
         paths, costs = step()
-    resident = world == 1 and args.in_flight == 2 and not args.upload_every_step
+    # What is resident when the timed region starts: the unit DATABASE (weighted, operands built).  The query rows are the
+    # step's input and cross the boundary the way every caller of the package hands them over -- host memory (page-locked) ->
+    # HBM inside the step, paths back to host memory inside the step: SURVEY 8d's wall time, VERDICT r5 item 1.
+    # --resident-rows: the rows where two untimed priming submits left them (Q == NULL, include/snk.h), for experiments.
+    resident = world == 1 and args.in_flight == 2 and args.resident_rows
     if world == 1 and args.in_flight == 2:
         batch.pin()
-        # the inputs of the timed region are resident in HBM when it starts (task contract): both workspaces of the
-        # two-in-flight pipeline receive the batch's rows here, untimed; the timed steps search them again (Q == NULL,
-        # include/snk.h).  The rate with the rows uploaded from the host in every step is the extra field `with_upload`.
-        for _ in range(2):
+        for _ in range(2):                  # both workspaces of the two-in-flight pipeline primed (and hold the rows for the resident-rows pass)
             paths, costs = eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(batch, K))
 
     def pipelined(steps, res):
@@ -596,6 +727,9 @@ def main():
         elapsed = float(t.item())
 
     timers = eng.timers()
+    # counters the rooflines of the two kernels without one until round 5 are priced on, read before any
+    # other pass adds to them: exact costs pass 3 took from the rows, list entries the re-rank read / gave exact distances
+    roof_counts = dict((k, eng.info(k)) for k in ('sparse_exact_costs', 'sparse_set_members', 'finalize_list_entries', 'finalize_reranked')) if world == 1 else {}
     # N > 1, database sharded: the same GPUs as independent replicas (every GPU the whole database -- B* needs 3.5 GB of
     # 288 -- and its own 32 utterances, no collective), timed the same way: an extra field, never `value`.  Sharding is for
     # databases beyond one GPU's memory; for one that fits, this is what the exchange costs.
@@ -633,17 +767,18 @@ def main():
                         'note': 'the same GPUs as %d independent replicas (whole database on every GPU, no collective), two steps in flight' % world}
         elif rank == 0:
             sys.stderr.write('replicas extra skipped: %s\n' % (err or 'a rank failed'))
-    # the same pipeline with the query rows uploaded from the host in every step (an extra field, never `value`)
-    with_upload = None
-    if world == 1 and args.in_flight == 2 and resident:
+    # the same pipeline in the OTHER input mode (an extra field, never `value`): rows resident in HBM, or uploaded every step
+    other_mode = None
+    if world == 1 and args.in_flight == 2:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        pu, cu = pipelined(args.steps, False)
+        pu, cu = pipelined(args.steps, not resident)
         torch.cuda.synchronize()
         eu = time.perf_counter() - t1
-        with_upload = {'value': frames_per_step * args.steps / eu, 'unit': 'frames/s', 'ms_per_step': eu / args.steps * 1e3,
-                       'same_results': bool(all(np.array_equal(a, b) for a, b in zip(pu, paths)) and np.array_equal(cu, costs)),
-                       'note': 'the query rows (%.1f MB per step) cross PCIe inside every timed step, from page-locked host memory' % (batch.Q.nbytes / 1e6)}
+        other_mode = {'value': frames_per_step * args.steps / eu, 'unit': 'frames/s', 'ms_per_step': eu / args.steps * 1e3,
+                      'same_results': bool(all(np.array_equal(a, b) for a, b in zip(pu, paths)) and np.array_equal(cu, costs)),
+                      'note': ('the query rows (%.1f MB per step) cross PCIe inside every timed step, from page-locked host memory' % (batch.Q.nbytes / 1e6)) if resident else
+                              'the query rows searched where two untimed priming submits left them in HBM (Q == NULL): a mode no caller of the package uses'}
     # a second, separately timed pass in the OTHER submission mode (an extra field, never `value`)
     two_in_flight = one_in_flight = None
     if world == 1 and args.in_flight == 1:
@@ -718,7 +853,8 @@ def main():
                        'sharding': 'none' if world == 1 else (
                            '%d independent replicas' % world if S == 1 else
                            'db-rows/%d + all-to-all of local top-K' % S + (' x %d replica groups' % n_groups if n_groups > 1 else '')),
-                       'exchange': None if world == 1 or S == 1 else args.exchange},
+                       'exchange': None if world == 1 or S == 1 else args.exchange,
+                       'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES')},
             'value_includes_query_upload': not resident,
             'filter_stage': {'bound': 'mfma', 'kernel': kname,
                              'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
@@ -751,18 +887,25 @@ def main():
             jbytes = jrows * K * 2 * Dj * 4 + jrows * K * K * 4        # gathered E and S rows (each read once per row pair) + the bounds written
             javg = jms / max(jl, 1)
             jfl = 2.0 * jrows * K * K * Dj
-            jtraffic, jsrc, jref = None, None, None
+            jtraffic, jsrc, jsrc_short, jref, jissue, jissue_src = None, None, None, None, None, None
             if variant1 and world == 1 and N == 1048576 and Dj == 302 and K == 100:
-                for jname in ('r05_traffic_joinlb2.json', 'r04_traffic_joinlb2.json'):
+                for jname in ('r06_traffic_joinlb2.json', 'r05_traffic_joinlb2.json', 'r04_traffic_joinlb2.json'):
                     tj, fresh = profiled_counters(jname, 'joinlb2_kernels.hip')
-                    if tj is None or abs(tj.get('rows_per_launch', 0) - jrows) > 0.01 * jrows:      # (the profiled call counts row PAIRS of one group: 9 599)
+                    # a counter file counts only when its rows per launch were READ FROM THE KERNEL TRACE of the pass that took the
+                    # counters (grid.x of join_lb2_kernel = row pairs), never assumed (r05's file assumed 9 599 after a regrouping had
+                    # made it 4 800: traffic wrong by 2 x)
+                    if tj is None or not tj.get('rows_from_trace') or not tj.get('rows_per_launch'):
                         continue
-                    scaled = tj['hbm_bytes_per_launch'] * jrows / tj['rows_per_launch']
+                    per_row = tj['hbm_bytes_per_launch'] / tj['rows_per_launch']
                     if fresh:
-                        jtraffic = scaled
-                        jsrc = 'profiles/%s (separate --pmc passes of this kernel and shape, the kernel source unchanged since; scaled by the rows)' % jname
+                        jtraffic = per_row * jrows
+                        jsrc = ('profiles/%s (separate --pmc passes of this kernel alone on %d row pairs per launch -- grid size read from the kernel '
+                                'trace of the same pass; the kernel source unchanged since; scaled to the %d rows of this run\'s launches)' % (jname, tj['rows_per_launch'], jrows))
+                        jsrc_short = 'profiles/' + jname
+                        if tj.get('issue_frac') is not None:
+                            jissue, jissue_src = tj['issue_frac'], 'profiles/%s: (4 SQ_INSTS_VALU + 8 MFMA) / SIMD cycles, the kernel alone' % jname
                     else:
-                        jref = {'file': 'profiles/' + jname, 'hbm_bytes_per_launch': scaled,
+                        jref = {'file': 'profiles/' + jname, 'hbm_bytes_per_launch': per_row * jrows,
                                 'note': 'counters of an EARLIER build of this kernel (its source has changed since the pass): not this run\'s traffic'}
                     break
             out['roofline'] = {
@@ -771,10 +914,12 @@ def main():
                            'K x K x Dj product on v_mfma_f32_32x32x16_bf16, proven lower bounds written as float32)' if variant1 else
                            'join_lb_kernel (joinfast_kernels.hip: v_mfma_f32_16x16x4_f32, rows weighted in float64 per gather)'),
                 'achieved': jbytes / (javg * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': jbytes / (javg * 1e-3) / 1e9 / 8000.0,
-                'traffic': jtraffic, 'traffic_source': jsrc, 'profiled_reference': jref,
+                'traffic': jtraffic, 'traffic_source': jsrc, 'traffic_source_short': jsrc_short, 'profiled_reference': jref,
+                'issue_frac': jissue, 'issue_frac_source': jissue_src,
+                'binds': 'vector-issue port (issue_frac), not HBM' if jissue is not None and jissue > 0.6 else None,
                 'avg_launch_ms': javg, 'launches': jl, 'rows_per_launch': jrows, 'algorithmic_bytes_per_launch': jbytes,
                 'flops_per_launch': jfl, 'mfma_tflops': jfl / (javg * 1e-3) / 1e12,
-                'rule': 'the whole-chip kernel with the largest total time under rocprofv3 (profiles/r05_d_kernel_stats.csv; the largest of all is a '
+                'rule': 'the whole-chip kernel with the largest total time under rocprofv3 (profiles/r06_*_kernel_stats.csv; the largest of all is a '
                         'latency chain on 16 workgroups: `largest_total_time_kernel`); timed here with '
                         'HIP events on the stream it is launched on, inside the timed region, while the K-NN of the next group shares the chip',
                 'note': 'algorithmic bytes per SURVEY 8d: every candidate row gathered once per row pair (2 K rows of Dj float32) + K^2 float32 bounds; '
@@ -795,6 +940,8 @@ def main():
                                        'whole-chip kernels do (sum of their stand-alone times 4.1 of the 4.6 ms step, DESIGN.md 4.3)'}
         else:
             out['roofline'] = dict(out['filter_stage'])
+        if world == 1 and roof_counts:
+            out['other_rooflines'] = other_rooflines(timers, roof_counts, rows_swept, K, Dt, Dj)
         if bf16_mode:
             # what the matrix pipe executes for those algorithmic flops: 64-column tiles, 4 bf16 terms per product
             dpad = (Dt + 3 + 63) // 64 * 64
@@ -817,7 +964,7 @@ def main():
                                                   'lo.hi%s) on Dt padded to 64 columns; frac above prices only the algorithmic '
                                                   '2 N rows Dt flops against the bf16 peak') % (terms, ' + lo.lo' if terms == 4 else '')}
         if world == 1 and N == 1048576 and Dt == 61 and two_pass:
-            for cname in ('r05_filter_counters.json', 'r04_filter_counters.json'):
+            for cname in ('r06_filter_counters.json', 'r05_filter_counters.json', 'r04_filter_counters.json'):
                 cj, fresh = profiled_counters(cname, 'knn16_kernels.hip')
                 if cj is None or int(cj.get('rows_per_launch', 0)) != int(round(rows_per_launch)):
                     continue
@@ -846,14 +993,10 @@ def main():
                 'note': 'margin = (filter threshold - exact K-th key) / assumed key error eps, over every row of the timed steps: '
                         'the factor by which the true key errors could exceed eps before a row could lose a neighbour; '
                         'prefilter_margin_rows counts the rows under 2 (include/snk.h, DESIGN.md 4.1a, 6.1)'}
-        if with_upload is not None:
-            # SURVEY 8d's wall time (target matrix on host -> path on host): the same pipeline with the query rows crossing
-            # PCIe inside every timed step.  `value` follows the bench contract (inputs resident in HBM when the timed region
-            # starts; value_includes_query_upload says which); this is the host-to-host rate beside it.
-            out['with_upload'] = with_upload
-            out['host_to_host'] = {'value': with_upload['value'], 'unit': 'frames/s', 'ms_per_step': with_upload['ms_per_step'],
-                                   'note': 'SURVEY 8d host -> host: query rows uploaded and paths downloaded inside every timed step (= with_upload)'}
-        out['config']['inputs'] = 'resident in HBM' if resident else 'uploaded from the host every step'
+        if other_mode is not None:
+            out['with_upload' if resident else 'resident_rows'] = other_mode
+        out['config']['inputs'] = ('database resident in HBM; query rows resident too (--resident-rows)' if resident else
+                                   'database resident in HBM; query rows host -> HBM and paths HBM -> host inside every timed step')
         if two_in_flight is not None:
             out['two_in_flight'] = two_in_flight
         if one_in_flight is not None:
@@ -902,8 +1045,9 @@ def main():
             # pass cost, each leg with the roofline of its dominant kernel
             legs = []
             for kind in ('permuted', 'speechlike'):
-                Fv, JCv = variant_database(kind, N, Dt, F_unw, JC_unw)
-                legs.append(shape_leg(eng, 'B*', Fv, JCv, wt, wj, T, U, K, leg_steps, kind=kind, targets_from=F_unw if kind == 'permuted' else None))
+                Fv, JCv, tg = variant_database(kind, N, Dt, F_unw, JC_unw)
+                legs.append(shape_leg(eng, 'B*', Fv, JCv, wt, wj, T, U, K, leg_steps, kind=kind, host_to_host=True,
+                                      targets_from=F_unw if kind == 'permuted' else None, targets=tg))
                 del Fv, JCv
             out['noncompact'] = legs
         if world == 1 and not args.no_shapes:
@@ -917,8 +1061,9 @@ def main():
                 Fs, JCs = synthetic_db(sN, sDt, sDj, seed=0)
                 wts, wjs = np.full(sDt, 0.4), np.full(sDj, 0.05)
                 for kind in kinds:
-                    Fk, JCk = (Fs, JCs) if kind == 'compact' else variant_database(kind, sN, sDt, Fs, JCs)
-                    shapes.append(shape_leg(eng, sname, Fk, JCk, wts, wjs, sT, sU, sK, leg_steps, kind=kind, targets_from=Fs if kind == 'permuted' else None))
+                    Fk, JCk = (Fs, JCs) if kind == 'compact' else variant_database(kind, sN, sDt, Fs, JCs)[:2]
+                    shapes.append(shape_leg(eng, sname, Fk, JCk, wts, wjs, sT, sU, sK, leg_steps, kind=kind, host_to_host=True,
+                                            targets_from=Fs if kind == 'permuted' else None))
                 del Fs, JCs
             out['shapes'] = shapes
         if world == 1 and not args.no_greedy:
@@ -928,17 +1073,17 @@ def main():
             for g in ('greedy_b1', 'greedy_b3'):
                 tripwires[g + '_bound_violations'] = out['extra'][g].get('bound_violations')
                 tripwires[g + '_bound_max_used'] = out['extra'][g].get('bound_max_used')
-        # ---- LAST key, compact: what SURVEY 8d asks for, where a tail of the line still shows it ----
+        # ---- the compact record: the LAST stdout line, what the driver parses (r05's 22.9 KB line did not parse).
+        # Everything else -- stage tables, every leg in full, the notes -- goes to --detail-out. ----
         def brief(leg):
             r = leg.get('roofline', {})
-            return {'frames_per_s': round(leg['frames_per_s']), 'ms_per_step': round(leg['ms_per_step'], 3), 'kernel': r.get('kernel'),
+            return {'frames_per_s': round(leg.get('host_to_host_frames_per_s', leg['frames_per_s'])), 'ms_per_step': round(leg.get('host_to_host_ms_per_step', leg['ms_per_step']), 3),
+                    'rows': 'host -> host' if 'host_to_host_frames_per_s' in leg else 'resident', 'kernel': str(r.get('kernel'))[:40],
                     'bound': r.get('bound'), 'frac': None if r.get('frac') is None else round(r['frac'], 3),
                     'redos': leg['batch_redos'] + leg['prefilter_fallbacks']}
-        summary = {'B*': {'frames_per_s_resident': round(value), 'host_to_host': None if with_upload is None else round(with_upload['value']),
-                          'kernel': out['roofline'].get('kernel', '')[:16].split(' ')[0], 'bound': out['roofline'].get('bound'),
-                          'frac': round(out['roofline'].get('frac', 0.0), 3),
-                          'frac_alone': round(out['roofline'].get('alone', {}).get('frac', 0.0), 3) or None},
-                   'tripwires': tripwires}
+        summary = {'tripwires': tripwires}
+        if other_mode is not None:
+            summary['resident_rows_frames_per_s' if not resident else 'host_to_host_frames_per_s'] = round(other_mode['value'])
         for leg in out.get('noncompact', []):
             summary['B* ' + leg['database']] = brief(leg)
         for leg in out.get('shapes', []):
@@ -946,11 +1091,25 @@ def main():
         if 'extra' in out:
             summary['greedy_us_per_step'] = {'B1': round(out['extra']['greedy_b1']['us_per_step'], 2), 'B3': round(out['extra']['greedy_b3']['us_per_step'], 2),
                                              'B3_frac_hbm': round(out['extra']['greedy_b3']['roofline'].get('frac', 0.0), 3)}
-        if cpu_ref is not None:
-            summary['cpu_frames_per_s'] = {'one_core': round(out['cpu_baseline']['value'], 1),
-                                           'all_cores': round(out['cpu_baseline'].get('all_cores', {}).get('value', 0.0), 1)}
+        if 'other_rooflines' in out:
+            summary['other_rooflines_frac_hbm'] = dict((k, _r(v['frac'], 3)) for k, v in out['other_rooflines'].items())
         out['summary'] = summary
-        print(json.dumps(out))
+        bad = check_rooflines(out)
+        out['roofline_check'] = 'every frac within [0, 1]' if not bad else {'invalid': bad}
+        line = compact_line(out)
+        if args.detail_out:
+            try:
+                dpath = args.detail_out if os.path.isabs(args.detail_out) else os.path.join(ROOT, args.detail_out)
+                os.makedirs(os.path.dirname(dpath) or '.', exist_ok=True)
+                with open(dpath, 'w') as f:
+                    json.dump(out, f, indent=1)
+                line['detail'] = args.detail_out
+            except OSError as ex:
+                line['detail'] = 'not written: %s' % str(ex)[:80]
+        text = json.dumps(line)
+        assert len(text) < 6144 and '\n' not in text, len(text)
+        sys.stdout.flush()
+        print(text, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -4,6 +4,6 @@ The compute path is libsnkhip.so (hand-written HIP for gfx950 behind the C ABI i
 include/snk.h).  There is no CPU fallback: constructing an engine without the library or
 without a gfx950 device raises.
 """
-from .engine import HipSearchEngine, QueryBatch, SnkError, device_count, library_path, load_library  # noqa: F401
+from .engine import HipSearchEngine, QueryBatch, SnkError, configure_runtime, device_count, library_path, load_library  # noqa: F401
 
-__all__ = ['HipSearchEngine', 'QueryBatch', 'SnkError', 'library_path', 'load_library']
+__all__ = ['HipSearchEngine', 'QueryBatch', 'SnkError', 'configure_runtime', 'library_path', 'load_library']

@@ -198,9 +198,9 @@ int snk_create(int device_id, snk_handle *out)
     h->device = device_id;
     h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (h->slabctr.ensure(64)) { delete h; return 1; }
-    if (h->margin_stat.ensure(2 * sizeof(unsigned int))) { delete h; return 1; }
+    if (h->margin_stat.ensure(8 * sizeof(unsigned int))) { delete h; return 1; }
     int rc = create_streams(h);
-    if (!rc) { const unsigned int init[2] = {0u, 0x7f800000u}; rc = h2d_sync(h, h->margin_stat.p, init, sizeof(init)); }
+    if (!rc) { const unsigned int init[8] = {0u, 0x7f800000u, 0u, 0u, 0u, 0u, 0u, 0u}; rc = h2d_sync(h, h->margin_stat.p, init, sizeof(init)); }
     if (rc) { (void)snk_destroy(h); return rc; }
     *out = h;
     return 0;
@@ -264,6 +264,8 @@ int snk_destroy(snk_handle h)
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 4; ++i) { if (h->vit_t0[i]) (void)hipEventDestroy(h->vit_t0[i]); if (h->vit_t1[i]) (void)hipEventDestroy(h->vit_t1[i]); }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->up_stream) (void)hipStreamDestroy(h->up_stream);
+    for (auto &b : h->bslot) if (b.q_up) (void)hipEventDestroy(b.q_up);
     if (h->knn_all_done) (void)hipEventDestroy(h->knn_all_done);
     if (h->knn_mid) (void)hipEventDestroy(h->knn_mid);
     for (auto &t : h->sticket) {

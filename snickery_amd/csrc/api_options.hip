@@ -91,13 +91,13 @@ int snk_reset_timers(snk_handle h)
     for (int i = 0; i < TM_COUNT; ++i) { h->tm_ms[i] = 0; h->tm_n[i] = 0; }
     h->greedy_bound_violations = 0; h->greedy_bound_max_used = 0.0;
     if (h->margin_stat.p && !h->bslot[0].busy && !h->bslot[1].busy && !h->sticket[0].busy && !h->sticket[1].busy) {
-        const unsigned int init[2] = {0u, 0x7f800000u};
+        const unsigned int init[8] = {0u, 0x7f800000u, 0u, 0u, 0u, 0u, 0u, 0u};
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipStreamSynchronize(h->stream));
         CHK(h2d_sync(h, h->margin_stat.p, init, sizeof(init)));
         if (h->vstats.p) {                                     // ... and the tripwire of the join bounds (joinfast_kernels.hip: stats[4], [5])
             for (int i = 0; i < 2; ++i) HIPCHK(hipStreamSynchronize(h->dp_stream[i]));
-            const unsigned long long init2[2] = {0ull, 0xffffffffull};
+            const unsigned long long init2[4] = {0ull, 0xffffffffull, 0ull, 0ull};      // ... and pass 3's counters ([6], [7])
             CHK(h2d_sync(h, reinterpret_cast<char *>(h->vstats.p) + 4 * sizeof(unsigned long long), init2, sizeof(init2)));
         }
     }
@@ -231,6 +231,14 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (!(value >= 0.0 && value <= 5.0) || value != (double)(int)value) return fail("join_bounds_delay must be 0 .. 5");
         CHK(no_batch_in_flight(h, "snk_set_option(join_bounds_delay)"));
         h->join_bounds_delay = (int)value;
+    } else if (!strcmp(name, "upload_stream")) {
+        if (value != 0.0 && value != 1.0) return fail("upload_stream must be 0 or 1");
+        CHK(no_batch_in_flight(h, "snk_set_option(upload_stream)"));
+        h->upload_stream = (int)value;
+    } else if (!strcmp(name, "split_one_group")) {
+        if (value != 0.0 && value != 1.0) return fail("split_one_group must be 0 or 1");
+        CHK(no_batch_in_flight(h, "snk_set_option(split_one_group)"));
+        h->split_one_group = (int)value;
     } else if (!strcmp(name, "join_lb_quadrants")) {
         if (value != 0.0 && value != 1.0) return fail("join_lb_quadrants must be 0 or 1");
         CHK(no_batch_in_flight(h, "snk_set_option(join_lb_quadrants)"));
@@ -361,6 +369,22 @@ int snk_get_info(snk_handle h, const char *name, double *out)
         float r; memcpy(&r, &v[1], 4);
         *out = name[10] == 'm' && name[11] == 'a' ? (double)v[0] : (double)r;
     }
+    else if (!strcmp(name, "finalize_list_entries") || !strcmp(name, "finalize_reranked")) {
+        // since the last snk_reset_timers: list entries the re-rank read ([2..3]) and entries it gave exact float64 distances
+        // ([4..5]) -- what the roofline of knn_finalize_kernel is priced on (bench.py)
+        unsigned long long v[4] = {0, 0, 0, 0};
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        CHK(d2h_sync(h, v, h->margin_stat.p, sizeof(v), h->stream));
+        *out = (double)v[name[9] == 'l' ? 1 : 2];
+    }
+    else if (!strcmp(name, "sparse_exact_costs") || !strcmp(name, "sparse_set_members")) {
+        // pass 3 of the sparse Viterbi path since the last snk_reset_timers: exact costs it took from the rows, members of the
+        // predecessor sets it looked at (natural successors and unusable units cost no row)
+        unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (h->vstats.p) { HIPCHK(hipSetDevice(h->device)); HIPCHK(hipDeviceSynchronize()); CHK(d2h_sync(h, v, h->vstats.p, sizeof(v), h->stream)); }
+        *out = (double)v[name[7] == 'e' ? 6 : 7];
+    }
     else if (!strcmp(name, "prefilter_two_pass")) *out = h->prefilter_two_pass;
     else if (!strcmp(name, "prefilter_balls")) *out = h->prefilter_balls;
     else if (!strcmp(name, "prefilter_ball_bound")) *out = h->prefilter_ball_bound;
@@ -389,6 +413,8 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "viterbi_fst32_slack")) *out = h->fst32_slack;
     else if (!strcmp(name, "join_lb_quadrants")) *out = get_join_lb_quadrants();
     else if (!strcmp(name, "join_bounds_delay")) *out = h->join_bounds_delay;
+    else if (!strcmp(name, "split_one_group")) *out = h->split_one_group;
+    else if (!strcmp(name, "upload_stream")) *out = h->upload_stream;
     else if (!strcmp(name, "viterbi_refine_gate")) *out = h->vit_refine_gate;
     else if (!strcmp(name, "viterbi_latch_mode")) *out = h->vit.mode;                 // 0: batches take the sparse path, 1: the dense kernels (judged, snk_engine.h)
     else if (!strcmp(name, "viterbi_latch_switches")) *out = (double)h->vit.switches;

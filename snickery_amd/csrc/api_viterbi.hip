@@ -243,7 +243,7 @@ int snk_knn_viterbi(snk_handle h, const double *Q, int64_t T, int D, int K, int6
 // so one sweep over the database serves every utterance of the group and the per-call stages
 // (sample minima, thresholds, bucket, re-rank) amortise.  first[g] .. first[g+1] are the utterances
 // of group g.
-std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offsets, int n_utts)
+std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offsets, int n_utts, bool knn_beside)
 {
     std::vector<int> first(1, 0);
     // as few groups as batch_rows allows, of equal size and an even number of them: two groups of 16 utterances take a
@@ -255,8 +255,10 @@ std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offset
         int64_t n_groups = (total + h->batch_rows - 1) / h->batch_rows;
         if (n_groups > 1 && (n_groups & 1)) ++n_groups;       // groups alternate between two workspaces and side streams
         // a batch that fits one group, but is long: two, so that the first one's Viterbi side runs beside the second one's K-NN
-        // (B5, 64 x 120 rows: 1.86 -> 1.91 M frames/s)
-        if (n_groups == 1 && total >= 6144 && n_utts >= 2) n_groups = 2;
+        // (B5, 64 x 120 rows: 1.86 -> 1.91 M frames/s).  Only where there IS a K-NN to run beside (the K-NN batch entry points:
+        // knn_beside); callers that bring their candidates (snk_viterbi_batch, the merged lists of a sharded step) keep one group,
+        // one launch of every pass.  Option split_one_group 0 keeps one group everywhere.
+        if (knn_beside && h->split_one_group && n_groups == 1 && total >= 6144 && n_utts >= 2) n_groups = 2;
         target = (total + n_groups - 1) / n_groups;
     }
     int64_t rows = 0;
@@ -392,7 +394,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     const int slot = h->bslot[h->bnext].busy ? (h->bnext ^ 1) : h->bnext;
     BatchSlot &b = h->bslot[slot];
     if (b.busy) return fail("snk_knn_viterbi_batch_submit: two batches are in flight already (collect one first)");
-    b.first = group_utterances(h, row_offsets, n_utts);
+    b.first = group_utterances(h, row_offsets, n_utts, true);
     b.n_groups = (int)b.first.size() - 1;
     b.n_utts = n_utts; b.K = K; b.D = D; b.total = total;
     b.offs.assign(row_offsets, row_offsets + n_utts + 1);
@@ -428,8 +430,24 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     b.probe_kind.assign((size_t)b.n_groups, 0);
     b.probe_limit.assign((size_t)b.n_groups, 0.0);
     if (Q) {
-        StageTimer t(h, h->stream, TM_H2D);
-        CHK(h2d_via(b.qstage, b.Qall.p, Q, (size_t)total * D * sizeof(double), h->stream));
+        // The rows travel on a stream of their own: this workspace is idle (its last batch was collected), so the copy needs to
+        // wait for nothing and runs on a DMA engine beside the batch before this one; the main stream only waits for its event.
+        // On the main stream (until round 5) the K-NN stream stood still for the 0.2 ms the 9.4 MB of a B* step take to cross
+        // PCIe -- the 6 % between the host -> host and the resident-rows rate.
+        hipStream_t us = h->stream;
+        if (h->upload_stream) {
+            if (!h->up_stream) HIPCHK(hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
+            if (!b.q_up) HIPCHK(hipEventCreateWithFlags(&b.q_up, hipEventDisableTiming));
+            us = h->up_stream;
+        }
+        {
+            StageTimer t(h, us, TM_H2D);
+            CHK(h2d_via(b.qstage, b.Qall.p, Q, (size_t)total * D * sizeof(double), us));
+        }
+        if (us != h->stream) {
+            HIPCHK(hipEventRecord(b.q_up, us));
+            HIPCHK(hipStreamWaitEvent(h->stream, b.q_up, 0));
+        }
         if (!h->tsel.empty()) launch_mask_columns(b.Qall.as<double>(), total, D, h->tmask.as<double>(), h->stream);
         b.q_rows = total; b.q_D = D;
         b.q_offs.assign(row_offsets, row_offsets + n_utts + 1);
@@ -623,7 +641,7 @@ int snk_viterbi_batch(snk_handle h, const int64_t *cand, const double *tdist, co
         CHK(h2d(h, h->mdist.p, tdist, (size_t)total * K * sizeof(double), h->stream));
     }
     {
-        const std::vector<int> first = group_utterances(h, row_offsets, n_utts);
+        const std::vector<int> first = group_utterances(h, row_offsets, n_utts, false);
         for (int g = 0; g + 1 < (int)first.size(); ++g)
             CHK(viterbi_group(h, g, row_offsets, first[g], first[g + 1], K, h->mcand.as<int64_t>(), h->mdist.as<double>(), true,
                               nullptr, nullptr, nullptr, n_utts));

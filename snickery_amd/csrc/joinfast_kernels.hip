@@ -674,6 +674,13 @@ join_exact_sparse2_kernel(const float *__restrict__ JC_unw, int Jp, int Dj, cons
         if (need & (1u << j)) item_s[base++] = (unsigned short)((tid << 2) | j);
     __syncthreads();
     const int total = total_s;
+    if (stats) {                                             // what the kernel's roofline is priced on (snk_get_info sparse_exact_costs / sparse_set_members)
+        if (tid == 0 && total) atomicAdd(&stats[6], (unsigned long long)total);
+        int mem = n;
+#pragma unroll
+        for (int m = 1; m <= 32; m <<= 1) mem += __shfl_xor(mem, m, 64);
+        if (lane == 0 && mem) atomicAdd(&stats[7], (unsigned long long)mem);
+    }
     const int n_chunks = (Dj + 15) / 16;
     const int g4 = lane >> 2, q = lane & 3;                 // loader role: rows 4 g4 + i, columns 4 q .. 4 q + 3 of the chunk
     float *const tE = tile[wv][0], *const tS = tile[wv][1];

@@ -1081,6 +1081,10 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
         __syncthreads();
     }
     const int n_sel = n_sel_s;
+    if (margin_stat && threadIdx.x == 0) {                  // what the kernel's roofline is priced on (snk_get_info: finalize_*)
+        atomicAdd(reinterpret_cast<unsigned long long *>(margin_stat) + 1, (unsigned long long)n);
+        atomicAdd(reinterpret_cast<unsigned long long *>(margin_stat) + 2, (unsigned long long)n_sel);
+    }
     // exact squared distance in the canonical order: acc = acc + (q_c - f_c)*(q_c - f_c),
     // c ascending, separately rounded sub / mul / add (bit-identical to the oracle)
     int SP = 256;                         // sort size: the selection, padded to a power of two

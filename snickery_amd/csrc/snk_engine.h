@@ -187,6 +187,7 @@ struct BatchSlot {    // one submitted batch (snk_knn_viterbi_batch_submit / _co
     // submit queues them behind a point inside its own first K-NN call, a collect that comes first queues them as they are
     bool tail_pending = false;
     hipEvent_t knn_end = nullptr;         // everything this batch queued on the main stream
+    hipEvent_t q_up = nullptr;            // this batch's query rows have arrived in Qall (recorded on the upload stream)
     int64_t total = 0;
     std::vector<int> first;
     std::vector<int64_t> offs;
@@ -207,6 +208,8 @@ struct ShardTicket {   // one submitted step of the sharded search (snk_sharded_
 struct snk_engine {
     int device = 0;
     hipStream_t stream = nullptr, stream2 = nullptr, copy_stream = nullptr;
+    hipStream_t up_stream = nullptr;       // query rows of a submitted batch: host -> HBM beside the batch before it (created at the first submit)
+    int upload_stream = 1;                 // option: 0 = the rows are uploaded on the main stream, as until round 5
     BatchSlot bslot[2];
     int bnext = 0;
     hipEvent_t knn_all_done = nullptr;
@@ -256,6 +259,7 @@ struct snk_engine {
     // SAME batch only (the side stream cannot wait for what is not queued yet) -- where the shape makes it pay (api_viterbi.hip);
     // 3 / 4: 1 / 2 whatever the shape.  knn_mid: where group g + 1 stands (api_knn.hip)
     int join_bounds_delay = 1;
+    int split_one_group = 1;   // a long batch that fits one K-NN call is cut into two groups (K-NN batch entry points only)
     hipEvent_t knn_mid = nullptr;
     bool knn_mid_recorded = false;
     int prefilter = 1;            // 1: bf16-split operands on the bf16 matrix pipe where the shape has a variant, 0: float32 operands
@@ -489,7 +493,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
 
 // Viterbi side of a group of utterances (api_viterbi.hip)
 bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts = 1);
-std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offsets, int n_utts);
+std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offsets, int n_utts, bool knn_beside);
 int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u0, int u1, int K,
                   const int64_t *cand_all, const double *tdist_all, bool side_stream,
                   int64_t *res_path = nullptr, int64_t *res_plen = nullptr, double *res_cost = nullptr,

@@ -122,6 +122,17 @@ def device_count():
     return int(n.value)
 
 
+def configure_runtime(hw_queues=8):
+    """OPT-IN process-wide tuning of the ROCm runtime, for callers that own the process (bench.py, a tuning job): an engine works on
+    four streams (K-NN, two Viterbi sides, copies) and the runtime maps a process's streams onto four hardware queues by default --
+    beside a framework's own streams two of them then share one (measured + 1..3 % on the B* step with eight).  Sets
+    GPU_MAX_HW_QUEUES unless the caller's environment already chose a number.  The runtime reads it when it STARTS: call this before
+    anything touches the GPU (before `import torch` initialises it, before the first engine).  Importing the package never does this
+    by itself.  Returns the value now in the environment."""
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', str(int(hw_queues)))
+    return os.environ['GPU_MAX_HW_QUEUES']
+
+
 def load_library():
     """Load libsnkhip.so and bind every symbol of include/snk.h.  Raises SnkError when the
     library has not been built (``python -c 'import __graft_entry__ as g; g.build()'`` or
@@ -133,10 +144,6 @@ def load_library():
     if not os.path.isfile(path):
         raise SnkError('%s not found: build it with `make` (hipcc --offload-arch=gfx950); '
                        'there is no CPU fallback' % path)
-    # An engine works on four streams (K-NN, two Viterbi sides, copies) and the ROCm runtime maps a process's streams onto four
-    # hardware queues by default -- beside a framework's own streams two of them then share one.  Eight queues, unless the caller
-    # chose a number (read when the runtime starts: effective if nothing has touched the GPU yet; measured +1..3 % on the B* step).
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the export is missing

@@ -311,3 +311,42 @@ def test_baseline_shapes_stay_on_the_fast_path(engine, N, Dt, Dj, T, K, U):
     JCw = o.weight(JC_unw, wj)
     opath, ocost = oc.viterbi(cand, dist, JCw)
     assert [int(v) for v in paths[0]] == opath and costs[0] == ocost
+
+
+def test_speechlike_voice_at_headline_size(engine):
+    """bench.py's speech-like leg at its own size: N = 1 048 576 units whose target AND join features are AR(1)
+    walks (consecutive frames a sizeable fraction of the data's spread apart: no compact tiles, no near-contiguous candidates,
+    join bounds that prune little), utterances from a HELD-OUT walk.  Sixteen query rows against the C oracle's brute force
+    over the whole database, the whole Viterbi of every utterance of a batch against the C oracle's recursion, tripwires clean."""
+    from bench import speechlike_voice
+    N, Dt, Dj, T, K, U = 1048576, 61, 302, 600, 100, 4
+    F_unw, JC_unw, held_out = speechlike_voice(N, Dt, Dj, seed=0)
+    wt, wj = np.full(Dt, 0.4), np.full(Dj, 0.05)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    utts = [held_out(T, u) * wt for u in range(U)]
+    engine.reset_timers()
+    for _ in range(3):                              # the engine judges the voice (filter latch, unit order, Viterbi path) over its first batches
+        paths, costs = engine.knn_viterbi_batch(utts, K)
+    assert engine.info('exact_row_fallbacks') == 0
+    assert engine.info('prefilter_margin_rows') == 0 and engine.info('join_bound_violations') == 0
+    cd = [engine.knn(u, K) for u in utts]
+    F = o.weight(F_unw, wt)
+    rows = np.unique(np.linspace(0, T - 1, 16).astype(np.int64))
+    oc_cand, oc_dist = oc.knn(F, utts[0][rows], K)
+    assert np.array_equal(cd[0][0][rows], oc_cand) and np.array_equal(cd[0][1][rows], oc_dist)
+    # a held-out frame's neighbours are strangers: not runs of consecutive units (what SURVEY 8d's walk gives)
+    runs = np.mean(np.diff(np.sort(cd[0][0], axis=1), axis=1) == 1)
+    assert runs < 0.2, runs
+    del F
+    JCw = o.weight(JC_unw, wj)
+    for u in range(U):
+        opath, ocost = oc.viterbi(cd[u][0], cd[u][1], JCw)
+        assert [int(v) for v in paths[u]] == opath and costs[u] == ocost
+    # the dense exact kernels (what the Viterbi latch may pick for such a voice) return the same
+    engine.set_option('viterbi_mode', 0)
+    try:
+        p0, c0 = engine.knn_viterbi_batch(utts, K)
+    finally:
+        engine.set_option('viterbi_mode', 2)
+    assert all(np.array_equal(a, b) for a, b in zip(paths, p0)) and np.array_equal(costs, c0)

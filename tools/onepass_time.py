@@ -13,7 +13,7 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 9600
 F0, JC0 = synthetic_db(N, Dt, Dj, seed=0)
 wt = np.full(Dt, 0.4); wj = np.full(Dj, 0.05)
 for kind in ('compact', 'permuted', 'speechlike'):
-    F_unw, JC_unw = (F0, JC0) if kind == 'compact' else variant_database(kind, N, Dt, F0, JC0)
+    F_unw, JC_unw = (F0, JC0) if kind == "compact" else variant_database(kind, N, Dt, F0, JC0)[:2]
     # a permuted voice keeps the speech its units were cut from: the rows follow the walk through the ORIGINAL order
     src = F0 if kind == 'permuted' else F_unw
     U = np.vstack([synthetic_targets(src, 600, seed=1 + s) * wt for s in range((rows + 599) // 600)])[:rows]
