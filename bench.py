@@ -402,33 +402,38 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
     return out
 
 
-def other_rooflines(timers, counts, rows, K, Dt, Dj):
-    """Rooflines of the two whole-chip kernels that had none until round 5, from the engine's HIP-event stage
-    timers over the timed steps and the kernels' own counters (snk_get_info):
-      join_exact_sparse2_kernel (pass 3): per exact cost two float32 rows of Dj columns (the rows are read in 64-byte pieces by
-        four neighbouring lanes and pass through LDS once; nothing is shared between costs) + per cell its set (16 B), candidate
-        (8 B), target distance (8 B) read and its record (64 B) written; beside the bytes, 5 separately rounded float64 operations
-        per column and cost (2 mul, sub, mul, add: the canonical order) against the non-FMA float64 vector rate (39.3 T op/s);
+def other_rooflines(timers, counts, rows, K, Dt, Dj, T):
+    """Rooflines of the two whole-chip kernels that had none until round 5: durations from the engine's
+    HIP-event stage timers over the timed steps, byte counts from the kernels' own counters (snk_get_info) taken in a separate
+    two-step counting pass of the same batch (the counts per launch are a property of the batch):
+      join_exact_sparse2_kernel (pass 3): per exact cost two float32 rows of Dj columns -- but never more than the 2 K rows a
+        step HAS (costs that share a row meet it again in L2; a cell has up to four predecessors) -- + per cell its set (16 B),
+        candidate (8 B), target distance (8 B) read and its record (64 B) written; beside the bytes, 5 separately rounded
+        float64 operations per column and cost (2 mul, sub, mul, add: the canonical order) against the non-FMA float64 vector
+        rate (39.3 T op/s);
       knn_finalize_kernel: per list entry its 8-byte key, per re-ranked entry its id (4 B) and its float32 row (Dt columns padded
         to 4), per row K results (16 B each) and the query row (8 B per column).
     `traffic` (counter bytes) is added by tools/summarise_round6.py from --pmc passes (profiles/r06_*_summary.md)."""
     out = {}
     def stage(name):
         return (timers[name][0] / timers[name][1], timers[name][1]) if name in timers and timers[name][1] else (0.0, 0)
+    nl = counts.get('launches', {})
     ms, n = stage('join_exact_sparse')
-    if n and counts.get('sparse_exact_costs', 0) > 0:
-        costs = counts['sparse_exact_costs'] / n
-        cells = rows * K / n
-        b = costs * 2 * Dj * 4 + cells * (16 + 8 + 8 + 64)
+    if n and nl.get('join_exact_sparse') and counts.get('sparse_exact_costs', 0) > 0:
+        costs = counts['sparse_exact_costs'] / nl['join_exact_sparse']
+        rpl = rows / n
+        cells = rpl * K
+        row_fetches = min(2.0 * costs, 2.0 * K * max(rpl - rpl / max(T, 1), 1.0))
+        b = row_fetches * Dj * 4 + cells * (16 + 8 + 8 + 64)
         ops = costs * Dj * 5.0
         out['join_exact_sparse2_kernel'] = {
             'bound': 'hbm', 'achieved': b / (ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': b / (ms * 1e-3) / 8e12,
-            'avg_launch_ms': ms, 'launches': n, 'exact_costs_per_launch': costs, 'set_members_per_launch': counts.get('sparse_set_members', 0) / n,
-            'cells_per_launch': cells, 'algorithmic_bytes_per_launch': b, 'f64_vector_ops_per_launch': ops,
+            'avg_launch_ms': ms, 'launches': n, 'exact_costs_per_launch': costs, 'set_members_per_launch': counts.get('sparse_set_members', 0) / nl['join_exact_sparse'],
+            'cells_per_launch': cells, 'row_fetches_per_launch': row_fetches, 'algorithmic_bytes_per_launch': b, 'f64_vector_ops_per_launch': ops,
             'f64_vector_frac': ops / (ms * 1e-3) / 39.3e12, 'traffic': None}
     ms, n = stage('knn_finalize')
-    if n and counts.get('finalize_list_entries', 0) > 0:
-        ent, sel = counts['finalize_list_entries'] / n, counts['finalize_reranked'] / n
+    if n and nl.get('knn_finalize') and counts.get('finalize_list_entries', 0) > 0:
+        ent, sel = counts['finalize_list_entries'] / nl['knn_finalize'], counts['finalize_reranked'] / nl['knn_finalize']
         rpl = rows / n
         fp = (Dt + 3) // 4 * 4
         b = ent * 8 + sel * (4 + fp * 4) + rpl * (K * 16 + Dt * 8)
@@ -729,7 +734,8 @@ def main():
     timers = eng.timers()
     # counters the rooflines of the two kernels without one until round 5 are priced on, read before any
     # other pass adds to them: exact costs pass 3 took from the rows, list entries the re-rank read / gave exact distances
-    roof_counts = dict((k, eng.info(k)) for k in ('sparse_exact_costs', 'sparse_set_members', 'finalize_list_entries', 'finalize_reranked')) if world == 1 else {}
+    roof_counts = {}
+    trip_main = dict((k, eng.info(k)) for k in ('prefilter_margin_rows', 'prefilter_min_margin', 'join_bound_violations', 'join_bound_min_margin')) if world == 1 else {}
     # N > 1, database sharded: the same GPUs as independent replicas (every GPU the whole database -- B* needs 3.5 GB of
     # 288 -- and its own 32 utterances, no collective), timed the same way: an extra field, never `value`.  Sharding is for
     # databases beyond one GPU's memory; for one that fits, this is what the exchange costs.
@@ -779,6 +785,18 @@ def main():
                       'same_results': bool(all(np.array_equal(a, b) for a, b in zip(pu, paths)) and np.array_equal(cu, costs)),
                       'note': ('the query rows (%.1f MB per step) cross PCIe inside every timed step, from page-locked host memory' % (batch.Q.nbytes / 1e6)) if resident else
                               'the query rows searched where two untimed priming submits left them in HBM (Q == NULL): a mode no caller of the package uses'}
+    if world == 1:
+        # the counting pass (untimed, two steps): the kernels add up what their rooflines are priced on only while option
+        # roofline_counters is on -- thousands of workgroups adding to one address cost 0.3-0.4 ms per launch (profiles/r06_a)
+        eng.set_option('roofline_counters', 1)
+        eng.reset_timers()
+        for _ in range(2):
+            eng.knn_viterbi_batch(batch, K)
+        tmc = eng.timers()
+        roof_counts = dict((k, eng.info(k)) for k in ('sparse_exact_costs', 'sparse_set_members', 'finalize_list_entries', 'finalize_reranked'))
+        roof_counts['launches'] = {'join_exact_sparse': tmc.get('join_exact_sparse', (0, 0))[1], 'knn_finalize': tmc.get('knn_finalize', (0, 0))[1]}
+        eng.set_option('roofline_counters', 0)
+        eng.reset_timers()
     # a second, separately timed pass in the OTHER submission mode (an extra field, never `value`)
     two_in_flight = one_in_flight = None
     if world == 1 and args.in_flight == 1:
@@ -941,7 +959,7 @@ def main():
         else:
             out['roofline'] = dict(out['filter_stage'])
         if world == 1 and roof_counts:
-            out['other_rooflines'] = other_rooflines(timers, roof_counts, rows_swept, K, Dt, Dj)
+            out['other_rooflines'] = other_rooflines(timers, roof_counts, rows_swept, K, Dt, Dj, T)
         if bf16_mode:
             # what the matrix pipe executes for those algorithmic flops: 64-column tiles, 4 bf16 terms per product
             dpad = (Dt + 3 + 63) // 64 * 64
@@ -980,7 +998,7 @@ def main():
             # tripwire of the bf16-split prefilter's key bound (untimed, after the timed region): the same step with the
             # float32-operand prefilter, whose bound is the analytical one of an f32 FMA chain, must select the same units;
             # and how close the exact K-th keys of the timed steps came to the filter thresholds (include/snk.h)
-            margin_rows, min_margin = eng.info('prefilter_margin_rows'), eng.info('prefilter_min_margin')
+            margin_rows, min_margin = trip_main.get('prefilter_margin_rows', eng.info('prefilter_margin_rows')), trip_main.get('prefilter_min_margin', eng.info('prefilter_min_margin'))
             pre_was = eng.info('prefilter')
             eng.set_option('prefilter', 0)
             eng.set_weights(wt, wj)
@@ -1013,8 +1031,8 @@ def main():
             out['cpu_baseline']['gpu_matches_cpu_path'] = bool(gp == ref[2])
             out['cpu_baseline']['gpu_matches_cpu_candidates'] = bool(np.array_equal(gcand, ref[0]))
         # the three tripwires of the probed MFMA accumulation bound, over the timed B* steps (before any other voice is uploaded)
-        tripwires = {'prefilter_margin_rows': eng.info('prefilter_margin_rows'), 'prefilter_min_margin': eng.info('prefilter_min_margin'),
-                     'join_bound_violations': eng.info('join_bound_violations'), 'join_bound_min_margin': eng.info('join_bound_min_margin')}
+        tripwires = dict(trip_main) if trip_main else {'prefilter_margin_rows': eng.info('prefilter_margin_rows'), 'prefilter_min_margin': eng.info('prefilter_min_margin'),
+                                                        'join_bound_violations': eng.info('join_bound_violations'), 'join_bound_min_margin': eng.info('join_bound_min_margin')}
         if 'prefilter_tripwire' in out:
             tripwires['gpu_matches_f32_prefilter'] = out['prefilter_tripwire']['gpu_matches_f32_prefilter']
         if world == 1 and args.viterbi_mode and isinstance(out.get('roofline'), dict) and 'join_lb2' in str(out['roofline'].get('kernel', '')):

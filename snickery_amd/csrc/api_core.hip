@@ -548,22 +548,32 @@ static int mean_tile_radius(snk_engine *h, double *out)
     return 0;
 }
 
-int reorder_units(snk_engine *h)
+// The order only buys speed: whatever goes wrong in here (an allocation on a nearly full device, a launch, a copy, an order that
+// is no permutation) must not fail the caller's K-NN call -- reorder_units() below catches it, puts the operands back in the
+// order they had and carries on.  *swapped: h->perm / h->perm2 are exchanged at the moment of the failure.
+static int reorder_units_try(snk_engine *h, bool *swapped, bool had)
 {
-    h->reorder_pending = false;
-    h->reorder_done = true;
-    if (!h->have_db || !h->have_weights || !kmeans_supported(h->Dt) || h->N < 4096 || h->ball_tiles < 1) return 0;
     double r_old = 0.0, r_new = 0.0;
     CHK(mean_tile_radius(h, &r_old));
     CHK(h->perm2.ensure((size_t)h->N * sizeof(int32_t)));
-    CHK(h->km_ws.ensure(kmeans_workspace_bytes(h->N, h->Dt)));
+    size_t ws = kmeans_workspace_bytes(h->N, h->Dt);
+    if (ws < kmeans_perm_check_bytes(h->N)) ws = kmeans_perm_check_bytes(h->N);
+    CHK(h->km_ws.ensure(ws));
     {
         StageTimer t(h, h->stream, TM_WEIGHTS);
         launch_kmeans_order(h->Fw.as<double>(), h->N, h->Dt, h->Dpad, h->reorder_iters, h->km_ws.p, h->perm2.as<int32_t>(), h->stream);
     }
     HIPCHK(hipGetLastError());
-    const bool had = h->perm_ready;
+    {
+        // a bad order would silently drop units from the prefilter: every unit must appear exactly once (non-finite features
+        // can break the chains' argmins)
+        launch_perm_check(h->perm2.as<int32_t>(), h->N, h->km_ws.p, h->stream);
+        unsigned int bad = 1u;
+        CHK(d2h_sync(h, &bad, h->km_ws.p, sizeof(bad), h->stream));
+        if (bad) return fail("reorder: the clustered order is not a permutation of the units (%u bad entries)", bad);
+    }
     std::swap(h->perm, h->perm2);
+    *swapped = true;
     h->perm_ready = true;
     CHK(build_prefilter_operands(h));
     HIPCHK(hipGetLastError());
@@ -573,9 +583,29 @@ int reorder_units(snk_engine *h)
     // the clusters' tiles are no tighter than the order the voice had (consecutive frames of a frame-level voice questioned by a
     // batch of far-away rows; units spread like a cloud): that order stays, and the voice is not clustered again
     std::swap(h->perm, h->perm2);
+    *swapped = false;
     h->perm_ready = had;
     h->reorder_useless = true;
     CHK(build_prefilter_operands(h));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int reorder_units(snk_engine *h)
+{
+    h->reorder_pending = false;
+    h->reorder_done = true;
+    if (!h->have_db || !h->have_weights || !kmeans_supported(h->Dt) || h->N < 4096 || h->ball_tiles < 1) return 0;
+    const bool had = h->perm_ready;
+    bool swapped = false;
+    if (reorder_units_try(h, &swapped, had) == 0) return 0;
+    // failed: the voice keeps the order it had and is not asked again (until the weights change); the caller's search goes on
+    (void)hipGetLastError();
+    h->reorder_failures += 1;
+    h->reorder_useless = true;
+    if (swapped) std::swap(h->perm, h->perm2);
+    h->perm_ready = had;
+    CHK(build_prefilter_operands(h));         // (this one must work: the operands may be half rebuilt)
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -91,7 +91,7 @@ int snk_reset_timers(snk_handle h)
     for (int i = 0; i < TM_COUNT; ++i) { h->tm_ms[i] = 0; h->tm_n[i] = 0; }
     h->greedy_bound_violations = 0; h->greedy_bound_max_used = 0.0;
     if (h->margin_stat.p && !h->bslot[0].busy && !h->bslot[1].busy && !h->sticket[0].busy && !h->sticket[1].busy) {
-        const unsigned int init[8] = {0u, 0x7f800000u, 0u, 0u, 0u, 0u, 0u, 0u};
+        const unsigned int init[8] = {0u, 0x7f800000u, 0u, 0u, 0u, 0u, (unsigned int)h->roofline_counters, 0u};
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipStreamSynchronize(h->stream));
         CHK(h2d_sync(h, h->margin_stat.p, init, sizeof(init)));
@@ -231,6 +231,21 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (!(value >= 0.0 && value <= 5.0) || value != (double)(int)value) return fail("join_bounds_delay must be 0 .. 5");
         CHK(no_batch_in_flight(h, "snk_set_option(join_bounds_delay)"));
         h->join_bounds_delay = (int)value;
+    } else if (!strcmp(name, "roofline_counters")) {
+        if (value != 0.0 && value != 1.0) return fail("roofline_counters must be 0 or 1");
+        CHK(no_batch_in_flight(h, "snk_set_option(roofline_counters)"));
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipDeviceSynchronize());
+        h->roofline_counters = (int)value;
+        const unsigned int on = (unsigned int)h->roofline_counters;
+        CHK(h2d_sync(h, reinterpret_cast<char *>(h->margin_stat.p) + 6 * sizeof(unsigned int), &on, sizeof(on)));
+        if (!h->vstats.p) {
+            CHK(h->vstats.ensure((128 + 16 * 1024) * sizeof(unsigned long long)));
+            HIPCHK(hipMemset(h->vstats.p, 0, 128 * sizeof(unsigned long long)));
+            HIPCHK(hipMemset(reinterpret_cast<char *>(h->vstats.p) + 5 * sizeof(unsigned long long), 0xff, 4));
+        }
+        const unsigned long long on64 = on;
+        CHK(h2d_sync(h, reinterpret_cast<char *>(h->vstats.p) + 8 * sizeof(unsigned long long), &on64, sizeof(on64)));
     } else if (!strcmp(name, "upload_stream")) {
         if (value != 0.0 && value != 1.0) return fail("upload_stream must be 0 or 1");
         CHK(no_batch_in_flight(h, "snk_set_option(upload_stream)"));
@@ -401,6 +416,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "reorder")) *out = h->reorder;
     else if (!strcmp(name, "reordered")) *out = h->perm_ready ? 1 : 0;               // 1: the prefilter's operands stand in an order the engine chose (kmeans_kernels.hip)
     else if (!strcmp(name, "reorders")) *out = (double)h->reorders;
+    else if (!strcmp(name, "reorder_failures")) *out = (double)h->reorder_failures;
     else if (!strcmp(name, "reorder_useless")) *out = h->reorder_useless ? 1 : 0;
     else if (!strcmp(name, "debug_perm_ptr")) *out = (double)(uintptr_t)(h->perm_ready ? h->perm.p : nullptr);     // developer aid: snk_copy_to_host reads it
     else if (!strcmp(name, "debug_ball_rad_ptr")) *out = (double)(uintptr_t)h->ball_rad.p;
@@ -415,6 +431,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "join_bounds_delay")) *out = h->join_bounds_delay;
     else if (!strcmp(name, "split_one_group")) *out = h->split_one_group;
     else if (!strcmp(name, "upload_stream")) *out = h->upload_stream;
+    else if (!strcmp(name, "roofline_counters")) *out = h->roofline_counters;
     else if (!strcmp(name, "viterbi_refine_gate")) *out = h->vit_refine_gate;
     else if (!strcmp(name, "viterbi_latch_mode")) *out = h->vit.mode;                 // 0: batches take the sparse path, 1: the dense kernels (judged, snk_engine.h)
     else if (!strcmp(name, "viterbi_latch_switches")) *out = (double)h->vit.switches;

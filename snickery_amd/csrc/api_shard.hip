@@ -743,29 +743,85 @@ int snk_sharded_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *
 // greedy search with the scan of every step split over the ranks (include/snk.h).  Host-driven: a step is the rank's scan
 // launch, one all-gather of 16 bytes per rank, the pick launch -- queued on the engine's stream without a host wait between
 // them over RCCL (a transport's callbacks synchronise themselves).
+// Collective verdict before the first step: every rank brings (ok, T, D, start_state) -- ok = its own preconditions
+// and allocations held -- and all ranks gather all records; unless every rank is ok and the arguments agree, EVERY rank returns
+// an error here, with nothing in flight.  (A rank without a communicator cannot tell anybody: that stays a local error.)
+static int sharded_greedy_preflight(snk_engine *h, bool ok, int64_t T, int D, int64_t start_state, const std::string &why)
+{
+    const int G = h->comm_ranks, me = h->comm_rank;
+    CHK(h->gshard.ensure((size_t)32 * (G + 1) + (size_t)16 * (G + 1)));
+    int64_t rec[4] = {ok ? 1 : 0, T, (int64_t)D, start_state};
+    char *base = reinterpret_cast<char *>(h->gshard.p) + (size_t)16 * (G + 1);
+    CHK(h2d(h, base, rec, sizeof(rec), h->stream));
+    CHK(comm_all_gather(h, base, base + 32, 32));
+    std::vector<int64_t> all((size_t)4 * G);
+    CHK(d2h_sync(h, all.data(), base + 32, (size_t)32 * G, h->stream));
+    for (int r = 0; r < G; ++r)
+        if (all[(size_t)4 * r] != 1)
+            return r == me ? fail("%s [refused on every rank]", why.c_str())
+                           : fail("snk_sharded_greedy: rank %d refused the call (its preconditions or allocations failed): refused on every rank", r);
+    for (int r = 0; r < G; ++r)
+        if (all[(size_t)4 * r + 1] != T || all[(size_t)4 * r + 2] != D || all[(size_t)4 * r + 3] != start_state)
+            return fail("snk_sharded_greedy: the ranks disagree about the call (rank %d: T=%lld D=%lld start_state=%lld, rank %d: T=%lld D=%d start_state=%lld)",
+                        r, (long long)all[(size_t)4 * r + 1], (long long)all[(size_t)4 * r + 2], (long long)all[(size_t)4 * r + 3], me, (long long)T, D, (long long)start_state);
+    return 0;
+}
+
+static int sharded_greedy_steps(snk_engine *h, int64_t nsteps, int64_t start_state, int64_t *path_out, double *dist_out);
+
 int snk_sharded_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t start_state,
                        int64_t *path_out, double *dist_out, int64_t *nsteps_out)
 {
-    CHK(check_ready(h, true, true));
-    CHK(no_batch_in_flight(h, "snk_sharded_greedy"));
+    if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
     if (h->comm_ranks < 1) return fail("snk_sharded_greedy: no communicator (snk_comm_init)");
-    if (!h->have_glay) return fail("snk_sharded_greedy: greedy layout not set (snk_set_greedy_layout)");
-    if (h->shard_offset != 0 || (h->global_N > 0 && h->global_N != h->N))
-        return fail("snk_sharded_greedy: every rank holds the whole database (this engine holds a shard of it)");
-    if (!path_out || !nsteps_out) return fail("snk_sharded_greedy: null output");
-    const GreedyLayout &g = h->glay;
-    if (start_state >= g.Nwin) return fail("snk_sharded_greedy: start_state %lld out of range", (long long)start_state);
-    CHK(upload_queries(h, Q, T, D));
-    const int64_t nsteps = T / g.me;
+    if (h->comm_dead) return fail("snk_sharded_greedy: the communicator was aborted after a local error (snk_comm_init again, on every rank)");
+    // ---- this rank's own preconditions: noted, not returned -- the verdict is collective ----
+    std::string why;
+    bool ok = true;
+    auto refuse = [&](int rc) { if (rc && ok) { ok = false; why = last_error_string(); } return rc; };
+    refuse(check_ready(h, true, true));
+    if (ok) refuse(no_batch_in_flight(h, "snk_sharded_greedy"));
+    if (ok && !h->have_glay) refuse(fail("snk_sharded_greedy: greedy layout not set (snk_set_greedy_layout)"));
+    if (ok && (h->shard_offset != 0 || (h->global_N > 0 && h->global_N != h->N)))
+        refuse(fail("snk_sharded_greedy: every rank holds the whole database (this engine holds a shard of it)"));
+    if (ok && (!path_out || !nsteps_out)) refuse(fail("snk_sharded_greedy: null output"));
+    if (ok && start_state >= h->glay.Nwin) refuse(fail("snk_sharded_greedy: start_state %lld out of range", (long long)start_state));
+    if (ok && (!Q || D != h->Dt || T < 0)) refuse(fail("snk_sharded_greedy: query matrix has %d columns (database: %d), %lld rows", D, h->Dt, (long long)T));
+    int64_t nsteps = 0;
+    if (ok) {
+        const GreedyLayout &g = h->glay;
+        nsteps = T / g.me;
+        // everything that can fail locally before the first step: the upload, the tiles, the step buffers
+        refuse(upload_queries(h, Q, T, D));
+        if (ok && nsteps > 0 && !h->gtiles_ready) {
+            if (!refuse(h->gtiles.ensure(greedy_tile_bytes(g, h->Dt)))) {
+                launch_greedy_tiles(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->JC_unw.as<float>(), h->Jp, h->gtiles.as<float>(), h->stream);
+                if (hipGetLastError() != hipSuccess) refuse(fail("snk_sharded_greedy: greedy tiles launch failed"));
+                else h->gtiles_ready = true;
+            }
+        }
+        if (ok && nsteps > 0) {
+            const int64_t ntiles = (g.Nwin + 63) / 64;
+            int64_t tlo = 0, thi = 0;
+            shard_plan(ntiles, h->comm_ranks, h->comm_rank, &tlo, &thi);
+            const int nblk = greedy_shard_blocks(g, h->Dt, h->n_cus, thi - tlo > 0 ? thi - tlo : 1);
+            if (refuse(h->gprev.ensure(2 * greedy_table_doubles(g, h->Dt) * sizeof(double) + 512)) ||
+                refuse(h->gsync.ensure(greedy_counter_bytes())) || refuse(h->gblkmin.ensure((size_t)nblk * sizeof(double))) ||
+                refuse(h->gblkarg.ensure((size_t)nblk * sizeof(int64_t))) || refuse(h->gpath.ensure((size_t)nsteps * sizeof(int64_t))) ||
+                refuse(h->gdist.ensure((size_t)nsteps * sizeof(double)))) { /* noted */ }
+        }
+    }
+    // (a failure INSIDE the verdict's own collective, or in a step's all-gather, leaves peers in a collective: abort the communicator)
+    CHK(sharded_fail(h, sharded_greedy_preflight(h, ok, T, D, start_state, why)));
     *nsteps_out = nsteps;
     if (nsteps == 0) { HIPCHK(hipStreamSynchronize(h->stream)); collect_timers(h); return 0; }
-    if (!h->gtiles_ready) {
-        CHK(h->gtiles.ensure(greedy_tile_bytes(g, h->Dt)));
-        launch_greedy_tiles(g, h->F_unw.as<float>(), h->Fp, h->Dt, h->JC_unw.as<float>(), h->Jp, h->gtiles.as<float>(), h->stream);
-        HIPCHK(hipGetLastError());
-        h->gtiles_ready = true;
-    }
+    return sharded_fail(h, sharded_greedy_steps(h, nsteps, start_state, path_out, dist_out));
+}
+
+static int sharded_greedy_steps(snk_engine *h, int64_t nsteps, int64_t start_state, int64_t *path_out, double *dist_out)
+{
+    const GreedyLayout &g = h->glay;
     const int G = h->comm_ranks, me = h->comm_rank;
     const int64_t ntiles = (g.Nwin + 63) / 64;
     int64_t tlo = 0, thi = 0;
@@ -778,8 +834,7 @@ int snk_sharded_greedy(snk_handle h, const double *Q, int64_t T, int D, int64_t 
     CHK(h->gblkarg.ensure((size_t)nblk * sizeof(int64_t)));
     CHK(h->gpath.ensure((size_t)nsteps * sizeof(int64_t)));
     CHK(h->gdist.ensure((size_t)nsteps * sizeof(double)));
-    CHK(h->gshard.ensure((size_t)16 * (G + 1)));
-    double *mine = h->gshard.as<double>(), *all = mine + 2;
+    double *mine = h->gshard.as<double>(), *all = mine + 2;           // (allocated by the pre-flight: 16 (G + 1) bytes for the steps + its own records)
     {
         // a rank without tiles (more ranks than tiles) contributes "nothing found"
         const double none_d = DBL_MAX;

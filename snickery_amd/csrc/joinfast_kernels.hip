@@ -674,7 +674,7 @@ join_exact_sparse2_kernel(const float *__restrict__ JC_unw, int Jp, int Dj, cons
         if (need & (1u << j)) item_s[base++] = (unsigned short)((tid << 2) | j);
     __syncthreads();
     const int total = total_s;
-    if (stats) {                                             // what the kernel's roofline is priced on (snk_get_info sparse_exact_costs / sparse_set_members)
+    if (stats && stats[8]) {                                 // what the kernel's roofline is priced on (snk_get_info sparse_exact_costs / sparse_set_members): option roofline_counters only -- same-address atomics of 7 500 workgroups cost 0.4 ms per launch
         if (tid == 0 && total) atomicAdd(&stats[6], (unsigned long long)total);
         int mem = n;
 #pragma unroll

@@ -21,10 +21,12 @@
 //                        2^-20 of its |products| + |C| -- the probed property of this instruction, knn16_kernels.hip /
 //                        snk_probe_mfma_bf16 --, the cross terms' sums are 2^-8 of the product of the norms; one float32 addition)
 //                      or (3 n_kb + 1) 2^-20   (one set, K > 128) ],
-//     ||ye|| ||ys|| <= (ne + ns) / 2,   |ne~ - ne| <= (n_kb + 12) 2^-24 ne,   four float32 operations in the epilogue,
+//     ||ye|| ||ys|| <= (ne + ns) / 2,   |ne~ - ne| <= (n_kb + 12) 2^-24 ne,   six float32 roundings in the epilogue,
 //   together e2 = ceps (ne~ + ns~), ceps from join_lb2_ceps: 3.4e-5 at 302 columns with two sets (7.1e-5 with one; the first
-//   form's 2.2 (D + 6) 2^-24 is 4.1e-5 there).  clo = sqrt(max(c2~ - e2, 0)) (1 - 2^-21) - eta (1 + 1e-4), clamped at 0
-//   (v_sqrt_f32, 1 ulp: the factor leaves 8).
+//   form's 2.2 (D + 6) 2^-24 is 4.1e-5 there).  clo = sqrt(c2~ - e2) (1 - 2^-21) - eta (1 + 1e-4), clamped at 0
+//   (v_sqrt_f32, 1 ulp: the factor leaves 8; a negative radicand gives NaN, which the clamp turns into 0).  The epilogue
+//   evaluates this as fma(sqrt(ne' + ns' - 2 G~), 1 - 2^-21, -(se' + ss')) with the per-row terms ne' = (1 - ceps) ne~ - 1e-30,
+//   se' = c24 (sqrt(ne~) + 2 Umax) prepared once per row (9 vector-issue slots per cell instead of 15).
 // One workgroup per row pair; KT = ceil(K / 32) wavefronts; wavefront w keeps the pieces of its 32 E rows in registers (the A
 // operand: lane l <-> row l & 31, columns 16 kb + 8 (l >> 5) + 0..7) and stages those of its 32 S rows in LDS for everybody
 // (fragment order, double buffered, one barrier per k-block).  The rows of the next PF k-blocks are in flight in registers
@@ -97,7 +99,7 @@ __device__ __forceinline__ void jf_split2(float y0, float y1, unsigned int &hi, 
 
 template <int KT, bool QUAD>
 __global__ void __launch_bounds__(64 * KT, 2)
-join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned int *__restrict__ umax_bits, float ceps,
+join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned int *__restrict__ umax_bits, float omc /* 1 - ceps, rounded down */,
                 int64_t n_units, const int64_t *__restrict__ cand, int K, float *__restrict__ Jlo,
                 float *__restrict__ scale_out, int Kq)
 {
@@ -105,7 +107,7 @@ join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned i
     constexpr int PF = (KT <= 3) ? 3 : 2;                     // k-blocks in flight
     __shared__ u32x4 Bs[2][KT][2][64];                        // [buffer][S tile][hi, lo][lane]
     __shared__ __align__(16) float m_s[JF2_MAXD];
-    __shared__ float ne_s[32 * KT], ns_s[32 * KT], sne_s[32 * KT], sns_s[32 * KT], pen_s[32 * KT], pns_s[32 * KT];
+    __shared__ float ne_s[32 * KT], ns_s[32 * KT], sne_s[32 * KT], sns_s[32 * KT];
     __shared__ int smax_bits;
     const int64_t r = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -203,13 +205,18 @@ join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned i
     // row norms: the two lanes of a row hold the sums of its two column halves
     ne += __shfl_xor(ne, 32, 64);
     ns += __shfl_xor(ns, 32, 64);
+    const float umax2 = 2.f * __uint_as_float(*umax_bits);
+    const float c24 = 5.9604644775390625e-08f * 1.0001f;
     if (half == 0) {
-        ne_s[kk] = ne;
-        ns_s[kk] = ns;
-        sne_s[kk] = __builtin_amdgcn_sqrtf(ne) * 1.000001f;
-        sns_s[kk] = __builtin_amdgcn_sqrtf(ns) * 1.000001f;
-        pen_s[kk] = okE ? 0.f : __builtin_inff();             // an unusable unit: every cell of its row / column is +inf
-        pns_s[kk] = okS ? 0.f : __builtin_inff();
+        // Everything of the epilogue that depends on ONE row only is done here, once per row instead of once per cell (the
+        // epilogue was a third of the kernel's vector instructions: 15 per cell, 64 cells per lane):
+        //   ne' = (1 - ceps) ne - 1e-30   (so that lo2 = ne' + ns' - 2 g~ = c2~ - ceps (ne~ + ns~) - 2e-30; omc is rounded down),
+        //   +inf for an unusable unit (every cell of its row / column then comes out +inf by itself: inf - finite = inf,
+        //   sqrt(inf) = inf, fma(inf, 1 - 2^-21, -t) = inf);   se' = c24 (sqrt(ne) + 2 Umax) -- its share of eta.
+        ne_s[kk] = okE ? __builtin_fmaf(omc, ne, -1e-30f) : __builtin_inff();
+        ns_s[kk] = okS ? __builtin_fmaf(omc, ns, -1e-30f) : __builtin_inff();
+        sne_s[kk] = c24 * (__builtin_amdgcn_sqrtf(ne) * 1.000001f + umax2);
+        sns_s[kk] = c24 * (__builtin_amdgcn_sqrtf(ns) * 1.000001f);
         // scale of the step (margin of pass 2): the largest centred norm among the usable rows
         const float big = fmaxf(okE ? ne : 0.f, okS ? ns : 0.f);
         atomicMax(&smax_bits, __float_as_int(big));
@@ -217,44 +224,40 @@ join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned i
     __syncthreads();
     // ---- epilogue, branch-free: 16 KT cells per lane; stores through a buffer descriptor of the step's K x K slab (the row
     // part of the address in the scalar offset, a lane whose column lies beyond K points out of range and is dropped).
-    // Overflowed float32 norms end as NaN or -inf under the maxima (v_max returns the other operand for a NaN): bound 0.
-    const float umax2 = 2.f * __uint_as_float(*umax_bits);
-    const float c24 = 5.9604644775390625e-08f * 1.0001f;
-    float nev[16], sev[16], pev[16];
+    // Overflowed float32 norms and negative lo2 end as NaN under the final maximum (v_max returns the other operand for a
+    // NaN; sqrt of a negative is NaN): bound 0.
+    float nev[16], sev[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int kp = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;       // row of the result = E row (crow32)
         nev[i] = ne_s[kp];
-        sev[i] = sne_s[kp] + umax2;
-        pev[i] = pen_s[kp];
+        sev[i] = sne_s[kp];
     }
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(Jlo + r * (int64_t)K * K, 0, K * K * 4, 0x00020000);
-    auto cell = [&](int j, int i, float nsv, float ssv, float psv) {
-        const float sum = nev[i] + nsv;
+    auto cell = [&](int j, int i, float nsv, float ssv) {
+        const float sum = nev[i] + nsv;                                      // (1 - ceps)(ne~ + ns~) - 2e-30, or +inf
         const float g = TWO ? acc[j][i] + accx[j][i] : acc[j][i];
-        const float c2 = __builtin_fmaf(-2.f, g, sum);                       // (2 g is exact: one rounding)
-        const float lo2 = __builtin_fmaf(-ceps, sum, c2) - 1e-30f;
-        const float sq = __builtin_amdgcn_sqrtf(__builtin_fmaxf(lo2, 0.f)) * (1.f - 4.76837158203125e-07f);
-        const float clo = __builtin_fmaxf(__builtin_fmaf(-c24, sev[i] + ssv, sq), 0.f);
-        return __builtin_fmaxf(__builtin_fmaxf(clo, pev[i]), psv);           // an unusable unit on either side: +inf
+        const float lo2 = __builtin_fmaf(-2.f, g, sum);                      // (2 g is exact: one rounding)
+        const float sq = __builtin_amdgcn_sqrtf(lo2);                        // NaN for lo2 < 0: bound 0 below
+        return __builtin_fmaxf(__builtin_fmaf(sq, 1.f - 4.76837158203125e-07f, -(sev[i] + ssv)), 0.f);
     };
     if (wave * 32 + 32 <= Ke) {                               // uniform: every row of this wavefront's tile exists
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
             const int k = j * 32 + row32;                       // column of the result = S row
-            const float nsv = ns_s[k], ssv = sns_s[k], psv = pns_s[k];
+            const float nsv = ns_s[k], ssv = sns_s[k];
             const int voff = k < Ks ? ((e0 + wave * 32 + 4 * half) * K + s0 + k) * 4 : 0x7ffffffc;
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, cell(j, i, nsv, ssv, psv)), ores, voff,
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, cell(j, i, nsv, ssv)), ores, voff,
                                                       ((i & 3) + 8 * (i >> 2)) * K * 4, 0);
         }
     } else {
         // the wavefront of the last, partly filled tile (K = 100: rows 96..127, four of them candidates): result registers whose
         // row lies beyond K in BOTH halves are skipped (a uniform test per register: 12 of its 16 at K = 100)
-        float nsv[KT], ssv[KT], psv[KT];
+        float nsv[KT], ssv[KT];
 #pragma unroll
-        for (int j = 0; j < KT; ++j) { const int k = j * 32 + row32; nsv[j] = ns_s[k]; ssv[j] = sns_s[k]; psv[j] = pns_s[k]; }
+        for (int j = 0; j < KT; ++j) { const int k = j * 32 + row32; nsv[j] = ns_s[k]; ssv[j] = sns_s[k]; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int kp0 = wave * 32 + (i & 3) + 8 * (i >> 2);
@@ -263,7 +266,7 @@ join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned i
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
                 const int k = j * 32 + row32;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, cell(j, i, nsv[j], ssv[j], psv[j])), ores,
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, cell(j, i, nsv[j], ssv[j])), ores,
                                                       (kp < Ke && k < Ks) ? ((e0 + kp) * K + s0 + k) * 4 : 0x7ffffffc, 0, 0);
             }
         }
@@ -276,16 +279,16 @@ join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned i
 }
 
 template <int KT>
-static void launch_join_lb2_t(const float *JW, int Jq, int n_kb, const unsigned int *umax_bits, float ceps, int64_t n_units,
+static void launch_join_lb2_t(const float *JW, int Jq, int n_kb, const unsigned int *umax_bits, float omc, int64_t n_units,
                               const int64_t *cand, int64_t R, int K, float *Jlo, float *scale, hipStream_t s, int Kq)
 {
     if (Kq > 0) {
         if constexpr (KT <= 4)
-            hipLaunchKernelGGL((join_lb2_kernel<KT, true>), dim3((unsigned)(R - 1), 4u), dim3(64 * KT), 0, s, JW, Jq, n_kb, umax_bits, ceps,
+            hipLaunchKernelGGL((join_lb2_kernel<KT, true>), dim3((unsigned)(R - 1), 4u), dim3(64 * KT), 0, s, JW, Jq, n_kb, umax_bits, omc,
                                n_units, cand, K, Jlo, scale, Kq);
         return;
     }
-    hipLaunchKernelGGL((join_lb2_kernel<KT, false>), dim3((unsigned)(R - 1), 1u), dim3(64 * KT), 0, s, JW, Jq, n_kb, umax_bits, ceps,
+    hipLaunchKernelGGL((join_lb2_kernel<KT, false>), dim3((unsigned)(R - 1), 1u), dim3(64 * KT), 0, s, JW, Jq, n_kb, umax_bits, omc,
                        n_units, cand, K, Jlo, scale, 0);
 }
 
@@ -308,7 +311,9 @@ double join_lb2_ceps(int Dj, int K)
     const double acc = two ? (n_kb + 1.0) * u20 + (2.0 * n_kb + 1.0) * u20 / 256.0 + u24 : (3.0 * n_kb + 1.0) * u20;
     const double cg = 1.02 * (3.02 * u18 + acc);
     const double gam = (n_kb + 12.0) * u24;
-    return (gam + cg * (1.0 + gam) + 4.0 * u24) * 1.0001;
+    // (six float32 roundings in the epilogue since the per-row terms are prepared once per row: (1 - ceps) ne, its sum with the
+    // other row's, the fused -2 g~; 4 until round 5)
+    return (gam + cg * (1.0 + gam) + 6.0 * u24) * 1.0001;
 }
 
 void launch_join_lb2(const float *JW, int Dj, const unsigned int *umax_bits, int64_t n_units, const int64_t *cand, int64_t R,
@@ -316,11 +321,12 @@ void launch_join_lb2(const float *JW, int Dj, const unsigned int *umax_bits, int
 {
     if (R < 2) return;
     const int Jq = join_lb2_pitch(Dj), n_kb = Jq / 16;
-    const float ceps = (float)join_lb2_ceps(Dj, K);
+    // 1 - ceps as the kernel multiplies the norms by it, rounded DOWN (a smaller factor is a looser, still valid bound)
+    const float omc = __builtin_nextafterf((float)(1.0 - join_lb2_ceps(Dj, K)), 0.f);
     const int Kq = join_lb2_quadrant(K);
     const int kt = ((Kq > 0 ? Kq : K) + 31) / 32;
     if (Kq > 0) (void)hipMemsetAsync(scale, 0, (size_t)(R - 1) * sizeof(float), s);       // the quadrants' workgroups take the maximum
-#define SNK_JLB2(KT_) launch_join_lb2_t<KT_>(JW, Jq, n_kb, umax_bits, ceps, n_units, cand, R, K, Jlo, scale, s, Kq)
+#define SNK_JLB2(KT_) launch_join_lb2_t<KT_>(JW, Jq, n_kb, umax_bits, omc, n_units, cand, R, K, Jlo, scale, s, Kq)
     switch (kt) {
     case 1: SNK_JLB2(1); break;
     case 2: SNK_JLB2(2); break;

@@ -205,7 +205,10 @@ km_order_kernel(const float *__restrict__ cen, const int *__restrict__ count, in
             if (taken[c]) continue;
             float acc = 0.f;
             for (int d = 0; d < Dp; ++d) { const float df = cen[(int64_t)c * Dp + d] - cen[(int64_t)cur * Dp + d]; acc = __builtin_fmaf(df, df, acc); }
-            if (acc < v) { v = acc; ii = c; }
+            // non-finite rows (NaN / inf features): a distance that compares as not-less must still leave a FREE cluster in ii, or the
+            // chain writes taken[0x7fffffff] and the order is no permutation; lowest index among equals, as in the reduction
+            acc = acc < FLT_MAX ? acc : FLT_MAX;
+            if (acc < v || (acc == v && c < ii)) { v = acc; ii = c; }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -287,9 +290,12 @@ km_chain_kernel(const double *__restrict__ Fw, int Dt, int Dpad, int Dp, int cap
                 const float d0 = xs[(size_t)d * cap + (f0 ? i0 : cur)] - cv, d1 = xs[(size_t)d * cap + (f1 ? i1 : cur)] - cv;
                 a0 = __builtin_fmaf(d0, d0, a0); a1 = __builtin_fmaf(d1, d1, a1);
             }
-            float v = f0 ? a0 : FLT_MAX;
-            int ii = i0;
-            if (f1 && a1 < v) { v = a1; ii = i1; }
+            // (non-finite distances count as FLT_MAX; a lane without a free member holds no index at all: ADVICE r5)
+            a0 = a0 < FLT_MAX ? a0 : FLT_MAX; a1 = a1 < FLT_MAX ? a1 : FLT_MAX;
+            float v = FLT_MAX;
+            int ii = 0x7fffffff;
+            if (f0) { v = a0; ii = i0; }
+            if (f1 && (a1 < v || ii == 0x7fffffff)) { v = a1; ii = i1; }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
                 const float ov = __shfl_xor(v, off, 64); const int oi = __shfl_xor(ii, off, 64);
@@ -315,7 +321,28 @@ size_t kmeans_workspace_bytes(int64_t N, int Dt)
     return (size_t)C * Dp * 4 + (size_t)C * 4 + (size_t)N * 4 + (size_t)(3 * C + 8) * 4 + (size_t)N * 4 + (size_t)(3 * C + 8) * 4 + 256;
 }
 
-bool kmeans_supported(int Dt) { return Dt >= 1 && Dt <= 256; }
+// km_assign keeps Dp x (KM_UB + KM_CJ) floats in LDS: widths whose tile would reach the 160 KB of a compute unit are not clustered
+// (Dt 253 .. 256 asked for exactly 163 840 bytes)
+bool kmeans_supported(int Dt) { return Dt >= 1 && (size_t)((Dt + 3) & ~3) * (KM_UB + KM_CJ) * sizeof(float) <= (size_t)150 * 1024; }
+
+// Is `perm` a permutation of 0 .. N-1?  seen: N zeroed words of scratch; *bad counts the entries out of range or seen before.
+__global__ void __launch_bounds__(256)
+km_perm_check_kernel(const int *__restrict__ perm, int64_t N, unsigned int *__restrict__ seen, unsigned int *__restrict__ bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int p = perm[i];
+    if (p < 0 || p >= N || atomicAdd(&seen[p], 1u) != 0u) atomicAdd(bad, 1u);
+}
+
+size_t kmeans_perm_check_bytes(int64_t N) { return (size_t)(N + 1) * sizeof(unsigned int); }
+
+void launch_perm_check(const int *perm, int64_t N, void *scratch, hipStream_t s)
+{
+    (void)hipMemsetAsync(scratch, 0, kmeans_perm_check_bytes(N), s);
+    unsigned int *seen = static_cast<unsigned int *>(scratch);
+    hipLaunchKernelGGL(km_perm_check_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, perm, N, seen + 1, seen);      // word 0: the verdict
+}
 
 void launch_kmeans_order(const double *Fw, int64_t N, int Dt, int Dpad, int iters, void *workspace, int *perm, hipStream_t s)
 {

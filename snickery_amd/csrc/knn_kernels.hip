@@ -1081,7 +1081,9 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
         __syncthreads();
     }
     const int n_sel = n_sel_s;
-    if (margin_stat && threadIdx.x == 0) {                  // what the kernel's roofline is priced on (snk_get_info: finalize_*)
+    // what the kernel's roofline is priced on (snk_get_info: finalize_*) -- only while option roofline_counters is on (word 6):
+    // 9 600 workgroups adding to ONE address serialise in L2 (+ 0.3 ms per launch when always on: profiles/r06_a)
+    if (margin_stat && threadIdx.x == 0 && margin_stat[6]) {
         atomicAdd(reinterpret_cast<unsigned long long *>(margin_stat) + 1, (unsigned long long)n);
         atomicAdd(reinterpret_cast<unsigned long long *>(margin_stat) + 2, (unsigned long long)n_sel);
     }

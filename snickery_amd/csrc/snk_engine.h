@@ -209,6 +209,7 @@ struct snk_engine {
     int device = 0;
     hipStream_t stream = nullptr, stream2 = nullptr, copy_stream = nullptr;
     hipStream_t up_stream = nullptr;       // query rows of a submitted batch: host -> HBM beside the batch before it (created at the first submit)
+    int roofline_counters = 0;             // option: the re-rank and pass 3 count what their rooflines are priced on (atomics on one address: off in production)
     int upload_stream = 1;                 // option: 0 = the rows are uploaded on the main stream, as until round 5
     BatchSlot bslot[2];
     int bnext = 0;
@@ -297,6 +298,7 @@ struct snk_engine {
     double reorder_radius_before = 0.0, reorder_radius_after = 0.0;      // mean radius of the tiles' balls around the last clustering
     bool perm_ready = false, reorder_pending = false, reorder_done = false, reorder_useless = false;
     int64_t reorders = 0;
+    int64_t reorder_failures = 0;     // attempts that failed (allocation, launch, an order that was no permutation): the voice kept its order, the call went on
     int64_t operand_gen = 0;              // generation of the prefilter's operands: what a batch listed is judged only against the operands it ran on
     int latch_rearm = 1;
     int64_t filter_calls = 0, probe_next = 16;

@@ -140,6 +140,8 @@ int kmeans_clusters(int64_t N, int Dt);
 bool kmeans_supported(int Dt);
 size_t kmeans_workspace_bytes(int64_t N, int Dt);
 void launch_kmeans_order(const double *Fw, int64_t N, int Dt, int Dpad, int iters, void *workspace, int *perm, hipStream_t s);
+size_t kmeans_perm_check_bytes(int64_t N);
+void launch_perm_check(const int *perm, int64_t N, void *scratch, hipStream_t s);      // scratch word 0 <- entries that make perm no permutation
 void launch_fmax(const double *fnorm, int64_t N, double *out, hipStream_t s);
 void launch_prepare_queries16(const double *Qp, const double *qnorm, int64_t T, int Dt, int Dpad,
                               const double *fmax2, double eps_c, void *B32, double *eps, hipStream_t s);

@@ -225,11 +225,13 @@ e4 = snickery_amd.HipSearchEngine(0)
 e4.upload_db(F, JC); e4.set_weights(wt, wj)
 assert refused(e4.sharded_greedy, rng.randn(12, Dt))                    # no communicator, no layout
 e4.comm_init_transport(2, 1, tr)
-assert refused(e4.sharded_greedy, rng.randn(12, Dt))                    # no layout
+n_ag = calls.count('ag')
+assert refused(e4.sharded_greedy, rng.randn(12, Dt))                    # no layout: refused through the collective verdict (every rank would refuse)
+assert calls.count('ag') == n_ag + 1 and 'refused on every rank' in snickery_amd.load_library().snk_last_error().decode()
 e4.set_greedy_layout(3, False, 0)
 n_ag = calls.count('ag')
 e4.sharded_greedy(rng.randn(12, Dt), return_distances=True)
-assert calls.count('ag') == n_ag + 4                                    # one all-gather per step
+assert calls.count('ag') == n_ag + 1 + 4                                # the collective verdict + one all-gather per step
 e4.sharded_greedy(rng.randn(2, Dt))                                     # shorter than one window: no step
 e4.close()
 

@@ -194,6 +194,17 @@ def test_library_collectives_three_ranks_one_gpu():
     assert out[0] is True and out[1] is True and out[2] is True
 
 
+def test_library_collectives_eight_ranks_one_gpu():
+    """G = 8, the size of the node the sharded search is for and never ran on: eight ranks on this one GPU over
+    the gloo transport -- the 8-peer compacted all-to-all-v, the merge tree of depth 3, uneven shards (60 001 units over 8 ranks),
+    5 utterances over 8 owners (three own none), the collective redo, two steps in flight; equal to the oracle on every rank."""
+    port = 19500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_lib_worker, args=(8, port, out, True), nprocs=8, join=True)
+    assert all(out[r] is True for r in range(8))
+
+
 def _greedy_worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -228,6 +239,32 @@ def _greedy_worker(rank, world, port, out):
             sp, sd = eng.greedy(U, start_state=start, return_distances=True)
             ok = ok and path == op and np.array_equal(d, od) and path == sp and np.array_equal(d, sd)
         eng.close()
+    # ---- a rank-local failure must refuse the call on EVERY rank, before any step's collective: the last rank has
+    # no greedy layout; then the ranks disagree about start_state; then a good call still works on the same communicator ----
+    N, Dt, Dj, me = 3000, 61, 40, 3
+    F_unw, JC_unw = o.synthetic_db(N, Dt, Dj, seed=77)
+    wt = np.full(Dt, 0.4); wj = np.full(Dj, 0.05)
+    eng = snickery_amd.HipSearchEngine(0)
+    eng.upload_db(F_unw, JC_unw); eng.set_weights(wt, wj)
+    if rank != world - 1:
+        eng.set_greedy_layout(me, False, 0)
+    eng.comm_init_transport(world, rank, gloo_transport(world))
+    U = o.synthetic_targets(F_unw, 30, seed=5) * wt
+    try:
+        eng.sharded_greedy(U)
+        ok = False
+    except snickery_amd.SnkError as e:
+        ok = ok and ('refused on every rank' in str(e))
+    eng.set_greedy_layout(me, False, 0)
+    try:
+        eng.sharded_greedy(U, start_state=5 if rank == 0 else 6)
+        ok = False
+    except snickery_amd.SnkError as e:
+        ok = ok and ('disagree' in str(e))
+    F, E, S = o.weighted_db(F_unw, JC_unw, wt, wj)
+    pr, cr, Fwin = o.greedy_layout(F, E, S, me, False, 0)
+    ok = ok and eng.sharded_greedy(U) == o.greedy_search(pr, cr, Fwin, o.greedy_queries(U, me, False))[0]
+    eng.close()
     out[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
@@ -294,25 +331,35 @@ def _run_bench_child(cmd, env):
     return r
 
 
-@pytest.mark.parametrize('nproc,shards,sharding', [(2, 0, 'db-rows/2 + all-to-all of local top-K'),
-                                                   (4, 2, 'db-rows/2 + all-to-all of local top-K x 2 replica groups'),
-                                                   (2, 1, '2 independent replicas')])
-def test_bench_multi_rank_one_gpu(nproc, shards, sharding):
-    """bench.py as the driver launches it for N > 1 (torch.distributed.run), ranks sharing the GPU:
-    database sharded over all ranks (default), shard groups x replica groups, independent replicas."""
+@pytest.mark.parametrize('nproc,shards,sharding,extra', [
+    (2, 0, 'db-rows/2 + all-to-all of local top-K', []),
+    (4, 2, 'db-rows/2 + all-to-all of local top-K x 2 replica groups', []),
+    (2, 1, '2 independent replicas', []),
+    # G = 8 (no 8-GPU box has ever been available): 8-peer all-to-all-v, the depth-3 merge tree, shards of
+    # uneven size (40 003 units over 8 ranks), 40 utterances over 8 owners ...
+    (8, 0, 'db-rows/8 + all-to-all of local top-K', ['--units', '40003']),
+    # ... and 5 utterances over 8 owners: three ranks own none (they still filter every row against their shard)
+    (8, 0, 'db-rows/8 + all-to-all of local top-K', ['--units', '40003', '--fixed-batch']),
+    (8, 4, 'db-rows/4 + all-to-all of local top-K x 2 replica groups', [])])
+def test_bench_multi_rank_one_gpu(nproc, shards, sharding, extra):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run), ranks sharing the GPU over the gloo transport:
+    database sharded over all ranks (default), shard groups x replica groups, independent replicas -- at 2, 4 and 8 ranks.
+    The last stdout line is the compact record (< 6 KB)."""
     env = dict(os.environ, SNK_BENCH_SHARE_GPU='1')
-    port = 23500 + (os.getpid() % 2000) + nproc * 3 + shards
+    port = 23500 + (os.getpid() % 2000) + nproc * 3 + shards + 7 * len(extra)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
            '--gpus', str(nproc), '--steps', '2', '--warmup', '1', '--units', '40000', '--frames', '60', '--utts', '5',
-           '--candidates', '20', '--no-cpu-baseline', '--db-shards', str(shards)]
+           '--candidates', '20', '--no-cpu-baseline', '--db-shards', str(shards), '--detail-out', ''] + extra
     r = _run_bench_child(cmd, env)
     assert r.returncode == 0, _child_report(r)
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1
+    assert len(lines) == 1 and r.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 6144
     js = json.loads(lines[0])
-    assert js['n_gpus'] == nproc and js['value'] > 0 and js['scaling'] == 'weak'
-    assert js['config']['utts_per_step'] == 5 * nproc and js['config']['sharding'] == sharding
+    fixed = '--fixed-batch' in extra
+    assert js['n_gpus'] == nproc and js['value'] > 0 and js['scaling'] == ('strong' if fixed else 'weak')
+    assert js['config']['utts_per_step'] == (5 if fixed else 5 * nproc) and js['config']['sharding'] == sharding
+    assert js['config']['units'] == int(extra[1]) if extra else 40000
     assert 'roofline' in js and 'FUNCTIONAL TEST' in js['note']
 
 
@@ -325,7 +372,7 @@ def test_bench_falls_back_to_the_callers_communicator_when_rccl_cannot_open():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
            '--gpus', '2', '--steps', '2', '--warmup', '1', '--units', '40000', '--frames', '60', '--utts', '5',
-           '--candidates', '20', '--no-cpu-baseline']
+           '--candidates', '20', '--no-cpu-baseline', '--detail-out', '']
     r = _run_bench_child(cmd, env)
     assert r.returncode == 0, _child_report(r)
     js = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])

@@ -329,12 +329,14 @@ def test_speechlike_voice_at_headline_size(engine):
     for _ in range(3):                              # the engine judges the voice (filter latch, unit order, Viterbi path) over its first batches
         paths, costs = engine.knn_viterbi_batch(utts, K)
     assert engine.info('exact_row_fallbacks') == 0
-    assert engine.info('prefilter_margin_rows') == 0 and engine.info('join_bound_violations') == 0
+    assert engine.info('prefilter_margin_rows') == 0, engine.info('prefilter_min_margin')
+    assert engine.info('join_bound_violations') == 0, engine.info('join_bound_min_margin')
     cd = [engine.knn(u, K) for u in utts]
     F = o.weight(F_unw, wt)
     rows = np.unique(np.linspace(0, T - 1, 16).astype(np.int64))
     oc_cand, oc_dist = oc.knn(F, utts[0][rows], K)
-    assert np.array_equal(cd[0][0][rows], oc_cand) and np.array_equal(cd[0][1][rows], oc_dist)
+    assert np.array_equal(cd[0][0][rows], oc_cand), 'candidates of the spot rows differ from the C oracle'
+    assert np.array_equal(cd[0][1][rows], oc_dist), 'distances of the spot rows differ from the C oracle'
     # a held-out frame's neighbours are strangers: not runs of consecutive units (what SURVEY 8d's walk gives)
     runs = np.mean(np.diff(np.sort(cd[0][0], axis=1), axis=1) == 1)
     assert runs < 0.2, runs
@@ -342,7 +344,8 @@ def test_speechlike_voice_at_headline_size(engine):
     JCw = o.weight(JC_unw, wj)
     for u in range(U):
         opath, ocost = oc.viterbi(cd[u][0], cd[u][1], JCw)
-        assert [int(v) for v in paths[u]] == opath and costs[u] == ocost
+        assert [int(v) for v in paths[u]] == opath, 'utterance %d: path differs from the C oracle' % u
+        assert costs[u] == ocost, ('utterance %d' % u, costs[u], ocost)
     # the dense exact kernels (what the Viterbi latch may pick for such a voice) return the same
     engine.set_option('viterbi_mode', 0)
     try:

@@ -39,8 +39,12 @@ for v, form in [(v, f) for v in variants for f in forms]:
     for _ in range(R): eng.viterbi_batch(cands, dists)
     dt = (time.time() - t0) / R
     st1 = [eng.info(x) for x in ('dense_cells', 'dense_steps', 'dense_exact_costs', 'set_overflows')]
-    extra = ' pass-3 exact costs / set members per call [%d, %d]' % (eng.info('sparse_exact_costs') / R, eng.info('sparse_set_members') / R)
+    tm_timed = eng.timers()
+    eng.set_option('roofline_counters', 1); eng.reset_timers()          # (one more call, counted: the counters cost time, the timed calls ran without)
+    eng.viterbi_batch(cands, dists)
+    extra = ' pass-3 exact costs / set members per call [%d, %d]' % (eng.info('sparse_exact_costs'), eng.info('sparse_set_members'))
+    eng.set_option('roofline_counters', 0)
     print('join_lb_variant %d join_exact_form %d: %.2f ms per call (with the upload of the candidates) same=%s stages %s refined cells / steps / exact costs / overflows per call %s'
-          % (v, form, dt * 1e3, same, {k: round(x[0] / R, 3) for k, x in eng.timers().items() if x[1]},
+          % (v, form, dt * 1e3, same, {k: round(x[0] / R, 3) for k, x in tm_timed.items() if x[1]},
              [round((b - a) / R) for a, b in zip(st0, st1)]) + extra, flush=True)
 eng.close()
