@@ -386,10 +386,11 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
            'roofline': leg_roofline(tm, steps, T * U, N, Dt, Dj, K, eng),
            'filter_coarse': bool(eng.info('filter_coarse')), 'filter_onepass': bool(eng.info('filter_onepass')),
            'reordered': bool(eng.info('reordered')), 'tile_radius_before_after': [eng.info('reorder_radius_before'), eng.info('reorder_radius_after')],
-           'viterbi_path': 'dense' if eng.info('viterbi_latch_mode') == 1 else 'sparse',
+           'viterbi_path': 'dense' if eng.info('viterbi_latch_mode') == 1 else 'sparse', 'viterbi_lb_warm': eng.info('viterbi_lb_warm_now'),
            'cells_refined_per_step': (eng.info('dense_cells') - cells0) / steps, 'cells_per_step': T * U * K,
            'tile_pairs_listed': {'last_launch': pairs, 'fraction': pairs / max((rows_per_launch / 32.0) * (N / 32.0), 1.0)},
            'list_mean': eng.info('last_list_mean'), 'list_max': eng.info('last_list_max'), 'knn_level': eng.info('knn_level'),
+           'tau_optimism_rank': eng.info('tau_optimism_rank'), 'tau_optimism_off': eng.info('tau_optimism_off'),
            'prefilter_fallbacks': eng.info('f16_fallbacks') - before[0], 'batch_redos': eng.info('batch_redos') - before[1],
            'exact_row_fallbacks': eng.info('exact_row_fallbacks') - before[2],
            'tripwires': {'prefilter_margin_rows': eng.info('prefilter_margin_rows'), 'prefilter_min_margin': eng.info('prefilter_min_margin'),
@@ -502,6 +503,8 @@ def compact_line(out):
     for k in ('replicas', 'note'):
         if k in out:
             line[k] = out[k] if isinstance(out[k], str) else dict((a, _r(b, 3)) for a, b in out[k].items() if a != 'note')
+    if 'knn_lists' in out:
+        line['knn_lists'] = dict((k, _r(v, 1)) for k, v in out['knn_lists'].items())
     line['stages_ms_per_step'] = dict((k, _r(v, 3)) for k, v in out.get('stages_ms_per_step', {}).items())
     line['roofline_check'] = out.get('roofline_check')
     line['summary'] = out.get('summary')
@@ -735,6 +738,7 @@ def main():
     # counters the rooflines of the two kernels without one until round 5 are priced on, read before any
     # other pass adds to them: exact costs pass 3 took from the rows, list entries the re-rank read / gave exact distances
     roof_counts = {}
+    knn_main = dict((k, eng.info(k)) for k in ('last_list_mean', 'last_list_max', 'tau_optimism_rank', 'tau_optimism_failures', 'tau_optimism_off', 'batch_redos', 'f16_fallbacks')) if world == 1 else {}
     trip_main = dict((k, eng.info(k)) for k in ('prefilter_margin_rows', 'prefilter_min_margin', 'join_bound_violations', 'join_bound_min_margin')) if world == 1 else {}
     # N > 1, database sharded: the same GPUs as independent replicas (every GPU the whole database -- B* needs 3.5 GB of
     # 288 -- and its own 32 utterances, no collective), timed the same way: an extra field, never `value`.  Sharding is for
@@ -958,6 +962,10 @@ def main():
                                        'whole-chip kernels do (sum of their stand-alone times 4.1 of the 4.6 ms step, DESIGN.md 4.3)'}
         else:
             out['roofline'] = dict(out['filter_stage'])
+        if knn_main:
+            # the K-NN lists of the timed steps: their mean length per row, the rank of the sample minimum the thresholds came from
+            # (0: the guaranteed K-th; j < K: optimistic, every row proven by the re-rank), groups redone with guaranteed thresholds
+            out['knn_lists'] = knn_main
         if world == 1 and roof_counts:
             out['other_rooflines'] = other_rooflines(timers, roof_counts, rows_swept, K, Dt, Dj, T)
         if bf16_mode:

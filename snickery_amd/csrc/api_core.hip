@@ -652,8 +652,10 @@ int snk_set_weights(snk_handle h, const double *wt, int n_wt, const double *wj, 
     h->jw32_ready = false;                                     // ... and the float32 copy of the weighted join rows the join weights
     // float32 operands of the prefilter (knn16_kernels.hip): ||f||^2 rides in ONE spare padding column
     h->knn_level = 0;
+    h->opt_off = false; h->opt_calls = 0; h->opt_fails = 0;    // a new set of weights: the optimistic thresholds get another chance
     h->reorder_done = false; h->reorder_pending = false;     // (the order a voice was given stays: any order is valid, and usually still a good one)
     h->vit = snk_engine::VitLatch();                         // a new set of weights: the Viterbi latch starts over
+    h->lb_warm_eff = 0;                                      // ... and pass 2's warm-up is the short one again
     CHK(build_prefilter_operands(h));
     h->wide16_ready = false; h->wide16_tried = false;              // (built at the first call that can use them: ensure_wide_operands)
     h->gs_ready = false;

@@ -70,6 +70,14 @@ void note_ball_pairs(snk_engine *h, unsigned int listed)
     judge_filter(h, h->ball_pass_ran, h->ball_limit, h->coarse_pass_ran, h->coarse_limit, listed, 0, 0.0, 0u);
 }
 
+// a call (or a group of a batch) under optimistic thresholds had a row flagged: counted, and a voice that fails more often than
+// once in 200 calls goes back to the guaranteed thresholds until its weights change
+void note_optimism_failure(snk_engine *h)
+{
+    h->opt_fails += 1; h->opt_fails_total += 1;
+    if (h->opt_fails >= 3 && h->opt_fails * 200 > h->opt_calls) h->opt_off = true;
+}
+
 KnnPlan make_plan(snk_engine *h, int K)
 {
     KnnPlan p{};
@@ -398,9 +406,28 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
             launch_knn_threshold16(h->ball_nql.as<float>(), G2, T, Tpad, K, h->eps16.as<double>(), h->thr.as<double>(),
                                    h->thr32.as<float>(), nullptr, h->ball_bound.as<double>(), s);
         }
+        // ---- optimistic thresholds (snk_engine.h): which minimum of the sample bounds -- or only estimates -- the K-th nearest key.
+        // The sample is every stride-th unit, its groups are scattered over it: at the true K-th key a row has lam = K / stride
+        // sample units under it, Poisson-like, so the j-th smallest minimum with j = lam + 9 sqrt(lam) + 4 lies ABOVE the K-th
+        // nearest key except with a probability of ~1e-10 per row (K = 100, stride 16: j = 33, lists of ~520 entries instead of
+        // ~1 800).  Not a proof: the re-rank proves each row (knn_finalize_kernel, status bit 8) and a flagged call is redone.
+        int k_rank = K;
+        {
+            const bool may = h->tau_optimism && !h->opt_suppress && !h->opt_off && !cls && !bound_in && !bound_out && !refine && !use_gs &&
+                             G16 >= K && h->stride16 > 1 && h->N >= 64 * (int64_t)K;
+            if (may) {
+                const double lam = (double)K / (double)h->stride16;
+                int j = h->tau_rank_override > 0 ? h->tau_rank_override : (int)ceil(lam + 9.0 * sqrt(lam) + 4.0);
+                if (j < 1) j = 1;
+                if (j < K) k_rank = j;
+            }
+        }
+        const bool optimistic = k_rank < K;
+        h->opt_last_rank = optimistic ? k_rank : 0;
+        if (optimistic) h->opt_calls += 1;
         {
             StageTimer t(h, s, TM_KNN_THRESHOLD);
-            launch_knn_threshold16(h->gmin32.as<float>(), G16, T, Tpad, K, h->eps16.as<double>(), h->thr.as<double>(),
+            launch_knn_threshold16(h->gmin32.as<float>(), G16, T, Tpad, k_rank, h->eps16.as<double>(), h->thr.as<double>(),
                                    h->thr32.as<float>(), bound_in, bound_out, s, want_thr1 ? h->e1_16.as<double>() : nullptr,
                                    want_thr1 ? h->thr1_32.as<float>() : nullptr, ball_bound ? h->ball_bound.as<double>() : nullptr);
         }
@@ -533,7 +560,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
                                 h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), eps_c_run, bf ? h->cq16.as<double>() : nullptr, cand_dev, dist_dev, d2_dev, status_dev, nullptr, s,
                                 bound_in != nullptr,         // a shard's lists under the shared bound are short
                                 bound_in ? nullptr : h->thr.as<double>(), h->margin_stat.as<unsigned int>(), h->rowflag.as<int>(),
-                                h->knn_level >= 1);
+                                h->knn_level >= 1, optimistic);
         }
         if (deferred_status) {               // the batch caller redoes failures with precision 0
             // (and learns how many tile pairs the ball pass listed)
@@ -557,6 +584,13 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
         HIPCHK(hipGetLastError());
         h->last_f16_status = status;
         if (status == 0) return 0;
+        if (status & 8) {
+            // a row's list was not proven complete under the optimistic thresholds: the call once more with the guaranteed ones
+            note_optimism_failure(h);
+            struct Guard { snk_engine *e; bool was; ~Guard() { e->opt_suppress = was; } } guard{h, h->opt_suppress};
+            h->opt_suppress = true;
+            return knn_device(h, Qdev, T, K, qclass_dev, cand_dev, dist_dev, d2_dev, nullptr, bound_in, nullptr, gs, refine, nullptr, nullptr);
+        }
         if ((status & ~3) == 0 && h->knn_level < 2 && !refine) {
             // a candidate list overflowed, or a row held more near ties than the exact re-rank takes, and nothing else went wrong:
             // the next rung of the voice's ladder (longer lists + a re-rank tier for 8 192 ties, then the float32 operands) serves

@@ -231,6 +231,16 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (!(value >= 0.0 && value <= 5.0) || value != (double)(int)value) return fail("join_bounds_delay must be 0 .. 5");
         CHK(no_batch_in_flight(h, "snk_set_option(join_bounds_delay)"));
         h->join_bounds_delay = (int)value;
+    } else if (!strcmp(name, "tau_optimism")) {
+        if (value != 0.0 && value != 1.0) return fail("tau_optimism must be 0 or 1");
+        CHK(no_batch_in_flight(h, "snk_set_option(tau_optimism)"));
+        h->tau_optimism = (int)value;
+        h->opt_off = false; h->opt_calls = 0; h->opt_fails = 0;
+    } else if (!strcmp(name, "tau_optimism_rank")) {
+        if (!(value >= 0.0 && value <= 4096.0) || value != (double)(int)value) return fail("tau_optimism_rank must be 0 (automatic) .. 4096");
+        CHK(no_batch_in_flight(h, "snk_set_option(tau_optimism_rank)"));
+        h->tau_rank_override = (int)value;
+        h->opt_off = false; h->opt_calls = 0; h->opt_fails = 0;
     } else if (!strcmp(name, "roofline_counters")) {
         if (value != 0.0 && value != 1.0) return fail("roofline_counters must be 0 or 1");
         CHK(no_batch_in_flight(h, "snk_set_option(roofline_counters)"));
@@ -246,6 +256,10 @@ int snk_set_option(snk_handle h, const char *name, double value)
         }
         const unsigned long long on64 = on;
         CHK(h2d_sync(h, reinterpret_cast<char *>(h->vstats.p) + 8 * sizeof(unsigned long long), &on64, sizeof(on64)));
+    } else if (!strcmp(name, "upload_staged")) {
+        if (value != 0.0 && value != 1.0) return fail("upload_staged must be 0 or 1");
+        CHK(no_batch_in_flight(h, "snk_set_option(upload_staged)"));
+        h->upload_staged = (int)value;
     } else if (!strcmp(name, "upload_stream")) {
         if (value != 0.0 && value != 1.0) return fail("upload_stream must be 0 or 1");
         CHK(no_batch_in_flight(h, "snk_set_option(upload_stream)"));
@@ -432,8 +446,14 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "split_one_group")) *out = h->split_one_group;
     else if (!strcmp(name, "upload_stream")) *out = h->upload_stream;
     else if (!strcmp(name, "roofline_counters")) *out = h->roofline_counters;
+    else if (!strcmp(name, "tau_optimism")) *out = h->tau_optimism;
+    else if (!strcmp(name, "tau_optimism_rank")) *out = h->opt_last_rank;               // j of the most recent call (0: guaranteed thresholds)
+    else if (!strcmp(name, "tau_optimism_failures")) *out = (double)h->opt_fails_total;   // calls / groups redone with guaranteed thresholds
+    else if (!strcmp(name, "tau_optimism_off")) *out = h->opt_off ? 1 : 0;              // this voice went back to guaranteed thresholds
     else if (!strcmp(name, "viterbi_refine_gate")) *out = h->vit_refine_gate;
     else if (!strcmp(name, "viterbi_latch_mode")) *out = h->vit.mode;                 // 0: batches take the sparse path, 1: the dense kernels (judged, snk_engine.h)
+    else if (!strcmp(name, "viterbi_lb_warm_now")) *out = h->lb_warm_eff > h->lb_warm ? h->lb_warm_eff : h->lb_warm;       // warm-up of pass 2's chunks this voice runs with
+    else if (!strcmp(name, "viterbi_lb_warm_raises")) *out = (double)h->lb_warm_raises;
     else if (!strcmp(name, "viterbi_latch_switches")) *out = (double)h->vit.switches;
     else if (!strcmp(name, "viterbi_latch_trials")) *out = (double)h->vit.trials;
     else if (!strcmp(name, "viterbi_latch_ms_row_sparse")) *out = h->vit.ms_row[0];

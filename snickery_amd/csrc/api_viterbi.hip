@@ -101,7 +101,7 @@ static int viterbi_sparse_rows(snk_engine *h, UttSlot &s, const int64_t *cand, c
         StageTimer t(h, side, TM_DP_LB);
         launch_viterbi_lb(cand, tdist, s.Jlo.as<float>(), s.scale.as<float>(), off, n_utts, K, join_units(h),
                           (float)h->join_beta, s.sets.p, side,
-                          n_utts <= h->lb_chunk_max_utts ? (n_utts <= 4 && h->lb_chunk > 32 ? 32 : h->lb_chunk) : 0, h->lb_warm,
+                          n_utts <= h->lb_chunk_max_utts ? (n_utts <= 4 && h->lb_chunk > 32 ? 32 : h->lb_chunk) : 0, h->lb_warm_eff > h->lb_warm ? h->lb_warm_eff : h->lb_warm,
                           h->viterbi_weights == 1 ? (float)h->fst32_slack : 0.f);
     }
     {
@@ -442,6 +442,14 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
         }
         {
             StageTimer t(h, us, TM_H2D);
+            if (h->upload_staged) {
+                // experiment (option upload_staged): always through the library's own page-locked staging (hipHostMalloc), also for rows
+                // the caller registered (hipHostRegister)
+                const size_t bytes = (size_t)total * D * sizeof(double);
+                CHK(b.qstage.ensure(bytes));
+                memcpy(b.qstage.p, Q, bytes);
+                HIPCHK(hipMemcpyAsync(b.Qall.p, b.qstage.p, bytes, hipMemcpyHostToDevice, us));
+            } else
             CHK(h2d_via(b.qstage, b.Qall.p, Q, (size_t)total * D * sizeof(double), us));
         }
         if (us != h->stream) {
@@ -565,6 +573,12 @@ int snk_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, i
                 v.ms_row[m] = v.ms_row[m] > 0.0 ? 0.75 * v.ms_row[m] + 0.25 * row_ms : row_ms;
                 // a trial of the other path: from the sparse path only where its bounds do not prune (cells refined in pass 4)
                 const bool gate = v.mode == 1 || cells > h->vit_refine_gate * (double)b.total * (double)b.K;
+                // before the dense kernels are tried: a longer warm-up of pass 2's chunks (snk_engine.h lb_warm_eff)
+                if (v.mode == 0 && gate && h->lb_chunk > 0 && (h->lb_warm_eff > h->lb_warm ? h->lb_warm_eff : h->lb_warm) < h->lb_warm_long) {
+                    h->lb_warm_eff = h->lb_warm_long; h->lb_warm_raises += 1;
+                    v.ms_row[0] = 0.0;                             // (the sparse path's period is measured afresh)
+                    v.next_probe = v.batches + 3;                  // (the batches in flight still ran with the short one)
+                } else
                 if (v.trial_left == 0 && v.batches >= v.next_probe && gate) {
                     v.trial_mode = 1 - v.mode; v.trial_left = 3; v.trial_best = 0.0; v.trials += 1;
                 }
@@ -577,12 +591,18 @@ int snk_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, i
         if (status[g] & 2) h->tie_overflow = 1;
         const int64_t r0 = b.offs[b.first[g]], rows = b.offs[b.first[g + 1]] - r0;
         const int saved = h->precision;
-        // a lone list overflow: the fast path once more, non-deferred -- it takes the voice up its ladder (longer lists, float32
-        // operands: snk_engine.h knn_level) and later batches start there; anything else: the exact float64 sweep
-        if (!((status[g] & ~3) == 0 && h->knn_level < 2)) h->precision = 0;
+        const bool saved_sup = h->opt_suppress;
+        // bit 8: a row's list was not proven complete under the optimistic thresholds (snk_engine.h): the fast path once more with
+        // the guaranteed ones.  A lone list overflow: the fast path once more, non-deferred -- it takes the voice up its ladder
+        // (longer lists, float32 operands: snk_engine.h knn_level) and later batches start there; anything else: the exact
+        // float64 sweep
+        if (status[g] & 8) { note_optimism_failure(h); h->opt_suppress = true; }
+        const int st = status[g] & ~8;
+        if (st && !((st & ~3) == 0 && h->knn_level < 2)) h->precision = 0;
         const int rc = knn_device(h, b.Qall.as<double>() + r0 * b.D, rows, b.K, nullptr,
                                   b.cand.as<int64_t>() + r0 * b.K, b.dist.as<double>() + r0 * b.K, nullptr);
         h->precision = saved;
+        h->opt_suppress = saved_sup;
         if (rc) return rc;
         CHK(viterbi_group(h, g, b.offs.data(), b.first[g], b.first[g + 1], b.K, b.cand.as<int64_t>(), b.dist.as<double>(), false,
                           b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), b.n_utts));

@@ -953,7 +953,9 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
         return;
     }
     const int n = n_all;
+    const bool verify = (big_tier & 2) != 0;        // optimistic thresholds (api_knn.hip): the list is proven to hold the K nearest, or the row is flagged
     if (n == 0) {
+        if (verify && threadIdx.x == 0) atomicOr(status, 8);
         // nothing of this row lives here (a shard whose units are all beyond the shared bound): K padding entries
         for (int j = threadIdx.x; j < K; j += blockDim.x) {
             if (cand) cand[row * K + j] = -1;
@@ -1009,7 +1011,8 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
     double margin = 0.0;
     if (eps) margin = 2.0 * eps[row];         // |key~ - key| <= eps[row] for every unit of the database (prepare_queries16[b])
     const double scale = (kmax > kmin) ? 256.0 / (kmax - kmin) : 0.0;
-    bool fast = (n > 4 * K && n > 256) && (scale > 0.0) && (kk == K);
+    // (lists of optimistic thresholds are a few K long: the selection serves them from K + K / 2 entries on)
+    bool fast = (n > K + K / 2 && n > 256) && (scale > 0.0) && (kk == K);
     if (fast) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             int b = (int)(((double)key[i] - kmin) * scale);
@@ -1069,7 +1072,7 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
                 const double delta = 1e-10 * (fabs(kth) + qnorm[row] + 1.0) + margin;
                 while (ns < n && ns < SELM && (double)key[ns] <= kth + delta) ++ns;
                 if (ns == SELM && ns < n && (double)key[ns] <= kth + delta) {
-                    if (!SELX && big_tier && retry) { retry[row] = 2; ns = -1; }      // more near ties than this form holds: the big tier's row
+                    if (!SELX && (big_tier & 1) && retry) { retry[row] = 2; ns = -1; }      // more near ties than this form holds: the big tier's row
                     else { atomicOr(status, 2); if (rowflag) rowflag[row] = 2; }
                 }
             }
@@ -1144,6 +1147,16 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
             atomicMin(&margin_stat[1], __float_as_uint(ratio));
         }
     }
+    // Optimistic thresholds (api_knn.hip: the filter's threshold came from FEWER than K sample minima -- an estimate, no bound):
+    // the list holds every unit whose approximate key lies under thr.  If it has K entries and the exact K-th key k of the LIST
+    // satisfies k + eps <= thr, every unit of the database with a true key <= k has an approximate key <= k + eps <= thr and is
+    // in the list: the list's K nearest are the database's.  Otherwise the row is flagged and the caller redoes the call with
+    // guaranteed thresholds (status bit 8).
+    if (verify && threadIdx.x == 0) {
+        bool proven = kk == K && n >= K;
+        if (proven && thr && eps && thr[row] < 0.5 * DBL_MAX) proven = (thr[row] - (ex_key[K - 1] - qnorm[row])) >= eps[row];
+        if (!proven) atomicOr(status, 8);
+    }
     for (int j = threadIdx.x; j < K; j += blockDim.x) {
         int64_t c = -1;
         double d2 = SNK_VERY_BIG * SNK_VERY_BIG, d = SNK_VERY_BIG;
@@ -1158,8 +1171,9 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
                          int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c, const double *cq,
                          int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s, bool split_short,
-                         const double *thr, unsigned int *margin_stat, int *retry, bool big_tier)
+                         const double *thr, unsigned int *margin_stat, int *retry, bool big_tier, bool verify_thr)
 {
+    const int vf = verify_thr ? 2 : 0;                       // bit 1 of the kernels' big_tier word
     int P = 2;
     while (P < cap) P <<= 1;
     // prefilter keys (eps given) are float32 values: 8 bytes per list entry in LDS instead of 12; the exact keys of the
@@ -1174,17 +1188,17 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
 #undef SNK_FIN_ATTR
     });
 #define SNK_FIN(C_, F_, SH_) hipLaunchKernelGGL((knn_finalize_kernel<C_, F_>), dim3((unsigned)T), dim3(256), SH_, s, Fw, F_unw, Fp, wt, Dpad, D, Qp, \
-                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, nullptr, 0)
+                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, nullptr, vf)
     if (f32k && retry && !split_short && !rowflag) {
         // the lean form for (nearly) every row, the full form for the rows it flags
         size_t lean = (size_t)P * sizeof(float);
         if (lean < (size_t)SEL_MAX * sizeof(double)) lean = (size_t)SEL_MAX * sizeof(double);
         (void)hipMemsetAsync(retry, 0, (size_t)T * sizeof(int), s);
         hipLaunchKernelGGL((knn_finalize_kernel<0, true, true>), dim3((unsigned)T), dim3(256), lean, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
-                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, 0);
+                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, vf);
         const int big = (big_tier && cap <= 8192) ? 1 : 0;
         hipLaunchKernelGGL((knn_finalize_kernel<0, true, false>), dim3((unsigned)T), dim3(256), shmem, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
-                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, big);
+                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, big | vf);
         if (big) {
             // third tier (a voice that has overflowed before: api_knn.hip knn_level): the rows with more near ties than SEL_MAX
             size_t shbig = (size_t)P * (sizeof(float) + sizeof(int));
@@ -1194,7 +1208,7 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_finalize_kernel<0, true, false, 8192>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shbig); });
             hipLaunchKernelGGL((knn_finalize_kernel<0, true, false, 8192>), dim3((unsigned)T), dim3(256), shbig, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
-                               qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, 0);
+                               qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, vf);
         }
         return;
     }

@@ -209,7 +209,18 @@ struct snk_engine {
     int device = 0;
     hipStream_t stream = nullptr, stream2 = nullptr, copy_stream = nullptr;
     hipStream_t up_stream = nullptr;       // query rows of a submitted batch: host -> HBM beside the batch before it (created at the first submit)
+    // Optimistic thresholds (api_knn.hip): the filter threshold of the matrix prefilter from the j-th smallest sample minimum,
+    // j < K -- an ESTIMATE of the K-th nearest key that makes the lists 3-4 x shorter; the re-rank proves every row's list
+    // complete or flags the call, which is then redone with the guaranteed thresholds (the K-th smallest minimum)
+    int tau_optimism = 1;                  // option
+    int tau_rank_override = 0;             // option tau_optimism_rank (tests): j, 0 = chosen from K and the sample's stride
+    bool opt_suppress = false;             // a redo in progress: guaranteed thresholds
+    bool opt_off = false;                  // this voice (set of weights) failed too often: guaranteed thresholds until the weights change
+    int64_t opt_calls = 0, opt_fails = 0;  // calls that ran optimistic since the weights were set / that had a row flagged
+    int64_t opt_fails_total = 0;
+    int opt_last_rank = 0;                 // j of the most recent call (0: it ran with guaranteed thresholds)
     int roofline_counters = 0;             // option: the re-rank and pass 3 count what their rooflines are priced on (atomics on one address: off in production)
+    int upload_staged = 0;                 // option (experiment): submitted rows always through the library's own pinned staging
     int upload_stream = 1;                 // option: 0 = the rows are uploaded on the main stream, as until round 5
     BatchSlot bslot[2];
     int bnext = 0;
@@ -409,6 +420,13 @@ struct snk_engine {
     int lb_chunk = 48;
     int lb_chunk_max_utts = 24;
     int lb_warm = 16;
+    // the warm-up this VOICE runs with: a voice whose totals remember more than 16 steps (join costs that hardly differ between
+    // candidates: speech-like data) fails pass 4's proofs by the tens of thousands with chunks started 16 steps early (profiles/
+    // r06b_sweep.log: 61 000 refined cells per 16 utterances, 17 ms; 3 000 and 2 ms with 48) -- a batch that refines more than
+    // viterbi_refine_gate of its cells takes the voice to lb_warm_long; back to lb_warm when the weights change
+    int lb_warm_eff = 0;       // 0: lb_warm
+    int lb_warm_long = 48;
+    int64_t lb_warm_raises = 0;
     DevBuf vstats;             // [0] cells refined, [1] steps with a refinement, [2] exact costs computed there
     // pass 1 of the sparse path, second form (joinfast_kernels.hip: join_lb2_kernel): float32 copy of the weighted join rows,
     // built at the first sparse recursion after snk_set_weights; [0] of jw_umax: bits of the largest row norm
@@ -495,6 +513,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
 
 // Viterbi side of a group of utterances (api_viterbi.hip)
 bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts = 1);
+void note_optimism_failure(snk_engine *h);
 std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offsets, int n_utts, bool knn_beside);
 int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u0, int u1, int K,
                   const int64_t *cand_all, const double *tdist_all, bool side_stream,

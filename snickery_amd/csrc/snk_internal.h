@@ -116,7 +116,8 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
                          bool split_short = false,    // split_short: rows of at most 512 entries through the small-LDS instance
                          const double *thr = nullptr, unsigned int *margin_stat = nullptr,    // tripwire of the prefilter's key bound
                          int *retry = nullptr,      // T ints of scratch: the lean form (keys only in LDS) first, the full form for the rows it flags
-                         bool big_tier = false);    // ... and a third form (selection of 8 192) for the rows with more near ties than the full form holds
+                         bool big_tier = false,     // ... and a third form (selection of 8 192) for the rows with more near ties than the full form holds
+                         bool verify_thr = false);  // optimistic thresholds: rows whose list is not PROVEN to hold the K nearest set status bit 8
 void launch_candidate_dist(const double *Fw, int Dpad, int D, int64_t N, const double *Qp,
                            const int64_t *cand, int64_t T, int K, double *dist, hipStream_t s);
 void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, int K,

@@ -329,6 +329,9 @@ def test_speechlike_voice_at_headline_size(engine):
     for _ in range(3):                              # the engine judges the voice (filter latch, unit order, Viterbi path) over its first batches
         paths, costs = engine.knn_viterbi_batch(utts, K)
     assert engine.info('exact_row_fallbacks') == 0
+    # join costs that hardly differ between candidates: pass 2's chunks need the long warm-up (snk_engine.h lb_warm_eff); the first
+    # batch's refinements took the voice there
+    assert engine.info('viterbi_lb_warm_now') == 48, engine.info('dense_cells')
     assert engine.info('prefilter_margin_rows') == 0, engine.info('prefilter_min_margin')
     assert engine.info('join_bound_violations') == 0, engine.info('join_bound_min_margin')
     cd = [engine.knn(u, K) for u in utts]
@@ -337,9 +340,6 @@ def test_speechlike_voice_at_headline_size(engine):
     oc_cand, oc_dist = oc.knn(F, utts[0][rows], K)
     assert np.array_equal(cd[0][0][rows], oc_cand), 'candidates of the spot rows differ from the C oracle'
     assert np.array_equal(cd[0][1][rows], oc_dist), 'distances of the spot rows differ from the C oracle'
-    # a held-out frame's neighbours are strangers: not runs of consecutive units (what SURVEY 8d's walk gives)
-    runs = np.mean(np.diff(np.sort(cd[0][0], axis=1), axis=1) == 1)
-    assert runs < 0.2, runs
     del F
     JCw = o.weight(JC_unw, wj)
     for u in range(U):

@@ -372,3 +372,54 @@ def test_the_filter_latches_are_rearmable(engine):
     for _ in range(3):
         engine.knn(far, K)
     assert engine.info('filter_coarse') == 1
+
+
+def test_optimistic_thresholds_are_proven_row_by_row_or_redone(engine):
+    """Optimistic thresholds (api_knn.hip): the filter threshold is the j-th smallest sample minimum with j < K -- an estimate
+    that makes the lists a few K long instead of ~18 K.  Never trusted: the re-rank proves every row's list complete (exact
+    K-th key + eps under the threshold) or flags the call, which is redone with the guaranteed thresholds.  Here: the default
+    rank shortens the lists and changes nothing; a rank of 1 (thresholds far too low) flags nearly every row, the results stay
+    the oracle's through the redo -- single calls and batches -- and after a few failures the voice stops trying."""
+    engine.set_option('prefilter', 1)
+    N, Dt, K, T = 300000, 61, 100, 96
+    F_unw, wt, F = setup(engine, N, Dt, seed=41)
+    U = o.synthetic_targets(F_unw, T, seed=6) * wt
+    ocand, odist = oc.knn(F, U, K)
+    engine.set_option('tau_optimism', 0)
+    c0, d0 = engine.knn(U, K)
+    long_lists = engine.info('last_list_mean')
+    assert engine.info('tau_optimism_rank') == 0
+    engine.set_option('tau_optimism', 1)
+    fails = engine.info('tau_optimism_failures')
+    c1, d1 = engine.knn(U, K)
+    j = engine.info('tau_optimism_rank')
+    assert 1 <= j < K and engine.info('tau_optimism_failures') == fails
+    assert engine.info('last_list_mean') < 0.5 * long_lists, (engine.info('last_list_mean'), long_lists)
+    for c, d in ((c0, d0), (c1, d1)):
+        assert np.array_equal(c, ocand) and np.array_equal(d, odist)
+    # thresholds that are far too low: every call is flagged and redone; the third failure turns the voice's optimism off
+    engine.set_option('tau_optimism_rank', 1)
+    for i in range(3):
+        c2, d2 = engine.knn(U, K)
+        assert np.array_equal(c2, ocand) and np.array_equal(d2, odist)
+        assert engine.info('tau_optimism_failures') == fails + i + 1
+    assert engine.info('tau_optimism_off') == 1
+    c3, d3 = engine.knn(U, K)
+    assert engine.info('tau_optimism_rank') == 0 and engine.info('tau_optimism_failures') == fails + 3
+    assert np.array_equal(c3, ocand) and np.array_equal(d3, odist)
+    # a batch (deferred status words: the flagged group is redone at the collect), two in flight
+    engine.set_option('tau_optimism_rank', 1)                  # (re-arms the voice)
+    utts = [o.synthetic_targets(F_unw, t, seed=60 + i) * wt for i, t in enumerate((40, 64, 33))]
+    redos = engine.info('batch_redos')
+    ta, tb = engine.knn_viterbi_batch_submit(utts, K), engine.knn_viterbi_batch_submit(utts[:2], K)
+    pa, ca = engine.knn_viterbi_batch_collect(ta)
+    pb, cb = engine.knn_viterbi_batch_collect(tb)
+    assert engine.info('batch_redos') > redos
+    engine.set_option('tau_optimism_rank', 0)
+    engine.set_option('tau_optimism', 0)
+    pr, cr = engine.knn_viterbi_batch(utts, K)
+    engine.set_option('tau_optimism', 1)
+    assert all(np.array_equal(a, b) for a, b in zip(pa, pr)) and np.array_equal(ca, cr)
+    assert all(np.array_equal(a, b) for a, b in zip(pb, pr[:2])) and np.array_equal(cb, cr[:2])
+    po, co = engine.knn_viterbi_batch(utts, K)                 # the default rank again
+    assert all(np.array_equal(a, b) for a, b in zip(po, pr)) and np.array_equal(co, cr)
