@@ -503,6 +503,8 @@ def compact_line(out):
     for k in ('replicas', 'note'):
         if k in out:
             line[k] = out[k] if isinstance(out[k], str) else dict((a, _r(b, 3)) for a, b in out[k].items() if a != 'note')
+    if 'host_ms_per_step' in out:
+        line['host_ms_per_step'] = dict((k, _r(v, 3)) for k, v in out['host_ms_per_step'].items())
     if 'knn_lists' in out:
         line['knn_lists'] = dict((k, _r(v, 1)) for k, v in out['knn_lists'].items())
     line['stages_ms_per_step'] = dict((k, _r(v, 3)) for k, v in out.get('stages_ms_per_step', {}).items())
@@ -697,12 +699,17 @@ def main():
         for _ in range(2):                  # both workspaces of the two-in-flight pipeline primed (and hold the rows for the resident-rows pass)
             paths, costs = eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(batch, K))
 
+    host_ms = {'submit': 0.0, 'collect': 0.0, 'n': 0}
+
     def pipelined(steps, res):
         pending, out = None, None
         for _ in range(steps):
+            h0 = time.perf_counter()
             ticket = eng.knn_viterbi_batch_submit(batch, K, resident=res)
+            h1 = time.perf_counter()
             if pending is not None:
                 out = eng.knn_viterbi_batch_collect(pending)
+            host_ms['submit'] += (h1 - h0) * 1e3; host_ms['collect'] += (time.perf_counter() - h1) * 1e3; host_ms['n'] += 1
             pending = ticket
         return eng.knn_viterbi_batch_collect(pending)
     eng.reset_timers()
@@ -729,6 +736,7 @@ def main():
             paths, costs = step()
     sync()
     elapsed = time.perf_counter() - t0
+    host_main = dict(host_ms)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if share_gpu else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -962,6 +970,9 @@ def main():
                                        'whole-chip kernels do (sum of their stand-alone times 4.1 of the 4.6 ms step, DESIGN.md 4.3)'}
         else:
             out['roofline'] = dict(out['filter_stage'])
+        if host_main['n']:
+            # the host's side of a step: time inside submit (uploads and launches queued) and inside collect (mostly waiting)
+            out['host_ms_per_step'] = {'submit': host_main['submit'] / host_main['n'], 'collect_wait': host_main['collect'] / host_main['n']}
         if knn_main:
             # the K-NN lists of the timed steps: their mean length per row, the rank of the sample minimum the thresholds came from
             # (0: the guaranteed K-th; j < K: optimistic, every row proven by the re-rank), groups redone with guaranteed thresholds

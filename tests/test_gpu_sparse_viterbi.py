@@ -260,3 +260,57 @@ def test_viterbi_latch_judges_the_two_exact_paths_and_keeps_the_results(engine):
     trials, mode = run(JC_unw[perm], 12)
     assert trials == 0 and mode == 0
     engine.set_option('viterbi_latch', 1)
+
+
+@pytest.mark.parametrize('delay', [0, 1, 2, 3, 4, 5])
+def test_delayed_viterbi_side_in_every_collect_order(engine, delay):
+    """join_bounds_delay (where the Viterbi side of a group starts; the last group of a batch is left to the next submit or to its own
+    collect) against delay 0: two batches in flight collected in order and out of order, a batch collected before the next is
+    submitted, batches of one group and of several, a batch cut into two groups -- the same paths and costs."""
+    N, Dt, Dj, K = 60000, 61, 151, 40
+    F_unw, JC_unw, wt, wj = _db(N, Dt, Dj, seed=17)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    engine.set_option('viterbi_mode', 2)
+    rng = np.random.RandomState(3)
+    big = [o.synthetic_targets(F_unw, T, seed=200 + i) * wt for i, T in enumerate((700, 650, 720, 600, 680, 710, 640, 690, 600, 660))]   # > 6 144 rows: two groups
+    small = [o.synthetic_targets(F_unw, T, seed=300 + i) * wt for i, T in enumerate((40, 64, 33))]                                       # one group: all tail
+    engine.set_option('batch_rows', 2048)
+    several = big[:6]                                                                                                                    # four groups of 2 048 rows
+    engine.set_option('batch_rows', 12288)
+    engine.set_option('join_bounds_delay', 0)
+    want = {}
+    for name, batch, rows in (('big', big, 12288), ('small', small, 12288), ('several', several, 2048)):
+        engine.set_option('batch_rows', rows)
+        want[name] = engine.knn_viterbi_batch(batch, K)
+    engine.set_option('join_bounds_delay', delay)
+
+    def same(got, name):
+        return all(np.array_equal(a, b) for a, b in zip(got[0], want[name][0])) and np.array_equal(got[1], want[name][1])
+    try:
+        for name, batch, rows in (('big', big, 12288), ('small', small, 12288), ('several', several, 2048)):
+            engine.set_option('batch_rows', rows)
+            other = 'small' if name != 'small' else 'big'
+            ob = small if name != 'small' else big
+            if rows != 12288:
+                other, ob = name, batch
+            # in order
+            ta, tb = engine.knn_viterbi_batch_submit(batch, K), engine.knn_viterbi_batch_submit(ob, K)
+            ga, gb = engine.knn_viterbi_batch_collect(ta), engine.knn_viterbi_batch_collect(tb)
+            assert same(ga, name) and same(gb, other), (delay, name, 'in order')
+            # out of order: the batch submitted last is collected first
+            ta, tb = engine.knn_viterbi_batch_submit(batch, K), engine.knn_viterbi_batch_submit(ob, K)
+            gb, ga = engine.knn_viterbi_batch_collect(tb), engine.knn_viterbi_batch_collect(ta)
+            assert same(ga, name) and same(gb, other), (delay, name, 'out of order')
+            # one at a time, then three submits with a collect in between
+            assert same(engine.knn_viterbi_batch_collect(engine.knn_viterbi_batch_submit(batch, K)), name)
+            ta = engine.knn_viterbi_batch_submit(batch, K)
+            tb = engine.knn_viterbi_batch_submit(ob, K)
+            ga = engine.knn_viterbi_batch_collect(ta)
+            tc = engine.knn_viterbi_batch_submit(batch, K)
+            gb, gc = engine.knn_viterbi_batch_collect(tb), engine.knn_viterbi_batch_collect(tc)
+            assert same(ga, name) and same(gb, other) and same(gc, name), (delay, name, 'three')
+    finally:
+        engine.set_option('join_bounds_delay', 1)
+        engine.set_option('batch_rows', 12288)
+    assert engine.info('join_bound_violations') == 0

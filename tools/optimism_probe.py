@@ -1,0 +1,35 @@
+"""Optimistic K-NN thresholds (api_knn.hip) on a voice: list lengths, flagged calls and stage times per rank j of the sample minimum
+the thresholds come from (0 = the engine's choice; K = guaranteed).   python tools/optimism_probe.py [--speechlike] [rows]"""
+import sys, os, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import snickery_amd
+from bench import synthetic_db, synthetic_targets, speechlike_voice
+args = [a for a in sys.argv[1:] if not a.startswith('--')]
+rows = int(args[0]) if args else 9600
+N, Dt, Dj, K = 1048576, 61, 302, 100
+held_out = None
+if '--speechlike' in sys.argv: F_unw, JC_unw, held_out = speechlike_voice(N, Dt, Dj, seed=0)
+else: F_unw, JC_unw = synthetic_db(N, Dt, Dj, seed=0)
+wt = np.full(Dt, 0.4); wj = np.full(Dj, 0.05)
+U = np.vstack([(held_out(600, s) if held_out else synthetic_targets(F_unw, 600, seed=1 + s)) * wt for s in range((rows + 599) // 600)])[:rows]
+eng = snickery_amd.HipSearchEngine(0)
+eng.upload_db(F_unw, JC_unw); eng.set_weights(wt, wj)
+eng.set_option('tau_optimism', 0)
+ref = eng.knn(U, K)
+for _ in range(2): eng.knn(U, K)          # (the filter latch settles)
+for j in (K, 0, 24, 33, 48, 64):
+    eng.set_option('tau_optimism', 0 if j == K else 1)
+    eng.set_option('tau_optimism_rank', 0 if j == K else j)
+    f0 = eng.info('tau_optimism_failures')
+    c, d = eng.knn(U, K)
+    eng.reset_timers()
+    t0 = time.time()
+    for _ in range(3): c, d = eng.knn(U, K)
+    dt = (time.time() - t0) / 3
+    print('rank %3d (ran with %3d): %.2f ms/call same=%s list mean %.0f max %.0f flagged calls %d off %d status %d coarse %d  %s' % (
+        j, eng.info('tau_optimism_rank'), dt * 1e3, np.array_equal(c, ref[0]) and np.array_equal(d, ref[1]), eng.info('last_list_mean'), eng.info('last_list_max'),
+        eng.info('tau_optimism_failures') - f0, eng.info('tau_optimism_off'), eng.info('last_f16_status'), eng.info('filter_coarse'),
+        {k: round(v[0] / 3, 3) for k, v in eng.timers().items() if v[1]}), flush=True)
+eng.close()
