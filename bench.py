@@ -359,22 +359,22 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
     batch = snickery_amd.QueryBatch([(targets(T, u) if targets is not None else
                                       synthetic_targets(F_unw if targets_from is None else targets_from, T, seed=1 + u)) * wt for u in range(U)])
     batch.pin()
-    for _ in range(4):                           # primes both workspaces; the engine judges the voice (filter passes, unit order, Viterbi path)
+    for _ in range(5):                           # primes every workspace; the engine judges the voice (filter passes, unit order, Viterbi path)
         eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(batch, K))
     before = (eng.info('f16_fallbacks'), eng.info('batch_redos'), eng.info('exact_row_fallbacks'))
     eng.reset_timers()
     cells0 = eng.info('dense_cells')
 
-    def run(resident):
+    def run(resident, depth=3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        pending = None
+        pending, res = [], None
         for _ in range(steps):
-            tk = eng.knn_viterbi_batch_submit(batch, K, resident=resident)
-            if pending is not None:
-                eng.knn_viterbi_batch_collect(pending)
-            pending = tk
-        res = eng.knn_viterbi_batch_collect(pending)
+            pending.append(eng.knn_viterbi_batch_submit(batch, K, resident=resident))
+            if len(pending) >= depth:
+                res = eng.knn_viterbi_batch_collect(pending.pop(0))
+        while pending:
+            res = eng.knn_viterbi_batch_collect(pending.pop(0))
         torch.cuda.synchronize()
         return time.perf_counter() - t0, res
     dt, _ = run(True)
@@ -536,11 +536,12 @@ def main():
                          '1: force that path; 0: dense exact float64 join costs')
     ap.add_argument('--opt', action='append', default=[], metavar='NAME=VALUE', help='engine option (snk_set_option), for experiments')
     ap.add_argument('--join-beta', type=float, default=None, help='margin of the predecessor sets (speed only)')
-    ap.add_argument('--in-flight', type=int, default=2, choices=(1, 2),
-                    help='N = 1: steps in flight; 2 (default) submits step i+1 before collecting step i, so the tail of a step '
+    ap.add_argument('--in-flight', type=int, default=3, choices=(1, 2, 3),
+                    help='N = 1: steps in flight; 2 submits step i+1 before collecting step i, so the tail of a step '
                          '(the per-utterance recursions of its last group, the copy of the results) runs beside the K-NN of the '
-                         'next one -- how a tuning loop over a tune set drives the engine; every step completes inside the timed '
-                         'region.  1: strictly one step at a time (reported as extra field one_in_flight otherwise)')
+                         'next one -- how a tuning loop over a tune set drives the engine; 3 (default; the library has three workspaces) '
+                         'submits step i+2 as well, so that the K-NN stream has work while the host waits for step i; every step '
+                         'completes inside the timed region.  1: strictly one step at a time (reported as extra field one_in_flight otherwise)')
     ap.add_argument('--resident-rows', action='store_true',
                     help='N = 1, experiments: `value` = the rate with the query rows left in HBM by two untimed priming submits '
                          '(default: `value` is the host -> host rate of SURVEY 8d -- the query rows are uploaded from and the paths '
@@ -693,35 +694,38 @@ def main():
     # step's input and cross the boundary the way every caller of the package hands them over -- host memory (page-locked) ->
     # HBM inside the step, paths back to host memory inside the step: SURVEY 8d's wall time, VERDICT r5 item 1.
     # --resident-rows: the rows where two untimed priming submits left them (Q == NULL, include/snk.h), for experiments.
-    resident = world == 1 and args.in_flight == 2 and args.resident_rows
-    if world == 1 and args.in_flight == 2:
+    resident = world == 1 and args.in_flight >= 2 and args.resident_rows
+    if world == 1 and args.in_flight >= 2:
         batch.pin()
-        for _ in range(2):                  # both workspaces of the two-in-flight pipeline primed (and hold the rows for the resident-rows pass)
+        for _ in range(3):                  # every workspace of the pipeline primed (and holds the rows for the resident-rows pass)
             paths, costs = eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(batch, K))
 
     host_ms = {'submit': 0.0, 'collect': 0.0, 'n': 0}
 
-    def pipelined(steps, res):
-        pending, out = None, None
+    def pipelined(steps, res, depth=None):
+        # `depth` steps in flight: a step is collected when `depth` are pending (every step completes before this returns)
+        depth = depth or max(args.in_flight, 2)
+        pending, out = [], None
         for _ in range(steps):
             h0 = time.perf_counter()
-            ticket = eng.knn_viterbi_batch_submit(batch, K, resident=res)
+            pending.append(eng.knn_viterbi_batch_submit(batch, K, resident=res))
             h1 = time.perf_counter()
-            if pending is not None:
-                out = eng.knn_viterbi_batch_collect(pending)
+            if len(pending) >= depth:
+                out = eng.knn_viterbi_batch_collect(pending.pop(0))
             host_ms['submit'] += (h1 - h0) * 1e3; host_ms['collect'] += (time.perf_counter() - h1) * 1e3; host_ms['n'] += 1
-            pending = ticket
-        return eng.knn_viterbi_batch_collect(pending)
+        while pending:
+            out = eng.knn_viterbi_batch_collect(pending.pop(0))
+        return out
     eng.reset_timers()
     sync()
     t0 = time.perf_counter()
-    if world == 1 and args.in_flight == 2:
-        # two steps in flight: step i+1 is submitted before step i is collected, so the tail of a step
+    if world == 1 and args.in_flight >= 2:
+        # steps in flight: step i+1 is submitted before step i is collected, so the tail of a step
         # (its last recursions, the copy of the results, the host-side hand-over) runs beside the K-NN
         # of the next one -- what a tuning loop over a tune set does.  All K steps complete inside
         # the timed region.
         paths, costs = pipelined(args.steps, resident)
-    elif world > 1 and args.in_flight == 2 and pipeline is not None:
+    elif world > 1 and args.in_flight >= 2 and pipeline is not None:
         my_utts.pin()
         submit, collect = pipeline
         pending = None
@@ -747,6 +751,7 @@ def main():
     # other pass adds to them: exact costs pass 3 took from the rows, list entries the re-rank read / gave exact distances
     roof_counts = {}
     knn_main = dict((k, eng.info(k)) for k in ('last_list_mean', 'last_list_max', 'tau_optimism_rank', 'tau_optimism_failures', 'tau_optimism_off', 'batch_redos', 'f16_fallbacks')) if world == 1 else {}
+    starved = (eng.info('submits_starved'), eng.info('submits_pipelined'), eng.info('submits_starved_recent')) if world == 1 else None
     trip_main = dict((k, eng.info(k)) for k in ('prefilter_margin_rows', 'prefilter_min_margin', 'join_bound_violations', 'join_bound_min_margin')) if world == 1 else {}
     # N > 1, database sharded: the same GPUs as independent replicas (every GPU the whole database -- B* needs 3.5 GB of
     # 288 -- and its own 32 utterances, no collective), timed the same way: an extra field, never `value`.  Sharding is for
@@ -787,7 +792,7 @@ def main():
             sys.stderr.write('replicas extra skipped: %s\n' % (err or 'a rank failed'))
     # the same pipeline in the OTHER input mode (an extra field, never `value`): rows resident in HBM, or uploaded every step
     other_mode = None
-    if world == 1 and args.in_flight == 2:
+    if world == 1 and args.in_flight >= 2:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         pu, cu = pipelined(args.steps, not resident)
@@ -797,6 +802,15 @@ def main():
                       'same_results': bool(all(np.array_equal(a, b) for a, b in zip(pu, paths)) and np.array_equal(cu, costs)),
                       'note': ('the query rows (%.1f MB per step) cross PCIe inside every timed step, from page-locked host memory' % (batch.Q.nbytes / 1e6)) if resident else
                               'the query rows searched where two untimed priming submits left them in HBM (Q == NULL): a mode no caller of the package uses'}
+    depth2 = None
+    if world == 1 and args.in_flight == 3:
+        # the same loop with TWO steps in flight (the depth of rounds 2-5), an extra field
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pipelined(args.steps, resident, depth=2)
+        torch.cuda.synchronize()
+        e2d = time.perf_counter() - t1
+        depth2 = {'value': frames_per_step * args.steps / e2d, 'unit': 'frames/s', 'ms_per_step': e2d / args.steps * 1e3}
     if world == 1:
         # the counting pass (untimed, two steps): the kernels add up what their rooflines are priced on only while option
         # roofline_counters is on -- thousands of workgroups adding to one address cost 0.3-0.4 ms per launch (profiles/r06_a)
@@ -879,7 +893,7 @@ def main():
                                    'T=%d frames x %d utterances per step, K=%d, search_epsilon=0'
                                    % (N, Dt, Dj, T, U, K),
                        'units': N, 'target_dim': Dt, 'join_dim': Dj, 'frames': T, 'utts_per_step': U, 'utts_per_gpu': U // world,
-                       'n_candidates': K, 'steps_in_flight': args.in_flight if (world == 1 or pipeline is not None) else 1,
+                       'n_candidates': K, 'steps_in_flight': args.in_flight if world == 1 else (min(args.in_flight, 2) if pipeline is not None else 1),
                        'sharding': 'none' if world == 1 else (
                            '%d independent replicas' % world if S == 1 else
                            'db-rows/%d + all-to-all of local top-K' % S + (' x %d replica groups' % n_groups if n_groups > 1 else '')),
@@ -973,6 +987,9 @@ def main():
         if host_main['n']:
             # the host's side of a step: time inside submit (uploads and launches queued) and inside collect (mostly waiting)
             out['host_ms_per_step'] = {'submit': host_main['submit'] / host_main['n'], 'collect_wait': host_main['collect'] / host_main['n']}
+            if starved:
+                # submits (since the engine was created) that found everything of the batch before already run: the K-NN stream was idle
+                out['host_ms_per_step'].update({'submits_that_found_the_stream_idle': starved[0], 'of_pipelined_submits': starved[1], 'recent_share': starved[2]})
         if knn_main:
             # the K-NN lists of the timed steps: their mean length per row, the rank of the sample minimum the thresholds came from
             # (0: the guaranteed K-th; j < K: optimistic, every row proven by the re-rank), groups redone with guaranteed thresholds
@@ -1032,6 +1049,8 @@ def main():
                         'prefilter_margin_rows counts the rows under 2 (include/snk.h, DESIGN.md 4.1a, 6.1)'}
         if other_mode is not None:
             out['with_upload' if resident else 'resident_rows'] = other_mode
+        if depth2 is not None:
+            out['two_steps_in_flight'] = depth2
         out['config']['inputs'] = ('database resident in HBM; query rows resident too (--resident-rows)' if resident else
                                    'database resident in HBM; query rows host -> HBM and paths HBM -> host inside every timed step')
         if two_in_flight is not None:
@@ -1121,6 +1140,8 @@ def main():
         summary = {'tripwires': tripwires}
         if other_mode is not None:
             summary['resident_rows_frames_per_s' if not resident else 'host_to_host_frames_per_s'] = round(other_mode['value'])
+        if depth2 is not None:
+            summary['two_steps_in_flight_frames_per_s'] = round(depth2['value'])
         for leg in out.get('noncompact', []):
             summary['B* ' + leg['database']] = brief(leg)
         for leg in out.get('shapes', []):

@@ -139,15 +139,18 @@ int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offs
 /* optional: page-lock a host buffer that is uploaded repeatedly (queued instead of blocking copies) */
 int snk_host_register(void *ptr, size_t bytes);
 int snk_host_unregister(void *ptr);
-/* The same in two halves: submit() queues the whole batch and returns, collect() waits for it.  Two
+/* The same in two halves: submit() queues the whole batch and returns, collect() waits for it.  Three
  * batches may be in flight; submitting batch i+1 before collecting batch i hides the tail of batch i
  * (last recursions, copy to the host) behind the K-NN of batch i+1 -- the shape of a tuning loop
- * over a large tune set (balance_stream_weights.py:82-92 searches the same utterances every iteration).
- * Q must stay valid until submit() returns; tickets are 0 / 1.
+ * over a large tune set (balance_stream_weights.py:82-92 searches the same utterances every iteration) --
+ * and submitting batch i+2 as well keeps the K-NN stream fed while the host waits for batch i (with two
+ * in flight the next submit can only follow that wait: the stream runs dry whenever the host is slower
+ * than the 0.3 ms of slack a B* step leaves).
+ * Q must stay valid until submit() returns; tickets are 0 .. 2.
  * Q == NULL: the query rows this ticket's workspace received with its previous submit are still on the device and are
  * searched again (same row_offsets and D required): a caller whose targets do not change between two searches -- a
  * tuning loop that only moves join weights, a benchmark with its inputs resident in HBM -- uploads them once per
- * workspace (two workspaces alternate: the first two submits carry Q). */
+ * workspace (three workspaces take turns: the first three submits carry Q). */
 int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *row_offsets, int n_utts,
                                  int D, int K, int *ticket_out);
 int snk_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, int64_t *path_len_out,

@@ -328,7 +328,7 @@ int snk_upload_db(snk_handle h, const float *F_unw, int64_t N, int Dt, const flo
     h->have_db = true;
     h->have_weights = false;
     h->have_classes = false;
-    h->bslot[0].q_rows = -1; h->bslot[1].q_rows = -1;      // a new voice: the next batch submit carries its query rows
+    for (auto &b : h->bslot) b.q_rows = -1;                  // a new voice: the next batch submit carries its query rows
     h->have_glay = false;
     h->gtiles_ready = false; h->gt16_ready = false;
     h->gh_ready = false; h->gj_ready = false;
@@ -389,7 +389,7 @@ int snk_set_column_selection(snk_handle h, const int *tcols, int nt, const int *
     }
     h->have_weights = false;                 // takes effect with the next snk_set_weights
     // rows resident in the batch workspaces were masked with the selection of their upload: the next submit must carry Q
-    h->bslot[0].q_rows = -1; h->bslot[1].q_rows = -1;
+    for (auto &b : h->bslot) b.q_rows = -1;
     return 0;
 }
 
@@ -741,7 +741,7 @@ int check_ready(snk_engine *h, bool need_target, bool need_join)
 // state changes (database, weights, classes) while a submitted batch is still in flight would be seen by it
 int no_batch_in_flight(snk_engine *h, const char *who)
 {
-    if (h && (h->bslot[0].busy || h->bslot[1].busy))
+    if (h && any_batch_busy(h))
         return fail("%s: a submitted batch is still in flight (snk_knn_viterbi_batch_collect it first)", who);
     if (h && (h->sticket[0].busy || h->sticket[1].busy))
         return fail("%s: a submitted sharded step is still in flight (snk_sharded_knn_viterbi_batch_collect it first)", who);

@@ -584,7 +584,10 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
         HIPCHK(hipGetLastError());
         h->last_f16_status = status;
         if (status == 0) return 0;
-        if (status & 8) {
+        // (bit 8 beside another bit: an overflowed pair list, pool or row list left rows unproven -- that bit's handling below is the
+        // remedy, not the thresholds' fault)
+        if (status != 8) status &= ~8;
+        if (status == 8) {
             // a row's list was not proven complete under the optimistic thresholds: the call once more with the guaranteed ones
             note_optimism_failure(h);
             struct Guard { snk_engine *e; bool was; ~Guard() { e->opt_suppress = was; } } guard{h, h->opt_suppress};

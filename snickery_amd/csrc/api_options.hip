@@ -90,7 +90,7 @@ int snk_reset_timers(snk_handle h)
     if (!h) return fail("null handle");
     for (int i = 0; i < TM_COUNT; ++i) { h->tm_ms[i] = 0; h->tm_n[i] = 0; }
     h->greedy_bound_violations = 0; h->greedy_bound_max_used = 0.0;
-    if (h->margin_stat.p && !h->bslot[0].busy && !h->bslot[1].busy && !h->sticket[0].busy && !h->sticket[1].busy) {
+    if (h->margin_stat.p && !any_batch_busy(h) && !h->sticket[0].busy && !h->sticket[1].busy) {
         const unsigned int init[8] = {0u, 0x7f800000u, 0u, 0u, 0u, 0u, (unsigned int)h->roofline_counters, 0u};
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -256,6 +256,10 @@ int snk_set_option(snk_handle h, const char *name, double value)
         }
         const unsigned long long on64 = on;
         CHK(h2d_sync(h, reinterpret_cast<char *>(h->vstats.p) + 8 * sizeof(unsigned long long), &on64, sizeof(on64)));
+    } else if (!strcmp(name, "tail_defer")) {
+        if (value != 0.0 && value != 1.0 && value != 2.0) return fail("tail_defer must be 0 (never), 1 (always) or 2 (while the host keeps up)");
+        CHK(no_batch_in_flight(h, "snk_set_option(tail_defer)"));
+        h->tail_defer = (int)value; h->starved_ema = 0.0;
     } else if (!strcmp(name, "upload_staged")) {
         if (value != 0.0 && value != 1.0) return fail("upload_staged must be 0 or 1");
         CHK(no_batch_in_flight(h, "snk_set_option(upload_staged)"));
@@ -445,6 +449,10 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "join_bounds_delay")) *out = h->join_bounds_delay;
     else if (!strcmp(name, "split_one_group")) *out = h->split_one_group;
     else if (!strcmp(name, "upload_stream")) *out = h->upload_stream;
+    else if (!strcmp(name, "tail_defer")) *out = h->tail_defer;
+    else if (!strcmp(name, "submits_starved")) *out = (double)h->submits_starved;     // pipelined submits that found the K-NN stream idle (the host was late)
+    else if (!strcmp(name, "submits_pipelined")) *out = (double)h->submits_seen;
+    else if (!strcmp(name, "submits_starved_recent")) *out = h->starved_ema;
     else if (!strcmp(name, "roofline_counters")) *out = h->roofline_counters;
     else if (!strcmp(name, "tau_optimism")) *out = h->tau_optimism;
     else if (!strcmp(name, "tau_optimism_rank")) *out = h->opt_last_rank;               // j of the most recent call (0: guaranteed thresholds)

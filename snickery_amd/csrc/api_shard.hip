@@ -688,7 +688,7 @@ int snk_sharded_knn_viterbi_batch_submit(snk_handle h, const double *Q, const in
                                          int *ticket_out)
 {
     CHK(sharded_check(h, Q, row_offsets, n_utts, D, K));
-    if (h->bslot[0].busy || h->bslot[1].busy)
+    if (any_batch_busy(h))
         return fail("snk_sharded_knn_viterbi_batch_submit: a submitted batch is still in flight (snk_knn_viterbi_batch_collect it first)");
     if (!ticket_out) return fail("snk_sharded_knn_viterbi_batch_submit: null ticket");
     const int slot = h->sticket[h->snext].busy ? (h->snext ^ 1) : h->snext;

@@ -391,9 +391,10 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     const int64_t total = row_offsets[n_utts];
     for (int u = 0; u < n_utts; ++u)
         if (row_offsets[u + 1] - row_offsets[u] < 1) return fail("snk_knn_viterbi_batch: utterance %d has no rows", u);
-    const int slot = h->bslot[h->bnext].busy ? (h->bnext ^ 1) : h->bnext;
+    int slot = h->bnext;
+    for (int k = 0; k < SNK_BATCH_SLOTS && h->bslot[slot].busy; ++k) slot = (slot + 1) % SNK_BATCH_SLOTS;
     BatchSlot &b = h->bslot[slot];
-    if (b.busy) return fail("snk_knn_viterbi_batch_submit: two batches are in flight already (collect one first)");
+    if (b.busy) return fail("snk_knn_viterbi_batch_submit: %d batches are in flight already (collect one first)", SNK_BATCH_SLOTS);
     b.first = group_utterances(h, row_offsets, n_utts, true);
     b.n_groups = (int)b.first.size() - 1;
     b.n_utts = n_utts; b.K = K; b.D = D; b.total = total;
@@ -430,10 +431,10 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     b.probe_kind.assign((size_t)b.n_groups, 0);
     b.probe_limit.assign((size_t)b.n_groups, 0.0);
     if (Q) {
-        // The rows travel on a stream of their own: this workspace is idle (its last batch was collected), so the copy needs to
-        // wait for nothing and runs on a DMA engine beside the batch before this one; the main stream only waits for its event.
-        // On the main stream (until round 5) the K-NN stream stood still for the 0.2 ms the 9.4 MB of a B* step take to cross
-        // PCIe -- the 6 % between the host -> host and the resident-rows rate.
+        // option upload_stream 1: the rows travel on a stream of their own -- this workspace is idle (its last batch was collected), so
+        // the copy needs to wait for nothing and runs on a DMA engine beside the batch before this one; the main stream only waits
+        // for its event.  Default 0: at the head of the main stream, where the K-NN stream stands still for the 0.3 ms the 9.4 MB
+        // of a B* step take to cross PCIe (why: snk_engine.h upload_stream).
         hipStream_t us = h->stream;
         if (h->upload_stream) {
             if (!h->up_stream) HIPCHK(hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
@@ -462,10 +463,23 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     } else if (b.q_rows != total || b.q_D != D || b.q_offs.size() != (size_t)n_utts + 1 ||
                !std::equal(b.q_offs.begin(), b.q_offs.end(), row_offsets)) {
         return fail("snk_knn_viterbi_batch_submit: no query matrix given and this workspace holds no rows of that shape "
-                    "(the first submit on each of the two workspaces must carry Q)");
+                    "(the first submit on each of the three workspaces must carry Q)");
     }
     bool tail = false;
-    const bool pipelined = h->bslot[slot ^ 1].busy;
+    const bool pipelined = any_batch_busy(h);
+    BatchSlot *const prev = (h->blast >= 0 && h->blast != slot && h->bslot[h->blast].busy) ? &h->bslot[h->blast] : nullptr;      // the batch submitted before this one
+    // Is the host keeping up?  The batch before this one is still in flight; if everything it queued on the main stream has
+    // already run, the K-NN stream stood idle while the host got here (it could not submit earlier: it was waiting for the
+    // batch before that one) -- and a tail left to THIS submit would have stood idle with it.  tail_defer 2 (default): a voice
+    // whose submits find the stream idle more often than not queues its tails at once instead (they then run in the gap);
+    // 1: always leave them to the next submit (round 5), 0: never.
+    if (prev && prev->knn_end) {
+        const bool idle = hipEventQuery(prev->knn_end) == hipSuccess;
+        (void)hipGetLastError();
+        h->submits_seen += 1; h->submits_starved += idle ? 1 : 0;
+        h->starved_ema = 0.9 * h->starved_ema + (idle ? 0.1 : 0.0);
+    }
+    const bool defer_tail = h->tail_defer == 1 || (h->tail_defer == 2 && h->starved_ema < 0.5);
     for (int g = 0; g < b.n_groups; ++g) {
         const int64_t r0 = row_offsets[b.first[g]], rows = row_offsets[b.first[g + 1]] - r0;
         CHK(knn_device(h, b.Qall.as<double>() + r0 * D, rows, K, nullptr, b.cand.as<int64_t>() + r0 * K,
@@ -488,7 +502,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
         const bool fits = h->join_bounds_delay == 3 || h->join_bounds_delay == 4 || (h->join_bounds_delay == 5 && h->filter_coarse) ||
                           (b.n_groups >= 2 && rows_per_group >= 4096 && K <= 128 && !h->filter_onepass);
         const bool delay = h->join_bounds_delay > 0 && fits && h->join_bounds_stream == 1 && !b.vit_dense && use_sparse_viterbi(h, K, n_utts);
-        if (g == 0) CHK(batch_flush_tail(h, h->bslot[slot ^ 1], h->knn_mid_recorded ? h->knn_mid : nullptr));      // the batch before this one
+        if (g == 0 && prev) CHK(batch_flush_tail(h, *prev, h->knn_mid_recorded ? h->knn_mid : nullptr));      // the batch before this one
         if (delay) {
             if (g > 0)
                 CHK(viterbi_group(h, g - 1, row_offsets, b.first[g - 1], b.first[g], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
@@ -499,7 +513,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
                 // The last group: left to the next submit (or to this batch's collect) where the caller keeps two batches in
                 // flight -- the other workspace is busy right now, so the next thing it does is very likely another submit.  A
                 // caller with one batch at a time (host work between submit and collect) gets it queued here, as before.
-                if (pipelined) tail = true;
+                if (pipelined && defer_tail) tail = true;
                 else CHK(viterbi_group(h, g, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
                                        b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), n_utts, true, nullptr));
             }
@@ -515,7 +529,8 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     if (!tail) CHK(batch_queue_results(h, b));
     HIPCHK(hipGetLastError());
     b.busy = true;
-    h->bnext = slot ^ 1;
+    h->bnext = (slot + 1) % SNK_BATCH_SLOTS;
+    h->blast = slot;
     *ticket_out = slot;
     return 0;
 }
@@ -524,7 +539,7 @@ int snk_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, i
 {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
-    if (ticket < 0 || ticket > 1 || !h->bslot[ticket].busy) return fail("snk_knn_viterbi_batch_collect: no batch behind ticket %d", ticket);
+    if (ticket < 0 || ticket >= SNK_BATCH_SLOTS || !h->bslot[ticket].busy) return fail("snk_knn_viterbi_batch_collect: no batch behind ticket %d", ticket);
     if (!path_out || !path_len_out || !cost_out) return fail("snk_knn_viterbi_batch_collect: null output");
     BatchSlot &b = h->bslot[ticket];
     const size_t sz_path = ((size_t)b.total * sizeof(int64_t) + 63) & ~(size_t)63;
@@ -596,7 +611,8 @@ int snk_knn_viterbi_batch_collect(snk_handle h, int ticket, int64_t *path_out, i
         // the guaranteed ones.  A lone list overflow: the fast path once more, non-deferred -- it takes the voice up its ladder
         // (longer lists, float32 operands: snk_engine.h knn_level) and later batches start there; anything else: the exact
         // float64 sweep
-        if (status[g] & 8) { note_optimism_failure(h); h->opt_suppress = true; }
+        // (beside another bit -- an overflowed pair list, pool or row list -- bit 8 is that overflow's doing, not the thresholds')
+        if (status[g] == 8) { note_optimism_failure(h); h->opt_suppress = true; }
         const int st = status[g] & ~8;
         if (st && !((st & ~3) == 0 && h->knn_level < 2)) h->precision = 0;
         const int rc = knn_device(h, b.Qall.as<double>() + r0 * b.D, rows, b.K, nullptr,
@@ -627,7 +643,7 @@ int snk_knn_viterbi_batch(snk_handle h, const double *Q, const int64_t *row_offs
                           int K, int64_t *path_out, int64_t *path_len_out, double *cost_out)
 {
     if (!path_out || !path_len_out || !cost_out) return fail("snk_knn_viterbi_batch: null/empty argument");
-    if (h && (h->bslot[0].busy || h->bslot[1].busy))
+    if (h && any_batch_busy(h))
         return fail("snk_knn_viterbi_batch: a submitted batch is still in flight (collect it first)");
     int ticket = -1;
     CHK(snk_knn_viterbi_batch_submit(h, Q, row_offsets, n_utts, D, K, &ticket));

@@ -168,7 +168,8 @@ struct UttSlot {      // per in-flight utterance workspace (batch pipeline uses 
     bool vit_recorded = false;          // a recursion was queued on this workspace (its event is valid)
 };
 
-struct BatchSlot {    // one submitted batch (snk_knn_viterbi_batch_submit / _collect): two may be in flight
+#define SNK_BATCH_SLOTS 3
+struct BatchSlot {    // one submitted batch (snk_knn_viterbi_batch_submit / _collect): SNK_BATCH_SLOTS may be in flight
     DevBuf Qall, cand, dist, path, plen, cost, status;
     HostBuf stage, qstage;                // results / query rows of this batch (pinned: the copies are queued, not waited for)
     hipEvent_t done = nullptr;            // results of this batch are in `stage`
@@ -220,10 +221,21 @@ struct snk_engine {
     int64_t opt_fails_total = 0;
     int opt_last_rank = 0;                 // j of the most recent call (0: it ran with guaranteed thresholds)
     int roofline_counters = 0;             // option: the re-rank and pass 3 count what their rooflines are priced on (atomics on one address: off in production)
+    int tail_defer = 1;                    // option (api_viterbi.hip snk_knn_viterbi_batch_submit): 0 never / 1 always / 2 while the host keeps up (measured: 2 flaps between the two and loses to both, profiles/r06f_ab.log)
+    int64_t submits_seen = 0, submits_starved = 0;      // pipelined submits / those that found the K-NN stream idle
+    double starved_ema = 0.0;
     int upload_staged = 0;                 // option (experiment): submitted rows always through the library's own pinned staging
-    int upload_stream = 1;                 // option: 0 = the rows are uploaded on the main stream, as until round 5
-    BatchSlot bslot[2];
+    // option: 1 = the rows of a submitted batch travel on a stream of their own.  Off: measured on the B* step (profiles/r06d_ab.log) the
+    // copy on its own stream costs the HOST 0.31 ms more per submit (0.59 against 0.27 ms) and the step is sensitive to exactly
+    // that -- the next batch is submitted when the one before the last is collected, 0.3 ms before the K-NN stream runs dry --:
+    // 4.75 M frames/s with it, 4.98 M with the 0.3 ms copy at the head of the main stream
+    int upload_stream = 0;
+    // Three workspaces: a caller that submits batch i + 2 before it collects batch i never lets the K-NN stream run dry while it
+    // waits for a batch's last recursions (with two, the next submit could only follow the collect of the batch before the last --
+    // 0.3 ms before the stream ran dry on a fast host, after it on a slow one: 4.1 .. 5.0 M frames/s by the box, profiles/r06f_ab.log)
+    BatchSlot bslot[SNK_BATCH_SLOTS];
     int bnext = 0;
+    int blast = -1;                        // the slot submitted most recently (its tail may be pending)
     hipEvent_t knn_all_done = nullptr;
     // database
     int64_t N = 0, Njc = 0, Nalloc = 0;
@@ -513,6 +525,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
 
 // Viterbi side of a group of utterances (api_viterbi.hip)
 bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts = 1);
+inline bool any_batch_busy(const snk_engine *h) { for (const auto &b : h->bslot) if (b.busy) return true; return false; }
 void note_optimism_failure(snk_engine *h);
 std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offsets, int n_utts, bool knn_beside);
 int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u0, int u1, int K,

@@ -418,11 +418,11 @@ class HipSearchEngine(object):
                                                        j.ctypes.data_as(ip) if j is not None else None, nj))
 
     def knn_viterbi_batch_submit(self, utterances, n_candidates, resident=False):
-        """Queue a batch and return at once; at most two batches may be in flight.  Returns a ticket
+        """Queue a batch and return at once; at most three batches may be in flight.  Returns a ticket
         for knn_viterbi_batch_collect.  Submitting the next batch before collecting this one hides
         this one's tail (last recursions, copy to the host) behind the next one's K-NN.
         resident: the rows of this very batch are still on the device from the previous submit on the workspace this
-        ticket gets (two workspaces alternate: the first two submits must upload) and are searched again without an
+        ticket gets (three workspaces take turns: the first three submits must upload) and are searched again without an
         upload (include/snk.h)."""
         b = _as_batch(utterances)
         ticket = ctypes.c_int(-1)

@@ -96,7 +96,7 @@ assert refused(e.join_bounds, c2[:1])
 e.path_scores(U[:30], c2[:, 0], 0, Dt, Dj)
 e.prefilter_minima(U)
 
-# ---- batches: one call, two in flight, a third refused, out-of-order collects, double collect, state changes under a batch ----
+# ---- batches: one call, three in flight, a fourth refused, out-of-order collects, double collect, state changes under a batch ----
 utts = [rng.randn(T, Dt) for T in (40, 3, 75, 1, 22)]
 for rows in (12288, 64, 1):                                             # grouping: one group, several, one utterance each
     e.set_option('batch_rows', rows)
@@ -106,14 +106,16 @@ e.set_option('batch_rows', 12288)
 qb = snickery_amd.QueryBatch(utts).pin()
 t0 = e.knn_viterbi_batch_submit(qb, 10)
 t1 = e.knn_viterbi_batch_submit(utts[:2], 10)
-assert refused(e.knn_viterbi_batch_submit, utts, 10)                    # two in flight already
+t9 = e.knn_viterbi_batch_submit(utts[:3], 10)                           # three workspaces: a third batch in flight
+assert refused(e.knn_viterbi_batch_submit, utts, 10)                    # three in flight already
+e.knn_viterbi_batch_collect(t9)
 assert refused(e.knn_viterbi_batch, utts, 10)
 assert refused(e.set_weights, wt, wj)                                   # no state change under a batch in flight
 assert refused(e.upload_db, F, JC)
 assert refused(e.set_column_selection, [0, 1], None)
 assert refused(e.join_costs, c2)
 e.knn_viterbi_batch_collect(t1)                                         # out of order
-assert refused(e.knn_viterbi_batch_submit, qb, 10, resident=True)       # the free workspace holds t1's rows: another shape
+assert refused(e.knn_viterbi_batch_submit, qb, 10, resident=True)       # the workspace next in turn holds other rows (t9's: another shape)
 t2 = e.knn_viterbi_batch_submit(qb, 10)
 e.knn_viterbi_batch_collect(t0)
 e.knn_viterbi_batch_collect(t2)
@@ -140,8 +142,8 @@ e.set_option('join_bounds_delay', 1); e.set_option('batch_rows', 12288)
 e2 = snickery_amd.HipSearchEngine(0)
 e2.upload_db(F, JC); e2.set_weights(wt, wj)
 assert refused(e2.knn_viterbi_batch_submit, qb, 10, resident=True)
-e2.knn_viterbi_batch_collect(e2.knn_viterbi_batch_submit(qb, 10))
-e2.knn_viterbi_batch_collect(e2.knn_viterbi_batch_submit(qb, 10))
+for _ in range(3):                                                      # three workspaces take turns: each must have seen the rows once
+    e2.knn_viterbi_batch_collect(e2.knn_viterbi_batch_submit(qb, 10))
 e2.knn_viterbi_batch_collect(e2.knn_viterbi_batch_submit(qb, 10, resident=True))
 e2.set_column_selection(list(range(0, Dt, 2)), None)
 e2.set_weights(wt, wj)

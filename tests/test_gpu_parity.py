@@ -261,8 +261,8 @@ def test_viterbi_batch_redo_on_overflow(engine):
 
 @pytest.mark.parametrize('delay', [0, 3, 4])
 def test_viterbi_batch_submit_collect(engine, delay):
-    """Two batches in flight (submit i+1 before collect i): results equal the one-call form and the
-    oracle, in submission order or not; a third submit and a one-call batch are refused while two /
+    """Batches in flight (submit i+1, i+2 before collect i; three workspaces): results equal the one-call form and the
+    oracle, in submission order or not; a fourth submit and a one-call batch are refused while three /
     any are pending; an overflowed group is redone at collect time.  delay 3 / 4: the Viterbi side of a group queued
     behind a point inside the next group's K-NN call, a batch's last group by the next submit or its own collect
     (join_bounds_delay, forced whatever the shape)."""
@@ -282,10 +282,13 @@ def test_viterbi_batch_submit_collect(engine, delay):
             assert list(ref[0][0][u]) == op and ref[0][1][u] == ocst
         t0 = engine.knn_viterbi_batch_submit(snickery_amd.QueryBatch(batches[0]).pin(), 20)
         t1 = engine.knn_viterbi_batch_submit(batches[1], 20)
+        t9 = engine.knn_viterbi_batch_submit(batches[2], 20)              # three workspaces: three batches in flight
         with pytest.raises(snickery_amd.SnkError):
-            engine.knn_viterbi_batch_submit(batches[2], 20)
+            engine.knn_viterbi_batch_submit(batches[2], 20)              # ... a fourth is refused
         with pytest.raises(snickery_amd.SnkError):
             engine.knn_viterbi_batch(batches[2], 20)
+        got9 = engine.knn_viterbi_batch_collect(t9)
+        assert all(np.array_equal(a, b) for a, b in zip(got9[0], ref[2][0])) and np.array_equal(got9[1], ref[2][1])
         with pytest.raises(snickery_amd.SnkError):           # no re-weighting under a batch in flight
             engine.set_weights(wt, wj)
         got1 = engine.knn_viterbi_batch_collect(t1)          # out of order

@@ -32,4 +32,29 @@ for j in (K, 0, 24, 33, 48, 64):
         j, eng.info('tau_optimism_rank'), dt * 1e3, np.array_equal(c, ref[0]) and np.array_equal(d, ref[1]), eng.info('last_list_mean'), eng.info('last_list_max'),
         eng.info('tau_optimism_failures') - f0, eng.info('tau_optimism_off'), eng.info('last_f16_status'), eng.info('filter_coarse'),
         {k: round(v[0] / 3, 3) for k, v in eng.timers().items() if v[1]}), flush=True)
+if '--hunt' in sys.argv:
+    # which rows are flagged: utterance by utterance (32 of them), then row by row
+    eng.set_option('tau_optimism', 1); eng.set_option('tau_optimism_rank', 0)
+    for sidx in range(32):
+        Us = (held_out(600, sidx) if held_out else synthetic_targets(F_unw, 600, seed=1 + sidx)) * wt
+        f0 = eng.info('tau_optimism_failures')
+        eng.set_option('tau_optimism', 1)                  # (re-arms the voice)
+        eng.knn(Us, K)
+        if eng.info('tau_optimism_failures') > f0:
+            print('utterance %d is flagged' % sidx, flush=True)
+            for r in range(600):
+                f1 = eng.info('tau_optimism_failures')
+                eng.set_option('tau_optimism', 1)
+                c1, d1 = eng.knn(Us[r:r + 1], K)
+                if eng.info('tau_optimism_failures') > f1:
+                    eng.set_option('tau_optimism', 0)
+                    c0, d0 = eng.knn(Us[r:r + 1], K)
+                    n_guar = eng.info('last_list_mean')
+                    eng.set_option('tau_optimism', 1); eng.set_option('tau_optimism_rank', 33)
+                    eng.set_option('prefilter', 1)
+                    print('  row %d alone is flagged too: guaranteed list %d entries, d_1 %.4f d_K %.4f, same=%s' % (r, n_guar, d0[0, 0], d0[0, -1], np.array_equal(c0, c1)), flush=True)
+                    break
+            else:
+                print('  no single row of it is flagged alone', flush=True)
+            break
 eng.close()
