@@ -345,9 +345,10 @@ def leg_roofline(tm, steps, rows_per_step, N, Dt, Dj, K, eng):
     return out
 
 
-def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', host_to_host=False, targets_from=None, targets=None):
-    """One BASELINE shape (or B* on a variant database) through the batch pipeline, two steps in flight, rows resident in HBM: frames/s,
-    stage times, the dominant kernel's roofline, fallbacks and tripwires.  An extra field of the JSON line, never `value`."""
+def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', host_to_host=False, targets_from=None, targets=None, depth=3):
+    """One BASELINE shape (or B* on a variant database) through the batch pipeline, three steps in flight, rows uploaded and paths
+    returned inside every step: frames/s, stage times (a second pass), the dominant kernel's roofline, fallbacks and tripwires.
+    An extra field of the record, never `value`."""
     import snickery_amd
     import torch
     N, Dt = F_unw.shape
@@ -362,10 +363,8 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
     for _ in range(5):                           # primes every workspace; the engine judges the voice (filter passes, unit order, Viterbi path)
         eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(batch, K))
     before = (eng.info('f16_fallbacks'), eng.info('batch_redos'), eng.info('exact_row_fallbacks'))
-    eng.reset_timers()
-    cells0 = eng.info('dense_cells')
 
-    def run(resident, depth=3):
+    def run(resident):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         pending, res = [], None
@@ -377,12 +376,21 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
             res = eng.knn_viterbi_batch_collect(pending.pop(0))
         torch.cuda.synchronize()
         return time.perf_counter() - t0, res
-    dt, _ = run(True)
+    # the rate: rows uploaded and paths returned inside every step, no stage timers (their timestamp events cost 4-7 % of a step);
+    # then the same loop once more with every stage timed, for the stage table and the leg's roofline
+    eng.set_option('timers', 2)
+    eng.reset_timers()
+    dth, _ = run(False)
+    eng.set_option('timers', 1)
+    eng.reset_timers()
+    cells0 = eng.info('dense_cells')
+    dt, _ = run(False)
     tm = eng.timers()
     pairs = eng.info('coarse_pairs')
     rows_per_launch = T * U / max(tm['knn_filter'][1] / steps, 1)
     out = {'shape': name, 'database': kind, 'units': N, 'target_dim': Dt, 'join_dim': Dj, 'frames': T, 'utts_per_step': U, 'n_candidates': K,
-           'frames_per_s': T * U * steps / dt, 'ms_per_step': dt / steps * 1e3, 'steps': steps,
+           'frames_per_s': T * U * steps / dth, 'ms_per_step': dth / steps * 1e3, 'steps': steps, 'rows': 'host -> host',
+           'frames_per_s_with_stage_timers': T * U * steps / dt,
            'roofline': leg_roofline(tm, steps, T * U, N, Dt, Dj, K, eng),
            'filter_coarse': bool(eng.info('filter_coarse')), 'filter_onepass': bool(eng.info('filter_onepass')),
            'reordered': bool(eng.info('reordered')), 'tile_radius_before_after': [eng.info('reorder_radius_before'), eng.info('reorder_radius_after')],
@@ -396,10 +404,8 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
            'tripwires': {'prefilter_margin_rows': eng.info('prefilter_margin_rows'), 'prefilter_min_margin': eng.info('prefilter_min_margin'),
                          'join_bound_violations': eng.info('join_bound_violations'), 'join_bound_min_margin': eng.info('join_bound_min_margin')},
            'stages_ms_per_step': dict((k, v[0] / steps) for k, v in tm.items() if v[1])}
-    if host_to_host:
-        dth, _ = run(False)
-        out['host_to_host_frames_per_s'] = T * U * steps / dth
-        out['host_to_host_ms_per_step'] = dth / steps * 1e3
+    out['host_to_host_frames_per_s'] = T * U * steps / dth
+    out['host_to_host_ms_per_step'] = dth / steps * 1e3
     return out
 
 
@@ -536,12 +542,14 @@ def main():
                          '1: force that path; 0: dense exact float64 join costs')
     ap.add_argument('--opt', action='append', default=[], metavar='NAME=VALUE', help='engine option (snk_set_option), for experiments')
     ap.add_argument('--join-beta', type=float, default=None, help='margin of the predecessor sets (speed only)')
-    ap.add_argument('--in-flight', type=int, default=3, choices=(1, 2, 3),
+    ap.add_argument('--in-flight', type=int, default=0, choices=(0, 1, 2, 3),
                     help='N = 1: steps in flight; 2 submits step i+1 before collecting step i, so the tail of a step '
                          '(the per-utterance recursions of its last group, the copy of the results) runs beside the K-NN of the '
-                         'next one -- how a tuning loop over a tune set drives the engine; 3 (default; the library has three workspaces) '
-                         'submits step i+2 as well, so that the K-NN stream has work while the host waits for step i; every step '
-                         'completes inside the timed region.  1: strictly one step at a time (reported as extra field one_in_flight otherwise)')
+                         'next one -- how a tuning loop over a tune set drives the engine; 3 (the library has three workspaces) '
+                         'submits step i+2 as well, so that the K-NN stream has work while the host waits for step i (a slow host; on a '
+                         'fast one the deeper queue costs more than it gives); 0 (default): the better of 2 and 3, tried for six steps '
+                         'each after the warm-up, untimed; every step completes inside the timed region.  1: strictly one step at a '
+                         'time (reported as extra field one_in_flight otherwise)')
     ap.add_argument('--resident-rows', action='store_true',
                     help='N = 1, experiments: `value` = the rate with the query rows left in HBM by two untimed priming submits '
                          '(default: `value` is the host -> host rate of SURVEY 8d -- the query rows are uploaded from and the paths '
@@ -694,8 +702,8 @@ def main():
     # step's input and cross the boundary the way every caller of the package hands them over -- host memory (page-locked) ->
     # HBM inside the step, paths back to host memory inside the step: SURVEY 8d's wall time, VERDICT r5 item 1.
     # --resident-rows: the rows where two untimed priming submits left them (Q == NULL, include/snk.h), for experiments.
-    resident = world == 1 and args.in_flight >= 2 and args.resident_rows
-    if world == 1 and args.in_flight >= 2:
+    resident = world == 1 and args.in_flight != 1 and args.resident_rows
+    if world == 1 and args.in_flight != 1:
         batch.pin()
         for _ in range(3):                  # every workspace of the pipeline primed (and holds the rows for the resident-rows pass)
             paths, costs = eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(batch, K))
@@ -704,7 +712,7 @@ def main():
 
     def pipelined(steps, res, depth=None):
         # `depth` steps in flight: a step is collected when `depth` are pending (every step completes before this returns)
-        depth = depth or max(args.in_flight, 2)
+        depth = depth or (args.in_flight if args.in_flight >= 2 else 2)
         pending, out = [], None
         for _ in range(steps):
             h0 = time.perf_counter()
@@ -716,6 +724,28 @@ def main():
         while pending:
             out = eng.knn_viterbi_batch_collect(pending.pop(0))
         return out
+    depth_probe = None
+    if world == 1 and args.in_flight == 0:
+        # how many steps to keep in flight is the caller's knob, and the better value depends on the HOST (two: the next submit
+        # follows the wait for the step before the last -- a slow host lets the K-NN stream run dry; three: never dry, but the
+        # deeper queue makes every submit slower): both tried here, untimed, the better one runs the timed region
+        eng.set_option('timers', 2)
+        depth_probe = {}
+        for d in (2, 3, 2, 3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            pipelined(6, resident, depth=d)
+            torch.cuda.synchronize()
+            depth_probe[d] = max(depth_probe.get(d, 0.0), frames_per_step * 6 / (time.perf_counter() - t1))
+        args.in_flight = 3 if depth_probe[3] > depth_probe[2] else 2
+        host_ms.update({'submit': 0.0, 'collect': 0.0, 'n': 0})
+    elif world > 1 and args.in_flight == 0:
+        args.in_flight = 2
+    if world == 1:
+        # inside the timed region only the roofline kernel's stage is timed (HIP events on its stream); the stage table comes from
+        # a second, untimed pass of the same loop with every stage timed: a timed stage is two timestamp events on its stream,
+        # ~60 per step, 4-7 % of it (profiles/r06h_ab.log)
+        eng.set_option('timers', 2)
     eng.reset_timers()
     sync()
     t0 = time.perf_counter()
@@ -747,6 +777,26 @@ def main():
         elapsed = float(t.item())
 
     timers = eng.timers()
+    staged = None
+    if world == 1:
+        # the stage pass: the same loop, every stage timed (an extra: its rate is `with_stage_timers`)
+        eng.set_option('timers', 1)
+        eng.reset_timers()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if args.in_flight >= 2:
+            pipelined(args.steps, resident)
+        else:
+            for _ in range(args.steps):
+                step()
+        torch.cuda.synchronize()
+        es = time.perf_counter() - t1
+        staged = {'value': frames_per_step * args.steps / es, 'unit': 'frames/s', 'ms_per_step': es / args.steps * 1e3}
+        timers_roof = timers
+        timers = eng.timers()
+        if 'join_lower_bounds' in timers_roof:
+            timers['join_lower_bounds'] = timers_roof['join_lower_bounds']      # (the roofline kernel: as timed inside the timed region)
+        eng.set_option('timers', 2)                                             # (the extra passes below run like the timed region)
     # counters the rooflines of the two kernels without one until round 5 are priced on, read before any
     # other pass adds to them: exact costs pass 3 took from the rows, list entries the re-rank read / gave exact distances
     roof_counts = {}
@@ -803,18 +853,20 @@ def main():
                       'note': ('the query rows (%.1f MB per step) cross PCIe inside every timed step, from page-locked host memory' % (batch.Q.nbytes / 1e6)) if resident else
                               'the query rows searched where two untimed priming submits left them in HBM (Q == NULL): a mode no caller of the package uses'}
     depth2 = None
-    if world == 1 and args.in_flight == 3:
-        # the same loop with TWO steps in flight (the depth of rounds 2-5), an extra field
+    if world == 1 and args.in_flight >= 2:
+        # the same loop at the OTHER depth (two steps in flight: the depth of rounds 2-5), an extra field
+        od = 2 if args.in_flight == 3 else 3
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        pipelined(args.steps, resident, depth=2)
+        pipelined(args.steps, resident, depth=od)
         torch.cuda.synchronize()
         e2d = time.perf_counter() - t1
-        depth2 = {'value': frames_per_step * args.steps / e2d, 'unit': 'frames/s', 'ms_per_step': e2d / args.steps * 1e3}
+        depth2 = {'steps_in_flight': od, 'value': frames_per_step * args.steps / e2d, 'unit': 'frames/s', 'ms_per_step': e2d / args.steps * 1e3}
     if world == 1:
         # the counting pass (untimed, two steps): the kernels add up what their rooflines are priced on only while option
         # roofline_counters is on -- thousands of workgroups adding to one address cost 0.3-0.4 ms per launch (profiles/r06_a)
         eng.set_option('roofline_counters', 1)
+        eng.set_option('timers', 1)
         eng.reset_timers()
         for _ in range(2):
             eng.knn_viterbi_batch(batch, K)
@@ -1050,7 +1102,11 @@ def main():
         if other_mode is not None:
             out['with_upload' if resident else 'resident_rows'] = other_mode
         if depth2 is not None:
-            out['two_steps_in_flight'] = depth2
+            out['other_depth'] = depth2
+        if depth_probe is not None:
+            out['depth_probe_frames_per_s'] = dict((str(k), v) for k, v in depth_probe.items())
+        if staged is not None:
+            out['with_stage_timers'] = staged
         out['config']['inputs'] = ('database resident in HBM; query rows resident too (--resident-rows)' if resident else
                                    'database resident in HBM; query rows host -> HBM and paths HBM -> host inside every timed step')
         if two_in_flight is not None:
@@ -1103,7 +1159,7 @@ def main():
             for kind in ('permuted', 'speechlike'):
                 Fv, JCv, tg = variant_database(kind, N, Dt, F_unw, JC_unw)
                 legs.append(shape_leg(eng, 'B*', Fv, JCv, wt, wj, T, U, K, leg_steps, kind=kind, host_to_host=True,
-                                      targets_from=F_unw if kind == 'permuted' else None, targets=tg))
+                                      targets_from=F_unw if kind == 'permuted' else None, targets=tg, depth=max(args.in_flight, 2)))
                 del Fv, JCv
             out['noncompact'] = legs
         if world == 1 and not args.no_shapes:
@@ -1119,7 +1175,7 @@ def main():
                 for kind in kinds:
                     Fk, JCk = (Fs, JCs) if kind == 'compact' else variant_database(kind, sN, sDt, Fs, JCs)[:2]
                     shapes.append(shape_leg(eng, sname, Fk, JCk, wts, wjs, sT, sU, sK, leg_steps, kind=kind, host_to_host=True,
-                                            targets_from=Fs if kind == 'permuted' else None))
+                                            targets_from=Fs if kind == 'permuted' else None, depth=max(args.in_flight, 2)))
                 del Fs, JCs
             out['shapes'] = shapes
         if world == 1 and not args.no_greedy:
@@ -1141,7 +1197,7 @@ def main():
         if other_mode is not None:
             summary['resident_rows_frames_per_s' if not resident else 'host_to_host_frames_per_s'] = round(other_mode['value'])
         if depth2 is not None:
-            summary['two_steps_in_flight_frames_per_s'] = round(depth2['value'])
+            summary['%d_steps_in_flight_frames_per_s' % depth2['steps_in_flight']] = round(depth2['value'])
         for leg in out.get('noncompact', []):
             summary['B* ' + leg['database']] = brief(leg)
         for leg in out.get('shapes', []):

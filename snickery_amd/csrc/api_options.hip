@@ -297,7 +297,8 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value < 0 || value > 1e6) return fail("pool_chunk_limit must be in 0..1e6");
         h->pool_chunk_limit = (int)value;
     } else if (!strcmp(name, "timers")) {
-        h->timers_on = value != 0.0;
+        if (value != 0.0 && value != 1.0 && value != 2.0) return fail("timers must be 0 (none), 1 (every stage) or 2 (the Viterbi side's bounds pass only)");
+        h->timers_on = (int)value;
     } else {
         return fail("snk_set_option: unknown option '%s'", name);
     }

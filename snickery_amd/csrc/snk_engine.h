@@ -395,7 +395,10 @@ struct snk_engine {
     int greedy_fallbacks = 0;             // utterance groups the float32 scan could not decide (mass ties) and the exact scan finished
     // options
     int cap = 4096;
-    double sample_frac = 1.0 / 16.0;
+    // stage A's sample: every 24th unit.  (1/16 until round 6: with the optimistic thresholds the lists no longer pay for a sparser
+    // sample the way they did -- ~650 entries at 1/16, ~780 at 1/24, ~900 at 1/32 for K = 100 -- while the sample sweep costs its
+    // share of the database: the B* step 3.84 -> 3.73 ms at 1/24, 3.80 at 1/32, profiles/r06f_ab.log, r06g_ab.log)
+    double sample_frac = 1.0 / 24.0;
     int min_sample_slabs = 256;           // small databases / shards: the sample stride shrinks to keep this many sampled slabs
     int nt_override = 0;
     int timers_on = 1;
@@ -463,7 +466,10 @@ hipEvent_t ev_get(snk_engine *h);
 
 struct StageTimer {     // records an event pair around a stage on a stream
     snk_engine *h; hipStream_t s; EvPair ep; bool on;
-    StageTimer(snk_engine *h_, hipStream_t s_, int id) : h(h_), s(s_), on(h_->timers_on != 0 && id >= 0)
+    // timers_on 1: every stage; 2: the bounds pass of the Viterbi side only (the bench line's roofline kernel) -- a timed stage is
+    // two timestamp events on its stream, ~60 of them per B* step: 4-7 % of the step (profiles/r06h_ab.log: 5.0 -> 5.2-5.4 M frames/s
+    // without); 0: none
+    StageTimer(snk_engine *h_, hipStream_t s_, int id) : h(h_), s(s_), on((h_->timers_on == 1 || (h_->timers_on == 2 && id == TM_JOIN_LB)) && id >= 0)
     {
         if (!on) return;
         ep.id = id; ep.a = ev_get(h); ep.b = ev_get(h);
