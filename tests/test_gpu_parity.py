@@ -324,7 +324,7 @@ def test_batch_submit_with_resident_rows(engine):
     results; rows of another shape, or a workspace that never received rows, are refused."""
     import snickery_amd
     F_unw, JC_unw, wt, wj, F, E, S = synth_setup(30000, 61, 40, seed=23)
-    eng = snickery_amd.HipSearchEngine()         # a fresh engine: its two workspaces hold no rows yet
+    eng = snickery_amd.HipSearchEngine()         # a fresh engine: its three workspaces hold no rows yet
     eng.upload_db(F_unw, JC_unw)
     eng.set_weights(wt, wj)
     a = snickery_amd.QueryBatch([o.synthetic_targets(F_unw, T, seed=40 + i) * wt for i, T in enumerate((33, 48, 20, 7))])
@@ -332,10 +332,14 @@ def test_batch_submit_with_resident_rows(engine):
     with pytest.raises(snickery_amd.SnkError):
         eng.knn_viterbi_batch_submit(a, 20, resident=True)
     want_a = eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(a, 20))        # workspace 0
-    want_b = eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(b, 20))        # workspace 1 (they alternate)
-    ta = eng.knn_viterbi_batch_submit(a, 20, resident=True)
-    tb = eng.knn_viterbi_batch_submit(b, 20, resident=True)
-    for got, want in ((eng.knn_viterbi_batch_collect(ta), want_a), (eng.knn_viterbi_batch_collect(tb), want_b)):
+    want_b = eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(b, 20))        # workspace 1 (they take turns)
+    with pytest.raises(snickery_amd.SnkError):   # workspace 2 never received rows
+        eng.knn_viterbi_batch_submit(a, 20, resident=True)
+    assert all(np.array_equal(x, y) for x, y in zip(eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(a, 20))[0], want_a[0]))      # workspace 2
+    ta = eng.knn_viterbi_batch_submit(a, 20, resident=True)                            # workspace 0 again: it holds the rows of `a`
+    tb = eng.knn_viterbi_batch_submit(b, 20, resident=True)                            # workspace 1: the rows of `b`
+    tc = eng.knn_viterbi_batch_submit(a, 20, resident=True)                            # workspace 2: the rows of `a`
+    for got, want in ((eng.knn_viterbi_batch_collect(ta), want_a), (eng.knn_viterbi_batch_collect(tb), want_b), (eng.knn_viterbi_batch_collect(tc), want_a)):
         assert all(np.array_equal(x, y) for x, y in zip(got[0], want[0])) and np.array_equal(got[1], want[1])
     with pytest.raises(snickery_amd.SnkError):   # workspace 0 holds the rows of `a`, not of `b`
         eng.knn_viterbi_batch_submit(b, 20, resident=True)
