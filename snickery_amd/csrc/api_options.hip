@@ -268,6 +268,10 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0) return fail("upload_stream must be 0 or 1");
         CHK(no_batch_in_flight(h, "snk_set_option(upload_stream)"));
         h->upload_stream = (int)value;
+    } else if (!strcmp(name, "wide_one_group")) {
+        if (value != 0.0 && value != 1.0) return fail("wide_one_group must be 0 or 1");
+        CHK(no_batch_in_flight(h, "snk_set_option(wide_one_group)"));
+        h->wide_one_group = (int)value;
     } else if (!strcmp(name, "split_one_group")) {
         if (value != 0.0 && value != 1.0) return fail("split_one_group must be 0 or 1");
         CHK(no_batch_in_flight(h, "snk_set_option(split_one_group)"));
@@ -449,6 +453,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "join_lb_quadrants")) *out = get_join_lb_quadrants();
     else if (!strcmp(name, "join_bounds_delay")) *out = h->join_bounds_delay;
     else if (!strcmp(name, "split_one_group")) *out = h->split_one_group;
+    else if (!strcmp(name, "wide_one_group")) *out = h->wide_one_group;
     else if (!strcmp(name, "upload_stream")) *out = h->upload_stream;
     else if (!strcmp(name, "tail_defer")) *out = h->tail_defer;
     else if (!strcmp(name, "submits_starved")) *out = (double)h->submits_starved;     // pipelined submits that found the K-NN stream idle (the host was late)

@@ -168,7 +168,7 @@ int snk_merge_viterbi_batch_dev(snk_handle h, const double *d2_dev, const int64_
         launch_merge_topk(d2_dev, id_dev, G, total, K, h->mcand.as<int64_t>(), h->mdist.as<double>(), h->stream);
     }
     {
-        const std::vector<int> first = group_utterances(h, row_offsets, n_utts, false);
+        const std::vector<int> first = group_utterances(h, row_offsets, n_utts, false, K);
         for (int g = 0; g + 1 < (int)first.size(); ++g)
             CHK(viterbi_group(h, g, row_offsets, first[g], first[g + 1], K, h->mcand.as<int64_t>(), h->mdist.as<double>(), true,
                               nullptr, nullptr, nullptr, n_utts));
@@ -564,7 +564,7 @@ static int sharded_submit(snk_engine *h, ShardTicket &t, const double *Q, const 
             StageTimer tm(h, h->stream, TM_MERGE);
             launch_merge_topk(d2_all, id_all, G, r_own, K, t.mcand.as<int64_t>(), t.mdist.as<double>(), h->stream);
         }
-        const std::vector<int> first = group_utterances(h, t.own_off.data(), n_own, false);
+        const std::vector<int> first = group_utterances(h, t.own_off.data(), n_own, false, K);
         for (int g = 0; g + 1 < (int)first.size(); ++g)
             CHK(viterbi_group(h, g, t.own_off.data(), first[g], first[g + 1], K, t.mcand.as<int64_t>(), t.mdist.as<double>(), true,
                               t.res_path.as<int64_t>(), t.res_plen.as<int64_t>(), t.res_cost.as<double>(), n_own));

@@ -243,7 +243,7 @@ int snk_knn_viterbi(snk_handle h, const double *Q, int64_t T, int D, int K, int6
 // so one sweep over the database serves every utterance of the group and the per-call stages
 // (sample minima, thresholds, bucket, re-rank) amortise.  first[g] .. first[g+1] are the utterances
 // of group g.
-std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offsets, int n_utts, bool knn_beside)
+std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offsets, int n_utts, bool knn_beside, int K)
 {
     std::vector<int> first(1, 0);
     // as few groups as batch_rows allows, of equal size and an even number of them: two groups of 16 utterances take a
@@ -259,6 +259,12 @@ std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offset
         // knn_beside); callers that bring their candidates (snk_viterbi_batch, the merged lists of a sharded step) keep one group,
         // one launch of every pass.  Option split_one_group 0 keeps one group everywhere.
         if (knn_beside && h->split_one_group && n_groups == 1 && total >= 6144 && n_utts >= 2) n_groups = 2;
+        // K > 128: the Viterbi side of a group is what a step waits for -- pass 1 on one accumulator set, pass 4 a chain of T steps
+        // that refines a tenth of them: 8 ms per group of 16 utterances at B4, and a chain takes as long for 32 utterances as for 16.
+        // So the whole batch is ONE group where it fits a K-NN call, and consecutive batches take the two side streams in turn
+        // (BatchSlot::gbase): two batches' chains run side by side instead of two groups' of one batch one after the other per
+        // stream (B4: 8.7 -> ms per step of 32 utterances, option wide_one_group).
+        if (knn_beside && h->wide_one_group && K > 128 && total <= SNK_KNN_MAX_ROWS) n_groups = 1;
         target = (total + n_groups - 1) / n_groups;
     }
     int64_t rows = 0;
@@ -363,7 +369,7 @@ static int batch_flush_tail(snk_engine *h, BatchSlot &b, hipEvent_t also_behind)
     const int g = b.n_groups - 1;
     struct Restore { snk_engine *e; bool v; ~Restore() { e->vit_now_dense = v; } } restore{h, h->vit_now_dense};
     h->vit_now_dense = false;                  // (a batch with a pending tail took the sparse path)
-    CHK(viterbi_group(h, g, b.offs.data(), b.first[g], b.first[g + 1], b.K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
+    CHK(viterbi_group(h, g + b.gbase, b.offs.data(), b.first[g], b.first[g + 1], b.K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
                       b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), b.n_utts, true, also_behind));
     return batch_queue_results(h, b);
 }
@@ -395,7 +401,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     for (int k = 0; k < SNK_BATCH_SLOTS && h->bslot[slot].busy; ++k) slot = (slot + 1) % SNK_BATCH_SLOTS;
     BatchSlot &b = h->bslot[slot];
     if (b.busy) return fail("snk_knn_viterbi_batch_submit: %d batches are in flight already (collect one first)", SNK_BATCH_SLOTS);
-    b.first = group_utterances(h, row_offsets, n_utts, true);
+    b.first = group_utterances(h, row_offsets, n_utts, true, K);
     b.n_groups = (int)b.first.size() - 1;
     b.n_utts = n_utts; b.K = K; b.D = D; b.total = total;
     b.offs.assign(row_offsets, row_offsets + n_utts + 1);
@@ -415,6 +421,7 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
     b.vit_dense = vit_auto && (b.vit_trial ? h->vit.trial_mode : h->vit.mode) == 1;
     b.vit_judged = vit_auto;
     b.seq = h->vit_seq++;
+    b.gbase = (b.n_groups == 1) ? (int)(b.seq & 1) : 0;       // one-group batches alternate between the two side streams / Viterbi workspaces
     if (!h->vit_t0[0])
         for (int i = 0; i < 4; ++i) { HIPCHK(hipEventCreate(&h->vit_t0[i])); HIPCHK(hipEventCreate(&h->vit_t1[i])); }
     HIPCHK(hipEventRecord(h->vit_t0[b.seq & 3], h->stream));
@@ -505,21 +512,21 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
         if (g == 0 && prev) CHK(batch_flush_tail(h, *prev, h->knn_mid_recorded ? h->knn_mid : nullptr));      // the batch before this one
         if (delay) {
             if (g > 0)
-                CHK(viterbi_group(h, g - 1, row_offsets, b.first[g - 1], b.first[g], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
+                CHK(viterbi_group(h, g - 1 + b.gbase, row_offsets, b.first[g - 1], b.first[g], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
                                   b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), n_utts, true,
                                   h->knn_mid_recorded ? h->knn_mid : nullptr));
-            HIPCHK(hipEventRecord(h->slot[g & 1].knn_done, h->stream));
+            HIPCHK(hipEventRecord(h->slot[(g + b.gbase) & 1].knn_done, h->stream));
             if (g == b.n_groups - 1) {
                 // The last group: left to the next submit (or to this batch's collect) where the caller keeps two batches in
                 // flight -- the other workspace is busy right now, so the next thing it does is very likely another submit.  A
                 // caller with one batch at a time (host work between submit and collect) gets it queued here, as before.
                 if (pipelined && defer_tail) tail = true;
-                else CHK(viterbi_group(h, g, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
+                else CHK(viterbi_group(h, g + b.gbase, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
                                        b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), n_utts, true, nullptr));
             }
             continue;
         }
-        CHK(viterbi_group(h, g, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
+        CHK(viterbi_group(h, g + b.gbase, row_offsets, b.first[g], b.first[g + 1], K, b.cand.as<int64_t>(), b.dist.as<double>(), true,
                           b.path.as<int64_t>(), b.plen.as<int64_t>(), b.cost.as<double>(), n_utts));
     }
     if (!b.knn_end) HIPCHK(hipEventCreateWithFlags(&b.knn_end, hipEventDisableTiming));
@@ -677,7 +684,7 @@ int snk_viterbi_batch(snk_handle h, const int64_t *cand, const double *tdist, co
         CHK(h2d(h, h->mdist.p, tdist, (size_t)total * K * sizeof(double), h->stream));
     }
     {
-        const std::vector<int> first = group_utterances(h, row_offsets, n_utts, false);
+        const std::vector<int> first = group_utterances(h, row_offsets, n_utts, false, K);
         for (int g = 0; g + 1 < (int)first.size(); ++g)
             CHK(viterbi_group(h, g, row_offsets, first[g], first[g + 1], K, h->mcand.as<int64_t>(), h->mdist.as<double>(), true,
                               nullptr, nullptr, nullptr, n_utts));

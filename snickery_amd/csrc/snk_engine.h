@@ -188,6 +188,7 @@ struct BatchSlot {    // one submitted batch (snk_knn_viterbi_batch_submit / _co
     // submit queues them behind a point inside its own first K-NN call, a collect that comes first queues them as they are
     bool tail_pending = false;
     hipEvent_t knn_end = nullptr;         // everything this batch queued on the main stream
+    int gbase = 0;                        // added to the group index where it picks a side stream / Viterbi workspace (one-group batches alternate)
     hipEvent_t q_up = nullptr;            // this batch's query rows have arrived in Qall (recorded on the upload stream)
     int64_t total = 0;
     std::vector<int> first;
@@ -283,6 +284,7 @@ struct snk_engine {
     // SAME batch only (the side stream cannot wait for what is not queued yet) -- where the shape makes it pay (api_viterbi.hip);
     // 3 / 4: 1 / 2 whatever the shape.  knn_mid: where group g + 1 stands (api_knn.hip)
     int join_bounds_delay = 1;
+    int wide_one_group = 1;    // K > 128: a batch that fits one K-NN call is ONE group, batches alternate between the side streams (api_viterbi.hip)
     int split_one_group = 1;   // a long batch that fits one K-NN call is cut into two groups (K-NN batch entry points only)
     hipEvent_t knn_mid = nullptr;
     bool knn_mid_recorded = false;
@@ -533,7 +535,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
 bool use_sparse_viterbi(const snk_engine *h, int K, int n_utts = 1);
 inline bool any_batch_busy(const snk_engine *h) { for (const auto &b : h->bslot) if (b.busy) return true; return false; }
 void note_optimism_failure(snk_engine *h);
-std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offsets, int n_utts, bool knn_beside);
+std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offsets, int n_utts, bool knn_beside, int K);
 int viterbi_group(snk_engine *h, int g, const int64_t *row_offsets, int u0, int u1, int K,
                   const int64_t *cand_all, const double *tdist_all, bool side_stream,
                   int64_t *res_path = nullptr, int64_t *res_plen = nullptr, double *res_cost = nullptr,

@@ -314,3 +314,38 @@ def test_delayed_viterbi_side_in_every_collect_order(engine, delay):
         engine.set_option('join_bounds_delay', 1)
         engine.set_option('batch_rows', 12288)
     assert engine.info('join_bound_violations') == 0
+
+
+def test_wide_candidate_sets_take_one_group_per_batch(engine):
+    """K > 128 (option wide_one_group): a batch that fits one K-NN call is ONE group and consecutive batches take the two side
+    streams / Viterbi workspaces in turn, so that two batches' recursions run side by side.  Same paths and costs as two groups
+    per batch, with one, two and three batches in flight, collected in and out of order."""
+    N, Dt, Dj, K = 60000, 61, 151, 160
+    F_unw, JC_unw, wt, wj = _db(N, Dt, Dj, seed=29)
+    engine.upload_db(F_unw, JC_unw)
+    engine.set_weights(wt, wj)
+    engine.set_option('viterbi_mode', 2)
+    batches = [[o.synthetic_targets(F_unw, T, seed=400 + 10 * b + i) * wt for i, T in enumerate(lens)]
+               for b, lens in enumerate([(300, 280, 310, 290, 305, 295, 300, 310, 290, 300, 280, 310, 290, 305, 295, 300, 310, 290, 300, 280, 310, 290),
+                                         (120, 90), (700, 650, 720, 600, 680, 710, 640, 690, 600, 660)])]
+    engine.set_option('wide_one_group', 0)
+    want = [engine.knn_viterbi_batch(b, K) for b in batches]
+    engine.set_option('wide_one_group', 1)
+
+    def same(got, i):
+        return all(np.array_equal(a, b) for a, b in zip(got[0], want[i][0])) and np.array_equal(got[1], want[i][1])
+    try:
+        for i, b in enumerate(batches):
+            assert same(engine.knn_viterbi_batch(b, K), i)
+        t = [engine.knn_viterbi_batch_submit(b, K) for b in batches]                     # three in flight: streams 0, 1, 0
+        got = [engine.knn_viterbi_batch_collect(x) for x in t]
+        assert all(same(g, i) for i, g in enumerate(got))
+        t = [engine.knn_viterbi_batch_submit(b, K) for b in batches]
+        g2, g0, g1 = engine.knn_viterbi_batch_collect(t[2]), engine.knn_viterbi_batch_collect(t[0]), engine.knn_viterbi_batch_collect(t[1])
+        assert same(g0, 0) and same(g1, 1) and same(g2, 2)
+        ta = engine.knn_viterbi_batch_submit(batches[0], K)
+        tb = engine.knn_viterbi_batch_submit(batches[0], K)                              # the same batch twice: both streams
+        assert same(engine.knn_viterbi_batch_collect(ta), 0) and same(engine.knn_viterbi_batch_collect(tb), 0)
+    finally:
+        engine.set_option('wide_one_group', 1)
+    assert engine.info('join_bound_violations') == 0

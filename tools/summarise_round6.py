@@ -190,8 +190,8 @@ if not stale:
 # ---- the summary ----
 ro = line['roofline']
 lines = ['# Round 6, profile %s%s' % (tag.split('_')[-1].upper(), '  (STALE: the tree has moved on since this pass)' if stale else ''), '',
-         'Commands (MI355X, 1 GPU, B* workload, 32 utterances per step, two steps in flight, query rows uploaded and paths returned inside '
-         'every timed step; `tools/prof_round6.sh`; kernel sources as in `gpurun_out/<tag>/csrc.sha256`, checked against the tree by this script):', '',
+         'Commands (MI355X, 1 GPU, B* workload, 32 utterances per step, %d steps in flight, query rows uploaded and paths returned inside '
+         'every timed step; `tools/prof_round6.sh`; kernel sources as in `gpurun_out/<tag>/csrc.sha256`, checked against the tree by this script):' % line['config'].get('steps_in_flight', 2), '',
          '* `python bench.py --steps %d --warmup %d` -> %s_bench.json (the compact line the driver parses, %d bytes) + %s_bench_detail.json: '
          '**%.0f frames/s host -> host** (%.3f ms per step; rows resident in HBM: %s); `roofline` = %s: %.0f GB/s of algorithmic bytes = '
          '**%.3f** of 8 TB/s, %.3f ms per launch of %d rows by HIP events inside the pipeline' % (
