@@ -260,6 +260,10 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0 && value != 2.0) return fail("tail_defer must be 0 (never), 1 (always) or 2 (while the host keeps up)");
         CHK(no_batch_in_flight(h, "snk_set_option(tail_defer)"));
         h->tail_defer = (int)value; h->starved_ema = 0.0;
+    } else if (!strcmp(name, "results_by_kernel")) {
+        if (value != 0.0 && value != 1.0) return fail("results_by_kernel must be 0 or 1");
+        CHK(no_batch_in_flight(h, "snk_set_option(results_by_kernel)"));
+        h->results_by_kernel = (int)value;
     } else if (!strcmp(name, "upload_staged")) {
         if (value != 0.0 && value != 1.0) return fail("upload_staged must be 0 or 1");
         CHK(no_batch_in_flight(h, "snk_set_option(upload_staged)"));
@@ -455,6 +459,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "split_one_group")) *out = h->split_one_group;
     else if (!strcmp(name, "wide_one_group")) *out = h->wide_one_group;
     else if (!strcmp(name, "upload_stream")) *out = h->upload_stream;
+    else if (!strcmp(name, "results_by_kernel")) *out = h->results_by_kernel;
     else if (!strcmp(name, "tail_defer")) *out = h->tail_defer;
     else if (!strcmp(name, "submits_starved")) *out = (double)h->submits_starved;     // pipelined submits that found the K-NN stream idle (the host was late)
     else if (!strcmp(name, "submits_pipelined")) *out = (double)h->submits_seen;

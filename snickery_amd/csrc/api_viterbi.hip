@@ -259,11 +259,12 @@ std::vector<int> group_utterances(const snk_engine *h, const int64_t *row_offset
         // knn_beside); callers that bring their candidates (snk_viterbi_batch, the merged lists of a sharded step) keep one group,
         // one launch of every pass.  Option split_one_group 0 keeps one group everywhere.
         if (knn_beside && h->split_one_group && n_groups == 1 && total >= 6144 && n_utts >= 2) n_groups = 2;
-        // K > 128: the Viterbi side of a group is what a step waits for -- pass 1 on one accumulator set, pass 4 a chain of T steps
-        // that refines a tenth of them: 8 ms per group of 16 utterances at B4, and a chain takes as long for 32 utterances as for 16.
-        // So the whole batch is ONE group where it fits a K-NN call, and consecutive batches take the two side streams in turn
-        // (BatchSlot::gbase): two batches' chains run side by side instead of two groups' of one batch one after the other per
-        // stream (B4: 8.7 -> ms per step of 32 utterances, option wide_one_group).
+        // option wide_one_group (default 0): K > 128, where the Viterbi side of a group is what a step waits for (pass 1 on one
+        // accumulator set, pass 4 a chain of T steps that refines a tenth of them: 8 ms per group of 16 utterances at B4, and a chain
+        // takes as long for 32 utterances as for 16) -- the whole batch as ONE group where it fits a K-NN call, consecutive batches
+        // taking the two side streams in turn (BatchSlot::gbase), so that two batches' chains run side by side.  Measured at B4:
+        // slower (9.6 -> 11.2 ms per step, profiles/r06k_b4.log: the single group's passes 1 and 3 are twice as long and nothing
+        // of its own batch runs beside them); with the quadrant form of pass 1 it breaks even (9.3 ms).  Kept as an option.
         if (knn_beside && h->wide_one_group && K > 128 && total <= SNK_KNN_MAX_ROWS) n_groups = 1;
         target = (total + n_groups - 1) / n_groups;
     }
@@ -347,11 +348,20 @@ static int batch_queue_results(snk_engine *h, BatchSlot &b)
     {
         StageTimer t(h, h->copy_stream, TM_D2H);
         char *st = (char *)b.stage.p;
+        if (h->results_by_kernel) {
+            // (a kernel's stores, not DMA copies: viterbi_kernels.hip results_to_host_kernel says why)
+            void *dst[5] = {st, st + sz_path, st + sz_path + sz_u, st + sz_path + 2 * sz_u, st + sz_path + 2 * sz_u + sz_st};
+            const void *src[5] = {b.path.p, b.plen.p, b.cost.p, b.status.p, h->vstats.p};
+            const size_t nb[5] = {(size_t)total * sizeof(int64_t), (size_t)n_utts * sizeof(int64_t), (size_t)n_utts * sizeof(double),
+                                  (size_t)3 * b.n_groups * sizeof(int), 4 * sizeof(unsigned long long)};
+            launch_results_to_host(dst, src, nb, 5, h->copy_stream);
+        } else {
         HIPCHK(hipMemcpyAsync(st, b.path.p, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
         HIPCHK(hipMemcpyAsync(st + sz_path, b.plen.p, (size_t)n_utts * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
         HIPCHK(hipMemcpyAsync(st + sz_path + sz_u, b.cost.p, (size_t)n_utts * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
         HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u, b.status.p, (size_t)3 * b.n_groups * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
         HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u + sz_st, h->vstats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->copy_stream));
+        }
     }
     HIPCHK(hipEventRecord(h->vit_t1[b.seq & 3], h->copy_stream));
     HIPCHK(hipEventRecord(b.done, h->copy_stream));

@@ -225,6 +225,7 @@ struct snk_engine {
     int tail_defer = 1;                    // option (api_viterbi.hip snk_knn_viterbi_batch_submit): 0 never / 1 always / 2 while the host keeps up (measured: 2 flaps between the two and loses to both, profiles/r06f_ab.log)
     int64_t submits_seen = 0, submits_starved = 0;      // pipelined submits / those that found the K-NN stream idle
     double starved_ema = 0.0;
+    int results_by_kernel = 1;             // option: a batch's results reach page-locked host memory by a kernel's stores, not DMA copies
     int upload_staged = 0;                 // option (experiment): submitted rows always through the library's own pinned staging
     // option: 1 = the rows of a submitted batch travel on a stream of their own.  Off: measured on the B* step (profiles/r06d_ab.log) the
     // copy on its own stream costs the HOST 0.31 ms more per submit (0.59 against 0.27 ms) and the step is sensitive to exactly
@@ -284,7 +285,7 @@ struct snk_engine {
     // SAME batch only (the side stream cannot wait for what is not queued yet) -- where the shape makes it pay (api_viterbi.hip);
     // 3 / 4: 1 / 2 whatever the shape.  knn_mid: where group g + 1 stands (api_knn.hip)
     int join_bounds_delay = 1;
-    int wide_one_group = 1;    // K > 128: a batch that fits one K-NN call is ONE group, batches alternate between the side streams (api_viterbi.hip)
+    int wide_one_group = 0;    // K > 128: a batch that fits one K-NN call is ONE group, batches alternate between the side streams (api_viterbi.hip; measured slower: off)
     int split_one_group = 1;   // a long batch that fits one K-NN call is cut into two groups (K-NN batch entry points only)
     hipEvent_t knn_mid = nullptr;
     bool knn_mid_recorded = false;

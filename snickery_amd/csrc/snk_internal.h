@@ -120,6 +120,7 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
                          bool verify_thr = false);  // optimistic thresholds: rows whose list is not PROVEN to hold the K nearest set status bit 8
 void launch_candidate_dist(const double *Fw, int Dpad, int D, int64_t N, const double *Qp,
                            const int64_t *cand, int64_t T, int K, double *dist, hipStream_t s);
+void launch_results_to_host(void *const *dst, const void *const *src, const size_t *bytes, int n, hipStream_t s);      // viterbi_kernels.hip
 void launch_merge_topk(const double *d2, const int64_t *id, int G, int64_t T, int K,
                        int64_t *cand, double *dist, hipStream_t s);
 // compacted exchange of the shards' lists (knn_kernels.hip)

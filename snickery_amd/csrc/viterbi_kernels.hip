@@ -401,4 +401,33 @@ void launch_viterbi_dp(const int64_t *cand, const double *tdist, const double *J
     launch_viterbi_dp_batch(cand, tdist, J, off, 1, 0, K, n_units, bp_global, path, path_len, cost, s, fst32);
 }
 
+
+// Results of a batch -> page-locked host memory by a KERNEL (stores over PCIe) instead of DMA copies: a copy queued behind events
+// that are minutes of GPU time away -- the batch's last recursions -- sits in the DMA engine's queue until they fire, and the
+// next batch's upload of query rows (same engine family) waited behind it (B4: 3-4 ms of a 9.6 ms step inside `h2d_queries`,
+// profiles/r06k_b4.log).  Five segments, 16-byte stores where aligned.
+struct D2HSegs { void *dst[5]; const void *src[5]; unsigned long long bytes[5]; };
+__global__ void __launch_bounds__(256)
+results_to_host_kernel(D2HSegs sg)
+{
+    for (int i = 0; i < 5; ++i) {
+        const unsigned long long n = sg.bytes[i];
+        if (!n) continue;
+        const unsigned long long n16 = ((((unsigned long long)sg.dst[i] | (unsigned long long)sg.src[i]) & 15ull) == 0) ? n / 16 : 0;
+        const uint4 *s4 = static_cast<const uint4 *>(sg.src[i]);
+        uint4 *d4 = static_cast<uint4 *>(sg.dst[i]);
+        for (unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x; k < n16; k += (unsigned long long)gridDim.x * 256) d4[k] = s4[k];
+        const unsigned char *s1 = static_cast<const unsigned char *>(sg.src[i]);
+        unsigned char *d1 = static_cast<unsigned char *>(sg.dst[i]);
+        for (unsigned long long k = n16 * 16 + (unsigned long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (unsigned long long)gridDim.x * 256) d1[k] = s1[k];
+    }
+}
+
+void launch_results_to_host(void *const *dst, const void *const *src, const size_t *bytes, int n, hipStream_t s)
+{
+    D2HSegs sg{};
+    for (int i = 0; i < 5; ++i) { sg.dst[i] = i < n ? dst[i] : nullptr; sg.src[i] = i < n ? src[i] : nullptr; sg.bytes[i] = i < n ? bytes[i] : 0; }
+    hipLaunchKernelGGL(results_to_host_kernel, dim3(16), dim3(256), 0, s, sg);
+}
+
 }  // namespace snk

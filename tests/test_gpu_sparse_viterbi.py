@@ -317,7 +317,7 @@ def test_delayed_viterbi_side_in_every_collect_order(engine, delay):
 
 
 def test_wide_candidate_sets_take_one_group_per_batch(engine):
-    """K > 128 (option wide_one_group): a batch that fits one K-NN call is ONE group and consecutive batches take the two side
+    """K > 128 with option wide_one_group (off by default: measured slower at B4): a batch that fits one K-NN call is ONE group and consecutive batches take the two side
     streams / Viterbi workspaces in turn, so that two batches' recursions run side by side.  Same paths and costs as two groups
     per batch, with one, two and three batches in flight, collected in and out of order."""
     N, Dt, Dj, K = 60000, 61, 151, 160
@@ -347,5 +347,5 @@ def test_wide_candidate_sets_take_one_group_per_batch(engine):
         tb = engine.knn_viterbi_batch_submit(batches[0], K)                              # the same batch twice: both streams
         assert same(engine.knn_viterbi_batch_collect(ta), 0) and same(engine.knn_viterbi_batch_collect(tb), 0)
     finally:
-        engine.set_option('wide_one_group', 1)
+        engine.set_option('wide_one_group', 0)
     assert engine.info('join_bound_violations') == 0
