@@ -355,7 +355,8 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
             CHK(h->cpairctl.ensure(4 * sizeof(unsigned int)));
             CHK(h->e1_16.ensure((size_t)Tpad * sizeof(double)));
             CHK(h->thr1_32.ensure((size_t)Tpad * sizeof(float)));
-            HIPCHK(hipMemsetAsync(h->cpairctl.p, 0, 4 * sizeof(unsigned int), s));
+            // (cleared by the call's knn_reset below, with the super balls' mask and the re-rank's retry flags: three dispatches
+            // less on the K-NN stream per call)
         }
         // accumulation of the coarse pass's own chain (one MFMA per k-block through C) on top of the three-term chain's
         const double c_coarse = eps_c_run + 1.02 * SNK_BF16_MFMA_UNIT * (double)(h->Dpad / 16 + 1);
@@ -364,8 +365,16 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
         if (bf) CHK(h->cq16.ensure((size_t)Tpad * sizeof(double)));
         CHK(h->thr32.ensure((size_t)Tpad * sizeof(float)));
         CHK(h->gmin32.ensure((size_t)Tpad * G16 * sizeof(float)));
+        // the balls of 32 tiles run first where the ball pass does (same test as below): their mask is cleared with the rest
+        const bool will_super = coarse && h->prefilter_balls && h->ball_tiles > 0 && slab_factor == 1 && !h->filter_coarse &&
+                                h->prefilter_super_balls && h->ball_supers > 0;
+        const size_t mask_words = will_super ? (size_t)h->ball_supers * ((Tpad / 32 + 31) / 32) : 0;
+        if (will_super) CHK(h->ball_mask.ensure(mask_words * sizeof(unsigned int)));
         launch_knn_reset(h->cnt.as<int>(), Tpad, status_dev, h->poolctl.as<unsigned int>(),
-                         h->slabctr.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, s);
+                         h->slabctr.as<unsigned int>(), h->chunkfill.as<int>(), max_chunks, s,
+                         coarse ? h->cpairctl.as<unsigned int>() : nullptr, 4,
+                         will_super ? h->ball_mask.as<unsigned int>() : nullptr, (long long)mask_words,
+                         h->rowflag.as<unsigned int>(), (long long)T);
         {
             StageTimer t(h, s, TM_PREP);
             if (bf)
@@ -452,7 +461,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
                         // the balls of 32 tiles first: a bit per (super ball, query tile); the tile pass visits the marked blocks
                         const size_t words = (size_t)h->ball_supers * ((Tpad / 32 + 31) / 32);
                         CHK(h->ball_mask.ensure(words * sizeof(unsigned int)));
-                        HIPCHK(hipMemsetAsync(h->ball_mask.p, 0, words * sizeof(unsigned int), s));
+                        if (!(will_super && words == mask_words)) HIPCHK(hipMemsetAsync(h->ball_mask.p, 0, words * sizeof(unsigned int), s));      // (else: cleared by knn_reset)
                         launch_knn_balls16b(h->prefilter == 2 ? 4 : 3, dch16, p0.grid_cus, h->ball_s16.p, h->b16l.p, h->ball_rad2.as<float>(),
                                             h->ball_tq.as<float>(), h->ball_nq.as<float>(), Tpad, h->ball_supers, nullptr, nullptr, 0u, s,
                                             h->ball_mask.as<unsigned int>(), nullptr);
@@ -560,7 +569,7 @@ int knn_device(snk_engine *h, const double *Qdev, int64_t T, int K, const int32_
                                 h->shard_offset, h->eps16.as<double>(), h->fnorm.as<double>(), eps_c_run, bf ? h->cq16.as<double>() : nullptr, cand_dev, dist_dev, d2_dev, status_dev, nullptr, s,
                                 bound_in != nullptr,         // a shard's lists under the shared bound are short
                                 bound_in ? nullptr : h->thr.as<double>(), h->margin_stat.as<unsigned int>(), h->rowflag.as<int>(),
-                                h->knn_level >= 1, optimistic);
+                                h->knn_level >= 1, optimistic, true);
         }
         if (deferred_status) {               // the batch caller redoes failures with precision 0
             // (and learns how many tile pairs the ball pass listed)

@@ -264,10 +264,6 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0) return fail("results_by_kernel must be 0 or 1");
         CHK(no_batch_in_flight(h, "snk_set_option(results_by_kernel)"));
         h->results_by_kernel = (int)value;
-    } else if (!strcmp(name, "upload_staged")) {
-        if (value != 0.0 && value != 1.0) return fail("upload_staged must be 0 or 1");
-        CHK(no_batch_in_flight(h, "snk_set_option(upload_staged)"));
-        h->upload_staged = (int)value;
     } else if (!strcmp(name, "upload_stream")) {
         if (value != 0.0 && value != 1.0) return fail("upload_stream must be 0 or 1");
         CHK(no_batch_in_flight(h, "snk_set_option(upload_stream)"));

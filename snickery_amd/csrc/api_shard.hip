@@ -580,6 +580,15 @@ static int sharded_submit(snk_engine *h, ShardTicket &t, const double *Q, const 
         HIPCHK(hipStreamWaitEvent(h->copy_stream, t.main_done, 0));
         for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(h->copy_stream, t.side_done[i], 0));
         char *st = (char *)t.stage.p;
+        if (h->results_by_kernel) {
+            // a kernel's stores, not DMA copies that would sit at the head of the engine's queue until this step's recursions are
+            // done, with the next step's upload behind them (viterbi_kernels.hip results_to_host_kernel)
+            void *dst[5] = {st, st + sz_path, st + sz_path + sz_u, st + sz_path + 2 * sz_u, nullptr};
+            const void *src[5] = {t.res_path.p, t.res_plen.p, t.res_cost.p, t.status.p, nullptr};
+            const size_t nb[5] = {n_own > 0 ? (size_t)r_own * sizeof(int64_t) : 0, n_own > 0 ? (size_t)n_own * sizeof(int64_t) : 0,
+                                  n_own > 0 ? (size_t)n_own * sizeof(double) : 0, n_status > 0 ? (size_t)n_status * sizeof(int) : 0, 0};
+            launch_results_to_host(dst, src, nb, 4, h->copy_stream);
+        } else {
         if (n_own > 0) {
             HIPCHK(hipMemcpyAsync(st, t.res_path.p, (size_t)r_own * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
             HIPCHK(hipMemcpyAsync(st + sz_path, t.res_plen.p, (size_t)n_own * sizeof(int64_t), hipMemcpyDeviceToHost, h->copy_stream));
@@ -587,6 +596,7 @@ static int sharded_submit(snk_engine *h, ShardTicket &t, const double *Q, const 
         }
         if (n_status > 0)
             HIPCHK(hipMemcpyAsync(st + sz_path + 2 * sz_u, t.status.p, (size_t)n_status * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
+        }
         HIPCHK(hipEventRecord(t.done, h->copy_stream));
     }
     HIPCHK(hipGetLastError());

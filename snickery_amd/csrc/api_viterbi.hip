@@ -460,14 +460,6 @@ int snk_knn_viterbi_batch_submit(snk_handle h, const double *Q, const int64_t *r
         }
         {
             StageTimer t(h, us, TM_H2D);
-            if (h->upload_staged) {
-                // experiment (option upload_staged): always through the library's own page-locked staging (hipHostMalloc), also for rows
-                // the caller registered (hipHostRegister)
-                const size_t bytes = (size_t)total * D * sizeof(double);
-                CHK(b.qstage.ensure(bytes));
-                memcpy(b.qstage.p, Q, bytes);
-                HIPCHK(hipMemcpyAsync(b.Qall.p, b.qstage.p, bytes, hipMemcpyHostToDevice, us));
-            } else
             CHK(h2d_via(b.qstage, b.Qall.p, Q, (size_t)total * D * sizeof(double), us));
         }
         if (us != h->stream) {

@@ -436,21 +436,29 @@ void launch_knn_filter(const KnnPlan &p, const double *Fw, const double *fnorm, 
 }
 
 // one launch instead of five memsets: list counters, status word, pool control, slab dispensers
+// (+ up to three more regions of words to clear: control words and masks of the passes that follow -- each used to be a
+// hipMemsetAsync of its own, a dispatch and a gap on the K-NN stream per call)
+struct ResetExtra { unsigned int *p[3]; long long n[3]; };
 __global__ void knn_reset_kernel(int *cnt, int64_t Tpad, int *status, unsigned int *pool_ctl,
-                                 unsigned int *slab_counter, int *chunk_fill, int max_chunks)
+                                 unsigned int *slab_counter, int *chunk_fill, int max_chunks, ResetExtra ex)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < Tpad) cnt[i] = 0;
     if (i < max_chunks) chunk_fill[i] = 0;
     if (i == 0) { *status = 0; pool_ctl[0] = 0; pool_ctl[1] = 0; slab_counter[0] = 0; slab_counter[1] = 0; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        for (long long k = i; k < ex.n[r]; k += (long long)gridDim.x * blockDim.x) ex.p[r][k] = 0u;
 }
 
 void launch_knn_reset(int *cnt, int64_t Tpad, int *status, unsigned int *pool_ctl,
-                      unsigned int *slab_counter, int *chunk_fill, int max_chunks, hipStream_t s)
+                      unsigned int *slab_counter, int *chunk_fill, int max_chunks, hipStream_t s,
+                      unsigned int *x0, long long n0, unsigned int *x1, long long n1, unsigned int *x2, long long n2)
 {
     const int64_t n = Tpad > max_chunks ? Tpad : max_chunks;
+    ResetExtra ex{{x0, x1, x2}, {x0 ? n0 : 0, x1 ? n1 : 0, x2 ? n2 : 0}};
     hipLaunchKernelGGL(knn_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cnt, Tpad, status,
-                       pool_ctl, slab_counter, chunk_fill, max_chunks);
+                       pool_ctl, slab_counter, chunk_fill, max_chunks, ex);
 }
 
 int knn_pool_chunk_entries() { return POOL_CHUNK; }
@@ -1171,7 +1179,7 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
                          int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c, const double *cq,
                          int64_t *cand, double *dist, double *d2_out, int *status, int *rowflag, hipStream_t s, bool split_short,
-                         const double *thr, unsigned int *margin_stat, int *retry, bool big_tier, bool verify_thr)
+                         const double *thr, unsigned int *margin_stat, int *retry, bool big_tier, bool verify_thr, bool retry_cleared)
 {
     const int vf = verify_thr ? 2 : 0;                       // bit 1 of the kernels' big_tier word
     int P = 2;
@@ -1193,7 +1201,7 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
         // the lean form for (nearly) every row, the full form for the rows it flags
         size_t lean = (size_t)P * sizeof(float);
         if (lean < (size_t)SEL_MAX * sizeof(double)) lean = (size_t)SEL_MAX * sizeof(double);
-        (void)hipMemsetAsync(retry, 0, (size_t)T * sizeof(int), s);
+        if (!retry_cleared) (void)hipMemsetAsync(retry, 0, (size_t)T * sizeof(int), s);
         hipLaunchKernelGGL((knn_finalize_kernel<0, true, true>), dim3((unsigned)T), dim3(256), lean, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
                            qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, vf);
         const int big = (big_tier && cap <= 8192) ? 1 : 0;

@@ -226,7 +226,6 @@ struct snk_engine {
     int64_t submits_seen = 0, submits_starved = 0;      // pipelined submits / those that found the K-NN stream idle
     double starved_ema = 0.0;
     int results_by_kernel = 1;             // option: a batch's results reach page-locked host memory by a kernel's stores, not DMA copies
-    int upload_staged = 0;                 // option (experiment): submitted rows always through the library's own pinned staging
     // option: 1 = the rows of a submitted batch travel on a stream of their own.  Off: measured on the B* step (profiles/r06d_ab.log) the
     // copy on its own stream costs the HOST 0.31 ms more per submit (0.59 against 0.27 ms) and the step is sensitive to exactly
     // that -- the next batch is submitted when the one before the last is collected, 0.3 ms before the K-NN stream runs dry --:

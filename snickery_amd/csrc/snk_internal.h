@@ -95,7 +95,9 @@ void launch_knn_filter(const KnnPlan &p, const double *Fw, const double *fnorm,
                        const int32_t *unit_class, const int32_t *query_class, hipStream_t s);
 size_t knn_pool_bytes(int max_chunks);
 void launch_knn_reset(int *cnt, int64_t Tpad, int *status, unsigned int *pool_ctl,
-                      unsigned int *slab_counter, int *chunk_fill, int max_chunks, hipStream_t s);
+                      unsigned int *slab_counter, int *chunk_fill, int max_chunks, hipStream_t s,
+                      unsigned int *x0 = nullptr, long long n0 = 0, unsigned int *x1 = nullptr, long long n1 = 0,
+                      unsigned int *x2 = nullptr, long long n2 = 0);      // + up to three regions of words to clear
 void launch_knn_bucket(const void *pool, const unsigned int *pool_ctl, const int *chunk_fill,
                        int max_chunks, int64_t Tpad, int64_t n_valid, int *cnt, double *lkey, int *lidx,
                        int cap, int *status, hipStream_t s, const int32_t *perm = nullptr,      // perm: the entries carry POSITIONS of a reordered operand
@@ -117,7 +119,8 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
                          const double *thr = nullptr, unsigned int *margin_stat = nullptr,    // tripwire of the prefilter's key bound
                          int *retry = nullptr,      // T ints of scratch: the lean form (keys only in LDS) first, the full form for the rows it flags
                          bool big_tier = false,     // ... and a third form (selection of 8 192) for the rows with more near ties than the full form holds
-                         bool verify_thr = false);  // optimistic thresholds: rows whose list is not PROVEN to hold the K nearest set status bit 8
+                         bool verify_thr = false,   // optimistic thresholds: rows whose list is not PROVEN to hold the K nearest set status bit 8
+                         bool retry_cleared = false);   // `retry` was zeroed by the call's knn_reset already
 void launch_candidate_dist(const double *Fw, int Dpad, int D, int64_t N, const double *Qp,
                            const int64_t *cand, int64_t T, int K, double *dist, hipStream_t s);
 void launch_results_to_host(void *const *dst, const void *const *src, const size_t *bytes, int n, hipStream_t s);      // viterbi_kernels.hip
