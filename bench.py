@@ -547,7 +547,7 @@ def main():
                          '(the per-utterance recursions of its last group, the copy of the results) runs beside the K-NN of the '
                          'next one -- how a tuning loop over a tune set drives the engine; 3 (the library has three workspaces) '
                          'submits step i+2 as well, so that the K-NN stream has work while the host waits for step i (a slow host; on a '
-                         'fast one the deeper queue costs more than it gives); 0 (default): the better of 2 and 3, tried for six steps '
+                         'fast one the deeper queue costs more than it gives); 0 (default): the better of 2 and 3, tried for ten steps '
                          'each after the warm-up, untimed; every step completes inside the timed region.  1: strictly one step at a '
                          'time (reported as extra field one_in_flight otherwise)')
     ap.add_argument('--resident-rows', action='store_true',
@@ -734,9 +734,9 @@ def main():
         for d in (2, 3, 2, 3):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            pipelined(6, resident, depth=d)
+            pipelined(10, resident, depth=d)
             torch.cuda.synchronize()
-            depth_probe[d] = max(depth_probe.get(d, 0.0), frames_per_step * 6 / (time.perf_counter() - t1))
+            depth_probe[d] = max(depth_probe.get(d, 0.0), frames_per_step * 10 / (time.perf_counter() - t1))
         args.in_flight = 3 if depth_probe[3] > depth_probe[2] else 2
         host_ms.update({'submit': 0.0, 'collect': 0.0, 'n': 0})
     elif world > 1 and args.in_flight == 0:

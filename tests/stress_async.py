@@ -1,4 +1,4 @@
-"""Stress of the two-batches-in-flight API: random ragged batches, random collect order, compared with
+"""Stress of the batches-in-flight API (three workspaces): random ragged batches, random collect order, compared with
 the one-call form.  python tests/stress_async.py [iterations] [seed] [join_bounds_delay]
 (join_bounds_delay 3 / 4: the Viterbi side of every group behind a point inside the next group's K-NN call whatever the shape,
 a batch's last group queued by the next submit or by its own collect -- the orders this script draws at random)."""
@@ -26,7 +26,7 @@ for it in range(n_iter):
     K = int(rng.choice([5, 20, 50]))
     lens = [int(rng.randint(1, 80)) for _ in range(int(rng.randint(1, 7)))]
     utts = [o.synthetic_targets(F_unw, T, seed=int(rng.randint(1 << 30))) * wt for T in lens]
-    while len(pending) == 2 or (pending and rng.rand() < 0.3):
+    while len(pending) == 3 or (pending and rng.rand() < 0.3):
         t, ref = pending.pop(int(rng.randint(len(pending))))
         got = eng.knn_viterbi_batch_collect(t)
         ok = all(np.array_equal(a, b) for a, b in zip(got[0], ref[0])) and np.array_equal(got[1], ref[1])
