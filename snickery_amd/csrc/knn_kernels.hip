@@ -1145,7 +1145,19 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
     // approximate key.  The exact K-th key is known now: room = thr - kth is what the keys of the true neighbours could
     // have been off by without being dropped.  Rows with room < 2 eps are the rows whose result would have been wrong
     // had the error assumption been violated by a factor of two; [1] keeps the smallest room / eps seen.
-    if (thr && eps && margin_stat && threadIdx.x == 0 && kk == K && n > K) {
+    // Optimistic thresholds (api_knn.hip: the filter's threshold came from FEWER than K sample minima -- an estimate, no bound):
+    // the list holds every unit whose approximate key lies under thr.  If it has K entries and the exact K-th key k of the LIST
+    // satisfies k + eps <= thr, every unit of the database with a true key <= k has an approximate key <= k + eps <= thr and is
+    // in the list: the list's K nearest are the database's.  Accepted only with TWICE that room (k + 2 eps <= thr), so that a row
+    // accepted here also passes the tripwire below -- a 2 x violation of the assumed eps would not have changed it; otherwise the
+    // row is flagged and the caller redoes the call with guaranteed thresholds (status bit 8), where the tripwire judges it.
+    bool flagged = false;
+    if (verify && threadIdx.x == 0) {
+        bool proven = kk == K && n >= K;
+        if (proven && thr && eps && thr[row] < 0.5 * DBL_MAX) proven = (thr[row] - (ex_key[K - 1] - qnorm[row])) >= 2.0 * eps[row];
+        if (!proven) { atomicOr(status, 8); flagged = true; }
+    }
+    if (thr && eps && margin_stat && threadIdx.x == 0 && kk == K && n > K && !flagged) {
         const double room = thr[row] - (ex_key[K - 1] - qnorm[row]);
         const double e = eps[row];
         if (e > 0.0 && thr[row] < 0.5 * DBL_MAX) {
@@ -1154,16 +1166,6 @@ knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_u
             if (!(ratio > 0.f)) ratio = 0.f;
             atomicMin(&margin_stat[1], __float_as_uint(ratio));
         }
-    }
-    // Optimistic thresholds (api_knn.hip: the filter's threshold came from FEWER than K sample minima -- an estimate, no bound):
-    // the list holds every unit whose approximate key lies under thr.  If it has K entries and the exact K-th key k of the LIST
-    // satisfies k + eps <= thr, every unit of the database with a true key <= k has an approximate key <= k + eps <= thr and is
-    // in the list: the list's K nearest are the database's.  Otherwise the row is flagged and the caller redoes the call with
-    // guaranteed thresholds (status bit 8).
-    if (verify && threadIdx.x == 0) {
-        bool proven = kk == K && n >= K;
-        if (proven && thr && eps && thr[row] < 0.5 * DBL_MAX) proven = (thr[row] - (ex_key[K - 1] - qnorm[row])) >= eps[row];
-        if (!proven) atomicOr(status, 8);
     }
     for (int j = threadIdx.x; j < K; j += blockDim.x) {
         int64_t c = -1;
