@@ -934,23 +934,24 @@ __device__ __forceinline__ int block_incl_scan_256(int v, int *wsum /* LDS [4] *
 // SELX > 0: the instance for the rows that hold more near ties than SEL_MAX (retry[row] == 2, left by the full form when the
 // launch has a big tier): a selection of SELX entries -- every list fits -- on 97 KB of LDS, for the few rows of a voice whose
 // units are so dense in key space that thousands of them lie inside the key margin (12 M units of SURVEY 8d's walk).
-// one row of the re-rank (the workgroup's 256 threads; every exit is uniform)
-template <int CLASS, bool F32K, bool LEAN, int SELX>
-__device__ __forceinline__ void
-knn_finalize_row(const int64_t row, const double *__restrict__ Fw, const float *__restrict__ F_unw, int Fp,
-                 const double *__restrict__ wt, int Dpad, int D, const double *__restrict__ Qp,
-                 const double *__restrict__ qnorm, int64_t T, int K,
-                 const int *__restrict__ cnt, const double *__restrict__ lkey,
-                 const int *__restrict__ lidx, int cap, int64_t id_offset,
-                 const double *__restrict__ eps, const double *__restrict__ fnorm, double eps_c,
-                 const double *__restrict__ cq,
-                 int64_t *__restrict__ cand, double *__restrict__ dist,
-                 double *__restrict__ d2_out, int *__restrict__ status, int *__restrict__ rowflag,
-                 const double *__restrict__ thr, unsigned int *__restrict__ margin_stat, int *__restrict__ retry,
-                 int big_tier)
+template <int CLASS, bool F32K, bool LEAN = false, int SELX = 0>
+__global__ void __launch_bounds__(256)
+knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_unw, int Fp,
+                    const double *__restrict__ wt, int Dpad, int D, const double *__restrict__ Qp,
+                    const double *__restrict__ qnorm, int64_t T, int K,
+                    const int *__restrict__ cnt, const double *__restrict__ lkey,
+                    const int *__restrict__ lidx, int cap, int64_t id_offset,
+                    const double *__restrict__ eps, const double *__restrict__ fnorm, double eps_c,
+                    const double *__restrict__ cq,
+                    int64_t *__restrict__ cand, double *__restrict__ dist,
+                    double *__restrict__ d2_out, int *__restrict__ status, int *__restrict__ rowflag,
+                    const double *__restrict__ thr, unsigned int *__restrict__ margin_stat, int *__restrict__ retry,
+                    int big_tier)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int SELM = SELX ? SELX : (CLASS == 1) ? FIN_SMALL : SEL_MAX;
+    const int64_t row = blockIdx.x;
+    if (!LEAN && retry && (SELX ? retry[row] != 2 : retry[row] != 1)) return;     // second / third launch: only the rows the form before left
     const int n_all = cnt[row];
     if (CLASS == 1 && n_all > FIN_SMALL) return;
     if (CLASS == 2 && n_all <= FIN_SMALL) return;
@@ -1176,41 +1177,6 @@ knn_finalize_row(const int64_t row, const double *__restrict__ Fw, const float *
     }
 }
 
-// rows_per_wg 1: a workgroup per row (the first launch of a call).  > 1: the later launches, which take only the rows the form
-// before flagged in `retry` -- usually none: a workgroup looks at rows_per_wg flags and exits (9 600 workgroups that each read one
-// flag and exit cost 65 us per launch, 2 % of a B* step; 1 200 that read eight cost 8)
-template <int CLASS, bool F32K, bool LEAN = false, int SELX = 0>
-__global__ void __launch_bounds__(256)
-knn_finalize_kernel(const double *__restrict__ Fw, const float *__restrict__ F_unw, int Fp,
-                    const double *__restrict__ wt, int Dpad, int D, const double *__restrict__ Qp,
-                    const double *__restrict__ qnorm, int64_t T, int K,
-                    const int *__restrict__ cnt, const double *__restrict__ lkey,
-                    const int *__restrict__ lidx, int cap, int64_t id_offset,
-                    const double *__restrict__ eps, const double *__restrict__ fnorm, double eps_c,
-                    const double *__restrict__ cq,
-                    int64_t *__restrict__ cand, double *__restrict__ dist,
-                    double *__restrict__ d2_out, int *__restrict__ status, int *__restrict__ rowflag,
-                    const double *__restrict__ thr, unsigned int *__restrict__ margin_stat, int *__restrict__ retry,
-                    int big_tier, int rows_per_wg)
-{
-    const int want = SELX ? 2 : 1;
-    if (rows_per_wg <= 1) {
-        const int64_t row = blockIdx.x;
-        if (!LEAN && retry && retry[row] != want) return;     // second / third launch: only the rows the form before left
-        knn_finalize_row<CLASS, F32K, LEAN, SELX>(row, Fw, F_unw, Fp, wt, Dpad, D, Qp, qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq,
-                                                   cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, big_tier);
-        return;
-    }
-    for (int r = 0; r < rows_per_wg; ++r) {
-        const int64_t row = (int64_t)blockIdx.x * rows_per_wg + r;
-        if (row >= T) break;
-        if (!LEAN && retry && retry[row] != want) continue;   // (uniform: every thread reads the same flag)
-        knn_finalize_row<CLASS, F32K, LEAN, SELX>(row, Fw, F_unw, Fp, wt, Dpad, D, Qp, qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq,
-                                                   cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, big_tier);
-        __syncthreads();                                      // the next row reuses the workgroup's LDS
-    }
-}
-
 void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const double *wt, int Dpad, int D, const double *Qp, const double *qnorm,
                          int64_t T, int K, const int *cnt, const double *lkey, const int *lidx,
                          int cap, int64_t id_offset, const double *eps, const double *fnorm, double eps_c, const double *cq,
@@ -1232,18 +1198,17 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
 #undef SNK_FIN_ATTR
     });
 #define SNK_FIN(C_, F_, SH_) hipLaunchKernelGGL((knn_finalize_kernel<C_, F_>), dim3((unsigned)T), dim3(256), SH_, s, Fw, F_unw, Fp, wt, Dpad, D, Qp, \
-                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, nullptr, vf, 1)
+                       qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, nullptr, vf)
     if (f32k && retry && !split_short && !rowflag) {
         // the lean form for (nearly) every row, the full form for the rows it flags
         size_t lean = (size_t)P * sizeof(float);
         if (lean < (size_t)SEL_MAX * sizeof(double)) lean = (size_t)SEL_MAX * sizeof(double);
         if (!retry_cleared) (void)hipMemsetAsync(retry, 0, (size_t)T * sizeof(int), s);
         hipLaunchKernelGGL((knn_finalize_kernel<0, true, true>), dim3((unsigned)T), dim3(256), lean, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
-                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, vf, 1);
+                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, vf);
         const int big = (big_tier && cap <= 8192) ? 1 : 0;
-        constexpr int RPW = 8;                                 // rows a workgroup of the later launches looks at
-        hipLaunchKernelGGL((knn_finalize_kernel<0, true, false>), dim3((unsigned)((T + RPW - 1) / RPW)), dim3(256), shmem, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
-                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, big | vf, RPW);
+        hipLaunchKernelGGL((knn_finalize_kernel<0, true, false>), dim3((unsigned)T), dim3(256), shmem, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
+                           qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, big | vf);
         if (big) {
             // third tier (a voice that has overflowed before: api_knn.hip knn_level): the rows with more near ties than SEL_MAX
             size_t shbig = (size_t)P * (sizeof(float) + sizeof(int));
@@ -1252,8 +1217,8 @@ void launch_knn_finalize(const double *Fw, const float *F_unw, int Fp, const dou
             lds_attr_ensure(attr_big, shbig, [&] {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_finalize_kernel<0, true, false, 8192>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shbig); });
-            hipLaunchKernelGGL((knn_finalize_kernel<0, true, false, 8192>), dim3((unsigned)((T + RPW - 1) / RPW)), dim3(256), shbig, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
-                               qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, vf, RPW);
+            hipLaunchKernelGGL((knn_finalize_kernel<0, true, false, 8192>), dim3((unsigned)T), dim3(256), shbig, s, Fw, F_unw, Fp, wt, Dpad, D, Qp,
+                               qnorm, T, K, cnt, lkey, lidx, cap, id_offset, eps, fnorm, eps_c, cq, cand, dist, d2_out, status, rowflag, thr, margin_stat, retry, vf);
         }
         return;
     }
