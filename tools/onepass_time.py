@@ -32,7 +32,12 @@ for kind in ('compact', 'permuted', 'speechlike'):
         f = tm['knn_filter'][0] / tm['knn_filter'][1]
         issued = 3 * 2.0 * rows * N * 64 / (f * 1e-3) / 1e12
         st = {k: round(v[0] / v[1], 3) for k, v in tm.items() if v[1]}
-        print('%s two_pass %d: filter %.3f ms per launch of %d rows (one-pass issued %.0f TFLOP/s = %.3f of the bf16 peak)  coarse %d onepass %d  same=%s  list mean %.0f  %s' % (
-            kind, two_pass, f, rows, issued, issued / BF16_MFMA_PEAK_TFLOPS, eng.info('filter_coarse'), eng.info('filter_onepass'),
+        # the issued figure prices the ONE-pass sweep (3 terms over every pair): printed only where that is what ran -- a two-pass
+        # filter skips most pairs, and its time against the one-pass work is no fraction of a peak (r06's first log printed 1.08)
+        ran_onepass = two_pass == 0 or eng.info('filter_onepass') == 1
+        what = ('one-pass issued %.0f TFLOP/s = %.3f of the bf16 peak' % (issued, issued / BF16_MFMA_PEAK_TFLOPS)) if ran_onepass else \
+               'two-pass filter (%s): most tile pairs skipped, no one-pass figure' % ('coarse sweep + refine' if eng.info('filter_coarse') == 1 else 'balls + refine')
+        print('%s two_pass %d: filter %.3f ms per launch of %d rows (%s)  coarse %d onepass %d  same=%s  list mean %.0f  %s' % (
+            kind, two_pass, f, rows, what, eng.info('filter_coarse'), eng.info('filter_onepass'),
             np.array_equal(ref[0], cand) and np.array_equal(ref[1], dist), eng.info('last_list_mean'), st), flush=True)
         eng.close()
