@@ -280,6 +280,10 @@ int snk_set_option(snk_handle h, const char *name, double value)
         if (value != 0.0 && value != 1.0) return fail("join_lb_quadrants must be 0 or 1");
         CHK(no_batch_in_flight(h, "snk_set_option(join_lb_quadrants)"));
         set_join_lb_quadrants((int)value);
+    } else if (!strcmp(name, "join_lb_one_set")) {
+        if (value != 0.0 && value != 1.0) return fail("join_lb_one_set must be 0 or 1");
+        CHK(no_batch_in_flight(h, "snk_set_option(join_lb_one_set)"));
+        set_join_lb_one_set((int)value);
     } else if (!strcmp(name, "join_exact_form")) {
         if (value != 0.0 && value != 1.0) return fail("join_exact_form must be 0 or 1");
         CHK(no_batch_in_flight(h, "snk_set_option(join_exact_form)"));
@@ -451,6 +455,7 @@ int snk_get_info(snk_handle h, const char *name, double *out)
     else if (!strcmp(name, "viterbi_latch")) *out = h->viterbi_latch;
     else if (!strcmp(name, "viterbi_fst32_slack")) *out = h->fst32_slack;
     else if (!strcmp(name, "join_lb_quadrants")) *out = get_join_lb_quadrants();
+    else if (!strcmp(name, "join_lb_one_set")) *out = get_join_lb_one_set();
     else if (!strcmp(name, "join_bounds_delay")) *out = h->join_bounds_delay;
     else if (!strcmp(name, "split_one_group")) *out = h->split_one_group;
     else if (!strcmp(name, "wide_one_group")) *out = h->wide_one_group;

@@ -97,14 +97,18 @@ __device__ __forceinline__ void jf_split2(float y0, float y1, unsigned int &hi, 
     lo = __builtin_bit_cast(unsigned int, __builtin_convertvector(rr, jf_bf16x2));
 }
 
-template <int KT, bool QUAD>
-__global__ void __launch_bounds__(64 * KT, 2)
+// ONESET (K <= 128 only; option join_lb_one_set): ONE accumulator set and one k-block in flight instead of two and two -- 119
+// registers instead of 246 at KT = 4, four workgroups per compute unit instead of two -- at the looser error constant of the
+// long chain (join_lb2_ceps: 7.1e-5 instead of 3.4e-5 at 302 columns).  The kernel touches none of its ceilings with two
+// wavefronts per SIMD parked at the same barrier; four hide the gather's latency behind one another.
+template <int KT, bool QUAD, bool ONESET = false>
+__global__ void __launch_bounds__(64 * KT, ONESET ? 4 : 2)
 join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned int *__restrict__ umax_bits, float omc /* 1 - ceps, rounded down */,
                 int64_t n_units, const int64_t *__restrict__ cand, int K, float *__restrict__ Jlo,
                 float *__restrict__ scale_out, int Kq)
 {
-    constexpr bool TWO = KT <= 4;                             // accumulators of their own for the cross terms
-    constexpr int PF = (KT <= 3) ? 3 : 2;                     // k-blocks in flight
+    constexpr bool TWO = KT <= 4 && !ONESET;                  // accumulators of their own for the cross terms
+    constexpr int PF = ONESET ? 1 : (KT <= 3) ? 3 : 2;        // k-blocks in flight
     __shared__ u32x4 Bs[2][KT][2][64];                        // [buffer][S tile][hi, lo][lane]
     __shared__ __align__(16) float m_s[JF2_MAXD];
     __shared__ float ne_s[32 * KT], ns_s[32 * KT], sne_s[32 * KT], sns_s[32 * KT];
@@ -278,6 +282,11 @@ join_lb2_kernel(const float *__restrict__ JW, int Jq, int n_kb, const unsigned i
     }
 }
 
+// process-wide switch, option join_lb_one_set (like join_lb_quadrants below)
+static int g_one_set = 0;
+void set_join_lb_one_set(int v) { g_one_set = v ? 1 : 0; }
+int get_join_lb_one_set() { return g_one_set; }
+
 template <int KT>
 static void launch_join_lb2_t(const float *JW, int Jq, int n_kb, const unsigned int *umax_bits, float omc, int64_t n_units,
                               const int64_t *cand, int64_t R, int K, float *Jlo, float *scale, hipStream_t s, int Kq)
@@ -287,6 +296,13 @@ static void launch_join_lb2_t(const float *JW, int Jq, int n_kb, const unsigned 
             hipLaunchKernelGGL((join_lb2_kernel<KT, true>), dim3((unsigned)(R - 1), 4u), dim3(64 * KT), 0, s, JW, Jq, n_kb, umax_bits, omc,
                                n_units, cand, K, Jlo, scale, Kq);
         return;
+    }
+    if constexpr (KT <= 4) {
+        if (g_one_set) {
+            hipLaunchKernelGGL((join_lb2_kernel<KT, false, true>), dim3((unsigned)(R - 1), 1u), dim3(64 * KT), 0, s, JW, Jq, n_kb, umax_bits, omc,
+                               n_units, cand, K, Jlo, scale, 0);
+            return;
+        }
     }
     hipLaunchKernelGGL((join_lb2_kernel<KT, false>), dim3((unsigned)(R - 1), 1u), dim3(64 * KT), 0, s, JW, Jq, n_kb, umax_bits, omc,
                        n_units, cand, K, Jlo, scale, 0);
@@ -307,7 +323,7 @@ double join_lb2_ceps(int Dj, int K)
     const double n_kb = (double)(join_lb2_pitch(Dj) / 16);
     const double u24 = 5.9604644775390625e-08, u20 = 9.5367431640625e-07, u18 = 3.814697265625e-06;
     const int Kt = join_lb2_quadrant(K) > 0 ? join_lb2_quadrant(K) : K;
-    const bool two = (Kt + 31) / 32 <= 4;
+    const bool two = (Kt + 31) / 32 <= 4 && !(g_one_set && join_lb2_quadrant(K) == 0);
     const double acc = two ? (n_kb + 1.0) * u20 + (2.0 * n_kb + 1.0) * u20 / 256.0 + u24 : (3.0 * n_kb + 1.0) * u20;
     const double cg = 1.02 * (3.02 * u18 + acc);
     const double gam = (n_kb + 12.0) * u24;

@@ -249,6 +249,8 @@ void launch_join_exact_sparse(const float *JC_unw, int Jp, int Dj, const double 
                               const float *Jlo = nullptr, const float *scale = nullptr, float ceps = 0.f, unsigned long long *stats = nullptr);
 void set_join_lb_quadrants(int q);         // 1: pass 1 of K > 128 as 2 x 2 quadrants (joinlb2_kernels.hip); 0 (default): one workgroup per row pair
 int get_join_lb_quadrants();
+void set_join_lb_one_set(int v);          // 1: pass 1 of K <= 128 on ONE accumulator set, one k-block in flight: half the registers, twice the workgroups per compute unit, a looser error constant
+int get_join_lb_one_set();
 void set_join_exact_form(int f);           // 1 (default): cooperative pass 3 (rows in coalesced chunks through LDS); 0: a lane per cell
 void set_viterbi_sparse_waves(int w);      // 1 (default) or 4: which form of pass 4 launch_viterbi_sparse runs (same results)
 void launch_viterbi_sparse(const int64_t *cand, const void *rec, const float *Jlo, const float *JC_unw, int Jp, int Dj,

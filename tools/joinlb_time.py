@@ -25,6 +25,7 @@ for s in range(U):
     c, d = eng.knn((held_out(T, s) if held_out else synthetic_targets(F_unw, T, seed=1 + s)) * wt, K)
     cands.append(c); dists.append(d)
 eng.set_option('viterbi_mode', 1)
+if '--one-set' in args: eng.set_option('join_lb_one_set', 1)
 ref = None
 forms = [int(a[1:]) for a in args if a in ('x0', 'x1')] or [1]
 for v, form in [(v, f) for v in variants for f in forms]:
