@@ -360,7 +360,11 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
     batch = snickery_amd.QueryBatch([(targets(T, u) if targets is not None else
                                       synthetic_targets(F_unw if targets_from is None else targets_from, T, seed=1 + u)) * wt for u in range(U)])
     batch.pin()
-    for _ in range(5):                           # primes every workspace; the engine judges the voice (filter passes, unit order, Viterbi path)
+    # primes every workspace; the engine judges the voice (filter passes, unit order, Viterbi path, pass 2's warm-up) and its latches'
+    # early probes run out: the counting probes of a voice on a slower filter come at calls 16, 48, 112, ... -- with five priming
+    # batches the speech-like leg read 3.1 M frames/s where every later run of the same loop gives 3.6-3.7 (profiles/
+    # r06z_timers_speech.log)
+    for _ in range(24):
         eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(batch, K))
     before = (eng.info('f16_fallbacks'), eng.info('batch_redos'), eng.info('exact_row_fallbacks'))
 
