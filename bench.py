@@ -1155,7 +1155,7 @@ def main():
                                                 'note': 'the same kernel on the same rows with nothing beside it, HIP events, this run'}
             except Exception as ex:          # (an extra: never the reason a bench line is missing)
                 out['roofline']['alone'] = {'error': str(ex)[:200]}
-        leg_steps = max(10, args.steps // 2)            # (a timed region's first and last step run without a neighbour: 2 ms per region)
+        leg_steps = max(20, args.steps)                 # (a timed region's first and last steps run without neighbours: ~2 steps' worth per region -- ten-step legs read 8 % low)
         if world == 1 and not args.no_variants and N >= 65536:
             # the same workload on databases whose tiles are not compact balls: what the fallbacks of the ball
             # pass cost, each leg with the roofline of its dominant kernel

@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import snickery_amd
 snickery_amd.configure_runtime()
+if '--torch' in sys.argv:
+    import torch                      # (bench.py imports torch first: its bundled HIP runtime is then the process's)
+    torch.cuda.synchronize()
 from bench import synthetic_db, synthetic_targets, speechlike_voice
 N, Dt, Dj, T, K, U = 1048576, 61, 302, 600, 100, 32
 wt = np.full(Dt, 0.4); wj = np.full(Dj, 0.05)
@@ -21,6 +24,17 @@ args = sys.argv[1:]
 for i, a in enumerate(args):
     if a == '--opt':
         n, v = args[i + 1].split('='); eng.set_option(n, float(v))
+if '--after-compact' in sys.argv:
+    # what bench.py does before this leg: the same engine has searched SURVEY 8d's walk and its permuted copy
+    F0, JC0 = synthetic_db(N, Dt, Dj, seed=0)
+    u0 = snickery_amd.QueryBatch([synthetic_targets(F0, T, seed=1 + u) * wt for u in range(U)]).pin()
+    eng.upload_db(F0, JC0); eng.set_weights(wt, wj)
+    for _ in range(8): eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(u0, K))
+    rng = np.random.RandomState(17); perm = rng.permutation(N)
+    eng.upload_db(F0[perm], JC0[np.concatenate([perm, [N]])]); eng.set_weights(wt, wj)
+    for _ in range(8): eng.knn_viterbi_batch_collect(eng.knn_viterbi_batch_submit(u0, K))
+    print('after the compact and the permuted voice: reordered %d filter_coarse %d onepass %d knn_level %d' % (
+        eng.info('reordered'), eng.info('filter_coarse'), eng.info('filter_onepass'), eng.info('knn_level')), flush=True)
 eng.upload_db(F_unw, JC_unw); eng.set_weights(wt, wj)
 batch = snickery_amd.QueryBatch(utts).pin()
 for _ in range(12):
@@ -37,6 +51,9 @@ def run(steps=20, depth=3):
     while pending:
         eng.knn_viterbi_batch_collect(pending.pop(0))
     return T * U * steps / (time.perf_counter() - t0)
+print('voice: reordered %d filter_coarse %d onepass %d knn_level %d warm %d rank %d off %d latch mode %d' % (
+    eng.info('reordered'), eng.info('filter_coarse'), eng.info('filter_onepass'), eng.info('knn_level'), eng.info('viterbi_lb_warm_now'),
+    eng.info('tau_optimism_rank'), eng.info('tau_optimism_off'), eng.info('viterbi_latch_mode')), flush=True)
 for mode in (2, 1, 0, 1, 2, 0, 2, 1):
     eng.set_option('timers', mode)
     eng.reset_timers()
