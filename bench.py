@@ -383,6 +383,7 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
     # the rate: rows uploaded and paths returned inside every step, no stage timers (their timestamp events cost 4-7 % of a step);
     # then the same loop once more with every stage timed, for the stage table and the leg's roofline
     eng.set_option('timers', 2)
+    run(False)                                   # (untimed: the same loop once, so that the timed one starts in its own regime -- the headline has its depth probe for that)
     eng.reset_timers()
     dth, _ = run(False)
     eng.set_option('timers', 1)
