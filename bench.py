@@ -395,8 +395,9 @@ def shape_leg(eng, name, F_unw, JC_unw, wt, wj, T, U, K, steps, kind='compact', 
     rows_per_launch = T * U / max(tm['knn_filter'][1] / steps, 1)
     out = {'shape': name, 'database': kind, 'units': N, 'target_dim': Dt, 'join_dim': Dj, 'frames': T, 'utts_per_step': U, 'n_candidates': K,
            # the leg's rate: the better of its two passes of the same loop (the first times the roofline stage only, the second every
-           # stage; on the speech-like voice the fully timed pass is reproducibly the FASTER one -- 3.55-3.62 against 3.40-3.46 M,
-           # profiles/r06z_timers_speech.log: the timestamp events between its kernels change how the streams interleave)
+           # stage).  A 20-step pass of a leg is bimodal -- the speech-like voice reads 3.37-3.40 or 3.58-3.67 M frames/s from one
+           # pass to the next whatever is timed (profiles/r06z_timers_speech.log, r06af_mask_scan.log: how the streams' loops fall
+           # into step) -- so one sample is not the leg's rate; both passes are in the detail record
            'frames_per_s': T * U * steps / min(dth, dt), 'ms_per_step': min(dth, dt) / steps * 1e3, 'steps': steps, 'rows': 'host -> host',
            'frames_per_s_roofline_stage_timed': T * U * steps / dth, 'frames_per_s_with_stage_timers': T * U * steps / dt,
            'roofline': leg_roofline(tm, steps, T * U, N, Dt, Dj, K, eng),

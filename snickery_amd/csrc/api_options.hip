@@ -304,8 +304,11 @@ int snk_set_option(snk_handle h, const char *name, double value)
     } else if (!strcmp(name, "pool_chunk_limit")) {
         if (value < 0 || value > 1e6) return fail("pool_chunk_limit must be in 0..1e6");
         h->pool_chunk_limit = (int)value;
+    } else if (!strcmp(name, "timers_mask")) {
+        if (!(value >= 0.0 && value < 4294967296.0)) return fail("timers_mask must be a 32-bit mask of stage ids");
+        h->timers_mask = (unsigned int)value;
     } else if (!strcmp(name, "timers")) {
-        if (value != 0.0 && value != 1.0 && value != 2.0) return fail("timers must be 0 (none), 1 (every stage) or 2 (the Viterbi side's bounds pass only)");
+        if (value != 0.0 && value != 1.0 && value != 2.0 && value != 3.0) return fail("timers must be 0 (none), 1 (every stage), 2 (the Viterbi side's bounds pass only) or 3 (the stages of timers_mask)");
         h->timers_on = (int)value;
     } else {
         return fail("snk_set_option: unknown option '%s'", name);

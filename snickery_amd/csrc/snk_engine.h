@@ -404,6 +404,7 @@ struct snk_engine {
     int min_sample_slabs = 256;           // small databases / shards: the sample stride shrinks to keep this many sampled slabs
     int nt_override = 0;
     int timers_on = 1;
+    unsigned int timers_mask = 0;          // timers 3 (experiments): the stages whose bit is set (option timers_mask)
     int n_cus = 256;
     int reserved_cus = 2;
     int batch_rows = 12288;    // rows per K-NN call of the batch entry points (utterances are grouped)
@@ -471,7 +472,7 @@ struct StageTimer {     // records an event pair around a stage on a stream
     // timers_on 1: every stage; 2: the bounds pass of the Viterbi side only (the bench line's roofline kernel) -- a timed stage is
     // two timestamp events on its stream, ~60 of them per B* step: 4-7 % of the step (profiles/r06h_ab.log: 5.0 -> 5.2-5.4 M frames/s
     // without); 0: none
-    StageTimer(snk_engine *h_, hipStream_t s_, int id) : h(h_), s(s_), on((h_->timers_on == 1 || (h_->timers_on == 2 && id == TM_JOIN_LB)) && id >= 0)
+    StageTimer(snk_engine *h_, hipStream_t s_, int id) : h(h_), s(s_), on((h_->timers_on == 1 || (h_->timers_on == 2 && id == TM_JOIN_LB) || (h_->timers_on == 3 && id >= 0 && ((h_->timers_mask >> id) & 1u))) && id >= 0)
     {
         if (!on) return;
         ep.id = id; ep.a = ev_get(h); ep.b = ev_get(h);

@@ -54,6 +54,20 @@ def run(steps=20, depth=3):
 print('voice: reordered %d filter_coarse %d onepass %d knn_level %d warm %d rank %d off %d latch mode %d' % (
     eng.info('reordered'), eng.info('filter_coarse'), eng.info('filter_onepass'), eng.info('knn_level'), eng.info('viterbi_lb_warm_now'),
     eng.info('tau_optimism_rank'), eng.info('tau_optimism_off'), eng.info('viterbi_latch_mode')), flush=True)
+if '--mask-scan' in sys.argv:
+    # which stage's timestamp events matter: every stage alone (timers 3 + timers_mask), between reference runs
+    names = ['h2d', 'prep', 'minima', 'threshold', 'filter', 'bucket', 'finalize', 'join', 'viterbi_dp', 'd2h', 'greedy_target', 'greedy_steps', 'weights',
+             'merge', 'join_lb', 'dp_lb', 'join_sparse', 'dp_sparse', 'ballmin']
+    eng.set_option('timers', 1); run(); eng.set_option('timers', 0); print('timers 0: %.0f' % run(), flush=True)
+    for i in (0, 1, 2, 3, 4, 5, 6, 9, 14, 15, 16, 17):
+        eng.set_option('timers', 3); eng.set_option('timers_mask', float(1 << i)); eng.reset_timers()
+        print('only %-12s: %.0f frames/s' % (names[i], run()), flush=True)
+    for label, mask in (('main stream', 0x7f), ('side streams', (1 << 14) | (1 << 15) | (1 << 16) | (1 << 17))):
+        eng.set_option('timers_mask', float(mask)); eng.reset_timers()
+        print('only %-12s: %.0f frames/s' % (label, run()), flush=True)
+    eng.set_option('timers', 1); print('timers 1: %.0f' % run(), flush=True)
+    eng.set_option('timers', 0); print('timers 0: %.0f' % run(), flush=True)
+    eng.close(); sys.exit(0)
 for mode in (2, 1, 0, 1, 2, 0, 2, 1):
     eng.set_option('timers', mode)
     eng.reset_timers()
