@@ -81,3 +81,18 @@ def test_no_gpu_work_before_the_process_group_exists():
     # the only torch.cuda call before the group exists is the device selection
     early = [n for line, n in calls if line < first['dist.init_process_group'] and n.startswith('torch.cuda')]
     assert early == ['torch.cuda.set_device']
+
+
+def test_the_profile_summariser_refuses_a_tree_that_has_moved_on(tmp_path):
+    """tools/summarise_round6.py compares the sha256 of every kernel source (and of bench.py), taken by tools/prof_round6.sh before
+    its first command, with the tree: counters of another build must not become this build's evidence."""
+    import hashlib
+    import subprocess
+    src = tmp_path / 'r06x'
+    src.mkdir()
+    good = hashlib.sha256(open(os.path.join(ROOT, 'bench.py'), 'rb').read()).hexdigest()
+    (src / 'csrc.sha256').write_text('%s  bench.py\n%s  snickery_amd/csrc/joinlb2_kernels.hip\n' % (good, '0' * 64))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'summarise_round6.py'), str(src), 'r06_x', '--out', str(tmp_path)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'refused' in (r.stderr + r.stdout) and 'joinlb2_kernels.hip' in (r.stderr + r.stdout)
+    assert not any(p.name.startswith('r06') and p.suffix == '.json' for p in tmp_path.iterdir())
